@@ -1,0 +1,139 @@
+"""ctypes binding of libbigsi_hip.so (include/bigsi_hip.h).
+
+The HIP library IS the product path: there is no CPU fallback.  If the shared object is missing or no
+GPU is visible, importing symbols still works (so `-m "not gpu"` tests can check the ABI) but any call
+that needs a device raises BigsiHipError.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbigsi_hip.so")
+
+OK, ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_RANGE, ERR_CAPACITY, ERR_STATE = 0, -1, -2, -3, -4, -5, -6
+RUN_FORCE_COUNTS = 1
+BLOOM_RAW = 1
+
+
+class BigsiHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libbigsi_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Info(C.Structure):
+    _fields_ = [("num_rows", C.c_uint64), ("num_cols", C.c_uint64), ("col_capacity", C.c_uint64),
+                ("row_bytes", C.c_uint64), ("row_stride_bytes", C.c_uint64), ("index_bytes", C.c_uint64),
+                ("num_hashes", C.c_uint32), ("device", C.c_int32)]
+
+
+class BatchInfo(C.Structure):
+    _fields_ = [("n_seqs", C.c_uint32), ("k", C.c_uint32), ("exact", C.c_uint32), ("count_bytes", C.c_uint32),
+                ("total_kmers", C.c_uint64), ("total_unique", C.c_uint64), ("total_hits", C.c_uint64),
+                ("bitmap_stride_bytes", C.c_uint64), ("counts_stride", C.c_uint64),
+                ("d_bitmaps", C.c_void_p), ("d_counts", C.c_void_p), ("d_num_unique", C.c_void_p)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("and_launches", C.c_uint64), ("and_ms", C.c_double),
+                ("kmerize_launches", C.c_uint64), ("kmerize_ms", C.c_double),
+                ("compact_launches", C.c_uint64), ("compact_ms", C.c_double)]
+
+
+_P = C.c_void_p
+_u64, _u32, _i32, _dbl = C.c_uint64, C.c_uint32, C.c_int, C.c_double
+
+# every symbol include/bigsi_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "bigsi_hip_last_error": (C.c_char_p, []),
+    "bigsi_hip_device_count": (_i32, [C.POINTER(C.c_int)]),
+    "bigsi_hip_open": (_i32, [_u64, _u64, _u64, _u32, _i32, C.POINTER(_P)]),
+    "bigsi_hip_close": (_i32, [_P]),
+    "bigsi_hip_get_info": (_i32, [_P, C.POINTER(Info)]),
+    "bigsi_hip_set_num_cols": (_i32, [_P, _u64]),
+    "bigsi_hip_set_num_hashes": (_i32, [_P, _u32]),
+    "bigsi_hip_reserve_cols": (_i32, [_P, _u64]),
+    "bigsi_hip_set_stream": (_i32, [_P, _P]),
+    "bigsi_hip_synchronize": (_i32, [_P]),
+    "bigsi_hip_set_rows": (_i32, [_P, _P, _u64, _P, _u64]),
+    "bigsi_hip_get_rows": (_i32, [_P, _P, _u64, _P, _u64]),
+    "bigsi_hip_clear": (_i32, [_P]),
+    "bigsi_hip_insert_column": (_i32, [_P, _u64, _P]),
+    "bigsi_hip_get_column": (_i32, [_P, _u64, _P]),
+    "bigsi_hip_insert_kmers": (_i32, [_P, _u64, C.c_char_p, _P, _u32, _u32]),
+    "bigsi_hip_fill_synthetic": (_i32, [_P, _u64, _u64, _u32]),
+    "bigsi_hip_bloom": (_i32, [_i32, C.c_char_p, _u64, _u32, _u64, _u32, _u32, _P]),
+    "bigsi_hip_lookup": (_i32, [_P, C.c_char_p, _u32, _u64, _P]),
+    "bigsi_hip_batch_create": (_i32, [_P, C.c_char_p, _P, _u32, _u32, C.POINTER(_P)]),
+    "bigsi_hip_batch_destroy": (_i32, [_P]),
+    "bigsi_hip_batch_run": (_i32, [_P, _dbl, _u32]),
+    "bigsi_hip_batch_get_info": (_i32, [_P, C.POINTER(BatchInfo)]),
+    "bigsi_hip_batch_set_outputs": (_i32, [_P, _P, _P]),
+    "bigsi_hip_batch_fetch_unique": (_i32, [_P, _P, _P, _P]),
+    "bigsi_hip_batch_fetch_hits": (_i32, [_P, _P, _P, _P, _u64]),
+    "bigsi_hip_batch_fetch_counts": (_i32, [_P, _u32, _P]),
+    "bigsi_hip_batch_fetch_bitmap": (_i32, [_P, _u32, _P]),
+    "bigsi_hip_batch_fetch_rows": (_i32, [_P, _u32, _P, _u64]),
+    "bigsi_hip_batch_lookup": (_i32, [_P, _u32, _P, _P, _u64]),
+    "bigsi_hip_batch_presence": (_i32, [_P, _u32, _P, _u32, _P]),
+    "bigsi_hip_compact_gathered": (_i32, [_P, _P, _u32, _u64, _P, _P, _P, _u64]),
+    "bigsi_hip_set_profiling": (_i32, [_P, _i32]),
+    "bigsi_hip_stats": (_i32, [_P, C.POINTER(Stats), _i32]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises if libbigsi_hip.so has not been built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BigsiHipError(ERR_STATE, "%s is missing: build it with bigsi_amd/csrc/build.sh "
+                                           "(or python -c 'import __graft_entry__ as g; g.build()')" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)      # AttributeError here = header and library out of sync
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != OK:
+        raise BigsiHipError(rc, (lib().bigsi_hip_last_error() or b"").decode("utf-8", "replace"))
+    return rc
+
+
+def device_count():
+    n = C.c_int(0)
+    check(lib().bigsi_hip_device_count(C.byref(n)))
+    return n.value
+
+
+def ptr(a):
+    """void* of a C-contiguous numpy array (or None)."""
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data
+
+
+def pack_seqs(seqs):
+    """list of str/bytes -> (blob bytes, uint64 offsets[n+1]).  Sequences must be ASCII: the reference hashes the
+    UTF-8 bytes of k *characters* (mmh3.hash(str)); for ASCII that is k bytes, which is what the kernels window."""
+    enc = []
+    for s in seqs:
+        if isinstance(s, str):
+            try:
+                s = s.encode("ascii")
+            except UnicodeEncodeError:
+                raise ValueError("query sequences must be ASCII for the hip-hbm backend")
+        enc.append(bytes(s))
+    off = np.zeros(len(enc) + 1, dtype=np.uint64)
+    if enc:
+        off[1:] = np.cumsum([len(e) for e in enc], dtype=np.uint64)
+    return b"".join(enc), off

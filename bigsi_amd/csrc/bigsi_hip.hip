@@ -1,0 +1,955 @@
+// bigsi_hip.hip -- host side of libbigsi_hip.so: the C ABI declared in include/bigsi_hip.h.
+// Plain HIP runtime (hipMalloc / streams / events); no torch types anywhere in this library.
+#include "bigsi_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "bigsi_kernels.hpp"
+
+using namespace bigsi;
+
+// ------------------------------------------------------------------------------ errors
+static thread_local char g_err[1024] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(e_ == hipErrorOutOfMemory ? BIGSI_ERR_NOMEM : BIGSI_ERR_HIP, "%s:%d %s: %s", __FILE__, \
+                        __LINE__, #expr, hipGetErrorString(e_));                                       \
+    } while (0)
+
+#define TRY(expr)            \
+    do {                     \
+        int rc_ = (expr);    \
+        if (rc_ != BIGSI_OK) \
+            return rc_;      \
+    } while (0)
+
+extern "C" const char *bigsi_hip_last_error(void) { return g_err; }
+
+extern "C" int bigsi_hip_device_count(int *out)
+{
+    if (!out) return fail(BIGSI_ERR_INVALID, "out is NULL");
+    HIP_TRY(hipGetDeviceCount(out));
+    return BIGSI_OK;
+}
+
+static inline uint64_t round_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+static inline uint64_t ceil_div(uint64_t x, uint64_t a) { return (x + a - 1) / a; }
+
+static int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+// ------------------------------------------------------------------------------ device buffer with growth
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes)
+    {
+        if (bytes <= cap) return BIGSI_OK;
+        if (p) { hipError_t e = hipFree(p); (void)e; p = nullptr; cap = 0; }
+        size_t want = std::max<size_t>(bytes, 256);
+        HIP_TRY(hipMalloc(&p, want));
+        cap = want;
+        return BIGSI_OK;
+    }
+    void release()
+    {
+        if (p) { hipError_t e = hipFree(p); (void)e; }
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct EventPair {
+    hipEvent_t a, b;
+};
+
+struct bigsi_hip_index {
+    int device = 0;
+    hipStream_t stream = nullptr, own_stream = nullptr;
+    uint64_t m = 0, n_cols = 0, cap_cols = 0, stride_words = 0;
+    uint32_t h = 0;
+    uint64_t *d_index = nullptr;
+    DevBuf stage, stage_ids;
+    // profiling
+    bool profiling = false;
+    std::vector<EventPair> ev_and, ev_km, ev_cp, ev_free;
+    uint64_t wv() const { return ceil_div(n_cols, 64); }
+    uint64_t rb() const { return ceil_div(n_cols, 8); }
+};
+
+static int use_device(const bigsi_hip_index *ix)
+{
+    HIP_TRY(hipSetDevice(ix->device));
+    return BIGSI_OK;
+}
+
+static uint64_t stride_for(uint64_t cols) { return std::max<uint64_t>(16, round_up(ceil_div(cols, 64), 16)); }
+
+// ------------------------------------------------------------------------------ lifecycle
+extern "C" int bigsi_hip_open(uint64_t num_rows, uint64_t num_cols, uint64_t col_capacity, uint32_t num_hashes, int device,
+                              bigsi_hip_index **out)
+{
+    if (!out) return fail(BIGSI_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (num_rows == 0) return fail(BIGSI_ERR_INVALID, "num_rows must be > 0");
+    if (num_hashes == 0) return fail(BIGSI_ERR_INVALID, "num_hashes must be > 0");
+    if (col_capacity < num_cols) col_capacity = num_cols;
+    if (col_capacity == 0) col_capacity = 64;
+    if (col_capacity > 0xFFFFFFFFull) return fail(BIGSI_ERR_INVALID, "col_capacity %llu exceeds 2^32-1 colours per shard", (unsigned long long)col_capacity);
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(BIGSI_ERR_INVALID, "device %d not in [0,%d)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    bigsi_hip_index *ix = new (std::nothrow) bigsi_hip_index();
+    if (!ix) return fail(BIGSI_ERR_NOMEM, "host allocation failed");
+    ix->device = device;
+    ix->m = num_rows;
+    ix->n_cols = num_cols;
+    ix->h = num_hashes;
+    ix->stride_words = stride_for(col_capacity);
+    ix->cap_cols = ix->stride_words * 64;
+    hipError_t e = hipStreamCreateWithFlags(&ix->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete ix; return fail(BIGSI_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    ix->stream = ix->own_stream;
+    const size_t bytes = (size_t)ix->m * ix->stride_words * 8;
+    e = hipMalloc((void **)&ix->d_index, bytes);
+    if (e != hipSuccess) {
+        hipError_t e2 = hipStreamDestroy(ix->own_stream); (void)e2;
+        delete ix;
+        return fail(BIGSI_ERR_NOMEM, "hipMalloc of %zu index bytes failed: %s", bytes, hipGetErrorString(e));
+    }
+    e = hipMemsetAsync(ix->d_index, 0, bytes, ix->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+    if (e != hipSuccess) {
+        hipError_t e2 = hipFree(ix->d_index); (void)e2;
+        e2 = hipStreamDestroy(ix->own_stream);
+        delete ix;
+        return fail(BIGSI_ERR_HIP, "zeroing the index failed: %s", hipGetErrorString(e));
+    }
+    *out = ix;
+    return BIGSI_OK;
+}
+
+static void recycle_events(bigsi_hip_index *ix)
+{
+    for (auto *v : {&ix->ev_and, &ix->ev_km, &ix->ev_cp}) {
+        for (auto &p : *v) ix->ev_free.push_back(p);
+        v->clear();
+    }
+}
+
+extern "C" int bigsi_hip_close(bigsi_hip_index *ix)
+{
+    if (!ix) return BIGSI_OK;
+    hipError_t e = hipSetDevice(ix->device);
+    e = hipStreamSynchronize(ix->stream);
+    recycle_events(ix);
+    for (auto &p : ix->ev_free) { e = hipEventDestroy(p.a); e = hipEventDestroy(p.b); }
+    ix->stage.release();
+    ix->stage_ids.release();
+    if (ix->d_index) e = hipFree(ix->d_index);
+    if (ix->own_stream) e = hipStreamDestroy(ix->own_stream);
+    (void)e;
+    delete ix;
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_get_info(const bigsi_hip_index *ix, bigsi_hip_info *out)
+{
+    if (!ix || !out) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    out->num_rows = ix->m;
+    out->num_cols = ix->n_cols;
+    out->col_capacity = ix->cap_cols;
+    out->row_bytes = ix->rb();
+    out->row_stride_bytes = ix->stride_words * 8;
+    out->index_bytes = ix->m * ix->stride_words * 8;
+    out->num_hashes = ix->h;
+    out->device = ix->device;
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_set_num_cols(bigsi_hip_index *ix, uint64_t num_cols)
+{
+    if (!ix) return fail(BIGSI_ERR_INVALID, "NULL index");
+    if (num_cols > ix->cap_cols)
+        return fail(BIGSI_ERR_CAPACITY, "num_cols %llu exceeds col_capacity %llu (call bigsi_hip_reserve_cols)",
+                    (unsigned long long)num_cols, (unsigned long long)ix->cap_cols);
+    ix->n_cols = num_cols;
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_set_num_hashes(bigsi_hip_index *ix, uint32_t num_hashes)
+{
+    if (!ix) return fail(BIGSI_ERR_INVALID, "NULL index");
+    if (num_hashes == 0) return fail(BIGSI_ERR_INVALID, "num_hashes must be > 0");
+    ix->h = num_hashes;
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_reserve_cols(bigsi_hip_index *ix, uint64_t col_capacity)
+{
+    if (!ix) return fail(BIGSI_ERR_INVALID, "NULL index");
+    if (col_capacity <= ix->cap_cols) return BIGSI_OK;
+    if (col_capacity > 0xFFFFFFFFull) return fail(BIGSI_ERR_INVALID, "col_capacity exceeds 2^32-1");
+    TRY(use_device(ix));
+    const uint64_t ns = stride_for(col_capacity);
+    uint64_t *nd = nullptr;
+    HIP_TRY(hipMalloc((void **)&nd, (size_t)ix->m * ns * 8));
+    const uint64_t total = ix->m * ns;
+    const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(total, kBlock), 256 * 8 * 4);
+    hipLaunchKernelGGL(k_restride, dim3(grid), dim3(kBlock), 0, ix->stream, ix->d_index, ix->stride_words, nd, ns, ix->m);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    HIP_TRY(hipFree(ix->d_index));
+    ix->d_index = nd;
+    ix->stride_words = ns;
+    ix->cap_cols = ns * 64;
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_set_stream(bigsi_hip_index *ix, void *hip_stream)
+{
+    if (!ix) return fail(BIGSI_ERR_INVALID, "NULL index");
+    TRY(use_device(ix));
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    ix->stream = hip_stream ? (hipStream_t)hip_stream : ix->own_stream;
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_synchronize(bigsi_hip_index *ix)
+{
+    if (!ix) return fail(BIGSI_ERR_INVALID, "NULL index");
+    TRY(use_device(ix));
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    return BIGSI_OK;
+}
+
+// ------------------------------------------------------------------------------ storage contract
+static const uint64_t kStageBytes = 64ull << 20;
+
+extern "C" int bigsi_hip_set_rows(bigsi_hip_index *ix, const uint64_t *row_ids, uint64_t n, const uint8_t *bytes, uint64_t row_bytes)
+{
+    if (!ix || (n && (!row_ids || !bytes))) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    if (row_bytes == 0 || row_bytes > ix->stride_words * 8)
+        return fail(BIGSI_ERR_CAPACITY, "row_bytes %llu not in [1, %llu] (row stride)", (unsigned long long)row_bytes,
+                    (unsigned long long)(ix->stride_words * 8));
+    for (uint64_t i = 0; i < n; i++)
+        if (row_ids[i] >= ix->m) return fail(BIGSI_ERR_RANGE, "row %llu out of range [0,%llu)", (unsigned long long)row_ids[i], (unsigned long long)ix->m);
+    TRY(use_device(ix));
+    const uint64_t per = std::max<uint64_t>(1, kStageBytes / row_bytes);
+    for (uint64_t i0 = 0; i0 < n; i0 += per) {
+        const uint64_t c = std::min(per, n - i0);
+        TRY(ix->stage.reserve(c * row_bytes));
+        TRY(ix->stage_ids.reserve(c * 8));
+        HIP_TRY(hipMemcpyAsync(ix->stage.p, bytes + i0 * row_bytes, c * row_bytes, hipMemcpyHostToDevice, ix->stream));
+        HIP_TRY(hipMemcpyAsync(ix->stage_ids.p, row_ids + i0, c * 8, hipMemcpyHostToDevice, ix->stream));
+        hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)c), dim3(kBlock), 0, ix->stream, (uint8_t *)ix->d_index,
+                           ix->stride_words * 8, ix->m, ix->stage_ids.as<uint64_t>(), ix->stage.as<uint8_t>(), row_bytes);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(ix->stream));   // staging buffers are reused by the next chunk
+    }
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_get_rows(bigsi_hip_index *ix, const uint64_t *row_ids, uint64_t n, uint8_t *out, uint64_t row_bytes)
+{
+    if (!ix || (n && (!row_ids || !out))) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    if (row_bytes == 0) return fail(BIGSI_ERR_INVALID, "row_bytes is 0");
+    for (uint64_t i = 0; i < n; i++)
+        if (row_ids[i] >= ix->m) return fail(BIGSI_ERR_RANGE, "row %llu out of range [0,%llu)", (unsigned long long)row_ids[i], (unsigned long long)ix->m);
+    TRY(use_device(ix));
+    const uint64_t per = std::max<uint64_t>(1, kStageBytes / row_bytes);
+    for (uint64_t i0 = 0; i0 < n; i0 += per) {
+        const uint64_t c = std::min(per, n - i0);
+        TRY(ix->stage.reserve(c * row_bytes));
+        TRY(ix->stage_ids.reserve(c * 8));
+        HIP_TRY(hipMemcpyAsync(ix->stage_ids.p, row_ids + i0, c * 8, hipMemcpyHostToDevice, ix->stream));
+        hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)c), dim3(kBlock), 0, ix->stream, (const uint8_t *)ix->d_index,
+                           ix->stride_words * 8, ix->m, ix->stage_ids.as<uint64_t>(), ix->stage.as<uint8_t>(), row_bytes);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(out + i0 * row_bytes, ix->stage.p, c * row_bytes, hipMemcpyDeviceToHost, ix->stream));
+        HIP_TRY(hipStreamSynchronize(ix->stream));
+    }
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_clear(bigsi_hip_index *ix)
+{
+    if (!ix) return fail(BIGSI_ERR_INVALID, "NULL index");
+    TRY(use_device(ix));
+    HIP_TRY(hipMemsetAsync(ix->d_index, 0, (size_t)ix->m * ix->stride_words * 8, ix->stream));
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_insert_column(bigsi_hip_index *ix, uint64_t col, const uint8_t *bloom)
+{
+    if (!ix || !bloom) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    if (col > ix->n_cols) return fail(BIGSI_ERR_RANGE, "column %llu beyond num_cols %llu", (unsigned long long)col, (unsigned long long)ix->n_cols);
+    if (col >= ix->cap_cols) return fail(BIGSI_ERR_CAPACITY, "column %llu beyond col_capacity %llu", (unsigned long long)col, (unsigned long long)ix->cap_cols);
+    TRY(use_device(ix));
+    const uint64_t nb = ceil_div(ix->m, 8);
+    TRY(ix->stage.reserve(nb));
+    HIP_TRY(hipMemcpyAsync(ix->stage.p, bloom, nb, hipMemcpyHostToDevice, ix->stream));
+    const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(ix->m, kBlock), 256 * 8);
+    hipLaunchKernelGGL(k_insert_column, dim3(grid), dim3(kBlock), 0, ix->stream, ix->d_index, ix->stride_words, ix->m, col, ix->stage.as<uint8_t>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    if (col == ix->n_cols) ix->n_cols++;
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_get_column(bigsi_hip_index *ix, uint64_t col, uint8_t *out)
+{
+    if (!ix || !out) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    if (col >= ix->cap_cols) return fail(BIGSI_ERR_RANGE, "column %llu beyond col_capacity", (unsigned long long)col);
+    TRY(use_device(ix));
+    const uint64_t nb = ceil_div(ix->m, 8);
+    TRY(ix->stage.reserve(nb));
+    const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(nb, kBlock), 256 * 8);
+    hipLaunchKernelGGL(k_get_column, dim3(grid), dim3(kBlock), 0, ix->stream, ix->d_index, ix->stride_words, ix->m, col, ix->stage.as<uint8_t>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, ix->stage.p, nb, hipMemcpyDeviceToHost, ix->stream));
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    return BIGSI_OK;
+}
+
+static int check_offsets(const uint64_t *offsets, uint32_t n_seqs)
+{
+    for (uint32_t i = 0; i < n_seqs; i++) {
+        if (offsets[i + 1] < offsets[i]) return fail(BIGSI_ERR_INVALID, "offsets must be non-decreasing");
+        if (offsets[i + 1] - offsets[i] > 0xFFFFFFF0ull) return fail(BIGSI_ERR_INVALID, "sequence %u longer than 2^32-16 bytes", i);
+    }
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_insert_kmers(bigsi_hip_index *ix, uint64_t col, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k)
+{
+    if (!ix || !offsets || (n_seqs && !seqs && offsets[n_seqs] > offsets[0])) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    if (k == 0) return fail(BIGSI_ERR_INVALID, "k must be > 0");
+    if (col >= ix->n_cols) return fail(BIGSI_ERR_RANGE, "column %llu >= num_cols %llu", (unsigned long long)col, (unsigned long long)ix->n_cols);
+    if (n_seqs == 0) return BIGSI_OK;
+    TRY(check_offsets(offsets, n_seqs));
+    TRY(use_device(ix));
+    const uint64_t base = offsets[0], nbytes = offsets[n_seqs] - base;
+    std::vector<uint64_t> rel(n_seqs + 1);
+    for (uint32_t i = 0; i <= n_seqs; i++) rel[i] = offsets[i] - base;
+    TRY(ix->stage.reserve(std::max<uint64_t>(nbytes, 1)));
+    TRY(ix->stage_ids.reserve((n_seqs + 1) * 8ull));
+    if (nbytes) HIP_TRY(hipMemcpyAsync(ix->stage.p, seqs + base, nbytes, hipMemcpyHostToDevice, ix->stream));
+    HIP_TRY(hipMemcpyAsync(ix->stage_ids.p, rel.data(), (n_seqs + 1) * 8ull, hipMemcpyHostToDevice, ix->stream));
+    hipLaunchKernelGGL(k_insert_kmers, dim3(n_seqs), dim3(kBlock), 0, ix->stream, ix->d_index, ix->stride_words, ix->m, ix->h, col,
+                       ix->stage.as<char>(), ix->stage_ids.as<uint64_t>(), k);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ix->stream));   // rel[] and the staging buffers go out of scope
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_fill_synthetic(bigsi_hip_index *ix, uint64_t seed, uint64_t shard, uint32_t and_draws)
+{
+    if (!ix) return fail(BIGSI_ERR_INVALID, "NULL index");
+    if (and_draws == 0 || and_draws > 8) return fail(BIGSI_ERR_INVALID, "and_draws must be in [1,8]");
+    TRY(use_device(ix));
+    hipLaunchKernelGGL(k_fill_synth, dim3(256 * 16), dim3(kBlock), 0, ix->stream, ix->d_index, ix->m, ix->stride_words, ix->n_cols, seed, shard, and_draws);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_bloom(int device, const char *kmers, uint64_t u, uint32_t k, uint64_t m, uint32_t h, uint32_t flags, uint8_t *out)
+{
+    if (!out || (u && !kmers)) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    if (k == 0 || m == 0 || h == 0) return fail(BIGSI_ERR_INVALID, "k, m and h must be > 0");
+    HIP_TRY(hipSetDevice(device));
+    const uint64_t nwords = ceil_div(m, 32), nb = ceil_div(m, 8);
+    uint32_t *d_bits = nullptr;
+    char *d_km = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_bits, nwords * 4));
+    hipError_t e = hipMemset(d_bits, 0, nwords * 4);
+    if (e == hipSuccess && u) {
+        e = hipMalloc((void **)&d_km, u * k);
+        if (e == hipSuccess) e = hipMemcpy(d_km, kmers, u * k, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(u, kBlock), 256 * 8);
+            hipLaunchKernelGGL(k_bloom, dim3(grid), dim3(kBlock), 0, 0, d_bits, m, h, d_km, u, k, (flags & BIGSI_BLOOM_RAW) != 0);
+            e = hipGetLastError();
+        }
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, d_bits, nb, hipMemcpyDeviceToHost);   // little-endian words == byte order
+    hipError_t e2 = hipFree(d_bits); (void)e2;
+    if (d_km) e2 = hipFree(d_km);
+    if (e != hipSuccess) return fail(BIGSI_ERR_HIP, "bigsi_hip_bloom: %s", hipGetErrorString(e));
+    return BIGSI_OK;
+}
+
+// ------------------------------------------------------------------------------ profiling events
+static int ev_begin(bigsi_hip_index *ix, EventPair *p)
+{
+    if (!ix->profiling) return BIGSI_OK;
+    if (ix->ev_free.empty()) {
+        EventPair n;
+        HIP_TRY(hipEventCreate(&n.a));
+        HIP_TRY(hipEventCreate(&n.b));
+        ix->ev_free.push_back(n);
+    }
+    *p = ix->ev_free.back();
+    ix->ev_free.pop_back();
+    HIP_TRY(hipEventRecord(p->a, ix->stream));
+    return BIGSI_OK;
+}
+
+static int ev_end(bigsi_hip_index *ix, EventPair *p, std::vector<EventPair> &dst)
+{
+    if (!ix->profiling) return BIGSI_OK;
+    HIP_TRY(hipEventRecord(p->b, ix->stream));
+    dst.push_back(*p);
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_set_profiling(bigsi_hip_index *ix, int on)
+{
+    if (!ix) return fail(BIGSI_ERR_INVALID, "NULL index");
+    ix->profiling = on != 0;
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_stats(bigsi_hip_index *ix, bigsi_hip_stats_t *out, int reset)
+{
+    if (!ix || !out) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    TRY(use_device(ix));
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    auto sum = [&](std::vector<EventPair> &v, uint64_t *n, double *ms) -> int {
+        *n = v.size();
+        *ms = 0;
+        for (auto &p : v) {
+            float t = 0;
+            HIP_TRY(hipEventElapsedTime(&t, p.a, p.b));
+            *ms += t;
+        }
+        return BIGSI_OK;
+    };
+    TRY(sum(ix->ev_and, &out->and_launches, &out->and_ms));
+    TRY(sum(ix->ev_km, &out->kmerize_launches, &out->kmerize_ms));
+    TRY(sum(ix->ev_cp, &out->compact_launches, &out->compact_ms));
+    if (reset) recycle_events(ix);
+    return BIGSI_OK;
+}
+
+// ------------------------------------------------------------------------------ batches
+struct HitBufs {
+    DevBuf chunk_hits, chunk_off, hit_off, hit_col, hit_cnt, overflow;
+    uint64_t cap = 0;   // hits the col/cnt buffers can hold
+    void release()
+    {
+        chunk_hits.release(); chunk_off.release(); hit_off.release(); hit_col.release(); hit_cnt.release(); overflow.release();
+    }
+};
+
+struct bigsi_hip_batch {
+    bigsi_hip_index *ix = nullptr;
+    uint32_t n_seqs = 0, k = 0;
+    std::vector<uint64_t> seq_off, pos_off, tab_off;
+    uint64_t total_pos = 0, max_pos = 0;
+    DevBuf seqs, d_seq_off, d_pos_off, d_tab_off, tab, first_pos, pos_unique, tmp, rows, num_kmers, num_unique, min_kmers;
+    DevBuf bitmaps, counts, scratch;
+    void *ext_bitmaps = nullptr, *ext_counts = nullptr;
+    HitBufs hits, ghits;
+    // state of the last run
+    bool ran = false, exact = false;
+    uint32_t count_bytes = 2;
+    double threshold = 1.0;
+    uint64_t wv = 0, wv_pad = 0;   // valid / padded words per row at run time
+    uint32_t run_h = 0;            // num_hashes the row ids of the last K1 were produced with
+    std::vector<uint32_t> h_num_unique, h_num_kmers;
+    bool host_counts_valid = false;
+};
+
+static uint64_t pow2_at_least(uint64_t x)
+{
+    uint64_t p = 2;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+extern "C" int bigsi_hip_batch_create(bigsi_hip_index *ix, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k, bigsi_hip_batch **out)
+{
+    if (!out) return fail(BIGSI_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!ix || !offsets) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    if (n_seqs == 0) return fail(BIGSI_ERR_INVALID, "a batch needs at least one sequence");
+    if (k == 0) return fail(BIGSI_ERR_INVALID, "k must be > 0");
+    TRY(check_offsets(offsets, n_seqs));
+    const uint64_t base = offsets[0], nbytes = offsets[n_seqs] - base;
+    if (nbytes && !seqs) return fail(BIGSI_ERR_INVALID, "seqs is NULL");
+    TRY(use_device(ix));
+    bigsi_hip_batch *b = new (std::nothrow) bigsi_hip_batch();
+    if (!b) return fail(BIGSI_ERR_NOMEM, "host allocation failed");
+    b->ix = ix;
+    b->n_seqs = n_seqs;
+    b->k = k;
+    b->seq_off.resize(n_seqs + 1);
+    b->pos_off.resize(n_seqs + 1);
+    b->tab_off.resize(n_seqs + 1);
+    b->pos_off[0] = b->tab_off[0] = 0;
+    for (uint32_t i = 0; i <= n_seqs; i++) b->seq_off[i] = offsets[i] - base;
+    for (uint32_t i = 0; i < n_seqs; i++) {
+        const uint64_t len = b->seq_off[i + 1] - b->seq_off[i];
+        const uint64_t n = len >= k ? len - k + 1 : 0;
+        b->pos_off[i + 1] = b->pos_off[i] + n;
+        b->tab_off[i + 1] = b->tab_off[i] + pow2_at_least(2 * n);
+        b->max_pos = std::max(b->max_pos, n);
+    }
+    b->total_pos = b->pos_off[n_seqs];
+    const uint64_t T = std::max<uint64_t>(b->total_pos, 1);
+    int rc = BIGSI_OK;
+    auto R = [&](DevBuf &d, size_t bytes) { if (rc == BIGSI_OK) rc = d.reserve(bytes); };
+    R(b->seqs, std::max<uint64_t>(nbytes, 1));
+    R(b->d_seq_off, (n_seqs + 1) * 8ull);
+    R(b->d_pos_off, (n_seqs + 1) * 8ull);
+    R(b->d_tab_off, (n_seqs + 1) * 8ull);
+    R(b->tab, b->tab_off[n_seqs] * 4);
+    R(b->first_pos, T * 4);
+    R(b->pos_unique, T * 4);
+    R(b->tmp, T * 4);
+    R(b->rows, T * ix->h * 8);
+    R(b->num_kmers, n_seqs * 4ull);
+    R(b->num_unique, n_seqs * 4ull);
+    R(b->min_kmers, n_seqs * 4ull);
+    auto H2D = [&](void *dst, const void *src, size_t bytes) {
+        if (rc == BIGSI_OK && bytes) {
+            hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ix->stream);
+            if (e != hipSuccess) rc = fail(BIGSI_ERR_HIP, "H2D copy: %s", hipGetErrorString(e));
+        }
+    };
+    H2D(b->seqs.p, seqs ? seqs + base : nullptr, nbytes);
+    H2D(b->d_seq_off.p, b->seq_off.data(), (n_seqs + 1) * 8ull);
+    H2D(b->d_pos_off.p, b->pos_off.data(), (n_seqs + 1) * 8ull);
+    H2D(b->d_tab_off.p, b->tab_off.data(), (n_seqs + 1) * 8ull);
+    if (rc == BIGSI_OK) {
+        hipError_t e = hipStreamSynchronize(ix->stream);
+        if (e != hipSuccess) rc = fail(BIGSI_ERR_HIP, "sync: %s", hipGetErrorString(e));
+    }
+    if (rc != BIGSI_OK) { bigsi_hip_batch_destroy(b); return rc; }
+    *out = b;
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_batch_destroy(bigsi_hip_batch *b)
+{
+    if (!b) return BIGSI_OK;
+    hipError_t e = hipSetDevice(b->ix->device);
+    e = hipStreamSynchronize(b->ix->stream);
+    (void)e;
+    for (DevBuf *d : {&b->seqs, &b->d_seq_off, &b->d_pos_off, &b->d_tab_off, &b->tab, &b->first_pos, &b->pos_unique, &b->tmp, &b->rows,
+                      &b->num_kmers, &b->num_unique, &b->min_kmers, &b->bitmaps, &b->counts, &b->scratch})
+        d->release();
+    b->hits.release();
+    b->ghits.release();
+    delete b;
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_batch_set_outputs(bigsi_hip_batch *b, void *d_bitmaps, void *d_counts)
+{
+    if (!b) return fail(BIGSI_ERR_INVALID, "NULL batch");
+    b->ext_bitmaps = d_bitmaps;
+    b->ext_counts = d_counts;
+    return BIGSI_OK;
+}
+
+// -------- K2 dispatch
+template <int P, typename CountT>
+static void launch_count_h(bigsi_hip_batch *b, unsigned grid, unsigned block, uint32_t tiles, CountT *out, uint64_t out_stride)
+{
+    bigsi_hip_index *ix = b->ix;
+#define BIGSI_LAUNCH_COUNT(H)                                                                                              \
+    hipLaunchKernelGGL((k_and_count<P, H, CountT>), dim3(grid), dim3(block), 0, ix->stream, ix->d_index, ix->stride_words, \
+                       (uint32_t)b->wv, b->rows.as<uint64_t>(), b->d_pos_off.as<uint64_t>(), b->num_unique.as<uint32_t>(), \
+                       ix->h, b->n_seqs, tiles, out, out_stride)
+    switch (ix->h) {
+    case 1: BIGSI_LAUNCH_COUNT(1); break;
+    case 2: BIGSI_LAUNCH_COUNT(2); break;
+    case 3: BIGSI_LAUNCH_COUNT(3); break;
+    case 4: BIGSI_LAUNCH_COUNT(4); break;
+    case 5: BIGSI_LAUNCH_COUNT(5); break;
+    default: BIGSI_LAUNCH_COUNT(0); break;
+    }
+#undef BIGSI_LAUNCH_COUNT
+}
+
+static int compact(bigsi_hip_batch *b, HitBufs &hb, const void *src, uint32_t n_shards, uint64_t shard_cols, bool write_only);
+
+// K1 for the whole batch (h may have changed since create: the rows buffer is sized for it here)
+static int run_kmerize(bigsi_hip_batch *b, double threshold)
+{
+    bigsi_hip_index *ix = b->ix;
+    EventPair ep{};
+    TRY(b->rows.reserve(std::max<uint64_t>(b->total_pos, 1) * ix->h * 8));
+    HIP_TRY(hipMemsetAsync(b->tab.p, 0xFF, b->tab_off[b->n_seqs] * 4, ix->stream));
+    TRY(ev_begin(ix, &ep));
+    hipLaunchKernelGGL(k_kmerize, dim3(b->n_seqs), dim3(kBlock), 0, ix->stream, b->seqs.as<char>(), b->d_seq_off.as<uint64_t>(),
+                       b->d_pos_off.as<uint64_t>(), b->d_tab_off.as<uint64_t>(), b->tab.as<uint32_t>(), b->k, ix->h, ix->m, threshold,
+                       b->first_pos.as<uint32_t>(), b->pos_unique.as<uint32_t>(), b->tmp.as<uint32_t>(), b->rows.as<uint64_t>(),
+                       b->num_kmers.as<uint32_t>(), b->num_unique.as<uint32_t>(), b->min_kmers.as<uint32_t>());
+    HIP_TRY(hipGetLastError());
+    TRY(ev_end(ix, &ep, ix->ev_km));
+    b->run_h = ix->h;
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_t flags)
+{
+    if (!b) return fail(BIGSI_ERR_INVALID, "NULL batch");
+    if (!(threshold <= 1.0)) return fail(BIGSI_ERR_INVALID, "threshold must be <= 1 (bigsi/graph/bigsi.py:176), got %g", threshold);
+    bigsi_hip_index *ix = b->ix;
+    if (ix->n_cols == 0) return fail(BIGSI_ERR_STATE, "index has no columns");
+    TRY(use_device(ix));
+    b->ran = false;
+    b->host_counts_valid = false;
+    b->threshold = threshold;
+    b->exact = (threshold == 1.0) && !(flags & BIGSI_RUN_FORCE_COUNTS);
+    b->wv = ix->wv();
+    b->wv_pad = round_up(b->wv, 2);
+
+    // K1
+    EventPair ep{};
+    TRY(run_kmerize(b, threshold));
+
+    // K2
+    static const int and_block = [] { int v = env_int("BIGSI_HIP_AND_BLOCK", 256); return (v == 64 || v == 128 || v == 256) ? v : 256; }();
+    static const int and_unroll = env_int("BIGSI_HIP_AND_UNROLL", 8);
+    const uint32_t tiles = (uint32_t)ceil_div(b->wv, (uint64_t)and_block * kVec);
+    const uint64_t nblk = ceil_div(b->n_seqs, 8) * 8 * (uint64_t)tiles;
+    if (nblk > 0x7FFFFFFFull) return fail(BIGSI_ERR_INVALID, "batch too large for one launch (%llu workgroups)", (unsigned long long)nblk);
+    const unsigned grid = (unsigned)nblk;
+    if (b->exact) {
+        uint64_t *out = (uint64_t *)b->ext_bitmaps;
+        if (!out) { TRY(b->bitmaps.reserve((size_t)b->n_seqs * b->wv_pad * 8)); out = b->bitmaps.as<uint64_t>(); }
+        TRY(ev_begin(ix, &ep));
+#define BIGSI_LAUNCH_EXACT(U)                                                                                                  \
+    hipLaunchKernelGGL((k_and_exact<U>), dim3(grid), dim3(and_block), 0, ix->stream, ix->d_index, ix->stride_words, (uint32_t)b->wv, \
+                       ix->n_cols, b->rows.as<uint64_t>(), b->d_pos_off.as<uint64_t>(), b->num_unique.as<uint32_t>(), ix->h,    \
+                       b->n_seqs, tiles, out, b->wv_pad)
+        if (and_unroll == 4) BIGSI_LAUNCH_EXACT(4);
+        else if (and_unroll == 16) BIGSI_LAUNCH_EXACT(16);
+        else BIGSI_LAUNCH_EXACT(8);
+#undef BIGSI_LAUNCH_EXACT
+        HIP_TRY(hipGetLastError());
+        TRY(ev_end(ix, &ep, ix->ev_and));
+    } else {
+        // planes needed for the largest possible count = max k-mers of any sequence in the batch
+        const uint64_t maxu = b->max_pos;
+        int P = maxu < (1ull << 6) ? 6 : maxu < (1ull << 10) ? 10 : maxu < (1ull << 16) ? 16 : 32;
+        b->count_bytes = P <= 16 ? 2 : 4;
+        const uint64_t cstride = b->wv_pad * 64;
+        void *out = b->ext_counts;
+        if (!out) { TRY(b->counts.reserve((size_t)b->n_seqs * cstride * b->count_bytes)); out = b->counts.p; }
+        TRY(ev_begin(ix, &ep));
+        switch (P) {
+        case 6: launch_count_h<6, uint16_t>(b, grid, and_block, tiles, (uint16_t *)out, cstride); break;
+        case 10: launch_count_h<10, uint16_t>(b, grid, and_block, tiles, (uint16_t *)out, cstride); break;
+        case 16: launch_count_h<16, uint16_t>(b, grid, and_block, tiles, (uint16_t *)out, cstride); break;
+        default: launch_count_h<32, uint32_t>(b, grid, and_block, tiles, (uint32_t *)out, cstride); break;
+        }
+        HIP_TRY(hipGetLastError());
+        TRY(ev_end(ix, &ep, ix->ev_and));
+    }
+
+    // K4 on this shard's own result
+    TRY(ev_begin(ix, &ep));
+    const void *src = b->exact ? (b->ext_bitmaps ? b->ext_bitmaps : b->bitmaps.p) : (b->ext_counts ? b->ext_counts : b->counts.p);
+    TRY(compact(b, b->hits, src, 1, ix->n_cols, false));
+    TRY(ev_end(ix, &ep, ix->ev_cp));
+    b->ran = true;
+    return BIGSI_OK;
+}
+
+// three compaction passes over [shard][seq][stride]; write_only re-runs just the write pass (after growing buffers)
+static int compact(bigsi_hip_batch *b, HitBufs &hb, const void *src, uint32_t n_shards, uint64_t shard_cols, bool write_only)
+{
+    bigsi_hip_index *ix = b->ix;
+    const uint32_t chunks = b->exact ? (uint32_t)ceil_div(b->wv, kBlock) : (uint32_t)ceil_div(b->wv_pad * 64, kChunkCols);
+    const uint64_t per_seq = (uint64_t)n_shards * chunks, nchunks = per_seq * b->n_seqs;
+    if (nchunks > 0x7FFFFFFFull) return fail(BIGSI_ERR_INVALID, "too many compaction chunks");
+    TRY(hb.chunk_hits.reserve(nchunks * 4));
+    TRY(hb.chunk_off.reserve(nchunks * 8));
+    TRY(hb.hit_off.reserve((b->n_seqs + 1) * 8ull));
+    TRY(hb.overflow.reserve(4));
+    if (hb.cap == 0) {
+        const uint64_t want = 1u << 16;
+        TRY(hb.hit_col.reserve(want * 4));
+        TRY(hb.hit_cnt.reserve(want * 4));
+        hb.cap = want;
+    }
+    const unsigned grid = (unsigned)nchunks;
+    HIP_TRY(hipMemsetAsync(hb.overflow.p, 0, 4, ix->stream));
+#define BIGSI_HITS_ARGS(SRC_T, STRIDE)                                                                                            \
+    (const SRC_T *)src, (uint64_t)(STRIDE), (uint32_t)b->wv, b->n_seqs, n_shards, chunks, shard_cols,                             \
+        b->exact ? b->num_unique.as<uint32_t>() : b->min_kmers.as<uint32_t>(), hb.chunk_hits.as<uint32_t>(),                      \
+        hb.chunk_off.as<uint64_t>(), hb.hit_col.as<uint32_t>(), hb.hit_cnt.as<uint32_t>(), hb.cap, hb.overflow.as<uint32_t>()
+#define BIGSI_HITS_LAUNCH(KERNEL, SRC_T, STRIDE) \
+    hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(kBlock), 0, ix->stream, BIGSI_HITS_ARGS(SRC_T, STRIDE))
+    for (int pass = write_only ? 1 : 0; pass < 2; pass++) {
+        if (b->exact) {
+            if (pass == 0) BIGSI_HITS_LAUNCH((k_hits_exact<false>), uint64_t, b->wv_pad);
+            else BIGSI_HITS_LAUNCH((k_hits_exact<true>), uint64_t, b->wv_pad);
+        } else if (b->count_bytes == 2) {
+            if (pass == 0) BIGSI_HITS_LAUNCH((k_hits_count<uint16_t, false>), uint16_t, b->wv_pad * 64);
+            else BIGSI_HITS_LAUNCH((k_hits_count<uint16_t, true>), uint16_t, b->wv_pad * 64);
+        } else {
+            if (pass == 0) BIGSI_HITS_LAUNCH((k_hits_count<uint32_t, false>), uint32_t, b->wv_pad * 64);
+            else BIGSI_HITS_LAUNCH((k_hits_count<uint32_t, true>), uint32_t, b->wv_pad * 64);
+        }
+        HIP_TRY(hipGetLastError());
+        if (pass == 0) {
+            hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(kBlock), 0, ix->stream, hb.chunk_hits.as<uint32_t>(), nchunks, (uint32_t)per_seq,
+                               b->n_seqs, hb.chunk_off.as<uint64_t>(), hb.hit_off.as<uint64_t>());
+            HIP_TRY(hipGetLastError());
+        }
+    }
+#undef BIGSI_HITS_LAUNCH
+#undef BIGSI_HITS_ARGS
+    return BIGSI_OK;
+}
+
+// synchronise, make sure the hit lists fit (grow + rewrite if the write pass overflowed), copy them out
+static int fetch_hits_from(bigsi_hip_batch *b, HitBufs &hb, const void *src, uint32_t n_shards, uint64_t shard_cols,
+                           uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t capacity)
+{
+    bigsi_hip_index *ix = b->ix;
+    std::vector<uint64_t> off(b->n_seqs + 1);
+    HIP_TRY(hipMemcpyAsync(off.data(), hb.hit_off.p, (b->n_seqs + 1) * 8ull, hipMemcpyDeviceToHost, ix->stream));
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    const uint64_t total = off[b->n_seqs];
+    if (total > hb.cap) {
+        TRY(hb.hit_col.reserve(total * 4));
+        TRY(hb.hit_cnt.reserve(total * 4));
+        hb.cap = total;
+        TRY(compact(b, hb, src, n_shards, shard_cols, true));
+        HIP_TRY(hipStreamSynchronize(ix->stream));
+    }
+    if (hit_offsets) memcpy(hit_offsets, off.data(), (b->n_seqs + 1) * 8ull);
+    if (total > capacity)
+        return fail(BIGSI_ERR_CAPACITY, "hit buffers hold %llu entries, %llu needed", (unsigned long long)capacity, (unsigned long long)total);
+    if (total && colours) HIP_TRY(hipMemcpy(colours, hb.hit_col.p, total * 4, hipMemcpyDeviceToHost));
+    if (total && counts) HIP_TRY(hipMemcpy(counts, hb.hit_cnt.p, total * 4, hipMemcpyDeviceToHost));
+    return BIGSI_OK;
+}
+
+static int need_run(bigsi_hip_batch *b)
+{
+    if (!b) return fail(BIGSI_ERR_INVALID, "NULL batch");
+    if (!b->ran) return fail(BIGSI_ERR_STATE, "bigsi_hip_batch_run has not completed for this batch");
+    return use_device(b->ix);
+}
+
+static int host_counts(bigsi_hip_batch *b)
+{
+    if (b->host_counts_valid) return BIGSI_OK;
+    b->h_num_unique.resize(b->n_seqs);
+    b->h_num_kmers.resize(b->n_seqs);
+    HIP_TRY(hipMemcpyAsync(b->h_num_unique.data(), b->num_unique.p, b->n_seqs * 4ull, hipMemcpyDeviceToHost, b->ix->stream));
+    HIP_TRY(hipMemcpyAsync(b->h_num_kmers.data(), b->num_kmers.p, b->n_seqs * 4ull, hipMemcpyDeviceToHost, b->ix->stream));
+    HIP_TRY(hipStreamSynchronize(b->ix->stream));
+    b->host_counts_valid = true;
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_batch_get_info(bigsi_hip_batch *b, bigsi_hip_batch_info *out)
+{
+    if (!b || !out) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    memset(out, 0, sizeof *out);
+    out->n_seqs = b->n_seqs;
+    out->k = b->k;
+    out->total_kmers = b->total_pos;
+    if (!b->ran) return BIGSI_OK;
+    TRY(use_device(b->ix));
+    TRY(host_counts(b));
+    out->exact = b->exact ? 1 : 0;
+    out->count_bytes = b->count_bytes;
+    for (uint32_t v : b->h_num_unique) out->total_unique += v;
+    uint64_t total = 0;
+    HIP_TRY(hipMemcpy(&total, b->hits.hit_off.as<uint64_t>() + b->n_seqs, 8, hipMemcpyDeviceToHost));
+    out->total_hits = total;
+    out->bitmap_stride_bytes = b->wv_pad * 8;
+    out->counts_stride = b->wv_pad * 64;
+    out->d_bitmaps = b->ext_bitmaps ? b->ext_bitmaps : b->bitmaps.p;
+    out->d_counts = b->ext_counts ? b->ext_counts : b->counts.p;
+    out->d_num_unique = b->num_unique.p;
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_batch_fetch_unique(bigsi_hip_batch *b, uint32_t *num_kmers, uint32_t *num_unique, uint32_t *min_kmers)
+{
+    TRY(need_run(b));
+    TRY(host_counts(b));
+    if (num_kmers) memcpy(num_kmers, b->h_num_kmers.data(), b->n_seqs * 4ull);
+    if (num_unique) memcpy(num_unique, b->h_num_unique.data(), b->n_seqs * 4ull);
+    if (min_kmers) HIP_TRY(hipMemcpy(min_kmers, b->min_kmers.p, b->n_seqs * 4ull, hipMemcpyDeviceToHost));
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_batch_fetch_hits(bigsi_hip_batch *b, uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t capacity)
+{
+    TRY(need_run(b));
+    const void *src = b->exact ? (b->ext_bitmaps ? b->ext_bitmaps : b->bitmaps.p) : (b->ext_counts ? b->ext_counts : b->counts.p);
+    return fetch_hits_from(b, b->hits, src, 1, b->ix->n_cols, hit_offsets, colours, counts, capacity);
+}
+
+extern "C" int bigsi_hip_compact_gathered(bigsi_hip_batch *b, const void *d_gathered, uint32_t n_shards, uint64_t shard_cols,
+                                          uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t capacity)
+{
+    TRY(need_run(b));
+    if (!d_gathered || n_shards == 0) return fail(BIGSI_ERR_INVALID, "bad gathered buffer");
+    if ((uint64_t)n_shards * shard_cols > 0xFFFFFFFFull) return fail(BIGSI_ERR_INVALID, "more than 2^32-1 colours in total");
+    TRY(compact(b, b->ghits, d_gathered, n_shards, shard_cols, false));
+    return fetch_hits_from(b, b->ghits, d_gathered, n_shards, shard_cols, hit_offsets, colours, counts, capacity);
+}
+
+extern "C" int bigsi_hip_batch_fetch_counts(bigsi_hip_batch *b, uint32_t seq, uint32_t *out)
+{
+    TRY(need_run(b));
+    if (!out) return fail(BIGSI_ERR_INVALID, "out is NULL");
+    if (b->exact) return fail(BIGSI_ERR_STATE, "the last run took the exact path; re-run with BIGSI_RUN_FORCE_COUNTS or threshold < 1");
+    if (seq >= b->n_seqs) return fail(BIGSI_ERR_RANGE, "sequence %u out of range", seq);
+    const uint64_t n = b->ix->n_cols, cstride = b->wv_pad * 64;
+    const uint8_t *src = (const uint8_t *)(b->ext_counts ? b->ext_counts : b->counts.p) + (uint64_t)seq * cstride * b->count_bytes;
+    HIP_TRY(hipStreamSynchronize(b->ix->stream));
+    if (b->count_bytes == 4) {
+        HIP_TRY(hipMemcpy(out, src, n * 4, hipMemcpyDeviceToHost));
+    } else {
+        std::vector<uint16_t> tmp(n);
+        HIP_TRY(hipMemcpy(tmp.data(), src, n * 2, hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < n; i++) out[i] = tmp[i];
+    }
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_batch_fetch_bitmap(bigsi_hip_batch *b, uint32_t seq, uint8_t *out)
+{
+    TRY(need_run(b));
+    if (!out) return fail(BIGSI_ERR_INVALID, "out is NULL");
+    if (!b->exact) return fail(BIGSI_ERR_STATE, "the last run took the counting path");
+    if (seq >= b->n_seqs) return fail(BIGSI_ERR_RANGE, "sequence %u out of range", seq);
+    const uint8_t *src = (const uint8_t *)(b->ext_bitmaps ? b->ext_bitmaps : b->bitmaps.p) + (uint64_t)seq * b->wv_pad * 8;
+    HIP_TRY(hipStreamSynchronize(b->ix->stream));
+    HIP_TRY(hipMemcpy(out, src, b->ix->rb(), hipMemcpyDeviceToHost));
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_batch_fetch_rows(bigsi_hip_batch *b, uint32_t seq, uint64_t *rows, uint64_t capacity)
+{
+    TRY(need_run(b));
+    if (seq >= b->n_seqs) return fail(BIGSI_ERR_RANGE, "sequence %u out of range", seq);
+    TRY(host_counts(b));
+    const uint64_t n = (uint64_t)b->h_num_unique[seq] * b->ix->h;
+    if (n > capacity) return fail(BIGSI_ERR_CAPACITY, "rows buffer holds %llu, %llu needed", (unsigned long long)capacity, (unsigned long long)n);
+    if (n) HIP_TRY(hipMemcpy(rows, b->rows.as<uint64_t>() + b->pos_off[seq] * b->ix->h, n * 8, hipMemcpyDeviceToHost));
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_batch_lookup(bigsi_hip_batch *b, uint32_t seq, uint32_t *first_pos, uint8_t *out_rows, uint64_t capacity_rows)
+{
+    TRY(need_run(b));
+    if (seq >= b->n_seqs) return fail(BIGSI_ERR_RANGE, "sequence %u out of range", seq);
+    TRY(host_counts(b));
+    bigsi_hip_index *ix = b->ix;
+    const uint32_t u = b->h_num_unique[seq];
+    if (u > capacity_rows) return fail(BIGSI_ERR_CAPACITY, "lookup buffer holds %llu rows, %u needed", (unsigned long long)capacity_rows, u);
+    if (u == 0) return BIGSI_OK;
+    const uint64_t wv = ix->wv(), rb = ix->rb();
+    if (first_pos) HIP_TRY(hipMemcpy(first_pos, b->first_pos.as<uint32_t>() + b->pos_off[seq], u * 4ull, hipMemcpyDeviceToHost));
+    if (!out_rows) return BIGSI_OK;
+    TRY(b->scratch.reserve((size_t)u * wv * 8));
+    const uint64_t wblocks = ceil_div(wv, kBlock);
+    if (wblocks * u > 0x7FFFFFFFull) return fail(BIGSI_ERR_INVALID, "lookup too large for one launch");
+    hipLaunchKernelGGL(k_lookup, dim3((unsigned)(wblocks * u)), dim3(kBlock), 0, ix->stream, ix->d_index, ix->stride_words, (uint32_t)wv,
+                       b->rows.as<uint64_t>() + b->pos_off[seq] * ix->h, ix->h, u, b->scratch.as<uint64_t>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy2DAsync(out_rows, rb, b->scratch.p, wv * 8, rb, u, hipMemcpyDeviceToHost, ix->stream));
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_batch_presence(bigsi_hip_batch *b, uint32_t seq, const uint32_t *colours, uint32_t n_colours, uint8_t *out)
+{
+    TRY(need_run(b));
+    if (seq >= b->n_seqs) return fail(BIGSI_ERR_RANGE, "sequence %u out of range", seq);
+    if (n_colours == 0) return BIGSI_OK;
+    if (!colours || !out) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    bigsi_hip_index *ix = b->ix;
+    for (uint32_t i = 0; i < n_colours; i++)
+        if (colours[i] >= ix->n_cols) return fail(BIGSI_ERR_RANGE, "colour %u >= num_cols", colours[i]);
+    TRY(host_counts(b));
+    const uint32_t n = b->h_num_kmers[seq];
+    if (n == 0) return BIGSI_OK;
+    const size_t cbytes = round_up((size_t)n_colours * 4, 256);
+    TRY(b->scratch.reserve(cbytes + (size_t)n_colours * n));
+    uint8_t *d_out = b->scratch.as<uint8_t>() + cbytes;
+    HIP_TRY(hipMemcpyAsync(b->scratch.p, colours, n_colours * 4ull, hipMemcpyHostToDevice, ix->stream));
+    if (ceil_div(n, kBlock) * n_colours > 0x7FFFFFFFull) return fail(BIGSI_ERR_INVALID, "presence request too large for one launch");
+    hipLaunchKernelGGL(k_presence, dim3((unsigned)(ceil_div(n, kBlock) * n_colours)), dim3(kBlock), 0, ix->stream, ix->d_index, ix->stride_words,
+                       b->rows.as<uint64_t>() + b->pos_off[seq] * ix->h, b->pos_unique.as<uint32_t>() + b->pos_off[seq], ix->h, n,
+                       b->scratch.as<uint32_t>(), n_colours, d_out);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)n_colours * n, hipMemcpyDeviceToHost, ix->stream));
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    return BIGSI_OK;
+}
+
+// one-shot KmerSignatureIndex.lookup for an explicit k-mer list: every k-mer is its own one-window sequence, so K1's
+// row ids land contiguously (u x h) and one k_lookup launch covers them all.
+extern "C" int bigsi_hip_lookup(bigsi_hip_index *ix, const char *kmers, uint32_t k, uint64_t u, uint8_t *out_rows)
+{
+    if (!ix || (u && (!kmers || !out_rows))) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    if (k == 0) return fail(BIGSI_ERR_INVALID, "k must be > 0");
+    if (u == 0) return BIGSI_OK;
+    if (u > 0x7FFFFFFFull) return fail(BIGSI_ERR_INVALID, "too many k-mers for one call");
+    if (ix->n_cols == 0) return fail(BIGSI_ERR_STATE, "index has no columns");
+    std::vector<uint64_t> off(u + 1);
+    for (uint64_t i = 0; i <= u; i++) off[i] = i * k;
+    bigsi_hip_batch *b = nullptr;
+    TRY(bigsi_hip_batch_create(ix, kmers, off.data(), (uint32_t)u, k, &b));
+    int rc = run_kmerize(b, 1.0);
+    const uint64_t wv = ix->wv(), rb = ix->rb();
+    if (rc == BIGSI_OK) rc = b->scratch.reserve((size_t)u * wv * 8);
+    if (rc == BIGSI_OK) {
+        const uint64_t wblocks = ceil_div(wv, kBlock);
+        if (wblocks * u > 0x7FFFFFFFull) rc = fail(BIGSI_ERR_INVALID, "lookup too large for one launch");
+        else {
+            hipLaunchKernelGGL(k_lookup, dim3((unsigned)(wblocks * u)), dim3(kBlock), 0, ix->stream, ix->d_index, ix->stride_words, (uint32_t)wv,
+                               b->rows.as<uint64_t>(), ix->h, (uint32_t)u, b->scratch.as<uint64_t>());
+            hipError_t e = hipGetLastError();
+            if (e == hipSuccess) e = hipMemcpy2DAsync(out_rows, rb, b->scratch.p, wv * 8, rb, u, hipMemcpyDeviceToHost, ix->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+            if (e != hipSuccess) rc = fail(BIGSI_ERR_HIP, "bigsi_hip_lookup: %s", hipGetErrorString(e));
+        }
+    }
+    bigsi_hip_batch_destroy(b);
+    return rc;
+}

@@ -1,0 +1,618 @@
+// bigsi_kernels.hpp -- CDNA4 (gfx950) device code of the BIGSI query hot path.
+//
+// Data layout in HBM: the index is m rows x stride_words uint64 (stride a multiple of 16 words = 128 B).
+// A row holds exactly the reference's row bytes (bitarray.tobytes(), bigsi/storage/base.py:85-99), so a
+// little-endian uint64 load of word w covers columns [64w, 64w+64) with column c at bit
+// ((c>>3)&7)*8 + 7-(c&7).  AND / popcount / bit-sliced addition are agnostic to that permutation; it is
+// only applied where set bits become colour ids (compaction, counter expansion).
+//
+// Kernels: K1 k_kmerize, K2/K3a k_and_exact, K2/K3b k_and_count,
+// K4 k_chunk_hits_* / k_scan_chunks / k_write_hits_*, K5 k_presence, plus lookup / storage / build helpers.
+// All bitwise, HBM-bound work: no MFMA.  Wavefront = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bigsi {
+
+constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+constexpr int kBlock = 256;      // 4 wavefronts
+constexpr int kVec = 2;          // uint64 words per lane per row load (16 B/lane, 1 KiB per wave instruction)
+
+// ------------------------------------------------------------------------------ small helpers
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// bit position, inside the little-endian uint64 of a row, of column (8*byte + j)
+__host__ __device__ __forceinline__ uint32_t bit_of_col(uint32_t c) { return ((c >> 3) & 7u) * 8u + 7u - (c & 7u); }
+
+// mask of the valid column bits of word w for an index of n_cols columns (pad bits stay zero)
+__host__ __device__ __forceinline__ uint64_t valid_mask(uint64_t w, uint64_t n_cols)
+{
+    uint64_t c0 = w * 64;
+    if (c0 + 64 <= n_cols) return ~0ull;
+    if (c0 >= n_cols) return 0ull;
+    uint64_t mask = 0;
+    for (int b = 0; b < 8; b++) {
+        uint64_t cb = c0 + 8 * (uint64_t)b;
+        uint64_t n = cb >= n_cols ? 0 : (n_cols - cb >= 8 ? 8 : n_cols - cb);
+        mask |= (uint64_t)((0xFFu << (8 - n)) & 0xFFu) << (8 * b);
+    }
+    return mask;
+}
+
+// reverse_comp's per-base map (bigsi/utils/fncts.py:12,38-39): A<->T, C<->G, anything else unchanged
+__device__ __forceinline__ uint8_t complement(uint8_t c)
+{
+    return c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : c == 'G' ? 'C' : c;
+}
+
+// byte j of the canonical form of the k-mer at s[0..k): forward strand or reverse complement
+struct KmerView {
+    const char *s;
+    uint32_t k;
+    bool rc;
+    __device__ __forceinline__ uint8_t operator[](uint32_t j) const
+    {
+        return rc ? complement((uint8_t)s[k - 1 - j]) : (uint8_t)s[j];
+    }
+};
+
+// canonical (bigsi/utils/fncts.py:51-54): lexicographic min of k-mer and reverse complement -> use rc?
+__device__ __forceinline__ bool use_revcomp(const char *s, uint32_t k)
+{
+    for (uint32_t j = 0; j < k; j++) {
+        uint8_t f = (uint8_t)s[j], r = complement((uint8_t)s[k - 1 - j]);
+        if (f != r) return r < f;
+    }
+    return false;
+}
+
+// mmh3.hash(kmer, seed) (bigsi/bloom/bloomfilter.py:6): MurmurHash3_x86_32, Austin Appleby's public-domain
+// algorithm, over the k bytes of the view.
+__device__ __forceinline__ uint32_t murmur3_32(const KmerView &v, uint32_t seed)
+{
+    const uint32_t c1 = 0xcc9e2d51u, c2 = 0x1b873593u;
+    uint32_t h1 = seed;
+    const uint32_t len = v.k, nblocks = len >> 2;
+    for (uint32_t i = 0; i < nblocks; i++) {
+        uint32_t k1 = (uint32_t)v[4 * i] | ((uint32_t)v[4 * i + 1] << 8) | ((uint32_t)v[4 * i + 2] << 16) |
+                      ((uint32_t)v[4 * i + 3] << 24);
+        k1 *= c1; k1 = rotl32(k1, 15); k1 *= c2;
+        h1 ^= k1; h1 = rotl32(h1, 13); h1 = h1 * 5u + 0xe6546b64u;
+    }
+    uint32_t k1 = 0;
+    const uint32_t t = nblocks * 4, rem = len & 3u;
+    if (rem == 3) k1 ^= (uint32_t)v[t + 2] << 16;
+    if (rem >= 2) k1 ^= (uint32_t)v[t + 1] << 8;
+    if (rem >= 1) { k1 ^= (uint32_t)v[t]; k1 *= c1; k1 = rotl32(k1, 15); k1 *= c2; h1 ^= k1; }
+    h1 ^= len;
+    h1 ^= h1 >> 16; h1 *= 0x85ebca6bu; h1 ^= h1 >> 13; h1 *= 0xc2b2ae35u; h1 ^= h1 >> 16;
+    return h1;
+}
+
+// _hash (bigsi/bloom/bloomfilter.py:5-6): signed 32-bit hash, Python floor-mod by m -> row in [0, m)
+__device__ __forceinline__ uint64_t row_of_hash(uint32_t h, uint64_t m)
+{
+    int64_t sh = (int64_t)(int32_t)h;
+    if (sh >= 0) return (uint64_t)sh % m;
+    uint64_t a = (uint64_t)(-sh) % m;
+    return a == 0 ? 0 : m - a;
+}
+
+// block-wide exclusive scan of one uint32 per thread (kBlock threads); returns prefix, *total = block sum.
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *total, uint32_t *lds /* >= kBlock/64 + 1 */)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(incl, d, 64);
+        if (lane >= (uint32_t)d) incl += o;
+    }
+    __syncthreads();   // protect lds reuse across calls
+    if (lane == 63) lds[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kBlock / 64; w++) {
+        uint32_t x = lds[w];
+        if (w < wave) base += x;
+        tot += x;
+    }
+    *total = tot;
+    return base + incl - v;
+}
+
+// ------------------------------------------------------------------------------ K1: k-merise + dedupe + hash
+// One workgroup per query sequence.  Restates, per sequence:
+//   seq_to_kmers (bigsi/utils/fncts.py:63-65)          every window of k bytes, no validation;
+//   set(kmers) (bigsi/graph/index.py:45, graph/bigsi.py:179)  unique *query strings* (a k-mer and its reverse
+//                                                       complement are two), kept in first-occurrence order;
+//   canonical + generate_hashes (fncts.py:51-54, bloom/bloomfilter.py:5-13, graph/index.py:62-70)
+//                                                       h row ids per unique k-mer, seeds 0..h-1;
+//   min_kmers = ceil(u * threshold) (graph/bigsi.py:179) in IEEE double, as Python evaluates it.
+// Dedupe: open-addressing table of positions in global scratch, keyed by string equality, class
+// representative = smallest position (deterministic whatever the atomics' order).
+__global__ __launch_bounds__(kBlock) void k_kmerize(
+    const char *__restrict__ seqs, const uint64_t *__restrict__ seq_off, const uint64_t *__restrict__ pos_off,
+    const uint64_t *__restrict__ tab_off, uint32_t *__restrict__ tab, uint32_t k, uint32_t h, uint64_t m, double threshold,
+    uint32_t *__restrict__ first_pos, uint32_t *__restrict__ pos_unique, uint32_t *__restrict__ tmp,
+    uint64_t *__restrict__ rows, uint32_t *__restrict__ num_kmers, uint32_t *__restrict__ num_unique,
+    uint32_t *__restrict__ min_kmers)
+{
+    __shared__ uint32_t lds[kBlock / 64 + 1];
+    const uint32_t q = blockIdx.x;
+    const char *s = seqs + seq_off[q];
+    const uint64_t len = seq_off[q + 1] - seq_off[q];
+    const uint32_t n = len >= k ? (uint32_t)(len - k + 1) : 0u;
+    const uint64_t P = pos_off[q];
+    uint32_t *t = tab + tab_off[q];
+    const uint32_t mask = (uint32_t)(tab_off[q + 1] - tab_off[q]) - 1u;   // table size is a power of two >= 2n
+    uint32_t *fp = first_pos + P, *pu = pos_unique + P, *tm = tmp + P;
+
+    // phase 1: insert every position; slot value converges to the smallest position of its string class
+    for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
+        uint32_t hsh = 2166136261u;
+        for (uint32_t j = 0; j < k; j++) hsh = (hsh ^ (uint8_t)s[i + j]) * 16777619u;
+        uint32_t slot = (hsh ^ (hsh >> 15)) & mask;
+        for (;;) {
+            uint32_t cur = atomicCAS(&t[slot], kEmpty, i);
+            if (cur == kEmpty) break;
+            bool eq = true;
+            for (uint32_t j = 0; j < k; j++)
+                if (s[cur + j] != s[i + j]) { eq = false; break; }
+            if (eq) { atomicMin(&t[slot], i); break; }
+            slot = (slot + 1) & mask;
+        }
+    }
+    __syncthreads();
+    // phase 2: representative of every position
+    for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
+        uint32_t hsh = 2166136261u;
+        for (uint32_t j = 0; j < k; j++) hsh = (hsh ^ (uint8_t)s[i + j]) * 16777619u;
+        uint32_t slot = (hsh ^ (hsh >> 15)) & mask;
+        uint32_t rep;
+        for (;;) {
+            rep = __hip_atomic_load(&t[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool eq = true;
+            for (uint32_t j = 0; j < k; j++)
+                if (s[rep + j] != s[i + j]) { eq = false; break; }
+            if (eq) break;
+            slot = (slot + 1) & mask;
+        }
+        pu[i] = rep;
+    }
+    __syncthreads();
+    // phase 3: ordered compaction of class representatives -> unique k-mers in first-occurrence order
+    uint32_t u = 0;
+    for (uint32_t base = 0; base < n; base += kBlock) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t flag = (i < n && pu[i] == i) ? 1u : 0u;
+        uint32_t tot;
+        const uint32_t pre = block_exclusive_scan(flag, &tot, lds);
+        if (flag) { fp[u + pre] = i; tm[i] = u + pre; }
+        u += tot;
+    }
+    __syncthreads();
+    // phase 4: position -> index of its unique k-mer (for presence strings, graph/bigsi.py:233)
+    for (uint32_t i = threadIdx.x; i < n; i += kBlock) pu[i] = tm[pu[i]];
+    if (threadIdx.x == 0) {
+        num_kmers[q] = n;
+        num_unique[q] = u;
+        min_kmers[q] = (uint32_t)ceil((double)u * threshold);   // one IEEE multiply, as Python's int*float
+    }
+    // phase 5: canonical k-mer -> h row ids
+    uint64_t *qrows = rows + P * h;
+    for (uint32_t j = threadIdx.x; j < u; j += kBlock) {
+        const char *km = s + fp[j];
+        KmerView v{km, k, use_revcomp(km, k)};
+        for (uint32_t sd = 0; sd < h; sd++) qrows[(uint64_t)j * h + sd] = row_of_hash(murmur3_32(v, sd), m);
+    }
+}
+
+// ------------------------------------------------------------------------------ K2 work decomposition
+// One wavefront streams one 128-word (1 KiB) column segment of every row a query needs: lane l holds words
+// [seg*128 + 2l, +2) -> each row read is ONE coalesced 1 KiB wave instruction (global_load_dwordx4), each
+// needed byte of a row is read exactly once, and row ids arrive through scalar loads (they are wave-uniform).
+// blockIdx -> (query, tile) is XCD-aware: hardware places block b on XCD b % 8, so all tiles of a query get the
+// same residue and run on one XCD, adjacent in dispatch order (their row-id lists and the address translations
+// of a row's page are shared in that XCD's L2).
+struct TileMap {
+    uint32_t q, tile;
+    bool valid;
+};
+__device__ __forceinline__ TileMap map_block(uint32_t b, uint32_t n_seqs, uint32_t tiles)
+{
+    const uint32_t xcd = b & 7u, slot = b >> 3;
+    const uint32_t ql = slot / tiles, tile = slot - ql * tiles;
+    const uint32_t q = ql * 8u + xcd;
+    return TileMap{q, tile, q < n_seqs};
+}
+
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ u64x2 load_row_seg(const uint64_t *__restrict__ index, uint64_t row, uint64_t stride_words, uint32_t w0)
+{
+    const u64x2 *p = reinterpret_cast<const u64x2 *>(index + row * stride_words + w0);
+    return __builtin_nontemporal_load(p);   // streamed once: keep it out of the way of the row-id lists in L2
+}
+
+// ------------------------------------------------------------------------------ K2 + K3a: exact
+// AND of every row of every unique k-mer of the query (graph/index.py:75-80 then graph/bigsi.py:192-195):
+// out[q][w] for w < wv.  Sequences without k-mers produce an all-zero bitmap (the host shim raises for them).
+template <int UNROLL>
+__global__ __launch_bounds__(kBlock) void k_and_exact(
+    const uint64_t *__restrict__ index, uint64_t stride_words, uint32_t wv, uint64_t n_cols,
+    const uint64_t *__restrict__ rows, const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ num_unique,
+    uint32_t h, uint32_t n_seqs, uint32_t tiles, uint64_t *__restrict__ out, uint64_t out_stride_words)
+{
+    const TileMap tm = map_block(blockIdx.x, n_seqs, tiles);
+    if (!tm.valid) return;
+    const uint32_t w0 = (tm.tile * blockDim.x + threadIdx.x) * kVec;
+    if (w0 >= wv) return;
+    const uint64_t R = (uint64_t)num_unique[tm.q] * h;
+    const uint64_t *qrows = rows + pos_off[tm.q] * h;
+    u64x2 acc = {~0ull, ~0ull};
+    uint64_t r = 0;
+    for (; r + UNROLL <= R; r += UNROLL) {
+        u64x2 v[UNROLL];
+#pragma unroll
+        for (int j = 0; j < UNROLL; j++) v[j] = load_row_seg(index, qrows[r + j], stride_words, w0);
+#pragma unroll
+        for (int j = 0; j < UNROLL; j++) acc &= v[j];
+    }
+    for (; r < R; r++) acc &= load_row_seg(index, qrows[r], stride_words, w0);
+    if (R == 0) acc = u64x2{0ull, 0ull};
+    acc.x &= valid_mask(w0, n_cols);
+    acc.y &= valid_mask(w0 + 1, n_cols);
+    uint64_t *o = out + (uint64_t)tm.q * out_stride_words + w0;
+    o[0] = acc.x;
+    if (w0 + 1 < out_stride_words) o[1] = acc.y;
+}
+
+// ------------------------------------------------------------------------------ K2 + K3b: per-sample counts
+// For every unique k-mer: AND of its h rows (graph/index.py:75-80), then +1 into the counters of the samples whose
+// bit survived (unpack_and_sum, graph/bigsi.py:35-44).  Counters are bit-sliced: P planes of uint64 per word, a
+// ripple-carry add of the AND-ed word costs 3 bit-ops per plane, far below what the HBM stream leaves the VALU
+// (see DESIGN.md).  Planes are expanded to integers once per (query, segment) and stored as CountT.
+template <int P, int H, typename CountT>
+__global__ __launch_bounds__(kBlock) void k_and_count(
+    const uint64_t *__restrict__ index, uint64_t stride_words, uint32_t wv,
+    const uint64_t *__restrict__ rows, const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ num_unique,
+    uint32_t h_rt, uint32_t n_seqs, uint32_t tiles, CountT *__restrict__ out, uint64_t out_stride /* counters per query */)
+{
+    const TileMap tm = map_block(blockIdx.x, n_seqs, tiles);
+    if (!tm.valid) return;
+    const uint32_t w0 = (tm.tile * blockDim.x + threadIdx.x) * kVec;
+    if (w0 >= wv) return;
+    const uint32_t h = H > 0 ? (uint32_t)H : h_rt;
+    const uint32_t u = num_unique[tm.q];
+    const uint64_t *qrows = rows + pos_off[tm.q] * h;
+    uint64_t pl[kVec][P];
+#pragma unroll
+    for (int v = 0; v < kVec; v++)
+#pragma unroll
+        for (int p = 0; p < P; p++) pl[v][p] = 0;
+
+    auto add = [&](u64x2 a) {
+        uint64_t c0 = a.x, c1 = a.y;
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            uint64_t t0 = pl[0][p] & c0, t1 = pl[1][p] & c1;
+            pl[0][p] ^= c0; pl[1][p] ^= c1;
+            c0 = t0; c1 = t1;
+        }
+    };
+
+    uint32_t j = 0;
+    if (H > 0) {
+        for (; j + 2 <= u; j += 2) {   // two k-mers = 2H independent row loads in flight per lane
+            u64x2 v[2 * (H > 0 ? H : 1)];
+#pragma unroll
+            for (int s = 0; s < 2 * H; s++) v[s] = load_row_seg(index, qrows[(uint64_t)j * H + s], stride_words, w0);
+            u64x2 a = v[0], b = v[H];
+#pragma unroll
+            for (int s = 1; s < H; s++) { a &= v[s]; b &= v[H + s]; }
+            add(a);
+            add(b);
+        }
+    }
+    for (; j < u; j++) {
+        u64x2 a = load_row_seg(index, qrows[(uint64_t)j * h], stride_words, w0);
+        for (uint32_t s = 1; s < h; s++) a &= load_row_seg(index, qrows[(uint64_t)j * h + s], stride_words, w0);
+        add(a);
+    }
+
+    // expand: column 8b+jj of word w sits at bit 8b+7-jj; 8 consecutive counters per store
+#pragma unroll
+    for (int v = 0; v < kVec; v++) {
+        const uint64_t cbase = ((uint64_t)w0 + v) * 64;
+        if (cbase >= out_stride) break;
+        CountT *o = out + (uint64_t)tm.q * out_stride + cbase;
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            CountT c[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; jj++) {
+                const int bit = 8 * b + 7 - jj;
+                uint32_t x = 0;
+#pragma unroll
+                for (int p = 0; p < P; p++) x |= (uint32_t)((pl[v][p] >> bit) & 1ull) << p;
+                c[jj] = (CountT)x;
+            }
+            if (sizeof(CountT) == 2) {
+                uint4 pk;
+                pk.x = (uint32_t)c[0] | ((uint32_t)c[1] << 16); pk.y = (uint32_t)c[2] | ((uint32_t)c[3] << 16);
+                pk.z = (uint32_t)c[4] | ((uint32_t)c[5] << 16); pk.w = (uint32_t)c[6] | ((uint32_t)c[7] << 16);
+                *reinterpret_cast<uint4 *>(o + 8 * b) = pk;
+            } else {
+                uint4 lo{(uint32_t)c[0], (uint32_t)c[1], (uint32_t)c[2], (uint32_t)c[3]};
+                uint4 hi{(uint32_t)c[4], (uint32_t)c[5], (uint32_t)c[6], (uint32_t)c[7]};
+                *reinterpret_cast<uint4 *>(o + 8 * b) = lo;
+                *reinterpret_cast<uint4 *>(o + 8 * b + 4) = hi;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ K4: threshold + compaction
+// Three passes over result buffers laid out [shard][seq][stride] (n_shards = 1 for a single GPU; > 1 for buffers
+// gathered from column shards): (a) hits per 2048-column chunk, (b) exclusive scan over chunks in
+// (seq, shard, chunk) order, (c) ordered write of (colour, count).  Colours ascend within a sequence
+// (exact_filter's np.where order, graph/bigsi.py:193-204; inexact_filter's dict order before its stable sort, :215-229).
+constexpr uint32_t kChunkCols = 2048;   // counting: kBlock threads x 8 columns per chunk; exact: kBlock words (16384 columns)
+
+__device__ __forceinline__ uint64_t chunk_index(uint32_t q, uint32_t shard, uint32_t chunk, uint32_t n_shards, uint32_t chunks)
+{
+    return ((uint64_t)q * n_shards + shard) * chunks + chunk;
+}
+
+// exact: a hit is a set bit of the AND bitmap; its count is num_unique[q].
+template <bool WRITE>
+__global__ __launch_bounds__(kBlock) void k_hits_exact(
+    const uint64_t *__restrict__ bitmaps, uint64_t stride_words, uint32_t wv, uint32_t n_seqs, uint32_t n_shards, uint32_t chunks,
+    uint64_t shard_cols, const uint32_t *__restrict__ num_unique,
+    uint32_t *__restrict__ chunk_hits, const uint64_t *__restrict__ chunk_off,
+    uint32_t *__restrict__ hit_col, uint32_t *__restrict__ hit_cnt, uint64_t capacity, uint32_t *__restrict__ overflow)
+{
+    __shared__ uint32_t lds[kBlock / 64 + 1];
+    const uint32_t chunk = blockIdx.x % chunks, sq = blockIdx.x / chunks;
+    const uint32_t shard = sq % n_shards, q = sq / n_shards;
+    const uint32_t w = chunk * kBlock + threadIdx.x;   // one 64-column word per thread
+    uint64_t bits = 0;
+    if (w < wv) bits = bitmaps[((uint64_t)shard * n_seqs + q) * stride_words + w];
+    const uint32_t mine = (uint32_t)__popcll(bits);
+    uint32_t tot;
+    const uint32_t pre = block_exclusive_scan(mine, &tot, lds);
+    const uint64_t ci = chunk_index(q, shard, chunk, n_shards, chunks);
+    if (!WRITE) {
+        if (threadIdx.x == 0) chunk_hits[ci] = tot;
+        return;
+    }
+    if (mine == 0) return;
+    uint64_t o = chunk_off[ci] + pre;
+    if (o + mine > capacity) { *overflow = 1; return; }
+    const uint32_t uq = num_unique[q];
+    const uint64_t cbase = (uint64_t)shard * shard_cols + (uint64_t)w * 64;
+    for (uint32_t c = 0; c < 64; c++)
+        if ((bits >> bit_of_col(c)) & 1ull) { hit_col[o] = (uint32_t)(cbase + c); hit_cnt[o] = uq; o++; }
+}
+
+// counting: a hit is a column with count >= min_kmers[q] (graph/bigsi.py:241-242); column < shard_cols only.
+template <typename CountT, bool WRITE>
+__global__ __launch_bounds__(kBlock) void k_hits_count(
+    const CountT *__restrict__ counts, uint64_t stride, uint32_t /*wv: unused, keeps both K4 signatures alike*/,
+    uint32_t n_seqs, uint32_t n_shards, uint32_t chunks,
+    uint64_t shard_cols, const uint32_t *__restrict__ min_kmers,
+    uint32_t *__restrict__ chunk_hits, const uint64_t *__restrict__ chunk_off,
+    uint32_t *__restrict__ hit_col, uint32_t *__restrict__ hit_cnt, uint64_t capacity, uint32_t *__restrict__ overflow)
+{
+    __shared__ uint32_t lds[kBlock / 64 + 1];
+    const uint32_t chunk = blockIdx.x % chunks, sq = blockIdx.x / chunks;
+    const uint32_t shard = sq % n_shards, q = sq / n_shards;
+    const uint64_t c0 = (uint64_t)chunk * kChunkCols + threadIdx.x * 8u;
+    const uint32_t thr = min_kmers[q];
+    uint32_t c[8];
+    uint32_t mine = 0;
+    const CountT *src = counts + ((uint64_t)shard * n_seqs + q) * stride + c0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        c[j] = (c0 + j < shard_cols) ? (uint32_t)src[j] : 0u;
+        if (c0 + j < shard_cols && c[j] >= thr) mine++;
+    }
+    uint32_t tot;
+    const uint32_t pre = block_exclusive_scan(mine, &tot, lds);
+    const uint64_t ci = chunk_index(q, shard, chunk, n_shards, chunks);
+    if (!WRITE) {
+        if (threadIdx.x == 0) chunk_hits[ci] = tot;
+        return;
+    }
+    if (mine == 0) return;
+    uint64_t o = chunk_off[ci] + pre;
+    if (o + mine > capacity) { *overflow = 1; return; }
+    const uint64_t cbase = (uint64_t)shard * shard_cols + c0;
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+        if (c0 + j < shard_cols && c[j] >= thr) { hit_col[o] = (uint32_t)(cbase + j); hit_cnt[o] = c[j]; o++; }
+}
+
+// exclusive scan of chunk_hits (n entries) by one workgroup; also hit_off[q] for every sequence and the total.
+__global__ __launch_bounds__(kBlock) void k_scan_chunks(
+    const uint32_t *__restrict__ chunk_hits, uint64_t n, uint32_t per_seq, uint32_t n_seqs,
+    uint64_t *__restrict__ chunk_off, uint64_t *__restrict__ hit_off)
+{
+    __shared__ uint32_t lds[kBlock / 64 + 1];
+    uint64_t carry = 0;
+    for (uint64_t base = 0; base < n; base += kBlock) {
+        const uint64_t i = base + threadIdx.x;
+        const uint32_t v = i < n ? chunk_hits[i] : 0u;
+        uint32_t tot;
+        const uint32_t pre = block_exclusive_scan(v, &tot, lds);
+        if (i < n) {
+            chunk_off[i] = carry + pre;
+            if (i % per_seq == 0) hit_off[i / per_seq] = carry + pre;
+        }
+        carry += tot;
+    }
+    if (threadIdx.x == 0) hit_off[n_seqs] = carry;
+}
+
+// ------------------------------------------------------------------------------ lookup (API parity)
+// KmerSignatureIndex.lookup for one sequence (graph/index.py:42-49): out[j][w] = AND of the h rows of unique k-mer j.
+__global__ __launch_bounds__(kBlock) void k_lookup(
+    const uint64_t *__restrict__ index, uint64_t stride_words, uint32_t wv, const uint64_t *__restrict__ qrows,
+    uint32_t h, uint32_t u, uint64_t *__restrict__ out)
+{
+    const uint32_t wblocks = (wv + kBlock - 1) / kBlock;
+    const uint32_t j = blockIdx.x / wblocks;
+    const uint32_t w = (blockIdx.x % wblocks) * kBlock + threadIdx.x;
+    if (j >= u || w >= wv) return;
+    uint64_t a = ~0ull;
+    for (uint32_t s = 0; s < h; s++) a &= index[qrows[(uint64_t)j * h + s] * stride_words + w];
+    out[(uint64_t)j * wv + w] = a;
+}
+
+// ------------------------------------------------------------------------------ K5: presence strings
+// graph/bigsi.py:232-237: for hit colour c and every k-mer position i (duplicates included), '1' iff every one of the
+// k-mer's h rows has bit c set.  out[hit][i] ASCII.
+__global__ __launch_bounds__(kBlock) void k_presence(
+    const uint64_t *__restrict__ index, uint64_t stride_words, const uint64_t *__restrict__ qrows,
+    const uint32_t *__restrict__ pos_unique, uint32_t h, uint32_t n, const uint32_t *__restrict__ colours, uint32_t n_colours,
+    uint8_t *__restrict__ out)
+{
+    const uint32_t pblocks = (n + kBlock - 1) / kBlock;
+    const uint32_t hit = blockIdx.x / pblocks;
+    const uint32_t i = (blockIdx.x % pblocks) * kBlock + threadIdx.x;
+    if (i >= n || hit >= n_colours) return;
+    const uint32_t c = colours[hit];
+    const uint64_t w = c >> 6, j = pos_unique[i];
+    uint64_t a = ~0ull;
+    for (uint32_t s = 0; s < h; s++) a &= index[qrows[j * h + s] * stride_words + w];
+    out[(uint64_t)hit * n + i] = ((a >> bit_of_col(c & 63u)) & 1ull) ? '1' : '0';
+}
+
+// ------------------------------------------------------------------------------ storage contract helpers
+// scatter n packed rows (rb bytes each) to rows row_ids[i]; bytes [rb, stride) of the row are zeroed.
+__global__ __launch_bounds__(kBlock) void k_scatter_rows(
+    uint8_t *__restrict__ index, uint64_t stride_bytes, uint64_t m, const uint64_t *__restrict__ row_ids,
+    const uint8_t *__restrict__ packed, uint64_t rb)
+{
+    const uint64_t i = blockIdx.x;   // one workgroup per row
+    const uint64_t row = row_ids[i];
+    if (row >= m) return;
+    uint8_t *dst = index + row * stride_bytes;
+    for (uint64_t b = threadIdx.x; b < stride_bytes; b += kBlock) dst[b] = b < rb ? packed[i * rb + b] : (uint8_t)0;
+}
+
+__global__ __launch_bounds__(kBlock) void k_gather_rows(
+    const uint8_t *__restrict__ index, uint64_t stride_bytes, uint64_t m, const uint64_t *__restrict__ row_ids,
+    uint8_t *__restrict__ packed, uint64_t rb)
+{
+    const uint64_t i = blockIdx.x;   // one workgroup per row
+    const uint64_t row = row_ids[i];
+    if (row >= m) return;
+    const uint8_t *src = index + row * stride_bytes;
+    for (uint64_t b = threadIdx.x; b < rb; b += kBlock) packed[i * rb + b] = b < stride_bytes ? src[b] : (uint8_t)0;
+}
+
+// re-stride rows when the column capacity grows (new stride > old stride); runs back to front is not needed because
+// the destination is a fresh allocation.
+__global__ __launch_bounds__(kBlock) void k_restride(
+    const uint64_t *__restrict__ src, uint64_t src_stride, uint64_t *__restrict__ dst, uint64_t dst_stride, uint64_t m)
+{
+    const uint64_t total = m * dst_stride;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (uint64_t)gridDim.x * kBlock) {
+        const uint64_t r = i / dst_stride, w = i - r * dst_stride;
+        dst[i] = w < src_stride ? src[r * src_stride + w] : 0ull;
+    }
+}
+
+// BitMatrix.insert_column / get_column (bigsi/matrix/bitmatrix.py:50-75): bloom bit r <-> bit `col` of row r.
+__global__ __launch_bounds__(kBlock) void k_insert_column(
+    uint64_t *__restrict__ index, uint64_t stride_words, uint64_t m, uint64_t col, const uint8_t *__restrict__ bloom)
+{
+    const uint64_t w = col >> 6, bit = bit_of_col((uint32_t)(col & 63u));
+    for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < m; r += (uint64_t)gridDim.x * kBlock) {
+        const uint64_t on = (bloom[r >> 3] >> (7 - (r & 7))) & 1u;
+        uint64_t *p = index + r * stride_words + w;
+        *p = (*p & ~(1ull << bit)) | (on << bit);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_get_column(
+    const uint64_t *__restrict__ index, uint64_t stride_words, uint64_t m, uint64_t col, uint8_t *__restrict__ bloom)
+{
+    // one thread per output byte = 8 rows
+    const uint64_t w = col >> 6, bit = bit_of_col((uint32_t)(col & 63u));
+    const uint64_t nb = (m + 7) / 8;
+    for (uint64_t b = (uint64_t)blockIdx.x * kBlock + threadIdx.x; b < nb; b += (uint64_t)gridDim.x * kBlock) {
+        uint32_t v = 0;
+        for (uint32_t j = 0; j < 8; j++) {
+            const uint64_t r = b * 8 + j;
+            if (r < m && ((index[r * stride_words + w] >> bit) & 1ull)) v |= 0x80u >> j;
+        }
+        bloom[b] = (uint8_t)v;
+    }
+}
+
+// Bloom-add k-mers to one sample column of the transposed matrix (bloom/bloomfilter.py:25-32 + graph/bigsi.py:151).
+__global__ __launch_bounds__(kBlock) void k_insert_kmers(
+    uint64_t *__restrict__ index, uint64_t stride_words, uint64_t m, uint32_t h, uint64_t col,
+    const char *__restrict__ seqs, const uint64_t *__restrict__ seq_off, uint32_t k)
+{
+    const uint32_t q = blockIdx.x;
+    const char *s = seqs + seq_off[q];
+    const uint64_t len = seq_off[q + 1] - seq_off[q];
+    const uint64_t n = len >= k ? len - k + 1 : 0;
+    const uint64_t w = col >> 6, bitmask = 1ull << bit_of_col((uint32_t)(col & 63u));
+    for (uint64_t i = threadIdx.x; i < n; i += kBlock) {
+        KmerView v{s + i, k, use_revcomp(s + i, k)};
+        for (uint32_t sd = 0; sd < h; sd++)
+            atomicOr((unsigned long long *)(index + row_of_hash(murmur3_32(v, sd), m) * stride_words + w), (unsigned long long)bitmask);
+    }
+}
+
+// BIGSI.bloom (graph/bigsi.py:150-155): u k-mers (k bytes each, packed) -> m-bit filter in the row byte format.
+__global__ __launch_bounds__(kBlock) void k_bloom(
+    uint32_t *__restrict__ bloom_words, uint64_t m, uint32_t h, const char *__restrict__ kmers, uint64_t u, uint32_t k, bool raw)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < u; i += (uint64_t)gridDim.x * kBlock) {
+        const char *km = kmers + i * k;
+        KmerView v{km, k, raw ? false : use_revcomp(km, k)};
+        for (uint32_t sd = 0; sd < h; sd++) {
+            const uint64_t r = row_of_hash(murmur3_32(v, sd), m);
+            // byte r/8, mask 0x80 >> (r%8), addressed through little-endian 32-bit words
+            atomicOr(&bloom_words[r >> 5], 1u << (8u * (uint32_t)((r >> 3) & 3u) + 7u - (uint32_t)(r & 7u)));
+        }
+    }
+}
+
+// synthetic contents: must match oracle/bigsi_oracle.c: orc_synth_word / orc_valid_mask bit for bit.
+__global__ __launch_bounds__(kBlock) void k_fill_synth(
+    uint64_t *__restrict__ index, uint64_t m, uint64_t stride_words, uint64_t n_cols, uint64_t seed, uint64_t shard, uint32_t draws)
+{
+    const uint64_t base = mix64(seed + shard * 0x632BE59BD9B4E019ull);
+    const uint64_t pairs_per_row = stride_words / 2, total = m * pairs_per_row;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (uint64_t)gridDim.x * kBlock) {
+        const uint64_t r = i / pairs_per_row, w = (i - r * pairs_per_row) * 2;
+        const uint64_t rk = mix64(base ^ (r * 0x9E3779B97F4A7C15ull));
+        u64x2 v = {~0ull, ~0ull};
+        for (uint32_t d = 0; d < draws; d++) {
+            v.x &= mix64(rk + (w * 8 + d) * 0xD1B54A32D192ED03ull);
+            v.y &= mix64(rk + ((w + 1) * 8 + d) * 0xD1B54A32D192ED03ull);
+        }
+        v.x &= valid_mask(w, n_cols);
+        v.y &= valid_mask(w + 1, n_cols);
+        *reinterpret_cast<u64x2 *>(index + r * stride_words + w) = v;
+    }
+}
+
+}   // namespace bigsi

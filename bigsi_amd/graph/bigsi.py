@@ -1,0 +1,182 @@
+"""`BIGSI`: the reference's index object (bigsi/graph/bigsi.py:129-275) over the hip-hbm backend.
+
+`search()` / `lookup()` keep the reference's signatures, return shapes, ordering, rounding and error behaviour, but
+the work between the query string and the hit list -- k-merise, dedupe, canonicalise, MurmurHash3, row fetch, AND,
+per-sample counts, threshold, compaction -- is ONE device batch (include/bigsi_hip.h: bigsi_hip_batch_run).  The host
+only assembles result dicts (names, percentages, optional score)."""
+import json
+import logging
+import math
+
+import numpy as np
+
+from ..bitrow import BitRow
+from ..bloom import _device_bloom
+from ..scoring import Scorer
+from ..storage import get_storage
+from ..utils import seq_to_kmers
+from .index import KmerSignatureIndex
+from .metadata import DELETION_SPECIAL_SAMPLE_NAME, SampleMetadata
+
+logger = logging.getLogger(__name__)
+
+DEFAULT_NPROC = 4
+MIN_UNIQUE_KMERS_IN_QUERY = 0
+DEFAULT_CONFIG = {"storage-engine": "hip-hbm", "storage-config": {"name": "default"}, "k": 31, "m": 25 * 10 ** 6, "h": 3}
+
+
+def validate_build_params(bloomfilters, samples):
+    if len(bloomfilters) != len(samples):
+        raise ValueError("There must be the same number of bloomfilters and sample names")
+
+
+class BigsiQueryResult(object):
+    """One hit; `todict()` key order is part of the contract (tests/graph/test_end_to_end.py:114-124)."""
+
+    def __init__(self, colour, sample_name, num_kmers_found, num_kmers):
+        self.colour = colour
+        self.sample_name = sample_name
+        self.num_kmers_found = num_kmers_found
+        self.num_kmers = num_kmers
+        self.percent_kmers_found = round(100 * float(num_kmers_found) / num_kmers, 2)
+        self.score = None
+
+    def todict(self):
+        out = {"percent_kmers_found": self.percent_kmers_found, "num_kmers": self.num_kmers,
+               "num_kmers_found": self.num_kmers_found, "sample_name": self.sample_name}
+        if self.score:
+            out.update(self.score)
+        return out
+
+    def tojson(self):
+        return json.dumps(self.todict())
+
+    __repr__ = tojson
+
+    def __eq__(self, other):
+        return self.todict() == other.todict()
+
+    def add_score(self, score):
+        self.score = score
+
+
+class BIGSI(SampleMetadata, KmerSignatureIndex):
+    def __init__(self, config=None):
+        self.config = DEFAULT_CONFIG if config is None else config
+        self.storage = get_storage(self.config)
+        SampleMetadata.__init__(self, self.storage)
+        KmerSignatureIndex.__init__(self, self.storage)
+        self.min_unique_kmers_in_query = MIN_UNIQUE_KMERS_IN_QUERY
+        self.scorer = Scorer(self.num_samples)
+
+    @property
+    def kmer_size(self):
+        return self.config["k"]
+
+    @property
+    def nproc(self):
+        return self.config.get("nproc", DEFAULT_NPROC)
+
+    # ------------------------------------------------------------------ construction
+    @classmethod
+    def bloom(cls, config, kmers):
+        """Bloom filter (m bits) of the canonical forms of `kmers`, built on the device."""
+        device = (config.get("storage-config") or {}).get("device", 0)
+        raw = _device_bloom(list(kmers), config["m"], config["h"], raw=False, device=device)
+        return BitRow.frombytes(raw.tobytes(), int(config["m"]))
+
+    @classmethod
+    def build(cls, config, bloomfilters, samples):
+        storage = get_storage(config)
+        validate_build_params(bloomfilters, samples)
+        SampleMetadata(storage).add_samples(samples)
+        KmerSignatureIndex.create(storage, bloomfilters, config["m"], config["h"], config.get("low_mem_build", False))
+        storage.close()
+        return cls(config)
+
+    def insert(self, bloomfilter, sample):
+        logger.warning("Build and merge is preferable to insert in most cases")
+        colour = self.add_sample(sample)
+        self.insert_bloom(bloomfilter, colour - 1)
+
+    def delete(self):
+        self.storage.delete_all()
+
+    def merge(self, bigsi):
+        assert self.bloomfilter_size == bigsi.bloomfilter_size
+        assert self.num_hashes == bigsi.num_hashes
+        assert self.kmer_size == bigsi.kmer_size
+        self.merge_indexes(bigsi)
+        self.merge_metadata(bigsi)
+
+    # ------------------------------------------------------------------ queries
+    def seq_to_kmers(self, seq):
+        return seq_to_kmers(seq, self.kmer_size)
+
+    def search(self, seq, threshold=1.0, score=False):
+        if len(seq) - self.kmer_size + 1 <= self.min_unique_kmers_in_query:
+            logger.warning("Query string should contain at least %i unique kmers. Your query contained %i unique kmers, "
+                           "and as a result the false discovery rate may be high. In future this will become an error."
+                           % (self.min_unique_kmers_in_query, max(len(seq) - self.kmer_size + 1, 0)))
+        assert threshold <= 1
+        return self.search_batch([seq], threshold, score)[0]
+
+    def search_batch(self, seqs, threshold=1.0, score=False):
+        """search() for many sequences in one device batch; a list of result lists in input order."""
+        assert threshold <= 1
+        seqs = list(seqs)
+        if not seqs:
+            return []
+        batch = self.storage.new_batch(seqs, self.kmer_size)
+        try:
+            batch.run(threshold)
+            num_kmers, num_unique, _ = batch.unique()
+            off, colours, counts = batch.hits()
+            exact = threshold == 1.0
+            out = []
+            for i in range(len(seqs)):
+                u, n = int(num_unique[i]), int(num_kmers[i])
+                if u == 0:
+                    # the reference fails on a query without k-mers: reduce() over nothing on the exact branch
+                    # (utils/fncts.py:24-25), an unbound accumulator on the other (graph/bigsi.py:35-44)
+                    if exact:
+                        raise TypeError("reduce() of empty sequence with no initial value")
+                    raise UnboundLocalError("local variable 'cumsum' referenced before assignment")
+                lo, hi = int(off[i]), int(off[i + 1])
+                out.append(self._assemble(batch, i, colours[lo:hi], counts[lo:hi], u, n, exact, score))
+            return out
+        finally:
+            batch.close()
+
+    def _assemble(self, batch, i, colours, counts, u, n, exact, score):
+        if exact:
+            # exact_filter (graph/bigsi.py:192-205): every set bit, ascending; a colour without a name is a KeyError
+            results = [BigsiQueryResult(int(c), self.colour_to_sample(int(c)), u, u) for c in colours]
+        else:
+            # inexact_filter (:211-230): only colours < num_samples are zipped in; stable sort by count, descending
+            keep = colours < self.num_samples
+            colours, counts = colours[keep], counts[keep]
+            order = np.argsort(-counts.astype(np.int64), kind="stable")
+            results = [BigsiQueryResult(int(colours[j]), self.colour_to_sample(int(colours[j])), int(counts[j]), u) for j in order]
+        if score and results:
+            if n == 1:   # the reference builds a 1-D matrix from a single row and then indexes it with two subscripts
+                raise IndexError("too many indices for array: array is 1-dimensional, but 2 were indexed")
+            cols = batch.presence(i, np.array([r.colour for r in results], dtype=np.uint32), n)
+            for r, col in zip(results, cols):
+                sd = self.scorer.score(col)
+                sd["kmer-presence"] = col
+                r.add_score(sd)
+        return [r.todict() for r in results if r.sample_name != DELETION_SPECIAL_SAMPLE_NAME]
+
+    # kept for callers that use the reference's helper names
+    def exact_filter(self, kmers_to_colours):
+        rows = list(kmers_to_colours.values())
+        acc = rows[0]
+        for r in rows[1:]:
+            acc = acc & r
+        colours = [i for i, b in enumerate(acc) if b]
+        return [BigsiQueryResult(c, self.colour_to_sample(c), len(kmers_to_colours), len(kmers_to_colours)) for c in colours]
+
+    def get_sample_list(self, colours):
+        names = self.colours_to_samples(colours)
+        return [names[c] for c in colours]

@@ -1,0 +1,124 @@
+"""BLAST-like score of a k-mer presence string (bigsi/scoring/score.py:7-151), computed on the host.
+
+Input is the '0'/'1' string the device produces per hit (k_presence); output is the reference's 17-key dict, in
+the reference's key order, with the reference's rounding behaviour:
+  * Python `round()` on Python floats for the score fields (score.py:81-88),
+  * numpy's `round` on numpy scalars for log_evalue / log_pvalue (score.py:134-151 call round() on np.float64),
+  * unrounded `np.exp` values for evalue / pvalue (score.py:125-132).
+Constants: k is hard-coded to 31 (score.py:61,99) and only the ungapped lambda/K are used.
+"""
+import math
+
+import numpy as np
+
+LAMBDA_UNGAPPED = 1.330
+K_UNGAPPED = 0.621
+MATCH, MISMATCH = 1, 2
+_K = 31
+_KMER_ADJUST = 3
+
+
+def _bits(s):
+    a = np.frombuffer(s.encode("ascii"), dtype=np.uint8) - ord("0")
+    if a.size and a.max() > 1:
+        raise ValueError("presence string must consist of '0' and '1'")
+    return a
+
+
+def remove_short_ones(s):
+    """Keep a 1 only where it starts a run of three (the string is virtually padded with 1s on the right)."""
+    a = _bits(s)
+    if a.size < 3:
+        return s
+    p = np.concatenate([a, np.ones(2, np.uint8)])
+    out = p[:-2] & p[1:-1] & p[2:]
+    return (out + ord("0")).astype(np.uint8).tobytes().decode("ascii")
+
+
+def run_lengths(a):
+    """(symbols, lengths) of the maximal runs of a 0/1 array."""
+    if a.size == 0:
+        return np.zeros(0, np.uint8), np.zeros(0, np.int64)
+    edges = np.flatnonzero(np.diff(a)) + 1
+    starts = np.concatenate([[0], edges])
+    ends = np.concatenate([edges, [a.size]])
+    return a[starts], (ends - starts).astype(np.int64)
+
+
+def tabulate_score(ss):
+    """{'0': [...], '1': [...]} run tallies; every run except the last is recorded one longer than it is --
+    the reference's counter is bumped before each comparison (score.py:19-32) and its known-answer test pins it."""
+    sym, ln = run_lengths(_bits(ss))
+    out = {"0": [], "1": []}
+    for i in range(sym.size):
+        out["1" if sym[i] else "0"].append(int(ln[i]) + (0 if i == sym.size - 1 else 1))
+    return out
+
+
+class Scorer(object):
+    def __init__(self, DB_SIZE, MATCH=MATCH, MISMATCH=MISMATCH, LAMBDA_UNGAPPED=LAMBDA_UNGAPPED, K_UNGAPPED=K_UNGAPPED,
+                 LAMBDA_GAPPED=1.28, K_GAPPED=0.46):
+        self.DB_SIZE = DB_SIZE
+        self.MATCH, self.MISMATCH = MATCH, MISMATCH
+        self.LAMBDA_UNGAPPED, self.K_UNGAPPED = LAMBDA_UNGAPPED, K_UNGAPPED
+        self.LAMBDA_GAPPED, self.K_GAPPED = LAMBDA_GAPPED, K_GAPPED
+        self.kmer_adjust = _KMER_ADJUST
+
+    def calculate_score(self, score_counter, convert):
+        best = worst = mid = self.MATCH * sum(score_counter["1"])
+        snp_span = _K + self.kmer_adjust
+        most = least = 0
+        for gap in score_counter["0"]:
+            lo = float(gap) / snp_span              # fewest SNPs that explain a gap of this many k-mers
+            hi = max((gap - snp_span) + 1, lo)      # most
+            most += hi
+            least += lo
+            typical = lo + 0.05 * hi
+            # each update rounds to 2 decimals, as the reference does inside its loop
+            best = round(best - self.MISMATCH * lo + self.MATCH * (gap - self.MISMATCH * lo), 2)
+            worst = round(worst - self.MISMATCH * hi + self.MATCH * (gap - self.MISMATCH * hi), 2)
+            mid = round(mid - self.MISMATCH * typical + self.MATCH * (gap - self.MISMATCH * typical), 2)
+        return {
+            "score": round(mid * convert, 2),
+            "min_score": round(worst * convert, 2),
+            "max_score": round(best * convert, 2),
+            "max_mismatches": math.ceil(most),
+            "min_mismatches": math.floor(least),
+            "mismatches": math.ceil(math.ceil(least) + (0.05 * math.floor(most))),
+        }
+
+    def score(self, s):
+        ss = remove_short_ones(s)
+        n = len(ss)
+        seq_len = n + _K - 1
+        d = self.calculate_score(tabulate_score(ss), seq_len / n)
+        d["max_nident"] = seq_len - d["min_mismatches"]
+        d["nident"] = seq_len - d["mismatches"]
+        d["min_nident"] = seq_len - d["max_mismatches"]
+        for key in ("pident", "max_pident", "min_pident"):
+            d[key] = 100 * float(d[key.replace("pident", "nident")]) / seq_len
+        d["length"] = seq_len
+        d["evalue"] = self.evalue(d["score"], seq_len)
+        d["pvalue"] = self.pvalue(d["evalue"])
+        d["log_evalue"] = round(self.log_evalue(d["score"], seq_len), 2)
+        d["log_pvalue"] = round(self.log_pvalue(d["log_evalue"]), 2)
+        return d
+
+    def bitscore(self, s):
+        return (self.LAMBDA_UNGAPPED * self.score(s)["score"] - np.log(self.K_UNGAPPED)) / np.log(2)
+
+    def evalue(self, score, n):
+        return self.K_UNGAPPED * self.DB_SIZE * n * np.exp(-self.LAMBDA_UNGAPPED * score)
+
+    def pvalue(self, evalue):
+        return 1 - np.exp(-evalue)
+
+    def log_evalue(self, score, n):
+        m = self.DB_SIZE if self.DB_SIZE != 0 else 1
+        return round(np.log10(self.K_UNGAPPED * m * n) - self.LAMBDA_UNGAPPED * score, 2)
+
+    def log_pvalue(self, log_evalue):
+        p = 1 - np.exp(-(10 ** log_evalue))
+        if p > 0:
+            return round(np.log10(p), 2)
+        return round(log_evalue, 2)      # p underflowed to 0: the reference falls back to log_evalue

@@ -1,0 +1,423 @@
+"""`hip-hbm`: a BIGSI storage backend whose bit matrix lives in MI355X HBM.
+
+Sits beside berkeleydb / rocksdb / redis behind the reference's storage registry
+(bigsi/storage/__init__.py:3-19).  "<row>:bitarray" records go to / come from the device matrix through
+libbigsi_hip.so (include/bigsi_hip.h); every other record (the four index integers, sample metadata) stays in a
+host dict, as they are a few bytes each.  Besides the plain contract the backend advertises `fused = True`:
+`BIGSI.search()` / `lookup()` then hand whole queries to the device (`search_batch`, `lookup_kmers`) instead of
+fetching rows one key at a time.
+
+storage-config keys
+    name         identity of the resident index; like a BerkeleyDB filename or a Redis server, the data
+                 outlives any one storage object (BIGSI.build closes and re-opens its storage,
+                 bigsi/graph/bigsi.py:171-172).  default "default"
+    device       HIP device ordinal.  default 0
+    m, h         rows / hashes, if known before the first row arrives (get_storage() copies them from the
+                 top-level config); otherwise rows are buffered until `number_of_rows` is stored
+    max_cols     initial column capacity (grown on demand by re-striding on the device).  default 1024
+    filename     optional snapshot file written by sync() and loaded when the index is not resident
+"""
+import json
+import os
+import re
+import struct
+
+import numpy as np
+
+from .. import _lib
+from .._lib import BigsiHipError, check
+from .contract import BaseStorage
+
+_ROW_KEY = re.compile(rb"^(\d+):bitarray$")
+_RESIDENT = {}        # name -> _Resident (process-wide, survives storage objects)
+_MAGIC = b"BIGSIHBM1\n"
+
+
+class _Resident(object):
+    """The device index plus the host-side records of one named store."""
+
+    def __init__(self, cfg):
+        self.cfg = dict(cfg)
+        self.device = int(cfg.get("device", 0))
+        self.kv = {}                 # bytes -> bytes, everything that is not a row
+        self.ix = None               # bigsi_hip_index*
+        self.m = None
+        self.pending = {}            # row -> bytes, only while m is unknown
+        self.written = None          # np.bool_[m]: rows that have been stored (KeyError semantics of a KV store)
+
+    # ---- device lifecycle
+    def _hint(self, key):
+        v = self.cfg.get(key)
+        return int(v) if v is not None else None
+
+    def open(self, m, n_cols=0, cap=None):
+        assert self.ix is None
+        h = self._hint("h") or 1
+        if b"ksi:num_hashes:int" in self.kv:
+            h = int(self.kv[b"ksi:num_hashes:int"])
+        cap = max(int(cap or 0), n_cols, self._hint("max_cols") or 1024)
+        out = _lib.C.c_void_p()
+        check(_lib.lib().bigsi_hip_open(int(m), int(n_cols), cap, h, self.device, _lib.C.byref(out)))
+        self.ix, self.m = out, int(m)
+        self.written = np.zeros(self.m, dtype=bool)
+
+    def ensure_open(self):
+        if self.ix is None:
+            m = self._hint("m")
+            if b"number_of_rows:int" in self.kv:
+                m = int(self.kv[b"number_of_rows:int"])
+            if m is None:
+                return False
+            n = int(self.kv.get(b"number_of_cols:int", b"0"))
+            self.open(m, n)
+        return True
+
+    def info(self):
+        inf = _lib.Info()
+        check(_lib.lib().bigsi_hip_get_info(self.ix, _lib.C.byref(inf)))
+        return inf
+
+    def free(self):
+        if self.ix is not None:
+            check(_lib.lib().bigsi_hip_close(self.ix))
+        self.ix, self.m, self.written = None, None, None
+        self.kv, self.pending = {}, {}
+
+    # ---- rows
+    def put_rows(self, row_ids, blobs):
+        """row_ids: sequence of ints; blobs: list of bytes (all of one length) or uint8[n, rb]."""
+        if not len(row_ids):
+            return
+        if not self.ensure_open():
+            for r, b in zip(row_ids, blobs):
+                self.pending[int(r)] = bytes(b)
+            return
+        if isinstance(blobs, np.ndarray):
+            packed = np.ascontiguousarray(blobs, dtype=np.uint8)
+            rb = packed.shape[1]
+        else:
+            lens = {len(b) for b in blobs}
+            if len(lens) != 1:        # ragged: one call per length class
+                for L in lens:
+                    sel = [i for i, b in enumerate(blobs) if len(b) == L]
+                    self.put_rows([row_ids[i] for i in sel], [blobs[i] for i in sel])
+                return
+            rb = lens.pop()
+            if rb == 0:               # an empty bitarray: the row exists and is all zero
+                packed, rb = np.zeros((len(blobs), 1), np.uint8), 1
+            else:
+                packed = np.frombuffer(b"".join(blobs), dtype=np.uint8).reshape(len(blobs), rb)
+        ids = np.ascontiguousarray(row_ids, dtype=np.uint64)
+        if ids.size and int(ids.max()) >= self.m:
+            raise KeyError("row %d outside [0, %d)" % (int(ids.max()), self.m))
+        if rb * 8 > self.info().col_capacity:
+            check(_lib.lib().bigsi_hip_reserve_cols(self.ix, rb * 8))
+        check(_lib.lib().bigsi_hip_set_rows(self.ix, _lib.ptr(ids), ids.size, _lib.ptr(packed), rb))
+        self.written[ids.astype(np.int64)] = True
+
+    def get_rows(self, row_ids, rb=None):
+        """uint8[n, rb]; rb defaults to ceil(num_cols/8).  KeyError for rows never stored."""
+        if not self.ensure_open():
+            try:
+                return [self.pending[int(r)] for r in row_ids]
+            except KeyError as e:
+                raise KeyError("%s:bitarray" % e.args[0])
+        ids = np.ascontiguousarray(row_ids, dtype=np.uint64)
+        bad = [int(r) for r in ids if int(r) >= self.m or not self.written[int(r)]]
+        if bad:
+            raise KeyError("%d:bitarray" % bad[0])
+        if rb is None:
+            rb = max(int(self.info().row_bytes), 1)
+        out = np.zeros((ids.size, rb), dtype=np.uint8)
+        if ids.size:
+            check(_lib.lib().bigsi_hip_get_rows(self.ix, _lib.ptr(ids), ids.size, _lib.ptr(out), rb))
+        return out
+
+    def flush_pending(self):
+        if self.pending and self.ensure_open():
+            items = sorted(self.pending.items())
+            self.pending = {}
+            self.put_rows([r for r, _ in items], [b for _, b in items])
+
+    # ---- the integers the device needs to hear about
+    def on_put(self, key, value):
+        if key == b"number_of_rows:int":
+            m = int(value)
+            if self.ix is not None and m != self.m:
+                raise BigsiHipError(_lib.ERR_INVALID, "number_of_rows %d differs from the resident index (%d rows)" % (m, self.m))
+            self.kv[key] = value
+            self.flush_pending()
+            return
+        self.kv[key] = value
+        if key == b"number_of_cols:int" and self.ensure_open():
+            n = int(value)
+            if n > self.info().col_capacity:
+                check(_lib.lib().bigsi_hip_reserve_cols(self.ix, n))
+            check(_lib.lib().bigsi_hip_set_num_cols(self.ix, n))
+        elif key == b"ksi:num_hashes:int" and self.ix is not None:
+            check(_lib.lib().bigsi_hip_set_num_hashes(self.ix, int(value)))
+
+
+class HipHbmStorage(BaseStorage):
+    fused = True      # BIGSI.search/lookup may call search_batch / lookup_kmers
+
+    def __init__(self, storage_config=None):
+        self.storage_config = dict(storage_config or {})
+        self.name = self.storage_config.get("name", "default")
+        _lib.lib()    # fail loudly, here, if the HIP library has not been built
+        res = _RESIDENT.get(self.name)
+        if res is None:
+            res = _RESIDENT[self.name] = _Resident(self.storage_config)
+            fn = self.storage_config.get("filename")
+            if fn and os.path.exists(fn):
+                _load_snapshot(res, fn)
+        self.res = res
+        self.storage = self       # reference convention: backend.storage[key] (base.py:13-21); routed below
+
+    def __repr__(self):
+        return "hip-hbm Storage"
+
+    # ---- raw primitives: rows to the device, the rest to the host dict
+    def _get_raw(self, key):
+        m = _ROW_KEY.match(key)
+        if m:
+            rows = self.res.get_rows([int(m.group(1))])
+            return bytes(rows[0]) if not isinstance(rows, list) else rows[0]
+        return self.res.kv[key]
+
+    def _put_raw(self, key, value):
+        m = _ROW_KEY.match(key)
+        if m:
+            self.res.put_rows([int(m.group(1))], [bytes(value)])
+        else:
+            self.res.on_put(key, bytes(value))
+
+    def _get_many_raw(self, keys):
+        keys = list(keys)
+        ms = [_ROW_KEY.match(k) for k in keys]
+        if keys and all(ms):
+            rows = self.res.get_rows([int(m.group(1)) for m in ms])
+            return [bytes(r) for r in rows]
+        return [self._get_raw(k) for k in keys]
+
+    def _put_many_raw(self, keys, values):
+        keys, values = list(keys), list(values)
+        ms = [_ROW_KEY.match(k) for k in keys]
+        if keys and all(ms):
+            self.res.put_rows([int(m.group(1)) for m in ms], [bytes(v) for v in values])
+        else:
+            for k, v in zip(keys, values):
+                self._put_raw(k, v)
+
+    # allow backend.storage[key] for code written against the reference's convention
+    def __contains__(self, key):
+        try:
+            self._get_raw(self.convert_key_to_bytes(key))
+            return True
+        except KeyError:
+            return False
+
+    def delete_all(self):
+        self.res.free()
+
+    def sync(self):
+        fn = self.storage_config.get("filename")
+        if fn:
+            _save_snapshot(self.res, fn)
+        if self.res.ix is not None:
+            check(_lib.lib().bigsi_hip_synchronize(self.res.ix))
+
+    def close(self):
+        self.res = None      # the resident index stays (see module docstring)
+
+    # ---- bulk / device-side construction (beyond the plain contract)
+    def set_rows_packed(self, row0, packed):
+        """rows row0 .. row0+n-1 from a uint8[n, rb] array in one call."""
+        self.res.put_rows(np.arange(row0, row0 + packed.shape[0], dtype=np.uint64), packed)
+
+    def get_rows_packed(self, row_ids, rb=None):
+        return self.res.get_rows(row_ids, rb)
+
+    def insert_column(self, col, bloom_bytes):
+        """BitMatrix.insert_column on the device (bigsi/matrix/bitmatrix.py:67-75)."""
+        res = self.res
+        if not res.ensure_open():
+            raise KeyError("number_of_rows:int")
+        if col >= res.info().col_capacity:
+            check(_lib.lib().bigsi_hip_reserve_cols(res.ix, max(col + 1, 2 * int(res.info().col_capacity))))
+        buf = np.frombuffer(bytes(bloom_bytes), dtype=np.uint8)
+        need = (res.m + 7) // 8
+        if buf.size < need:
+            buf = np.concatenate([buf, np.zeros(need - buf.size, np.uint8)])
+        check(_lib.lib().bigsi_hip_insert_column(res.ix, int(col), _lib.ptr(np.ascontiguousarray(buf))))
+        res.written[:] = True
+        res.kv[b"number_of_cols:int"] = str(int(res.info().num_cols)).encode()
+
+    def get_column(self, col):
+        res = self.res
+        out = np.zeros((res.m + 7) // 8, dtype=np.uint8)
+        check(_lib.lib().bigsi_hip_get_column(res.ix, int(col), _lib.ptr(out)))
+        return out.tobytes()
+
+    def fill_synthetic(self, seed, shard=0, and_draws=2):
+        check(_lib.lib().bigsi_hip_fill_synthetic(self.res.ix, int(seed), int(shard), int(and_draws)))
+        self.res.written[:] = True
+
+    def insert_kmers(self, col, seqs, k):
+        blob, off = _lib.pack_seqs(seqs)
+        check(_lib.lib().bigsi_hip_insert_kmers(self.res.ix, int(col), blob, _lib.ptr(off), len(seqs), int(k)))
+
+    # ---- fused query path
+    @property
+    def handle(self):
+        if not self.res.ensure_open():
+            raise KeyError("number_of_rows:int")
+        return self.res.ix
+
+    def lookup_kmers(self, kmers):
+        """{kmer: row bytes} for a list of distinct k-mer strings (graph/index.py:42-49); any lengths."""
+        out = {}
+        rb = max(int(self.res.info().row_bytes), 1) if self.res.ensure_open() else 1
+        by_len = {}
+        for km in kmers:
+            by_len.setdefault(len(km), []).append(km)
+        for k, group in by_len.items():
+            if k == 0:
+                raise ValueError("cannot look up an empty k-mer")
+            blob, _ = _lib.pack_seqs(group)
+            rows = np.zeros((len(group), rb), dtype=np.uint8)
+            check(_lib.lib().bigsi_hip_lookup(self.handle, blob, k, len(group), _lib.ptr(rows)))
+            for km, r in zip(group, rows):
+                out[km] = r.tobytes()
+        return out
+
+    def new_batch(self, seqs, k):
+        return QueryBatch(self, seqs, k)
+
+
+class QueryBatch(object):
+    """A batch of query sequences staged on the device (bigsi_hip_batch)."""
+
+    def __init__(self, storage, seqs, k):
+        self.storage = storage
+        self.n = len(seqs)
+        blob, off = _lib.pack_seqs(seqs)
+        self._off = off
+        out = _lib.C.c_void_p()
+        check(_lib.lib().bigsi_hip_batch_create(storage.handle, blob, _lib.ptr(off), self.n, int(k), _lib.C.byref(out)))
+        self.b = out
+        self.k = int(k)
+
+    def close(self):
+        if self.b is not None:
+            check(_lib.lib().bigsi_hip_batch_destroy(self.b))
+            self.b = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def run(self, threshold, force_counts=False):
+        check(_lib.lib().bigsi_hip_batch_run(self.b, float(threshold), _lib.RUN_FORCE_COUNTS if force_counts else 0))
+
+    def info(self):
+        inf = _lib.BatchInfo()
+        check(_lib.lib().bigsi_hip_batch_get_info(self.b, _lib.C.byref(inf)))
+        return inf
+
+    def unique(self):
+        nk = np.zeros(self.n, np.uint32)
+        nu = np.zeros(self.n, np.uint32)
+        mk = np.zeros(self.n, np.uint32)
+        check(_lib.lib().bigsi_hip_batch_fetch_unique(self.b, _lib.ptr(nk), _lib.ptr(nu), _lib.ptr(mk)))
+        return nk, nu, mk
+
+    def hits(self):
+        """(offsets uint64[n+1], colours uint32[], counts uint32[]), ascending colour inside each sequence."""
+        off = np.zeros(self.n + 1, np.uint64)
+        cap = 1 << 12
+        while True:
+            col = np.zeros(cap, np.uint32)
+            cnt = np.zeros(cap, np.uint32)
+            rc = _lib.lib().bigsi_hip_batch_fetch_hits(self.b, _lib.ptr(off), _lib.ptr(col), _lib.ptr(cnt), cap)
+            if rc == _lib.ERR_CAPACITY:
+                cap = int(off[-1])
+                continue
+            check(rc)
+            total = int(off[-1])
+            return off, col[:total], cnt[:total]
+
+    def counts(self, i):
+        out = np.zeros(int(self.storage.res.info().num_cols), np.uint32)
+        check(_lib.lib().bigsi_hip_batch_fetch_counts(self.b, i, _lib.ptr(out)))
+        return out
+
+    def bitmap(self, i):
+        out = np.zeros(max(int(self.storage.res.info().row_bytes), 1), np.uint8)
+        check(_lib.lib().bigsi_hip_batch_fetch_bitmap(self.b, i, _lib.ptr(out)))
+        return out
+
+    def rows(self, i, num_unique):
+        h = int(self.storage.res.info().num_hashes)
+        out = np.zeros((max(int(num_unique), 1), h), np.uint64)
+        check(_lib.lib().bigsi_hip_batch_fetch_rows(self.b, i, _lib.ptr(out), out.size))
+        return out[:int(num_unique)]
+
+    def lookup(self, i, num_unique):
+        rb = max(int(self.storage.res.info().row_bytes), 1)
+        first = np.zeros(max(int(num_unique), 1), np.uint32)
+        rows = np.zeros((max(int(num_unique), 1), rb), np.uint8)
+        check(_lib.lib().bigsi_hip_batch_lookup(self.b, i, _lib.ptr(first), _lib.ptr(rows), rows.shape[0]))
+        return first[:int(num_unique)], rows[:int(num_unique)]
+
+    def presence(self, i, colours, num_kmers):
+        """['0101..', ...]: one presence string (length num_kmers) per colour (graph/bigsi.py:232-237)."""
+        colours = np.ascontiguousarray(colours, dtype=np.uint32)
+        if colours.size == 0 or num_kmers == 0:
+            return ["" for _ in colours]
+        out = np.zeros((colours.size, int(num_kmers)), np.uint8)
+        check(_lib.lib().bigsi_hip_batch_presence(self.b, i, _lib.ptr(colours), colours.size, _lib.ptr(out)))
+        return [r.tobytes().decode("ascii") for r in out]
+
+
+# ------------------------------------------------------------------------------- snapshots (sync / reopen)
+def _save_snapshot(res, fn):
+    header = {"kv": {k.decode("latin-1"): v.decode("latin-1") for k, v in res.kv.items()},
+              "m": res.m, "rb": 0}
+    tmp = fn + ".tmp"
+    with open(tmp, "wb") as f:
+        if res.ix is not None:
+            header["rb"] = max(int(res.info().row_bytes), 1)
+            header["written"] = np.packbits(res.written).tobytes().hex()
+        hb = json.dumps(header).encode("utf-8")
+        f.write(_MAGIC + struct.pack("<Q", len(hb)) + hb)
+        if res.ix is not None:
+            rb, step = header["rb"], max(1, (64 << 20) // header["rb"])
+            for r0 in range(0, res.m, step):
+                ids = np.arange(r0, min(res.m, r0 + step), dtype=np.uint64)
+                out = np.zeros((ids.size, rb), np.uint8)
+                check(_lib.lib().bigsi_hip_get_rows(res.ix, _lib.ptr(ids), ids.size, _lib.ptr(out), rb))
+                f.write(out.tobytes())
+    os.replace(tmp, fn)
+
+
+def _load_snapshot(res, fn):
+    with open(fn, "rb") as f:
+        if f.read(len(_MAGIC)) != _MAGIC:
+            raise BigsiHipError(_lib.ERR_INVALID, "%s is not a hip-hbm snapshot" % fn)
+        (n,) = struct.unpack("<Q", f.read(8))
+        header = json.loads(f.read(n).decode("utf-8"))
+        res.kv = {k.encode("latin-1"): v.encode("latin-1") for k, v in header["kv"].items()}
+        if header.get("m") and header.get("rb"):
+            m, rb = int(header["m"]), int(header["rb"])
+            n_cols = int(res.kv.get(b"number_of_cols:int", b"0"))
+            res.open(m, n_cols, cap=rb * 8)
+            step = max(1, (64 << 20) // rb)
+            for r0 in range(0, m, step):
+                cnt = min(m, r0 + step) - r0
+                blob = np.frombuffer(f.read(cnt * rb), dtype=np.uint8).reshape(cnt, rb)
+                ids = np.arange(r0, r0 + cnt, dtype=np.uint64)
+                check(_lib.lib().bigsi_hip_set_rows(res.ix, _lib.ptr(ids), cnt, _lib.ptr(np.ascontiguousarray(blob)), rb))
+            res.written = np.unpackbits(np.frombuffer(bytes.fromhex(header["written"]), np.uint8))[:m].astype(bool)

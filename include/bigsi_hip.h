@@ -1,0 +1,192 @@
+/*
+ * bigsi_hip.h -- C ABI of libbigsi_hip.so: the BIGSI query hot path on an HBM-resident
+ * bit-sliced signature matrix (AMD MI355X / gfx950).
+ *
+ * This is the drop-in boundary.  The reference (Phelimb/BIGSI, pure Python) reaches its storage
+ * through the `bigsi.storage` plugin contract (bigsi/storage/base.py:9-151, registry
+ * bigsi/storage/__init__.py:3-19); a `hip-hbm` backend binds the entry points below with ctypes
+ * (INTEGRATION.md shows the stub).  Every entry point cites the reference interface it replaces;
+ * paths are relative to the reference root.
+ *
+ * Conventions
+ *   - every function returns 0 (BIGSI_OK) or a negative BIGSI_ERR_* code; the message of the last
+ *     failure on the calling thread is bigsi_hip_last_error().
+ *   - the caller owns all host buffers; no call retains a host pointer after it returns.
+ *   - one index / batch handle may be used from one host thread at a time; distinct handles are
+ *     independent.  HIP contexts do not survive fork(): open after forking (bulk_search,
+ *     bigsi/__main__.py:273-287, forks one worker per chunk).
+ *   - ROW FORMAT: a row is the reference's `bitarray.tobytes()` (bigsi/storage/base.py:85-99):
+ *     ceil(num_cols/8) bytes, column c at byte c/8 under mask 0x80 >> (c%8), zero pad bits.
+ *     The device stores exactly these bytes, zero-extended to a 128-byte-multiple row stride.
+ */
+#ifndef BIGSI_HIP_H
+#define BIGSI_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BIGSI_OK 0
+#define BIGSI_ERR_INVALID (-1)  /* bad argument                                   */
+#define BIGSI_ERR_HIP (-2)      /* HIP runtime failure (message carries hipGetErrorString) */
+#define BIGSI_ERR_NOMEM (-3)    /* host or device allocation failed                */
+#define BIGSI_ERR_RANGE (-4)    /* row / column / sequence index out of range      */
+#define BIGSI_ERR_CAPACITY (-5) /* caller's output buffer is too small             */
+#define BIGSI_ERR_STATE (-6)    /* call made in the wrong order (e.g. fetch before run) */
+
+typedef struct bigsi_hip_index bigsi_hip_index; /* one device-resident m x N bit matrix (one column shard) */
+typedef struct bigsi_hip_batch bigsi_hip_batch; /* one batch of query sequences staged on the device       */
+
+const char *bigsi_hip_last_error(void);
+int bigsi_hip_device_count(int *out);
+
+/* ------------------------------------------------------------------ index lifecycle
+ * Replaces opening a KV store and reading its four integers: BerkeleyDBStorage.__init__
+ * (bigsi/storage/berkeleydb.py:6-19), BitMatrix.__init__ (bigsi/matrix/bitmatrix.py:14-17),
+ * KmerSignatureIndex.__init__ (bigsi/graph/index.py:21-25).  Rows start out all-zero. */
+int bigsi_hip_open(uint64_t num_rows, uint64_t num_cols, uint64_t col_capacity, uint32_t num_hashes,
+                   int device, bigsi_hip_index **out);
+int bigsi_hip_close(bigsi_hip_index *ix); /* BaseStorage.close, bigsi/storage/base.py:149-151 */
+
+typedef struct {
+    uint64_t num_rows;         /* m  = ksi:bloomfilter_size = number_of_rows */
+    uint64_t num_cols;         /* N  = number_of_cols                        */
+    uint64_t col_capacity;     /* columns the current row stride can hold    */
+    uint64_t row_bytes;        /* ceil(num_cols / 8): bytes of one row in the reference format */
+    uint64_t row_stride_bytes; /* device row pitch (multiple of 128)         */
+    uint64_t index_bytes;      /* device bytes held by the matrix            */
+    uint32_t num_hashes;       /* h  = ksi:num_hashes                        */
+    int32_t device;
+} bigsi_hip_info;
+int bigsi_hip_get_info(const bigsi_hip_index *ix, bigsi_hip_info *out);
+
+/* BitMatrix.set_num_cols (bigsi/matrix/bitmatrix.py:45-47).  Fails with BIGSI_ERR_CAPACITY beyond col_capacity. */
+int bigsi_hip_set_num_cols(bigsi_hip_index *ix, uint64_t num_cols);
+/* storage.set_integer("ksi:num_hashes", h) (bigsi/graph/index.py:11,33). */
+int bigsi_hip_set_num_hashes(bigsi_hip_index *ix, uint32_t num_hashes);
+/* Grow the row stride on the device so that insert / merge can append columns
+ * (bigsi/matrix/bitmatrix.py:67-75, bigsi/graph/index.py:54-60). */
+int bigsi_hip_reserve_cols(bigsi_hip_index *ix, uint64_t col_capacity);
+/* Run this index's kernels and copies on a caller-owned hipStream_t (e.g. torch's current stream, so
+ * that RCCL collectives issued by the caller are ordered after them).  NULL restores the private stream. */
+int bigsi_hip_set_stream(bigsi_hip_index *ix, void *hip_stream);
+int bigsi_hip_synchronize(bigsi_hip_index *ix);
+
+/* ------------------------------------------------------------- storage contract
+ * BaseStorage.set_bitarrays / get_bitarrays / batch_set / batch_get over "<row>:bitarray" keys
+ * (bigsi/storage/base.py:43-59, 85-109): n rows of row_bytes bytes each, packed, in row_ids order.
+ * row_bytes may be anything up to the stride; bytes beyond it are zeroed (set) / not returned (get). */
+int bigsi_hip_set_rows(bigsi_hip_index *ix, const uint64_t *row_ids, uint64_t n, const uint8_t *bytes, uint64_t row_bytes);
+int bigsi_hip_get_rows(bigsi_hip_index *ix, const uint64_t *row_ids, uint64_t n, uint8_t *out, uint64_t row_bytes);
+int bigsi_hip_clear(bigsi_hip_index *ix); /* delete_all (bigsi/storage/base.py:132-133): all rows zero */
+
+/* BitMatrix.insert_column (bigsi/matrix/bitmatrix.py:67-75) / BaseStorage.set_bits (bigsi/storage/base.py:111-122):
+ * bloom = one sample's Bloom filter, ceil(num_rows/8) bytes in the row format above (bit r = row r);
+ * writes bit `col` of every row.  col may equal num_cols (append; num_cols grows by one). */
+int bigsi_hip_insert_column(bigsi_hip_index *ix, uint64_t col, const uint8_t *bloom);
+/* BitMatrix.get_column (bigsi/matrix/bitmatrix.py:50-61): out = ceil(num_rows/8) bytes. */
+int bigsi_hip_get_column(bigsi_hip_index *ix, uint64_t col, uint8_t *out);
+
+/* Bloom-add every k-mer of every sequence to sample `col` directly on the transposed matrix: OR of
+ * BloomFilter.update (bigsi/bloom/bloomfilter.py:25-32) with canonical k-mers (bigsi/graph/bigsi.py:151). */
+int bigsi_hip_insert_kmers(bigsi_hip_index *ix, uint64_t col, const char *seqs, const uint64_t *offsets,
+                           uint32_t n_seqs, uint32_t k);
+
+/* Seeded synthetic contents, generated on the device (never crosses PCIe): word w of row r =
+ * AND of `and_draws` draws of a counter-based hash of (seed, shard, r, w); bit density 2^-and_draws.
+ * The CPU mirror is oracle/bigsi_oracle.c: orc_synth_word.  Not in the reference (benchmark input). */
+int bigsi_hip_fill_synthetic(bigsi_hip_index *ix, uint64_t seed, uint64_t shard, uint32_t and_draws);
+
+/* BIGSI.bloom (bigsi/graph/bigsi.py:150-155) + BloomFilter (bigsi/bloom/bloomfilter.py:16-32, zero-initialised):
+ * u k-mers of k ASCII bytes each -> Bloom filter of m bits, out = ceil(m/8) bytes.  Needs no index.
+ * BIGSI_BLOOM_RAW hashes the elements as given (BloomFilter.add / generate_hashes, bloomfilter.py:9-27);
+ * without it they are canonicalised first, as BIGSI.bloom does (graph/bigsi.py:151). */
+#define BIGSI_BLOOM_RAW 1u
+int bigsi_hip_bloom(int device, const char *kmers, uint64_t u, uint32_t k, uint64_t m, uint32_t h, uint32_t flags, uint8_t *out);
+
+/* -------------------------------------------------------------- fused query path
+ * One batch = n_seqs query sequences (ASCII, concatenated; sequence i = seqs[offsets[i] .. offsets[i+1])).
+ * create  uploads them and sizes the device workspace.
+ * run     launches, asynchronously on the index's stream, the whole of BIGSI.search up to the hit list
+ *         (bigsi/graph/bigsi.py:174-230 with bigsi/graph/index.py:42-80, bigsi/utils/fncts.py:24-65,
+ *         bigsi/bloom/bloomfilter.py:5-13, bigsi/matrix/bitmatrix.py:30-37, bigsi/storage/base.py:96-109):
+ *           K1 k-merise, dedupe query k-mers, canonicalise, MurmurHash3 -> h row ids per unique k-mer;
+ *           K2 fetch rows, AND across h, then AND across k-mers (threshold == 1.0, exact_filter) or
+ *              per-sample counts in bit-sliced counters (threshold < 1, inexact_filter);
+ *           K4 min_kmers = ceil(num_unique * threshold) in IEEE double (graph/bigsi.py:179), keep samples with
+ *              count >= min_kmers, compact to (colour, count) lists in ascending colour order.
+ * fetch_* synchronise and copy results out.  A batch can be run any number of times. */
+/* KmerSignatureIndex.lookup for an explicit k-mer list (bigsi/graph/index.py:42-49): u k-mers of k ASCII bytes,
+ * out_rows = u rows of row_bytes bytes (AND of each k-mer's h rows), in input order.  One-shot, synchronous. */
+int bigsi_hip_lookup(bigsi_hip_index *ix, const char *kmers, uint32_t k, uint64_t u, uint8_t *out_rows);
+
+#define BIGSI_RUN_FORCE_COUNTS 1u /* use the counting path even when threshold == 1.0 */
+
+int bigsi_hip_batch_create(bigsi_hip_index *ix, const char *seqs, const uint64_t *offsets, uint32_t n_seqs,
+                           uint32_t k, bigsi_hip_batch **out);
+int bigsi_hip_batch_destroy(bigsi_hip_batch *b);
+int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_t flags);
+
+typedef struct {
+    uint32_t n_seqs;
+    uint32_t k;
+    uint32_t exact;        /* 1: last run took the exact (AND) path, 0: counting path */
+    uint32_t count_bytes;  /* bytes per per-sample counter of the last counting run (2 or 4) */
+    uint64_t total_kmers;  /* sum over sequences of len - k + 1                  */
+    uint64_t total_unique; /* sum of unique query k-mers (after run)             */
+    uint64_t total_hits;   /* hits of the last run                               */
+    uint64_t bitmap_stride_bytes; /* pitch of one sequence in the exact result buffer  */
+    uint64_t counts_stride;       /* counters per sequence in the counts buffer        */
+    void *d_bitmaps;       /* device: n_seqs x bitmap_stride_bytes, row format, exact runs   */
+    void *d_counts;        /* device: n_seqs x counts_stride counters, counting runs         */
+    void *d_num_unique;    /* device: uint32[n_seqs]                                         */
+} bigsi_hip_batch_info;
+int bigsi_hip_batch_get_info(bigsi_hip_batch *b, bigsi_hip_batch_info *out); /* synchronises */
+
+/* Write the per-sample result of later runs into caller-owned device memory (e.g. this rank's slot of an
+ * RCCL all-gather buffer) instead of the batch's own buffers.  Either may be NULL (= keep own buffer). */
+int bigsi_hip_batch_set_outputs(bigsi_hip_batch *b, void *d_bitmaps, void *d_counts);
+
+/* per sequence: number of k-mers n (with duplicates), unique query k-mers u = len(set(kmers))
+ * (graph/bigsi.py:177-179) and min_kmers.  Any pointer may be NULL. */
+int bigsi_hip_batch_fetch_unique(bigsi_hip_batch *b, uint32_t *num_kmers, uint32_t *num_unique, uint32_t *min_kmers);
+/* hits of sequence i are [hit_offsets[i], hit_offsets[i+1]) of colours/counts, ascending colour.
+ * BIGSI_ERR_CAPACITY (with hit_offsets filled) if capacity < hit_offsets[n_seqs]. */
+int bigsi_hip_batch_fetch_hits(bigsi_hip_batch *b, uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t capacity);
+/* counting runs: per-sample k-mer counts of one sequence (unpack_and_sum, graph/bigsi.py:35-44), out[num_cols]. */
+int bigsi_hip_batch_fetch_counts(bigsi_hip_batch *b, uint32_t seq, uint32_t *out);
+/* exact runs: AND of all fetched rows of one sequence (graph/bigsi.py:192-195), out[row_bytes], row format. */
+int bigsi_hip_batch_fetch_bitmap(bigsi_hip_batch *b, uint32_t seq, uint8_t *out);
+/* row ids K1 produced for one sequence: num_unique x num_hashes, k-mers in first-occurrence order, seeds 0..h-1. */
+int bigsi_hip_batch_fetch_rows(bigsi_hip_batch *b, uint32_t seq, uint64_t *rows, uint64_t capacity);
+/* KmerSignatureIndex.lookup for one sequence (graph/index.py:42-49): for each unique k-mer (first-occurrence
+ * order) its position in the sequence and the AND of its h rows (row_bytes bytes each, row format). */
+int bigsi_hip_batch_lookup(bigsi_hip_batch *b, uint32_t seq, uint32_t *first_pos, uint8_t *out_rows, uint64_t capacity_rows);
+/* BIGSI.score's presence strings (graph/bigsi.py:232-237): for each of n_colours colours, n ASCII '0'/'1'
+ * characters, one per k-mer position of the sequence in order (duplicates included).  out[n_colours * n]. */
+int bigsi_hip_batch_presence(bigsi_hip_batch *b, uint32_t seq, const uint32_t *colours, uint32_t n_colours, uint8_t *out);
+
+/* Multi-GPU assembly: compact hits from result buffers gathered from n_shards column shards
+ * (layout [shard][seq][stride]; colour = shard * shard_cols + local column).  Device pointers in,
+ * host hit lists out, same format as fetch_hits.  d_num_unique/min_kmers come from any one shard's batch. */
+int bigsi_hip_compact_gathered(bigsi_hip_batch *b, const void *d_gathered, uint32_t n_shards, uint64_t shard_cols,
+                               uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t capacity);
+
+/* ------------------------------------------------------------------ measurement */
+typedef struct {
+    uint64_t and_launches;   /* row-fetch-AND kernel launches timed since the last reset   */
+    double and_ms;           /* their summed duration (HIP events on the launch stream)     */
+    uint64_t kmerize_launches;
+    double kmerize_ms;
+    uint64_t compact_launches;
+    double compact_ms;
+} bigsi_hip_stats_t;
+int bigsi_hip_set_profiling(bigsi_hip_index *ix, int on); /* record HIP events around each kernel of batch_run */
+int bigsi_hip_stats(bigsi_hip_index *ix, bigsi_hip_stats_t *out, int reset); /* synchronises */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BIGSI_HIP_H */

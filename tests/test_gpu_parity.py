@@ -1,0 +1,395 @@
+"""Parity of the HIP path (through libbigsi_hip.so) with the reference: golden vectors produced by running the
+unmodified reference (tests/golden) and the CPU oracle (oracle/) on seeded inputs.  Bit-exact for everything
+integer / byte / index; float score fields as stated in conftest.py.  Needs a real MI355X: `pytest -m gpu`."""
+import itertools
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, assert_results_equal, check_search, load_golden, unjson
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import bigsi_amd
+    from bigsi_amd import _lib
+    assert _lib.device_count() >= 1, "no HIP device visible"
+    return bigsi_amd
+
+
+_counter = itertools.count()
+
+
+def cfg(k, m, h, **sc):
+    sc.setdefault("name", "t%d" % next(_counter))
+    return {"storage-engine": "hip-hbm", "storage-config": sc, "k": k, "m": m, "h": h}
+
+
+def rows_hex(b):
+    return [bytes(r).hex() for r in b.storage.get_rows_packed(np.arange(b.bloomfilter_size))]
+
+
+def seq_kmers(s, k):
+    return [s[i:i + k] for i in range(len(s) - k + 1)]
+
+
+# --------------------------------------------------------------------------------------------- hashing / bloom
+def test_g1_device_hashing(hip):
+    from bigsi_amd.bloom import BloomFilter, generate_hashes
+    g = load_golden("g1_hash.json")
+    assert generate_hashes("ATT", 3, 25) == {2, 15, 17}          # bigsi/tests/bloom/test_create_bloomfilter.py:6-8
+    assert generate_hashes("ATT", 1, 25) == {15}
+    assert generate_hashes("ATT", 2, 50) == {15, 27}
+    big = 0
+    for rec in g["generate_hashes"]:
+        if rec["m"] > 1 << 26:                                    # 2^31 and 2^32+15: a 0.25-0.5 GB filter per call
+            big += 1
+            if big > 6:
+                continue
+        assert generate_hashes(rec["s"], rec["h"], rec["m"]) == set(rec["set"]), rec
+    # canonicalisation on the device: BIGSI.bloom of a k-mer == raw filter of its golden canonical form
+    for rec in g["canonical"]:
+        c = {"m": 5003, "h": 4, "storage-config": {}}
+        a = hip.BIGSI.bloom(c, [rec["s"]])
+        b = BloomFilter(5003, 4).update([rec["canonical"]]).bitarray
+        assert a == b, rec
+
+
+def test_g1_row_ids_from_k1(hip):
+    """Row ids straight out of K1 (signed hash, Python floor-mod) at real moduli, vs the pinned oracle."""
+    from oracle import coracle
+    g = load_golden("g1_hash.json")
+    for m, h in [(1000, 3), (25000000, 4), (7, 3)]:
+        c = cfg(31, m, h, max_cols=64)
+        b = hip.BIGSI.build(c, [hip.BIGSI.bloom(c, ["A" * 31])], ["s"])
+        seqs = [r["s"] for r in g["canonical"] if len(r["s"]) == 31]
+        batch = b.storage.new_batch(seqs, 31)
+        batch.run(1.0)
+        _, nu, _ = batch.unique()
+        for i, s in enumerate(seqs):
+            assert nu[i] == 1
+            assert [int(x) for x in batch.rows(i, 1)[0]] == coracle.kmer_rows(s, h, m), (s, m)
+        batch.close()
+        b.delete()
+
+
+# --------------------------------------------------------------------------------------------- lookup
+def test_g2_lookup(hip):
+    from bigsi_amd import BitRow
+    for case in load_golden("g2_lookup.json"):
+        c = cfg(case["k"], case["m"], case["h"])
+        blooms = [hip.BIGSI.bloom(c, ks) for ks in case["samples"]]
+        for bl, want in zip(blooms, case["blooms"]):
+            assert bl.tobytes().hex() == want
+        b = hip.BIGSI.build(c, blooms, ["s1", "s2"])
+        assert rows_hex(b) == case["rows"]
+        for lk in case["lookups"]:
+            got = b.lookup(lk["kmers"], remove_trailing_zeros=lk["remove_trailing_zeros"])
+            assert {k: v.to01() for k, v in got.items()} == lk["result"], lk
+        # the reference's own assertions (bigsi/tests/graph/test_index.py:34-45)
+        assert b.lookup(["ATC", "ATC", "ATT", "TTT"]) == {"ATC": BitRow("11"), "ATT": BitRow("10"), "TTT": BitRow("01")}
+        b.delete()
+
+
+# --------------------------------------------------------------------------------------------- search
+@pytest.mark.parametrize("name", ["g3_search.json", "g4_config1.json"])
+def test_g3_g4_search(hip, name):
+    case = load_golden(name)
+    k, m, h = case["k"], case["m"], case["h"]
+    c = cfg(k, m, h)
+    names = list(case["samples"].keys())
+    kms = [seq_kmers(v, k) if isinstance(v, str) else v for v in case["samples"].values()]
+    blooms = [hip.BIGSI.bloom(c, x) for x in kms]
+    for bl, want in zip(blooms, case["blooms"]):
+        assert bl.tobytes().hex() == want
+    b = hip.BIGSI.build(c, blooms, names)
+    assert rows_hex(b) == case["rows"]
+    for s in case["searches"]:
+        t = int(s["threshold"]) if s.get("threshold_is_int") else s["threshold"]
+        check_search(lambda: b.search(s["seq"], t, s["score"]), s, "%s t=%r score=%r" % (s["seq"][:20], t, s["score"]))
+    if "after_delete_a" in case:
+        d = case["after_delete_a"]
+        b.delete_sample("a")
+        assert b.num_samples == d["num_samples"]
+        assert b.colour_to_sample(0) == d["colour_to_sample_0"]
+        assert b.sample_to_colour("a") == d["sample_to_colour_a"]
+        for s in d["searches"]:
+            check_search(lambda: b.search(s["seq"], s["threshold"], s["score"]), s, "deleted")
+    b.delete()
+
+
+def test_reference_end_to_end_asserts(hip):
+    """The reference's own end-to-end expectations (bigsi/tests/graph/test_end_to_end.py:12-131)."""
+    import json
+    from bigsi_amd import BitRow
+    c = cfg(3, 1000, 3)
+    b = hip.BIGSI.build(c, [hip.BIGSI.bloom(c, ["ATC", "ATA"])], ["1"])
+    assert (b.kmer_size, b.bloomfilter_size, b.num_hashes, b.num_samples) == (3, 1000, 3, 1)
+    assert b.lookup("ATC") == {"ATC": BitRow("1")}
+    assert b.colour_to_sample(0) == "1" and b.sample_to_colour("1") == 0
+    b.insert(hip.BIGSI.bloom(c, ["ATC", "ATT"]), "2")
+    assert b.num_samples == 2
+    assert b.lookup(["ATC", "ATA", "ATT"]) == {"ATC": BitRow("11"), "ATA": BitRow("10"), "ATT": BitRow("01")}
+    assert b.colour_to_sample(1) == "2" and b.sample_to_colour("2") == 1
+    with pytest.raises(ValueError):
+        b.insert(hip.BIGSI.bloom(c, ["ATC"]), "1")
+    b.delete()
+    with pytest.raises(BaseException):
+        hip.BIGSI(c)                       # empty store
+    k1, k2 = seq_kmers("ATACACAAT", 3), seq_kmers("ATACACAAC", 3)
+    b = hip.BIGSI.build(c, [hip.BIGSI.bloom(c, k1), hip.BIGSI.bloom(c, k2)], ["a", "b"])
+    assert b.search("ACAGTTAAC", 0.5) == []
+    assert b.lookup("AAT") == {"AAT": BitRow("10")}
+    res = b.search("ATACACAAT", 0.5)
+    assert res[0] == {"percent_kmers_found": 100.0, "num_kmers": 6, "num_kmers_found": 6, "sample_name": "a"}
+    assert json.dumps(res[0]) == '{"percent_kmers_found": 100.0, "num_kmers": 6, "num_kmers_found": 6, "sample_name": "a"}'
+    assert res[1] == {"percent_kmers_found": 83.33, "num_kmers": 6, "num_kmers_found": 5, "sample_name": "b"}
+    b.delete()
+
+
+def test_g7_random_index(hip):
+    g = load_golden("g7_random.json")
+    z = np.load(GOLDEN + "/g7_random.npz")
+    k, m, h, N = g["k"], g["m"], g["h"], g["n_cols"]
+    c = cfg(k, m, h)
+    blooms = [hip.BIGSI.bloom(c, seq_kmers(a, k) + seq_kmers(b_, k)) for a, b_ in g["sample_seqs"]]
+    b = hip.BIGSI.build(c, blooms, g["sample_names"])
+    assert np.array_equal(b.storage.get_rows_packed(np.arange(m)), z["rows"])
+    # per-sample counts (unpack_and_sum) and exact bitmaps for all 48 queries in ONE batch
+    batch = b.storage.new_batch(g["queries"], k)
+    batch.run(0.5)
+    nk, nu, mk = batch.unique()
+    for qi, s in enumerate(g["queries"]):
+        assert nk[qi] == len(s) - k + 1 and nu[qi] == len(set(seq_kmers(s, k)))
+        assert np.array_equal(batch.counts(qi), z["counts"][qi][:N].astype(np.uint32))
+    batch.run(1.0)
+    for qi in range(len(g["queries"])):
+        want = np.packbits(z["counts"][qi][: 8 * ((N + 7) // 8)] == nu[qi])
+        assert np.array_equal(batch.bitmap(qi), want)
+    batch.close()
+    for rec in g["lookups"]:
+        got = b.lookup(seq_kmers(rec["seq"], k), remove_trailing_zeros=False)
+        assert {km: v.tobytes().hex() for km, v in got.items()} == rec["lookup"]
+    for s in g["searches"]:
+        check_search(lambda: b.search(g["queries"][s["q"]], s["threshold"], s["score"]), s, "q%d t=%r" % (s["q"], s["threshold"]))
+    # batched front-end gives the same lists as one-by-one calls
+    multi = b.search_batch(g["queries"][:10], 0.4)
+    for qi in range(10):
+        assert multi[qi] == b.search(g["queries"][qi], 0.4)
+    b.delete()
+
+
+# --------------------------------------------------------------------------------------------- storage contract
+def test_g8_storage_contract(hip):
+    from bigsi_amd import BitRow
+    from bigsi_amd.matrix import BitMatrix
+    from bigsi_amd.storage import get_storage
+    g = load_golden("g8_storage.json")
+    st = get_storage(cfg(3, 25, 1))
+    st.delete_all()
+    # bigsi/tests/storage/test_storage.py
+    st["test"] = b"123"
+    assert st["test"] == b"123"
+    st.set_integer("test", 112)
+    assert st.get_integer("test") == 112
+    st.set_string("test", "abc")
+    assert st.get_string("test") == "abc"
+    ba = BitRow("110101111010")
+    st.set_bitarray("test", ba)
+    assert st["test:bitarray"].hex() == g["bitarray_bytes"]["stored_hex"]
+    assert st.get_bitarray("test")[:12] == ba
+    assert st.get_bit("test", 1) is True and st.get_bit("test", 2) is False
+    st.set_bit("test", 0, 0)
+    assert st.get_bitarray("test").to01() == g["after_set_bit_0_0"]
+    assert [st.incr("testinc"), st.incr("testinc")] == g["incr"]
+    st.delete_all()
+    with pytest.raises(BaseException):
+        st.get_string("test")
+    # bigsi/tests/matrix/test_bitmatrix.py on device rows
+    rows = [BitRow("001"), BitRow("001"), BitRow("111"), BitRow("001"), BitRow("111")] * 5
+    bm = BitMatrix.create(st, rows, len(rows), 3)
+    bm.set_rows(range(25), rows)
+    assert list(bm.get_rows(range(3))) == rows[:3]
+    s = g["bitmatrix"]
+    assert bm.get_column(0).to01() == s["col0"] and bm.get_column(2).to01() == s["col2"]
+    bm.insert_column(BitRow("1" * 25), 0)
+    assert bm.get_column(0).to01() == s["col0_after_insert"]
+    assert bm.get_row(1).to01() == s["row1_after_insert0"]
+    bm.insert_column(BitRow("1" * 25), 3)
+    assert bm.get_row(1).to01() == s["row1_after_insert3"] and bm.num_cols == s["num_cols_after"]
+    with pytest.raises(KeyError):
+        st.get_bitarray(25)            # a row that was never stored
+    st.delete_all()
+    # insert + merge end to end
+    c = cfg(3, 1000, 3)
+    b = hip.BIGSI.build(c, [hip.BIGSI.bloom(c, ["ATC", "ATA"])], ["1"])
+    b.insert(hip.BIGSI.bloom(c, ["ATC", "ATT"]), "2")
+    assert b.num_samples == g["insert"]["num_samples"]
+    assert {k: v.to01() for k, v in b.lookup(["ATC", "ATA", "ATT"]).items()} == g["insert"]["lookup"]
+    assert rows_hex(b) == g["insert"]["rows"]
+    b.delete()
+    c1, c2 = cfg(3, 1000, 3), cfg(3, 1000, 3)
+    b1 = hip.BIGSI.build(c1, [hip.BIGSI.bloom(c1, seq_kmers("ATACACAAT", 3))], ["a"])
+    b2 = hip.BIGSI.build(c2, [hip.BIGSI.bloom(c2, seq_kmers("ATACACAAC", 3))], ["b"])
+    b1.merge(b2)
+    assert b1.num_samples == g["merge"]["num_samples"]
+    assert_results_equal(b1.search("ATACACAAT", 0.5), unjson(g["merge"]["search"]["results"]), "merge")
+    assert rows_hex(b1) == g["merge"]["rows"]
+    b1.delete()
+    b2.delete()
+
+
+def test_snapshot_roundtrip(hip, tmp_path):
+    from bigsi_amd.storage import hip_hbm
+    fn = str(tmp_path / "idx.hbm")
+    c = cfg(3, 1000, 3, filename=fn)
+    k1 = seq_kmers("ATACACAAT", 3)
+    b = hip.BIGSI.build(c, [hip.BIGSI.bloom(c, k1)], ["a"])     # build() syncs -> snapshot written
+    want = b.search("ATACACAAT", 1.0)
+    rows = rows_hex(b)
+    hip_hbm._RESIDENT.pop(c["storage-config"]["name"]).free()    # "restart": the resident index is gone
+    b2 = hip.BIGSI(c)
+    assert rows_hex(b2) == rows and b2.search("ATACACAAT", 1.0) == want
+    b2.delete()
+
+
+# --------------------------------------------------------------------------------------------- synthetic index vs oracle
+def synth_index(hip, m, n_cols, h, seed, shard=0, draws=2):
+    from bigsi_amd.storage import get_storage
+    c = cfg(31, m, h, max_cols=n_cols)
+    st = get_storage(c)
+    st.delete_all()
+    st.set_integer("number_of_rows", m)
+    st.set_integer("number_of_cols", n_cols)
+    st.set_integer("ksi:bloomfilter_size", m)
+    st.set_integer("ksi:num_hashes", h)
+    st.fill_synthetic(seed, shard, draws)
+    return c, st
+
+
+def random_seqs(rng, n, lo, hi):
+    return ["".join(rng.choice(list("ACGT"), size=int(rng.integers(lo, hi + 1)))) for _ in range(n)]
+
+
+@pytest.mark.parametrize("m,n_cols,h,maxlen", [
+    (5003, 1000, 3, 90),          # P=6  (< 64 k-mers), ragged last word, 2 waves
+    (20011, 9999, 4, 700),        # P=10, C2-like row width (157 words)
+    (3001, 70, 1, 1500),          # P=16, single hash, two words
+    (2003, 130, 2, 400),          # h=2
+    (2003, 64, 5, 200),           # h=5, exactly one word
+    (2003, 65, 7, 100),           # runtime-h kernel (h > 5)
+    (50021, 40000, 3, 300),       # 625 words: two 256-thread tiles
+])
+def test_synthetic_vs_oracle(hip, m, n_cols, h, maxlen):
+    from oracle import coracle
+    from oracle.ref_model import SynthOracle
+    seed = 20260928 + m
+    c, st = synth_index(hip, m, n_cols, h, seed)
+    orc = SynthOracle(seed, 0, m, n_cols, h, 31, 2)
+    # the fill kernel against the CPU generator, sampled rows + first/last
+    ids = np.unique(np.concatenate([[0, m - 1], np.random.default_rng(1).integers(0, m, 40)])).astype(np.uint64)
+    got = st.get_rows_packed(ids)
+    for i, r in enumerate(ids):
+        assert np.array_equal(got[i], coracle.synth_row(seed, 0, int(r), n_cols, 2)), r
+    rng = np.random.default_rng(m)
+    seqs = random_seqs(rng, 10, 31, maxlen) + ["A" * 40, "ACGT" * 20, "N" * 31, "ACGTN" * 12, "acgt" * 10, "AC", ""]
+    # plant three of them into a few samples (Bloom-add on the transposed matrix)
+    plants = [(0, seqs[0]), (n_cols - 1, seqs[0]), (n_cols // 2, seqs[1]), (min(63, n_cols - 1), seqs[2][:60])]
+    for col, s in plants:
+        st.insert_kmers(col, [s], 31)
+        orc.insert_kmers(col, s)
+    batch = st.new_batch(seqs, 31)
+    for thr in (0.35, 1.0):
+        batch.run(thr, force_counts=(thr == 1.0 and h == 2))
+        nk, nu, mk = batch.unique()
+        off, colours, counts = batch.hits()
+        inf = batch.info()
+        for i, s in enumerate(seqs):
+            u, cnt = orc.counts(s)
+            assert nu[i] == u and nk[i] == max(len(s) - 30, 0)
+            assert mk[i] == int(np.ceil(u * thr))
+            lo, hi = int(off[i]), int(off[i + 1])
+            if inf.exact:
+                _, bm = orc.exact_bitmap(s) if u else (0, np.zeros(orc.rb, np.uint8))
+                assert np.array_equal(batch.bitmap(i), bm)
+                want = np.flatnonzero(np.unpackbits(bm)[:n_cols]) if u else np.zeros(0, int)
+                assert np.array_equal(colours[lo:hi], want) and (counts[lo:hi] == u).all()
+            else:
+                assert np.array_equal(batch.counts(i), cnt.astype(np.uint32))
+                want = np.flatnonzero(cnt >= mk[i])
+                assert np.array_equal(colours[lo:hi], want)
+                assert np.array_equal(counts[lo:hi], cnt[want].astype(np.uint32))
+    # planted sequences are exact hits of their samples
+    batch.run(1.0)
+    off, colours, counts = batch.hits()
+    assert {0, n_cols - 1} <= set(colours[int(off[0]):int(off[1])].tolist())
+    assert n_cols // 2 in set(colours[int(off[1]):int(off[2])].tolist())
+    # lookup rows and presence strings of one query against the oracle
+    kmers, uniq, rows = orc.per_kmer_rows(seqs[0])
+    first, got_rows = batch.lookup(0, len(uniq))
+    assert [seqs[0][p:p + 31] for p in first] == uniq
+    assert np.array_equal(got_rows, rows)
+    cols = np.array([0, n_cols - 1, n_cols // 3], dtype=np.uint32)
+    pres = batch.presence(0, cols, len(kmers))
+    bits = np.unpackbits(rows, axis=1)
+    idx = {km: j for j, km in enumerate(uniq)}
+    for cc, p in zip(cols, pres):
+        assert p == "".join("1" if bits[idx[km], cc] else "0" for km in kmers)
+    batch.close()
+    st.delete_all()
+
+
+def test_long_query_uint32_counters(hip):
+    """> 65535 k-mers in one query: P=32 planes, uint32 counters."""
+    from oracle.ref_model import SynthOracle
+    m, n_cols, h = 1009, 100, 2
+    c, st = synth_index(hip, m, n_cols, h, 77, draws=1)
+    orc = SynthOracle(77, 0, m, n_cols, h, 31, 1)
+    rng = np.random.default_rng(3)
+    s = "".join(rng.choice(list("ACGT"), size=66000))
+    batch = st.new_batch([s, "ACGT" * 10], 31)
+    batch.run(0.5)
+    assert batch.info().count_bytes == 4
+    for i, q in enumerate([s, "ACGT" * 10]):
+        u, cnt = orc.counts(q)
+        assert batch.unique()[1][i] == u
+        assert np.array_equal(batch.counts(i), cnt.astype(np.uint32))
+    batch.close()
+    st.delete_all()
+
+
+def test_size_independent_properties(hip):
+    """Properties that hold at any size: strand symmetry, idempotence under repetition, exact == (count == u),
+    planted round trip."""
+    m, n_cols, h = 200003, 30000, 4
+    c, st = synth_index(hip, m, n_cols, h, 5)
+    rng = np.random.default_rng(9)
+    base = random_seqs(rng, 6, 200, 400)
+    comp = str.maketrans("ACGT", "TGCA")
+    seqs = base + [s[::-1].translate(comp) for s in base]
+    for i, s in enumerate(base):
+        st.insert_kmers(100 * i + 7, [s], 31)
+    batch = st.new_batch(seqs, 31)
+    batch.run(0.5)
+    _, nu, _ = batch.unique()
+    cnts = [batch.counts(i) for i in range(len(seqs))]
+    for i in range(len(base)):
+        assert nu[i] == nu[i + len(base)]
+        assert np.array_equal(cnts[i], cnts[i + len(base)])          # reverse complement: same canonical k-mers
+        assert cnts[i][100 * i + 7] == nu[i]                          # planted sample holds every k-mer
+    batch.run(1.0)
+    off, colours, _ = batch.hits()
+    for i in range(len(seqs)):
+        assert np.array_equal(colours[int(off[i]):int(off[i + 1])], np.flatnonzero(cnts[i] == nu[i]))
+    batch.close()
+    # tandem repeat s+s: the unique k-mers of s plus at most 30 junction windows -> counts move by at most 30
+    rep = st.new_batch([s + s for s in base], 31)
+    rep.run(0.5)
+    _, nu2, _ = rep.unique()
+    for i in range(len(base)):
+        d = rep.counts(i).astype(np.int64) - cnts[i].astype(np.int64)
+        assert nu[i] <= nu2[i] <= nu[i] + 30 and d.min() >= 0 and d.max() <= 30
+    rep.close()
+    st.delete_all()
