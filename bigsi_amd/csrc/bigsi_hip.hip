@@ -485,6 +485,9 @@ struct bigsi_hip_batch {
     double threshold = 1.0;
     uint64_t wv = 0, wv_pad = 0;   // valid / padded words per row at run time
     uint32_t run_h = 0;            // num_hashes the row ids of the last K1 were produced with
+    const void *g_src = nullptr;   // last gathered buffer handed to compact_gathered
+    uint32_t g_shards = 0;
+    uint64_t g_shard_cols = 0;
     std::vector<uint32_t> h_num_unique, h_num_kmers;
     bool host_counts_valid = false;
 };
@@ -821,14 +824,26 @@ extern "C" int bigsi_hip_batch_fetch_hits(bigsi_hip_batch *b, uint64_t *hit_offs
     return fetch_hits_from(b, b->hits, src, 1, b->ix->n_cols, hit_offsets, colours, counts, capacity);
 }
 
-extern "C" int bigsi_hip_compact_gathered(bigsi_hip_batch *b, const void *d_gathered, uint32_t n_shards, uint64_t shard_cols,
-                                          uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t capacity)
+extern "C" int bigsi_hip_batch_compact_gathered(bigsi_hip_batch *b, const void *d_gathered, uint32_t n_shards, uint64_t shard_cols)
 {
     TRY(need_run(b));
     if (!d_gathered || n_shards == 0) return fail(BIGSI_ERR_INVALID, "bad gathered buffer");
     if ((uint64_t)n_shards * shard_cols > 0xFFFFFFFFull) return fail(BIGSI_ERR_INVALID, "more than 2^32-1 colours in total");
+    b->g_src = d_gathered;
+    b->g_shards = n_shards;
+    b->g_shard_cols = shard_cols;
+    EventPair ep{};
+    TRY(ev_begin(b->ix, &ep));
     TRY(compact(b, b->ghits, d_gathered, n_shards, shard_cols, false));
-    return fetch_hits_from(b, b->ghits, d_gathered, n_shards, shard_cols, hit_offsets, colours, counts, capacity);
+    TRY(ev_end(b->ix, &ep, b->ix->ev_cp));
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_batch_fetch_gathered_hits(bigsi_hip_batch *b, uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t capacity)
+{
+    TRY(need_run(b));
+    if (!b->g_src) return fail(BIGSI_ERR_STATE, "bigsi_hip_batch_compact_gathered has not been called");
+    return fetch_hits_from(b, b->ghits, b->g_src, b->g_shards, b->g_shard_cols, hit_offsets, colours, counts, capacity);
 }
 
 extern "C" int bigsi_hip_batch_fetch_counts(bigsi_hip_batch *b, uint32_t seq, uint32_t *out)

@@ -1,0 +1,107 @@
+"""Column-range sharding of one BIGSI index over the GPUs of a node.
+
+Every stage of the query path is independent per sample column -- hashing depends only on the query, AND and
+counting are per column -- so rank g (one process per GPU) holds ALL m rows of columns
+[g * shard_cols, (g+1) * shard_cols) and runs K1-K3 on its slice for the same query batch.  The only exchange is
+one all-gather per batch of the per-sample result vectors (exact: one bit per sample, the AND bitmap; thresholded:
+one uint16/uint32 count per sample), RCCL over xGMI through torch.distributed (backend "nccl" is RCCL on ROCm).
+The local result is written by the kernels straight into this rank's slot of the gather buffer
+(bigsi_hip_batch_set_outputs), so the collective runs in place; compaction to (colour, count) lists then runs
+on every rank over the gathered [shard][seq][stride] buffer with colour = shard * shard_cols + local column.
+
+Row-range sharding is deliberately not offered: a query touches random rows, so every k-mer would need an
+AND-reduce across GPUs.
+"""
+import numpy as np
+
+from . import _lib
+from ._lib import check
+
+
+def plan_shards(total_cols, world_size):
+    """(shard_cols, [(first_col, n_cols) per rank]): equal-width shards, the last one possibly short or empty."""
+    shard_cols = -(-int(total_cols) // int(world_size))
+    spans = []
+    for g in range(world_size):
+        lo = min(g * shard_cols, total_cols)
+        spans.append((lo, min(shard_cols, total_cols - lo)))
+    return shard_cols, spans
+
+
+def globalise(hit_offsets, colours, counts, shard_cols, shard):
+    """Colour ids of one shard's local hit list -> global colours (host-side helper for per-shard fetches)."""
+    return hit_offsets, colours.astype(np.uint64) + np.uint64(shard) * np.uint64(shard_cols), counts
+
+
+class ShardGroup(object):
+    """torch.distributed plumbing: rank / world, the gather buffer and the in-place all-gather."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def gather_buffer(self, bytes_per_rank, device):
+        import torch
+        return torch.zeros((self.world, int(bytes_per_rank)), dtype=torch.uint8, device=device)
+
+    def all_gather_in_place(self, buf):
+        """buf: [world, bytes]; slot [rank] already holds this rank's result."""
+        if self.world == 1:
+            return buf
+        self.dist.all_gather_into_tensor(buf.view(-1), buf[self.rank].clone() if buf.device.type == "cpu" else buf[self.rank],
+                                         group=self.group)
+        return buf
+
+
+class ShardedSearch(object):
+    """Query batches against this rank's column shard + the collective that makes every rank see the whole result."""
+
+    def __init__(self, storage, shard_cols, group=None, device=None):
+        import torch
+        self.torch = torch
+        self.storage = storage
+        self.shard_cols = int(shard_cols)
+        self.sg = ShardGroup(group)
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        # the library's kernels must be ordered with RCCL's: run both on torch's current stream
+        check(_lib.lib().bigsi_hip_set_stream(storage.handle, torch.cuda.current_stream(self.device).cuda_stream))
+        self._buf = None
+        self._buf_key = None
+
+    def prepare(self, batch, exact, count_bytes=2):
+        """Point the batch's result at this rank's slot of a [world, n_seqs*stride] gather buffer."""
+        inf = self.storage.res.info()
+        wv_pad = (-(-int(inf.num_cols) // 64) + 1) // 2 * 2
+        stride_bytes = wv_pad * 8 if exact else wv_pad * 64 * count_bytes
+        key = (batch.n, stride_bytes, exact)
+        if self._buf_key != key:
+            self._buf = self.sg.gather_buffer(batch.n * stride_bytes, self.device)
+            self._buf_key = key
+        slot = self._buf[self.sg.rank].data_ptr()
+        check(_lib.lib().bigsi_hip_batch_set_outputs(batch.b, slot if exact else None, None if exact else slot))
+        return self._buf
+
+    def step(self, batch, threshold):
+        """Asynchronous: local K1-K4, all-gather of the per-sample vectors, compaction of the gathered result."""
+        exact = threshold == 1.0
+        buf = self._buf
+        batch.run(threshold)
+        self.sg.all_gather_in_place(buf)
+        check(_lib.lib().bigsi_hip_batch_compact_gathered(batch.b, buf.data_ptr(), self.sg.world, self.shard_cols))
+        return buf
+
+    def fetch(self, batch):
+        off = np.zeros(batch.n + 1, np.uint64)
+        cap = 1 << 12
+        while True:
+            col = np.zeros(cap, np.uint32)
+            cnt = np.zeros(cap, np.uint32)
+            rc = _lib.lib().bigsi_hip_batch_fetch_gathered_hits(batch.b, _lib.ptr(off), _lib.ptr(col), _lib.ptr(cnt), cap)
+            if rc == _lib.ERR_CAPACITY:
+                cap = int(off[-1])
+                continue
+            check(rc)
+            return off, col[: int(off[-1])], cnt[: int(off[-1])]

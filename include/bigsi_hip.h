@@ -168,11 +168,12 @@ int bigsi_hip_batch_lookup(bigsi_hip_batch *b, uint32_t seq, uint32_t *first_pos
  * characters, one per k-mer position of the sequence in order (duplicates included).  out[n_colours * n]. */
 int bigsi_hip_batch_presence(bigsi_hip_batch *b, uint32_t seq, const uint32_t *colours, uint32_t n_colours, uint8_t *out);
 
-/* Multi-GPU assembly: compact hits from result buffers gathered from n_shards column shards
- * (layout [shard][seq][stride]; colour = shard * shard_cols + local column).  Device pointers in,
- * host hit lists out, same format as fetch_hits.  d_num_unique/min_kmers come from any one shard's batch. */
-int bigsi_hip_compact_gathered(bigsi_hip_batch *b, const void *d_gathered, uint32_t n_shards, uint64_t shard_cols,
-                               uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t capacity);
+/* Multi-GPU assembly: compact hits from result buffers gathered from n_shards column shards (device pointer,
+ * layout [shard][seq][stride] with this batch's strides; colour = shard * shard_cols + local column).
+ * compact_gathered is asynchronous on the index's stream (call it after the RCCL all-gather, which the caller
+ * issues on the same stream); fetch_gathered_hits synchronises and copies out, same format as fetch_hits. */
+int bigsi_hip_batch_compact_gathered(bigsi_hip_batch *b, const void *d_gathered, uint32_t n_shards, uint64_t shard_cols);
+int bigsi_hip_batch_fetch_gathered_hits(bigsi_hip_batch *b, uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t capacity);
 
 /* ------------------------------------------------------------------ measurement */
 typedef struct {
