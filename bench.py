@@ -1,0 +1,213 @@
+#!/usr/bin/env python
+"""bench.py -- BIGSI query hot path on MI355X: k-mer lookups/s and achieved HBM GB/s of the row-fetch-AND kernel.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the whole device path (K1 k-merise/dedupe/hash -> K2 row fetch + AND -> K4 threshold +
+compaction [-> RCCL all-gather of per-sample result vectors + compaction of the gathered result when N > 1]) over one
+batch of synthetic queries that is already resident in HBM.  Default workload = BASELINE.json configs[2], the largest
+single-GPU configuration: synthetic 10M-row x 100k-sample index (125 GB), h=4, 256 x 1 kbp queries, threshold 1.0.
+Scaling is WEAK: every rank holds a 10M x 100k column shard (index = 10M x N*100k samples) and looks every query up
+in its shard; `value` sums the k-mer lookups all ranks performed (each against its own shard) per second, and
+config.kmer_lookups_per_s_full_index gives the rate against the whole N-shard index.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+SEED = 20260928
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--rows", type=int, default=10_000_000)
+    p.add_argument("--cols", type=int, default=100_000, help="sample columns PER GPU shard")
+    p.add_argument("--hashes", type=int, default=4)
+    p.add_argument("--batch", type=int, default=256)
+    p.add_argument("--qlen", type=int, default=1000)
+    p.add_argument("--k", type=int, default=31)
+    p.add_argument("--threshold", type=float, default=1.0)
+    p.add_argument("--and-draws", type=int, default=2, help="bit density of the synthetic index = 2^-draws")
+    p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample (0 = skip)")
+    p.add_argument("--cpu-rows", type=int, default=200_000)
+    p.add_argument("--no-verify", action="store_true")
+    return p.parse_args()
+
+
+def make_queries(batch, qlen, rank_independent_seed=1):
+    rng = np.random.default_rng(rank_independent_seed)       # every rank sees the same queries
+    return ["".join(rng.choice(list("ACGT"), size=qlen)) for _ in range(batch)]
+
+
+def cpu_baseline(args, seqs, exact):
+    """The C oracle (reference-shaped: per-k-mer canonicalisation, MurmurHash3 x h, per-row copy + AND, then AND-all or
+    unpack-to-int32-and-add), single thread, on a bounded sample of the SAME queries.  The index keeps the full row
+    width (per-lookup work identical to the GPU run) but only --cpu-rows rows, so that it fits host RAM."""
+    from oracle import coracle
+    m = min(args.rows, args.cpu_rows)
+    t0 = time.time()
+    table = coracle.synth_fill(SEED, 0, 0, m, args.cols, args.and_draws)
+    fill_s = time.time() - t0
+    done_kmers, t_query, nq = 0, 0.0, 0
+    while t_query < args.cpu_seconds:              # cycle through the bench queries until the time budget is used
+        s = seqs[nq % len(seqs)]
+        t1 = time.time()
+        u, _, _ = coracle.query(table, args.hashes, s, args.k, want_counts=not exact, want_and=exact)
+        t_query += time.time() - t1
+        done_kmers += u
+        nq += 1
+    return {"value": done_kmers / t_query, "unit": "kmer_lookups/s", "cores": 1, "kind": "port",
+            "sample": "%d query executions cycling over the %d bench queries (%d unique k-mers, %.1f s) on a %d-row x %d-sample slice of the synthetic "
+                      "index (full row width, rows reduced to fit host RAM; table fill %.1f s not timed); oracle/bigsi_oracle.c orc_query, "
+                      "rows served from RAM instead of BerkeleyDB" % (nq, len(seqs), done_kmers, t_query, m, args.cols, fill_s)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs a torch.distributed.run launch with %d ranks" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+
+    import torch
+    import torch.distributed as dist
+    from bigsi_amd import _lib
+    from bigsi_amd._lib import check
+    from bigsi_amd.parallel import ShardedSearch
+    from bigsi_amd.storage import get_storage
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    exact = args.threshold == 1.0
+    # ---------------- index: this rank's column shard, generated on the device
+    st = get_storage({"storage-engine": "hip-hbm", "k": args.k, "m": args.rows, "h": args.hashes,
+                      "storage-config": {"name": "bench", "device": local_rank, "max_cols": args.cols}})
+    st.delete_all()
+    for key, v in (("number_of_rows", args.rows), ("number_of_cols", args.cols),
+                   ("ksi:bloomfilter_size", args.rows), ("ksi:num_hashes", args.hashes)):
+        st.set_integer(key, v)
+    t0 = time.time()
+    st.fill_synthetic(SEED, rank, args.and_draws)
+    fill_s = time.time() - t0
+    info = st.res.info()
+
+    # ---------------- queries: uniform ACGT; ~1% of them planted into a few samples of every shard
+    seqs = make_queries(args.batch, args.qlen)
+    planted = list(range(0, args.batch, 97))[:8]
+    for j, qi in enumerate(planted):
+        st.insert_kmers((1009 * (j + 1) + 13 * rank) % args.cols, [seqs[qi]], args.k)
+    batch = st.new_batch(seqs, args.k)
+    sh = ShardedSearch(st, args.cols, device=dev)          # also moves the library onto torch's current stream
+    count_bytes = 2 if (args.qlen - args.k + 1) < 65536 else 4
+    sh.prepare(batch, exact, count_bytes)
+    check(_lib.lib().bigsi_hip_set_profiling(st.handle, 1))
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        sh.step(batch, args.threshold)
+    sync_all()
+    stats = _lib.Stats()
+    check(_lib.lib().bigsi_hip_stats(st.handle, _lib.C.byref(stats), 1))     # drop warmup events
+
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sh.step(batch, args.threshold)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    check(_lib.lib().bigsi_hip_stats(st.handle, _lib.C.byref(stats), 1))
+
+    # ---------------- results of the last step, algorithmic bytes, verification
+    off, colours, counts = sh.fetch(batch)
+    nk, nu, mk = batch.unique()
+    total_unique = int(nu.sum())
+    wv = -(-args.cols // 64)
+    uniq_rows = 0
+    for i in range(args.batch):
+        uniq_rows += np.unique(batch.rows(i, nu[i])).size      # each needed row counted once (reference fetches the union once)
+    out_bytes = args.batch * (wv * 8 if exact else args.cols * count_bytes)
+    alg_bytes = uniq_rows * wv * 8 + out_bytes
+    and_ms = stats.and_ms / max(stats.and_launches, 1)
+    achieved = alg_bytes / (and_ms * 1e-3) / 1e9
+
+    verified = None
+    if not args.no_verify and rank == 0:
+        # planted round trip on every shard + one sampled query against the oracle on this rank's shard
+        from oracle.ref_model import SynthOracle
+        for j, qi in enumerate(planted):
+            hits = set(colours[int(off[qi]):int(off[qi + 1])].tolist())
+            for g in range(world):
+                assert g * args.cols + (1009 * (j + 1) + 13 * g) % args.cols in hits, "planted query %d missing on shard %d" % (qi, g)
+        orc = SynthOracle(SEED, 0, args.rows, args.cols, args.hashes, args.k, args.and_draws)
+        for j, qi in enumerate(planted):
+            orc.insert_kmers((1009 * (j + 1)) % args.cols, seqs[qi])
+        for qi in (planted[0], 1):
+            u, cnt = orc.counts(seqs[qi])
+            want = np.flatnonzero(cnt >= (u if exact else mk[qi]))
+            got = colours[int(off[qi]):int(off[qi + 1])]
+            got0 = got[got < args.cols]
+            assert u == nu[qi] and np.array_equal(got0, want), "oracle mismatch on query %d" % qi
+        verified = "planted round trip on %d shard(s) + 2 queries bit-exact vs oracle" % world
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        per_rank_rate = total_unique / (elapsed / args.steps)
+        line = {
+            "metric": "kmer_lookups_per_s", "value": per_rank_rate * world, "unit": "kmer_lookups/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[2]: synthetic %d-row x %d-sample index per GPU (%.1f GB HBM), h=%d, %d x %d bp queries, "
+                            "k=%d, threshold=%g (%s)" % (args.rows, args.cols, info.index_bytes / 1e9, args.hashes, args.batch, args.qlen,
+                                                         args.k, args.threshold, "exact" if exact else "counts"),
+                "rows": args.rows, "cols_per_gpu": args.cols, "total_cols": args.cols * world, "hashes": args.hashes,
+                "batch": args.batch, "qlen": args.qlen, "unique_kmers_per_batch": total_unique, "hits_last_step": int(off[-1]),
+                "kmer_lookups_per_s_full_index": per_rank_rate, "parallelism": "column-shard x%d + RCCL all-gather" % world,
+                "index_fill_s": fill_s, "verified": verified,
+            },
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "k_and_exact" if exact else "k_and_count",
+                         "alg_bytes_per_launch": alg_bytes, "kernel_ms": and_ms, "launches_timed": int(stats.and_launches),
+                         "kmerize_ms": stats.kmerize_ms / max(stats.kmerize_launches, 1),
+                         "compact_ms": stats.compact_ms / max(stats.compact_launches, 1)},
+        }
+        if args.cpu_seconds > 0:
+            line["cpu_baseline"] = cpu_baseline(args, seqs, exact)
+        print(json.dumps(line), flush=True)
+    batch.close()
+    st.delete_all()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

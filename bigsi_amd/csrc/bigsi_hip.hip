@@ -480,7 +480,7 @@ struct bigsi_hip_batch {
     void *ext_bitmaps = nullptr, *ext_counts = nullptr;
     HitBufs hits, ghits;
     // state of the last run
-    bool ran = false, exact = false;
+    bool ran = false, exact = false, compacted = false;
     uint32_t count_bytes = 2;
     double threshold = 1.0;
     uint64_t wv = 0, wv_pad = 0;   // valid / padded words per row at run time
@@ -683,6 +683,9 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
         TRY(ev_end(ix, &ep, ix->ev_and));
     }
 
+    b->compacted = !(flags & BIGSI_RUN_SKIP_COMPACT);
+    b->ran = true;
+    if (!b->compacted) return BIGSI_OK;
     // K4 on this shard's own result
     TRY(ev_begin(ix, &ep));
     const void *src = b->exact ? (b->ext_bitmaps ? b->ext_bitmaps : b->bitmaps.p) : (b->ext_counts ? b->ext_counts : b->counts.p);
@@ -797,7 +800,7 @@ extern "C" int bigsi_hip_batch_get_info(bigsi_hip_batch *b, bigsi_hip_batch_info
     out->count_bytes = b->count_bytes;
     for (uint32_t v : b->h_num_unique) out->total_unique += v;
     uint64_t total = 0;
-    HIP_TRY(hipMemcpy(&total, b->hits.hit_off.as<uint64_t>() + b->n_seqs, 8, hipMemcpyDeviceToHost));
+    if (b->compacted) HIP_TRY(hipMemcpy(&total, b->hits.hit_off.as<uint64_t>() + b->n_seqs, 8, hipMemcpyDeviceToHost));
     out->total_hits = total;
     out->bitmap_stride_bytes = b->wv_pad * 8;
     out->counts_stride = b->wv_pad * 64;
@@ -821,6 +824,10 @@ extern "C" int bigsi_hip_batch_fetch_hits(bigsi_hip_batch *b, uint64_t *hit_offs
 {
     TRY(need_run(b));
     const void *src = b->exact ? (b->ext_bitmaps ? b->ext_bitmaps : b->bitmaps.p) : (b->ext_counts ? b->ext_counts : b->counts.p);
+    if (!b->compacted) {   // the run skipped K4: do it now
+        TRY(compact(b, b->hits, src, 1, b->ix->n_cols, false));
+        b->compacted = true;
+    }
     return fetch_hits_from(b, b->hits, src, 1, b->ix->n_cols, hit_offsets, colours, counts, capacity);
 }
 

@@ -57,7 +57,11 @@ class ShardGroup(object):
 
 
 class ShardedSearch(object):
-    """Query batches against this rank's column shard + the collective that makes every rank see the whole result."""
+    """Query batches against this rank's column shard + the collective that makes every rank see the whole result.
+
+    Owns one torch side stream: the library's kernels are put on it (bigsi_hip_set_stream) and the RCCL collective is
+    issued under it, so kernel -> all-gather -> compaction are ordered by torch's usual stream semantics.  (torch's
+    default stream has handle 0, which the C ABI reserves for "use the library's private stream".)"""
 
     def __init__(self, storage, shard_cols, group=None, device=None):
         import torch
@@ -66,10 +70,13 @@ class ShardedSearch(object):
         self.shard_cols = int(shard_cols)
         self.sg = ShardGroup(group)
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
-        # the library's kernels must be ordered with RCCL's: run both on torch's current stream
-        check(_lib.lib().bigsi_hip_set_stream(storage.handle, torch.cuda.current_stream(self.device).cuda_stream))
+        self.stream = torch.cuda.Stream(self.device)
+        check(_lib.lib().bigsi_hip_set_stream(storage.handle, self.stream.cuda_stream))
         self._buf = None
         self._buf_key = None
+
+    def close(self):
+        check(_lib.lib().bigsi_hip_set_stream(self.storage.handle, None))
 
     def prepare(self, batch, exact, count_bytes=2):
         """Point the batch's result at this rank's slot of a [world, n_seqs*stride] gather buffer."""
@@ -78,22 +85,28 @@ class ShardedSearch(object):
         stride_bytes = wv_pad * 8 if exact else wv_pad * 64 * count_bytes
         key = (batch.n, stride_bytes, exact)
         if self._buf_key != key:
-            self._buf = self.sg.gather_buffer(batch.n * stride_bytes, self.device)
+            with self.torch.cuda.stream(self.stream):
+                self._buf = self.sg.gather_buffer(batch.n * stride_bytes, self.device)
+            self.stream.synchronize()
             self._buf_key = key
         slot = self._buf[self.sg.rank].data_ptr()
         check(_lib.lib().bigsi_hip_batch_set_outputs(batch.b, slot if exact else None, None if exact else slot))
         return self._buf
 
     def step(self, batch, threshold):
-        """Asynchronous: local K1-K4, all-gather of the per-sample vectors, compaction of the gathered result."""
-        exact = threshold == 1.0
-        buf = self._buf
-        batch.run(threshold)
-        self.sg.all_gather_in_place(buf)
-        check(_lib.lib().bigsi_hip_batch_compact_gathered(batch.b, buf.data_ptr(), self.sg.world, self.shard_cols))
-        return buf
+        """Asynchronous: local K1-K3 (+K4 when alone), all-gather of the per-sample vectors, K4 over the gathered result."""
+        if self.sg.world == 1:
+            batch.run(threshold)
+            return self._buf
+        with self.torch.cuda.stream(self.stream):
+            batch.run(threshold, skip_compact=True)
+            self.sg.all_gather_in_place(self._buf)
+            check(_lib.lib().bigsi_hip_batch_compact_gathered(batch.b, self._buf.data_ptr(), self.sg.world, self.shard_cols))
+        return self._buf
 
     def fetch(self, batch):
+        if self.sg.world == 1:
+            return batch.hits()
         off = np.zeros(batch.n + 1, np.uint64)
         cap = 1 << 12
         while True:
