@@ -158,6 +158,19 @@ def main():
     and_ms = stats.and_ms / max(stats.and_launches, 1)
     achieved = alg_bytes / (and_ms * 1e-3) / 1e9
 
+    # HBM traffic of this kernel on this workload, when a PMC pass for it has been committed (PMC counters cannot be
+    # collected from inside the timed run; see profiles/)
+    traffic, traffic_src = None, None
+    wkey = "rows=%d cols=%d hashes=%d batch=%d qlen=%d k=%d threshold=%s draws=%d" % (
+        args.rows, args.cols, args.hashes, args.batch, args.qlen, args.k, repr(float(args.threshold)), args.and_draws)
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            ent = json.load(f).get(wkey)
+        if ent:
+            traffic, traffic_src = ent["traffic_bytes_per_launch"], ent["source"]
+    except OSError:
+        pass
+
     verified = None
     if not args.no_verify and rank == 0:
         # planted round trip on every shard + one sampled query against the oracle on this rank's shard
@@ -194,7 +207,7 @@ def main():
                 "index_fill_s": fill_s, "verified": verified,
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "k_and_exact" if exact else "k_and_count",
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_and_exact" if exact else "k_and_count",
                          "alg_bytes_per_launch": alg_bytes, "kernel_ms": and_ms, "launches_timed": int(stats.and_launches),
                          "kmerize_ms": stats.kmerize_ms / max(stats.kmerize_launches, 1),
                          "compact_ms": stats.compact_ms / max(stats.compact_launches, 1)},
