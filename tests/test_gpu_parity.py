@@ -393,3 +393,58 @@ def test_size_independent_properties(hip):
         assert nu[i] <= nu2[i] <= nu[i] + 30 and d.min() >= 0 and d.max() <= 30
     rep.close()
     st.delete_all()
+
+
+def test_gathered_compaction_two_shards_on_one_gpu(hip):
+    """Everything of the multi-GPU exchange except the RCCL call: two column shards run one after the other on this GPU,
+    each writing its per-sample vectors into its slot of a [shard][seq][stride] buffer (bigsi_hip_batch_set_outputs), then
+    bigsi_hip_batch_compact_gathered over the whole buffer; hits must equal the oracle's on the concatenated index."""
+    import torch
+    from bigsi_amd import _lib
+    from oracle.ref_model import SynthOracle
+    m, shard_cols, h, world = 6007, 1000, 3, 2
+    rng = np.random.default_rng(11)
+    seqs = random_seqs(rng, 6, 31, 300) + ["ACGT" * 30]
+    shards, orcs = [], []
+    for g in range(world):
+        c, st = synth_index(hip, m, shard_cols, h, 321, shard=g, draws=1)
+        orc = SynthOracle(321, g, m, shard_cols, h, 31, 1)
+        st.insert_kmers(5 + 3 * g, [seqs[0]], 31)
+        orc.insert_kmers(5 + 3 * g, seqs[0])
+        shards.append(st)
+        orcs.append(orc)
+    wv_pad = (-(-shard_cols // 64) + 1) // 2 * 2
+    for thr in (1.0, 0.3):
+        exact = thr == 1.0
+        stride = wv_pad * 8 if exact else wv_pad * 64 * 2
+        buf = torch.zeros((world, len(seqs) * stride), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        batches = []
+        for g, st in enumerate(shards):
+            b = st.new_batch(seqs, 31)
+            slot = buf[g].data_ptr()
+            _lib.check(_lib.lib().bigsi_hip_batch_set_outputs(b.b, slot if exact else None, None if exact else slot))
+            b.run(thr, skip_compact=True)
+            _lib.check(_lib.lib().bigsi_hip_synchronize(st.handle))
+            batches.append(b)
+        b0 = batches[0]
+        _lib.check(_lib.lib().bigsi_hip_batch_compact_gathered(b0.b, buf.data_ptr(), world, shard_cols))
+        off = np.zeros(len(seqs) + 1, np.uint64)
+        col = np.zeros(1 << 16, np.uint32)
+        cnt = np.zeros(1 << 16, np.uint32)
+        _lib.check(_lib.lib().bigsi_hip_batch_fetch_gathered_hits(b0.b, _lib.ptr(off), _lib.ptr(col), _lib.ptr(cnt), col.size))
+        _, nu, mk = b0.unique()
+        for i, s in enumerate(seqs):
+            want_cnt = np.concatenate([o.counts(s)[1] for o in orcs])
+            want = np.flatnonzero(want_cnt >= (nu[i] if exact else mk[i]))
+            lo, hi = int(off[i]), int(off[i + 1])
+            assert np.array_equal(col[lo:hi], want), (thr, i)
+            assert np.array_equal(cnt[lo:hi], want_cnt[want].astype(np.uint32))
+        # a shard's own (local) hit list is still available after a skip_compact run
+        loff, lcol, _ = batches[1].hits()
+        want1 = np.flatnonzero(orcs[1].counts(seqs[0])[1] >= (nu[0] if exact else mk[0]))
+        assert np.array_equal(lcol[int(loff[0]):int(loff[1])], want1)
+        for b in batches:
+            b.close()
+    for st in shards:
+        st.delete_all()
