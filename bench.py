@@ -158,6 +158,20 @@ def main():
     and_ms = stats.and_ms / max(stats.and_launches, 1)
     achieved = alg_bytes / (and_ms * 1e-3) / 1e9
 
+    # PCIe-inclusive rate of the host-buffer boundary (never `value`): sequences in host memory -> batch_create (H2D) ->
+    # run -> fetch_hits (D2H), a few repetitions outside the timed region
+    pcie_rate = None
+    if world == 1:
+        reps = 3
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            b2 = st.new_batch(seqs, args.k)
+            b2.run(args.threshold)
+            b2.hits()
+            b2.close()
+        pcie_rate = total_unique * reps / (time.perf_counter() - t1)
+
     # HBM traffic of this kernel on this workload, when a PMC pass for it has been committed (PMC counters cannot be
     # collected from inside the timed run; see profiles/)
     traffic, traffic_src = None, None
@@ -205,6 +219,7 @@ def main():
                 "batch": args.batch, "qlen": args.qlen, "unique_kmers_per_batch": total_unique, "hits_last_step": int(off[-1]),
                 "kmer_lookups_per_s_full_index": per_rank_rate, "parallelism": "column-shard x%d + RCCL all-gather" % world,
                 "index_fill_s": fill_s, "verified": verified,
+                "pcie_inclusive_kmer_lookups_per_s": pcie_rate,
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_and_exact" if exact else "k_and_count",

@@ -95,6 +95,15 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise BigsiHipError(ERR_STATE, "%s is missing: build it with bigsi_amd/csrc/build.sh "
                                            "(or python -c 'import __graft_entry__ as g; g.build()')" % LIB_PATH)
+        # One process must hold ONE HIP runtime.  PyTorch-ROCm wheels bundle their own libamdhip64; if this library pulls
+        # in /opt/rocm's copy first, a later `import torch` finds "No HIP GPUs".  Loading torch first (when it is
+        # installed) makes both share torch's copy, which is what the multi-GPU path (torch.distributed/RCCL) needs
+        # anyway.  BIGSI_HIP_NO_TORCH=1 skips this for torch-free deployments.
+        if not os.environ.get("BIGSI_HIP_NO_TORCH"):
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)      # AttributeError here = header and library out of sync

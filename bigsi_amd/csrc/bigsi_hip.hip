@@ -476,6 +476,7 @@ struct bigsi_hip_batch {
     std::vector<uint64_t> seq_off, pos_off, tab_off;
     uint64_t total_pos = 0, max_pos = 0;
     DevBuf seqs, d_seq_off, d_pos_off, d_tab_off, tab, first_pos, pos_unique, tmp, rows, num_kmers, num_unique, min_kmers;
+    DevBuf pos_query, hsh, rep;   // per k-mer position: owning sequence, dedupe hash, class representative
     DevBuf bitmaps, counts, scratch;
     void *ext_bitmaps = nullptr, *ext_counts = nullptr;
     HitBufs hits, ghits;
@@ -539,6 +540,9 @@ extern "C" int bigsi_hip_batch_create(bigsi_hip_index *ix, const char *seqs, con
     R(b->first_pos, T * 4);
     R(b->pos_unique, T * 4);
     R(b->tmp, T * 4);
+    R(b->pos_query, T * 4);
+    R(b->hsh, T * 4);
+    R(b->rep, T * 4);
     R(b->rows, T * ix->h * 8);
     R(b->num_kmers, n_seqs * 4ull);
     R(b->num_unique, n_seqs * 4ull);
@@ -553,6 +557,10 @@ extern "C" int bigsi_hip_batch_create(bigsi_hip_index *ix, const char *seqs, con
     H2D(b->d_seq_off.p, b->seq_off.data(), (n_seqs + 1) * 8ull);
     H2D(b->d_pos_off.p, b->pos_off.data(), (n_seqs + 1) * 8ull);
     H2D(b->d_tab_off.p, b->tab_off.data(), (n_seqs + 1) * 8ull);
+    std::vector<uint32_t> pos_query(b->total_pos);
+    for (uint32_t i = 0; i < n_seqs; i++)
+        std::fill(pos_query.begin() + b->pos_off[i], pos_query.begin() + b->pos_off[i + 1], i);
+    H2D(b->pos_query.p, pos_query.data(), b->total_pos * 4);
     if (rc == BIGSI_OK) {
         hipError_t e = hipStreamSynchronize(ix->stream);
         if (e != hipSuccess) rc = fail(BIGSI_ERR_HIP, "sync: %s", hipGetErrorString(e));
@@ -568,7 +576,7 @@ extern "C" int bigsi_hip_batch_destroy(bigsi_hip_batch *b)
     hipError_t e = hipSetDevice(b->ix->device);
     e = hipStreamSynchronize(b->ix->stream);
     (void)e;
-    for (DevBuf *d : {&b->seqs, &b->d_seq_off, &b->d_pos_off, &b->d_tab_off, &b->tab, &b->first_pos, &b->pos_unique, &b->tmp, &b->rows,
+    for (DevBuf *d : {&b->pos_query, &b->hsh, &b->rep, &b->seqs, &b->d_seq_off, &b->d_pos_off, &b->d_tab_off, &b->tab, &b->first_pos, &b->pos_unique, &b->tmp, &b->rows,
                       &b->num_kmers, &b->num_unique, &b->min_kmers, &b->bitmaps, &b->counts, &b->scratch})
         d->release();
     b->hits.release();
@@ -615,10 +623,23 @@ static int run_kmerize(bigsi_hip_batch *b, double threshold)
     TRY(b->rows.reserve(std::max<uint64_t>(b->total_pos, 1) * ix->h * 8));
     HIP_TRY(hipMemsetAsync(b->tab.p, 0xFF, b->tab_off[b->n_seqs] * 4, ix->stream));
     TRY(ev_begin(ix, &ep));
-    hipLaunchKernelGGL(k_kmerize, dim3(b->n_seqs), dim3(kBlock), 0, ix->stream, b->seqs.as<char>(), b->d_seq_off.as<uint64_t>(),
-                       b->d_pos_off.as<uint64_t>(), b->d_tab_off.as<uint64_t>(), b->tab.as<uint32_t>(), b->k, ix->h, ix->m, threshold,
-                       b->first_pos.as<uint32_t>(), b->pos_unique.as<uint32_t>(), b->tmp.as<uint32_t>(), b->rows.as<uint64_t>(),
+    const uint64_t T = b->total_pos;
+    const unsigned pgrid = (unsigned)ceil_div(std::max<uint64_t>(T, 1), kBlock);
+    if (T) {
+        hipLaunchKernelGGL(k_kmer_insert, dim3(pgrid), dim3(kBlock), 0, ix->stream, b->seqs.as<char>(), b->d_seq_off.as<uint64_t>(),
+                           b->d_pos_off.as<uint64_t>(), b->pos_query.as<uint32_t>(), b->d_tab_off.as<uint64_t>(), b->tab.as<uint32_t>(),
+                           b->k, T, b->hsh.as<uint32_t>());
+        hipLaunchKernelGGL(k_kmer_resolve, dim3(pgrid), dim3(kBlock), 0, ix->stream, b->seqs.as<char>(), b->d_seq_off.as<uint64_t>(),
+                           b->d_pos_off.as<uint64_t>(), b->pos_query.as<uint32_t>(), b->d_tab_off.as<uint64_t>(), b->tab.as<uint32_t>(),
+                           b->k, T, b->hsh.as<uint32_t>(), b->rep.as<uint32_t>());
+    }
+    hipLaunchKernelGGL(k_kmer_rank, dim3(b->n_seqs), dim3(kBlock), 0, ix->stream, b->d_seq_off.as<uint64_t>(), b->d_pos_off.as<uint64_t>(),
+                       b->rep.as<uint32_t>(), b->k, threshold, b->first_pos.as<uint32_t>(), b->tmp.as<uint32_t>(), b->pos_unique.as<uint32_t>(),
                        b->num_kmers.as<uint32_t>(), b->num_unique.as<uint32_t>(), b->min_kmers.as<uint32_t>());
+    if (T)
+        hipLaunchKernelGGL(k_kmer_rows, dim3(pgrid), dim3(kBlock), 0, ix->stream, b->seqs.as<char>(), b->d_seq_off.as<uint64_t>(),
+                           b->d_pos_off.as<uint64_t>(), b->pos_query.as<uint32_t>(), b->rep.as<uint32_t>(), b->tmp.as<uint32_t>(), b->k, ix->h,
+                           ix->m, T, b->rows.as<uint64_t>());
     HIP_TRY(hipGetLastError());
     TRY(ev_end(ix, &ep, ix->ev_km));
     b->run_h = ix->h;

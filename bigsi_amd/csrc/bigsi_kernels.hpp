@@ -6,7 +6,7 @@
 // ((c>>3)&7)*8 + 7-(c&7).  AND / popcount / bit-sliced addition are agnostic to that permutation; it is
 // only applied where set bits become colour ids (compaction, counter expansion).
 //
-// Kernels: K1 k_kmerize, K2/K3a k_and_exact, K2/K3b k_and_count,
+// Kernels: K1 k_kmer_insert/resolve/rank/rows, K2/K3a k_and_exact, K2/K3b k_and_count,
 // K4 k_chunk_hits_* / k_scan_chunks / k_write_hits_*, K5 k_presence, plus lookup / storage / build helpers.
 // All bitwise, HBM-bound work: no MFMA.  Wavefront = 64 lanes everywhere.
 #pragma once
@@ -132,90 +132,130 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *t
 }
 
 // ------------------------------------------------------------------------------ K1: k-merise + dedupe + hash
-// One workgroup per query sequence.  Restates, per sequence:
+// Restates, per query sequence:
 //   seq_to_kmers (bigsi/utils/fncts.py:63-65)          every window of k bytes, no validation;
 //   set(kmers) (bigsi/graph/index.py:45, graph/bigsi.py:179)  unique *query strings* (a k-mer and its reverse
 //                                                       complement are two), kept in first-occurrence order;
 //   canonical + generate_hashes (fncts.py:51-54, bloom/bloomfilter.py:5-13, graph/index.py:62-70)
 //                                                       h row ids per unique k-mer, seeds 0..h-1;
 //   min_kmers = ceil(u * threshold) (graph/bigsi.py:179) in IEEE double, as Python evaluates it.
-// Dedupe: open-addressing table of positions in global scratch, keyed by string equality, class
-// representative = smallest position (deterministic whatever the atomics' order).
-__global__ __launch_bounds__(kBlock) void k_kmerize(
+// Four launches, the three string-heavy ones with ONE THREAD PER K-MER POSITION of the whole batch (a 256 x 1 kbp batch
+// is 248k positions: the chip is full, where one workgroup per query left 252 of 256 CUs with 4 waves each):
+//   K1a k_kmer_insert   open-addressing table of positions per query (global scratch), keyed by string equality; the
+//                       slot converges to the smallest position of its class (deterministic whatever the atomics' order)
+//   K1b k_kmer_resolve  every position reads its class representative
+//   K1c k_kmer_rank     one workgroup per query: ordered compaction of representatives -> unique index, u, min_kmers
+//   K1d k_kmer_rows     representatives: canonical form, MurmurHash3 with seeds 0..h-1, floor-mod m -> row ids
+struct PosRef {
+    uint32_t q, i;
+    const char *s;
+};
+__device__ __forceinline__ PosRef locate(uint64_t p, const uint32_t *__restrict__ pos_query, const uint64_t *__restrict__ pos_off,
+                                         const char *__restrict__ seqs, const uint64_t *__restrict__ seq_off)
+{
+    const uint32_t q = pos_query[p];
+    return PosRef{q, (uint32_t)(p - pos_off[q]), seqs + seq_off[q]};
+}
+
+__device__ __forceinline__ uint32_t fnv1a(const char *s, uint32_t k)
+{
+    uint32_t h = 2166136261u;
+    for (uint32_t j = 0; j < k; j++) h = (h ^ (uint8_t)s[j]) * 16777619u;
+    return h ^ (h >> 15);
+}
+
+__device__ __forceinline__ bool kmer_equal(const char *a, const char *b, uint32_t k)
+{
+    for (uint32_t j = 0; j < k; j++)
+        if (a[j] != b[j]) return false;
+    return true;
+}
+
+__global__ __launch_bounds__(kBlock) void k_kmer_insert(
     const char *__restrict__ seqs, const uint64_t *__restrict__ seq_off, const uint64_t *__restrict__ pos_off,
-    const uint64_t *__restrict__ tab_off, uint32_t *__restrict__ tab, uint32_t k, uint32_t h, uint64_t m, double threshold,
-    uint32_t *__restrict__ first_pos, uint32_t *__restrict__ pos_unique, uint32_t *__restrict__ tmp,
-    uint64_t *__restrict__ rows, uint32_t *__restrict__ num_kmers, uint32_t *__restrict__ num_unique,
-    uint32_t *__restrict__ min_kmers)
+    const uint32_t *__restrict__ pos_query, const uint64_t *__restrict__ tab_off, uint32_t *__restrict__ tab,
+    uint32_t k, uint64_t total_pos, uint32_t *__restrict__ hsh)
+{
+    const uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (p >= total_pos) return;
+    const PosRef r = locate(p, pos_query, pos_off, seqs, seq_off);
+    uint32_t *t = tab + tab_off[r.q];
+    const uint32_t mask = (uint32_t)(tab_off[r.q + 1] - tab_off[r.q]) - 1u;   // table size: power of two >= 2n
+    const uint32_t hv = fnv1a(r.s + r.i, k);
+    hsh[p] = hv;
+    uint32_t slot = hv & mask;
+    for (;;) {
+        const uint32_t cur = atomicCAS(&t[slot], kEmpty, r.i);
+        if (cur == kEmpty) break;
+        if (kmer_equal(r.s + cur, r.s + r.i, k)) { atomicMin(&t[slot], r.i); break; }
+        slot = (slot + 1) & mask;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_kmer_resolve(
+    const char *__restrict__ seqs, const uint64_t *__restrict__ seq_off, const uint64_t *__restrict__ pos_off,
+    const uint32_t *__restrict__ pos_query, const uint64_t *__restrict__ tab_off, const uint32_t *__restrict__ tab,
+    uint32_t k, uint64_t total_pos, const uint32_t *__restrict__ hsh, uint32_t *__restrict__ rep)
+{
+    const uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (p >= total_pos) return;
+    const PosRef r = locate(p, pos_query, pos_off, seqs, seq_off);
+    const uint32_t *t = tab + tab_off[r.q];
+    const uint32_t mask = (uint32_t)(tab_off[r.q + 1] - tab_off[r.q]) - 1u;
+    uint32_t slot = hsh[p] & mask;
+    uint32_t c;
+    for (;;) {
+        c = t[slot];      // the table is final: written by the previous launch
+        if (c == r.i || kmer_equal(r.s + c, r.s + r.i, k)) break;
+        slot = (slot + 1) & mask;
+    }
+    rep[p] = c;
+}
+
+__global__ __launch_bounds__(kBlock) void k_kmer_rank(
+    const uint64_t *__restrict__ seq_off, const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ rep,
+    uint32_t k, double threshold, uint32_t *__restrict__ first_pos, uint32_t *__restrict__ uidx, uint32_t *__restrict__ pos_unique,
+    uint32_t *__restrict__ num_kmers, uint32_t *__restrict__ num_unique, uint32_t *__restrict__ min_kmers)
 {
     __shared__ uint32_t lds[kBlock / 64 + 1];
     const uint32_t q = blockIdx.x;
-    const char *s = seqs + seq_off[q];
     const uint64_t len = seq_off[q + 1] - seq_off[q];
     const uint32_t n = len >= k ? (uint32_t)(len - k + 1) : 0u;
     const uint64_t P = pos_off[q];
-    uint32_t *t = tab + tab_off[q];
-    const uint32_t mask = (uint32_t)(tab_off[q + 1] - tab_off[q]) - 1u;   // table size is a power of two >= 2n
-    uint32_t *fp = first_pos + P, *pu = pos_unique + P, *tm = tmp + P;
-
-    // phase 1: insert every position; slot value converges to the smallest position of its string class
-    for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
-        uint32_t hsh = 2166136261u;
-        for (uint32_t j = 0; j < k; j++) hsh = (hsh ^ (uint8_t)s[i + j]) * 16777619u;
-        uint32_t slot = (hsh ^ (hsh >> 15)) & mask;
-        for (;;) {
-            uint32_t cur = atomicCAS(&t[slot], kEmpty, i);
-            if (cur == kEmpty) break;
-            bool eq = true;
-            for (uint32_t j = 0; j < k; j++)
-                if (s[cur + j] != s[i + j]) { eq = false; break; }
-            if (eq) { atomicMin(&t[slot], i); break; }
-            slot = (slot + 1) & mask;
-        }
-    }
-    __syncthreads();
-    // phase 2: representative of every position
-    for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
-        uint32_t hsh = 2166136261u;
-        for (uint32_t j = 0; j < k; j++) hsh = (hsh ^ (uint8_t)s[i + j]) * 16777619u;
-        uint32_t slot = (hsh ^ (hsh >> 15)) & mask;
-        uint32_t rep;
-        for (;;) {
-            rep = __hip_atomic_load(&t[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            bool eq = true;
-            for (uint32_t j = 0; j < k; j++)
-                if (s[rep + j] != s[i + j]) { eq = false; break; }
-            if (eq) break;
-            slot = (slot + 1) & mask;
-        }
-        pu[i] = rep;
-    }
-    __syncthreads();
-    // phase 3: ordered compaction of class representatives -> unique k-mers in first-occurrence order
+    const uint32_t *rp = rep + P;
+    uint32_t *fp = first_pos + P, *ux = uidx + P, *pu = pos_unique + P;
     uint32_t u = 0;
     for (uint32_t base = 0; base < n; base += kBlock) {
         const uint32_t i = base + threadIdx.x;
-        const uint32_t flag = (i < n && pu[i] == i) ? 1u : 0u;
+        const uint32_t flag = (i < n && rp[i] == i) ? 1u : 0u;
         uint32_t tot;
         const uint32_t pre = block_exclusive_scan(flag, &tot, lds);
-        if (flag) { fp[u + pre] = i; tm[i] = u + pre; }
+        if (flag) { fp[u + pre] = i; ux[i] = u + pre; }
         u += tot;
     }
     __syncthreads();
-    // phase 4: position -> index of its unique k-mer (for presence strings, graph/bigsi.py:233)
-    for (uint32_t i = threadIdx.x; i < n; i += kBlock) pu[i] = tm[pu[i]];
+    for (uint32_t i = threadIdx.x; i < n; i += kBlock) pu[i] = ux[rp[i]];   // position -> its unique k-mer (graph/bigsi.py:233)
     if (threadIdx.x == 0) {
         num_kmers[q] = n;
         num_unique[q] = u;
-        min_kmers[q] = (uint32_t)ceil((double)u * threshold);   // one IEEE multiply, as Python's int*float
+        const double mk = ceil((double)u * threshold);      // one IEEE multiply, as Python's int * float
+        min_kmers[q] = mk > 0.0 ? (uint32_t)mk : 0u;          // counts are >= 0, so a negative bound behaves like 0
     }
-    // phase 5: canonical k-mer -> h row ids
-    uint64_t *qrows = rows + P * h;
-    for (uint32_t j = threadIdx.x; j < u; j += kBlock) {
-        const char *km = s + fp[j];
-        KmerView v{km, k, use_revcomp(km, k)};
-        for (uint32_t sd = 0; sd < h; sd++) qrows[(uint64_t)j * h + sd] = row_of_hash(murmur3_32(v, sd), m);
-    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_kmer_rows(
+    const char *__restrict__ seqs, const uint64_t *__restrict__ seq_off, const uint64_t *__restrict__ pos_off,
+    const uint32_t *__restrict__ pos_query, const uint32_t *__restrict__ rep, const uint32_t *__restrict__ uidx,
+    uint32_t k, uint32_t h, uint64_t m, uint64_t total_pos, uint64_t *__restrict__ rows)
+{
+    const uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (p >= total_pos) return;
+    const PosRef r = locate(p, pos_query, pos_off, seqs, seq_off);
+    if (rep[p] != r.i) return;        // duplicates of an earlier window contribute nothing
+    const char *km = r.s + r.i;
+    const KmerView v{km, k, use_revcomp(km, k)};
+    uint64_t *dst = rows + (pos_off[r.q] + uidx[p]) * h;
+    for (uint32_t sd = 0; sd < h; sd++) dst[sd] = row_of_hash(murmur3_32(v, sd), m);
 }
 
 // ------------------------------------------------------------------------------ K2 work decomposition
