@@ -44,6 +44,8 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample (0 = skip)")
     p.add_argument("--cpu-rows", type=int, default=200_000)
     p.add_argument("--no-verify", action="store_true")
+    p.add_argument("--force-dist", action="store_true",
+                   help="initialise the RCCL process group and take the gather path even with one rank (exercises the N>1 code)")
     return p.parse_args()
 
 
@@ -94,9 +96,11 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     exact = args.threshold == 1.0
     # ---------------- index: this rank's column shard, generated on the device
@@ -117,13 +121,13 @@ def main():
     for j, qi in enumerate(planted):
         st.insert_kmers((1009 * (j + 1) + 13 * rank) % args.cols, [seqs[qi]], args.k)
     batch = st.new_batch(seqs, args.k)
-    sh = ShardedSearch(st, args.cols, device=dev)          # also moves the library onto torch's current stream
+    sh = ShardedSearch(st, args.cols, device=dev, force_gather=args.force_dist)   # puts the library on a torch stream
     count_bytes = 2 if (args.qlen - args.k + 1) < 65536 else 4
     sh.prepare(batch, exact, count_bytes)
     check(_lib.lib().bigsi_hip_set_profiling(st.handle, 1))
 
     def sync_all():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -139,7 +143,7 @@ def main():
         sh.step(batch, args.threshold)
     sync_all()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -161,7 +165,7 @@ def main():
     # PCIe-inclusive rate of the host-buffer boundary (never `value`): sequences in host memory -> batch_create (H2D) ->
     # run -> fetch_hits (D2H), a few repetitions outside the timed region
     pcie_rate = None
-    if world == 1:
+    if world == 1 and not args.force_dist:
         reps = 3
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
@@ -204,6 +208,7 @@ def main():
             assert u == nu[qi] and np.array_equal(got0, want), "oracle mismatch on query %d" % qi
         verified = "planted round trip on %d shard(s) + 2 queries bit-exact vs oracle" % world
 
+    line = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         per_rank_rate = total_unique / (elapsed / args.steps)
@@ -227,14 +232,20 @@ def main():
                          "kmerize_ms": stats.kmerize_ms / max(stats.kmerize_launches, 1),
                          "compact_ms": stats.compact_ms / max(stats.compact_launches, 1)},
         }
-        if args.cpu_seconds > 0:
+        if args.cpu_seconds > 0 and world == 1:        # reported at N=1 only
             line["cpu_baseline"] = cpu_baseline(args, seqs, exact)
-        print(json.dumps(line), flush=True)
     batch.close()
     st.delete_all()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints a version banner through C stdio (block-buffered when stdout is a pipe/file): flush it out first so
+        # that the JSON line is the last thing on stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -625,10 +625,17 @@ static int run_kmerize(bigsi_hip_batch *b, double threshold)
     TRY(ev_begin(ix, &ep));
     const uint64_t T = b->total_pos;
     const unsigned pgrid = (unsigned)ceil_div(std::max<uint64_t>(T, 1), kBlock);
+#define BIGSI_K1_INSERT(KF)                                                                                                   \
+    hipLaunchKernelGGL((k_kmer_insert<KF>), dim3(pgrid), dim3(kBlock), 0, ix->stream, b->seqs.as<char>(), b->d_seq_off.as<uint64_t>(), \
+                       b->d_pos_off.as<uint64_t>(), b->pos_query.as<uint32_t>(), b->d_tab_off.as<uint64_t>(), b->tab.as<uint32_t>(), \
+                       b->k, T, b->hsh.as<uint32_t>())
+#define BIGSI_K1_ROWS(KF)                                                                                                     \
+    hipLaunchKernelGGL((k_kmer_rows<KF>), dim3(pgrid), dim3(kBlock), 0, ix->stream, b->seqs.as<char>(), b->d_seq_off.as<uint64_t>(), \
+                       b->d_pos_off.as<uint64_t>(), b->pos_query.as<uint32_t>(), b->rep.as<uint32_t>(), b->tmp.as<uint32_t>(), b->k, \
+                       ix->h, ix->m, T, b->rows.as<uint64_t>())
     if (T) {
-        hipLaunchKernelGGL(k_kmer_insert, dim3(pgrid), dim3(kBlock), 0, ix->stream, b->seqs.as<char>(), b->d_seq_off.as<uint64_t>(),
-                           b->d_pos_off.as<uint64_t>(), b->pos_query.as<uint32_t>(), b->d_tab_off.as<uint64_t>(), b->tab.as<uint32_t>(),
-                           b->k, T, b->hsh.as<uint32_t>());
+        if (b->k == 31) BIGSI_K1_INSERT(31);
+        else BIGSI_K1_INSERT(0);
         hipLaunchKernelGGL(k_kmer_resolve, dim3(pgrid), dim3(kBlock), 0, ix->stream, b->seqs.as<char>(), b->d_seq_off.as<uint64_t>(),
                            b->d_pos_off.as<uint64_t>(), b->pos_query.as<uint32_t>(), b->d_tab_off.as<uint64_t>(), b->tab.as<uint32_t>(),
                            b->k, T, b->hsh.as<uint32_t>(), b->rep.as<uint32_t>());
@@ -636,10 +643,12 @@ static int run_kmerize(bigsi_hip_batch *b, double threshold)
     hipLaunchKernelGGL(k_kmer_rank, dim3(b->n_seqs), dim3(kBlock), 0, ix->stream, b->d_seq_off.as<uint64_t>(), b->d_pos_off.as<uint64_t>(),
                        b->rep.as<uint32_t>(), b->k, threshold, b->first_pos.as<uint32_t>(), b->tmp.as<uint32_t>(), b->pos_unique.as<uint32_t>(),
                        b->num_kmers.as<uint32_t>(), b->num_unique.as<uint32_t>(), b->min_kmers.as<uint32_t>());
-    if (T)
-        hipLaunchKernelGGL(k_kmer_rows, dim3(pgrid), dim3(kBlock), 0, ix->stream, b->seqs.as<char>(), b->d_seq_off.as<uint64_t>(),
-                           b->d_pos_off.as<uint64_t>(), b->pos_query.as<uint32_t>(), b->rep.as<uint32_t>(), b->tmp.as<uint32_t>(), b->k, ix->h,
-                           ix->m, T, b->rows.as<uint64_t>());
+    if (T) {
+        if (b->k == 31) BIGSI_K1_ROWS(31);
+        else BIGSI_K1_ROWS(0);
+    }
+#undef BIGSI_K1_INSERT
+#undef BIGSI_K1_ROWS
     HIP_TRY(hipGetLastError());
     TRY(ev_end(ix, &ep, ix->ev_km));
     b->run_h = ix->h;

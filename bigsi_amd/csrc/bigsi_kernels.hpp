@@ -164,6 +164,64 @@ __device__ __forceinline__ uint32_t fnv1a(const char *s, uint32_t k)
     return h ^ (h >> 15);
 }
 
+// Compile-time k (KF = 31, the reference's default k, bigsi/constants.py:13): the window is loaded once into registers
+// with KF independent byte loads and everything after that (dedupe hash, canonical choice, MurmurHash3 x h) is
+// straight-line register code.  KF = 0 is the generic run-time-k path.
+template <int KF>
+struct RegKmer {
+    uint8_t f[KF > 0 ? KF : 1];
+    __device__ __forceinline__ void load(const char *s)
+    {
+#pragma unroll
+        for (int j = 0; j < KF; j++) f[j] = (uint8_t)s[j];
+    }
+    __device__ __forceinline__ uint32_t fnv() const
+    {
+        uint32_t h = 2166136261u;
+#pragma unroll
+        for (int j = 0; j < KF; j++) h = (h ^ f[j]) * 16777619u;
+        return h ^ (h >> 15);
+    }
+    // canonical form packed into little-endian words (utils/fncts.py:51-54)
+    __device__ __forceinline__ void canonical_words(uint32_t (&w)[(KF + 3) / 4 > 0 ? (KF + 3) / 4 : 1]) const
+    {
+        bool rc = false, decided = false;
+#pragma unroll
+        for (int j = 0; j < KF; j++) {
+            const uint8_t a = f[j], b = complement(f[KF - 1 - j]);
+            if (!decided && a != b) { rc = b < a; decided = true; }
+        }
+#pragma unroll
+        for (int i = 0; i < (KF + 3) / 4; i++) w[i] = 0;
+#pragma unroll
+        for (int j = 0; j < KF; j++) {
+            const uint8_t c = rc ? complement(f[KF - 1 - j]) : f[j];
+            w[j >> 2] |= (uint32_t)c << (8 * (j & 3));
+        }
+    }
+};
+
+// MurmurHash3_x86_32 over KF bytes already packed in words (tail bytes in the low bits of the last word)
+template <int KF>
+__device__ __forceinline__ uint32_t murmur3_words(const uint32_t *w, uint32_t seed)
+{
+    const uint32_t c1 = 0xcc9e2d51u, c2 = 0x1b873593u;
+    uint32_t h1 = seed;
+#pragma unroll
+    for (int i = 0; i < KF / 4; i++) {
+        uint32_t k1 = w[i];
+        k1 *= c1; k1 = rotl32(k1, 15); k1 *= c2;
+        h1 ^= k1; h1 = rotl32(h1, 13); h1 = h1 * 5u + 0xe6546b64u;
+    }
+    if (KF & 3) {
+        uint32_t k1 = w[KF / 4];
+        k1 *= c1; k1 = rotl32(k1, 15); k1 *= c2; h1 ^= k1;
+    }
+    h1 ^= (uint32_t)KF;
+    h1 ^= h1 >> 16; h1 *= 0x85ebca6bu; h1 ^= h1 >> 13; h1 *= 0xc2b2ae35u; h1 ^= h1 >> 16;
+    return h1;
+}
+
 __device__ __forceinline__ bool kmer_equal(const char *a, const char *b, uint32_t k)
 {
     for (uint32_t j = 0; j < k; j++)
@@ -171,6 +229,7 @@ __device__ __forceinline__ bool kmer_equal(const char *a, const char *b, uint32_
     return true;
 }
 
+template <int KF>
 __global__ __launch_bounds__(kBlock) void k_kmer_insert(
     const char *__restrict__ seqs, const uint64_t *__restrict__ seq_off, const uint64_t *__restrict__ pos_off,
     const uint32_t *__restrict__ pos_query, const uint64_t *__restrict__ tab_off, uint32_t *__restrict__ tab,
@@ -181,7 +240,14 @@ __global__ __launch_bounds__(kBlock) void k_kmer_insert(
     const PosRef r = locate(p, pos_query, pos_off, seqs, seq_off);
     uint32_t *t = tab + tab_off[r.q];
     const uint32_t mask = (uint32_t)(tab_off[r.q + 1] - tab_off[r.q]) - 1u;   // table size: power of two >= 2n
-    const uint32_t hv = fnv1a(r.s + r.i, k);
+    uint32_t hv;
+    if (KF > 0) {
+        RegKmer<KF> km;
+        km.load(r.s + r.i);
+        hv = km.fnv();
+    } else {
+        hv = fnv1a(r.s + r.i, k);
+    }
     hsh[p] = hv;
     uint32_t slot = hv & mask;
     for (;;) {
@@ -243,6 +309,7 @@ __global__ __launch_bounds__(kBlock) void k_kmer_rank(
     }
 }
 
+template <int KF>
 __global__ __launch_bounds__(kBlock) void k_kmer_rows(
     const char *__restrict__ seqs, const uint64_t *__restrict__ seq_off, const uint64_t *__restrict__ pos_off,
     const uint32_t *__restrict__ pos_query, const uint32_t *__restrict__ rep, const uint32_t *__restrict__ uidx,
@@ -253,9 +320,17 @@ __global__ __launch_bounds__(kBlock) void k_kmer_rows(
     const PosRef r = locate(p, pos_query, pos_off, seqs, seq_off);
     if (rep[p] != r.i) return;        // duplicates of an earlier window contribute nothing
     const char *km = r.s + r.i;
-    const KmerView v{km, k, use_revcomp(km, k)};
     uint64_t *dst = rows + (pos_off[r.q] + uidx[p]) * h;
-    for (uint32_t sd = 0; sd < h; sd++) dst[sd] = row_of_hash(murmur3_32(v, sd), m);
+    if (KF > 0) {
+        RegKmer<KF> reg;
+        reg.load(km);
+        uint32_t w[(KF + 3) / 4 > 0 ? (KF + 3) / 4 : 1];
+        reg.canonical_words(w);
+        for (uint32_t sd = 0; sd < h; sd++) dst[sd] = row_of_hash(murmur3_words<KF>(w, sd), m);
+    } else {
+        const KmerView v{km, k, use_revcomp(km, k)};
+        for (uint32_t sd = 0; sd < h; sd++) dst[sd] = row_of_hash(murmur3_32(v, sd), m);
+    }
 }
 
 // ------------------------------------------------------------------------------ K2 work decomposition
@@ -484,21 +559,33 @@ __global__ __launch_bounds__(kBlock) void k_hits_count(
         if (c0 + j < shard_cols && c[j] >= thr) { hit_col[o] = (uint32_t)(cbase + j); hit_cnt[o] = c[j]; o++; }
 }
 
-// exclusive scan of chunk_hits (n entries) by one workgroup; also hit_off[q] for every sequence and the total.
+// exclusive scan of chunk_hits (n entries) by one workgroup, kScanItems consecutive entries per thread per round;
+// also hit_off[q] for every sequence and the total.
+constexpr int kScanItems = 16;
 __global__ __launch_bounds__(kBlock) void k_scan_chunks(
     const uint32_t *__restrict__ chunk_hits, uint64_t n, uint32_t per_seq, uint32_t n_seqs,
     uint64_t *__restrict__ chunk_off, uint64_t *__restrict__ hit_off)
 {
     __shared__ uint32_t lds[kBlock / 64 + 1];
     uint64_t carry = 0;
-    for (uint64_t base = 0; base < n; base += kBlock) {
-        const uint64_t i = base + threadIdx.x;
-        const uint32_t v = i < n ? chunk_hits[i] : 0u;
+    for (uint64_t base = 0; base < n; base += (uint64_t)kBlock * kScanItems) {
+        const uint64_t i0 = base + (uint64_t)threadIdx.x * kScanItems;
+        uint32_t v[kScanItems], sum = 0;
+#pragma unroll
+        for (int j = 0; j < kScanItems; j++) {
+            v[j] = i0 + j < n ? chunk_hits[i0 + j] : 0u;
+            sum += v[j];
+        }
         uint32_t tot;
-        const uint32_t pre = block_exclusive_scan(v, &tot, lds);
-        if (i < n) {
-            chunk_off[i] = carry + pre;
-            if (i % per_seq == 0) hit_off[i / per_seq] = carry + pre;
+        uint64_t run = carry + block_exclusive_scan(sum, &tot, lds);
+#pragma unroll
+        for (int j = 0; j < kScanItems; j++) {
+            const uint64_t i = i0 + j;
+            if (i < n) {
+                chunk_off[i] = run;
+                if (i % per_seq == 0) hit_off[i / per_seq] = run;
+            }
+            run += v[j];
         }
         carry += tot;
     }

@@ -49,7 +49,7 @@ class ShardGroup(object):
 
     def all_gather_in_place(self, buf):
         """buf: [world, bytes]; slot [rank] already holds this rank's result."""
-        if self.world == 1:
+        if not self.dist.is_initialized():
             return buf
         self.dist.all_gather_into_tensor(buf.view(-1), buf[self.rank].clone() if buf.device.type == "cpu" else buf[self.rank],
                                          group=self.group)
@@ -63,9 +63,10 @@ class ShardedSearch(object):
     issued under it, so kernel -> all-gather -> compaction are ordered by torch's usual stream semantics.  (torch's
     default stream has handle 0, which the C ABI reserves for "use the library's private stream".)"""
 
-    def __init__(self, storage, shard_cols, group=None, device=None):
+    def __init__(self, storage, shard_cols, group=None, device=None, force_gather=False):
         import torch
         self.torch = torch
+        self.force_gather = force_gather      # take the all-gather path even with one rank (testing)
         self.storage = storage
         self.shard_cols = int(shard_cols)
         self.sg = ShardGroup(group)
@@ -95,7 +96,7 @@ class ShardedSearch(object):
 
     def step(self, batch, threshold):
         """Asynchronous: local K1-K3 (+K4 when alone), all-gather of the per-sample vectors, K4 over the gathered result."""
-        if self.sg.world == 1:
+        if self.sg.world == 1 and not self.force_gather:
             batch.run(threshold)
             return self._buf
         with self.torch.cuda.stream(self.stream):
@@ -105,7 +106,7 @@ class ShardedSearch(object):
         return self._buf
 
     def fetch(self, batch):
-        if self.sg.world == 1:
+        if self.sg.world == 1 and not self.force_gather:
             return batch.hits()
         off = np.zeros(batch.n + 1, np.uint64)
         cap = 1 << 12

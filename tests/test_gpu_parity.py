@@ -448,3 +448,95 @@ def test_gathered_compaction_two_shards_on_one_gpu(hip):
             b.close()
     for st in shards:
         st.delete_all()
+
+
+def test_full_size_c3_properties(hip):
+    """BASELINE configs[2] at full size (10M rows x 100k samples, h=4, 1 kbp queries; 125 GB of HBM): size-independent
+    properties + one query recomputed by the oracle from the synthetic generator."""
+    from bigsi_amd._lib import BigsiHipError
+    from oracle.ref_model import SynthOracle
+    m, n_cols, h = 10_000_000, 100_000, 4
+    try:
+        c, st = synth_index(hip, m, n_cols, h, 20260928)
+    except BigsiHipError as e:
+        pytest.skip("cannot hold the 125 GB index on this device: %s" % e)
+    rng = np.random.default_rng(1)
+    base = random_seqs(rng, 8, 1000, 1000)
+    comp = str.maketrans("ACGT", "TGCA")
+    seqs = base + [s[::-1].translate(comp) for s in base[:4]]
+    st.insert_kmers(99_999, [base[0]], 31)      # last column: the ragged final word
+    st.insert_kmers(31_337, [base[1]], 31)
+    batch = st.new_batch(seqs, 31)
+    batch.run(0.4)
+    _, nu, mk = batch.unique()
+    assert (nu[:8] == 970).all() and (mk == 388).all()
+    cnts = [batch.counts(i) for i in range(len(seqs))]
+    off, colours, counts = batch.hits()
+    assert colours[int(off[0]):int(off[1])].tolist() == [99_999] and counts[int(off[0])] == 970
+    assert colours[int(off[1]):int(off[2])].tolist() == [31_337]
+    for i in range(4):
+        assert np.array_equal(cnts[i], cnts[8 + i])                     # strand symmetry
+    for i in range(2, 8):
+        assert off[i + 1] == off[i] and cnts[i].max() < 388            # random queries: no sample near the threshold
+    batch.run(1.0)
+    off, colours, _ = batch.hits()
+    for i in range(len(seqs)):
+        assert np.array_equal(colours[int(off[i]):int(off[i + 1])], np.flatnonzero(cnts[i] == nu[i]))
+    orc = SynthOracle(20260928, 0, m, n_cols, h, 31, 2)
+    orc.insert_kmers(99_999, base[0])
+    u, cnt = orc.counts(base[0])
+    assert u == 970 and np.array_equal(cnts[0], cnt.astype(np.uint32))
+    batch.close()
+    st.delete_all()
+
+
+def test_many_hits_regrow_and_threshold_zero(hip):
+    """threshold 0 returns EVERY sample (count >= 0), far beyond the device hit buffers' initial capacity (65536): the
+    write pass must be re-run after growing them, and the lists must still be complete and ordered."""
+    from oracle.ref_model import SynthOracle
+    m, n_cols, h = 5003, 40000, 2
+    c, st = synth_index(hip, m, n_cols, h, 8, draws=1)
+    orc = SynthOracle(8, 0, m, n_cols, h, 31, 1)
+    seqs = random_seqs(np.random.default_rng(2), 5, 40, 60)
+    batch = st.new_batch(seqs, 31)
+    batch.run(0.0)
+    off, colours, counts = batch.hits()
+    assert int(off[-1]) == n_cols * len(seqs)
+    for i, s in enumerate(seqs):
+        _, cnt = orc.counts(s)
+        assert np.array_equal(colours[int(off[i]):int(off[i + 1])], np.arange(n_cols))
+        assert np.array_equal(counts[int(off[i]):int(off[i + 1])], cnt.astype(np.uint32))
+    batch.run(0.5)          # and back to a small list with the big buffers still around
+    off, colours, counts = batch.hits()
+    for i, s in enumerate(seqs):
+        u, cnt = orc.counts(s)
+        assert np.array_equal(colours[int(off[i]):int(off[i + 1])], np.flatnonzero(cnt >= int(np.ceil(u * 0.5))))
+    batch.close()
+    st.delete_all()
+
+
+@pytest.mark.parametrize("k", [1, 4, 32, 33, 45, 64])
+def test_other_kmer_sizes_vs_oracle(hip, k):
+    """run-time-k kernels (everything except the k=31 specialisation), including k > 32 and the 4-byte-block/tail
+    boundaries of MurmurHash3."""
+    from bigsi_amd.storage import get_storage
+    from oracle.ref_model import SynthOracle
+    m, n_cols, h = 3001, 300, 3
+    c = cfg(k, m, h, max_cols=n_cols)
+    st = get_storage(c)
+    st.delete_all()
+    for key, v in (("number_of_rows", m), ("number_of_cols", n_cols), ("ksi:bloomfilter_size", m), ("ksi:num_hashes", h)):
+        st.set_integer(key, v)
+    st.fill_synthetic(k, 0, 1)
+    orc = SynthOracle(k, 0, m, n_cols, h, k, 1)
+    seqs = random_seqs(np.random.default_rng(k), 6, max(k, 2), 150) + ["ACGTN" * 30, "A" * (k + 5)]
+    st.insert_kmers(3, [seqs[0]], k)
+    orc.insert_kmers(3, seqs[0])
+    batch = st.new_batch(seqs, k)
+    batch.run(0.6)
+    _, nu, mk = batch.unique()
+    for i, s in enumerate(seqs):
+        u, cnt = orc.counts(s)
+        assert nu[i] == u and np.array_equal(batch.counts(i), cnt.astype(np.uint32)), (k, i)
+    batch.close()
+    st.delete_all()
