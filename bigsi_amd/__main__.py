@@ -1,0 +1,84 @@
+"""`python -m bigsi_amd <command>`: the query-side commands of the reference CLI (bigsi/__main__.py:103-320) on the
+hip-hbm backend.  argparse instead of hug; same command names, arguments and output text."""
+import argparse
+import os
+import sys
+
+import yaml
+
+from . import BIGSI
+from .bitrow import BitRow
+from .frontend import bulk_search, read_fasta, search
+from .graph.bigsi import DEFAULT_CONFIG
+from .storage import get_storage
+from .utils import seq_to_kmers
+
+
+def get_config_from_file(config_file):            # __main__.py:86-94
+    config_file = config_file or os.environ.get("BIGSI_CONFIG")
+    if not config_file:
+        return DEFAULT_CONFIG
+    with open(config_file) as f:
+        return yaml.safe_load(f)
+
+
+def main(argv=None):
+    p = argparse.ArgumentParser(prog="bigsi_amd")
+    sub = p.add_subparsers(dest="cmd", required=True)
+
+    def common(sp):
+        sp.add_argument("--config", "-c", default=None)
+        return sp
+
+    sp = common(sub.add_parser("search"))
+    sp.add_argument("seq")
+    sp.add_argument("--threshold", "-t", type=float, default=1.0)
+    sp.add_argument("--score", action="store_true")
+    sp.add_argument("--format", choices=["json", "csv"], default="json")
+    sp = common(sub.add_parser("bulk_search"))
+    sp.add_argument("fasta")
+    sp.add_argument("--threshold", "-t", type=float, default=1.0)
+    sp.add_argument("--score", action="store_true")
+    sp.add_argument("--format", choices=["json", "csv"], default="json")
+    sp.add_argument("--stream", action="store_true")
+    sp = common(sub.add_parser("bloom", help="Bloom filter of the k-mers of a FASTA file or a one-k-mer-per-line text file"))
+    sp.add_argument("infile")
+    sp.add_argument("outfile")
+    sp = common(sub.add_parser("build"))
+    sp.add_argument("--bloomfilters", "-b", action="append", default=[])
+    sp.add_argument("--samples", "-s", action="append", default=[])
+    sp = common(sub.add_parser("insert"))
+    sp.add_argument("bloomfilter")
+    sp.add_argument("sample")
+    common(sub.add_parser("delete"))
+    a = p.parse_args(argv)
+    config = get_config_from_file(a.config)
+
+    if a.cmd == "search":
+        print(search(BIGSI(config), a.seq, a.threshold, a.score, a.format))
+    elif a.cmd == "bulk_search":
+        text = bulk_search(BIGSI(config), a.fasta, a.threshold, a.score, a.format, a.stream)
+        if text is not None:
+            print(text)
+    elif a.cmd == "bloom":
+        first = open(a.infile).read(1)
+        if first == ">":
+            kmers = [km for _, s in read_fasta(a.infile) for km in seq_to_kmers(s, config["k"])]
+        else:
+            kmers = [l.strip() for l in open(a.infile) if l.strip()]
+        with open(a.outfile, "wb") as f:
+            f.write(BIGSI.bloom(config, kmers).tobytes())
+    elif a.cmd == "build":
+        blooms = [BitRow.frombytes(open(b, "rb").read(), config["m"]) for b in a.bloomfilters]
+        BIGSI.build(config, blooms, a.samples)
+        print('{"result": "success"}')
+    elif a.cmd == "insert":
+        BIGSI(config).insert(BitRow.frombytes(open(a.bloomfilter, "rb").read(), config["m"]), a.sample)
+        print('{"result": "success"}')
+    elif a.cmd == "delete":
+        get_storage(config).delete_all()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

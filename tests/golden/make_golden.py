@@ -423,6 +423,75 @@ def g8_storage():
     dump("g8_storage.json", out)
 
 
+# ------------------------- G9: the reference's own front-end (bigsi/__main__.py) -- search / bulk_search text output
+def g9_frontend():
+    """Runs bigsi.__main__.bigsi().search / .bulk_search unmodified.  Extra stand-ins, import-time only:
+    `hug` (used purely as decorators / type annotations: a permissive object whose calls return the decorated function),
+    `pyfasta.Fasta` (dict of record name -> sequence in file order), `humanfriendly` (unused on this path)."""
+    import contextlib
+    import io
+    import tempfile
+
+    import yaml
+
+    class _Any(object):
+        def __getattr__(self, name):
+            return _Any()
+
+        def __call__(self, *a, **k):
+            if len(a) == 1 and callable(a[0]) and not k and not isinstance(a[0], _Any):
+                return a[0]
+            return _Any()
+
+    sys.modules["hug"] = _Any()
+    sys.modules["humanfriendly"] = types.ModuleType("humanfriendly")
+    pyfasta = types.ModuleType("pyfasta")
+
+    class Fasta(dict):
+        def __init__(self, path):
+            dict.__init__(self, read_fasta(path))
+
+    pyfasta.Fasta = Fasta
+    sys.modules["pyfasta"] = pyfasta
+    import bigsi.__main__ as ref_main
+
+    c = cfg("g9", 31, 1000, 3)
+    c["nproc"] = 1
+    ref_storage.get_storage(c).delete_all()
+    base = [l.strip() for l in open(os.path.join(REF, "bigsi/tests/data/test_kmers.txt")) if l.strip()]
+    q_example = read_fasta(os.path.join(REF, "example-data/query.fasta"))
+    q_test = read_fasta(os.path.join(REF, "bigsi/tests/data/query.fasta"))
+    samples = {"s1": base, "s2": base[:50] + list(seq_to_kmers(q_example[0][1], 31)),
+               'we,ird "name"': list(seq_to_kmers(q_test[0][1], 31)) + list(seq_to_kmers(q_example[3][1], 31))}
+    blooms = [BIGSI.bloom(c, ks) for ks in samples.values()]
+    BIGSI.build(c, blooms, list(samples.keys()))
+    out = {"k": 31, "m": 1000, "h": 3, "samples": samples, "cases": []}
+    fastas = {"example": os.path.join(REF, "example-data/query.fasta"), "tests": os.path.join(REF, "bigsi/tests/data/query.fasta")}
+    out["fasta_text"] = {k: open(v).read() for k, v in fastas.items()}
+    with tempfile.TemporaryDirectory() as td:
+        cf = os.path.join(td, "c.yaml")
+        with open(cf, "w") as f:
+            yaml.safe_dump(c, f)
+        api = ref_main.bigsi()
+        for thr in (1.0, 0.4):
+            for score in (False, True):
+                for fmt in ("json", "csv"):
+                    for seq in (base[0] + base[1][:5], q_test[0][1], q_example[0][1][:80]):
+                        out["cases"].append({"cmd": "search", "seq": seq, "threshold": thr, "score": score, "format": fmt,
+                                             "out": api.search(seq, thr, cf, score, fmt)})
+                    for fname, fpath in fastas.items():
+                        if score and fname == "example" and thr != 0.4:
+                            continue      # keep the fixture small: 20 records x presence strings
+                        out["cases"].append({"cmd": "bulk_search", "fasta": fname, "threshold": thr, "score": score, "format": fmt,
+                                             "stream": False, "out": api.bulk_search(fpath, thr, cf, score, fmt, False)})
+                        buf = io.StringIO()
+                        with contextlib.redirect_stdout(buf):
+                            ret = api.bulk_search(fpath, thr, cf, score, fmt, True)
+                        out["cases"].append({"cmd": "bulk_search", "fasta": fname, "threshold": thr, "score": score, "format": fmt,
+                                             "stream": True, "out": ret, "stdout": buf.getvalue()})
+    dump("g9_frontend.json", out, indent=None)
+
+
 if __name__ == "__main__":
     g1_hash()
     g2_lookup()
@@ -432,3 +501,4 @@ if __name__ == "__main__":
     g6_arith()
     g7_random()
     g8_storage()
+    g9_frontend()

@@ -1,0 +1,123 @@
+"""Front-end text output (search / bulk_search, JSON + CSV + streaming) against goldens captured from the reference's
+own bigsi.__main__ (tests/golden/g9_frontend.json).  CPU part: formatting with a stub index that replays the golden
+results; GPU part: the whole thing end to end on the device."""
+import io
+import json
+
+import pytest
+
+from conftest import load_golden, unjson
+
+
+def _golden_results(g):
+    """(seq, threshold, score) -> result list, recovered from the golden JSON outputs."""
+    table = {}
+    for c in g["cases"]:
+        if c["format"] != "json":
+            continue
+        if c["cmd"] == "search":
+            d = json.loads(c["out"])
+            table[(d["query"], c["threshold"], c["score"])] = d["results"]
+        elif not c["stream"]:
+            for d in json.loads(c["out"]):
+                table[(d["query"], c["threshold"], c["score"])] = d["results"]
+    return table
+
+
+class ReplayIndex(object):
+    def __init__(self, table):
+        self.table = table
+
+    def search(self, seq, threshold=1.0, score=False):
+        return self.table[(seq, threshold, score)]
+
+    def search_batch(self, seqs, threshold=1.0, score=False):
+        return [self.table[(s, threshold, score)] for s in seqs]
+
+
+def _run_cases(index, g, tmp_path, compare):
+    from bigsi_amd import frontend
+    paths = {}
+    for name, text in g["fasta_text"].items():
+        p = tmp_path / (name + ".fasta")
+        p.write_text(text)
+        paths[name] = str(p)
+    n = 0
+    for c in g["cases"]:
+        if c["cmd"] == "search":
+            got = frontend.search(index, c["seq"], c["threshold"], c["score"], c["format"])
+            compare(got, c["out"], c)
+        else:
+            buf = io.StringIO()
+            got = frontend.bulk_search(index, paths[c["fasta"]], c["threshold"], c["score"], c["format"], c["stream"], out=buf)
+            compare(got, c["out"], c)
+            if c["stream"]:
+                compare(buf.getvalue(), c["stdout"], c)
+        n += 1
+    assert n == len(g["cases"]) and n > 40
+
+
+def test_frontend_formatting_replay(tmp_path):
+    g = load_golden("g9_frontend.json")
+
+    def same(got, want, c):
+        assert got == want, (c["cmd"], c.get("fasta"), c["threshold"], c["score"], c["format"], c.get("stream"))
+
+    _run_cases(ReplayIndex(_golden_results(g)), g, tmp_path, same)
+
+
+def test_read_fasta(tmp_path):
+    from bigsi_amd.frontend import read_fasta
+    p = tmp_path / "a.fa"
+    p.write_text(">r1 desc\nACGT\nAC\n\n>r2\nGG\n>empty\n")
+    assert read_fasta(str(p)) == [("r1 desc", "ACGTAC"), ("r2", "GG"), ("empty", "")]
+
+
+@pytest.mark.gpu
+def test_frontend_end_to_end_on_device(tmp_path):
+    import bigsi_amd
+    from conftest import FLOAT_TOL_KEYS
+    g = load_golden("g9_frontend.json")
+    cfg = {"storage-engine": "hip-hbm", "storage-config": {"name": "g9"}, "k": g["k"], "m": g["m"], "h": g["h"]}
+    blooms = [bigsi_amd.BIGSI.bloom(cfg, ks) for ks in g["samples"].values()]
+    b = bigsi_amd.BIGSI.build(cfg, blooms, list(g["samples"].keys()))
+
+    def same(got, want, c):
+        if got == want:
+            return
+        # the only permitted difference: last-ulp evalue/pvalue digits inside score dicts (see conftest.FLOAT_TOL_KEYS)
+        assert c["score"] and c["format"] == "json", (c["cmd"], c["threshold"], c["format"])
+        def strip(x):
+            if isinstance(x, dict):
+                return {k: strip(v) for k, v in x.items() if k not in FLOAT_TOL_KEYS}
+            if isinstance(x, list):
+                return [strip(v) for v in x]
+            return x
+        parse = (lambda t: [json.loads(l) for l in t.splitlines()]) if c.get("stream") else json.loads
+        assert strip(parse(got)) == strip(parse(want))
+
+    cases = dict(g)
+    # csv with score embeds evalue/pvalue digits too: compare those through the json cases only
+    cases["cases"] = [c for c in g["cases"] if not (c["score"] and c["format"] == "csv")]
+    n_all = len(g["cases"])
+    try:
+        from bigsi_amd import frontend
+        paths = {}
+        for name, text in g["fasta_text"].items():
+            p = tmp_path / (name + ".fasta")
+            p.write_text(text)
+            paths[name] = str(p)
+        for c in cases["cases"]:
+            if c["cmd"] == "search":
+                same(frontend.search(b, c["seq"], c["threshold"], c["score"], c["format"]), c["out"], c)
+            else:
+                buf = io.StringIO()
+                got = frontend.bulk_search(b, paths[c["fasta"]], c["threshold"], c["score"], c["format"], c["stream"], out=buf)
+                if c["stream"]:
+                    assert got is None
+                    same(buf.getvalue(), c["stdout"], c)
+                else:
+                    same(got, c["out"], c)
+        assert n_all > 40
+    finally:
+        b.delete()
