@@ -63,6 +63,8 @@ SIGNATURES = {
     "bigsi_hip_clear": (_i32, [_P]),
     "bigsi_hip_insert_column": (_i32, [_P, _u64, _P]),
     "bigsi_hip_get_column": (_i32, [_P, _u64, _P]),
+    "bigsi_hip_insert_columns": (_i32, [_P, _u64, _u64, _P, _u64]),
+    "bigsi_hip_append_index": (_i32, [_P, _P]),
     "bigsi_hip_insert_kmers": (_i32, [_P, _u64, C.c_char_p, _P, _u32, _u32]),
     "bigsi_hip_fill_synthetic": (_i32, [_P, _u64, _u64, _u32]),
     "bigsi_hip_bloom": (_i32, [_i32, C.c_char_p, _u64, _u32, _u64, _u32, _u32, _P]),

@@ -324,6 +324,52 @@ extern "C" int bigsi_hip_insert_column(bigsi_hip_index *ix, uint64_t col, const 
     return BIGSI_OK;
 }
 
+extern "C" int bigsi_hip_insert_columns(bigsi_hip_index *ix, uint64_t col0, uint64_t n, const uint8_t *blooms, uint64_t bloom_stride_bytes)
+{
+    if (!ix || (n && !blooms)) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    if (n == 0) return BIGSI_OK;
+    const uint64_t nb = ceil_div(ix->m, 8);
+    if (bloom_stride_bytes < nb) return fail(BIGSI_ERR_INVALID, "bloom_stride_bytes %llu < ceil(num_rows/8) = %llu", (unsigned long long)bloom_stride_bytes, (unsigned long long)nb);
+    if (col0 > ix->n_cols) return fail(BIGSI_ERR_RANGE, "column %llu beyond num_cols %llu", (unsigned long long)col0, (unsigned long long)ix->n_cols);
+    if (col0 + n > ix->cap_cols) return fail(BIGSI_ERR_CAPACITY, "columns [%llu,%llu) beyond col_capacity %llu", (unsigned long long)col0, (unsigned long long)(col0 + n), (unsigned long long)ix->cap_cols);
+    TRY(use_device(ix));
+    // stage at most ~256 MB of filters per launch
+    const uint64_t per = std::max<uint64_t>(1, (256ull << 20) / nb);
+    for (uint64_t c0 = 0; c0 < n; c0 += per) {
+        const uint64_t cn = std::min(per, n - c0);
+        TRY(ix->stage.reserve(cn * nb));
+        HIP_TRY(hipMemcpy2DAsync(ix->stage.p, nb, blooms + c0 * bloom_stride_bytes, bloom_stride_bytes, nb, cn, hipMemcpyHostToDevice, ix->stream));
+        const uint64_t items = ix->m * (((col0 + c0 + cn - 1) >> 6) - ((col0 + c0) >> 6) + 1);
+        const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(items, kBlock), 256 * 32);
+        hipLaunchKernelGGL(k_insert_columns, dim3(grid), dim3(kBlock), 0, ix->stream, ix->d_index, ix->stride_words, ix->m, col0 + c0, cn,
+                           ix->stage.as<uint8_t>(), nb);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(ix->stream));
+    }
+    if (col0 + n > ix->n_cols) ix->n_cols = col0 + n;
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_append_index(bigsi_hip_index *dst, const bigsi_hip_index *src)
+{
+    if (!dst || !src) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    if (dst == src) return fail(BIGSI_ERR_INVALID, "cannot append an index to itself");
+    if (dst->m != src->m) return fail(BIGSI_ERR_INVALID, "row counts differ (%llu vs %llu)", (unsigned long long)dst->m, (unsigned long long)src->m);
+    if (dst->device != src->device) return fail(BIGSI_ERR_INVALID, "both indexes must live on the same device");
+    if (src->n_cols == 0) return BIGSI_OK;
+    TRY(bigsi_hip_reserve_cols(dst, dst->n_cols + src->n_cols));
+    TRY(use_device(dst));
+    HIP_TRY(hipStreamSynchronize(src->stream));
+    const uint64_t per_row = ceil_div(dst->n_cols + src->n_cols, 8) - (dst->n_cols >> 3);
+    const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(dst->m * per_row, kBlock), 256 * 32);
+    hipLaunchKernelGGL(k_append_columns, dim3(grid), dim3(kBlock), 0, dst->stream, (uint8_t *)dst->d_index, dst->stride_words * 8, dst->n_cols,
+                       (const uint8_t *)src->d_index, src->stride_words * 8, src->n_cols, dst->m);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(dst->stream));
+    dst->n_cols += src->n_cols;
+    return BIGSI_OK;
+}
+
 extern "C" int bigsi_hip_get_column(bigsi_hip_index *ix, uint64_t col, uint8_t *out)
 {
     if (!ix || !out) return fail(BIGSI_ERR_INVALID, "NULL argument");

@@ -690,6 +690,57 @@ __global__ __launch_bounds__(kBlock) void k_get_column(
     }
 }
 
+// transpose (bigsi/matrix/transpose.py:33-43) on the device: n Bloom filters (bloom c at blooms + c*bloom_stride, m bits,
+// row byte format) become columns [col0, col0+n) of the matrix.  One thread per (row, 64-column word); the 8 threads of
+// 8 consecutive rows read the same Bloom byte (one L1 line per wave), the word is read-modified-written once.
+__global__ __launch_bounds__(kBlock) void k_insert_columns(
+    uint64_t *__restrict__ index, uint64_t stride_words, uint64_t m, uint64_t col0, uint64_t ncols,
+    const uint8_t *__restrict__ blooms, uint64_t bloom_stride)
+{
+    const uint64_t w0 = col0 >> 6, nwords = ((col0 + ncols - 1) >> 6) - w0 + 1;
+    const uint64_t total = m * nwords;
+    for (uint64_t item = (uint64_t)blockIdx.x * kBlock + threadIdx.x; item < total; item += (uint64_t)gridDim.x * kBlock) {
+        const uint64_t r = item % m, w = w0 + item / m;
+        const uint64_t clo = col0 > w * 64 ? col0 : w * 64;
+        const uint64_t chi = col0 + ncols < w * 64 + 64 ? col0 + ncols : w * 64 + 64;
+        uint64_t mask = 0, val = 0;
+        for (uint64_t c = clo; c < chi; c++) {
+            const uint64_t bit = (blooms[(c - col0) * bloom_stride + (r >> 3)] >> (7 - (r & 7))) & 1u;
+            const uint32_t b = bit_of_col((uint32_t)(c & 63u));
+            mask |= 1ull << b;
+            val |= bit << b;
+        }
+        uint64_t *p = index + r * stride_words + w;
+        *p = (*p & ~mask) | val;
+    }
+}
+
+// merge_indexes (bigsi/graph/index.py:54-60): append the n2 columns of src after the n1 columns of dst, row by row,
+// device to device.  One thread per (row, destination byte); bits are MSB-first inside a byte, so a column offset that
+// is not a multiple of 8 is a bit shift across source bytes.
+__global__ __launch_bounds__(kBlock) void k_append_columns(
+    uint8_t *__restrict__ dst, uint64_t dst_stride, uint64_t n1, const uint8_t *__restrict__ src, uint64_t src_stride,
+    uint64_t n2, uint64_t m)
+{
+    const uint64_t j0 = n1 >> 3, j1 = (n1 + n2 + 7) >> 3, per_row = j1 - j0;
+    const uint64_t total = m * per_row;
+    for (uint64_t item = (uint64_t)blockIdx.x * kBlock + threadIdx.x; item < total; item += (uint64_t)gridDim.x * kBlock) {
+        const uint64_t r = item / per_row, j = j0 + item % per_row;
+        uint8_t *d = dst + r * dst_stride + j;
+        const uint8_t *sr = src + r * src_stride;
+        uint32_t v = 0;
+        for (uint32_t t = 0; t < 8; t++) {
+            const uint64_t c = j * 8 + t;
+            uint32_t bit;
+            if (c < n1) bit = (*d >> (7 - t)) & 1u;
+            else if (c < n1 + n2) { const uint64_t sc = c - n1; bit = (sr[sc >> 3] >> (7 - (sc & 7))) & 1u; }
+            else bit = 0;
+            v |= bit << (7 - t);
+        }
+        *d = (uint8_t)v;
+    }
+}
+
 // Bloom-add k-mers to one sample column of the transposed matrix (bloom/bloomfilter.py:25-32 + graph/bigsi.py:151).
 __global__ __launch_bounds__(kBlock) void k_insert_kmers(
     uint64_t *__restrict__ index, uint64_t stride_words, uint64_t m, uint32_t h, uint64_t col,

@@ -94,6 +94,29 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
         storage.close()
         return cls(config)
 
+    @classmethod
+    def build_from_sequences(cls, config, samples):
+        """Build an index straight from sequences, no Bloom files and no transpose: `samples` maps sample name ->
+        list of sequences; every k-mer of every sequence is Bloom-added to that sample's column on the device
+        (k_insert_kmers = BIGSI.bloom + build of the reference, graph/bigsi.py:150-172, fused).  Same rows as
+        build(config, [bloom(config, kmers of s) for s in samples], names)."""
+        storage = get_storage(config)
+        names = list(samples.keys())
+        SampleMetadata(storage).add_samples(names)
+        storage.set_integer("ksi:bloomfilter_size", config["m"])
+        storage.set_integer("ksi:num_hashes", config["h"])
+        storage.set_integer("number_of_rows", config["m"])
+        storage.set_integer("number_of_cols", len(names))
+        storage.res.ensure_open()
+        storage.res.written[:] = True
+        for colour, name in enumerate(names):
+            seqs = [samples[name]] if isinstance(samples[name], str) else list(samples[name])
+            if seqs:
+                storage.insert_kmers(colour, seqs, config["k"])
+        storage.sync()
+        storage.close()
+        return cls(config)
+
     def insert(self, bloomfilter, sample):
         logger.warning("Build and merge is preferable to insert in most cases")
         colour = self.add_sample(sample)

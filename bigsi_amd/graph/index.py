@@ -7,7 +7,6 @@ import numpy as np
 
 from ..bitrow import BitRow, row_bytes_of
 from ..matrix import BitMatrix
-from ..matrix.transpose import transpose_packed
 
 BLOOMFILTER_SIZE_KEY = "ksi:bloomfilter_size"
 NUM_HASH_FUNCTS_KEY = "ksi:num_hashes"
@@ -34,11 +33,21 @@ class KmerSignatureIndex(object):
         storage.set_integer(BLOOMFILTER_SIZE_KEY, bloomfilter_size)
         storage.set_integer(NUM_HASH_FUNCTS_KEY, num_hashes)
         storage.set_integer("number_of_rows", bloomfilter_size)
-        packed = transpose_packed(blooms, bloomfilter_size)                 # m x ceil(N/8)
-        if packed.shape[1]:
-            storage.set_rows_packed(0, packed)
-        else:
-            storage.set_rows_packed(0, np.zeros((bloomfilter_size, 1), np.uint8))
+        storage.set_integer("number_of_cols", 0)
+        # transpose on the device, a slab of filters at a time (the reference materialises an N x m bool array,
+        # matrix/transpose.py:37-40)
+        nb = (int(bloomfilter_size) + 7) // 8
+        slab = max(64, ((128 << 20) // max(nb, 1)) // 64 * 64)
+        for c0 in range(0, len(blooms), slab):
+            part = blooms[c0:c0 + slab]
+            arr = np.zeros((len(part), nb), dtype=np.uint8)
+            for i, bf in enumerate(part):
+                data = np.frombuffer(row_bytes_of(bf)[0], dtype=np.uint8)[:nb]
+                arr[i, : data.size] = data
+            storage.insert_columns(c0, arr)
+        if not blooms:
+            storage.res.ensure_open()
+            storage.res.written[:] = True
         storage.set_integer("number_of_cols", len(blooms))
         storage.sync()
         return cls(storage)
@@ -55,14 +64,19 @@ class KmerSignatureIndex(object):
         self.bitmatrix.insert_column(bloomfilter, column_index)
 
     def merge_indexes(self, ksi):
-        """Append the other index's columns to every row (graph/index.py:54-60), in row blocks through the host."""
+        """Append the other index's columns to every row (graph/index.py:54-60): one device-to-device kernel when both
+        live on the same GPU, else in row blocks through the host."""
         n1, n2 = self.bitmatrix.num_cols, ksi.bitmatrix.num_cols
-        m = self.bloomfilter_size
-        rb1, rb2 = (n1 + 7) // 8, (n2 + 7) // 8
-        step = max(1, (32 << 20) // max(rb1 + rb2, 1))
-        for r0 in range(0, m, step):
-            ids = np.arange(r0, min(m, r0 + step), dtype=np.uint64)
-            a = np.unpackbits(self.storage.get_rows_packed(ids, max(rb1, 1)), axis=1)[:, :n1]
-            b = np.unpackbits(ksi.storage.get_rows_packed(ids, max(rb2, 1)), axis=1)[:, :n2]
-            self.storage.set_rows_packed(r0, np.packbits(np.concatenate([a, b], axis=1), axis=1))
+        same_gpu = getattr(ksi.storage, "fused", False) and ksi.storage.res.device == self.storage.res.device
+        if same_gpu:
+            self.storage.append_from(ksi.storage)
+        else:
+            m = self.bloomfilter_size
+            rb1, rb2 = (n1 + 7) // 8, (n2 + 7) // 8
+            step = max(1, (32 << 20) // max(rb1 + rb2, 1))
+            for r0 in range(0, m, step):
+                ids = np.arange(r0, min(m, r0 + step), dtype=np.uint64)
+                a = np.unpackbits(self.storage.get_rows_packed(ids, max(rb1, 1)), axis=1)[:, :n1]
+                b = np.unpackbits(np.stack([np.frombuffer(r.tobytes(), np.uint8) for r in ksi.bitmatrix.get_rows(ids, False)]), axis=1)[:, :n2]
+                self.storage.set_rows_packed(r0, np.packbits(np.concatenate([a, b], axis=1), axis=1))
         self.bitmatrix.set_num_cols(n1 + n2)

@@ -253,6 +253,27 @@ class HipHbmStorage(BaseStorage):
         res.written[:] = True
         res.kv[b"number_of_cols:int"] = str(int(res.info().num_cols)).encode()
 
+    def insert_columns(self, col0, blooms):
+        """n Bloom filters (uint8[n, >= ceil(m/8)]) -> columns [col0, col0+n): the transpose runs on the device."""
+        res = self.res
+        if not res.ensure_open():
+            raise KeyError("number_of_rows:int")
+        blooms = np.ascontiguousarray(blooms, dtype=np.uint8)
+        n, need = blooms.shape[0], (res.m + 7) // 8
+        if blooms.shape[1] < need:
+            blooms = np.concatenate([blooms, np.zeros((n, need - blooms.shape[1]), np.uint8)], axis=1)
+        if col0 + n > res.info().col_capacity:
+            check(_lib.lib().bigsi_hip_reserve_cols(res.ix, col0 + n))
+        check(_lib.lib().bigsi_hip_insert_columns(res.ix, int(col0), n, _lib.ptr(blooms), blooms.shape[1]))
+        res.written[:] = True
+        res.kv[b"number_of_cols:int"] = str(int(res.info().num_cols)).encode()
+
+    def append_from(self, other):
+        """Append every column of another resident hip-hbm index (same device, same m), device to device."""
+        check(_lib.lib().bigsi_hip_append_index(self.handle, other.handle))
+        self.res.written[:] = True
+        self.res.kv[b"number_of_cols:int"] = str(int(self.res.info().num_cols)).encode()
+
     def get_column(self, col):
         res = self.res
         out = np.zeros((res.m + 7) // 8, dtype=np.uint8)

@@ -86,6 +86,13 @@ int bigsi_hip_clear(bigsi_hip_index *ix); /* delete_all (bigsi/storage/base.py:1
  * bloom = one sample's Bloom filter, ceil(num_rows/8) bytes in the row format above (bit r = row r);
  * writes bit `col` of every row.  col may equal num_cols (append; num_cols grows by one). */
 int bigsi_hip_insert_column(bigsi_hip_index *ix, uint64_t col, const uint8_t *bloom);
+/* transpose + BitMatrix.create (bigsi/matrix/transpose.py:33-43, bigsi/graph/index.py:27-40), on the device: n Bloom
+ * filters (filter i at blooms + i*bloom_stride_bytes, ceil(num_rows/8) bytes each) become columns [col0, col0+n).
+ * col0 <= num_cols; num_cols grows to col0+n if that is larger.  Needs col0+n <= col_capacity. */
+int bigsi_hip_insert_columns(bigsi_hip_index *ix, uint64_t col0, uint64_t n, const uint8_t *blooms, uint64_t bloom_stride_bytes);
+/* KmerSignatureIndex.merge_indexes (bigsi/graph/index.py:54-60): append all columns of src after dst's, device to
+ * device (same device, same num_rows); dst's capacity grows as needed. */
+int bigsi_hip_append_index(bigsi_hip_index *dst, const bigsi_hip_index *src);
 /* BitMatrix.get_column (bigsi/matrix/bitmatrix.py:50-61): out = ceil(num_rows/8) bytes. */
 int bigsi_hip_get_column(bigsi_hip_index *ix, uint64_t col, uint8_t *out);
 

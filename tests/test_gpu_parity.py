@@ -540,3 +540,53 @@ def test_other_kmer_sizes_vs_oracle(hip, k):
         assert nu[i] == u and np.array_equal(batch.counts(i), cnt.astype(np.uint32)), (k, i)
     batch.close()
     st.delete_all()
+
+
+def test_device_build_paths(hip):
+    """Three ways to the same matrix: (1) Bloom filters + device transpose (BIGSI.build), (2) straight from sequences
+    (build_from_sequences), (3) the golden rows the reference stored; plus unaligned multi-column inserts and the
+    device-to-device merge at column offsets that are not multiples of 8."""
+    from bigsi_amd.storage import get_storage
+    g = load_golden("g7_random.json")
+    z = np.load(GOLDEN + "/g7_random.npz")
+    k, m, h, N = g["k"], g["m"], g["h"], g["n_cols"]
+    c2 = cfg(k, m, h)
+    b2 = hip.BIGSI.build_from_sequences(c2, {n: [a, b_] for n, (a, b_) in zip(g["sample_names"], g["sample_seqs"])})
+    assert np.array_equal(b2.storage.get_rows_packed(np.arange(m)), z["rows"])
+    assert b2.num_samples == N and b2.colour_to_sample(N - 1) == g["sample_names"][-1]
+    s0 = g["searches"][0]
+    check_search(lambda: b2.search(g["queries"][s0["q"]], s0["threshold"], s0["score"]), s0, "from_sequences")
+    # columns inserted in odd-sized groups at odd offsets == one-shot build
+    blooms = np.stack([np.frombuffer(hip.BIGSI.bloom(c2, seq_kmers(a, k) + seq_kmers(b_, k)).tobytes(), np.uint8)
+                       for a, b_ in g["sample_seqs"]])
+    st = get_storage(cfg(k, m, h, max_cols=8))       # tiny capacity: forces re-striding while columns arrive
+    st.delete_all()
+    st.set_integer("number_of_rows", m)
+    st.set_integer("number_of_cols", 0)
+    c0 = 0
+    for n in (1, 7, 64, 3, 61, 64):
+        st.insert_columns(c0, blooms[c0:c0 + n])
+        c0 += n
+    assert c0 == N and int(st.res.info().num_cols) == N
+    assert np.array_equal(st.get_rows_packed(np.arange(m)), z["rows"])
+    st.insert_columns(5, blooms[100:103])          # overwrite in the middle
+    want = np.unpackbits(z["rows"], axis=1)
+    want[:, 5:8] = np.unpackbits(blooms[100:103], axis=1)[:, :m].T
+    assert np.array_equal(st.get_rows_packed(np.arange(m)), np.packbits(want, axis=1))
+    st.delete_all()
+    # merge: 13 + 200 + 5 columns
+    parts = []
+    for lo, hi in ((0, 13), (13, 200), (195, 200)):
+        cc = cfg(k, m, h)
+        parts.append(hip.BIGSI.build(cc, [hip.BitRow.frombytes(blooms[i].tobytes(), m) for i in range(lo, hi)],
+                                     ["p%d_%d" % (lo, i) for i in range(lo, hi)]))
+    parts[0].merge(parts[1])
+    parts[0].merge(parts[2])
+    cols = list(range(0, 200)) + list(range(195, 200))
+    want = np.packbits(np.unpackbits(z["rows"], axis=1)[:, cols], axis=1)
+    assert parts[0].num_samples == 205 and parts[0].bitmatrix.num_cols == 205
+    assert np.array_equal(parts[0].storage.get_rows_packed(np.arange(m)), want)
+    assert parts[0].colour_to_sample(204) == "p195_199"
+    for p in parts:
+        p.delete()
+    b2.delete()
