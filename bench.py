@@ -55,26 +55,23 @@ def make_queries(batch, qlen, rank_independent_seed=1):
 
 
 def cpu_baseline(args, seqs, exact):
-    """The C oracle (reference-shaped: per-k-mer canonicalisation, MurmurHash3 x h, per-row copy + AND, then AND-all or
-    unpack-to-int32-and-add), single thread, on a bounded sample of the SAME queries.  The index keeps the full row
-    width (per-lookup work identical to the GPU run) but only --cpu-rows rows, so that it fits host RAM."""
-    from oracle import coracle
-    m = min(args.rows, args.cpu_rows)
-    t0 = time.time()
-    table = coracle.synth_fill(SEED, 0, 0, m, args.cols, args.and_draws)
-    fill_s = time.time() - t0
-    done_kmers, t_query, nq = 0, 0.0, 0
-    while t_query < args.cpu_seconds:              # cycle through the bench queries until the time budget is used
-        s = seqs[nq % len(seqs)]
-        t1 = time.time()
-        u, _, _ = coracle.query(table, args.hashes, s, args.k, want_counts=not exact, want_and=exact)
-        t_query += time.time() - t1
-        done_kmers += u
-        nq += 1
-    return {"value": done_kmers / t_query, "unit": "kmer_lookups/s", "cores": 1, "kind": "port",
-            "sample": "%d query executions cycling over the %d bench queries (%d unique k-mers, %.1f s) on a %d-row x %d-sample slice of the synthetic "
-                      "index (full row width, rows reduced to fit host RAM; table fill %.1f s not timed); oracle/bigsi_oracle.c orc_query, "
-                      "rows served from RAM instead of BerkeleyDB" % (nq, len(seqs), done_kmers, t_query, m, args.cols, fill_s)}
+    """oracle/cpu_baseline.py in a fresh subprocess (its fork pool must not inherit a HIP context): the C oracle
+    (reference-shaped port) on ONE core -- the reported `value` -- plus, for context, the reference's own
+    process-pool-over-sequences parallelism (bulk_search) on every physical core."""
+    import subprocess
+    half = max(args.cpu_seconds / 2.0, 1.0)
+    cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--rows", str(min(args.rows, args.cpu_rows)),
+           "--cols", str(args.cols), "--hashes", str(args.hashes), "--k", str(args.k), "--and-draws", str(args.and_draws),
+           "--seed", str(SEED), "--batch", str(args.batch), "--qlen", str(args.qlen), "--exact", str(int(exact)),
+           "--seconds", str(half)]
+    r = json.loads(subprocess.run(cmd, check=True, capture_output=True, text=True, timeout=600).stdout.strip().splitlines()[-1])
+    return {"value": r["one_core"]["rate"], "unit": "kmer_lookups/s", "cores": 1, "kind": "port",
+            "sample": "%d unique k-mer lookups in %.1f s cycling over the %d bench queries, on a %d-row x %d-sample slice of the same "
+                      "synthetic index (full row width, rows reduced to fit host RAM); oracle/bigsi_oracle.c orc_query; rows served from RAM "
+                      "instead of BerkeleyDB" % (r["one_core"]["lookups"], r["one_core"]["seconds"], len(seqs), r["rows"], r["cols"]),
+            "pool": {"value": r["pool"]["rate"], "cores": r["pool"]["threads"], "host_threads": r["host_threads"],
+                     "sample": "fork pool over query sequences (the reference's bulk_search parallelism), %d workers x %.1f s"
+                               % (r["pool"]["threads"], r["pool"]["seconds"])}}
 
 
 def main():

@@ -730,14 +730,18 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
         uint64_t *out = (uint64_t *)b->ext_bitmaps;
         if (!out) { TRY(b->bitmaps.reserve((size_t)b->n_seqs * b->wv_pad * 8)); out = b->bitmaps.as<uint64_t>(); }
         TRY(ev_begin(ix, &ep));
+#define COMMA ,
 #define BIGSI_LAUNCH_EXACT(U)                                                                                                  \
     hipLaunchKernelGGL((k_and_exact<U>), dim3(grid), dim3(and_block), 0, ix->stream, ix->d_index, ix->stride_words, (uint32_t)b->wv, \
                        ix->n_cols, b->rows.as<uint64_t>(), b->d_pos_off.as<uint64_t>(), b->num_unique.as<uint32_t>(), ix->h,    \
                        b->n_seqs, tiles, out, b->wv_pad)
+        static const int and_nt = env_int("BIGSI_HIP_AND_NT", 1);     // 0: plain loads (A/B against non-temporal)
         if (and_unroll == 4) BIGSI_LAUNCH_EXACT(4);
         else if (and_unroll == 16) BIGSI_LAUNCH_EXACT(16);
+        else if (!and_nt) BIGSI_LAUNCH_EXACT(8 COMMA false);
         else BIGSI_LAUNCH_EXACT(8);
 #undef BIGSI_LAUNCH_EXACT
+#undef COMMA
         HIP_TRY(hipGetLastError());
         TRY(ev_end(ix, &ep, ix->ev_and));
     } else {

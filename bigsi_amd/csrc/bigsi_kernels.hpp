@@ -354,16 +354,18 @@ __device__ __forceinline__ TileMap map_block(uint32_t b, uint32_t n_seqs, uint32
 
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 
+template <bool NT = true>
 __device__ __forceinline__ u64x2 load_row_seg(const uint64_t *__restrict__ index, uint64_t row, uint64_t stride_words, uint32_t w0)
 {
     const u64x2 *p = reinterpret_cast<const u64x2 *>(index + row * stride_words + w0);
-    return __builtin_nontemporal_load(p);   // streamed once: keep it out of the way of the row-id lists in L2
+    if (NT) return __builtin_nontemporal_load(p);   // streamed once: keep it out of the way of the row-id lists in L2
+    return *p;
 }
 
 // ------------------------------------------------------------------------------ K2 + K3a: exact
 // AND of every row of every unique k-mer of the query (graph/index.py:75-80 then graph/bigsi.py:192-195):
 // out[q][w] for w < wv.  Sequences without k-mers produce an all-zero bitmap (the host shim raises for them).
-template <int UNROLL>
+template <int UNROLL, bool NT = true>
 __global__ __launch_bounds__(kBlock) void k_and_exact(
     const uint64_t *__restrict__ index, uint64_t stride_words, uint32_t wv, uint64_t n_cols,
     const uint64_t *__restrict__ rows, const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ num_unique,
@@ -380,11 +382,11 @@ __global__ __launch_bounds__(kBlock) void k_and_exact(
     for (; r + UNROLL <= R; r += UNROLL) {
         u64x2 v[UNROLL];
 #pragma unroll
-        for (int j = 0; j < UNROLL; j++) v[j] = load_row_seg(index, qrows[r + j], stride_words, w0);
+        for (int j = 0; j < UNROLL; j++) v[j] = load_row_seg<NT>(index, qrows[r + j], stride_words, w0);
 #pragma unroll
         for (int j = 0; j < UNROLL; j++) acc &= v[j];
     }
-    for (; r < R; r++) acc &= load_row_seg(index, qrows[r], stride_words, w0);
+    for (; r < R; r++) acc &= load_row_seg<NT>(index, qrows[r], stride_words, w0);
     if (R == 0) acc = u64x2{0ull, 0ull};
     acc.x &= valid_mask(w0, n_cols);
     acc.y &= valid_mask(w0 + 1, n_cols);
