@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libbigsi_hip.so")
 OK, ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_RANGE, ERR_CAPACITY, ERR_STATE = 0, -1, -2, -3, -4, -5, -6
 RUN_FORCE_COUNTS = 1
 RUN_SKIP_COMPACT = 2
+RUN_K1_GLOBAL = 4
 BLOOM_RAW = 1
 
 

@@ -520,7 +520,7 @@ struct bigsi_hip_batch {
     bigsi_hip_index *ix = nullptr;
     uint32_t n_seqs = 0, k = 0;
     std::vector<uint64_t> seq_off, pos_off, tab_off;
-    uint64_t total_pos = 0, max_pos = 0;
+    uint64_t total_pos = 0, max_pos = 0, max_len = 0;
     DevBuf seqs, d_seq_off, d_pos_off, d_tab_off, tab, first_pos, pos_unique, tmp, rows, num_kmers, num_unique, min_kmers;
     DevBuf pos_query, hsh, rep;   // per k-mer position: owning sequence, dedupe hash, class representative
     DevBuf bitmaps, counts, scratch;
@@ -573,6 +573,7 @@ extern "C" int bigsi_hip_batch_create(bigsi_hip_index *ix, const char *seqs, con
         b->pos_off[i + 1] = b->pos_off[i] + n;
         b->tab_off[i + 1] = b->tab_off[i] + pow2_at_least(2 * n);
         b->max_pos = std::max(b->max_pos, n);
+        b->max_len = std::max(b->max_len, len);
     }
     b->total_pos = b->pos_off[n_seqs];
     const uint64_t T = std::max<uint64_t>(b->total_pos, 1);
@@ -662,11 +663,33 @@ static void launch_count_h(bigsi_hip_batch *b, unsigned grid, unsigned block, ui
 static int compact(bigsi_hip_batch *b, HitBufs &hb, const void *src, uint32_t n_shards, uint64_t shard_cols, bool write_only);
 
 // K1 for the whole batch (h may have changed since create: the rows buffer is sized for it here)
-static int run_kmerize(bigsi_hip_batch *b, double threshold)
+static int run_kmerize(bigsi_hip_batch *b, double threshold, bool force_global = false)
 {
     bigsi_hip_index *ix = b->ix;
     EventPair ep{};
     TRY(b->rows.reserve(std::max<uint64_t>(b->total_pos, 1) * ix->h * 8));
+    static const int k1_global = env_int("BIGSI_HIP_K1_GLOBAL", 0);
+    if (!force_global && !k1_global && b->max_pos <= kLdsMaxPos) {
+        // fused single-launch K1: dedupe table + sequence in LDS
+        uint32_t tab_cap = 2;
+        while (tab_cap < 2 * b->max_pos) tab_cap <<= 1;
+        uint32_t block = 64;
+        while (block < b->max_pos && block < 1024) block <<= 1;
+        const size_t lds = (size_t)tab_cap * 4 + 64 + round_up(b->max_len + 16, 16);
+        TRY(ev_begin(ix, &ep));
+#define BIGSI_K1_LDS(KF)                                                                                                        \
+    hipLaunchKernelGGL((k_kmerize_lds<KF>), dim3(b->n_seqs), dim3(block), lds, ix->stream, b->seqs.as<char>(), b->d_seq_off.as<uint64_t>(), \
+                       b->d_pos_off.as<uint64_t>(), b->k, ix->h, ix->m, threshold, tab_cap, b->first_pos.as<uint32_t>(), b->tmp.as<uint32_t>(), \
+                       b->pos_unique.as<uint32_t>(), b->rep.as<uint32_t>(), b->rows.as<uint64_t>(), b->num_kmers.as<uint32_t>(),      \
+                       b->num_unique.as<uint32_t>(), b->min_kmers.as<uint32_t>())
+        if (b->k == 31) BIGSI_K1_LDS(31);
+        else BIGSI_K1_LDS(0);
+#undef BIGSI_K1_LDS
+        HIP_TRY(hipGetLastError());
+        TRY(ev_end(ix, &ep, ix->ev_km));
+        b->run_h = ix->h;
+        return BIGSI_OK;
+    }
     HIP_TRY(hipMemsetAsync(b->tab.p, 0xFF, b->tab_off[b->n_seqs] * 4, ix->stream));
     TRY(ev_begin(ix, &ep));
     const uint64_t T = b->total_pos;
@@ -717,7 +740,7 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
 
     // K1
     EventPair ep{};
-    TRY(run_kmerize(b, threshold));
+    TRY(run_kmerize(b, threshold, (flags & BIGSI_RUN_K1_GLOBAL) != 0));
 
     // K2
     static const int and_block = [] { int v = env_int("BIGSI_HIP_AND_BLOCK", 256); return (v == 64 || v == 128 || v == 256) ? v : 256; }();

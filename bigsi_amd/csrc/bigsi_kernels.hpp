@@ -107,8 +107,9 @@ __device__ __forceinline__ uint64_t row_of_hash(uint32_t h, uint64_t m)
     return a == 0 ? 0 : m - a;
 }
 
-// block-wide exclusive scan of one uint32 per thread (kBlock threads); returns prefix, *total = block sum.
-__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *total, uint32_t *lds /* >= kBlock/64 + 1 */)
+// block-wide exclusive scan of one uint32 per thread (blockDim.x a multiple of 64, up to 1024); returns prefix,
+// *total = block sum.
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *total, uint32_t *lds /* >= blockDim.x/64 entries */)
 {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t incl = v;
@@ -121,8 +122,8 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *t
     if (lane == 63) lds[wave] = incl;
     __syncthreads();
     uint32_t base = 0, tot = 0;
-#pragma unroll
-    for (uint32_t w = 0; w < kBlock / 64; w++) {
+    const uint32_t nw = blockDim.x >> 6;
+    for (uint32_t w = 0; w < nw; w++) {
         uint32_t x = lds[w];
         if (w < wave) base += x;
         tot += x;
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(kBlock) void k_kmer_rank(
     uint32_t k, double threshold, uint32_t *__restrict__ first_pos, uint32_t *__restrict__ uidx, uint32_t *__restrict__ pos_unique,
     uint32_t *__restrict__ num_kmers, uint32_t *__restrict__ num_unique, uint32_t *__restrict__ min_kmers)
 {
-    __shared__ uint32_t lds[kBlock / 64 + 1];
+    __shared__ uint32_t lds[16];
     const uint32_t q = blockIdx.x;
     const uint64_t len = seq_off[q + 1] - seq_off[q];
     const uint32_t n = len >= k ? (uint32_t)(len - k + 1) : 0u;
@@ -330,6 +331,98 @@ __global__ __launch_bounds__(kBlock) void k_kmer_rows(
     } else {
         const KmerView v{km, k, use_revcomp(km, k)};
         for (uint32_t sd = 0; sd < h; sd++) dst[sd] = row_of_hash(murmur3_32(v, sd), m);
+    }
+}
+
+// K1 fused: ONE launch for batches whose longest query has at most kLdsMaxPos k-mer positions (a 4 kbp query; reads
+// and gene-length queries).  One workgroup per query; the sequence and the dedupe table live in LDS (ds_cmpst / ds_min
+// instead of L2 atomics), and the workgroup goes insert -> resolve -> ordered compaction -> hash without leaving the CU.
+// Same results as the four-kernel path above, which remains the route for longer queries.
+constexpr uint32_t kLdsMaxPos = 4096;
+
+template <int KF>
+__global__ __launch_bounds__(1024) void k_kmerize_lds(
+    const char *__restrict__ seqs, const uint64_t *__restrict__ seq_off, const uint64_t *__restrict__ pos_off,
+    uint32_t k, uint32_t h, uint64_t m, double threshold, uint32_t tab_cap, uint32_t *__restrict__ first_pos,
+    uint32_t *__restrict__ uidx, uint32_t *__restrict__ pos_unique, uint32_t *__restrict__ rep_out, uint64_t *__restrict__ rows,
+    uint32_t *__restrict__ num_kmers, uint32_t *__restrict__ num_unique, uint32_t *__restrict__ min_kmers)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *scan = tab + tab_cap;                      // 16 entries
+    char *sq = reinterpret_cast<char *>(scan + 16);      // the query's bytes
+    const uint32_t q = blockIdx.x;
+    const char *s = seqs + seq_off[q];
+    const uint32_t len = (uint32_t)(seq_off[q + 1] - seq_off[q]);
+    const uint32_t n = len >= k ? len - k + 1 : 0u;
+    const uint64_t P = pos_off[q];
+    uint32_t tsize = 2;
+    while (tsize < 2 * n) tsize <<= 1;
+    const uint32_t mask = tsize - 1;
+    for (uint32_t i = threadIdx.x; i < tsize; i += blockDim.x) tab[i] = kEmpty;
+    for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) sq[i] = s[i];
+    __syncthreads();
+    auto hash_at = [&](uint32_t i) -> uint32_t {
+        if (KF > 0) {
+            RegKmer<KF> km;
+            km.load(sq + i);
+            return km.fnv();
+        }
+        return fnv1a(sq + i, k);
+    };
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        uint32_t slot = hash_at(i) & mask;
+        for (;;) {
+            const uint32_t cur = atomicCAS(&tab[slot], kEmpty, i);
+            if (cur == kEmpty) break;
+            if (kmer_equal(sq + cur, sq + i, k)) { atomicMin(&tab[slot], i); break; }
+            slot = (slot + 1) & mask;
+        }
+    }
+    __syncthreads();
+    uint32_t *fp = first_pos + P, *ux = uidx + P, *pu = pos_unique + P, *rp = rep_out + P;
+    uint64_t *qrows = rows + P * h;
+    uint32_t u = 0;
+    for (uint32_t base = 0; base < n; base += blockDim.x) {
+        const uint32_t i = base + threadIdx.x;
+        uint32_t c = kEmpty;
+        if (i < n) {
+            uint32_t slot = hash_at(i) & mask;
+            for (;;) {
+                c = tab[slot];
+                if (c == i || kmer_equal(sq + c, sq + i, k)) break;
+                slot = (slot + 1) & mask;
+            }
+            rp[i] = c;
+        }
+        const uint32_t flag = (i < n && c == i) ? 1u : 0u;
+        uint32_t tot;
+        const uint32_t pre = block_exclusive_scan(flag, &tot, scan);
+        if (flag) {
+            const uint32_t j = u + pre;
+            fp[j] = i;
+            ux[i] = j;
+            uint64_t *dst = qrows + (uint64_t)j * h;
+            if (KF > 0) {
+                RegKmer<KF> reg;
+                reg.load(sq + i);
+                uint32_t w[(KF + 3) / 4 > 0 ? (KF + 3) / 4 : 1];
+                reg.canonical_words(w);
+                for (uint32_t sd = 0; sd < h; sd++) dst[sd] = row_of_hash(murmur3_words<KF>(w, sd), m);
+            } else {
+                const KmerView v{sq + i, k, use_revcomp(sq + i, k)};
+                for (uint32_t sd = 0; sd < h; sd++) dst[sd] = row_of_hash(murmur3_32(v, sd), m);
+            }
+        }
+        u += tot;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) pu[i] = ux[rp[i]];
+    if (threadIdx.x == 0) {
+        num_kmers[q] = n;
+        num_unique[q] = u;
+        const double mk = ceil((double)u * threshold);
+        min_kmers[q] = mk > 0.0 ? (uint32_t)mk : 0u;
     }
 }
 
@@ -500,7 +593,7 @@ __global__ __launch_bounds__(kBlock) void k_hits_exact(
     uint32_t *__restrict__ chunk_hits, const uint64_t *__restrict__ chunk_off,
     uint32_t *__restrict__ hit_col, uint32_t *__restrict__ hit_cnt, uint64_t capacity, uint32_t *__restrict__ overflow)
 {
-    __shared__ uint32_t lds[kBlock / 64 + 1];
+    __shared__ uint32_t lds[16];
     const uint32_t chunk = blockIdx.x % chunks, sq = blockIdx.x / chunks;
     const uint32_t shard = sq % n_shards, q = sq / n_shards;
     const uint32_t w = chunk * kBlock + threadIdx.x;   // one 64-column word per thread
@@ -532,7 +625,7 @@ __global__ __launch_bounds__(kBlock) void k_hits_count(
     uint32_t *__restrict__ chunk_hits, const uint64_t *__restrict__ chunk_off,
     uint32_t *__restrict__ hit_col, uint32_t *__restrict__ hit_cnt, uint64_t capacity, uint32_t *__restrict__ overflow)
 {
-    __shared__ uint32_t lds[kBlock / 64 + 1];
+    __shared__ uint32_t lds[16];
     const uint32_t chunk = blockIdx.x % chunks, sq = blockIdx.x / chunks;
     const uint32_t shard = sq % n_shards, q = sq / n_shards;
     const uint64_t c0 = (uint64_t)chunk * kChunkCols + threadIdx.x * 8u;
@@ -568,7 +661,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_chunks(
     const uint32_t *__restrict__ chunk_hits, uint64_t n, uint32_t per_seq, uint32_t n_seqs,
     uint64_t *__restrict__ chunk_off, uint64_t *__restrict__ hit_off)
 {
-    __shared__ uint32_t lds[kBlock / 64 + 1];
+    __shared__ uint32_t lds[16];
     uint64_t carry = 0;
     for (uint64_t base = 0; base < n; base += (uint64_t)kBlock * kScanItems) {
         const uint64_t i0 = base + (uint64_t)threadIdx.x * kScanItems;

@@ -130,6 +130,7 @@ int bigsi_hip_bloom(int device, const char *kmers, uint64_t u, uint32_t k, uint6
 int bigsi_hip_lookup(bigsi_hip_index *ix, const char *kmers, uint32_t k, uint64_t u, uint8_t *out_rows);
 
 #define BIGSI_RUN_FORCE_COUNTS 1u /* use the counting path even when threshold == 1.0 */
+#define BIGSI_RUN_K1_GLOBAL 4u   /* take the multi-launch K1 (global-memory dedupe table) even for short queries (testing) */
 #define BIGSI_RUN_SKIP_COMPACT 2u /* stop after K2/K3: the caller compacts a gathered buffer instead (multi-GPU) */
 
 int bigsi_hip_batch_create(bigsi_hip_index *ix, const char *seqs, const uint64_t *offsets, uint32_t n_seqs,

@@ -590,3 +590,41 @@ def test_device_build_paths(hip):
     for p in parts:
         p.delete()
     b2.delete()
+
+
+@pytest.mark.parametrize("k,lens", [(31, [31, 61, 500, 4126]), (31, [4127, 100]), (5, [5, 4100, 9, 4]), (33, [33, 2000, 40])])
+def test_k1_fused_lds_equals_global_path(hip, k, lens):
+    """K1 has two routes -- one fused launch with the dedupe table in LDS (all queries <= 4096 positions) and the
+    four-kernel global-table route (longer queries, or forced by BIGSI_RUN_K1_GLOBAL).  Same row ids, unique counts,
+    position->unique maps (seen through presence strings) and hits from both, and both equal the oracle."""
+    from bigsi_amd.storage import get_storage
+    from oracle import coracle
+    m, n_cols, h = 2503, 128, 3
+    st = get_storage(cfg(k, m, h, max_cols=n_cols))
+    st.delete_all()
+    for key, v in (("number_of_rows", m), ("number_of_cols", n_cols), ("ksi:bloomfilter_size", m), ("ksi:num_hashes", h)):
+        st.set_integer(key, v)
+    st.fill_synthetic(3, 0, 1)
+    rng = np.random.default_rng(sum(lens) + k)
+    seqs = ["".join(rng.choice(list("ACGT" if i % 2 else "AC"), size=L)) for i, L in enumerate(lens)]   # "AC" strings: many duplicate k-mers
+    batch = st.new_batch(seqs, k)
+    outs = []
+    for forced in (False, True):
+        batch.run(0.5, k1_global=forced)
+        nk, nu, mk = batch.unique()
+        off, col, cnt = batch.hits()
+        rows = [batch.rows(i, nu[i]).copy() for i in range(len(seqs))]
+        pres = [batch.presence(i, np.arange(4, dtype=np.uint32), nk[i]) for i in range(len(seqs))]
+        first = [batch.lookup(i, nu[i])[0].copy() for i in range(len(seqs))]
+        outs.append((nk.copy(), nu.copy(), mk.copy(), off.copy(), col.copy(), cnt.copy(), rows, pres, first))
+    a, b = outs
+    for x, y in zip(a[:6], b[:6]):
+        assert np.array_equal(x, y)
+    for i in range(len(seqs)):
+        assert np.array_equal(a[6][i], b[6][i]) and a[7][i] == b[7][i] and np.array_equal(a[8][i], b[8][i])
+        fp, p2u = coracle.unique_kmers(seqs[i], k)
+        assert np.array_equal(a[8][i], fp)
+        want_rows = np.array([coracle.kmer_rows(seqs[i][p:p + k], h, m) for p in fp], dtype=np.uint64).reshape(len(fp), h)
+        assert np.array_equal(a[6][i], want_rows)
+    batch.close()
+    st.delete_all()
