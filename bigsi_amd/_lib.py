@@ -16,6 +16,7 @@ OK, ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_RANGE, ERR_CAPACITY, ERR_STATE = 0, -1,
 RUN_FORCE_COUNTS = 1
 RUN_SKIP_COMPACT = 2
 RUN_K1_GLOBAL = 4
+RUN_SPARSE_COUNTS = 8
 BLOOM_RAW = 1
 
 

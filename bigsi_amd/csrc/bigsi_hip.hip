@@ -527,7 +527,7 @@ struct bigsi_hip_batch {
     void *ext_bitmaps = nullptr, *ext_counts = nullptr;
     HitBufs hits, ghits;
     // state of the last run
-    bool ran = false, exact = false, compacted = false;
+    bool ran = false, exact = false, compacted = false, sparse_counts = false;
     uint32_t count_bytes = 2;
     double threshold = 1.0;
     uint64_t wv = 0, wv_pad = 0;   // valid / padded words per row at run time
@@ -642,13 +642,14 @@ extern "C" int bigsi_hip_batch_set_outputs(bigsi_hip_batch *b, void *d_bitmaps, 
 
 // -------- K2 dispatch
 template <int P, typename CountT>
-static void launch_count_h(bigsi_hip_batch *b, unsigned grid, unsigned block, uint32_t tiles, CountT *out, uint64_t out_stride)
+static void launch_count_h(bigsi_hip_batch *b, unsigned grid, unsigned block, uint32_t tiles, CountT *out, uint64_t out_stride,
+                           uint64_t *hit_bitmap, uint32_t sparse)
 {
     bigsi_hip_index *ix = b->ix;
 #define BIGSI_LAUNCH_COUNT(H)                                                                                              \
     hipLaunchKernelGGL((k_and_count<P, H, CountT>), dim3(grid), dim3(block), 0, ix->stream, ix->d_index, ix->stride_words, \
                        (uint32_t)b->wv, b->rows.as<uint64_t>(), b->d_pos_off.as<uint64_t>(), b->num_unique.as<uint32_t>(), \
-                       ix->h, b->n_seqs, tiles, out, out_stride)
+                       ix->h, b->n_seqs, tiles, out, out_stride, b->min_kmers.as<uint32_t>(), ix->n_cols, hit_bitmap, b->wv_pad, sparse)
     switch (ix->h) {
     case 1: BIGSI_LAUNCH_COUNT(1); break;
     case 2: BIGSI_LAUNCH_COUNT(2); break;
@@ -775,12 +776,17 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
         const uint64_t cstride = b->wv_pad * 64;
         void *out = b->ext_counts;
         if (!out) { TRY(b->counts.reserve((size_t)b->n_seqs * cstride * b->count_bytes)); out = b->counts.p; }
+        // the kernel also leaves the thresholded hit bitmap (count >= min_kmers), which is what K4 compacts on a single GPU
+        TRY(b->bitmaps.reserve((size_t)b->n_seqs * b->wv_pad * 8));
+        uint64_t *hb = b->bitmaps.as<uint64_t>();
+        b->sparse_counts = (flags & BIGSI_RUN_SPARSE_COUNTS) && !b->ext_counts;
+        const uint32_t sparse = b->sparse_counts ? 1u : 0u;
         TRY(ev_begin(ix, &ep));
         switch (P) {
-        case 6: launch_count_h<6, uint16_t>(b, grid, and_block, tiles, (uint16_t *)out, cstride); break;
-        case 10: launch_count_h<10, uint16_t>(b, grid, and_block, tiles, (uint16_t *)out, cstride); break;
-        case 16: launch_count_h<16, uint16_t>(b, grid, and_block, tiles, (uint16_t *)out, cstride); break;
-        default: launch_count_h<32, uint32_t>(b, grid, and_block, tiles, (uint32_t *)out, cstride); break;
+        case 6: launch_count_h<6, uint16_t>(b, grid, and_block, tiles, (uint16_t *)out, cstride, hb, sparse); break;
+        case 10: launch_count_h<10, uint16_t>(b, grid, and_block, tiles, (uint16_t *)out, cstride, hb, sparse); break;
+        case 16: launch_count_h<16, uint16_t>(b, grid, and_block, tiles, (uint16_t *)out, cstride, hb, sparse); break;
+        default: launch_count_h<32, uint32_t>(b, grid, and_block, tiles, (uint32_t *)out, cstride, hb, sparse); break;
         }
         HIP_TRY(hipGetLastError());
         TRY(ev_end(ix, &ep, ix->ev_and));
@@ -798,11 +804,15 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
     return BIGSI_OK;
 }
 
-// three compaction passes over [shard][seq][stride]; write_only re-runs just the write pass (after growing buffers)
-static int compact(bigsi_hip_batch *b, HitBufs &hb, const void *src, uint32_t n_shards, uint64_t shard_cols, bool write_only)
+// three compaction passes over [shard][seq][stride]; write_only re-runs just the write pass (after growing buffers).
+// `from_counts`: src is a counter buffer gathered from several shards -> threshold while compacting (k_hits_count);
+// otherwise src is a hit bitmap (the exact AND, or the counting kernel's fused count >= min_kmers mask) and the per-hit
+// count comes from `counters` (null on the exact path: every hit has count == num_unique).
+static int compact_ex(bigsi_hip_batch *b, HitBufs &hb, const void *src, bool from_counts, const void *counters,
+                      uint32_t n_shards, uint64_t shard_cols, bool write_only)
 {
     bigsi_hip_index *ix = b->ix;
-    const uint32_t chunks = b->exact ? (uint32_t)ceil_div(b->wv, kBlock) : (uint32_t)ceil_div(b->wv_pad * 64, kChunkCols);
+    const uint32_t chunks = !from_counts ? (uint32_t)ceil_div(b->wv, kBlock) : (uint32_t)ceil_div(b->wv_pad * 64, kChunkCols);
     const uint64_t per_seq = (uint64_t)n_shards * chunks, nchunks = per_seq * b->n_seqs;
     if (nchunks > 0x7FFFFFFFull) return fail(BIGSI_ERR_INVALID, "too many compaction chunks");
     TRY(hb.chunk_hits.reserve(nchunks * 4));
@@ -817,22 +827,27 @@ static int compact(bigsi_hip_batch *b, HitBufs &hb, const void *src, uint32_t n_
     }
     const unsigned grid = (unsigned)nchunks;
     HIP_TRY(hipMemsetAsync(hb.overflow.p, 0, 4, ix->stream));
-#define BIGSI_HITS_ARGS(SRC_T, STRIDE)                                                                                            \
-    (const SRC_T *)src, (uint64_t)(STRIDE), (uint32_t)b->wv, b->n_seqs, n_shards, chunks, shard_cols,                             \
-        b->exact ? b->num_unique.as<uint32_t>() : b->min_kmers.as<uint32_t>(), hb.chunk_hits.as<uint32_t>(),                      \
-        hb.chunk_off.as<uint64_t>(), hb.hit_col.as<uint32_t>(), hb.hit_cnt.as<uint32_t>(), hb.cap, hb.overflow.as<uint32_t>()
-#define BIGSI_HITS_LAUNCH(KERNEL, SRC_T, STRIDE) \
-    hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(kBlock), 0, ix->stream, BIGSI_HITS_ARGS(SRC_T, STRIDE))
+#define BIGSI_HITS_COMMON                                                                                                        \
+    b->n_seqs, n_shards, chunks, shard_cols, from_counts ? b->min_kmers.as<uint32_t>() : b->num_unique.as<uint32_t>(),          \
+        hb.chunk_hits.as<uint32_t>(), hb.chunk_off.as<uint64_t>(), hb.hit_col.as<uint32_t>(), hb.hit_cnt.as<uint32_t>(), hb.cap, \
+        hb.overflow.as<uint32_t>()
     for (int pass = write_only ? 1 : 0; pass < 2; pass++) {
-        if (b->exact) {
-            if (pass == 0) BIGSI_HITS_LAUNCH((k_hits_exact<false>), uint64_t, b->wv_pad);
-            else BIGSI_HITS_LAUNCH((k_hits_exact<true>), uint64_t, b->wv_pad);
+        if (!from_counts) {
+            const uint64_t *bm = (const uint64_t *)src;
+            if (pass == 0)
+                hipLaunchKernelGGL((k_hits_exact<false>), dim3(grid), dim3(kBlock), 0, ix->stream, bm, b->wv_pad, (uint32_t)b->wv, BIGSI_HITS_COMMON,
+                                   counters, b->count_bytes, b->wv_pad * 64);
+            else
+                hipLaunchKernelGGL((k_hits_exact<true>), dim3(grid), dim3(kBlock), 0, ix->stream, bm, b->wv_pad, (uint32_t)b->wv, BIGSI_HITS_COMMON,
+                                   counters, b->count_bytes, b->wv_pad * 64);
         } else if (b->count_bytes == 2) {
-            if (pass == 0) BIGSI_HITS_LAUNCH((k_hits_count<uint16_t, false>), uint16_t, b->wv_pad * 64);
-            else BIGSI_HITS_LAUNCH((k_hits_count<uint16_t, true>), uint16_t, b->wv_pad * 64);
+            const uint16_t *c16 = (const uint16_t *)src;
+            if (pass == 0) hipLaunchKernelGGL((k_hits_count<uint16_t, false>), dim3(grid), dim3(kBlock), 0, ix->stream, c16, b->wv_pad * 64, (uint32_t)b->wv, BIGSI_HITS_COMMON);
+            else hipLaunchKernelGGL((k_hits_count<uint16_t, true>), dim3(grid), dim3(kBlock), 0, ix->stream, c16, b->wv_pad * 64, (uint32_t)b->wv, BIGSI_HITS_COMMON);
         } else {
-            if (pass == 0) BIGSI_HITS_LAUNCH((k_hits_count<uint32_t, false>), uint32_t, b->wv_pad * 64);
-            else BIGSI_HITS_LAUNCH((k_hits_count<uint32_t, true>), uint32_t, b->wv_pad * 64);
+            const uint32_t *c32 = (const uint32_t *)src;
+            if (pass == 0) hipLaunchKernelGGL((k_hits_count<uint32_t, false>), dim3(grid), dim3(kBlock), 0, ix->stream, c32, b->wv_pad * 64, (uint32_t)b->wv, BIGSI_HITS_COMMON);
+            else hipLaunchKernelGGL((k_hits_count<uint32_t, true>), dim3(grid), dim3(kBlock), 0, ix->stream, c32, b->wv_pad * 64, (uint32_t)b->wv, BIGSI_HITS_COMMON);
         }
         HIP_TRY(hipGetLastError());
         if (pass == 0) {
@@ -841,9 +856,19 @@ static int compact(bigsi_hip_batch *b, HitBufs &hb, const void *src, uint32_t n_
             HIP_TRY(hipGetLastError());
         }
     }
-#undef BIGSI_HITS_LAUNCH
-#undef BIGSI_HITS_ARGS
+#undef BIGSI_HITS_COMMON
     return BIGSI_OK;
+}
+
+// this shard's own result (n_shards == 1): always a bitmap; gathered buffers: bitmaps (exact) or counters (counting)
+static int compact(bigsi_hip_batch *b, HitBufs &hb, const void *src, uint32_t n_shards, uint64_t shard_cols, bool write_only)
+{
+    if (&hb == &b->hits) {
+        const void *bm = b->exact ? (b->ext_bitmaps ? b->ext_bitmaps : b->bitmaps.p) : b->bitmaps.p;
+        const void *counters = b->exact ? nullptr : (b->ext_counts ? b->ext_counts : b->counts.p);
+        return compact_ex(b, hb, bm, false, counters, 1, shard_cols, write_only);
+    }
+    return compact_ex(b, hb, src, !b->exact, nullptr, n_shards, shard_cols, write_only);
 }
 
 // synchronise, make sure the hit lists fit (grow + rewrite if the write pass overflowed), copy them out
@@ -961,6 +986,7 @@ extern "C" int bigsi_hip_batch_fetch_counts(bigsi_hip_batch *b, uint32_t seq, ui
     TRY(need_run(b));
     if (!out) return fail(BIGSI_ERR_INVALID, "out is NULL");
     if (b->exact) return fail(BIGSI_ERR_STATE, "the last run took the exact path; re-run with BIGSI_RUN_FORCE_COUNTS or threshold < 1");
+    if (b->sparse_counts) return fail(BIGSI_ERR_STATE, "the last run used BIGSI_RUN_SPARSE_COUNTS: only counters of hits were stored");
     if (seq >= b->n_seqs) return fail(BIGSI_ERR_RANGE, "sequence %u out of range", seq);
     const uint64_t n = b->ix->n_cols, cstride = b->wv_pad * 64;
     const uint8_t *src = (const uint8_t *)(b->ext_counts ? b->ext_counts : b->counts.p) + (uint64_t)seq * cstride * b->count_bytes;

@@ -497,7 +497,9 @@ template <int P, int H, typename CountT>
 __global__ __launch_bounds__(kBlock) void k_and_count(
     const uint64_t *__restrict__ index, uint64_t stride_words, uint32_t wv,
     const uint64_t *__restrict__ rows, const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ num_unique,
-    uint32_t h_rt, uint32_t n_seqs, uint32_t tiles, CountT *__restrict__ out, uint64_t out_stride /* counters per query */)
+    uint32_t h_rt, uint32_t n_seqs, uint32_t tiles, CountT *__restrict__ out, uint64_t out_stride /* counters per query */,
+    const uint32_t *__restrict__ min_kmers, uint64_t n_cols, uint64_t *__restrict__ hit_bitmap /* [seq][bm_stride] or null */,
+    uint64_t bm_stride, uint32_t sparse /* 1: store counters only for words that contain a hit */)
 {
     const TileMap tm = map_block(blockIdx.x, n_seqs, tiles);
     if (!tm.valid) return;
@@ -541,11 +543,31 @@ __global__ __launch_bounds__(kBlock) void k_and_count(
         add(a);
     }
 
+    // threshold in bit-sliced form (graph/bigsi.py:241-242: count >= min_kmers): MSB-first comparator over the planes,
+    // ~2 bit-ops per plane per word; the threshold is wave-uniform so its bit tests are scalar branches
+    uint64_t ge[kVec];
+    {
+        const uint32_t thr = min_kmers[tm.q];
+#pragma unroll
+        for (int v = 0; v < kVec; v++) {
+            uint64_t gt = 0, eq = ~0ull;
+            if (P < 32 && (thr >> P) != 0) eq = 0;            // threshold above any representable count
+#pragma unroll
+            for (int p = P - 1; p >= 0; p--) {
+                if ((thr >> p) & 1u) eq &= pl[v][p];
+                else { gt |= eq & pl[v][p]; eq &= ~pl[v][p]; }
+            }
+            ge[v] = (gt | eq) & valid_mask((uint64_t)w0 + v, n_cols);
+            if (hit_bitmap && (uint64_t)w0 + v < bm_stride) hit_bitmap[(uint64_t)tm.q * bm_stride + w0 + v] = ge[v];
+        }
+    }
+
     // expand: column 8b+jj of word w sits at bit 8b+7-jj; 8 consecutive counters per store
 #pragma unroll
     for (int v = 0; v < kVec; v++) {
         const uint64_t cbase = ((uint64_t)w0 + v) * 64;
         if (cbase >= out_stride) break;
+        if (sparse && ge[v] == 0) continue;
         CountT *o = out + (uint64_t)tm.q * out_stride + cbase;
 #pragma unroll
         for (int b = 0; b < 8; b++) {
@@ -591,7 +613,8 @@ __global__ __launch_bounds__(kBlock) void k_hits_exact(
     const uint64_t *__restrict__ bitmaps, uint64_t stride_words, uint32_t wv, uint32_t n_seqs, uint32_t n_shards, uint32_t chunks,
     uint64_t shard_cols, const uint32_t *__restrict__ num_unique,
     uint32_t *__restrict__ chunk_hits, const uint64_t *__restrict__ chunk_off,
-    uint32_t *__restrict__ hit_col, uint32_t *__restrict__ hit_cnt, uint64_t capacity, uint32_t *__restrict__ overflow)
+    uint32_t *__restrict__ hit_col, uint32_t *__restrict__ hit_cnt, uint64_t capacity, uint32_t *__restrict__ overflow,
+    const void *__restrict__ counters /* null: every hit's count is num_unique[q] */, uint32_t counter_bytes, uint64_t counter_stride)
 {
     __shared__ uint32_t lds[16];
     const uint32_t chunk = blockIdx.x % chunks, sq = blockIdx.x / chunks;
@@ -612,8 +635,15 @@ __global__ __launch_bounds__(kBlock) void k_hits_exact(
     if (o + mine > capacity) { *overflow = 1; return; }
     const uint32_t uq = num_unique[q];
     const uint64_t cbase = (uint64_t)shard * shard_cols + (uint64_t)w * 64;
+    const uint64_t cnt0 = ((uint64_t)shard * n_seqs + q) * counter_stride + (uint64_t)w * 64;
     for (uint32_t c = 0; c < 64; c++)
-        if ((bits >> bit_of_col(c)) & 1ull) { hit_col[o] = (uint32_t)(cbase + c); hit_cnt[o] = uq; o++; }
+        if ((bits >> bit_of_col(c)) & 1ull) {
+            hit_col[o] = (uint32_t)(cbase + c);
+            hit_cnt[o] = !counters ? uq
+                         : counter_bytes == 2 ? (uint32_t) reinterpret_cast<const uint16_t *>(counters)[cnt0 + c]
+                                              : reinterpret_cast<const uint32_t *>(counters)[cnt0 + c];
+            o++;
+        }
 }
 
 // counting: a hit is a column with count >= min_kmers[q] (graph/bigsi.py:241-242); column < shard_cols only.

@@ -152,7 +152,7 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
             return []
         batch = self.storage.new_batch(seqs, self.kmer_size)
         try:
-            batch.run(threshold)
+            batch.run(threshold, sparse_counts=True)      # hit lists only: counters of non-hits are never stored
             num_kmers, num_unique, _ = batch.unique()
             off, colours, counts = batch.hits()
             exact = threshold == 1.0

@@ -90,6 +90,8 @@ class ShardedSearch(object):
                 self._buf = self.sg.gather_buffer(batch.n * stride_bytes, self.device)
             self.stream.synchronize()
             self._buf_key = key
+        if self.sg.world == 1 and not self.force_gather:
+            return self._buf          # alone: results stay in the batch's own buffers, nothing to exchange
         slot = self._buf[self.sg.rank].data_ptr()
         check(_lib.lib().bigsi_hip_batch_set_outputs(batch.b, slot if exact else None, None if exact else slot))
         return self._buf
@@ -97,7 +99,7 @@ class ShardedSearch(object):
     def step(self, batch, threshold):
         """Asynchronous: local K1-K3 (+K4 when alone), all-gather of the per-sample vectors, K4 over the gathered result."""
         if self.sg.world == 1 and not self.force_gather:
-            batch.run(threshold)
+            batch.run(threshold, sparse_counts=True)
             return self._buf
         with self.torch.cuda.stream(self.stream):
             batch.run(threshold, skip_compact=True)

@@ -628,3 +628,30 @@ def test_k1_fused_lds_equals_global_path(hip, k, lens):
         assert np.array_equal(a[6][i], want_rows)
     batch.close()
     st.delete_all()
+
+
+def test_sparse_counts_run_gives_same_hits(hip):
+    """BIGSI_RUN_SPARSE_COUNTS (what BIGSI.search uses): counters are stored only for words containing a hit, the hit
+    lists (colours AND counts) must be identical to a full-counter run, for thresholds from 0 to 1."""
+    from bigsi_amd._lib import BigsiHipError
+    m, n_cols, h = 7001, 3000, 3
+    c, st = synth_index(hip, m, n_cols, h, 17, draws=1)
+    seqs = random_seqs(np.random.default_rng(4), 12, 31, 200)
+    for i in (0, 3):
+        st.insert_kmers(100 * i + 1, [seqs[i]], 31)
+        st.insert_kmers(2999, [seqs[i][:50]], 31)
+    batch = st.new_batch(seqs, 31)
+    for thr in (0.0, 0.2, 0.5, 0.9, 1.0):
+        batch.run(thr, force_counts=True)
+        full = [x.copy() for x in batch.hits()]
+        cnt0 = batch.counts(0).copy()
+        batch.run(thr, force_counts=True, sparse_counts=True)
+        sparse = batch.hits()
+        for a, b in zip(full, sparse):
+            assert np.array_equal(a, b), thr
+        with pytest.raises(BigsiHipError):
+            batch.counts(0)
+        lo, hi = int(full[0][0]), int(full[0][1])
+        assert np.array_equal(full[2][lo:hi], cnt0[full[1][lo:hi]])
+    batch.close()
+    st.delete_all()
