@@ -117,10 +117,12 @@ def main():
     planted = list(range(0, args.batch, 97))[:8]
     for j, qi in enumerate(planted):
         st.insert_kmers((1009 * (j + 1) + 13 * rank) % args.cols, [seqs[qi]], args.k)
-    batch = st.new_batch(seqs, args.k)
     sh = ShardedSearch(st, args.cols, device=dev, force_gather=args.force_dist)   # puts the library on a torch stream
+    # sharded runs alternate two staged copies of the batch, so that the exchange of one overlaps the kernels of the other
+    batches = [st.new_batch(seqs, args.k) for _ in range(2 if sh.gathering else 1)]
+    batch = batches[0]
     count_bytes = 2 if (args.qlen - args.k + 1) < 65536 else 4
-    sh.prepare(batch, exact, count_bytes)
+    sh.prepare(batches, exact, count_bytes)
     check(_lib.lib().bigsi_hip_set_profiling(st.handle, 1))
 
     def sync_all():
@@ -129,7 +131,7 @@ def main():
         torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
-        sh.step(batch, args.threshold)
+        sh.step(batches, args.threshold)
     sync_all()
     stats = _lib.Stats()
     check(_lib.lib().bigsi_hip_stats(st.handle, _lib.C.byref(stats), 1))     # drop warmup events
@@ -137,7 +139,7 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        sh.step(batch, args.threshold)
+        sh.step(batches, args.threshold)
     sync_all()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -147,6 +149,7 @@ def main():
     check(_lib.lib().bigsi_hip_stats(st.handle, _lib.C.byref(stats), 1))
 
     # ---------------- results of the last step, algorithmic bytes, verification
+    batch = batches[(args.steps - 1) % len(batches)]      # the batch the last step ran on
     off, colours, counts = sh.fetch(batch)
     nk, nu, mk = batch.unique()
     total_unique = int(nu.sum())
@@ -233,7 +236,8 @@ def main():
         }
         if args.cpu_seconds > 0 and world == 1:        # reported at N=1 only
             line["cpu_baseline"] = cpu_baseline(args, seqs, exact)
-    batch.close()
+    for b_ in batches:
+        b_.close()
     st.delete_all()
     if use_dist:
         dist.barrier()

@@ -454,8 +454,9 @@ extern "C" int bigsi_hip_bloom(int device, const char *kmers, uint64_t u, uint32
 }
 
 // ------------------------------------------------------------------------------ profiling events
-static int ev_begin(bigsi_hip_index *ix, EventPair *p)
+static int ev_begin(bigsi_hip_index *ix, EventPair *p, hipStream_t st = nullptr)
 {
+    if (!st) st = ix->stream;
     if (!ix->profiling) return BIGSI_OK;
     if (ix->ev_free.empty()) {
         EventPair n;
@@ -465,14 +466,15 @@ static int ev_begin(bigsi_hip_index *ix, EventPair *p)
     }
     *p = ix->ev_free.back();
     ix->ev_free.pop_back();
-    HIP_TRY(hipEventRecord(p->a, ix->stream));
+    HIP_TRY(hipEventRecord(p->a, st));
     return BIGSI_OK;
 }
 
-static int ev_end(bigsi_hip_index *ix, EventPair *p, std::vector<EventPair> &dst)
+static int ev_end(bigsi_hip_index *ix, EventPair *p, std::vector<EventPair> &dst, hipStream_t st = nullptr)
 {
     if (!ix->profiling) return BIGSI_OK;
-    HIP_TRY(hipEventRecord(p->b, ix->stream));
+    if (!st) st = ix->stream;
+    HIP_TRY(hipEventRecord(p->b, st));
     dst.push_back(*p);
     return BIGSI_OK;
 }
@@ -532,6 +534,7 @@ struct bigsi_hip_batch {
     double threshold = 1.0;
     uint64_t wv = 0, wv_pad = 0;   // valid / padded words per row at run time
     uint32_t run_h = 0;            // num_hashes the row ids of the last K1 were produced with
+    hipStream_t gstream = nullptr; // stream of the gathered compaction (null: the index's stream)
     const void *g_src = nullptr;   // last gathered buffer handed to compact_gathered
     uint32_t g_shards = 0;
     uint64_t g_shard_cols = 0;
@@ -809,9 +812,8 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
 // otherwise src is a hit bitmap (the exact AND, or the counting kernel's fused count >= min_kmers mask) and the per-hit
 // count comes from `counters` (null on the exact path: every hit has count == num_unique).
 static int compact_ex(bigsi_hip_batch *b, HitBufs &hb, const void *src, bool from_counts, const void *counters,
-                      uint32_t n_shards, uint64_t shard_cols, bool write_only)
+                      uint32_t n_shards, uint64_t shard_cols, bool write_only, hipStream_t st)
 {
-    bigsi_hip_index *ix = b->ix;
     const uint32_t chunks = !from_counts ? (uint32_t)ceil_div(b->wv, kBlock) : (uint32_t)ceil_div(b->wv_pad * 64, kChunkCols);
     const uint64_t per_seq = (uint64_t)n_shards * chunks, nchunks = per_seq * b->n_seqs;
     if (nchunks > 0x7FFFFFFFull) return fail(BIGSI_ERR_INVALID, "too many compaction chunks");
@@ -826,7 +828,7 @@ static int compact_ex(bigsi_hip_batch *b, HitBufs &hb, const void *src, bool fro
         hb.cap = want;
     }
     const unsigned grid = (unsigned)nchunks;
-    HIP_TRY(hipMemsetAsync(hb.overflow.p, 0, 4, ix->stream));
+    HIP_TRY(hipMemsetAsync(hb.overflow.p, 0, 4, st));
 #define BIGSI_HITS_COMMON                                                                                                        \
     b->n_seqs, n_shards, chunks, shard_cols, from_counts ? b->min_kmers.as<uint32_t>() : b->num_unique.as<uint32_t>(),          \
         hb.chunk_hits.as<uint32_t>(), hb.chunk_off.as<uint64_t>(), hb.hit_col.as<uint32_t>(), hb.hit_cnt.as<uint32_t>(), hb.cap, \
@@ -835,23 +837,23 @@ static int compact_ex(bigsi_hip_batch *b, HitBufs &hb, const void *src, bool fro
         if (!from_counts) {
             const uint64_t *bm = (const uint64_t *)src;
             if (pass == 0)
-                hipLaunchKernelGGL((k_hits_exact<false>), dim3(grid), dim3(kBlock), 0, ix->stream, bm, b->wv_pad, (uint32_t)b->wv, BIGSI_HITS_COMMON,
+                hipLaunchKernelGGL((k_hits_exact<false>), dim3(grid), dim3(kBlock), 0, st, bm, b->wv_pad, (uint32_t)b->wv, BIGSI_HITS_COMMON,
                                    counters, b->count_bytes, b->wv_pad * 64);
             else
-                hipLaunchKernelGGL((k_hits_exact<true>), dim3(grid), dim3(kBlock), 0, ix->stream, bm, b->wv_pad, (uint32_t)b->wv, BIGSI_HITS_COMMON,
+                hipLaunchKernelGGL((k_hits_exact<true>), dim3(grid), dim3(kBlock), 0, st, bm, b->wv_pad, (uint32_t)b->wv, BIGSI_HITS_COMMON,
                                    counters, b->count_bytes, b->wv_pad * 64);
         } else if (b->count_bytes == 2) {
             const uint16_t *c16 = (const uint16_t *)src;
-            if (pass == 0) hipLaunchKernelGGL((k_hits_count<uint16_t, false>), dim3(grid), dim3(kBlock), 0, ix->stream, c16, b->wv_pad * 64, (uint32_t)b->wv, BIGSI_HITS_COMMON);
-            else hipLaunchKernelGGL((k_hits_count<uint16_t, true>), dim3(grid), dim3(kBlock), 0, ix->stream, c16, b->wv_pad * 64, (uint32_t)b->wv, BIGSI_HITS_COMMON);
+            if (pass == 0) hipLaunchKernelGGL((k_hits_count<uint16_t, false>), dim3(grid), dim3(kBlock), 0, st, c16, b->wv_pad * 64, (uint32_t)b->wv, BIGSI_HITS_COMMON);
+            else hipLaunchKernelGGL((k_hits_count<uint16_t, true>), dim3(grid), dim3(kBlock), 0, st, c16, b->wv_pad * 64, (uint32_t)b->wv, BIGSI_HITS_COMMON);
         } else {
             const uint32_t *c32 = (const uint32_t *)src;
-            if (pass == 0) hipLaunchKernelGGL((k_hits_count<uint32_t, false>), dim3(grid), dim3(kBlock), 0, ix->stream, c32, b->wv_pad * 64, (uint32_t)b->wv, BIGSI_HITS_COMMON);
-            else hipLaunchKernelGGL((k_hits_count<uint32_t, true>), dim3(grid), dim3(kBlock), 0, ix->stream, c32, b->wv_pad * 64, (uint32_t)b->wv, BIGSI_HITS_COMMON);
+            if (pass == 0) hipLaunchKernelGGL((k_hits_count<uint32_t, false>), dim3(grid), dim3(kBlock), 0, st, c32, b->wv_pad * 64, (uint32_t)b->wv, BIGSI_HITS_COMMON);
+            else hipLaunchKernelGGL((k_hits_count<uint32_t, true>), dim3(grid), dim3(kBlock), 0, st, c32, b->wv_pad * 64, (uint32_t)b->wv, BIGSI_HITS_COMMON);
         }
         HIP_TRY(hipGetLastError());
         if (pass == 0) {
-            hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(kBlock), 0, ix->stream, hb.chunk_hits.as<uint32_t>(), nchunks, (uint32_t)per_seq,
+            hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(kBlock), 0, st, hb.chunk_hits.as<uint32_t>(), nchunks, (uint32_t)per_seq,
                                b->n_seqs, hb.chunk_off.as<uint64_t>(), hb.hit_off.as<uint64_t>());
             HIP_TRY(hipGetLastError());
         }
@@ -866,26 +868,26 @@ static int compact(bigsi_hip_batch *b, HitBufs &hb, const void *src, uint32_t n_
     if (&hb == &b->hits) {
         const void *bm = b->exact ? (b->ext_bitmaps ? b->ext_bitmaps : b->bitmaps.p) : b->bitmaps.p;
         const void *counters = b->exact ? nullptr : (b->ext_counts ? b->ext_counts : b->counts.p);
-        return compact_ex(b, hb, bm, false, counters, 1, shard_cols, write_only);
+        return compact_ex(b, hb, bm, false, counters, 1, shard_cols, write_only, b->ix->stream);
     }
-    return compact_ex(b, hb, src, !b->exact, nullptr, n_shards, shard_cols, write_only);
+    return compact_ex(b, hb, src, !b->exact, nullptr, n_shards, shard_cols, write_only, b->gstream ? b->gstream : b->ix->stream);
 }
 
 // synchronise, make sure the hit lists fit (grow + rewrite if the write pass overflowed), copy them out
 static int fetch_hits_from(bigsi_hip_batch *b, HitBufs &hb, const void *src, uint32_t n_shards, uint64_t shard_cols,
                            uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t capacity)
 {
-    bigsi_hip_index *ix = b->ix;
+    hipStream_t st = (&hb == &b->ghits && b->gstream) ? b->gstream : b->ix->stream;
     std::vector<uint64_t> off(b->n_seqs + 1);
-    HIP_TRY(hipMemcpyAsync(off.data(), hb.hit_off.p, (b->n_seqs + 1) * 8ull, hipMemcpyDeviceToHost, ix->stream));
-    HIP_TRY(hipStreamSynchronize(ix->stream));
+    HIP_TRY(hipMemcpyAsync(off.data(), hb.hit_off.p, (b->n_seqs + 1) * 8ull, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     const uint64_t total = off[b->n_seqs];
     if (total > hb.cap) {
         TRY(hb.hit_col.reserve(total * 4));
         TRY(hb.hit_cnt.reserve(total * 4));
         hb.cap = total;
         TRY(compact(b, hb, src, n_shards, shard_cols, true));
-        HIP_TRY(hipStreamSynchronize(ix->stream));
+        HIP_TRY(hipStreamSynchronize(st));
     }
     if (hit_offsets) memcpy(hit_offsets, off.data(), (b->n_seqs + 1) * 8ull);
     if (total > capacity)
@@ -968,9 +970,16 @@ extern "C" int bigsi_hip_batch_compact_gathered(bigsi_hip_batch *b, const void *
     b->g_shards = n_shards;
     b->g_shard_cols = shard_cols;
     EventPair ep{};
-    TRY(ev_begin(b->ix, &ep));
+    TRY(ev_begin(b->ix, &ep, b->gstream));
     TRY(compact(b, b->ghits, d_gathered, n_shards, shard_cols, false));
-    TRY(ev_end(b->ix, &ep, b->ix->ev_cp));
+    TRY(ev_end(b->ix, &ep, b->ix->ev_cp, b->gstream));
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_batch_set_gather_stream(bigsi_hip_batch *b, void *hip_stream)
+{
+    if (!b) return fail(BIGSI_ERR_INVALID, "NULL batch");
+    b->gstream = (hipStream_t)hip_stream;
     return BIGSI_OK;
 }
 

@@ -59,11 +59,16 @@ class ShardGroup(object):
 class ShardedSearch(object):
     """Query batches against this rank's column shard + the collective that makes every rank see the whole result.
 
-    Owns one torch side stream: the library's kernels are put on it (bigsi_hip_set_stream) and the RCCL collective is
-    issued under it, so kernel -> all-gather -> compaction are ordered by torch's usual stream semantics.  (torch's
-    default stream has handle 0, which the C ABI reserves for "use the library's private stream".)"""
+    Two torch streams.  `stream` (compute) carries the library's K1-K3 kernels (bigsi_hip_set_stream); `comm` carries the
+    RCCL all-gather and the compaction of the gathered buffer (bigsi_hip_batch_set_gather_stream).  With two batches /
+    gather buffers used alternately (`slots=2`) the exchange of batch i overlaps the row-AND kernels of batch i+1:
+        compute:  run(i) ---------------- run(i+1) ------------- run(i+2) ...
+        comm:            gather(i) K4g(i)          gather(i+1) K4g(i+1)
+    Events order the two: comm waits for run(i); run(i+2) waits until gather/compaction of batch i released its buffer.
+    (torch's default stream has handle 0, which the C ABI reserves for "use the library's private stream", hence the
+    explicit side streams.)"""
 
-    def __init__(self, storage, shard_cols, group=None, device=None, force_gather=False):
+    def __init__(self, storage, shard_cols, group=None, device=None, force_gather=False, slots=2):
         import torch
         self.torch = torch
         self.force_gather = force_gather      # take the all-gather path even with one rank (testing)
@@ -72,43 +77,68 @@ class ShardedSearch(object):
         self.sg = ShardGroup(group)
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.stream = torch.cuda.Stream(self.device)
+        self.comm = torch.cuda.Stream(self.device)
         check(_lib.lib().bigsi_hip_set_stream(storage.handle, self.stream.cuda_stream))
-        self._buf = None
+        self.slots = int(slots)
+        self._bufs = [None] * self.slots
         self._buf_key = None
+        self._ev_run = [torch.cuda.Event() for _ in range(self.slots)]
+        self._ev_free = [None] * self.slots       # recorded on comm when a slot's gather + compaction are done
+        self._i = 0
+
+    @property
+    def gathering(self):
+        return self.sg.world > 1 or self.force_gather
 
     def close(self):
         check(_lib.lib().bigsi_hip_set_stream(self.storage.handle, None))
 
-    def prepare(self, batch, exact, count_bytes=2):
-        """Point the batch's result at this rank's slot of a [world, n_seqs*stride] gather buffer."""
+    def prepare(self, batches, exact, count_bytes=2):
+        """Give each batch (one per slot) its own [world, n_seqs*stride] gather buffer and point the batch's result at
+        this rank's slot of it."""
+        if not isinstance(batches, (list, tuple)):
+            batches = [batches]
+        if not self.gathering:
+            return
+        assert len(batches) <= self.slots
         inf = self.storage.res.info()
         wv_pad = (-(-int(inf.num_cols) // 64) + 1) // 2 * 2
         stride_bytes = wv_pad * 8 if exact else wv_pad * 64 * count_bytes
-        key = (batch.n, stride_bytes, exact)
-        if self._buf_key != key:
+        for s, batch in enumerate(batches):
             with self.torch.cuda.stream(self.stream):
-                self._buf = self.sg.gather_buffer(batch.n * stride_bytes, self.device)
-            self.stream.synchronize()
-            self._buf_key = key
-        if self.sg.world == 1 and not self.force_gather:
-            return self._buf          # alone: results stay in the batch's own buffers, nothing to exchange
-        slot = self._buf[self.sg.rank].data_ptr()
-        check(_lib.lib().bigsi_hip_batch_set_outputs(batch.b, slot if exact else None, None if exact else slot))
-        return self._buf
+                self._bufs[s] = self.sg.gather_buffer(batch.n * stride_bytes, self.device)
+            slot = self._bufs[s][self.sg.rank].data_ptr()
+            check(_lib.lib().bigsi_hip_batch_set_outputs(batch.b, slot if exact else None, None if exact else slot))
+            check(_lib.lib().bigsi_hip_batch_set_gather_stream(batch.b, self.comm.cuda_stream))
+        self.stream.synchronize()
 
-    def step(self, batch, threshold):
-        """Asynchronous: local K1-K3 (+K4 when alone), all-gather of the per-sample vectors, K4 over the gathered result."""
-        if self.sg.world == 1 and not self.force_gather:
+    def step(self, batches, threshold):
+        """Asynchronous.  Alone: K1-K4 of the next batch.  Sharded: K1-K3 on the compute stream, then all-gather of the
+        per-sample vectors + K4 over the gathered result on the comm stream."""
+        if not isinstance(batches, (list, tuple)):
+            batches = [batches]
+        s = self._i % len(batches)
+        batch = batches[s]
+        self._i += 1
+        if not self.gathering:
             batch.run(threshold, sparse_counts=True)
-            return self._buf
-        with self.torch.cuda.stream(self.stream):
+            return
+        torch = self.torch
+        with torch.cuda.stream(self.stream):
+            if self._ev_free[s] is not None:
+                self.stream.wait_event(self._ev_free[s])        # this slot's previous exchange has released the buffer
             batch.run(threshold, skip_compact=True)
-            self.sg.all_gather_in_place(self._buf)
-            check(_lib.lib().bigsi_hip_batch_compact_gathered(batch.b, self._buf.data_ptr(), self.sg.world, self.shard_cols))
-        return self._buf
+            self._ev_run[s].record(self.stream)
+        with torch.cuda.stream(self.comm):
+            self.comm.wait_event(self._ev_run[s])
+            self.sg.all_gather_in_place(self._bufs[s])
+            check(_lib.lib().bigsi_hip_batch_compact_gathered(batch.b, self._bufs[s].data_ptr(), self.sg.world, self.shard_cols))
+            if self._ev_free[s] is None:
+                self._ev_free[s] = torch.cuda.Event()
+            self._ev_free[s].record(self.comm)
 
     def fetch(self, batch):
-        if self.sg.world == 1 and not self.force_gather:
+        if not self.gathering:
             return batch.hits()
         off = np.zeros(batch.n + 1, np.uint64)
         cap = 1 << 12

@@ -183,6 +183,10 @@ int bigsi_hip_batch_presence(bigsi_hip_batch *b, uint32_t seq, const uint32_t *c
  * layout [shard][seq][stride] with this batch's strides; colour = shard * shard_cols + local column).
  * compact_gathered is asynchronous on the index's stream (call it after the RCCL all-gather, which the caller
  * issues on the same stream); fetch_gathered_hits synchronises and copies out, same format as fetch_hits. */
+/* Run this batch's gathered compaction (and the copies of fetch_gathered_hits) on a caller-owned hipStream_t -- typically
+ * the stream the collective is issued under, so that all-gather + compaction of one batch overlap the row-AND kernels of
+ * the next batch on the index's stream.  NULL = the index's stream. */
+int bigsi_hip_batch_set_gather_stream(bigsi_hip_batch *b, void *hip_stream);
 int bigsi_hip_batch_compact_gathered(bigsi_hip_batch *b, const void *d_gathered, uint32_t n_shards, uint64_t shard_cols);
 int bigsi_hip_batch_fetch_gathered_hits(bigsi_hip_batch *b, uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t capacity);
 
