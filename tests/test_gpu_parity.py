@@ -655,3 +655,96 @@ def test_sparse_counts_run_gives_same_hits(hip):
         assert np.array_equal(full[2][lo:hi], cnt0[full[1][lo:hi]])
     batch.close()
     st.delete_all()
+
+
+def test_error_behaviour(hip):
+    """Error codes of the C ABI and the exceptions the host shim turns them into (and the reference's own assertion
+    for threshold > 1, bigsi/graph/bigsi.py:176)."""
+    from bigsi_amd import _lib
+    from bigsi_amd._lib import BigsiHipError, C
+    L = _lib.lib()
+    out = C.c_void_p()
+    assert L.bigsi_hip_open(100, 8, 8, 3, 99, C.byref(out)) == _lib.ERR_INVALID and b"device" in L.bigsi_hip_last_error()
+    assert L.bigsi_hip_open(0, 8, 8, 3, 0, C.byref(out)) == _lib.ERR_INVALID
+    assert L.bigsi_hip_open(100, 8, 8, 0, 0, C.byref(out)) == _lib.ERR_INVALID
+    _lib.check(L.bigsi_hip_open(100, 70, 70, 3, 0, C.byref(out)))
+    ix = out
+    ids = np.array([5, 100], dtype=np.uint64)
+    buf = np.zeros((2, 9), np.uint8)
+    assert L.bigsi_hip_set_rows(ix, _lib.ptr(ids), 2, _lib.ptr(buf), 9) == _lib.ERR_RANGE
+    assert L.bigsi_hip_get_rows(ix, _lib.ptr(ids), 2, _lib.ptr(buf), 9) == _lib.ERR_RANGE
+    big = np.zeros((1, 4096), np.uint8)
+    assert L.bigsi_hip_set_rows(ix, _lib.ptr(ids), 1, _lib.ptr(big), 4096) == _lib.ERR_CAPACITY
+    assert L.bigsi_hip_set_num_cols(ix, 10 ** 6) == _lib.ERR_CAPACITY
+    assert L.bigsi_hip_insert_kmers(ix, 70, b"ACGT", _lib.ptr(np.array([0, 4], np.uint64)), 1, 3) == _lib.ERR_RANGE
+    b = C.c_void_p()
+    off = np.array([0, 4], np.uint64)
+    assert L.bigsi_hip_batch_create(ix, b"ACGT", _lib.ptr(off), 1, 0, C.byref(b)) == _lib.ERR_INVALID        # k = 0
+    assert L.bigsi_hip_batch_create(ix, b"ACGT", _lib.ptr(off), 0, 3, C.byref(b)) == _lib.ERR_INVALID        # empty batch
+    assert L.bigsi_hip_batch_create(ix, b"ACGT", _lib.ptr(np.array([4, 0], np.uint64)), 1, 3, C.byref(b)) == _lib.ERR_INVALID
+    _lib.check(L.bigsi_hip_batch_create(ix, b"ACGT", _lib.ptr(off), 1, 3, C.byref(b)))
+    cnt = np.zeros(70, np.uint32)
+    assert L.bigsi_hip_batch_fetch_counts(b, 0, _lib.ptr(cnt)) == _lib.ERR_STATE                              # before run
+    assert L.bigsi_hip_batch_run(b, 1.5, 0) == _lib.ERR_INVALID                                                # threshold > 1
+    assert L.bigsi_hip_batch_run(b, float("nan"), 0) == _lib.ERR_INVALID
+    _lib.check(L.bigsi_hip_batch_run(b, 1.0, 0))
+    assert L.bigsi_hip_batch_fetch_counts(b, 0, _lib.ptr(cnt)) == _lib.ERR_STATE                              # exact run
+    assert L.bigsi_hip_batch_fetch_bitmap(b, 3, _lib.ptr(buf)) == _lib.ERR_RANGE
+    hoff = np.zeros(2, np.uint64)
+    _lib.check(L.bigsi_hip_batch_run(b, -0.5, 0))            # negative threshold: every sample is a hit, like count >= ceil(<0)
+    assert L.bigsi_hip_batch_fetch_hits(b, _lib.ptr(hoff), None, None, 0) == _lib.ERR_CAPACITY and hoff[1] == 70
+    _lib.check(L.bigsi_hip_batch_destroy(b))
+    _lib.check(L.bigsi_hip_close(ix))
+    assert L.bigsi_hip_close(None) == 0 and L.bigsi_hip_batch_destroy(None) == 0
+    # host shim
+    c = cfg(3, 1000, 3)
+    bb = hip.BIGSI.build(c, [hip.BIGSI.bloom(c, ["ATC", "ATA"])], ["1"])
+    with pytest.raises(AssertionError):
+        bb.search("ATCATA", 1.5)
+    with pytest.raises(ValueError):
+        bb.search("ATCéTA", 1.0)              # non-ASCII query
+    with pytest.raises(ValueError):
+        bb.lookup([""])
+    with pytest.raises(ValueError):
+        hip.BIGSI.build(c, [hip.BIGSI.bloom(c, ["ATC"])], ["a", "b"])
+    with pytest.raises(TypeError):
+        bb.search("AT", 1.0)
+    with pytest.raises(UnboundLocalError):
+        bb.search("AT", 0.5)
+    assert bb.search("ATCATA", -1) == bb.search("ATCATA", 0)      # the reference accepts any threshold <= 1
+    bb.delete()
+
+
+def test_migrate_from_reference_style_storage(hip):
+    """An index held by a plain KV store in the reference's record format (here: the golden G3 rows in a dict) moves
+    into HBM through the contract and answers like the reference."""
+    from bigsi_amd.migrate import migrate_index
+    from bigsi_amd.storage import get_storage
+    from bigsi_amd.storage.contract import BaseStorage
+
+    class Dict(BaseStorage):
+        def __init__(self):
+            self.storage = {}
+
+        def delete_all(self):
+            self.storage = {}
+
+    case = load_golden("g3_search.json")
+    src = Dict()
+    names = list(case["samples"].keys())
+    for r, hx in enumerate(case["rows"]):
+        src.storage[("%d:bitarray" % r).encode()] = bytes.fromhex(hx)
+    for key, v in (("number_of_rows", case["m"]), ("number_of_cols", len(names)), ("ksi:bloomfilter_size", case["m"]), ("ksi:num_hashes", case["h"])):
+        src.set_integer(key, v)
+    for c, nme in enumerate(names):
+        src.set_string("metadata:%d" % c, nme)
+        src.set_integer("metadata:%s" % nme, c)
+    src.set_integer("metadata:colour_count", len(names))
+    c = cfg(case["k"], case["m"], case["h"])
+    assert migrate_index(src, get_storage(c)) == (case["m"], len(names), len(names))
+    b = hip.BIGSI(c)
+    assert rows_hex(b) == case["rows"]
+    for s in case["searches"][:60]:
+        t = int(s["threshold"]) if s.get("threshold_is_int") else s["threshold"]
+        check_search(lambda: b.search(s["seq"], t, s["score"]), s, "migrated")
+    b.delete()
