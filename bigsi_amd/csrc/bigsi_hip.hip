@@ -530,6 +530,7 @@ struct bigsi_hip_batch {
     HitBufs hits, ghits;
     // state of the last run
     bool ran = false, exact = false, compacted = false, sparse_counts = false;
+    bool local_from_counts = false;   // the last counting run was row-sliced: hits come from thresholding the counters
     uint32_t count_bytes = 2;
     double threshold = 1.0;
     uint64_t wv = 0, wv_pad = 0;   // valid / padded words per row at run time
@@ -646,13 +647,13 @@ extern "C" int bigsi_hip_batch_set_outputs(bigsi_hip_batch *b, void *d_bitmaps, 
 // -------- K2 dispatch
 template <int P, typename CountT>
 static void launch_count_h(bigsi_hip_batch *b, unsigned grid, unsigned block, uint32_t tiles, CountT *out, uint64_t out_stride,
-                           uint64_t *hit_bitmap, uint32_t sparse)
+                           uint64_t *hit_bitmap, uint32_t sparse, uint32_t slices)
 {
     bigsi_hip_index *ix = b->ix;
 #define BIGSI_LAUNCH_COUNT(H)                                                                                              \
     hipLaunchKernelGGL((k_and_count<P, H, CountT>), dim3(grid), dim3(block), 0, ix->stream, ix->d_index, ix->stride_words, \
                        (uint32_t)b->wv, b->rows.as<uint64_t>(), b->d_pos_off.as<uint64_t>(), b->num_unique.as<uint32_t>(), \
-                       ix->h, b->n_seqs, tiles, out, out_stride, b->min_kmers.as<uint32_t>(), ix->n_cols, hit_bitmap, b->wv_pad, sparse)
+                       ix->h, b->n_seqs, tiles, out, out_stride, b->min_kmers.as<uint32_t>(), ix->n_cols, hit_bitmap, b->wv_pad, sparse, slices)
     switch (ix->h) {
     case 1: BIGSI_LAUNCH_COUNT(1); break;
     case 2: BIGSI_LAUNCH_COUNT(2); break;
@@ -750,18 +751,30 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
     static const int and_block = [] { int v = env_int("BIGSI_HIP_AND_BLOCK", 256); return (v == 64 || v == 128 || v == 256) ? v : 256; }();
     static const int and_unroll = env_int("BIGSI_HIP_AND_UNROLL", 8);
     const uint32_t tiles = (uint32_t)ceil_div(b->wv, (uint64_t)and_block * kVec);
-    const uint64_t nblk = ceil_div(b->n_seqs, 8) * 8 * (uint64_t)tiles;
+    // small batches: cut every query's row list into slices so that ~2k wavefronts are in flight (see map_block)
+    static const int slices_env = env_int("BIGSI_HIP_SLICES", 0);
+    uint32_t slices = 1;
+    {
+        const uint64_t waves = (uint64_t)b->n_seqs * ceil_div(b->wv, 64 * kVec);
+        if (slices_env > 0) slices = (uint32_t)slices_env;
+        else if (waves < 1024) slices = (uint32_t)std::min<uint64_t>({64, ceil_div(2048, std::max<uint64_t>(waves, 1)), std::max<uint64_t>(b->max_pos / 16, 1)});
+        if (b->ext_bitmaps || b->ext_counts) slices = 1;      // gathered buffers are written in place, without presets
+        slices = std::max<uint32_t>(slices, 1);
+    }
+    b->local_from_counts = false;
+    const uint64_t nblk = ceil_div(b->n_seqs, 8) * 8 * (uint64_t)tiles * slices;
     if (nblk > 0x7FFFFFFFull) return fail(BIGSI_ERR_INVALID, "batch too large for one launch (%llu workgroups)", (unsigned long long)nblk);
     const unsigned grid = (unsigned)nblk;
     if (b->exact) {
         uint64_t *out = (uint64_t *)b->ext_bitmaps;
         if (!out) { TRY(b->bitmaps.reserve((size_t)b->n_seqs * b->wv_pad * 8)); out = b->bitmaps.as<uint64_t>(); }
+        if (slices > 1) HIP_TRY(hipMemsetAsync(out, 0xFF, (size_t)b->n_seqs * b->wv_pad * 8, ix->stream));
         TRY(ev_begin(ix, &ep));
 #define COMMA ,
 #define BIGSI_LAUNCH_EXACT(U)                                                                                                  \
     hipLaunchKernelGGL((k_and_exact<U>), dim3(grid), dim3(and_block), 0, ix->stream, ix->d_index, ix->stride_words, (uint32_t)b->wv, \
                        ix->n_cols, b->rows.as<uint64_t>(), b->d_pos_off.as<uint64_t>(), b->num_unique.as<uint32_t>(), ix->h,    \
-                       b->n_seqs, tiles, out, b->wv_pad)
+                       b->n_seqs, tiles, out, b->wv_pad, slices)
         static const int and_nt = env_int("BIGSI_HIP_AND_NT", 1);     // 0: plain loads (A/B against non-temporal)
         if (and_unroll == 4) BIGSI_LAUNCH_EXACT(4);
         else if (and_unroll == 16) BIGSI_LAUNCH_EXACT(16);
@@ -782,14 +795,18 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
         // the kernel also leaves the thresholded hit bitmap (count >= min_kmers), which is what K4 compacts on a single GPU
         TRY(b->bitmaps.reserve((size_t)b->n_seqs * b->wv_pad * 8));
         uint64_t *hb = b->bitmaps.as<uint64_t>();
-        b->sparse_counts = (flags & BIGSI_RUN_SPARSE_COUNTS) && !b->ext_counts;
+        b->sparse_counts = (flags & BIGSI_RUN_SPARSE_COUNTS) && !b->ext_counts && slices == 1;
         const uint32_t sparse = b->sparse_counts ? 1u : 0u;
+        if (slices > 1) {
+            HIP_TRY(hipMemsetAsync(out, 0, (size_t)b->n_seqs * cstride * b->count_bytes, ix->stream));
+            b->local_from_counts = true;      // K4 thresholds the summed counters
+        }
         TRY(ev_begin(ix, &ep));
         switch (P) {
-        case 6: launch_count_h<6, uint16_t>(b, grid, and_block, tiles, (uint16_t *)out, cstride, hb, sparse); break;
-        case 10: launch_count_h<10, uint16_t>(b, grid, and_block, tiles, (uint16_t *)out, cstride, hb, sparse); break;
-        case 16: launch_count_h<16, uint16_t>(b, grid, and_block, tiles, (uint16_t *)out, cstride, hb, sparse); break;
-        default: launch_count_h<32, uint32_t>(b, grid, and_block, tiles, (uint32_t *)out, cstride, hb, sparse); break;
+        case 6: launch_count_h<6, uint16_t>(b, grid, and_block, tiles, (uint16_t *)out, cstride, hb, sparse, slices); break;
+        case 10: launch_count_h<10, uint16_t>(b, grid, and_block, tiles, (uint16_t *)out, cstride, hb, sparse, slices); break;
+        case 16: launch_count_h<16, uint16_t>(b, grid, and_block, tiles, (uint16_t *)out, cstride, hb, sparse, slices); break;
+        default: launch_count_h<32, uint32_t>(b, grid, and_block, tiles, (uint32_t *)out, cstride, hb, sparse, slices); break;
         }
         HIP_TRY(hipGetLastError());
         TRY(ev_end(ix, &ep, ix->ev_and));
@@ -865,6 +882,8 @@ static int compact_ex(bigsi_hip_batch *b, HitBufs &hb, const void *src, bool fro
 // this shard's own result (n_shards == 1): always a bitmap; gathered buffers: bitmaps (exact) or counters (counting)
 static int compact(bigsi_hip_batch *b, HitBufs &hb, const void *src, uint32_t n_shards, uint64_t shard_cols, bool write_only)
 {
+    if (&hb == &b->hits && b->local_from_counts && !b->exact)
+        return compact_ex(b, hb, b->counts.p, true, nullptr, 1, shard_cols, write_only, b->ix->stream);
     if (&hb == &b->hits) {
         const void *bm = b->exact ? (b->ext_bitmaps ? b->ext_bitmaps : b->bitmaps.p) : b->bitmaps.p;
         const void *counters = b->exact ? nullptr : (b->ext_counts ? b->ext_counts : b->counts.p);

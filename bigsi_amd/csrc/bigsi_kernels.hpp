@@ -170,7 +170,7 @@ __device__ __forceinline__ uint32_t fnv1a(const char *s, uint32_t k)
 // straight-line register code.  KF = 0 is the generic run-time-k path.
 template <int KF>
 struct RegKmer {
-    uint8_t f[KF > 0 ? KF : 1];
+    uint32_t f[KF > 0 ? KF : 1];      // one register per byte (a uint8_t array would live in scratch)
     __device__ __forceinline__ void load(const char *s)
     {
 #pragma unroll
@@ -189,14 +189,14 @@ struct RegKmer {
         bool rc = false, decided = false;
 #pragma unroll
         for (int j = 0; j < KF; j++) {
-            const uint8_t a = f[j], b = complement(f[KF - 1 - j]);
+            const uint8_t a = (uint8_t)f[j], b = complement((uint8_t)f[KF - 1 - j]);
             if (!decided && a != b) { rc = b < a; decided = true; }
         }
 #pragma unroll
         for (int i = 0; i < (KF + 3) / 4; i++) w[i] = 0;
 #pragma unroll
         for (int j = 0; j < KF; j++) {
-            const uint8_t c = rc ? complement(f[KF - 1 - j]) : f[j];
+            const uint8_t c = rc ? complement((uint8_t)f[KF - 1 - j]) : (uint8_t)f[j];
             w[j >> 2] |= (uint32_t)c << (8 * (j & 3));
         }
     }
@@ -341,6 +341,17 @@ __global__ __launch_bounds__(kBlock) void k_kmer_rows(
 constexpr uint32_t kLdsMaxPos = 4096;
 
 template <int KF>
+__device__ __forceinline__ uint32_t dedupe_hash(const char *km, uint32_t k)
+{
+    if (KF > 0) {
+        RegKmer<KF> r;
+        r.load(km);
+        return r.fnv();
+    }
+    return fnv1a(km, k);
+}
+
+template <int KF>
 __global__ __launch_bounds__(1024) void k_kmerize_lds(
     const char *__restrict__ seqs, const uint64_t *__restrict__ seq_off, const uint64_t *__restrict__ pos_off,
     uint32_t k, uint32_t h, uint64_t m, double threshold, uint32_t tab_cap, uint32_t *__restrict__ first_pos,
@@ -362,16 +373,8 @@ __global__ __launch_bounds__(1024) void k_kmerize_lds(
     for (uint32_t i = threadIdx.x; i < tsize; i += blockDim.x) tab[i] = kEmpty;
     for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) sq[i] = s[i];
     __syncthreads();
-    auto hash_at = [&](uint32_t i) -> uint32_t {
-        if (KF > 0) {
-            RegKmer<KF> km;
-            km.load(sq + i);
-            return km.fnv();
-        }
-        return fnv1a(sq + i, k);
-    };
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        uint32_t slot = hash_at(i) & mask;
+        uint32_t slot = dedupe_hash<KF>(sq + i, k) & mask;
         for (;;) {
             const uint32_t cur = atomicCAS(&tab[slot], kEmpty, i);
             if (cur == kEmpty) break;
@@ -387,7 +390,7 @@ __global__ __launch_bounds__(1024) void k_kmerize_lds(
         const uint32_t i = base + threadIdx.x;
         uint32_t c = kEmpty;
         if (i < n) {
-            uint32_t slot = hash_at(i) & mask;
+            uint32_t slot = dedupe_hash<KF>(sq + i, k) & mask;
             for (;;) {
                 c = tab[slot];
                 if (c == i || kmer_equal(sq + c, sq + i, k)) break;
@@ -433,16 +436,20 @@ __global__ __launch_bounds__(1024) void k_kmerize_lds(
 // blockIdx -> (query, tile) is XCD-aware: hardware places block b on XCD b % 8, so all tiles of a query get the
 // same residue and run on one XCD, adjacent in dispatch order (their row-id lists and the address translations
 // of a row's page are shared in that XCD's L2).
+// Small batches do not fill the chip that way (one 1 kbp query on a 100k-sample index is 13 wavefronts), so a launch may
+// also cut every query's row list into `slices` pieces handled by different workgroups, which combine through atomics
+// (AND for the exact bitmap, ADD for counters).  slices == 1 is the plain, atomic-free path used by large batches.
 struct TileMap {
-    uint32_t q, tile;
+    uint32_t q, tile, slice;
     bool valid;
 };
-__device__ __forceinline__ TileMap map_block(uint32_t b, uint32_t n_seqs, uint32_t tiles)
+__device__ __forceinline__ TileMap map_block(uint32_t b, uint32_t n_seqs, uint32_t tiles, uint32_t slices = 1)
 {
     const uint32_t xcd = b & 7u, slot = b >> 3;
-    const uint32_t ql = slot / tiles, tile = slot - ql * tiles;
+    const uint32_t per_q = tiles * slices;
+    const uint32_t ql = slot / per_q, rem = slot - ql * per_q;
     const uint32_t q = ql * 8u + xcd;
-    return TileMap{q, tile, q < n_seqs};
+    return TileMap{q, rem / slices, rem % slices, q < n_seqs};
 }
 
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
@@ -462,16 +469,20 @@ template <int UNROLL, bool NT = true>
 __global__ __launch_bounds__(kBlock) void k_and_exact(
     const uint64_t *__restrict__ index, uint64_t stride_words, uint32_t wv, uint64_t n_cols,
     const uint64_t *__restrict__ rows, const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ num_unique,
-    uint32_t h, uint32_t n_seqs, uint32_t tiles, uint64_t *__restrict__ out, uint64_t out_stride_words)
+    uint32_t h, uint32_t n_seqs, uint32_t tiles, uint64_t *__restrict__ out, uint64_t out_stride_words,
+    uint32_t slices /* > 1: `out` was preset to all ones and slices combine with atomicAnd */)
 {
-    const TileMap tm = map_block(blockIdx.x, n_seqs, tiles);
+    const TileMap tm = map_block(blockIdx.x, n_seqs, tiles, slices);
     if (!tm.valid) return;
     const uint32_t w0 = (tm.tile * blockDim.x + threadIdx.x) * kVec;
     if (w0 >= wv) return;
-    const uint64_t R = (uint64_t)num_unique[tm.q] * h;
+    const uint64_t Rall = (uint64_t)num_unique[tm.q] * h;
+    const uint64_t per = (Rall + slices - 1) / slices;
+    uint64_t r = (uint64_t)tm.slice * per;
+    const uint64_t R = r + per < Rall ? r + per : Rall;
+    if (slices > 1 && r >= R && Rall != 0) return;        // nothing in this slice
     const uint64_t *qrows = rows + pos_off[tm.q] * h;
     u64x2 acc = {~0ull, ~0ull};
-    uint64_t r = 0;
     for (; r + UNROLL <= R; r += UNROLL) {
         u64x2 v[UNROLL];
 #pragma unroll
@@ -480,12 +491,17 @@ __global__ __launch_bounds__(kBlock) void k_and_exact(
         for (int j = 0; j < UNROLL; j++) acc &= v[j];
     }
     for (; r < R; r++) acc &= load_row_seg<NT>(index, qrows[r], stride_words, w0);
-    if (R == 0) acc = u64x2{0ull, 0ull};
+    if (Rall == 0) acc = u64x2{0ull, 0ull};
     acc.x &= valid_mask(w0, n_cols);
     acc.y &= valid_mask(w0 + 1, n_cols);
     uint64_t *o = out + (uint64_t)tm.q * out_stride_words + w0;
-    o[0] = acc.x;
-    if (w0 + 1 < out_stride_words) o[1] = acc.y;
+    if (slices > 1) {
+        atomicAnd((unsigned long long *)o, (unsigned long long)acc.x);
+        if (w0 + 1 < out_stride_words) atomicAnd((unsigned long long *)(o + 1), (unsigned long long)acc.y);
+    } else {
+        o[0] = acc.x;
+        if (w0 + 1 < out_stride_words) o[1] = acc.y;
+    }
 }
 
 // ------------------------------------------------------------------------------ K2 + K3b: per-sample counts
@@ -499,14 +515,19 @@ __global__ __launch_bounds__(kBlock) void k_and_count(
     const uint64_t *__restrict__ rows, const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ num_unique,
     uint32_t h_rt, uint32_t n_seqs, uint32_t tiles, CountT *__restrict__ out, uint64_t out_stride /* counters per query */,
     const uint32_t *__restrict__ min_kmers, uint64_t n_cols, uint64_t *__restrict__ hit_bitmap /* [seq][bm_stride] or null */,
-    uint64_t bm_stride, uint32_t sparse /* 1: store counters only for words that contain a hit */)
+    uint64_t bm_stride, uint32_t sparse /* 1: store counters only for words that contain a hit */,
+    uint32_t slices /* > 1: counters were preset to zero, slices add into them atomically; no fused threshold */)
 {
-    const TileMap tm = map_block(blockIdx.x, n_seqs, tiles);
+    const TileMap tm = map_block(blockIdx.x, n_seqs, tiles, slices);
     if (!tm.valid) return;
     const uint32_t w0 = (tm.tile * blockDim.x + threadIdx.x) * kVec;
     if (w0 >= wv) return;
     const uint32_t h = H > 0 ? (uint32_t)H : h_rt;
-    const uint32_t u = num_unique[tm.q];
+    const uint32_t uall = num_unique[tm.q];
+    const uint32_t per = (uall + slices - 1) / slices;
+    const uint32_t j0 = tm.slice * per;
+    const uint32_t u = j0 + per < uall ? j0 + per : uall;      // this slice covers unique k-mers [j0, u)
+    if (slices > 1 && j0 >= u) return;
     const uint64_t *qrows = rows + pos_off[tm.q] * h;
     uint64_t pl[kVec][P];
 #pragma unroll
@@ -524,7 +545,7 @@ __global__ __launch_bounds__(kBlock) void k_and_count(
         }
     };
 
-    uint32_t j = 0;
+    uint32_t j = j0;
     if (H > 0) {
         for (; j + 2 <= u; j += 2) {   // two k-mers = 2H independent row loads in flight per lane
             u64x2 v[2 * (H > 0 ? H : 1)];
@@ -546,7 +567,10 @@ __global__ __launch_bounds__(kBlock) void k_and_count(
     // threshold in bit-sliced form (graph/bigsi.py:241-242: count >= min_kmers): MSB-first comparator over the planes,
     // ~2 bit-ops per plane per word; the threshold is wave-uniform so its bit tests are scalar branches
     uint64_t ge[kVec];
-    {
+    if (slices > 1) {
+#pragma unroll
+        for (int v = 0; v < kVec; v++) ge[v] = ~0ull;      // partial counts: thresholding happens in K4, from the summed counters
+    } else {
         const uint32_t thr = min_kmers[tm.q];
 #pragma unroll
         for (int v = 0; v < kVec; v++) {
@@ -569,7 +593,10 @@ __global__ __launch_bounds__(kBlock) void k_and_count(
         if (cbase >= out_stride) break;
         if (sparse && ge[v] == 0) continue;
         CountT *o = out + (uint64_t)tm.q * out_stride + cbase;
-#pragma unroll
+        // 64 columns x P planes: fully unrolled up to 16 planes; for the 32-plane (> 65535 k-mers) variant the byte loop
+        // stays rolled (run-time shift amounts, plane indices still compile-time) to keep the code and registers bounded
+        constexpr int kByteUnroll = P > 16 ? 1 : 8;
+#pragma unroll kByteUnroll
         for (int b = 0; b < 8; b++) {
             CountT c[8];
 #pragma unroll
@@ -580,7 +607,20 @@ __global__ __launch_bounds__(kBlock) void k_and_count(
                 for (int p = 0; p < P; p++) x |= (uint32_t)((pl[v][p] >> bit) & 1ull) << p;
                 c[jj] = (CountT)x;
             }
-            if (sizeof(CountT) == 2) {
+            if (slices > 1) {
+                // partial sums never exceed the query's k-mer count, so packed uint16 pairs cannot carry into each other
+                if (sizeof(CountT) == 2) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const uint32_t pk = (uint32_t)c[2 * i] | ((uint32_t)c[2 * i + 1] << 16);
+                        if (pk) atomicAdd(reinterpret_cast<uint32_t *>(o + 8 * b) + i, pk);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; i++)
+                        if (c[i]) atomicAdd(reinterpret_cast<uint32_t *>(o + 8 * b) + i, (uint32_t)c[i]);
+                }
+            } else if (sizeof(CountT) == 2) {
                 uint4 pk;
                 pk.x = (uint32_t)c[0] | ((uint32_t)c[1] << 16); pk.y = (uint32_t)c[2] | ((uint32_t)c[3] << 16);
                 pk.z = (uint32_t)c[4] | ((uint32_t)c[5] << 16); pk.w = (uint32_t)c[6] | ((uint32_t)c[7] << 16);

@@ -649,8 +649,10 @@ def test_sparse_counts_run_gives_same_hits(hip):
         sparse = batch.hits()
         for a, b in zip(full, sparse):
             assert np.array_equal(a, b), thr
-        with pytest.raises(BigsiHipError):
-            batch.counts(0)
+        try:        # large batches store counters sparsely (then fetch_counts refuses); small, row-sliced ones keep them all
+            assert np.array_equal(batch.counts(0), cnt0)
+        except BigsiHipError as e:
+            assert e.code == -6
         lo, hi = int(full[0][0]), int(full[0][1])
         assert np.array_equal(full[2][lo:hi], cnt0[full[1][lo:hi]])
     batch.close()
@@ -748,3 +750,29 @@ def test_migrate_from_reference_style_storage(hip):
         t = int(s["threshold"]) if s.get("threshold_is_int") else s["threshold"]
         check_search(lambda: b.search(s["seq"], t, s["score"]), s, "migrated")
     b.delete()
+
+
+def test_sparse_counters_refuse_fetch_counts_on_large_batches(hip):
+    """A batch big enough to run unsliced (>= 1024 wavefronts) with BIGSI_RUN_SPARSE_COUNTS: hit lists complete, counters
+    of non-hit words never stored, fetch_counts -> BIGSI_ERR_STATE."""
+    from bigsi_amd._lib import BigsiHipError
+    from oracle.ref_model import SynthOracle
+    m, n_cols, h = 4001, 64 * 40, 3         # 40 words -> 1 wave per query: 1100 queries = 1100 waves
+    c, st = synth_index(hip, m, n_cols, h, 23, draws=1)
+    orc = SynthOracle(23, 0, m, n_cols, h, 31, 1)
+    seqs = random_seqs(np.random.default_rng(6), 1100, 31, 45)
+    st.insert_kmers(77, [seqs[5]], 31)
+    orc.insert_kmers(77, seqs[5])
+    batch = st.new_batch(seqs, 31)
+    batch.run(0.8, sparse_counts=True)
+    off, col, cnt = batch.hits()
+    with pytest.raises(BigsiHipError):
+        batch.counts(5)
+    for i in (0, 5, 700, 1099):
+        u, want_cnt = orc.counts(seqs[i])
+        want = np.flatnonzero(want_cnt >= int(np.ceil(u * 0.8)))
+        assert np.array_equal(col[int(off[i]):int(off[i + 1])], want)
+        assert np.array_equal(cnt[int(off[i]):int(off[i + 1])], want_cnt[want].astype(np.uint32))
+    assert 77 in col[int(off[5]):int(off[6])].tolist()
+    batch.close()
+    st.delete_all()
