@@ -17,6 +17,7 @@ RUN_FORCE_COUNTS = 1
 RUN_SKIP_COMPACT = 2
 RUN_K1_GLOBAL = 4
 RUN_SPARSE_COUNTS = 8
+RUN_NO_SORT = 16
 BLOOM_RAW = 1
 
 

@@ -525,6 +525,7 @@ struct bigsi_hip_batch {
     uint64_t total_pos = 0, max_pos = 0, max_len = 0;
     DevBuf seqs, d_seq_off, d_pos_off, d_tab_off, tab, first_pos, pos_unique, tmp, rows, num_kmers, num_unique, min_kmers;
     DevBuf pos_query, hsh, rep;   // per k-mer position: owning sequence, dedupe hash, class representative
+    DevBuf rows_sorted;           // the row ids K2 streams: each query's list in address order (k_sort_rows)
     DevBuf bitmaps, counts, scratch;
     void *ext_bitmaps = nullptr, *ext_counts = nullptr;
     HitBufs hits, ghits;
@@ -627,7 +628,7 @@ extern "C" int bigsi_hip_batch_destroy(bigsi_hip_batch *b)
     hipError_t e = hipSetDevice(b->ix->device);
     e = hipStreamSynchronize(b->ix->stream);
     (void)e;
-    for (DevBuf *d : {&b->pos_query, &b->hsh, &b->rep, &b->seqs, &b->d_seq_off, &b->d_pos_off, &b->d_tab_off, &b->tab, &b->first_pos, &b->pos_unique, &b->tmp, &b->rows,
+    for (DevBuf *d : {&b->rows_sorted, &b->pos_query, &b->hsh, &b->rep, &b->seqs, &b->d_seq_off, &b->d_pos_off, &b->d_tab_off, &b->tab, &b->first_pos, &b->pos_unique, &b->tmp, &b->rows,
                       &b->num_kmers, &b->num_unique, &b->min_kmers, &b->bitmaps, &b->counts, &b->scratch})
         d->release();
     b->hits.release();
@@ -646,13 +647,13 @@ extern "C" int bigsi_hip_batch_set_outputs(bigsi_hip_batch *b, void *d_bitmaps, 
 
 // -------- K2 dispatch
 template <int P, typename CountT>
-static void launch_count_h(bigsi_hip_batch *b, unsigned grid, unsigned block, uint32_t tiles, CountT *out, uint64_t out_stride,
-                           uint64_t *hit_bitmap, uint32_t sparse, uint32_t slices)
+static void launch_count_h(bigsi_hip_batch *b, const uint64_t *k2_rows, unsigned grid, unsigned block, uint32_t tiles, CountT *out,
+                           uint64_t out_stride, uint64_t *hit_bitmap, uint32_t sparse, uint32_t slices)
 {
     bigsi_hip_index *ix = b->ix;
 #define BIGSI_LAUNCH_COUNT(H)                                                                                              \
     hipLaunchKernelGGL((k_and_count<P, H, CountT>), dim3(grid), dim3(block), 0, ix->stream, ix->d_index, ix->stride_words, \
-                       (uint32_t)b->wv, b->rows.as<uint64_t>(), b->d_pos_off.as<uint64_t>(), b->num_unique.as<uint32_t>(), \
+                       (uint32_t)b->wv, k2_rows, b->d_pos_off.as<uint64_t>(), b->num_unique.as<uint32_t>(), \
                        ix->h, b->n_seqs, tiles, out, out_stride, b->min_kmers.as<uint32_t>(), ix->n_cols, hit_bitmap, b->wv_pad, sparse, slices)
     switch (ix->h) {
     case 1: BIGSI_LAUNCH_COUNT(1); break;
@@ -747,8 +748,26 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
     EventPair ep{};
     TRY(run_kmerize(b, threshold, (flags & BIGSI_RUN_K1_GLOBAL) != 0));
 
+    // K1e: address-ordered copy of the row lists for K2 (BIGSI_HIP_SORT_ROWS=0 streams them in hash order instead)
+    static const int sort_rows = env_int("BIGSI_HIP_SORT_ROWS", 1);
+    const uint64_t *k2_rows = b->rows.as<uint64_t>();
+    // exact path only: there every row can move freely (+4.7 % C3, +7.6 % C4-shard, interleaved A/B); on the counting path a
+    // k-mer's h rows must stay together and ordering k-mers by their first row measured 1.00x
+    if (sort_rows && b->exact && !(flags & BIGSI_RUN_NO_SORT) && b->total_pos) {
+        TRY(b->rows_sorted.reserve(std::max<uint64_t>(b->total_pos, 1) * ix->h * 8));
+        uint32_t shift = 0;
+        while (((ix->m - 1) >> shift) >= (uint64_t)kSortBuckets) shift++;
+        TRY(ev_begin(ix, &ep));
+        hipLaunchKernelGGL(k_sort_rows, dim3(b->n_seqs), dim3(kBlock), 0, ix->stream, b->rows.as<uint64_t>(), b->rows_sorted.as<uint64_t>(),
+                           b->d_pos_off.as<uint64_t>(), b->num_unique.as<uint32_t>(), ix->h, 1u, shift);
+        HIP_TRY(hipGetLastError());
+        TRY(ev_end(ix, &ep, ix->ev_km));
+        k2_rows = b->rows_sorted.as<uint64_t>();
+    }
     // K2
-    static const int and_block = [] { int v = env_int("BIGSI_HIP_AND_BLOCK", 256); return (v == 64 || v == 128 || v == 256) ? v : 256; }();
+    static const int and_block_env = [] { int v = env_int("BIGSI_HIP_AND_BLOCK", 256); return (v >= 64 && v <= 1024 && v % 64 == 0) ? v : 256; }();
+    // the counting kernels are compiled for at most 256 threads per workgroup (register budget of the plane arrays)
+    const int and_block = b->exact ? and_block_env : std::min(and_block_env, 256);
     static const int and_unroll = env_int("BIGSI_HIP_AND_UNROLL", 8);
     const uint32_t tiles = (uint32_t)ceil_div(b->wv, (uint64_t)and_block * kVec);
     // small batches: cut every query's row list into slices so that ~2k wavefronts are in flight (see map_block)
@@ -773,7 +792,7 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
 #define COMMA ,
 #define BIGSI_LAUNCH_EXACT(U)                                                                                                  \
     hipLaunchKernelGGL((k_and_exact<U>), dim3(grid), dim3(and_block), 0, ix->stream, ix->d_index, ix->stride_words, (uint32_t)b->wv, \
-                       ix->n_cols, b->rows.as<uint64_t>(), b->d_pos_off.as<uint64_t>(), b->num_unique.as<uint32_t>(), ix->h,    \
+                       ix->n_cols, k2_rows, b->d_pos_off.as<uint64_t>(), b->num_unique.as<uint32_t>(), ix->h,    \
                        b->n_seqs, tiles, out, b->wv_pad, slices)
         static const int and_nt = env_int("BIGSI_HIP_AND_NT", 1);     // 0: plain loads (A/B against non-temporal)
         if (and_unroll == 4) BIGSI_LAUNCH_EXACT(4);
@@ -803,10 +822,10 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
         }
         TRY(ev_begin(ix, &ep));
         switch (P) {
-        case 6: launch_count_h<6, uint16_t>(b, grid, and_block, tiles, (uint16_t *)out, cstride, hb, sparse, slices); break;
-        case 10: launch_count_h<10, uint16_t>(b, grid, and_block, tiles, (uint16_t *)out, cstride, hb, sparse, slices); break;
-        case 16: launch_count_h<16, uint16_t>(b, grid, and_block, tiles, (uint16_t *)out, cstride, hb, sparse, slices); break;
-        default: launch_count_h<32, uint32_t>(b, grid, and_block, tiles, (uint32_t *)out, cstride, hb, sparse, slices); break;
+        case 6: launch_count_h<6, uint16_t>(b, k2_rows, grid, and_block, tiles, (uint16_t *)out, cstride, hb, sparse, slices); break;
+        case 10: launch_count_h<10, uint16_t>(b, k2_rows, grid, and_block, tiles, (uint16_t *)out, cstride, hb, sparse, slices); break;
+        case 16: launch_count_h<16, uint16_t>(b, k2_rows, grid, and_block, tiles, (uint16_t *)out, cstride, hb, sparse, slices); break;
+        default: launch_count_h<32, uint32_t>(b, k2_rows, grid, and_block, tiles, (uint32_t *)out, cstride, hb, sparse, slices); break;
         }
         HIP_TRY(hipGetLastError());
         TRY(ev_end(ix, &ep, ix->ev_and));

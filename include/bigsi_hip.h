@@ -133,6 +133,7 @@ int bigsi_hip_lookup(bigsi_hip_index *ix, const char *kmers, uint32_t k, uint64_
 #define BIGSI_RUN_K1_GLOBAL 4u   /* take the multi-launch K1 (global-memory dedupe table) even for short queries (testing) */
 #define BIGSI_RUN_SPARSE_COUNTS 8u /* counting path: store per-sample counters only where a sample reaches min_kmers
                                       (hit lists are complete; fetch_counts is unavailable for that run) */
+#define BIGSI_RUN_NO_SORT 16u      /* stream each query's rows in hash order instead of address order (A/B measurements) */
 #define BIGSI_RUN_SKIP_COMPACT 2u /* stop after K2/K3: the caller compacts a gathered buffer instead (multi-GPU) */
 
 int bigsi_hip_batch_create(bigsi_hip_index *ix, const char *seqs, const uint64_t *offsets, uint32_t n_seqs,
