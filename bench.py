@@ -173,7 +173,7 @@ def main():
         t1 = time.perf_counter()
         for _ in range(reps):
             b2 = st.new_batch(seqs, args.k)
-            b2.run(args.threshold)
+            b2.run(args.threshold, sparse_counts=True)
             b2.hits()
             b2.close()
         pcie_rate = total_unique * reps / (time.perf_counter() - t1)
