@@ -18,6 +18,7 @@ RUN_SKIP_COMPACT = 2
 RUN_K1_GLOBAL = 4
 RUN_SPARSE_COUNTS = 8
 RUN_NO_SORT = 16
+RUN_EARLY_EXIT = 32
 BLOOM_RAW = 1
 
 

@@ -793,7 +793,7 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
 #define BIGSI_LAUNCH_EXACT(U)                                                                                                  \
     hipLaunchKernelGGL((k_and_exact<U>), dim3(grid), dim3(and_block), 0, ix->stream, ix->d_index, ix->stride_words, (uint32_t)b->wv, \
                        ix->n_cols, k2_rows, b->d_pos_off.as<uint64_t>(), b->num_unique.as<uint32_t>(), ix->h,    \
-                       b->n_seqs, tiles, out, b->wv_pad, slices)
+                       b->n_seqs, tiles, out, b->wv_pad, slices, (flags & BIGSI_RUN_EARLY_EXIT) ? 1u : 0u)
         static const int and_nt = env_int("BIGSI_HIP_AND_NT", 1);     // 0: plain loads (A/B against non-temporal)
         if (and_unroll == 4) BIGSI_LAUNCH_EXACT(4);
         else if (and_unroll == 16) BIGSI_LAUNCH_EXACT(16);

@@ -512,7 +512,8 @@ __global__ __launch_bounds__(1024) void k_and_exact(
     const uint64_t *__restrict__ index, uint64_t stride_words, uint32_t wv, uint64_t n_cols,
     const uint64_t *__restrict__ rows, const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ num_unique,
     uint32_t h, uint32_t n_seqs, uint32_t tiles, uint64_t *__restrict__ out, uint64_t out_stride_words,
-    uint32_t slices /* > 1: `out` was preset to all ones and slices combine with atomicAnd */)
+    uint32_t slices /* > 1: `out` was preset to all ones and slices combine with atomicAnd */,
+    uint32_t early_exit /* 1: a wavefront stops fetching once its 8192-column segment of the running AND is all zero */)
 {
     const TileMap tm = map_block(blockIdx.x, n_seqs, tiles, slices);
     if (!tm.valid) return;
@@ -531,6 +532,9 @@ __global__ __launch_bounds__(1024) void k_and_exact(
         for (int j = 0; j < UNROLL; j++) v[j] = load_row_seg<NT>(index, qrows[r + j], stride_words, w0);
 #pragma unroll
         for (int j = 0; j < UNROLL; j++) acc &= v[j];
+        // opt-in (BIGSI_RUN_EARLY_EXIT): no further row can set a bit again, so the result is unchanged; the bytes of the
+        // remaining rows are simply not read (NOT used by bench.py, whose algorithmic bytes assume every row is fetched)
+        if (early_exit && __ballot((acc.x | acc.y) != 0) == 0) { r = R; break; }
     }
     for (; r < R; r++) acc &= load_row_seg<NT>(index, qrows[r], stride_words, w0);
     if (Rall == 0) acc = u64x2{0ull, 0ull};

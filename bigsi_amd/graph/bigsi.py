@@ -152,7 +152,9 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
             return []
         batch = self.storage.new_batch(seqs, self.kmer_size)
         try:
-            batch.run(threshold, sparse_counts=True)      # hit lists only: counters of non-hits are never stored
+            # hit lists only: counters of non-hits are never stored; config key `early_exit: true` additionally lets an exact
+            # search stop reading a query's rows once no sample can match any more (identical results)
+            batch.run(threshold, sparse_counts=True, early_exit=bool(self.config.get("early_exit", False)))
             num_kmers, num_unique, _ = batch.unique()
             off, colours, counts = batch.hits()
             exact = threshold == 1.0
@@ -190,16 +192,3 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
                 sd["kmer-presence"] = col
                 r.add_score(sd)
         return [r.todict() for r in results if r.sample_name != DELETION_SPECIAL_SAMPLE_NAME]
-
-    # kept for callers that use the reference's helper names
-    def exact_filter(self, kmers_to_colours):
-        rows = list(kmers_to_colours.values())
-        acc = rows[0]
-        for r in rows[1:]:
-            acc = acc & r
-        colours = [i for i, b in enumerate(acc) if b]
-        return [BigsiQueryResult(c, self.colour_to_sample(c), len(kmers_to_colours), len(kmers_to_colours)) for c in colours]
-
-    def get_sample_list(self, colours):
-        names = self.colours_to_samples(colours)
-        return [names[c] for c in colours]

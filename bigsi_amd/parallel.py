@@ -28,11 +28,6 @@ def plan_shards(total_cols, world_size):
     return shard_cols, spans
 
 
-def globalise(hit_offsets, colours, counts, shard_cols, shard):
-    """Colour ids of one shard's local hit list -> global colours (host-side helper for per-shard fetches)."""
-    return hit_offsets, colours.astype(np.uint64) + np.uint64(shard) * np.uint64(shard_cols), counts
-
-
 class ShardGroup(object):
     """torch.distributed plumbing: rank / world, the gather buffer and the in-place all-gather."""
 

@@ -134,6 +134,8 @@ int bigsi_hip_lookup(bigsi_hip_index *ix, const char *kmers, uint32_t k, uint64_
 #define BIGSI_RUN_SPARSE_COUNTS 8u /* counting path: store per-sample counters only where a sample reaches min_kmers
                                       (hit lists are complete; fetch_counts is unavailable for that run) */
 #define BIGSI_RUN_NO_SORT 16u      /* stream each query's rows in hash order instead of address order (A/B measurements) */
+#define BIGSI_RUN_EARLY_EXIT 32u   /* exact path: stop fetching a query's rows for a column segment once its running AND is
+                                      all zero (same results, fewer bytes; not what the reference does, hence opt-in) */
 #define BIGSI_RUN_SKIP_COMPACT 2u /* stop after K2/K3: the caller compacts a gathered buffer instead (multi-GPU) */
 
 int bigsi_hip_batch_create(bigsi_hip_index *ix, const char *seqs, const uint64_t *offsets, uint32_t n_seqs,

@@ -776,3 +776,31 @@ def test_sparse_counters_refuse_fetch_counts_on_large_batches(hip):
     assert 77 in col[int(off[5]):int(off[6])].tolist()
     batch.close()
     st.delete_all()
+
+
+def test_early_exit_gives_identical_results(hip):
+    """BIGSI_RUN_EARLY_EXIT skips rows once a segment's running AND is zero; bitmaps and hit lists must not change."""
+    m, n_cols, h = 100003, 20000, 3
+    c, st = synth_index(hip, m, n_cols, h, 31)
+    seqs = random_seqs(np.random.default_rng(8), 300, 200, 600)     # >= 1024 wavefronts: the unsliced path
+    for i in (0, 17, 299):
+        st.insert_kmers(1000 + i, [seqs[i]], 31)
+        st.insert_kmers(n_cols - 1, [seqs[i]], 31)
+    batch = st.new_batch(seqs, 31)
+    batch.run(1.0)
+    ref = [x.copy() for x in batch.hits()]
+    ref_bm = [batch.bitmap(i).copy() for i in (0, 1, 17, 299)]
+    batch.run(1.0, early_exit=True)
+    got = batch.hits()
+    for a, b in zip(ref, got):
+        assert np.array_equal(a, b)
+    for j, i in enumerate((0, 1, 17, 299)):
+        assert np.array_equal(batch.bitmap(i), ref_bm[j])
+    assert int(ref[0][-1]) == 6
+    small = st.new_batch(seqs[:2], 31)                                  # sliced (atomicAnd) path
+    small.run(1.0, early_exit=True)
+    off, col, _ = small.hits()
+    assert col[int(off[0]):int(off[1])].tolist() == [1000, n_cols - 1] and off[2] == off[1]
+    small.close()
+    batch.close()
+    st.delete_all()
