@@ -157,9 +157,8 @@ def main():
     uniq_rows = 0
     for i in range(args.batch):
         uniq_rows += np.unique(batch.rows(i, nu[i])).size      # each needed row counted once (reference fetches the union once)
-    gathering = world > 1 or args.force_dist
-    # result vectors the kernel stores: the AND / hit bitmap, plus full per-sample counters only when they are gathered
-    out_bytes = args.batch * (wv * 8 + (args.cols * count_bytes if (not exact and gathering) else 0))
+    # result vector the kernel stores: one bit per sample (AND bitmap / thresholded hit mask); counters only where hits are
+    out_bytes = args.batch * wv * 8
     alg_bytes = uniq_rows * wv * 8 + out_bytes
     and_ms = stats.and_ms / max(stats.and_launches, 1)
     achieved = alg_bytes / (and_ms * 1e-3) / 1e9

@@ -87,6 +87,8 @@ SIGNATURES = {
     "bigsi_hip_batch_presence": (_i32, [_P, _u32, _P, _u32, _P]),
     "bigsi_hip_batch_set_gather_stream": (_i32, [_P, _P]),
     "bigsi_hip_batch_compact_gathered": (_i32, [_P, _P, _u32, _u64]),
+    "bigsi_hip_batch_compact_gathered_masks": (_i32, [_P, _P, _u32, _u64, _u32]),
+    "bigsi_hip_batch_set_gathered_hit_outputs": (_i32, [_P, _P, _P, _u64]),
     "bigsi_hip_batch_fetch_gathered_hits": (_i32, [_P, _P, _P, _P, _u64]),
     "bigsi_hip_set_profiling": (_i32, [_P, _i32]),
     "bigsi_hip_stats": (_i32, [_P, C.POINTER(Stats), _i32]),

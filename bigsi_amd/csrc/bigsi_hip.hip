@@ -512,6 +512,11 @@ extern "C" int bigsi_hip_stats(bigsi_hip_index *ix, bigsi_hip_stats_t *out, int 
 struct HitBufs {
     DevBuf chunk_hits, chunk_off, hit_off, hit_col, hit_cnt, overflow;
     uint64_t cap = 0;   // hits the col/cnt buffers can hold
+    uint32_t *xcol = nullptr, *xcnt = nullptr;   // caller-owned hit buffers (e.g. torch tensors that are then all-reduced)
+    uint64_t xcap = 0;
+    uint32_t *col() const { return xcol ? xcol : hit_col.as<uint32_t>(); }
+    uint32_t *cnt() const { return xcnt ? xcnt : hit_cnt.as<uint32_t>(); }
+    uint64_t capacity() const { return xcol ? xcap : cap; }
     void release()
     {
         chunk_hits.release(); chunk_off.release(); hit_off.release(); hit_col.release(); hit_cnt.release(); overflow.release();
@@ -540,6 +545,8 @@ struct bigsi_hip_batch {
     const void *g_src = nullptr;   // last gathered buffer handed to compact_gathered
     uint32_t g_shards = 0;
     uint64_t g_shard_cols = 0;
+    uint32_t g_own = 0;
+    bool g_masks = false;          // the gathered buffer holds hit masks of a counting run (counts come from this rank's counters)
     std::vector<uint32_t> h_num_unique, h_num_kmers;
     bool host_counts_valid = false;
 };
@@ -813,7 +820,7 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
         if (!out) { TRY(b->counts.reserve((size_t)b->n_seqs * cstride * b->count_bytes)); out = b->counts.p; }
         // the kernel also leaves the thresholded hit bitmap (count >= min_kmers), which is what K4 compacts on a single GPU
         TRY(b->bitmaps.reserve((size_t)b->n_seqs * b->wv_pad * 8));
-        uint64_t *hb = b->bitmaps.as<uint64_t>();
+        uint64_t *hb = b->ext_bitmaps ? (uint64_t *)b->ext_bitmaps : b->bitmaps.as<uint64_t>();
         b->sparse_counts = (flags & BIGSI_RUN_SPARSE_COUNTS) && !b->ext_counts && slices == 1;
         const uint32_t sparse = b->sparse_counts ? 1u : 0u;
         if (slices > 1) {
@@ -848,7 +855,7 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
 // otherwise src is a hit bitmap (the exact AND, or the counting kernel's fused count >= min_kmers mask) and the per-hit
 // count comes from `counters` (null on the exact path: every hit has count == num_unique).
 static int compact_ex(bigsi_hip_batch *b, HitBufs &hb, const void *src, bool from_counts, const void *counters,
-                      uint32_t n_shards, uint64_t shard_cols, bool write_only, hipStream_t st)
+                      uint32_t n_shards, uint64_t shard_cols, bool write_only, hipStream_t st, uint32_t own_shard = kAllShards)
 {
     const uint32_t chunks = !from_counts ? (uint32_t)ceil_div(b->wv, kBlock) : (uint32_t)ceil_div(b->wv_pad * 64, kChunkCols);
     const uint64_t per_seq = (uint64_t)n_shards * chunks, nchunks = per_seq * b->n_seqs;
@@ -857,7 +864,7 @@ static int compact_ex(bigsi_hip_batch *b, HitBufs &hb, const void *src, bool fro
     TRY(hb.chunk_off.reserve(nchunks * 8));
     TRY(hb.hit_off.reserve((b->n_seqs + 1) * 8ull));
     TRY(hb.overflow.reserve(4));
-    if (hb.cap == 0) {
+    if (hb.cap == 0 && !hb.xcol) {
         const uint64_t want = 1u << 16;
         TRY(hb.hit_col.reserve(want * 4));
         TRY(hb.hit_cnt.reserve(want * 4));
@@ -867,17 +874,16 @@ static int compact_ex(bigsi_hip_batch *b, HitBufs &hb, const void *src, bool fro
     HIP_TRY(hipMemsetAsync(hb.overflow.p, 0, 4, st));
 #define BIGSI_HITS_COMMON                                                                                                        \
     b->n_seqs, n_shards, chunks, shard_cols, from_counts ? b->min_kmers.as<uint32_t>() : b->num_unique.as<uint32_t>(),          \
-        hb.chunk_hits.as<uint32_t>(), hb.chunk_off.as<uint64_t>(), hb.hit_col.as<uint32_t>(), hb.hit_cnt.as<uint32_t>(), hb.cap, \
-        hb.overflow.as<uint32_t>()
+        hb.chunk_hits.as<uint32_t>(), hb.chunk_off.as<uint64_t>(), hb.col(), hb.cnt(), hb.capacity(), hb.overflow.as<uint32_t>()
     for (int pass = write_only ? 1 : 0; pass < 2; pass++) {
         if (!from_counts) {
             const uint64_t *bm = (const uint64_t *)src;
             if (pass == 0)
                 hipLaunchKernelGGL((k_hits_exact<false>), dim3(grid), dim3(kBlock), 0, st, bm, b->wv_pad, (uint32_t)b->wv, BIGSI_HITS_COMMON,
-                                   counters, b->count_bytes, b->wv_pad * 64);
+                                   counters, b->count_bytes, b->wv_pad * 64, own_shard);
             else
                 hipLaunchKernelGGL((k_hits_exact<true>), dim3(grid), dim3(kBlock), 0, st, bm, b->wv_pad, (uint32_t)b->wv, BIGSI_HITS_COMMON,
-                                   counters, b->count_bytes, b->wv_pad * 64);
+                                   counters, b->count_bytes, b->wv_pad * 64, own_shard);
         } else if (b->count_bytes == 2) {
             const uint16_t *c16 = (const uint16_t *)src;
             if (pass == 0) hipLaunchKernelGGL((k_hits_count<uint16_t, false>), dim3(grid), dim3(kBlock), 0, st, c16, b->wv_pad * 64, (uint32_t)b->wv, BIGSI_HITS_COMMON);
@@ -904,11 +910,14 @@ static int compact(bigsi_hip_batch *b, HitBufs &hb, const void *src, uint32_t n_
     if (&hb == &b->hits && b->local_from_counts && !b->exact)
         return compact_ex(b, hb, b->counts.p, true, nullptr, 1, shard_cols, write_only, b->ix->stream);
     if (&hb == &b->hits) {
-        const void *bm = b->exact ? (b->ext_bitmaps ? b->ext_bitmaps : b->bitmaps.p) : b->bitmaps.p;
+        const void *bm = b->ext_bitmaps ? b->ext_bitmaps : b->bitmaps.p;
         const void *counters = b->exact ? nullptr : (b->ext_counts ? b->ext_counts : b->counts.p);
         return compact_ex(b, hb, bm, false, counters, 1, shard_cols, write_only, b->ix->stream);
     }
-    return compact_ex(b, hb, src, !b->exact, nullptr, n_shards, shard_cols, write_only, b->gstream ? b->gstream : b->ix->stream);
+    hipStream_t gst = b->gstream ? b->gstream : b->ix->stream;
+    if (!b->exact && b->g_masks)
+        return compact_ex(b, hb, src, false, b->ext_counts ? b->ext_counts : b->counts.p, n_shards, shard_cols, write_only, gst, b->g_own);
+    return compact_ex(b, hb, src, !b->exact, nullptr, n_shards, shard_cols, write_only, gst);
 }
 
 // synchronise, make sure the hit lists fit (grow + rewrite if the write pass overflowed), copy them out
@@ -920,7 +929,11 @@ static int fetch_hits_from(bigsi_hip_batch *b, HitBufs &hb, const void *src, uin
     HIP_TRY(hipMemcpyAsync(off.data(), hb.hit_off.p, (b->n_seqs + 1) * 8ull, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     const uint64_t total = off[b->n_seqs];
-    if (total > hb.cap) {
+    if (hb.xcol && total > hb.xcap) {
+        if (hit_offsets) memcpy(hit_offsets, off.data(), (b->n_seqs + 1) * 8ull);
+        return fail(BIGSI_ERR_CAPACITY, "caller-owned hit buffers hold %llu entries, %llu needed", (unsigned long long)hb.xcap, (unsigned long long)total);
+    }
+    if (!hb.xcol && total > hb.cap) {
         TRY(hb.hit_col.reserve(total * 4));
         TRY(hb.hit_cnt.reserve(total * 4));
         hb.cap = total;
@@ -930,8 +943,8 @@ static int fetch_hits_from(bigsi_hip_batch *b, HitBufs &hb, const void *src, uin
     if (hit_offsets) memcpy(hit_offsets, off.data(), (b->n_seqs + 1) * 8ull);
     if (total > capacity)
         return fail(BIGSI_ERR_CAPACITY, "hit buffers hold %llu entries, %llu needed", (unsigned long long)capacity, (unsigned long long)total);
-    if (total && colours) HIP_TRY(hipMemcpy(colours, hb.hit_col.p, total * 4, hipMemcpyDeviceToHost));
-    if (total && counts) HIP_TRY(hipMemcpy(counts, hb.hit_cnt.p, total * 4, hipMemcpyDeviceToHost));
+    if (total && colours) HIP_TRY(hipMemcpy(colours, hb.col(), total * 4, hipMemcpyDeviceToHost));
+    if (total && counts) HIP_TRY(hipMemcpy(counts, hb.cnt(), total * 4, hipMemcpyDeviceToHost));
     return BIGSI_OK;
 }
 
@@ -1007,10 +1020,43 @@ extern "C" int bigsi_hip_batch_compact_gathered(bigsi_hip_batch *b, const void *
     b->g_src = d_gathered;
     b->g_shards = n_shards;
     b->g_shard_cols = shard_cols;
+    b->g_masks = false;
     EventPair ep{};
     TRY(ev_begin(b->ix, &ep, b->gstream));
     TRY(compact(b, b->ghits, d_gathered, n_shards, shard_cols, false));
     TRY(ev_end(b->ix, &ep, b->ix->ev_cp, b->gstream));
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_batch_compact_gathered_masks(bigsi_hip_batch *b, const void *d_gathered_masks, uint32_t n_shards, uint64_t shard_cols,
+                                                      uint32_t own_shard)
+{
+    TRY(need_run(b));
+    if (!d_gathered_masks || n_shards == 0 || own_shard >= n_shards) return fail(BIGSI_ERR_INVALID, "bad gathered buffer / shard");
+    if ((uint64_t)n_shards * shard_cols > 0xFFFFFFFFull) return fail(BIGSI_ERR_INVALID, "more than 2^32-1 colours in total");
+    if (b->exact) return bigsi_hip_batch_compact_gathered(b, d_gathered_masks, n_shards, shard_cols);
+    if (b->sparse_counts == false && b->local_from_counts) return fail(BIGSI_ERR_STATE, "row-sliced run: no hit masks were produced");
+    b->g_src = d_gathered_masks;
+    b->g_shards = n_shards;
+    b->g_shard_cols = shard_cols;
+    b->g_own = own_shard;
+    b->g_masks = true;
+    hipStream_t st = b->gstream ? b->gstream : b->ix->stream;
+    EventPair ep{};
+    TRY(ev_begin(b->ix, &ep, st));
+    const void *counters = b->ext_counts ? b->ext_counts : b->counts.p;
+    TRY(compact_ex(b, b->ghits, d_gathered_masks, false, counters, n_shards, shard_cols, false, st, own_shard));
+    TRY(ev_end(b->ix, &ep, b->ix->ev_cp, st));
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_batch_set_gathered_hit_outputs(bigsi_hip_batch *b, void *d_colours, void *d_counts, uint64_t capacity)
+{
+    if (!b) return fail(BIGSI_ERR_INVALID, "NULL batch");
+    if ((d_colours == nullptr) != (d_counts == nullptr)) return fail(BIGSI_ERR_INVALID, "give both buffers or neither");
+    b->ghits.xcol = (uint32_t *)d_colours;
+    b->ghits.xcnt = (uint32_t *)d_counts;
+    b->ghits.xcap = d_colours ? capacity : 0;
     return BIGSI_OK;
 }
 

@@ -621,7 +621,7 @@ __global__ __launch_bounds__(kBlock) void k_and_count(
 #pragma unroll
         for (int v = 0; v < kVec; v++) {
             uint64_t gt = 0, eq = ~0ull;
-            if (P < 32 && (thr >> P) != 0) eq = 0;            // threshold above any representable count
+            if (P < 32 && (thr >> (P & 31)) != 0) eq = 0;     // threshold above any representable count
 #pragma unroll
             for (int p = P - 1; p >= 0; p--) {
                 if ((thr >> p) & 1u) eq &= pl[v][p];
@@ -686,6 +686,7 @@ __global__ __launch_bounds__(kBlock) void k_and_count(
 // gathered from column shards): (a) hits per 2048-column chunk, (b) exclusive scan over chunks in
 // (seq, shard, chunk) order, (c) ordered write of (colour, count).  Colours ascend within a sequence
 // (exact_filter's np.where order, graph/bigsi.py:193-204; inexact_filter's dict order before its stable sort, :215-229).
+constexpr uint32_t kAllShards = 0xFFFFFFFFu;
 constexpr uint32_t kChunkCols = 2048;   // counting: kBlock threads x 8 columns per chunk; exact: kBlock words (16384 columns)
 
 __device__ __forceinline__ uint64_t chunk_index(uint32_t q, uint32_t shard, uint32_t chunk, uint32_t n_shards, uint32_t chunks)
@@ -700,7 +701,9 @@ __global__ __launch_bounds__(kBlock) void k_hits_exact(
     uint64_t shard_cols, const uint32_t *__restrict__ num_unique,
     uint32_t *__restrict__ chunk_hits, const uint64_t *__restrict__ chunk_off,
     uint32_t *__restrict__ hit_col, uint32_t *__restrict__ hit_cnt, uint64_t capacity, uint32_t *__restrict__ overflow,
-    const void *__restrict__ counters /* null: every hit's count is num_unique[q] */, uint32_t counter_bytes, uint64_t counter_stride)
+    const void *__restrict__ counters /* null: every hit's count is num_unique[q] */, uint32_t counter_bytes, uint64_t counter_stride,
+    uint32_t own_shard /* kAllShards: counters cover every shard ([shard][seq][stride]); else they are THIS rank's ([seq][stride])
+                          and hits of other shards get count 0 (the caller sums the arrays of all ranks) */)
 {
     __shared__ uint32_t lds[16];
     const uint32_t chunk = blockIdx.x % chunks, sq = blockIdx.x / chunks;
@@ -721,11 +724,13 @@ __global__ __launch_bounds__(kBlock) void k_hits_exact(
     if (o + mine > capacity) { *overflow = 1; return; }
     const uint32_t uq = num_unique[q];
     const uint64_t cbase = (uint64_t)shard * shard_cols + (uint64_t)w * 64;
-    const uint64_t cnt0 = ((uint64_t)shard * n_seqs + q) * counter_stride + (uint64_t)w * 64;
+    const bool owned = own_shard == kAllShards || own_shard == shard;
+    const uint64_t cnt0 = (own_shard == kAllShards ? (uint64_t)shard * n_seqs + q : (uint64_t)q) * counter_stride + (uint64_t)w * 64;
     for (uint32_t c = 0; c < 64; c++)
         if ((bits >> bit_of_col(c)) & 1ull) {
             hit_col[o] = (uint32_t)(cbase + c);
             hit_cnt[o] = !counters ? uq
+                         : !owned ? 0u
                          : counter_bytes == 2 ? (uint32_t) reinterpret_cast<const uint16_t *>(counters)[cnt0 + c]
                                               : reinterpret_cast<const uint32_t *>(counters)[cnt0 + c];
             o++;

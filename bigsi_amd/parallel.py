@@ -3,11 +3,14 @@
 Every stage of the query path is independent per sample column -- hashing depends only on the query, AND and
 counting are per column -- so rank g (one process per GPU) holds ALL m rows of columns
 [g * shard_cols, (g+1) * shard_cols) and runs K1-K3 on its slice for the same query batch.  The only exchange is
-one all-gather per batch of the per-sample result vectors (exact: one bit per sample, the AND bitmap; thresholded:
-one uint16/uint32 count per sample), RCCL over xGMI through torch.distributed (backend "nccl" is RCCL on ROCm).
-The local result is written by the kernels straight into this rank's slot of the gather buffer
-(bigsi_hip_batch_set_outputs), so the collective runs in place; compaction to (colour, count) lists then runs
-on every rank over the gathered [shard][seq][stride] buffer with colour = shard * shard_cols + local column.
+one all-gather per batch of ONE BIT PER SAMPLE -- the AND bitmap of an exact search, or the `count >= min_kmers` hit mask
+the counting kernel leaves for a thresholded one -- RCCL over xGMI through torch.distributed (backend "nccl" is RCCL on
+ROCm).  The local vector is written by the kernels straight into this rank's slot of the gather buffer
+(bigsi_hip_batch_set_outputs), so the collective runs in place; compaction to (colour, count) lists then runs on every
+rank over the gathered [shard][seq][stride] buffer with colour = shard * shard_cols + local column.  For a thresholded
+search each rank fills the counts of the hits that lie in ITS shard from its own counters (zero elsewhere) and one small
+fixed-size all-reduce (sum) of the per-hit count array completes the lists: 3.2 MB + 256 KB per rank and batch at C3
+instead of the 51 MB of uint16 counters a dense exchange would move.
 
 Row-range sharding is deliberately not offered: a query touches random rows, so every k-mer would need an
 AND-reduce across GPUs.
@@ -76,7 +79,9 @@ class ShardedSearch(object):
         check(_lib.lib().bigsi_hip_set_stream(storage.handle, self.stream.cuda_stream))
         self.slots = int(slots)
         self._bufs = [None] * self.slots
-        self._buf_key = None
+        self._hitbufs = [None] * self.slots       # (colours, counts) int32 tensors of the gathered hit lists, per slot
+        self._slot_of = {}
+        self._exact = True
         self._ev_run = [torch.cuda.Event() for _ in range(self.slots)]
         self._ev_free = [None] * self.slots       # recorded on comm when a slot's gather + compaction are done
         self._i = 0
@@ -98,14 +103,39 @@ class ShardedSearch(object):
         assert len(batches) <= self.slots
         inf = self.storage.res.info()
         wv_pad = (-(-int(inf.num_cols) // 64) + 1) // 2 * 2
-        stride_bytes = wv_pad * 8 if exact else wv_pad * 64 * count_bytes
+        stride_bytes = wv_pad * 8                   # one bit per sample, exact bitmap or thresholded hit mask
+        self._exact = bool(exact)
+        self._slot_of = {id(batch): s for s, batch in enumerate(batches)}
         for s, batch in enumerate(batches):
             with self.torch.cuda.stream(self.stream):
                 self._bufs[s] = self.sg.gather_buffer(batch.n * stride_bytes, self.device)
             slot = self._bufs[s][self.sg.rank].data_ptr()
-            check(_lib.lib().bigsi_hip_batch_set_outputs(batch.b, slot if exact else None, None if exact else slot))
+            check(_lib.lib().bigsi_hip_batch_set_outputs(batch.b, slot, None))
             check(_lib.lib().bigsi_hip_batch_set_gather_stream(batch.b, self.comm.cuda_stream))
+            if not exact:
+                self._set_hit_capacity(s, batch, 1 << 16)
         self.stream.synchronize()
+
+    def _set_hit_capacity(self, s, batch, cap):
+        """(Re)allocate slot s's gathered hit list buffers: torch tensors, because the counts get all-reduced."""
+        torch = self.torch
+        with torch.cuda.stream(self.comm):
+            col = torch.zeros(cap, dtype=torch.int32, device=self.device)
+            cnt = torch.zeros(cap, dtype=torch.int32, device=self.device)
+        self.comm.synchronize()
+        self._hitbufs[s] = (col, cnt)
+        check(_lib.lib().bigsi_hip_batch_set_gathered_hit_outputs(batch.b, col.data_ptr(), cnt.data_ptr(), cap))
+
+    def _exchange(self, s, batch):
+        """On the comm stream: all-gather the bit vectors, compact, and (thresholded) sum the per-hit counts."""
+        self.sg.all_gather_in_place(self._bufs[s])
+        if self._exact:
+            check(_lib.lib().bigsi_hip_batch_compact_gathered(batch.b, self._bufs[s].data_ptr(), self.sg.world, self.shard_cols))
+        else:
+            check(_lib.lib().bigsi_hip_batch_compact_gathered_masks(batch.b, self._bufs[s].data_ptr(), self.sg.world, self.shard_cols,
+                                                                   self.sg.rank))
+            if self.sg.dist.is_initialized():
+                self.sg.dist.all_reduce(self._hitbufs[s][1], group=self.sg.group)
 
     def step(self, batches, threshold):
         """Asynchronous.  Alone: K1-K4 of the next batch.  Sharded: K1-K3 on the compute stream, then all-gather of the
@@ -122,20 +152,34 @@ class ShardedSearch(object):
         with torch.cuda.stream(self.stream):
             if self._ev_free[s] is not None:
                 self.stream.wait_event(self._ev_free[s])        # this slot's previous exchange has released the buffer
-            batch.run(threshold, skip_compact=True)
+            batch.run(threshold, skip_compact=True, sparse_counts=True)
             self._ev_run[s].record(self.stream)
         with torch.cuda.stream(self.comm):
             self.comm.wait_event(self._ev_run[s])
-            self.sg.all_gather_in_place(self._bufs[s])
-            check(_lib.lib().bigsi_hip_batch_compact_gathered(batch.b, self._bufs[s].data_ptr(), self.sg.world, self.shard_cols))
+            self._exchange(s, batch)
             if self._ev_free[s] is None:
                 self._ev_free[s] = torch.cuda.Event()
             self._ev_free[s].record(self.comm)
 
-    def fetch(self, batch):
+    def fetch(self, batch, slot=None):
         if not self.gathering:
             return batch.hits()
         off = np.zeros(batch.n + 1, np.uint64)
+        if not self._exact:
+            # caller-owned hit buffers: on overflow grow them and redo this batch's exchange (rare: > capacity hits)
+            s = slot if slot is not None else self._slot_of[id(batch)]
+            while True:
+                cap = self._hitbufs[s][0].numel()
+                col = np.zeros(cap, np.uint32)
+                cnt = np.zeros(cap, np.uint32)
+                rc = _lib.lib().bigsi_hip_batch_fetch_gathered_hits(batch.b, _lib.ptr(off), _lib.ptr(col), _lib.ptr(cnt), cap)
+                if rc == _lib.ERR_CAPACITY:
+                    self._set_hit_capacity(s, batch, 1 << int(off[-1] - 1).bit_length())
+                    with self.torch.cuda.stream(self.comm):
+                        self._exchange(s, batch)
+                    continue
+                check(rc)
+                return off, col[: int(off[-1])], cnt[: int(off[-1])]
         cap = 1 << 12
         while True:
             col = np.zeros(cap, np.uint32)

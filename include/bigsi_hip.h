@@ -191,6 +191,16 @@ int bigsi_hip_batch_presence(bigsi_hip_batch *b, uint32_t seq, const uint32_t *c
  * the next batch on the index's stream.  NULL = the index's stream. */
 int bigsi_hip_batch_set_gather_stream(bigsi_hip_batch *b, void *hip_stream);
 int bigsi_hip_batch_compact_gathered(bigsi_hip_batch *b, const void *d_gathered, uint32_t n_shards, uint64_t shard_cols);
+/* Thresholded search over column shards without moving per-sample counters: the counting kernel also leaves each
+ * shard's hit mask (1 bit per sample: count >= min_kmers) in the bitmap output (bigsi_hip_batch_set_outputs), which is what
+ * gets all-gathered.  compact_gathered_masks compacts the gathered masks -- identically on every rank -- and fills each
+ * hit's count from THIS rank's counters when the hit lies in shard `own_shard`, 0 otherwise; the caller then sums the
+ * count arrays of all ranks (one fixed-size all-reduce over the buffer given to set_gathered_hit_outputs). */
+int bigsi_hip_batch_compact_gathered_masks(bigsi_hip_batch *b, const void *d_gathered_masks, uint32_t n_shards, uint64_t shard_cols,
+                                           uint32_t own_shard);
+/* Put the gathered hit lists (colours, counts: uint32[capacity] each) into caller-owned device memory.  With caller-owned
+ * buffers fetch_gathered_hits reports BIGSI_ERR_CAPACITY instead of growing them. */
+int bigsi_hip_batch_set_gathered_hit_outputs(bigsi_hip_batch *b, void *d_colours, void *d_counts, uint64_t capacity);
 int bigsi_hip_batch_fetch_gathered_hits(bigsi_hip_batch *b, uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t capacity);
 
 /* ------------------------------------------------------------------ measurement */

@@ -396,9 +396,11 @@ def test_size_independent_properties(hip):
 
 
 def test_gathered_compaction_two_shards_on_one_gpu(hip):
-    """Everything of the multi-GPU exchange except the RCCL call: two column shards run one after the other on this GPU,
-    each writing its per-sample vectors into its slot of a [shard][seq][stride] buffer (bigsi_hip_batch_set_outputs), then
-    bigsi_hip_batch_compact_gathered over the whole buffer; hits must equal the oracle's on the concatenated index."""
+    """Everything of the multi-GPU exchange except the RCCL calls: two column shards run one after the other on this GPU,
+    each writing its per-sample bit vector (exact AND bitmap / thresholded hit mask) into its slot of a [shard][seq][stride]
+    buffer (bigsi_hip_batch_set_outputs); then, as every rank would, each shard's batch compacts the whole buffer
+    (compact_gathered / compact_gathered_masks with its own shard id) and the per-hit counts are summed over "ranks".
+    Hits must equal the oracle's on the concatenated index.  Also the dense variant (gathered uint16 counters)."""
     import torch
     from bigsi_amd import _lib
     from oracle.ref_model import SynthOracle
@@ -414,36 +416,59 @@ def test_gathered_compaction_two_shards_on_one_gpu(hip):
         shards.append(st)
         orcs.append(orc)
     wv_pad = (-(-shard_cols // 64) + 1) // 2 * 2
-    for thr in (1.0, 0.3):
+    L = _lib.lib()
+
+    def fetch(b):
+        off = np.zeros(len(seqs) + 1, np.uint64)
+        col = np.zeros(1 << 16, np.uint32)
+        cnt = np.zeros(1 << 16, np.uint32)
+        _lib.check(L.bigsi_hip_batch_fetch_gathered_hits(b.b, _lib.ptr(off), _lib.ptr(col), _lib.ptr(cnt), col.size))
+        return off, col[: int(off[-1])], cnt[: int(off[-1])]
+
+    for thr, dense in ((1.0, False), (0.3, False), (0.3, True)):
         exact = thr == 1.0
-        stride = wv_pad * 8 if exact else wv_pad * 64 * 2
+        stride = wv_pad * 64 * 2 if dense else wv_pad * 8
         buf = torch.zeros((world, len(seqs) * stride), dtype=torch.uint8, device="cuda")
         torch.cuda.synchronize()
         batches = []
         for g, st in enumerate(shards):
             b = st.new_batch(seqs, 31)
             slot = buf[g].data_ptr()
-            _lib.check(_lib.lib().bigsi_hip_batch_set_outputs(b.b, slot if exact else None, None if exact else slot))
-            b.run(thr, skip_compact=True)
-            _lib.check(_lib.lib().bigsi_hip_synchronize(st.handle))
+            _lib.check(L.bigsi_hip_batch_set_outputs(b.b, None if dense else slot, slot if dense else None))
+            b.run(thr, skip_compact=True, sparse_counts=not dense)
+            _lib.check(L.bigsi_hip_synchronize(st.handle))
             batches.append(b)
-        b0 = batches[0]
-        _lib.check(_lib.lib().bigsi_hip_batch_compact_gathered(b0.b, buf.data_ptr(), world, shard_cols))
-        off = np.zeros(len(seqs) + 1, np.uint64)
-        col = np.zeros(1 << 16, np.uint32)
-        cnt = np.zeros(1 << 16, np.uint32)
-        _lib.check(_lib.lib().bigsi_hip_batch_fetch_gathered_hits(b0.b, _lib.ptr(off), _lib.ptr(col), _lib.ptr(cnt), col.size))
-        _, nu, mk = b0.unique()
+        per_rank = []
+        for g, b in enumerate(batches):
+            if exact or dense:
+                _lib.check(L.bigsi_hip_batch_compact_gathered(b.b, buf.data_ptr(), world, shard_cols))
+            else:
+                _lib.check(L.bigsi_hip_batch_compact_gathered_masks(b.b, buf.data_ptr(), world, shard_cols, g))
+            per_rank.append(fetch(b))
+        off, col = per_rank[0][0], per_rank[0][1]
+        for r in per_rank[1:]:
+            assert np.array_equal(r[0], off) and np.array_equal(r[1], col)        # every rank derives the same lists
+        if exact or dense:
+            cnt = per_rank[0][2]
+            assert all(np.array_equal(r[2], cnt) for r in per_rank)
+        else:
+            cnt = sum(r[2].astype(np.uint64) for r in per_rank).astype(np.uint32)  # the all-reduce
+            for g, r in enumerate(per_rank):                                       # each rank only knows its own shard's counts
+                other = (col // shard_cols) != g
+                assert not r[2][other].any()
+        _, nu, mk = batches[0].unique()
         for i, s in enumerate(seqs):
             want_cnt = np.concatenate([o.counts(s)[1] for o in orcs])
             want = np.flatnonzero(want_cnt >= (nu[i] if exact else mk[i]))
             lo, hi = int(off[i]), int(off[i + 1])
-            assert np.array_equal(col[lo:hi], want), (thr, i)
-            assert np.array_equal(cnt[lo:hi], want_cnt[want].astype(np.uint32))
+            assert np.array_equal(col[lo:hi], want), (thr, dense, i)
+            assert np.array_equal(cnt[lo:hi], want_cnt[want].astype(np.uint32)), (thr, dense, i)
         # a shard's own (local) hit list is still available after a skip_compact run
-        loff, lcol, _ = batches[1].hits()
-        want1 = np.flatnonzero(orcs[1].counts(seqs[0])[1] >= (nu[0] if exact else mk[0]))
+        loff, lcol, lcnt = batches[1].hits()
+        c1 = orcs[1].counts(seqs[0])[1]
+        want1 = np.flatnonzero(c1 >= (nu[0] if exact else mk[0]))
         assert np.array_equal(lcol[int(loff[0]):int(loff[1])], want1)
+        assert np.array_equal(lcnt[int(loff[0]):int(loff[1])], c1[want1].astype(np.uint32))
         for b in batches:
             b.close()
     for st in shards:
