@@ -75,6 +75,7 @@ SIGNATURES = {
     "bigsi_hip_lookup": (_i32, [_P, C.c_char_p, _u32, _u64, _P]),
     "bigsi_hip_batch_create": (_i32, [_P, C.c_char_p, _P, _u32, _u32, C.POINTER(_P)]),
     "bigsi_hip_batch_destroy": (_i32, [_P]),
+    "bigsi_hip_batch_reload": (_i32, [_P, C.c_char_p, _P, _u32, _u32]),
     "bigsi_hip_batch_run": (_i32, [_P, _dbl, _u32]),
     "bigsi_hip_batch_get_info": (_i32, [_P, C.POINTER(BatchInfo)]),
     "bigsi_hip_batch_set_outputs": (_i32, [_P, _P, _P]),

@@ -536,6 +536,7 @@ struct bigsi_hip_batch {
     HitBufs hits, ghits;
     // state of the last run
     bool ran = false, exact = false, compacted = false, sparse_counts = false;
+    bool pos_query_loaded = false;    // pos_query holds this load's position -> sequence map
     bool local_from_counts = false;   // the last counting run was row-sliced: hits come from thresholding the counters
     uint32_t count_bytes = 2;
     double threshold = 1.0;
@@ -558,22 +559,16 @@ static uint64_t pow2_at_least(uint64_t x)
     return p;
 }
 
-extern "C" int bigsi_hip_batch_create(bigsi_hip_index *ix, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k, bigsi_hip_batch **out)
+// (re)load a batch object with sequences: host-side prefix arrays, grow-only device buffers, H2D copies
+static int batch_load(bigsi_hip_batch *b, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k)
 {
-    if (!out) return fail(BIGSI_ERR_INVALID, "out is NULL");
-    *out = nullptr;
-    if (!ix || !offsets) return fail(BIGSI_ERR_INVALID, "NULL argument");
-    if (n_seqs == 0) return fail(BIGSI_ERR_INVALID, "a batch needs at least one sequence");
-    if (k == 0) return fail(BIGSI_ERR_INVALID, "k must be > 0");
-    TRY(check_offsets(offsets, n_seqs));
+    bigsi_hip_index *ix = b->ix;
     const uint64_t base = offsets[0], nbytes = offsets[n_seqs] - base;
-    if (nbytes && !seqs) return fail(BIGSI_ERR_INVALID, "seqs is NULL");
-    TRY(use_device(ix));
-    bigsi_hip_batch *b = new (std::nothrow) bigsi_hip_batch();
-    if (!b) return fail(BIGSI_ERR_NOMEM, "host allocation failed");
-    b->ix = ix;
     b->n_seqs = n_seqs;
     b->k = k;
+    b->ran = b->compacted = b->host_counts_valid = false;
+    b->g_src = nullptr;
+    b->max_pos = b->max_len = 0;
     b->seq_off.resize(n_seqs + 1);
     b->pos_off.resize(n_seqs + 1);
     b->tab_off.resize(n_seqs + 1);
@@ -595,12 +590,9 @@ extern "C" int bigsi_hip_batch_create(bigsi_hip_index *ix, const char *seqs, con
     R(b->d_seq_off, (n_seqs + 1) * 8ull);
     R(b->d_pos_off, (n_seqs + 1) * 8ull);
     R(b->d_tab_off, (n_seqs + 1) * 8ull);
-    R(b->tab, b->tab_off[n_seqs] * 4);
     R(b->first_pos, T * 4);
     R(b->pos_unique, T * 4);
     R(b->tmp, T * 4);
-    R(b->pos_query, T * 4);
-    R(b->hsh, T * 4);
     R(b->rep, T * 4);
     R(b->rows, T * ix->h * 8);
     R(b->num_kmers, n_seqs * 4ull);
@@ -616,17 +608,47 @@ extern "C" int bigsi_hip_batch_create(bigsi_hip_index *ix, const char *seqs, con
     H2D(b->d_seq_off.p, b->seq_off.data(), (n_seqs + 1) * 8ull);
     H2D(b->d_pos_off.p, b->pos_off.data(), (n_seqs + 1) * 8ull);
     H2D(b->d_tab_off.p, b->tab_off.data(), (n_seqs + 1) * 8ull);
-    std::vector<uint32_t> pos_query(b->total_pos);
-    for (uint32_t i = 0; i < n_seqs; i++)
-        std::fill(pos_query.begin() + b->pos_off[i], pos_query.begin() + b->pos_off[i + 1], i);
-    H2D(b->pos_query.p, pos_query.data(), b->total_pos * 4);
+    b->pos_query_loaded = false;
     if (rc == BIGSI_OK) {
-        hipError_t e = hipStreamSynchronize(ix->stream);
+        hipError_t e = hipStreamSynchronize(ix->stream);      // the host vectors above are read by the copies
         if (e != hipSuccess) rc = fail(BIGSI_ERR_HIP, "sync: %s", hipGetErrorString(e));
     }
+    return rc;
+}
+
+static int check_batch_args(bigsi_hip_index *ix, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k)
+{
+    if (!ix || !offsets) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    if (n_seqs == 0) return fail(BIGSI_ERR_INVALID, "a batch needs at least one sequence");
+    if (k == 0) return fail(BIGSI_ERR_INVALID, "k must be > 0");
+    TRY(check_offsets(offsets, n_seqs));
+    if (offsets[n_seqs] - offsets[0] && !seqs) return fail(BIGSI_ERR_INVALID, "seqs is NULL");
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_batch_create(bigsi_hip_index *ix, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k, bigsi_hip_batch **out)
+{
+    if (!out) return fail(BIGSI_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    TRY(check_batch_args(ix, seqs, offsets, n_seqs, k));
+    TRY(use_device(ix));
+    bigsi_hip_batch *b = new (std::nothrow) bigsi_hip_batch();
+    if (!b) return fail(BIGSI_ERR_NOMEM, "host allocation failed");
+    b->ix = ix;
+    int rc = batch_load(b, seqs, offsets, n_seqs, k);
     if (rc != BIGSI_OK) { bigsi_hip_batch_destroy(b); return rc; }
     *out = b;
     return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_batch_reload(bigsi_hip_batch *b, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k)
+{
+    if (!b) return fail(BIGSI_ERR_INVALID, "NULL batch");
+    TRY(check_batch_args(b->ix, seqs, offsets, n_seqs, k));
+    TRY(use_device(b->ix));
+    HIP_TRY(hipStreamSynchronize(b->ix->stream));
+    if (b->gstream) HIP_TRY(hipStreamSynchronize(b->gstream));
+    return batch_load(b, seqs, offsets, n_seqs, k);
 }
 
 extern "C" int bigsi_hip_batch_destroy(bigsi_hip_batch *b)
@@ -702,6 +724,18 @@ static int run_kmerize(bigsi_hip_batch *b, double threshold, bool force_global =
         TRY(ev_end(ix, &ep, ix->ev_km));
         b->run_h = ix->h;
         return BIGSI_OK;
+    }
+    {   // the multi-launch route's scratch (allocated lazily: batches of short queries never need it)
+        const uint64_t Tn = std::max<uint64_t>(b->total_pos, 1);
+        TRY(b->tab.reserve(b->tab_off[b->n_seqs] * 4));
+        TRY(b->hsh.reserve(Tn * 4));
+        if (b->pos_query.cap < Tn * 4 || !b->pos_query_loaded) {
+            TRY(b->pos_query.reserve(Tn * 4));
+            std::vector<uint32_t> pq(b->total_pos);
+            for (uint32_t i = 0; i < b->n_seqs; i++) std::fill(pq.begin() + b->pos_off[i], pq.begin() + b->pos_off[i + 1], i);
+            if (b->total_pos) HIP_TRY(hipMemcpy(b->pos_query.p, pq.data(), b->total_pos * 4, hipMemcpyHostToDevice));
+            b->pos_query_loaded = true;
+        }
     }
     HIP_TRY(hipMemsetAsync(b->tab.p, 0xFF, b->tab_off[b->n_seqs] * 4, ix->stream));
     TRY(ev_begin(ix, &ep));

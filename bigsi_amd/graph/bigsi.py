@@ -123,6 +123,10 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
         self.insert_bloom(bloomfilter, colour - 1)
 
     def delete(self):
+        batch = getattr(self, "_batch", None)
+        if batch is not None:
+            batch.close()
+            self._batch = None
         self.storage.delete_all()
 
     def merge(self, bigsi):
@@ -150,28 +154,30 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
         seqs = list(seqs)
         if not seqs:
             return []
-        batch = self.storage.new_batch(seqs, self.kmer_size)
-        try:
-            # hit lists only: counters of non-hits are never stored; config key `early_exit: true` additionally lets an exact
-            # search stop reading a query's rows once no sample can match any more (identical results)
-            batch.run(threshold, sparse_counts=True, early_exit=bool(self.config.get("early_exit", False)))
-            num_kmers, num_unique, _ = batch.unique()
-            off, colours, counts = batch.hits()
-            exact = threshold == 1.0
-            out = []
-            for i in range(len(seqs)):
-                u, n = int(num_unique[i]), int(num_kmers[i])
-                if u == 0:
-                    # the reference fails on a query without k-mers: reduce() over nothing on the exact branch
-                    # (utils/fncts.py:24-25), an unbound accumulator on the other (graph/bigsi.py:35-44)
-                    if exact:
-                        raise TypeError("reduce() of empty sequence with no initial value")
-                    raise UnboundLocalError("local variable 'cumsum' referenced before assignment")
-                lo, hi = int(off[i]), int(off[i + 1])
-                out.append(self._assemble(batch, i, colours[lo:hi], counts[lo:hi], u, n, exact, score))
-            return out
-        finally:
-            batch.close()
+        # one batch workspace per index object, reloaded for every call (allocation is paid once)
+        batch = getattr(self, "_batch", None)
+        if batch is None or batch.b is None or batch.storage.res is not self.storage.res:
+            batch = self._batch = self.storage.new_batch(seqs, self.kmer_size)
+        else:
+            batch.reload(seqs, self.kmer_size)
+        # hit lists only: counters of non-hits are never stored; config key `early_exit: true` additionally lets an exact
+        # search stop reading a query's rows once no sample can match any more (identical results)
+        batch.run(threshold, sparse_counts=True, early_exit=bool(self.config.get("early_exit", False)))
+        num_kmers, num_unique, _ = batch.unique()
+        off, colours, counts = batch.hits()
+        exact = threshold == 1.0
+        out = []
+        for i in range(len(seqs)):
+            u, n = int(num_unique[i]), int(num_kmers[i])
+            if u == 0:
+                # the reference fails on a query without k-mers: reduce() over nothing on the exact branch
+                # (utils/fncts.py:24-25), an unbound accumulator on the other (graph/bigsi.py:35-44)
+                if exact:
+                    raise TypeError("reduce() of empty sequence with no initial value")
+                raise UnboundLocalError("local variable 'cumsum' referenced before assignment")
+            lo, hi = int(off[i]), int(off[i + 1])
+            out.append(self._assemble(batch, i, colours[lo:hi], counts[lo:hi], u, n, exact, score))
+        return out
 
     def _assemble(self, batch, i, colours, counts, u, n, exact, score):
         if exact:

@@ -21,6 +21,7 @@ import json
 import os
 import re
 import struct
+import weakref
 
 import numpy as np
 
@@ -44,6 +45,7 @@ class _Resident(object):
         self.m = None
         self.pending = {}            # row -> bytes, only while m is unknown
         self.written = None          # np.bool_[m]: rows that have been stored (KeyError semantics of a KV store)
+        self.batches = weakref.WeakSet()   # live QueryBatch objects: they hold the index handle and must die before it
 
     # ---- device lifecycle
     def _hint(self, key):
@@ -78,6 +80,8 @@ class _Resident(object):
         return inf
 
     def free(self):
+        for b in list(self.batches):
+            b.close()
         if self.ix is not None:
             check(_lib.lib().bigsi_hip_close(self.ix))
         self.ix, self.m, self.written = None, None, None
@@ -328,6 +332,15 @@ class QueryBatch(object):
         check(_lib.lib().bigsi_hip_batch_create(storage.handle, blob, _lib.ptr(off), self.n, int(k), _lib.C.byref(out)))
         self.b = out
         self.k = int(k)
+        storage.res.batches.add(self)
+
+    def reload(self, seqs, k=None):
+        """Stage a different set of sequences in this batch object, keeping its device buffers (bigsi_hip_batch_reload)."""
+        blob, off = _lib.pack_seqs(seqs)
+        self.k = int(k) if k is not None else self.k
+        check(_lib.lib().bigsi_hip_batch_reload(self.b, blob, _lib.ptr(off), len(seqs), self.k))
+        self.n, self._off = len(seqs), off
+        return self
 
     def close(self):
         if self.b is not None:

@@ -141,6 +141,9 @@ int bigsi_hip_lookup(bigsi_hip_index *ix, const char *kmers, uint32_t k, uint64_
 int bigsi_hip_batch_create(bigsi_hip_index *ix, const char *seqs, const uint64_t *offsets, uint32_t n_seqs,
                            uint32_t k, bigsi_hip_batch **out);
 int bigsi_hip_batch_destroy(bigsi_hip_batch *b);
+/* Load a different set of sequences into an existing batch object: device buffers are kept and only grow, so a serving
+ * loop pays allocation once.  Output / stream settings of the batch are kept; results of earlier runs are discarded. */
+int bigsi_hip_batch_reload(bigsi_hip_batch *b, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k);
 int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_t flags);
 
 typedef struct {

@@ -829,3 +829,35 @@ def test_early_exit_gives_identical_results(hip):
     small.close()
     batch.close()
     st.delete_all()
+
+
+def test_batch_reload_reuses_workspace(hip):
+    """bigsi_hip_batch_reload: new sequences (more, fewer, longer, a different k, long enough to switch K1 route) in the
+    same batch object give the same results as a fresh batch."""
+    from oracle.ref_model import SynthOracle
+    m, n_cols, h = 9001, 500, 3
+    c, st = synth_index(hip, m, n_cols, h, 3, draws=1)
+    rng = np.random.default_rng(12)
+    sets = [(31, random_seqs(rng, 5, 40, 80)), (31, random_seqs(rng, 40, 31, 300)), (31, random_seqs(rng, 2, 5000, 6000)),
+            (15, random_seqs(rng, 7, 15, 100)), (31, ["ACGT" * 20])]
+    batch = st.new_batch(sets[0][1], 31)
+    for k, seqs in sets:
+        batch.reload(seqs, k)
+        orc = SynthOracle(3, 0, m, n_cols, h, k, 1)
+        for thr in (1.0, 0.5):
+            batch.run(thr)
+            _, nu, mk = batch.unique()
+            off, col, cnt = batch.hits()
+            assert batch.n == len(seqs) and len(off) == len(seqs) + 1
+            for i, s in enumerate(seqs):
+                u, want_cnt = orc.counts(s)
+                want = np.flatnonzero(want_cnt >= (u if thr == 1.0 else mk[i]))
+                assert nu[i] == u and np.array_equal(col[int(off[i]):int(off[i + 1])], want), (k, thr, i)
+    batch.close()
+    # the index object's cached workspace: many searches of different shapes through one BIGSI
+    b = hip.BIGSI.build(cfg(3, 1000, 3), [hip.BIGSI.bloom({"m": 1000, "h": 3, "storage-config": {}}, ["ATC", "ATA"])], ["1"])
+    r1 = b.search("ATCATA", 0.5)
+    r2 = b.search_batch(["ATC", "ATCATAATC", "GGG"], 0.5)
+    assert b.search("ATCATA", 0.5) == r1 and r2[0] == b.search("ATC", 0.5) and r2[2] == []
+    b.delete()
+    st.delete_all()
