@@ -704,13 +704,13 @@ static int run_kmerize(bigsi_hip_batch *b, double threshold, bool force_global =
     EventPair ep{};
     TRY(b->rows.reserve(std::max<uint64_t>(b->total_pos, 1) * ix->h * 8));
     static const int k1_global = env_int("BIGSI_HIP_K1_GLOBAL", 0);
-    if (!force_global && !k1_global && b->max_pos <= kLdsMaxPos) {
-        // fused single-launch K1: dedupe table + sequence in LDS
-        uint32_t tab_cap = 2;
-        while (tab_cap < 2 * b->max_pos) tab_cap <<= 1;
+    uint32_t tab_cap = 2;
+    while (tab_cap < 2 * b->max_pos && tab_cap < (1u << 30)) tab_cap <<= 1;
+    const size_t lds = (size_t)tab_cap * 4 + 64 + round_up(b->max_len + 16, 16);
+    // fused single-launch K1 (dedupe table + sequence in LDS) when every query fits the default 64 KiB dynamic-LDS window
+    if (!force_global && !k1_global && b->max_pos <= kLdsMaxPos && lds <= 60 * 1024) {
         uint32_t block = 64;
         while (block < b->max_pos && block < 1024) block <<= 1;
-        const size_t lds = (size_t)tab_cap * 4 + 64 + round_up(b->max_len + 16, 16);
         TRY(ev_begin(ix, &ep));
 #define BIGSI_K1_LDS(KF)                                                                                                        \
     hipLaunchKernelGGL((k_kmerize_lds<KF>), dim3(b->n_seqs), dim3(block), lds, ix->stream, b->seqs.as<char>(), b->d_seq_off.as<uint64_t>(), \

@@ -49,6 +49,7 @@ int bigsi_hip_device_count(int *out);
 int bigsi_hip_open(uint64_t num_rows, uint64_t num_cols, uint64_t col_capacity, uint32_t num_hashes,
                    int device, bigsi_hip_index **out);
 int bigsi_hip_close(bigsi_hip_index *ix); /* BaseStorage.close, bigsi/storage/base.py:149-151 */
+/* Destroy every batch created on an index before closing it: batches hold the index handle. */
 
 typedef struct {
     uint64_t num_rows;         /* m  = ksi:bloomfilter_size = number_of_rows */

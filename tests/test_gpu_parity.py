@@ -861,3 +861,25 @@ def test_batch_reload_reuses_workspace(hip):
     assert b.search("ATCATA", 0.5) == r1 and r2[0] == b.search("ATC", 0.5) and r2[2] == []
     b.delete()
     st.delete_all()
+
+
+def test_huge_k_takes_the_global_k1_route(hip):
+    """k so large that sequence + table exceed the LDS window even though there are few positions."""
+    from bigsi_amd.storage import get_storage
+    from oracle.ref_model import SynthOracle
+    k, m, n_cols, h = 70000, 1009, 64, 2
+    st = get_storage(cfg(k, m, h, max_cols=n_cols))
+    st.delete_all()
+    for key, v in (("number_of_rows", m), ("number_of_cols", n_cols), ("ksi:bloomfilter_size", m), ("ksi:num_hashes", h)):
+        st.set_integer(key, v)
+    st.fill_synthetic(1, 0, 1)
+    s = "".join(np.random.default_rng(0).choice(list("ACGT"), size=k + 40))
+    orc = SynthOracle(1, 0, m, n_cols, h, k, 1)
+    batch = st.new_batch([s, s[:k]], k)
+    batch.run(0.5)
+    _, nu, _ = batch.unique()
+    for i, q in enumerate([s, s[:k]]):
+        u, cnt = orc.counts(q)
+        assert nu[i] == u and np.array_equal(batch.counts(i), cnt.astype(np.uint32))
+    batch.close()
+    st.delete_all()
