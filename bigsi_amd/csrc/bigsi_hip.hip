@@ -542,6 +542,8 @@ struct bigsi_hip_batch {
     double threshold = 1.0;
     uint64_t wv = 0, wv_pad = 0;   // valid / padded words per row at run time
     uint32_t run_h = 0;            // num_hashes the row ids of the last K1 were produced with
+    hipEvent_t done = nullptr;     // recorded at the end of every run: fetches wait on it, not on the whole stream, so the
+                                   // results of one batch can be read while the next batch's kernels are queued behind it
     hipStream_t gstream = nullptr; // stream of the gathered compaction (null: the index's stream)
     const void *g_src = nullptr;   // last gathered buffer handed to compact_gathered
     uint32_t g_shards = 0;
@@ -662,6 +664,7 @@ extern "C" int bigsi_hip_batch_destroy(bigsi_hip_batch *b)
         d->release();
     b->hits.release();
     b->ghits.release();
+    if (b->done) { e = hipEventDestroy(b->done); (void)e; }
     delete b;
     return BIGSI_OK;
 }
@@ -875,13 +878,18 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
     }
 
     b->compacted = !(flags & BIGSI_RUN_SKIP_COMPACT);
-    b->ran = true;
-    if (!b->compacted) return BIGSI_OK;
+    if (!b->done) HIP_TRY(hipEventCreateWithFlags(&b->done, hipEventDisableTiming));
+    if (!b->compacted) {
+        HIP_TRY(hipEventRecord(b->done, ix->stream));
+        b->ran = true;
+        return BIGSI_OK;
+    }
     // K4 on this shard's own result
     TRY(ev_begin(ix, &ep));
     const void *src = b->exact ? (b->ext_bitmaps ? b->ext_bitmaps : b->bitmaps.p) : (b->ext_counts ? b->ext_counts : b->counts.p);
     TRY(compact(b, b->hits, src, 1, ix->n_cols, false));
     TRY(ev_end(ix, &ep, ix->ev_cp));
+    HIP_TRY(hipEventRecord(b->done, ix->stream));
     b->ran = true;
     return BIGSI_OK;
 }
@@ -962,8 +970,9 @@ static int fetch_hits_from(bigsi_hip_batch *b, HitBufs &hb, const void *src, uin
 {
     hipStream_t st = (&hb == &b->ghits && b->gstream) ? b->gstream : b->ix->stream;
     std::vector<uint64_t> off(b->n_seqs + 1);
-    HIP_TRY(hipMemcpyAsync(off.data(), hb.hit_off.p, (b->n_seqs + 1) * 8ull, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    // local hit lists were produced before b->done (already waited for); gathered ones on the gather stream
+    if (&hb == &b->ghits || !b->compacted) HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpy(off.data(), hb.hit_off.p, (b->n_seqs + 1) * 8ull, hipMemcpyDeviceToHost));
     const uint64_t total = off[b->n_seqs];
     if (hb.xcol && total > hb.xcap) {
         if (hit_offsets) memcpy(hit_offsets, off.data(), (b->n_seqs + 1) * 8ull);
@@ -988,7 +997,9 @@ static int need_run(bigsi_hip_batch *b)
 {
     if (!b) return fail(BIGSI_ERR_INVALID, "NULL batch");
     if (!b->ran) return fail(BIGSI_ERR_STATE, "bigsi_hip_batch_run has not completed for this batch");
-    return use_device(b->ix);
+    TRY(use_device(b->ix));
+    if (b->done) HIP_TRY(hipEventSynchronize(b->done));      // this batch's kernels; later batches may still be running
+    return BIGSI_OK;
 }
 
 static int host_counts(bigsi_hip_batch *b)
@@ -996,9 +1007,8 @@ static int host_counts(bigsi_hip_batch *b)
     if (b->host_counts_valid) return BIGSI_OK;
     b->h_num_unique.resize(b->n_seqs);
     b->h_num_kmers.resize(b->n_seqs);
-    HIP_TRY(hipMemcpyAsync(b->h_num_unique.data(), b->num_unique.p, b->n_seqs * 4ull, hipMemcpyDeviceToHost, b->ix->stream));
-    HIP_TRY(hipMemcpyAsync(b->h_num_kmers.data(), b->num_kmers.p, b->n_seqs * 4ull, hipMemcpyDeviceToHost, b->ix->stream));
-    HIP_TRY(hipStreamSynchronize(b->ix->stream));
+    HIP_TRY(hipMemcpy(b->h_num_unique.data(), b->num_unique.p, b->n_seqs * 4ull, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(b->h_num_kmers.data(), b->num_kmers.p, b->n_seqs * 4ull, hipMemcpyDeviceToHost));
     b->host_counts_valid = true;
     return BIGSI_OK;
 }
@@ -1011,7 +1021,7 @@ extern "C" int bigsi_hip_batch_get_info(bigsi_hip_batch *b, bigsi_hip_batch_info
     out->k = b->k;
     out->total_kmers = b->total_pos;
     if (!b->ran) return BIGSI_OK;
-    TRY(use_device(b->ix));
+    TRY(need_run(b));          // waits for this batch's completion event
     TRY(host_counts(b));
     out->exact = b->exact ? 1 : 0;
     out->count_bytes = b->count_bytes;
@@ -1043,6 +1053,7 @@ extern "C" int bigsi_hip_batch_fetch_hits(bigsi_hip_batch *b, uint64_t *hit_offs
     const void *src = b->exact ? (b->ext_bitmaps ? b->ext_bitmaps : b->bitmaps.p) : (b->ext_counts ? b->ext_counts : b->counts.p);
     if (!b->compacted) {   // the run skipped K4: do it now
         TRY(compact(b, b->hits, src, 1, b->ix->n_cols, false));
+        HIP_TRY(hipStreamSynchronize(b->ix->stream));
         b->compacted = true;
     }
     return fetch_hits_from(b, b->hits, src, 1, b->ix->n_cols, hit_offsets, colours, counts, capacity);
@@ -1119,7 +1130,6 @@ extern "C" int bigsi_hip_batch_fetch_counts(bigsi_hip_batch *b, uint32_t seq, ui
     if (seq >= b->n_seqs) return fail(BIGSI_ERR_RANGE, "sequence %u out of range", seq);
     const uint64_t n = b->ix->n_cols, cstride = b->wv_pad * 64;
     const uint8_t *src = (const uint8_t *)(b->ext_counts ? b->ext_counts : b->counts.p) + (uint64_t)seq * cstride * b->count_bytes;
-    HIP_TRY(hipStreamSynchronize(b->ix->stream));
     if (b->count_bytes == 4) {
         HIP_TRY(hipMemcpy(out, src, n * 4, hipMemcpyDeviceToHost));
     } else {
@@ -1137,7 +1147,6 @@ extern "C" int bigsi_hip_batch_fetch_bitmap(bigsi_hip_batch *b, uint32_t seq, ui
     if (!b->exact) return fail(BIGSI_ERR_STATE, "the last run took the counting path");
     if (seq >= b->n_seqs) return fail(BIGSI_ERR_RANGE, "sequence %u out of range", seq);
     const uint8_t *src = (const uint8_t *)(b->ext_bitmaps ? b->ext_bitmaps : b->bitmaps.p) + (uint64_t)seq * b->wv_pad * 8;
-    HIP_TRY(hipStreamSynchronize(b->ix->stream));
     HIP_TRY(hipMemcpy(out, src, b->ix->rb(), hipMemcpyDeviceToHost));
     return BIGSI_OK;
 }

@@ -62,8 +62,12 @@ def bulk_search(bigsi, fasta, threshold=1.0, score=False, format="json", stream=
     """All records of a FASTA file in one device batch.  Returns the combined text (stream=False) or prints one record
     per line as the reference's streaming branch does and returns None."""
     seqs = [s for _, s in read_fasta(fasta)]
-    results = bigsi.search_batch(seqs, threshold, score) if seqs else []
-    dd = [search_record(s, threshold, r) for s, r in zip(seqs, results)]
+    if hasattr(bigsi, "search_stream"):       # device batches of `batch_size`, host assembly overlapped with the next batch
+        size = int(getattr(bigsi, "config", {}).get("batch_size", 256))
+        dd = [search_record(s, threshold, r) for s, r in bigsi.search_stream(seqs, threshold, score, batch_size=size)]
+    else:
+        results = bigsi.search_batch(seqs, threshold, score) if seqs else []
+        dd = [search_record(s, threshold, r) for s, r in zip(seqs, results)]
     if not stream:
         if format == "csv":
             return "\n".join(d_to_csv(d, False, False) for d in dd)

@@ -123,10 +123,8 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
         self.insert_bloom(bloomfilter, colour - 1)
 
     def delete(self):
-        batch = getattr(self, "_batch", None)
-        if batch is not None:
+        for batch in self.__dict__.pop("_workspaces", {}).values():
             batch.close()
-            self._batch = None
         self.storage.delete_all()
 
     def merge(self, bigsi):
@@ -148,26 +146,27 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
         assert threshold <= 1
         return self.search_batch([seq], threshold, score)[0]
 
-    def search_batch(self, seqs, threshold=1.0, score=False):
-        """search() for many sequences in one device batch; a list of result lists in input order."""
-        assert threshold <= 1
-        seqs = list(seqs)
-        if not seqs:
-            return []
-        # one batch workspace per index object, reloaded for every call (allocation is paid once)
-        batch = getattr(self, "_batch", None)
+    def _workspace(self, slot, seqs):
+        """Batch workspace `slot` of this index object, staged with `seqs` (created once, then only reloaded)."""
+        ws = self.__dict__.setdefault("_workspaces", {})
+        batch = ws.get(slot)
         if batch is None or batch.b is None or batch.storage.res is not self.storage.res:
-            batch = self._batch = self.storage.new_batch(seqs, self.kmer_size)
+            batch = ws[slot] = self.storage.new_batch(seqs, self.kmer_size)
         else:
             batch.reload(seqs, self.kmer_size)
+        return batch
+
+    def _launch(self, batch, threshold):
         # hit lists only: counters of non-hits are never stored; config key `early_exit: true` additionally lets an exact
         # search stop reading a query's rows once no sample can match any more (identical results)
         batch.run(threshold, sparse_counts=True, early_exit=bool(self.config.get("early_exit", False)))
+
+    def _collect(self, batch, n_seqs, threshold, score):
         num_kmers, num_unique, _ = batch.unique()
         off, colours, counts = batch.hits()
         exact = threshold == 1.0
         out = []
-        for i in range(len(seqs)):
+        for i in range(n_seqs):
             u, n = int(num_unique[i]), int(num_kmers[i])
             if u == 0:
                 # the reference fails on a query without k-mers: reduce() over nothing on the exact branch
@@ -178,6 +177,43 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
             lo, hi = int(off[i]), int(off[i + 1])
             out.append(self._assemble(batch, i, colours[lo:hi], counts[lo:hi], u, n, exact, score))
         return out
+
+    def search_batch(self, seqs, threshold=1.0, score=False):
+        """search() for many sequences in one device batch; a list of result lists in input order."""
+        assert threshold <= 1
+        seqs = list(seqs)
+        if not seqs:
+            return []
+        batch = self._workspace(0, seqs)
+        self._launch(batch, threshold)
+        return self._collect(batch, len(seqs), threshold, score)
+
+    def search_stream(self, seqs, threshold=1.0, score=False, batch_size=256):
+        """Generator over (sequence, results) for an arbitrarily long iterable of sequences, `batch_size` per device batch,
+        two workspaces deep: while the GPU runs batch i+1 the host fetches and assembles batch i (fetches wait on the
+        batch's own completion event, not on the stream)."""
+        assert threshold <= 1
+        pending, slot, chunk = None, 0, []
+
+        def submit(chunk, slot):
+            batch = self._workspace(slot, chunk)
+            self._launch(batch, threshold)
+            return batch, chunk
+
+        for s in seqs:
+            chunk.append(s)
+            if len(chunk) == batch_size:
+                nxt = submit(chunk, slot)
+                if pending is not None:
+                    yield from zip(pending[1], self._collect(pending[0], len(pending[1]), threshold, score))
+                pending, slot, chunk = nxt, slot ^ 1, []
+        if chunk:
+            nxt = submit(chunk, slot)
+            if pending is not None:
+                yield from zip(pending[1], self._collect(pending[0], len(pending[1]), threshold, score))
+            pending = nxt
+        if pending is not None:
+            yield from zip(pending[1], self._collect(pending[0], len(pending[1]), threshold, score))
 
     def _assemble(self, batch, i, colours, counts, u, n, exact, score):
         if exact:

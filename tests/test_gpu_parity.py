@@ -883,3 +883,21 @@ def test_huge_k_takes_the_global_k1_route(hip):
         assert nu[i] == u and np.array_equal(batch.counts(i), cnt.astype(np.uint32))
     batch.close()
     st.delete_all()
+
+
+def test_search_stream_pipelined_equals_one_by_one(hip):
+    """search_stream (two workspaces, batch i assembled while batch i+1 runs) == search() per sequence, in order, for batch
+    sizes that do and do not divide the input, with and without score."""
+    g = load_golden("g7_random.json")
+    k, m, h = g["k"], g["m"], g["h"]
+    c = cfg(k, m, h)
+    b = hip.BIGSI.build_from_sequences(c, {n: [a, b_] for n, (a, b_) in zip(g["sample_names"], g["sample_seqs"])})
+    qs = g["queries"]
+    for thr, score in ((1.0, False), (0.4, False), (0.7, True)):
+        want = [b.search(q, thr, score) for q in qs]
+        for bs in (1, 5, 16, 48, 100):
+            got = list(b.search_stream(iter(qs), thr, score, batch_size=bs))
+            assert [s for s, _ in got] == qs
+            assert [r for _, r in got] == want, (thr, score, bs)
+    assert list(b.search_stream([], 1.0)) == []
+    b.delete()
