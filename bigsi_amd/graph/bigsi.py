@@ -165,9 +165,15 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
         num_kmers, num_unique, _ = batch.unique()
         off, colours, counts = batch.hits()
         exact = threshold == 1.0
+        if num_unique[:n_seqs].all() and int(off[n_seqs]) == 0:
+            return [[] for _ in range(n_seqs)]             # the common bulk case: nothing found anywhere in the batch
+        nhits = np.diff(off.astype(np.int64))
         out = []
         for i in range(n_seqs):
             u, n = int(num_unique[i]), int(num_kmers[i])
+            if u and not nhits[i]:
+                out.append([])
+                continue
             if u == 0:
                 # the reference fails on a query without k-mers: reduce() over nothing on the exact branch
                 # (utils/fncts.py:24-25), an unbound accumulator on the other (graph/bigsi.py:35-44)
@@ -188,12 +194,13 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
         self._launch(batch, threshold)
         return self._collect(batch, len(seqs), threshold, score)
 
-    def search_stream(self, seqs, threshold=1.0, score=False, batch_size=256):
-        """Generator over (sequence, results) for an arbitrarily long iterable of sequences, `batch_size` per device batch,
-        two workspaces deep: while the GPU runs batch i+1 the host fetches and assembles batch i (fetches wait on the
-        batch's own completion event, not on the stream)."""
+    def search_stream(self, seqs, threshold=1.0, score=False, batch_size=None, batch_kmers=1 << 18):
+        """Generator over (sequence, results) for an arbitrarily long iterable of sequences, two workspaces deep: while
+        the GPU runs batch i+1 the host fetches and assembles batch i (fetches wait on the batch's own completion event, not
+        on the stream).  A device batch closes after `batch_size` sequences if given, else once it holds about
+        `batch_kmers` k-mers (256 x 1 kbp, or ~8000 reads of 61 bp)."""
         assert threshold <= 1
-        pending, slot, chunk = None, 0, []
+        pending, slot, chunk, held = None, 0, [], 0
 
         def submit(chunk, slot):
             batch = self._workspace(slot, chunk)
@@ -202,11 +209,12 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
 
         for s in seqs:
             chunk.append(s)
-            if len(chunk) == batch_size:
+            held += max(len(s) - self.kmer_size + 1, 1)
+            if (len(chunk) == batch_size) if batch_size else (held >= batch_kmers):
                 nxt = submit(chunk, slot)
                 if pending is not None:
                     yield from zip(pending[1], self._collect(pending[0], len(pending[1]), threshold, score))
-                pending, slot, chunk = nxt, slot ^ 1, []
+                pending, slot, chunk, held = nxt, slot ^ 1, [], 0
         if chunk:
             nxt = submit(chunk, slot)
             if pending is not None:
