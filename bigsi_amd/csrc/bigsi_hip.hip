@@ -707,6 +707,24 @@ static int run_kmerize(bigsi_hip_batch *b, double threshold, bool force_global =
     EventPair ep{};
     TRY(b->rows.reserve(std::max<uint64_t>(b->total_pos, 1) * ix->h * 8));
     static const int k1_global = env_int("BIGSI_HIP_K1_GLOBAL", 0);
+    static const int k1_wave = env_int("BIGSI_HIP_K1_WAVE", 1);
+    if (!force_global && !k1_global && k1_wave && b->max_pos <= 64) {
+        // probe / read-length queries: one wavefront per query, no LDS, no atomics
+        TRY(ev_begin(ix, &ep));
+        const unsigned grid = (unsigned)ceil_div(b->n_seqs, kBlock / 64);
+#define BIGSI_K1_WAVE(KF)                                                                                                      \
+    hipLaunchKernelGGL((k_kmerize_wave<KF>), dim3(grid), dim3(kBlock), 0, ix->stream, b->seqs.as<char>(), b->d_seq_off.as<uint64_t>(),     \
+                       b->d_pos_off.as<uint64_t>(), b->k, ix->h, ix->m, threshold, b->n_seqs, b->first_pos.as<uint32_t>(),                \
+                       b->pos_unique.as<uint32_t>(), b->rep.as<uint32_t>(), b->rows.as<uint64_t>(), b->num_kmers.as<uint32_t>(),           \
+                       b->num_unique.as<uint32_t>(), b->min_kmers.as<uint32_t>())
+        if (b->k == 31) BIGSI_K1_WAVE(31);
+        else BIGSI_K1_WAVE(0);
+#undef BIGSI_K1_WAVE
+        HIP_TRY(hipGetLastError());
+        TRY(ev_end(ix, &ep, ix->ev_km));
+        b->run_h = ix->h;
+        return BIGSI_OK;
+    }
     uint32_t tab_cap = 2;
     while (tab_cap < 2 * b->max_pos && tab_cap < (1u << 30)) tab_cap <<= 1;
     const size_t lds = (size_t)tab_cap * 4 + 64 + round_up(b->max_len + 16, 16);

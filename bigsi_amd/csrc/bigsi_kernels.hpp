@@ -51,7 +51,12 @@ __host__ __device__ __forceinline__ uint64_t valid_mask(uint64_t w, uint64_t n_c
 // reverse_comp's per-base map (bigsi/utils/fncts.py:12,38-39): A<->T, C<->G, anything else unchanged
 __device__ __forceinline__ uint8_t complement(uint8_t c)
 {
-    return c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : c == 'G' ? 'C' : c;
+    // branchless: 'A' ^ 'T' == 0x15 and 'C' ^ 'G' == 0x04 (a chain of ?: compiles to divergent exec-mask branches, and this
+    // runs 2k times per k-mer)
+    const uint32_t x = c;
+    const uint32_t at = (uint32_t)(x == 'A') | (uint32_t)(x == 'T');
+    const uint32_t cg = (uint32_t)(x == 'C') | (uint32_t)(x == 'G');
+    return (uint8_t)(x ^ (at * 0x15u) ^ (cg * 0x04u));
 }
 
 // byte j of the canonical form of the k-mer at s[0..k): forward strand or reverse complement
@@ -186,17 +191,20 @@ struct RegKmer {
     // canonical form packed into little-endian words (utils/fncts.py:51-54)
     __device__ __forceinline__ void canonical_words(uint32_t (&w)[(KF + 3) / 4 > 0 ? (KF + 3) / 4 : 1]) const
     {
-        bool rc = false, decided = false;
+        // lexicographic compare of the k-mer with its reverse complement, first difference decides; select-only code
+        uint32_t rc = 0, decided = 0;
 #pragma unroll
         for (int j = 0; j < KF; j++) {
-            const uint8_t a = (uint8_t)f[j], b = complement((uint8_t)f[KF - 1 - j]);
-            if (!decided && a != b) { rc = b < a; decided = true; }
+            const uint32_t a = f[j], b = complement((uint8_t)f[KF - 1 - j]);
+            const uint32_t take = (decided ^ 1u) & (uint32_t)(a != b);
+            rc = take ? (uint32_t)(b < a) : rc;
+            decided |= take;
         }
 #pragma unroll
         for (int i = 0; i < (KF + 3) / 4; i++) w[i] = 0;
 #pragma unroll
         for (int j = 0; j < KF; j++) {
-            const uint8_t c = rc ? complement((uint8_t)f[KF - 1 - j]) : (uint8_t)f[j];
+            const uint32_t c = rc ? (uint32_t)complement((uint8_t)f[KF - 1 - j]) : f[j];
             w[j >> 2] |= (uint32_t)c << (8 * (j & 3));
         }
     }
@@ -422,6 +430,63 @@ __global__ __launch_bounds__(1024) void k_kmerize_lds(
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) pu[i] = ux[rp[i]];
     if (threadIdx.x == 0) {
+        num_kmers[q] = n;
+        num_unique[q] = u;
+        const double mk = ceil((double)u * threshold);
+        min_kmers[q] = mk > 0.0 ? (uint32_t)mk : 0u;
+    }
+}
+
+// K1 for probe / read-length queries (at most 64 k-mer positions, e.g. the 61-mers of BASELINE config 2): ONE WAVEFRONT
+// PER QUERY, four queries per workgroup, lane i = position i.  Duplicates are found by broadcasting each lane's dedupe
+// hash in turn (64 shuffles, string compare only on a hash match), first occurrences are ranked with ballot + popcount:
+// no LDS, no atomics, no barriers.  Same outputs as the other two routes.
+template <int KF>
+__global__ __launch_bounds__(kBlock) void k_kmerize_wave(
+    const char *__restrict__ seqs, const uint64_t *__restrict__ seq_off, const uint64_t *__restrict__ pos_off,
+    uint32_t k, uint32_t h, uint64_t m, double threshold, uint32_t n_seqs, uint32_t *__restrict__ first_pos,
+    uint32_t *__restrict__ pos_unique, uint32_t *__restrict__ rep_out, uint64_t *__restrict__ rows,
+    uint32_t *__restrict__ num_kmers, uint32_t *__restrict__ num_unique, uint32_t *__restrict__ min_kmers)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t q = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (q >= n_seqs) return;                       // whole wavefront leaves together
+    const char *s = seqs + seq_off[q];
+    const uint32_t len = (uint32_t)(seq_off[q + 1] - seq_off[q]);
+    const uint32_t n = len >= k ? len - k + 1 : 0u;      // <= 64 by the launch condition
+    const uint64_t P = pos_off[q];
+    const bool live = lane < n;
+    const uint32_t fp = live ? dedupe_hash<KF>(s + lane, k) : 0u;
+    uint32_t rep = lane;
+    for (uint32_t j = 0; j + 1 < n; j++) {         // wave-uniform trip count
+        const uint32_t fj = __shfl(fp, (int)j, 64);
+        if (live && lane > j && rep == lane && fp == fj && kmer_equal(s + j, s + lane, k)) rep = j;
+    }
+    const bool first = live && rep == lane;
+    const unsigned long long mask = __ballot(first);
+    const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    const uint32_t u = (uint32_t)__popcll(mask);
+    if (live) {
+        rep_out[P + lane] = rep;
+        pos_unique[P + lane] = (uint32_t)__popcll(mask & (rep ? (~0ull >> (64 - rep)) : 0ull));   // rank of its representative
+    }
+    if (first) {
+        const uint32_t j = (uint32_t)__popcll(mask & below);
+        first_pos[P + j] = lane;
+        uint64_t *dst = rows + (P + j) * h;
+        const char *km = s + lane;
+        if (KF > 0) {
+            RegKmer<KF> reg;
+            reg.load(km);
+            uint32_t w[(KF + 3) / 4 > 0 ? (KF + 3) / 4 : 1];
+            reg.canonical_words(w);
+            for (uint32_t sd = 0; sd < h; sd++) dst[sd] = row_of_hash(murmur3_words<KF>(w, sd), m);
+        } else {
+            const KmerView v{km, k, use_revcomp(km, k)};
+            for (uint32_t sd = 0; sd < h; sd++) dst[sd] = row_of_hash(murmur3_32(v, sd), m);
+        }
+    }
+    if (lane == 0) {
         num_kmers[q] = n;
         num_unique[q] = u;
         const double mk = ceil((double)u * threshold);

@@ -131,7 +131,7 @@ int bigsi_hip_bloom(int device, const char *kmers, uint64_t u, uint32_t k, uint6
 int bigsi_hip_lookup(bigsi_hip_index *ix, const char *kmers, uint32_t k, uint64_t u, uint8_t *out_rows);
 
 #define BIGSI_RUN_FORCE_COUNTS 1u /* use the counting path even when threshold == 1.0 */
-#define BIGSI_RUN_K1_GLOBAL 4u   /* take the multi-launch K1 (global-memory dedupe table) even for short queries (testing) */
+#define BIGSI_RUN_K1_GLOBAL 4u   /* take the multi-launch K1 (global-memory dedupe table) whatever the query lengths (testing) */
 #define BIGSI_RUN_SPARSE_COUNTS 8u /* counting path: store per-sample counters only where a sample reaches min_kmers
                                       (hit lists are complete; fetch_counts is unavailable for that run) */
 #define BIGSI_RUN_NO_SORT 16u      /* stream each query's rows in hash order instead of address order (A/B measurements) */

@@ -617,10 +617,12 @@ def test_device_build_paths(hip):
     b2.delete()
 
 
-@pytest.mark.parametrize("k,lens", [(31, [31, 61, 500, 4126]), (31, [4127, 100]), (5, [5, 4100, 9, 4]), (33, [33, 2000, 40])])
+@pytest.mark.parametrize("k,lens", [(31, [31, 61, 500, 4126]), (31, [4127, 100]), (5, [5, 4100, 9, 4]), (33, [33, 2000, 40]),
+                                    (31, [31, 61, 94, 40, 30, 93]), (4, [4, 10, 67, 5, 3, 66]), (1, [64, 1, 2])])
 def test_k1_fused_lds_equals_global_path(hip, k, lens):
-    """K1 has two routes -- one fused launch with the dedupe table in LDS (all queries <= 4096 positions) and the
-    four-kernel global-table route (longer queries, or forced by BIGSI_RUN_K1_GLOBAL).  Same row ids, unique counts,
+    """K1 has three routes -- one wavefront per query (all queries <= 64 positions), one fused launch with the dedupe table
+    in LDS (all queries <= 4096 positions) and the four-kernel global-table route (longer queries, or forced by
+    BIGSI_RUN_K1_GLOBAL).  Same row ids, unique counts,
     position->unique maps (seen through presence strings) and hits from both, and both equal the oracle."""
     from bigsi_amd.storage import get_storage
     from oracle import coracle
