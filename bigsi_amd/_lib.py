@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbigsi_hip.so")
+# BIGSI_HIP_LIB selects another build of the same ABI (kernel A/B experiments); default: the in-tree library
+LIB_PATH = os.environ.get("BIGSI_HIP_LIB") or os.path.join(_HERE, "libbigsi_hip.so")
 
 OK, ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_RANGE, ERR_CAPACITY, ERR_STATE = 0, -1, -2, -3, -4, -5, -6
 RUN_FORCE_COUNTS = 1

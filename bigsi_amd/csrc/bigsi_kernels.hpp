@@ -658,15 +658,20 @@ __global__ __launch_bounds__(kBlock) void k_and_count(
 
     uint32_t j = j0;
     if (H > 0) {
-        for (; j + 2 <= u; j += 2) {   // two k-mers = 2H independent row loads in flight per lane
-            u64x2 v[2 * (H > 0 ? H : 1)];
+        // KM k-mers per iteration so that 8-12 independent row loads are in flight per lane whatever h is (h=3: 12 loads
+        // measured +1.9 % over 6; h=4: 8 vs 16 no difference)
+        constexpr int KM = H == 1 ? 8 : H <= 3 ? 4 : 2;
+        for (; j + KM <= u; j += KM) {
+            u64x2 v[KM * (H > 0 ? H : 1)];
 #pragma unroll
-            for (int s = 0; s < 2 * H; s++) v[s] = load_row_seg(index, qrows[(uint64_t)j * H + s], stride_words, w0);
-            u64x2 a = v[0], b = v[H];
+            for (int s = 0; s < KM * H; s++) v[s] = load_row_seg(index, qrows[(uint64_t)j * H + s], stride_words, w0);
 #pragma unroll
-            for (int s = 1; s < H; s++) { a &= v[s]; b &= v[H + s]; }
-            add(a);
-            add(b);
+            for (int g = 0; g < KM; g++) {
+                u64x2 a = v[g * H];
+#pragma unroll
+                for (int s = 1; s < H; s++) a &= v[g * H + s];
+                add(a);
+            }
         }
     }
     for (; j < u; j++) {
