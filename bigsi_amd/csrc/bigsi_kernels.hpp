@@ -674,9 +674,16 @@ __global__ __launch_bounds__(kBlock) void k_and_count(
             }
         }
     }
-    for (; j < u; j++) {
-        u64x2 a = load_row_seg(index, qrows[(uint64_t)j * h], stride_words, w0);
-        for (uint32_t s = 1; s < h; s++) a &= load_row_seg(index, qrows[(uint64_t)j * h + s], stride_words, w0);
+    for (; j < u; j++) {     // tail k-mers, and every k-mer when h is a run-time value (h > 5): rows in groups of four loads
+        const uint64_t *kr = qrows + (uint64_t)j * h;
+        u64x2 a = {~0ull, ~0ull};
+        uint32_t s = 0;
+        for (; s + 4 <= h; s += 4) {
+            const u64x2 l0 = load_row_seg(index, kr[s], stride_words, w0), l1 = load_row_seg(index, kr[s + 1], stride_words, w0);
+            const u64x2 l2 = load_row_seg(index, kr[s + 2], stride_words, w0), l3 = load_row_seg(index, kr[s + 3], stride_words, w0);
+            a &= (l0 & l1) & (l2 & l3);
+        }
+        for (; s < h; s++) a &= load_row_seg(index, kr[s], stride_words, w0);
         add(a);
     }
 
