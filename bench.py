@@ -44,6 +44,7 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample (0 = skip)")
     p.add_argument("--cpu-rows", type=int, default=200_000)
     p.add_argument("--no-verify", action="store_true")
+    p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU dry runs)")
     p.add_argument("--force-dist", action="store_true",
                    help="initialise the RCCL process group and take the gather path even with one rank (exercises the N>1 code)")
     return p.parse_args()
@@ -91,13 +92,18 @@ def main():
     from bigsi_amd.parallel import ShardedSearch
     from bigsi_amd.storage import get_storage
 
+    if os.environ.get("BIGSI_BENCH_DEVICE"):          # dry runs: several ranks sharing one GPU
+        local_rank = int(os.environ["BIGSI_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     exact = args.threshold == 1.0
     # ---------------- index: this rank's column shard, generated on the device

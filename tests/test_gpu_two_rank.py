@@ -1,0 +1,30 @@
+"""Two real ranks of bench.py on ONE GPU (gloo backend carrying CUDA tensors; RCCL refuses two ranks on one device): the
+rank-dependent halves of the column-shard path -- per-shard synthetic contents and planting, in-place all-gather slots,
+gathered compaction with colour = shard * shard_cols + local, per-hit count all-reduce, two alternating batches on the
+compute / comm streams -- run with two actual processes and the bench's own verification against the oracle."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("threshold", ["1.0", "0.4"])
+def test_bench_two_ranks_on_one_gpu(threshold):
+    env = dict(os.environ, BIGSI_BENCH_DEVICE="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "1", "--rows", "400000",
+           "--cols", "20000", "--backend", "gloo", "--threshold", threshold, "--cpu-seconds", "0"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["total_cols"] == 40000
+    assert d["config"]["hits_last_step"] == 6                      # 3 planted queries x 2 shards
+    assert "2 shard(s)" in d["config"]["verified"]
+    assert d["value"] == pytest.approx(2 * d["config"]["kmer_lookups_per_s_full_index"])
+    assert r.stdout.strip().splitlines()[-1] == line                # the JSON is the last line on stdout
