@@ -51,6 +51,8 @@ def main(argv=None):
     sp.add_argument("bloomfilter")
     sp.add_argument("sample")
     common(sub.add_parser("delete"))
+    sp = common(sub.add_parser("import-bdb", help="load an existing BerkeleyDB index (v0.3 file, or a v0.1 directory with graph + metadata) into HBM"))
+    sp.add_argument("path")
     a = p.parse_args(argv)
     config = get_config_from_file(a.config)
 
@@ -75,6 +77,13 @@ def main(argv=None):
     elif a.cmd == "insert":
         BIGSI(config).insert(BitRow.frombytes(open(a.bloomfilter, "rb").read(), config["m"]), a.sample)
         print('{"result": "success"}')
+    elif a.cmd == "import-bdb":
+        from . import bdb
+        dst = get_storage(config)
+        if os.path.isdir(a.path):
+            print("rows=%d cols=%d k=%d" % bdb.import_v01_index(a.path, dst))
+        else:
+            print("rows=%d cols=%d" % bdb.import_index(a.path, dst))
     elif a.cmd == "delete":
         get_storage(config).delete_all()
     return 0
