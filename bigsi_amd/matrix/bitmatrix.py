@@ -1,60 +1,91 @@
-"""Row-oriented view of the bit matrix held by a storage backend (bigsi/matrix/bitmatrix.py:1-75).
+"""`BitMatrix`: the m x N bit matrix of an index as the layers above the storage contract see it.
 
-Knows nothing about k-mers.  With the hip-hbm backend the column operations run as device kernels instead of m
-read-modify-writes of whole rows (the reference's insert_column, bitmatrix.py:67-75)."""
+API-compatible with the reference's class of the same name (bigsi/matrix/bitmatrix.py:1-75) -- rows in and out as
+bit rows, the two dimension records, column read / insert -- but written for a backend whose matrix is device
+resident: dimensions are read through properties, column operations go to `storage.insert_column` / `get_column`
+(one kernel over all m rows) when the backend has them, and only fall back to the per-row read-modify-write loop of
+the generic contract (`set_bits`, bigsi/storage/base.py:111-122) for backends that do not.
+"""
 from ..bitrow import BitRow, row_bytes_of
 
-NUM_ROWS_KEY = "number_of_rows"
-NUM_COLS_KEY = "number_of_cols"
+NUM_ROWS_KEY, NUM_COLS_KEY = "number_of_rows", "number_of_cols"
+
+
+def _trim(row, width):
+    return row[:width]
 
 
 class BitMatrix(object):
     def __init__(self, storage):
         self.storage = storage
-        self.num_rows = storage.get_integer(NUM_ROWS_KEY)     # KeyError on an empty store, like the reference
-        self.num_cols = storage.get_integer(NUM_COLS_KEY)
+        # both records must exist: opening an empty store is an error, as in the reference (bitmatrix.py:16-17)
+        self._rows = storage.get_integer(NUM_ROWS_KEY)
+        self._cols = storage.get_integer(NUM_COLS_KEY)
+
+    # ---- dimensions
+    @property
+    def num_rows(self):
+        return self._rows
+
+    @property
+    def num_cols(self):
+        return self._cols
+
+    @num_cols.setter
+    def num_cols(self, value):
+        self.set_num_cols(value)
+
+    def set_num_cols(self, num_cols):
+        self._cols = int(num_cols)
+        self.storage.set_integer(NUM_COLS_KEY, self._cols)
 
     @classmethod
     def create(cls, storage, rows, num_rows, num_cols):
-        storage.set_integer(NUM_ROWS_KEY, num_rows)           # first, so the device matrix can be sized
+        """Store `rows` (an iterable of num_rows bit rows) and the two dimension records; returns the opened matrix.
+        The row count is written first so that a device backend can size its matrix before the rows arrive."""
+        storage.set_integer(NUM_ROWS_KEY, int(num_rows))
         storage.set_bitarrays(range(num_rows), rows)
-        storage.set_integer(NUM_COLS_KEY, num_cols)
+        storage.set_integer(NUM_COLS_KEY, int(num_cols))
         storage.sync()
         return cls(storage)
 
+    # ---- rows
     def get_row(self, row_index):
-        return self.storage.get_bitarray(row_index)[: self.num_cols]
+        return _trim(self.storage.get_bitarray(row_index), self._cols)
 
     def get_rows(self, row_indexes, remove_trailing_zeros=True):
-        rows = self.storage.get_bitarrays(row_indexes)
-        return (r[: self.num_cols] for r in rows) if remove_trailing_zeros else rows
+        """Generator over the requested rows; `remove_trailing_zeros` cuts the byte padding off (bitmatrix.py:30-37)."""
+        fetched = self.storage.get_bitarrays(row_indexes)
+        if not remove_trailing_zeros:
+            return fetched
+        width = self._cols
+        return (_trim(r, width) for r in fetched)
 
     def set_row(self, row_index, bitarray):
-        return self.storage.set_bitarray(row_index, bitarray)
+        self.storage.set_bitarray(row_index, bitarray)
 
     def set_rows(self, row_indexes, bitarrays):
-        return self.storage.set_bitarrays(row_indexes, bitarrays)
+        self.storage.set_bitarrays(row_indexes, bitarrays)
 
-    def set_num_cols(self, num_cols):
-        self.num_cols = num_cols
-        self.storage.set_integer(NUM_COLS_KEY, num_cols)
-
+    # ---- columns
     def get_column(self, column_index):
-        if hasattr(self.storage, "get_column"):
-            return BitRow.frombytes(self.storage.get_column(column_index), self.num_rows)
-        rows = range(self.num_rows)
-        return BitRow(list(self.storage.get_bits(list(rows), [column_index] * self.num_rows)))
+        reader = getattr(self.storage, "get_column", None)
+        if reader is not None:
+            return BitRow.frombytes(reader(column_index), self._rows)
+        every_row = list(range(self._rows))
+        return BitRow(list(self.storage.get_bits(every_row, [column_index] * self._rows)))
 
     def get_columns(self, column_indexes):
-        for c in column_indexes:
-            yield self.get_column(c)
+        return (self.get_column(c) for c in column_indexes)
 
     def insert_column(self, bitarray, column_index):
+        """Write one sample's Bloom filter into column `column_index`; appending (index == num_cols) grows the matrix."""
         data, nbits = row_bytes_of(bitarray)
-        if hasattr(self.storage, "insert_column"):
-            self.storage.insert_column(column_index, data)
+        writer = getattr(self.storage, "insert_column", None)
+        if writer is not None:
+            writer(column_index, data)
         else:
             bits = BitRow.frombytes(data, nbits).tolist()
             self.storage.set_bits(list(range(nbits)), [column_index] * nbits, bits)
-        if column_index >= self.num_cols:
-            self.set_num_cols(self.num_cols + 1)
+        if column_index >= self._cols:
+            self.set_num_cols(self._cols + 1)
