@@ -903,3 +903,55 @@ def test_search_stream_pipelined_equals_one_by_one(hip):
             assert [r for _, r in got] == want, (thr, score, bs)
     assert list(b.search_stream([], 1.0)) == []
     b.delete()
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_fuzz_random_shapes_vs_oracle(hip, seed):
+    """Seeded random shapes: column counts around byte / word / tile boundaries, h 1..8, k 1..40, batch sizes from 1 (row
+    sliced, atomics) to hundreds (unsliced), thresholds incl. 0 / tiny / 1, queries with duplicates, N, lowercase, too short."""
+    from bigsi_amd.storage import get_storage
+    from oracle.ref_model import SynthOracle
+    rng = np.random.default_rng(1000 + seed)
+    n_cols = int(rng.choice([1, 7, 8, 9, 63, 64, 65, 127, 128, 129, 1000, 8191, 8192, 8193, 16385, 33000]))
+    m = int(rng.choice([1, 2, 97, 1009, 65537, 300007]))
+    h = int(rng.integers(1, 9))
+    k = int(rng.choice([1, 2, 5, 15, 31, 31, 31, 32, 40]))
+    draws = int(rng.integers(1, 4))
+    st = get_storage(cfg(k, m, h, max_cols=n_cols))
+    st.delete_all()
+    for key, v in (("number_of_rows", m), ("number_of_cols", n_cols), ("ksi:bloomfilter_size", m), ("ksi:num_hashes", h)):
+        st.set_integer(key, v)
+    st.fill_synthetic(seed, 0, draws)
+    orc = SynthOracle(seed, 0, m, n_cols, h, k, draws)
+    nq = int(rng.choice([1, 2, 9, 40, 300])) if n_cols * m < 2e9 else 3
+    alphabet = list("ACGT") if seed % 3 else list("ACGTNacgt")
+    seqs = []
+    for i in range(nq):
+        L = int(rng.integers(max(k - 2, 0), k + int(rng.choice([1, 8, 70, 300]))))
+        s = "".join(rng.choice(alphabet, size=L))
+        if i % 4 == 1 and L > 2 * k:
+            s = s[: L // 2] + s[: L // 2]                      # repeats -> duplicate k-mers
+        seqs.append(s)
+    for j in range(min(3, nq)):
+        col = int(rng.integers(0, n_cols))
+        st.insert_kmers(col, [seqs[j]], k)
+        orc.insert_kmers(col, seqs[j])
+    batch = st.new_batch(seqs, k)
+    check = list(range(nq)) if nq <= 40 else sorted(set([0, 1, 2] + rng.integers(0, nq, 12).tolist()))
+    for thr in (1.0, float(rng.choice([0.0, 0.05, 0.3, 0.5, 0.77, 0.999]))):
+        batch.run(thr, sparse_counts=bool(seed % 2))
+        _, nu, mk = batch.unique()
+        off, col, cnt = batch.hits()
+        for i in check:
+            u, want_cnt = orc.counts(seqs[i])
+            assert nu[i] == u, (seed, i)
+            if u == 0:
+                want = np.zeros(0, int) if thr == 1.0 else np.flatnonzero(want_cnt >= 0) if mk[i] == 0 else np.zeros(0, int)
+            else:
+                want = np.flatnonzero(want_cnt >= (u if thr == 1.0 else mk[i]))
+            lo, hi = int(off[i]), int(off[i + 1])
+            assert np.array_equal(col[lo:hi], want), (seed, thr, i, n_cols, m, h, k)
+            if u:
+                assert np.array_equal(cnt[lo:hi], want_cnt[want].astype(np.uint32)), (seed, thr, i)
+    batch.close()
+    st.delete_all()
