@@ -41,7 +41,7 @@ def main(argv=None):
     sp.add_argument("--score", action="store_true")
     sp.add_argument("--format", choices=["json", "csv"], default="json")
     sp.add_argument("--stream", action="store_true")
-    sp = common(sub.add_parser("bloom", help="Bloom filter of the k-mers of a FASTA file or a one-k-mer-per-line text file"))
+    sp = common(sub.add_parser("bloom", help="Bloom filter of the k-mers of a Cortex .ctx graph, a FASTA file or a one-k-mer-per-line text file"))
     sp.add_argument("infile")
     sp.add_argument("outfile")
     sp = common(sub.add_parser("build"))
@@ -63,8 +63,11 @@ def main(argv=None):
         if text is not None:
             print(text)
     elif a.cmd == "bloom":
-        first = open(a.infile).read(1)
-        if first == ">":
+        first = open(a.infile, "rb").read(6)
+        if first == b"CORTEX":                      # the reference's input: a Cortex graph (bigsi/__main__.py:120-131)
+            from .cortex import extract_kmers_from_ctx
+            kmers = list(extract_kmers_from_ctx(a.infile, config["k"]))
+        elif first[:1] == b">":
             kmers = [km for _, s in read_fasta(a.infile) for km in seq_to_kmers(s, config["k"])]
         else:
             kmers = [l.strip() for l in open(a.infile) if l.strip()]

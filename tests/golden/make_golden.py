@@ -492,6 +492,20 @@ def g9_frontend():
     dump("g9_frontend.json", out, indent=None)
 
 
+# ------------------------------- G10: k-mers of the reference's Cortex (.ctx) graph files
+def g10_cortex():
+    import base64
+    from bigsi.utils.cortex import GraphReader, extract_kmers_from_ctx
+    out = []
+    for rel in ("bigsi/tests/data/test_kmers.ctx", "example-data/test1.ctx", "example-data/test2.ctx"):
+        path = os.path.join(REF, rel)
+        gr = GraphReader(path)
+        out.append({"file": rel, "ctx_base64": base64.b64encode(open(path, "rb").read()).decode(),
+                    "kmer_size": gr.kmer_size, "num_colours": gr.num_colours, "num_records": gr.num_records,
+                    "kmers_k31": list(extract_kmers_from_ctx(path, 31)), "kmers_k21": list(extract_kmers_from_ctx(path, 21))})
+    dump("g10_cortex.json", out, indent=None)
+
+
 if __name__ == "__main__":
     g1_hash()
     g2_lookup()
@@ -502,3 +516,4 @@ if __name__ == "__main__":
     g7_random()
     g8_storage()
     g9_frontend()
+    g10_cortex()

@@ -219,3 +219,20 @@ def test_shard_planning():
     assert sc == 3 and spans == [(0, 3), (3, 3), (6, 3), (9, 1)]
     assert plan_shards(5, 8)[1][5:] == [(5, 0), (5, 0), (5, 0)]
     assert math.ceil(7 * 0.1) == 1
+
+
+def test_cortex_reader_vs_reference(tmp_path):
+    """bigsi_amd.cortex against the reference's own reader on its three .ctx files (tests/golden/g10_cortex.json)."""
+    import base64
+    from bigsi_amd.cortex import CortexFormatError, extract_kmers_from_ctx, read_kmers
+    for case in load_golden("g10_cortex.json"):
+        p = tmp_path / os.path.basename(case["file"])
+        p.write_bytes(base64.b64decode(case["ctx_base64"]))
+        ksz, kmers = read_kmers(str(p))
+        assert ksz == case["kmer_size"] and len(kmers) == case["num_records"]
+        assert list(extract_kmers_from_ctx(str(p), 31)) == case["kmers_k31"]
+        assert list(extract_kmers_from_ctx(str(p), 21)) == case["kmers_k21"]
+    bad = tmp_path / "bad.ctx"
+    bad.write_bytes(b"CORTEX\x05\x00\x00\x00")
+    with pytest.raises(CortexFormatError):
+        read_kmers(str(bad))
