@@ -506,6 +506,18 @@ def g10_cortex():
     dump("g10_cortex.json", out, indent=None)
 
 
+# ------------------------------- G11: the reference's example index files (data, copied verbatim)
+def g11_example_bdb_files():
+    """example-data/test-bigsi/{graph,metadata}: a v0.1-format BerkeleyDB pair the reference ships as example data
+    (scripts/convert_v01_to_v03.py documents its layout).  Used to pin bigsi_amd/bdb.py on real BerkeleyDB files."""
+    import shutil
+    for name in ("graph", "metadata"):
+        dst = os.path.join(HERE, "bdb_v01_%s.db" % name)
+        shutil.copyfile(os.path.join(REF, "example-data/test-bigsi", name), dst)
+        os.chmod(dst, 0o644)
+        print("copied", dst)
+
+
 if __name__ == "__main__":
     g1_hash()
     g2_lookup()
@@ -517,3 +529,4 @@ if __name__ == "__main__":
     g8_storage()
     g9_frontend()
     g10_cortex()
+    g11_example_bdb_files()
