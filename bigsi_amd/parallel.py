@@ -190,3 +190,102 @@ class ShardedSearch(object):
                 continue
             check(rc)
             return off, col[: int(off[-1])], cnt[: int(off[-1])]
+
+
+class ShardedBIGSI(object):
+    """One BIGSI index whose samples are spread over the ranks of a process group: `search_batch` returns exactly what
+    `BIGSI.search` would return on the concatenation of all shards (rank 0's samples first, then rank 1's, ...).
+
+    Every rank calls the same methods with the same arguments (SPMD).  `local` is this rank's ordinary `bigsi_amd.BIGSI`
+    over its shard.  Device work and the two collectives per batch are ShardedSearch's; the host side exchanges only
+    sample names (once) and, for `score=True`, the presence strings of the hits, each produced on the rank that owns the
+    hit's column (k_presence) -- the n x N matrix the reference materialises for scoring (graph/bigsi.py:232-237) never
+    exists anywhere."""
+
+    def __init__(self, local, group=None, device=None):
+        import torch.distributed as dist
+        from .scoring import Scorer
+        self.local = local
+        self.dist = dist
+        self.group = group
+        sizes = self._gather(int(local.bitmatrix.num_cols))
+        self.shard_cols = max(max(sizes), 1)
+        self.shard_sizes = sizes
+        names = self._gather([local.colour_to_sample(c) for c in range(local.num_samples)])
+        self.names = names                                   # names[shard][local colour]
+        self.num_samples = sum(len(n) for n in names)
+        self.engine = ShardedSearch(local.storage, self.shard_cols, group=group, device=device, force_gather=True)
+        self.scorer = Scorer(self.num_samples)               # DB_SIZE = number of samples of the whole index
+        self._batch = None
+
+    def _gather(self, obj):
+        if not self.dist.is_initialized():
+            return [obj]
+        out = [None] * self.dist.get_world_size(self.group)
+        self.dist.all_gather_object(out, obj, group=self.group)
+        return out
+
+    def search_batch(self, seqs, threshold=1.0, score=False):
+        from .graph.bigsi import BigsiQueryResult
+        from .graph.metadata import DELETION_SPECIAL_SAMPLE_NAME
+        assert threshold <= 1
+        seqs = list(seqs)
+        if not seqs:
+            return []
+        if self._batch is None:
+            self._batch = self.local.storage.new_batch(seqs, self.local.kmer_size)
+        else:
+            self._batch.reload(seqs, self.local.kmer_size)
+        batch, sh, exact = self._batch, self.engine, threshold == 1.0
+        count_bytes = 2 if max(len(s) for s in seqs) - self.local.kmer_size + 1 < 65536 else 4
+        sh.prepare([batch], exact, count_bytes)
+        sh.step([batch], threshold)
+        off, colours, counts = sh.fetch(batch)
+        num_kmers, num_unique, _ = batch.unique()
+        rank = sh.sg.rank
+        out, wanted = [], []                                 # wanted: (seq index, [local colours on this rank])
+        for i in range(len(seqs)):
+            u, n = int(num_unique[i]), int(num_kmers[i])
+            if u == 0:
+                if exact:
+                    raise TypeError("reduce() of empty sequence with no initial value")
+                raise UnboundLocalError("local variable 'cumsum' referenced before assignment")
+            lo, hi = int(off[i]), int(off[i + 1])
+            col, cnt = colours[lo:hi].astype(np.int64), counts[lo:hi]
+            shard, local_c = col // self.shard_cols, col % self.shard_cols
+            if not exact:
+                keep = local_c < np.array([len(self.names[s]) for s in shard], dtype=np.int64) if len(shard) else np.zeros(0, bool)
+                shard, local_c, cnt = shard[keep], local_c[keep], cnt[keep]
+                order = np.argsort(-cnt.astype(np.int64), kind="stable")
+                shard, local_c, cnt = shard[order], local_c[order], cnt[order]
+            res = [BigsiQueryResult((int(s), int(c)), self.names[int(s)][int(c)], u if exact else int(f), u)
+                   for s, c, f in zip(shard, local_c, cnt)]
+            if score and res and n == 1:
+                raise IndexError("too many indices for array: array is 1-dimensional, but 2 were indexed")
+            wanted.append([int(c) for s, c in zip(shard, local_c) if int(s) == rank] if score else [])
+            out.append((res, n))
+        if score:
+            mine = {}
+            for i, cols in enumerate(wanted):
+                if cols:
+                    strings = batch.presence(i, np.array(cols, dtype=np.uint32), out[i][1])
+                    mine.update({(i, rank, c): s for c, s in zip(cols, strings)})
+            merged = {}
+            for part in self._gather(mine):
+                merged.update(part)
+            for i, (res, n) in enumerate(out):
+                for r in res:
+                    col = merged[(i, r.colour[0], r.colour[1])]
+                    sd = self.scorer.score(col)
+                    sd["kmer-presence"] = col
+                    r.add_score(sd)
+        return [[r.todict() for r in res if r.sample_name != DELETION_SPECIAL_SAMPLE_NAME] for res, _ in out]
+
+    def search(self, seq, threshold=1.0, score=False):
+        return self.search_batch([seq], threshold, score)[0]
+
+    def close(self):
+        if self._batch is not None:
+            self._batch.close()
+            self._batch = None
+        self.engine.close()

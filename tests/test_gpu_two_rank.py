@@ -28,3 +28,30 @@ def test_bench_two_ranks_on_one_gpu(threshold):
     assert "2 shard(s)" in d["config"]["verified"]
     assert d["value"] == pytest.approx(2 * d["config"]["kmer_lookups_per_s_full_index"])
     assert r.stdout.strip().splitlines()[-1] == line                # the JSON is the last line on stdout
+
+
+@pytest.mark.gpu
+def test_sharded_bigsi_equals_whole_index(tmp_path):
+    """ShardedBIGSI over two uneven shards (103 + 97 samples, two processes) must return, query for query, what the
+    reference returned on the WHOLE 200-sample index (G7 goldens): names, counts, order, percentages and -- for score=True --
+    presence strings extracted on the rank that owns each hit."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import assert_results_equal, load_golden, unjson
+    out = tmp_path / "sharded.json"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(ROOT, "tests", "helpers", "sharded_worker.py"), str(out)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = json.load(open(out))
+    g = load_golden("g7_random.json")
+    assert len(got["searches"]) == len(g["searches"])
+    for s, res in zip(g["searches"], got["searches"]):
+        if "raises" in s["out"]:
+            assert res.get("raises") == s["out"]["raises"]
+        else:
+            assert "results" in res, res
+            assert_results_equal(res["results"], unjson(s["out"]["results"]), "q%d t=%r score=%r" % (s["q"], s["threshold"], s["score"]))
+    want = {(s["q"], s["threshold"]): s["out"]["results"] for s in g["searches"] if not s["score"] and "results" in s["out"]}
+    for qi in range(10):
+        assert_results_equal(got["batch"][qi], unjson(want[(qi, 0.4)]), "batch q%d" % qi)
