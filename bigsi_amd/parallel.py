@@ -107,13 +107,20 @@ class ShardedSearch(object):
         self._exact = bool(exact)
         self._slot_of = {id(batch): s for s, batch in enumerate(batches)}
         for s, batch in enumerate(batches):
-            with self.torch.cuda.stream(self.stream):
-                self._bufs[s] = self.sg.gather_buffer(batch.n * stride_bytes, self.device)
+            need = batch.n * stride_bytes
+            if self._bufs[s] is None or self._bufs[s].shape[1] != need:      # buffers are kept across calls of one shape
+                with self.torch.cuda.stream(self.stream):
+                    self._bufs[s] = self.sg.gather_buffer(need, self.device)
             slot = self._bufs[s][self.sg.rank].data_ptr()
             check(_lib.lib().bigsi_hip_batch_set_outputs(batch.b, slot, None))
             check(_lib.lib().bigsi_hip_batch_set_gather_stream(batch.b, self.comm.cuda_stream))
-            if not exact:
+            if exact:
+                check(_lib.lib().bigsi_hip_batch_set_gathered_hit_outputs(batch.b, None, None, 0))
+            elif self._hitbufs[s] is None:
                 self._set_hit_capacity(s, batch, 1 << 16)
+            else:
+                col, cnt = self._hitbufs[s]
+                check(_lib.lib().bigsi_hip_batch_set_gathered_hit_outputs(batch.b, col.data_ptr(), cnt.data_ptr(), col.numel()))
         self.stream.synchronize()
 
     def _set_hit_capacity(self, s, batch, cap):
