@@ -8,7 +8,7 @@ import yaml
 
 from . import BIGSI
 from .bitrow import BitRow
-from .frontend import bulk_search, read_fasta, search
+from .frontend import bulk_search, read_fasta, search, variant_search
 from .graph.bigsi import DEFAULT_CONFIG
 from .storage import get_storage
 from .utils import seq_to_kmers
@@ -41,6 +41,15 @@ def main(argv=None):
     sp.add_argument("--score", action="store_true")
     sp.add_argument("--format", choices=["json", "csv"], default="json")
     sp.add_argument("--stream", action="store_true")
+    sp = common(sub.add_parser("variant_search"))
+    sp.add_argument("reference")
+    sp.add_argument("ref")
+    sp.add_argument("pos", type=int)
+    sp.add_argument("alt")
+    sp.add_argument("--gene", "-g", default=None)
+    sp.add_argument("--genbank", "-b", default=None)
+    sp.add_argument("--format", choices=["json", "csv"], default="json")
+    sp.add_argument("--probes", default=None, help="output of `mykrobe variants make-probes` for this variant (skips calling it)")
     sp = common(sub.add_parser("bloom", help="Bloom filter of the k-mers of a Cortex .ctx graph, a FASTA file or a one-k-mer-per-line text file"))
     sp.add_argument("infile")
     sp.add_argument("outfile")
@@ -62,6 +71,8 @@ def main(argv=None):
         text = bulk_search(BIGSI(config), a.fasta, a.threshold, a.score, a.format, a.stream)
         if text is not None:
             print(text)
+    elif a.cmd == "variant_search":
+        print(variant_search(BIGSI(config), a.reference, a.ref, a.pos, a.alt, a.gene, a.genbank, a.format, a.probes))
     elif a.cmd == "bloom":
         first = open(a.infile, "rb").read(6)
         if first == b"CORTEX":                      # the reference's input: a Cortex graph (bigsi/__main__.py:120-131)

@@ -88,3 +88,16 @@ def bulk_search(bigsi, fasta, threshold=1.0, score=False, format="json", stream=
         else:
             print(json.dumps(d), file=out)
     return None
+
+
+def variant_search(bigsi, reference, ref, pos, alt, gene=None, genbank=None, format="json", probes=None):
+    """Text of the reference's `variant_search` command (bigsi/__main__.py:222-246)."""
+    from .variant_search import BIGSIAminoAcidMutationSearch, BIGSIVariantSearch
+    if genbank and gene:
+        d = BIGSIAminoAcidMutationSearch(bigsi, reference, genbank).search(gene, ref, pos, alt, probes=probes)
+    elif genbank or gene:
+        raise ValueError("genbank and gene must be supplied together")
+    else:
+        d = BIGSIVariantSearch(bigsi, reference).search(ref, pos, alt, probes=probes)
+    d["citation"] = CITATION
+    return d_to_csv(d) if format == "csv" else json.dumps(d, indent=4)

@@ -524,6 +524,101 @@ def g11_example_bdb_files():
         print("copied", dst)
 
 
+# ------------------------------- G12: variant genotyping (cmds/variant_search.py) over exact searches
+def g12_variant():
+    """Runs BIGSIVariantSearch / BIGSIAminoAcidMutationSearch and the `variant_search` command of bigsi.__main__
+    unmodified.  The external probe generator (`mykrobe variants make-probes`, a subprocess in the reference) is not
+    installed, so `create_variant_probe_set` is patched on the instance/class to return a canned probe FASTA -- the
+    searches, the ref/alt split by record name, genotype calls and output text are the reference's.  The reference emits
+    results in set-iteration order (varies with PYTHONHASHSEED); the fixture stores them sorted by sample name."""
+    import tempfile
+
+    import yaml
+    import bigsi.__main__ as ref_main          # stand-ins for hug / pyfasta installed by g9_frontend()
+    from bigsi.cmds import variant_search as ref_vs
+    rng = np.random.default_rng(12)
+    k, m, h = 21, 5000, 3
+    c = cfg("g12", k, m, h)
+    ref_storage.get_storage(c).delete_all()
+    genome = "".join(rng.choice(list("ACGT"), size=400))
+    other = "".join(rng.choice(list("ACGT"), size=400))
+
+    def mutate(g, pos, base):
+        return g[:pos] + base + g[pos + 1:]
+
+    variants = []
+    for pos in (60, 150, 151, 300):
+        refb = genome[pos]
+        alts = [b for b in "ACGT" if b != refb]
+        variants.append((pos, refb, alts))
+    p0, r0, a0 = variants[0]
+    p1, r1, a1 = variants[1]
+    p3, r3, a3 = variants[3]
+    samples = {
+        "wildtype": [genome],
+        "snp60": [mutate(genome, p0, a0[0])],
+        "het60": [genome, mutate(genome, p0, a0[0])],
+        "snp150_second_alt": [mutate(genome, p1, a1[1])],
+        "double": [mutate(mutate(genome, p0, a0[0]), p3, a3[2])],
+        "unrelated": [other],
+        "partial": [genome[:p3 - 3]],
+    }
+    blooms = [BIGSI.bloom(c, [km for s in seqs for km in seq_to_kmers(s, k)]) for seqs in samples.values()]
+    b = BIGSI.build(c, blooms, list(samples.keys()))
+    b.delete_sample("unrelated")
+
+    def probe(g, pos):
+        return g[pos - k + 1: pos + k]
+
+    def norm(res):
+        return sorted(res, key=lambda r: r["sample_name"])
+
+    out = {"k": k, "m": m, "h": h, "samples": samples, "deleted": ["unrelated"], "cases": [], "cli": []}
+    with tempfile.TemporaryDirectory() as td:
+        cf = os.path.join(td, "c.yaml")
+        with open(cf, "w") as f:
+            yaml.safe_dump(c, f)
+        for pos, refb, alts in variants:
+            refs = [probe(genome, pos)]
+            for alt_base, alt_list in [(a, [a]) for a in alts] + [("X", alts)]:
+                alt_seqs = [probe(mutate(genome, pos, a), pos) for a in alt_list]
+                fasta = "".join(">ref-%s%d%s?var_name=%s%d%s&num_alts=%d\n%s\n" % (refb, pos, alt_base, refb, pos, alt_base, len(alt_seqs), r)
+                                for r in refs)
+                fasta += "".join(">alt-%s%d%s-%d\n%s\n" % (refb, pos, alt_base, i, a) for i, a in enumerate(alt_seqs))
+                vs = ref_vs.BIGSIVariantSearch(b, "ref.fa")
+                vs.create_variant_probe_set = lambda var_name, _f=fasta: _f.encode()
+                d = vs.search(refb, pos, alt_base)
+                assert norm(d["results"]) == norm(vs.genotype_alleles(refs, alt_seqs))
+                out["cases"].append({"ref_base": refb, "pos": pos, "alt_base": alt_base, "probes_fasta": fasta,
+                                     "refs": refs, "alts": alt_seqs, "query": d["query"], "results": norm(d["results"])})
+        # the command (json and csv), and the amino-acid flavour (gene + genbank), probe sets patched at class level
+        case = out["cases"][0]
+        saved = (ref_vs.BIGSIVariantSearch.create_variant_probe_set, ref_vs.BIGSIAminoAcidMutationSearch.create_variant_probe_set)
+        ref_vs.BIGSIVariantSearch.create_variant_probe_set = lambda self, var_name: case["probes_fasta"].encode()
+        ref_vs.BIGSIAminoAcidMutationSearch.create_variant_probe_set = lambda self, var_name: case["probes_fasta"].encode()
+        try:
+            api = ref_main.bigsi()
+            for fmt in ("json", "csv"):
+                for gene, genbank in ((None, None), ("rpoB", "x.gb")):
+                    text = api.variant_search("ref.fa", case["ref_base"], case["pos"], case["alt_base"], gene, genbank, cf, fmt)
+                    if fmt == "json":
+                        d = json.loads(text)
+                        d["results"] = norm(d["results"])
+                        keys = list(json.loads(text).keys())
+                        rec = {"parsed": d, "key_order": keys, "indent4": text.startswith('{\n    "')}
+                    else:
+                        lines = text.split("\r\n")
+                        rec = {"header": lines[0], "rows_sorted": sorted(lines[1:-1]), "tail": lines[-1]}
+                    out["cli"].append({"format": fmt, "gene": gene, "genbank": genbank, "case": 0, "out": rec})
+            try:
+                api.variant_search("ref.fa", "A", 1, "T", "rpoB", None, cf, "json")
+            except Exception as e:
+                out["gene_without_genbank"] = type(e).__name__
+        finally:
+            ref_vs.BIGSIVariantSearch.create_variant_probe_set, ref_vs.BIGSIAminoAcidMutationSearch.create_variant_probe_set = saved
+    dump("g12_variant.json", out, indent=None)
+
+
 if __name__ == "__main__":
     g1_hash()
     g2_lookup()
@@ -536,3 +631,4 @@ if __name__ == "__main__":
     g9_frontend()
     g10_cortex()
     g11_example_bdb_files()
+    g12_variant()
