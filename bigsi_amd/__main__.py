@@ -30,12 +30,21 @@ def main(argv=None):
         sp.add_argument("--config", "-c", default=None)
         return sp
 
-    sp = common(sub.add_parser("search"))
+    def shardable(sp):
+        sp.add_argument("--sharded", action="store_true",
+                        help="the index is spread by column range over the ranks of a `python -m torch.distributed.run` launch "
+                             "(one process per GPU); rank 0 prints")
+        sp.add_argument("--out", "-o", default=None,
+                        help="with --sharded: write the text to this file instead of stdout (transport libraries announce "
+                             "themselves on stdout)")
+        return sp
+
+    sp = shardable(common(sub.add_parser("search")))
     sp.add_argument("seq")
     sp.add_argument("--threshold", "-t", type=float, default=1.0)
     sp.add_argument("--score", action="store_true")
     sp.add_argument("--format", choices=["json", "csv"], default="json")
-    sp = common(sub.add_parser("bulk_search"))
+    sp = shardable(common(sub.add_parser("bulk_search")))
     sp.add_argument("fasta")
     sp.add_argument("--threshold", "-t", type=float, default=1.0)
     sp.add_argument("--score", action="store_true")
@@ -53,7 +62,7 @@ def main(argv=None):
     sp = common(sub.add_parser("bloom", help="Bloom filter of the k-mers of a Cortex .ctx graph, a FASTA file or a one-k-mer-per-line text file"))
     sp.add_argument("infile")
     sp.add_argument("outfile")
-    sp = common(sub.add_parser("build"))
+    sp = shardable(common(sub.add_parser("build")))
     sp.add_argument("--bloomfilters", "-b", action="append", default=[])
     sp.add_argument("--samples", "-s", action="append", default=[])
     sp = common(sub.add_parser("insert"))
@@ -65,6 +74,8 @@ def main(argv=None):
     a = p.parse_args(argv)
     config = get_config_from_file(a.config)
 
+    if getattr(a, "sharded", False):
+        return sharded_main(a, config)
     if a.cmd == "search":
         print(search(BIGSI(config), a.seq, a.threshold, a.score, a.format))
     elif a.cmd == "bulk_search":
@@ -100,6 +111,39 @@ def main(argv=None):
             print("rows=%d cols=%d" % bdb.import_index(a.path, dst))
     elif a.cmd == "delete":
         get_storage(config).delete_all()
+    return 0
+
+
+def sharded_main(a, config):
+    """search / bulk_search / build on a column-sharded index: every rank runs the same command (SPMD), the device work
+    and the exchange are bigsi_amd.parallel's, and only rank 0 writes to stdout."""
+    import io
+
+    from .parallel import ShardedBIGSI
+    rank, world, _ = ShardedBIGSI.launch()
+    if a.cmd == "build":
+        sb = ShardedBIGSI.build(config, a.bloomfilters, a.samples)
+        text = '{"result": "success"}'
+    else:
+        sb = ShardedBIGSI.open(config)
+        if a.cmd == "search":
+            text = search(sb, a.seq, a.threshold, a.score, a.format)
+        else:
+            sink = io.StringIO()
+            text = bulk_search(sb, a.fasta, a.threshold, a.score, a.format, a.stream, out=sink)
+            if text is None:                      # --stream: the records were printed into `sink`
+                text = sink.getvalue()[:-1]
+    if rank == 0:
+        if a.out:
+            with open(a.out, "w", newline="") as f:
+                f.write(text + "\n")
+        else:
+            print(text)
+    sb.close()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
     return 0
 
 

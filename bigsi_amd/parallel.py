@@ -15,6 +15,8 @@ instead of the 51 MB of uint16 counters a dense exchange would move.
 Row-range sharding is deliberately not offered: a query touches random rows, so every k-mer would need an
 AND-reduce across GPUs.
 """
+import os
+
 import numpy as np
 
 from . import _lib
@@ -199,6 +201,22 @@ class ShardedSearch(object):
             return off, col[: int(off[-1])], cnt[: int(off[-1])]
 
 
+def shard_config(config, rank, world, device=None):
+    """`config` for one rank of a sharded index: resident name and snapshot file get a ".shard<r>-of-<w>" suffix, the
+    device ordinal is the rank's own.  world == 1 returns the config unchanged apart from the device."""
+    cfg = dict(config)
+    sc = dict(cfg.get("storage-config") or {})
+    if world > 1:
+        tag = ".shard%d-of-%d" % (rank, world)
+        sc["name"] = str(sc.get("name", "default")) + tag
+        if sc.get("filename"):
+            sc["filename"] = str(sc["filename"]) + tag
+    if device is not None:
+        sc["device"] = int(device)
+    cfg["storage-config"] = sc
+    return cfg
+
+
 class ShardedBIGSI(object):
     """One BIGSI index whose samples are spread over the ranks of a process group: `search_batch` returns exactly what
     `BIGSI.search` would return on the concatenation of all shards (rank 0's samples first, then rank 1's, ...).
@@ -224,6 +242,58 @@ class ShardedBIGSI(object):
         self.engine = ShardedSearch(local.storage, self.shard_cols, group=group, device=device, force_gather=True)
         self.scorer = Scorer(self.num_samples)               # DB_SIZE = number of samples of the whole index
         self._batch = None
+
+    # ---- one index spread over the ranks of a torch.distributed.run launch (CLI: --sharded)
+    @staticmethod
+    def launch(backend=None):
+        """(rank, world, torch.device) of this process; joins the default process group from the launcher's environment
+        (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*) if that has not happened yet.  BIGSI_SHARD_DEVICE overrides the device
+        ordinal (several ranks on one GPU, with backend "gloo": RCCL refuses two ranks on one device)."""
+        import torch
+        import torch.distributed as dist
+        rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+        ordinal = int(os.environ.get("BIGSI_SHARD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(ordinal)
+        dev = torch.device("cuda", ordinal)
+        if world > 1 and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29512")
+            backend = backend or os.environ.get("BIGSI_SHARD_BACKEND", "nccl")
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+        return rank, world, dev
+
+    @classmethod
+    def open(cls, config, backend=None):
+        """The shard of `config`'s index that belongs to this rank (see shard_config), wrapped for whole-index queries."""
+        from .graph.bigsi import BIGSI
+        rank, world, dev = cls.launch(backend)
+        return cls(BIGSI(shard_config(config, rank, world, dev.index)), device=dev)
+
+    @classmethod
+    def build(cls, config, bloomfilters, samples, backend=None):
+        """BIGSI.build (graph/bigsi.py:157-172) with the samples dealt out in contiguous column ranges, rank r keeping
+        range r: every rank passes the same full lists (or only its own range filled in -- entries outside a
+        rank's range are never touched, so `bloomfilters` may hold None or a file name to load there)."""
+        from .bitrow import BitRow
+        from .graph.bigsi import BIGSI
+        rank, world, dev = cls.launch(backend)
+        if len(bloomfilters) != len(samples):
+            raise ValueError("There must be the same number of bloomfilters and sample names")
+        if len(samples) < world:
+            raise ValueError("%d samples cannot be spread over %d shards" % (len(samples), world))
+        lo, hi = rank * len(samples) // world, (rank + 1) * len(samples) // world      # sizes differ by at most one, none empty
+        n = hi - lo
+        cfg = shard_config(config, rank, world, dev.index)
+        mine = []
+        for b in bloomfilters[lo:lo + n]:
+            if isinstance(b, str):
+                with open(b, "rb") as f:
+                    b = BitRow.frombytes(f.read(), config["m"])
+            mine.append(b)
+        return cls(BIGSI.build(cfg, mine, list(samples[lo:lo + n])), device=dev)
 
     def _gather(self, obj):
         if not self.dist.is_initialized():

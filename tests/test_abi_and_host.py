@@ -219,6 +219,12 @@ def test_shard_planning():
     assert sc == 3 and spans == [(0, 3), (3, 3), (6, 3), (9, 1)]
     assert plan_shards(5, 8)[1][5:] == [(5, 0), (5, 0), (5, 0)]
     assert math.ceil(7 * 0.1) == 1
+    from bigsi_amd.parallel import shard_config
+    base = {"k": 31, "m": 1000, "h": 3, "storage-config": {"name": "ix", "filename": "/data/ix.hbm"}}
+    c1 = shard_config(base, 1, 4, 1)
+    assert c1["storage-config"] == {"name": "ix.shard1-of-4", "filename": "/data/ix.hbm.shard1-of-4", "device": 1}
+    assert base["storage-config"] == {"name": "ix", "filename": "/data/ix.hbm"} and c1["k"] == 31       # input untouched
+    assert shard_config(base, 0, 1, 0)["storage-config"] == {"name": "ix", "filename": "/data/ix.hbm", "device": 0}
 
 
 def test_cortex_reader_vs_reference(tmp_path):

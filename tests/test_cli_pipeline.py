@@ -67,3 +67,63 @@ def test_bloom_build_search_commands(tmp_path):
             n += 1
     assert n >= 12
     cli(["delete", "--config", str(cf)], str(tmp_path))
+
+
+def cli_sharded(args, cwd, port, nproc=2):
+    """The same command under `python -m torch.distributed.run`, both ranks on the test box's one GPU (gloo carries the
+    CUDA tensors; RCCL refuses two ranks on one device).  Text comes back through --out: gloo / RCCL print banners on stdout."""
+    out = os.path.join(cwd, "sharded_out.txt")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", "bigsi_amd"] + args + ["--sharded", "--out", out]
+    r = subprocess.run(cmd, cwd=cwd, capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, PYTHONPATH=ROOT, BIGSI_SHARD_DEVICE="0", BIGSI_SHARD_BACKEND="gloo", MASTER_ADDR="127.0.0.1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    with open(out, newline="") as f:
+        return nl(f.read())
+
+
+@pytest.mark.gpu
+def test_sharded_build_and_search_commands(tmp_path):
+    """build / search / bulk_search with --sharded: the three G9 samples dealt over two ranks (1 + 2 columns), each rank's
+    shard persisted in its own snapshot file between commands; output text = the reference's on the whole index (G9)."""
+    g9 = load_golden("g9_frontend.json")
+    cfg = {"storage-engine": "hip-hbm", "k": 31, "m": 1000, "h": 3,
+           "storage-config": {"name": "clish", "filename": str(tmp_path / "index.hbm")}}
+    cf = tmp_path / "config.yaml"
+    cf.write_text(yaml.safe_dump(cfg))
+    names = list(g9["samples"].keys())
+    args = ["build", "--config", str(cf)]
+    for i, nme in enumerate(names):
+        kf = tmp_path / ("s%d.kmers" % i)
+        kf.write_text("\n".join(g9["samples"][nme]) + "\n")
+        cli(["bloom", str(kf), str(tmp_path / ("s%d.bloom" % i)), "--config", str(cf)], str(tmp_path))
+        args += ["-b", str(tmp_path / ("s%d.bloom" % i)), "-s", nme]
+    assert "success" in cli_sharded(args, str(tmp_path), 29551)
+    assert os.path.exists(str(tmp_path / "index.hbm.shard0-of-2")) and os.path.exists(str(tmp_path / "index.hbm.shard1-of-2"))
+    fasta = tmp_path / "tests.fasta"
+    fasta.write_text(g9["fasta_text"]["tests"])
+    n, port = 0, 29552
+    for c in g9["cases"]:
+        if c["score"] and c["format"] == "csv":
+            continue                                  # last-ulp evalue/pvalue digits: compared through json in test_frontend.py
+        if c["cmd"] == "search" and c["seq"] == g9["cases"][0]["seq"]:
+            extra = ["--score"] if c["score"] else []
+            out = cli_sharded(["search", c["seq"], "--threshold", str(c["threshold"]), "--format", c["format"], "--config", str(cf)] + extra,
+                              str(tmp_path), port)
+            want = nl(c["out"] + "\n")
+        elif c["cmd"] == "bulk_search" and c["fasta"] == "tests" and not c["score"]:
+            extra = ["--stream"] if c["stream"] else []
+            out = cli_sharded(["bulk_search", str(fasta), "--threshold", str(c["threshold"]), "--format", c["format"], "--config", str(cf)] + extra,
+                              str(tmp_path), port)
+            want = nl(c["stdout"]) if c["stream"] else nl(c["out"] + "\n")
+        else:
+            continue
+        port += 1
+        if c["score"]:
+            from conftest import FLOAT_TOL_KEYS
+            strip = lambda d: [{k: v for k, v in r.items() if k not in FLOAT_TOL_KEYS} for r in d["results"]]     # noqa: E731
+            assert strip(json.loads(out)) == strip(json.loads(want))
+        else:
+            assert out == want, (c["cmd"], c["threshold"], c["format"], c.get("stream"))
+        n += 1
+    assert n >= 10, n
