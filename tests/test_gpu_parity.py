@@ -3,6 +3,8 @@ unmodified reference (tests/golden) and the CPU oracle (oracle/) on seeded input
 integer / byte / index; float score fields as stated in conftest.py.  Needs a real MI355X: `pytest -m gpu`."""
 import itertools
 
+import os
+
 import numpy as np
 import pytest
 
@@ -905,7 +907,7 @@ def test_search_stream_pipelined_equals_one_by_one(hip):
     b.delete()
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BIGSI_FUZZ_SEEDS", "48"))))      # a longer campaign: BIGSI_FUZZ_SEEDS=1000
 def test_fuzz_random_shapes_vs_oracle(hip, seed):
     """Seeded random shapes: column counts around byte / word / tile boundaries, h 1..8, k 1..40, batch sizes from 1 (row
     sliced, atomics) to hundreds (unsliced), thresholds incl. 0 / tiny / 1, queries with duplicates, N, lowercase, too short."""
