@@ -48,7 +48,7 @@ def assert_result_equal(got, want, ctx=""):
         if k in FLOAT_TOL_KEYS:
             assert g == pytest.approx(w, **FLOAT_TOL_KEYS[k]), "%s %s: %r vs %r" % (ctx, k, g, w)
         else:
-            assert g == w and type(g).__name__.replace("float64", "float") == type(w).__name__, \
+            assert g == w and type(g).__name__.replace("float64", "float") == type(w).__name__.replace("float64", "float"), \
                 "%s %s: %r vs %r" % (ctx, k, g, w)
 
 

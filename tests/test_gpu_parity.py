@@ -957,3 +957,89 @@ def test_fuzz_random_shapes_vs_oracle(hip, seed):
                 assert np.array_equal(cnt[lo:hi], want_cnt[want].astype(np.uint32)), (seed, thr, i)
     batch.close()
     st.delete_all()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BIGSI_API_FUZZ_SEEDS", "16"))))
+def test_fuzz_api_vs_oracle_model(hip, seed):
+    """The whole API against the oracle's restatement of BIGSI.search (pinned to the reference by test_oracle_golden.py):
+    random samples built three ways (bloom+build, build_from_sequences, build then insert / merge), a soft-deleted
+    sample, and random queries -- substrings, mutated, repeated, reverse strand, junk -- at random thresholds with and
+    without scores; result lists (names, counts, order, percentages, score dicts, exceptions) must be identical."""
+    import bigsi_amd
+    from bigsi_amd.utils import seq_to_kmers
+    from oracle.ref_model import OracleBIGSI
+    rng = np.random.default_rng(5000 + seed)
+    k = int(rng.choice([5, 11, 21, 31]))
+    m = int(rng.choice([251, 1000, 4099, 20011]))
+    h = int(rng.integers(1, 5))
+    n = int(rng.choice([1, 3, 8, 9, 33, 70]))
+    genomes = ["".join(rng.choice(list("ACGT"), size=int(rng.integers(k + 5, 400)))) for _ in range(max(2, n // 3))]
+    samples = {}
+    for i in range(n):
+        g = genomes[int(rng.integers(0, len(genomes)))]
+        a = int(rng.integers(0, max(len(g) - k - 4, 1)))
+        frag = g[a:a + int(rng.integers(k, 250))]
+        extra = genomes[int(rng.integers(0, len(genomes)))][: int(rng.integers(k, 3 * k))]
+        samples["s%d" % i] = [frag, extra] if i % 3 else [frag]
+    names = list(samples)
+    kmers_of = lambda seqs: [km for s in seqs for km in seq_to_kmers(s, k)]      # noqa: E731
+    how = seed % 3
+    c = cfg(k, m, h)
+    if how == 0:
+        b = bigsi_amd.BIGSI.build(c, [bigsi_amd.BIGSI.bloom(c, kmers_of(samples[nm])) for nm in names], names)
+    elif how == 1:
+        b = bigsi_amd.BIGSI.build_from_sequences(c, samples)
+    else:                                            # first part built, one inserted, the rest merged in from a second index
+        cut = max(1, n // 2)
+        first = names[:cut]
+        b = bigsi_amd.BIGSI.build(c, [bigsi_amd.BIGSI.bloom(c, kmers_of(samples[nm])) for nm in first], first)
+        rest = names[cut:]
+        if rest:
+            b.insert(bigsi_amd.BIGSI.bloom(c, kmers_of(samples[rest[0]])), rest[0])
+        if len(rest) > 1:
+            c2 = cfg(k, m, h)
+            b2 = bigsi_amd.BIGSI.build(c2, [bigsi_amd.BIGSI.bloom(c2, kmers_of(samples[nm])) for nm in rest[1:]], rest[1:])
+            b.merge(b2)
+            b2.delete()
+        # like the reference, a BIGSI object sizes its Scorer when it is constructed (graph/bigsi.py:140): open the grown
+        # index afresh, as the next process would
+        b = bigsi_amd.BIGSI(c)
+    orc = OracleBIGSI.build([OracleBIGSI.bloom(kmers_of(samples[nm]), m, h) for nm in names], list(names), k, m, h)
+    assert b.num_samples == n
+    if n > 2 and seed % 2:
+        b.delete_sample(names[1])
+        orc.names[1] = "D3L3T3D"
+    try:
+        queries = []
+        for qi in range(14):
+            g = genomes[qi % len(genomes)]
+            a = int(rng.integers(0, max(len(g) - k, 1)))
+            s = g[a:a + int(rng.integers(k - 1, 4 * k + 40))]
+            if qi % 5 == 1 and len(s) > 2:
+                p = int(rng.integers(0, len(s)))
+                s = s[:p] + "ACGT"[("ACGT".index(s[p]) + 1) % 4] + s[p + 1:]
+            if qi % 5 == 2:
+                s = s + s
+            if qi % 5 == 3:
+                s = bigsi_amd.utils.reverse_comp(s)
+            if qi % 7 == 6:
+                s = s[: len(s) // 2] + "N" + s[len(s) // 2:].lower()
+            queries.append(s)
+        queries += [genomes[0][:k], genomes[0][: k + 1], "A" * (k - 1)]
+        for s in queries:
+            for thr in (1.0, float(rng.choice([0.0, 0.2, 0.5, 0.9])), 1):
+                for score in (False, True):
+                    try:
+                        want = {"results": orc.search(s, thr, score)}
+                    except BaseException as e:  # noqa: BLE001
+                        want = {"raises": type(e).__name__}
+                    check_search(lambda: b.search(s, thr, score), {"out": want}, "seed %d q=%s t=%r score=%r" % (seed, s[:12], thr, score))
+        got = b.search_batch([q for q in queries if len(q) >= k], 0.5)
+        for q, r in zip([q for q in queries if len(q) >= k], got):
+            assert_results_equal(r, orc.search(q, 0.5), "batch " + q[:12])
+        km = list(dict.fromkeys(kmers_of([queries[0]])))[:20]
+        if km:
+            lk, want_lk = b.lookup(km), orc.lookup(km)
+            assert {x: v.to01() for x, v in lk.items()} == want_lk
+    finally:
+        b.delete()
