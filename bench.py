@@ -124,8 +124,9 @@ def main():
     for j, qi in enumerate(planted):
         st.insert_kmers((1009 * (j + 1) + 13 * rank) % args.cols, [seqs[qi]], args.k)
     sh = ShardedSearch(st, args.cols, device=dev, force_gather=args.force_dist)   # puts the library on a torch stream
-    # sharded runs alternate two staged copies of the batch, so that the exchange of one overlaps the kernels of the other
-    batches = [st.new_batch(seqs, args.k) for _ in range(2 if sh.gathering else 1)]
+    # consecutive steps alternate two staged copies of the batch (a serving loop's two workspaces): K1 of one overlaps the
+    # row-AND kernel of the other on the library's pre stream, and in sharded runs so does the exchange
+    batches = [st.new_batch(seqs, args.k) for _ in range(2)]
     batch = batches[0]
     count_bytes = 2 if (args.qlen - args.k + 1) < 65536 else 4
     sh.prepare(batches, exact, count_bytes)

@@ -91,6 +91,9 @@ struct EventPair {
 struct bigsi_hip_index {
     int device = 0;
     hipStream_t stream = nullptr, own_stream = nullptr;
+    // query upload + K1 (+ row sort) of a batch run here, so that they overlap the row-AND kernel of the batch before it;
+    // `stream` (possibly the caller's) joins through the batch's k1_done event before K2
+    hipStream_t pre_stream = nullptr;
     uint64_t m = 0, n_cols = 0, cap_cols = 0, stride_words = 0;
     uint32_t h = 0;
     uint64_t *d_index = nullptr;
@@ -136,10 +139,25 @@ extern "C" int bigsi_hip_open(uint64_t num_rows, uint64_t num_cols, uint64_t col
     hipError_t e = hipStreamCreateWithFlags(&ix->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete ix; return fail(BIGSI_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     ix->stream = ix->own_stream;
+    {
+        // lowest priority: when the row-AND kernel of one batch and K1 of the next are both ready, the row-AND kernel's
+        // workgroups are placed first (all of them have to be resident together, see k_and_exact) and K1 fills the gaps
+        int least = 0, greatest = 0;
+        e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+        static const int pre_prio = env_int("BIGSI_HIP_PRE_PRIORITY", 1);
+        if (e == hipSuccess && pre_prio) e = hipStreamCreateWithPriority(&ix->pre_stream, hipStreamNonBlocking, least);
+        else e = hipStreamCreateWithFlags(&ix->pre_stream, hipStreamNonBlocking);
+    }
+    if (e != hipSuccess) {
+        hipError_t e2 = hipStreamDestroy(ix->own_stream); (void)e2;
+        delete ix;
+        return fail(BIGSI_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
     const size_t bytes = (size_t)ix->m * ix->stride_words * 8;
     e = hipMalloc((void **)&ix->d_index, bytes);
     if (e != hipSuccess) {
         hipError_t e2 = hipStreamDestroy(ix->own_stream); (void)e2;
+        e2 = hipStreamDestroy(ix->pre_stream);
         delete ix;
         return fail(BIGSI_ERR_NOMEM, "hipMalloc of %zu index bytes failed: %s", bytes, hipGetErrorString(e));
     }
@@ -148,6 +166,7 @@ extern "C" int bigsi_hip_open(uint64_t num_rows, uint64_t num_cols, uint64_t col
     if (e != hipSuccess) {
         hipError_t e2 = hipFree(ix->d_index); (void)e2;
         e2 = hipStreamDestroy(ix->own_stream);
+        e2 = hipStreamDestroy(ix->pre_stream);
         delete ix;
         return fail(BIGSI_ERR_HIP, "zeroing the index failed: %s", hipGetErrorString(e));
     }
@@ -168,12 +187,14 @@ extern "C" int bigsi_hip_close(bigsi_hip_index *ix)
     if (!ix) return BIGSI_OK;
     hipError_t e = hipSetDevice(ix->device);
     e = hipStreamSynchronize(ix->stream);
+    if (ix->pre_stream) e = hipStreamSynchronize(ix->pre_stream);
     recycle_events(ix);
     for (auto &p : ix->ev_free) { e = hipEventDestroy(p.a); e = hipEventDestroy(p.b); }
     ix->stage.release();
     ix->stage_ids.release();
     if (ix->d_index) e = hipFree(ix->d_index);
     if (ix->own_stream) e = hipStreamDestroy(ix->own_stream);
+    if (ix->pre_stream) e = hipStreamDestroy(ix->pre_stream);
     (void)e;
     delete ix;
     return BIGSI_OK;
@@ -245,6 +266,7 @@ extern "C" int bigsi_hip_synchronize(bigsi_hip_index *ix)
 {
     if (!ix) return fail(BIGSI_ERR_INVALID, "NULL index");
     TRY(use_device(ix));
+    HIP_TRY(hipStreamSynchronize(ix->pre_stream));
     HIP_TRY(hipStreamSynchronize(ix->stream));
     return BIGSI_OK;
 }
@@ -490,6 +512,7 @@ extern "C" int bigsi_hip_stats(bigsi_hip_index *ix, bigsi_hip_stats_t *out, int 
 {
     if (!ix || !out) return fail(BIGSI_ERR_INVALID, "NULL argument");
     TRY(use_device(ix));
+    HIP_TRY(hipStreamSynchronize(ix->pre_stream));
     HIP_TRY(hipStreamSynchronize(ix->stream));
     auto sum = [&](std::vector<EventPair> &v, uint64_t *n, double *ms) -> int {
         *n = v.size();
@@ -544,6 +567,9 @@ struct bigsi_hip_batch {
     uint32_t run_h = 0;            // num_hashes the row ids of the last K1 were produced with
     hipEvent_t done = nullptr;     // recorded at the end of every run: fetches wait on it, not on the whole stream, so the
                                    // results of one batch can be read while the next batch's kernels are queued behind it
+    hipEvent_t k1_done = nullptr;  // recorded on the index's pre_stream after K1 (+ row sort); the main stream waits on it before K2
+    hipEvent_t g_done = nullptr;   // recorded on the gather stream after a gathered compaction (it reads K1's per-query arrays)
+    bool dirty = false;            // a run was started and its `done` event has not been recorded (error path): full syncs needed
     hipStream_t gstream = nullptr; // stream of the gathered compaction (null: the index's stream)
     const void *g_src = nullptr;   // last gathered buffer handed to compact_gathered
     uint32_t g_shards = 0;
@@ -602,7 +628,7 @@ static int batch_load(bigsi_hip_batch *b, const char *seqs, const uint64_t *offs
     R(b->min_kmers, n_seqs * 4ull);
     auto H2D = [&](void *dst, const void *src, size_t bytes) {
         if (rc == BIGSI_OK && bytes) {
-            hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ix->stream);
+            hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ix->pre_stream);
             if (e != hipSuccess) rc = fail(BIGSI_ERR_HIP, "H2D copy: %s", hipGetErrorString(e));
         }
     };
@@ -612,10 +638,25 @@ static int batch_load(bigsi_hip_batch *b, const char *seqs, const uint64_t *offs
     H2D(b->d_tab_off.p, b->tab_off.data(), (n_seqs + 1) * 8ull);
     b->pos_query_loaded = false;
     if (rc == BIGSI_OK) {
-        hipError_t e = hipStreamSynchronize(ix->stream);      // the host vectors above are read by the copies
+        hipError_t e = hipStreamSynchronize(ix->pre_stream);  // the host vectors above are read by the copies
         if (e != hipSuccess) rc = fail(BIGSI_ERR_HIP, "sync: %s", hipGetErrorString(e));
     }
     return rc;
+}
+
+// host-side wait for everything queued on behalf of this batch (its K1 on the pre stream, K2-K4 on the index stream up to
+// `done`, gathered compaction on the gather stream)
+static int batch_quiesce(bigsi_hip_batch *b)
+{
+    if (b->dirty) {
+        HIP_TRY(hipStreamSynchronize(b->ix->pre_stream));
+        HIP_TRY(hipStreamSynchronize(b->ix->stream));
+        b->dirty = false;
+    } else if (b->done) {
+        HIP_TRY(hipEventSynchronize(b->done));
+    }
+    if (b->g_done) HIP_TRY(hipEventSynchronize(b->g_done));
+    return BIGSI_OK;
 }
 
 static int check_batch_args(bigsi_hip_index *ix, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k)
@@ -648,8 +689,8 @@ extern "C" int bigsi_hip_batch_reload(bigsi_hip_batch *b, const char *seqs, cons
     if (!b) return fail(BIGSI_ERR_INVALID, "NULL batch");
     TRY(check_batch_args(b->ix, seqs, offsets, n_seqs, k));
     TRY(use_device(b->ix));
-    HIP_TRY(hipStreamSynchronize(b->ix->stream));
-    if (b->gstream) HIP_TRY(hipStreamSynchronize(b->gstream));
+    // only THIS batch's earlier work has to be over before its buffers are rewritten: other batches may still be running
+    TRY(batch_quiesce(b));
     return batch_load(b, seqs, offsets, n_seqs, k);
 }
 
@@ -657,7 +698,9 @@ extern "C" int bigsi_hip_batch_destroy(bigsi_hip_batch *b)
 {
     if (!b) return BIGSI_OK;
     hipError_t e = hipSetDevice(b->ix->device);
+    e = hipStreamSynchronize(b->ix->pre_stream);
     e = hipStreamSynchronize(b->ix->stream);
+    if (b->gstream && b->g_done) e = hipEventSynchronize(b->g_done);
     (void)e;
     for (DevBuf *d : {&b->rows_sorted, &b->pos_query, &b->hsh, &b->rep, &b->seqs, &b->d_seq_off, &b->d_pos_off, &b->d_tab_off, &b->tab, &b->first_pos, &b->pos_unique, &b->tmp, &b->rows,
                       &b->num_kmers, &b->num_unique, &b->min_kmers, &b->bitmaps, &b->counts, &b->scratch})
@@ -665,6 +708,8 @@ extern "C" int bigsi_hip_batch_destroy(bigsi_hip_batch *b)
     b->hits.release();
     b->ghits.release();
     if (b->done) { e = hipEventDestroy(b->done); (void)e; }
+    if (b->k1_done) { e = hipEventDestroy(b->k1_done); (void)e; }
+    if (b->g_done) { e = hipEventDestroy(b->g_done); (void)e; }
     delete b;
     return BIGSI_OK;
 }
@@ -700,20 +745,42 @@ static void launch_count_h(bigsi_hip_batch *b, const uint64_t *k2_rows, unsigned
 
 static int compact(bigsi_hip_batch *b, HitBufs &hb, const void *src, uint32_t n_shards, uint64_t shard_cols, bool write_only);
 
+// the stream K1 and the row sort run on.  Default: the index stream itself.  BIGSI_HIP_K1_OVERLAP=1 moves them to the pre
+// stream so that they overlap the row-AND kernel of the batch before; measured a LOSS at C3 (exact: K2 1.93 -> 2.12-2.22 ms,
+// the late-placed workgroups break the lock-step sweep of k_and_exact; counts: +-0), kept for A/B runs only
+static hipStream_t k1_stream(const bigsi_hip_index *ix)
+{
+    static const int overlap = env_int("BIGSI_HIP_K1_OVERLAP", 0);
+    return overlap ? ix->pre_stream : ix->stream;
+}
+
 // K1 for the whole batch (h may have changed since create: the rows buffer is sized for it here)
 static int run_kmerize(bigsi_hip_batch *b, double threshold, bool force_global = false)
 {
     bigsi_hip_index *ix = b->ix;
     EventPair ep{};
+    hipStream_t ks = k1_stream(ix);
+    // K1 rewrites arrays the previous run of THIS batch may still be reading (K2/K4 on the index stream, a gathered
+    // compaction on the gather stream); other batches' kernels are not waited for -- that is the overlap
+    if (ks != ix->stream) {
+        if (b->dirty) {
+            HIP_TRY(hipStreamSynchronize(ix->stream));
+            b->dirty = false;
+        } else if (b->done) {
+            HIP_TRY(hipStreamWaitEvent(ks, b->done, 0));
+        }
+    }
+    // (on the index stream itself the callers' own ordering applies, as for every other entry point)
+    if (b->g_done && b->gstream && b->gstream != ks) HIP_TRY(hipStreamWaitEvent(ks, b->g_done, 0));
     TRY(b->rows.reserve(std::max<uint64_t>(b->total_pos, 1) * ix->h * 8));
     static const int k1_global = env_int("BIGSI_HIP_K1_GLOBAL", 0);
     static const int k1_wave = env_int("BIGSI_HIP_K1_WAVE", 1);
     if (!force_global && !k1_global && k1_wave && b->max_pos <= 64) {
         // probe / read-length queries: one wavefront per query, no LDS, no atomics
-        TRY(ev_begin(ix, &ep));
+        TRY(ev_begin(ix, &ep, ks));
         const unsigned grid = (unsigned)ceil_div(b->n_seqs, kBlock / 64);
 #define BIGSI_K1_WAVE(KF)                                                                                                      \
-    hipLaunchKernelGGL((k_kmerize_wave<KF>), dim3(grid), dim3(kBlock), 0, ix->stream, b->seqs.as<char>(), b->d_seq_off.as<uint64_t>(),     \
+    hipLaunchKernelGGL((k_kmerize_wave<KF>), dim3(grid), dim3(kBlock), 0, ks, b->seqs.as<char>(), b->d_seq_off.as<uint64_t>(),     \
                        b->d_pos_off.as<uint64_t>(), b->k, ix->h, ix->m, threshold, b->n_seqs, b->first_pos.as<uint32_t>(),                \
                        b->pos_unique.as<uint32_t>(), b->rep.as<uint32_t>(), b->rows.as<uint64_t>(), b->num_kmers.as<uint32_t>(),           \
                        b->num_unique.as<uint32_t>(), b->min_kmers.as<uint32_t>())
@@ -721,7 +788,7 @@ static int run_kmerize(bigsi_hip_batch *b, double threshold, bool force_global =
         else BIGSI_K1_WAVE(0);
 #undef BIGSI_K1_WAVE
         HIP_TRY(hipGetLastError());
-        TRY(ev_end(ix, &ep, ix->ev_km));
+        TRY(ev_end(ix, &ep, ix->ev_km, ks));
         b->run_h = ix->h;
         return BIGSI_OK;
     }
@@ -732,9 +799,9 @@ static int run_kmerize(bigsi_hip_batch *b, double threshold, bool force_global =
     if (!force_global && !k1_global && b->max_pos <= kLdsMaxPos && lds <= 60 * 1024) {
         uint32_t block = 64;
         while (block < b->max_pos && block < 1024) block <<= 1;
-        TRY(ev_begin(ix, &ep));
+        TRY(ev_begin(ix, &ep, ks));
 #define BIGSI_K1_LDS(KF)                                                                                                        \
-    hipLaunchKernelGGL((k_kmerize_lds<KF>), dim3(b->n_seqs), dim3(block), lds, ix->stream, b->seqs.as<char>(), b->d_seq_off.as<uint64_t>(), \
+    hipLaunchKernelGGL((k_kmerize_lds<KF>), dim3(b->n_seqs), dim3(block), lds, ks, b->seqs.as<char>(), b->d_seq_off.as<uint64_t>(), \
                        b->d_pos_off.as<uint64_t>(), b->k, ix->h, ix->m, threshold, tab_cap, b->first_pos.as<uint32_t>(), b->tmp.as<uint32_t>(), \
                        b->pos_unique.as<uint32_t>(), b->rep.as<uint32_t>(), b->rows.as<uint64_t>(), b->num_kmers.as<uint32_t>(),      \
                        b->num_unique.as<uint32_t>(), b->min_kmers.as<uint32_t>())
@@ -742,7 +809,7 @@ static int run_kmerize(bigsi_hip_batch *b, double threshold, bool force_global =
         else BIGSI_K1_LDS(0);
 #undef BIGSI_K1_LDS
         HIP_TRY(hipGetLastError());
-        TRY(ev_end(ix, &ep, ix->ev_km));
+        TRY(ev_end(ix, &ep, ix->ev_km, ks));
         b->run_h = ix->h;
         return BIGSI_OK;
     }
@@ -758,26 +825,26 @@ static int run_kmerize(bigsi_hip_batch *b, double threshold, bool force_global =
             b->pos_query_loaded = true;
         }
     }
-    HIP_TRY(hipMemsetAsync(b->tab.p, 0xFF, b->tab_off[b->n_seqs] * 4, ix->stream));
-    TRY(ev_begin(ix, &ep));
+    HIP_TRY(hipMemsetAsync(b->tab.p, 0xFF, b->tab_off[b->n_seqs] * 4, ks));
+    TRY(ev_begin(ix, &ep, ks));
     const uint64_t T = b->total_pos;
     const unsigned pgrid = (unsigned)ceil_div(std::max<uint64_t>(T, 1), kBlock);
 #define BIGSI_K1_INSERT(KF)                                                                                                   \
-    hipLaunchKernelGGL((k_kmer_insert<KF>), dim3(pgrid), dim3(kBlock), 0, ix->stream, b->seqs.as<char>(), b->d_seq_off.as<uint64_t>(), \
+    hipLaunchKernelGGL((k_kmer_insert<KF>), dim3(pgrid), dim3(kBlock), 0, ks, b->seqs.as<char>(), b->d_seq_off.as<uint64_t>(), \
                        b->d_pos_off.as<uint64_t>(), b->pos_query.as<uint32_t>(), b->d_tab_off.as<uint64_t>(), b->tab.as<uint32_t>(), \
                        b->k, T, b->hsh.as<uint32_t>())
 #define BIGSI_K1_ROWS(KF)                                                                                                     \
-    hipLaunchKernelGGL((k_kmer_rows<KF>), dim3(pgrid), dim3(kBlock), 0, ix->stream, b->seqs.as<char>(), b->d_seq_off.as<uint64_t>(), \
+    hipLaunchKernelGGL((k_kmer_rows<KF>), dim3(pgrid), dim3(kBlock), 0, ks, b->seqs.as<char>(), b->d_seq_off.as<uint64_t>(), \
                        b->d_pos_off.as<uint64_t>(), b->pos_query.as<uint32_t>(), b->rep.as<uint32_t>(), b->tmp.as<uint32_t>(), b->k, \
                        ix->h, ix->m, T, b->rows.as<uint64_t>())
     if (T) {
         if (b->k == 31) BIGSI_K1_INSERT(31);
         else BIGSI_K1_INSERT(0);
-        hipLaunchKernelGGL(k_kmer_resolve, dim3(pgrid), dim3(kBlock), 0, ix->stream, b->seqs.as<char>(), b->d_seq_off.as<uint64_t>(),
+        hipLaunchKernelGGL(k_kmer_resolve, dim3(pgrid), dim3(kBlock), 0, ks, b->seqs.as<char>(), b->d_seq_off.as<uint64_t>(),
                            b->d_pos_off.as<uint64_t>(), b->pos_query.as<uint32_t>(), b->d_tab_off.as<uint64_t>(), b->tab.as<uint32_t>(),
                            b->k, T, b->hsh.as<uint32_t>(), b->rep.as<uint32_t>());
     }
-    hipLaunchKernelGGL(k_kmer_rank, dim3(b->n_seqs), dim3(kBlock), 0, ix->stream, b->d_seq_off.as<uint64_t>(), b->d_pos_off.as<uint64_t>(),
+    hipLaunchKernelGGL(k_kmer_rank, dim3(b->n_seqs), dim3(kBlock), 0, ks, b->d_seq_off.as<uint64_t>(), b->d_pos_off.as<uint64_t>(),
                        b->rep.as<uint32_t>(), b->k, threshold, b->first_pos.as<uint32_t>(), b->tmp.as<uint32_t>(), b->pos_unique.as<uint32_t>(),
                        b->num_kmers.as<uint32_t>(), b->num_unique.as<uint32_t>(), b->min_kmers.as<uint32_t>());
     if (T) {
@@ -787,8 +854,19 @@ static int run_kmerize(bigsi_hip_batch *b, double threshold, bool force_global =
 #undef BIGSI_K1_INSERT
 #undef BIGSI_K1_ROWS
     HIP_TRY(hipGetLastError());
-    TRY(ev_end(ix, &ep, ix->ev_km));
+    TRY(ev_end(ix, &ep, ix->ev_km, ks));
     b->run_h = ix->h;
+    return BIGSI_OK;
+}
+
+// K1's outputs become visible to the index stream (K2, K4, lookups): it waits for the pre stream's work of this batch
+static int k1_publish(bigsi_hip_batch *b)
+{
+    bigsi_hip_index *ix = b->ix;
+    if (k1_stream(ix) == ix->stream) return BIGSI_OK;       // same stream: already ordered
+    if (!b->k1_done) HIP_TRY(hipEventCreateWithFlags(&b->k1_done, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(b->k1_done, k1_stream(ix)));
+    HIP_TRY(hipStreamWaitEvent(ix->stream, b->k1_done, 0));
     return BIGSI_OK;
 }
 
@@ -806,9 +884,10 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
     b->wv = ix->wv();
     b->wv_pad = round_up(b->wv, 2);
 
-    // K1
+    // K1 (on the pre stream)
     EventPair ep{};
     TRY(run_kmerize(b, threshold, (flags & BIGSI_RUN_K1_GLOBAL) != 0));
+    b->dirty = true;        // until `done` is recorded at the end
 
     // K1e: address-ordered copy of the row lists for K2 (BIGSI_HIP_SORT_ROWS=0 streams them in hash order instead)
     static const int sort_rows = env_int("BIGSI_HIP_SORT_ROWS", 1);
@@ -821,13 +900,14 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
         TRY(b->rows_sorted.reserve(std::max<uint64_t>(b->total_pos, 1) * ix->h * 8));
         uint32_t shift = 0;
         while (((ix->m - 1) >> shift) >= (uint64_t)kSortBuckets) shift++;
-        TRY(ev_begin(ix, &ep));
-        hipLaunchKernelGGL(k_sort_rows, dim3(b->n_seqs), dim3(kBlock), 0, ix->stream, b->rows.as<uint64_t>(), b->rows_sorted.as<uint64_t>(),
+        TRY(ev_begin(ix, &ep, k1_stream(ix)));
+        hipLaunchKernelGGL(k_sort_rows, dim3(b->n_seqs), dim3(kBlock), 0, k1_stream(ix), b->rows.as<uint64_t>(), b->rows_sorted.as<uint64_t>(),
                            b->d_pos_off.as<uint64_t>(), b->num_unique.as<uint32_t>(), ix->h, 1u, shift);
         HIP_TRY(hipGetLastError());
-        TRY(ev_end(ix, &ep, ix->ev_km));
+        TRY(ev_end(ix, &ep, ix->ev_km, k1_stream(ix)));
         k2_rows = b->rows_sorted.as<uint64_t>();
     }
+    TRY(k1_publish(b));
     // K2
     static const int and_block_env = [] { int v = env_int("BIGSI_HIP_AND_BLOCK", 256); return (v >= 64 && v <= 1024 && v % 64 == 0) ? v : 256; }();
     // the counting kernels are compiled for at most 256 threads per workgroup (register budget of the plane arrays)
@@ -900,6 +980,7 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
     if (!b->compacted) {
         HIP_TRY(hipEventRecord(b->done, ix->stream));
         b->ran = true;
+        b->dirty = false;
         return BIGSI_OK;
     }
     // K4 on this shard's own result
@@ -909,6 +990,7 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
     TRY(ev_end(ix, &ep, ix->ev_cp));
     HIP_TRY(hipEventRecord(b->done, ix->stream));
     b->ran = true;
+    b->dirty = false;
     return BIGSI_OK;
 }
 
@@ -1077,9 +1159,29 @@ extern "C" int bigsi_hip_batch_fetch_hits(bigsi_hip_batch *b, uint64_t *hit_offs
     return fetch_hits_from(b, b->hits, src, 1, b->ix->n_cols, hit_offsets, colours, counts, capacity);
 }
 
+// gathered compaction is queued behind the batch's run through its `done` event: no host-side wait, so the caller can go on
+// to launch the next batch while this one's row-AND kernel is still running
+static int gather_begin(bigsi_hip_batch *b, hipStream_t st)
+{
+    if (!b) return fail(BIGSI_ERR_INVALID, "NULL batch");
+    if (!b->ran) return fail(BIGSI_ERR_STATE, "bigsi_hip_batch_run has not completed for this batch");
+    TRY(use_device(b->ix));
+    if (b->done) HIP_TRY(hipStreamWaitEvent(st, b->done, 0));
+    return BIGSI_OK;
+}
+
+static int gather_end(bigsi_hip_batch *b, hipStream_t st)
+{
+    if (!b->g_done) HIP_TRY(hipEventCreateWithFlags(&b->g_done, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(b->g_done, st));
+    return BIGSI_OK;
+}
+
 extern "C" int bigsi_hip_batch_compact_gathered(bigsi_hip_batch *b, const void *d_gathered, uint32_t n_shards, uint64_t shard_cols)
 {
-    TRY(need_run(b));
+    if (!b) return fail(BIGSI_ERR_INVALID, "NULL batch");
+    hipStream_t gst = b->gstream ? b->gstream : b->ix->stream;
+    TRY(gather_begin(b, gst));
     if (!d_gathered || n_shards == 0) return fail(BIGSI_ERR_INVALID, "bad gathered buffer");
     if ((uint64_t)n_shards * shard_cols > 0xFFFFFFFFull) return fail(BIGSI_ERR_INVALID, "more than 2^32-1 colours in total");
     b->g_src = d_gathered;
@@ -1090,13 +1192,15 @@ extern "C" int bigsi_hip_batch_compact_gathered(bigsi_hip_batch *b, const void *
     TRY(ev_begin(b->ix, &ep, b->gstream));
     TRY(compact(b, b->ghits, d_gathered, n_shards, shard_cols, false));
     TRY(ev_end(b->ix, &ep, b->ix->ev_cp, b->gstream));
+    TRY(gather_end(b, gst));
     return BIGSI_OK;
 }
 
 extern "C" int bigsi_hip_batch_compact_gathered_masks(bigsi_hip_batch *b, const void *d_gathered_masks, uint32_t n_shards, uint64_t shard_cols,
                                                       uint32_t own_shard)
 {
-    TRY(need_run(b));
+    if (!b) return fail(BIGSI_ERR_INVALID, "NULL batch");
+    TRY(gather_begin(b, b->gstream ? b->gstream : b->ix->stream));
     if (!d_gathered_masks || n_shards == 0 || own_shard >= n_shards) return fail(BIGSI_ERR_INVALID, "bad gathered buffer / shard");
     if ((uint64_t)n_shards * shard_cols > 0xFFFFFFFFull) return fail(BIGSI_ERR_INVALID, "more than 2^32-1 colours in total");
     if (b->exact) return bigsi_hip_batch_compact_gathered(b, d_gathered_masks, n_shards, shard_cols);
@@ -1112,6 +1216,7 @@ extern "C" int bigsi_hip_batch_compact_gathered_masks(bigsi_hip_batch *b, const 
     const void *counters = b->ext_counts ? b->ext_counts : b->counts.p;
     TRY(compact_ex(b, b->ghits, d_gathered_masks, false, counters, n_shards, shard_cols, false, st, own_shard));
     TRY(ev_end(b->ix, &ep, b->ix->ev_cp, st));
+    TRY(gather_end(b, st));
     return BIGSI_OK;
 }
 
@@ -1243,6 +1348,7 @@ extern "C" int bigsi_hip_lookup(bigsi_hip_index *ix, const char *kmers, uint32_t
     bigsi_hip_batch *b = nullptr;
     TRY(bigsi_hip_batch_create(ix, kmers, off.data(), (uint32_t)u, k, &b));
     int rc = run_kmerize(b, 1.0);
+    if (rc == BIGSI_OK) rc = k1_publish(b);
     const uint64_t wv = ix->wv(), rb = ix->rb();
     if (rc == BIGSI_OK) rc = b->scratch.reserve((size_t)u * wv * 8);
     if (rc == BIGSI_OK) {

@@ -143,7 +143,10 @@ int bigsi_hip_batch_create(bigsi_hip_index *ix, const char *seqs, const uint64_t
                            uint32_t k, bigsi_hip_batch **out);
 int bigsi_hip_batch_destroy(bigsi_hip_batch *b);
 /* Load a different set of sequences into an existing batch object: device buffers are kept and only grow, so a serving
- * loop pays allocation once.  Output / stream settings of the batch are kept; results of earlier runs are discarded. */
+ * loop pays allocation once.  Output / stream settings of the batch are kept; results of earlier runs are discarded.
+ * create and reload copy the sequences on a library-internal upload stream and return when the copy is complete; reload
+ * waits for the earlier work of THIS batch only, so it can be called while another batch's kernels are still running
+ * (two alternating batch objects = upload of one overlaps the row-AND kernel of the other). */
 int bigsi_hip_batch_reload(bigsi_hip_batch *b, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k);
 int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_t flags);
 
@@ -188,8 +191,9 @@ int bigsi_hip_batch_presence(bigsi_hip_batch *b, uint32_t seq, const uint32_t *c
 
 /* Multi-GPU assembly: compact hits from result buffers gathered from n_shards column shards (device pointer,
  * layout [shard][seq][stride] with this batch's strides; colour = shard * shard_cols + local column).
- * compact_gathered is asynchronous on the index's stream (call it after the RCCL all-gather, which the caller
- * issues on the same stream); fetch_gathered_hits synchronises and copies out, same format as fetch_hits. */
+ * compact_gathered* are asynchronous, also for the host: they are queued (on the gather stream, below) behind this batch's
+ * run through an event, never by waiting for it -- call them after the RCCL all-gather, which the caller issues on the
+ * same stream; fetch_gathered_hits synchronises and copies out, same format as fetch_hits. */
 /* Run this batch's gathered compaction (and the copies of fetch_gathered_hits) on a caller-owned hipStream_t -- typically
  * the stream the collective is issued under, so that all-gather + compaction of one batch overlap the row-AND kernels of
  * the next batch on the index's stream.  NULL = the index's stream. */
