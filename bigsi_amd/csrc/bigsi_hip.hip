@@ -85,7 +85,7 @@ struct DevBuf {
 };
 
 struct EventPair {
-    hipEvent_t a, b;
+    hipEvent_t a = nullptr, b = nullptr;
 };
 
 struct bigsi_hip_index {
@@ -99,7 +99,7 @@ struct bigsi_hip_index {
     uint64_t *d_index = nullptr;
     DevBuf stage, stage_ids;
     // profiling
-    bool profiling = false;
+    int profiling = 0;            // 0 off, 1 every kernel group of a run, 2 the row-AND kernel only
     std::vector<EventPair> ev_and, ev_km, ev_cp, ev_free;
     uint64_t wv() const { return ceil_div(n_cols, 64); }
     uint64_t rb() const { return ceil_div(n_cols, 8); }
@@ -476,10 +476,11 @@ extern "C" int bigsi_hip_bloom(int device, const char *kmers, uint64_t u, uint32
 }
 
 // ------------------------------------------------------------------------------ profiling events
-static int ev_begin(bigsi_hip_index *ix, EventPair *p, hipStream_t st = nullptr)
+static int ev_begin(bigsi_hip_index *ix, EventPair *p, hipStream_t st = nullptr, bool row_and = false)
 {
     if (!st) st = ix->stream;
-    if (!ix->profiling) return BIGSI_OK;
+    *p = EventPair{};
+    if (!ix->profiling || (ix->profiling == 2 && !row_and)) return BIGSI_OK;
     if (ix->ev_free.empty()) {
         EventPair n;
         HIP_TRY(hipEventCreate(&n.a));
@@ -494,7 +495,7 @@ static int ev_begin(bigsi_hip_index *ix, EventPair *p, hipStream_t st = nullptr)
 
 static int ev_end(bigsi_hip_index *ix, EventPair *p, std::vector<EventPair> &dst, hipStream_t st = nullptr)
 {
-    if (!ix->profiling) return BIGSI_OK;
+    if (!p->a) return BIGSI_OK;          // not being timed
     if (!st) st = ix->stream;
     HIP_TRY(hipEventRecord(p->b, st));
     dst.push_back(*p);
@@ -504,7 +505,7 @@ static int ev_end(bigsi_hip_index *ix, EventPair *p, std::vector<EventPair> &dst
 extern "C" int bigsi_hip_set_profiling(bigsi_hip_index *ix, int on)
 {
     if (!ix) return fail(BIGSI_ERR_INVALID, "NULL index");
-    ix->profiling = on != 0;
+    ix->profiling = on == 2 ? 2 : (on != 0);
     return BIGSI_OK;
 }
 
@@ -932,7 +933,7 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
         uint64_t *out = (uint64_t *)b->ext_bitmaps;
         if (!out) { TRY(b->bitmaps.reserve((size_t)b->n_seqs * b->wv_pad * 8)); out = b->bitmaps.as<uint64_t>(); }
         if (slices > 1) HIP_TRY(hipMemsetAsync(out, 0xFF, (size_t)b->n_seqs * b->wv_pad * 8, ix->stream));
-        TRY(ev_begin(ix, &ep));
+        TRY(ev_begin(ix, &ep, nullptr, true));
 #define COMMA ,
 #define BIGSI_LAUNCH_EXACT(U)                                                                                                  \
     hipLaunchKernelGGL((k_and_exact<U>), dim3(grid), dim3(and_block), 0, ix->stream, ix->d_index, ix->stride_words, (uint32_t)b->wv, \
@@ -964,7 +965,7 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
             HIP_TRY(hipMemsetAsync(out, 0, (size_t)b->n_seqs * cstride * b->count_bytes, ix->stream));
             b->local_from_counts = true;      // K4 thresholds the summed counters
         }
-        TRY(ev_begin(ix, &ep));
+        TRY(ev_begin(ix, &ep, nullptr, true));
         switch (P) {
         case 6: launch_count_h<6, uint16_t>(b, k2_rows, grid, and_block, tiles, (uint16_t *)out, cstride, hb, sparse, slices); break;
         case 10: launch_count_h<10, uint16_t>(b, k2_rows, grid, and_block, tiles, (uint16_t *)out, cstride, hb, sparse, slices); break;

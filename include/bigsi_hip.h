@@ -220,7 +220,9 @@ typedef struct {
     uint64_t compact_launches;
     double compact_ms;
 } bigsi_hip_stats_t;
-int bigsi_hip_set_profiling(bigsi_hip_index *ix, int on); /* record HIP events around each kernel of batch_run */
+/* record HIP events around the kernels of batch_run: 0 off, 1 around K1 / K2 / K4 each, 2 around the row-AND kernel only
+ * (an event record costs the stream 5-7 us, which matters for batches of short reads) */
+int bigsi_hip_set_profiling(bigsi_hip_index *ix, int on);
 int bigsi_hip_stats(bigsi_hip_index *ix, bigsi_hip_stats_t *out, int reset); /* synchronises */
 
 #ifdef __cplusplus
