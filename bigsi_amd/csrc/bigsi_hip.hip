@@ -793,9 +793,16 @@ static int run_kmerize(bigsi_hip_batch *b, double threshold, bool force_global =
         b->run_h = ix->h;
         return BIGSI_OK;
     }
-    uint32_t tab_cap = 2;
-    while (tab_cap < 2 * b->max_pos && tab_cap < (1u << 30)) tab_cap <<= 1;
-    const size_t lds = (size_t)tab_cap * 4 + 64 + round_up(b->max_len + 16, 16);
+    // dedupe table of the LDS route: 4 slots per position when that fits the LDS window (shorter probe chains), else 2
+    const uint32_t hs_cap = (uint32_t)round_up(std::max<uint64_t>(b->max_pos, 1), 4);
+    uint32_t tab_mult = 4, tab_cap = 2;
+    size_t lds = 0;
+    for (;; tab_mult = 2) {
+        tab_cap = 2;
+        while (tab_cap < tab_mult * b->max_pos && tab_cap < (1u << 30)) tab_cap <<= 1;
+        lds = (size_t)tab_cap * 4 + 64 + (size_t)hs_cap * 4 + round_up(b->max_len + 16, 16);
+        if (lds <= 60 * 1024 || tab_mult == 2) break;
+    }
     // fused single-launch K1 (dedupe table + sequence in LDS) when every query fits the default 64 KiB dynamic-LDS window
     if (!force_global && !k1_global && b->max_pos <= kLdsMaxPos && lds <= 60 * 1024) {
         uint32_t block = 64;
@@ -803,7 +810,7 @@ static int run_kmerize(bigsi_hip_batch *b, double threshold, bool force_global =
         TRY(ev_begin(ix, &ep, ks));
 #define BIGSI_K1_LDS(KF)                                                                                                        \
     hipLaunchKernelGGL((k_kmerize_lds<KF>), dim3(b->n_seqs), dim3(block), lds, ks, b->seqs.as<char>(), b->d_seq_off.as<uint64_t>(), \
-                       b->d_pos_off.as<uint64_t>(), b->k, ix->h, ix->m, threshold, tab_cap, b->first_pos.as<uint32_t>(), b->tmp.as<uint32_t>(), \
+                       b->d_pos_off.as<uint64_t>(), b->k, ix->h, ix->m, threshold, tab_cap, tab_mult, hs_cap, b->first_pos.as<uint32_t>(), b->tmp.as<uint32_t>(), \
                        b->pos_unique.as<uint32_t>(), b->rep.as<uint32_t>(), b->rows.as<uint64_t>(), b->num_kmers.as<uint32_t>(),      \
                        b->num_unique.as<uint32_t>(), b->min_kmers.as<uint32_t>())
         if (b->k == 31) BIGSI_K1_LDS(31);
@@ -902,8 +909,13 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
         uint32_t shift = 0;
         while (((ix->m - 1) >> shift) >= (uint64_t)kSortBuckets) shift++;
         TRY(ev_begin(ix, &ep, k1_stream(ix)));
-        hipLaunchKernelGGL(k_sort_rows, dim3(b->n_seqs), dim3(kBlock), 0, k1_stream(ix), b->rows.as<uint64_t>(), b->rows_sorted.as<uint64_t>(),
-                           b->d_pos_off.as<uint64_t>(), b->num_unique.as<uint32_t>(), ix->h, 1u, shift);
+        // 1024 threads per query for long row lists (a 1 kbp query at h=4 has 3880 rows), 256 otherwise
+        if (b->max_pos * ix->h >= 2048)
+            hipLaunchKernelGGL((k_sort_rows<1024>), dim3(b->n_seqs), dim3(1024), 0, k1_stream(ix), b->rows.as<uint64_t>(), b->rows_sorted.as<uint64_t>(),
+                               b->d_pos_off.as<uint64_t>(), b->num_unique.as<uint32_t>(), ix->h, 1u, shift);
+        else
+            hipLaunchKernelGGL((k_sort_rows<kBlock>), dim3(b->n_seqs), dim3(kBlock), 0, k1_stream(ix), b->rows.as<uint64_t>(), b->rows_sorted.as<uint64_t>(),
+                               b->d_pos_off.as<uint64_t>(), b->num_unique.as<uint32_t>(), ix->h, 1u, shift);
         HIP_TRY(hipGetLastError());
         TRY(ev_end(ix, &ep, ix->ev_km, k1_stream(ix)));
         k2_rows = b->rows_sorted.as<uint64_t>();

@@ -106,10 +106,14 @@ __device__ __forceinline__ uint32_t murmur3_32(const KmerView &v, uint32_t seed)
 // _hash (bigsi/bloom/bloomfilter.py:5-6): signed 32-bit hash, Python floor-mod by m -> row in [0, m)
 __device__ __forceinline__ uint64_t row_of_hash(uint32_t h, uint64_t m)
 {
-    int64_t sh = (int64_t)(int32_t)h;
-    if (sh >= 0) return (uint64_t)sh % m;
-    uint64_t a = (uint64_t)(-sh) % m;
-    return a == 0 ? 0 : m - a;
+    const int32_t sh = (int32_t)h;
+    const uint32_t mag = sh >= 0 ? (uint32_t)sh : 0u - (uint32_t)sh;      // |hash| <= 2^31 fits 32 bits
+    if (m <= 0xFFFFFFFFull) {                                              // (wave-uniform) 32-bit division: ~4x cheaper than 64-bit
+        const uint32_t a = mag % (uint32_t)m;
+        return sh >= 0 || a == 0 ? (uint64_t)a : m - a;
+    }
+    const uint64_t a = (uint64_t)mag % m;
+    return sh >= 0 || a == 0 ? a : m - a;
 }
 
 // block-wide exclusive scan of one uint32 per thread (blockDim.x a multiple of 64, up to 1024); returns prefix,
@@ -362,33 +366,41 @@ __device__ __forceinline__ uint32_t dedupe_hash(const char *km, uint32_t k)
 template <int KF>
 __global__ __launch_bounds__(1024) void k_kmerize_lds(
     const char *__restrict__ seqs, const uint64_t *__restrict__ seq_off, const uint64_t *__restrict__ pos_off,
-    uint32_t k, uint32_t h, uint64_t m, double threshold, uint32_t tab_cap, uint32_t *__restrict__ first_pos,
+    uint32_t k, uint32_t h, uint64_t m, double threshold, uint32_t tab_cap, uint32_t tab_mult, uint32_t hs_cap, uint32_t *__restrict__ first_pos,
     uint32_t *__restrict__ uidx, uint32_t *__restrict__ pos_unique, uint32_t *__restrict__ rep_out, uint64_t *__restrict__ rows,
     uint32_t *__restrict__ num_kmers, uint32_t *__restrict__ num_unique, uint32_t *__restrict__ min_kmers)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
     uint32_t *scan = tab + tab_cap;                      // 16 entries
-    char *sq = reinterpret_cast<char *>(scan + 16);      // the query's bytes
+    uint32_t *hs = scan + 16;                            // hs[i]: 32-bit hash of the k-mer at position i (hs_cap entries)
+    char *sq = reinterpret_cast<char *>(hs + hs_cap);    // the query's bytes
     const uint32_t q = blockIdx.x;
     const char *s = seqs + seq_off[q];
     const uint32_t len = (uint32_t)(seq_off[q + 1] - seq_off[q]);
     const uint32_t n = len >= k ? len - k + 1 : 0u;
     const uint64_t P = pos_off[q];
     uint32_t tsize = 2;
-    while (tsize < 2 * n) tsize <<= 1;
+    while (tsize < tab_mult * n) tsize <<= 1;            // load factor <= 1/tab_mult: short probe chains
     const uint32_t mask = tsize - 1;
     for (uint32_t i = threadIdx.x; i < tsize; i += blockDim.x) tab[i] = kEmpty;
     for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) sq[i] = s[i];
     __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) hs[i] = dedupe_hash<KF>(sq + i, k);
+    __syncthreads();
+    // two positions hold the same k-mer iff their bytes are equal; the stored hashes settle almost every comparison with
+    // one LDS word instead of a divergent byte loop
+    uint32_t my_slot = 0;                                // where this thread's FIRST position ended up
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        uint32_t slot = dedupe_hash<KF>(sq + i, k) & mask;
+        const uint32_t hv = hs[i];
+        uint32_t slot = hv & mask;
         for (;;) {
             const uint32_t cur = atomicCAS(&tab[slot], kEmpty, i);
             if (cur == kEmpty) break;
-            if (kmer_equal(sq + cur, sq + i, k)) { atomicMin(&tab[slot], i); break; }
+            if (hs[cur] == hv && kmer_equal(sq + cur, sq + i, k)) { atomicMin(&tab[slot], i); break; }
             slot = (slot + 1) & mask;
         }
+        if (i == threadIdx.x) my_slot = slot;
     }
     __syncthreads();
     uint32_t *fp = first_pos + P, *ux = uidx + P, *pu = pos_unique + P, *rp = rep_out + P;
@@ -397,13 +409,18 @@ __global__ __launch_bounds__(1024) void k_kmerize_lds(
     for (uint32_t base = 0; base < n; base += blockDim.x) {
         const uint32_t i = base + threadIdx.x;
         uint32_t c = kEmpty;
-        if (i < n) {
-            uint32_t slot = dedupe_hash<KF>(sq + i, k) & mask;
+        if (i < n && base == 0) {
+            c = tab[my_slot];           // the slot holds the smallest position with this k-mer once all inserts are done
+        } else if (i < n) {
+            const uint32_t hv = hs[i];
+            uint32_t slot = hv & mask;
             for (;;) {
                 c = tab[slot];
-                if (c == i || kmer_equal(sq + c, sq + i, k)) break;
+                if (c == i || (hs[c] == hv && kmer_equal(sq + c, sq + i, k))) break;
                 slot = (slot + 1) & mask;
             }
+        }
+        if (i < n) {
             rp[i] = c;
         }
         const uint32_t flag = (i < n && c == i) ? 1u : 0u;
@@ -502,34 +519,36 @@ __global__ __launch_bounds__(kBlock) void k_kmerize_wave(
 // `group` = h keeps each k-mer's h rows together and sorts k-mers by their first row (counting path).
 // The order inside a bucket depends on atomics; the results of K2 do not.
 constexpr int kSortBuckets = 8192;
-__global__ __launch_bounds__(kBlock) void k_sort_rows(
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_sort_rows(
     const uint64_t *__restrict__ rows, uint64_t *__restrict__ sorted, const uint64_t *__restrict__ pos_off,
     const uint32_t *__restrict__ num_unique, uint32_t h, uint32_t group, uint32_t shift)
 {
     __shared__ uint32_t hist[kSortBuckets];
     __shared__ uint32_t lds[16];
+    constexpr int kPer = kSortBuckets / BLOCK;      // consecutive buckets scanned by one thread
     const uint32_t q = blockIdx.x;
     const uint64_t n_items = (uint64_t)num_unique[q] * h / group;
     const uint64_t *src = rows + pos_off[q] * h;
     uint64_t *dst = sorted + pos_off[q] * h;
-    for (uint32_t i = threadIdx.x; i < kSortBuckets; i += kBlock) hist[i] = 0;
+    for (uint32_t i = threadIdx.x; i < kSortBuckets; i += BLOCK) hist[i] = 0;
     __syncthreads();
-    for (uint64_t i = threadIdx.x; i < n_items; i += kBlock) {
+    for (uint64_t i = threadIdx.x; i < n_items; i += BLOCK) {
         const uint64_t b = src[i * group] >> shift;
         atomicAdd(&hist[b < kSortBuckets ? b : kSortBuckets - 1], 1u);
     }
     __syncthreads();
-    {   // exclusive scan of the histogram, 4 consecutive buckets per thread
-        uint32_t v[kSortBuckets / kBlock], sum = 0;
+    {   // exclusive scan of the histogram
+        uint32_t v[kPer], sum = 0;
 #pragma unroll
-        for (int j = 0; j < kSortBuckets / kBlock; j++) { v[j] = hist[threadIdx.x * (kSortBuckets / kBlock) + j]; sum += v[j]; }
+        for (int j = 0; j < kPer; j++) { v[j] = hist[threadIdx.x * kPer + j]; sum += v[j]; }
         uint32_t tot;
         uint32_t run = block_exclusive_scan(sum, &tot, lds);
 #pragma unroll
-        for (int j = 0; j < kSortBuckets / kBlock; j++) { hist[threadIdx.x * (kSortBuckets / kBlock) + j] = run; run += v[j]; }
+        for (int j = 0; j < kPer; j++) { hist[threadIdx.x * kPer + j] = run; run += v[j]; }
     }
     __syncthreads();
-    for (uint64_t i = threadIdx.x; i < n_items; i += kBlock) {
+    for (uint64_t i = threadIdx.x; i < n_items; i += BLOCK) {
         const uint64_t b = src[i * group] >> shift;
         const uint32_t pos = atomicAdd(&hist[b < kSortBuckets ? b : kSortBuckets - 1], 1u);
         for (uint32_t s = 0; s < group; s++) dst[(uint64_t)pos * group + s] = src[i * group + s];
