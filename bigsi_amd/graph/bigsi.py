@@ -6,7 +6,6 @@ per-sample counts, threshold, compaction -- is ONE device batch (include/bigsi_h
 only assembles result dicts (names, percentages, optional score)."""
 import json
 import logging
-import math
 
 import numpy as np
 

@@ -1,6 +1,6 @@
 """Soak: thousands of runs, reloads and batch create/destroy cycles on one index; device memory must return to its
 starting level (no leaks) and results must stay identical."""
-import os, subprocess, sys
+import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bigsi_amd.storage import get_storage

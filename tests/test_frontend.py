@@ -6,7 +6,7 @@ import json
 
 import pytest
 
-from conftest import load_golden, unjson
+from conftest import load_golden
 
 
 def _golden_results(g):
