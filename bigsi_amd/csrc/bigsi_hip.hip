@@ -91,8 +91,8 @@ struct EventPair {
 struct bigsi_hip_index {
     int device = 0;
     hipStream_t stream = nullptr, own_stream = nullptr;
-    // query upload + K1 (+ row sort) of a batch run here, so that they overlap the row-AND kernel of the batch before it;
-    // `stream` (possibly the caller's) joins through the batch's k1_done event before K2
+    // the sequences of a batch are uploaded here, so that loading one batch does not wait for the kernels of another
+    // (and, with BIGSI_HIP_K1_OVERLAP=1 only, K1 and the row sort run here too: see k1_stream)
     hipStream_t pre_stream = nullptr;
     uint64_t m = 0, n_cols = 0, cap_cols = 0, stride_words = 0;
     uint32_t h = 0;
@@ -140,8 +140,7 @@ extern "C" int bigsi_hip_open(uint64_t num_rows, uint64_t num_cols, uint64_t col
     if (e != hipSuccess) { delete ix; return fail(BIGSI_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     ix->stream = ix->own_stream;
     {
-        // lowest priority: when the row-AND kernel of one batch and K1 of the next are both ready, the row-AND kernel's
-        // workgroups are placed first (all of them have to be resident together, see k_and_exact) and K1 fills the gaps
+        // lowest priority: whatever runs here must not delay the workgroups of a row-AND kernel on the index stream
         int least = 0, greatest = 0;
         e = hipDeviceGetStreamPriorityRange(&least, &greatest);
         static const int pre_prio = env_int("BIGSI_HIP_PRE_PRIORITY", 1);
@@ -568,7 +567,7 @@ struct bigsi_hip_batch {
     uint32_t run_h = 0;            // num_hashes the row ids of the last K1 were produced with
     hipEvent_t done = nullptr;     // recorded at the end of every run: fetches wait on it, not on the whole stream, so the
                                    // results of one batch can be read while the next batch's kernels are queued behind it
-    hipEvent_t k1_done = nullptr;  // recorded on the index's pre_stream after K1 (+ row sort); the main stream waits on it before K2
+    hipEvent_t k1_done = nullptr;  // only when K1 runs on the pre stream: recorded after K1 (+ row sort), the index stream waits on it before K2
     hipEvent_t g_done = nullptr;   // recorded on the gather stream after a gathered compaction (it reads K1's per-query arrays)
     bool dirty = false;            // a run was started and its `done` event has not been recorded (error path): full syncs needed
     hipStream_t gstream = nullptr; // stream of the gathered compaction (null: the index's stream)
@@ -892,7 +891,7 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
     b->wv = ix->wv();
     b->wv_pad = round_up(b->wv, 2);
 
-    // K1 (on the pre stream)
+    // K1
     EventPair ep{};
     TRY(run_kmerize(b, threshold, (flags & BIGSI_RUN_K1_GLOBAL) != 0));
     b->dirty = true;        // until `done` is recorded at the end
