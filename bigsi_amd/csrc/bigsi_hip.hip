@@ -272,6 +272,7 @@ extern "C" int bigsi_hip_synchronize(bigsi_hip_index *ix)
 
 // ------------------------------------------------------------------------------ storage contract
 static const uint64_t kStageBytes = 64ull << 20;
+static const uint64_t kInlineScanMax = 4096;     // K4 chunks up to which the write pass does its own prefix sum (compact_ex)
 
 extern "C" int bigsi_hip_set_rows(bigsi_hip_index *ix, const uint64_t *row_ids, uint64_t n, const uint8_t *bytes, uint64_t row_bytes)
 {
@@ -1027,6 +1028,9 @@ static int compact_ex(bigsi_hip_batch *b, HitBufs &hb, const void *src, bool fro
         hb.cap = want;
     }
     const unsigned grid = (unsigned)nchunks;
+    // bit-vector inputs with few chunks: no scan launch, the write pass sums the chunk totals before it itself (kInlineScanMax
+    // x 4 bytes read per workgroup, out of L2)
+    uint64_t *inline_off = (!from_counts && nchunks <= kInlineScanMax) ? hb.hit_off.as<uint64_t>() : nullptr;
     HIP_TRY(hipMemsetAsync(hb.overflow.p, 0, 4, st));
 #define BIGSI_HITS_COMMON                                                                                                        \
     b->n_seqs, n_shards, chunks, shard_cols, from_counts ? b->min_kmers.as<uint32_t>() : b->num_unique.as<uint32_t>(),          \
@@ -1036,10 +1040,10 @@ static int compact_ex(bigsi_hip_batch *b, HitBufs &hb, const void *src, bool fro
             const uint64_t *bm = (const uint64_t *)src;
             if (pass == 0)
                 hipLaunchKernelGGL((k_hits_exact<false>), dim3(grid), dim3(kBlock), 0, st, bm, b->wv_pad, (uint32_t)b->wv, BIGSI_HITS_COMMON,
-                                   counters, b->count_bytes, b->wv_pad * 64, own_shard);
+                                   counters, b->count_bytes, b->wv_pad * 64, own_shard, (uint64_t *)nullptr);
             else
                 hipLaunchKernelGGL((k_hits_exact<true>), dim3(grid), dim3(kBlock), 0, st, bm, b->wv_pad, (uint32_t)b->wv, BIGSI_HITS_COMMON,
-                                   counters, b->count_bytes, b->wv_pad * 64, own_shard);
+                                   counters, b->count_bytes, b->wv_pad * 64, own_shard, inline_off);
         } else if (b->count_bytes == 2) {
             const uint16_t *c16 = (const uint16_t *)src;
             if (pass == 0) hipLaunchKernelGGL((k_hits_count<uint16_t, false>), dim3(grid), dim3(kBlock), 0, st, c16, b->wv_pad * 64, (uint32_t)b->wv, BIGSI_HITS_COMMON);
@@ -1050,7 +1054,7 @@ static int compact_ex(bigsi_hip_batch *b, HitBufs &hb, const void *src, bool fro
             else hipLaunchKernelGGL((k_hits_count<uint32_t, true>), dim3(grid), dim3(kBlock), 0, st, c32, b->wv_pad * 64, (uint32_t)b->wv, BIGSI_HITS_COMMON);
         }
         HIP_TRY(hipGetLastError());
-        if (pass == 0) {
+        if (pass == 0 && !inline_off) {
             hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(kBlock), 0, st, hb.chunk_hits.as<uint32_t>(), nchunks, (uint32_t)per_seq,
                                b->n_seqs, hb.chunk_off.as<uint64_t>(), hb.hit_off.as<uint64_t>());
             HIP_TRY(hipGetLastError());

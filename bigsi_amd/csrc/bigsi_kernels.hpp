@@ -799,7 +799,9 @@ __global__ __launch_bounds__(kBlock) void k_hits_exact(
     uint32_t *__restrict__ hit_col, uint32_t *__restrict__ hit_cnt, uint64_t capacity, uint32_t *__restrict__ overflow,
     const void *__restrict__ counters /* null: every hit's count is num_unique[q] */, uint32_t counter_bytes, uint64_t counter_stride,
     uint32_t own_shard /* kAllShards: counters cover every shard ([shard][seq][stride]); else they are THIS rank's ([seq][stride])
-                          and hits of other shards get count 0 (the caller sums the arrays of all ranks) */)
+                          and hits of other shards get count 0 (the caller sums the arrays of all ranks) */,
+    uint64_t *__restrict__ inline_hit_off /* write pass only; non-null: there was no k_scan_chunks launch -- every workgroup sums
+                          the chunk totals before its own (a few thousand at most, see compact_ex) and hit_off is written here */)
 {
     __shared__ uint32_t lds[16];
     const uint32_t chunk = blockIdx.x % chunks, sq = blockIdx.x / chunks;
@@ -815,8 +817,22 @@ __global__ __launch_bounds__(kBlock) void k_hits_exact(
         if (threadIdx.x == 0) chunk_hits[ci] = tot;
         return;
     }
+    uint64_t base;
+    if (inline_hit_off) {
+        uint32_t part = 0, before;
+        for (uint64_t i = threadIdx.x; i < ci; i += kBlock) part += chunk_hits[i];
+        block_exclusive_scan(part, &before, lds);
+        base = before;
+        const uint64_t per_seq = (uint64_t)n_shards * chunks;
+        if (threadIdx.x == 0) {
+            if (ci % per_seq == 0) inline_hit_off[q] = base;
+            if (ci + 1 == per_seq * n_seqs) inline_hit_off[n_seqs] = base + tot;
+        }
+    } else {
+        base = chunk_off[ci];
+    }
     if (mine == 0) return;
-    uint64_t o = chunk_off[ci] + pre;
+    uint64_t o = base + pre;
     if (o + mine > capacity) { *overflow = 1; return; }
     const uint32_t uq = num_unique[q];
     const uint64_t cbase = (uint64_t)shard * shard_cols + (uint64_t)w * 64;
