@@ -756,7 +756,7 @@ static hipStream_t k1_stream(const bigsi_hip_index *ix)
 }
 
 // K1 for the whole batch (h may have changed since create: the rows buffer is sized for it here)
-static int run_kmerize(bigsi_hip_batch *b, double threshold, bool force_global = false)
+static int run_kmerize(bigsi_hip_batch *b, double threshold, bool force_global = false, bool want_sorted = false, bool *sorted = nullptr)
 {
     bigsi_hip_index *ix = b->ix;
     EventPair ep{};
@@ -807,12 +807,16 @@ static int run_kmerize(bigsi_hip_batch *b, double threshold, bool force_global =
     if (!force_global && !k1_global && b->max_pos <= kLdsMaxPos && lds <= 60 * 1024) {
         uint32_t block = 64;
         while (block < b->max_pos && block < 1024) block <<= 1;
+        if (want_sorted) {
+            TRY(b->rows_sorted.reserve(std::max<uint64_t>(b->total_pos, 1) * ix->h * 8));
+            if (sorted) *sorted = true;
+        }
         TRY(ev_begin(ix, &ep, ks));
 #define BIGSI_K1_LDS(KF)                                                                                                        \
     hipLaunchKernelGGL((k_kmerize_lds<KF>), dim3(b->n_seqs), dim3(block), lds, ks, b->seqs.as<char>(), b->d_seq_off.as<uint64_t>(), \
                        b->d_pos_off.as<uint64_t>(), b->k, ix->h, ix->m, threshold, tab_cap, tab_mult, hs_cap, b->first_pos.as<uint32_t>(), b->tmp.as<uint32_t>(), \
                        b->pos_unique.as<uint32_t>(), b->rep.as<uint32_t>(), b->rows.as<uint64_t>(), b->num_kmers.as<uint32_t>(),      \
-                       b->num_unique.as<uint32_t>(), b->min_kmers.as<uint32_t>())
+                       b->num_unique.as<uint32_t>(), b->min_kmers.as<uint32_t>(), want_sorted ? b->rows_sorted.as<uint64_t>() : (uint64_t *)nullptr)
         if (b->k == 31) BIGSI_K1_LDS(31);
         else BIGSI_K1_LDS(0);
 #undef BIGSI_K1_LDS
@@ -892,19 +896,20 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
     b->wv = ix->wv();
     b->wv_pad = round_up(b->wv, 2);
 
-    // K1
-    EventPair ep{};
-    TRY(run_kmerize(b, threshold, (flags & BIGSI_RUN_K1_GLOBAL) != 0));
-    b->dirty = true;        // until `done` is recorded at the end
-
     // K1e: address-ordered copy of the row lists for K2 (BIGSI_HIP_SORT_ROWS=0 streams them in hash order instead)
     static const int sort_rows = env_int("BIGSI_HIP_SORT_ROWS", 1);
-    const uint64_t *k2_rows = b->rows.as<uint64_t>();
+    const bool want_sorted = sort_rows && b->exact && !(flags & BIGSI_RUN_NO_SORT) && b->total_pos && b->max_pos * ix->h >= 1024;
+    // K1 (its LDS route emits the sorted list itself; the other routes leave that to k_sort_rows below)
+    EventPair ep{};
+    bool sorted_by_k1 = false;
+    TRY(run_kmerize(b, threshold, (flags & BIGSI_RUN_K1_GLOBAL) != 0, want_sorted, &sorted_by_k1));
+    b->dirty = true;        // until `done` is recorded at the end
+    const uint64_t *k2_rows = sorted_by_k1 ? b->rows_sorted.as<uint64_t>() : b->rows.as<uint64_t>();
     // exact path only: there every row can move freely (+4.7 % C3, +7.6 % C4-shard, interleaved A/B); on the counting path a
     // k-mer's h rows must stay together and ordering k-mers by their first row measured 1.00x
     // and only for long row lists (>= 1024 rows per query): for read-length queries (C2: 93 rows) the extra launch costs more
     // than the ordering gains (0.100 vs 0.083 ms per step measured)
-    if (sort_rows && b->exact && !(flags & BIGSI_RUN_NO_SORT) && b->total_pos && b->max_pos * ix->h >= 1024) {
+    if (want_sorted && !sorted_by_k1) {
         TRY(b->rows_sorted.reserve(std::max<uint64_t>(b->total_pos, 1) * ix->h * 8));
         uint32_t shift = 0;
         while (((ix->m - 1) >> shift) >= (uint64_t)kSortBuckets) shift++;

@@ -368,7 +368,8 @@ __global__ __launch_bounds__(1024) void k_kmerize_lds(
     const char *__restrict__ seqs, const uint64_t *__restrict__ seq_off, const uint64_t *__restrict__ pos_off,
     uint32_t k, uint32_t h, uint64_t m, double threshold, uint32_t tab_cap, uint32_t tab_mult, uint32_t hs_cap, uint32_t *__restrict__ first_pos,
     uint32_t *__restrict__ uidx, uint32_t *__restrict__ pos_unique, uint32_t *__restrict__ rep_out, uint64_t *__restrict__ rows,
-    uint32_t *__restrict__ num_kmers, uint32_t *__restrict__ num_unique, uint32_t *__restrict__ min_kmers)
+    uint32_t *__restrict__ num_kmers, uint32_t *__restrict__ num_unique, uint32_t *__restrict__ min_kmers,
+    uint64_t *__restrict__ rows_sorted /* non-null: also emit the query's row list in address order (what k_sort_rows does) */)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
@@ -445,6 +446,32 @@ __global__ __launch_bounds__(1024) void k_kmerize_lds(
         u += tot;
     }
     __syncthreads();
+    if (rows_sorted) {
+        // K1e fused: counting sort of the u*h row ids by their top bits, the dedupe table's LDS reused as the histogram
+        // (tsize >= 2n buckets: about one row per bucket at h <= 4).  Order inside a bucket depends on atomics; K2's result does not.
+        uint32_t shift = 0;
+        while (((m - 1) >> shift) >= (uint64_t)tsize) shift++;
+        const uint32_t R = u * h;
+        uint64_t *qsorted = rows_sorted + P * h;
+        for (uint32_t i = threadIdx.x; i < tsize; i += blockDim.x) tab[i] = 0;
+        __syncthreads();
+        for (uint32_t r = threadIdx.x; r < R; r += blockDim.x) atomicAdd(&tab[qrows[r] >> shift], 1u);
+        __syncthreads();
+        const uint32_t per = (tsize + blockDim.x - 1) / blockDim.x, b0 = threadIdx.x * per;
+        uint32_t sum = 0, tot;
+        for (uint32_t j = 0; j < per; j++) sum += b0 + j < tsize ? tab[b0 + j] : 0u;
+        uint32_t run = block_exclusive_scan(sum, &tot, scan);
+        for (uint32_t j = 0; j < per && b0 + j < tsize; j++) {
+            const uint32_t v = tab[b0 + j];
+            tab[b0 + j] = run;
+            run += v;
+        }
+        __syncthreads();
+        for (uint32_t r = threadIdx.x; r < R; r += blockDim.x) {
+            const uint64_t row = qrows[r];
+            qsorted[atomicAdd(&tab[row >> shift], 1u)] = row;
+        }
+    }
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) pu[i] = ux[rp[i]];
     if (threadIdx.x == 0) {
         num_kmers[q] = n;
