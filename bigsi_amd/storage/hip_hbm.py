@@ -319,6 +319,22 @@ class HipHbmStorage(BaseStorage):
     def new_batch(self, seqs, k):
         return QueryBatch(self, seqs, k)
 
+    def search_batch(self, seqs, k, threshold=1.0):
+        """The fused query path in one call, the shape INTEGRATION.md binds into the reference's BIGSI.search: for every
+        sequence (num_kmers, num_unique_kmers, colours, counts) with colours ascending (exact: counts == num_unique;
+        thresholded: every colour with count >= ceil(num_unique * threshold), graph/bigsi.py:179,241-242).  Names,
+        ordering by count, percentages and scores stay with the caller."""
+        assert threshold <= 1                                   # graph/bigsi.py:176
+        batch = QueryBatch(self, list(seqs), k)
+        try:
+            batch.run(threshold, sparse_counts=True)
+            nk, nu, _ = batch.unique()
+            off, col, cnt = batch.hits()
+            return [(int(nk[i]), int(nu[i]), col[int(off[i]):int(off[i + 1])].copy(), cnt[int(off[i]):int(off[i + 1])].copy())
+                    for i in range(batch.n)]
+        finally:
+            batch.close()
+
 
 class QueryBatch(object):
     """A batch of query sequences staged on the device (bigsi_hip_batch)."""

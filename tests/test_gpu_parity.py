@@ -1043,3 +1043,26 @@ def test_fuzz_api_vs_oracle_model(hip, seed):
             assert {x: v.to01() for x, v in lk.items()} == want_lk
     finally:
         b.delete()
+
+
+def test_storage_search_batch_entry_point(hip):
+    """HipHbmStorage.search_batch -- the one call INTEGRATION.md dispatches BIGSI.search to -- against the G7 goldens."""
+    import bigsi_amd
+    g = load_golden("g7_random.json")
+    c = cfg(g["k"], g["m"], g["h"])
+    b = bigsi_amd.BIGSI.build_from_sequences(c, {nm: list(s) for nm, s in zip(g["sample_names"], g["sample_seqs"])})
+    try:
+        names = g["sample_names"]
+        for thr in (1.0, 0.4):
+            cases = [s for s in g["searches"] if s["threshold"] == thr and not s["score"] and "results" in s["out"]]
+            got = b.storage.search_batch([g["queries"][s["q"]] for s in cases], g["k"], thr)
+            for s, (nk, nu, col, cnt) in zip(cases, got):
+                want = s["out"]["results"]
+                assert sorted(names[int(x)] for x in col) == sorted(r["sample_name"] for r in want), (s["q"], thr)
+                by_name = {r["sample_name"]: r for r in want}
+                assert list(col) == sorted(col)
+                for x, f in zip(col, cnt):
+                    r = by_name[names[int(x)]]
+                    assert (int(f), nu) == (r["num_kmers_found"], r["num_kmers"])
+    finally:
+        b.delete()
