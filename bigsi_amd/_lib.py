@@ -147,6 +147,18 @@ def ptr(a):
 def pack_seqs(seqs):
     """list of str/bytes -> (blob bytes, uint64 offsets[n+1]).  Sequences must be ASCII: the reference hashes the
     UTF-8 bytes of k *characters* (mmh3.hash(str)); for ASCII that is k bytes, which is what the kernels window."""
+    if not isinstance(seqs, (list, tuple)):
+        seqs = list(seqs)
+    if seqs and all(type(s) is str for s in seqs):
+        # fast path (bulk reads): one join + one encode; for ASCII text the character lengths are the byte lengths
+        text = "".join(seqs)
+        try:
+            blob = text.encode("ascii")
+        except UnicodeEncodeError:
+            raise ValueError("query sequences must be ASCII for the hip-hbm backend")
+        off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum(np.fromiter(map(len, seqs), dtype=np.uint64, count=len(seqs)))
+        return blob, off
     enc = []
     for s in seqs:
         if isinstance(s, str):

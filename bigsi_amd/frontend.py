@@ -63,7 +63,7 @@ def bulk_search(bigsi, fasta, threshold=1.0, score=False, format="json", stream=
     per line as the reference's streaming branch does and returns None."""
     seqs = [s for _, s in read_fasta(fasta)]
     if hasattr(bigsi, "search_stream"):       # device batches of `batch_size`, host assembly overlapped with the next batch
-        size = getattr(bigsi, "config", {}).get("batch_size")          # default: batches of ~262k k-mers
+        size = getattr(bigsi, "config", {}).get("batch_size")          # default: batches of ~524k k-mers
         dd = [search_record(s, threshold, r) for s, r in bigsi.search_stream(seqs, threshold, score, batch_size=size)]
     else:
         results = bigsi.search_batch(seqs, threshold, score) if seqs else []
