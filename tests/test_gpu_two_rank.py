@@ -31,6 +31,22 @@ def test_bench_two_ranks_on_one_gpu(threshold):
 
 
 @pytest.mark.gpu
+def test_bench_eight_ranks_on_one_gpu():
+    """world_size 8 (the node the scaling bench runs on) squeezed onto the one GPU of the test box: eight gather slots, colour
+    offsets of eight shards, the count all-reduce over eight ranks, planted hits found on every shard."""
+    env = dict(os.environ, BIGSI_BENCH_DEVICE="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", "29543", os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "1", "--rows", "200000",
+           "--cols", "10000", "--backend", "gloo", "--threshold", "0.4", "--cpu-seconds", "0"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 8 and d["config"]["total_cols"] == 80000
+    assert d["config"]["hits_last_step"] == 24                     # 3 planted queries x 8 shards
+    assert "8 shard(s)" in d["config"]["verified"]
+
+
+@pytest.mark.gpu
 def test_sharded_bigsi_equals_whole_index(tmp_path):
     """ShardedBIGSI over two uneven shards (103 + 97 samples, two processes) must return, query for query, what the
     reference returned on the WHOLE 200-sample index (G7 goldens): names, counts, order, percentages and -- for score=True --
