@@ -1,22 +1,37 @@
 #!/usr/bin/env python
 """bench.py -- BIGSI query hot path on MI355X: k-mer lookups/s and achieved HBM GB/s of the row-fetch-AND kernel.
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload c3|c2|c4|c5|northstar] [--threshold T]
 
-A "step" is one pass of the whole device path (K1 k-merise/dedupe/hash -> K2 row fetch + AND -> K4 threshold +
-compaction [-> RCCL all-gather of per-sample result vectors + compaction of the gathered result when N > 1]) over one
-batch of synthetic queries that is already resident in HBM.  Default workload = BASELINE.json configs[2], the largest
-single-GPU configuration: synthetic 10M-row x 100k-sample index (125 GB), h=4, 256 x 1 kbp queries, threshold 1.0.
-Scaling is WEAK: every rank holds a 10M x 100k column shard (index = 10M x N*100k samples) and looks every query up
-in its shard; `value` sums the k-mer lookups all ranks performed (each against its own shard) per second, and
-config.kmer_lookups_per_s_full_index gives the rate against the whole N-shard index.
-Prints ONE JSON line on rank 0.
+With N > 1 and no launcher environment the script starts its own N ranks (one process per GPU, RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* set for them); under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` it is
+one of the launcher's ranks.  Either way rank 0 prints ONE JSON line.
+
+A "step" is one pass of the whole device path over one batch of synthetic queries that is already resident in HBM:
+K1 k-merise/dedupe/hash -> K2 row fetch + AND (or bit-sliced counting) -> K4 threshold + compaction, and for N > 1 the RCCL
+all-gather of the per-sample result vectors, the compaction of the gathered result and (thresholded searches) the all-reduce
+of the per-hit counts, issued by libbigsi_hip.so on its own communicator.
+
+Workloads are BASELINE.json's configurations; each names a WHOLE index, which is split by column range over the N GPUs
+(strong scaling: total work fixed).  `value` = unique query k-mers looked up in the WHOLE index per second of wall time,
+exchange included -- every rank looks every k-mer up in its shard, so the shard-level lookups/s summed over ranks
+(config.shard_lookups_per_s_sum) is N times that and is NOT the headline.
+    c3 (default)  BASELINE configs[2]: 10M rows x 100k samples (125 GB), h=4, 8192 x 1 kbp queries, threshold 1.0
+    c2            BASELINE configs[1]: 1M x 10k, h=3, 1000 x 61-mers, a different batch every step (32 staged batches cycle)
+    c4            BASELINE configs[3]: 25M x 500k, h=3 (1.56 TB: needs 8 GPUs), 256 x 1 kbp queries per step
+    c5            BASELINE configs[4]: c4 at threshold 0.4 with score=True presence extraction for the hits
+    northstar     BASELINE north_star: 10M x 500k, h=3 (625 GB: needs >= 4 GPUs)
+`--shard-of P` runs, on fewer GPUs, the first N of the P column shards of the workload (e.g. `--workload c4 --shard-of 8
+--gpus 1` is what one GPU of the 8-GPU C4 run does; value is then the rate against that part of the index and says so).
+`--scaling weak` instead gives every GPU the workload's whole shape (index = N x the columns).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -25,7 +40,22 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+HBM_BYTES = 288e9            # per GPU (spec); an index shard may take at most FIT_FRACTION of it
+FIT_FRACTION = 0.93
 SEED = 20260928
+
+WORKLOADS = {
+    "c2": dict(rows=1_000_000, cols=10_000, hashes=3, batch=1000, qlen=61, threshold=1.0, distinct=32, score=False,
+               name="BASELINE configs[1]"),
+    "c3": dict(rows=10_000_000, cols=100_000, hashes=4, batch=8192, qlen=1000, threshold=1.0, distinct=2, score=False,
+               name="BASELINE configs[2]"),
+    "c4": dict(rows=25_000_000, cols=500_000, hashes=3, batch=256, qlen=1000, threshold=1.0, distinct=2, score=False,
+               name="BASELINE configs[3]"),
+    "c5": dict(rows=25_000_000, cols=500_000, hashes=3, batch=256, qlen=1000, threshold=0.4, distinct=2, score=True,
+               name="BASELINE configs[4]"),
+    "northstar": dict(rows=10_000_000, cols=500_000, hashes=3, batch=256, qlen=1000, threshold=1.0, distinct=2, score=False,
+                      name="BASELINE north_star shape"),
+}
 
 
 def parse():
@@ -33,67 +63,149 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--rows", type=int, default=10_000_000)
-    p.add_argument("--cols", type=int, default=100_000, help="sample columns PER GPU shard")
-    p.add_argument("--hashes", type=int, default=4)
-    p.add_argument("--batch", type=int, default=256)
-    p.add_argument("--qlen", type=int, default=1000)
+    p.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    p.add_argument("--scaling", default="strong", choices=["strong", "weak"])
+    p.add_argument("--shard-of", type=int, default=0, help="hold the first --gpus of this many column shards of the workload")
+    # overrides of the workload's shape (ad-hoc runs, tests)
+    p.add_argument("--rows", type=int)
+    p.add_argument("--cols", type=int, help="sample columns of the WHOLE index (strong) / per GPU (weak)")
+    p.add_argument("--hashes", type=int)
+    p.add_argument("--batch", type=int)
+    p.add_argument("--qlen", type=int)
+    p.add_argument("--threshold", type=float)
+    p.add_argument("--distinct-batches", type=int, help="staged query batches the steps cycle through")
+    p.add_argument("--score", type=int, choices=[0, 1])
     p.add_argument("--k", type=int, default=31)
-    p.add_argument("--threshold", type=float, default=1.0)
     p.add_argument("--and-draws", type=int, default=2, help="bit density of the synthetic index = 2^-draws")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample (0 = skip)")
     p.add_argument("--cpu-rows", type=int, default=200_000)
     p.add_argument("--no-verify", action="store_true")
-    p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU dry runs)")
+    p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for several ranks on one GPU)")
+    p.add_argument("--one-device", action="store_true", help="every rank uses device 0 (dry runs of the N>1 path on a 1-GPU box; needs --backend gloo)")
     p.add_argument("--force-dist", action="store_true",
-                   help="initialise the RCCL process group and take the gather path even with one rank (exercises the N>1 code)")
-    return p.parse_args()
+                   help="initialise the process group and take the exchange path even with one rank (exercises the N>1 code)")
+    a = p.parse_args()
+    w = dict(WORKLOADS[a.workload])
+    a.custom = []
+    for key, arg in (("rows", a.rows), ("cols", a.cols), ("hashes", a.hashes), ("batch", a.batch), ("qlen", a.qlen),
+                     ("threshold", a.threshold), ("distinct", a.distinct_batches), ("score", a.score)):
+        if arg is not None:
+            w[key] = type(w[key])(arg)
+            a.custom.append(key)
+    a.w = w
+    return a
 
 
-def make_queries(batch, qlen, rank_independent_seed=1):
-    rng = np.random.default_rng(rank_independent_seed)       # every rank sees the same queries
-    return ["".join(rng.choice(list("ACGT"), size=qlen)) for _ in range(batch)]
+def rand_seqs(rng, n, qlen):
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    return [lut[r].tobytes().decode("ascii") for r in rng.integers(0, 4, size=(n, qlen), dtype=np.uint8)]
 
 
-def cpu_baseline(args, seqs, exact):
+# ------------------------------------------------------------------------------------------------ self launch
+def self_launch(args):
+    """--gpus N without a launcher: start N ranks of this script, wait, relay rank 0's JSON line."""
+    n = args.gpus
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out0 = tempfile.NamedTemporaryFile("w+", prefix="bigsi_bench_rank0_", suffix=".out", delete=False)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=out0 if r == 0 else sys.stderr, stderr=sys.stderr))
+    rc = 0
+    try:
+        while any(p.poll() is None for p in procs):
+            bad = [p for p in procs if p.poll() not in (None, 0)]
+            if bad:                    # one rank died: the others would wait for it in a collective for ever
+                rc = bad[0].returncode
+                break
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate() if rc else p.wait()
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    rc = rc or max(abs(p.returncode or 0) for p in procs)
+    out0.seek(0)
+    text = out0.read()
+    out0.close()
+    os.unlink(out0.name)
+    if rc:
+        sys.stderr.write(text)
+        raise SystemExit("bench.py: a rank failed (exit code %d)" % rc)
+    sys.stdout.write(text)
+    sys.stdout.flush()
+
+
+def cpu_baseline(args, w, cols_cpu, exact):
     """oracle/cpu_baseline.py in a fresh subprocess (its fork pool must not inherit a HIP context): the C oracle
     (reference-shaped port) on ONE core -- the reported `value` -- plus, for context, the reference's own
-    process-pool-over-sequences parallelism (bulk_search) on every physical core."""
-    import subprocess
-    half = max(args.cpu_seconds / 2.0, 1.0)
-    cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--rows", str(min(args.rows, args.cpu_rows)),
-           "--cols", str(args.cols), "--hashes", str(args.hashes), "--k", str(args.k), "--and-draws", str(args.and_draws),
-           "--seed", str(SEED), "--batch", str(args.batch), "--qlen", str(args.qlen), "--exact", str(int(exact)),
-           "--seconds", str(half)]
-    r = json.loads(subprocess.run(cmd, check=True, capture_output=True, text=True, timeout=600).stdout.strip().splitlines()[-1])
+    process-pool-over-sequences parallelism (bulk_search) on every physical core, best / median of three runs."""
+    cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--rows", str(min(w["rows"], args.cpu_rows)),
+           "--cols", str(cols_cpu), "--hashes", str(w["hashes"]), "--k", str(args.k), "--and-draws", str(args.and_draws),
+           "--seed", str(SEED), "--batch", str(min(w["batch"], 256)), "--qlen", str(w["qlen"]), "--exact", str(int(exact)),
+           "--seconds", str(max(args.cpu_seconds / 3.0, 1.0)), "--pool-runs", "3", "--pool-seconds", str(max(args.cpu_seconds / 6.0, 1.0))]
+    r = json.loads(subprocess.run(cmd, check=True, capture_output=True, text=True, timeout=900).stdout.strip().splitlines()[-1])
     return {"value": r["one_core"]["rate"], "unit": "kmer_lookups/s", "cores": 1, "kind": "port",
-            "sample": "%d unique k-mer lookups in %.1f s cycling over the %d bench queries, on a %d-row x %d-sample slice of the same "
-                      "synthetic index (full row width, rows reduced to fit host RAM); oracle/bigsi_oracle.c orc_query; rows served from RAM "
-                      "instead of BerkeleyDB" % (r["one_core"]["lookups"], r["one_core"]["seconds"], len(seqs), r["rows"], r["cols"]),
-            "pool": {"value": r["pool"]["rate"], "cores": r["pool"]["threads"], "host_threads": r["host_threads"],
-                     "sample": "fork pool over query sequences (the reference's bulk_search parallelism), %d workers x %.1f s"
-                               % (r["pool"]["threads"], r["pool"]["seconds"])}}
+            "sample": "%d unique k-mer lookups in %.1f s cycling over %d of the bench's queries, on a %d-row x %d-sample slice of the same "
+                      "synthetic index (full row width of one GPU's shard, rows reduced to fit host RAM); oracle/bigsi_oracle.c orc_query; rows "
+                      "served from RAM instead of BerkeleyDB" % (r["one_core"]["lookups"], r["one_core"]["seconds"], min(w["batch"], 256),
+                                                                r["rows"], r["cols"]),
+            "pool": {"value": r["pool"]["rate_median"], "best": r["pool"]["rate_best"], "runs": r["pool"]["rates"],
+                     "cores": r["pool"]["threads"], "host_threads": r["host_threads"],
+                     "sample": "fork pool over query sequences (the reference's bulk_search parallelism), %d workers, median of %d runs of %.1f s"
+                               % (r["pool"]["threads"], len(r["pool"]["rates"]), r["pool"]["seconds"])}}
 
 
 def main():
     args = parse()
+    w = args.w
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs a torch.distributed.run launch with %d ranks" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+
+    # ---------------- this rank's part of the workload
+    from bigsi_amd.parallel import ShardedSearch, plan_shards
+    parts = args.shard_of or world
+    if parts < world:
+        raise SystemExit("--shard-of %d is fewer than --gpus %d" % (parts, world))
+    if args.scaling == "weak":
+        shard_cols, my_cols, total_cols = w["cols"], w["cols"], w["cols"] * world
+    else:
+        shard_cols, spans = plan_shards(w["cols"], parts)
+        my_cols, total_cols = spans[rank][1], sum(n for _, n in spans[:world])
+    words = -(-shard_cols // 64)
+    stride_bytes = max(16, -(-words // 16) * 16) * 8          # the library's row pitch: 128-byte multiples
+    need = w["rows"] * stride_bytes
+    if need > HBM_BYTES * FIT_FRACTION:
+        raise SystemExit("workload %s on %d GPU(s): a shard of %d rows x %d samples is %.0f GB, more than one MI355X holds (288 GB); "
+                         "use more GPUs (or --shard-of P to run some of P shards)" % (args.workload, parts, w["rows"], shard_cols, need / 1e9))
+    if my_cols <= 0:
+        raise SystemExit("rank %d would hold no columns" % rank)
 
     import torch
     import torch.distributed as dist
     from bigsi_amd import _lib
     from bigsi_amd._lib import check
-    from bigsi_amd.parallel import ShardedSearch
     from bigsi_amd.storage import get_storage
 
-    if os.environ.get("BIGSI_BENCH_DEVICE"):          # dry runs: several ranks sharing one GPU
-        local_rank = int(os.environ["BIGSI_BENCH_DEVICE"])
+    if args.one_device or os.environ.get("BIGSI_BENCH_DEVICE"):          # dry runs: several ranks sharing one GPU
+        local_rank = int(os.environ.get("BIGSI_BENCH_DEVICE", "0"))
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d needs device %d but only %d GPU(s) are visible (--one-device --backend gloo shares one)"
+                         % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
@@ -105,30 +217,41 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    exact = args.threshold == 1.0
+    thr = w["threshold"]
+    exact = thr == 1.0
     # ---------------- index: this rank's column shard, generated on the device
-    st = get_storage({"storage-engine": "hip-hbm", "k": args.k, "m": args.rows, "h": args.hashes,
-                      "storage-config": {"name": "bench", "device": local_rank, "max_cols": args.cols}})
+    st = get_storage({"storage-engine": "hip-hbm", "k": args.k, "m": w["rows"], "h": w["hashes"],
+                      "storage-config": {"name": "bench", "device": local_rank, "max_cols": shard_cols}})
     st.delete_all()
-    for key, v in (("number_of_rows", args.rows), ("number_of_cols", args.cols),
-                   ("ksi:bloomfilter_size", args.rows), ("ksi:num_hashes", args.hashes)):
+    for key, v in (("number_of_rows", w["rows"]), ("number_of_cols", my_cols),
+                   ("ksi:bloomfilter_size", w["rows"]), ("ksi:num_hashes", w["hashes"])):
         st.set_integer(key, v)
     t0 = time.time()
     st.fill_synthetic(SEED, rank, args.and_draws)
     fill_s = time.time() - t0
     info = st.res.info()
 
-    # ---------------- queries: uniform ACGT; ~1% of them planted into a few samples of every shard
-    seqs = make_queries(args.batch, args.qlen)
-    planted = list(range(0, args.batch, 97))[:8]
+    # ---------------- queries: uniform ACGT, the same on every rank; a few of them planted into a sample of every shard
+    nb = max(1, w["distinct"])
+    all_seqs = [rand_seqs(np.random.default_rng(1 + i), w["batch"], w["qlen"]) for i in range(nb)]
+    seqs = all_seqs[0]
+    planted = list(range(0, w["batch"], 97))[:8]
+
+    def plant_col(j, g, cols_g):
+        return (1009 * (j + 1) + 13 * g) % cols_g
+
+    # thresholded runs plant the first 70 % of a query's k-mers only, so that hits carry partial counts
+    n_kmers = w["qlen"] - args.k + 1
+    plant_len = w["qlen"] if exact else args.k - 1 + int(np.ceil(0.7 * n_kmers))
     for j, qi in enumerate(planted):
-        st.insert_kmers((1009 * (j + 1) + 13 * rank) % args.cols, [seqs[qi]], args.k)
-    sh = ShardedSearch(st, args.cols, device=dev, force_gather=args.force_dist)   # puts the library on a torch stream
-    # consecutive steps alternate two staged copies of the batch (a serving loop's two workspaces): K1 of one overlaps the
-    # row-AND kernel of the other on the library's pre stream, and in sharded runs so does the exchange
-    batches = [st.new_batch(seqs, args.k) for _ in range(2)]
-    batch = batches[0]
-    count_bytes = 2 if (args.qlen - args.k + 1) < 65536 else 4
+        st.insert_kmers(plant_col(j, rank, my_cols), [seqs[qi][:plant_len]], args.k)
+    if args.one_device and world > 1 and args.backend == "nccl":
+        raise SystemExit("--one-device needs --backend gloo: RCCL refuses two ranks on one device")
+    sh = ShardedSearch(st, shard_cols, device=dev, force_gather=args.force_dist, slots=max(2, nb))
+    # the steps cycle through `nb` staged batches (a serving loop's workspaces): with >= 2 the exchange of one batch overlaps
+    # the row-AND kernel of the next, and with many (c2) the rows of a step are not what the last steps left in the caches
+    batches = [st.new_batch(s_, args.k) for s_ in all_seqs]
+    count_bytes = 2 if (w["qlen"] - args.k + 1) < 65536 else 4
     sh.prepare(batches, exact, count_bytes)
     check(_lib.lib().bigsi_hip_set_profiling(st.handle, 1))
 
@@ -138,9 +261,9 @@ def main():
         torch.cuda.synchronize(dev)
 
     warm = _lib.Stats()
-    for w in range(args.warmup):
-        sh.step(batches, args.threshold)
-        if w == 0:            # the first step pays one-off costs (code object load, allocations): keep it out of the K1 / K4 figures
+    for i in range(args.warmup):
+        sh.step(batches, thr)
+        if i == 0:            # the first step pays one-off costs (code object load, allocations): keep it out of the K1 / K4 figures
             sync_all()
             check(_lib.lib().bigsi_hip_stats(st.handle, _lib.C.byref(warm), 1))
     sync_all()
@@ -152,7 +275,7 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        sh.step(batches, args.threshold)
+        sh.step(batches, thr)
     sync_all()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -161,22 +284,44 @@ def main():
         elapsed = float(t.item())
     check(_lib.lib().bigsi_hip_stats(st.handle, _lib.C.byref(stats), 1))
 
-    # ---------------- results of the last step, algorithmic bytes, verification
-    batch = batches[(args.steps - 1) % len(batches)]      # the batch the last step ran on
+    # ---------------- results of the first staged batch, algorithmic bytes, verification
+    # (its last run: step index (k * nb) for the largest such index below warmup + steps)
+    batch = batches[0]
     off, colours, counts = sh.fetch(batch)
     nk, nu, mk = batch.unique()
     total_unique = int(nu.sum())
-    wv = -(-args.cols // 64)
+    wv = -(-my_cols // 64)
     uniq_rows = 0
-    for i in range(args.batch):
+    for i in range(w["batch"]):
         uniq_rows += np.unique(batch.rows(i, nu[i])).size      # each needed row counted once (reference fetches the union once)
     # result vector the kernel stores: one bit per sample (AND bitmap / thresholded hit mask); counters only where hits are
-    out_bytes = args.batch * wv * 8
-    alg_bytes = uniq_rows * wv * 8 + out_bytes
+    out_bytes = w["batch"] * wv * 8
+    alg_bytes = uniq_rows * wv * 8 + out_bytes                 # SURVEY.md section 8d, this rank's shard
     and_ms = stats.and_ms / max(stats.and_launches, 1)
     achieved = alg_bytes / (and_ms * 1e-3) / 1e9
+    per_rank_gbs = [achieved]
+    if use_dist:
+        t = torch.zeros(world, dtype=torch.float64, device=dev)
+        t[rank] = achieved
+        dist.all_reduce(t)
+        per_rank_gbs = [float(x) for x in t.tolist()]
 
-    # PCIe-inclusive rate of the host-buffer boundary (never `value`): sequences in host memory -> batch_create (H2D) ->
+    # score=True (configs[4]): presence strings of every hit of the batch, on the rank that owns the hit's column
+    presence = None
+    if w["score"]:
+        t1 = time.perf_counter()
+        n_strings = 0
+        for i in range(w["batch"]):
+            cols_i = colours[int(off[i]):int(off[i + 1])].astype(np.int64)
+            mine = cols_i[(cols_i // shard_cols) == rank] - rank * shard_cols
+            if mine.size:
+                strs = batch.presence(i, mine.astype(np.uint32), int(nk[i]))
+                n_strings += len(strs)
+                if i in planted:
+                    assert all(s_.count("1") >= plant_len - args.k + 1 for s_ in strs if s_)
+        presence = {"strings": n_strings, "ms_per_batch": (time.perf_counter() - t1) * 1e3}
+
+    # PCIe-inclusive rate of the host-buffer boundary (never `value`): sequences in host memory -> batch_reload (H2D) ->
     # run -> fetch_hits (D2H), a few repetitions outside the timed region
     pcie_rate = None
     if world == 1 and not args.force_dist:
@@ -188,8 +333,8 @@ def main():
         t1 = time.perf_counter()
         for i in range(reps):
             cur = ws[i % 2]
-            cur.reload(seqs)                       # H2D of the sequences (waits for this workspace's previous batch only)
-            cur.run(args.threshold, sparse_counts=True)
+            cur.reload(all_seqs[i % nb])           # H2D of the sequences (waits for this workspace's previous batch only)
+            cur.run(thr, sparse_counts=True)
             if i:
                 ws[(i - 1) % 2].hits()             # D2H of the previous batch's hit lists while `cur` runs
         ws[(reps - 1) % 2].hits()
@@ -201,7 +346,7 @@ def main():
     # collected from inside the timed run; see profiles/)
     traffic, traffic_src = None, None
     wkey = "rows=%d cols=%d hashes=%d batch=%d qlen=%d k=%d threshold=%s draws=%d" % (
-        args.rows, args.cols, args.hashes, args.batch, args.qlen, args.k, repr(float(args.threshold)), args.and_draws)
+        w["rows"], my_cols, w["hashes"], w["batch"], w["qlen"], args.k, repr(float(thr)), args.and_draws)
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             ent = json.load(f).get(wkey)
@@ -212,52 +357,74 @@ def main():
 
     verified = None
     if not args.no_verify and rank == 0:
-        # planted round trip on every shard + one sampled query against the oracle on this rank's shard
+        # planted round trip on every shard + sampled queries against the oracle on this rank's shard
         from oracle.ref_model import SynthOracle
+        spans_cols = [my_cols] * world if args.scaling == "weak" else [n for _, n in plan_shards(w["cols"], parts)[1][:world]]
         for j, qi in enumerate(planted):
             hits = set(colours[int(off[qi]):int(off[qi + 1])].tolist())
             for g in range(world):
-                assert g * args.cols + (1009 * (j + 1) + 13 * g) % args.cols in hits, "planted query %d missing on shard %d" % (qi, g)
-        orc = SynthOracle(SEED, 0, args.rows, args.cols, args.hashes, args.k, args.and_draws)
+                assert g * shard_cols + plant_col(j, g, spans_cols[g]) in hits, "planted query %d missing on shard %d" % (qi, g)
+        orc = SynthOracle(SEED, 0, w["rows"], my_cols, w["hashes"], args.k, args.and_draws)
         for j, qi in enumerate(planted):
-            orc.insert_kmers((1009 * (j + 1)) % args.cols, seqs[qi])
-        for qi in (planted[0], 1):
+            orc.insert_kmers(plant_col(j, 0, my_cols), seqs[qi][:plant_len])
+        sample = sorted(set([planted[0], 1 % w["batch"], w["batch"] // 2, w["batch"] - 1]))
+        for qi in sample:
             u, cnt = orc.counts(seqs[qi])
             want = np.flatnonzero(cnt >= (u if exact else mk[qi]))
-            got = colours[int(off[qi]):int(off[qi + 1])]
-            got0 = got[got < args.cols]
-            assert u == nu[qi] and np.array_equal(got0, want), "oracle mismatch on query %d" % qi
-        verified = "planted round trip on %d shard(s) + 2 queries bit-exact vs oracle" % world
+            lo, hi = int(off[qi]), int(off[qi + 1])
+            sel = colours[lo:hi] < shard_cols                   # rank 0's shard
+            assert u == nu[qi] and np.array_equal(colours[lo:hi][sel], want), "oracle mismatch on query %d" % qi
+            assert np.array_equal(counts[lo:hi][sel], cnt[want].astype(np.uint32)), "oracle count mismatch on query %d" % qi
+        verified = "planted round trip on %d shard(s) + %d queries bit-exact (colours and counts) vs oracle" % (world, len(sample))
 
     line = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        per_rank_rate = total_unique / (elapsed / args.steps)
+        rate = total_unique / (elapsed / args.steps)
+        cr = sh.comm_ranks()
+        whole = args.scaling == "strong" and parts == world
         line = {
-            "metric": "kmer_lookups_per_s", "value": per_rank_rate * world, "unit": "kmer_lookups/s",
+            "metric": "kmer_lookups_per_s", "value": rate, "unit": "kmer_lookups/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[2]: synthetic %d-row x %d-sample index per GPU (%.1f GB HBM), h=%d, %d x %d bp queries, "
-                            "k=%d, threshold=%g (%s)" % (args.rows, args.cols, info.index_bytes / 1e9, args.hashes, args.batch, args.qlen,
-                                                         args.k, args.threshold, "exact" if exact else "counts"),
-                "rows": args.rows, "cols_per_gpu": args.cols, "total_cols": args.cols * world, "hashes": args.hashes,
-                "batch": args.batch, "qlen": args.qlen, "unique_kmers_per_batch": total_unique, "hits_last_step": int(off[-1]),
-                "kmer_lookups_per_s_full_index": per_rank_rate, "parallelism": "column-shard x%d + RCCL all-gather" % world,
-                "index_fill_s": fill_s, "verified": verified,
+                "workload": "%s%s: synthetic %d-row x %d-sample index%s, h=%d, %d x %d bp queries per step (%d staged batches), k=%d, "
+                            "threshold=%g (%s)%s"
+                            % (w["name"], " (shape overridden: %s)" % ",".join(args.custom) if args.custom else "", w["rows"],
+                               w["cols"] if args.scaling == "strong" else total_cols,
+                               "" if whole and world == 1 else
+                               (" column-sharded over %d GPUs (%d samples each)" % (world, shard_cols) if whole else
+                                " of which this run holds %d of %d column shards (%d samples)" % (world, parts, total_cols)
+                                if args.scaling == "strong" else " = %d samples per GPU, weak scaling" % shard_cols),
+                               w["hashes"], w["batch"], w["qlen"], nb, args.k, thr, "exact" if exact else "counts",
+                               ", score=True presence extraction" if w["score"] else ""),
+                "workload_key": args.workload, "rows": w["rows"], "cols_per_gpu": shard_cols, "total_cols": total_cols,
+                "index_gb_per_gpu": info.index_bytes / 1e9, "hashes": w["hashes"], "batch": w["batch"], "qlen": w["qlen"],
+                "unique_kmers_per_batch": total_unique, "hits_first_batch": int(off[-1]),
+                "value_is": "unique query k-mers per second against the %d samples held by this run, exchange included" % total_cols,
+                "shard_lookups_per_s_sum": rate * world,
+                "aggregate_GBps": sum(per_rank_gbs), "per_rank_GBps": per_rank_gbs,
+                "parallelism": "column-shard x%d%s" % (world, "" if not use_dist else
+                                                      " + ncclAllGather of 1 bit/sample (library-owned RCCL communicator)"
+                                                      if sh.exchange == "rccl" else " + torch.distributed(%s) all-gather" % args.backend),
+                "backend": args.backend if use_dist else None, "exchange": sh.exchange if use_dist else None,
+                "rccl_ranks": cr[1] if cr else None,
+                "index_fill_s": fill_s, "verified": verified, "presence": presence,
                 "pcie_inclusive_kmer_lookups_per_s": pcie_rate,
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_and_exact" if exact else "k_and_count",
                          "alg_bytes_per_launch": alg_bytes, "kernel_ms": and_ms, "launches_timed": int(stats.and_launches),
-                         # per step, from warmup steps 2..W: K1 (+ row sort on the exact path); K4's three launches
+                         "rank": 0,
+                         # per step, from warmup steps 2..W: K1 (+ row sort on the exact path); K4
                          "kmerize_ms": warm.kmerize_ms / (args.warmup - 1) if args.warmup > 1 else None,
                          "compact_ms": warm.compact_ms / (args.warmup - 1) if args.warmup > 1 else None},
         }
         if args.cpu_seconds > 0 and world == 1:        # reported at N=1 only
-            line["cpu_baseline"] = cpu_baseline(args, seqs, exact)
+            line["cpu_baseline"] = cpu_baseline(args, w, my_cols, exact)
     for b_ in batches:
         b_.close()
+    sh.close()
     st.delete_all()
     if use_dist:
         dist.barrier()

@@ -1,6 +1,7 @@
 """`python -m bigsi_amd <command>`: the query-side commands of the reference CLI (bigsi/__main__.py:103-320) on the
 hip-hbm backend.  argparse instead of hug; same command names, arguments and output text."""
 import argparse
+import json
 import os
 import sys
 
@@ -65,6 +66,9 @@ def main(argv=None):
     sp = shardable(common(sub.add_parser("build")))
     sp.add_argument("--bloomfilters", "-b", action="append", default=[])
     sp.add_argument("--samples", "-s", action="append", default=[])
+    sp.add_argument("--from_file", default=None, help="TSV of bloomfilter path <tab> sample name (bigsi/__main__.py:139-156)")
+    sp = common(sub.add_parser("merge", help="append the samples of the index described by MERGE_CONFIG (bigsi/__main__.py:173-181)"))
+    sp.add_argument("merge_config")
     sp = common(sub.add_parser("insert"))
     sp.add_argument("bloomfilter")
     sp.add_argument("sample")
@@ -96,11 +100,19 @@ def main(argv=None):
         with open(a.outfile, "wb") as f:
             f.write(BIGSI.bloom(config, kmers).tobytes())
     elif a.cmd == "build":
-        blooms = [BitRow.frombytes(open(b, "rb").read(), config["m"]) for b in a.bloomfilters]
-        BIGSI.build(config, blooms, a.samples)
+        paths, samples = build_inputs(a)
+        build_in_slabs(config, paths, samples)
         print('{"result": "success"}')
+    elif a.cmd == "merge":
+        other_config = get_config_from_file(a.merge_config)
+        index = BIGSI(config)
+        index.merge(BIGSI(other_config))
+        index.storage.sync()                        # the snapshot file is the only thing the next process sees
+        print(json.dumps({"result": "merged %s into %s." % (a.merge_config, a.config)}))
     elif a.cmd == "insert":
-        BIGSI(config).insert(BitRow.frombytes(open(a.bloomfilter, "rb").read(), config["m"]), a.sample)
+        index = BIGSI(config)
+        index.insert(BitRow.frombytes(open(a.bloomfilter, "rb").read(), config["m"]), a.sample)
+        index.storage.sync()                        # persist: the reference's backends write through
         print('{"result": "success"}')
     elif a.cmd == "import-bdb":
         from . import bdb
@@ -114,6 +126,59 @@ def main(argv=None):
     return 0
 
 
+def build_inputs(a):
+    """(bloom filter paths, sample names) of a `build` command line, as the reference resolves them
+    (bigsi/__main__.py:139-160): --from_file XOR -b; sample names default to the filter paths."""
+    import csv
+    paths, samples = list(a.bloomfilters), list(a.samples)
+    if a.from_file and paths:
+        raise ValueError("You can only specify blooms via from_file or bloomfilters, but not both")
+    if a.from_file:
+        paths, samples = [], []
+        with open(a.from_file, "r") as tsv:
+            for row in csv.reader(tsv, delimiter="\t"):
+                paths.append(row[0])
+                samples.append(row[1])
+    if samples:
+        assert len(samples) == len(paths)
+    else:
+        samples = list(paths)
+    return paths, samples
+
+
+def parse_size(text):
+    """'4GB' / '512 MiB' / 1000 -> bytes (the reference hands config['max_build_mem_bytes'] to humanfriendly.parse_size:
+    decimal multiples for kB/MB/GB, binary ones for KiB/MiB/GiB)."""
+    import re
+    if isinstance(text, (int, float)):
+        return int(text)
+    m = re.fullmatch(r"\s*([0-9.]+)\s*(?:([kmgtp])(i?)b?|b|bytes?)?\s*", str(text).lower())
+    if not m:
+        raise ValueError("cannot parse size %r" % (text,))
+    value = float(m.group(1))
+    if m.group(2):
+        value *= (1024 if m.group(3) else 1000) ** ("kmgtp".index(m.group(2)) + 1)
+    return int(value)
+
+
+def build_in_slabs(config, paths, samples):
+    """BIGSI.build with bounded host memory: the filters are read and sent to the device `max_build_mem_bytes` at a time
+    (config key, as in the reference's chunked build, bigsi/cmds/build.py:43-73) -- the first slab builds the index, later slabs
+    append their columns in place (the device transpose writes columns [col0, col0+n) of the resident matrix), so no
+    temporary indexes and no merges are needed."""
+    limit = parse_size(config["max_build_mem_bytes"]) if config.get("max_build_mem_bytes") else None
+    per = (int(config["m"]) + 7) // 8
+    slab = len(paths) if not limit else max(1, limit // max(per, 1))
+    if limit and limit < per:
+        raise ValueError("Max memory must be at least the Bloomfilter size in bytes")
+    load = lambda b: BitRow.frombytes(open(b, "rb").read(), config["m"])      # noqa: E731
+    index = BIGSI.build(config, [load(b) for b in paths[:slab]], samples[:slab])
+    for i in range(slab, len(paths), slab):
+        index.insert_many([load(b) for b in paths[i:i + slab]], samples[i:i + slab])
+    index.storage.sync()
+    return index
+
+
 def sharded_main(a, config):
     """search / bulk_search / build on a column-sharded index: every rank runs the same command (SPMD), the device work
     and the exchange are bigsi_amd.parallel's, and only rank 0 writes to stdout."""
@@ -122,7 +187,8 @@ def sharded_main(a, config):
     from .parallel import ShardedBIGSI
     rank, world, _ = ShardedBIGSI.launch()
     if a.cmd == "build":
-        sb = ShardedBIGSI.build(config, a.bloomfilters, a.samples)
+        paths, samples = build_inputs(a)
+        sb = ShardedBIGSI.build(config, paths, samples)
         text = '{"result": "success"}'
     else:
         sb = ShardedBIGSI.open(config)

@@ -42,6 +42,12 @@ class BatchInfo(C.Structure):
                 ("d_bitmaps", C.c_void_p), ("d_counts", C.c_void_p), ("d_num_unique", C.c_void_p)]
 
 
+class GroupInfo(C.Structure):
+    _fields_ = [("num_rows", C.c_uint64), ("num_cols", C.c_uint64), ("col_capacity", C.c_uint64), ("shard_cols", C.c_uint64),
+                ("row_bytes", C.c_uint64), ("index_bytes", C.c_uint64), ("num_hashes", C.c_uint32), ("n_shards", C.c_uint32),
+                ("rccl", C.c_uint32)]
+
+
 class Stats(C.Structure):
     _fields_ = [("and_launches", C.c_uint64), ("and_ms", C.c_double),
                 ("kmerize_launches", C.c_uint64), ("kmerize_ms", C.c_double),
@@ -92,6 +98,37 @@ SIGNATURES = {
     "bigsi_hip_batch_compact_gathered_masks": (_i32, [_P, _P, _u32, _u64, _u32]),
     "bigsi_hip_batch_set_gathered_hit_outputs": (_i32, [_P, _P, _P, _u64]),
     "bigsi_hip_batch_fetch_gathered_hits": (_i32, [_P, _P, _P, _P, _u64]),
+    "bigsi_hip_batch_set_result_cols": (_i32, [_P, _u64]),
+    "bigsi_hip_search_batch": (_i32, [_P, C.c_char_p, _P, _u32, _u32, _dbl, _u32, _P, _P, _P, _P, _P, _P, _u64]),
+    "bigsi_hip_comm_unique_id": (_i32, [_P]),
+    "bigsi_hip_comm_init_rank": (_i32, [_i32, _P, _i32, _i32, C.POINTER(_P)]),
+    "bigsi_hip_comm_destroy": (_i32, [_P]),
+    "bigsi_hip_comm_info": (_i32, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "bigsi_hip_batch_set_comm": (_i32, [_P, _P, _u64]),
+    "bigsi_hip_batch_run_sharded": (_i32, [_P, _dbl, _u32]),
+    "bigsi_hip_group_open": (_i32, [_u64, _u64, _u64, _u32, C.POINTER(C.c_int), _i32, C.POINTER(_P)]),
+    "bigsi_hip_group_close": (_i32, [_P]),
+    "bigsi_hip_group_get_info": (_i32, [_P, C.POINTER(GroupInfo)]),
+    "bigsi_hip_group_shard": (_i32, [_P, _u32, C.POINTER(_P)]),
+    "bigsi_hip_group_set_num_cols": (_i32, [_P, _u64]),
+    "bigsi_hip_group_set_num_hashes": (_i32, [_P, _u32]),
+    "bigsi_hip_group_synchronize": (_i32, [_P]),
+    "bigsi_hip_group_clear": (_i32, [_P]),
+    "bigsi_hip_group_set_rows": (_i32, [_P, _P, _u64, _P, _u64]),
+    "bigsi_hip_group_get_rows": (_i32, [_P, _P, _u64, _P, _u64]),
+    "bigsi_hip_group_insert_columns": (_i32, [_P, _u64, _u64, _P, _u64]),
+    "bigsi_hip_group_get_column": (_i32, [_P, _u64, _P]),
+    "bigsi_hip_group_insert_kmers": (_i32, [_P, _u64, C.c_char_p, _P, _u32, _u32]),
+    "bigsi_hip_group_fill_synthetic": (_i32, [_P, _u64, _u32]),
+    "bigsi_hip_group_lookup": (_i32, [_P, C.c_char_p, _u32, _u64, _P]),
+    "bigsi_hip_group_batch_create": (_i32, [_P, C.c_char_p, _P, _u32, _u32, C.POINTER(_P)]),
+    "bigsi_hip_group_batch_reload": (_i32, [_P, C.c_char_p, _P, _u32, _u32]),
+    "bigsi_hip_group_batch_destroy": (_i32, [_P]),
+    "bigsi_hip_group_batch_run": (_i32, [_P, _dbl, _u32]),
+    "bigsi_hip_group_batch_fetch_unique": (_i32, [_P, _P, _P, _P]),
+    "bigsi_hip_group_batch_fetch_hits": (_i32, [_P, _P, _P, _P, _u64]),
+    "bigsi_hip_group_batch_presence": (_i32, [_P, _u32, _P, _u32, _P]),
+    "bigsi_hip_group_search_batch": (_i32, [_P, C.c_char_p, _P, _u32, _u32, _dbl, _u32, _P, _P, _P, _P, _P, _P, _u64]),
     "bigsi_hip_set_profiling": (_i32, [_P, _i32]),
     "bigsi_hip_stats": (_i32, [_P, C.POINTER(Stats), _i32]),
 }

@@ -1,8 +1,6 @@
 // bigsi_hip.hip -- host side of libbigsi_hip.so: the C ABI declared in include/bigsi_hip.h.
 // Plain HIP runtime (hipMalloc / streams / events); no torch types anywhere in this library.
-#include "bigsi_hip.h"
-
-#include <hip/hip_runtime.h>
+#include "bigsi_internal.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -20,7 +18,7 @@ using namespace bigsi;
 // ------------------------------------------------------------------------------ errors
 static thread_local char g_err[1024] = "";
 
-static int fail(int code, const char *fmt, ...)
+int bigsi_fail(int code, const char *fmt, ...)
 {
     va_list ap;
     va_start(ap, fmt);
@@ -28,21 +26,6 @@ static int fail(int code, const char *fmt, ...)
     va_end(ap);
     return code;
 }
-
-#define HIP_TRY(expr)                                                                                   \
-    do {                                                                                                \
-        hipError_t e_ = (expr);                                                                         \
-        if (e_ != hipSuccess)                                                                           \
-            return fail(e_ == hipErrorOutOfMemory ? BIGSI_ERR_NOMEM : BIGSI_ERR_HIP, "%s:%d %s: %s", __FILE__, \
-                        __LINE__, #expr, hipGetErrorString(e_));                                       \
-    } while (0)
-
-#define TRY(expr)            \
-    do {                     \
-        int rc_ = (expr);    \
-        if (rc_ != BIGSI_OK) \
-            return rc_;      \
-    } while (0)
 
 extern "C" const char *bigsi_hip_last_error(void) { return g_err; }
 
@@ -53,63 +36,12 @@ extern "C" int bigsi_hip_device_count(int *out)
     return BIGSI_OK;
 }
 
-static inline uint64_t round_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
-static inline uint64_t ceil_div(uint64_t x, uint64_t a) { return (x + a - 1) / a; }
-
-static int env_int(const char *name, int dflt)
-{
-    const char *v = getenv(name);
-    return v && *v ? atoi(v) : dflt;
-}
-
-// ------------------------------------------------------------------------------ device buffer with growth
-struct DevBuf {
-    void *p = nullptr;
-    size_t cap = 0;
-    int reserve(size_t bytes)
-    {
-        if (bytes <= cap) return BIGSI_OK;
-        if (p) { hipError_t e = hipFree(p); (void)e; p = nullptr; cap = 0; }
-        size_t want = std::max<size_t>(bytes, 256);
-        HIP_TRY(hipMalloc(&p, want));
-        cap = want;
-        return BIGSI_OK;
-    }
-    void release()
-    {
-        if (p) { hipError_t e = hipFree(p); (void)e; }
-        p = nullptr;
-        cap = 0;
-    }
-    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
-};
-
-struct EventPair {
-    hipEvent_t a = nullptr, b = nullptr;
-};
-
-struct bigsi_hip_index {
-    int device = 0;
-    hipStream_t stream = nullptr, own_stream = nullptr;
-    // the sequences of a batch are uploaded here, so that loading one batch does not wait for the kernels of another
-    // (and, with BIGSI_HIP_K1_OVERLAP=1 only, K1 and the row sort run here too: see k1_stream)
-    hipStream_t pre_stream = nullptr;
-    uint64_t m = 0, n_cols = 0, cap_cols = 0, stride_words = 0;
-    uint32_t h = 0;
-    uint64_t *d_index = nullptr;
-    DevBuf stage, stage_ids;
-    // profiling
-    int profiling = 0;            // 0 off, 1 every kernel group of a run, 2 the row-AND kernel only
-    std::vector<EventPair> ev_and, ev_km, ev_cp, ev_free;
-    uint64_t wv() const { return ceil_div(n_cols, 64); }
-    uint64_t rb() const { return ceil_div(n_cols, 8); }
-};
-
-static int use_device(const bigsi_hip_index *ix)
+int bigsi_use_device(const bigsi_hip_index *ix)
 {
     HIP_TRY(hipSetDevice(ix->device));
     return BIGSI_OK;
 }
+#define use_device bigsi_use_device
 
 static uint64_t stride_for(uint64_t cols) { return std::max<uint64_t>(16, round_up(ceil_div(cols, 64), 16)); }
 
@@ -533,54 +465,6 @@ extern "C" int bigsi_hip_stats(bigsi_hip_index *ix, bigsi_hip_stats_t *out, int 
 }
 
 // ------------------------------------------------------------------------------ batches
-struct HitBufs {
-    DevBuf chunk_hits, chunk_off, hit_off, hit_col, hit_cnt, overflow;
-    uint64_t cap = 0;   // hits the col/cnt buffers can hold
-    uint32_t *xcol = nullptr, *xcnt = nullptr;   // caller-owned hit buffers (e.g. torch tensors that are then all-reduced)
-    uint64_t xcap = 0;
-    uint32_t *col() const { return xcol ? xcol : hit_col.as<uint32_t>(); }
-    uint32_t *cnt() const { return xcnt ? xcnt : hit_cnt.as<uint32_t>(); }
-    uint64_t capacity() const { return xcol ? xcap : cap; }
-    void release()
-    {
-        chunk_hits.release(); chunk_off.release(); hit_off.release(); hit_col.release(); hit_cnt.release(); overflow.release();
-    }
-};
-
-struct bigsi_hip_batch {
-    bigsi_hip_index *ix = nullptr;
-    uint32_t n_seqs = 0, k = 0;
-    std::vector<uint64_t> seq_off, pos_off, tab_off;
-    uint64_t total_pos = 0, max_pos = 0, max_len = 0;
-    DevBuf seqs, d_seq_off, d_pos_off, d_tab_off, tab, first_pos, pos_unique, tmp, rows, num_kmers, num_unique, min_kmers;
-    DevBuf pos_query, hsh, rep;   // per k-mer position: owning sequence, dedupe hash, class representative
-    DevBuf rows_sorted;           // the row ids K2 streams: each query's list in address order (k_sort_rows)
-    DevBuf bitmaps, counts, scratch;
-    void *ext_bitmaps = nullptr, *ext_counts = nullptr;
-    HitBufs hits, ghits;
-    // state of the last run
-    bool ran = false, exact = false, compacted = false, sparse_counts = false;
-    bool pos_query_loaded = false;    // pos_query holds this load's position -> sequence map
-    bool local_from_counts = false;   // the last counting run was row-sliced: hits come from thresholding the counters
-    uint32_t count_bytes = 2;
-    double threshold = 1.0;
-    uint64_t wv = 0, wv_pad = 0;   // valid / padded words per row at run time
-    uint32_t run_h = 0;            // num_hashes the row ids of the last K1 were produced with
-    hipEvent_t done = nullptr;     // recorded at the end of every run: fetches wait on it, not on the whole stream, so the
-                                   // results of one batch can be read while the next batch's kernels are queued behind it
-    hipEvent_t k1_done = nullptr;  // only when K1 runs on the pre stream: recorded after K1 (+ row sort), the index stream waits on it before K2
-    hipEvent_t g_done = nullptr;   // recorded on the gather stream after a gathered compaction (it reads K1's per-query arrays)
-    bool dirty = false;            // a run was started and its `done` event has not been recorded (error path): full syncs needed
-    hipStream_t gstream = nullptr; // stream of the gathered compaction (null: the index's stream)
-    const void *g_src = nullptr;   // last gathered buffer handed to compact_gathered
-    uint32_t g_shards = 0;
-    uint64_t g_shard_cols = 0;
-    uint32_t g_own = 0;
-    bool g_masks = false;          // the gathered buffer holds hit masks of a counting run (counts come from this rank's counters)
-    std::vector<uint32_t> h_num_unique, h_num_kmers;
-    bool host_counts_valid = false;
-};
-
 static uint64_t pow2_at_least(uint64_t x)
 {
     uint64_t p = 2;
@@ -708,10 +592,21 @@ extern "C" int bigsi_hip_batch_destroy(bigsi_hip_batch *b)
         d->release();
     b->hits.release();
     b->ghits.release();
+    b->gbuf.release();
     if (b->done) { e = hipEventDestroy(b->done); (void)e; }
     if (b->k1_done) { e = hipEventDestroy(b->k1_done); (void)e; }
     if (b->g_done) { e = hipEventDestroy(b->g_done); (void)e; }
     delete b;
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_batch_set_result_cols(bigsi_hip_batch *b, uint64_t cols)
+{
+    if (!b) return fail(BIGSI_ERR_INVALID, "NULL batch");
+    if (cols > b->ix->cap_cols)
+        return fail(BIGSI_ERR_CAPACITY, "result width %llu exceeds col_capacity %llu (call bigsi_hip_reserve_cols)", (unsigned long long)cols,
+                    (unsigned long long)b->ix->cap_cols);
+    b->result_cols = cols;
     return BIGSI_OK;
 }
 
@@ -887,13 +782,18 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
     if (!b) return fail(BIGSI_ERR_INVALID, "NULL batch");
     if (!(threshold <= 1.0)) return fail(BIGSI_ERR_INVALID, "threshold must be <= 1 (bigsi/graph/bigsi.py:176), got %g", threshold);
     bigsi_hip_index *ix = b->ix;
-    if (ix->n_cols == 0) return fail(BIGSI_ERR_STATE, "index has no columns");
+    // (a shard of a wider index may be empty: its result vectors, result_cols wide, are then all zero)
+    if (ix->n_cols == 0 && b->result_cols == 0) return fail(BIGSI_ERR_STATE, "index has no columns");
     TRY(use_device(ix));
     b->ran = false;
     b->host_counts_valid = false;
     b->threshold = threshold;
     b->exact = (threshold == 1.0) && !(flags & BIGSI_RUN_FORCE_COUNTS);
-    b->wv = ix->wv();
+    // result vectors as wide as the index, or as the shard width agreed by a group of column shards (uneven shards then
+    // still exchange buffers of one geometry; words beyond this shard's num_cols are zero through valid_mask)
+    b->wv = ceil_div(std::max(ix->n_cols, b->result_cols), 64);
+    if (b->wv > ix->stride_words)
+        return fail(BIGSI_ERR_CAPACITY, "result width %llu columns exceeds the row stride (call bigsi_hip_reserve_cols)", (unsigned long long)b->result_cols);
     b->wv_pad = round_up(b->wv, 2);
 
     // K1e: address-ordered copy of the row lists for K2 (BIGSI_HIP_SORT_ROWS=0 streams them in hash order instead)
@@ -1104,6 +1004,7 @@ static int fetch_hits_from(bigsi_hip_batch *b, HitBufs &hb, const void *src, uin
         TRY(hb.hit_cnt.reserve(total * 4));
         hb.cap = total;
         TRY(compact(b, hb, src, n_shards, shard_cols, true));
+        if (&hb == &b->ghits && b->comm && !b->exact) TRY(bigsi_reduce_gathered_counts(b));   // every rank takes this branch: totals are identical
         HIP_TRY(hipStreamSynchronize(st));
     }
     if (hit_offsets) memcpy(hit_offsets, off.data(), (b->n_seqs + 1) * 8ull);

@@ -1,0 +1,153 @@
+// bigsi_internal.hpp -- host-side structures shared by the translation units of libbigsi_hip.so
+// (bigsi_hip.hip: single-shard C ABI; bigsi_shard.hip: RCCL exchange, device groups, one-call search).
+#pragma once
+#include "bigsi_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+#include <vector>
+
+// ------------------------------------------------------------------------------ errors
+int bigsi_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+#define fail bigsi_fail
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(e_ == hipErrorOutOfMemory ? BIGSI_ERR_NOMEM : BIGSI_ERR_HIP, "%s:%d %s: %s", __FILE__, \
+                        __LINE__, #expr, hipGetErrorString(e_));                                       \
+    } while (0)
+
+#define TRY(expr)            \
+    do {                     \
+        int rc_ = (expr);    \
+        if (rc_ != BIGSI_OK) \
+            return rc_;      \
+    } while (0)
+
+static inline uint64_t round_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+static inline uint64_t ceil_div(uint64_t x, uint64_t a) { return (x + a - 1) / a; }
+
+// Tuning knobs (A/B measurements: scripts/ab_*.py) are read from the environment only in builds made with
+// -DBIGSI_HIP_TUNING (csrc/build.sh tuning); the product library takes the defaults and never calls getenv.
+static inline int env_int(const char *name, int dflt)
+{
+#ifdef BIGSI_HIP_TUNING
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
+}
+
+// ------------------------------------------------------------------------------ device buffer with growth
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes)
+    {
+        if (bytes <= cap) return BIGSI_OK;
+        if (p) { hipError_t e = hipFree(p); (void)e; p = nullptr; cap = 0; }
+        size_t want = std::max<size_t>(bytes, 256);
+        HIP_TRY(hipMalloc(&p, want));
+        cap = want;
+        return BIGSI_OK;
+    }
+    void release()
+    {
+        if (p) { hipError_t e = hipFree(p); (void)e; }
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+};
+
+struct bigsi_hip_index {
+    int device = 0;
+    hipStream_t stream = nullptr, own_stream = nullptr;
+    // the sequences of a batch are uploaded here, so that loading one batch does not wait for the kernels of another
+    // (and, with BIGSI_HIP_K1_OVERLAP=1 only, K1 and the row sort run here too: see k1_stream)
+    hipStream_t pre_stream = nullptr;
+    uint64_t m = 0, n_cols = 0, cap_cols = 0, stride_words = 0;
+    uint32_t h = 0;
+    uint64_t *d_index = nullptr;
+    DevBuf stage, stage_ids;
+    // profiling
+    int profiling = 0;            // 0 off, 1 every kernel group of a run, 2 the row-AND kernel only
+    std::vector<EventPair> ev_and, ev_km, ev_cp, ev_free;
+    uint64_t wv() const { return ceil_div(n_cols, 64); }
+    uint64_t rb() const { return ceil_div(n_cols, 8); }
+};
+
+struct bigsi_hip_comm;
+
+// ------------------------------------------------------------------------------ batches
+struct HitBufs {
+    DevBuf chunk_hits, chunk_off, hit_off, hit_col, hit_cnt, overflow;
+    uint64_t cap = 0;   // hits the col/cnt buffers can hold
+    uint32_t *xcol = nullptr, *xcnt = nullptr;   // caller-owned hit buffers (e.g. torch tensors that are then all-reduced)
+    uint64_t xcap = 0;
+    uint32_t *col() const { return xcol ? xcol : hit_col.as<uint32_t>(); }
+    uint32_t *cnt() const { return xcnt ? xcnt : hit_cnt.as<uint32_t>(); }
+    uint64_t capacity() const { return xcol ? xcap : cap; }
+    void release()
+    {
+        chunk_hits.release(); chunk_off.release(); hit_off.release(); hit_col.release(); hit_cnt.release(); overflow.release();
+    }
+};
+
+struct bigsi_hip_batch {
+    bigsi_hip_index *ix = nullptr;
+    uint32_t n_seqs = 0, k = 0;
+    std::vector<uint64_t> seq_off, pos_off, tab_off;
+    uint64_t total_pos = 0, max_pos = 0, max_len = 0;
+    DevBuf seqs, d_seq_off, d_pos_off, d_tab_off, tab, first_pos, pos_unique, tmp, rows, num_kmers, num_unique, min_kmers;
+    DevBuf pos_query, hsh, rep;   // per k-mer position: owning sequence, dedupe hash, class representative
+    DevBuf rows_sorted;           // the row ids K2 streams: each query's list in address order (k_sort_rows)
+    DevBuf bitmaps, counts, scratch;
+    void *ext_bitmaps = nullptr, *ext_counts = nullptr;
+    HitBufs hits, ghits;
+    // state of the last run
+    bool ran = false, exact = false, compacted = false, sparse_counts = false;
+    bool pos_query_loaded = false;    // pos_query holds this load's position -> sequence map
+    bool local_from_counts = false;   // the last counting run was row-sliced: hits come from thresholding the counters
+    uint32_t count_bytes = 2;
+    double threshold = 1.0;
+    uint64_t wv = 0, wv_pad = 0;   // valid / padded words per row at run time
+    uint32_t run_h = 0;            // num_hashes the row ids of the last K1 were produced with
+    hipEvent_t done = nullptr;     // recorded at the end of every run: fetches wait on it, not on the whole stream, so the
+                                   // results of one batch can be read while the next batch's kernels are queued behind it
+    hipEvent_t k1_done = nullptr;  // only when K1 runs on the pre stream: recorded after K1 (+ row sort), the index stream waits on it before K2
+    hipEvent_t g_done = nullptr;   // recorded on the gather stream after a gathered compaction (it reads K1's per-query arrays)
+    bool dirty = false;            // a run was started and its `done` event has not been recorded (error path): full syncs needed
+    hipStream_t gstream = nullptr; // stream of the gathered compaction (null: the index's stream)
+    const void *g_src = nullptr;   // last gathered buffer handed to compact_gathered
+    uint32_t g_shards = 0;
+    uint64_t g_shard_cols = 0;
+    uint32_t g_own = 0;
+    bool g_masks = false;          // the gathered buffer holds hit masks of a counting run (counts come from this rank's counters)
+    std::vector<uint32_t> h_num_unique, h_num_kmers;
+    bool host_counts_valid = false;
+    // column-shard exchange (bigsi_shard.hip)
+    uint64_t result_cols = 0;      // > 0: width of the per-sample result vectors (the group's shard_cols), so that every shard of
+                                   // an index produces vectors of ONE geometry whatever its own num_cols; 0: the index's num_cols
+    bigsi_hip_comm *comm = nullptr; // attached communicator (bigsi_hip_batch_set_comm)
+    uint64_t shard_cols = 0;
+    DevBuf gbuf;                   // [world][n_seqs][wv_pad] gathered bit vectors; this rank's slot is what K2 writes
+    void *gbuf_ext = nullptr;      // loopback groups: the group's shared buffer instead of gbuf
+};
+
+
+// internal entry points of bigsi_hip.hip used by bigsi_shard.hip
+int bigsi_use_device(const bigsi_hip_index *ix);
+// write pass of the gathered compaction again after the hit buffers grew (fetch_gathered_hits); defined in bigsi_shard.hip
+int bigsi_reduce_gathered_counts(bigsi_hip_batch *b);

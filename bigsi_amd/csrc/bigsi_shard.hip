@@ -1,0 +1,787 @@
+// bigsi_shard.hip -- column shards of one index: the RCCL exchange, device groups, and the one-call search
+// (include/bigsi_hip.h, sections "one-call search" and "column shards").  Host code only, on top of the single-shard entry
+// points of bigsi_hip.hip; the one kernel here sums per-hit count arrays of shards that share a device.
+#include "bigsi_internal.hpp"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // types and prototypes only: the library is loaded at run time
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <set>
+
+// ------------------------------------------------------------------------------ RCCL, loaded on first use
+// dlopen by SONAME: a process that already holds a librccl.so.1 (torch bundles one) gets that copy, anything else finds
+// /opt/rocm's through the library's RUNPATH.  Linking it at build time would pull a second HIP runtime in under torch.
+namespace {
+struct RcclApi {
+    void *handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    char err[256] = "";
+};
+
+RcclApi *rccl()
+{
+    static RcclApi api;
+    static bool tried = false;
+    if (tried) return api.handle ? &api : nullptr;
+    tried = true;
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) {
+        snprintf(api.err, sizeof api.err, "%s", dlerror());
+        return nullptr;
+    }
+    bool ok = true;
+    auto sym = [&](const char *name) -> void * {
+        void *p = dlsym(h, name);
+        if (!p) {
+            ok = false;
+            snprintf(api.err, sizeof api.err, "librccl has no symbol %s", name);
+        }
+        return p;
+    };
+#define RCCL_SYM(field, name) api.field = reinterpret_cast<decltype(api.field)>(sym(name))
+    RCCL_SYM(GetUniqueId, "ncclGetUniqueId");
+    RCCL_SYM(CommInitRank, "ncclCommInitRank");
+    RCCL_SYM(CommInitAll, "ncclCommInitAll");
+    RCCL_SYM(CommDestroy, "ncclCommDestroy");
+    RCCL_SYM(CommCount, "ncclCommCount");
+    RCCL_SYM(CommUserRank, "ncclCommUserRank");
+    RCCL_SYM(AllGather, "ncclAllGather");
+    RCCL_SYM(AllReduce, "ncclAllReduce");
+    RCCL_SYM(GroupStart, "ncclGroupStart");
+    RCCL_SYM(GroupEnd, "ncclGroupEnd");
+    RCCL_SYM(GetErrorString, "ncclGetErrorString");
+#undef RCCL_SYM
+    if (!ok) {
+        dlclose(h);
+        return nullptr;
+    }
+    api.handle = h;
+    return &api;
+}
+
+int need_rccl(RcclApi **out)
+{
+    RcclApi *r = rccl();
+    if (!r) return fail(BIGSI_ERR_STATE, "RCCL is not available (dlopen of librccl.so.1 failed or it lacks a symbol)");
+    *out = r;
+    return BIGSI_OK;
+}
+}   // namespace
+
+#define NCCL_TRY(api, expr)                                                                                                 \
+    do {                                                                                                                    \
+        ncclResult_t r_ = (expr);                                                                                           \
+        if (r_ != ncclSuccess)                                                                                              \
+            return fail(BIGSI_ERR_HIP, "%s:%d %s: %s", __FILE__, __LINE__, #expr, (api)->GetErrorString(r_));            \
+    } while (0)
+
+// ------------------------------------------------------------------------------ one-call search
+extern "C" int bigsi_hip_search_batch(bigsi_hip_index *ix, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k,
+                                      double threshold, uint32_t flags, uint32_t *num_kmers, uint32_t *num_unique, uint32_t *min_kmers,
+                                      uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t hit_capacity)
+{
+    if (!hit_offsets) return fail(BIGSI_ERR_INVALID, "hit_offsets is NULL");
+    bigsi_hip_batch *b = nullptr;
+    TRY(bigsi_hip_batch_create(ix, seqs, offsets, n_seqs, k, &b));
+    int rc = bigsi_hip_batch_run(b, threshold, (flags & ~BIGSI_RUN_SKIP_COMPACT) | BIGSI_RUN_SPARSE_COUNTS);
+    if (rc == BIGSI_OK) rc = bigsi_hip_batch_fetch_unique(b, num_kmers, num_unique, min_kmers);
+    if (rc == BIGSI_OK) rc = bigsi_hip_batch_fetch_hits(b, hit_offsets, colours, counts, hit_capacity);
+    bigsi_hip_batch_destroy(b);      // leaves the thread's error message of a failed call above in place
+    return rc;
+}
+
+// ------------------------------------------------------------------------------ communicators
+struct bigsi_hip_comm {
+    ncclComm_t comm = nullptr;          // null: member of a group whose shards share a device (no RCCL)
+    int rank = 0, world = 1, device = 0;
+    hipStream_t stream = nullptr;       // collectives and gathered compaction run here
+    bigsi_hip_group *group = nullptr;   // non-null: collectives are issued by the group for all its members at once
+};
+
+static int comm_alloc(int device, int rank, int world, bigsi_hip_comm **out)
+{
+    HIP_TRY(hipSetDevice(device));
+    bigsi_hip_comm *c = new (std::nothrow) bigsi_hip_comm();
+    if (!c) return fail(BIGSI_ERR_NOMEM, "host allocation failed");
+    c->rank = rank;
+    c->world = world;
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(BIGSI_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_comm_unique_id(uint8_t *id)
+{
+    if (!id) return fail(BIGSI_ERR_INVALID, "id is NULL");
+    RcclApi *api = nullptr;
+    TRY(need_rccl(&api));
+    static_assert(sizeof(ncclUniqueId) == BIGSI_HIP_COMM_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId u;
+    NCCL_TRY(api, api->GetUniqueId(&u));
+    memcpy(id, &u, sizeof u);
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_comm_init_rank(int device, const uint8_t *id, int rank, int world, bigsi_hip_comm **out)
+{
+    if (!out || !id) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world) return fail(BIGSI_ERR_INVALID, "rank %d not in [0,%d)", rank, world);
+    RcclApi *api = nullptr;
+    TRY(need_rccl(&api));
+    bigsi_hip_comm *c = nullptr;
+    TRY(comm_alloc(device, rank, world, &c));
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    ncclResult_t r = api->CommInitRank(&c->comm, world, u, rank);
+    if (r != ncclSuccess) {
+        hipError_t e = hipStreamDestroy(c->stream); (void)e;
+        delete c;
+        return fail(BIGSI_ERR_HIP, "ncclCommInitRank(rank %d of %d, device %d): %s", rank, world, device, api->GetErrorString(r));
+    }
+    *out = c;
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_comm_destroy(bigsi_hip_comm *c)
+{
+    if (!c) return BIGSI_OK;
+    hipError_t e = hipSetDevice(c->device);
+    if (c->stream) e = hipStreamSynchronize(c->stream);
+    if (c->comm) {
+        RcclApi *api = rccl();
+        if (api) api->CommDestroy(c->comm);
+    }
+    if (c->stream) e = hipStreamDestroy(c->stream);
+    (void)e;
+    delete c;
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_comm_info(const bigsi_hip_comm *c, int *rank, int *world)
+{
+    if (!c) return fail(BIGSI_ERR_INVALID, "NULL communicator");
+    int r = c->rank, w = c->world;
+    if (c->comm) {
+        RcclApi *api = nullptr;
+        TRY(need_rccl(&api));
+        NCCL_TRY(api, api->CommCount(c->comm, &w));
+        NCCL_TRY(api, api->CommUserRank(c->comm, &r));
+    }
+    if (rank) *rank = r;
+    if (world) *world = w;
+    return BIGSI_OK;
+}
+
+// ------------------------------------------------------------------------------ a batch on one shard of a sharded index
+extern "C" int bigsi_hip_batch_set_comm(bigsi_hip_batch *b, bigsi_hip_comm *c, uint64_t shard_cols)
+{
+    if (!b) return fail(BIGSI_ERR_INVALID, "NULL batch");
+    if (!c) {
+        if (b->comm) {      // an exchange of this batch may still be in flight on the communicator's stream
+            TRY(bigsi_use_device(b->ix));
+            if (b->g_done) HIP_TRY(hipEventSynchronize(b->g_done));
+            HIP_TRY(hipStreamSynchronize(b->comm->stream));
+        }
+        b->comm = nullptr;
+        b->shard_cols = b->result_cols = 0;
+        b->ext_bitmaps = nullptr;
+        b->gstream = nullptr;
+        return BIGSI_OK;
+    }
+    bigsi_hip_index *ix = b->ix;
+    if (c->device != ix->device) return fail(BIGSI_ERR_INVALID, "communicator is on device %d, the index on device %d", c->device, ix->device);
+    if (shard_cols == 0 || shard_cols < ix->n_cols)
+        return fail(BIGSI_ERR_INVALID, "shard_cols %llu is smaller than this shard's %llu columns", (unsigned long long)shard_cols,
+                    (unsigned long long)ix->n_cols);
+    if ((uint64_t)c->world * shard_cols > 0xFFFFFFFFull) return fail(BIGSI_ERR_INVALID, "more than 2^32-1 colours in total");
+    TRY(bigsi_hip_reserve_cols(ix, shard_cols));          // no-op when the stride already covers it
+    TRY(bigsi_hip_batch_set_result_cols(b, shard_cols));
+    b->comm = c;
+    b->shard_cols = shard_cols;
+    b->gstream = c->stream;
+    return BIGSI_OK;
+}
+
+// bytes of one shard's slot of the gather buffer for the batch's current load
+static uint64_t slot_bytes(const bigsi_hip_batch *b)
+{
+    const uint64_t wv = ceil_div(std::max(b->ix->n_cols, b->result_cols), 64);
+    return (uint64_t)b->n_seqs * round_up(wv, 2) * 8;
+}
+
+// point K2's output at this rank's slot (growing the library-owned buffer first if the load needs more)
+static int prepare_slot(bigsi_hip_batch *b, void *shared /* loopback groups: one buffer for all members */)
+{
+    const bigsi_hip_comm *c = b->comm;
+    const uint64_t per = slot_bytes(b);
+    uint8_t *g = (uint8_t *)shared;
+    if (!g) {
+        if (b->gbuf.cap < per * c->world) {
+            // the previous exchange of this batch may still be reading the old buffer
+            if (b->done) HIP_TRY(hipEventSynchronize(b->done));
+            if (b->g_done) HIP_TRY(hipEventSynchronize(b->g_done));
+            TRY(b->gbuf.reserve(per * c->world));
+        }
+        g = b->gbuf.as<uint8_t>();
+    }
+    b->gbuf_ext = shared;
+    b->ext_bitmaps = g + per * c->rank;
+    return BIGSI_OK;
+}
+
+static uint8_t *gather_base(const bigsi_hip_batch *b) { return b->gbuf_ext ? (uint8_t *)b->gbuf_ext : b->gbuf.as<uint8_t>(); }
+
+// after the collective: compaction of the gathered vectors on the communicator's stream (already queued behind the run)
+static int compact_after_gather(bigsi_hip_batch *b)
+{
+    const bigsi_hip_comm *c = b->comm;
+    if (b->exact) return bigsi_hip_batch_compact_gathered(b, gather_base(b), (uint32_t)c->world, b->shard_cols);
+    return bigsi_hip_batch_compact_gathered_masks(b, gather_base(b), (uint32_t)c->world, b->shard_cols, (uint32_t)c->rank);
+}
+
+// thresholded searches: every rank filled in the counts of the hits of its own shard, zero elsewhere -> sum over ranks.
+// Fixed size (the capacity of the hit buffers, identical on every rank: it only ever grows with the identical totals).
+int bigsi_reduce_gathered_counts(bigsi_hip_batch *b)
+{
+    bigsi_hip_comm *c = b->comm;
+    if (!c || c->group || !c->comm) return BIGSI_OK;      // groups reduce all their members at once (group_reduce_counts)
+    RcclApi *api = nullptr;
+    TRY(need_rccl(&api));
+    NCCL_TRY(api, api->AllReduce(b->ghits.cnt(), b->ghits.cnt(), b->ghits.capacity(), ncclUint32, ncclSum, c->comm, c->stream));
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_batch_run_sharded(bigsi_hip_batch *b, double threshold, uint32_t flags)
+{
+    if (!b) return fail(BIGSI_ERR_INVALID, "NULL batch");
+    bigsi_hip_comm *c = b->comm;
+    if (!c) return fail(BIGSI_ERR_STATE, "no communicator attached (bigsi_hip_batch_set_comm)");
+    if (c->group) return fail(BIGSI_ERR_STATE, "this batch belongs to a device group: use bigsi_hip_group_batch_run");
+    TRY(bigsi_use_device(b->ix));
+    TRY(prepare_slot(b, nullptr));
+    TRY(bigsi_hip_batch_run(b, threshold, flags | BIGSI_RUN_SKIP_COMPACT | BIGSI_RUN_SPARSE_COUNTS));
+    RcclApi *api = nullptr;
+    TRY(need_rccl(&api));
+    HIP_TRY(hipStreamWaitEvent(c->stream, b->done, 0));
+    // in place: this rank's slot is where its kernels wrote
+    NCCL_TRY(api, api->AllGather(b->ext_bitmaps, gather_base(b), slot_bytes(b), ncclUint8, c->comm, c->stream));
+    TRY(compact_after_gather(b));
+    if (!b->exact) TRY(bigsi_reduce_gathered_counts(b));
+    return BIGSI_OK;
+}
+
+// ------------------------------------------------------------------------------ device groups (one process, several GPUs)
+struct bigsi_hip_group {
+    std::vector<bigsi_hip_index *> ix;
+    std::vector<bigsi_hip_comm *> comm;
+    uint64_t m = 0, n_cols = 0, cap_cols = 0, shard_cols = 0;
+    uint32_t h = 0;
+    bool rccl = false;
+    uint32_t n() const { return (uint32_t)ix.size(); }
+    // columns of the whole index that live on shard i, for a given total
+    uint64_t cols_of(uint32_t i, uint64_t total) const
+    {
+        const uint64_t lo = (uint64_t)i * shard_cols;
+        return total <= lo ? 0 : std::min(shard_cols, total - lo);
+    }
+};
+
+struct bigsi_hip_group_batch {
+    bigsi_hip_group *g = nullptr;
+    std::vector<bigsi_hip_batch *> b;
+    DevBuf shared;                       // loopback groups: the one gather buffer all members write their slot of
+    bool ran = false;
+    uint64_t reduced_cap = 0;            // hit-buffer capacity the last count reduction covered
+};
+
+__global__ void k_add_counts(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, uint64_t n)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) dst[i] += src[i];
+}
+
+extern "C" int bigsi_hip_group_open(uint64_t num_rows, uint64_t num_cols, uint64_t col_capacity, uint32_t num_hashes,
+                                    const int *device_ids, int n_dev, bigsi_hip_group **out)
+{
+    if (!out || !device_ids) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    if (n_dev < 1 || n_dev > 64) return fail(BIGSI_ERR_INVALID, "n_dev %d not in [1,64]", n_dev);
+    if (col_capacity < num_cols) col_capacity = num_cols;
+    if (col_capacity == 0) col_capacity = 64 * (uint64_t)n_dev;
+    bigsi_hip_group *g = new (std::nothrow) bigsi_hip_group();
+    if (!g) return fail(BIGSI_ERR_NOMEM, "host allocation failed");
+    g->m = num_rows;
+    g->h = num_hashes;
+    g->shard_cols = round_up(ceil_div(col_capacity, (uint64_t)n_dev), 64);
+    g->cap_cols = g->shard_cols * (uint64_t)n_dev;
+    g->n_cols = num_cols;
+    if (g->cap_cols > 0xFFFFFFFFull) {
+        delete g;
+        return fail(BIGSI_ERR_INVALID, "more than 2^32-1 colours in total");
+    }
+    std::set<int> distinct(device_ids, device_ids + n_dev);
+    g->rccl = (int)distinct.size() == n_dev;
+    int rc = BIGSI_OK;
+    for (int i = 0; i < n_dev && rc == BIGSI_OK; i++) {
+        bigsi_hip_index *ix = nullptr;
+        rc = bigsi_hip_open(num_rows, g->cols_of((uint32_t)i, num_cols), g->shard_cols, num_hashes, device_ids[i], &ix);
+        if (rc == BIGSI_OK) g->ix.push_back(ix);
+    }
+    for (int i = 0; i < n_dev && rc == BIGSI_OK; i++) {
+        bigsi_hip_comm *c = nullptr;
+        rc = comm_alloc(device_ids[i], i, n_dev, &c);
+        if (rc == BIGSI_OK) {
+            c->group = g;
+            g->comm.push_back(c);
+        }
+    }
+    if (rc == BIGSI_OK && g->rccl) {
+        RcclApi *api = nullptr;
+        rc = need_rccl(&api);
+        if (rc == BIGSI_OK) {
+            std::vector<ncclComm_t> comms(n_dev);
+            ncclResult_t r = api->CommInitAll(comms.data(), n_dev, device_ids);
+            if (r != ncclSuccess) rc = fail(BIGSI_ERR_HIP, "ncclCommInitAll over %d devices: %s", n_dev, api->GetErrorString(r));
+            else
+                for (int i = 0; i < n_dev; i++) g->comm[i]->comm = comms[i];
+        }
+    }
+    if (rc != BIGSI_OK) {
+        char keep[1024];
+        snprintf(keep, sizeof keep, "%s", bigsi_hip_last_error());
+        bigsi_hip_group_close(g);
+        return fail(rc, "%s", keep);
+    }
+    *out = g;
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_group_close(bigsi_hip_group *g)
+{
+    if (!g) return BIGSI_OK;
+    for (auto *c : g->comm) bigsi_hip_comm_destroy(c);
+    for (auto *ix : g->ix) bigsi_hip_close(ix);
+    delete g;
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_group_get_info(const bigsi_hip_group *g, bigsi_hip_group_info *out)
+{
+    if (!g || !out) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    memset(out, 0, sizeof *out);
+    out->num_rows = g->m;
+    out->num_cols = g->n_cols;
+    out->col_capacity = g->cap_cols;
+    out->shard_cols = g->shard_cols;
+    out->row_bytes = ceil_div(g->n_cols, 8);
+    out->num_hashes = g->h;
+    out->n_shards = g->n();
+    out->rccl = g->rccl ? 1 : 0;
+    for (auto *ix : g->ix) {
+        bigsi_hip_info inf;
+        TRY(bigsi_hip_get_info(ix, &inf));
+        out->index_bytes += inf.index_bytes;
+    }
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_group_shard(bigsi_hip_group *g, uint32_t i, bigsi_hip_index **out)
+{
+    if (!g || !out) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    if (i >= g->n()) return fail(BIGSI_ERR_RANGE, "shard %u not in [0,%u)", i, g->n());
+    *out = g->ix[i];
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_group_set_num_cols(bigsi_hip_group *g, uint64_t num_cols)
+{
+    if (!g) return fail(BIGSI_ERR_INVALID, "NULL group");
+    if (num_cols > g->cap_cols)
+        return fail(BIGSI_ERR_CAPACITY, "num_cols %llu exceeds the group's col_capacity %llu (fixed when the group was opened)",
+                    (unsigned long long)num_cols, (unsigned long long)g->cap_cols);
+    for (uint32_t i = 0; i < g->n(); i++) TRY(bigsi_hip_set_num_cols(g->ix[i], g->cols_of(i, num_cols)));
+    g->n_cols = num_cols;
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_group_set_num_hashes(bigsi_hip_group *g, uint32_t num_hashes)
+{
+    if (!g) return fail(BIGSI_ERR_INVALID, "NULL group");
+    for (auto *ix : g->ix) TRY(bigsi_hip_set_num_hashes(ix, num_hashes));
+    g->h = num_hashes;
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_group_synchronize(bigsi_hip_group *g)
+{
+    if (!g) return fail(BIGSI_ERR_INVALID, "NULL group");
+    for (uint32_t i = 0; i < g->n(); i++) {
+        TRY(bigsi_hip_synchronize(g->ix[i]));
+        HIP_TRY(hipStreamSynchronize(g->comm[i]->stream));
+    }
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_group_clear(bigsi_hip_group *g)
+{
+    if (!g) return fail(BIGSI_ERR_INVALID, "NULL group");
+    for (auto *ix : g->ix) TRY(bigsi_hip_clear(ix));
+    return BIGSI_OK;
+}
+
+// whole rows <-> per-shard rows: shard_cols is a multiple of 64, so shard i's bytes are [i * shard_cols / 8, ...) of a row
+extern "C" int bigsi_hip_group_set_rows(bigsi_hip_group *g, const uint64_t *row_ids, uint64_t n, const uint8_t *bytes, uint64_t row_bytes)
+{
+    if (!g || (n && (!row_ids || !bytes))) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    if (row_bytes == 0 || row_bytes > g->cap_cols / 8)
+        return fail(BIGSI_ERR_CAPACITY, "row_bytes %llu not in [1, %llu]", (unsigned long long)row_bytes, (unsigned long long)(g->cap_cols / 8));
+    const uint64_t sb = g->shard_cols / 8;
+    std::vector<uint8_t> part;
+    for (uint32_t i = 0; i < g->n(); i++) {
+        const uint64_t lo = (uint64_t)i * sb;
+        // shards beyond the end of the given bytes are zeroed: bytes past row_bytes read as zero (bigsi_hip_set_rows)
+        const uint64_t w = row_bytes > lo ? std::min(sb, row_bytes - lo) : 0;
+        const uint64_t pw = std::max<uint64_t>(w, 1);
+        part.assign(n * pw, 0);
+        if (w)
+            for (uint64_t r = 0; r < n; r++) memcpy(part.data() + r * pw, bytes + r * row_bytes + lo, w);
+        TRY(bigsi_hip_set_rows(g->ix[i], row_ids, n, part.data(), pw));
+    }
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_group_get_rows(bigsi_hip_group *g, const uint64_t *row_ids, uint64_t n, uint8_t *out, uint64_t row_bytes)
+{
+    if (!g || (n && (!row_ids || !out))) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    if (row_bytes == 0) return fail(BIGSI_ERR_INVALID, "row_bytes is 0");
+    const uint64_t sb = g->shard_cols / 8;
+    memset(out, 0, n * row_bytes);
+    std::vector<uint8_t> part;
+    for (uint32_t i = 0; i < g->n(); i++) {
+        const uint64_t lo = (uint64_t)i * sb;
+        if (row_bytes <= lo) break;
+        const uint64_t w = std::min(sb, row_bytes - lo);
+        part.resize(n * w);
+        TRY(bigsi_hip_get_rows(g->ix[i], row_ids, n, part.data(), w));
+        for (uint64_t r = 0; r < n; r++) memcpy(out + r * row_bytes + lo, part.data() + r * w, w);
+    }
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_group_insert_columns(bigsi_hip_group *g, uint64_t col0, uint64_t n, const uint8_t *blooms, uint64_t bloom_stride_bytes)
+{
+    if (!g || (n && !blooms)) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    if (col0 > g->n_cols) return fail(BIGSI_ERR_RANGE, "column %llu beyond num_cols %llu", (unsigned long long)col0, (unsigned long long)g->n_cols);
+    if (col0 + n > g->cap_cols)
+        return fail(BIGSI_ERR_CAPACITY, "columns [%llu,%llu) beyond the group's col_capacity %llu", (unsigned long long)col0,
+                    (unsigned long long)(col0 + n), (unsigned long long)g->cap_cols);
+    const uint64_t total = std::max(g->n_cols, col0 + n);
+    for (uint64_t c = col0; c < col0 + n;) {
+        const uint32_t i = (uint32_t)(c / g->shard_cols);
+        const uint64_t local = c - (uint64_t)i * g->shard_cols;
+        const uint64_t cnt = std::min(col0 + n - c, g->shard_cols - local);
+        // the shard's own num_cols must reach `local` before it can take columns there (earlier shards are full by then)
+        bigsi_hip_info inf;
+        TRY(bigsi_hip_get_info(g->ix[i], &inf));
+        if (inf.num_cols < local) TRY(bigsi_hip_set_num_cols(g->ix[i], local));
+        TRY(bigsi_hip_insert_columns(g->ix[i], local, cnt, blooms + (c - col0) * bloom_stride_bytes, bloom_stride_bytes));
+        c += cnt;
+    }
+    return bigsi_hip_group_set_num_cols(g, total);
+}
+
+static int locate_col(bigsi_hip_group *g, uint64_t col, uint32_t *shard, uint64_t *local)
+{
+    if (col >= g->cap_cols) return fail(BIGSI_ERR_RANGE, "column %llu beyond col_capacity %llu", (unsigned long long)col, (unsigned long long)g->cap_cols);
+    *shard = (uint32_t)(col / g->shard_cols);
+    *local = col - (uint64_t)*shard * g->shard_cols;
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_group_get_column(bigsi_hip_group *g, uint64_t col, uint8_t *out)
+{
+    if (!g || !out) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    uint32_t i;
+    uint64_t local;
+    TRY(locate_col(g, col, &i, &local));
+    return bigsi_hip_get_column(g->ix[i], local, out);
+}
+
+extern "C" int bigsi_hip_group_insert_kmers(bigsi_hip_group *g, uint64_t col, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k)
+{
+    if (!g) return fail(BIGSI_ERR_INVALID, "NULL group");
+    if (col >= g->n_cols) return fail(BIGSI_ERR_RANGE, "column %llu >= num_cols %llu", (unsigned long long)col, (unsigned long long)g->n_cols);
+    uint32_t i;
+    uint64_t local;
+    TRY(locate_col(g, col, &i, &local));
+    return bigsi_hip_insert_kmers(g->ix[i], local, seqs, offsets, n_seqs, k);
+}
+
+extern "C" int bigsi_hip_group_fill_synthetic(bigsi_hip_group *g, uint64_t seed, uint32_t and_draws)
+{
+    if (!g) return fail(BIGSI_ERR_INVALID, "NULL group");
+    for (uint32_t i = 0; i < g->n(); i++) TRY(bigsi_hip_fill_synthetic(g->ix[i], seed, i, and_draws));
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_group_lookup(bigsi_hip_group *g, const char *kmers, uint32_t k, uint64_t u, uint8_t *out_rows)
+{
+    if (!g || (u && (!kmers || !out_rows))) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    if (g->n_cols == 0) return fail(BIGSI_ERR_STATE, "index has no columns");
+    const uint64_t rb = ceil_div(g->n_cols, 8), sb = g->shard_cols / 8;
+    std::vector<uint8_t> part;
+    for (uint32_t i = 0; i < g->n(); i++) {
+        const uint64_t nc = g->cols_of(i, g->n_cols);
+        if (!nc) break;
+        const uint64_t w = ceil_div(nc, 8);
+        part.resize(u * w);
+        TRY(bigsi_hip_lookup(g->ix[i], kmers, k, u, part.data()));
+        for (uint64_t r = 0; r < u; r++) memcpy(out_rows + r * rb + (uint64_t)i * sb, part.data() + r * w, w);
+    }
+    return BIGSI_OK;
+}
+
+// ---- fused query path over all shards
+extern "C" int bigsi_hip_group_batch_create(bigsi_hip_group *g, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k,
+                                            bigsi_hip_group_batch **out)
+{
+    if (!g || !out) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    bigsi_hip_group_batch *gb = new (std::nothrow) bigsi_hip_group_batch();
+    if (!gb) return fail(BIGSI_ERR_NOMEM, "host allocation failed");
+    gb->g = g;
+    int rc = BIGSI_OK;
+    for (uint32_t i = 0; i < g->n() && rc == BIGSI_OK; i++) {
+        bigsi_hip_batch *b = nullptr;
+        rc = bigsi_hip_batch_create(g->ix[i], seqs, offsets, n_seqs, k, &b);
+        if (rc == BIGSI_OK) {
+            gb->b.push_back(b);
+            rc = bigsi_hip_batch_set_comm(b, g->comm[i], g->shard_cols);
+        }
+    }
+    if (rc != BIGSI_OK) {
+        char keep[1024];
+        snprintf(keep, sizeof keep, "%s", bigsi_hip_last_error());
+        bigsi_hip_group_batch_destroy(gb);
+        return fail(rc, "%s", keep);
+    }
+    *out = gb;
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_group_batch_reload(bigsi_hip_group_batch *gb, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k)
+{
+    if (!gb) return fail(BIGSI_ERR_INVALID, "NULL batch");
+    gb->ran = false;
+    for (auto *b : gb->b) TRY(bigsi_hip_batch_reload(b, seqs, offsets, n_seqs, k));
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_group_batch_destroy(bigsi_hip_group_batch *gb)
+{
+    if (!gb) return BIGSI_OK;
+    for (auto *b : gb->b) bigsi_hip_batch_destroy(b);
+    if (gb->shared.p && !gb->g->ix.empty()) {
+        hipError_t e = hipSetDevice(gb->g->ix[0]->device); (void)e;
+    }
+    gb->shared.release();
+    delete gb;
+    return BIGSI_OK;
+}
+
+// sum of the members' per-hit count arrays, over `cap` entries: RCCL all-reduce, or -- shards sharing a device -- an add
+// kernel into every member's array in turn (each ends up with the sum, as after an all-reduce)
+static int group_reduce_counts(bigsi_hip_group_batch *gb)
+{
+    bigsi_hip_group *g = gb->g;
+    const uint64_t cap = gb->b[0]->ghits.capacity();
+    for (auto *b : gb->b)
+        if (b->ghits.capacity() != cap) return fail(BIGSI_ERR_STATE, "hit buffers of the shards have diverged");
+    gb->reduced_cap = cap;
+    if (g->rccl) {
+        RcclApi *api = nullptr;
+        TRY(need_rccl(&api));
+        NCCL_TRY(api, api->GroupStart());
+        for (uint32_t i = 0; i < g->n(); i++) {
+            bigsi_hip_batch *b = gb->b[i];
+            HIP_TRY(hipSetDevice(g->ix[i]->device));
+            ncclResult_t r = api->AllReduce(b->ghits.cnt(), b->ghits.cnt(), cap, ncclUint32, ncclSum, g->comm[i]->comm, g->comm[i]->stream);
+            if (r != ncclSuccess) {
+                api->GroupEnd();
+                return fail(BIGSI_ERR_HIP, "ncclAllReduce on shard %u: %s", i, api->GetErrorString(r));
+            }
+        }
+        NCCL_TRY(api, api->GroupEnd());
+        return BIGSI_OK;
+    }
+    // one device: member 0 collects (the host only ever reads member 0's lists)
+    HIP_TRY(hipSetDevice(g->ix[0]->device));
+    hipStream_t s0 = g->comm[0]->stream;
+    for (uint32_t i = 1; i < g->n(); i++) {
+        HIP_TRY(hipStreamWaitEvent(s0, gb->b[i]->g_done, 0));
+        hipLaunchKernelGGL(k_add_counts, dim3(256), dim3(256), 0, s0, gb->b[0]->ghits.cnt(), gb->b[i]->ghits.cnt(), cap);
+        HIP_TRY(hipGetLastError());
+    }
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_group_batch_run(bigsi_hip_group_batch *gb, double threshold, uint32_t flags)
+{
+    if (!gb) return fail(BIGSI_ERR_INVALID, "NULL batch");
+    bigsi_hip_group *g = gb->g;
+    gb->ran = false;
+    void *shared = nullptr;
+    if (!g->rccl) {
+        // every member's slot lives in ONE buffer on the shared device: the "all-gather" is the kernels' own stores
+        const uint64_t need = slot_bytes(gb->b[0]) * g->n();
+        HIP_TRY(hipSetDevice(g->ix[0]->device));
+        if (gb->shared.cap < need) {
+            for (auto *b : gb->b) {
+                if (b->done) HIP_TRY(hipEventSynchronize(b->done));
+                if (b->g_done) HIP_TRY(hipEventSynchronize(b->g_done));
+            }
+            TRY(gb->shared.reserve(need));
+        }
+        shared = gb->shared.p;
+    }
+    // K1-K3 on every device, asynchronously
+    for (uint32_t i = 0; i < g->n(); i++) {
+        bigsi_hip_batch *b = gb->b[i];
+        TRY(bigsi_use_device(b->ix));
+        if (shared)      // a member's K2 overwrites its slot: every member's previous compaction of the shared buffer must be over
+            for (auto *o : gb->b)
+                if (o != b && o->g_done) HIP_TRY(hipStreamWaitEvent(b->ix->stream, o->g_done, 0));
+        TRY(prepare_slot(b, shared));
+        TRY(bigsi_hip_batch_run(b, threshold, flags | BIGSI_RUN_SKIP_COMPACT | BIGSI_RUN_SPARSE_COUNTS));
+    }
+    // the exchange
+    if (g->rccl) {
+        RcclApi *api = nullptr;
+        TRY(need_rccl(&api));
+        for (uint32_t i = 0; i < g->n(); i++) {
+            HIP_TRY(hipSetDevice(g->ix[i]->device));
+            HIP_TRY(hipStreamWaitEvent(g->comm[i]->stream, gb->b[i]->done, 0));
+        }
+        NCCL_TRY(api, api->GroupStart());
+        for (uint32_t i = 0; i < g->n(); i++) {
+            bigsi_hip_batch *b = gb->b[i];
+            HIP_TRY(hipSetDevice(g->ix[i]->device));
+            ncclResult_t r = api->AllGather(b->ext_bitmaps, gather_base(b), slot_bytes(b), ncclUint8, g->comm[i]->comm, g->comm[i]->stream);
+            if (r != ncclSuccess) {
+                api->GroupEnd();
+                return fail(BIGSI_ERR_HIP, "ncclAllGather on shard %u: %s", i, api->GetErrorString(r));
+            }
+        }
+        NCCL_TRY(api, api->GroupEnd());
+    } else {
+        HIP_TRY(hipSetDevice(g->ix[0]->device));
+        for (uint32_t i = 0; i < g->n(); i++)
+            for (auto *o : gb->b) HIP_TRY(hipStreamWaitEvent(g->comm[i]->stream, o->done, 0));     // every slot written
+    }
+    for (uint32_t i = 0; i < g->n(); i++) {
+        TRY(bigsi_use_device(gb->b[i]->ix));
+        TRY(compact_after_gather(gb->b[i]));
+    }
+    if (!gb->b[0]->exact) TRY(group_reduce_counts(gb));
+    gb->ran = true;
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_group_batch_fetch_unique(bigsi_hip_group_batch *gb, uint32_t *num_kmers, uint32_t *num_unique, uint32_t *min_kmers)
+{
+    if (!gb) return fail(BIGSI_ERR_INVALID, "NULL batch");
+    if (!gb->ran) return fail(BIGSI_ERR_STATE, "bigsi_hip_group_batch_run has not completed for this batch");
+    return bigsi_hip_batch_fetch_unique(gb->b[0], num_kmers, num_unique, min_kmers);     // K1 is the same on every shard
+}
+
+extern "C" int bigsi_hip_group_batch_fetch_hits(bigsi_hip_group_batch *gb, uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t capacity)
+{
+    if (!gb) return fail(BIGSI_ERR_INVALID, "NULL batch");
+    if (!gb->ran) return fail(BIGSI_ERR_STATE, "bigsi_hip_group_batch_run has not completed for this batch");
+    if (!hit_offsets) return fail(BIGSI_ERR_INVALID, "hit_offsets is NULL");
+    bigsi_hip_group *g = gb->g;
+    if (!gb->b[0]->exact) {
+        // a fetch with unbounded caller capacity makes every member grow + rewrite its lists if they overflowed (all members
+        // see the same totals); the counts then have to be summed again over the larger arrays
+        for (uint32_t i = 0; i < g->n(); i++) {
+            TRY(bigsi_use_device(gb->b[i]->ix));
+            TRY(bigsi_hip_batch_fetch_gathered_hits(gb->b[i], hit_offsets, nullptr, nullptr, ~0ull));
+        }
+        if (gb->b[0]->ghits.capacity() != gb->reduced_cap) {
+            if (!g->rccl)      // the rewritten arrays hold own-shard counts only; member 0's add must see them complete
+                for (uint32_t i = 1; i < g->n(); i++) {
+                    HIP_TRY(hipSetDevice(g->ix[i]->device));
+                    HIP_TRY(hipEventRecord(gb->b[i]->g_done, g->comm[i]->stream));
+                }
+            TRY(group_reduce_counts(gb));
+        }
+    }
+    TRY(bigsi_use_device(gb->b[0]->ix));
+    return bigsi_hip_batch_fetch_gathered_hits(gb->b[0], hit_offsets, colours, counts, capacity);
+}
+
+extern "C" int bigsi_hip_group_batch_presence(bigsi_hip_group_batch *gb, uint32_t seq, const uint32_t *colours, uint32_t n_colours, uint8_t *out)
+{
+    if (!gb) return fail(BIGSI_ERR_INVALID, "NULL batch");
+    if (!gb->ran) return fail(BIGSI_ERR_STATE, "bigsi_hip_group_batch_run has not completed for this batch");
+    if (n_colours == 0) return BIGSI_OK;
+    if (!colours || !out) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    bigsi_hip_group *g = gb->g;
+    for (uint32_t j = 0; j < n_colours; j++)
+        if (colours[j] >= g->n_cols) return fail(BIGSI_ERR_RANGE, "colour %u >= num_cols", colours[j]);
+    std::vector<uint32_t> nk(gb->b[0]->n_seqs);
+    TRY(bigsi_hip_batch_fetch_unique(gb->b[0], nk.data(), nullptr, nullptr));
+    if (seq >= nk.size()) return fail(BIGSI_ERR_RANGE, "sequence %u out of range", seq);
+    const uint32_t n = nk[seq];
+    if (n == 0) return BIGSI_OK;
+    // each colour's string is produced on the device that owns the column (K5 there), then placed in the caller's order
+    std::vector<uint32_t> local, where;
+    std::vector<uint8_t> part;
+    for (uint32_t i = 0; i < g->n(); i++) {
+        local.clear();
+        where.clear();
+        for (uint32_t j = 0; j < n_colours; j++)
+            if (colours[j] / g->shard_cols == i) {
+                local.push_back((uint32_t)(colours[j] - (uint64_t)i * g->shard_cols));
+                where.push_back(j);
+            }
+        if (local.empty()) continue;
+        part.resize((size_t)local.size() * n);
+        TRY(bigsi_hip_batch_presence(gb->b[i], seq, local.data(), (uint32_t)local.size(), part.data()));
+        for (size_t t = 0; t < local.size(); t++) memcpy(out + (size_t)where[t] * n, part.data() + t * n, n);
+    }
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_group_search_batch(bigsi_hip_group *g, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k,
+                                            double threshold, uint32_t flags, uint32_t *num_kmers, uint32_t *num_unique, uint32_t *min_kmers,
+                                            uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t hit_capacity)
+{
+    if (!hit_offsets) return fail(BIGSI_ERR_INVALID, "hit_offsets is NULL");
+    bigsi_hip_group_batch *gb = nullptr;
+    TRY(bigsi_hip_group_batch_create(g, seqs, offsets, n_seqs, k, &gb));
+    int rc = bigsi_hip_group_batch_run(gb, threshold, flags);
+    if (rc == BIGSI_OK) rc = bigsi_hip_group_batch_fetch_unique(gb, num_kmers, num_unique, min_kmers);
+    if (rc == BIGSI_OK) rc = bigsi_hip_group_batch_fetch_hits(gb, hit_offsets, colours, counts, hit_capacity);
+    bigsi_hip_group_batch_destroy(gb);
+    return rc;
+}

@@ -9,7 +9,7 @@ import logging
 
 import numpy as np
 
-from ..bitrow import BitRow
+from ..bitrow import BitRow, row_bytes_of
 from ..bloom import _device_bloom
 from ..scoring import Scorer
 from ..storage import get_storage
@@ -120,6 +120,21 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
         logger.warning("Build and merge is preferable to insert in most cases")
         colour = self.add_sample(sample)
         self.insert_bloom(bloomfilter, colour - 1)
+
+    def insert_many(self, bloomfilters, samples):
+        """Append several samples at once: their filters become the next columns through ONE device transpose
+        (bigsi_hip_insert_columns) instead of a column-at-a-time loop.  Same result as insert() called for each in turn
+        (graph/bigsi.py:244-247)."""
+        validate_build_params(bloomfilters, samples)
+        col0 = self.num_samples
+        self.add_samples(samples)
+        nb = (int(self.bloomfilter_size) + 7) // 8
+        arr = np.zeros((len(bloomfilters), nb), dtype=np.uint8)
+        for i, bf in enumerate(bloomfilters):
+            data = np.frombuffer(row_bytes_of(getattr(bf, "bitarray", bf))[0], dtype=np.uint8)[:nb]
+            arr[i, : data.size] = data
+        self.storage.insert_columns(col0, arr)
+        self.bitmatrix.set_num_cols(max(self.bitmatrix.num_cols, col0 + len(bloomfilters)))
 
     def delete(self):
         for batch in self.__dict__.pop("_workspaces", {}).values():

@@ -36,8 +36,10 @@ class KmerSignatureIndex(object):
         storage.set_integer("number_of_cols", 0)
         # transpose on the device, a slab of filters at a time (the reference materialises an N x m bool array,
         # matrix/transpose.py:37-40)
+        # `lowmem` (the reference's low_mem_build, matrix/transpose.py:14-30: transpose in row chunks to bound host memory):
+        # here the bound is the host staging slab, 16 MB of filters at a time instead of 128 MB
         nb = (int(bloomfilter_size) + 7) // 8
-        slab = max(64, ((128 << 20) // max(nb, 1)) // 64 * 64)
+        slab = max(64, (((16 if lowmem else 128) << 20) // max(nb, 1)) // 64 * 64)
         for c0 in range(0, len(blooms), slab):
             part = blooms[c0:c0 + slab]
             arr = np.zeros((len(part), nb), dtype=np.uint8)

@@ -4,9 +4,10 @@ Every stage of the query path is independent per sample column -- hashing depend
 counting are per column -- so rank g (one process per GPU) holds ALL m rows of columns
 [g * shard_cols, (g+1) * shard_cols) and runs K1-K3 on its slice for the same query batch.  The only exchange is
 one all-gather per batch of ONE BIT PER SAMPLE -- the AND bitmap of an exact search, or the `count >= min_kmers` hit mask
-the counting kernel leaves for a thresholded one -- RCCL over xGMI through torch.distributed (backend "nccl" is RCCL on
-ROCm).  The local vector is written by the kernels straight into this rank's slot of the gather buffer
-(bigsi_hip_batch_set_outputs), so the collective runs in place; compaction to (colour, count) lists then runs on every
+the counting kernel leaves for a thresholded one -- RCCL over xGMI, issued by libbigsi_hip.so itself on its own
+communicator (include/bigsi_hip.h, "column shards"); torch.distributed is the launcher-side plumbing (rendezvous, the
+128-byte communicator id, barriers).  The local vector is written by the kernels straight into this rank's slot of the
+gather buffer, so the collective runs in place; compaction to (colour, count) lists then runs on every
 rank over the gathered [shard][seq][stride] buffer with colour = shard * shard_cols + local column.  For a thresholded
 search each rank fills the counts of the hits that lie in ITS shard from its own counters (zero elsewhere) and one small
 fixed-size all-reduce (sum) of the per-hit count array completes the lists: 3.2 MB + 256 KB per rank and batch at C3
@@ -57,86 +58,136 @@ class ShardGroup(object):
 
 
 class ShardedSearch(object):
-    """Query batches against this rank's column shard + the collective that makes every rank see the whole result.
+    """Query batches against this rank's column shard + the exchange that makes every rank see the whole result.
 
-    Two torch streams.  `stream` (compute) carries the library's K1-K3 kernels (bigsi_hip_set_stream); `comm` carries the
-    RCCL all-gather and the compaction of the gathered buffer (bigsi_hip_batch_set_gather_stream).  With two batches /
-    gather buffers used alternately (`slots=2`) the exchange of batch i overlaps the row-AND kernels of batch i+1:
-        compute:  run(i) ---------------- run(i+1) ------------- run(i+2) ...
-        comm:            gather(i) K4g(i)          gather(i+1) K4g(i+1)
-    Events order the two: comm waits for run(i); run(i+2) waits until gather/compaction of batch i released its buffer.
+    exchange="rccl" (default whenever the process group's backend is RCCL, or there is no process group): the library
+    itself issues ncclAllGather / ncclAllReduce on its own communicator and stream (bigsi_hip_comm_init_rank,
+    bigsi_hip_batch_run_sharded); torch.distributed only carries the 128-byte communicator id to the other ranks once.
+        index stream:  run(i) ---------------- run(i+1) ------------- run(i+2) ...
+        comm stream:          gather(i) K4g(i)          gather(i+1) K4g(i+1)
+    With two batches used alternately the exchange of batch i overlaps the row-AND kernels of batch i+1; events inside the
+    library order the two streams, the host never waits between steps.
+
+    exchange="torch": the same schedule with torch.distributed collectives on two torch streams -- for process groups
+    whose backend is not RCCL (gloo: several ranks sharing one GPU in tests; RCCL refuses two ranks on one device).
     (torch's default stream has handle 0, which the C ABI reserves for "use the library's private stream", hence the
     explicit side streams.)"""
 
-    def __init__(self, storage, shard_cols, group=None, device=None, force_gather=False, slots=2):
+    def __init__(self, storage, shard_cols, group=None, device=None, force_gather=False, slots=2, exchange=None):
         import torch
         self.torch = torch
-        self.force_gather = force_gather      # take the all-gather path even with one rank (testing)
+        self.force_gather = force_gather      # take the gather path even with one rank (testing)
         self.storage = storage
         self.shard_cols = int(shard_cols)
         self.sg = ShardGroup(group)
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
-        self.stream = torch.cuda.Stream(self.device)
-        self.comm = torch.cuda.Stream(self.device)
-        check(_lib.lib().bigsi_hip_set_stream(storage.handle, self.stream.cuda_stream))
+        if exchange is None:
+            backend = self.sg.dist.get_backend(group) if self.sg.dist.is_initialized() else "nccl"
+            exchange = "rccl" if "nccl" in str(backend) else "torch"
+        assert exchange in ("rccl", "torch")
+        self.exchange = exchange
+        self.comm = None
         self.slots = int(slots)
-        self._bufs = [None] * self.slots
-        self._hitbufs = [None] * self.slots       # (colours, counts) int32 tensors of the gathered hit lists, per slot
-        self._slot_of = {}
         self._exact = True
-        self._ev_run = [torch.cuda.Event() for _ in range(self.slots)]
-        self._ev_free = [None] * self.slots       # recorded on comm when a slot's gather + compaction are done
         self._i = 0
+        if not self.gathering:
+            return
+        L = _lib.lib()
+        inf = storage.res.info()
+        if inf.col_capacity < self.shard_cols:       # every shard is as wide as the widest: one geometry for the exchange
+            check(L.bigsi_hip_reserve_cols(storage.handle, self.shard_cols))
+        if exchange == "rccl":
+            ident = np.zeros(128, np.uint8)
+            if self.sg.rank == 0:
+                check(L.bigsi_hip_comm_unique_id(_lib.ptr(ident)))
+            if self.sg.dist.is_initialized() and self.sg.world > 1:
+                box = [ident.tobytes()]
+                self.sg.dist.broadcast_object_list(box, src=self.sg.dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                ident = np.frombuffer(box[0], np.uint8).copy()
+            out = _lib.C.c_void_p()
+            check(L.bigsi_hip_comm_init_rank(int(self.device.index), _lib.ptr(ident), self.sg.rank, self.sg.world, _lib.C.byref(out)))
+            self.comm = out
+        else:
+            self.stream = torch.cuda.Stream(self.device)
+            self.comm_stream = torch.cuda.Stream(self.device)
+            check(L.bigsi_hip_set_stream(storage.handle, self.stream.cuda_stream))
+            self._bufs = [None] * self.slots
+            self._hitbufs = [None] * self.slots       # (colours, counts) int32 tensors of the gathered hit lists, per slot
+            self._slot_of = {}
+            self._ev_run = [torch.cuda.Event() for _ in range(self.slots)]
+            self._ev_free = [None] * self.slots       # recorded on comm when a slot's gather + compaction are done
 
     @property
     def gathering(self):
         return self.sg.world > 1 or self.force_gather
 
+    def comm_ranks(self):
+        """(rank, world) as the library's RCCL communicator reports them; None without one."""
+        if self.comm is None:
+            return None
+        r, w = _lib.C.c_int(0), _lib.C.c_int(0)
+        check(_lib.lib().bigsi_hip_comm_info(self.comm, _lib.C.byref(r), _lib.C.byref(w)))
+        return r.value, w.value
+
     def close(self):
-        check(_lib.lib().bigsi_hip_set_stream(self.storage.handle, None))
+        if not self.gathering:
+            return
+        if self.exchange == "torch":
+            check(_lib.lib().bigsi_hip_set_stream(self.storage.handle, None))
+        elif self.comm is not None:
+            for b in list(self.storage.res.batches):
+                if b.b is not None:
+                    check(_lib.lib().bigsi_hip_batch_set_comm(b.b, None, 0))
+            check(_lib.lib().bigsi_hip_comm_destroy(self.comm))
+            self.comm = None
 
     def prepare(self, batches, exact, count_bytes=2):
-        """Give each batch (one per slot) its own [world, n_seqs*stride] gather buffer and point the batch's result at
-        this rank's slot of it."""
+        """Attach each batch (one per slot) to the exchange: results `shard_cols` wide, written straight into this rank's
+        slot of a [world, n_seqs * stride] gather buffer."""
         if not isinstance(batches, (list, tuple)):
             batches = [batches]
         if not self.gathering:
             return
-        assert len(batches) <= self.slots
-        inf = self.storage.res.info()
-        wv_pad = (-(-int(inf.num_cols) // 64) + 1) // 2 * 2
-        stride_bytes = wv_pad * 8                   # one bit per sample, exact bitmap or thresholded hit mask
         self._exact = bool(exact)
+        L = _lib.lib()
+        if self.exchange == "rccl":
+            for batch in batches:
+                check(L.bigsi_hip_batch_set_comm(batch.b, self.comm, self.shard_cols))
+            return
+        assert len(batches) <= self.slots
+        wv_pad = (-(-self.shard_cols // 64) + 1) // 2 * 2     # from the group's shard width, NOT this rank's own num_cols
+        stride_bytes = wv_pad * 8                   # one bit per sample, exact bitmap or thresholded hit mask
         self._slot_of = {id(batch): s for s, batch in enumerate(batches)}
         for s, batch in enumerate(batches):
+            check(L.bigsi_hip_batch_set_result_cols(batch.b, self.shard_cols))
             need = batch.n * stride_bytes
             if self._bufs[s] is None or self._bufs[s].shape[1] != need:      # buffers are kept across calls of one shape
                 with self.torch.cuda.stream(self.stream):
                     self._bufs[s] = self.sg.gather_buffer(need, self.device)
             slot = self._bufs[s][self.sg.rank].data_ptr()
-            check(_lib.lib().bigsi_hip_batch_set_outputs(batch.b, slot, None))
-            check(_lib.lib().bigsi_hip_batch_set_gather_stream(batch.b, self.comm.cuda_stream))
+            check(L.bigsi_hip_batch_set_outputs(batch.b, slot, None))
+            check(L.bigsi_hip_batch_set_gather_stream(batch.b, self.comm_stream.cuda_stream))
             if exact:
-                check(_lib.lib().bigsi_hip_batch_set_gathered_hit_outputs(batch.b, None, None, 0))
+                check(L.bigsi_hip_batch_set_gathered_hit_outputs(batch.b, None, None, 0))
             elif self._hitbufs[s] is None:
                 self._set_hit_capacity(s, batch, 1 << 16)
             else:
                 col, cnt = self._hitbufs[s]
-                check(_lib.lib().bigsi_hip_batch_set_gathered_hit_outputs(batch.b, col.data_ptr(), cnt.data_ptr(), col.numel()))
+                check(L.bigsi_hip_batch_set_gathered_hit_outputs(batch.b, col.data_ptr(), cnt.data_ptr(), col.numel()))
         self.stream.synchronize()
 
     def _set_hit_capacity(self, s, batch, cap):
         """(Re)allocate slot s's gathered hit list buffers: torch tensors, because the counts get all-reduced."""
         torch = self.torch
-        with torch.cuda.stream(self.comm):
+        with torch.cuda.stream(self.comm_stream):
             col = torch.zeros(cap, dtype=torch.int32, device=self.device)
             cnt = torch.zeros(cap, dtype=torch.int32, device=self.device)
-        self.comm.synchronize()
+        self.comm_stream.synchronize()
         self._hitbufs[s] = (col, cnt)
         check(_lib.lib().bigsi_hip_batch_set_gathered_hit_outputs(batch.b, col.data_ptr(), cnt.data_ptr(), cap))
 
     def _exchange(self, s, batch):
-        """On the comm stream: all-gather the bit vectors, compact, and (thresholded) sum the per-hit counts."""
+        """torch exchange, on the comm stream: all-gather the bit vectors, compact, and (thresholded) sum the per-hit counts."""
         self.sg.all_gather_in_place(self._bufs[s])
         if self._exact:
             check(_lib.lib().bigsi_hip_batch_compact_gathered(batch.b, self._bufs[s].data_ptr(), self.sg.world, self.shard_cols))
@@ -147,8 +198,8 @@ class ShardedSearch(object):
                 self.sg.dist.all_reduce(self._hitbufs[s][1], group=self.sg.group)
 
     def step(self, batches, threshold):
-        """Asynchronous.  Alone: K1-K4 of the next batch.  Sharded: K1-K3 on the compute stream, then all-gather of the
-        per-sample vectors + K4 over the gathered result on the comm stream."""
+        """Asynchronous.  Alone: K1-K4 of the next batch.  Sharded: K1-K3, then all-gather of the per-sample vectors + K4
+        over the gathered result on the communicator's stream."""
         if not isinstance(batches, (list, tuple)):
             batches = [batches]
         s = self._i % len(batches)
@@ -157,24 +208,27 @@ class ShardedSearch(object):
         if not self.gathering:
             batch.run(threshold, sparse_counts=True)
             return
+        if self.exchange == "rccl":
+            check(_lib.lib().bigsi_hip_batch_run_sharded(batch.b, float(threshold), 0))
+            return
         torch = self.torch
         with torch.cuda.stream(self.stream):
             if self._ev_free[s] is not None:
                 self.stream.wait_event(self._ev_free[s])        # this slot's previous exchange has released the buffer
             batch.run(threshold, skip_compact=True, sparse_counts=True)
             self._ev_run[s].record(self.stream)
-        with torch.cuda.stream(self.comm):
-            self.comm.wait_event(self._ev_run[s])
+        with torch.cuda.stream(self.comm_stream):
+            self.comm_stream.wait_event(self._ev_run[s])
             self._exchange(s, batch)
             if self._ev_free[s] is None:
                 self._ev_free[s] = torch.cuda.Event()
-            self._ev_free[s].record(self.comm)
+            self._ev_free[s].record(self.comm_stream)
 
     def fetch(self, batch, slot=None):
         if not self.gathering:
             return batch.hits()
         off = np.zeros(batch.n + 1, np.uint64)
-        if not self._exact:
+        if self.exchange == "torch" and not self._exact:
             # caller-owned hit buffers: on overflow grow them and redo this batch's exchange (rare: > capacity hits)
             s = slot if slot is not None else self._slot_of[id(batch)]
             while True:
@@ -184,11 +238,12 @@ class ShardedSearch(object):
                 rc = _lib.lib().bigsi_hip_batch_fetch_gathered_hits(batch.b, _lib.ptr(off), _lib.ptr(col), _lib.ptr(cnt), cap)
                 if rc == _lib.ERR_CAPACITY:
                     self._set_hit_capacity(s, batch, 1 << int(off[-1] - 1).bit_length())
-                    with self.torch.cuda.stream(self.comm):
+                    with self.torch.cuda.stream(self.comm_stream):
                         self._exchange(s, batch)
                     continue
                 check(rc)
                 return off, col[: int(off[-1])], cnt[: int(off[-1])]
+        # library-owned hit lists (they grow inside the library; with RCCL every rank re-reduces the counts identically)
         cap = 1 << 12
         while True:
             col = np.zeros(cap, np.uint32)

@@ -12,6 +12,10 @@ storage-config keys
                  outlives any one storage object (BIGSI.build closes and re-opens its storage,
                  bigsi/graph/bigsi.py:171-172).  default "default"
     device       HIP device ordinal.  default 0
+    devices      list of HIP device ordinals: ONE index split by column range over several GPUs of this process
+                 (bigsi_hip_group_*: one shard per device, RCCL all-gather of the per-sample result bits inside every
+                 query batch).  The column capacity (`max_cols`) is then fixed: shard width = ceil(max_cols / n) rounded
+                 up to 64, colour c lives on device c // width.  A device may be repeated (tests on a one-GPU box)
     m, h         rows / hashes, if known before the first row arrives (get_storage() copies them from the
                  top-level config); otherwise rows are buffered until `number_of_rows` is stored
     max_cols     initial column capacity (grown on demand by re-striding on the device).  default 1024
@@ -40,12 +44,23 @@ class _Resident(object):
     def __init__(self, cfg):
         self.cfg = dict(cfg)
         self.device = int(cfg.get("device", 0))
+        self.devices = [int(d) for d in cfg["devices"]] if cfg.get("devices") else None   # group mode (bigsi_hip_group_*)
         self.kv = {}                 # bytes -> bytes, everything that is not a row
         self.ix = None               # bigsi_hip_index*
         self.m = None
         self.pending = {}            # row -> bytes, only while m is unknown
         self.written = None          # np.bool_[m]: rows that have been stored (KeyError semantics of a KV store)
+        self.uniform_len = None      # byte length every stored row was given (None: as wide as the index is now)
+        self.rowlen = None           # np.uint32[m] once rows of differing lengths have been stored
         self.batches = weakref.WeakSet()   # live QueryBatch objects: they hold the index handle and must die before it
+
+    @property
+    def is_group(self):
+        return self.devices is not None
+
+    def fn(self, name):
+        """The C entry point `name` for this index: bigsi_hip_<name>, or bigsi_hip_group_<name> for a multi-GPU group."""
+        return getattr(_lib.lib(), ("bigsi_hip_group_" if self.is_group else "bigsi_hip_") + name)
 
     # ---- device lifecycle
     def _hint(self, key):
@@ -59,7 +74,11 @@ class _Resident(object):
             h = int(self.kv[b"ksi:num_hashes:int"])
         cap = max(int(cap or 0), n_cols, self._hint("max_cols") or 1024)
         out = _lib.C.c_void_p()
-        check(_lib.lib().bigsi_hip_open(int(m), int(n_cols), cap, h, self.device, _lib.C.byref(out)))
+        if self.is_group:
+            devs = (_lib.C.c_int * len(self.devices))(*self.devices)
+            check(_lib.lib().bigsi_hip_group_open(int(m), int(n_cols), cap, h, devs, len(self.devices), _lib.C.byref(out)))
+        else:
+            check(_lib.lib().bigsi_hip_open(int(m), int(n_cols), cap, h, self.device, _lib.C.byref(out)))
         self.ix, self.m = out, int(m)
         self.written = np.zeros(self.m, dtype=bool)
 
@@ -75,16 +94,25 @@ class _Resident(object):
         return True
 
     def info(self):
-        inf = _lib.Info()
-        check(_lib.lib().bigsi_hip_get_info(self.ix, _lib.C.byref(inf)))
+        inf = _lib.GroupInfo() if self.is_group else _lib.Info()
+        check(self.fn("get_info")(self.ix, _lib.C.byref(inf)))
         return inf
+
+    def reserve_cols(self, cols):
+        """Grow the column capacity (re-striding on the device); a group's capacity is fixed when it is opened."""
+        if self.is_group:
+            if cols > self.info().col_capacity:
+                raise BigsiHipError(_lib.ERR_CAPACITY, "a multi-GPU index cannot grow beyond the max_cols it was opened with "
+                                                       "(%d columns asked, capacity %d)" % (cols, self.info().col_capacity))
+            return
+        check(_lib.lib().bigsi_hip_reserve_cols(self.ix, int(cols)))
 
     def free(self):
         for b in list(self.batches):
             b.close()
         if self.ix is not None:
-            check(_lib.lib().bigsi_hip_close(self.ix))
-        self.ix, self.m, self.written = None, None, None
+            check(self.fn("close")(self.ix))
+        self.ix, self.m, self.written, self.rowlen = None, None, None, None
         self.kv, self.pending = {}, {}
 
     # ---- rows
@@ -92,6 +120,7 @@ class _Resident(object):
         """row_ids: sequence of ints; blobs: list of bytes (all of one length) or uint8[n, rb]."""
         if not len(row_ids):
             return
+        stored_len = None
         if not self.ensure_open():
             for r, b in zip(row_ids, blobs):
                 self.pending[int(r)] = bytes(b)
@@ -108,16 +137,18 @@ class _Resident(object):
                 return
             rb = lens.pop()
             if rb == 0:               # an empty bitarray: the row exists and is all zero
-                packed, rb = np.zeros((len(blobs), 1), np.uint8), 1
+                packed, rb, stored_len = np.zeros((len(blobs), 1), np.uint8), 1, 0
             else:
                 packed = np.frombuffer(b"".join(blobs), dtype=np.uint8).reshape(len(blobs), rb)
         ids = np.ascontiguousarray(row_ids, dtype=np.uint64)
         if ids.size and int(ids.max()) >= self.m:
             raise KeyError("row %d outside [0, %d)" % (int(ids.max()), self.m))
         if rb * 8 > self.info().col_capacity:
-            check(_lib.lib().bigsi_hip_reserve_cols(self.ix, rb * 8))
-        check(_lib.lib().bigsi_hip_set_rows(self.ix, _lib.ptr(ids), ids.size, _lib.ptr(packed), rb))
-        self.written[ids.astype(np.int64)] = True
+            self.reserve_cols(rb * 8)
+        check(self.fn("set_rows")(self.ix, _lib.ptr(ids), ids.size, _lib.ptr(packed), rb))
+        idx = ids.astype(np.int64)
+        self.written[idx] = True
+        self._note_lengths(idx, stored_len if stored_len is not None else rb)
 
     def get_rows(self, row_ids, rb=None):
         """uint8[n, rb]; rb defaults to ceil(num_cols/8).  KeyError for rows never stored."""
@@ -130,12 +161,38 @@ class _Resident(object):
         bad = [int(r) for r in ids if int(r) >= self.m or not self.written[int(r)]]
         if bad:
             raise KeyError("%d:bitarray" % bad[0])
+        if rb is None and self.rowlen is not None:
+            # rows were stored with differing byte lengths: a KV store hands each value back as it was stored
+            # (bigsi/storage/base.py:96-99) -- fetch at the widest length, cut each row to its own
+            lens = self.rowlen[ids.astype(np.int64)]
+            wide = max(int(lens.max()) if lens.size else 1, 1)
+            full = np.zeros((ids.size, wide), dtype=np.uint8)
+            if ids.size:
+                check(self.fn("get_rows")(self.ix, _lib.ptr(ids), ids.size, _lib.ptr(full), wide))
+            return [full[i, : int(n)].tobytes() for i, n in enumerate(lens)]
         if rb is None:
-            rb = max(int(self.info().row_bytes), 1)
+            rb = max(int(self.info().row_bytes), 1) if self.uniform_len is None else max(int(self.uniform_len), 1)
+            cut = self.uniform_len == 0
+        else:
+            cut = False
         out = np.zeros((ids.size, rb), dtype=np.uint8)
         if ids.size:
-            check(_lib.lib().bigsi_hip_get_rows(self.ix, _lib.ptr(ids), ids.size, _lib.ptr(out), rb))
-        return out
+            check(self.fn("get_rows")(self.ix, _lib.ptr(ids), ids.size, _lib.ptr(out), rb))
+        return [b"" for _ in range(ids.size)] if cut else out
+
+    def _note_lengths(self, idx, n):
+        """Remember the byte length rows were stored with.  While every stored row has ONE length (any index built
+        through BitMatrix) that is a single integer; only a store that really mixes lengths pays for a per-row array."""
+        if self.rowlen is None and (self.uniform_len is None or self.uniform_len == n):
+            self.uniform_len = n
+            return
+        if self.rowlen is None:
+            self.rowlen = np.full(self.m, self.uniform_len, dtype=np.uint32)
+        self.rowlen[idx] = n
+
+    def lengths_reset(self):
+        """Every row now has the index's current width (a device-side build / insert / merge rewrote them all)."""
+        self.rowlen, self.uniform_len = None, None
 
     def flush_pending(self):
         if self.pending and self.ensure_open():
@@ -156,10 +213,10 @@ class _Resident(object):
         if key == b"number_of_cols:int" and self.ensure_open():
             n = int(value)
             if n > self.info().col_capacity:
-                check(_lib.lib().bigsi_hip_reserve_cols(self.ix, n))
-            check(_lib.lib().bigsi_hip_set_num_cols(self.ix, n))
+                self.reserve_cols(n)
+            check(self.fn("set_num_cols")(self.ix, n))
         elif key == b"ksi:num_hashes:int" and self.ix is not None:
-            check(_lib.lib().bigsi_hip_set_num_hashes(self.ix, int(value)))
+            check(self.fn("set_num_hashes")(self.ix, int(value)))
 
 
 class HipHbmStorage(BaseStorage):
@@ -170,6 +227,18 @@ class HipHbmStorage(BaseStorage):
         self.name = self.storage_config.get("name", "default")
         _lib.lib()    # fail loudly, here, if the HIP library has not been built
         res = _RESIDENT.get(self.name)
+        if res is not None and res.ix is None and not res.kv and not res.pending:
+            res.__init__(self.storage_config)       # an emptied (deleted) store: the name is free to describe something else
+        elif res is not None:
+            # one name = one resident index: a second config under the same name must describe the same thing, it is not
+            # silently served somebody else's matrix (m / h are only compared when both sides state them)
+            for key in ("device", "devices", "filename", "m", "h"):
+                a, b = res.cfg.get(key), self.storage_config.get(key)
+                if key in ("device",):
+                    a, b = int(a or 0), int(b or 0)
+                if a != b and (key in ("device", "devices", "filename") or (a is not None and b is not None)):
+                    raise BigsiHipError(_lib.ERR_STATE, "a resident hip-hbm index named %r already exists with %s=%r (this config says %r): "
+                                                        "give the other index its own storage-config name" % (self.name, key, a, b))
         if res is None:
             res = _RESIDENT[self.name] = _Resident(self.storage_config)
             fn = self.storage_config.get("filename")
@@ -222,14 +291,20 @@ class HipHbmStorage(BaseStorage):
             return False
 
     def delete_all(self):
+        """BaseStorage.delete_all (bigsi/storage/base.py:132-133; berkeleydb.py removes the file): the resident index AND its
+        snapshot file go, so that a later process does not find the deleted index again."""
         self.res.free()
+        fn = self.storage_config.get("filename")
+        for f in ((fn, fn + ".tmp") if fn else ()):
+            if os.path.exists(f):
+                os.remove(f)
 
     def sync(self):
         fn = self.storage_config.get("filename")
         if fn:
             _save_snapshot(self.res, fn)
         if self.res.ix is not None:
-            check(_lib.lib().bigsi_hip_synchronize(self.res.ix))
+            check(self.res.fn("synchronize")(self.res.ix))
 
     def close(self):
         self.res = None      # the resident index stays (see module docstring)
@@ -248,13 +323,18 @@ class HipHbmStorage(BaseStorage):
         if not res.ensure_open():
             raise KeyError("number_of_rows:int")
         if col >= res.info().col_capacity:
-            check(_lib.lib().bigsi_hip_reserve_cols(res.ix, max(col + 1, 2 * int(res.info().col_capacity))))
+            res.reserve_cols(max(col + 1, 2 * int(res.info().col_capacity)))
         buf = np.frombuffer(bytes(bloom_bytes), dtype=np.uint8)
         need = (res.m + 7) // 8
         if buf.size < need:
             buf = np.concatenate([buf, np.zeros(need - buf.size, np.uint8)])
-        check(_lib.lib().bigsi_hip_insert_column(res.ix, int(col), _lib.ptr(np.ascontiguousarray(buf))))
+        buf = np.ascontiguousarray(buf)
+        if res.is_group:
+            check(_lib.lib().bigsi_hip_group_insert_columns(res.ix, int(col), 1, _lib.ptr(buf), buf.size))
+        else:
+            check(_lib.lib().bigsi_hip_insert_column(res.ix, int(col), _lib.ptr(buf)))
         res.written[:] = True
+        res.lengths_reset()
         res.kv[b"number_of_cols:int"] = str(int(res.info().num_cols)).encode()
 
     def insert_columns(self, col0, blooms):
@@ -267,30 +347,38 @@ class HipHbmStorage(BaseStorage):
         if blooms.shape[1] < need:
             blooms = np.concatenate([blooms, np.zeros((n, need - blooms.shape[1]), np.uint8)], axis=1)
         if col0 + n > res.info().col_capacity:
-            check(_lib.lib().bigsi_hip_reserve_cols(res.ix, col0 + n))
-        check(_lib.lib().bigsi_hip_insert_columns(res.ix, int(col0), n, _lib.ptr(blooms), blooms.shape[1]))
+            res.reserve_cols(col0 + n)
+        check(res.fn("insert_columns")(res.ix, int(col0), n, _lib.ptr(blooms), blooms.shape[1]))
         res.written[:] = True
+        res.lengths_reset()
         res.kv[b"number_of_cols:int"] = str(int(res.info().num_cols)).encode()
 
     def append_from(self, other):
         """Append every column of another resident hip-hbm index (same device, same m), device to device."""
+        if self.res.is_group or other.res.is_group:
+            raise BigsiHipError(_lib.ERR_STATE, "merge is not available for multi-GPU (devices=[...]) indexes")
         check(_lib.lib().bigsi_hip_append_index(self.handle, other.handle))
         self.res.written[:] = True
+        self.res.lengths_reset()
         self.res.kv[b"number_of_cols:int"] = str(int(self.res.info().num_cols)).encode()
 
     def get_column(self, col):
         res = self.res
         out = np.zeros((res.m + 7) // 8, dtype=np.uint8)
-        check(_lib.lib().bigsi_hip_get_column(res.ix, int(col), _lib.ptr(out)))
+        check(res.fn("get_column")(res.ix, int(col), _lib.ptr(out)))
         return out.tobytes()
 
     def fill_synthetic(self, seed, shard=0, and_draws=2):
-        check(_lib.lib().bigsi_hip_fill_synthetic(self.res.ix, int(seed), int(shard), int(and_draws)))
+        if self.res.is_group:       # shard i of the group is filled as (seed, shard i)
+            check(_lib.lib().bigsi_hip_group_fill_synthetic(self.res.ix, int(seed), int(and_draws)))
+        else:
+            check(_lib.lib().bigsi_hip_fill_synthetic(self.res.ix, int(seed), int(shard), int(and_draws)))
         self.res.written[:] = True
+        self.res.lengths_reset()
 
     def insert_kmers(self, col, seqs, k):
         blob, off = _lib.pack_seqs(seqs)
-        check(_lib.lib().bigsi_hip_insert_kmers(self.res.ix, int(col), blob, _lib.ptr(off), len(seqs), int(k)))
+        check(self.res.fn("insert_kmers")(self.res.ix, int(col), blob, _lib.ptr(off), len(seqs), int(k)))
 
     # ---- fused query path
     @property
@@ -311,7 +399,7 @@ class HipHbmStorage(BaseStorage):
                 raise ValueError("cannot look up an empty k-mer")
             blob, _ = _lib.pack_seqs(group)
             rows = np.zeros((len(group), rb), dtype=np.uint8)
-            check(_lib.lib().bigsi_hip_lookup(self.handle, blob, k, len(group), _lib.ptr(rows)))
+            check(self.res.fn("lookup")(self.handle, blob, k, len(group), _lib.ptr(rows)))
             for km, r in zip(group, rows):
                 out[km] = r.tobytes()
         return out
@@ -342,25 +430,33 @@ class QueryBatch(object):
     def __init__(self, storage, seqs, k):
         self.storage = storage
         self.n = len(seqs)
+        self.group = storage.res.is_group          # a batch over all shards of a multi-GPU index (bigsi_hip_group_batch)
         blob, off = _lib.pack_seqs(seqs)
         self._off = off
         out = _lib.C.c_void_p()
-        check(_lib.lib().bigsi_hip_batch_create(storage.handle, blob, _lib.ptr(off), self.n, int(k), _lib.C.byref(out)))
+        check(self._fn("create")(storage.handle, blob, _lib.ptr(off), self.n, int(k), _lib.C.byref(out)))
         self.b = out
         self.k = int(k)
         storage.res.batches.add(self)
+
+    def _fn(self, name):
+        return getattr(_lib.lib(), ("bigsi_hip_group_batch_" if self.group else "bigsi_hip_batch_") + name)
+
+    def _single_only(self, what):
+        if self.group:
+            raise BigsiHipError(_lib.ERR_STATE, "%s is not available on a multi-GPU batch (use the shard's own index)" % what)
 
     def reload(self, seqs, k=None):
         """Stage a different set of sequences in this batch object, keeping its device buffers (bigsi_hip_batch_reload)."""
         blob, off = _lib.pack_seqs(seqs)
         self.k = int(k) if k is not None else self.k
-        check(_lib.lib().bigsi_hip_batch_reload(self.b, blob, _lib.ptr(off), len(seqs), self.k))
+        check(self._fn("reload")(self.b, blob, _lib.ptr(off), len(seqs), self.k))
         self.n, self._off = len(seqs), off
         return self
 
     def close(self):
         if self.b is not None:
-            check(_lib.lib().bigsi_hip_batch_destroy(self.b))
+            check(self._fn("destroy")(self.b))
             self.b = None
 
     def __del__(self):
@@ -373,9 +469,12 @@ class QueryBatch(object):
         flags = ((_lib.RUN_FORCE_COUNTS if force_counts else 0) | (_lib.RUN_SKIP_COMPACT if skip_compact else 0) |
                  (_lib.RUN_K1_GLOBAL if k1_global else 0) | (_lib.RUN_SPARSE_COUNTS if sparse_counts else 0) |
                  (_lib.RUN_EARLY_EXIT if early_exit else 0))
-        check(_lib.lib().bigsi_hip_batch_run(self.b, float(threshold), flags))
+        if self.group:
+            flags &= ~(_lib.RUN_SKIP_COMPACT | _lib.RUN_SPARSE_COUNTS)      # the group run sets what it needs itself
+        check(self._fn("run")(self.b, float(threshold), flags))
 
     def info(self):
+        self._single_only("info()")
         inf = _lib.BatchInfo()
         check(_lib.lib().bigsi_hip_batch_get_info(self.b, _lib.C.byref(inf)))
         return inf
@@ -384,7 +483,7 @@ class QueryBatch(object):
         nk = np.zeros(self.n, np.uint32)
         nu = np.zeros(self.n, np.uint32)
         mk = np.zeros(self.n, np.uint32)
-        check(_lib.lib().bigsi_hip_batch_fetch_unique(self.b, _lib.ptr(nk), _lib.ptr(nu), _lib.ptr(mk)))
+        check(self._fn("fetch_unique")(self.b, _lib.ptr(nk), _lib.ptr(nu), _lib.ptr(mk)))
         return nk, nu, mk
 
     def hits(self):
@@ -394,7 +493,7 @@ class QueryBatch(object):
         while True:
             col = np.zeros(cap, np.uint32)
             cnt = np.zeros(cap, np.uint32)
-            rc = _lib.lib().bigsi_hip_batch_fetch_hits(self.b, _lib.ptr(off), _lib.ptr(col), _lib.ptr(cnt), cap)
+            rc = self._fn("fetch_hits")(self.b, _lib.ptr(off), _lib.ptr(col), _lib.ptr(cnt), cap)
             if rc == _lib.ERR_CAPACITY:
                 cap = int(off[-1])
                 continue
@@ -403,22 +502,26 @@ class QueryBatch(object):
             return off, col[:total], cnt[:total]
 
     def counts(self, i):
+        self._single_only("counts()")
         out = np.zeros(int(self.storage.res.info().num_cols), np.uint32)
         check(_lib.lib().bigsi_hip_batch_fetch_counts(self.b, i, _lib.ptr(out)))
         return out
 
     def bitmap(self, i):
+        self._single_only("bitmap()")
         out = np.zeros(max(int(self.storage.res.info().row_bytes), 1), np.uint8)
         check(_lib.lib().bigsi_hip_batch_fetch_bitmap(self.b, i, _lib.ptr(out)))
         return out
 
     def rows(self, i, num_unique):
+        self._single_only("rows()")
         h = int(self.storage.res.info().num_hashes)
         out = np.zeros((max(int(num_unique), 1), h), np.uint64)
         check(_lib.lib().bigsi_hip_batch_fetch_rows(self.b, i, _lib.ptr(out), out.size))
         return out[:int(num_unique)]
 
     def lookup(self, i, num_unique):
+        self._single_only("lookup()")
         rb = max(int(self.storage.res.info().row_bytes), 1)
         first = np.zeros(max(int(num_unique), 1), np.uint32)
         rows = np.zeros((max(int(num_unique), 1), rb), np.uint8)
@@ -431,7 +534,7 @@ class QueryBatch(object):
         if colours.size == 0 or num_kmers == 0:
             return ["" for _ in colours]
         out = np.zeros((colours.size, int(num_kmers)), np.uint8)
-        check(_lib.lib().bigsi_hip_batch_presence(self.b, i, _lib.ptr(colours), colours.size, _lib.ptr(out)))
+        check(self._fn("presence")(self.b, i, _lib.ptr(colours), colours.size, _lib.ptr(out)))
         return [r.tobytes().decode("ascii") for r in out]
 
 
@@ -442,8 +545,11 @@ def _save_snapshot(res, fn):
     tmp = fn + ".tmp"
     with open(tmp, "wb") as f:
         if res.ix is not None:
-            header["rb"] = max(int(res.info().row_bytes), 1)
+            header["rb"] = max(int(res.info().row_bytes), int(res.uniform_len or 0), int(res.rowlen.max()) if res.rowlen is not None else 0, 1)
             header["written"] = np.packbits(res.written).tobytes().hex()
+            header["uniform_len"] = res.uniform_len
+            if res.rowlen is not None:
+                header["rowlen"] = res.rowlen.tobytes().hex()
         hb = json.dumps(header).encode("utf-8")
         f.write(_MAGIC + struct.pack("<Q", len(hb)) + hb)
         if res.ix is not None:
@@ -451,7 +557,7 @@ def _save_snapshot(res, fn):
             for r0 in range(0, res.m, step):
                 ids = np.arange(r0, min(res.m, r0 + step), dtype=np.uint64)
                 out = np.zeros((ids.size, rb), np.uint8)
-                check(_lib.lib().bigsi_hip_get_rows(res.ix, _lib.ptr(ids), ids.size, _lib.ptr(out), rb))
+                check(res.fn("get_rows")(res.ix, _lib.ptr(ids), ids.size, _lib.ptr(out), rb))
                 f.write(out.tobytes())
     os.replace(tmp, fn)
 
@@ -472,5 +578,8 @@ def _load_snapshot(res, fn):
                 cnt = min(m, r0 + step) - r0
                 blob = np.frombuffer(f.read(cnt * rb), dtype=np.uint8).reshape(cnt, rb)
                 ids = np.arange(r0, r0 + cnt, dtype=np.uint64)
-                check(_lib.lib().bigsi_hip_set_rows(res.ix, _lib.ptr(ids), cnt, _lib.ptr(np.ascontiguousarray(blob)), rb))
+                check(res.fn("set_rows")(res.ix, _lib.ptr(ids), cnt, _lib.ptr(np.ascontiguousarray(blob)), rb))
             res.written = np.unpackbits(np.frombuffer(bytes.fromhex(header["written"]), np.uint8))[:m].astype(bool)
+            res.uniform_len = header.get("uniform_len")
+            if header.get("rowlen"):
+                res.rowlen = np.frombuffer(bytes.fromhex(header["rowlen"]), np.uint32).copy()

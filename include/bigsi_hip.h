@@ -131,13 +131,14 @@ int bigsi_hip_bloom(int device, const char *kmers, uint64_t u, uint32_t k, uint6
 int bigsi_hip_lookup(bigsi_hip_index *ix, const char *kmers, uint32_t k, uint64_t u, uint8_t *out_rows);
 
 #define BIGSI_RUN_FORCE_COUNTS 1u /* use the counting path even when threshold == 1.0 */
-#define BIGSI_RUN_K1_GLOBAL 4u   /* take the multi-launch K1 (global-memory dedupe table) whatever the query lengths (testing) */
+#define BIGSI_RUN_SKIP_COMPACT 2u /* stop after K2/K3: the caller compacts a gathered buffer instead (multi-GPU) */
 #define BIGSI_RUN_SPARSE_COUNTS 8u /* counting path: store per-sample counters only where a sample reaches min_kmers
                                       (hit lists are complete; fetch_counts is unavailable for that run) */
-#define BIGSI_RUN_NO_SORT 16u      /* stream each query's rows in hash order instead of address order (A/B measurements) */
-#define BIGSI_RUN_EARLY_EXIT 32u   /* exact path: stop fetching a query's rows for a column segment once its running AND is
-                                      all zero (same results, fewer bytes; not what the reference does, hence opt-in) */
-#define BIGSI_RUN_SKIP_COMPACT 2u /* stop after K2/K3: the caller compacts a gathered buffer instead (multi-GPU) */
+/* test / A-B flags: same results, different route (tests/test_gpu_parity.py, scripts/ab_*.py); not for production callers */
+#define BIGSI_RUN_K1_GLOBAL 4u   /* take the multi-launch K1 (global-memory dedupe table) whatever the query lengths */
+#define BIGSI_RUN_NO_SORT 16u    /* stream each query's rows in hash order instead of address order */
+#define BIGSI_RUN_EARLY_EXIT 32u /* exact path: stop fetching a query's rows for a column segment once its running AND is
+                                    all zero (fewer bytes than the reference reads, hence opt-in) */
 
 int bigsi_hip_batch_create(bigsi_hip_index *ix, const char *seqs, const uint64_t *offsets, uint32_t n_seqs,
                            uint32_t k, bigsi_hip_batch **out);
@@ -169,6 +170,10 @@ int bigsi_hip_batch_get_info(bigsi_hip_batch *b, bigsi_hip_batch_info *out); /* 
 /* Write the per-sample result of later runs into caller-owned device memory (e.g. this rank's slot of an
  * RCCL all-gather buffer) instead of the batch's own buffers.  Either may be NULL (= keep own buffer). */
 int bigsi_hip_batch_set_outputs(bigsi_hip_batch *b, void *d_bitmaps, void *d_counts);
+/* Width, in columns, of the per-sample result vectors of later runs (default 0 = the index's num_cols).  The shards of one
+ * index all set the group's shard width here, so that uneven shards still exchange buffers of ONE geometry (strides, word
+ * counts); needs cols <= col_capacity.  Columns beyond the shard's own num_cols read as zero. */
+int bigsi_hip_batch_set_result_cols(bigsi_hip_batch *b, uint64_t cols);
 
 /* per sequence: number of k-mers n (with duplicates), unique query k-mers u = len(set(kmers))
  * (graph/bigsi.py:177-179) and min_kmers.  Any pointer may be NULL. */
@@ -210,6 +215,84 @@ int bigsi_hip_batch_compact_gathered_masks(bigsi_hip_batch *b, const void *d_gat
  * buffers fetch_gathered_hits reports BIGSI_ERR_CAPACITY instead of growing them. */
 int bigsi_hip_batch_set_gathered_hit_outputs(bigsi_hip_batch *b, void *d_colours, void *d_counts, uint64_t capacity);
 int bigsi_hip_batch_fetch_gathered_hits(bigsi_hip_batch *b, uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t capacity);
+
+/* ------------------------------------------------------------------ one-call search
+ * The whole of BIGSI.search for a batch of sequences in ONE call (what a non-Python binder of this boundary needs):
+ * create + run + fetch_unique + fetch_hits + destroy.  Outputs as in fetch_unique / fetch_hits; any of num_kmers /
+ * num_unique / min_kmers may be NULL.  BIGSI_ERR_CAPACITY (hit_offsets filled) when hit_capacity is too small. */
+int bigsi_hip_search_batch(bigsi_hip_index *ix, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k,
+                           double threshold, uint32_t flags, uint32_t *num_kmers, uint32_t *num_unique, uint32_t *min_kmers,
+                           uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t hit_capacity);
+
+/* ------------------------------------------------------------------ column shards: the exchange (RCCL over xGMI)
+ * An index too wide for one GPU is split by COLUMN RANGE: shard g holds all num_rows rows of columns
+ * [g * shard_cols, (g+1) * shard_cols).  Every shard runs K1-K3 on the same queries; the only exchange is one
+ * ncclAllGather per batch of ONE BIT PER SAMPLE (the AND bitmap, or the count >= min_kmers mask of a thresholded search)
+ * followed by the compaction of the gathered [shard][seq][stride] buffer on every rank, and -- thresholded searches only --
+ * one fixed-size ncclAllReduce (sum) of the per-hit count array, each rank having filled in the hits of its own shard.
+ * The reference has no counterpart: its only parallelism is bulk_search's fork pool (bigsi/__main__.py:273-287).
+ * librccl.so.1 is loaded with dlopen at the first call (a process that already holds torch's copy shares it).
+ *
+ * One process per GPU: rank 0 calls bigsi_hip_comm_unique_id and passes the 128 bytes to the other ranks out of band
+ * (torch.distributed store, MPI, a file); every rank then calls bigsi_hip_comm_init_rank for its device. */
+#define BIGSI_HIP_COMM_ID_BYTES 128
+typedef struct bigsi_hip_comm bigsi_hip_comm;
+int bigsi_hip_comm_unique_id(uint8_t *id /* [BIGSI_HIP_COMM_ID_BYTES] */);
+int bigsi_hip_comm_init_rank(int device, const uint8_t *id, int rank, int world, bigsi_hip_comm **out);
+int bigsi_hip_comm_destroy(bigsi_hip_comm *c);
+int bigsi_hip_comm_info(const bigsi_hip_comm *c, int *rank, int *world); /* as the communicator reports them (ncclCommCount) */
+/* Attach a batch to its rank's communicator: results are produced `shard_cols` wide (see set_result_cols; the index's
+ * capacity grows to it if needed) straight into this rank's slot of a library-owned gather buffer.  NULL detaches. */
+int bigsi_hip_batch_set_comm(bigsi_hip_batch *b, bigsi_hip_comm *c, uint64_t shard_cols);
+/* K1-K3 on the index's stream, then -- queued behind them on the communicator's own stream, no host-side wait -- all-gather,
+ * gathered compaction and count all-reduce.  With two batches used alternately the exchange of one overlaps the row-AND
+ * kernel of the other.  Results: bigsi_hip_batch_fetch_unique / bigsi_hip_batch_fetch_gathered_hits (global colours =
+ * shard * shard_cols + local column), identical on every rank. */
+int bigsi_hip_batch_run_sharded(bigsi_hip_batch *b, double threshold, uint32_t flags);
+
+/* One process driving several GPUs: a group owns one column shard per device and a communicator per shard
+ * (ncclCommInitAll); every call below fans out to the devices, collectives are issued inside ncclGroupStart/End.
+ * This is what the `hip-hbm` backend opens for storage-config {"devices": [0, 1, ...]}: one get_storage() call
+ * (bigsi/storage/__init__.py:3-19) reaches every GPU of the node.  shard_cols = ceil(col_capacity / n_dev) rounded up to
+ * 64 columns, fixed for the life of the group; colour c lives on shard c / shard_cols.  A device may be listed more than
+ * once (testing on a one-GPU box): its shards then exchange through shared device memory instead of RCCL. */
+typedef struct bigsi_hip_group bigsi_hip_group;
+typedef struct bigsi_hip_group_batch bigsi_hip_group_batch;
+int bigsi_hip_group_open(uint64_t num_rows, uint64_t num_cols, uint64_t col_capacity, uint32_t num_hashes,
+                         const int *device_ids, int n_dev, bigsi_hip_group **out);
+int bigsi_hip_group_close(bigsi_hip_group *g);
+typedef struct {
+    uint64_t num_rows, num_cols, col_capacity, shard_cols, row_bytes, index_bytes; /* whole index; index_bytes summed over devices */
+    uint32_t num_hashes, n_shards;
+    uint32_t rccl; /* 1: shards exchange through RCCL; 0: shared device memory (repeated device ids) */
+} bigsi_hip_group_info;
+int bigsi_hip_group_get_info(const bigsi_hip_group *g, bigsi_hip_group_info *out);
+/* the shard on device_ids[i], for the single-index entry points above (bulk fills, profiling, statistics) */
+int bigsi_hip_group_shard(bigsi_hip_group *g, uint32_t i, bigsi_hip_index **out);
+int bigsi_hip_group_set_num_cols(bigsi_hip_group *g, uint64_t num_cols);
+int bigsi_hip_group_set_num_hashes(bigsi_hip_group *g, uint32_t num_hashes);
+int bigsi_hip_group_synchronize(bigsi_hip_group *g);
+int bigsi_hip_group_clear(bigsi_hip_group *g);
+/* storage contract over whole rows (row_bytes = bytes of a row of the WHOLE index, as bigsi_hip_set_rows / get_rows) */
+int bigsi_hip_group_set_rows(bigsi_hip_group *g, const uint64_t *row_ids, uint64_t n, const uint8_t *bytes, uint64_t row_bytes);
+int bigsi_hip_group_get_rows(bigsi_hip_group *g, const uint64_t *row_ids, uint64_t n, uint8_t *out, uint64_t row_bytes);
+int bigsi_hip_group_insert_columns(bigsi_hip_group *g, uint64_t col0, uint64_t n, const uint8_t *blooms, uint64_t bloom_stride_bytes);
+int bigsi_hip_group_get_column(bigsi_hip_group *g, uint64_t col, uint8_t *out);
+int bigsi_hip_group_insert_kmers(bigsi_hip_group *g, uint64_t col, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k);
+int bigsi_hip_group_fill_synthetic(bigsi_hip_group *g, uint64_t seed, uint32_t and_draws); /* shard i = fill_synthetic(seed, i) */
+int bigsi_hip_group_lookup(bigsi_hip_group *g, const char *kmers, uint32_t k, uint64_t u, uint8_t *out_rows);
+/* fused query path over all shards; same meaning as the bigsi_hip_batch_* calls, colours are global */
+int bigsi_hip_group_batch_create(bigsi_hip_group *g, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k,
+                                 bigsi_hip_group_batch **out);
+int bigsi_hip_group_batch_reload(bigsi_hip_group_batch *gb, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k);
+int bigsi_hip_group_batch_destroy(bigsi_hip_group_batch *gb);
+int bigsi_hip_group_batch_run(bigsi_hip_group_batch *gb, double threshold, uint32_t flags); /* asynchronous */
+int bigsi_hip_group_batch_fetch_unique(bigsi_hip_group_batch *gb, uint32_t *num_kmers, uint32_t *num_unique, uint32_t *min_kmers);
+int bigsi_hip_group_batch_fetch_hits(bigsi_hip_group_batch *gb, uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t capacity);
+int bigsi_hip_group_batch_presence(bigsi_hip_group_batch *gb, uint32_t seq, const uint32_t *colours, uint32_t n_colours, uint8_t *out);
+int bigsi_hip_group_search_batch(bigsi_hip_group *g, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k,
+                                 double threshold, uint32_t flags, uint32_t *num_kmers, uint32_t *num_unique, uint32_t *min_kmers,
+                                 uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t hit_capacity);
 
 /* ------------------------------------------------------------------ measurement */
 typedef struct {

@@ -54,11 +54,13 @@ def main():
     p.add_argument("--exact", type=int, default=1)
     p.add_argument("--seconds", type=float, default=10.0)
     p.add_argument("--threads", type=int, default=0)
+    p.add_argument("--pool-runs", type=int, default=1, help="repetitions of the pool leg (its rate moves from run to run)")
+    p.add_argument("--pool-seconds", type=float, default=0.0, help="duration of each pool run (default: --seconds)")
     a = p.parse_args()
     if a.threads <= 0:
         a.threads = max(1, (os.cpu_count() or 2) // 2)      # one worker per physical core (SMT siblings share the FPU/LSU)
-    rng = np.random.default_rng(1)                            # same queries as bench.py: make_queries()
-    seqs = ["".join(rng.choice(list("ACGT"), size=a.qlen)) for _ in range(a.batch)]
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)              # same queries as bench.py: rand_seqs(default_rng(1), ...)
+    seqs = [lut[r].tobytes().decode("ascii") for r in np.random.default_rng(1).integers(0, 4, size=(a.batch, a.qlen), dtype=np.uint8)]
     _T.update(args=a, seqs=seqs)
     coracle.lib()
     ctx = mp.get_context("fork")
@@ -72,11 +74,15 @@ def main():
     fill_s = time.time() - t0
     _T["table"] = table
     one_done, one_t = _work((0, a.seconds))
+    pool_s = a.pool_seconds or a.seconds
+    rates = []
     with ctx.Pool(a.threads) as pool:                        # workers inherit the table copy-on-write
-        res = pool.map(_work, [(w, a.seconds) for w in range(a.threads)])
-    pool_done, pool_t = sum(r[0] for r in res), max(r[1] for r in res)
+        for _ in range(max(1, a.pool_runs)):
+            res = pool.map(_work, [(w, pool_s) for w in range(a.threads)])
+            rates.append(sum(r[0] for r in res) / max(r[1] for r in res))
     print(json.dumps({"one_core": {"lookups": one_done, "seconds": one_t, "rate": one_done / one_t},
-                      "pool": {"threads": a.threads, "lookups": pool_done, "seconds": pool_t, "rate": pool_done / pool_t},
+                      "pool": {"threads": a.threads, "seconds": pool_s, "rates": rates, "rate": float(np.median(rates)),
+                               "rate_median": float(np.median(rates)), "rate_best": max(rates)},
                       "rows": a.rows, "cols": a.cols, "fill_seconds": fill_s, "host_threads": os.cpu_count()}))
 
 

@@ -1,0 +1,210 @@
+"""Per-workload kernel measurements behind DESIGN.md section 5 / profiles/*.json (one JSON object per line on stdout).
+
+    python scripts/measure.py [c2stream] [c3batch] [p16] [c4shard] [northstar] [k5] [transpose] ...
+
+Every figure is a HIP-event duration recorded by the library around its own kernels (bigsi_hip_set_profiling) over
+`reps` launches; run the same command under `rocprofv3 --kernel-trace --stats` for the per-kernel table that goes to
+profiles/.  Algorithmic bytes follow SURVEY.md section 8d: unique rows x ceil(N/64) x 8 + result vectors."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bigsi_amd import _lib  # noqa: E402
+from bigsi_amd._lib import check  # noqa: E402
+from bigsi_amd.storage import get_storage  # noqa: E402
+
+SEED = 20260928
+PEAK = 8000.0
+
+
+def open_index(name, m, n_cols, h, draws=2, k=31):
+    st = get_storage({"storage-engine": "hip-hbm", "k": k, "m": m, "h": h,
+                      "storage-config": {"name": name, "device": 0, "max_cols": n_cols}})
+    st.delete_all()
+    for key, v in (("number_of_rows", m), ("number_of_cols", n_cols), ("ksi:bloomfilter_size", m), ("ksi:num_hashes", h)):
+        st.set_integer(key, v)
+    t0 = time.time()
+    st.fill_synthetic(SEED, 0, draws)
+    return st, time.time() - t0
+
+
+def rand_seqs(rng, n, qlen):
+    a = rng.integers(0, 4, size=(n, qlen), dtype=np.uint8)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    return [lut[r].tobytes().decode("ascii") for r in a]
+
+
+def stats(st, reset=1):
+    s = _lib.Stats()
+    check(_lib.lib().bigsi_hip_stats(st.handle, _lib.C.byref(s), reset))
+    return s
+
+
+def alg_bytes(batch, n_seqs, n_cols):
+    _, nu, _ = batch.unique()
+    wv = -(-n_cols // 64)
+    rows = 0
+    for i in range(n_seqs):
+        rows += np.unique(batch.rows(i, nu[i])).size
+    return int(nu.sum()), rows, rows * wv * 8 + n_seqs * wv * 8
+
+
+def run_steps(st, batches, threshold, reps, warm=3, prof=2, **kw):
+    """(wall ms/step, Stats) over `reps` steps cycling through `batches`."""
+    L = _lib.lib()
+    for i in range(warm):
+        batches[i % len(batches)].run(threshold, **kw)
+    check(L.bigsi_hip_synchronize(st.handle))
+    check(L.bigsi_hip_set_profiling(st.handle, prof))
+    stats(st)
+    t0 = time.perf_counter()
+    for i in range(reps):
+        batches[i % len(batches)].run(threshold, **kw)
+    check(L.bigsi_hip_synchronize(st.handle))
+    wall = (time.perf_counter() - t0) / reps * 1e3
+    s = stats(st)
+    check(L.bigsi_hip_set_profiling(st.handle, 0))
+    return wall, s
+
+
+def emit(name, **kw):
+    kw = dict(workload=name, **kw)
+    print(json.dumps(kw), flush=True)
+
+
+def kernel_line(name, st, batches, n_cols, threshold, reps, note="", **kw):
+    nseq = batches[0].n
+    wall, s = run_steps(st, batches, threshold, reps, prof=2, **kw)            # row-AND kernel only: clean step time
+    _, s1 = run_steps(st, batches, threshold, min(reps, 20), prof=1, **kw)     # every kernel group (event overhead in the step)
+    lookups, rows, ab = alg_bytes(batches[0], nseq, n_cols)
+    k2 = s.and_ms / max(s.and_launches, 1)
+    emit(name, threshold=threshold, n_seqs=nseq, distinct_batches=len(batches), step_ms=wall, k2_ms=k2,
+         k1_ms=s1.kmerize_ms / max(s1.and_launches, 1), k4_ms=s1.compact_ms / max(s1.and_launches, 1),
+         lookups_per_batch=lookups, unique_rows=rows, alg_bytes=ab, GBps=ab / k2 / 1e6, frac=ab / k2 / 1e6 / PEAK,
+         lookups_per_s=lookups / wall * 1e3, note=note)
+
+
+def c2stream():
+    """BASELINE configs[1] with a DIFFERENT batch every step: 32 staged batches of 1000 random 61-mers cycle, so the rows of
+    a step (117 MB) are not the rows the previous steps left in the 256 MiB Infinity Cache."""
+    m, n, h = 1_000_000, 10_000, 3
+    st, _ = open_index("c2", m, n, h)
+    rng = np.random.default_rng(7)
+    same = [st.new_batch(rand_seqs(np.random.default_rng(1), 1000, 61), 31)]
+    many = [st.new_batch(rand_seqs(rng, 1000, 61), 31) for _ in range(32)]
+    for thr in (1.0, 0.4):
+        kernel_line("c2_same_batch", st, same, n, thr, 200, note="one batch repeated: rows are cache resident")
+        kernel_line("c2_stream", st, many, n, thr, 320, note="32 distinct batches cycling")
+    for b in same + many:
+        b.close()
+    st.delete_all()
+
+
+def c3batch():
+    """C3 index; 256 vs 2048 vs 8192 queries per launch (does the address-ordered sweep survive a grid that is not co-resident?)."""
+    m, n, h = 10_000_000, 100_000, 4
+    st, _ = open_index("c3", m, n, h)
+    rng = np.random.default_rng(1)
+    for nq in (256, 2048, 8192):
+        bs = [st.new_batch(rand_seqs(rng, nq, 1000), 31) for _ in range(2)]
+        for thr in (1.0, 0.4):
+            kernel_line("c3_batch%d" % nq, st, bs, n, thr, max(4, 5120 // nq), sparse_counts=True)
+        for b in bs:
+            b.close()
+    st.delete_all()
+
+
+def p16():
+    """Counting kernel with P=16 planes (1024..65535 k-mers per query): 256 x 2 kbp and 128 x 4 kbp at t=0.4 vs exact."""
+    m, n, h = 10_000_000, 100_000, 4
+    st, _ = open_index("c3", m, n, h)
+    rng = np.random.default_rng(3)
+    for nq, ql in ((256, 1000), (256, 2000), (128, 4000), (64, 8000)):
+        bs = [st.new_batch(rand_seqs(rng, nq, ql), 31) for _ in range(2)]
+        for thr in (1.0, 0.4):
+            kernel_line("c3_q%dbp" % ql, st, bs, n, thr, 12, sparse_counts=True)
+        for b in bs:
+            b.close()
+    st.delete_all()
+
+
+def shard(name, m, n, h):
+    st, fill = open_index(name, m, n, h)
+    rng = np.random.default_rng(1)
+    bs = [st.new_batch(rand_seqs(rng, 256, 1000), 31) for _ in range(2)]
+    for thr in (1.0, 0.4):
+        kernel_line(name, st, bs, n, thr, 20, note="fill %.2f s" % fill, sparse_counts=True)
+    for b in bs:
+        b.close()
+    st.delete_all()
+
+
+def c4shard():
+    shard("c4_shard_25Mx62500_h3", 25_000_000, 62_500, 3)
+
+
+def northstar():
+    shard("northstar_shard_10Mx62500_h3", 10_000_000, 62_500, 3)
+    shard("northstar_shard_10Mx62500_h4", 10_000_000, 62_500, 4)
+
+
+def k5():
+    """Presence strings (score=True) at scale: one 1 kbp query planted into H samples of a 10M x 62.5k shard, H = 64 .. 8192."""
+    m, n, h = 10_000_000, 62_500, 3
+    st, _ = open_index("k5", m, n, h)
+    rng = np.random.default_rng(11)
+    seqs = rand_seqs(rng, 8, 1000)
+    for H in (64, 1024, 8192):
+        cols = rng.choice(n, size=H, replace=False)
+        for c in cols[: min(H, 8192)]:
+            st.insert_kmers(int(c), [seqs[0][:700]], 31)
+        b = st.new_batch(seqs, 31)
+        b.run(0.4, sparse_counts=True)
+        off, col, cnt = b.hits()
+        nk, nu, _ = b.unique()
+        hits = col[int(off[0]):int(off[1])]
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            s = b.presence(0, hits, int(nk[0]))
+        dt = (time.perf_counter() - t0) / reps
+        words = np.unique(hits // 64).size
+        ab = int(nu[0]) * h * words * 8 + hits.size * int(nk[0])
+        emit("k5_presence", hits=int(hits.size), hit_words=int(words), positions=int(nk[0]), call_ms=dt * 1e3, alg_bytes=ab,
+             GBps_call=ab / dt / 1e9, note="whole bigsi_hip_batch_presence call incl. D2H of the strings")
+        assert all(x.count("1") >= 670 for x in s[:4])
+        b.close()
+    st.delete_all()
+
+
+def transpose():
+    """Bloom filters -> matrix columns on the device (bigsi_hip_insert_columns): n filters of m bits, host-staged."""
+    for m, ncols in ((1_000_000, 4096), (10_000_000, 512)):
+        st = get_storage({"storage-engine": "hip-hbm", "k": 31, "m": m, "h": 3,
+                          "storage-config": {"name": "tr", "device": 0, "max_cols": ncols}})
+        st.delete_all()
+        for key, v in (("number_of_rows", m), ("number_of_cols", 0), ("ksi:bloomfilter_size", m), ("ksi:num_hashes", 3)):
+            st.set_integer(key, v)
+        nb = (m + 7) // 8
+        blooms = np.random.default_rng(5).integers(0, 256, size=(ncols, nb), dtype=np.uint8)
+        st.insert_columns(0, blooms[:64])      # warm
+        t0 = time.perf_counter()
+        st.insert_columns(0, blooms)
+        dt = time.perf_counter() - t0
+        emit("insert_columns", m=m, cols=ncols, call_ms=dt * 1e3, bloom_bytes=int(blooms.nbytes),
+             GBps_call=2 * blooms.nbytes / dt / 1e9, note="whole call incl. H2D staging of the filters; in+out bytes")
+        got = st.get_rows_packed([0, 1, m - 1], (ncols + 7) // 8)
+        want = np.packbits(np.unpackbits(blooms[:, [0, 0, (m - 1) // 8]], axis=1)[:, [0, 1, 16 + (m - 1) % 8]].T, axis=1)
+        assert np.array_equal(got, want)
+        st.delete_all()
+
+
+if __name__ == "__main__":
+    todo = sys.argv[1:] or ["c2stream", "c3batch", "p16", "c4shard", "northstar", "k5", "transpose"]
+    for t in todo:
+        globals()[t]()

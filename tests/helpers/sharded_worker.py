@@ -18,14 +18,13 @@ torch.cuda.set_device(0)                                   # both ranks share th
 dist.init_process_group("gloo", rank=rank, world_size=world)
 g = json.load(open(os.path.join(ROOT, "tests", "golden", "g7_random.json")))
 n = len(g["sample_names"])
-lo, hi = rank * n // world + (3 if rank else 0), (rank + 1) * n // world + (3 if rank + 1 < world else 0)   # uneven shards: 103 / 97
-if rank == 0:
-    lo = 0
+split = int(sys.argv[2]) if len(sys.argv) > 2 else 103                # uneven shards: `split` samples on rank 0, the rest on rank 1
+lo, hi = (0, split) if rank == 0 else (split, n)
 names = g["sample_names"][lo:hi]
 cfg = {"storage-engine": "hip-hbm", "storage-config": {"name": "shard%d" % rank, "device": 0}, "k": g["k"], "m": g["m"], "h": g["h"]}
 local = BIGSI.build_from_sequences(cfg, {nm: list(g["sample_seqs"][lo + i]) for i, nm in enumerate(names)})
 sb = ShardedBIGSI(local, device=torch.device("cuda", 0))
-assert sb.num_samples == n and sb.shard_sizes == [103, 97]
+assert sb.num_samples == n and sb.shard_sizes == [split, n - split]
 out = []
 for s in g["searches"]:
     q = g["queries"][s["q"]]

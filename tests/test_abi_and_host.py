@@ -194,17 +194,6 @@ def test_metadata_on_dict_storage():
     assert sm.colour_to_sample(2) == "b_duplicate_in_merge" and sm.colour_to_sample(3) == "c"
 
 
-def test_transpose_matches_numpy():
-    from bigsi_amd import BitRow
-    from bigsi_amd.matrix.transpose import transpose, transpose_packed
-    rng = np.random.default_rng(0)
-    for n, m in [(5, 10), (10, 10), (7, 33), (1, 8), (9, 65)]:
-        a = rng.integers(0, 2, size=(n, m)).astype(bool)
-        rows = list(transpose([BitRow(r) for r in a]))
-        assert [r.tolist() for r in rows] == a.T.tolist()
-        assert np.array_equal(np.unpackbits(transpose_packed([BitRow(r) for r in a]), axis=1)[:, :n], a.T.astype(np.uint8))
-
-
 def test_fused_backend_is_required():
     from bigsi_amd.graph.index import KmerSignatureIndex
     st = make_dict_storage()

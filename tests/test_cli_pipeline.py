@@ -66,7 +66,35 @@ def test_bloom_build_search_commands(tmp_path):
             assert out == nl(c["out"] + "\n")
             n += 1
     assert n >= 12
+    # insert: a fourth sample (a copy of the first one's filter) must still be there in the NEXT process
+    probe = g9["samples"][names[0]][0]
+    before = json.loads(cli(["search", probe, "--config", str(cf)], str(tmp_path)))
+    assert "success" in cli(["insert", blooms[0], "inserted_copy", "--config", str(cf)], str(tmp_path))
+    after = json.loads(cli(["search", probe, "--config", str(cf)], str(tmp_path)))
+    assert [r["sample_name"] for r in after["results"]] == [r["sample_name"] for r in before["results"]] + ["inserted_copy"]
+    # merge: a second index (one sample, built from a TSV with --from_file under a 1-filter memory bound) appended to the first
+    cfg2 = dict(cfg, **{"storage-config": {"name": "cli2", "filename": str(tmp_path / "index2.hbm")}, "max_build_mem_bytes": "125B"})
+    cf2 = tmp_path / "config2.yaml"
+    cf2.write_text(yaml.safe_dump(cfg2))
+    tsv = tmp_path / "blooms.tsv"
+    tsv.write_text("%s\tmerged_a\n%s\tmerged_b\n" % (blooms[1], blooms[2]))
+    assert "success" in cli(["build", "--from_file", str(tsv), "--config", str(cf2)], str(tmp_path))       # two slabs of one filter
+    two = json.loads(cli(["search", g9["samples"][names[1]][0], "--config", str(cf2)], str(tmp_path)))
+    assert [r["sample_name"] for r in two["results"]] == ["merged_a"]
+    assert "merged" in cli(["merge", str(cf2), "--config", str(cf)], str(tmp_path))
+    merged = json.loads(cli(["search", g9["samples"][names[1]][0], "--config", str(cf)], str(tmp_path)))
+    assert [r["sample_name"] for r in merged["results"]] == [names[1], "merged_a"]
+    # delete: the snapshot goes too -- the next process finds no index, and the same config can be built again
     cli(["delete", "--config", str(cf)], str(tmp_path))
+    assert not os.path.exists(cfg["storage-config"]["filename"])
+    r = subprocess.run([sys.executable, "-m", "bigsi_amd", "search", probe, "--config", str(cf)], cwd=str(tmp_path), capture_output=True,
+                       text=True, timeout=600, env=dict(os.environ, PYTHONPATH=ROOT))
+    assert r.returncode != 0
+    assert "success" in cli(args, str(tmp_path))
+    again = json.loads(cli(["search", probe, "--config", str(cf)], str(tmp_path)))
+    assert again == before
+    cli(["delete", "--config", str(cf)], str(tmp_path))
+    cli(["delete", "--config", str(cf2)], str(tmp_path))
 
 
 def cli_sharded(args, cwd, port, nproc=2):

@@ -1,0 +1,238 @@
+"""The multi-GPU boundary of the C ABI on a one-GPU box.
+
+* device groups (bigsi_hip_group_*, storage-config {"devices": [...]}) with a device listed several times: every shard is a
+  real index with its own streams and batch objects, uneven and EMPTY shards included; the exchange runs through shared
+  device memory instead of RCCL.  Everything is checked against the oracle on the concatenated index, and the reference's
+  own G7 results (goldens) must come out of BIGSI on top of a three-shard group.
+* the RCCL calls themselves with the one rank a one-GPU box allows: a one-device group (ncclCommInitAll over [0]) and a
+  one-rank communicator (bigsi_hip_comm_init_rank + bigsi_hip_batch_run_sharded): ncclAllGather / ncclAllReduce are really
+  issued, on the library's own communicator stream.
+The N-rank RCCL run is the driver's scaling bench (bench.py --gpus N), which verifies planted hits on every shard."""
+import itertools
+
+import numpy as np
+import pytest
+
+from conftest import check_search, load_golden
+
+pytestmark = pytest.mark.gpu
+_counter = itertools.count()
+
+
+def rand_seqs(rng, n, lo, hi):
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    return [lut[rng.integers(0, 4, size=int(rng.integers(lo, hi + 1)))].tobytes().decode("ascii") for _ in range(n)]
+
+
+def group_storage(m, total_cols, h, devices, seed=77, draws=1):
+    from bigsi_amd.storage import get_storage
+    cfg = {"storage-engine": "hip-hbm", "k": 31, "m": m, "h": h,
+           "storage-config": {"name": "grp%d" % next(_counter), "devices": devices, "max_cols": total_cols}}
+    st = get_storage(cfg)
+    st.delete_all()
+    for key, v in (("number_of_rows", m), ("number_of_cols", total_cols), ("ksi:bloomfilter_size", m), ("ksi:num_hashes", h)):
+        st.set_integer(key, v)
+    st.fill_synthetic(seed, 0, draws)
+    return cfg, st
+
+
+def shard_oracles(st, m, h, seed, draws):
+    from oracle.ref_model import SynthOracle
+    inf = st.res.info()
+    sc, total = int(inf.shard_cols), int(inf.num_cols)
+    orcs = []
+    for i in range(int(inf.n_shards)):
+        n_i = max(0, min(sc, total - i * sc))
+        orcs.append(SynthOracle(seed, i, m, n_i, h, 31, draws) if n_i else None)
+    return sc, orcs
+
+
+def whole_counts(orcs, sc, seq):
+    """per-sample counts on the concatenated index, indexed by GLOBAL colour (shard * shard_cols + local)."""
+    u, out = 0, np.zeros(len(orcs) * sc, np.int64)
+    for i, o in enumerate(orcs):
+        if o is not None:
+            u, c = o.counts(seq)
+            out[i * sc: i * sc + c.size] = c
+    return u, out
+
+
+@pytest.mark.parametrize("devices,total", [([0, 0], 200), ([0, 0, 0], 200), ([0, 0], 129), ([0, 0, 0, 0], 1000), ([0], 150)])
+def test_group_vs_oracle(devices, total):
+    """shard widths: 200/2 -> 128 + 72; 200/3 -> 128 + 72 + 0 (an empty shard); 129/2 -> 128 + 1; 1000/4 -> 256 x 3 + 232;
+    a one-device group exchanges through RCCL (one rank)."""
+    from bigsi_amd import _lib
+    m, h, seed = 20011, 3, 77
+    cfg, st = group_storage(m, total, h, devices, seed)
+    inf = st.res.info()
+    assert inf.n_shards == len(devices) and inf.rccl == (1 if len(devices) == 1 else 0)
+    sc, orcs = shard_oracles(st, m, h, seed, 1)
+    rng = np.random.default_rng(total)
+    seqs = rand_seqs(rng, 9, 31, 400) + ["ACGT" * 20, "N" * 40]
+    plant = [0, total - 1, min(total - 1, sc), total // 2]
+    for j, c in enumerate(plant):
+        st.insert_kmers(c, [seqs[j][: max(31, len(seqs[j]) * (3 if j % 2 else 4) // 4)]], 31)
+        orcs[c // sc].insert_kmers(c % sc, seqs[j][: max(31, len(seqs[j]) * (3 if j % 2 else 4) // 4)])
+    # storage contract over whole rows: what the device holds == the shards' rows side by side
+    ids = np.array([0, 1, m // 2, m - 1], dtype=np.uint64)
+    got = st.get_rows_packed(ids, (total + 7) // 8)
+    for t, r in enumerate(ids):
+        want = np.zeros(len(orcs) * sc // 8, np.uint8)
+        for i, o in enumerate(orcs):
+            if o is not None:
+                row = o.row(int(r))
+                want[i * sc // 8: i * sc // 8 + row.size] = row
+        assert np.array_equal(got[t], want[: (total + 7) // 8])
+    batch = st.new_batch(seqs, 31)
+    for thr in (1.0, 0.3, 0.0):
+        batch.run(thr)
+        nk, nu, mk = batch.unique()
+        off, col, cnt = batch.hits()
+        for i, s in enumerate(seqs):
+            u, wc = whole_counts(orcs, sc, s)
+            assert nu[i] == u
+            valid = np.zeros(wc.size, bool)
+            for g, o in enumerate(orcs):
+                if o is not None:
+                    valid[g * sc: g * sc + o.n_cols] = True
+            want = np.flatnonzero(valid & (wc >= (u if thr == 1.0 else mk[i])))
+            lo, hi = int(off[i]), int(off[i + 1])
+            assert np.array_equal(col[lo:hi], want), (thr, i, col[lo:hi][:5], want[:5])
+            assert np.array_equal(cnt[lo:hi], wc[want].astype(np.uint32)), (thr, i)
+        if thr == 0.3:      # presence strings, each produced on the shard that owns the column
+            i = 0
+            hits = col[int(off[0]):int(off[1])]
+            strs = batch.presence(0, hits, int(nk[0]))
+            for c, sgot in zip(hits.tolist(), strs):
+                kmers, uniq, rows = orcs[c // sc].per_kmer_rows(seqs[0])
+                bits = np.unpackbits(rows, axis=1)[:, c % sc]
+                idx = {km: t for t, km in enumerate(uniq)}
+                assert sgot == "".join("1" if bits[idx[km]] else "0" for km in kmers)
+    batch.close()
+    # lookup of explicit k-mers: AND of the h rows, whole-index bytes
+    kms = [seqs[0][:31], seqs[1][:31]]
+    got = st.lookup_kmers(kms)
+    for km in kms:
+        want = np.zeros(len(orcs) * sc // 8, np.uint8)
+        for i, o in enumerate(orcs):
+            if o is not None:
+                _, _, rows = o.per_kmer_rows(km)
+                want[i * sc // 8: i * sc // 8 + rows.shape[1]] = rows[0]
+        assert got[km] == want[: (total + 7) // 8].tobytes()
+    # the one-call entry point of the C ABI
+    blob, offs = _lib.pack_seqs(seqs)
+    nk2, nu2, mk2 = (np.zeros(len(seqs), np.uint32) for _ in range(3))
+    hoff = np.zeros(len(seqs) + 1, np.uint64)
+    hc, hn = np.zeros(1 << 16, np.uint32), np.zeros(1 << 16, np.uint32)
+    _lib.check(_lib.lib().bigsi_hip_group_search_batch(st.handle, blob, _lib.ptr(offs), len(seqs), 31, 0.3, 0, _lib.ptr(nk2), _lib.ptr(nu2),
+                                                       _lib.ptr(mk2), _lib.ptr(hoff), _lib.ptr(hc), _lib.ptr(hn), hc.size))
+    batch = st.new_batch(seqs, 31)
+    batch.run(0.3)
+    off, col, cnt = batch.hits()
+    assert np.array_equal(hoff, off) and np.array_equal(hc[: int(off[-1])], col) and np.array_equal(hn[: int(off[-1])], cnt)
+    batch.close()
+    st.delete_all()
+
+
+@pytest.mark.parametrize("devices", [[0, 0], [0]])
+def test_group_hit_lists_regrow(devices):
+    """threshold 0 returns every sample of every query: more hits than the shards' gathered hit buffers start with (65536),
+    so every shard must grow + rewrite its lists and the per-hit counts must be reduced again over the larger arrays."""
+    m, h, total, seed = 5003, 2, 1500, 9
+    cfg, st = group_storage(m, total, h, devices, seed)
+    sc, orcs = shard_oracles(st, m, h, seed, 1)
+    seqs = rand_seqs(np.random.default_rng(3), 64, 40, 70)
+    batch = st.new_batch(seqs, 31)
+    batch.run(0.0)
+    off, col, cnt = batch.hits()
+    assert int(off[-1]) == total * len(seqs) > 65536
+    for i in (0, 17, 63):
+        u, wc = whole_counts(orcs, sc, seqs[i])
+        valid = np.concatenate([np.arange(g * sc, g * sc + o.n_cols) for g, o in enumerate(orcs) if o is not None])
+        assert np.array_equal(col[int(off[i]):int(off[i + 1])], valid)
+        assert np.array_equal(cnt[int(off[i]):int(off[i + 1])], wc[valid].astype(np.uint32))
+    batch.run(0.6)          # back to short lists with the large buffers still around
+    off, col, cnt = batch.hits()
+    _, nu, mk = batch.unique()
+    for i in (0, 17, 63):
+        u, wc = whole_counts(orcs, sc, seqs[i])
+        valid = np.zeros(wc.size, bool)
+        for g, o in enumerate(orcs):
+            if o is not None:
+                valid[g * sc: g * sc + o.n_cols] = True
+        want = np.flatnonzero(valid & (wc >= mk[i]))
+        assert np.array_equal(col[int(off[i]):int(off[i + 1])], want)
+        assert np.array_equal(cnt[int(off[i]):int(off[i + 1])], wc[want].astype(np.uint32))
+    batch.close()
+    st.delete_all()
+
+
+def test_bigsi_over_three_shards_reproduces_reference_results():
+    """The reference's own answers on the 200-sample G7 index (goldens: searches with and without scores, exceptions,
+    lookups) from BIGSI on top of ONE get_storage() call that spreads the index over three shards (128 + 72 + 0 columns)."""
+    from bigsi_amd import BIGSI
+    g = load_golden("g7_random.json")
+    k, m, h = g["k"], g["m"], g["h"]
+    cfg = {"storage-engine": "hip-hbm", "k": k, "m": m, "h": h,
+           "storage-config": {"name": "grp%d" % next(_counter), "devices": [0, 0, 0], "max_cols": len(g["sample_names"])}}
+    b = BIGSI.build_from_sequences(cfg, {nm: list(g["sample_seqs"][i]) for i, nm in enumerate(g["sample_names"])})
+    assert b.storage.res.info().n_shards == 3 and b.num_samples == 200
+    for rec in g["lookups"]:
+        kms = [rec["seq"][i:i + k] for i in range(len(rec["seq"]) - k + 1)]
+        got = b.lookup(kms, remove_trailing_zeros=False)
+        assert {km: v.tobytes().hex() for km, v in got.items()} == rec["lookup"]
+    for s in g["searches"]:
+        check_search(lambda: b.search(g["queries"][s["q"]], s["threshold"], s["score"]), s, "q%d t=%r" % (s["q"], s["threshold"]))
+    multi = b.search_batch(g["queries"][:10], 0.4)
+    for qi in range(10):
+        assert multi[qi] == b.search(g["queries"][qi], 0.4)
+    # the same index built through the Bloom-filter route (device transpose routed to the owning shards) holds the same rows
+    cfg2 = {"storage-engine": "hip-hbm", "k": k, "m": m, "h": h,
+            "storage-config": {"name": "grp%d" % next(_counter), "devices": [0, 0, 0], "max_cols": 200}}
+    blooms = [BIGSI.bloom({"k": k, "m": m, "h": h, "storage-config": {}}, [a[i:i + k] for i in range(len(a) - k + 1)] + [c[i:i + k] for i in range(len(c) - k + 1)])
+              for a, c in g["sample_seqs"]]
+    b2 = BIGSI.build(cfg2, blooms, g["sample_names"])
+    ids = np.arange(m)
+    assert np.array_equal(b2.storage.get_rows_packed(ids), b.storage.get_rows_packed(ids))
+    assert b2.search(g["queries"][0], 0.4) == b.search(g["queries"][0], 0.4)
+    b2.delete()
+    b.delete()
+
+
+@pytest.mark.parametrize("threshold", [1.0, 0.3])
+def test_one_rank_rccl_communicator(threshold):
+    """bigsi_hip_comm_init_rank + bigsi_hip_batch_run_sharded with world = 1: the library's own ncclAllGather (in place) and
+    ncclAllReduce on its communicator stream, two batches alternating so that exchanges overlap the next run."""
+    from bigsi_amd.parallel import ShardedSearch
+    from bigsi_amd.storage import get_storage
+    from oracle.ref_model import SynthOracle
+    m, n, h, seed = 30011, 5000, 3, 5
+    cfg = {"storage-engine": "hip-hbm", "k": 31, "m": m, "h": h, "storage-config": {"name": "comm%d" % next(_counter), "max_cols": n}}
+    st = get_storage(cfg)
+    st.delete_all()
+    for key, v in (("number_of_rows", m), ("number_of_cols", n), ("ksi:bloomfilter_size", m), ("ksi:num_hashes", h)):
+        st.set_integer(key, v)
+    st.fill_synthetic(seed, 0, 1)
+    orc = SynthOracle(seed, 0, m, n, h, 31, 1)
+    rng = np.random.default_rng(8)
+    sets = [rand_seqs(rng, 12, 31, 300) for _ in range(2)]
+    st.insert_kmers(4999, [sets[0][0]], 31)
+    orc.insert_kmers(4999, sets[0][0])
+    sh = ShardedSearch(st, n + 120, force_gather=True)          # a shard width larger than this shard's own columns
+    assert sh.exchange == "rccl" and sh.comm_ranks() == (0, 1)
+    batches = [st.new_batch(s, 31) for s in sets]
+    sh.prepare(batches, threshold == 1.0)
+    for _ in range(5):
+        sh.step(batches, threshold)
+    for b, seqs in zip(batches, sets):
+        off, col, cnt = sh.fetch(b)
+        _, nu, mk = b.unique()
+        for i, s in enumerate(seqs):
+            u, c = orc.counts(s)
+            want = np.flatnonzero(c >= (u if threshold == 1.0 else mk[i]))
+            assert np.array_equal(col[int(off[i]):int(off[i + 1])], want)
+            assert np.array_equal(cnt[int(off[i]):int(off[i + 1])], c[want].astype(np.uint32))
+    for b in batches:
+        b.close()
+    sh.close()
+    st.delete_all()

@@ -1066,3 +1066,16 @@ def test_storage_search_batch_entry_point(hip):
                     assert (int(f), nu) == (r["num_kmers_found"], r["num_kmers"])
     finally:
         b.delete()
+
+
+def test_transpose_on_device_matches_numpy(hip):
+    from bigsi_amd import BitRow
+    from bigsi_amd.matrix.transpose import transpose, transpose_packed
+    rng = np.random.default_rng(0)
+    for n, m in [(5, 10), (10, 10), (7, 33), (1, 8), (9, 65)]:
+        a = rng.integers(0, 2, size=(n, m)).astype(bool)
+        rows = list(transpose([BitRow(r) for r in a]))
+        assert [r.tolist() for r in rows] == a.T.tolist()
+        assert np.array_equal(np.unpackbits(transpose_packed([BitRow(r) for r in a]), axis=1)[:, :n], a.T.astype(np.uint8))
+
+

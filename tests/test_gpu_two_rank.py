@@ -12,43 +12,84 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _bench(args, launcher_ranks=0, timeout=900):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable]
+    if launcher_ranks:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(launcher_ranks), "--master-addr", "127.0.0.1",
+                "--master-port", "29541"]
+    cmd += [os.path.join(ROOT, "bench.py")] + args
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    assert r.stdout.strip().splitlines()[-1] == line                # the JSON is the last line on stdout
+    return json.loads(line)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("threshold", ["1.0", "0.4"])
-def test_bench_two_ranks_on_one_gpu(threshold):
-    env = dict(os.environ, BIGSI_BENCH_DEVICE="0", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "1", "--rows", "400000",
-           "--cols", "20000", "--backend", "gloo", "--threshold", threshold, "--cpu-seconds", "0"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
-    assert r.returncode == 0, r.stderr[-2000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-    d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["total_cols"] == 40000
-    assert d["config"]["hits_last_step"] == 6                      # 3 planted queries x 2 shards
+def test_bench_self_launches_two_ranks(threshold):
+    """`python bench.py --gpus 2` as typed, no launcher: the script starts its own two ranks (here both on the one GPU of the
+    test box, gloo carrying the exchange) and rank 0 prints the line; strong scaling -- the index is split, `value` is the rate
+    against the whole of it."""
+    d = _bench(["--gpus", "2", "--steps", "6", "--warmup", "2", "--rows", "400000", "--cols", "40000", "--batch", "256",
+                "--backend", "gloo", "--one-device", "--threshold", threshold, "--cpu-seconds", "0"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["total_cols"] == 40000 and d["config"]["cols_per_gpu"] == 20000
+    assert d["config"]["hits_first_batch"] == 6                    # 3 planted queries x 2 shards
     assert "2 shard(s)" in d["config"]["verified"]
-    assert d["value"] == pytest.approx(2 * d["config"]["kmer_lookups_per_s_full_index"])
-    assert r.stdout.strip().splitlines()[-1] == line                # the JSON is the last line on stdout
+    assert d["config"]["shard_lookups_per_s_sum"] == pytest.approx(2 * d["value"])
+    assert len(d["config"]["per_rank_GBps"]) == 2 and d["config"]["exchange"] == "torch"
+    assert d["value"] == pytest.approx(d["config"]["unique_kmers_per_batch"] / d["ms_per_step"] * 1e3)
 
 
 @pytest.mark.gpu
-def test_bench_eight_ranks_on_one_gpu():
-    """world_size 8 (the node the scaling bench runs on) squeezed onto the one GPU of the test box: eight gather slots, colour
-    offsets of eight shards, the count all-reduce over eight ranks, planted hits found on every shard."""
-    env = dict(os.environ, BIGSI_BENCH_DEVICE="0", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
-           "--master-port", "29543", os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "1", "--rows", "200000",
-           "--cols", "10000", "--backend", "gloo", "--threshold", "0.4", "--cpu-seconds", "0"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
-    assert r.returncode == 0, r.stderr[-2000:]
-    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+@pytest.mark.parametrize("cols", ["129", "257", "1000"])
+def test_bench_uneven_shards(cols):
+    """Shard widths that straddle a 64-column word (65 + 64), a 128-column pair of words (129 + 128), and three ranks
+    (334 + 334 + 332): every rank must size its result vectors from the group's shard width, not from its own column count."""
+    world = 3 if cols == "1000" else 2
+    d = _bench(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--rows", "50021", "--cols", cols, "--batch", "200",
+                "--qlen", "200", "--backend", "gloo", "--one-device", "--threshold", "0.4", "--cpu-seconds", "0"])
+    assert d["n_gpus"] == world and d["config"]["total_cols"] == int(cols)
+    assert d["config"]["hits_first_batch"] == 3 * world and "%d shard(s)" % world in d["config"]["verified"]
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_under_the_launcher():
+    """world_size 8 (the node the scaling bench runs on) squeezed onto the one GPU of the test box, started the way the
+    driver starts it (torch.distributed.run): eight gather slots, colour offsets of eight shards, the count all-reduce over
+    eight ranks, planted hits found on every shard."""
+    d = _bench(["--gpus", "8", "--steps", "4", "--warmup", "1", "--rows", "200000", "--cols", "80000", "--batch", "256",
+                "--backend", "gloo", "--one-device", "--threshold", "0.4", "--cpu-seconds", "0"], launcher_ranks=8)
     assert d["n_gpus"] == 8 and d["config"]["total_cols"] == 80000
-    assert d["config"]["hits_last_step"] == 24                     # 3 planted queries x 8 shards
+    assert d["config"]["hits_first_batch"] == 24                   # 3 planted queries x 8 shards
     assert "8 shard(s)" in d["config"]["verified"]
 
 
 @pytest.mark.gpu
-def test_sharded_bigsi_equals_whole_index(tmp_path):
-    """ShardedBIGSI over two uneven shards (103 + 97 samples, two processes) must return, query for query, what the
+def test_bench_one_rank_rccl_exchange():
+    """--force-dist: the RCCL process group and the library's own communicator with the one rank a one-GPU box allows."""
+    d = _bench(["--gpus", "1", "--steps", "4", "--warmup", "2", "--rows", "400000", "--cols", "20000", "--batch", "256",
+                "--force-dist", "--threshold", "0.4", "--cpu-seconds", "0"])
+    assert d["config"]["exchange"] == "rccl" and d["config"]["rccl_ranks"] == 1 and "1 shard(s)" in d["config"]["verified"]
+
+
+@pytest.mark.gpu
+def test_bench_named_workloads_refuse_what_does_not_fit():
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c4", "--gpus", "1"], env=env, capture_output=True,
+                       text=True, timeout=300, cwd=ROOT)
+    assert r.returncode != 0 and "more than one MI355X holds" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("split", [103, 136, 65, 129])
+def test_sharded_bigsi_equals_whole_index(tmp_path, split):
+    """ShardedBIGSI over two uneven shards (103 + 97, 136 + 64, 65 + 135, 129 + 71 samples: word counts 2+2, 3+1, 2+3, 3+2; two processes) must return, query for query, what the
     reference returned on the WHOLE 200-sample index (G7 goldens): names, counts, order, percentages and -- for score=True --
     presence strings extracted on the rank that owns each hit."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -56,7 +97,7 @@ def test_sharded_bigsi_equals_whole_index(tmp_path):
     out = tmp_path / "sharded.json"
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29547", os.path.join(ROOT, "tests", "helpers", "sharded_worker.py"), str(out)]
+           "--master-port", "29547", os.path.join(ROOT, "tests", "helpers", "sharded_worker.py"), str(out), str(split)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     got = json.load(open(out))
