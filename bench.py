@@ -297,8 +297,11 @@ def main():
     # result vector the kernel stores: one bit per sample (AND bitmap / thresholded hit mask); counters only where hits are
     out_bytes = w["batch"] * wv * 8
     alg_bytes = uniq_rows * wv * 8 + out_bytes                 # SURVEY.md section 8d, this rank's shard
+    # a large batch goes out as several row-AND launches of ~1000 workgroups each: per-launch figures, as rocprofv3 reports them
+    launches_per_step = max(stats.and_launches, 1) / args.steps
     and_ms = stats.and_ms / max(stats.and_launches, 1)
-    achieved = alg_bytes / (and_ms * 1e-3) / 1e9
+    alg_bytes_launch = alg_bytes / launches_per_step
+    achieved = alg_bytes_launch / (and_ms * 1e-3) / 1e9
     per_rank_gbs = [achieved]
     if use_dist:
         t = torch.zeros(world, dtype=torch.float64, device=dev)
@@ -414,7 +417,8 @@ def main():
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_and_exact" if exact else "k_and_count",
-                         "alg_bytes_per_launch": alg_bytes, "kernel_ms": and_ms, "launches_timed": int(stats.and_launches),
+                         "alg_bytes_per_launch": alg_bytes_launch, "kernel_ms": and_ms, "launches_timed": int(stats.and_launches),
+                         "launches_per_step": launches_per_step, "alg_bytes_per_step": alg_bytes,
                          "rank": 0,
                          # per step, from warmup steps 2..W: K1 (+ row sort on the exact path); K4
                          "kmerize_ms": warm.kmerize_ms / (args.warmup - 1) if args.warmup > 1 else None,

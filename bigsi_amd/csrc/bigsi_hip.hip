@@ -204,7 +204,6 @@ extern "C" int bigsi_hip_synchronize(bigsi_hip_index *ix)
 
 // ------------------------------------------------------------------------------ storage contract
 static const uint64_t kStageBytes = 64ull << 20;
-static const uint64_t kInlineScanMax = 4096;     // K4 chunks up to which the write pass does its own prefix sum (compact_ex)
 
 extern "C" int bigsi_hip_set_rows(bigsi_hip_index *ix, const uint64_t *row_ids, uint64_t n, const uint8_t *bytes, uint64_t row_bytes)
 {
@@ -425,11 +424,12 @@ static int ev_begin(bigsi_hip_index *ix, EventPair *p, hipStream_t st = nullptr,
     return BIGSI_OK;
 }
 
-static int ev_end(bigsi_hip_index *ix, EventPair *p, std::vector<EventPair> &dst, hipStream_t st = nullptr)
+static int ev_end(bigsi_hip_index *ix, EventPair *p, std::vector<EventPair> &dst, hipStream_t st = nullptr, uint32_t launches = 1)
 {
     if (!p->a) return BIGSI_OK;          // not being timed
     if (!st) st = ix->stream;
     HIP_TRY(hipEventRecord(p->b, st));
+    p->launches = launches;
     dst.push_back(*p);
     return BIGSI_OK;
 }
@@ -448,9 +448,10 @@ extern "C" int bigsi_hip_stats(bigsi_hip_index *ix, bigsi_hip_stats_t *out, int 
     HIP_TRY(hipStreamSynchronize(ix->pre_stream));
     HIP_TRY(hipStreamSynchronize(ix->stream));
     auto sum = [&](std::vector<EventPair> &v, uint64_t *n, double *ms) -> int {
-        *n = v.size();
+        *n = 0;
         *ms = 0;
         for (auto &p : v) {
+            *n += p.launches;
             float t = 0;
             HIP_TRY(hipEventElapsedTime(&t, p.a, p.b));
             *ms += t;
@@ -619,15 +620,26 @@ extern "C" int bigsi_hip_batch_set_outputs(bigsi_hip_batch *b, void *d_bitmaps, 
 }
 
 // -------- K2 dispatch
+// one launch of the counting kernel over the queries [q0, q1) of the batch
+struct CountLaunch {
+    const uint64_t *k2_rows;
+    unsigned block;
+    uint32_t tiles, segs;       // wide kernel: column tiles per query; narrow kernel (segs > 0): 256-byte segments per query
+    void *out;
+    uint64_t out_stride;
+    uint64_t *hit_bitmap;
+    uint32_t sparse, slices;
+};
+
 template <int P, typename CountT>
-static void launch_count_h(bigsi_hip_batch *b, const uint64_t *k2_rows, unsigned grid, unsigned block, uint32_t tiles, CountT *out,
-                           uint64_t out_stride, uint64_t *hit_bitmap, uint32_t sparse, uint32_t slices)
+static void launch_count_wide(bigsi_hip_batch *b, const CountLaunch &c, uint32_t q0, uint32_t q1)
 {
     bigsi_hip_index *ix = b->ix;
-#define BIGSI_LAUNCH_COUNT(H)                                                                                              \
-    hipLaunchKernelGGL((k_and_count<P, H, CountT>), dim3(grid), dim3(block), 0, ix->stream, ix->d_index, ix->stride_words, \
-                       (uint32_t)b->wv, k2_rows, b->d_pos_off.as<uint64_t>(), b->num_unique.as<uint32_t>(), \
-                       ix->h, b->n_seqs, tiles, out, out_stride, b->min_kmers.as<uint32_t>(), ix->n_cols, hit_bitmap, b->wv_pad, sparse, slices)
+    const unsigned grid = (unsigned)(ceil_div(q1 - q0, 8) * 8 * (uint64_t)c.tiles * c.slices);
+#define BIGSI_LAUNCH_COUNT(H)                                                                                               \
+    hipLaunchKernelGGL((k_and_count<P, H, CountT>), dim3(grid), dim3(c.block), 0, ix->stream, ix->d_index, ix->stride_words, \
+                       (uint32_t)b->wv, c.k2_rows, b->d_pos_off.as<uint64_t>(), b->num_unique.as<uint32_t>(), ix->h, q0, q1,  \
+                       c.tiles, (CountT *)c.out, c.out_stride, b->min_kmers.as<uint32_t>(), ix->n_cols, c.hit_bitmap, b->wv_pad, c.sparse, c.slices)
     switch (ix->h) {
     case 1: BIGSI_LAUNCH_COUNT(1); break;
     case 2: BIGSI_LAUNCH_COUNT(2); break;
@@ -637,6 +649,42 @@ static void launch_count_h(bigsi_hip_batch *b, const uint64_t *k2_rows, unsigned
     default: BIGSI_LAUNCH_COUNT(0); break;
     }
 #undef BIGSI_LAUNCH_COUNT
+}
+
+// narrow rows: instantiated for the plane counts of reads / gene-length queries and h = 2..4 (count_narrow_ok)
+static bool count_narrow_ok(int P, uint32_t h) { return (P == 6 || P == 10) && h >= 2 && h <= 4; }
+
+template <int P>
+static void launch_count_narrow(bigsi_hip_batch *b, const CountLaunch &c, uint32_t q0, uint32_t q1)
+{
+    bigsi_hip_index *ix = b->ix;
+    const unsigned grid = (unsigned)ceil_div((uint64_t)(q1 - q0) * c.segs, kBlock / 64);
+#define BIGSI_LAUNCH_COUNT_NARROW(H)                                                                                         \
+    hipLaunchKernelGGL((k_and_count_narrow<P, H, 16, uint16_t>), dim3(grid), dim3(kBlock), 0, ix->stream, ix->d_index,          \
+                       ix->stride_words, (uint32_t)b->wv, c.k2_rows, b->d_pos_off.as<uint64_t>(), b->num_unique.as<uint32_t>(), q0, \
+                       q1, c.segs, (uint16_t *)c.out, c.out_stride, b->min_kmers.as<uint32_t>(), ix->n_cols, c.hit_bitmap, b->wv_pad, c.sparse)
+    switch (ix->h) {
+    case 2: BIGSI_LAUNCH_COUNT_NARROW(2); break;
+    case 3: BIGSI_LAUNCH_COUNT_NARROW(3); break;
+    default: BIGSI_LAUNCH_COUNT_NARROW(4); break;
+    }
+#undef BIGSI_LAUNCH_COUNT_NARROW
+}
+
+static void launch_count(bigsi_hip_batch *b, int P, const CountLaunch &c, uint32_t q0, uint32_t q1)
+{
+    if (c.segs) {
+        if (P == 6) launch_count_narrow<6>(b, c, q0, q1);
+        else launch_count_narrow<10>(b, c, q0, q1);
+        return;
+    }
+    switch (P) {
+    case 6: launch_count_wide<6, uint16_t>(b, c, q0, q1); break;
+    case 10: launch_count_wide<10, uint16_t>(b, c, q0, q1); break;
+    case 12: launch_count_wide<12, uint16_t>(b, c, q0, q1); break;
+    case 16: launch_count_wide<16, uint16_t>(b, c, q0, q1); break;
+    default: launch_count_wide<32, uint32_t>(b, c, q0, q1); break;
+    }
 }
 
 static int compact(bigsi_hip_batch *b, HitBufs &hb, const void *src, uint32_t n_shards, uint64_t shard_cols, bool write_only);
@@ -832,10 +880,24 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
     const int and_block = b->exact ? and_block_env : std::min(and_block_env, 256);
     static const int and_unroll = env_int("BIGSI_HIP_AND_UNROLL", 8);
     const uint32_t tiles = (uint32_t)ceil_div(b->wv, (uint64_t)and_block * kVec);
+    // planes needed for the largest possible count = max k-mers of any sequence in the batch
+    const uint64_t maxu = b->max_pos;
+    const int P = maxu < (1ull << 6) ? 6 : maxu < (1ull << 10) ? 10 : maxu < (1ull << 12) ? 12 : maxu < (1ull << 16) ? 16 : 32;
+    // narrow rows (reads against a small index, or a thin column shard): one wavefront = four 256-byte row segments of four
+    // different rows instead of one 1 KiB segment of one row -- taken when it keeps clearly more lanes live than the wide
+    // kernel, or when row lists are so short that the wide kernel's chain of load rounds is what a step waits for
+    static const int narrow_env = env_int("BIGSI_HIP_NARROW", -1);      // -1 heuristic, 0 never, 1 whenever possible
+    const uint32_t segs_narrow = (uint32_t)ceil_div(b->wv, 16 * kVec);
+    bool narrow = false;
+    if (narrow_env != 0 && b->wv <= 1024 && (b->exact || (count_narrow_ok(P, ix->h) && !b->ext_counts))) {
+        const double wide_util = (double)b->wv / (double)(ceil_div(b->wv, 64 * kVec) * 64 * kVec);
+        const double narrow_util = (double)b->wv / (double)(segs_narrow * 16 * kVec);
+        narrow = narrow_env == 1 || narrow_util >= wide_util + 0.04 || b->max_pos * ix->h <= 512;
+    }
     // small batches: cut every query's row list into slices so that ~2k wavefronts are in flight (see map_block)
     static const int slices_env = env_int("BIGSI_HIP_SLICES", 0);
     uint32_t slices = 1;
-    {
+    if (!narrow) {
         const uint64_t waves = (uint64_t)b->n_seqs * ceil_div(b->wv, 64 * kVec);
         if (slices_env > 0) slices = (uint32_t)slices_env;
         else if (waves < 1024) slices = (uint32_t)std::min<uint64_t>({64, ceil_div(2048, std::max<uint64_t>(waves, 1)), std::max<uint64_t>(b->max_pos / 16, 1)});
@@ -843,32 +905,49 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
         slices = std::max<uint32_t>(slices, 1);
     }
     b->local_from_counts = false;
-    const uint64_t nblk = ceil_div(b->n_seqs, 8) * 8 * (uint64_t)tiles * slices;
-    if (nblk > 0x7FFFFFFFull) return fail(BIGSI_ERR_INVALID, "batch too large for one launch (%llu workgroups)", (unsigned long long)nblk);
-    const unsigned grid = (unsigned)nblk;
+    // large batches go out as several launches of about k2_blocks workgroups (all co-resident, sweeping the address-ordered
+    // row lists together); queries per launch a multiple of 8 (the blockIdx -> XCD map)
+    static const int k2_blocks = env_int("BIGSI_HIP_K2_BLOCKS", 1024);
+    const uint64_t blocks_per_q = narrow ? 1 : (uint64_t)tiles * slices;      // narrow: a fraction of a workgroup per query
+    uint32_t chunk_q = b->n_seqs;
+    {
+        const uint64_t total_blocks = narrow ? ceil_div((uint64_t)b->n_seqs * segs_narrow, kBlock / 64) : ceil_div(b->n_seqs, 8) * 8 * blocks_per_q;
+        if (total_blocks > 0x7FFFFFFFull) return fail(BIGSI_ERR_INVALID, "batch too large for one launch (%llu workgroups)", (unsigned long long)total_blocks);
+        if (k2_blocks > 0 && b->exact && !narrow && total_blocks > 2ull * (uint64_t)k2_blocks)
+            chunk_q = (uint32_t)std::max<uint64_t>(8, ((uint64_t)k2_blocks / blocks_per_q) / 8 * 8);
+    }
+    uint32_t n_launches = 0;
     if (b->exact) {
         uint64_t *out = (uint64_t *)b->ext_bitmaps;
         if (!out) { TRY(b->bitmaps.reserve((size_t)b->n_seqs * b->wv_pad * 8)); out = b->bitmaps.as<uint64_t>(); }
         if (slices > 1) HIP_TRY(hipMemsetAsync(out, 0xFF, (size_t)b->n_seqs * b->wv_pad * 8, ix->stream));
         TRY(ev_begin(ix, &ep, nullptr, true));
+        static const int and_nt = env_int("BIGSI_HIP_AND_NT", 1);     // 0: plain loads (A/B against non-temporal)
+        for (uint32_t q0 = 0; q0 < b->n_seqs; q0 += chunk_q, n_launches++) {
+            const uint32_t q1 = std::min<uint64_t>((uint64_t)q0 + chunk_q, b->n_seqs);
+            if (narrow) {
+                const unsigned grid = (unsigned)ceil_div((uint64_t)(q1 - q0) * segs_narrow, kBlock / 64);
+                hipLaunchKernelGGL((k_and_exact_narrow<16, 8>), dim3(grid), dim3(kBlock), 0, ix->stream, ix->d_index, ix->stride_words,
+                                   (uint32_t)b->wv, ix->n_cols, k2_rows, b->d_pos_off.as<uint64_t>(), b->num_unique.as<uint32_t>(), ix->h, q0, q1,
+                                   segs_narrow, out, b->wv_pad);
+                continue;
+            }
+            const unsigned grid = (unsigned)(ceil_div(q1 - q0, 8) * 8 * blocks_per_q);
 #define COMMA ,
 #define BIGSI_LAUNCH_EXACT(U)                                                                                                  \
     hipLaunchKernelGGL((k_and_exact<U>), dim3(grid), dim3(and_block), 0, ix->stream, ix->d_index, ix->stride_words, (uint32_t)b->wv, \
-                       ix->n_cols, k2_rows, b->d_pos_off.as<uint64_t>(), b->num_unique.as<uint32_t>(), ix->h,    \
-                       b->n_seqs, tiles, out, b->wv_pad, slices, (flags & BIGSI_RUN_EARLY_EXIT) ? 1u : 0u)
-        static const int and_nt = env_int("BIGSI_HIP_AND_NT", 1);     // 0: plain loads (A/B against non-temporal)
-        if (and_unroll == 4) BIGSI_LAUNCH_EXACT(4);
-        else if (and_unroll == 16) BIGSI_LAUNCH_EXACT(16);
-        else if (!and_nt) BIGSI_LAUNCH_EXACT(8 COMMA false);
-        else BIGSI_LAUNCH_EXACT(8);
+                       ix->n_cols, k2_rows, b->d_pos_off.as<uint64_t>(), b->num_unique.as<uint32_t>(), ix->h, q0,    \
+                       q1, tiles, out, b->wv_pad, slices, (flags & BIGSI_RUN_EARLY_EXIT) ? 1u : 0u)
+            if (and_unroll == 4) BIGSI_LAUNCH_EXACT(4);
+            else if (and_unroll == 16) BIGSI_LAUNCH_EXACT(16);
+            else if (!and_nt) BIGSI_LAUNCH_EXACT(8 COMMA false);
+            else BIGSI_LAUNCH_EXACT(8);
 #undef BIGSI_LAUNCH_EXACT
 #undef COMMA
+        }
         HIP_TRY(hipGetLastError());
-        TRY(ev_end(ix, &ep, ix->ev_and));
+        TRY(ev_end(ix, &ep, ix->ev_and, nullptr, n_launches));
     } else {
-        // planes needed for the largest possible count = max k-mers of any sequence in the batch
-        const uint64_t maxu = b->max_pos;
-        int P = maxu < (1ull << 6) ? 6 : maxu < (1ull << 10) ? 10 : maxu < (1ull << 16) ? 16 : 32;
         b->count_bytes = P <= 16 ? 2 : 4;
         const uint64_t cstride = b->wv_pad * 64;
         void *out = b->ext_counts;
@@ -883,14 +962,11 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
             b->local_from_counts = true;      // K4 thresholds the summed counters
         }
         TRY(ev_begin(ix, &ep, nullptr, true));
-        switch (P) {
-        case 6: launch_count_h<6, uint16_t>(b, k2_rows, grid, and_block, tiles, (uint16_t *)out, cstride, hb, sparse, slices); break;
-        case 10: launch_count_h<10, uint16_t>(b, k2_rows, grid, and_block, tiles, (uint16_t *)out, cstride, hb, sparse, slices); break;
-        case 16: launch_count_h<16, uint16_t>(b, k2_rows, grid, and_block, tiles, (uint16_t *)out, cstride, hb, sparse, slices); break;
-        default: launch_count_h<32, uint32_t>(b, k2_rows, grid, and_block, tiles, (uint32_t *)out, cstride, hb, sparse, slices); break;
-        }
+        const CountLaunch cl{k2_rows, (unsigned)and_block, tiles, narrow ? segs_narrow : 0u, out, cstride, hb, sparse, slices};
+        for (uint32_t q0 = 0; q0 < b->n_seqs; q0 += chunk_q, n_launches++)
+            launch_count(b, P, cl, q0, (uint32_t)std::min<uint64_t>((uint64_t)q0 + chunk_q, b->n_seqs));
         HIP_TRY(hipGetLastError());
-        TRY(ev_end(ix, &ep, ix->ev_and));
+        TRY(ev_end(ix, &ep, ix->ev_and, nullptr, n_launches));
     }
 
     b->compacted = !(flags & BIGSI_RUN_SKIP_COMPACT);
@@ -922,34 +998,47 @@ static int compact_ex(bigsi_hip_batch *b, HitBufs &hb, const void *src, bool fro
     const uint32_t chunks = !from_counts ? (uint32_t)ceil_div(b->wv, kBlock) : (uint32_t)ceil_div(b->wv_pad * 64, kChunkCols);
     const uint64_t per_seq = (uint64_t)n_shards * chunks, nchunks = per_seq * b->n_seqs;
     if (nchunks > 0x7FFFFFFFull) return fail(BIGSI_ERR_INVALID, "too many compaction chunks");
-    TRY(hb.chunk_hits.reserve(nchunks * 4));
-    TRY(hb.chunk_off.reserve(nchunks * 8));
     TRY(hb.hit_off.reserve((b->n_seqs + 1) * 8ull));
-    TRY(hb.overflow.reserve(4));
     if (hb.cap == 0 && !hb.xcol) {
         const uint64_t want = 1u << 16;
         TRY(hb.hit_col.reserve(want * 4));
         TRY(hb.hit_cnt.reserve(want * 4));
         hb.cap = want;
     }
+    if (!from_counts) {
+        // bit vectors (the AND bitmap / the fused count >= min_kmers mask): ONE launch -- count, chained scan, ordered write
+        // (k_hits_fused).  `write_only` (the lists overflowed and were grown) simply runs it again.
+        if (hb.lb_state.cap < nchunks * 8 || !hb.lb_ticket.p) {
+            TRY(hb.lb_state.reserve(nchunks * 8));
+            TRY(hb.lb_ticket.reserve(8));
+            HIP_TRY(hipMemsetAsync(hb.lb_state.p, 0, hb.lb_state.cap, st));       // fresh memory: generation 0 everywhere
+            HIP_TRY(hipMemsetAsync(hb.lb_ticket.p, 0, 8, st));
+            hb.ticket_base = 0;
+            hb.gen = 0;
+        }
+        if (++hb.gen >= (1u << 20)) {      // the 20-bit generation wraps: make every stale word unmistakably old again
+            HIP_TRY(hipMemsetAsync(hb.lb_state.p, 0, hb.lb_state.cap, st));
+            hb.gen = 1;
+        }
+        hipLaunchKernelGGL(k_hits_fused, dim3((unsigned)nchunks), dim3(kBlock), 0, st, (const uint64_t *)src, b->wv_pad, (uint32_t)b->wv, b->n_seqs,
+                           n_shards, chunks, shard_cols, b->num_unique.as<uint32_t>(), hb.lb_ticket.as<unsigned long long>(), hb.ticket_base,
+                           hb.lb_state.as<uint64_t>(), hb.gen, hb.hit_off.as<uint64_t>(), hb.col(), hb.cnt(), hb.capacity(), counters,
+                           b->count_bytes, b->wv_pad * 64, own_shard);
+        HIP_TRY(hipGetLastError());
+        hb.ticket_base += nchunks;
+        return BIGSI_OK;
+    }
+    // gathered dense counters / row-sliced local counters: threshold while compacting, three passes
+    TRY(hb.chunk_hits.reserve(nchunks * 4));
+    TRY(hb.chunk_off.reserve(nchunks * 8));
+    TRY(hb.overflow.reserve(4));
     const unsigned grid = (unsigned)nchunks;
-    // bit-vector inputs with few chunks: no scan launch, the write pass sums the chunk totals before it itself (kInlineScanMax
-    // x 4 bytes read per workgroup, out of L2)
-    uint64_t *inline_off = (!from_counts && nchunks <= kInlineScanMax) ? hb.hit_off.as<uint64_t>() : nullptr;
     HIP_TRY(hipMemsetAsync(hb.overflow.p, 0, 4, st));
 #define BIGSI_HITS_COMMON                                                                                                        \
-    b->n_seqs, n_shards, chunks, shard_cols, from_counts ? b->min_kmers.as<uint32_t>() : b->num_unique.as<uint32_t>(),          \
-        hb.chunk_hits.as<uint32_t>(), hb.chunk_off.as<uint64_t>(), hb.col(), hb.cnt(), hb.capacity(), hb.overflow.as<uint32_t>()
+    b->n_seqs, n_shards, chunks, shard_cols, b->min_kmers.as<uint32_t>(), hb.chunk_hits.as<uint32_t>(), hb.chunk_off.as<uint64_t>(), \
+        hb.col(), hb.cnt(), hb.capacity(), hb.overflow.as<uint32_t>()
     for (int pass = write_only ? 1 : 0; pass < 2; pass++) {
-        if (!from_counts) {
-            const uint64_t *bm = (const uint64_t *)src;
-            if (pass == 0)
-                hipLaunchKernelGGL((k_hits_exact<false>), dim3(grid), dim3(kBlock), 0, st, bm, b->wv_pad, (uint32_t)b->wv, BIGSI_HITS_COMMON,
-                                   counters, b->count_bytes, b->wv_pad * 64, own_shard, (uint64_t *)nullptr);
-            else
-                hipLaunchKernelGGL((k_hits_exact<true>), dim3(grid), dim3(kBlock), 0, st, bm, b->wv_pad, (uint32_t)b->wv, BIGSI_HITS_COMMON,
-                                   counters, b->count_bytes, b->wv_pad * 64, own_shard, inline_off);
-        } else if (b->count_bytes == 2) {
+        if (b->count_bytes == 2) {
             const uint16_t *c16 = (const uint16_t *)src;
             if (pass == 0) hipLaunchKernelGGL((k_hits_count<uint16_t, false>), dim3(grid), dim3(kBlock), 0, st, c16, b->wv_pad * 64, (uint32_t)b->wv, BIGSI_HITS_COMMON);
             else hipLaunchKernelGGL((k_hits_count<uint16_t, true>), dim3(grid), dim3(kBlock), 0, st, c16, b->wv_pad * 64, (uint32_t)b->wv, BIGSI_HITS_COMMON);
@@ -959,7 +1048,7 @@ static int compact_ex(bigsi_hip_batch *b, HitBufs &hb, const void *src, bool fro
             else hipLaunchKernelGGL((k_hits_count<uint32_t, true>), dim3(grid), dim3(kBlock), 0, st, c32, b->wv_pad * 64, (uint32_t)b->wv, BIGSI_HITS_COMMON);
         }
         HIP_TRY(hipGetLastError());
-        if (pass == 0 && !inline_off) {
+        if (pass == 0) {
             hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(kBlock), 0, st, hb.chunk_hits.as<uint32_t>(), nchunks, (uint32_t)per_seq,
                                b->n_seqs, hb.chunk_off.as<uint64_t>(), hb.hit_off.as<uint64_t>());
             HIP_TRY(hipGetLastError());

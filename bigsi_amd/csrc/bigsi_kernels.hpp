@@ -596,12 +596,15 @@ struct TileMap {
     uint32_t q, tile, slice;
     bool valid;
 };
-__device__ __forceinline__ TileMap map_block(uint32_t b, uint32_t n_seqs, uint32_t tiles, uint32_t slices = 1)
+// A launch covers the queries [q0, n_seqs): large batches are cut into launches of about a thousand workgroups, all
+// co-resident, which then sweep the (address-ordered) row lists together -- a grid several times the chip's residency
+// desynchronises that sweep and measured 2.5 % slower at C3.
+__device__ __forceinline__ TileMap map_block(uint32_t b, uint32_t q0, uint32_t n_seqs, uint32_t tiles, uint32_t slices = 1)
 {
     const uint32_t xcd = b & 7u, slot = b >> 3;
     const uint32_t per_q = tiles * slices;
     const uint32_t ql = slot / per_q, rem = slot - ql * per_q;
-    const uint32_t q = ql * 8u + xcd;
+    const uint32_t q = q0 + ql * 8u + xcd;
     return TileMap{q, rem / slices, rem % slices, q < n_seqs};
 }
 
@@ -622,11 +625,11 @@ template <int UNROLL, bool NT = true>
 __global__ __launch_bounds__(1024) void k_and_exact(
     const uint64_t *__restrict__ index, uint64_t stride_words, uint32_t wv, uint64_t n_cols,
     const uint64_t *__restrict__ rows, const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ num_unique,
-    uint32_t h, uint32_t n_seqs, uint32_t tiles, uint64_t *__restrict__ out, uint64_t out_stride_words,
+    uint32_t h, uint32_t q0, uint32_t n_seqs, uint32_t tiles, uint64_t *__restrict__ out, uint64_t out_stride_words,
     uint32_t slices /* > 1: `out` was preset to all ones and slices combine with atomicAnd */,
     uint32_t early_exit /* 1: a wavefront stops fetching once its 8192-column segment of the running AND is all zero */)
 {
-    const TileMap tm = map_block(blockIdx.x, n_seqs, tiles, slices);
+    const TileMap tm = map_block(blockIdx.x, q0, n_seqs, tiles, slices);
     if (!tm.valid) return;
     const uint32_t w0 = (tm.tile * blockDim.x + threadIdx.x) * kVec;
     if (w0 >= wv) return;
@@ -670,12 +673,12 @@ template <int P, int H, typename CountT>
 __global__ __launch_bounds__(kBlock) void k_and_count(
     const uint64_t *__restrict__ index, uint64_t stride_words, uint32_t wv,
     const uint64_t *__restrict__ rows, const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ num_unique,
-    uint32_t h_rt, uint32_t n_seqs, uint32_t tiles, CountT *__restrict__ out, uint64_t out_stride /* counters per query */,
+    uint32_t h_rt, uint32_t q0, uint32_t n_seqs, uint32_t tiles, CountT *__restrict__ out, uint64_t out_stride /* counters per query */,
     const uint32_t *__restrict__ min_kmers, uint64_t n_cols, uint64_t *__restrict__ hit_bitmap /* [seq][bm_stride] or null */,
     uint64_t bm_stride, uint32_t sparse /* 1: store counters only for words that contain a hit */,
     uint32_t slices /* > 1: counters were preset to zero, slices add into them atomically; no fused threshold */)
 {
-    const TileMap tm = map_block(blockIdx.x, n_seqs, tiles, slices);
+    const TileMap tm = map_block(blockIdx.x, q0, n_seqs, tiles, slices);
     if (!tm.valid) return;
     const uint32_t w0 = (tm.tile * blockDim.x + threadIdx.x) * kVec;
     if (w0 >= wv) return;
@@ -804,10 +807,170 @@ __global__ __launch_bounds__(kBlock) void k_and_count(
     }
 }
 
+
+// ------------------------------------------------------------------------------ K2 for NARROW rows (reads on small / sharded indexes)
+// A 1 KiB wavefront load wastes lanes when a row is shorter than that (BASELINE configs[1]: 10 000 samples = 157 words =
+// 1.2 wavefronts, 61 % of the lanes live), and one wavefront walking a query's whole row list is a chain of dependent
+// load rounds (93 rows / 8 in flight = 12 round trips at C2: the kernel is latency-bound, not bandwidth-bound).
+// Here a wavefront is cut into 64/G sub-groups of G lanes; a sub-group covers a G*16-byte column segment of ONE row, and the
+// 64/G sub-groups of a wavefront stream DIFFERENT rows of the query at the same segment: every lane is live for widths
+// that are multiples of G*2 words, one wave instruction has 64/G rows in flight (x UNROLL), and the sub-groups' partial
+// results are combined at the end with two cross-lane steps.  One wavefront per (query, segment); a workgroup is just
+// four consecutive such wavefronts.
+template <int G, int UNROLL>
+__global__ __launch_bounds__(kBlock) void k_and_exact_narrow(
+    const uint64_t *__restrict__ index, uint64_t stride_words, uint32_t wv, uint64_t n_cols,
+    const uint64_t *__restrict__ rows, const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ num_unique,
+    uint32_t h, uint32_t q0, uint32_t n_seqs, uint32_t segs, uint64_t *__restrict__ out, uint64_t out_stride_words)
+{
+    constexpr uint32_t RPW = 64 / G;
+    const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u, g = lane / G, l = lane % G;
+    const uint32_t ql = wave / segs, seg = wave - ql * segs;
+    const uint32_t q = q0 + ql;
+    if (q >= n_seqs) return;                                   // whole wavefront
+    const uint32_t w0 = (seg * G + l) * kVec;
+    const bool live = w0 < wv;
+    const uint64_t R = (uint64_t)num_unique[q] * h;
+    const uint64_t *qrows = rows + pos_off[q] * h;
+    const u64x2 ones = {~0ull, ~0ull};
+    u64x2 acc = ones;
+    for (uint64_t r0 = 0; r0 < R; r0 += RPW * UNROLL) {          // wave-uniform trip count
+        u64x2 v[UNROLL];
+#pragma unroll
+        for (int j = 0; j < UNROLL; j++) {
+            const uint64_t r = r0 + (uint64_t)j * RPW + g;
+            v[j] = (live && r < R) ? load_row_seg(index, qrows[r], stride_words, w0) : ones;
+        }
+#pragma unroll
+        for (int j = 0; j < UNROLL; j++) acc &= v[j];
+    }
+#pragma unroll
+    for (int d = G; d < 64; d <<= 1) {                           // AND across the sub-groups
+        acc.x &= __shfl_xor(acc.x, d, 64);
+        acc.y &= __shfl_xor(acc.y, d, 64);
+    }
+    if (R == 0) acc = u64x2{0ull, 0ull};
+    if (g != 0 || !live) return;
+    acc.x &= valid_mask(w0, n_cols);
+    acc.y &= valid_mask(w0 + 1, n_cols);
+    uint64_t *o = out + (uint64_t)q * out_stride_words + w0;
+    o[0] = acc.x;
+    if (w0 + 1 < out_stride_words) o[1] = acc.y;
+}
+
+// counting twin: sub-group g takes the unique k-mers g, g + 64/G, ... (all h rows of a k-mer stay in one lane), the
+// sub-groups' bit-sliced counters are added plane-wise at the end (a full adder per plane), after which every sub-group
+// holds the sums and expands its share of each word's 8 byte-columns.
+template <int P, int H, int G, typename CountT>
+__global__ __launch_bounds__(kBlock) void k_and_count_narrow(
+    const uint64_t *__restrict__ index, uint64_t stride_words, uint32_t wv,
+    const uint64_t *__restrict__ rows, const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ num_unique,
+    uint32_t q0, uint32_t n_seqs, uint32_t segs, CountT *__restrict__ out, uint64_t out_stride /* counters per query */,
+    const uint32_t *__restrict__ min_kmers, uint64_t n_cols, uint64_t *__restrict__ hit_bitmap, uint64_t bm_stride, uint32_t sparse)
+{
+    static_assert(H > 0, "compile-time h only");
+    constexpr uint32_t RPW = 64 / G;
+    constexpr int KM = H == 1 ? 8 : H <= 3 ? 4 : 2;             // k-mers per round per sub-group: 8-12 loads in flight
+    const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u, g = lane / G, l = lane % G;
+    const uint32_t ql = wave / segs, seg = wave - ql * segs;
+    const uint32_t q = q0 + ql;
+    if (q >= n_seqs) return;
+    const uint32_t w0 = (seg * G + l) * kVec;
+    const bool live = w0 < wv;
+    const uint32_t u = num_unique[q];
+    const uint64_t *qrows = rows + pos_off[q] * H;
+    const u64x2 zero = {0ull, 0ull};
+    uint64_t pl[kVec][P];
+#pragma unroll
+    for (int v = 0; v < kVec; v++)
+#pragma unroll
+        for (int p = 0; p < P; p++) pl[v][p] = 0;
+    for (uint32_t j0 = 0; j0 < u; j0 += RPW * KM) {             // wave-uniform trip count
+        u64x2 v[KM * H];
+#pragma unroll
+        for (int t = 0; t < KM; t++) {
+            const uint32_t j = j0 + (uint32_t)t * RPW + g;
+#pragma unroll
+            for (int s = 0; s < H; s++)
+                v[t * H + s] = (live && j < u) ? load_row_seg(index, qrows[(uint64_t)j * H + s], stride_words, w0) : zero;
+        }
+#pragma unroll
+        for (int t = 0; t < KM; t++) {
+            u64x2 a = v[t * H];
+#pragma unroll
+            for (int s = 1; s < H; s++) a &= v[t * H + s];
+            uint64_t c0 = a.x, c1 = a.y;
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                const uint64_t t0 = pl[0][p] & c0, t1 = pl[1][p] & c1;
+                pl[0][p] ^= c0; pl[1][p] ^= c1;
+                c0 = t0; c1 = t1;
+            }
+        }
+    }
+    // sum the sub-groups' counters: plane-wise full adder with the partner's planes (counts never exceed u < 2^P)
+#pragma unroll
+    for (int d = G; d < 64; d <<= 1) {
+#pragma unroll
+        for (int v = 0; v < kVec; v++) {
+            uint64_t carry = 0;
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                const uint64_t a = pl[v][p], b = __shfl_xor(a, d, 64);
+                pl[v][p] = a ^ b ^ carry;
+                carry = (a & b) | (carry & (a ^ b));
+            }
+        }
+    }
+    if (!live) return;
+    const uint32_t thr = min_kmers[q];
+#pragma unroll
+    for (int v = 0; v < kVec; v++) {
+        uint64_t gt = 0, eq = ~0ull;
+        if (P < 32 && (thr >> (P & 31)) != 0) eq = 0;
+#pragma unroll
+        for (int p = P - 1; p >= 0; p--) {
+            if ((thr >> p) & 1u) eq &= pl[v][p];
+            else { gt |= eq & pl[v][p]; eq &= ~pl[v][p]; }
+        }
+        const uint64_t ge = (gt | eq) & valid_mask((uint64_t)w0 + v, n_cols);
+        if (g == 0 && hit_bitmap && (uint64_t)w0 + v < bm_stride) hit_bitmap[(uint64_t)q * bm_stride + w0 + v] = ge;
+        const uint64_t cbase = ((uint64_t)w0 + v) * 64;
+        if (cbase >= out_stride || (sparse && ge == 0)) continue;
+        CountT *o = out + (uint64_t)q * out_stride + cbase;
+        // the 8 byte-columns of the word are shared out over the sub-groups (every sub-group holds the sums)
+        for (uint32_t b = g; b < 8; b += RPW) {
+            CountT c[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; jj++) {
+                const uint32_t bit = 8 * b + 7 - jj;
+                uint32_t x = 0;
+#pragma unroll
+                for (int p = 0; p < P; p++) x |= (uint32_t)((pl[v][p] >> bit) & 1ull) << p;
+                c[jj] = (CountT)x;
+            }
+            if (sizeof(CountT) == 2) {
+                uint4 pk;
+                pk.x = (uint32_t)c[0] | ((uint32_t)c[1] << 16); pk.y = (uint32_t)c[2] | ((uint32_t)c[3] << 16);
+                pk.z = (uint32_t)c[4] | ((uint32_t)c[5] << 16); pk.w = (uint32_t)c[6] | ((uint32_t)c[7] << 16);
+                *reinterpret_cast<uint4 *>(o + 8 * b) = pk;
+            } else {
+                uint4 lo{(uint32_t)c[0], (uint32_t)c[1], (uint32_t)c[2], (uint32_t)c[3]};
+                uint4 hi{(uint32_t)c[4], (uint32_t)c[5], (uint32_t)c[6], (uint32_t)c[7]};
+                *reinterpret_cast<uint4 *>(o + 8 * b) = lo;
+                *reinterpret_cast<uint4 *>(o + 8 * b + 4) = hi;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------ K4: threshold + compaction
-// Three passes over result buffers laid out [shard][seq][stride] (n_shards = 1 for a single GPU; > 1 for buffers
-// gathered from column shards): (a) hits per 2048-column chunk, (b) exclusive scan over chunks in
-// (seq, shard, chunk) order, (c) ordered write of (colour, count).  Colours ascend within a sequence
+// Result buffers are laid out [shard][seq][stride] (n_shards = 1 for a single GPU; > 1 for buffers gathered from column
+// shards); hits come out as (colour, count) in (seq, shard, column) order.  Bit vectors -- every production path -- take
+// ONE launch (k_hits_fused); dense counter buffers take three passes: (a) hits per 2048-column chunk, (b) exclusive scan
+// over chunks, (c) ordered write.  Colours ascend within a sequence
 // (exact_filter's np.where order, graph/bigsi.py:193-204; inexact_filter's dict order before its stable sort, :215-229).
 constexpr uint32_t kAllShards = 0xFFFFFFFFu;
 constexpr uint32_t kChunkCols = 2048;   // counting: kBlock threads x 8 columns per chunk; exact: kBlock words (16384 columns)
@@ -817,50 +980,74 @@ __device__ __forceinline__ uint64_t chunk_index(uint32_t q, uint32_t shard, uint
     return ((uint64_t)q * n_shards + shard) * chunks + chunk;
 }
 
-// exact: a hit is a set bit of the AND bitmap; its count is num_unique[q].
-template <bool WRITE>
-__global__ __launch_bounds__(kBlock) void k_hits_exact(
+// K4 in ONE launch for bit-vector inputs (the AND bitmap of an exact search, the hit mask of a thresholded one): count,
+// chained scan and ordered write fused through a decoupled look-back.  A workgroup takes a TICKET (one atomic on a
+// monotonic counter) and processes item `ticket - ticket_base` in (seq, shard, chunk) order, so every item before its own
+// is held by a workgroup that is already running: waiting for their totals cannot deadlock whatever order the hardware
+// dispatches workgroups in.  Each item publishes one 64-bit word {generation, value, status} with a single agent-scope
+// store -- first its own total (AGGREGATE), then, once the look-back has summed its predecessors, the inclusive PREFIX --
+// so flag and payload can never be seen apart, and words of earlier launches (other generation) read as EMPTY: no memset.
+constexpr uint64_t kLbAggregate = 1, kLbPrefix = 2;
+__device__ __forceinline__ uint64_t lb_pack(uint32_t gen, uint64_t value, uint64_t status) { return ((uint64_t)gen << 44) | (value << 2) | status; }
+
+__global__ __launch_bounds__(kBlock) void k_hits_fused(
     const uint64_t *__restrict__ bitmaps, uint64_t stride_words, uint32_t wv, uint32_t n_seqs, uint32_t n_shards, uint32_t chunks,
     uint64_t shard_cols, const uint32_t *__restrict__ num_unique,
-    uint32_t *__restrict__ chunk_hits, const uint64_t *__restrict__ chunk_off,
-    uint32_t *__restrict__ hit_col, uint32_t *__restrict__ hit_cnt, uint64_t capacity, uint32_t *__restrict__ overflow,
-    const void *__restrict__ counters /* null: every hit's count is num_unique[q] */, uint32_t counter_bytes, uint64_t counter_stride,
-    uint32_t own_shard /* kAllShards: counters cover every shard ([shard][seq][stride]); else they are THIS rank's ([seq][stride])
-                          and hits of other shards get count 0 (the caller sums the arrays of all ranks) */,
-    uint64_t *__restrict__ inline_hit_off /* write pass only; non-null: there was no k_scan_chunks launch -- every workgroup sums
-                          the chunk totals before its own (a few thousand at most, see compact_ex) and hit_off is written here */)
+    unsigned long long *__restrict__ ticket, uint64_t ticket_base, uint64_t *__restrict__ state, uint32_t gen,
+    uint64_t *__restrict__ hit_off, uint32_t *__restrict__ hit_col, uint32_t *__restrict__ hit_cnt, uint64_t capacity,
+    const void *__restrict__ counters, uint32_t counter_bytes, uint64_t counter_stride, uint32_t own_shard)
 {
     __shared__ uint32_t lds[16];
-    const uint32_t chunk = blockIdx.x % chunks, sq = blockIdx.x / chunks;
-    const uint32_t shard = sq % n_shards, q = sq / n_shards;
+    __shared__ uint64_t s_item, s_base;
+    if (threadIdx.x == 0) s_item = atomicAdd(ticket, 1ull) - ticket_base;
+    __syncthreads();
+    const uint64_t ci = s_item, n_items = (uint64_t)n_seqs * n_shards * chunks;
+    const uint32_t chunk = (uint32_t)(ci % chunks);
+    const uint64_t sq = ci / chunks;
+    const uint32_t shard = (uint32_t)(sq % n_shards), q = (uint32_t)(sq / n_shards);
     const uint32_t w = chunk * kBlock + threadIdx.x;   // one 64-column word per thread
     uint64_t bits = 0;
     if (w < wv) bits = bitmaps[((uint64_t)shard * n_seqs + q) * stride_words + w];
     const uint32_t mine = (uint32_t)__popcll(bits);
     uint32_t tot;
     const uint32_t pre = block_exclusive_scan(mine, &tot, lds);
-    const uint64_t ci = chunk_index(q, shard, chunk, n_shards, chunks);
-    if (!WRITE) {
-        if (threadIdx.x == 0) chunk_hits[ci] = tot;
-        return;
-    }
-    uint64_t base;
-    if (inline_hit_off) {
-        uint32_t part = 0, before;
-        for (uint64_t i = threadIdx.x; i < ci; i += kBlock) part += chunk_hits[i];
-        block_exclusive_scan(part, &before, lds);
-        base = before;
-        const uint64_t per_seq = (uint64_t)n_shards * chunks;
-        if (threadIdx.x == 0) {
-            if (ci % per_seq == 0) inline_hit_off[q] = base;
-            if (ci + 1 == per_seq * n_seqs) inline_hit_off[n_seqs] = base + tot;
+    if (threadIdx.x < 64) {                             // the first wavefront publishes and looks back
+        const uint32_t lane = threadIdx.x;
+        if (lane == 0)
+            __hip_atomic_store(&state[ci], lb_pack(gen, tot, ci == 0 ? kLbPrefix : kLbAggregate), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint64_t excl = 0;
+        int64_t pos = (int64_t)ci - 1;                  // lanes look at items pos, pos-1, ..., pos-63
+        while (pos >= 0) {
+            const int64_t j = pos - (int64_t)lane;
+            uint64_t word = lb_pack(gen, 0, kLbPrefix);  // before the first item: an empty prefix
+            if (j >= 0) {
+                for (;;) {
+                    word = __hip_atomic_load(&state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((uint32_t)(word >> 44) == gen && (word & 3ull) != 0) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            const uint64_t value = (word >> 2) & ((1ull << 42) - 1);
+            const unsigned long long has_prefix = __ballot((word & 3ull) == kLbPrefix);
+            const uint32_t stop = has_prefix ? (uint32_t)__builtin_ctzll(has_prefix) : 64u;   // nearest item whose prefix is known
+            uint64_t part = lane <= stop ? value : 0;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+            excl += part;
+            if (has_prefix) break;
+            pos -= 64;
         }
-    } else {
-        base = chunk_off[ci];
+        if (lane == 0) {
+            if (ci != 0) __hip_atomic_store(&state[ci], lb_pack(gen, excl + tot, kLbPrefix), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_base = excl;
+            if (chunk == 0 && shard == 0) hit_off[q] = excl;
+            if (ci + 1 == n_items) hit_off[n_seqs] = excl + tot;
+        }
     }
+    __syncthreads();
     if (mine == 0) return;
-    uint64_t o = base + pre;
-    if (o + mine > capacity) { *overflow = 1; return; }
+    uint64_t o = s_base + pre;
+    if (o + mine > capacity) return;                    // the host sees total > capacity, grows the lists and runs this again
     const uint32_t uq = num_unique[q];
     const uint64_t cbase = (uint64_t)shard * shard_cols + (uint64_t)w * 64;
     const bool owned = own_shard == kAllShards || own_shard == shard;
