@@ -982,44 +982,51 @@ __device__ __forceinline__ uint64_t chunk_index(uint32_t q, uint32_t shard, uint
 
 // K4 in ONE launch for bit-vector inputs (the AND bitmap of an exact search, the hit mask of a thresholded one): count,
 // chained scan and ordered write fused through a decoupled look-back.  A workgroup takes a TICKET (one atomic on a
-// monotonic counter) and processes item `ticket - ticket_base` in (seq, shard, chunk) order, so every item before its own
-// is held by a workgroup that is already running: waiting for their totals cannot deadlock whatever order the hardware
-// dispatches workgroups in.  Each item publishes one 64-bit word {generation, value, status} with a single agent-scope
-// store -- first its own total (AGGREGATE), then, once the look-back has summed its predecessors, the inclusive PREFIX --
-// so flag and payload can never be seen apart, and words of earlier launches (other generation) read as EMPTY: no memset.
+// monotonic counter) and processes the `ipb` consecutive items [ticket * ipb, +ipb) of the (seq, shard, chunk) order, so
+// every group before its own is held by a workgroup that is already running: waiting for their totals cannot deadlock
+// whatever order the hardware dispatches workgroups in.  (One word serves ~90 tickets per microsecond: `ipb` keeps the
+// number of tickets in the hundreds.)  Each group publishes one 64-bit word {generation, value, status} with a single
+// agent-scope store -- first its own total (AGGREGATE), then, once the look-back has summed its predecessors, the
+// inclusive PREFIX -- so flag and payload can never be seen apart, and words of earlier launches (other generation) read
+// as EMPTY: no memset between launches.
 constexpr uint64_t kLbAggregate = 1, kLbPrefix = 2;
 __device__ __forceinline__ uint64_t lb_pack(uint32_t gen, uint64_t value, uint64_t status) { return ((uint64_t)gen << 44) | (value << 2) | status; }
 
 __global__ __launch_bounds__(kBlock) void k_hits_fused(
     const uint64_t *__restrict__ bitmaps, uint64_t stride_words, uint32_t wv, uint32_t n_seqs, uint32_t n_shards, uint32_t chunks,
-    uint64_t shard_cols, const uint32_t *__restrict__ num_unique,
+    uint64_t shard_cols, const uint32_t *__restrict__ num_unique, uint32_t ipb,
     unsigned long long *__restrict__ ticket, uint64_t ticket_base, uint64_t *__restrict__ state, uint32_t gen,
     uint64_t *__restrict__ hit_off, uint32_t *__restrict__ hit_col, uint32_t *__restrict__ hit_cnt, uint64_t capacity,
     const void *__restrict__ counters, uint32_t counter_bytes, uint64_t counter_stride, uint32_t own_shard)
 {
     __shared__ uint32_t lds[16];
-    __shared__ uint64_t s_item, s_base;
-    if (threadIdx.x == 0) s_item = atomicAdd(ticket, 1ull) - ticket_base;
+    __shared__ uint64_t s_group, s_base;
+    if (threadIdx.x == 0) s_group = atomicAdd(ticket, 1ull) - ticket_base;
     __syncthreads();
-    const uint64_t ci = s_item, n_items = (uint64_t)n_seqs * n_shards * chunks;
-    const uint32_t chunk = (uint32_t)(ci % chunks);
-    const uint64_t sq = ci / chunks;
-    const uint32_t shard = (uint32_t)(sq % n_shards), q = (uint32_t)(sq / n_shards);
-    const uint32_t w = chunk * kBlock + threadIdx.x;   // one 64-column word per thread
-    uint64_t bits = 0;
-    if (w < wv) bits = bitmaps[((uint64_t)shard * n_seqs + q) * stride_words + w];
-    const uint32_t mine = (uint32_t)__popcll(bits);
-    uint32_t tot;
-    const uint32_t pre = block_exclusive_scan(mine, &tot, lds);
+    const uint64_t grp = s_group, n_items = (uint64_t)n_seqs * n_shards * chunks;
+    const uint64_t i0 = grp * ipb, i1 = i0 + ipb < n_items ? i0 + ipb : n_items;
+    auto word_of = [&](uint64_t ci, uint32_t *w_out) -> uint64_t {
+        const uint32_t chunk = (uint32_t)(ci % chunks);
+        const uint64_t sq = ci / chunks;
+        const uint32_t shard = (uint32_t)(sq % n_shards), q = (uint32_t)(sq / n_shards);
+        const uint32_t w = chunk * kBlock + threadIdx.x;   // one 64-column word per thread
+        *w_out = w;
+        return w < wv ? bitmaps[((uint64_t)shard * n_seqs + q) * stride_words + w] : 0ull;
+    };
+    // pass 1: the group's total
+    uint32_t mine = 0, w_unused;
+    for (uint64_t ci = i0; ci < i1; ci++) mine += (uint32_t)__popcll(word_of(ci, &w_unused));
+    uint32_t gtot;
+    block_exclusive_scan(mine, &gtot, lds);
     if (threadIdx.x < 64) {                             // the first wavefront publishes and looks back
         const uint32_t lane = threadIdx.x;
         if (lane == 0)
-            __hip_atomic_store(&state[ci], lb_pack(gen, tot, ci == 0 ? kLbPrefix : kLbAggregate), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&state[grp], lb_pack(gen, gtot, grp == 0 ? kLbPrefix : kLbAggregate), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint64_t excl = 0;
-        int64_t pos = (int64_t)ci - 1;                  // lanes look at items pos, pos-1, ..., pos-63
+        int64_t pos = (int64_t)grp - 1;                 // lanes look at groups pos, pos-1, ..., pos-63
         while (pos >= 0) {
             const int64_t j = pos - (int64_t)lane;
-            uint64_t word = lb_pack(gen, 0, kLbPrefix);  // before the first item: an empty prefix
+            uint64_t word = lb_pack(gen, 0, kLbPrefix);  // before the first group: an empty prefix
             if (j >= 0) {
                 for (;;) {
                     word = __hip_atomic_load(&state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1029,7 +1036,7 @@ __global__ __launch_bounds__(kBlock) void k_hits_fused(
             }
             const uint64_t value = (word >> 2) & ((1ull << 42) - 1);
             const unsigned long long has_prefix = __ballot((word & 3ull) == kLbPrefix);
-            const uint32_t stop = has_prefix ? (uint32_t)__builtin_ctzll(has_prefix) : 64u;   // nearest item whose prefix is known
+            const uint32_t stop = has_prefix ? (uint32_t)__builtin_ctzll(has_prefix) : 64u;   // nearest group whose prefix is known
             uint64_t part = lane <= stop ? value : 0;
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
@@ -1038,29 +1045,41 @@ __global__ __launch_bounds__(kBlock) void k_hits_fused(
             pos -= 64;
         }
         if (lane == 0) {
-            if (ci != 0) __hip_atomic_store(&state[ci], lb_pack(gen, excl + tot, kLbPrefix), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (grp != 0) __hip_atomic_store(&state[grp], lb_pack(gen, excl + gtot, kLbPrefix), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_base = excl;
-            if (chunk == 0 && shard == 0) hit_off[q] = excl;
-            if (ci + 1 == n_items) hit_off[n_seqs] = excl + tot;
+            if (i1 == n_items) hit_off[n_seqs] = excl + gtot;
         }
     }
     __syncthreads();
-    if (mine == 0) return;
-    uint64_t o = s_base + pre;
-    if (o + mine > capacity) return;                    // the host sees total > capacity, grows the lists and runs this again
-    const uint32_t uq = num_unique[q];
-    const uint64_t cbase = (uint64_t)shard * shard_cols + (uint64_t)w * 64;
-    const bool owned = own_shard == kAllShards || own_shard == shard;
-    const uint64_t cnt0 = (own_shard == kAllShards ? (uint64_t)shard * n_seqs + q : (uint64_t)q) * counter_stride + (uint64_t)w * 64;
-    for (uint32_t c = 0; c < 64; c++)
-        if ((bits >> bit_of_col(c)) & 1ull) {
-            hit_col[o] = (uint32_t)(cbase + c);
-            hit_cnt[o] = !counters ? uq
-                         : !owned ? 0u
-                         : counter_bytes == 2 ? (uint32_t) reinterpret_cast<const uint16_t *>(counters)[cnt0 + c]
-                                              : reinterpret_cast<const uint32_t *>(counters)[cnt0 + c];
-            o++;
-        }
+    // pass 2: item by item, ordered write (the words come back out of L2)
+    uint64_t base = s_base;
+    for (uint64_t ci = i0; ci < i1; ci++) {
+        uint32_t w;
+        const uint64_t bits = word_of(ci, &w);
+        const uint32_t cnt = (uint32_t)__popcll(bits);
+        uint32_t tot;
+        const uint32_t pre = block_exclusive_scan(cnt, &tot, lds);
+        const uint32_t chunk = (uint32_t)(ci % chunks);
+        const uint64_t sq = ci / chunks;
+        const uint32_t shard = (uint32_t)(sq % n_shards), q = (uint32_t)(sq / n_shards);
+        if (threadIdx.x == 0 && chunk == 0 && shard == 0) hit_off[q] = base;
+        uint64_t o = base + pre;
+        base += tot;
+        if (cnt == 0 || o + cnt > capacity) continue;     // overflow: the host sees total > capacity, grows the lists, runs this again
+        const uint32_t uq = num_unique[q];
+        const uint64_t cbase = (uint64_t)shard * shard_cols + (uint64_t)w * 64;
+        const bool owned = own_shard == kAllShards || own_shard == shard;
+        const uint64_t cnt0 = (own_shard == kAllShards ? (uint64_t)shard * n_seqs + q : (uint64_t)q) * counter_stride + (uint64_t)w * 64;
+        for (uint32_t c = 0; c < 64; c++)
+            if ((bits >> bit_of_col(c)) & 1ull) {
+                hit_col[o] = (uint32_t)(cbase + c);
+                hit_cnt[o] = !counters ? uq
+                             : !owned ? 0u
+                             : counter_bytes == 2 ? (uint32_t) reinterpret_cast<const uint16_t *>(counters)[cnt0 + c]
+                                                  : reinterpret_cast<const uint32_t *>(counters)[cnt0 + c];
+                o++;
+            }
+    }
 }
 
 // counting: a hit is a column with count >= min_kmers[q] (graph/bigsi.py:241-242); column < shard_cols only.
