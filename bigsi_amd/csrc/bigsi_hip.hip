@@ -1008,16 +1008,14 @@ static int compact_ex(bigsi_hip_batch *b, HitBufs &hb, const void *src, bool fro
     if (!from_counts) {
         // bit vectors (the AND bitmap / the fused count >= min_kmers mask): ONE launch -- count, chained scan, ordered write
         // (k_hits_fused).  `write_only` (the lists overflowed and were grown) simply runs it again.
-        // items per workgroup: a few hundred tickets whatever the batch size (the ticket counter is ONE contended word)
-        static const int k4_groups = env_int("BIGSI_HIP_K4_GROUPS", 256);
-        const uint32_t ipb = (uint32_t)std::min<uint64_t>(32, std::max<uint64_t>(1, ceil_div(nchunks, (uint64_t)std::max(k4_groups, 1))));
+        // items per workgroup such that the grid stays below what the chip holds at once (see k_hits_fused)
+        static const int k4_groups = env_int("BIGSI_HIP_K4_GROUPS", (int)kHitsMaxGroups);
+        const uint64_t max_groups = (uint64_t)std::min<int>(std::max(k4_groups, 1), (int)kHitsMaxGroups);
+        const uint32_t ipb = (uint32_t)ceil_div(nchunks, max_groups);
         const uint64_t ngroups = ceil_div(nchunks, ipb);
-        if (hb.lb_state.cap < ngroups * 8 || !hb.lb_ticket.p) {
-            TRY(hb.lb_state.reserve(ngroups * 8));
-            TRY(hb.lb_ticket.reserve(8));
+        if (hb.lb_state.cap < kHitsMaxGroups * 8) {
+            TRY(hb.lb_state.reserve(kHitsMaxGroups * 8));
             HIP_TRY(hipMemsetAsync(hb.lb_state.p, 0, hb.lb_state.cap, st));       // fresh memory: generation 0 everywhere
-            HIP_TRY(hipMemsetAsync(hb.lb_ticket.p, 0, 8, st));
-            hb.ticket_base = 0;
             hb.gen = 0;
         }
         if (++hb.gen >= (1u << 20)) {      // the 20-bit generation wraps: make every stale word unmistakably old again
@@ -1025,11 +1023,9 @@ static int compact_ex(bigsi_hip_batch *b, HitBufs &hb, const void *src, bool fro
             hb.gen = 1;
         }
         hipLaunchKernelGGL(k_hits_fused, dim3((unsigned)ngroups), dim3(kBlock), 0, st, (const uint64_t *)src, b->wv_pad, (uint32_t)b->wv, b->n_seqs,
-                           n_shards, chunks, shard_cols, b->num_unique.as<uint32_t>(), ipb, hb.lb_ticket.as<unsigned long long>(), hb.ticket_base,
-                           hb.lb_state.as<uint64_t>(), hb.gen, hb.hit_off.as<uint64_t>(), hb.col(), hb.cnt(), hb.capacity(), counters,
-                           b->count_bytes, b->wv_pad * 64, own_shard);
+                           n_shards, chunks, shard_cols, b->num_unique.as<uint32_t>(), ipb, hb.lb_state.as<uint64_t>(), hb.gen,
+                           hb.hit_off.as<uint64_t>(), hb.col(), hb.cnt(), hb.capacity(), counters, b->count_bytes, b->wv_pad * 64, own_shard);
         HIP_TRY(hipGetLastError());
-        hb.ticket_base += ngroups;
         return BIGSI_OK;
     }
     // gathered dense counters / row-sliced local counters: threshold while compacting, three passes

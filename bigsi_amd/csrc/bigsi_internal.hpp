@@ -94,10 +94,9 @@ struct bigsi_hip_comm;
 // ------------------------------------------------------------------------------ batches
 struct HitBufs {
     DevBuf chunk_hits, chunk_off, hit_off, hit_col, hit_cnt, overflow;
-    // one-launch K4 (k_hits_fused): look-back state word per chunk, the ticket counter, and the host's view of both
-    DevBuf lb_state, lb_ticket;
-    uint64_t ticket_base = 0;   // tickets handed out by all earlier launches on these buffers
-    uint32_t gen = 0;           // generation tag of the state words of the next launch (20 bits, 0 = never used)
+    // one-launch K4 (k_hits_fused): one state word per workgroup, tagged with the launch's generation
+    DevBuf lb_state;
+    uint32_t gen = 0;           // generation tag of the state words of the last launch (20 bits, 0 = never used)
     uint64_t cap = 0;   // hits the col/cnt buffers can hold
     uint32_t *xcol = nullptr, *xcnt = nullptr;   // caller-owned hit buffers (e.g. torch tensors that are then all-reduced)
     uint64_t xcap = 0;
@@ -107,7 +106,7 @@ struct HitBufs {
     void release()
     {
         chunk_hits.release(); chunk_off.release(); hit_off.release(); hit_col.release(); hit_cnt.release(); overflow.release();
-        lb_state.release(); lb_ticket.release();
+        lb_state.release();
     }
 };
 

@@ -981,29 +981,28 @@ __device__ __forceinline__ uint64_t chunk_index(uint32_t q, uint32_t shard, uint
 }
 
 // K4 in ONE launch for bit-vector inputs (the AND bitmap of an exact search, the hit mask of a thresholded one): count,
-// chained scan and ordered write fused through a decoupled look-back.  A workgroup takes a TICKET (one atomic on a
-// monotonic counter) and processes the `ipb` consecutive items [ticket * ipb, +ipb) of the (seq, shard, chunk) order, so
-// every group before its own is held by a workgroup that is already running: waiting for their totals cannot deadlock
-// whatever order the hardware dispatches workgroups in.  (One word serves ~90 tickets per microsecond: `ipb` keeps the
-// number of tickets in the hundreds.)  Each group publishes one 64-bit word {generation, value, status} with a single
-// agent-scope store -- first its own total (AGGREGATE), then, once the look-back has summed its predecessors, the
-// inclusive PREFIX -- so flag and payload can never be seen apart, and words of earlier launches (other generation) read
-// as EMPTY: no memset between launches.
-constexpr uint64_t kLbAggregate = 1, kLbPrefix = 2;
-__device__ __forceinline__ uint64_t lb_pack(uint32_t gen, uint64_t value, uint64_t status) { return ((uint64_t)gen << 44) | (value << 2) | status; }
+// scan and ordered write fused.  Workgroup g owns the `ipb` consecutive items [g * ipb, +ipb) of the (seq, shard, chunk)
+// order; the host picks ipb so that the grid never exceeds kHitsMaxGroups workgroups -- fewer than the chip holds at once
+// (256 CUs x 8 of these workgroups), so every workgroup becomes resident no matter in which order the hardware dispatches
+// them or what else is draining from the CUs, and waiting for the others' totals cannot deadlock.
+//   pass 1  the group's hit total -> published as ONE 64-bit word {generation, total + 1} by an agent-scope store (flag and
+//           payload in one granule: never seen apart; words of earlier launches carry another generation and read as
+//           "not yet": no memset between launches);
+//   scan    every thread polls the words of a share of the PRECEDING groups (all loads in flight at once) and the
+//           workgroup sums them: the exclusive prefix, one round trip instead of a chain of look-back steps;
+//   pass 2  item by item (the words come back out of L2), ordered write of (colour, count).
+constexpr uint32_t kHitsMaxGroups = 1024;
+__device__ __forceinline__ uint64_t lb_pack(uint32_t gen, uint64_t value) { return ((uint64_t)gen << 44) | (value + 1); }
 
 __global__ __launch_bounds__(kBlock) void k_hits_fused(
     const uint64_t *__restrict__ bitmaps, uint64_t stride_words, uint32_t wv, uint32_t n_seqs, uint32_t n_shards, uint32_t chunks,
-    uint64_t shard_cols, const uint32_t *__restrict__ num_unique, uint32_t ipb,
-    unsigned long long *__restrict__ ticket, uint64_t ticket_base, uint64_t *__restrict__ state, uint32_t gen,
+    uint64_t shard_cols, const uint32_t *__restrict__ num_unique, uint32_t ipb, uint64_t *__restrict__ state, uint32_t gen,
     uint64_t *__restrict__ hit_off, uint32_t *__restrict__ hit_col, uint32_t *__restrict__ hit_cnt, uint64_t capacity,
     const void *__restrict__ counters, uint32_t counter_bytes, uint64_t counter_stride, uint32_t own_shard)
 {
     __shared__ uint32_t lds[16];
-    __shared__ uint64_t s_group, s_base;
-    if (threadIdx.x == 0) s_group = atomicAdd(ticket, 1ull) - ticket_base;
-    __syncthreads();
-    const uint64_t grp = s_group, n_items = (uint64_t)n_seqs * n_shards * chunks;
+    __shared__ uint64_t lds64[kBlock / 64];
+    const uint64_t grp = blockIdx.x, n_items = (uint64_t)n_seqs * n_shards * chunks;
     const uint64_t i0 = grp * ipb, i1 = i0 + ipb < n_items ? i0 + ipb : n_items;
     auto word_of = [&](uint64_t ci, uint32_t *w_out) -> uint64_t {
         const uint32_t chunk = (uint32_t)(ci % chunks);
@@ -1018,41 +1017,27 @@ __global__ __launch_bounds__(kBlock) void k_hits_fused(
     for (uint64_t ci = i0; ci < i1; ci++) mine += (uint32_t)__popcll(word_of(ci, &w_unused));
     uint32_t gtot;
     block_exclusive_scan(mine, &gtot, lds);
-    if (threadIdx.x < 64) {                             // the first wavefront publishes and looks back
-        const uint32_t lane = threadIdx.x;
-        if (lane == 0)
-            __hip_atomic_store(&state[grp], lb_pack(gen, gtot, grp == 0 ? kLbPrefix : kLbAggregate), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint64_t excl = 0;
-        int64_t pos = (int64_t)grp - 1;                 // lanes look at groups pos, pos-1, ..., pos-63
-        while (pos >= 0) {
-            const int64_t j = pos - (int64_t)lane;
-            uint64_t word = lb_pack(gen, 0, kLbPrefix);  // before the first group: an empty prefix
-            if (j >= 0) {
-                for (;;) {
-                    word = __hip_atomic_load(&state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((uint32_t)(word >> 44) == gen && (word & 3ull) != 0) break;
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            }
-            const uint64_t value = (word >> 2) & ((1ull << 42) - 1);
-            const unsigned long long has_prefix = __ballot((word & 3ull) == kLbPrefix);
-            const uint32_t stop = has_prefix ? (uint32_t)__builtin_ctzll(has_prefix) : 64u;   // nearest group whose prefix is known
-            uint64_t part = lane <= stop ? value : 0;
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
-            excl += part;
-            if (has_prefix) break;
-            pos -= 64;
+    if (threadIdx.x == 0) __hip_atomic_store(&state[grp], lb_pack(gen, gtot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // scan: totals of all preceding groups
+    uint64_t part = 0;
+    for (uint64_t j = threadIdx.x; j < grp; j += kBlock) {
+        uint64_t word;
+        for (;;) {
+            word = __hip_atomic_load(&state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((uint32_t)(word >> 44) == gen && (word & ((1ull << 44) - 1)) != 0) break;
+            __builtin_amdgcn_s_sleep(1);
         }
-        if (lane == 0) {
-            if (grp != 0) __hip_atomic_store(&state[grp], lb_pack(gen, excl + gtot, kLbPrefix), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_base = excl;
-            if (i1 == n_items) hit_off[n_seqs] = excl + gtot;
-        }
+        part += (word & ((1ull << 44) - 1)) - 1;
     }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+    if ((threadIdx.x & 63u) == 0) lds64[threadIdx.x >> 6] = part;
     __syncthreads();
-    // pass 2: item by item, ordered write (the words come back out of L2)
-    uint64_t base = s_base;
+    uint64_t base = 0;
+#pragma unroll
+    for (int i = 0; i < kBlock / 64; i++) base += lds64[i];
+    if (threadIdx.x == 0 && i1 == n_items) hit_off[n_seqs] = base + gtot;
+    // pass 2: ordered write
     for (uint64_t ci = i0; ci < i1; ci++) {
         uint32_t w;
         const uint64_t bits = word_of(ci, &w);
