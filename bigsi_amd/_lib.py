@@ -51,7 +51,8 @@ class GroupInfo(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("and_launches", C.c_uint64), ("and_ms", C.c_double),
                 ("kmerize_launches", C.c_uint64), ("kmerize_ms", C.c_double),
-                ("compact_launches", C.c_uint64), ("compact_ms", C.c_double)]
+                ("compact_launches", C.c_uint64), ("compact_ms", C.c_double),
+                ("presence_launches", C.c_uint64), ("presence_ms", C.c_double), ("presence_bytes", C.c_uint64)]
 
 
 _P = C.c_void_p
@@ -93,6 +94,8 @@ SIGNATURES = {
     "bigsi_hip_batch_fetch_rows": (_i32, [_P, _u32, _P, _u64]),
     "bigsi_hip_batch_lookup": (_i32, [_P, _u32, _P, _P, _u64]),
     "bigsi_hip_batch_presence": (_i32, [_P, _u32, _P, _u32, _P]),
+    "bigsi_hip_batch_presence_hits": (_i32, [_P, _P, _P, _P, _u64, _P]),
+    "bigsi_hip_group_batch_presence_hits": (_i32, [_P, _P, _P, _P, _u64, _P]),
     "bigsi_hip_batch_set_gather_stream": (_i32, [_P, _P]),
     "bigsi_hip_batch_compact_gathered": (_i32, [_P, _P, _u32, _u64]),
     "bigsi_hip_batch_compact_gathered_masks": (_i32, [_P, _P, _u32, _u64, _u32]),

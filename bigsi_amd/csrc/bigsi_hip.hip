@@ -107,7 +107,7 @@ extern "C" int bigsi_hip_open(uint64_t num_rows, uint64_t num_cols, uint64_t col
 
 static void recycle_events(bigsi_hip_index *ix)
 {
-    for (auto *v : {&ix->ev_and, &ix->ev_km, &ix->ev_cp}) {
+    for (auto *v : {&ix->ev_and, &ix->ev_km, &ix->ev_cp, &ix->ev_pr}) {
         for (auto &p : *v) ix->ev_free.push_back(p);
         v->clear();
     }
@@ -461,7 +461,12 @@ extern "C" int bigsi_hip_stats(bigsi_hip_index *ix, bigsi_hip_stats_t *out, int 
     TRY(sum(ix->ev_and, &out->and_launches, &out->and_ms));
     TRY(sum(ix->ev_km, &out->kmerize_launches, &out->kmerize_ms));
     TRY(sum(ix->ev_cp, &out->compact_launches, &out->compact_ms));
-    if (reset) recycle_events(ix);
+    TRY(sum(ix->ev_pr, &out->presence_launches, &out->presence_ms));
+    out->presence_bytes = ix->presence_bytes;
+    if (reset) {
+        recycle_events(ix);
+        ix->presence_bytes = 0;
+    }
     return BIGSI_OK;
 }
 
@@ -588,7 +593,7 @@ extern "C" int bigsi_hip_batch_destroy(bigsi_hip_batch *b)
     e = hipStreamSynchronize(b->ix->stream);
     if (b->gstream && b->g_done) e = hipEventSynchronize(b->g_done);
     (void)e;
-    for (DevBuf *d : {&b->rows_sorted, &b->pos_query, &b->hsh, &b->rep, &b->seqs, &b->d_seq_off, &b->d_pos_off, &b->d_tab_off, &b->tab, &b->first_pos, &b->pos_unique, &b->tmp, &b->rows,
+    for (DevBuf *d : {&b->pres_in, &b->pres_bits, &b->pres_out, &b->rows_sorted, &b->pos_query, &b->hsh, &b->rep, &b->seqs, &b->d_seq_off, &b->d_pos_off, &b->d_tab_off, &b->tab, &b->first_pos, &b->pos_unique, &b->tmp, &b->rows,
                       &b->num_kmers, &b->num_unique, &b->min_kmers, &b->bitmaps, &b->counts, &b->scratch})
         d->release();
     b->hits.release();
@@ -624,7 +629,7 @@ extern "C" int bigsi_hip_batch_set_outputs(bigsi_hip_batch *b, void *d_bitmaps, 
 struct CountLaunch {
     const uint64_t *k2_rows;
     unsigned block;
-    uint32_t tiles, segs;       // wide kernel: column tiles per query; narrow kernel (segs > 0): 256-byte segments per query
+    uint32_t tiles;             // column tiles per query
     void *out;
     uint64_t out_stride;
     uint64_t *hit_bitmap;
@@ -651,33 +656,8 @@ static void launch_count_wide(bigsi_hip_batch *b, const CountLaunch &c, uint32_t
 #undef BIGSI_LAUNCH_COUNT
 }
 
-// narrow rows: instantiated for the plane counts of reads / gene-length queries and h = 2..4 (count_narrow_ok)
-static bool count_narrow_ok(int P, uint32_t h) { return (P == 6 || P == 10) && h >= 2 && h <= 4; }
-
-template <int P>
-static void launch_count_narrow(bigsi_hip_batch *b, const CountLaunch &c, uint32_t q0, uint32_t q1)
-{
-    bigsi_hip_index *ix = b->ix;
-    const unsigned grid = (unsigned)ceil_div((uint64_t)(q1 - q0) * c.segs, kBlock / 64);
-#define BIGSI_LAUNCH_COUNT_NARROW(H)                                                                                         \
-    hipLaunchKernelGGL((k_and_count_narrow<P, H, 16, uint16_t>), dim3(grid), dim3(kBlock), 0, ix->stream, ix->d_index,          \
-                       ix->stride_words, (uint32_t)b->wv, c.k2_rows, b->d_pos_off.as<uint64_t>(), b->num_unique.as<uint32_t>(), q0, \
-                       q1, c.segs, (uint16_t *)c.out, c.out_stride, b->min_kmers.as<uint32_t>(), ix->n_cols, c.hit_bitmap, b->wv_pad, c.sparse)
-    switch (ix->h) {
-    case 2: BIGSI_LAUNCH_COUNT_NARROW(2); break;
-    case 3: BIGSI_LAUNCH_COUNT_NARROW(3); break;
-    default: BIGSI_LAUNCH_COUNT_NARROW(4); break;
-    }
-#undef BIGSI_LAUNCH_COUNT_NARROW
-}
-
 static void launch_count(bigsi_hip_batch *b, int P, const CountLaunch &c, uint32_t q0, uint32_t q1)
 {
-    if (c.segs) {
-        if (P == 6) launch_count_narrow<6>(b, c, q0, q1);
-        else launch_count_narrow<10>(b, c, q0, q1);
-        return;
-    }
     switch (P) {
     case 6: launch_count_wide<6, uint16_t>(b, c, q0, q1); break;
     case 10: launch_count_wide<10, uint16_t>(b, c, q0, q1); break;
@@ -883,21 +863,10 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
     // planes needed for the largest possible count = max k-mers of any sequence in the batch
     const uint64_t maxu = b->max_pos;
     const int P = maxu < (1ull << 6) ? 6 : maxu < (1ull << 10) ? 10 : maxu < (1ull << 12) ? 12 : maxu < (1ull << 16) ? 16 : 32;
-    // narrow rows (reads against a small index, or a thin column shard): one wavefront = four 256-byte row segments of four
-    // different rows instead of one 1 KiB segment of one row -- taken when it keeps clearly more lanes live than the wide
-    // kernel, or when row lists are so short that the wide kernel's chain of load rounds is what a step waits for
-    static const int narrow_env = env_int("BIGSI_HIP_NARROW", -1);      // -1 heuristic, 0 never, 1 whenever possible
-    const uint32_t segs_narrow = (uint32_t)ceil_div(b->wv, 16 * kVec);
-    bool narrow = false;
-    if (narrow_env != 0 && b->wv <= 1024 && (b->exact || (count_narrow_ok(P, ix->h) && !b->ext_counts))) {
-        const double wide_util = (double)b->wv / (double)(ceil_div(b->wv, 64 * kVec) * 64 * kVec);
-        const double narrow_util = (double)b->wv / (double)(segs_narrow * 16 * kVec);
-        narrow = narrow_env == 1 || narrow_util >= wide_util + 0.04 || b->max_pos * ix->h <= 512;
-    }
     // small batches: cut every query's row list into slices so that ~2k wavefronts are in flight (see map_block)
     static const int slices_env = env_int("BIGSI_HIP_SLICES", 0);
     uint32_t slices = 1;
-    if (!narrow) {
+    {
         const uint64_t waves = (uint64_t)b->n_seqs * ceil_div(b->wv, 64 * kVec);
         if (slices_env > 0) slices = (uint32_t)slices_env;
         else if (waves < 1024) slices = (uint32_t)std::min<uint64_t>({64, ceil_div(2048, std::max<uint64_t>(waves, 1)), std::max<uint64_t>(b->max_pos / 16, 1)});
@@ -908,12 +877,12 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
     // large batches go out as several launches of about k2_blocks workgroups (all co-resident, sweeping the address-ordered
     // row lists together); queries per launch a multiple of 8 (the blockIdx -> XCD map)
     static const int k2_blocks = env_int("BIGSI_HIP_K2_BLOCKS", 1024);
-    const uint64_t blocks_per_q = narrow ? 1 : (uint64_t)tiles * slices;      // narrow: a fraction of a workgroup per query
+    const uint64_t blocks_per_q = (uint64_t)tiles * slices;
     uint32_t chunk_q = b->n_seqs;
     {
-        const uint64_t total_blocks = narrow ? ceil_div((uint64_t)b->n_seqs * segs_narrow, kBlock / 64) : ceil_div(b->n_seqs, 8) * 8 * blocks_per_q;
+        const uint64_t total_blocks = ceil_div(b->n_seqs, 8) * 8 * blocks_per_q;
         if (total_blocks > 0x7FFFFFFFull) return fail(BIGSI_ERR_INVALID, "batch too large for one launch (%llu workgroups)", (unsigned long long)total_blocks);
-        if (k2_blocks > 0 && b->exact && !narrow && total_blocks > 2ull * (uint64_t)k2_blocks)
+        if (k2_blocks > 0 && b->exact && total_blocks > 2ull * (uint64_t)k2_blocks)
             chunk_q = (uint32_t)std::max<uint64_t>(8, ((uint64_t)k2_blocks / blocks_per_q) / 8 * 8);
     }
     uint32_t n_launches = 0;
@@ -925,13 +894,6 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
         static const int and_nt = env_int("BIGSI_HIP_AND_NT", 1);     // 0: plain loads (A/B against non-temporal)
         for (uint32_t q0 = 0; q0 < b->n_seqs; q0 += chunk_q, n_launches++) {
             const uint32_t q1 = std::min<uint64_t>((uint64_t)q0 + chunk_q, b->n_seqs);
-            if (narrow) {
-                const unsigned grid = (unsigned)ceil_div((uint64_t)(q1 - q0) * segs_narrow, kBlock / 64);
-                hipLaunchKernelGGL((k_and_exact_narrow<16, 8>), dim3(grid), dim3(kBlock), 0, ix->stream, ix->d_index, ix->stride_words,
-                                   (uint32_t)b->wv, ix->n_cols, k2_rows, b->d_pos_off.as<uint64_t>(), b->num_unique.as<uint32_t>(), ix->h, q0, q1,
-                                   segs_narrow, out, b->wv_pad);
-                continue;
-            }
             const unsigned grid = (unsigned)(ceil_div(q1 - q0, 8) * 8 * blocks_per_q);
 #define COMMA ,
 #define BIGSI_LAUNCH_EXACT(U)                                                                                                  \
@@ -962,7 +924,7 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
             b->local_from_counts = true;      // K4 thresholds the summed counters
         }
         TRY(ev_begin(ix, &ep, nullptr, true));
-        const CountLaunch cl{k2_rows, (unsigned)and_block, tiles, narrow ? segs_narrow : 0u, out, cstride, hb, sparse, slices};
+        const CountLaunch cl{k2_rows, (unsigned)and_block, tiles, out, cstride, hb, sparse, slices};
         for (uint32_t q0 = 0; q0 < b->n_seqs; q0 += chunk_q, n_launches++)
             launch_count(b, P, cl, q0, (uint32_t)std::min<uint64_t>((uint64_t)q0 + chunk_q, b->n_seqs));
         HIP_TRY(hipGetLastError());
@@ -1342,6 +1304,110 @@ extern "C" int bigsi_hip_batch_presence(bigsi_hip_batch *b, uint32_t seq, const 
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)n_colours * n, hipMemcpyDeviceToHost, ix->stream));
     HIP_TRY(hipStreamSynchronize(ix->stream));
+    return BIGSI_OK;
+}
+
+// K5 at scale: the presence strings of all hits of the batch (see k_presence_bits).  The host sorts each sequence's hits by
+// colour and groups them into 128-column word pairs (a few microseconds per thousand hits); the device does the rest.
+extern "C" int bigsi_hip_batch_presence_hits(bigsi_hip_batch *b, const uint64_t *hit_offsets, const uint32_t *colours, uint8_t *out,
+                                             uint64_t out_capacity, uint64_t *string_offsets)
+{
+    TRY(need_run(b));
+    if (!hit_offsets || !string_offsets) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    bigsi_hip_index *ix = b->ix;
+    const uint32_t nq = b->n_seqs;
+    const uint64_t n_hits = hit_offsets[nq] - hit_offsets[0], h0 = hit_offsets[0];
+    if (n_hits && !colours) return fail(BIGSI_ERR_INVALID, "colours is NULL");
+    if (n_hits > 0xFFFFFFF0ull) return fail(BIGSI_ERR_INVALID, "too many hits for one call");
+    TRY(host_counts(b));
+    // host side: string offsets, per-sequence colour order, word pairs
+    std::vector<uint32_t> hit_seq(n_hits), perm(n_hits), order;
+    std::vector<uint64_t> pair_off(nq + 1, 0);
+    std::vector<PresencePair> pairs;
+    uint64_t str = 0, alg = 0;
+    uint32_t max_u = 0, max_n = 0, max_pairs = 0;
+    for (uint32_t q = 0; q < nq; q++) {
+        if (hit_offsets[q + 1] < hit_offsets[q]) return fail(BIGSI_ERR_INVALID, "hit_offsets must be non-decreasing");
+        const uint64_t lo = hit_offsets[q] - h0, hi = hit_offsets[q + 1] - h0;
+        for (uint64_t t = lo; t < hi; t++) {
+            if (colours[h0 + t] >= ix->n_cols) return fail(BIGSI_ERR_RANGE, "colour %u >= num_cols", colours[h0 + t]);
+            hit_seq[t] = q;
+            string_offsets[t] = str;
+            str += b->h_num_kmers[q];
+        }
+        pair_off[q] = pairs.size();
+        if (hi == lo || b->h_num_kmers[q] == 0) continue;
+        order.resize(hi - lo);
+        for (uint64_t t = lo; t < hi; t++) order[t - lo] = (uint32_t)t;
+        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return colours[h0 + x] < colours[h0 + y]; });
+        uint64_t words = 0, last_word = ~0ull;
+        for (size_t r = 0; r < order.size(); r++) {
+            const uint32_t c = colours[h0 + order[r]];
+            if (r && c == colours[h0 + order[r - 1]]) return fail(BIGSI_ERR_INVALID, "colour %u listed twice for sequence %u", c, q);
+            const uint32_t wp = c >> 7;
+            if (pairs.size() == pair_off[q] || pairs.back().wpair != wp) pairs.push_back(PresencePair{wp, (uint32_t)(lo + r), 0ull, 0ull});
+            const uint64_t bit = 1ull << bit_of_col(c & 63u);
+            if (c & 64u) pairs.back().mask_hi |= bit;
+            else pairs.back().mask_lo |= bit;
+            perm[lo + r] = order[r];
+            if ((uint64_t)(c >> 6) != last_word) { words++; last_word = c >> 6; }
+        }
+        max_u = std::max(max_u, b->h_num_unique[q]);
+        max_n = std::max(max_n, b->h_num_kmers[q]);
+        max_pairs = std::max<uint32_t>(max_pairs, (uint32_t)(pairs.size() - pair_off[q]));
+        alg += (uint64_t)b->h_num_unique[q] * b->run_h * words * 8 + (hi - lo) * b->h_num_kmers[q];
+    }
+    pair_off[nq] = pairs.size();
+    string_offsets[n_hits] = str;
+    if (str > out_capacity) return fail(BIGSI_ERR_CAPACITY, "string buffer holds %llu bytes, %llu needed", (unsigned long long)out_capacity, (unsigned long long)str);
+    if (n_hits == 0 || str == 0) return BIGSI_OK;
+    if (!out) return fail(BIGSI_ERR_INVALID, "out is NULL");
+    if (b->run_h != ix->h) return fail(BIGSI_ERR_STATE, "num_hashes changed since the batch was run");
+    // device buffers: [pair_off | str_off | hit_seq | perm | pairs] in one upload
+    const size_t o_pair_off = 0, o_str = round_up(o_pair_off + (nq + 1) * 8ull, 256), o_seq = round_up(o_str + (n_hits + 1) * 8, 256);
+    const size_t o_perm = round_up(o_seq + n_hits * 4, 256), o_pairs = round_up(o_perm + n_hits * 4, 256);
+    const size_t in_bytes = o_pairs + pairs.size() * sizeof(PresencePair);
+    std::vector<uint8_t> stage(in_bytes);
+    memcpy(stage.data() + o_pair_off, pair_off.data(), (nq + 1) * 8ull);
+    memcpy(stage.data() + o_str, string_offsets, (n_hits + 1) * 8);
+    memcpy(stage.data() + o_seq, hit_seq.data(), n_hits * 4);
+    memcpy(stage.data() + o_perm, perm.data(), n_hits * 4);
+    memcpy(stage.data() + o_pairs, pairs.data(), pairs.size() * sizeof(PresencePair));
+    const uint32_t bits_stride = (uint32_t)ceil_div(std::max<uint32_t>(max_u, 1), 16);
+    TRY(b->pres_in.reserve(in_bytes));
+    TRY(b->pres_bits.reserve((size_t)n_hits * bits_stride * 2));
+    TRY(b->pres_out.reserve(str));
+    HIP_TRY(hipMemcpyAsync(b->pres_in.p, stage.data(), in_bytes, hipMemcpyHostToDevice, ix->stream));
+    const uint8_t *din = b->pres_in.as<uint8_t>();
+    EventPair ep{};
+    TRY(ev_begin(ix, &ep));
+    const dim3 grid_a((unsigned)ceil_div(std::max<uint32_t>(max_pairs, 1), kBlock), (unsigned)ceil_div(std::max<uint32_t>(max_u, 1), 16), nq);
+#define BIGSI_PRESENCE(H)                                                                                                      \
+    hipLaunchKernelGGL((k_presence_bits<H>), grid_a, dim3(kBlock), 0, ix->stream, ix->d_index, ix->stride_words, b->rows.as<uint64_t>(), \
+                       b->d_pos_off.as<uint64_t>(), b->num_unique.as<uint32_t>(), ix->h, (const uint64_t *)(din + o_pair_off),        \
+                       (const PresencePair *)(din + o_pairs), (const uint32_t *)(din + o_perm), b->pres_bits.as<uint16_t>(), bits_stride)
+    switch (ix->h) {
+    case 1: BIGSI_PRESENCE(1); break;
+    case 2: BIGSI_PRESENCE(2); break;
+    case 3: BIGSI_PRESENCE(3); break;
+    case 4: BIGSI_PRESENCE(4); break;
+    case 5: BIGSI_PRESENCE(5); break;
+    default: BIGSI_PRESENCE(0); break;
+    }
+#undef BIGSI_PRESENCE
+    HIP_TRY(hipGetLastError());
+    for (uint64_t t0 = 0; t0 < n_hits; t0 += 65535) {          // grid.y limit
+        const uint64_t cnt = std::min<uint64_t>(65535, n_hits - t0);
+        hipLaunchKernelGGL(k_presence_expand, dim3((unsigned)ceil_div(std::max<uint32_t>(max_n, 1), kBlock), (unsigned)cnt), dim3(kBlock), 0, ix->stream,
+                           b->pres_bits.as<uint16_t>() + t0 * bits_stride, bits_stride, (const uint32_t *)(din + o_seq) + t0,
+                           (const uint64_t *)(din + o_str) + t0, b->d_pos_off.as<uint64_t>(), b->num_kmers.as<uint32_t>(), b->pos_unique.as<uint32_t>(),
+                           b->pres_out.as<uint8_t>());
+    }
+    HIP_TRY(hipGetLastError());
+    TRY(ev_end(ix, &ep, ix->ev_pr));
+    if (ep.a) ix->presence_bytes += alg;
+    HIP_TRY(hipMemcpyAsync(out, b->pres_out.p, str, hipMemcpyDeviceToHost, ix->stream));
+    HIP_TRY(hipStreamSynchronize(ix->stream));       // `stage` and the caller's buffers
     return BIGSI_OK;
 }
 

@@ -84,7 +84,8 @@ struct bigsi_hip_index {
     DevBuf stage, stage_ids;
     // profiling
     int profiling = 0;            // 0 off, 1 every kernel group of a run, 2 the row-AND kernel only
-    std::vector<EventPair> ev_and, ev_km, ev_cp, ev_free;
+    std::vector<EventPair> ev_and, ev_km, ev_cp, ev_pr, ev_free;
+    uint64_t presence_bytes = 0;   // algorithmic bytes of the timed presence_hits calls
     uint64_t wv() const { return ceil_div(n_cols, 64); }
     uint64_t rb() const { return ceil_div(n_cols, 8); }
 };
@@ -119,6 +120,7 @@ struct bigsi_hip_batch {
     DevBuf pos_query, hsh, rep;   // per k-mer position: owning sequence, dedupe hash, class representative
     DevBuf rows_sorted;           // the row ids K2 streams: each query's list in address order (k_sort_rows)
     DevBuf bitmaps, counts, scratch;
+    DevBuf pres_in, pres_bits, pres_out;   // K5 at scale (presence_hits): host-built pair lists, presence bits, strings
     void *ext_bitmaps = nullptr, *ext_counts = nullptr;
     HitBufs hits, ghits;
     // state of the last run

@@ -808,164 +808,6 @@ __global__ __launch_bounds__(kBlock) void k_and_count(
 }
 
 
-// ------------------------------------------------------------------------------ K2 for NARROW rows (reads on small / sharded indexes)
-// A 1 KiB wavefront load wastes lanes when a row is shorter than that (BASELINE configs[1]: 10 000 samples = 157 words =
-// 1.2 wavefronts, 61 % of the lanes live), and one wavefront walking a query's whole row list is a chain of dependent
-// load rounds (93 rows / 8 in flight = 12 round trips at C2: the kernel is latency-bound, not bandwidth-bound).
-// Here a wavefront is cut into 64/G sub-groups of G lanes; a sub-group covers a G*16-byte column segment of ONE row, and the
-// 64/G sub-groups of a wavefront stream DIFFERENT rows of the query at the same segment: every lane is live for widths
-// that are multiples of G*2 words, one wave instruction has 64/G rows in flight (x UNROLL), and the sub-groups' partial
-// results are combined at the end with two cross-lane steps.  One wavefront per (query, segment); a workgroup is just
-// four consecutive such wavefronts.
-template <int G, int UNROLL>
-__global__ __launch_bounds__(kBlock) void k_and_exact_narrow(
-    const uint64_t *__restrict__ index, uint64_t stride_words, uint32_t wv, uint64_t n_cols,
-    const uint64_t *__restrict__ rows, const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ num_unique,
-    uint32_t h, uint32_t q0, uint32_t n_seqs, uint32_t segs, uint64_t *__restrict__ out, uint64_t out_stride_words)
-{
-    constexpr uint32_t RPW = 64 / G;
-    const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    const uint32_t lane = threadIdx.x & 63u, g = lane / G, l = lane % G;
-    const uint32_t ql = wave / segs, seg = wave - ql * segs;
-    const uint32_t q = q0 + ql;
-    if (q >= n_seqs) return;                                   // whole wavefront
-    const uint32_t w0 = (seg * G + l) * kVec;
-    const bool live = w0 < wv;
-    const uint64_t R = (uint64_t)num_unique[q] * h;
-    const uint64_t *qrows = rows + pos_off[q] * h;
-    const u64x2 ones = {~0ull, ~0ull};
-    u64x2 acc = ones;
-    for (uint64_t r0 = 0; r0 < R; r0 += RPW * UNROLL) {          // wave-uniform trip count
-        u64x2 v[UNROLL];
-#pragma unroll
-        for (int j = 0; j < UNROLL; j++) {
-            const uint64_t r = r0 + (uint64_t)j * RPW + g;
-            v[j] = (live && r < R) ? load_row_seg(index, qrows[r], stride_words, w0) : ones;
-        }
-#pragma unroll
-        for (int j = 0; j < UNROLL; j++) acc &= v[j];
-    }
-#pragma unroll
-    for (int d = G; d < 64; d <<= 1) {                           // AND across the sub-groups
-        acc.x &= __shfl_xor(acc.x, d, 64);
-        acc.y &= __shfl_xor(acc.y, d, 64);
-    }
-    if (R == 0) acc = u64x2{0ull, 0ull};
-    if (g != 0 || !live) return;
-    acc.x &= valid_mask(w0, n_cols);
-    acc.y &= valid_mask(w0 + 1, n_cols);
-    uint64_t *o = out + (uint64_t)q * out_stride_words + w0;
-    o[0] = acc.x;
-    if (w0 + 1 < out_stride_words) o[1] = acc.y;
-}
-
-// counting twin: sub-group g takes the unique k-mers g, g + 64/G, ... (all h rows of a k-mer stay in one lane), the
-// sub-groups' bit-sliced counters are added plane-wise at the end (a full adder per plane), after which every sub-group
-// holds the sums and expands its share of each word's 8 byte-columns.
-template <int P, int H, int G, typename CountT>
-__global__ __launch_bounds__(kBlock) void k_and_count_narrow(
-    const uint64_t *__restrict__ index, uint64_t stride_words, uint32_t wv,
-    const uint64_t *__restrict__ rows, const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ num_unique,
-    uint32_t q0, uint32_t n_seqs, uint32_t segs, CountT *__restrict__ out, uint64_t out_stride /* counters per query */,
-    const uint32_t *__restrict__ min_kmers, uint64_t n_cols, uint64_t *__restrict__ hit_bitmap, uint64_t bm_stride, uint32_t sparse)
-{
-    static_assert(H > 0, "compile-time h only");
-    constexpr uint32_t RPW = 64 / G;
-    constexpr int KM = H == 1 ? 8 : H <= 3 ? 4 : 2;             // k-mers per round per sub-group: 8-12 loads in flight
-    const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    const uint32_t lane = threadIdx.x & 63u, g = lane / G, l = lane % G;
-    const uint32_t ql = wave / segs, seg = wave - ql * segs;
-    const uint32_t q = q0 + ql;
-    if (q >= n_seqs) return;
-    const uint32_t w0 = (seg * G + l) * kVec;
-    const bool live = w0 < wv;
-    const uint32_t u = num_unique[q];
-    const uint64_t *qrows = rows + pos_off[q] * H;
-    const u64x2 zero = {0ull, 0ull};
-    uint64_t pl[kVec][P];
-#pragma unroll
-    for (int v = 0; v < kVec; v++)
-#pragma unroll
-        for (int p = 0; p < P; p++) pl[v][p] = 0;
-    for (uint32_t j0 = 0; j0 < u; j0 += RPW * KM) {             // wave-uniform trip count
-        u64x2 v[KM * H];
-#pragma unroll
-        for (int t = 0; t < KM; t++) {
-            const uint32_t j = j0 + (uint32_t)t * RPW + g;
-#pragma unroll
-            for (int s = 0; s < H; s++)
-                v[t * H + s] = (live && j < u) ? load_row_seg(index, qrows[(uint64_t)j * H + s], stride_words, w0) : zero;
-        }
-#pragma unroll
-        for (int t = 0; t < KM; t++) {
-            u64x2 a = v[t * H];
-#pragma unroll
-            for (int s = 1; s < H; s++) a &= v[t * H + s];
-            uint64_t c0 = a.x, c1 = a.y;
-#pragma unroll
-            for (int p = 0; p < P; p++) {
-                const uint64_t t0 = pl[0][p] & c0, t1 = pl[1][p] & c1;
-                pl[0][p] ^= c0; pl[1][p] ^= c1;
-                c0 = t0; c1 = t1;
-            }
-        }
-    }
-    // sum the sub-groups' counters: plane-wise full adder with the partner's planes (counts never exceed u < 2^P)
-#pragma unroll
-    for (int d = G; d < 64; d <<= 1) {
-#pragma unroll
-        for (int v = 0; v < kVec; v++) {
-            uint64_t carry = 0;
-#pragma unroll
-            for (int p = 0; p < P; p++) {
-                const uint64_t a = pl[v][p], b = __shfl_xor(a, d, 64);
-                pl[v][p] = a ^ b ^ carry;
-                carry = (a & b) | (carry & (a ^ b));
-            }
-        }
-    }
-    if (!live) return;
-    const uint32_t thr = min_kmers[q];
-#pragma unroll
-    for (int v = 0; v < kVec; v++) {
-        uint64_t gt = 0, eq = ~0ull;
-        if (P < 32 && (thr >> (P & 31)) != 0) eq = 0;
-#pragma unroll
-        for (int p = P - 1; p >= 0; p--) {
-            if ((thr >> p) & 1u) eq &= pl[v][p];
-            else { gt |= eq & pl[v][p]; eq &= ~pl[v][p]; }
-        }
-        const uint64_t ge = (gt | eq) & valid_mask((uint64_t)w0 + v, n_cols);
-        if (g == 0 && hit_bitmap && (uint64_t)w0 + v < bm_stride) hit_bitmap[(uint64_t)q * bm_stride + w0 + v] = ge;
-        const uint64_t cbase = ((uint64_t)w0 + v) * 64;
-        if (cbase >= out_stride || (sparse && ge == 0)) continue;
-        CountT *o = out + (uint64_t)q * out_stride + cbase;
-        // the 8 byte-columns of the word are shared out over the sub-groups (every sub-group holds the sums)
-        for (uint32_t b = g; b < 8; b += RPW) {
-            CountT c[8];
-#pragma unroll
-            for (int jj = 0; jj < 8; jj++) {
-                const uint32_t bit = 8 * b + 7 - jj;
-                uint32_t x = 0;
-#pragma unroll
-                for (int p = 0; p < P; p++) x |= (uint32_t)((pl[v][p] >> bit) & 1ull) << p;
-                c[jj] = (CountT)x;
-            }
-            if (sizeof(CountT) == 2) {
-                uint4 pk;
-                pk.x = (uint32_t)c[0] | ((uint32_t)c[1] << 16); pk.y = (uint32_t)c[2] | ((uint32_t)c[3] << 16);
-                pk.z = (uint32_t)c[4] | ((uint32_t)c[5] << 16); pk.w = (uint32_t)c[6] | ((uint32_t)c[7] << 16);
-                *reinterpret_cast<uint4 *>(o + 8 * b) = pk;
-            } else {
-                uint4 lo{(uint32_t)c[0], (uint32_t)c[1], (uint32_t)c[2], (uint32_t)c[3]};
-                uint4 hi{(uint32_t)c[4], (uint32_t)c[5], (uint32_t)c[6], (uint32_t)c[7]};
-                *reinterpret_cast<uint4 *>(o + 8 * b) = lo;
-                *reinterpret_cast<uint4 *>(o + 8 * b + 4) = hi;
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------ K4: threshold + compaction
 // Result buffers are laid out [shard][seq][stride] (n_shards = 1 for a single GPU; > 1 for buffers gathered from column
 // shards); hits come out as (colour, count) in (seq, shard, column) order.  Bit vectors -- every production path -- take
@@ -1170,6 +1012,82 @@ __global__ __launch_bounds__(kBlock) void k_presence(
     uint64_t a = ~0ull;
     for (uint32_t s = 0; s < h; s++) a &= index[qrows[j * h + s] * stride_words + w];
     out[(uint64_t)hit * n + i] = ((a >> bit_of_col(c & 63u)) & 1ull) ? '1' : '0';
+}
+
+// ------------------------------------------------------------------------------ K5 at scale: all hits of a batch in one pass
+// BIGSI.score (graph/bigsi.py:232-237) needs, for every hit (sequence q, colour c), the n-character string whose i-th
+// character says whether the k-mer at position i is present in sample c.  k_presence above spends h dependent 8-byte loads
+// per (hit, position); with thousands of hits per query (threshold 0.4 on a 500k-sample index) that is the wrong unit of
+// work.  Here the unit is (unique k-mer, 128-column PAIR OF WORDS that contains hits): the h rows are AND-ed once per pair
+// with 16-byte loads, coalesced over the consecutive hit pairs of a query, and ALL hits of the pair take their bit from
+// that one AND.  A thread keeps the AND-ed words of 16 unique k-mers in registers and emits, per hit, the 16 presence bits
+// as one uint16 (bits[hit][k-mer / 16]); k_presence_expand then writes the ASCII strings over the n positions
+// (duplicates included) from those bits.  Bytes: u x h x 16 per hit pair -- the K2 stream restricted to the hit words.
+struct PresencePair {
+    uint32_t wpair;          // word pair: columns [128 * wpair, +128)
+    uint32_t base;           // rank, among the query's hits sorted by colour, of the pair's first hit (global index into perm)
+    uint64_t mask_lo, mask_hi;   // hit bits of the two words (row bit order)
+};
+
+// column-order view of a word in row bit order: reverse the bits inside every byte
+__device__ __forceinline__ uint64_t by_column(uint64_t x) { return __builtin_bswap64(__builtin_bitreverse64(x)); }
+
+template <int H>
+__global__ __launch_bounds__(kBlock) void k_presence_bits(
+    const uint64_t *__restrict__ index, uint64_t stride_words, const uint64_t *__restrict__ rows, const uint64_t *__restrict__ pos_off,
+    const uint32_t *__restrict__ num_unique, uint32_t h_rt, const uint64_t *__restrict__ pair_off, const PresencePair *__restrict__ pairs,
+    const uint32_t *__restrict__ perm, uint16_t *__restrict__ bits, uint32_t bits_stride)
+{
+    const uint32_t h = H > 0 ? (uint32_t)H : h_rt;
+    const uint32_t q = blockIdx.z, jc = blockIdx.y;
+    const uint32_t u = num_unique[q];
+    const uint32_t j0 = jc * 16u;
+    if (j0 >= u) return;
+    const uint64_t p = pair_off[q] + (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (p >= pair_off[q + 1]) return;
+    const PresencePair pr = pairs[p];
+    const uint64_t *qrows = rows + pos_off[q] * h;
+    const uint64_t woff = (uint64_t)pr.wpair * 2;
+    u64x2 a[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+        const uint32_t j = j0 + t;
+        u64x2 v = {0ull, 0ull};
+        if (j < u) {                                   // wave-uniform
+            v = load_row_seg(index, qrows[(uint64_t)j * h], stride_words, (uint32_t)woff);
+            for (uint32_t s = 1; s < h; s++) v &= load_row_seg(index, qrows[(uint64_t)j * h + s], stride_words, (uint32_t)woff);
+        }
+        a[t] = v;
+    }
+    uint32_t rank = pr.base;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        uint64_t m = by_column(half ? pr.mask_hi : pr.mask_lo);      // bit c set <=> column 64 * word + c is a hit
+        while (m) {
+            const uint32_t c = (uint32_t)__builtin_ctzll(m);
+            m &= m - 1;
+            const uint32_t bp = bit_of_col(c);
+            uint32_t out = 0;
+#pragma unroll
+            for (int t = 0; t < 16; t++) out |= (uint32_t)(((half ? a[t].y : a[t].x) >> bp) & 1ull) << t;
+            bits[(uint64_t)perm[rank] * bits_stride + jc] = (uint16_t)out;
+            rank++;
+        }
+    }
+}
+
+// strings[hit][i] = '0' + bit (unique k-mer of position i) of the hit's presence bits
+__global__ __launch_bounds__(kBlock) void k_presence_expand(
+    const uint16_t *__restrict__ bits, uint32_t bits_stride, const uint32_t *__restrict__ hit_seq, const uint64_t *__restrict__ str_off,
+    const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ num_kmers, const uint32_t *__restrict__ pos_unique,
+    uint8_t *__restrict__ out)
+{
+    const uint64_t hit = blockIdx.y;
+    const uint32_t q = hit_seq[hit];
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= num_kmers[q]) return;
+    const uint32_t j = pos_unique[pos_off[q] + i];
+    out[str_off[hit] + i] = (uint8_t)('0' + ((bits[hit * bits_stride + (j >> 4)] >> (j & 15u)) & 1u));
 }
 
 // ------------------------------------------------------------------------------ storage contract helpers

@@ -772,6 +772,58 @@ extern "C" int bigsi_hip_group_batch_presence(bigsi_hip_group_batch *gb, uint32_
     return BIGSI_OK;
 }
 
+// all hits of the batch: each shard produces the strings of the hits it owns (K5 there, one pass per shard), the host puts
+// them in the caller's order
+extern "C" int bigsi_hip_group_batch_presence_hits(bigsi_hip_group_batch *gb, const uint64_t *hit_offsets, const uint32_t *colours, uint8_t *out,
+                                                   uint64_t out_capacity, uint64_t *string_offsets)
+{
+    if (!gb) return fail(BIGSI_ERR_INVALID, "NULL batch");
+    if (!gb->ran) return fail(BIGSI_ERR_STATE, "bigsi_hip_group_batch_run has not completed for this batch");
+    if (!hit_offsets || !string_offsets) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    bigsi_hip_group *g = gb->g;
+    const uint32_t nq = gb->b[0]->n_seqs;
+    const uint64_t h0 = hit_offsets[0], n_hits = hit_offsets[nq] - h0;
+    if (n_hits && !colours) return fail(BIGSI_ERR_INVALID, "colours is NULL");
+    std::vector<uint32_t> nk(nq);
+    TRY(bigsi_hip_batch_fetch_unique(gb->b[0], nk.data(), nullptr, nullptr));
+    uint64_t str = 0;
+    for (uint32_t q = 0; q < nq; q++)
+        for (uint64_t t = hit_offsets[q] - h0; t < hit_offsets[q + 1] - h0; t++) {
+            if (colours[h0 + t] >= g->n_cols) return fail(BIGSI_ERR_RANGE, "colour %u >= num_cols", colours[h0 + t]);
+            string_offsets[t] = str;
+            str += nk[q];
+        }
+    string_offsets[n_hits] = str;
+    if (str > out_capacity) return fail(BIGSI_ERR_CAPACITY, "string buffer holds %llu bytes, %llu needed", (unsigned long long)out_capacity, (unsigned long long)str);
+    if (n_hits == 0 || str == 0) return BIGSI_OK;
+    if (!out) return fail(BIGSI_ERR_INVALID, "out is NULL");
+    std::vector<uint64_t> off(nq + 1), soff;
+    std::vector<uint32_t> local, where;
+    std::vector<uint8_t> part;
+    for (uint32_t i = 0; i < g->n(); i++) {
+        local.clear();
+        where.clear();
+        for (uint32_t q = 0; q < nq; q++) {
+            off[q] = local.size();
+            for (uint64_t t = hit_offsets[q] - h0; t < hit_offsets[q + 1] - h0; t++)
+                if (colours[h0 + t] / g->shard_cols == i) {
+                    local.push_back((uint32_t)(colours[h0 + t] - (uint64_t)i * g->shard_cols));
+                    where.push_back((uint32_t)t);
+                }
+        }
+        off[nq] = local.size();
+        if (local.empty()) continue;
+        uint64_t need = 0;
+        for (uint32_t t : where) need += string_offsets[t + 1] - string_offsets[t];
+        part.resize(need);
+        soff.resize(local.size() + 1);
+        TRY(bigsi_use_device(gb->b[i]->ix));
+        TRY(bigsi_hip_batch_presence_hits(gb->b[i], off.data(), local.data(), part.data(), need, soff.data()));
+        for (size_t r = 0; r < where.size(); r++) memcpy(out + string_offsets[where[r]], part.data() + soff[r], soff[r + 1] - soff[r]);
+    }
+    return BIGSI_OK;
+}
+
 extern "C" int bigsi_hip_group_search_batch(bigsi_hip_group *g, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k,
                                             double threshold, uint32_t flags, uint32_t *num_kmers, uint32_t *num_unique, uint32_t *min_kmers,
                                             uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t hit_capacity)

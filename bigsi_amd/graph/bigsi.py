@@ -190,9 +190,18 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
             raise UnboundLocalError("local variable 'cumsum' referenced before assignment")
         out = [[] for _ in range(n_seqs)]
         off64 = off.astype(np.int64)
+        strings = None
+        if score:
+            # graph/bigsi.py:232-237 for every hit of the batch in ONE device pass (K5): strings[t] belongs to hit t of `colours`
+            if ((np.diff(off64[:n_seqs + 1]) > 0) & (num_kmers[:n_seqs] == 1)).any():
+                # the reference builds a 1-D matrix from a single row and then indexes it with two subscripts
+                raise IndexError("too many indices for array: array is 1-dimensional, but 2 were indexed")
+            blob, soff = batch.presence_hits(off, colours, num_kmers)
+            text, soff = blob.tobytes().decode("ascii"), soff.astype(np.int64)
+            strings = (text, soff)
         for i in np.flatnonzero(np.diff(off64[:n_seqs + 1])).tolist():      # only the sequences that have hits
             lo, hi = int(off64[i]), int(off64[i + 1])
-            out[i] = self._assemble(batch, i, colours[lo:hi], counts[lo:hi], int(nu[i]), int(num_kmers[i]), exact, score)
+            out[i] = self._assemble(lo, colours[lo:hi], counts[lo:hi], int(nu[i]), exact, strings)
         return out
 
     def search_batch(self, seqs, threshold=1.0, score=False):
@@ -235,21 +244,24 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
         if pending is not None:
             yield from zip(pending[1], self._collect(pending[0], len(pending[1]), threshold, score))
 
-    def _assemble(self, batch, i, colours, counts, u, n, exact, score):
+    def _assemble(self, first_hit, colours, counts, u, exact, strings):
+        """Result dicts of one sequence from its slice of the batch's hit lists; `strings` = (text, offsets) of the batch's
+        presence strings (score=True), indexed by position in the hit lists, `first_hit` = position of this slice's first hit."""
+        idx = np.arange(len(colours))
         if exact:
             # exact_filter (graph/bigsi.py:192-205): every set bit, ascending; a colour without a name is a KeyError
             results = [BigsiQueryResult(int(c), self.colour_to_sample(int(c)), u, u) for c in colours]
         else:
             # inexact_filter (:211-230): only colours < num_samples are zipped in; stable sort by count, descending
             keep = colours < self.num_samples
-            colours, counts = colours[keep], counts[keep]
+            colours, counts, idx = colours[keep], counts[keep], idx[keep]
             order = np.argsort(-counts.astype(np.int64), kind="stable")
+            idx = idx[order]
             results = [BigsiQueryResult(int(colours[j]), self.colour_to_sample(int(colours[j])), int(counts[j]), u) for j in order]
-        if score and results:
-            if n == 1:   # the reference builds a 1-D matrix from a single row and then indexes it with two subscripts
-                raise IndexError("too many indices for array: array is 1-dimensional, but 2 were indexed")
-            cols = batch.presence(i, np.array([r.colour for r in results], dtype=np.uint32), n)
-            for r, col in zip(results, cols):
+        if strings is not None and results:
+            text, soff = strings
+            for r, t in zip(results, idx.tolist()):
+                col = text[int(soff[first_hit + t]):int(soff[first_hit + t + 1])]
                 sd = self.scorer.score(col)
                 sd["kmer-presence"] = col
                 r.add_score(sd)

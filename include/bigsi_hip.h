@@ -193,6 +193,13 @@ int bigsi_hip_batch_lookup(bigsi_hip_batch *b, uint32_t seq, uint32_t *first_pos
 /* BIGSI.score's presence strings (graph/bigsi.py:232-237): for each of n_colours colours, n ASCII '0'/'1'
  * characters, one per k-mer position of the sequence in order (duplicates included).  out[n_colours * n]. */
 int bigsi_hip_batch_presence(bigsi_hip_batch *b, uint32_t seq, const uint32_t *colours, uint32_t n_colours, uint8_t *out);
+/* The same for the hits of EVERY sequence of the batch in one pass (score=True on a thresholded search with thousands of hits
+ * per query): colours of sequence i = colours[hit_offsets[i] .. hit_offsets[i+1]) in any order (the layout fetch_hits
+ * returns).  The string of hit t starts at out[string_offsets[t]] and is num_kmers(sequence of t) characters long;
+ * string_offsets gets hit_offsets[n_seqs] + 1 entries.  BIGSI_ERR_CAPACITY (string_offsets filled) if out_capacity is
+ * smaller than string_offsets[n_hits]. */
+int bigsi_hip_batch_presence_hits(bigsi_hip_batch *b, const uint64_t *hit_offsets, const uint32_t *colours, uint8_t *out,
+                                  uint64_t out_capacity, uint64_t *string_offsets);
 
 /* Multi-GPU assembly: compact hits from result buffers gathered from n_shards column shards (device pointer,
  * layout [shard][seq][stride] with this batch's strides; colour = shard * shard_cols + local column).
@@ -290,6 +297,8 @@ int bigsi_hip_group_batch_run(bigsi_hip_group_batch *gb, double threshold, uint3
 int bigsi_hip_group_batch_fetch_unique(bigsi_hip_group_batch *gb, uint32_t *num_kmers, uint32_t *num_unique, uint32_t *min_kmers);
 int bigsi_hip_group_batch_fetch_hits(bigsi_hip_group_batch *gb, uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t capacity);
 int bigsi_hip_group_batch_presence(bigsi_hip_group_batch *gb, uint32_t seq, const uint32_t *colours, uint32_t n_colours, uint8_t *out);
+int bigsi_hip_group_batch_presence_hits(bigsi_hip_group_batch *gb, const uint64_t *hit_offsets, const uint32_t *colours, uint8_t *out,
+                                        uint64_t out_capacity, uint64_t *string_offsets);
 int bigsi_hip_group_search_batch(bigsi_hip_group *g, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k,
                                  double threshold, uint32_t flags, uint32_t *num_kmers, uint32_t *num_unique, uint32_t *min_kmers,
                                  uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t hit_capacity);
@@ -302,6 +311,9 @@ typedef struct {
     double kmerize_ms;
     uint64_t compact_launches;
     double compact_ms;
+    uint64_t presence_launches; /* bigsi_hip_batch_presence_hits calls: K5 (both kernels) */
+    double presence_ms;
+    uint64_t presence_bytes;    /* algorithmic bytes of those calls: unique k-mers x h x 8 x distinct hit words + string bytes */
 } bigsi_hip_stats_t;
 /* record HIP events around the kernels of batch_run: 0 off, 1 around K1 / K2 / K4 each, 2 around the row-AND kernel only
  * (an event record costs the stream 5-7 us, which matters for batches of short reads) */

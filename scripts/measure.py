@@ -155,30 +155,41 @@ def northstar():
 
 
 def k5():
-    """Presence strings (score=True) at scale: one 1 kbp query planted into H samples of a 10M x 62.5k shard, H = 64 .. 8192."""
+    """Presence strings (score=True) at scale: 64 x 1 kbp queries on a 10M x 62.5k shard, each planted (70 % of its k-mers)
+    into H samples, H = 16 .. 4096 per query -> up to 262k hits per batch; bigsi_hip_batch_presence_hits, kernel time from
+    the library's events, whole-call time (host pair lists + H2D + kernels + D2H of the strings) from the wall clock."""
     m, n, h = 10_000_000, 62_500, 3
     st, _ = open_index("k5", m, n, h)
     rng = np.random.default_rng(11)
-    seqs = rand_seqs(rng, 8, 1000)
-    for H in (64, 1024, 8192):
-        cols = rng.choice(n, size=H, replace=False)
-        for c in cols[: min(H, 8192)]:
-            st.insert_kmers(int(c), [seqs[0][:700]], 31)
+    seqs = rand_seqs(rng, 64, 1000)
+    L = _lib.lib()
+    done = 0
+    for H in (16, 256, 4096):
+        for qi, s in enumerate(seqs):
+            for c in rng.choice(n, size=H - done, replace=False):
+                st.insert_kmers(int(c), [s[:700]], 31)
+        done = H
         b = st.new_batch(seqs, 31)
         b.run(0.4, sparse_counts=True)
         off, col, cnt = b.hits()
         nk, nu, _ = b.unique()
-        hits = col[int(off[0]):int(off[1])]
+        b.presence_hits(off, col, nk)                      # warm (allocations)
+        check(L.bigsi_hip_set_profiling(st.handle, 1))
+        stats(st)
+        reps = 3
         t0 = time.perf_counter()
-        reps = 5
         for _ in range(reps):
-            s = b.presence(0, hits, int(nk[0]))
+            blob, soff = b.presence_hits(off, col, nk)
         dt = (time.perf_counter() - t0) / reps
-        words = np.unique(hits // 64).size
-        ab = int(nu[0]) * h * words * 8 + hits.size * int(nk[0])
-        emit("k5_presence", hits=int(hits.size), hit_words=int(words), positions=int(nk[0]), call_ms=dt * 1e3, alg_bytes=ab,
-             GBps_call=ab / dt / 1e9, note="whole bigsi_hip_batch_presence call incl. D2H of the strings")
-        assert all(x.count("1") >= 670 for x in s[:4])
+        s_ = stats(st)
+        check(L.bigsi_hip_set_profiling(st.handle, 0))
+        kms = s_.presence_ms / max(s_.presence_launches, 1)
+        ab = s_.presence_bytes / max(s_.presence_launches, 1)
+        ones = np.frombuffer(blob, np.uint8)[: int(soff[8])].reshape(8, -1)
+        assert ((ones == ord("1")).sum(axis=1) >= 670).all()
+        emit("k5_presence_hits", n_seqs=len(seqs), hits=int(off[-1]), positions=int(nk[0]), kernels_ms=kms, call_ms=dt * 1e3,
+             alg_bytes=ab, GBps=ab / kms / 1e6, frac=ab / kms / 1e6 / PEAK, string_bytes=int(soff[-1]),
+             note="k_presence_bits + k_presence_expand; alg bytes = unique k-mers x h x 8 x distinct hit words + string bytes")
         b.close()
     st.delete_all()
 
