@@ -52,7 +52,8 @@ class Stats(C.Structure):
     _fields_ = [("and_launches", C.c_uint64), ("and_ms", C.c_double),
                 ("kmerize_launches", C.c_uint64), ("kmerize_ms", C.c_double),
                 ("compact_launches", C.c_uint64), ("compact_ms", C.c_double),
-                ("presence_launches", C.c_uint64), ("presence_ms", C.c_double), ("presence_bytes", C.c_uint64)]
+                ("presence_launches", C.c_uint64), ("presence_ms", C.c_double), ("presence_bytes", C.c_uint64),
+                ("transpose_launches", C.c_uint64), ("transpose_ms", C.c_double)]
 
 
 _P = C.c_void_p
@@ -76,6 +77,7 @@ SIGNATURES = {
     "bigsi_hip_insert_column": (_i32, [_P, _u64, _P]),
     "bigsi_hip_get_column": (_i32, [_P, _u64, _P]),
     "bigsi_hip_insert_columns": (_i32, [_P, _u64, _u64, _P, _u64]),
+    "bigsi_hip_insert_columns_device": (_i32, [_P, _u64, _u64, _P, _u64]),
     "bigsi_hip_append_index": (_i32, [_P, _P]),
     "bigsi_hip_insert_kmers": (_i32, [_P, _u64, C.c_char_p, _P, _u32, _u32]),
     "bigsi_hip_fill_synthetic": (_i32, [_P, _u64, _u64, _u32]),

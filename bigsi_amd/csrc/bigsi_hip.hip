@@ -107,7 +107,7 @@ extern "C" int bigsi_hip_open(uint64_t num_rows, uint64_t num_cols, uint64_t col
 
 static void recycle_events(bigsi_hip_index *ix)
 {
-    for (auto *v : {&ix->ev_and, &ix->ev_km, &ix->ev_cp, &ix->ev_pr}) {
+    for (auto *v : {&ix->ev_and, &ix->ev_km, &ix->ev_cp, &ix->ev_pr, &ix->ev_tr}) {
         for (auto &p : *v) ix->ev_free.push_back(p);
         v->clear();
     }
@@ -277,28 +277,75 @@ extern "C" int bigsi_hip_insert_column(bigsi_hip_index *ix, uint64_t col, const 
     return BIGSI_OK;
 }
 
-extern "C" int bigsi_hip_insert_columns(bigsi_hip_index *ix, uint64_t col0, uint64_t n, const uint8_t *blooms, uint64_t bloom_stride_bytes)
+static int ev_begin(bigsi_hip_index *ix, EventPair *p, hipStream_t st = nullptr, bool row_and = false);
+static int ev_end(bigsi_hip_index *ix, EventPair *p, std::vector<EventPair> &dst, hipStream_t st = nullptr, uint32_t launches = 1);
+
+// n filters already on the device -> columns [col0, col0 + n): whole 64-column words through the tiled transpose
+// (k_transpose_tiles), the ragged head (up to the next multiple of 128 columns) and tail through k_insert_columns
+static int transpose_device(bigsi_hip_index *ix, uint64_t col0, uint64_t n, const uint8_t *d_blooms, uint64_t bstride)
+{
+    const uint64_t nb = ceil_div(ix->m, 8), end = col0 + n;
+    auto slow = [&](uint64_t ca, uint64_t cnt) -> int {
+        if (!cnt) return BIGSI_OK;
+        const uint64_t items = ix->m * (((ca + cnt - 1) >> 6) - (ca >> 6) + 1);
+        const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(items, kBlock), 256 * 32);
+        hipLaunchKernelGGL(k_insert_columns, dim3(grid), dim3(kBlock), 0, ix->stream, ix->d_index, ix->stride_words, ix->m, ca, cnt,
+                           d_blooms + (ca - col0) * bstride, bstride);
+        HIP_TRY(hipGetLastError());
+        return BIGSI_OK;
+    };
+    const uint64_t c_lo = std::min(end, round_up(col0, 128)), n_words = (end - c_lo) / 64, c_hi = c_lo + n_words * 64;
+    static const int tiled = env_int("BIGSI_HIP_TRANSPOSE_TILED", 1);
+    if (!tiled || n_words == 0 || bstride % 16 || ((uintptr_t)d_blooms & 15u) || ceil_div(n_words, 8) > 65535) return slow(col0, n);
+    TRY(slow(col0, c_lo - col0));
+    hipLaunchKernelGGL(k_transpose_tiles, dim3((unsigned)ceil_div(ix->m, kTransposeTile), (unsigned)ceil_div(n_words, 8)), dim3(kBlock), 0, ix->stream,
+                       ix->d_index, ix->stride_words, ix->m, c_lo / 64, n_words, d_blooms + (c_lo - col0) * bstride, bstride, nb);
+    HIP_TRY(hipGetLastError());
+    return slow(c_hi, end - c_hi);
+}
+
+static int check_insert_columns(bigsi_hip_index *ix, uint64_t col0, uint64_t n, const void *blooms, uint64_t bloom_stride_bytes)
 {
     if (!ix || (n && !blooms)) return fail(BIGSI_ERR_INVALID, "NULL argument");
-    if (n == 0) return BIGSI_OK;
     const uint64_t nb = ceil_div(ix->m, 8);
-    if (bloom_stride_bytes < nb) return fail(BIGSI_ERR_INVALID, "bloom_stride_bytes %llu < ceil(num_rows/8) = %llu", (unsigned long long)bloom_stride_bytes, (unsigned long long)nb);
+    if (n && bloom_stride_bytes < nb) return fail(BIGSI_ERR_INVALID, "bloom_stride_bytes %llu < ceil(num_rows/8) = %llu", (unsigned long long)bloom_stride_bytes, (unsigned long long)nb);
     if (col0 > ix->n_cols) return fail(BIGSI_ERR_RANGE, "column %llu beyond num_cols %llu", (unsigned long long)col0, (unsigned long long)ix->n_cols);
     if (col0 + n > ix->cap_cols) return fail(BIGSI_ERR_CAPACITY, "columns [%llu,%llu) beyond col_capacity %llu", (unsigned long long)col0, (unsigned long long)(col0 + n), (unsigned long long)ix->cap_cols);
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_insert_columns(bigsi_hip_index *ix, uint64_t col0, uint64_t n, const uint8_t *blooms, uint64_t bloom_stride_bytes)
+{
+    TRY(check_insert_columns(ix, col0, n, blooms, bloom_stride_bytes));
+    if (n == 0) return BIGSI_OK;
     TRY(use_device(ix));
-    // stage at most ~256 MB of filters per launch
-    const uint64_t per = std::max<uint64_t>(1, (256ull << 20) / nb);
+    // filters are staged a slab at a time at a 16-byte pitch (vector loads): at least 512 of them when 2 GB allow it (one
+    // transpose tile is 512 columns wide), otherwise about 256 MB worth
+    const uint64_t nb = ceil_div(ix->m, 8), pitch = round_up(nb, 16);
+    const uint64_t stage_bytes = std::min<uint64_t>(std::max<uint64_t>(512 * pitch, 256ull << 20), 2048ull << 20);
+    uint64_t per = std::max<uint64_t>(1, stage_bytes / pitch);
+    if (per >= 128) per = per / 128 * 128;
     for (uint64_t c0 = 0; c0 < n; c0 += per) {
         const uint64_t cn = std::min(per, n - c0);
-        TRY(ix->stage.reserve(cn * nb));
-        HIP_TRY(hipMemcpy2DAsync(ix->stage.p, nb, blooms + c0 * bloom_stride_bytes, bloom_stride_bytes, nb, cn, hipMemcpyHostToDevice, ix->stream));
-        const uint64_t items = ix->m * (((col0 + c0 + cn - 1) >> 6) - ((col0 + c0) >> 6) + 1);
-        const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(items, kBlock), 256 * 32);
-        hipLaunchKernelGGL(k_insert_columns, dim3(grid), dim3(kBlock), 0, ix->stream, ix->d_index, ix->stride_words, ix->m, col0 + c0, cn,
-                           ix->stage.as<uint8_t>(), nb);
-        HIP_TRY(hipGetLastError());
+        TRY(ix->stage.reserve(cn * pitch));
+        HIP_TRY(hipMemcpy2DAsync(ix->stage.p, pitch, blooms + c0 * bloom_stride_bytes, bloom_stride_bytes, nb, cn, hipMemcpyHostToDevice, ix->stream));
+        TRY(transpose_device(ix, col0 + c0, cn, ix->stage.as<uint8_t>(), pitch));
         HIP_TRY(hipStreamSynchronize(ix->stream));
     }
+    if (col0 + n > ix->n_cols) ix->n_cols = col0 + n;
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_insert_columns_device(bigsi_hip_index *ix, uint64_t col0, uint64_t n, const void *d_blooms, uint64_t bloom_stride_bytes)
+{
+    TRY(check_insert_columns(ix, col0, n, d_blooms, bloom_stride_bytes));
+    if (n == 0) return BIGSI_OK;
+    TRY(use_device(ix));
+    EventPair ep{};
+    TRY(ev_begin(ix, &ep));
+    TRY(transpose_device(ix, col0, n, (const uint8_t *)d_blooms, bloom_stride_bytes));
+    TRY(ev_end(ix, &ep, ix->ev_tr));
+    HIP_TRY(hipStreamSynchronize(ix->stream));
     if (col0 + n > ix->n_cols) ix->n_cols = col0 + n;
     return BIGSI_OK;
 }
@@ -407,7 +454,7 @@ extern "C" int bigsi_hip_bloom(int device, const char *kmers, uint64_t u, uint32
 }
 
 // ------------------------------------------------------------------------------ profiling events
-static int ev_begin(bigsi_hip_index *ix, EventPair *p, hipStream_t st = nullptr, bool row_and = false)
+static int ev_begin(bigsi_hip_index *ix, EventPair *p, hipStream_t st, bool row_and)
 {
     if (!st) st = ix->stream;
     *p = EventPair{};
@@ -424,7 +471,7 @@ static int ev_begin(bigsi_hip_index *ix, EventPair *p, hipStream_t st = nullptr,
     return BIGSI_OK;
 }
 
-static int ev_end(bigsi_hip_index *ix, EventPair *p, std::vector<EventPair> &dst, hipStream_t st = nullptr, uint32_t launches = 1)
+static int ev_end(bigsi_hip_index *ix, EventPair *p, std::vector<EventPair> &dst, hipStream_t st, uint32_t launches)
 {
     if (!p->a) return BIGSI_OK;          // not being timed
     if (!st) st = ix->stream;
@@ -462,6 +509,7 @@ extern "C" int bigsi_hip_stats(bigsi_hip_index *ix, bigsi_hip_stats_t *out, int 
     TRY(sum(ix->ev_km, &out->kmerize_launches, &out->kmerize_ms));
     TRY(sum(ix->ev_cp, &out->compact_launches, &out->compact_ms));
     TRY(sum(ix->ev_pr, &out->presence_launches, &out->presence_ms));
+    TRY(sum(ix->ev_tr, &out->transpose_launches, &out->transpose_ms));
     out->presence_bytes = ix->presence_bytes;
     if (reset) {
         recycle_events(ix);

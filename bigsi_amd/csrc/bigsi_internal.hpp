@@ -84,7 +84,7 @@ struct bigsi_hip_index {
     DevBuf stage, stage_ids;
     // profiling
     int profiling = 0;            // 0 off, 1 every kernel group of a run, 2 the row-AND kernel only
-    std::vector<EventPair> ev_and, ev_km, ev_cp, ev_pr, ev_free;
+    std::vector<EventPair> ev_and, ev_km, ev_cp, ev_pr, ev_tr, ev_free;
     uint64_t presence_bytes = 0;   // algorithmic bytes of the timed presence_hits calls
     uint64_t wv() const { return ceil_div(n_cols, 64); }
     uint64_t rb() const { return ceil_div(n_cols, 8); }

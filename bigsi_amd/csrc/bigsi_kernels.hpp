@@ -1179,6 +1179,95 @@ __global__ __launch_bounds__(kBlock) void k_insert_columns(
     }
 }
 
+// The transpose as a bandwidth kernel (full 64-column words; k_insert_columns above keeps the ragged edges).
+// A workgroup moves a tile of 512 rows x 512 columns: 64 bytes of each of 512 filters in, 64 bytes of each of 512 rows out,
+// both as whole 64-byte runs (16 bytes per lane, four lanes per run), so every sector that crosses the memory interface is
+// used in full and nothing is read-modified-written.  In between, the tile is 64 blocks of 64 x 64 bits; a wavefront
+// transposes a block in registers -- lane l holds the 64 row bits of one column, six butterfly steps (exchange with lane
+// l ^ j, j = 32 .. 1) leave lane i holding the 64 column bits of row i -- reading its operands from and writing its results
+// to LDS (pitch 72 bytes: conflict-free 8-byte accesses for 32 lanes at a stride of one LDS row).
+// Bit order: both the filters and the rows keep the reference's byte format (bit 7 - (i & 7) of byte i >> 3), so in a
+// little-endian uint64 element i sits at bit_of_col(i); by_column() turns that into plain order for the butterfly, and lane
+// l is given column bit_of_col(l) of the word, which puts every result bit where the row format wants it.
+constexpr int kTransposeTile = 512, kTransposePitch = 72;
+
+__device__ __forceinline__ uint64_t transpose64_lanes(uint64_t a, uint32_t lane)
+{
+    // after the six steps: bit k of lane i = bit i of (the original value of) lane k
+#define BIGSI_TR_STEP(J, M)                                                                   \
+    {                                                                                         \
+        const uint64_t p = __shfl_xor(a, J, 64);                                              \
+        a = (lane & J) ? (((p >> J) & M) | (a & ~M)) : ((a & M) | ((p & M) << J));            \
+    }
+    BIGSI_TR_STEP(32, 0x00000000FFFFFFFFull)
+    BIGSI_TR_STEP(16, 0x0000FFFF0000FFFFull)
+    BIGSI_TR_STEP(8, 0x00FF00FF00FF00FFull)
+    BIGSI_TR_STEP(4, 0x0F0F0F0F0F0F0F0Full)
+    BIGSI_TR_STEP(2, 0x3333333333333333ull)
+    BIGSI_TR_STEP(1, 0x5555555555555555ull)
+#undef BIGSI_TR_STEP
+    return a;
+}
+
+__global__ __launch_bounds__(kBlock) void k_transpose_tiles(
+    uint64_t *__restrict__ index, uint64_t stride_words, uint64_t m, uint64_t w_first /* first column word written; even */,
+    uint64_t n_words /* whole 64-column words to write */, const uint8_t *__restrict__ blooms /* filter of column 64 * w_first */,
+    uint64_t bstride /* bytes between filters; multiple of 16 */, uint64_t nb /* valid bytes of a filter: ceil(m / 8) */)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lin[kTransposeTile * kTransposePitch];
+    __shared__ __attribute__((aligned(16))) uint8_t lout[kTransposeTile * kTransposePitch];
+    const uint64_t tile_r = blockIdx.x, tile_c = blockIdx.y;
+    const uint64_t r0 = tile_r * kTransposeTile, byte0 = tile_r * (kTransposeTile / 8);
+    const uint64_t w0 = tile_c * 8;
+    const uint32_t words_here = (uint32_t)(n_words - w0 < 8 ? n_words - w0 : 8), cols_here = words_here * 64;
+    // phase 1: 64 bytes of each column's filter -> lin[col][0..64)
+#pragma unroll
+    for (int it = 0; it < kTransposeTile * 4 / kBlock; it++) {
+        const uint32_t item = it * kBlock + threadIdx.x, col = item >> 2, part = item & 3u;
+        uint64_t lo = 0, hi = 0;
+        if (col < cols_here) {
+            const uint64_t off = byte0 + part * 16;
+            const uint8_t *src = blooms + (w0 * 64 + col) * bstride + off;
+            if (off + 16 <= nb) {
+                const u64x2 v = *reinterpret_cast<const u64x2 *>(src);
+                lo = v.x;
+                hi = v.y;
+            } else {
+                for (uint32_t t = 0; t < 16 && off + t < nb; t++) {
+                    if (t < 8) lo |= (uint64_t)src[t] << (8 * t);
+                    else hi |= (uint64_t)src[t] << (8 * (t - 8));
+                }
+            }
+        }
+        uint64_t *d = reinterpret_cast<uint64_t *>(lin + col * kTransposePitch + part * 16);
+        d[0] = lo;
+        d[1] = hi;
+    }
+    __syncthreads();
+    // phase 2: 8 column words x 8 row chunks of 64 x 64 bits, 16 blocks per wavefront
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t mycol = bit_of_col(lane);
+    for (uint32_t blk = wave; blk < 64; blk += kBlock / 64) {
+        const uint32_t cw = blk & 7u, rc = blk >> 3;
+        if (cw >= words_here) continue;                  // wave-uniform
+        uint64_t v = *reinterpret_cast<const uint64_t *>(lin + (cw * 64 + mycol) * kTransposePitch + rc * 8);
+        v = transpose64_lanes(by_column(v), lane);
+        *reinterpret_cast<uint64_t *>(lout + (rc * 64 + lane) * kTransposePitch + cw * 8) = v;
+    }
+    __syncthreads();
+    // phase 3: lout[row][0 .. 8 * words_here) -> the rows' words [w_first + w0, +words_here)
+#pragma unroll
+    for (int it = 0; it < kTransposeTile * 4 / kBlock; it++) {
+        const uint32_t item = it * kBlock + threadIdx.x, row = item >> 2, part = item & 3u;
+        const uint64_t r = r0 + row;
+        if (r >= m || part * 2 >= words_here) continue;
+        const uint64_t *sp = reinterpret_cast<const uint64_t *>(lout + row * kTransposePitch + part * 16);
+        uint64_t *dst = index + r * stride_words + w_first + w0 + part * 2;
+        if (part * 2 + 1 < words_here) *reinterpret_cast<u64x2 *>(dst) = u64x2{sp[0], sp[1]};
+        else dst[0] = sp[0];
+    }
+}
+
 // merge_indexes (bigsi/graph/index.py:54-60): append the n2 columns of src after the n1 columns of dst, row by row,
 // device to device.  One thread per (row, destination byte); bits are MSB-first inside a byte, so a column offset that
 // is not a multiple of 8 is a bit shift across source bytes.

@@ -91,6 +91,9 @@ int bigsi_hip_insert_column(bigsi_hip_index *ix, uint64_t col, const uint8_t *bl
  * filters (filter i at blooms + i*bloom_stride_bytes, ceil(num_rows/8) bytes each) become columns [col0, col0+n).
  * col0 <= num_cols; num_cols grows to col0+n if that is larger.  Needs col0+n <= col_capacity. */
 int bigsi_hip_insert_columns(bigsi_hip_index *ix, uint64_t col0, uint64_t n, const uint8_t *blooms, uint64_t bloom_stride_bytes);
+/* The same with the filters already in device memory (e.g. written there by a Bloom-construction kernel): no staging copy.
+ * A 16-byte aligned pointer and pitch take the tiled transpose; anything else the column-at-a-time route. */
+int bigsi_hip_insert_columns_device(bigsi_hip_index *ix, uint64_t col0, uint64_t n, const void *d_blooms, uint64_t bloom_stride_bytes);
 /* KmerSignatureIndex.merge_indexes (bigsi/graph/index.py:54-60): append all columns of src after dst's, device to
  * device (same device, same num_rows); dst's capacity grows as needed. */
 int bigsi_hip_append_index(bigsi_hip_index *dst, const bigsi_hip_index *src);
@@ -314,6 +317,8 @@ typedef struct {
     uint64_t presence_launches; /* bigsi_hip_batch_presence_hits calls: K5 (both kernels) */
     double presence_ms;
     uint64_t presence_bytes;    /* algorithmic bytes of those calls: unique k-mers x h x 8 x distinct hit words + string bytes */
+    uint64_t transpose_launches; /* bigsi_hip_insert_columns_device calls (the build transpose, filters resident) */
+    double transpose_ms;
 } bigsi_hip_stats_t;
 /* record HIP events around the kernels of batch_run: 0 off, 1 around K1 / K2 / K4 each, 2 around the row-AND kernel only
  * (an event record costs the stream 5-7 us, which matters for batches of short reads) */

@@ -195,24 +195,34 @@ def k5():
 
 
 def transpose():
-    """Bloom filters -> matrix columns on the device (bigsi_hip_insert_columns): n filters of m bits, host-staged."""
-    for m, ncols in ((1_000_000, 4096), (10_000_000, 512)):
+    """Bloom filters -> matrix columns (the build transpose): filters resident in device memory
+    (bigsi_hip_insert_columns_device), kernel time from the library's events; bytes = filters in + rows out."""
+    import torch
+    L = _lib.lib()
+    for m, ncols in ((10_000_000, 8192), (1_000_000, 100_000), (1_000_000, 100_000 - 37)):
         st = get_storage({"storage-engine": "hip-hbm", "k": 31, "m": m, "h": 3,
                           "storage-config": {"name": "tr", "device": 0, "max_cols": ncols}})
         st.delete_all()
         for key, v in (("number_of_rows", m), ("number_of_cols", 0), ("ksi:bloomfilter_size", m), ("ksi:num_hashes", 3)):
             st.set_integer(key, v)
         nb = (m + 7) // 8
-        blooms = np.random.default_rng(5).integers(0, 256, size=(ncols, nb), dtype=np.uint8)
-        st.insert_columns(0, blooms[:64])      # warm
-        t0 = time.perf_counter()
-        st.insert_columns(0, blooms)
-        dt = time.perf_counter() - t0
-        emit("insert_columns", m=m, cols=ncols, call_ms=dt * 1e3, bloom_bytes=int(blooms.nbytes),
-             GBps_call=2 * blooms.nbytes / dt / 1e9, note="whole call incl. H2D staging of the filters; in+out bytes")
-        got = st.get_rows_packed([0, 1, m - 1], (ncols + 7) // 8)
-        want = np.packbits(np.unpackbits(blooms[:, [0, 0, (m - 1) // 8]], axis=1)[:, [0, 1, 16 + (m - 1) % 8]].T, axis=1)
-        assert np.array_equal(got, want)
+        pitch = -(-nb // 16) * 16
+        blooms = torch.randint(0, 256, (ncols, pitch), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        check(L.bigsi_hip_insert_columns_device(st.handle, 0, 512, blooms.data_ptr(), pitch))      # warm
+        check(L.bigsi_hip_set_profiling(st.handle, 1))
+        stats(st)
+        check(L.bigsi_hip_insert_columns_device(st.handle, 0, ncols, blooms.data_ptr(), pitch))
+        s = stats(st)
+        check(L.bigsi_hip_set_profiling(st.handle, 0))
+        moved = 2 * ncols * nb
+        for r in (0, 1, 511, 512, m // 2 + 3, m - 1):
+            bits = ((blooms[:, r >> 3] >> (7 - (r & 7))) & 1).cpu().numpy()
+            assert np.array_equal(st.get_rows_packed([r], (ncols + 7) // 8)[0], np.packbits(bits)), r
+        emit("transpose_device", m=m, cols=ncols, kernels_ms=s.transpose_ms, bytes_in_plus_out=moved,
+             GBps=moved / s.transpose_ms / 1e6, frac=moved / s.transpose_ms / 1e6 / PEAK,
+             note="k_transpose_tiles (+ k_insert_columns for ragged edges); filters resident in HBM")
+        del blooms
         st.delete_all()
 
 

@@ -1079,3 +1079,31 @@ def test_transpose_on_device_matches_numpy(hip):
         assert np.array_equal(np.unpackbits(transpose_packed([BitRow(r) for r in a]), axis=1)[:, :n], a.T.astype(np.uint8))
 
 
+
+
+@pytest.mark.parametrize("m,first,second", [(5003, 700, 300), (4096, 1024, 64), (1000, 129, 1), (70000, 64, 1000), (513, 5, 250)])
+def test_tiled_transpose_matches_numpy(hip, m, first, second):
+    """bigsi_hip_insert_columns: whole 64-column words go through the tiled LDS transpose, ragged heads / tails through the
+    column-at-a-time kernel; appending at a column that is not a multiple of 128, row counts that are not multiples of 8 or
+    512, filters shorter than a vector load.  Rows must equal numpy's transpose of the filters bit for bit."""
+    from bigsi_amd.storage import get_storage
+    rng = np.random.default_rng(m + first)
+    n = first + second
+    bits = rng.integers(0, 2, size=(n, m), dtype=np.uint8)
+    blooms = np.packbits(bits, axis=1)                      # filter c = row c, MSB first: the reference's Bloom file format
+    st = get_storage(cfg(31, m, 3, max_cols=n))
+    st.delete_all()
+    for key, v in (("number_of_rows", m), ("number_of_cols", 0), ("ksi:bloomfilter_size", m), ("ksi:num_hashes", 3)):
+        st.set_integer(key, v)
+    st.insert_columns(0, blooms[:first])
+    st.insert_columns(first, blooms[first:])
+    got = st.get_rows_packed(np.arange(m), (n + 7) // 8)
+    assert np.array_equal(got, np.packbits(bits.T, axis=1))
+    # overwrite a middle range in place (col0 < num_cols): the neighbours must survive
+    lo = min(70, n - 1)
+    hi = min(n, lo + 200)
+    bits2 = bits.copy()
+    bits2[lo:hi] ^= 1
+    st.insert_columns(lo, np.packbits(bits2[lo:hi], axis=1))
+    assert np.array_equal(st.get_rows_packed(np.arange(m), (n + 7) // 8), np.packbits(bits2.T, axis=1))
+    st.delete_all()
