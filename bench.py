@@ -321,14 +321,14 @@ def main():
         check(_lib.lib().bigsi_hip_set_profiling(st.handle, 1))
         check(_lib.lib().bigsi_hip_stats(st.handle, _lib.C.byref(_lib.Stats()), 1))
         t1 = time.perf_counter()
-        blob, soff = batch.presence_hits(off_own, col_own, nk)
+        blob, starts, lens = batch.presence_hits(off_own, col_own, nk)
         call_ms = (time.perf_counter() - t1) * 1e3
         ps = _lib.Stats()
         check(_lib.lib().bigsi_hip_stats(st.handle, _lib.C.byref(ps), 1))
         for j, qi in enumerate(planted):                          # the planted sample's string shows the planted k-mers
             t = int(off_own[qi]) + int(np.searchsorted(col_own[int(off_own[qi]):int(off_own[qi + 1])], plant_col(j, rank, my_cols)))
-            assert int((blob[int(soff[t]):int(soff[t + 1])] == ord("1")).sum()) >= plant_len - args.k + 1
-        presence = {"strings": int(col_own.size), "string_bytes": int(soff[-1]), "kernels_ms": ps.presence_ms, "call_ms": call_ms,
+            assert int((blob[int(starts[t]):int(starts[t] + lens[t])] == ord("1")).sum()) >= plant_len - args.k + 1
+        presence = {"strings": int(col_own.size), "string_bytes": int(lens.sum()), "kernels_ms": ps.presence_ms, "call_ms": call_ms,
                     "alg_bytes": int(ps.presence_bytes), "GBps": ps.presence_bytes / max(ps.presence_ms, 1e-9) / 1e6}
 
     # PCIe-inclusive rate of the host-buffer boundary (never `value`): sequences in host memory -> batch_reload (H2D) ->

@@ -1381,7 +1381,7 @@ extern "C" int bigsi_hip_batch_presence_hits(bigsi_hip_batch *b, const uint64_t 
             if (colours[h0 + t] >= ix->n_cols) return fail(BIGSI_ERR_RANGE, "colour %u >= num_cols", colours[h0 + t]);
             hit_seq[t] = q;
             string_offsets[t] = str;
-            str += b->h_num_kmers[q];
+            str += round_up(b->h_num_kmers[q], 16);       // every string starts on a 16-byte boundary (16-character stores)
         }
         pair_off[q] = pairs.size();
         if (hi == lo || b->h_num_kmers[q] == 0) continue;
@@ -1421,9 +1421,9 @@ extern "C" int bigsi_hip_batch_presence_hits(bigsi_hip_batch *b, const uint64_t 
     memcpy(stage.data() + o_seq, hit_seq.data(), n_hits * 4);
     memcpy(stage.data() + o_perm, perm.data(), n_hits * 4);
     memcpy(stage.data() + o_pairs, pairs.data(), pairs.size() * sizeof(PresencePair));
-    const uint32_t bits_stride = (uint32_t)ceil_div(std::max<uint32_t>(max_u, 1), 16);
+    const uint32_t n_chunks = (uint32_t)ceil_div(std::max<uint32_t>(max_u, 1), 16);
     TRY(b->pres_in.reserve(in_bytes));
-    TRY(b->pres_bits.reserve((size_t)n_hits * bits_stride * 2));
+    TRY(b->pres_bits.reserve((size_t)n_hits * n_chunks * 2));
     TRY(b->pres_out.reserve(str));
     HIP_TRY(hipMemcpyAsync(b->pres_in.p, stage.data(), in_bytes, hipMemcpyHostToDevice, ix->stream));
     const uint8_t *din = b->pres_in.as<uint8_t>();
@@ -1433,7 +1433,7 @@ extern "C" int bigsi_hip_batch_presence_hits(bigsi_hip_batch *b, const uint64_t 
 #define BIGSI_PRESENCE(H)                                                                                                      \
     hipLaunchKernelGGL((k_presence_bits<H>), grid_a, dim3(kBlock), 0, ix->stream, ix->d_index, ix->stride_words, b->rows.as<uint64_t>(), \
                        b->d_pos_off.as<uint64_t>(), b->num_unique.as<uint32_t>(), ix->h, (const uint64_t *)(din + o_pair_off),        \
-                       (const PresencePair *)(din + o_pairs), (const uint32_t *)(din + o_perm), b->pres_bits.as<uint16_t>(), bits_stride)
+                       (const PresencePair *)(din + o_pairs), (const uint32_t *)(din + o_perm), b->pres_bits.as<uint16_t>(), n_hits)
     switch (ix->h) {
     case 1: BIGSI_PRESENCE(1); break;
     case 2: BIGSI_PRESENCE(2); break;
@@ -1446,10 +1446,9 @@ extern "C" int bigsi_hip_batch_presence_hits(bigsi_hip_batch *b, const uint64_t 
     HIP_TRY(hipGetLastError());
     for (uint64_t t0 = 0; t0 < n_hits; t0 += 65535) {          // grid.y limit
         const uint64_t cnt = std::min<uint64_t>(65535, n_hits - t0);
-        hipLaunchKernelGGL(k_presence_expand, dim3((unsigned)ceil_div(std::max<uint32_t>(max_n, 1), kBlock), (unsigned)cnt), dim3(kBlock), 0, ix->stream,
-                           b->pres_bits.as<uint16_t>() + t0 * bits_stride, bits_stride, (const uint32_t *)(din + o_seq) + t0,
-                           (const uint64_t *)(din + o_str) + t0, b->d_pos_off.as<uint64_t>(), b->num_kmers.as<uint32_t>(), b->pos_unique.as<uint32_t>(),
-                           b->pres_out.as<uint8_t>());
+        hipLaunchKernelGGL(k_presence_expand, dim3((unsigned)ceil_div(std::max<uint32_t>(max_n, 1), kBlock * 16), (unsigned)cnt), dim3(kBlock), 0, ix->stream,
+                           b->pres_bits.as<uint16_t>(), n_hits, t0, (const uint32_t *)(din + o_seq), (const uint64_t *)(din + o_str),
+                           b->d_pos_off.as<uint64_t>(), b->num_kmers.as<uint32_t>(), b->pos_unique.as<uint32_t>(), b->pres_out.as<uint8_t>());
     }
     HIP_TRY(hipGetLastError());
     TRY(ev_end(ix, &ep, ix->ev_pr));

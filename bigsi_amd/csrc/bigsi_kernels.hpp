@@ -1036,7 +1036,7 @@ template <int H>
 __global__ __launch_bounds__(kBlock) void k_presence_bits(
     const uint64_t *__restrict__ index, uint64_t stride_words, const uint64_t *__restrict__ rows, const uint64_t *__restrict__ pos_off,
     const uint32_t *__restrict__ num_unique, uint32_t h_rt, const uint64_t *__restrict__ pair_off, const PresencePair *__restrict__ pairs,
-    const uint32_t *__restrict__ perm, uint16_t *__restrict__ bits, uint32_t bits_stride)
+    const uint32_t *__restrict__ perm, uint16_t *__restrict__ bits /* [k-mer chunk][hit] */, uint64_t n_hits)
 {
     const uint32_t h = H > 0 ? (uint32_t)H : h_rt;
     const uint32_t q = blockIdx.z, jc = blockIdx.y;
@@ -1047,19 +1047,41 @@ __global__ __launch_bounds__(kBlock) void k_presence_bits(
     if (p >= pair_off[q + 1]) return;
     const PresencePair pr = pairs[p];
     const uint64_t *qrows = rows + pos_off[q] * h;
-    const uint64_t woff = (uint64_t)pr.wpair * 2;
+    const uint32_t woff = pr.wpair * 2u;
+    const u64x2 zero = {0ull, 0ull};
     u64x2 a[16];
+    if (H > 0) {
+        // four k-mers = 4 x h independent 16-byte loads in flight, then their ANDs
 #pragma unroll
-    for (int t = 0; t < 16; t++) {
-        const uint32_t j = j0 + t;
-        u64x2 v = {0ull, 0ull};
-        if (j < u) {                                   // wave-uniform
-            v = load_row_seg(index, qrows[(uint64_t)j * h], stride_words, (uint32_t)woff);
-            for (uint32_t s = 1; s < h; s++) v &= load_row_seg(index, qrows[(uint64_t)j * h + s], stride_words, (uint32_t)woff);
+        for (int t0 = 0; t0 < 16; t0 += 4) {
+            u64x2 tmp[4 * (H > 0 ? H : 1)];
+#pragma unroll
+            for (int x = 0; x < 4 * H; x++) {
+                const uint32_t j = j0 + t0 + x / H;
+                tmp[x] = j < u ? load_row_seg(index, qrows[(uint64_t)j * H + x % H], stride_words, woff) : zero;   // j < u is wave-uniform
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                u64x2 v = tmp[t * H];
+#pragma unroll
+                for (int sidx = 1; sidx < H; sidx++) v &= tmp[t * H + sidx];
+                a[t0 + t] = v;
+            }
         }
-        a[t] = v;
+    } else {
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const uint32_t j = j0 + t;
+            u64x2 v = zero;
+            if (j < u) {
+                v = load_row_seg(index, qrows[(uint64_t)j * h], stride_words, woff);
+                for (uint32_t sidx = 1; sidx < h; sidx++) v &= load_row_seg(index, qrows[(uint64_t)j * h + sidx], stride_words, woff);
+            }
+            a[t] = v;
+        }
     }
     uint32_t rank = pr.base;
+    uint16_t *dst = bits + (uint64_t)jc * n_hits;      // chunk-major: the hits of consecutive pairs are neighbours in memory
 #pragma unroll
     for (int half = 0; half < 2; half++) {
         uint64_t m = by_column(half ? pr.mask_hi : pr.mask_lo);      // bit c set <=> column 64 * word + c is a hit
@@ -1070,24 +1092,36 @@ __global__ __launch_bounds__(kBlock) void k_presence_bits(
             uint32_t out = 0;
 #pragma unroll
             for (int t = 0; t < 16; t++) out |= (uint32_t)(((half ? a[t].y : a[t].x) >> bp) & 1ull) << t;
-            bits[(uint64_t)perm[rank] * bits_stride + jc] = (uint16_t)out;
+            dst[perm[rank]] = (uint16_t)out;
             rank++;
         }
     }
 }
 
-// strings[hit][i] = '0' + bit (unique k-mer of position i) of the hit's presence bits
+// strings: 16 characters per thread, one 16-byte store (every string starts at a multiple of 16 bytes);
+// character i of hit t = '0' + bit (unique k-mer of position i) of the hit's presence bits
 __global__ __launch_bounds__(kBlock) void k_presence_expand(
-    const uint16_t *__restrict__ bits, uint32_t bits_stride, const uint32_t *__restrict__ hit_seq, const uint64_t *__restrict__ str_off,
+    const uint16_t *__restrict__ bits, uint64_t n_hits, uint64_t hit0, const uint32_t *__restrict__ hit_seq, const uint64_t *__restrict__ str_off,
     const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ num_kmers, const uint32_t *__restrict__ pos_unique,
     uint8_t *__restrict__ out)
 {
-    const uint64_t hit = blockIdx.y;
+    const uint64_t hit = hit0 + blockIdx.y;
     const uint32_t q = hit_seq[hit];
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= num_kmers[q]) return;
-    const uint32_t j = pos_unique[pos_off[q] + i];
-    out[str_off[hit] + i] = (uint8_t)('0' + ((bits[hit * bits_stride + (j >> 4)] >> (j & 15u)) & 1u));
+    const uint32_t n = num_kmers[q];
+    const uint32_t i0 = (blockIdx.x * kBlock + threadIdx.x) * 16u;
+    if (i0 >= n) return;
+    const uint32_t *pu = pos_unique + pos_off[q];
+    uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+        uint32_t ch = 0;
+        if (i0 + t < n) {
+            const uint32_t j = pu[i0 + t];
+            ch = '0' + ((bits[(uint64_t)(j >> 4) * n_hits + hit] >> (j & 15u)) & 1u);
+        }
+        w[t >> 2] |= ch << (8 * (t & 3));
+    }
+    *reinterpret_cast<uint4 *>(out + str_off[hit] + i0) = uint4{w[0], w[1], w[2], w[3]};
 }
 
 // ------------------------------------------------------------------------------ storage contract helpers

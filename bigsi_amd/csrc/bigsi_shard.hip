@@ -791,7 +791,7 @@ extern "C" int bigsi_hip_group_batch_presence_hits(bigsi_hip_group_batch *gb, co
         for (uint64_t t = hit_offsets[q] - h0; t < hit_offsets[q + 1] - h0; t++) {
             if (colours[h0 + t] >= g->n_cols) return fail(BIGSI_ERR_RANGE, "colour %u >= num_cols", colours[h0 + t]);
             string_offsets[t] = str;
-            str += nk[q];
+            str += round_up(nk[q], 16);
         }
     string_offsets[n_hits] = str;
     if (str > out_capacity) return fail(BIGSI_ERR_CAPACITY, "string buffer holds %llu bytes, %llu needed", (unsigned long long)out_capacity, (unsigned long long)str);
@@ -814,7 +814,7 @@ extern "C" int bigsi_hip_group_batch_presence_hits(bigsi_hip_group_batch *gb, co
         off[nq] = local.size();
         if (local.empty()) continue;
         uint64_t need = 0;
-        for (uint32_t t : where) need += string_offsets[t + 1] - string_offsets[t];
+        for (uint32_t t : where) need += string_offsets[t + 1] - string_offsets[t];      // padded lengths: the shard pads the same way
         part.resize(need);
         soff.resize(local.size() + 1);
         TRY(bigsi_use_device(gb->b[i]->ix));

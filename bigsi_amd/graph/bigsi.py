@@ -196,9 +196,8 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
             if ((np.diff(off64[:n_seqs + 1]) > 0) & (num_kmers[:n_seqs] == 1)).any():
                 # the reference builds a 1-D matrix from a single row and then indexes it with two subscripts
                 raise IndexError("too many indices for array: array is 1-dimensional, but 2 were indexed")
-            blob, soff = batch.presence_hits(off, colours, num_kmers)
-            text, soff = blob.tobytes().decode("ascii"), soff.astype(np.int64)
-            strings = (text, soff)
+            blob, starts, lens = batch.presence_hits(off, colours, num_kmers)
+            strings = (blob.tobytes().decode("latin-1"), starts, lens)
         for i in np.flatnonzero(np.diff(off64[:n_seqs + 1])).tolist():      # only the sequences that have hits
             lo, hi = int(off64[i]), int(off64[i + 1])
             out[i] = self._assemble(lo, colours[lo:hi], counts[lo:hi], int(nu[i]), exact, strings)
@@ -246,7 +245,7 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
 
     def _assemble(self, first_hit, colours, counts, u, exact, strings):
         """Result dicts of one sequence from its slice of the batch's hit lists; `strings` = (text, offsets) of the batch's
-        presence strings (score=True), indexed by position in the hit lists, `first_hit` = position of this slice's first hit."""
+        presence strings (score=True: text, starts, lengths), indexed by position in the hit lists, `first_hit` = position of this slice's first hit."""
         idx = np.arange(len(colours))
         if exact:
             # exact_filter (graph/bigsi.py:192-205): every set bit, ascending; a colour without a name is a KeyError
@@ -259,9 +258,9 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
             idx = idx[order]
             results = [BigsiQueryResult(int(colours[j]), self.colour_to_sample(int(colours[j])), int(counts[j]), u) for j in order]
         if strings is not None and results:
-            text, soff = strings
+            text, starts, lens = strings
             for r, t in zip(results, idx.tolist()):
-                col = text[int(soff[first_hit + t]):int(soff[first_hit + t + 1])]
+                col = text[int(starts[first_hit + t]):int(starts[first_hit + t] + lens[first_hit + t])]
                 sd = self.scorer.score(col)
                 sd["kmer-presence"] = col
                 r.add_score(sd)

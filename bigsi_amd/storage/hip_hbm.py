@@ -540,16 +540,16 @@ class QueryBatch(object):
 
     def presence_hits(self, off, colours, num_kmers):
         """Presence strings for the hits of EVERY sequence in one device pass (bigsi_hip_batch_presence_hits): `off`, `colours` as
-        hits() returns them (any colour order inside a sequence).  Returns (blob uint8[], string_offsets uint64[n_hits + 1]):
-        the string of hit t is blob[string_offsets[t]:string_offsets[t + 1]]."""
+        hits() returns them (any colour order inside a sequence).  Returns (blob uint8[], starts int64[n_hits], lengths
+        int64[n_hits]): the string of hit t is blob[starts[t] : starts[t] + lengths[t]] (starts are 16-byte aligned)."""
         off = np.ascontiguousarray(off, dtype=np.uint64)
         colours = np.ascontiguousarray(colours, dtype=np.uint32)
         n_hits = int(off[self.n] - off[0])
-        lens = np.repeat(np.asarray(num_kmers[: self.n], dtype=np.uint64), np.diff(off[: self.n + 1]).astype(np.int64))
-        blob = np.zeros(max(int(lens.sum()), 1), np.uint8)
+        lens = np.repeat(np.asarray(num_kmers[: self.n], dtype=np.int64), np.diff(off[: self.n + 1]).astype(np.int64))
+        blob = np.zeros(max(int(((lens + 15) // 16 * 16).sum()), 16), np.uint8)
         soff = np.zeros(n_hits + 1, np.uint64)
         check(self._fn("presence_hits")(self.b, _lib.ptr(off), _lib.ptr(colours) if n_hits else None, _lib.ptr(blob), blob.size, _lib.ptr(soff)))
-        return blob, soff
+        return blob, soff[:-1].astype(np.int64), lens
 
 
 # ------------------------------------------------------------------------------- snapshots (sync / reopen)

@@ -198,9 +198,9 @@ int bigsi_hip_batch_lookup(bigsi_hip_batch *b, uint32_t seq, uint32_t *first_pos
 int bigsi_hip_batch_presence(bigsi_hip_batch *b, uint32_t seq, const uint32_t *colours, uint32_t n_colours, uint8_t *out);
 /* The same for the hits of EVERY sequence of the batch in one pass (score=True on a thresholded search with thousands of hits
  * per query): colours of sequence i = colours[hit_offsets[i] .. hit_offsets[i+1]) in any order (the layout fetch_hits
- * returns).  The string of hit t starts at out[string_offsets[t]] and is num_kmers(sequence of t) characters long;
- * string_offsets gets hit_offsets[n_seqs] + 1 entries.  BIGSI_ERR_CAPACITY (string_offsets filled) if out_capacity is
- * smaller than string_offsets[n_hits]. */
+ * returns).  The string of hit t starts at out[string_offsets[t]] -- always a multiple of 16 -- and is num_kmers(sequence
+ * of t) characters long (the bytes up to the next string are padding); string_offsets gets hit_offsets[n_seqs] + 1
+ * entries, the last one the bytes needed.  BIGSI_ERR_CAPACITY (string_offsets filled) if out_capacity is smaller. */
 int bigsi_hip_batch_presence_hits(bigsi_hip_batch *b, const uint64_t *hit_offsets, const uint32_t *colours, uint8_t *out,
                                   uint64_t out_capacity, uint64_t *string_offsets);
 
