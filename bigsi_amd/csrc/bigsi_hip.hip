@@ -1433,7 +1433,7 @@ extern "C" int bigsi_hip_batch_presence_hits(bigsi_hip_batch *b, const uint64_t 
 #define BIGSI_PRESENCE(H)                                                                                                      \
     hipLaunchKernelGGL((k_presence_bits<H>), grid_a, dim3(kBlock), 0, ix->stream, ix->d_index, ix->stride_words, b->rows.as<uint64_t>(), \
                        b->d_pos_off.as<uint64_t>(), b->num_unique.as<uint32_t>(), ix->h, (const uint64_t *)(din + o_pair_off),        \
-                       (const PresencePair *)(din + o_pairs), (const uint32_t *)(din + o_perm), b->pres_bits.as<uint16_t>(), n_hits)
+                       (const PresencePair *)(din + o_pairs), (const uint32_t *)(din + o_perm), b->pres_bits.as<uint16_t>(), n_chunks)
     switch (ix->h) {
     case 1: BIGSI_PRESENCE(1); break;
     case 2: BIGSI_PRESENCE(2); break;
@@ -1447,7 +1447,7 @@ extern "C" int bigsi_hip_batch_presence_hits(bigsi_hip_batch *b, const uint64_t 
     for (uint64_t t0 = 0; t0 < n_hits; t0 += 65535) {          // grid.y limit
         const uint64_t cnt = std::min<uint64_t>(65535, n_hits - t0);
         hipLaunchKernelGGL(k_presence_expand, dim3((unsigned)ceil_div(std::max<uint32_t>(max_n, 1), kBlock * 16), (unsigned)cnt), dim3(kBlock), 0, ix->stream,
-                           b->pres_bits.as<uint16_t>(), n_hits, t0, (const uint32_t *)(din + o_seq), (const uint64_t *)(din + o_str),
+                           b->pres_bits.as<uint16_t>(), n_chunks, t0, (const uint32_t *)(din + o_seq), (const uint64_t *)(din + o_str),
                            b->d_pos_off.as<uint64_t>(), b->num_kmers.as<uint32_t>(), b->pos_unique.as<uint32_t>(), b->pres_out.as<uint8_t>());
     }
     HIP_TRY(hipGetLastError());

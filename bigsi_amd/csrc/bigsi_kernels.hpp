@@ -1033,10 +1033,10 @@ struct PresencePair {
 __device__ __forceinline__ uint64_t by_column(uint64_t x) { return __builtin_bswap64(__builtin_bitreverse64(x)); }
 
 template <int H>
-__global__ __launch_bounds__(kBlock) void k_presence_bits(
+__global__ __launch_bounds__(kBlock, 4) void k_presence_bits(      // <= 128 VGPRs: 16 AND-ed word pairs + 12 loads in flight
     const uint64_t *__restrict__ index, uint64_t stride_words, const uint64_t *__restrict__ rows, const uint64_t *__restrict__ pos_off,
     const uint32_t *__restrict__ num_unique, uint32_t h_rt, const uint64_t *__restrict__ pair_off, const PresencePair *__restrict__ pairs,
-    const uint32_t *__restrict__ perm, uint16_t *__restrict__ bits /* [k-mer chunk][hit] */, uint64_t n_hits)
+    const uint32_t *__restrict__ perm, uint16_t *__restrict__ bits /* [hit][k-mer chunk] */, uint32_t bits_stride)
 {
     const uint32_t h = H > 0 ? (uint32_t)H : h_rt;
     const uint32_t q = blockIdx.z, jc = blockIdx.y;
@@ -1081,7 +1081,8 @@ __global__ __launch_bounds__(kBlock) void k_presence_bits(
         }
     }
     uint32_t rank = pr.base;
-    uint16_t *dst = bits + (uint64_t)jc * n_hits;      // chunk-major: the hits of consecutive pairs are neighbours in memory
+    // hit-major: scattered 2-byte stores, merged in L2 (the whole array is a few tens of MB); the layout is chosen for
+    // k_presence_expand, whose wavefronts then read consecutive chunks of one hit (chunk-major measured 1.5x slower overall)
 #pragma unroll
     for (int half = 0; half < 2; half++) {
         uint64_t m = by_column(half ? pr.mask_hi : pr.mask_lo);      // bit c set <=> column 64 * word + c is a hit
@@ -1092,7 +1093,7 @@ __global__ __launch_bounds__(kBlock) void k_presence_bits(
             uint32_t out = 0;
 #pragma unroll
             for (int t = 0; t < 16; t++) out |= (uint32_t)(((half ? a[t].y : a[t].x) >> bp) & 1ull) << t;
-            dst[perm[rank]] = (uint16_t)out;
+            bits[(uint64_t)perm[rank] * bits_stride + jc] = (uint16_t)out;
             rank++;
         }
     }
@@ -1101,7 +1102,7 @@ __global__ __launch_bounds__(kBlock) void k_presence_bits(
 // strings: 16 characters per thread, one 16-byte store (every string starts at a multiple of 16 bytes);
 // character i of hit t = '0' + bit (unique k-mer of position i) of the hit's presence bits
 __global__ __launch_bounds__(kBlock) void k_presence_expand(
-    const uint16_t *__restrict__ bits, uint64_t n_hits, uint64_t hit0, const uint32_t *__restrict__ hit_seq, const uint64_t *__restrict__ str_off,
+    const uint16_t *__restrict__ bits, uint32_t bits_stride, uint64_t hit0, const uint32_t *__restrict__ hit_seq, const uint64_t *__restrict__ str_off,
     const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ num_kmers, const uint32_t *__restrict__ pos_unique,
     uint8_t *__restrict__ out)
 {
@@ -1117,7 +1118,7 @@ __global__ __launch_bounds__(kBlock) void k_presence_expand(
         uint32_t ch = 0;
         if (i0 + t < n) {
             const uint32_t j = pu[i0 + t];
-            ch = '0' + ((bits[(uint64_t)(j >> 4) * n_hits + hit] >> (j & 15u)) & 1u);
+            ch = '0' + ((bits[hit * bits_stride + (j >> 4)] >> (j & 15u)) & 1u);
         }
         w[t >> 2] |= ch << (8 * (t & 3));
     }
@@ -1248,13 +1249,17 @@ __global__ __launch_bounds__(kBlock) void k_transpose_tiles(
     uint64_t n_words /* whole 64-column words to write */, const uint8_t *__restrict__ blooms /* filter of column 64 * w_first */,
     uint64_t bstride /* bytes between filters; multiple of 16 */, uint64_t nb /* valid bytes of a filter: ceil(m / 8) */)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lin[kTransposeTile * kTransposePitch];
-    __shared__ __attribute__((aligned(16))) uint8_t lout[kTransposeTile * kTransposePitch];
+    // ONE tile buffer: line L holds, before the transpose, the 64 row-bytes of column L and, after it, the 64 column-bytes
+    // of row L.  Block (cw, rc) of 64 x 64 bits sits at lines [64 cw, +64), bytes [8 rc, +8) and its transpose belongs at
+    // lines [64 rc, +64), bytes [8 cw, +8) -- the place of block (rc, cw) -- so blocks are transposed in mirrored pairs, each
+    // written where the other was read (37 KB of LDS instead of 74: four workgroups per CU keep loads, butterflies and
+    // stores of different tiles overlapping).
+    __shared__ __attribute__((aligned(16))) uint8_t tile[kTransposeTile * kTransposePitch];
     const uint64_t tile_r = blockIdx.x, tile_c = blockIdx.y;
     const uint64_t r0 = tile_r * kTransposeTile, byte0 = tile_r * (kTransposeTile / 8);
     const uint64_t w0 = tile_c * 8;
     const uint32_t words_here = (uint32_t)(n_words - w0 < 8 ? n_words - w0 : 8), cols_here = words_here * 64;
-    // phase 1: 64 bytes of each column's filter -> lin[col][0..64)
+    // phase 1: 64 bytes of each column's filter -> tile[col][0..64) (columns beyond the last word: zeros)
 #pragma unroll
     for (int it = 0; it < kTransposeTile * 4 / kBlock; it++) {
         const uint32_t item = it * kBlock + threadIdx.x, col = item >> 2, part = item & 3u;
@@ -1263,7 +1268,7 @@ __global__ __launch_bounds__(kBlock) void k_transpose_tiles(
             const uint64_t off = byte0 + part * 16;
             const uint8_t *src = blooms + (w0 * 64 + col) * bstride + off;
             if (off + 16 <= nb) {
-                const u64x2 v = *reinterpret_cast<const u64x2 *>(src);
+                const u64x2 v = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(src));
                 lo = v.x;
                 hi = v.y;
             } else {
@@ -1273,31 +1278,40 @@ __global__ __launch_bounds__(kBlock) void k_transpose_tiles(
                 }
             }
         }
-        uint64_t *d = reinterpret_cast<uint64_t *>(lin + col * kTransposePitch + part * 16);
+        uint64_t *d = reinterpret_cast<uint64_t *>(tile + col * kTransposePitch + part * 16);
         d[0] = lo;
         d[1] = hi;
     }
     __syncthreads();
-    // phase 2: 8 column words x 8 row chunks of 64 x 64 bits, 16 blocks per wavefront
+    // phase 2: the 36 unordered pairs {(cw, rc), (rc, cw)} of the 8 x 8 blocks, nine per wavefront
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t mycol = bit_of_col(lane);
-    for (uint32_t blk = wave; blk < 64; blk += kBlock / 64) {
-        const uint32_t cw = blk & 7u, rc = blk >> 3;
-        if (cw >= words_here) continue;                  // wave-uniform
-        uint64_t v = *reinterpret_cast<const uint64_t *>(lin + (cw * 64 + mycol) * kTransposePitch + rc * 8);
-        v = transpose64_lanes(by_column(v), lane);
-        *reinterpret_cast<uint64_t *>(lout + (rc * 64 + lane) * kTransposePitch + cw * 8) = v;
+    for (uint32_t pi = wave; pi < 36; pi += kBlock / 64) {
+        // pi -> (x, y) with x <= y: row y of the lower triangle starts at y (y + 1) / 2
+        uint32_t y = 0;
+        while ((y + 1) * (y + 2) / 2 <= pi) y++;
+        const uint32_t x = pi - y * (y + 1) / 2;
+        uint8_t *pa = tile + (x * 64) * kTransposePitch + y * 8;      // block (cw = x, rc = y): lines of column word x
+        uint8_t *pb = tile + (y * 64) * kTransposePitch + x * 8;      // block (cw = y, rc = x)
+        uint64_t va = *reinterpret_cast<const uint64_t *>(pa + mycol * kTransposePitch);
+        uint64_t vb = x != y ? *reinterpret_cast<const uint64_t *>(pb + mycol * kTransposePitch) : 0ull;
+        va = transpose64_lanes(by_column(va), lane);
+        if (x != y) vb = transpose64_lanes(by_column(vb), lane);
+        // every lane of the wavefront has read both blocks before any lane overwrites them (the butterflies in between are
+        // wavefront-wide exchanges), and no other wavefront touches this pair
+        *reinterpret_cast<uint64_t *>(pb + lane * kTransposePitch) = va;      // rows of chunk y, column word x
+        if (x != y) *reinterpret_cast<uint64_t *>(pa + lane * kTransposePitch) = vb;
     }
     __syncthreads();
-    // phase 3: lout[row][0 .. 8 * words_here) -> the rows' words [w_first + w0, +words_here)
+    // phase 3: tile[row][0 .. 8 * words_here) -> the rows' words [w_first + w0, +words_here)
 #pragma unroll
     for (int it = 0; it < kTransposeTile * 4 / kBlock; it++) {
         const uint32_t item = it * kBlock + threadIdx.x, row = item >> 2, part = item & 3u;
         const uint64_t r = r0 + row;
         if (r >= m || part * 2 >= words_here) continue;
-        const uint64_t *sp = reinterpret_cast<const uint64_t *>(lout + row * kTransposePitch + part * 16);
+        const uint64_t *sp = reinterpret_cast<const uint64_t *>(tile + row * kTransposePitch + part * 16);
         uint64_t *dst = index + r * stride_words + w_first + w0 + part * 2;
-        if (part * 2 + 1 < words_here) *reinterpret_cast<u64x2 *>(dst) = u64x2{sp[0], sp[1]};
+        if (part * 2 + 1 < words_here) __builtin_nontemporal_store(u64x2{sp[0], sp[1]}, reinterpret_cast<u64x2 *>(dst));
         else dst[0] = sp[0];
     }
 }
