@@ -1430,10 +1430,15 @@ extern "C" int bigsi_hip_batch_presence_hits(bigsi_hip_batch *b, const uint64_t 
     EventPair ep{};
     TRY(ev_begin(ix, &ep));
     const dim3 grid_a((unsigned)ceil_div(std::max<uint32_t>(max_pairs, 1), kBlock), (unsigned)ceil_div(std::max<uint32_t>(max_u, 1), 16), nq);
-#define BIGSI_PRESENCE(H)                                                                                                      \
-    hipLaunchKernelGGL((k_presence_bits<H>), grid_a, dim3(kBlock), 0, ix->stream, ix->d_index, ix->stride_words, b->rows.as<uint64_t>(), \
-                       b->d_pos_off.as<uint64_t>(), b->num_unique.as<uint32_t>(), ix->h, (const uint64_t *)(din + o_pair_off),        \
-                       (const PresencePair *)(din + o_pairs), (const uint32_t *)(din + o_perm), b->pres_bits.as<uint16_t>(), n_chunks)
+    static const int k5_waves = env_int("BIGSI_HIP_K5_WAVES", 2);
+#define BIGSI_PRESENCE_ARGS                                                                                                        \
+    grid_a, dim3(kBlock), 0, ix->stream, ix->d_index, ix->stride_words, b->rows.as<uint64_t>(), b->d_pos_off.as<uint64_t>(),            \
+        b->num_unique.as<uint32_t>(), ix->h, (const uint64_t *)(din + o_pair_off), (const PresencePair *)(din + o_pairs),              \
+        (const uint32_t *)(din + o_perm), b->pres_bits.as<uint16_t>(), n_chunks
+#define COMMA ,
+#define BIGSI_PRESENCE(H)                                                                          \
+    if (k5_waves == 4) hipLaunchKernelGGL((k_presence_bits<H COMMA 4>), BIGSI_PRESENCE_ARGS);        \
+    else hipLaunchKernelGGL((k_presence_bits<H COMMA 2>), BIGSI_PRESENCE_ARGS)
     switch (ix->h) {
     case 1: BIGSI_PRESENCE(1); break;
     case 2: BIGSI_PRESENCE(2); break;
@@ -1443,12 +1448,16 @@ extern "C" int bigsi_hip_batch_presence_hits(bigsi_hip_batch *b, const uint64_t 
     default: BIGSI_PRESENCE(0); break;
     }
 #undef BIGSI_PRESENCE
+#undef BIGSI_PRESENCE_ARGS
+#undef COMMA
     HIP_TRY(hipGetLastError());
-    for (uint64_t t0 = 0; t0 < n_hits; t0 += 65535) {          // grid.y limit
-        const uint64_t cnt = std::min<uint64_t>(65535, n_hits - t0);
-        hipLaunchKernelGGL(k_presence_expand, dim3((unsigned)ceil_div(std::max<uint32_t>(max_n, 1), kBlock * 16), (unsigned)cnt), dim3(kBlock), 0, ix->stream,
-                           b->pres_bits.as<uint16_t>(), n_chunks, t0, (const uint32_t *)(din + o_seq), (const uint64_t *)(din + o_str),
-                           b->d_pos_off.as<uint64_t>(), b->num_kmers.as<uint32_t>(), b->pos_unique.as<uint32_t>(), b->pres_out.as<uint8_t>());
+    {
+        const uint32_t pieces = (uint32_t)ceil_div(std::max<uint32_t>(max_n, 1), 16);
+        const uint64_t blocks = ceil_div(n_hits * pieces, kBlock);
+        if (blocks > 0x7FFFFFFFull) return fail(BIGSI_ERR_INVALID, "presence request too large for one launch");
+        hipLaunchKernelGGL(k_presence_expand, dim3((unsigned)blocks), dim3(kBlock), 0, ix->stream, b->pres_bits.as<uint16_t>(), n_chunks, n_hits, pieces,
+                           (const uint32_t *)(din + o_seq), (const uint64_t *)(din + o_str), b->d_pos_off.as<uint64_t>(), b->num_kmers.as<uint32_t>(),
+                           b->pos_unique.as<uint32_t>(), b->pres_out.as<uint8_t>());
     }
     HIP_TRY(hipGetLastError());
     TRY(ev_end(ix, &ep, ix->ev_pr));

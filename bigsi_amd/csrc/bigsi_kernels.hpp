@@ -1032,8 +1032,8 @@ struct PresencePair {
 // column-order view of a word in row bit order: reverse the bits inside every byte
 __device__ __forceinline__ uint64_t by_column(uint64_t x) { return __builtin_bswap64(__builtin_bitreverse64(x)); }
 
-template <int H>
-__global__ __launch_bounds__(kBlock, 4) void k_presence_bits(      // <= 128 VGPRs: 16 AND-ed word pairs + 12 loads in flight
+template <int H, int WAVES = 2>      // WAVES = 2: the compiler keeps all 16 x h loads of a thread in flight (~200 VGPRs), measured faster than 4
+__global__ __launch_bounds__(kBlock, WAVES) void k_presence_bits(
     const uint64_t *__restrict__ index, uint64_t stride_words, const uint64_t *__restrict__ rows, const uint64_t *__restrict__ pos_off,
     const uint32_t *__restrict__ num_unique, uint32_t h_rt, const uint64_t *__restrict__ pair_off, const PresencePair *__restrict__ pairs,
     const uint32_t *__restrict__ perm, uint16_t *__restrict__ bits /* [hit][k-mer chunk] */, uint32_t bits_stride)
@@ -1100,25 +1100,29 @@ __global__ __launch_bounds__(kBlock, 4) void k_presence_bits(      // <= 128 VGP
 }
 
 // strings: 16 characters per thread, one 16-byte store (every string starts at a multiple of 16 bytes);
-// character i of hit t = '0' + bit (unique k-mer of position i) of the hit's presence bits
+// character i of hit t = '0' + bit (unique k-mer of position i) of the hit's presence bits.  Thread -> (hit, 16-character
+// piece), `pieces` pieces per hit, flattened over the grid so that workgroups are full whatever the query length.
 __global__ __launch_bounds__(kBlock) void k_presence_expand(
-    const uint16_t *__restrict__ bits, uint32_t bits_stride, uint64_t hit0, const uint32_t *__restrict__ hit_seq, const uint64_t *__restrict__ str_off,
-    const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ num_kmers, const uint32_t *__restrict__ pos_unique,
-    uint8_t *__restrict__ out)
+    const uint16_t *__restrict__ bits, uint32_t bits_stride, uint64_t n_hits, uint32_t pieces, const uint32_t *__restrict__ hit_seq,
+    const uint64_t *__restrict__ str_off, const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ num_kmers,
+    const uint32_t *__restrict__ pos_unique, uint8_t *__restrict__ out)
 {
-    const uint64_t hit = hit0 + blockIdx.y;
+    const uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint64_t hit = idx / pieces;
+    if (hit >= n_hits) return;
+    const uint32_t i0 = (uint32_t)(idx - hit * pieces) * 16u;
     const uint32_t q = hit_seq[hit];
     const uint32_t n = num_kmers[q];
-    const uint32_t i0 = (blockIdx.x * kBlock + threadIdx.x) * 16u;
     if (i0 >= n) return;
     const uint32_t *pu = pos_unique + pos_off[q];
+    const uint16_t *hb = bits + hit * bits_stride;
     uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int t = 0; t < 16; t++) {
         uint32_t ch = 0;
         if (i0 + t < n) {
             const uint32_t j = pu[i0 + t];
-            ch = '0' + ((bits[hit * bits_stride + (j >> 4)] >> (j & 15u)) & 1u);
+            ch = '0' + ((hb[j >> 4] >> (j & 15u)) & 1u);
         }
         w[t >> 2] |= ch << (8 * (t & 3));
     }
@@ -1259,28 +1263,24 @@ __global__ __launch_bounds__(kBlock) void k_transpose_tiles(
     const uint64_t r0 = tile_r * kTransposeTile, byte0 = tile_r * (kTransposeTile / 8);
     const uint64_t w0 = tile_c * 8;
     const uint32_t words_here = (uint32_t)(n_words - w0 < 8 ? n_words - w0 : 8), cols_here = words_here * 64;
-    // phase 1: 64 bytes of each column's filter -> tile[col][0..64) (columns beyond the last word: zeros)
+    // phase 1: 64 bytes of each column's filter -> tile[col][0..64) (columns beyond the last word: zeros).  A 16-byte load
+    // that starts inside the filter's pitch is always in bounds (pitch and offsets are multiples of 16); bytes past
+    // ceil(m / 8), like bits past m inside the last byte, belong to rows >= m, which phase 3 never stores.
+    u64x2 ld[kTransposeTile * 4 / kBlock];
 #pragma unroll
     for (int it = 0; it < kTransposeTile * 4 / kBlock; it++) {
         const uint32_t item = it * kBlock + threadIdx.x, col = item >> 2, part = item & 3u;
-        uint64_t lo = 0, hi = 0;
-        if (col < cols_here) {
-            const uint64_t off = byte0 + part * 16;
-            const uint8_t *src = blooms + (w0 * 64 + col) * bstride + off;
-            if (off + 16 <= nb) {
-                const u64x2 v = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(src));
-                lo = v.x;
-                hi = v.y;
-            } else {
-                for (uint32_t t = 0; t < 16 && off + t < nb; t++) {
-                    if (t < 8) lo |= (uint64_t)src[t] << (8 * t);
-                    else hi |= (uint64_t)src[t] << (8 * (t - 8));
-                }
-            }
-        }
+        const uint64_t off = byte0 + part * 16;
+        const bool ok = col < cols_here && off + 16 <= bstride && off < nb;
+        const u64x2 *src = reinterpret_cast<const u64x2 *>(blooms + (w0 * 64 + (ok ? col : 0)) * bstride + (ok ? off : 0));
+        ld[it] = ok ? __builtin_nontemporal_load(src) : u64x2{0ull, 0ull};
+    }
+#pragma unroll
+    for (int it = 0; it < kTransposeTile * 4 / kBlock; it++) {
+        const uint32_t item = it * kBlock + threadIdx.x, col = item >> 2, part = item & 3u;
         uint64_t *d = reinterpret_cast<uint64_t *>(tile + col * kTransposePitch + part * 16);
-        d[0] = lo;
-        d[1] = hi;
+        d[0] = ld[it].x;
+        d[1] = ld[it].y;
     }
     __syncthreads();
     // phase 2: the 36 unordered pairs {(cw, rc), (rc, cw)} of the 8 x 8 blocks, nine per wavefront
