@@ -296,9 +296,11 @@ static int transpose_device(bigsi_hip_index *ix, uint64_t col0, uint64_t n, cons
     };
     const uint64_t c_lo = std::min(end, round_up(col0, 128)), n_words = (end - c_lo) / 64, c_hi = c_lo + n_words * 64;
     static const int tiled = env_int("BIGSI_HIP_TRANSPOSE_TILED", 1);
-    if (!tiled || n_words == 0 || bstride % 16 || ((uintptr_t)d_blooms & 15u) || ceil_div(n_words, 8) > 65535) return slow(col0, n);
+    const uint64_t sup_blocks = ceil_div(ceil_div(ix->m, kTransposeTile), kTransposeSuper) * ceil_div(ceil_div(n_words, 8), kTransposeSuper) *
+                                (uint64_t)(kTransposeSuper * kTransposeSuper);
+    if (!tiled || n_words == 0 || bstride % 16 || ((uintptr_t)d_blooms & 15u) || sup_blocks > 0x7FFFFFFFull) return slow(col0, n);
     TRY(slow(col0, c_lo - col0));
-    hipLaunchKernelGGL(k_transpose_tiles, dim3((unsigned)ceil_div(ix->m, kTransposeTile), (unsigned)ceil_div(n_words, 8)), dim3(kBlock), 0, ix->stream,
+    hipLaunchKernelGGL(k_transpose_tiles, dim3((unsigned)sup_blocks), dim3(kBlock), 0, ix->stream,
                        ix->d_index, ix->stride_words, ix->m, c_lo / 64, n_words, d_blooms + (c_lo - col0) * bstride, bstride, nb);
     HIP_TRY(hipGetLastError());
     return slow(c_hi, end - c_hi);

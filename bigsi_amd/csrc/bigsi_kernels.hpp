@@ -1116,14 +1116,16 @@ __global__ __launch_bounds__(kBlock) void k_presence_expand(
     if (i0 >= n) return;
     const uint32_t *pu = pos_unique + pos_off[q];
     const uint16_t *hb = bits + hit * bits_stride;
+    // two rounds of 16 independent loads (positions -> unique k-mer, then that k-mer's chunk of the hit's bits), then ALU only
+    uint32_t j[16], v[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) j[t] = pu[i0 + t < n ? i0 + t : i0];
+#pragma unroll
+    for (int t = 0; t < 16; t++) v[t] = hb[j[t] >> 4];
     uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int t = 0; t < 16; t++) {
-        uint32_t ch = 0;
-        if (i0 + t < n) {
-            const uint32_t j = pu[i0 + t];
-            ch = '0' + ((hb[j >> 4] >> (j & 15u)) & 1u);
-        }
+        const uint32_t ch = i0 + t < n ? '0' + ((v[t] >> (j[t] & 15u)) & 1u) : 0u;
         w[t >> 2] |= ch << (8 * (t & 3));
     }
     *reinterpret_cast<uint4 *>(out + str_off[hit] + i0) = uint4{w[0], w[1], w[2], w[3]};
@@ -1228,7 +1230,7 @@ __global__ __launch_bounds__(kBlock) void k_insert_columns(
 // Bit order: both the filters and the rows keep the reference's byte format (bit 7 - (i & 7) of byte i >> 3), so in a
 // little-endian uint64 element i sits at bit_of_col(i); by_column() turns that into plain order for the butterfly, and lane
 // l is given column bit_of_col(l) of the word, which puts every result bit where the row format wants it.
-constexpr int kTransposeTile = 512, kTransposePitch = 72;
+constexpr int kTransposeTile = 512, kTransposePitch = 72, kTransposeSuper = 32;
 
 __device__ __forceinline__ uint64_t transpose64_lanes(uint64_t a, uint32_t lane)
 {
@@ -1259,7 +1261,13 @@ __global__ __launch_bounds__(kBlock) void k_transpose_tiles(
     // written where the other was read (37 KB of LDS instead of 74: four workgroups per CU keep loads, butterflies and
     // stores of different tiles overlapping).
     __shared__ __attribute__((aligned(16))) uint8_t tile[kTransposeTile * kTransposePitch];
-    const uint64_t tile_r = blockIdx.x, tile_c = blockIdx.y;
+    // workgroup -> tile in SUPERTILES of 32 x 32 tiles: the ~1000 workgroups resident at any time then read 2 KB runs of
+    // each filter and write 2 KB runs of each row (DRAM-page sized), instead of 64-byte pieces strided by a whole row or filter
+    const uint64_t tiles_c = (n_words + 7) / 8, sup_c = (tiles_c + kTransposeSuper - 1) / kTransposeSuper;
+    const uint64_t sup = blockIdx.x / (kTransposeSuper * kTransposeSuper), within = blockIdx.x % (kTransposeSuper * kTransposeSuper);
+    const uint64_t tile_r = (sup / sup_c) * kTransposeSuper + within % kTransposeSuper;
+    const uint64_t tile_c = (sup % sup_c) * kTransposeSuper + within / kTransposeSuper;
+    if (tile_r * kTransposeTile >= m || tile_c >= tiles_c) return;
     const uint64_t r0 = tile_r * kTransposeTile, byte0 = tile_r * (kTransposeTile / 8);
     const uint64_t w0 = tile_c * 8;
     const uint32_t words_here = (uint32_t)(n_words - w0 < 8 ? n_words - w0 : 8), cols_here = words_here * 64;
