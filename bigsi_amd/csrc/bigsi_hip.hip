@@ -1371,7 +1371,8 @@ extern "C" int bigsi_hip_batch_presence_hits(bigsi_hip_batch *b, const uint64_t 
     if (n_hits > 0xFFFFFFF0ull) return fail(BIGSI_ERR_INVALID, "too many hits for one call");
     TRY(host_counts(b));
     // host side: string offsets, per-sequence colour order, word pairs
-    std::vector<uint32_t> hit_seq(n_hits), perm(n_hits), order;
+    std::vector<uint32_t> hit_seq(n_hits), perm(n_hits), order;      // hit_seq: k-mers of the hit's sequence (its string length)
+    std::vector<uint64_t> hit_pos0(n_hits);
     std::vector<uint64_t> pair_off(nq + 1, 0);
     std::vector<PresencePair> pairs;
     uint64_t str = 0, alg = 0;
@@ -1381,7 +1382,8 @@ extern "C" int bigsi_hip_batch_presence_hits(bigsi_hip_batch *b, const uint64_t 
         const uint64_t lo = hit_offsets[q] - h0, hi = hit_offsets[q + 1] - h0;
         for (uint64_t t = lo; t < hi; t++) {
             if (colours[h0 + t] >= ix->n_cols) return fail(BIGSI_ERR_RANGE, "colour %u >= num_cols", colours[h0 + t]);
-            hit_seq[t] = q;
+            hit_seq[t] = b->h_num_kmers[q];
+            hit_pos0[t] = b->pos_off[q];
             string_offsets[t] = str;
             str += round_up(b->h_num_kmers[q], 16);       // every string starts on a 16-byte boundary (16-character stores)
         }
@@ -1415,13 +1417,14 @@ extern "C" int bigsi_hip_batch_presence_hits(bigsi_hip_batch *b, const uint64_t 
     if (b->run_h != ix->h) return fail(BIGSI_ERR_STATE, "num_hashes changed since the batch was run");
     // device buffers: [pair_off | str_off | hit_seq | perm | pairs] in one upload
     const size_t o_pair_off = 0, o_str = round_up(o_pair_off + (nq + 1) * 8ull, 256), o_seq = round_up(o_str + (n_hits + 1) * 8, 256);
-    const size_t o_perm = round_up(o_seq + n_hits * 4, 256), o_pairs = round_up(o_perm + n_hits * 4, 256);
+    const size_t o_perm = round_up(o_seq + n_hits * 4, 256), o_pos0 = round_up(o_perm + n_hits * 4, 256), o_pairs = round_up(o_pos0 + n_hits * 8, 256);
     const size_t in_bytes = o_pairs + pairs.size() * sizeof(PresencePair);
     std::vector<uint8_t> stage(in_bytes);
     memcpy(stage.data() + o_pair_off, pair_off.data(), (nq + 1) * 8ull);
     memcpy(stage.data() + o_str, string_offsets, (n_hits + 1) * 8);
     memcpy(stage.data() + o_seq, hit_seq.data(), n_hits * 4);
     memcpy(stage.data() + o_perm, perm.data(), n_hits * 4);
+    memcpy(stage.data() + o_pos0, hit_pos0.data(), n_hits * 8);
     memcpy(stage.data() + o_pairs, pairs.data(), pairs.size() * sizeof(PresencePair));
     const uint32_t n_chunks = (uint32_t)ceil_div(std::max<uint32_t>(max_u, 1), 16);
     TRY(b->pres_in.reserve(in_bytes));
@@ -1458,7 +1461,7 @@ extern "C" int bigsi_hip_batch_presence_hits(bigsi_hip_batch *b, const uint64_t 
         const uint64_t blocks = ceil_div(n_hits * pieces, kBlock);
         if (blocks > 0x7FFFFFFFull) return fail(BIGSI_ERR_INVALID, "presence request too large for one launch");
         hipLaunchKernelGGL(k_presence_expand, dim3((unsigned)blocks), dim3(kBlock), 0, ix->stream, b->pres_bits.as<uint16_t>(), n_chunks, n_hits, pieces,
-                           (const uint32_t *)(din + o_seq), (const uint64_t *)(din + o_str), b->d_pos_off.as<uint64_t>(), b->num_kmers.as<uint32_t>(),
+                           (const uint32_t *)(din + o_seq), (const uint64_t *)(din + o_pos0), (const uint64_t *)(din + o_str),
                            b->pos_unique.as<uint32_t>(), b->pres_out.as<uint8_t>());
     }
     HIP_TRY(hipGetLastError());

@@ -1030,7 +1030,11 @@ struct PresencePair {
 };
 
 // column-order view of a word in row bit order: reverse the bits inside every byte
-__device__ __forceinline__ uint64_t by_column(uint64_t x) { return __builtin_bswap64(__builtin_bitreverse64(x)); }
+__device__ __forceinline__ uint64_t by_column(uint64_t x)
+{
+    const uint32_t lo = __builtin_bswap32(__builtin_bitreverse32((uint32_t)x)), hi = __builtin_bswap32(__builtin_bitreverse32((uint32_t)(x >> 32)));
+    return ((uint64_t)hi << 32) | lo;
+}
 
 template <int H, int WAVES = 2>      // WAVES = 2: the compiler keeps all 16 x h loads of a thread in flight (~200 VGPRs), measured faster than 4
 __global__ __launch_bounds__(kBlock, WAVES) void k_presence_bits(
@@ -1103,18 +1107,17 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_presence_bits(
 // character i of hit t = '0' + bit (unique k-mer of position i) of the hit's presence bits.  Thread -> (hit, 16-character
 // piece), `pieces` pieces per hit, flattened over the grid so that workgroups are full whatever the query length.
 __global__ __launch_bounds__(kBlock) void k_presence_expand(
-    const uint16_t *__restrict__ bits, uint32_t bits_stride, uint64_t n_hits, uint32_t pieces, const uint32_t *__restrict__ hit_seq,
-    const uint64_t *__restrict__ str_off, const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ num_kmers,
-    const uint32_t *__restrict__ pos_unique, uint8_t *__restrict__ out)
+    const uint16_t *__restrict__ bits, uint32_t bits_stride, uint64_t n_hits, uint32_t pieces, const uint32_t *__restrict__ hit_n,
+    const uint64_t *__restrict__ hit_pos0 /* per hit: k-mers of its sequence and where its position -> unique map starts (host-made:
+    two dependent loads fewer per thread) */, const uint64_t *__restrict__ str_off, const uint32_t *__restrict__ pos_unique, uint8_t *__restrict__ out)
 {
     const uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     const uint64_t hit = idx / pieces;
     if (hit >= n_hits) return;
     const uint32_t i0 = (uint32_t)(idx - hit * pieces) * 16u;
-    const uint32_t q = hit_seq[hit];
-    const uint32_t n = num_kmers[q];
+    const uint32_t n = hit_n[hit];
     if (i0 >= n) return;
-    const uint32_t *pu = pos_unique + pos_off[q];
+    const uint32_t *pu = pos_unique + hit_pos0[hit];
     const uint16_t *hb = bits + hit * bits_stride;
     // two rounds of 16 independent loads (positions -> unique k-mer, then that k-mer's chunk of the hit's bits), then ALU only
     uint32_t j[16], v[16];
@@ -1232,22 +1235,39 @@ __global__ __launch_bounds__(kBlock) void k_insert_columns(
 // l is given column bit_of_col(l) of the word, which puts every result bit where the row format wants it.
 constexpr int kTransposeTile = 512, kTransposePitch = 72, kTransposeSuper = 32;
 
-__device__ __forceinline__ uint64_t transpose64_lanes(uint64_t a, uint32_t lane)
+// 64 x 64 bit transpose across the lanes of a wavefront, on 32-bit halves (64-bit shifts run at a quarter of the rate):
+// after it, bit k of lane i = bit i of (the original value of) lane k.  Step j (32, 16, .. 1) swaps, between lanes l and
+// l ^ j, the off-diagonal j x j blocks.  Each lane ROTATES what its partner needs into place before the exchange (towards
+// the high bits if the lane has bit j set, towards the low bits otherwise: one v_alignbit with a per-lane amount) and
+// merges what it receives under a per-lane mask (one v_bfi): three VALU operations and one ds_bpermute per half and step.
+__device__ __forceinline__ uint32_t rotl32v(uint32_t x, uint32_t r) { return __builtin_amdgcn_alignbit(x, x, (32u - r) & 31u); }
+
+__device__ __forceinline__ uint64_t transpose64_lanes(uint64_t a64, uint32_t lane)
 {
-    // after the six steps: bit k of lane i = bit i of (the original value of) lane k
-#define BIGSI_TR_STEP(J, M)                                                                   \
-    {                                                                                         \
-        const uint64_t p = __shfl_xor(a, J, 64);                                              \
-        a = (lane & J) ? (((p >> J) & M) | (a & ~M)) : ((a & M) | ((p & M) << J));            \
+    uint32_t lo = (uint32_t)a64, hi = (uint32_t)(a64 >> 32);
+    {   // j = 32: whole halves change lanes
+        const bool s = (lane & 32u) != 0;
+        const uint32_t recv = (uint32_t)__shfl_xor((int)(s ? lo : hi), 32, 64);
+        lo = s ? recv : lo;
+        hi = s ? hi : recv;
     }
-    BIGSI_TR_STEP(32, 0x00000000FFFFFFFFull)
-    BIGSI_TR_STEP(16, 0x0000FFFF0000FFFFull)
-    BIGSI_TR_STEP(8, 0x00FF00FF00FF00FFull)
-    BIGSI_TR_STEP(4, 0x0F0F0F0F0F0F0F0Full)
-    BIGSI_TR_STEP(2, 0x3333333333333333ull)
-    BIGSI_TR_STEP(1, 0x5555555555555555ull)
+#define BIGSI_TR_STEP(J, M)                                                                                  \
+    {                                                                                                        \
+        const bool s = (lane & J) != 0;                                                                      \
+        const uint32_t rot = s ? (uint32_t)J : 32u - (uint32_t)J;   /* s: partner wants my bits J higher; else J lower */ \
+        const uint32_t keep = s ? ~(uint32_t)M : (uint32_t)M;       /* the bits of my own value that stay */  \
+        const uint32_t rl = (uint32_t)__shfl_xor((int)rotl32v(lo, rot), J, 64);                              \
+        const uint32_t rh = (uint32_t)__shfl_xor((int)rotl32v(hi, rot), J, 64);                              \
+        lo = (lo & keep) | (rl & ~keep);                                                                     \
+        hi = (hi & keep) | (rh & ~keep);                                                                     \
+    }
+    BIGSI_TR_STEP(16, 0x0000FFFFu)
+    BIGSI_TR_STEP(8, 0x00FF00FFu)
+    BIGSI_TR_STEP(4, 0x0F0F0F0Fu)
+    BIGSI_TR_STEP(2, 0x33333333u)
+    BIGSI_TR_STEP(1, 0x55555555u)
 #undef BIGSI_TR_STEP
-    return a;
+    return ((uint64_t)hi << 32) | lo;
 }
 
 __global__ __launch_bounds__(kBlock) void k_transpose_tiles(
