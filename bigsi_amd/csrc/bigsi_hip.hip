@@ -1457,7 +1457,7 @@ extern "C" int bigsi_hip_batch_presence_hits(bigsi_hip_batch *b, const uint64_t 
 #undef COMMA
     HIP_TRY(hipGetLastError());
     {
-        const uint32_t pieces = (uint32_t)ceil_div(std::max<uint32_t>(max_n, 1), 16);
+        const uint32_t pieces = (uint32_t)pow2_at_least(ceil_div(std::max<uint32_t>(max_n, 1), 16));      // power of two: shifts, not divisions
         const uint64_t blocks = ceil_div(n_hits * pieces, kBlock);
         if (blocks > 0x7FFFFFFFull) return fail(BIGSI_ERR_INVALID, "presence request too large for one launch");
         hipLaunchKernelGGL(k_presence_expand, dim3((unsigned)blocks), dim3(kBlock), 0, ix->stream, b->pres_bits.as<uint16_t>(), n_chunks, n_hits, pieces,

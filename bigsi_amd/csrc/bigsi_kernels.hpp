@@ -1111,10 +1111,12 @@ __global__ __launch_bounds__(kBlock) void k_presence_expand(
     const uint64_t *__restrict__ hit_pos0 /* per hit: k-mers of its sequence and where its position -> unique map starts (host-made:
     two dependent loads fewer per thread) */, const uint64_t *__restrict__ str_off, const uint32_t *__restrict__ pos_unique, uint8_t *__restrict__ out)
 {
+    // `pieces` is a power of two (the host rounds up): no 64-bit division per thread
     const uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    const uint64_t hit = idx / pieces;
+    const uint32_t shift = 31u - (uint32_t)__builtin_clz(pieces);
+    const uint64_t hit = idx >> shift;
     if (hit >= n_hits) return;
-    const uint32_t i0 = (uint32_t)(idx - hit * pieces) * 16u;
+    const uint32_t i0 = (uint32_t)(idx & (pieces - 1u)) * 16u;
     const uint32_t n = hit_n[hit];
     if (i0 >= n) return;
     const uint32_t *pu = pos_unique + hit_pos0[hit];
