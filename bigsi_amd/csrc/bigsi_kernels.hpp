@@ -1105,26 +1105,45 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_presence_bits(
 
 // strings: 16 characters per thread, one 16-byte store (every string starts at a multiple of 16 bytes);
 // character i of hit t = '0' + bit (unique k-mer of position i) of the hit's presence bits.  Thread -> (hit, 16-character
-// piece), `pieces` pieces per hit, flattened over the grid so that workgroups are full whatever the query length.
+// piece), `pieces` (a power of two) pieces per hit, flattened over the grid.  A thread needs the position -> unique k-mer map
+// of its 16 consecutive positions; read directly that is a 64-byte stride between lanes (one cache line per lane and load:
+// measured 0.5 TB/s).  Instead the G = min(pieces, 64) lanes that share a hit fetch its G * 16 entries with 16 coalesced
+// loads and pass them through LDS (pitch 20 dwords per lane: conflict-free 16-byte reads).
 __global__ __launch_bounds__(kBlock) void k_presence_expand(
     const uint16_t *__restrict__ bits, uint32_t bits_stride, uint64_t n_hits, uint32_t pieces, const uint32_t *__restrict__ hit_n,
     const uint64_t *__restrict__ hit_pos0 /* per hit: k-mers of its sequence and where its position -> unique map starts (host-made:
     two dependent loads fewer per thread) */, const uint64_t *__restrict__ str_off, const uint32_t *__restrict__ pos_unique, uint8_t *__restrict__ out)
 {
-    // `pieces` is a power of two (the host rounds up): no 64-bit division per thread
+    __shared__ __attribute__((aligned(16))) uint32_t stage[(kBlock / 64) * 64 * 20];
     const uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     const uint32_t shift = 31u - (uint32_t)__builtin_clz(pieces);
     const uint64_t hit = idx >> shift;
-    if (hit >= n_hits) return;
-    const uint32_t i0 = (uint32_t)(idx & (pieces - 1u)) * 16u;
-    const uint32_t n = hit_n[hit];
-    if (i0 >= n) return;
-    const uint32_t *pu = pos_unique + hit_pos0[hit];
-    const uint16_t *hb = bits + hit * bits_stride;
-    // two rounds of 16 independent loads (positions -> unique k-mer, then that k-mer's chunk of the hit's bits), then ALU only
-    uint32_t j[16], v[16];
+    const bool has_hit = hit < n_hits;
+    const uint32_t piece = (uint32_t)(idx & (pieces - 1u));
+    const uint32_t n = has_hit ? hit_n[hit] : 0u;
+    const uint32_t lane = threadIdx.x & 63u, G = pieces < 64u ? pieces : 64u;
+    const uint32_t sub = lane & (G - 1u), lane0 = lane - sub;          // my place among the G lanes that share my hit
+    const uint32_t base_pos = (piece - sub) * 16u;                      // first position the G lanes cover together
+    uint32_t *mine = stage + (threadIdx.x >> 6) * (64 * 20);
+    const uint32_t *pu = pos_unique + (has_hit ? hit_pos0[hit] : 0);
 #pragma unroll
-    for (int t = 0; t < 16; t++) j[t] = pu[i0 + t < n ? i0 + t : i0];
+    for (int t = 0; t < 16; t++) {
+        const uint32_t e = (uint32_t)t * G + sub;                       // entry e of the group's G * 16
+        const uint32_t pos = base_pos + e;
+        const uint32_t v = pos < n ? pu[pos] : 0u;
+        mine[(lane0 + (e >> 4)) * 20 + (e & 15u)] = v;
+    }
+    __builtin_amdgcn_wave_barrier();                                    // same wavefront: LDS operations complete in order
+    uint32_t j[16];
+#pragma unroll
+    for (int k4 = 0; k4 < 4; k4++) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(mine + lane * 20 + k4 * 4);
+        j[k4 * 4] = v.x; j[k4 * 4 + 1] = v.y; j[k4 * 4 + 2] = v.z; j[k4 * 4 + 3] = v.w;
+    }
+    const uint32_t i0 = piece * 16u;
+    if (!has_hit || i0 >= n) return;
+    const uint16_t *hb = bits + hit * bits_stride;
+    uint32_t v[16];
 #pragma unroll
     for (int t = 0; t < 16; t++) v[t] = hb[j[t] >> 4];
     uint32_t w[4] = {0, 0, 0, 0};
