@@ -1,0 +1,135 @@
+"""Condense gpurun_out/prof (scripts/profile_all.sh) into profiles/r02_*: per workload one JSON (the command's own line(s),
+the rocprofv3 average duration of the dominant kernel from the SAME run, algorithmic bytes, fraction of the 8 TB/s HBM peak)
+plus the kernel-stats CSV it came from; and profiles/pmc_traffic.json from the PMC passes.
+
+    python scripts/make_profiles.py                      # after a profile_all.sh run came back
+    python scripts/make_profiles.py --pmc-reduce IN OUT  # on the GPU box: counter_collection.csv -> per-kernel averages"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "prof")
+DST = os.path.join(ROOT, "profiles")
+PEAK = 8000.0
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "").strip()
+
+
+def pmc_reduce(src, dst):
+    """rocprofv3 counter_collection.csv (one row per dispatch and counter) -> {kernel: {counter: {dispatches, avg}}}."""
+    acc = {}
+    with open(src) as f:
+        for r in csv.DictReader(f):
+            k = short(r["Kernel_Name"])
+            a = acc.setdefault(k, {}).setdefault(r["Counter_Name"], [0, 0.0])
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+    out = {k: {c: {"dispatches": n, "avg": tot / n} for c, (n, tot) in v.items()} for k, v in acc.items()}
+    with open(dst, "w") as f:
+        json.dump(out, f, indent=1)
+
+
+def kernel_stats(tag):
+    path = os.path.join(SRC, tag + "_kernel_stats.csv")
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        return {short(r["Name"]): {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"])}
+                for r in csv.DictReader(f)}
+
+
+def json_lines(tag):
+    path = os.path.join(SRC, tag + ".stdout")
+    if not os.path.exists(path):
+        return []
+    return [json.loads(l) for l in open(path) if l.startswith("{")]
+
+
+def main():
+    os.makedirs(DST, exist_ok=True)
+    summary = {}
+    for path in sorted(glob.glob(os.path.join(SRC, "r02_*_kernel_stats.csv"))):
+        tag = os.path.basename(path)[: -len("_kernel_stats.csv")]
+        ks, lines = kernel_stats(tag), json_lines(tag)
+        rec = {"command": "scripts/profile_all.sh: " + tag, "kernels": {k: v for k, v in ks.items() if k.startswith("bigsi::")}}
+        if lines and "roofline" in lines[-1]:              # a bench.py line
+            d = lines[-1]
+            r = d["roofline"]
+            names = [k for k in ks if ("k_and_exact" in k if r["kernel"] == "k_and_exact" else "k_and_count" in k)]
+            dom = max(names, key=lambda k: ks[k]["calls"] * ks[k]["avg_ns"]) if names else None
+            rec["bench_same_run"] = d
+            if dom:
+                ns = ks[dom]["avg_ns"]
+                rec["dominant_kernel"] = {"name": dom, "rocprof_avg_ns": ns, "calls": ks[dom]["calls"], "hip_event_avg_ns": r["kernel_ms"] * 1e6,
+                                          "alg_bytes_per_launch": r["alg_bytes_per_launch"], "GBps_rocprof": r["alg_bytes_per_launch"] / ns,
+                                          "frac_of_8TBps": r["alg_bytes_per_launch"] / ns / PEAK}
+                summary[tag] = {"workload": d["config"]["workload"], "value_lookups_per_s": d["value"], "ms_per_step": d["ms_per_step"],
+                                "kernel": dom, "kernel_ns": ns, "GBps": r["alg_bytes_per_launch"] / ns, "frac": r["alg_bytes_per_launch"] / ns / PEAK,
+                                "k1_ms": r["kmerize_ms"], "k4_ms": r["compact_ms"]}
+        else:
+            rec["measure_lines"] = lines
+            summary[tag] = {"lines": [{k: v for k, v in l.items() if k in ("workload", "threshold", "n_seqs", "hits", "m", "cols", "GBps", "frac",
+                                                                          "k2_ms", "kernels_ms", "step_ms", "lookups_per_s")} for l in lines]}
+        with open(os.path.join(DST, tag + ".json"), "w") as f:
+            json.dump(rec, f, indent=1)
+        shutil.copy(path, os.path.join(DST, tag + "_kernel_stats.csv"))
+    for name in ("r02_bench_default", "r02_bench_t04"):
+        lines = json_lines(name)
+        if lines:
+            with open(os.path.join(DST, name + ".json"), "w") as f:
+                json.dump(lines[-1], f)
+    # PMC: traffic per launch of the row-AND kernel = FETCH_SIZE x 2 (gfx950: 128-byte requests tallied at 64, MI355X_MICROARCH.md) + WRITE_SIZE,
+    # both reported in KiB; calibration: WRITE_SIZE of k_fill_synth must equal the index bytes
+    traffic, pmc = {}, {}
+    for thr, kern in (("1.0", "k_and_exact"), ("0.4", "k_and_count")):
+        try:
+            fe = json.load(open(os.path.join(SRC, "pmc_FETCH_SIZE_%s.json" % thr)))
+            wr = json.load(open(os.path.join(SRC, "pmc_WRITE_SIZE_%s.json" % thr)))
+        except OSError:
+            continue
+        pmc["threshold=" + thr] = {k: {"FETCH_SIZE_avg_kib": fe.get(k, {}).get("FETCH_SIZE", {}).get("avg"), "WRITE_SIZE_avg_kib": wr.get(k, {}).get("WRITE_SIZE", {}).get("avg"),
+                                       "dispatches": fe.get(k, {}).get("FETCH_SIZE", {}).get("dispatches")} for k in sorted(set(fe) | set(wr)) if k.startswith("bigsi::")}
+        name = [k for k in fe if kern in k]
+        if not name:
+            continue
+        k = name[0]
+        fetch = fe[k]["FETCH_SIZE"]["avg"] * 1024 * 2
+        write = wr[k]["WRITE_SIZE"]["avg"] * 1024
+        key = "rows=10000000 cols=100000 hashes=4 batch=8192 qlen=1000 k=31 threshold=%s draws=2" % thr
+        traffic[key] = {"kernel": k, "traffic_bytes_per_launch": fetch + write, "fetch_bytes_corrected": fetch, "write_bytes": write,
+                        "source": "profiles/r02_c3_pmc.json (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes; FETCH_SIZE doubled per "
+                                  "MI355X_MICROARCH.md, calibrated on k_fill_synth's WRITE_SIZE = index bytes)"}
+    if pmc:
+        with open(os.path.join(DST, "r02_c3_pmc.json"), "w") as f:
+            json.dump({"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python bench.py --steps 2 --warmup 1 --cpu-seconds 0 "
+                                  "--no-verify [--threshold 0.4]  (one counter per pass; scripts/profile_all.sh)",
+                       "units": "KiB per dispatch, averaged over the dispatches of a kernel", "runs": pmc}, f, indent=1)
+        old = {}
+        try:
+            old = json.load(open(os.path.join(DST, "pmc_traffic.json")))
+        except OSError:
+            pass
+        old.update(traffic)
+        with open(os.path.join(DST, "pmc_traffic.json"), "w") as f:
+            json.dump(old, f, indent=1)
+    with open(os.path.join(DST, "r02_summary.json"), "w") as f:
+        json.dump(summary, f, indent=1)
+    for k, v in summary.items():
+        if "frac" in v:
+            print("%-28s %8.1f M lookups/s  step %9.4f ms  %-34s %10.0f ns  %6.0f GB/s  frac %.3f" % (k, v["value_lookups_per_s"] / 1e6, v["ms_per_step"], v["kernel"][:34], v["kernel_ns"], v["GBps"], v["frac"]))
+        else:
+            for l in v["lines"]:
+                print("%-28s %s" % (k, json.dumps(l)))
+
+
+if __name__ == "__main__":
+    if len(sys.argv) == 4 and sys.argv[1] == "--pmc-reduce":
+        pmc_reduce(sys.argv[2], sys.argv[3])
+    else:
+        main()
