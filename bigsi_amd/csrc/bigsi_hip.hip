@@ -778,8 +778,12 @@ static int run_kmerize(bigsi_hip_batch *b, double threshold, bool force_global =
     }
     // fused single-launch K1 (dedupe table + sequence in LDS) when every query fits the default 64 KiB dynamic-LDS window
     if (!force_global && !k1_global && b->max_pos <= kLdsMaxPos && lds <= 60 * 1024) {
+        // one thread per position for small batches (latency); once there are several queries per CU anyway, smaller
+        // workgroups that loop over the positions let more queries overlap their barrier-separated phases
+        static const int k1_block_env = env_int("BIGSI_HIP_K1_BLOCK", 0);
+        const uint32_t block_cap = k1_block_env > 0 ? (uint32_t)k1_block_env : (b->n_seqs >= 1024 ? 256u : 1024u);
         uint32_t block = 64;
-        while (block < b->max_pos && block < 1024) block <<= 1;
+        while (block < b->max_pos && block < block_cap) block <<= 1;
         if (want_sorted) {
             TRY(b->rows_sorted.reserve(std::max<uint64_t>(b->total_pos, 1) * ix->h * 8));
             if (sorted) *sorted = true;
