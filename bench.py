@@ -19,7 +19,8 @@ exchange included -- every rank looks every k-mer up in its shard, so the shard-
     c3 (default)  BASELINE configs[2]: 10M rows x 100k samples (125 GB), h=4, 8192 x 1 kbp queries, threshold 1.0
     c2            BASELINE configs[1]: 1M x 10k, h=3, 1000 x 61-mers, a different batch every step (32 staged batches cycle)
     c4            BASELINE configs[3]: 25M x 500k, h=3 (1.56 TB: needs 8 GPUs), 256 x 1 kbp queries per step
-    c5            BASELINE configs[4]: c4 at threshold 0.4 with score=True presence extraction for the hits
+    c5            BASELINE configs[4]: c4 at threshold 0.4 with score=True: every step also brings the hit lists to the host and
+                  extracts the presence strings of all hits (K5) -- 16 queries x 16 planted samples per shard and batch
     northstar     BASELINE north_star: 10M x 500k, h=3 (625 GB: needs >= 4 GPUs)
 `--shard-of P` runs, on fewer GPUs, the first N of the P column shards of the workload (e.g. `--workload c4 --shard-of 8
 --gpus 1` is what one GPU of the 8-GPU C4 run does; value is then the rate against that part of the index and says so).
@@ -245,6 +246,15 @@ def main():
     plant_len = w["qlen"] if exact else args.k - 1 + int(np.ceil(0.7 * n_kmers))
     for j, qi in enumerate(planted):
         st.insert_kmers(plant_col(j, rank, my_cols), [seqs[qi][:plant_len]], args.k)
+
+    # score=True workloads need hits to score: the first 16 queries of every staged batch are planted (70 % of their k-mers)
+    # into 16 samples of every shard -> 256 hits per shard and batch on top of the verification plants
+    def score_plants(g, cols_g):
+        return [(bi, qi, (7919 * (16 * qi + t) + 11 + 13 * g + 101 * bi) % cols_g) for bi in range(nb) for qi in range(min(16, w["batch"])) for t in range(16)]
+
+    if w["score"]:
+        for bi, qi, c in score_plants(rank, my_cols):
+            st.insert_kmers(c, [all_seqs[bi][qi][:plant_len]], args.k)
     if args.one_device and world > 1 and args.backend == "nccl":
         raise SystemExit("--one-device needs --backend gloo: RCCL refuses two ranks on one device")
     sh = ShardedSearch(st, shard_cols, device=dev, force_gather=args.force_dist, slots=max(2, nb))
@@ -260,9 +270,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    step_no = [0]
+
+    def own_hits(batch):
+        """this rank's share of the batch's (global) hit lists: offsets + local colours, for K5 on the owning GPU"""
+        off, colours, counts = sh.fetch(batch)
+        owned = (colours.astype(np.int64) // shard_cols) == rank
+        csum = np.concatenate([[0], np.cumsum(owned)])
+        off_own = csum[off.astype(np.int64)].astype(np.uint64)
+        return off_own, (colours[owned].astype(np.int64) - rank * shard_cols).astype(np.uint32)
+
+    def step():
+        """One pass of the path over the next staged batch.  score=True workloads (configs[4]) go on to what BIGSI.score needs
+        from the device: the hit lists come back to the host and the presence strings of every hit are extracted (K5) on the
+        rank that owns the hit's column -- that makes their step synchronous."""
+        batch = batches[step_no[0] % len(batches)]
+        step_no[0] += 1
+        sh.step(batches, thr)
+        if w["score"]:
+            off_own, col_own = own_hits(batch)
+            batch.presence_hits(off_own, col_own, batch.unique()[0])
+
     warm = _lib.Stats()
     for i in range(args.warmup):
-        sh.step(batches, thr)
+        step()
         if i == 0:            # the first step pays one-off costs (code object load, allocations): keep it out of the K1 / K4 figures
             sync_all()
             check(_lib.lib().bigsi_hip_stats(st.handle, _lib.C.byref(warm), 1))
@@ -275,7 +306,7 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        sh.step(batches, thr)
+        step()
     sync_all()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -309,15 +340,10 @@ def main():
         dist.all_reduce(t)
         per_rank_gbs = [float(x) for x in t.tolist()]
 
-    # score=True (configs[4]): presence strings of every hit of the batch (K5, one pass), each rank for the hits whose columns
-    # it owns -- outside the timed steps; reported per batch
+    # score=True (configs[4]): the K5 leg of a step once more, timed on its own (events + wall clock) and checked
     presence = None
     if w["score"]:
-        owned = (colours.astype(np.int64) // shard_cols) == rank
-        off_own = np.zeros(w["batch"] + 1, np.uint64)
-        off_own[1:] = np.cumsum([int(owned[int(off[i]):int(off[i + 1])].sum()) for i in range(w["batch"])])
-        col_own = (colours[owned].astype(np.int64) - rank * shard_cols).astype(np.uint32)
-        batch.presence_hits(off_own, col_own, nk)                 # warm: allocations
+        off_own, col_own = own_hits(batch)
         check(_lib.lib().bigsi_hip_set_profiling(st.handle, 1))
         check(_lib.lib().bigsi_hip_stats(st.handle, _lib.C.byref(_lib.Stats()), 1))
         t1 = time.perf_counter()
@@ -377,6 +403,9 @@ def main():
         orc = SynthOracle(SEED, 0, w["rows"], my_cols, w["hashes"], args.k, args.and_draws)
         for j, qi in enumerate(planted):
             orc.insert_kmers(plant_col(j, 0, my_cols), seqs[qi][:plant_len])
+        if w["score"]:
+            for bi, qi, c in score_plants(0, my_cols):
+                orc.insert_kmers(c, all_seqs[bi][qi][:plant_len])
         sample = sorted(set([planted[0], 1 % w["batch"], w["batch"] // 2, w["batch"] - 1]))
         for qi in sample:
             u, cnt = orc.counts(seqs[qi])
