@@ -684,6 +684,7 @@ struct CountLaunch {
     uint64_t out_stride;
     uint64_t *hit_bitmap;
     uint32_t sparse, slices;
+    bool deep;                  // software-pipelined row loads (small grids; h = 3 or 4 only)
 };
 
 template <int P, typename CountT>
@@ -691,19 +692,27 @@ static void launch_count_wide(bigsi_hip_batch *b, const CountLaunch &c, uint32_t
 {
     bigsi_hip_index *ix = b->ix;
     const unsigned grid = (unsigned)(ceil_div(q1 - q0, 8) * 8 * (uint64_t)c.tiles * c.slices);
-#define BIGSI_LAUNCH_COUNT(H)                                                                                               \
-    hipLaunchKernelGGL((k_and_count<P, H, CountT>), dim3(grid), dim3(c.block), 0, ix->stream, ix->d_index, ix->stride_words, \
-                       (uint32_t)b->wv, c.k2_rows, b->d_pos_off.as<uint64_t>(), b->num_unique.as<uint32_t>(), ix->h, q0, q1,  \
-                       c.tiles, (CountT *)c.out, c.out_stride, b->min_kmers.as<uint32_t>(), ix->n_cols, c.hit_bitmap, b->wv_pad, c.sparse, c.slices)
+#define BIGSI_COUNT_ARGS                                                                                                      \
+    dim3(grid), dim3(c.block), 0, ix->stream, ix->d_index, ix->stride_words, (uint32_t)b->wv, c.k2_rows, b->d_pos_off.as<uint64_t>(), \
+        b->num_unique.as<uint32_t>(), ix->h, q0, q1, c.tiles, (CountT *)c.out, c.out_stride, b->min_kmers.as<uint32_t>(), ix->n_cols,  \
+        c.hit_bitmap, b->wv_pad, c.sparse, c.slices
+#define COMMA ,
+#define BIGSI_LAUNCH_COUNT(H) hipLaunchKernelGGL((k_and_count<P, H, CountT>), BIGSI_COUNT_ARGS)
+#define BIGSI_LAUNCH_COUNT_DEEP(H)                                                                        \
+    if (c.deep) hipLaunchKernelGGL((k_and_count<P COMMA H COMMA CountT COMMA 2>), BIGSI_COUNT_ARGS);       \
+    else hipLaunchKernelGGL((k_and_count<P, H, CountT>), BIGSI_COUNT_ARGS)
     switch (ix->h) {
     case 1: BIGSI_LAUNCH_COUNT(1); break;
     case 2: BIGSI_LAUNCH_COUNT(2); break;
-    case 3: BIGSI_LAUNCH_COUNT(3); break;
-    case 4: BIGSI_LAUNCH_COUNT(4); break;
+    case 3: BIGSI_LAUNCH_COUNT_DEEP(3); break;
+    case 4: BIGSI_LAUNCH_COUNT_DEEP(4); break;
     case 5: BIGSI_LAUNCH_COUNT(5); break;
     default: BIGSI_LAUNCH_COUNT(0); break;
     }
 #undef BIGSI_LAUNCH_COUNT
+#undef BIGSI_LAUNCH_COUNT_DEEP
+#undef BIGSI_COUNT_ARGS
+#undef COMMA
 }
 
 static void launch_count(bigsi_hip_batch *b, int P, const CountLaunch &c, uint32_t q0, uint32_t q1)
@@ -978,7 +987,13 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
             b->local_from_counts = true;      // K4 thresholds the summed counters
         }
         TRY(ev_begin(ix, &ep, nullptr, true));
-        const CountLaunch cl{k2_rows, (unsigned)and_block, tiles, out, cstride, hb, sparse, slices};
+        // fewer than ~3 wavefronts per SIMD in the whole grid (e.g. 128 gene-length queries): the software-pipelined loop,
+        // whose wavefronts load the next k-mers' rows while adding the current ones (5.6 -> 6.3 TB/s at 128 x 2-4 kbp; with a
+        // full grid other wavefronts already cover the ALU phase and it measured -2 ... +0 %)
+        static const int deep_env = env_int("BIGSI_HIP_COUNT_DEEP", -1);
+        const uint64_t grid_waves = (uint64_t)b->n_seqs * tiles * (and_block / 64);
+        const bool deep = deep_env >= 0 ? deep_env != 0 : (slices == 1 && grid_waves < 3 * 1024);
+        const CountLaunch cl{k2_rows, (unsigned)and_block, tiles, out, cstride, hb, sparse, slices, deep};
         for (uint32_t q0 = 0; q0 < b->n_seqs; q0 += chunk_q, n_launches++)
             launch_count(b, P, cl, q0, (uint32_t)std::min<uint64_t>((uint64_t)q0 + chunk_q, b->n_seqs));
         HIP_TRY(hipGetLastError());

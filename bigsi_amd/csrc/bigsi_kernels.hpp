@@ -669,7 +669,8 @@ __global__ __launch_bounds__(1024) void k_and_exact(
 // bit survived (unpack_and_sum, graph/bigsi.py:35-44).  Counters are bit-sliced: P planes of uint64 per word, a
 // ripple-carry add of the AND-ed word costs 3 bit-ops per plane, far below what the HBM stream leaves the VALU
 // (see DESIGN.md).  Planes are expanded to integers once per (query, segment) and stored as CountT.
-template <int P, int H, typename CountT>
+template <int P, int H, typename CountT, int KMX = 1 /* 2: software-pipelined loads, for grids too small to fill the SIMDs
+    with wavefronts (128 x 4 kbp queries = 2 wavefronts per SIMD: 5.6 -> 6.3 TB/s) */>
 __global__ __launch_bounds__(kBlock) void k_and_count(
     const uint64_t *__restrict__ index, uint64_t stride_words, uint32_t wv,
     const uint64_t *__restrict__ rows, const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ num_unique,
@@ -710,16 +711,44 @@ __global__ __launch_bounds__(kBlock) void k_and_count(
         // KM k-mers per iteration so that 8-12 independent row loads are in flight per lane whatever h is (h=3: 12 loads
         // measured +1.9 % over 6; h=4: 8 vs 16 no difference)
         constexpr int KM = H == 1 ? 8 : H <= 3 ? 4 : 2;
-        for (; j + KM <= u; j += KM) {
-            u64x2 v[KM * (H > 0 ? H : 1)];
+        if (KMX == 2) {
+            // software pipeline: the loads of the NEXT KM k-mers are issued before the bit-sliced adds of the current ones, so
+            // a wavefront keeps the memory system busy through its own ALU phase (matters when few wavefronts share a SIMD)
+            u64x2 cur[KM * (H > 0 ? H : 1)], nxt[KM * (H > 0 ? H : 1)];
+            if (j + KM <= u) {
 #pragma unroll
-            for (int s = 0; s < KM * H; s++) v[s] = load_row_seg(index, qrows[(uint64_t)j * H + s], stride_words, w0);
+                for (int s = 0; s < KM * H; s++) cur[s] = load_row_seg(index, qrows[(uint64_t)j * H + s], stride_words, w0);
+            }
+            for (; j + KM <= u; j += KM) {
+                const bool more = j + 2 * KM <= u;       // wave-uniform
+                if (more) {
 #pragma unroll
-            for (int g = 0; g < KM; g++) {
-                u64x2 a = v[g * H];
+                    for (int s = 0; s < KM * H; s++) nxt[s] = load_row_seg(index, qrows[(uint64_t)(j + KM) * H + s], stride_words, w0);
+                }
 #pragma unroll
-                for (int s = 1; s < H; s++) a &= v[g * H + s];
-                add(a);
+                for (int g = 0; g < KM; g++) {
+                    u64x2 a = cur[g * H];
+#pragma unroll
+                    for (int s = 1; s < H; s++) a &= cur[g * H + s];
+                    add(a);
+                }
+                if (more) {
+#pragma unroll
+                    for (int s = 0; s < KM * H; s++) cur[s] = nxt[s];
+                }
+            }
+        } else {
+            for (; j + KM <= u; j += KM) {
+                u64x2 v[KM * (H > 0 ? H : 1)];
+#pragma unroll
+                for (int s = 0; s < KM * H; s++) v[s] = load_row_seg(index, qrows[(uint64_t)j * H + s], stride_words, w0);
+#pragma unroll
+                for (int g = 0; g < KM; g++) {
+                    u64x2 a = v[g * H];
+#pragma unroll
+                    for (int s = 1; s < H; s++) a &= v[g * H + s];
+                    add(a);
+                }
             }
         }
     }
