@@ -296,7 +296,7 @@ class ShardedBIGSI(object):
         self.num_samples = sum(len(n) for n in names)
         self.engine = ShardedSearch(local.storage, self.shard_cols, group=group, device=device, force_gather=True)
         self.scorer = Scorer(self.num_samples)               # DB_SIZE = number of samples of the whole index
-        self._batch = None
+        self._batches = {}                                   # workspace slot -> QueryBatch (two, alternating, in search_stream)
 
     # ---- one index spread over the ranks of a torch.distributed.run launch (CLI: --sharded)
     @staticmethod
@@ -357,67 +357,103 @@ class ShardedBIGSI(object):
         self.dist.all_gather_object(out, obj, group=self.group)
         return out
 
-    def search_batch(self, seqs, threshold=1.0, score=False):
+    # ---- queries: submit (asynchronous device work + exchange) / collect (fetch, names, scores), two workspaces deep
+    def _submit(self, slot, seqs, threshold):
+        batch = self._batches.get(slot)
+        if batch is None:
+            batch = self._batches[slot] = self.local.storage.new_batch(seqs, self.local.kmer_size)
+        else:
+            batch.reload(seqs, self.local.kmer_size)
+        workspaces = [self._batches[s] for s in sorted(self._batches)]
+        exact = threshold == 1.0
+        count_bytes = 2 if max(len(s) for s in seqs) - self.local.kmer_size + 1 < 65536 else 4
+        self.engine.prepare(workspaces, exact, count_bytes)
+        self.engine._i = sorted(self._batches).index(slot)       # the engine steps the workspace we just loaded
+        self.engine.step(workspaces, threshold)
+        return batch
+
+    def _collect(self, batch, n_seqs, threshold, score):
         from .graph.bigsi import BigsiQueryResult
         from .graph.metadata import DELETION_SPECIAL_SAMPLE_NAME
-        assert threshold <= 1
-        seqs = list(seqs)
-        if not seqs:
-            return []
-        if self._batch is None:
-            self._batch = self.local.storage.new_batch(seqs, self.local.kmer_size)
-        else:
-            self._batch.reload(seqs, self.local.kmer_size)
-        batch, sh, exact = self._batch, self.engine, threshold == 1.0
-        count_bytes = 2 if max(len(s) for s in seqs) - self.local.kmer_size + 1 < 65536 else 4
-        sh.prepare([batch], exact, count_bytes)
-        sh.step([batch], threshold)
+        sh, exact = self.engine, threshold == 1.0
         off, colours, counts = sh.fetch(batch)
         num_kmers, num_unique, _ = batch.unique()
         rank = sh.sg.rank
-        out, wanted = [], []                                 # wanted: (seq index, [local colours on this rank])
-        for i in range(len(seqs)):
+        out = []
+        for i in range(n_seqs):
             u, n = int(num_unique[i]), int(num_kmers[i])
             if u == 0:
                 if exact:
                     raise TypeError("reduce() of empty sequence with no initial value")
                 raise UnboundLocalError("local variable 'cumsum' referenced before assignment")
             lo, hi = int(off[i]), int(off[i + 1])
-            col, cnt = colours[lo:hi].astype(np.int64), counts[lo:hi]
+            col, cnt, pos = colours[lo:hi].astype(np.int64), counts[lo:hi], np.arange(lo, hi)
             shard, local_c = col // self.shard_cols, col % self.shard_cols
             if not exact:
                 keep = local_c < np.array([len(self.names[s]) for s in shard], dtype=np.int64) if len(shard) else np.zeros(0, bool)
-                shard, local_c, cnt = shard[keep], local_c[keep], cnt[keep]
+                shard, local_c, cnt, pos = shard[keep], local_c[keep], cnt[keep], pos[keep]
                 order = np.argsort(-cnt.astype(np.int64), kind="stable")
-                shard, local_c, cnt = shard[order], local_c[order], cnt[order]
+                shard, local_c, cnt, pos = shard[order], local_c[order], cnt[order], pos[order]
             res = [BigsiQueryResult((int(s), int(c)), self.names[int(s)][int(c)], u if exact else int(f), u)
                    for s, c, f in zip(shard, local_c, cnt)]
             if score and res and n == 1:
                 raise IndexError("too many indices for array: array is 1-dimensional, but 2 were indexed")
-            wanted.append([int(c) for s, c in zip(shard, local_c) if int(s) == rank] if score else [])
-            out.append((res, n))
+            out.append((res, pos))
         if score:
-            mine = {}
-            for i, cols in enumerate(wanted):
-                if cols:
-                    strings = batch.presence(i, np.array(cols, dtype=np.uint32), out[i][1])
-                    mine.update({(i, rank, c): s for c, s in zip(cols, strings)})
-            merged = {}
-            for part in self._gather(mine):
-                merged.update(part)
-            for i, (res, n) in enumerate(out):
-                for r in res:
-                    col = merged[(i, r.colour[0], r.colour[1])]
+            # graph/bigsi.py:232-237 for every hit of the batch: ONE K5 pass on each rank over the hits whose columns it owns
+            # (bigsi_hip_batch_presence_hits), then one exchange of (hit positions, strings) so that every rank can score
+            owned = (colours.astype(np.int64) // self.shard_cols) == rank
+            csum = np.concatenate([[0], np.cumsum(owned)])
+            off_own = csum[off.astype(np.int64)].astype(np.uint64)
+            col_own = (colours[owned].astype(np.int64) - rank * self.shard_cols).astype(np.uint32)
+            blob, starts, lens = batch.presence_hits(off_own, col_own, num_kmers)
+            text = blob.tobytes().decode("latin-1")
+            mine = (np.flatnonzero(owned), [text[int(a):int(a + n)] for a, n in zip(starts, lens)])
+            strings = {}
+            for where, strs in self._gather(mine):
+                strings.update(zip(where.tolist(), strs))
+            for res, pos in out:
+                for r, t in zip(res, pos.tolist()):
+                    col = strings[t]
                     sd = self.scorer.score(col)
                     sd["kmer-presence"] = col
                     r.add_score(sd)
         return [[r.todict() for r in res if r.sample_name != DELETION_SPECIAL_SAMPLE_NAME] for res, _ in out]
 
+    def search_batch(self, seqs, threshold=1.0, score=False):
+        assert threshold <= 1
+        seqs = list(seqs)
+        if not seqs:
+            return []
+        return self._collect(self._submit(0, seqs, threshold), len(seqs), threshold, score)
+
+    def search_stream(self, seqs, threshold=1.0, score=False, batch_size=None, batch_kmers=1 << 19):
+        """Generator over (sequence, results), two workspaces deep like BIGSI.search_stream: while the GPUs run (and exchange)
+        batch i+1, the host fetches and assembles batch i.  Every rank iterates it in step (SPMD)."""
+        assert threshold <= 1
+        pending, slot, chunk, held = None, 0, [], 0
+        k = self.local.kmer_size
+        for s in seqs:
+            chunk.append(s)
+            held += max(len(s) - k + 1, 1)
+            if (len(chunk) == batch_size) if batch_size else (held >= batch_kmers):
+                nxt = (self._submit(slot, chunk, threshold), chunk)
+                if pending is not None:
+                    yield from zip(pending[1], self._collect(pending[0], len(pending[1]), threshold, score))
+                pending, slot, chunk, held = nxt, slot ^ 1, [], 0
+        if chunk:
+            nxt = (self._submit(slot, chunk, threshold), chunk)
+            if pending is not None:
+                yield from zip(pending[1], self._collect(pending[0], len(pending[1]), threshold, score))
+            pending = nxt
+        if pending is not None:
+            yield from zip(pending[1], self._collect(pending[0], len(pending[1]), threshold, score))
+
     def search(self, seq, threshold=1.0, score=False):
         return self.search_batch([seq], threshold, score)[0]
 
     def close(self):
-        if self._batch is not None:
-            self._batch.close()
-            self._batch = None
+        for batch in self._batches.values():
+            batch.close()
+        self._batches = {}
         self.engine.close()
