@@ -728,6 +728,61 @@ static void launch_count(bigsi_hip_batch *b, int P, const CountLaunch &c, uint32
 
 static int compact(bigsi_hip_batch *b, HitBufs &hb, const void *src, uint32_t n_shards, uint64_t shard_cols, bool write_only);
 
+// Reads against a narrow index: K1 + K2 + K4 in one launch (k_reads_fused) when the batch qualifies.
+static bool reads_fusable(const bigsi_hip_batch *b, uint32_t flags)
+{
+    static const int fuse = env_int("BIGSI_HIP_FUSE_READS", 1);
+    const bigsi_hip_index *ix = b->ix;
+    const bool exact = b->exact;
+    return fuse && b->k == 31 && b->total_pos > 0 && b->max_pos <= 63 && b->n_seqs <= kHitsMaxGroups && b->wv <= (uint64_t)kBlock * kVec &&
+           ix->h >= 2 && ix->h <= 4 && !b->ext_bitmaps && !b->ext_counts && b->result_cols == 0 &&
+           !(flags & (BIGSI_RUN_SKIP_COMPACT | BIGSI_RUN_K1_GLOBAL | BIGSI_RUN_EARLY_EXIT | BIGSI_RUN_NO_SORT)) &&
+           (exact || (flags & BIGSI_RUN_SPARSE_COUNTS));     // the fused kernel keeps counters in registers: hits only
+}
+
+static int launch_reads_fused(bigsi_hip_batch *b)
+{
+    bigsi_hip_index *ix = b->ix;
+    HitBufs &hb = b->hits;
+    TRY(b->bitmaps.reserve((size_t)b->n_seqs * b->wv_pad * 8));
+    TRY(hb.hit_off.reserve((b->n_seqs + 1) * 8ull));
+    if (hb.cap == 0 && !hb.xcol) {
+        const uint64_t want = 1u << 16;
+        TRY(hb.hit_col.reserve(want * 4));
+        TRY(hb.hit_cnt.reserve(want * 4));
+        hb.cap = want;
+    }
+    if (hb.lb_state.cap < kHitsMaxGroups * 8) {
+        TRY(hb.lb_state.reserve(kHitsMaxGroups * 8));
+        HIP_TRY(hipMemsetAsync(hb.lb_state.p, 0, hb.lb_state.cap, ix->stream));
+        hb.gen = 0;
+    }
+    if (++hb.gen >= (1u << 20)) {
+        HIP_TRY(hipMemsetAsync(hb.lb_state.p, 0, hb.lb_state.cap, ix->stream));
+        hb.gen = 1;
+    }
+#define BIGSI_READS_ARGS                                                                                                          \
+    dim3(b->n_seqs), dim3(kBlock), 0, ix->stream, ix->d_index, ix->stride_words, (uint32_t)b->wv, ix->n_cols, ix->m, b->threshold,      \
+        b->seqs.as<char>(), b->d_seq_off.as<uint64_t>(), b->d_pos_off.as<uint64_t>(), b->n_seqs, b->first_pos.as<uint32_t>(),         \
+        b->pos_unique.as<uint32_t>(), b->rep.as<uint32_t>(), b->rows.as<uint64_t>(), b->num_kmers.as<uint32_t>(),                      \
+        b->num_unique.as<uint32_t>(), b->min_kmers.as<uint32_t>(), b->bitmaps.as<uint64_t>(), b->wv_pad, hb.lb_state.as<uint64_t>(),  \
+        hb.gen, hb.hit_off.as<uint64_t>(), hb.col(), hb.cnt(), hb.capacity()
+#define COMMA ,
+#define BIGSI_READS(H)                                                                              \
+    if (b->exact) hipLaunchKernelGGL((k_reads_fused<H COMMA true>), BIGSI_READS_ARGS);                \
+    else hipLaunchKernelGGL((k_reads_fused<H COMMA false>), BIGSI_READS_ARGS)
+    switch (ix->h) {
+    case 2: BIGSI_READS(2); break;
+    case 3: BIGSI_READS(3); break;
+    default: BIGSI_READS(4); break;
+    }
+#undef BIGSI_READS
+#undef BIGSI_READS_ARGS
+#undef COMMA
+    HIP_TRY(hipGetLastError());
+    return BIGSI_OK;
+}
+
 // the stream K1 and the row sort run on.  Default: the index stream itself.  BIGSI_HIP_K1_OVERLAP=1 moves them to the pre
 // stream so that they overlap the row-AND kernel of the batch before; measured a LOSS at C3 (exact: K2 1.93 -> 2.12-2.22 ms,
 // the late-placed workgroups break the lock-step sweep of k_and_exact; counts: +-0), kept for A/B runs only
@@ -886,6 +941,29 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
     if (b->wv > ix->stride_words)
         return fail(BIGSI_ERR_CAPACITY, "result width %llu columns exceeds the row stride (call bigsi_hip_reserve_cols)", (unsigned long long)b->result_cols);
     b->wv_pad = round_up(b->wv, 2);
+
+    b->fused_run = false;
+    if (reads_fusable(b, flags)) {
+        // (K1 rewrites arrays the previous run of this batch may still be reading on the gather stream)
+        if (b->g_done && b->gstream && b->gstream != ix->stream) HIP_TRY(hipStreamWaitEvent(ix->stream, b->g_done, 0));
+        TRY(b->rows.reserve(std::max<uint64_t>(b->total_pos, 1) * ix->h * 8));
+        EventPair fe{};
+        b->dirty = true;
+        TRY(ev_begin(ix, &fe, nullptr, true));
+        TRY(launch_reads_fused(b));
+        TRY(ev_end(ix, &fe, ix->ev_and));
+        b->run_h = ix->h;
+        b->fused_run = true;
+        b->local_from_counts = false;
+        b->count_bytes = 2;
+        b->sparse_counts = !b->exact;
+        b->compacted = true;
+        if (!b->done) HIP_TRY(hipEventCreateWithFlags(&b->done, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(b->done, ix->stream));
+        b->ran = true;
+        b->dirty = false;
+        return BIGSI_OK;
+    }
 
     // K1e: address-ordered copy of the row lists for K2 (BIGSI_HIP_SORT_ROWS=0 streams them in hash order instead)
     static const int sort_rows = env_int("BIGSI_HIP_SORT_ROWS", 1);
@@ -1123,7 +1201,8 @@ static int fetch_hits_from(bigsi_hip_batch *b, HitBufs &hb, const void *src, uin
         TRY(hb.hit_col.reserve(total * 4));
         TRY(hb.hit_cnt.reserve(total * 4));
         hb.cap = total;
-        TRY(compact(b, hb, src, n_shards, shard_cols, true));
+        if (&hb == &b->hits && b->fused_run) TRY(launch_reads_fused(b));      // counters lived in registers: the whole pass again
+        else TRY(compact(b, hb, src, n_shards, shard_cols, true));
         if (&hb == &b->ghits && b->comm && !b->exact) TRY(bigsi_reduce_gathered_counts(b));   // every rank takes this branch: totals are identical
         HIP_TRY(hipStreamSynchronize(st));
     }

@@ -127,6 +127,7 @@ struct bigsi_hip_batch {
     bool ran = false, exact = false, compacted = false, sparse_counts = false;
     bool pos_query_loaded = false;    // pos_query holds this load's position -> sequence map
     bool local_from_counts = false;   // the last counting run was row-sliced: hits come from thresholding the counters
+    bool fused_run = false;           // the last run was the one-launch read kernel (k_reads_fused)
     uint32_t count_bytes = 2;
     double threshold = 1.0;
     uint64_t wv = 0, wv_pad = 0;   // valid / padded words per row at run time

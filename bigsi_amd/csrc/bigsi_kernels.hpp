@@ -33,6 +33,13 @@ __host__ __device__ __forceinline__ uint64_t mix64(uint64_t x)
 // bit position, inside the little-endian uint64 of a row, of column (8*byte + j)
 __host__ __device__ __forceinline__ uint32_t bit_of_col(uint32_t c) { return ((c >> 3) & 7u) * 8u + 7u - (c & 7u); }
 
+// column-order view of a word in row bit order: reverse the bits inside every byte
+__device__ __forceinline__ uint64_t by_column(uint64_t x)
+{
+    const uint32_t lo = __builtin_bswap32(__builtin_bitreverse32((uint32_t)x)), hi = __builtin_bswap32(__builtin_bitreverse32((uint32_t)(x >> 32)));
+    return ((uint64_t)hi << 32) | lo;
+}
+
 // mask of the valid column bits of word w for an index of n_cols columns (pad bits stay zero)
 __host__ __device__ __forceinline__ uint64_t valid_mask(uint64_t w, uint64_t n_cols)
 {
@@ -938,6 +945,194 @@ __global__ __launch_bounds__(kBlock) void k_hits_fused(
     }
 }
 
+// ------------------------------------------------------------------------------ reads: K1 + K2 + K4 in ONE launch
+// A batch of reads against a narrow index (BASELINE configs[1]: 1000 x 61-mers, 10 000 samples) is three short kernels
+// and three launch boundaries: 7 + 24 + 7 us of kernels in a 43 us step.  When every query has < 64 k-mer positions, a row
+// fits one workgroup's lanes (<= 512 words) and the batch has at most kHitsMaxGroups queries, ONE workgroup per query does
+// the whole path: wavefront 0 k-merises / dedupes / hashes exactly as k_kmerize_wave does (and leaves the same arrays in
+// global memory for lookup / presence / fetch_rows), the row ids go to the other wavefronts through LDS, all of them
+// stream and AND (or count) the rows, and the hit list is written through k_hits_fused's scan -- the workgroup publishes its
+// total and sums those of the queries before it (the grid is co-resident by construction).  Same results, one launch.
+template <int H, bool EXACT>
+__global__ __launch_bounds__(kBlock) void k_reads_fused(
+    const uint64_t *__restrict__ index, uint64_t stride_words, uint32_t wv, uint64_t n_cols, uint64_t m, double threshold,
+    const char *__restrict__ seqs, const uint64_t *__restrict__ seq_off, const uint64_t *__restrict__ pos_off, uint32_t n_seqs,
+    uint32_t *__restrict__ first_pos, uint32_t *__restrict__ pos_unique, uint32_t *__restrict__ rep_out, uint64_t *__restrict__ rows,
+    uint32_t *__restrict__ num_kmers, uint32_t *__restrict__ num_unique, uint32_t *__restrict__ min_kmers,
+    uint64_t *__restrict__ out_bits, uint64_t out_stride_words,
+    uint64_t *__restrict__ state, uint32_t gen, uint64_t *__restrict__ hit_off, uint32_t *__restrict__ hit_col, uint32_t *__restrict__ hit_cnt,
+    uint64_t capacity)
+{
+    constexpr int KF = 31, P = 6;
+    __shared__ uint64_t s_rows[64 * H];
+    __shared__ uint32_t s_u, s_min;
+    __shared__ uint32_t lds[16];
+    __shared__ uint64_t lds64[kBlock / 64];
+    const uint32_t q = blockIdx.x;
+    // ---- K1 (wavefront 0): see k_kmerize_wave
+    if (threadIdx.x < 64) {
+        const uint32_t lane = threadIdx.x;
+        const char *s = seqs + seq_off[q];
+        const uint32_t len = (uint32_t)(seq_off[q + 1] - seq_off[q]);
+        const uint32_t n = len >= KF ? len - KF + 1 : 0u;      // < 64 by the launch condition
+        const uint64_t P0 = pos_off[q];
+        const bool live = lane < n;
+        const uint32_t fp = live ? dedupe_hash<KF>(s + lane, KF) : 0u;
+        uint32_t rep = lane;
+        for (uint32_t j = 0; j + 1 < n; j++) {
+            const uint32_t fj = __shfl(fp, (int)j, 64);
+            if (live && lane > j && rep == lane && fp == fj && kmer_equal(s + j, s + lane, KF)) rep = j;
+        }
+        const bool first = live && rep == lane;
+        const unsigned long long mask = __ballot(first);
+        const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+        const uint32_t u = (uint32_t)__popcll(mask);
+        if (live) {
+            rep_out[P0 + lane] = rep;
+            pos_unique[P0 + lane] = (uint32_t)__popcll(mask & (rep ? (~0ull >> (64 - rep)) : 0ull));
+        }
+        if (first) {
+            const uint32_t j = (uint32_t)__popcll(mask & below);
+            first_pos[P0 + j] = lane;
+            RegKmer<KF> reg;
+            reg.load(s + lane);
+            uint32_t w[(KF + 3) / 4];
+            reg.canonical_words(w);
+#pragma unroll
+            for (int sd = 0; sd < H; sd++) {
+                const uint64_t r = row_of_hash(murmur3_words<KF>(w, (uint32_t)sd), m);
+                rows[(P0 + j) * H + sd] = r;
+                s_rows[j * H + sd] = r;
+            }
+        }
+        if (lane == 0) {
+            const double mk = ceil((double)u * threshold);
+            const uint32_t mn = mk > 0.0 ? (uint32_t)mk : 0u;
+            num_kmers[q] = n;
+            num_unique[q] = u;
+            min_kmers[q] = mn;
+            s_u = u;
+            s_min = mn;
+        }
+    }
+    __syncthreads();
+    // ---- K2: lane = two words of the row
+    const uint32_t u = s_u;
+    const uint32_t w0 = threadIdx.x * kVec;
+    const bool live = w0 < wv;
+    uint64_t hitw[kVec] = {0ull, 0ull};
+    uint64_t pl[kVec][P];
+    if (EXACT) {
+        const uint32_t R = u * H;
+        const u64x2 ones = {~0ull, ~0ull};
+        u64x2 acc = ones;
+        if (live) {
+            for (uint32_t r = 0; r < R; r += 8) {
+                u64x2 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = r + j < R ? load_row_seg(index, s_rows[r + j], stride_words, w0) : ones;
+#pragma unroll
+                for (int j = 0; j < 8; j++) acc &= v[j];
+            }
+            if (R == 0) acc = u64x2{0ull, 0ull};
+            hitw[0] = acc.x & valid_mask(w0, n_cols);
+            hitw[1] = acc.y & valid_mask(w0 + 1, n_cols);
+        }
+    } else {
+#pragma unroll
+        for (int v = 0; v < kVec; v++)
+#pragma unroll
+            for (int p = 0; p < P; p++) pl[v][p] = 0;
+        if (live) {
+            constexpr int KM = H <= 2 ? 4 : H == 3 ? 4 : 2;
+            const u64x2 zero = {0ull, 0ull};
+            for (uint32_t j = 0; j < u; j += KM) {
+                u64x2 v[KM * H];
+#pragma unroll
+                for (int t = 0; t < KM * H; t++) v[t] = j + t / H < u ? load_row_seg(index, s_rows[(j + t / H) * H + t % H], stride_words, w0) : zero;
+#pragma unroll
+                for (int g = 0; g < KM; g++) {
+                    u64x2 a = v[g * H];
+#pragma unroll
+                    for (int t = 1; t < H; t++) a &= v[g * H + t];
+                    uint64_t c0 = a.x, c1 = a.y;
+#pragma unroll
+                    for (int p = 0; p < P; p++) {
+                        const uint64_t t0 = pl[0][p] & c0, t1 = pl[1][p] & c1;
+                        pl[0][p] ^= c0; pl[1][p] ^= c1;
+                        c0 = t0; c1 = t1;
+                    }
+                }
+            }
+            const uint32_t thr = s_min;
+#pragma unroll
+            for (int v = 0; v < kVec; v++) {
+                uint64_t gt = 0, eq = ~0ull;
+                if ((thr >> P) != 0) eq = 0;
+#pragma unroll
+                for (int p = P - 1; p >= 0; p--) {
+                    if ((thr >> p) & 1u) eq &= pl[v][p];
+                    else { gt |= eq & pl[v][p]; eq &= ~pl[v][p]; }
+                }
+                hitw[v] = (gt | eq) & valid_mask((uint64_t)w0 + v, n_cols);
+            }
+        }
+    }
+    if (live) {
+        uint64_t *o = out_bits + (uint64_t)q * out_stride_words + w0;
+        o[0] = hitw[0];
+        if (w0 + 1 < out_stride_words) o[1] = hitw[1];
+    }
+    // ---- K4: this query's hits after those of the queries before it
+    const uint32_t mine = (uint32_t)(__popcll(hitw[0]) + __popcll(hitw[1]));
+    uint32_t tot;
+    const uint32_t pre = block_exclusive_scan(mine, &tot, lds);
+    if (threadIdx.x == 0) __hip_atomic_store(&state[q], lb_pack(gen, tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint64_t part = 0;
+    for (uint64_t j = threadIdx.x; j < q; j += kBlock) {
+        uint64_t word;
+        for (;;) {
+            word = __hip_atomic_load(&state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((uint32_t)(word >> 44) == gen && (word & ((1ull << 44) - 1)) != 0) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        part += (word & ((1ull << 44) - 1)) - 1;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+    if ((threadIdx.x & 63u) == 0) lds64[threadIdx.x >> 6] = part;
+    __syncthreads();
+    uint64_t base = 0;
+#pragma unroll
+    for (int i = 0; i < kBlock / 64; i++) base += lds64[i];
+    if (threadIdx.x == 0) {
+        hit_off[q] = base;
+        if (q + 1 == n_seqs) hit_off[n_seqs] = base + tot;
+    }
+    if (mine == 0) return;
+    uint64_t o = base + pre;
+    if (o + mine > capacity) return;                    // the host sees total > capacity, grows the lists and launches again
+#pragma unroll
+    for (int v = 0; v < kVec; v++) {
+        uint64_t mcol = by_column(hitw[v]);
+        while (mcol) {
+            const uint32_t c = (uint32_t)__builtin_ctzll(mcol);
+            mcol &= mcol - 1;
+            hit_col[o] = (uint32_t)(((uint64_t)w0 + v) * 64 + c);
+            if (EXACT) {
+                hit_cnt[o] = u;
+            } else {
+                const uint32_t bp = bit_of_col(c);
+                uint32_t x = 0;
+#pragma unroll
+                for (int p = 0; p < P; p++) x |= (uint32_t)((pl[v][p] >> bp) & 1ull) << p;
+                hit_cnt[o] = x;
+            }
+            o++;
+        }
+    }
+}
+
 // counting: a hit is a column with count >= min_kmers[q] (graph/bigsi.py:241-242); column < shard_cols only.
 template <typename CountT, bool WRITE>
 __global__ __launch_bounds__(kBlock) void k_hits_count(
@@ -1058,12 +1253,6 @@ struct PresencePair {
     uint64_t mask_lo, mask_hi;   // hit bits of the two words (row bit order)
 };
 
-// column-order view of a word in row bit order: reverse the bits inside every byte
-__device__ __forceinline__ uint64_t by_column(uint64_t x)
-{
-    const uint32_t lo = __builtin_bswap32(__builtin_bitreverse32((uint32_t)x)), hi = __builtin_bswap32(__builtin_bitreverse32((uint32_t)(x >> 32)));
-    return ((uint64_t)hi << 32) | lo;
-}
 
 template <int H, int WAVES = 2>      // WAVES = 2: the compiler keeps all 16 x h loads of a thread in flight (~200 VGPRs), measured faster than 4
 __global__ __launch_bounds__(kBlock, WAVES) void k_presence_bits(

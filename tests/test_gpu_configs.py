@@ -77,6 +77,18 @@ def test_c2_full_workload_every_query():
     st.insert_kmers(n - 1, [seqs[3]], 31)                         # last column: the ragged final word
     orc.insert_kmers(n - 1, seqs[3])
     check_queries(st, orc, seqs, range(1000))
+    # the route BIGSI.search takes for such a batch (hit lists only): K1 + K2 + K4 in one launch (k_reads_fused)
+    batch = st.new_batch(seqs, 31)
+    for thr in (1.0, 0.4):
+        batch.run(thr, sparse_counts=True)
+        _, nu, mk = batch.unique()
+        off, colours, counts = batch.hits()
+        for i in range(0, 1000, 7):
+            u, cnt = orc.counts(seqs[i])
+            want = np.flatnonzero(cnt >= (u if thr == 1.0 else mk[i]))
+            assert nu[i] == u and np.array_equal(colours[int(off[i]):int(off[i + 1])], want), (thr, i)
+            assert np.array_equal(counts[int(off[i]):int(off[i + 1])], cnt[want].astype(np.uint32)), (thr, i)
+    batch.close()
     st.delete_all()
 
 

@@ -1107,3 +1107,46 @@ def test_tiled_transpose_matches_numpy(hip, m, first, second):
     st.insert_columns(lo, np.packbits(bits2[lo:hi], axis=1))
     assert np.array_equal(st.get_rows_packed(np.arange(m), (n + 7) // 8), np.packbits(bits2.T, axis=1))
     st.delete_all()
+
+
+@pytest.mark.parametrize("h,n_cols", [(3, 10000), (2, 700), (4, 32768), (3, 65)])
+def test_one_launch_read_path_equals_three_launch_path(hip, h, n_cols):
+    """Batches of reads (< 64 k-mers each, k = 31, at most 1024 queries, rows of at most 512 words) take k_reads_fused: K1 + K2 +
+    K4 in one launch.  Everything observable -- k-mer counts, row ids, hit lists, AND bitmaps, presence strings -- must equal
+    the three-launch route (forced here with the K1_GLOBAL test flag) and the oracle, for exact and thresholded searches,
+    including reads shorter than k, duplicates, N and lowercase, and a hit list that outgrows its initial buffers."""
+    from oracle.ref_model import SynthOracle
+    m, seed = 30011, 77 + h
+    c, st = synth_index(hip, m, n_cols, h, seed, draws=1)
+    orc = SynthOracle(seed, 0, m, n_cols, h, 31, 1)
+    rng = np.random.default_rng(n_cols)
+    seqs = random_seqs(rng, 300, 31, 93) + ["A" * 60, "ACGT" * 15, "N" * 40, "acgtacgtac" * 5, "AC", "", "ACGTN" * 12]
+    st.insert_kmers(n_cols - 1, [seqs[0]], 31)
+    orc.insert_kmers(n_cols - 1, seqs[0])
+    st.insert_kmers(3, [seqs[1][:50]], 31)
+    orc.insert_kmers(3, seqs[1][:50])
+    fused, plain = st.new_batch(seqs, 31), st.new_batch(seqs, 31)
+    for thr in (1.0, 0.4, 0.0):
+        fused.run(thr, sparse_counts=True)
+        plain.run(thr, sparse_counts=True, k1_global=True)
+        a, b_ = fused.unique(), plain.unique()
+        assert all(np.array_equal(x, y) for x, y in zip(a, b_))
+        fo, fc, fn = fused.hits()
+        po, pc, pn = plain.hits()
+        assert np.array_equal(fo, po) and np.array_equal(fc, pc) and np.array_equal(fn, pn), thr
+        if thr == 0.0:
+            assert int(fo[-1]) > 65536 or n_cols * len(seqs) <= 65536
+        for i in (0, 1, 5, 300, 301, 302, 303, 306):
+            assert np.array_equal(fused.rows(i, a[1][i]), plain.rows(i, a[1][i]))
+            u, cnt = orc.counts(seqs[i])
+            want = np.flatnonzero(cnt >= (u if thr == 1.0 else a[2][i]))
+            assert a[1][i] == u and np.array_equal(fc[int(fo[i]):int(fo[i + 1])], want), (thr, i)
+            assert np.array_equal(fn[int(fo[i]):int(fo[i + 1])], cnt[want].astype(np.uint32))
+            if thr == 1.0:
+                assert np.array_equal(fused.bitmap(i), plain.bitmap(i))
+        if thr == 0.4:
+            hits = fc[int(fo[1]):int(fo[2])]
+            assert fused.presence(1, hits, int(a[0][1])) == plain.presence(1, hits, int(a[0][1]))
+    fused.close()
+    plain.close()
+    st.delete_all()
