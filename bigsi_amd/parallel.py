@@ -98,16 +98,43 @@ class ShardedSearch(object):
             check(L.bigsi_hip_reserve_cols(storage.handle, self.shard_cols))
         if exchange == "rccl":
             ident = np.zeros(128, np.uint8)
-            if self.sg.rank == 0:
-                check(L.bigsi_hip_comm_unique_id(_lib.ptr(ident)))
-            if self.sg.dist.is_initialized() and self.sg.world > 1:
-                box = [ident.tobytes()]
+            ok, err = 1, None
+            try:
+                if self.sg.rank == 0:
+                    check(L.bigsi_hip_comm_unique_id(_lib.ptr(ident)))
+            except _lib.BigsiHipError as e:
+                ok, err = 0, e
+            multi = self.sg.dist.is_initialized() and self.sg.world > 1
+            if multi:
+                box = [ident.tobytes() if ok else None]
                 self.sg.dist.broadcast_object_list(box, src=self.sg.dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-                ident = np.frombuffer(box[0], np.uint8).copy()
-            out = _lib.C.c_void_p()
-            check(L.bigsi_hip_comm_init_rank(int(self.device.index), _lib.ptr(ident), self.sg.rank, self.sg.world, _lib.C.byref(out)))
-            self.comm = out
-        else:
+                ok = int(box[0] is not None)
+                if ok:
+                    ident = np.frombuffer(box[0], np.uint8).copy()
+            if ok:
+                out = _lib.C.c_void_p()
+                try:
+                    check(L.bigsi_hip_comm_init_rank(int(self.device.index), _lib.ptr(ident), self.sg.rank, self.sg.world, _lib.C.byref(out)))
+                    self.comm = out
+                except _lib.BigsiHipError as e:
+                    ok, err = 0, e
+            if multi:
+                # every rank must take the same route: if the library's communicator did not come up everywhere, all fall
+                # back to torch.distributed's collectives (same RCCL underneath, torch's communicator)
+                flag = torch.tensor([ok], dtype=torch.int32, device=self.device)
+                self.sg.dist.all_reduce(flag, op=self.sg.dist.ReduceOp.MIN, group=group)
+                ok = int(flag.item())
+            if not ok:
+                if not multi:
+                    raise err
+                import warnings
+                warnings.warn("libbigsi_hip could not bring up its own RCCL communicator on every rank (%s): "
+                              "falling back to torch.distributed collectives" % (err,))
+                if self.comm is not None:
+                    check(L.bigsi_hip_comm_destroy(self.comm))
+                    self.comm = None
+                self.exchange = exchange = "torch"
+        if exchange == "torch":
             self.stream = torch.cuda.Stream(self.device)
             self.comm_stream = torch.cuda.Stream(self.device)
             check(L.bigsi_hip_set_stream(storage.handle, self.stream.cuda_stream))
