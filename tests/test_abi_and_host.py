@@ -231,3 +231,42 @@ def test_cortex_reader_vs_reference(tmp_path):
     bad.write_bytes(b"CORTEX\x05\x00\x00\x00")
     with pytest.raises(CortexFormatError):
         read_kmers(str(bad))
+
+
+def test_cli_build_inputs_and_sizes(tmp_path):
+    """Host logic of the `build` command line (bigsi/__main__.py:139-160): --from_file XOR -b, sample names default to the
+    filter paths; max_build_mem_bytes sizes as humanfriendly reads them."""
+    import argparse
+    from bigsi_amd.__main__ import build_inputs, parse_size
+    tsv = tmp_path / "f.tsv"
+    tsv.write_text("a.bloom\tsample a\nb.bloom\tb\n")
+    ns = argparse.Namespace(bloomfilters=[], samples=[], from_file=str(tsv))
+    assert build_inputs(ns) == (["a.bloom", "b.bloom"], ["sample a", "b"])
+    ns = argparse.Namespace(bloomfilters=["x", "y"], samples=[], from_file=None)
+    assert build_inputs(ns) == (["x", "y"], ["x", "y"])
+    with pytest.raises(ValueError):
+        build_inputs(argparse.Namespace(bloomfilters=["x"], samples=[], from_file=str(tsv)))
+    with pytest.raises(AssertionError):
+        build_inputs(argparse.Namespace(bloomfilters=["x", "y"], samples=["only one"], from_file=None))
+    assert [parse_size(t) for t in ("4GB", "512 MiB", 1000, "100", "2kb", "10 bytes", "1.5 GiB")] == \
+        [4_000_000_000, 536_870_912, 1000, 100, 2000, 10, 1_610_612_736]
+    with pytest.raises(ValueError):
+        parse_size("lots")
+
+
+def test_plan_shards_and_bench_workloads():
+    """Column-range plan of a sharded index and the bench's named workloads: every BASELINE config is there, the ones that
+    do not fit one GPU say so before touching a device."""
+    import subprocess
+    import sys
+    from bigsi_amd.parallel import plan_shards
+    assert plan_shards(129, 2) == (65, [(0, 65), (65, 64)])
+    assert plan_shards(1000, 3) == (334, [(0, 334), (334, 334), (668, 332)])
+    assert plan_shards(5, 8)[1][5:] == [(5, 0), (5, 0), (5, 0)]
+    sys.path.insert(0, ROOT)
+    import bench
+    assert set(bench.WORKLOADS) == {"c2", "c3", "c4", "c5", "northstar"}
+    assert bench.WORKLOADS["c4"]["rows"] * bench.WORKLOADS["c4"]["cols"] == 25_000_000 * 500_000 and bench.WORKLOADS["c5"]["threshold"] == 0.4
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "northstar", "--gpus", "1"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "more than one MI355X holds" in r.stderr
