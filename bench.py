@@ -452,7 +452,8 @@ def main():
                 "pcie_inclusive_kmer_lookups_per_s": pcie_rate,
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_and_exact" if exact else "k_and_count",
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "k_reads_fused (K1 + row-AND + K4 in one launch)" if batch.info().one_launch else "k_and_exact" if exact else "k_and_count",
                          "alg_bytes_per_launch": alg_bytes_launch, "kernel_ms": and_ms, "launches_timed": int(stats.and_launches),
                          "launches_per_step": launches_per_step, "alg_bytes_per_step": alg_bytes,
                          "rank": 0,

@@ -39,7 +39,8 @@ class BatchInfo(C.Structure):
     _fields_ = [("n_seqs", C.c_uint32), ("k", C.c_uint32), ("exact", C.c_uint32), ("count_bytes", C.c_uint32),
                 ("total_kmers", C.c_uint64), ("total_unique", C.c_uint64), ("total_hits", C.c_uint64),
                 ("bitmap_stride_bytes", C.c_uint64), ("counts_stride", C.c_uint64),
-                ("d_bitmaps", C.c_void_p), ("d_counts", C.c_void_p), ("d_num_unique", C.c_void_p)]
+                ("d_bitmaps", C.c_void_p), ("d_counts", C.c_void_p), ("d_num_unique", C.c_void_p),
+                ("one_launch", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class GroupInfo(C.Structure):

@@ -1070,7 +1070,8 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
         // full grid other wavefronts already cover the ALU phase and it measured -2 ... +0 %)
         static const int deep_env = env_int("BIGSI_HIP_COUNT_DEEP", -1);
         const uint64_t grid_waves = (uint64_t)b->n_seqs * tiles * (and_block / 64);
-        const bool deep = deep_env >= 0 ? deep_env != 0 : (slices == 1 && grid_waves < 3 * 1024);
+        // (only with >= 12 planes, i.e. queries of >= 1024 k-mers: at 10 planes the ALU phase is short and it measured -2 %)
+        const bool deep = deep_env >= 0 ? deep_env != 0 : (slices == 1 && P >= 12 && grid_waves < 3 * 1024);
         const CountLaunch cl{k2_rows, (unsigned)and_block, tiles, out, cstride, hb, sparse, slices, deep};
         for (uint32_t q0 = 0; q0 < b->n_seqs; q0 += chunk_q, n_launches++)
             launch_count(b, P, cl, q0, (uint32_t)std::min<uint64_t>((uint64_t)q0 + chunk_q, b->n_seqs));
@@ -1255,6 +1256,7 @@ extern "C" int bigsi_hip_batch_get_info(bigsi_hip_batch *b, bigsi_hip_batch_info
     out->d_bitmaps = b->ext_bitmaps ? b->ext_bitmaps : b->bitmaps.p;
     out->d_counts = b->ext_counts ? b->ext_counts : b->counts.p;
     out->d_num_unique = b->num_unique.p;
+    out->one_launch = b->fused_run ? 1 : 0;
     return BIGSI_OK;
 }
 

@@ -167,6 +167,8 @@ typedef struct {
     void *d_bitmaps;       /* device: n_seqs x bitmap_stride_bytes, row format, exact runs   */
     void *d_counts;        /* device: n_seqs x counts_stride counters, counting runs         */
     void *d_num_unique;    /* device: uint32[n_seqs]                                         */
+    uint32_t one_launch;   /* 1: the last run was the one-launch read kernel (K1 + K2 + K4 fused) */
+    uint32_t reserved;
 } bigsi_hip_batch_info;
 int bigsi_hip_batch_get_info(bigsi_hip_batch *b, bigsi_hip_batch_info *out); /* synchronises */
 

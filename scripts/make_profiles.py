@@ -61,7 +61,8 @@ def main():
         if lines and "roofline" in lines[-1]:              # a bench.py line
             d = lines[-1]
             r = d["roofline"]
-            names = [k for k in ks if ("k_and_exact" in k if r["kernel"] == "k_and_exact" else "k_and_count" in k)]
+            want = "k_reads_fused" if "k_reads_fused" in r["kernel"] else r["kernel"]
+            names = [k for k in ks if want in k] or [k for k in ks if "k_reads_fused" in k]
             dom = max(names, key=lambda k: ks[k]["calls"] * ks[k]["avg_ns"]) if names else None
             rec["bench_same_run"] = d
             if dom:
