@@ -20,7 +20,8 @@ exchange included -- every rank looks every k-mer up in its shard, so the shard-
     c2            BASELINE configs[1]: 1M x 10k, h=3, 1000 x 61-mers, a different batch every step (32 staged batches cycle)
     c4            BASELINE configs[3]: 25M x 500k, h=3 (1.56 TB: needs 8 GPUs), 256 x 1 kbp queries per step
     c5            BASELINE configs[4]: c4 at threshold 0.4 with score=True: every step also brings the hit lists to the host and
-                  extracts the presence strings of all hits (K5) -- 16 queries x 16 planted samples per shard and batch
+                  extracts the presence strings of all hits (K5), one batch behind the launches -- 16 queries x 16 planted
+                  samples per shard and batch
     northstar     BASELINE north_star: 10M x 500k, h=3 (625 GB: needs >= 4 GPUs)
 `--shard-of P` runs, on fewer GPUs, the first N of the P column shards of the workload (e.g. `--workload c4 --shard-of 8
 --gpus 1` is what one GPU of the 8-GPU C4 run does; value is then the rate against that part of the index and says so).
@@ -280,16 +281,25 @@ def main():
         off_own = csum[off.astype(np.int64)].astype(np.uint64)
         return off_own, (colours[owned].astype(np.int64) - rank * shard_cols).astype(np.uint32)
 
+    pending = [None]
+
+    def collect():
+        """score=True: what BIGSI.score needs from the device for the batch launched one step ago -- its hit lists come back to
+        the host and the presence strings of every hit are extracted (K5) on the rank that owns the hit's column."""
+        if pending[0] is not None:
+            off_own, col_own = own_hits(pending[0])
+            pending[0].presence_hits(off_own, col_own, pending[0].unique()[0])
+            pending[0] = None
+
     def step():
-        """One pass of the path over the next staged batch.  score=True workloads (configs[4]) go on to what BIGSI.score needs
-        from the device: the hit lists come back to the host and the presence strings of every hit are extracted (K5) on the
-        rank that owns the hit's column -- that makes their step synchronous."""
+        """One pass of the path over the next staged batch.  score=True workloads (configs[4]) are two batches deep: the next
+        batch is launched first, then the previous one is collected, so the host's share overlaps the row-AND kernel."""
         batch = batches[step_no[0] % len(batches)]
         step_no[0] += 1
         sh.step(batches, thr)
         if w["score"]:
-            off_own, col_own = own_hits(batch)
-            batch.presence_hits(off_own, col_own, batch.unique()[0])
+            collect()
+            pending[0] = batch
 
     warm = _lib.Stats()
     for i in range(args.warmup):
@@ -297,6 +307,7 @@ def main():
         if i == 0:            # the first step pays one-off costs (code object load, allocations): keep it out of the K1 / K4 figures
             sync_all()
             check(_lib.lib().bigsi_hip_stats(st.handle, _lib.C.byref(warm), 1))
+    collect()
     sync_all()
     check(_lib.lib().bigsi_hip_stats(st.handle, _lib.C.byref(warm), 1))      # K1 / K4 durations come from the warmup steps
     # timed region: HIP events around the row-AND kernel only (every event record costs the stream 5-7 us)
@@ -307,6 +318,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    collect()                      # the last batch's share, inside the timed region
     sync_all()
     elapsed = time.perf_counter() - t0
     if use_dist:
