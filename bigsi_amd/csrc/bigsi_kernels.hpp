@@ -1512,7 +1512,8 @@ __device__ __forceinline__ uint64_t transpose64_lanes(uint64_t a64, uint32_t lan
 __global__ __launch_bounds__(kBlock) void k_transpose_tiles(
     uint64_t *__restrict__ index, uint64_t stride_words, uint64_t m, uint64_t w_first /* first column word written; even */,
     uint64_t n_words /* whole 64-column words to write */, const uint8_t *__restrict__ blooms /* filter of column 64 * w_first */,
-    uint64_t bstride /* bytes between filters; multiple of 16 */, uint64_t nb /* valid bytes of a filter: ceil(m / 8) */)
+    uint64_t bstride /* bytes between filters; multiple of 16 */, uint64_t nb /* valid bytes of a filter: ceil(m / 8) */,
+    uint32_t rg, uint32_t cg /* tiles per XCD group along rows / columns: powers of two, rg * cg <= 128 */)
 {
     // ONE tile buffer: line L holds, before the transpose, the 64 row-bytes of column L and, after it, the 64 column-bytes
     // of row L.  Block (cw, rc) of 64 x 64 bits sits at lines [64 cw, +64), bytes [8 rc, +8) and its transpose belongs at
@@ -1523,9 +1524,15 @@ __global__ __launch_bounds__(kBlock) void k_transpose_tiles(
     // workgroup -> tile in SUPERTILES of 32 x 32 tiles: the ~1000 workgroups resident at any time then read 2 KB runs of
     // each filter and write 2 KB runs of each row (DRAM-page sized), instead of 64-byte pieces strided by a whole row or filter
     const uint64_t tiles_c = (n_words + 7) / 8, sup_c = (tiles_c + kTransposeSuper - 1) / kTransposeSuper;
-    const uint64_t sup = blockIdx.x / (kTransposeSuper * kTransposeSuper), within = blockIdx.x % (kTransposeSuper * kTransposeSuper);
-    const uint64_t tile_r = (sup / sup_c) * kTransposeSuper + within % kTransposeSuper;
-    const uint64_t tile_c = (sup % sup_c) * kTransposeSuper + within / kTransposeSuper;
+    const uint64_t sup = blockIdx.x / (kTransposeSuper * kTransposeSuper);
+    const uint32_t within = blockIdx.x % (kTransposeSuper * kTransposeSuper);
+    // inside a supertile: groups of rg x cg neighbouring tiles go to the SAME XCD (block b runs on XCD b % 8), one right after
+    // the other: row-neighbours share the 128-byte lines of the filters, column-neighbours those of the rows, and with
+    // consecutive blocks they landed in different L2s (FETCH_SIZE showed every filter line read about twice)
+    const uint32_t gsz = rg * cg, xcd = within & 7u, sl = within >> 3, t = sl % gsz, g = (sl / gsz) * 8u + xcd;
+    const uint32_t gpr = kTransposeSuper / cg;      // groups per supertile row of groups
+    const uint64_t tile_r = (sup / sup_c) * kTransposeSuper + (g / gpr) * rg + t % rg;
+    const uint64_t tile_c = (sup % sup_c) * kTransposeSuper + (g % gpr) * cg + t / rg;
     if (tile_r * kTransposeTile >= m || tile_c >= tiles_c) return;
     const uint64_t r0 = tile_r * kTransposeTile, byte0 = tile_r * (kTransposeTile / 8);
     const uint64_t w0 = tile_c * 8;
