@@ -1509,6 +1509,7 @@ __device__ __forceinline__ uint64_t transpose64_lanes(uint64_t a64, uint32_t lan
     return ((uint64_t)hi << 32) | lo;
 }
 
+template <int RT>      // RT = 1: one 512-row tile per workgroup (64-byte filter runs); 2: two stacked tiles, their 128-byte filter runs loaded in one go
 __global__ __launch_bounds__(kBlock) void k_transpose_tiles(
     uint64_t *__restrict__ index, uint64_t stride_words, uint64_t m, uint64_t w_first /* first column word written; even */,
     uint64_t n_words /* whole 64-column words to write */, const uint8_t *__restrict__ blooms /* filter of column 64 * w_first */,
@@ -1533,33 +1534,41 @@ __global__ __launch_bounds__(kBlock) void k_transpose_tiles(
     const uint32_t gpr = kTransposeSuper / cg;      // groups per supertile row of groups
     const uint64_t tile_r = (sup / sup_c) * kTransposeSuper + (g / gpr) * rg + t % rg;
     const uint64_t tile_c = (sup % sup_c) * kTransposeSuper + (g % gpr) * cg + t / rg;
-    if (tile_r * kTransposeTile >= m || tile_c >= tiles_c) return;
-    const uint64_t r0 = tile_r * kTransposeTile, byte0 = tile_r * (kTransposeTile / 8);
+    if (tile_r * kTransposeTile * RT >= m || tile_c >= tiles_c) return;
+    const uint64_t byte0 = tile_r * (kTransposeTile / 8) * RT;
     const uint64_t w0 = tile_c * 8;
     const uint32_t words_here = (uint32_t)(n_words - w0 < 8 ? n_words - w0 : 8), cols_here = words_here * 64;
     // phase 1: 64 bytes of each column's filter -> tile[col][0..64) (columns beyond the last word: zeros).  A 16-byte load
     // that starts inside the filter's pitch is always in bounds (pitch and offsets are multiples of 16); bytes past
     // ceil(m / 8), like bits past m inside the last byte, belong to rows >= m, which phase 3 never stores.
-    u64x2 ld[kTransposeTile * 4 / kBlock];
+    // (RT = 2: 8 lanes x 16 bytes = one whole 128-byte line per filter and wave instruction; a thread's parts all have the
+    // same index, so its loads all belong to the same one of the two stacked tiles)
+    constexpr int kParts = 4 * RT, kLoads = kTransposeTile * kParts / kBlock;
+    u64x2 ld[kLoads];
 #pragma unroll
-    for (int it = 0; it < kTransposeTile * 4 / kBlock; it++) {
-        const uint32_t item = it * kBlock + threadIdx.x, col = item >> 2, part = item & 3u;
+    for (int it = 0; it < kLoads; it++) {
+        const uint32_t item = it * kBlock + threadIdx.x, col = item / kParts, part = item % kParts;
         const uint64_t off = byte0 + part * 16;
         const bool ok = col < cols_here && off + 16 <= bstride && off < nb;
         const u64x2 *src = reinterpret_cast<const u64x2 *>(blooms + (w0 * 64 + (ok ? col : 0)) * bstride + (ok ? off : 0));
         ld[it] = ok ? __builtin_nontemporal_load(src) : u64x2{0ull, 0ull};
     }
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t mycol = bit_of_col(lane);
 #pragma unroll
-    for (int it = 0; it < kTransposeTile * 4 / kBlock; it++) {
-        const uint32_t item = it * kBlock + threadIdx.x, col = item >> 2, part = item & 3u;
-        uint64_t *d = reinterpret_cast<uint64_t *>(tile + col * kTransposePitch + part * 16);
+    for (int half = 0; half < RT; half++) {
+    const uint64_t r0 = (tile_r * RT + half) * kTransposeTile;
+    if (half) __syncthreads();                          // phase 3 of the first tile has read the buffer
+#pragma unroll
+    for (int it = 0; it < kLoads; it++) {
+        const uint32_t item = it * kBlock + threadIdx.x, col = item / kParts, part = item % kParts;
+        if ((int)(part >> 2) != half) continue;
+        uint64_t *d = reinterpret_cast<uint64_t *>(tile + col * kTransposePitch + (part & 3u) * 16);
         d[0] = ld[it].x;
         d[1] = ld[it].y;
     }
     __syncthreads();
     // phase 2: the 36 unordered pairs {(cw, rc), (rc, cw)} of the 8 x 8 blocks, nine per wavefront
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t mycol = bit_of_col(lane);
     for (uint32_t pi = wave; pi < 36; pi += kBlock / 64) {
         // pi -> (x, y) with x <= y: row y of the lower triangle starts at y (y + 1) / 2
         uint32_t y = 0;
@@ -1587,6 +1596,7 @@ __global__ __launch_bounds__(kBlock) void k_transpose_tiles(
         uint64_t *dst = index + r * stride_words + w_first + w0 + part * 2;
         if (part * 2 + 1 < words_here) __builtin_nontemporal_store(u64x2{sp[0], sp[1]}, reinterpret_cast<u64x2 *>(dst));
         else dst[0] = sp[0];
+    }
     }
 }
 
