@@ -15,6 +15,16 @@
  *   - one index / batch handle may be used from one host thread at a time; distinct handles are
  *     independent.  HIP contexts do not survive fork(): open after forking (bulk_search,
  *     bigsi/__main__.py:273-287, forks one worker per chunk).
+ *   - LAYERS.  A binder needs only what its host does:
+ *       CORE       index lifecycle + storage contract + bigsi_hip_lookup + bigsi_hip_search_batch (the whole of
+ *                  BIGSI.search for a batch in ONE call) + bigsi_hip_batch_presence_hits: enough for any host.
+ *       BATCHES    bigsi_hip_batch_*: staged workspaces and asynchronous runs for serving loops.
+ *       MULTI-GPU  bigsi_hip_comm_* / batch_set_comm / batch_run_sharded (one process per GPU) and bigsi_hip_group_*
+ *                  (one process, N GPUs): the RCCL exchange is issued by the library.
+ *       EXCHANGE-BY-CALLER  set_stream, batch_set_outputs / set_result_cols / set_gather_stream / compact_gathered*,
+ *                  set_gathered_hit_outputs: for hosts that bring their own collective (gloo in the tests).
+ *       MEASUREMENT  fill_synthetic, insert_columns_device, set_profiling, stats, the BIGSI_RUN_* test flags.
+ *     The library reads no environment variables (tuning knobs exist only in builds made with -DBIGSI_HIP_TUNING).
  *   - ROW FORMAT: a row is the reference's `bitarray.tobytes()` (bigsi/storage/base.py:85-99):
  *     ceil(num_cols/8) bytes, column c at byte c/8 under mask 0x80 >> (c%8), zero pad bits.
  *     The device stores exactly these bytes, zero-extended to a 128-byte-multiple row stride.
@@ -42,7 +52,7 @@ typedef struct bigsi_hip_batch bigsi_hip_batch; /* one batch of query sequences 
 const char *bigsi_hip_last_error(void);
 int bigsi_hip_device_count(int *out);
 
-/* ------------------------------------------------------------------ index lifecycle
+/* ================================================================== CORE: index lifecycle
  * Replaces opening a KV store and reading its four integers: BerkeleyDBStorage.__init__
  * (bigsi/storage/berkeleydb.py:6-19), BitMatrix.__init__ (bigsi/matrix/bitmatrix.py:14-17),
  * KmerSignatureIndex.__init__ (bigsi/graph/index.py:21-25).  Rows start out all-zero. */
@@ -75,7 +85,7 @@ int bigsi_hip_reserve_cols(bigsi_hip_index *ix, uint64_t col_capacity);
 int bigsi_hip_set_stream(bigsi_hip_index *ix, void *hip_stream);
 int bigsi_hip_synchronize(bigsi_hip_index *ix);
 
-/* ------------------------------------------------------------- storage contract
+/* ================================================================== CORE: storage contract
  * BaseStorage.set_bitarrays / get_bitarrays / batch_set / batch_get over "<row>:bitarray" keys
  * (bigsi/storage/base.py:43-59, 85-109): n rows of row_bytes bytes each, packed, in row_ids order.
  * row_bytes may be anything up to the stride; bytes beyond it are zeroed (set) / not returned (get). */
@@ -117,7 +127,7 @@ int bigsi_hip_fill_synthetic(bigsi_hip_index *ix, uint64_t seed, uint64_t shard,
 #define BIGSI_BLOOM_RAW 1u
 int bigsi_hip_bloom(int device, const char *kmers, uint64_t u, uint32_t k, uint64_t m, uint32_t h, uint32_t flags, uint8_t *out);
 
-/* -------------------------------------------------------------- fused query path
+/* ================================================================== BATCHES (and CORE: bigsi_hip_lookup): fused query path
  * One batch = n_seqs query sequences (ASCII, concatenated; sequence i = seqs[offsets[i] .. offsets[i+1])).
  * create  uploads them and sizes the device workspace.
  * run     launches, asynchronously on the index's stream, the whole of BIGSI.search up to the hit list
@@ -206,7 +216,7 @@ int bigsi_hip_batch_presence(bigsi_hip_batch *b, uint32_t seq, const uint32_t *c
 int bigsi_hip_batch_presence_hits(bigsi_hip_batch *b, const uint64_t *hit_offsets, const uint32_t *colours, uint8_t *out,
                                   uint64_t out_capacity, uint64_t *string_offsets);
 
-/* Multi-GPU assembly: compact hits from result buffers gathered from n_shards column shards (device pointer,
+/* EXCHANGE-BY-CALLER.  Multi-GPU assembly: compact hits from result buffers gathered from n_shards column shards (device pointer,
  * layout [shard][seq][stride] with this batch's strides; colour = shard * shard_cols + local column).
  * compact_gathered* are asynchronous, also for the host: they are queued (on the gather stream, below) behind this batch's
  * run through an event, never by waiting for it -- call them after the RCCL all-gather, which the caller issues on the
@@ -228,7 +238,7 @@ int bigsi_hip_batch_compact_gathered_masks(bigsi_hip_batch *b, const void *d_gat
 int bigsi_hip_batch_set_gathered_hit_outputs(bigsi_hip_batch *b, void *d_colours, void *d_counts, uint64_t capacity);
 int bigsi_hip_batch_fetch_gathered_hits(bigsi_hip_batch *b, uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t capacity);
 
-/* ------------------------------------------------------------------ one-call search
+/* ================================================================== CORE: one-call search
  * The whole of BIGSI.search for a batch of sequences in ONE call (what a non-Python binder of this boundary needs):
  * create + run + fetch_unique + fetch_hits + destroy.  Outputs as in fetch_unique / fetch_hits; any of num_kmers /
  * num_unique / min_kmers may be NULL.  BIGSI_ERR_CAPACITY (hit_offsets filled) when hit_capacity is too small. */
@@ -236,7 +246,7 @@ int bigsi_hip_search_batch(bigsi_hip_index *ix, const char *seqs, const uint64_t
                            double threshold, uint32_t flags, uint32_t *num_kmers, uint32_t *num_unique, uint32_t *min_kmers,
                            uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t hit_capacity);
 
-/* ------------------------------------------------------------------ column shards: the exchange (RCCL over xGMI)
+/* ================================================================== MULTI-GPU: column shards, the exchange (RCCL over xGMI)
  * An index too wide for one GPU is split by COLUMN RANGE: shard g holds all num_rows rows of columns
  * [g * shard_cols, (g+1) * shard_cols).  Every shard runs K1-K3 on the same queries; the only exchange is one
  * ncclAllGather per batch of ONE BIT PER SAMPLE (the AND bitmap, or the count >= min_kmers mask of a thresholded search)
@@ -308,7 +318,7 @@ int bigsi_hip_group_search_batch(bigsi_hip_group *g, const char *seqs, const uin
                                  double threshold, uint32_t flags, uint32_t *num_kmers, uint32_t *num_unique, uint32_t *min_kmers,
                                  uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t hit_capacity);
 
-/* ------------------------------------------------------------------ measurement */
+/* ================================================================== MEASUREMENT */
 typedef struct {
     uint64_t and_launches;   /* row-fetch-AND kernel launches timed since the last reset   */
     double and_ms;           /* their summed duration (HIP events on the launch stream)     */
