@@ -85,6 +85,8 @@ SIGNATURES = {
     "bigsi_hip_bloom": (_i32, [_i32, C.c_char_p, _u64, _u32, _u64, _u32, _u32, _P]),
     "bigsi_hip_lookup": (_i32, [_P, C.c_char_p, _u32, _u64, _P]),
     "bigsi_hip_batch_create": (_i32, [_P, C.c_char_p, _P, _u32, _u32, C.POINTER(_P)]),
+    "bigsi_hip_batch_create_elements": (_i32, [_P, C.c_char_p, _P, _P, _P, _P, _u32, C.POINTER(_P)]),
+    "bigsi_hip_lookup_raw": (_i32, [_P, C.c_char_p, _P, _u64, _P]),
     "bigsi_hip_batch_destroy": (_i32, [_P]),
     "bigsi_hip_batch_reload": (_i32, [_P, C.c_char_p, _P, _u32, _u32]),
     "bigsi_hip_batch_run": (_i32, [_P, _dbl, _u32]),
@@ -128,6 +130,8 @@ SIGNATURES = {
     "bigsi_hip_group_fill_synthetic": (_i32, [_P, _u64, _u32]),
     "bigsi_hip_group_lookup": (_i32, [_P, C.c_char_p, _u32, _u64, _P]),
     "bigsi_hip_group_batch_create": (_i32, [_P, C.c_char_p, _P, _u32, _u32, C.POINTER(_P)]),
+    "bigsi_hip_group_batch_create_elements": (_i32, [_P, C.c_char_p, _P, _P, _P, _P, _u32, C.POINTER(_P)]),
+    "bigsi_hip_group_lookup_raw": (_i32, [_P, C.c_char_p, _P, _u64, _P]),
     "bigsi_hip_group_batch_reload": (_i32, [_P, C.c_char_p, _P, _u32, _u32]),
     "bigsi_hip_group_batch_destroy": (_i32, [_P]),
     "bigsi_hip_group_batch_run": (_i32, [_P, _dbl, _u32]),
@@ -189,7 +193,8 @@ def ptr(a):
 
 def pack_seqs(seqs):
     """list of str/bytes -> (blob bytes, uint64 offsets[n+1]).  Sequences must be ASCII: the reference hashes the
-    UTF-8 bytes of k *characters* (mmh3.hash(str)); for ASCII that is k bytes, which is what the kernels window."""
+    UTF-8 bytes of k *characters* (mmh3.hash(str)); for ASCII that is k bytes, which is what the kernels window.  Callers
+    route non-ASCII text through the element batches instead (BIGSI._elements_of, bigsi_hip_batch_create_elements)."""
     if not isinstance(seqs, (list, tuple)):
         seqs = list(seqs)
     if seqs and all(type(s) is str for s in seqs):

@@ -14,17 +14,25 @@ DEFAULT_DEVICE = 0
 
 def _device_bloom(elements, m, h, raw, device=None):
     """uint8[ceil(m/8)]: the m-bit filter of `elements` (strings of any one length per call group)."""
+    from .utils import canonical
     out = np.zeros((int(m) + 7) // 8, dtype=np.uint8)
-    by_len = {}
-    for e in elements:
-        by_len.setdefault(len(e), []).append(e)
     dev = DEFAULT_DEVICE if device is None else device
-    for k, group in by_len.items():
+    # The reference hashes the UTF-8 bytes of k CHARACTERS (bloomfilter.py:5-6).  ASCII elements go to the device as they are
+    # (it canonicalises byte-wise, which is character-wise for ASCII); anything else is canonicalised here, character by
+    # character as utils/fncts.py:38-54 does, and hashed raw on the device as its UTF-8 bytes.
+    groups = {}
+    for e in elements:
+        if isinstance(e, str) and not e.isascii():
+            data = (e if raw else canonical(e)).encode("utf-8")
+            groups.setdefault((len(data), True), []).append(data)
+        else:
+            groups.setdefault((len(e), raw), []).append(e)
+    for (k, as_is), group in groups.items():
         if k == 0:
             raise ValueError("cannot hash an empty element")
-        blob, _ = _lib.pack_seqs(group)
+        blob, _ = _lib.pack_seqs(group) if not isinstance(group[0], bytes) else (b"".join(group), None)
         part = np.zeros_like(out)
-        check(_lib.lib().bigsi_hip_bloom(dev, blob, len(group), k, int(m), int(h), _lib.BLOOM_RAW if raw else 0, _lib.ptr(part)))
+        check(_lib.lib().bigsi_hip_bloom(dev, blob, len(group), k, int(m), int(h), _lib.BLOOM_RAW if as_is else 0, _lib.ptr(part)))
         out |= part
     return out
 

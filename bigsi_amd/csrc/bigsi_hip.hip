@@ -632,9 +632,100 @@ extern "C" int bigsi_hip_batch_create(bigsi_hip_index *ix, const char *seqs, con
     return BIGSI_OK;
 }
 
+extern "C" int bigsi_hip_batch_create_elements(bigsi_hip_index *ix, const char *blob, const uint64_t *elem_offsets, const uint64_t *seq_elem_offsets,
+                                               const uint32_t *pos_unique, const uint64_t *seq_pos_offsets, uint32_t n_seqs, bigsi_hip_batch **out)
+{
+    if (!out) return fail(BIGSI_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!ix || !elem_offsets || !seq_elem_offsets || !seq_pos_offsets) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    if (n_seqs == 0) return fail(BIGSI_ERR_INVALID, "a batch needs at least one sequence");
+    const uint64_t e_base = seq_elem_offsets[0], n_elems = seq_elem_offsets[n_seqs] - e_base;
+    const uint64_t p_base = seq_pos_offsets[0], n_pos = seq_pos_offsets[n_seqs] - p_base;
+    if (n_pos && !pos_unique) return fail(BIGSI_ERR_INVALID, "pos_unique is NULL");
+    if (n_pos > 0xFFFFFFF0ull) return fail(BIGSI_ERR_INVALID, "too many k-mer positions");
+    const uint64_t b_base = elem_offsets[e_base], n_bytes = elem_offsets[e_base + n_elems] - b_base;
+    if (n_bytes && !blob) return fail(BIGSI_ERR_INVALID, "blob is NULL");
+    TRY(use_device(ix));
+    bigsi_hip_batch *b = new (std::nothrow) bigsi_hip_batch();
+    if (!b) return fail(BIGSI_ERR_NOMEM, "host allocation failed");
+    b->ix = ix;
+    b->n_seqs = n_seqs;
+    b->k = 0;
+    b->elements = true;
+    b->pos_off.resize(n_seqs + 1);
+    b->seq_off.resize(n_elems + 1);              // element byte offsets (relative)
+    std::vector<uint64_t> eso(n_seqs + 1);
+    std::vector<uint32_t> first(std::max<uint64_t>(n_pos, 1)), rep(std::max<uint64_t>(n_pos, 1));
+    int rc = BIGSI_OK;
+    for (uint64_t e = 0; e <= n_elems && rc == BIGSI_OK; e++) {
+        if (e && elem_offsets[e_base + e] < elem_offsets[e_base + e - 1]) rc = fail(BIGSI_ERR_INVALID, "elem_offsets must be non-decreasing");
+        b->seq_off[e] = elem_offsets[e_base + e] - b_base;
+    }
+    for (uint32_t i = 0; i <= n_seqs; i++) {
+        b->pos_off[i] = seq_pos_offsets[i] - p_base;
+        eso[i] = seq_elem_offsets[i] - e_base;
+    }
+    for (uint32_t i = 0; i < n_seqs && rc == BIGSI_OK; i++) {
+        if (b->pos_off[i + 1] < b->pos_off[i] || eso[i + 1] < eso[i]) { rc = fail(BIGSI_ERR_INVALID, "offsets must be non-decreasing"); break; }
+        const uint64_t n = b->pos_off[i + 1] - b->pos_off[i], u = eso[i + 1] - eso[i];
+        if (u > n) { rc = fail(BIGSI_ERR_INVALID, "sequence %u lists %llu unique k-mers for %llu positions", i, (unsigned long long)u, (unsigned long long)n); break; }
+        const uint32_t *pu = pos_unique + p_base + b->pos_off[i];
+        uint32_t *fp = first.data() + b->pos_off[i], *rp = rep.data() + b->pos_off[i];
+        for (uint64_t j = 0; j < u; j++) fp[j] = 0xFFFFFFFFu;
+        for (uint64_t t = 0; t < n && rc == BIGSI_OK; t++) {
+            if (pu[t] >= u) rc = fail(BIGSI_ERR_RANGE, "pos_unique[%llu] of sequence %u is %u, beyond its %llu unique k-mers", (unsigned long long)t, i, pu[t], (unsigned long long)u);
+            else if (fp[pu[t]] == 0xFFFFFFFFu) fp[pu[t]] = (uint32_t)t;
+        }
+        for (uint64_t j = 0; j < u && rc == BIGSI_OK; j++)
+            if (fp[j] == 0xFFFFFFFFu) rc = fail(BIGSI_ERR_INVALID, "unique k-mer %llu of sequence %u occurs at no position", (unsigned long long)j, i);
+        for (uint64_t t = 0; t < n && rc == BIGSI_OK; t++) rp[t] = fp[pu[t]];
+        b->max_pos = std::max(b->max_pos, n);
+    }
+    b->total_pos = n_pos;
+    const uint64_t T = std::max<uint64_t>(n_pos, 1);
+    auto R = [&](DevBuf &d, size_t bytes) { if (rc == BIGSI_OK) rc = d.reserve(bytes); };
+    R(b->seqs, std::max<uint64_t>(n_bytes, 1));
+    R(b->d_seq_off, (n_elems + 1) * 8);
+    R(b->elem_seq_off, (n_seqs + 1) * 8ull);
+    R(b->d_pos_off, (n_seqs + 1) * 8ull);
+    R(b->first_pos, T * 4);
+    R(b->pos_unique, T * 4);
+    R(b->rep, T * 4);
+    R(b->rows, T * ix->h * 8);
+    R(b->num_kmers, n_seqs * 4ull);
+    R(b->num_unique, n_seqs * 4ull);
+    R(b->min_kmers, n_seqs * 4ull);
+    auto H2D = [&](void *dst, const void *src, size_t bytes) {
+        if (rc == BIGSI_OK && bytes) {
+            hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ix->pre_stream);
+            if (e != hipSuccess) rc = fail(BIGSI_ERR_HIP, "H2D copy: %s", hipGetErrorString(e));
+        }
+    };
+    H2D(b->seqs.p, blob ? blob + b_base : nullptr, n_bytes);
+    H2D(b->d_seq_off.p, b->seq_off.data(), (n_elems + 1) * 8);
+    H2D(b->elem_seq_off.p, eso.data(), (n_seqs + 1) * 8ull);
+    H2D(b->d_pos_off.p, b->pos_off.data(), (n_seqs + 1) * 8ull);
+    H2D(b->first_pos.p, first.data(), n_pos * 4);
+    H2D(b->pos_unique.p, pos_unique ? pos_unique + p_base : nullptr, n_pos * 4);
+    H2D(b->rep.p, rep.data(), n_pos * 4);
+    if (rc == BIGSI_OK) {
+        hipError_t e = hipStreamSynchronize(ix->pre_stream);
+        if (e != hipSuccess) rc = fail(BIGSI_ERR_HIP, "sync: %s", hipGetErrorString(e));
+    }
+    if (rc != BIGSI_OK) {
+        char keep[1024];
+        snprintf(keep, sizeof keep, "%s", bigsi_hip_last_error());
+        bigsi_hip_batch_destroy(b);
+        return fail(rc, "%s", keep);
+    }
+    *out = b;
+    return BIGSI_OK;
+}
+
 extern "C" int bigsi_hip_batch_reload(bigsi_hip_batch *b, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k)
 {
     if (!b) return fail(BIGSI_ERR_INVALID, "NULL batch");
+    if (b->elements) return fail(BIGSI_ERR_STATE, "a batch of explicit k-mers cannot be reloaded: create a new one");
     TRY(check_batch_args(b->ix, seqs, offsets, n_seqs, k));
     TRY(use_device(b->ix));
     // only THIS batch's earlier work has to be over before its buffers are rewritten: other batches may still be running
@@ -650,7 +741,7 @@ extern "C" int bigsi_hip_batch_destroy(bigsi_hip_batch *b)
     e = hipStreamSynchronize(b->ix->stream);
     if (b->gstream && b->g_done) e = hipEventSynchronize(b->g_done);
     (void)e;
-    for (DevBuf *d : {&b->pres_in, &b->pres_bits, &b->pres_out, &b->rows_sorted, &b->pos_query, &b->hsh, &b->rep, &b->seqs, &b->d_seq_off, &b->d_pos_off, &b->d_tab_off, &b->tab, &b->first_pos, &b->pos_unique, &b->tmp, &b->rows,
+    for (DevBuf *d : {&b->elem_seq_off, &b->pres_in, &b->pres_bits, &b->pres_out, &b->rows_sorted, &b->pos_query, &b->hsh, &b->rep, &b->seqs, &b->d_seq_off, &b->d_pos_off, &b->d_tab_off, &b->tab, &b->first_pos, &b->pos_unique, &b->tmp, &b->rows,
                       &b->num_kmers, &b->num_unique, &b->min_kmers, &b->bitmaps, &b->counts, &b->scratch})
         d->release();
     b->hits.release();
@@ -818,6 +909,16 @@ static int run_kmerize(bigsi_hip_batch *b, double threshold, bool force_global =
     // (on the index stream itself the callers' own ordering applies, as for every other entry point)
     if (b->g_done && b->gstream && b->gstream != ks) HIP_TRY(hipStreamWaitEvent(ks, b->g_done, 0));
     TRY(b->rows.reserve(std::max<uint64_t>(b->total_pos, 1) * ix->h * 8));
+    if (b->elements) {       // explicit k-mers: only the hashing is left of K1
+        TRY(ev_begin(ix, &ep, ks));
+        hipLaunchKernelGGL(k_rows_raw, dim3(b->n_seqs), dim3(kBlock), 0, ks, b->seqs.as<char>(), b->d_seq_off.as<uint64_t>(), b->elem_seq_off.as<uint64_t>(),
+                           b->d_pos_off.as<uint64_t>(), ix->h, ix->m, threshold, b->rows.as<uint64_t>(), b->num_kmers.as<uint32_t>(),
+                           b->num_unique.as<uint32_t>(), b->min_kmers.as<uint32_t>());
+        HIP_TRY(hipGetLastError());
+        TRY(ev_end(ix, &ep, ix->ev_km, ks));
+        b->run_h = ix->h;
+        return BIGSI_OK;
+    }
     static const int k1_global = env_int("BIGSI_HIP_K1_GLOBAL", 0);
     static const int k1_wave = env_int("BIGSI_HIP_K1_WAVE", 1);
     if (!force_global && !k1_global && k1_wave && b->max_pos <= 64) {
@@ -1606,6 +1707,39 @@ extern "C" int bigsi_hip_lookup(bigsi_hip_index *ix, const char *kmers, uint32_t
             if (e == hipSuccess) e = hipMemcpy2DAsync(out_rows, rb, b->scratch.p, wv * 8, rb, u, hipMemcpyDeviceToHost, ix->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
             if (e != hipSuccess) rc = fail(BIGSI_ERR_HIP, "bigsi_hip_lookup: %s", hipGetErrorString(e));
+        }
+    }
+    bigsi_hip_batch_destroy(b);
+    return rc;
+}
+
+// KmerSignatureIndex.lookup for explicit, already canonical elements of any byte lengths (non-ASCII k-mers): every element is
+// its own one-position sequence of an element batch, k_rows_raw hashes them, one k_lookup launch ANDs their rows.
+extern "C" int bigsi_hip_lookup_raw(bigsi_hip_index *ix, const char *blob, const uint64_t *elem_offsets, uint64_t u, uint8_t *out_rows)
+{
+    if (!ix || (u && (!elem_offsets || !out_rows))) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    if (u == 0) return BIGSI_OK;
+    if (u > 0x7FFFFFFFull) return fail(BIGSI_ERR_INVALID, "too many k-mers for one call");
+    if (ix->n_cols == 0) return fail(BIGSI_ERR_STATE, "index has no columns");
+    std::vector<uint64_t> one(u + 1);
+    std::vector<uint32_t> zero(u, 0u);
+    for (uint64_t i = 0; i <= u; i++) one[i] = i;
+    bigsi_hip_batch *b = nullptr;
+    TRY(bigsi_hip_batch_create_elements(ix, blob, elem_offsets, one.data(), zero.data(), one.data(), (uint32_t)u, &b));
+    int rc = run_kmerize(b, 1.0);
+    if (rc == BIGSI_OK) rc = k1_publish(b);
+    const uint64_t wv = ix->wv(), rb = ix->rb();
+    if (rc == BIGSI_OK) rc = b->scratch.reserve((size_t)u * wv * 8);
+    if (rc == BIGSI_OK) {
+        const uint64_t wblocks = ceil_div(wv, kBlock);
+        if (wblocks * u > 0x7FFFFFFFull) rc = fail(BIGSI_ERR_INVALID, "lookup too large for one launch");
+        else {
+            hipLaunchKernelGGL(k_lookup, dim3((unsigned)(wblocks * u)), dim3(kBlock), 0, ix->stream, ix->d_index, ix->stride_words, (uint32_t)wv,
+                               b->rows.as<uint64_t>(), ix->h, (uint32_t)u, b->scratch.as<uint64_t>());
+            hipError_t e = hipGetLastError();
+            if (e == hipSuccess) e = hipMemcpy2DAsync(out_rows, rb, b->scratch.p, wv * 8, rb, u, hipMemcpyDeviceToHost, ix->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+            if (e != hipSuccess) rc = fail(BIGSI_ERR_HIP, "bigsi_hip_lookup_raw: %s", hipGetErrorString(e));
         }
     }
     bigsi_hip_batch_destroy(b);

@@ -128,6 +128,8 @@ struct bigsi_hip_batch {
     bool pos_query_loaded = false;    // pos_query holds this load's position -> sequence map
     bool local_from_counts = false;   // the last counting run was row-sliced: hits come from thresholding the counters
     bool fused_run = false;           // the last run was the one-launch read kernel (k_reads_fused)
+    bool elements = false;            // k-mers were given explicitly (bigsi_hip_batch_create_elements): K1 = k_rows_raw
+    DevBuf elem_seq_off;              // elements: first element of every sequence
     uint32_t count_bytes = 2;
     double threshold = 1.0;
     uint64_t wv = 0, wv_pad = 0;   // valid / padded words per row at run time

@@ -488,6 +488,31 @@ __global__ __launch_bounds__(1024) void k_kmerize_lds(
     }
 }
 
+// K1 for batches whose k-mers arrive as explicit byte strings ("elements", bigsi_hip_batch_create_elements): the host has
+// k-merised, deduplicated and canonicalised (a non-ASCII query: the reference windows k CHARACTERS and hashes their UTF-8 bytes,
+// utils/fncts.py:38-65, bloom/bloomfilter.py:5-6); what is left of K1 is MurmurHash3 over each element's bytes with seeds
+// 0..h-1, the floor-mod, and min_kmers.
+__global__ __launch_bounds__(kBlock) void k_rows_raw(
+    const char *__restrict__ blob, const uint64_t *__restrict__ elem_off, const uint64_t *__restrict__ seq_elem_off,
+    const uint64_t *__restrict__ pos_off, uint32_t h, uint64_t m, double threshold, uint64_t *__restrict__ rows,
+    uint32_t *__restrict__ num_kmers, uint32_t *__restrict__ num_unique, uint32_t *__restrict__ min_kmers)
+{
+    const uint32_t q = blockIdx.x;
+    const uint64_t e0 = seq_elem_off[q], P0 = pos_off[q];
+    const uint32_t u = (uint32_t)(seq_elem_off[q + 1] - e0);
+    for (uint32_t j = threadIdx.x; j < u; j += kBlock) {
+        const uint64_t a = elem_off[e0 + j];
+        const KmerView v{blob + a, (uint32_t)(elem_off[e0 + j + 1] - a), false};
+        for (uint32_t sd = 0; sd < h; sd++) rows[(P0 + j) * h + sd] = row_of_hash(murmur3_32(v, sd), m);
+    }
+    if (threadIdx.x == 0) {
+        num_kmers[q] = (uint32_t)(pos_off[q + 1] - P0);
+        num_unique[q] = u;
+        const double mk = ceil((double)u * threshold);
+        min_kmers[q] = mk > 0.0 ? (uint32_t)mk : 0u;
+    }
+}
+
 // K1 for probe / read-length queries (at most 64 k-mer positions, e.g. the 61-mers of BASELINE config 2): ONE WAVEFRONT
 // PER QUERY, four queries per workgroup, lane i = position i.  Duplicates are found by broadcasting each lane's dedupe
 // hash in turn (64 shuffles, string compare only on a hash match), first occurrences are ranked with ballot + popcount:

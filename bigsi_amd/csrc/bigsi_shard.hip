@@ -560,9 +560,26 @@ extern "C" int bigsi_hip_group_lookup(bigsi_hip_group *g, const char *kmers, uin
     return BIGSI_OK;
 }
 
+extern "C" int bigsi_hip_group_lookup_raw(bigsi_hip_group *g, const char *blob, const uint64_t *elem_offsets, uint64_t u, uint8_t *out_rows)
+{
+    if (!g || (u && (!blob || !elem_offsets || !out_rows))) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    if (g->n_cols == 0) return fail(BIGSI_ERR_STATE, "index has no columns");
+    const uint64_t rb = ceil_div(g->n_cols, 8), sb = g->shard_cols / 8;
+    std::vector<uint8_t> part;
+    for (uint32_t i = 0; i < g->n(); i++) {
+        const uint64_t nc = g->cols_of(i, g->n_cols);
+        if (!nc) break;
+        const uint64_t w = ceil_div(nc, 8);
+        part.resize(u * w);
+        TRY(bigsi_hip_lookup_raw(g->ix[i], blob, elem_offsets, u, part.data()));
+        for (uint64_t r = 0; r < u; r++) memcpy(out_rows + r * rb + (uint64_t)i * sb, part.data() + r * w, w);
+    }
+    return BIGSI_OK;
+}
+
 // ---- fused query path over all shards
-extern "C" int bigsi_hip_group_batch_create(bigsi_hip_group *g, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k,
-                                            bigsi_hip_group_batch **out)
+// one member batch per shard (made by `make`), each bound to its shard's communicator
+template <typename Make> static int group_batch_new(bigsi_hip_group *g, bigsi_hip_group_batch **out, Make make)
 {
     if (!g || !out) return fail(BIGSI_ERR_INVALID, "NULL argument");
     *out = nullptr;
@@ -572,7 +589,7 @@ extern "C" int bigsi_hip_group_batch_create(bigsi_hip_group *g, const char *seqs
     int rc = BIGSI_OK;
     for (uint32_t i = 0; i < g->n() && rc == BIGSI_OK; i++) {
         bigsi_hip_batch *b = nullptr;
-        rc = bigsi_hip_batch_create(g->ix[i], seqs, offsets, n_seqs, k, &b);
+        rc = make(g->ix[i], &b);
         if (rc == BIGSI_OK) {
             gb->b.push_back(b);
             rc = bigsi_hip_batch_set_comm(b, g->comm[i], g->shard_cols);
@@ -586,6 +603,21 @@ extern "C" int bigsi_hip_group_batch_create(bigsi_hip_group *g, const char *seqs
     }
     *out = gb;
     return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_group_batch_create(bigsi_hip_group *g, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k,
+                                            bigsi_hip_group_batch **out)
+{
+    return group_batch_new(g, out, [&](bigsi_hip_index *ix, bigsi_hip_batch **b) { return bigsi_hip_batch_create(ix, seqs, offsets, n_seqs, k, b); });
+}
+
+extern "C" int bigsi_hip_group_batch_create_elements(bigsi_hip_group *g, const char *blob, const uint64_t *elem_offsets,
+                                                     const uint64_t *seq_elem_offsets, const uint32_t *pos_unique,
+                                                     const uint64_t *seq_pos_offsets, uint32_t n_seqs, bigsi_hip_group_batch **out)
+{
+    return group_batch_new(g, out, [&](bigsi_hip_index *ix, bigsi_hip_batch **b) {
+        return bigsi_hip_batch_create_elements(ix, blob, elem_offsets, seq_elem_offsets, pos_unique, seq_pos_offsets, n_seqs, b);
+    });
 }
 
 extern "C" int bigsi_hip_group_batch_reload(bigsi_hip_group_batch *gb, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k)

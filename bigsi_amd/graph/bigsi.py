@@ -59,6 +59,13 @@ class BigsiQueryResult(object):
         self.score = score
 
 
+class _Done(object):
+    """search_stream: a chunk whose results are already there (it held non-ASCII sequences)."""
+
+    def __init__(self, results):
+        self.results = results
+
+
 class BIGSI(SampleMetadata, KmerSignatureIndex):
     def __init__(self, config=None):
         self.config = DEFAULT_CONFIG if config is None else config
@@ -203,12 +210,46 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
             out[i] = self._assemble(lo, colours[lo:hi], counts[lo:hi], int(nu[i]), exact, strings)
         return out
 
+    def _elements_of(self, seq):
+        """A non-ASCII query as the device takes it: its unique k-mers (k CHARACTERS each, utils/fncts.py:63-65) in
+        first-occurrence order, canonical (character-wise, fncts.py:38-54) and UTF-8 encoded -- the bytes the reference hashes
+        (bloom/bloomfilter.py:5-6) -- plus, for every position, the index of its unique k-mer."""
+        from ..utils import canonical
+        k, index, uniq, pos = self.kmer_size, {}, [], []
+        for i in range(len(seq) - k + 1):
+            km = seq[i:i + k]
+            j = index.get(km)
+            if j is None:
+                j = index[km] = len(uniq)
+                uniq.append(canonical(km).encode("utf-8"))
+            pos.append(j)
+        return uniq, pos
+
+    def _search_wide(self, seqs, threshold, score):
+        """search_batch for sequences with non-ASCII characters: k-merised here, hashed / fetched / combined on the device."""
+        batch = self.storage.new_element_batch([self._elements_of(s) for s in seqs])
+        try:
+            self._launch(batch, threshold)
+            return self._collect(batch, len(seqs), threshold, score)
+        finally:
+            batch.close()
+
     def search_batch(self, seqs, threshold=1.0, score=False):
         """search() for many sequences in one device batch; a list of result lists in input order."""
         assert threshold <= 1
         seqs = list(seqs)
         if not seqs:
             return []
+        wide = [i for i, s in enumerate(seqs) if not s.isascii()]
+        if wide:
+            out = [None] * len(seqs)
+            rest = [i for i in range(len(seqs)) if seqs[i].isascii()]
+            for i, r in zip(wide, self._search_wide([seqs[i] for i in wide], threshold, score)):
+                out[i] = r
+            if rest:
+                for i, r in zip(rest, self.search_batch([seqs[i] for i in rest], threshold, score)):
+                    out[i] = r
+            return out
         batch = self._workspace(0, seqs)
         self._launch(batch, threshold)
         return self._collect(batch, len(seqs), threshold, score)
@@ -223,9 +264,14 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
         pending, slot, chunk, held = None, 0, [], 0
 
         def submit(chunk, slot):
+            if not all(s.isascii() for s in chunk):      # rare: answered at once through search_batch's non-ASCII route
+                return _Done(self.search_batch(chunk, threshold, score)), chunk
             batch = self._workspace(slot, chunk)
             self._launch(batch, threshold)
             return batch, chunk
+
+        def done(p):
+            return p[0].results if isinstance(p[0], _Done) else self._collect(p[0], len(p[1]), threshold, score)
 
         for s in seqs:
             chunk.append(s)
@@ -233,15 +279,15 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
             if (len(chunk) == batch_size) if batch_size else (held >= batch_kmers):
                 nxt = submit(chunk, slot)
                 if pending is not None:
-                    yield from zip(pending[1], self._collect(pending[0], len(pending[1]), threshold, score))
+                    yield from zip(pending[1], done(pending))
                 pending, slot, chunk, held = nxt, slot ^ 1, [], 0
         if chunk:
             nxt = submit(chunk, slot)
             if pending is not None:
-                yield from zip(pending[1], self._collect(pending[0], len(pending[1]), threshold, score))
+                yield from zip(pending[1], done(pending))
             pending = nxt
         if pending is not None:
-            yield from zip(pending[1], self._collect(pending[0], len(pending[1]), threshold, score))
+            yield from zip(pending[1], done(pending))
 
     def _assemble(self, first_hit, colours, counts, u, exact, strings):
         """Result dicts of one sequence from its slice of the batch's hit lists; `strings` = (text, offsets) of the batch's

@@ -399,6 +399,18 @@ class ShardedBIGSI(object):
         self.engine.step(workspaces, threshold)
         return batch
 
+    def _search_wide(self, seqs, threshold, score):
+        """Sequences with non-ASCII characters: an explicit-k-mer batch (BIGSI._elements_of) through the same exchange."""
+        batch = self.local.storage.new_element_batch([self.local._elements_of(s) for s in seqs])
+        try:
+            count_bytes = 2 if max(len(s) for s in seqs) - self.local.kmer_size + 1 < 65536 else 4
+            self.engine.prepare([batch], threshold == 1.0, count_bytes)
+            self.engine._i = 0
+            self.engine.step([batch], threshold)
+            return self._collect(batch, len(seqs), threshold, score)
+        finally:
+            batch.close()
+
     def _collect(self, batch, n_seqs, threshold, score):
         from .graph.bigsi import BigsiQueryResult
         from .graph.metadata import DELETION_SPECIAL_SAMPLE_NAME
@@ -452,6 +464,16 @@ class ShardedBIGSI(object):
         seqs = list(seqs)
         if not seqs:
             return []
+        wide = [i for i, s in enumerate(seqs) if not s.isascii()]
+        if wide:
+            out = [None] * len(seqs)
+            rest = [i for i in range(len(seqs)) if seqs[i].isascii()]
+            for i, r in zip(wide, self._search_wide([seqs[i] for i in wide], threshold, score)):
+                out[i] = r
+            if rest:
+                for i, r in zip(rest, self.search_batch([seqs[i] for i in rest], threshold, score)):
+                    out[i] = r
+            return out
         return self._collect(self._submit(0, seqs, threshold), len(seqs), threshold, score)
 
     def search_stream(self, seqs, threshold=1.0, score=False, batch_size=None, batch_kmers=1 << 19):
@@ -460,19 +482,30 @@ class ShardedBIGSI(object):
         assert threshold <= 1
         pending, slot, chunk, held = None, 0, [], 0
         k = self.local.kmer_size
+
+        def flush(chunk):
+            """Submit `chunk`; yield the results of the batch before it (or, for a chunk holding non-ASCII sequences -- which
+            rebinds the exchange -- drain the pipeline and answer the chunk at once)."""
+            nonlocal pending, slot
+            if not all(s.isascii() for s in chunk):
+                if pending is not None:
+                    yield from zip(pending[1], self._collect(pending[0], len(pending[1]), threshold, score))
+                    pending = None
+                yield from zip(chunk, self.search_batch(chunk, threshold, score))
+                return
+            nxt = (self._submit(slot, chunk, threshold), chunk)
+            if pending is not None:
+                yield from zip(pending[1], self._collect(pending[0], len(pending[1]), threshold, score))
+            pending, slot = nxt, slot ^ 1
+
         for s in seqs:
             chunk.append(s)
             held += max(len(s) - k + 1, 1)
             if (len(chunk) == batch_size) if batch_size else (held >= batch_kmers):
-                nxt = (self._submit(slot, chunk, threshold), chunk)
-                if pending is not None:
-                    yield from zip(pending[1], self._collect(pending[0], len(pending[1]), threshold, score))
-                pending, slot, chunk, held = nxt, slot ^ 1, [], 0
+                yield from flush(chunk)
+                chunk, held = [], 0
         if chunk:
-            nxt = (self._submit(slot, chunk, threshold), chunk)
-            if pending is not None:
-                yield from zip(pending[1], self._collect(pending[0], len(pending[1]), threshold, score))
-            pending = nxt
+            yield from flush(chunk)
         if pending is not None:
             yield from zip(pending[1], self._collect(pending[0], len(pending[1]), threshold, score))
 

@@ -389,11 +389,23 @@ class HipHbmStorage(BaseStorage):
 
     def lookup_kmers(self, kmers):
         """{kmer: row bytes} for a list of distinct k-mer strings (graph/index.py:42-49); any lengths."""
+        from ..utils import canonical
         out = {}
         rb = max(int(self.res.info().row_bytes), 1) if self.res.ensure_open() else 1
         by_len = {}
+        wide = [km for km in kmers if isinstance(km, str) and not km.isascii()]
+        if wide:
+            # non-ASCII k-mers (k characters, hashed as UTF-8): canonical form on the host, hashing + row AND on the device
+            data = [canonical(km).encode("utf-8") for km in wide]
+            off = np.zeros(len(data) + 1, np.uint64)
+            off[1:] = np.cumsum([len(d) for d in data])
+            rows = np.zeros((len(data), rb), dtype=np.uint8)
+            check(self.res.fn("lookup_raw")(self.handle, b"".join(data), _lib.ptr(off), len(data), _lib.ptr(rows)))
+            for km, r in zip(wide, rows):
+                out[km] = r.tobytes()
         for km in kmers:
-            by_len.setdefault(len(km), []).append(km)
+            if km not in out:
+                by_len.setdefault(len(km), []).append(km)
         for k, group in by_len.items():
             if k == 0:
                 raise ValueError("cannot look up an empty k-mer")
@@ -406,6 +418,11 @@ class HipHbmStorage(BaseStorage):
 
     def new_batch(self, seqs, k):
         return QueryBatch(self, seqs, k)
+
+    def new_element_batch(self, queries):
+        """A batch whose k-mers are given explicitly (bigsi_hip_batch_create_elements): `queries` = [(unique canonical k-mers
+        as bytes, first-occurrence order; position -> unique index list)] -- the route of non-ASCII sequences."""
+        return ElementBatch(self, queries)
 
     def search_batch(self, seqs, k, threshold=1.0):
         """The fused query path in one call, the shape INTEGRATION.md binds into the reference's BIGSI.search: for every
@@ -550,6 +567,29 @@ class QueryBatch(object):
         soff = np.zeros(n_hits + 1, np.uint64)
         check(self._fn("presence_hits")(self.b, _lib.ptr(off), _lib.ptr(colours) if n_hits else None, _lib.ptr(blob), blob.size, _lib.ptr(soff)))
         return blob, soff[:-1].astype(np.int64), lens
+
+
+class ElementBatch(QueryBatch):
+    """QueryBatch over explicit k-mers: same run / unique / hits / presence interface, no reload."""
+
+    def __init__(self, storage, queries):      # noqa: D107 - does not call QueryBatch.__init__ (different constructor on the C side)
+        self.storage, self.n, self.group, self.k = storage, len(queries), storage.res.is_group, 0
+        elems = [e for uniq, _ in queries for e in uniq]
+        eoff = np.zeros(len(elems) + 1, np.uint64)
+        eoff[1:] = np.cumsum([len(e) for e in elems])
+        seoff = np.zeros(self.n + 1, np.uint64)
+        seoff[1:] = np.cumsum([len(uniq) for uniq, _ in queries])
+        spoff = np.zeros(self.n + 1, np.uint64)
+        spoff[1:] = np.cumsum([len(pu) for _, pu in queries])
+        pu = np.ascontiguousarray([j for _, p in queries for j in p], dtype=np.uint32)
+        out = _lib.C.c_void_p()
+        check(self._fn("create_elements")(storage.handle, b"".join(elems), _lib.ptr(eoff), _lib.ptr(seoff),
+                                          _lib.ptr(pu) if pu.size else None, _lib.ptr(spoff), self.n, _lib.C.byref(out)))
+        self.b = out
+        storage.res.batches.add(self)
+
+    def reload(self, seqs, k=None):
+        raise BigsiHipError(_lib.ERR_STATE, "a batch of explicit k-mers cannot be reloaded")
 
 
 # ------------------------------------------------------------------------------- snapshots (sync / reopen)

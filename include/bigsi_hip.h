@@ -142,6 +142,8 @@ int bigsi_hip_bloom(int device, const char *kmers, uint64_t u, uint32_t k, uint6
 /* KmerSignatureIndex.lookup for an explicit k-mer list (bigsi/graph/index.py:42-49): u k-mers of k ASCII bytes,
  * out_rows = u rows of row_bytes bytes (AND of each k-mer's h rows), in input order.  One-shot, synchronous. */
 int bigsi_hip_lookup(bigsi_hip_index *ix, const char *kmers, uint32_t k, uint64_t u, uint8_t *out_rows);
+/* The same for u elements of any byte lengths, hashed as they are (already canonical): the non-ASCII twin of bigsi_hip_lookup. */
+int bigsi_hip_lookup_raw(bigsi_hip_index *ix, const char *blob, const uint64_t *elem_offsets, uint64_t u, uint8_t *out_rows);
 
 #define BIGSI_RUN_FORCE_COUNTS 1u /* use the counting path even when threshold == 1.0 */
 #define BIGSI_RUN_SKIP_COMPACT 2u /* stop after K2/K3: the caller compacts a gathered buffer instead (multi-GPU) */
@@ -155,6 +157,16 @@ int bigsi_hip_lookup(bigsi_hip_index *ix, const char *kmers, uint32_t k, uint64_
 
 int bigsi_hip_batch_create(bigsi_hip_index *ix, const char *seqs, const uint64_t *offsets, uint32_t n_seqs,
                            uint32_t k, bigsi_hip_batch **out);
+/* A batch whose k-mers are given explicitly ("elements"), for sequences that are not byte strings of k-byte windows: the
+ * reference k-merises CHARACTERS (bigsi/utils/fncts.py:63-65), reverse-complements them one by one (:12,38-39), compares
+ * Python strings (:51-54) and hashes the UTF-8 bytes (bigsi/bloom/bloomfilter.py:5-6), so the k-mers of a non-ASCII query have
+ * different byte lengths.  The host lists, per sequence, its unique k-mers in first-occurrence order, already canonical
+ * (element e = blob[elem_offsets[e] .. elem_offsets[e+1]); sequence i owns elements [seq_elem_offsets[i], seq_elem_offsets[i+1])),
+ * and for every k-mer position of every sequence the index of its unique k-mer (pos_unique, sequence i owns
+ * [seq_pos_offsets[i], seq_pos_offsets[i+1])).  Hashing, row fetch, AND, counts, threshold, compaction and presence run on the
+ * device as for any batch; bigsi_hip_batch_reload is not available for such a batch. */
+int bigsi_hip_batch_create_elements(bigsi_hip_index *ix, const char *blob, const uint64_t *elem_offsets, const uint64_t *seq_elem_offsets,
+                                    const uint32_t *pos_unique, const uint64_t *seq_pos_offsets, uint32_t n_seqs, bigsi_hip_batch **out);
 int bigsi_hip_batch_destroy(bigsi_hip_batch *b);
 /* Load a different set of sequences into an existing batch object: device buffers are kept and only grow, so a serving
  * loop pays allocation once.  Output / stream settings of the batch are kept; results of earlier runs are discarded.
@@ -303,9 +315,13 @@ int bigsi_hip_group_get_column(bigsi_hip_group *g, uint64_t col, uint8_t *out);
 int bigsi_hip_group_insert_kmers(bigsi_hip_group *g, uint64_t col, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k);
 int bigsi_hip_group_fill_synthetic(bigsi_hip_group *g, uint64_t seed, uint32_t and_draws); /* shard i = fill_synthetic(seed, i) */
 int bigsi_hip_group_lookup(bigsi_hip_group *g, const char *kmers, uint32_t k, uint64_t u, uint8_t *out_rows);
+int bigsi_hip_group_lookup_raw(bigsi_hip_group *g, const char *blob, const uint64_t *elem_offsets, uint64_t u, uint8_t *out_rows);
 /* fused query path over all shards; same meaning as the bigsi_hip_batch_* calls, colours are global */
 int bigsi_hip_group_batch_create(bigsi_hip_group *g, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k,
                                  bigsi_hip_group_batch **out);
+int bigsi_hip_group_batch_create_elements(bigsi_hip_group *g, const char *blob, const uint64_t *elem_offsets,
+                                          const uint64_t *seq_elem_offsets, const uint32_t *pos_unique,
+                                          const uint64_t *seq_pos_offsets, uint32_t n_seqs, bigsi_hip_group_batch **out);
 int bigsi_hip_group_batch_reload(bigsi_hip_group_batch *gb, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k);
 int bigsi_hip_group_batch_destroy(bigsi_hip_group_batch *gb);
 int bigsi_hip_group_batch_run(bigsi_hip_group_batch *gb, double threshold, uint32_t flags); /* asynchronous */

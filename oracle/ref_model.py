@@ -100,6 +100,27 @@ class Scorer:                # scoring/score.py:35-151
         return d
 
 
+# ---------------------------------------------------------------- non-ASCII text
+# The reference works on Python str: k CHARACTERS per k-mer, reverse_comp / canonical character by character
+# (utils/fncts.py:38-54), mmh3.hash of the str = of its UTF-8 bytes (bloom/bloomfilter.py:5-6).  bigsi_oracle.c works on bytes,
+# which is the same thing for ASCII; these restate the character-wise forms for everything else (pinned by golden G13).
+_COMPLEMENT = str.maketrans("ACGT", "TGCA")
+
+
+def canonical_chars(km):             # fncts.py:38-39, 51-54
+    rc = km[::-1].translate(_COMPLEMENT)
+    return km if km <= rc else rc
+
+
+def kmer_rows_chars(km, h, m):       # bloomfilter.py:5-6 on the canonical k-mer
+    c = canonical_chars(km)
+    return [coracle.row_of(c, seed, m) for seed in range(h)]
+
+
+def _rows_of(km, h, m):
+    return coracle.kmer_rows(km, h, m) if km.isascii() else kmer_rows_chars(km, h, m)
+
+
 # ---------------------------------------------------------------- the index
 class OracleBIGSI:
     """rows: uint8[m, rb] in the reference's storage format; names[c] = sample name of colour c."""
@@ -116,7 +137,7 @@ class OracleBIGSI:
     def bloom(kmers, m, h):
         bits = np.zeros(m, dtype=np.uint8)
         for km in kmers:
-            for r in coracle.kmer_rows(km, h, m):
+            for r in _rows_of(km, h, m):
                 bits[r] = 1
         return np.packbits(bits)       # == bitarray.tobytes(): MSB first, zero padded
 
@@ -136,9 +157,15 @@ class OracleBIGSI:
         uniq = list(dict.fromkeys(kmers))
         if not uniq:
             return {}
-        out = coracle.lookup(self.rows, self.h, uniq, len(uniq[0]))
+        out = self._per_kmer(uniq, len(uniq[0]))
         nb = self.num_samples if remove_trailing_zeros else None
         return {km: bytes_to_01(out[i].tobytes(), nb) for i, km in enumerate(uniq)}
+
+    def _per_kmer(self, uniq, k):
+        """uint8[u, rb]: the AND of each k-mer's h rows (graph/index.py:42-49 + bitvector_index.py:36-41)."""
+        if all(km.isascii() for km in uniq):
+            return coracle.lookup(self.rows, self.h, uniq, k)
+        return np.stack([np.bitwise_and.reduce(self.rows[_rows_of(km, self.h, self.m)], axis=0) for km in uniq])
 
     def counts(self, seq):
         """(u, int32[num_samples]) of graph/bigsi.py:212-215 for one query."""
@@ -151,7 +178,7 @@ class OracleBIGSI:
         uniq = list(dict.fromkeys(kmers))
         u = len(uniq)
         min_kmers = math.ceil(u * threshold)
-        per_kmer = coracle.lookup(self.rows, self.h, uniq, self.k) if u else np.zeros((0, self.rb), np.uint8)
+        per_kmer = self._per_kmer(uniq, self.k) if u else np.zeros((0, self.rb), np.uint8)
         if threshold == 1.0:                                  # exact_filter, graph/bigsi.py:192-205
             if u == 0:
                 raise TypeError("reduce() of empty sequence with no initial value")

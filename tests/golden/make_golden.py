@@ -619,7 +619,36 @@ def g12_variant():
     dump("g12_variant.json", out, indent=None)
 
 
+# ------------------------------------------------ G13: non-ASCII sequences (k CHARACTERS, hashed as their UTF-8 bytes)
+def g13_unicode():
+    """The reference slices k characters (utils/fncts.py:63-65), reverse-complements character by character
+    (fncts.py:12,38-39), compares Python strings (fncts.py:51-54) and hashes the UTF-8 bytes (bloom/bloomfilter.py:5-6)."""
+    c = cfg("g13", 3, 1000, 3)
+    ref_storage.get_storage(c).delete_all()
+    samples = {"u1": "AT\u03b1CA\u03b2AT", "u2": "\u03a9ATACA\u03a9", "a": "ATACACAAT", "e": "G\u00e9N\u00f4ME\U0001F9ECGAT"}
+    blooms = [BIGSI.bloom(c, seq_to_kmers(s, 3)) for s in samples.values()]
+    b = BIGSI.build(c, blooms, list(samples.keys()))
+    strings = ["AT\u03b1", "\u03b1TA", "\u03a9AT", "G\u00e9N", "ME\U0001F9EC", "\U0001F9ECGA", "ATA", "\u00e9\u00e9\u00e9"]
+    case = {"k": 3, "m": 1000, "h": 3, "samples": samples, "blooms": [x.tobytes().hex() for x in blooms], "rows": rows_of(b),
+            "canonical": [{"s": s, "canonical": canonical(s), "reverse_comp": reverse_comp(s),
+                           "rows_in_seed_order": [ref_bloom._hash(canonical(s), sd, 1000) for sd in range(3)]} for s in strings],
+            "lookups": [], "searches": []}
+    for kms in (["AT\u03b1", "ATA"], ["\u03a9AT", "TA\u03a9", "G\u00e9N"], ["\U0001F9ECGA"]):
+        for rtz in (True, False):
+            case["lookups"].append({"kmers": kms, "remove_trailing_zeros": rtz, "lookup": lookup_dict(b.lookup(kms, rtz))})
+    seqs = ["AT\u03b1CA\u03b2AT", "\u03a9ATACA\u03a9", "AT\u03b1CA", "G\u00e9N\u00f4ME\U0001F9ECGAT", "\u00f4ME\U0001F9ECGATACA", "\u03b1\u03b2",
+            "AT\u03b1", "ATACACAAT\u03b1", "\u00e9\u00e9\u00e9\u00e9\u00e9"]
+    for s in seqs:
+        for t in (1.0, 0.5, 0.3, 0.0):
+            for sc in (False, True):
+                case["searches"].append({"seq": s, "threshold": t, "score": sc, "out": run_search(b, s, t, sc)})
+    dump("g13_unicode.json", case)
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["g13"]:       # only the fixture added in round 2 (the others are byte-identical re-runs)
+        g13_unicode()
+        sys.exit(0)
     g1_hash()
     g2_lookup()
     g3_search()
@@ -632,3 +661,4 @@ if __name__ == "__main__":
     g10_cortex()
     g11_example_bdb_files()
     g12_variant()
+    g13_unicode()

@@ -34,8 +34,12 @@ for s in g["searches"]:
         res = {"raises": type(e).__name__, "message": str(e)[:300]}
     out.append(res)
 batch = sb.search_batch(g["queries"][:10], 0.4)
+# non-ASCII text through the exchange: an accented character spliced into three queries (explicit-k-mer batches)
+wide_q = [q[:45] + "\u00e9" + q[45:] for q in g["queries"][:3]]
+wide = [sb.search(q, 0.3, True) for q in wide_q]
+mixed = [r for _, r in sb.search_stream([g["queries"][0], wide_q[0], g["queries"][1], wide_q[1], g["queries"][2]], 0.3, batch_size=2)]
 if rank == 0:
-    json.dump({"searches": out, "batch": batch}, open(sys.argv[1], "w"))
+    json.dump({"searches": out, "batch": batch, "wide": wide, "mixed": mixed}, open(sys.argv[1], "w"))
 sb.close()
 local.delete()
 dist.barrier()

@@ -199,6 +199,39 @@ def test_bigsi_over_three_shards_reproduces_reference_results():
     b.delete()
 
 
+def test_non_ascii_queries_over_three_shards():
+    """Golden G13's Greek / accented / 4-byte samples at colours 0, 64, 65 and 129 of a 130-sample index over three shards
+    (64 + 64 + 2 columns): lookups and searches (with scores, and the reference's exceptions) equal the oracle, which
+    tests/test_oracle_golden.py::test_g13_non_ascii_text pins to the reference's own answers on these strings."""
+    from bigsi_amd import BIGSI
+    from oracle.ref_model import OracleBIGSI, seq_to_kmers
+    g = load_golden("g13_unicode.json")
+    k, m, h = g["k"], g["m"], g["h"]
+    rng = np.random.default_rng(13)
+    seqs = ["".join(rng.choice(list("ACGT"), size=9)) for _ in range(130)]
+    for col, s in zip((0, 64, 65, 129), g["samples"].values()):
+        seqs[col] = s
+    names = ["s%d" % i for i in range(130)]
+    cfg = {"storage-engine": "hip-hbm", "k": k, "m": m, "h": h,
+           "storage-config": {"name": "grp%d" % next(_counter), "devices": [0, 0, 0], "max_cols": 130}}
+    blooms = [BIGSI.bloom(cfg, seq_to_kmers(s, k)) for s in seqs]
+    b = BIGSI.build(cfg, blooms, names)
+    assert b.storage.res.info().n_shards == 3
+    o = OracleBIGSI.build([OracleBIGSI.bloom(seq_to_kmers(s, k), m, h) for s in seqs], names, k, m, h)
+    assert np.array_equal(b.storage.get_rows_packed(np.arange(m)), o.rows)
+    for lk in g["lookups"]:
+        got = b.lookup(lk["kmers"], remove_trailing_zeros=lk["remove_trailing_zeros"])
+        assert {x: v.to01() for x, v in got.items()} == o.lookup(lk["kmers"], lk["remove_trailing_zeros"])
+    for c in g["searches"]:
+        try:
+            want = {"results": o.search(c["seq"], c["threshold"], c["score"])}
+        except (TypeError, UnboundLocalError, IndexError) as e:
+            want = {"raises": type(e).__name__}
+        assert ("raises" in want) == ("raises" in c["out"])
+        check_search(lambda: b.search(c["seq"], c["threshold"], c["score"]), {"out": want}, "%s t=%r" % (c["seq"], c["threshold"]))
+    b.delete()
+
+
 @pytest.mark.parametrize("threshold", [1.0, 0.3])
 def test_one_rank_rccl_communicator(threshold):
     """bigsi_hip_comm_init_rank + bigsi_hip_batch_run_sharded with world = 1: the library's own ncclAllGather (in place) and

@@ -112,3 +112,12 @@ def test_sharded_bigsi_equals_whole_index(tmp_path, split):
     want = {(s["q"], s["threshold"]): s["out"]["results"] for s in g["searches"] if not s["score"] and "results" in s["out"]}
     for qi in range(10):
         assert_results_equal(got["batch"][qi], unjson(want[(qi, 0.4)]), "batch q%d" % qi)
+    # non-ASCII queries (an accented character spliced in): against the oracle on the whole index (pinned on such text by G13)
+    from oracle.ref_model import OracleBIGSI, seq_to_kmers
+    k, m, h = g["k"], g["m"], g["h"]
+    o = OracleBIGSI.build([OracleBIGSI.bloom(seq_to_kmers(a, k) + seq_to_kmers(c, k), m, h) for a, c in g["sample_seqs"]], g["sample_names"], k, m, h)
+    wide_q = [q[:45] + "\u00e9" + q[45:] for q in g["queries"][:3]]
+    for q, res in zip(wide_q, got["wide"]):
+        assert_results_equal(res, o.search(q, 0.3, True), "non-ASCII")
+    for q, res in zip([g["queries"][0], wide_q[0], g["queries"][1], wide_q[1], g["queries"][2]], got["mixed"]):
+        assert_results_equal(res, o.search(q, 0.3), "stream with non-ASCII")

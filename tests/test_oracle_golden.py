@@ -74,6 +74,27 @@ def test_g3_g4_search(name):
             check_search(lambda: o.search(s["seq"], s["threshold"], s["score"]), s, "deleted")
 
 
+def test_g13_non_ascii_text():
+    """k CHARACTERS per k-mer, character-wise canonical form, UTF-8 bytes hashed: the reference run on Greek / accented /
+    4-byte text (tests/golden/make_golden.py: g13_unicode)."""
+    from oracle.ref_model import canonical_chars, kmer_rows_chars
+    g = load_golden("g13_unicode.json")
+    k, m, h = g["k"], g["m"], g["h"]
+    for rec in g["canonical"]:
+        assert canonical_chars(rec["s"]) == rec["canonical"]
+        assert kmer_rows_chars(rec["s"], h, m) == rec["rows_in_seed_order"]
+    names = list(g["samples"])
+    blooms = [OracleBIGSI.bloom(seq_to_kmers(s, k), m, h) for s in g["samples"].values()]
+    for b, want in zip(blooms, g["blooms"]):
+        assert b.tobytes().hex() == want
+    o = OracleBIGSI.build(blooms, names, k, m, h)
+    assert [r.tobytes().hex() for r in o.rows] == g["rows"]
+    for lk in g["lookups"]:
+        assert o.lookup(lk["kmers"], lk["remove_trailing_zeros"]) == lk["lookup"], lk
+    for case in g["searches"]:
+        check_search(lambda: o.search(case["seq"], case["threshold"], case["score"]), case)
+
+
 def test_g5_scoring():
     g = load_golden("g5_scoring.json")
     for rec in g["helpers"]["remove_short_ones"]:
