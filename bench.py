@@ -310,8 +310,10 @@ def main():
     collect()
     sync_all()
     check(_lib.lib().bigsi_hip_stats(st.handle, _lib.C.byref(warm), 1))      # K1 / K4 durations come from the warmup steps
-    # timed region: HIP events around the row-AND kernel only (every event record costs the stream 5-7 us)
-    check(_lib.lib().bigsi_hip_set_profiling(st.handle, 2))
+    # timed region: HIP events around the row-AND kernel only, and -- an event record costs the stream 5-7 us -- for steps of
+    # a few tens of microseconds (short reads) only around every 8th of them, so that the region runs at its untimed speed
+    short_steps = w["batch"] * max(w["qlen"] - args.k + 1, 1) < (1 << 17)
+    check(_lib.lib().bigsi_hip_set_profiling(st.handle, 8 if short_steps and args.steps >= 64 else 2))
     stats = _lib.Stats()
 
     sync_all()
@@ -341,7 +343,7 @@ def main():
     out_bytes = w["batch"] * wv * 8
     alg_bytes = uniq_rows * wv * 8 + out_bytes                 # SURVEY.md section 8d, this rank's shard
     # a large batch goes out as several row-AND launches of ~1000 workgroups each: per-launch figures, as rocprofv3 reports them
-    launches_per_step = max(stats.and_launches, 1) / args.steps
+    launches_per_step = max(stats.and_launches_total, 1) / args.steps
     and_ms = stats.and_ms / max(stats.and_launches, 1)
     alg_bytes_launch = alg_bytes / launches_per_step
     achieved = alg_bytes_launch / (and_ms * 1e-3) / 1e9

@@ -20,6 +20,7 @@ RUN_K1_GLOBAL = 4
 RUN_SPARSE_COUNTS = 8
 RUN_NO_SORT = 16
 RUN_EARLY_EXIT = 32
+RUN_WEAK_FINGERPRINT = 64
 BLOOM_RAW = 1
 
 
@@ -54,7 +55,8 @@ class Stats(C.Structure):
                 ("kmerize_launches", C.c_uint64), ("kmerize_ms", C.c_double),
                 ("compact_launches", C.c_uint64), ("compact_ms", C.c_double),
                 ("presence_launches", C.c_uint64), ("presence_ms", C.c_double), ("presence_bytes", C.c_uint64),
-                ("transpose_launches", C.c_uint64), ("transpose_ms", C.c_double)]
+                ("transpose_launches", C.c_uint64), ("transpose_ms", C.c_double),
+                ("and_launches_total", C.c_uint64)]
 
 
 _P = C.c_void_p

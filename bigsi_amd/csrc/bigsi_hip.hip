@@ -468,6 +468,7 @@ static int ev_begin(bigsi_hip_index *ix, EventPair *p, hipStream_t st, bool row_
     if (!st) st = ix->stream;
     *p = EventPair{};
     if (!ix->profiling || (ix->profiling == 2 && !row_and)) return BIGSI_OK;
+    if (ix->prof_every > 1 && row_and && (ix->prof_tick++ % ix->prof_every) != 0) return BIGSI_OK;      // sampled: this run goes untimed
     if (ix->ev_free.empty()) {
         EventPair n;
         HIP_TRY(hipEventCreate(&n.a));
@@ -482,6 +483,7 @@ static int ev_begin(bigsi_hip_index *ix, EventPair *p, hipStream_t st, bool row_
 
 static int ev_end(bigsi_hip_index *ix, EventPair *p, std::vector<EventPair> &dst, hipStream_t st, uint32_t launches)
 {
+    if (&dst == &ix->ev_and) ix->and_total += launches;
     if (!p->a) return BIGSI_OK;          // not being timed
     if (!st) st = ix->stream;
     HIP_TRY(hipEventRecord(p->b, st));
@@ -493,7 +495,9 @@ static int ev_end(bigsi_hip_index *ix, EventPair *p, std::vector<EventPair> &dst
 extern "C" int bigsi_hip_set_profiling(bigsi_hip_index *ix, int on)
 {
     if (!ix) return fail(BIGSI_ERR_INVALID, "NULL index");
-    ix->profiling = on == 2 ? 2 : (on != 0);
+    ix->profiling = on >= 2 ? 2 : (on != 0);
+    ix->prof_every = on > 2 ? (uint32_t)on : 1u;
+    ix->prof_tick = 0;
     return BIGSI_OK;
 }
 
@@ -520,9 +524,11 @@ extern "C" int bigsi_hip_stats(bigsi_hip_index *ix, bigsi_hip_stats_t *out, int 
     TRY(sum(ix->ev_pr, &out->presence_launches, &out->presence_ms));
     TRY(sum(ix->ev_tr, &out->transpose_launches, &out->transpose_ms));
     out->presence_bytes = ix->presence_bytes;
+    out->and_launches_total = ix->and_total;
     if (reset) {
         recycle_events(ix);
         ix->presence_bytes = 0;
+        ix->and_total = 0;
     }
     return BIGSI_OK;
 }
@@ -838,8 +844,19 @@ static bool reads_fusable(const bigsi_hip_batch *b, uint32_t flags)
            (exact || (flags & BIGSI_RUN_SPARSE_COUNTS));     // the fused kernel keeps counters in registers: hits only
 }
 
+#ifdef BIGSI_HIP_TUNING
+// tuning builds only (not declared in include/bigsi_hip.h): the phase timestamps of the last k_reads_fused launch, 8 per workgroup
+extern "C" int bigsi_hip_debug_phases(bigsi_hip_index *ix, uint64_t *out, uint32_t n_groups)
+{
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), std::min<uint32_t>(n_groups, 1024u) * 64ull));
+    return BIGSI_OK;
+}
+#endif
+
 static int launch_reads_fused(bigsi_hip_batch *b)
 {
+    const uint32_t fp_mask = b->weak_fp ? 1u : ~0u;
     bigsi_hip_index *ix = b->ix;
     HitBufs &hb = b->hits;
     TRY(b->bitmaps.reserve((size_t)b->n_seqs * b->wv_pad * 8));
@@ -864,7 +881,7 @@ static int launch_reads_fused(bigsi_hip_batch *b)
         b->seqs.as<char>(), b->d_seq_off.as<uint64_t>(), b->d_pos_off.as<uint64_t>(), b->n_seqs, b->first_pos.as<uint32_t>(),         \
         b->pos_unique.as<uint32_t>(), b->rep.as<uint32_t>(), b->rows.as<uint64_t>(), b->num_kmers.as<uint32_t>(),                      \
         b->num_unique.as<uint32_t>(), b->min_kmers.as<uint32_t>(), b->bitmaps.as<uint64_t>(), b->wv_pad, hb.lb_state.as<uint64_t>(),  \
-        hb.gen, hb.hit_off.as<uint64_t>(), hb.col(), hb.cnt(), hb.capacity()
+        hb.gen, hb.hit_off.as<uint64_t>(), hb.col(), hb.cnt(), hb.capacity(), fp_mask
 #define COMMA ,
 #define BIGSI_READS(H)                                                                              \
     if (b->exact) hipLaunchKernelGGL((k_reads_fused<H COMMA true>), BIGSI_READS_ARGS);                \
@@ -1058,6 +1075,7 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
         EventPair fe{};
         b->dirty = true;
         TRY(ev_begin(ix, &fe, nullptr, true));
+        b->weak_fp = (flags & BIGSI_RUN_WEAK_FINGERPRINT) != 0;
         TRY(launch_reads_fused(b));
         TRY(ev_end(ix, &fe, ix->ev_and));
         b->run_h = ix->h;

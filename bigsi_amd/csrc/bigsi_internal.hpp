@@ -84,6 +84,8 @@ struct bigsi_hip_index {
     DevBuf stage, stage_ids;
     // profiling
     int profiling = 0;            // 0 off, 1 every kernel group of a run, 2 the row-AND kernel only
+    uint32_t prof_every = 1, prof_tick = 0;      // level 2 sampled: every prof_every-th run is timed
+    uint64_t and_total = 0;       // row-AND launches since the last stats reset, timed or not
     std::vector<EventPair> ev_and, ev_km, ev_cp, ev_pr, ev_tr, ev_free;
     uint64_t presence_bytes = 0;   // algorithmic bytes of the timed presence_hits calls
     uint64_t wv() const { return ceil_div(n_cols, 64); }
@@ -127,6 +129,7 @@ struct bigsi_hip_batch {
     bool ran = false, exact = false, compacted = false, sparse_counts = false;
     bool pos_query_loaded = false;    // pos_query holds this load's position -> sequence map
     bool local_from_counts = false;   // the last counting run was row-sliced: hits come from thresholding the counters
+    bool weak_fp = false;         // BIGSI_RUN_WEAK_FINGERPRINT of the last one-launch run (a re-launch after a regrow repeats it)
     bool fused_run = false;           // the last run was the one-launch read kernel (k_reads_fused)
     bool elements = false;            // k-mers were given explicitly (bigsi_hip_batch_create_elements): K1 = k_rows_raw
     DevBuf elem_seq_off;              // elements: first element of every sequence

@@ -532,10 +532,19 @@ __global__ __launch_bounds__(kBlock) void k_kmerize_wave(
     const uint32_t n = len >= k ? len - k + 1 : 0u;      // <= 64 by the launch condition
     const uint64_t P = pos_off[q];
     const bool live = lane < n;
-    const uint32_t fp = live ? dedupe_hash<KF>(s + lane, k) : 0u;
+    RegKmer<KF> reg;                               // the k-mer's bytes, loaded once for the fingerprint and the hashes
+    uint32_t fp = 0;
+    if (KF > 0) {
+        if (live) {
+            reg.load(s + lane);
+            fp = reg.fnv();
+        }
+    } else if (live) {
+        fp = fnv1a(s + lane, k);
+    }
     uint32_t rep = lane;
-    for (uint32_t j = 0; j + 1 < n; j++) {         // wave-uniform trip count
-        const uint32_t fj = __shfl(fp, (int)j, 64);
+    for (uint32_t j = 0; j + 1 < n; j++) {         // wave-uniform trip count and lane index: a v_readlane, no LDS round trip
+        const uint32_t fj = (uint32_t)__builtin_amdgcn_readlane((int)fp, (int)j);
         if (live && lane > j && rep == lane && fp == fj && kmer_equal(s + j, s + lane, k)) rep = j;
     }
     const bool first = live && rep == lane;
@@ -552,8 +561,6 @@ __global__ __launch_bounds__(kBlock) void k_kmerize_wave(
         uint64_t *dst = rows + (P + j) * h;
         const char *km = s + lane;
         if (KF > 0) {
-            RegKmer<KF> reg;
-            reg.load(km);
             uint32_t w[(KF + 3) / 4 > 0 ? (KF + 3) / 4 : 1];
             reg.canonical_words(w);
             for (uint32_t sd = 0; sd < h; sd++) dst[sd] = row_of_hash(murmur3_words<KF>(w, sd), m);
@@ -978,6 +985,13 @@ __global__ __launch_bounds__(kBlock) void k_hits_fused(
 // global memory for lookup / presence / fetch_rows), the row ids go to the other wavefronts through LDS, all of them
 // stream and AND (or count) the rows, and the hit list is written through k_hits_fused's scan -- the workgroup publishes its
 // total and sums those of the queries before it (the grid is co-resident by construction).  Same results, one launch.
+#ifdef BIGSI_HIP_TUNING
+// tuning builds only: per-workgroup timestamps of k_reads_fused's phases (100 MHz wall clock), read by bigsi_hip_debug_phases
+__device__ uint64_t g_phase[1024 * 8];
+#define BIGSI_PHASE(i) do { if (threadIdx.x == 0) g_phase[(blockIdx.x & 1023u) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define BIGSI_PHASE(i) do { } while (0)
+#endif
 template <int H, bool EXACT>
 __global__ __launch_bounds__(kBlock) void k_reads_fused(
     const uint64_t *__restrict__ index, uint64_t stride_words, uint32_t wv, uint64_t n_cols, uint64_t m, double threshold,
@@ -986,78 +1000,179 @@ __global__ __launch_bounds__(kBlock) void k_reads_fused(
     uint32_t *__restrict__ num_kmers, uint32_t *__restrict__ num_unique, uint32_t *__restrict__ min_kmers,
     uint64_t *__restrict__ out_bits, uint64_t out_stride_words,
     uint64_t *__restrict__ state, uint32_t gen, uint64_t *__restrict__ hit_off, uint32_t *__restrict__ hit_col, uint32_t *__restrict__ hit_cnt,
-    uint64_t capacity)
+    uint64_t capacity, uint32_t fp_mask /* ~0; 1 = BIGSI_RUN_WEAK_FINGERPRINT */)
 {
     constexpr int KF = 31, P = 6;
-    __shared__ uint64_t s_rows[64 * H];
+    __shared__ uint64_t s_rows[64 * H], s_hrow[64 * H];   // row ids: of the unique k-mers / of every position, per seed
+    __shared__ uint32_t s_seq[24], s_cmp[25];             // the query's bytes (63 positions + 30 = 93 at most); their complements
+    __shared__ uint8_t s_first[64];                       // position of the j-th unique k-mer
     __shared__ uint32_t s_u, s_min;
     __shared__ uint32_t lds[16];
     __shared__ uint64_t lds64[kBlock / 64];
     const uint32_t q = blockIdx.x;
-    // ---- K1 (wavefront 0): see k_kmerize_wave
-    if (threadIdx.x < 64) {
-        const uint32_t lane = threadIdx.x;
+    BIGSI_PHASE(0);
+    // ---- K1 on two wavefronts, on packed words.  The query's bytes (<= 93) and their complements are staged in LDS once.
+    // Wavefront A finds each k-mer's first occurrence (k_kmerize_wave's scheme with a scalar fast path); wavefront B builds
+    // the canonical form of EVERY position (forward words against byte-reversed complement words, compared as big-endian
+    // numbers = lexicographically, utils/fncts.py:51-54) and hashes it for all H seeds, sharing the seed-independent part of
+    // MurmurHash3.  The rows of the first occurrences are compacted afterwards.  A and B rotate with the query number so that
+    // the workgroups sharing a CU load different SIMDs.  (One wavefront working byte by byte was 6.3 us of a 32 us kernel,
+    // with the HBM idle: about 4 x 1150 VALU instructions per CU, most of them on one SIMD.)
+    {
+        const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+        const uint32_t wave_a = (q >> 8) & 3u, wave_b = (wave_a + 2u) & 3u;
         const char *s = seqs + seq_off[q];
         const uint32_t len = (uint32_t)(seq_off[q + 1] - seq_off[q]);
         const uint32_t n = len >= KF ? len - KF + 1 : 0u;      // < 64 by the launch condition
         const uint64_t P0 = pos_off[q];
-        const bool live = lane < n;
-        const uint32_t fp = live ? dedupe_hash<KF>(s + lane, KF) : 0u;
-        uint32_t rep = lane;
-        for (uint32_t j = 0; j + 1 < n; j++) {
-            const uint32_t fj = __shfl(fp, (int)j, 64);
-            if (live && lane > j && rep == lane && fp == fj && kmer_equal(s + j, s + lane, KF)) rep = j;
-        }
-        const bool first = live && rep == lane;
-        const unsigned long long mask = __ballot(first);
-        const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
-        const uint32_t u = (uint32_t)__popcll(mask);
-        if (live) {
-            rep_out[P0 + lane] = rep;
-            pos_unique[P0 + lane] = (uint32_t)__popcll(mask & (rep ? (~0ull >> (64 - rep)) : 0ull));
-        }
-        if (first) {
-            const uint32_t j = (uint32_t)__popcll(mask & below);
-            first_pos[P0 + j] = lane;
-            RegKmer<KF> reg;
-            reg.load(s + lane);
-            uint32_t w[(KF + 3) / 4];
-            reg.canonical_words(w);
-#pragma unroll
-            for (int sd = 0; sd < H; sd++) {
-                const uint64_t r = row_of_hash(murmur3_words<KF>(w, (uint32_t)sd), m);
-                rows[(P0 + j) * H + sd] = r;
-                s_rows[j * H + sd] = r;
+        if (threadIdx.x < 100) {                           // s_cmp carries 4 pad bytes in front (the word at byte p - 1 is read)
+            const uint32_t t = threadIdx.x;
+            const uint8_t c = t < len ? (uint8_t)s[t] : (uint8_t)0;
+            if (t < 96) {
+                reinterpret_cast<uint8_t *>(s_seq)[t] = c;
+                reinterpret_cast<uint8_t *>(s_cmp)[4 + t] = complement(c);
+            } else {
+                reinterpret_cast<uint8_t *>(s_cmp)[t - 96] = 0;
             }
         }
-        if (lane == 0) {
-            const double mk = ceil((double)u * threshold);
-            const uint32_t mn = mk > 0.0 ? (uint32_t)mk : 0u;
-            num_kmers[q] = n;
-            num_unique[q] = u;
-            min_kmers[q] = mn;
-            s_u = u;
-            s_min = mn;
+        __syncthreads();
+        BIGSI_PHASE(4);
+        const bool live = lane < n;
+        uint32_t wf[8];                                    // the k-mer at position `lane`, little-endian words (last: 3 bytes)
+        if (wave == wave_a || wave == wave_b) {
+            uint32_t d[9];
+#pragma unroll
+            for (int i = 0; i < 9; i++) d[i] = s_seq[(lane >> 2) + i];
+#pragma unroll
+            for (int i = 0; i < 8; i++) wf[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], lane & 3u);
+            wf[7] &= 0x00ffffffu;
+        }
+        if (wave == wave_a) {
+            uint32_t fp = 0;                               // fingerprint: equal k-mers have equal ones; a match is verified word by word
+#pragma unroll
+            for (int i = 0; i < 8; i++) fp = (fp ^ wf[i]) * 0x9E3779B1u;
+            fp = live ? (fp ^ (fp >> 15)) & fp_mask : 0u;
+            BIGSI_PHASE(5);
+            // rep = the first position holding this lane's k-mer.  Branch-free pass: the lowest lane with the same fingerprint
+            // (independent v_readlane / compare / select triples, highest lane first so that the lowest match is kept; a serial
+            // loop with a scalar early-out ran at 70 ns per position, all dependency stalls), then one word-by-word check
+            // against that lane.  A fingerprint collision between different k-mers (2^-32 per pair) sends the wavefront
+            // through the exact pairwise loop instead.
+            uint32_t cand = lane;
+            for (int jb = 48; jb >= 0; jb -= 16) {
+                if ((uint32_t)jb >= n) continue;
+#pragma unroll
+                for (int t = 15; t >= 0; t--) {
+                    const uint32_t fj = (uint32_t)__builtin_amdgcn_readlane((int)fp, jb + t);
+                    cand = fp == fj ? (uint32_t)(jb + t) : cand;
+                }
+            }
+            cand = min(cand, lane);                        // (lanes at or beyond n are not live and never representatives)
+            const bool dup = live && cand < lane;
+            bool same = true;
+#pragma unroll
+            for (int i = 0; i < 8; i++) same = same && (uint32_t)__shfl((int)wf[i], (int)cand, 64) == wf[i];
+            uint32_t rep = dup ? cand : lane;
+            if (__ballot(dup && !same) != 0ull) {          // wave-uniform, practically never
+                rep = lane;
+                for (uint32_t j = 0; j + 1 < n; j++) {
+                    bool eq = live && lane > j && rep == lane;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) eq = eq && wf[i] == (uint32_t)__builtin_amdgcn_readlane((int)wf[i], (int)j);
+                    if (eq) rep = j;
+                }
+            }
+            BIGSI_PHASE(6);
+            const bool first = live && rep == lane;
+            const unsigned long long mask = __ballot(first);
+            const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+            const uint32_t u = (uint32_t)__popcll(mask);
+            if (live) {
+                rep_out[P0 + lane] = rep;
+                pos_unique[P0 + lane] = (uint32_t)__popcll(mask & (rep ? (~0ull >> (64 - rep)) : 0ull));
+            }
+            if (first) {
+                const uint32_t j = (uint32_t)__popcll(mask & below);
+                first_pos[P0 + j] = lane;
+                s_first[j] = (uint8_t)lane;
+            }
+            if (lane == 0) {
+                const double mk = ceil((double)u * threshold);
+                const uint32_t mn = mk > 0.0 ? (uint32_t)mk : 0u;
+                num_kmers[q] = n;
+                num_unique[q] = u;
+                min_kmers[q] = mn;
+                s_u = u;
+                s_min = mn;
+            }
+            BIGSI_PHASE(7);
+        }
+        if (wave == wave_b) {
+            // reverse complement, big-endian: x[i] = complement bytes p+27-4i .. p+30-4i as one little-endian word, i.e. bytes
+            // 4i .. 4i+3 of the reverse complement with the FIRST in the top byte (the last word holds 3 bytes + a zero)
+            uint32_t e[9], x[8];
+            const uint32_t base = ((lane + 31u) >> 2) - 7u, sh = (lane + 3u) & 3u;
+#pragma unroll
+            for (int i = 0; i < 9; i++) e[i] = s_cmp[base + i];
+#pragma unroll
+            for (int i = 0; i < 8; i++) x[i] = __builtin_amdgcn_alignbyte(e[8 - i], e[7 - i], sh);
+            x[7] &= 0xffffff00u;
+            bool rc = false, decided = false;              // reverse complement < k-mer ?
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const uint32_t f = __builtin_bswap32(wf[i]);
+                const bool ne = f != x[i];
+                rc = (!decided && ne) ? x[i] < f : rc;
+                decided = decided || ne;
+            }
+            uint32_t k1[8];                                // MurmurHash3_x86_32: the per-word mix does not depend on the seed
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                uint32_t w = rc ? __builtin_bswap32(x[i]) : wf[i];
+                w *= 0xcc9e2d51u; w = rotl32(w, 15); w *= 0x1b873593u;
+                k1[i] = w;
+            }
+#pragma unroll
+            for (int sd = 0; sd < H; sd++) {
+                uint32_t h1 = (uint32_t)sd;
+#pragma unroll
+                for (int i = 0; i < 7; i++) { h1 ^= k1[i]; h1 = rotl32(h1, 13); h1 = h1 * 5u + 0xe6546b64u; }
+                h1 ^= k1[7];                               // the 3 tail bytes
+                h1 ^= (uint32_t)KF;
+                h1 ^= h1 >> 16; h1 *= 0x85ebca6bu; h1 ^= h1 >> 13; h1 *= 0xc2b2ae35u; h1 ^= h1 >> 16;
+                if (live) s_hrow[lane * H + sd] = row_of_hash(h1, m);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < s_u * H) {                      // rows of the unique k-mers, first-occurrence order (u * H <= 252)
+            const uint32_t j = threadIdx.x / H, t = threadIdx.x - j * H;
+            const uint64_t r = s_hrow[(uint32_t)s_first[j] * H + t];
+            s_rows[threadIdx.x] = r;
+            rows[P0 * H + threadIdx.x] = r;
         }
     }
     __syncthreads();
-    // ---- K2: lane = two words of the row
+    // ---- K2: lane = two words of the row.  (Splitting a query's rows over groups of lanes -- 3 x 79 lanes for the 157-word
+    // rows of configs[1] -- so that three times the bytes are in flight measured +-0: with ~1000 workgroups resident the phase
+    // already moves 5.7 TB/s of 1.25 KB rows, and the HBM is the limit, not the round trips.)
     const uint32_t u = s_u;
+    BIGSI_PHASE(1);
     const uint32_t w0 = threadIdx.x * kVec;
     const bool live = w0 < wv;
     uint64_t hitw[kVec] = {0ull, 0ull};
     uint64_t pl[kVec][P];
     if (EXACT) {
+        constexpr int UNR = 16;
         const uint32_t R = u * H;
         const u64x2 ones = {~0ull, ~0ull};
         u64x2 acc = ones;
         if (live) {
-            for (uint32_t r = 0; r < R; r += 8) {
-                u64x2 v[8];
+            for (uint32_t r = 0; r < R; r += UNR) {
+                u64x2 v[UNR];
 #pragma unroll
-                for (int j = 0; j < 8; j++) v[j] = r + j < R ? load_row_seg(index, s_rows[r + j], stride_words, w0) : ones;
+                for (int j = 0; j < UNR; j++) v[j] = r + j < R ? load_row_seg(index, s_rows[r + j], stride_words, w0) : ones;
 #pragma unroll
-                for (int j = 0; j < 8; j++) acc &= v[j];
+                for (int j = 0; j < UNR; j++) acc &= v[j];
             }
             if (R == 0) acc = u64x2{0ull, 0ull};
             hitw[0] = acc.x & valid_mask(w0, n_cols);
@@ -1069,7 +1184,7 @@ __global__ __launch_bounds__(kBlock) void k_reads_fused(
 #pragma unroll
             for (int p = 0; p < P; p++) pl[v][p] = 0;
         if (live) {
-            constexpr int KM = H <= 2 ? 4 : H == 3 ? 4 : 2;
+            constexpr int KM = H <= 2 ? 8 : H == 3 ? 6 : 4;
             const u64x2 zero = {0ull, 0ull};
             for (uint32_t j = 0; j < u; j += KM) {
                 u64x2 v[KM * H];
@@ -1103,6 +1218,7 @@ __global__ __launch_bounds__(kBlock) void k_reads_fused(
             }
         }
     }
+    BIGSI_PHASE(2);
     if (live) {
         uint64_t *o = out_bits + (uint64_t)q * out_stride_words + w0;
         o[0] = hitw[0];
@@ -1134,6 +1250,7 @@ __global__ __launch_bounds__(kBlock) void k_reads_fused(
         hit_off[q] = base;
         if (q + 1 == n_seqs) hit_off[n_seqs] = base + tot;
     }
+    BIGSI_PHASE(3);
     if (mine == 0) return;
     uint64_t o = base + pre;
     if (o + mine > capacity) return;                    // the host sees total > capacity, grows the lists and launches again

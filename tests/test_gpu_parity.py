@@ -1156,12 +1156,18 @@ def test_one_launch_read_path_equals_three_launch_path(hip, h, n_cols):
     orc.insert_kmers(n_cols - 1, seqs[0])
     st.insert_kmers(3, [seqs[1][:50]], 31)
     orc.insert_kmers(3, seqs[1][:50])
-    fused, plain = st.new_batch(seqs, 31), st.new_batch(seqs, 31)
+    fused, plain, weak = st.new_batch(seqs, 31), st.new_batch(seqs, 31), st.new_batch(seqs, 31)
     for thr in (1.0, 0.4, 0.0):
         fused.run(thr, sparse_counts=True)
         plain.run(thr, sparse_counts=True, k1_global=True)
         a, b_ = fused.unique(), plain.unique()
         assert all(np.array_equal(x, y) for x, y in zip(a, b_))
+        # the dedupe's exact pairwise route (taken on a fingerprint collision; forced with 1-bit fingerprints): same everything
+        weak.run(thr, sparse_counts=True, weak_fingerprint=True)
+        assert all(np.array_equal(x, y) for x, y in zip(a, weak.unique()))
+        assert all(np.array_equal(x, y) for x, y in zip(fused.hits(), weak.hits()))
+        for i in range(len(seqs)):
+            assert np.array_equal(fused.rows(i, a[1][i]), weak.rows(i, a[1][i])), i
         fo, fc, fn = fused.hits()
         po, pc, pn = plain.hits()
         assert np.array_equal(fo, po) and np.array_equal(fc, pc) and np.array_equal(fn, pn), thr
@@ -1180,4 +1186,5 @@ def test_one_launch_read_path_equals_three_launch_path(hip, h, n_cols):
             assert fused.presence(1, hits, int(a[0][1])) == plain.presence(1, hits, int(a[0][1]))
     fused.close()
     plain.close()
+    weak.close()
     st.delete_all()
