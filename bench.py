@@ -470,6 +470,12 @@ def main():
                          "kernel": "k_reads_fused (K1 + row-AND + K4 in one launch)" if batch.info().one_launch else "k_and_exact" if exact else "k_and_count",
                          "alg_bytes_per_launch": alg_bytes_launch, "kernel_ms": and_ms, "launches_timed": int(stats.and_launches),
                          "launches_per_step": launches_per_step, "alg_bytes_per_step": alg_bytes,
+                         # bytes of a step over the step's wall time: what the HBM delivers to the whole pipeline.  For batches of
+                         # reads the one-launch kernels of consecutive steps overlap on the library's three read streams (one
+                         # step's k-merising and compaction under its neighbours' row fetches), so each kernel's own duration
+                         # -- `kernel_ms`, what `achieved` is priced on -- spans its neighbours too and exceeds the step time.
+                         "step_GBps": alg_bytes / (ms_per_step * 1e-3) / 1e9, "step_frac": alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "concurrent_launches": 3 if batch.info().one_launch else 1,
                          "rank": 0,
                          # per step, from warmup steps 2..W: K1 (+ row sort on the exact path); K4
                          "kmerize_ms": warm.kmerize_ms / (args.warmup - 1) if args.warmup > 1 else None,

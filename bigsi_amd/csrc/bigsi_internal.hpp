@@ -72,12 +72,17 @@ struct EventPair {
     uint32_t launches = 1;      // kernel launches bracketed by the pair (large batches go out as several K2 launches)
 };
 
+constexpr int kReadStreams = 3;
+
 struct bigsi_hip_index {
     int device = 0;
     hipStream_t stream = nullptr, own_stream = nullptr;
     // the sequences of a batch are uploaded here, so that loading one batch does not wait for the kernels of another
     // (and, with BIGSI_HIP_K1_OVERLAP=1 only, K1 and the row sort run here too: see k1_stream)
     hipStream_t pre_stream = nullptr;
+    hipStream_t rd_stream[kReadStreams] = {};      // k_reads_fused launches alternate over these (created at the first one)
+    uint32_t rd_next = 0;
+    bool rd_pending = false;      // something may still be running on them
     uint64_t m = 0, n_cols = 0, cap_cols = 0, stride_words = 0;
     uint32_t h = 0;
     uint64_t *d_index = nullptr;
@@ -129,6 +134,7 @@ struct bigsi_hip_batch {
     bool ran = false, exact = false, compacted = false, sparse_counts = false;
     bool pos_query_loaded = false;    // pos_query holds this load's position -> sequence map
     bool local_from_counts = false;   // the last counting run was row-sliced: hits come from thresholding the counters
+    hipStream_t run_stream = nullptr;   // the stream `done` was last recorded on
     bool weak_fp = false;         // BIGSI_RUN_WEAK_FINGERPRINT of the last one-launch run (a re-launch after a regrow repeats it)
     bool fused_run = false;           // the last run was the one-launch read kernel (k_reads_fused)
     bool elements = false;            // k-mers were given explicitly (bigsi_hip_batch_create_elements): K1 = k_rows_raw
