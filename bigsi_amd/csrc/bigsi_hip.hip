@@ -787,7 +787,7 @@ extern "C" int bigsi_hip_batch_destroy(bigsi_hip_batch *b)
     if (b->done) e = hipEventSynchronize(b->done);           // a run on one of the read streams
     if (b->gstream && b->g_done) e = hipEventSynchronize(b->g_done);
     (void)e;
-    for (DevBuf *d : {&b->elem_seq_off, &b->pres_in, &b->pres_bits, &b->pres_out, &b->rows_sorted, &b->pos_query, &b->hsh, &b->rep, &b->seqs, &b->d_seq_off, &b->d_pos_off, &b->d_tab_off, &b->tab, &b->first_pos, &b->pos_unique, &b->tmp, &b->rows,
+    for (DevBuf *d : {&b->pres_desc, &b->elem_seq_off, &b->pres_in, &b->pres_bits, &b->pres_out, &b->rows_sorted, &b->pos_query, &b->hsh, &b->rep, &b->seqs, &b->d_seq_off, &b->d_pos_off, &b->d_tab_off, &b->tab, &b->first_pos, &b->pos_unique, &b->tmp, &b->rows,
                       &b->num_kmers, &b->num_unique, &b->min_kmers, &b->bitmaps, &b->counts, &b->scratch})
         d->release();
     b->hits.release();
@@ -1649,9 +1649,10 @@ extern "C" int bigsi_hip_batch_presence_hits(bigsi_hip_batch *b, const uint64_t 
     if (n_hits > 0xFFFFFFF0ull) return fail(BIGSI_ERR_INVALID, "too many hits for one call");
     TRY(host_counts(b));
     // host side: string offsets, per-sequence colour order, word pairs
-    std::vector<uint32_t> hit_seq(n_hits), perm(n_hits), order;      // hit_seq: k-mers of the hit's sequence (its string length)
+    std::vector<uint32_t> hit_seq(n_hits), hit_q(n_hits), perm(n_hits), order;      // hit_seq: k-mers of the hit's sequence (its string length); hit_q: which sequence
     std::vector<uint64_t> hit_pos0(n_hits);
     std::vector<uint64_t> pair_off(nq + 1, 0);
+    for (uint64_t t = 0; t < n_hits; t++) perm[t] = (uint32_t)t;
     std::vector<PresencePair> pairs;
     uint64_t str = 0, alg = 0;
     uint32_t max_u = 0, max_n = 0, max_pairs = 0;
@@ -1661,6 +1662,7 @@ extern "C" int bigsi_hip_batch_presence_hits(bigsi_hip_batch *b, const uint64_t 
         for (uint64_t t = lo; t < hi; t++) {
             if (colours[h0 + t] >= ix->n_cols) return fail(BIGSI_ERR_RANGE, "colour %u >= num_cols", colours[h0 + t]);
             hit_seq[t] = b->h_num_kmers[q];
+            hit_q[t] = q;
             hit_pos0[t] = b->pos_off[q];
             string_offsets[t] = str;
             str += round_up(b->h_num_kmers[q], 16);       // every string starts on a 16-byte boundary (16-character stores)
@@ -1696,18 +1698,29 @@ extern "C" int bigsi_hip_batch_presence_hits(bigsi_hip_batch *b, const uint64_t 
     // device buffers: [pair_off | str_off | hit_seq | perm | pairs] in one upload
     const size_t o_pair_off = 0, o_str = round_up(o_pair_off + (nq + 1) * 8ull, 256), o_seq = round_up(o_str + (n_hits + 1) * 8, 256);
     const size_t o_perm = round_up(o_seq + n_hits * 4, 256), o_pos0 = round_up(o_perm + n_hits * 4, 256), o_pairs = round_up(o_pos0 + n_hits * 8, 256);
-    const size_t in_bytes = o_pairs + pairs.size() * sizeof(PresencePair);
+    const size_t o_q = round_up(o_pairs + pairs.size() * sizeof(PresencePair), 256), o_hoff = round_up(o_q + n_hits * 4, 256);
+    const size_t in_bytes = o_hoff + (nq + 1) * 8ull;
     std::vector<uint8_t> stage(in_bytes);
     memcpy(stage.data() + o_pair_off, pair_off.data(), (nq + 1) * 8ull);
-    memcpy(stage.data() + o_str, string_offsets, (n_hits + 1) * 8);
+    // the device works in rank order (each sequence's hits by colour): string offset of the hit with that rank; the other per-hit
+    // values (k-mers, map start, sequence) are the same for all hits of a sequence, whose hits keep their index range
+    for (uint64_t r = 0; r < n_hits; r++) reinterpret_cast<uint64_t *>(stage.data() + o_str)[r] = string_offsets[perm[r]];
     memcpy(stage.data() + o_seq, hit_seq.data(), n_hits * 4);
     memcpy(stage.data() + o_perm, perm.data(), n_hits * 4);
     memcpy(stage.data() + o_pos0, hit_pos0.data(), n_hits * 8);
     memcpy(stage.data() + o_pairs, pairs.data(), pairs.size() * sizeof(PresencePair));
+    memcpy(stage.data() + o_q, hit_q.data(), n_hits * 4);
+    for (uint32_t q = 0; q <= nq; q++) reinterpret_cast<uint64_t *>(stage.data() + o_hoff)[q] = hit_offsets[q] - h0;
     const uint32_t n_chunks = (uint32_t)ceil_div(std::max<uint32_t>(max_u, 1), 16);
     TRY(b->pres_in.reserve(in_bytes));
-    TRY(b->pres_bits.reserve((size_t)n_hits * n_chunks * 2));
+    TRY(b->pres_bits.reserve((size_t)round_up(n_hits, 32) * n_chunks * 2 + 16));
     TRY(b->pres_out.reserve(str));
+    const uint64_t max_pieces = (b->total_pos >> 4) + nq + 1;      // marks | list of unmarked pieces | their number
+    TRY(b->pres_desc.reserve(round_up(max_pieces * 4, 256) + max_pieces * 8 + 256));
+    uint32_t *d_marks = b->pres_desc.as<uint32_t>();
+    uint2 *d_listed = reinterpret_cast<uint2 *>(b->pres_desc.as<uint8_t>() + round_up(max_pieces * 4, 256));
+    uint32_t *d_listed_n = reinterpret_cast<uint32_t *>(b->pres_desc.as<uint8_t>() + round_up(max_pieces * 4, 256) + max_pieces * 8);
+    HIP_TRY(hipMemsetAsync(d_listed_n, 0, 4, ix->stream));
     HIP_TRY(hipMemcpyAsync(b->pres_in.p, stage.data(), in_bytes, hipMemcpyHostToDevice, ix->stream));
     const uint8_t *din = b->pres_in.as<uint8_t>();
     EventPair ep{};
@@ -1717,7 +1730,7 @@ extern "C" int bigsi_hip_batch_presence_hits(bigsi_hip_batch *b, const uint64_t 
 #define BIGSI_PRESENCE_ARGS                                                                                                        \
     grid_a, dim3(kBlock), 0, ix->stream, ix->d_index, ix->stride_words, b->rows.as<uint64_t>(), b->d_pos_off.as<uint64_t>(),            \
         b->num_unique.as<uint32_t>(), ix->h, (const uint64_t *)(din + o_pair_off), (const PresencePair *)(din + o_pairs),              \
-        (const uint32_t *)(din + o_perm), b->pres_bits.as<uint16_t>(), n_chunks
+        b->pres_bits.as<uint16_t>(), n_chunks
 #define COMMA ,
 #define BIGSI_PRESENCE(H)                                                                          \
     if (k5_waves == 4) hipLaunchKernelGGL((k_presence_bits<H COMMA 4>), BIGSI_PRESENCE_ARGS);        \
@@ -1736,11 +1749,21 @@ extern "C" int bigsi_hip_batch_presence_hits(bigsi_hip_batch *b, const uint64_t 
     HIP_TRY(hipGetLastError());
     {
         const uint32_t pieces = (uint32_t)pow2_at_least(ceil_div(std::max<uint32_t>(max_n, 1), 16));      // power of two: shifts, not divisions
-        const uint64_t blocks = ceil_div(n_hits * pieces, kBlock);
-        if (blocks > 0x7FFFFFFFull) return fail(BIGSI_ERR_INVALID, "presence request too large for one launch");
-        hipLaunchKernelGGL(k_presence_expand, dim3((unsigned)blocks), dim3(kBlock), 0, ix->stream, b->pres_bits.as<uint16_t>(), n_chunks, n_hits, pieces,
-                           (const uint32_t *)(din + o_seq), (const uint64_t *)(din + o_pos0), (const uint64_t *)(din + o_str),
-                           b->pos_unique.as<uint32_t>(), b->pres_out.as<uint8_t>());
+        const uint64_t groups = ceil_div(n_hits, kPresenceHits * kPresenceRounds), blocks = ceil_div(groups * pieces, kBlock);
+        if (blocks > 0x7FFFFFFFull || groups > 0x7FFFFFFFull)
+            return fail(BIGSI_ERR_INVALID, "presence request too large for one launch");
+        hipLaunchKernelGGL(k_presence_pieces, dim3(nq), dim3(kBlock), 0, ix->stream, b->pos_unique.as<uint32_t>(), b->d_pos_off.as<uint64_t>(),
+                           b->num_kmers.as<uint32_t>(), d_marks, d_listed_n, d_listed);
+#define BIGSI_EXPAND_ARGS                                                                                                          \
+    dim3((unsigned)blocks), dim3(kBlock), 0, ix->stream, b->pres_bits.as<uint16_t>(), n_chunks, n_hits, pieces,                          \
+        (const uint32_t *)(din + o_seq), (const uint64_t *)(din + o_pos0), (const uint64_t *)(din + o_str), b->pres_out.as<uint8_t>(),    \
+        (const uint32_t *)(din + o_q), d_marks
+        if (pieces >= 64) hipLaunchKernelGGL(k_presence_expand<true>, BIGSI_EXPAND_ARGS);
+        else hipLaunchKernelGGL(k_presence_expand<false>, BIGSI_EXPAND_ARGS);
+#undef BIGSI_EXPAND_ARGS
+        hipLaunchKernelGGL(k_presence_expand_listed, dim3(1024), dim3(kBlock), 0, ix->stream, b->pres_bits.as<uint16_t>(), n_chunks, d_listed_n, d_listed,
+                           (const uint64_t *)(din + o_hoff), b->d_pos_off.as<uint64_t>(), b->num_kmers.as<uint32_t>(), b->pos_unique.as<uint32_t>(),
+                           (const uint64_t *)(din + o_str), b->pres_out.as<uint8_t>());
     }
     HIP_TRY(hipGetLastError());
     TRY(ev_end(ix, &ep, ix->ev_pr));

@@ -127,7 +127,7 @@ struct bigsi_hip_batch {
     DevBuf pos_query, hsh, rep;   // per k-mer position: owning sequence, dedupe hash, class representative
     DevBuf rows_sorted;           // the row ids K2 streams: each query's list in address order (k_sort_rows)
     DevBuf bitmaps, counts, scratch;
-    DevBuf pres_in, pres_bits, pres_out;   // K5 at scale (presence_hits): host-built pair lists, presence bits, strings
+    DevBuf pres_in, pres_bits, pres_out, pres_desc;   // K5 at scale (presence_hits): host-built pair lists, presence bits, strings, piece marks
     void *ext_bitmaps = nullptr, *ext_counts = nullptr;
     HitBufs hits, ghits;
     // state of the last run

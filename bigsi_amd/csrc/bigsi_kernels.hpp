@@ -1389,6 +1389,15 @@ __global__ __launch_bounds__(kBlock) void k_presence(
 // that one AND.  A thread keeps the AND-ed words of 16 unique k-mers in registers and emits, per hit, the 16 presence bits
 // as one uint16 (bits[hit][k-mer / 16]); k_presence_expand then writes the ASCII strings over the n positions
 // (duplicates included) from those bits.  Bytes: u x h x 16 per hit pair -- the K2 stream restricted to the hit words.
+// presence bits of hit number `rank` (rank among the call's hits, each sequence's hits in colour order), unique k-mers
+// 16 * chunk .. +15: tiles of 32 ranks, [tile][chunk][rank % 32].  k_presence_bits then stores runs of consecutive ranks
+// next to each other (hit-major rows cost it a third of its time in isolated 2-byte stores: 373 vs 251 us without stores,
+// 319 us with this layout), and k_presence_expand reads the chunks of 4 consecutive ranks as one 8-byte word.
+__device__ __forceinline__ uint64_t presence_bits_at(uint64_t rank, uint32_t chunk, uint32_t n_chunks)
+{
+    return ((rank >> 5) * n_chunks + chunk) * 32u + (rank & 31u);
+}
+
 struct PresencePair {
     uint32_t wpair;          // word pair: columns [128 * wpair, +128)
     uint32_t base;           // rank, among the query's hits sorted by colour, of the pair's first hit (global index into perm)
@@ -1400,7 +1409,7 @@ template <int H, int WAVES = 2>      // WAVES = 2: the compiler keeps all 16 x h
 __global__ __launch_bounds__(kBlock, WAVES) void k_presence_bits(
     const uint64_t *__restrict__ index, uint64_t stride_words, const uint64_t *__restrict__ rows, const uint64_t *__restrict__ pos_off,
     const uint32_t *__restrict__ num_unique, uint32_t h_rt, const uint64_t *__restrict__ pair_off, const PresencePair *__restrict__ pairs,
-    const uint32_t *__restrict__ perm, uint16_t *__restrict__ bits /* [hit][k-mer chunk] */, uint32_t bits_stride)
+    uint16_t *__restrict__ bits /* presence_bits_at(rank, chunk) */, uint32_t bits_stride)
 {
     const uint32_t h = H > 0 ? (uint32_t)H : h_rt;
     const uint32_t q = blockIdx.z, jc = blockIdx.y;
@@ -1445,8 +1454,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_presence_bits(
         }
     }
     uint32_t rank = pr.base;
-    // hit-major: scattered 2-byte stores, merged in L2 (the whole array is a few tens of MB); the layout is chosen for
-    // k_presence_expand, whose wavefronts then read consecutive chunks of one hit (chunk-major measured 1.5x slower overall)
+    // (layout: presence_bits_at)
 #pragma unroll
     for (int half = 0; half < 2; half++) {
         uint64_t m = by_column(half ? pr.mask_hi : pr.mask_lo);      // bit c set <=> column 64 * word + c is a hit
@@ -1457,7 +1465,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_presence_bits(
             uint32_t out = 0;
 #pragma unroll
             for (int t = 0; t < 16; t++) out |= (uint32_t)(((half ? a[t].y : a[t].x) >> bp) & 1ull) << t;
-            bits[(uint64_t)perm[rank] * bits_stride + jc] = (uint16_t)out;
+            bits[presence_bits_at(rank, jc, bits_stride)] = (uint16_t)out;
             rank++;
         }
     }
@@ -1469,50 +1477,120 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_presence_bits(
 // of its 16 consecutive positions; read directly that is a 64-byte stride between lanes (one cache line per lane and load:
 // measured 0.5 TB/s).  Instead the G = min(pieces, 64) lanes that share a hit fetch its G * 16 entries with 16 coalesced
 // loads and pass them through LDS (pitch 20 dwords per lane: conflict-free 16-byte reads).
+// Most 16-position pieces of a query hold 16 DISTINCT k-mers that are also new to the query, i.e. consecutive unique indices
+// j0 .. j0+15 (always, unless the piece touches a repeat): the piece's characters are then 16 consecutive bits of the hit's
+// presence bits.  k_presence_pieces marks those pieces once per call (bit 31 + j0) and lists the others; k_presence_expand
+// turns the marked pieces of every hit into characters (two shuffled 16-bit chunks, four 24-bit multiplies: 4 bits -> 4
+// bytes), k_presence_expand_listed walks the position -> unique k-mer map for the listed ones.  (The map for every piece ran
+// at 1.1 TB/s of string bytes, VALU-bound; keeping it as a fallback inside the fast kernel held that kernel at 4 waves per
+// SIMD, latency-bound at 2.6 TB/s.)
+__global__ __launch_bounds__(kBlock) void k_presence_pieces(
+    const uint32_t *__restrict__ pos_unique, const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ num_kmers, uint32_t *__restrict__ desc,
+    uint32_t *__restrict__ listed_count, uint2 *__restrict__ listed)
+{
+    const uint32_t q = blockIdx.x, n = num_kmers[q];
+    const uint64_t P0 = pos_off[q];
+    const uint32_t *pu = pos_unique + P0;
+    uint32_t *d = desc + (P0 >> 4) + q;                    // ceil(n / 16) entries per sequence, disjoint by construction
+    for (uint32_t pc = threadIdx.x; pc * 16u < n; pc += kBlock) {
+        const uint32_t i0 = pc * 16u, cnt = min(16u, n - i0), j0 = pu[i0];
+        bool run = true;
+        for (uint32_t t = 1; t < cnt; t++) run = run && pu[i0 + t] == j0 + t;
+        d[pc] = (j0 & 0x7fffffffu) | (run ? 0x80000000u : 0u);
+        if (!run) listed[atomicAdd(listed_count, 1u)] = uint2{q, pc};
+    }
+}
+
+// the listed pieces (they touch a repeated k-mer): one workgroup per piece at a time, its threads over the hits of the
+// piece's sequence; character t of the piece = bit pos_unique[i0 + t] of the hit's presence bits
+__global__ __launch_bounds__(kBlock) void k_presence_expand_listed(
+    const uint16_t *__restrict__ bits, uint32_t bits_stride, const uint32_t *__restrict__ listed_count, const uint2 *__restrict__ listed,
+    const uint64_t *__restrict__ seq_hit_off /* per sequence: its first hit (the hits of a call are grouped by sequence) */,
+    const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ num_kmers, const uint32_t *__restrict__ pos_unique,
+    const uint64_t *__restrict__ str_off, uint8_t *__restrict__ out)
+{
+    const uint32_t count = *listed_count;
+    for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
+        const uint2 ent = listed[e];
+        const uint32_t q = ent.x, i0 = ent.y * 16u, n = num_kmers[q], cnt = min(16u, n - i0);
+        const uint32_t *pu = pos_unique + pos_off[q] + i0;
+        uint32_t j[16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) j[t] = (uint32_t)t < cnt ? pu[t] : 0u;
+        for (uint64_t hit = seq_hit_off[q] + threadIdx.x; hit < seq_hit_off[q + 1]; hit += kBlock) {       // hit = rank
+            uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+                const uint32_t ch = (uint32_t)t < cnt ? '0' + (((uint32_t)bits[presence_bits_at(hit, j[t] >> 4, bits_stride)] >> (j[t] & 15u)) & 1u) : 0u;
+                w[t >> 2] |= ch << (8 * (t & 3));
+            }
+            *reinterpret_cast<uint4 *>(out + str_off[hit] + i0) = uint4{w[0], w[1], w[2], w[3]};
+        }
+    }
+}
+
+// The marked pieces.  A thread writes piece `piece` of kPresenceHits consecutive hits per round, two levels of loads each: the
+// hit's record (scalar loads when a whole wavefront shares the hit, ONE_HIT), then the piece's mark and -- independent of it --
+// chunk `piece` of the hit's presence bits, one coalesced 2-byte load per lane; the chunk a piece really starts in lies a few
+// lanes to the left (unique index <= position) and comes over by a lane shuffle.
+constexpr int kPresenceHits = 4, kPresenceRounds = 4;
+template <bool ONE_HIT>
 __global__ __launch_bounds__(kBlock) void k_presence_expand(
     const uint16_t *__restrict__ bits, uint32_t bits_stride, uint64_t n_hits, uint32_t pieces, const uint32_t *__restrict__ hit_n,
-    const uint64_t *__restrict__ hit_pos0 /* per hit: k-mers of its sequence and where its position -> unique map starts (host-made:
-    two dependent loads fewer per thread) */, const uint64_t *__restrict__ str_off, const uint32_t *__restrict__ pos_unique, uint8_t *__restrict__ out)
+    const uint64_t *__restrict__ hit_pos0 /* per hit: where its sequence's position -> unique map starts */, const uint64_t *__restrict__ str_off,
+    uint8_t *__restrict__ out, const uint32_t *__restrict__ hit_seq /* per hit: its sequence */, const uint32_t *__restrict__ desc /* k_presence_pieces */)
+    // "hit" = rank throughout: the per-hit arrays arrive in rank order, str_off[rank] is where that hit's string goes
 {
-    __shared__ __attribute__((aligned(16))) uint32_t stage[(kBlock / 64) * 64 * 20];
     const uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     const uint32_t shift = 31u - (uint32_t)__builtin_clz(pieces);
-    const uint64_t hit = idx >> shift;
-    const bool has_hit = hit < n_hits;
+    uint32_t group = (uint32_t)(idx >> shift);             // < 2^31 by the launch condition
+    if (ONE_HIT) group = (uint32_t)__builtin_amdgcn_readfirstlane((int)group);      // pieces >= 64: the wavefront's lanes share it
     const uint32_t piece = (uint32_t)(idx & (pieces - 1u));
-    const uint32_t n = has_hit ? hit_n[hit] : 0u;
-    const uint32_t lane = threadIdx.x & 63u, G = pieces < 64u ? pieces : 64u;
-    const uint32_t sub = lane & (G - 1u), lane0 = lane - sub;          // my place among the G lanes that share my hit
-    const uint32_t base_pos = (piece - sub) * 16u;                      // first position the G lanes cover together
-    uint32_t *mine = stage + (threadIdx.x >> 6) * (64 * 20);
-    const uint32_t *pu = pos_unique + (has_hit ? hit_pos0[hit] : 0);
+    const uint32_t lane = threadIdx.x & 63u, G = pieces < 64u ? pieces : 64u, sub = lane & (G - 1u);
+#pragma unroll 1
+    for (uint32_t round = 0; round < (uint32_t)kPresenceRounds; round++) {
+        const uint64_t hit0 = ((uint64_t)group * kPresenceRounds + round) * kPresenceHits;
+        if (hit0 >= n_hits) break;
+        uint32_t n[kPresenceHits], d[kPresenceHits], cw[kPresenceHits];
+        uint64_t so[kPresenceHits];
 #pragma unroll
-    for (int t = 0; t < 16; t++) {
-        const uint32_t e = (uint32_t)t * G + sub;                       // entry e of the group's G * 16
-        const uint32_t pos = base_pos + e;
-        const uint32_t v = pos < n ? pu[pos] : 0u;
-        mine[(lane0 + (e >> 4)) * 20 + (e & 15u)] = v;
+        for (int u = 0; u < kPresenceHits; u++) {
+            const uint64_t hit = hit0 + u;
+            const bool has = hit < n_hits;
+            n[u] = has ? hit_n[hit] : 0u;
+            so[u] = has ? str_off[hit] : 0ull;
+            d[u] = has ? (uint32_t)(hit_pos0[hit] >> 4) + hit_seq[hit] + piece : 0u;       // where the piece's mark is
+        }
+        {   // chunk `piece` of the four ranks: four neighbouring 16-bit words of one tile (hit0 is a multiple of 4)
+            const uint64_t four = *reinterpret_cast<const uint64_t *>(bits + presence_bits_at(hit0, min(piece, bits_stride - 1u), bits_stride));
+#pragma unroll
+            for (int u = 0; u < kPresenceHits; u++) {
+                cw[u] = (uint32_t)(four >> (16 * u)) & 0xffffu;
+                d[u] = piece * 16u < n[u] ? desc[d[u]] : 0u;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kPresenceHits; u++) {
+            // a run of consecutive unique k-mers j0 .. : 16 consecutive presence bits, starting in chunk c <= piece
+            const uint32_t j0 = d[u] & 0x7fffffffu, c = j0 >> 4, r = j0 & 15u, delta = piece - c;
+            uint32_t lo = (uint32_t)__shfl((int)cw[u], (int)(lane - delta), 64);       // (every lane takes part in the shuffles)
+            uint32_t hi = (uint32_t)__shfl((int)cw[u], (int)(lane - delta + 1u), 64);
+            if (!(d[u] >> 31)) continue;                                             // no piece here, or a listed one
+            if (delta > sub) lo = bits[presence_bits_at(hit0 + u, c, bits_stride)];         // the chunk belongs to a lane of another wavefront
+            if (r && (delta > sub + 1u || (delta == 0u && sub + 1u >= G))) hi = bits[presence_bits_at(hit0 + u, min(c + 1u, bits_stride - 1u), bits_stride)];
+            const uint32_t x16 = (lo | (hi << 16)) >> r, cnt = min(16u, n[u] - piece * 16u);
+            uint32_t o[4];
+#pragma unroll
+            for (int k4 = 0; k4 < 4; k4++) {
+                // 4 bits -> 4 bytes: bit i of x lands on bits i, i+7, i+14, i+21 of the product, of which 0, 8, 16, 24 are kept
+                const uint32_t x = (x16 >> (4 * k4)) & 15u;
+                const uint32_t ch = (__umul24(x, 0x204081u) & 0x01010101u) + 0x30303030u;
+                const int valid = (int)cnt - 4 * k4;
+                o[k4] = valid >= 4 ? ch : valid <= 0 ? 0u : ch & ((1u << (8 * valid)) - 1u);
+            }
+            *reinterpret_cast<uint4 *>(out + so[u] + piece * 16u) = uint4{o[0], o[1], o[2], o[3]};
+        }
     }
-    __builtin_amdgcn_wave_barrier();                                    // same wavefront: LDS operations complete in order
-    uint32_t j[16];
-#pragma unroll
-    for (int k4 = 0; k4 < 4; k4++) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(mine + lane * 20 + k4 * 4);
-        j[k4 * 4] = v.x; j[k4 * 4 + 1] = v.y; j[k4 * 4 + 2] = v.z; j[k4 * 4 + 3] = v.w;
-    }
-    const uint32_t i0 = piece * 16u;
-    if (!has_hit || i0 >= n) return;
-    const uint16_t *hb = bits + hit * bits_stride;
-    uint32_t v[16];
-#pragma unroll
-    for (int t = 0; t < 16; t++) v[t] = hb[j[t] >> 4];
-    uint32_t w[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int t = 0; t < 16; t++) {
-        const uint32_t ch = i0 + t < n ? '0' + ((v[t] >> (j[t] & 15u)) & 1u) : 0u;
-        w[t >> 2] |= ch << (8 * (t & 3));
-    }
-    *reinterpret_cast<uint4 *>(out + str_off[hit] + i0) = uint4{w[0], w[1], w[2], w[3]};
 }
 
 // ------------------------------------------------------------------------------ storage contract helpers
