@@ -878,7 +878,7 @@ static bool reads_fusable(const bigsi_hip_batch *b, uint32_t flags)
     static const int fuse = env_int("BIGSI_HIP_FUSE_READS", 1);
     const bigsi_hip_index *ix = b->ix;
     const bool exact = b->exact;
-    return fuse && b->k == 31 && b->total_pos > 0 && b->max_pos <= 63 && b->n_seqs <= kHitsMaxGroups && b->wv <= (uint64_t)kBlock * kVec &&
+    return fuse && b->k == 31 && b->total_pos > 0 && b->max_pos <= 63 && b->n_seqs <= kReadsMaxSeqs && b->wv <= (uint64_t)kBlock * kVec &&
            ix->h >= 2 && ix->h <= 4 && !b->ext_bitmaps && !b->ext_counts && b->result_cols == 0 &&
            !(flags & (BIGSI_RUN_SKIP_COMPACT | BIGSI_RUN_K1_GLOBAL | BIGSI_RUN_EARLY_EXIT | BIGSI_RUN_NO_SORT)) &&
            (exact || (flags & BIGSI_RUN_SPARSE_COUNTS));     // the fused kernel keeps counters in registers: hits only
@@ -908,10 +908,13 @@ static int launch_reads_fused(bigsi_hip_batch *b, hipStream_t st = nullptr)
         TRY(hb.hit_cnt.reserve(want * 4));
         hb.cap = want;
     }
-    if (hb.lb_state.cap < kHitsMaxGroups * 8) {
-        TRY(hb.lb_state.reserve(kHitsMaxGroups * 8));
-        HIP_TRY(hipMemsetAsync(hb.lb_state.p, 0, hb.lb_state.cap, st));
-        hb.gen = 0;
+    {   // one word per query + one per section of kReadsSection queries (at least what the compaction kernels expect)
+        const uint64_t need = std::max<uint64_t>((uint64_t)b->n_seqs + b->n_seqs / kReadsSection + 2, kHitsMaxGroups) * 8;
+        if (hb.lb_state.cap < need) {
+            TRY(hb.lb_state.reserve(need));
+            HIP_TRY(hipMemsetAsync(hb.lb_state.p, 0, hb.lb_state.cap, st));
+            hb.gen = 0;
+        }
     }
     if (++hb.gen >= (1u << 20)) {
         HIP_TRY(hipMemsetAsync(hb.lb_state.p, 0, hb.lb_state.cap, st));

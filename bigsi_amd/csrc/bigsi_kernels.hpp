@@ -992,6 +992,8 @@ __device__ uint64_t g_phase[1024 * 8];
 #else
 #define BIGSI_PHASE(i) do { } while (0)
 #endif
+constexpr int kReadsSection = 1024;           // queries whose hit totals a workgroup of k_reads_fused sums directly
+constexpr uint32_t kReadsMaxSeqs = 1u << 20;  // queries per launch of k_reads_fused at most
 template <int H, bool EXACT>
 __global__ __launch_bounds__(kBlock) void k_reads_fused(
     const uint64_t *__restrict__ index, uint64_t stride_words, uint32_t wv, uint64_t n_cols, uint64_t m, double threshold,
@@ -1228,17 +1230,22 @@ __global__ __launch_bounds__(kBlock) void k_reads_fused(
     const uint32_t mine = (uint32_t)(__popcll(hitw[0]) + __popcll(hitw[1]));
     uint32_t tot;
     const uint32_t pre = block_exclusive_scan(mine, &tot, lds);
-    if (threadIdx.x == 0) __hip_atomic_store(&state[q], lb_pack(gen, tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint64_t part = 0;
-    for (uint64_t j = threadIdx.x; j < q; j += kBlock) {
-        uint64_t word;
+    // two levels: inside its section of kReadsSection queries a workgroup sums the totals of the queries before it (one pass over
+    // at most 1023 words: they are published unconditionally, in dispatch order, so nothing here can wait for a workgroup that
+    // has not started); the section's last workgroup also publishes the running total for the next section, a chain of
+    // n_seqs / kReadsSection links that runs far ahead of the row fetches.  state: [n_seqs totals | one running total per section]
+    const uint32_t first = q & ~(uint32_t)(kReadsSection - 1), section = q / kReadsSection;
+    auto wait_for = [&](const uint64_t *w) -> uint64_t {
         for (;;) {
-            word = __hip_atomic_load(&state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((uint32_t)(word >> 44) == gen && (word & ((1ull << 44) - 1)) != 0) break;
+            const uint64_t word = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((uint32_t)(word >> 44) == gen && (word & ((1ull << 44) - 1)) != 0) return (word & ((1ull << 44) - 1)) - 1;
             __builtin_amdgcn_s_sleep(1);
         }
-        part += (word & ((1ull << 44) - 1)) - 1;
-    }
+    };
+    if (threadIdx.x == 0) __hip_atomic_store(&state[q], lb_pack(gen, tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint64_t part = 0;
+    for (uint32_t j = first + threadIdx.x; j < q; j += kBlock) part += wait_for(&state[j]);
+    if (threadIdx.x == 0 && section) part += wait_for(&state[n_seqs + section]);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
     if ((threadIdx.x & 63u) == 0) lds64[threadIdx.x >> 6] = part;
@@ -1246,6 +1253,8 @@ __global__ __launch_bounds__(kBlock) void k_reads_fused(
     uint64_t base = 0;
 #pragma unroll
     for (int i = 0; i < kBlock / 64; i++) base += lds64[i];
+    if (threadIdx.x == 0 && q + 1 == first + kReadsSection)
+        __hip_atomic_store(&state[n_seqs + section + 1], lb_pack(gen, base + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (threadIdx.x == 0) {
         hit_off[q] = base;
         if (q + 1 == n_seqs) hit_off[n_seqs] = base + tot;

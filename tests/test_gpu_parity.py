@@ -1188,3 +1188,30 @@ def test_one_launch_read_path_equals_three_launch_path(hip, h, n_cols):
     plain.close()
     weak.close()
     st.delete_all()
+
+
+def test_one_launch_read_path_beyond_one_section(hip):
+    """More reads than one section of k_reads_fused's hit-offset chain (1024 queries): 2600 reads in one launch -- section
+    boundaries at queries 1023/1024 and 2047/2048, a ragged last section -- against the three-launch route, at thresholds
+    that give none, some and (0.0: every sample, lists regrown) all hits."""
+    m, n_cols, h, seed = 30011, 1500, 3, 91
+    c, st = synth_index(hip, m, n_cols, h, seed, draws=1)
+    rng = np.random.default_rng(5)
+    seqs = random_seqs(rng, 2600, 31, 93)
+    for i in (0, 1023, 1024, 2047, 2048, 2599):
+        st.insert_kmers((7 * i + 3) % n_cols, [seqs[i]], 31)
+    fused, plain = st.new_batch(seqs, 31), st.new_batch(seqs, 31)
+    for thr in (1.0, 0.4, 0.0):
+        fused.run(thr, sparse_counts=True)
+        assert fused.info().one_launch == 1
+        plain.run(thr, sparse_counts=True, k1_global=True)
+        assert all(np.array_equal(x, y) for x, y in zip(fused.unique(), plain.unique()))
+        fo, fc, fn = fused.hits()
+        po, pc, pn = plain.hits()
+        assert np.array_equal(fo, po) and np.array_equal(fc, pc) and np.array_equal(fn, pn), thr
+        if thr == 1.0:
+            for i in (0, 1023, 1024, 2047, 2048, 2599):
+                assert (7 * i + 3) % n_cols in fc[int(fo[i]):int(fo[i + 1])]
+    fused.close()
+    plain.close()
+    st.delete_all()
