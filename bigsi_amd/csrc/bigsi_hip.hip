@@ -338,6 +338,13 @@ static int transpose_device(bigsi_hip_index *ix, uint64_t col0, uint64_t n, cons
 #define BIGSI_TR_ARGS                                                                                                          \
     dim3((unsigned)sup_blocks), dim3(kBlock), 0, ix->stream, ix->d_index, ix->stride_words, ix->m, c_lo / 64, n_words,                \
         d_blooms + (c_lo - col0) * bstride, bstride, nb, (uint32_t)tr_rg, (uint32_t)tr_cg
+#ifdef BIGSI_HIP_TUNING
+    {
+        static const int skip = env_int("BIGSI_HIP_TR_SKIP", 0);
+        static bool set = false;
+        if (!set) { const uint32_t v = (uint32_t)skip; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_tr_skip), &v, 4)); set = true; }
+    }
+#endif
     if (tr_double) hipLaunchKernelGGL((k_transpose_tiles<2>), BIGSI_TR_ARGS);
     else hipLaunchKernelGGL((k_transpose_tiles<1>), BIGSI_TR_ARGS);
 #undef BIGSI_TR_ARGS

@@ -1707,15 +1707,38 @@ constexpr int kTransposeTile = 512, kTransposePitch = 72, kTransposeSuper = 32;
 // after it, bit k of lane i = bit i of (the original value of) lane k.  Step j (32, 16, .. 1) swaps, between lanes l and
 // l ^ j, the off-diagonal j x j blocks.  Each lane ROTATES what its partner needs into place before the exchange (towards
 // the high bits if the lane has bit j set, towards the low bits otherwise: one v_alignbit with a per-lane amount) and
-// merges what it receives under a per-lane mask (one v_bfi): three VALU operations and one ds_bpermute per half and step.
+// merges what it receives under a per-lane mask (one v_bfi).
+// The exchange itself stays in the vector ALUs: lane ^ 1 and ^ 2 are quad permutes, ^ 4 and ^ 8 two row mirrors each (DPP
+// modifiers of a v_mov), ^ 16 and ^ 32 gfx950's v_permlane16_swap / v_permlane32_swap (each checked lane by lane on the
+// hardware) instead of 11 ds_bpermute through the CU's one LDS crossbar.  Neither this nor a variant with 8 x 8 bit blocks in
+// registers (2x fewer VALU operations) moved the kernel: with the butterflies skipped altogether (BIGSI_HIP_TR_SKIP=1 in a
+// tuning build) it runs at the same 3.1 TB/s -- the bound is the access pattern, 128-byte reads and 64-byte writes at large
+// strides, half of what the HBM gives a copy (6.3 TB/s).
 __device__ __forceinline__ uint32_t rotl32v(uint32_t x, uint32_t r) { return __builtin_amdgcn_alignbit(x, x, (32u - r) & 31u); }
+
+template <int J> __device__ __forceinline__ uint32_t lane_xor(uint32_t x, uint32_t lane)
+{
+    constexpr int kQuadXor1 = 0xB1, kQuadXor2 = 0x4E, kQuadReverse = 0x1B, kRowMirror = 0x140, kRowHalfMirror = 0x141;
+    if (J == 1) return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, kQuadXor1, 0xF, 0xF, true);
+    if (J == 2) return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, kQuadXor2, 0xF, 0xF, true);
+    if (J == 4)      // i -> 7 - i within 8 lanes is i ^ 7; reversing each quad is ^ 3
+        return (uint32_t)__builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp((int)x, kRowHalfMirror, 0xF, 0xF, true), kQuadReverse, 0xF, 0xF, true);
+    if (J == 8)      // i ^ 15, then i ^ 7
+        return (uint32_t)__builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp((int)x, kRowMirror, 0xF, 0xF, true), kRowHalfMirror, 0xF, 0xF, true);
+    if (J == 16) {   // odd rows (16 lanes) of the first operand <-> even rows of the second
+        const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+        return (lane & 16u) ? r[0] : r[1];
+    }
+    const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return (lane & 32u) ? r[0] : r[1];
+}
 
 __device__ __forceinline__ uint64_t transpose64_lanes(uint64_t a64, uint32_t lane)
 {
     uint32_t lo = (uint32_t)a64, hi = (uint32_t)(a64 >> 32);
     {   // j = 32: whole halves change lanes
         const bool s = (lane & 32u) != 0;
-        const uint32_t recv = (uint32_t)__shfl_xor((int)(s ? lo : hi), 32, 64);
+        const uint32_t recv = lane_xor<32>(s ? lo : hi, lane);
         lo = s ? recv : lo;
         hi = s ? hi : recv;
     }
@@ -1724,8 +1747,8 @@ __device__ __forceinline__ uint64_t transpose64_lanes(uint64_t a64, uint32_t lan
         const bool s = (lane & J) != 0;                                                                      \
         const uint32_t rot = s ? (uint32_t)J : 32u - (uint32_t)J;   /* s: partner wants my bits J higher; else J lower */ \
         const uint32_t keep = s ? ~(uint32_t)M : (uint32_t)M;       /* the bits of my own value that stay */  \
-        const uint32_t rl = (uint32_t)__shfl_xor((int)rotl32v(lo, rot), J, 64);                              \
-        const uint32_t rh = (uint32_t)__shfl_xor((int)rotl32v(hi, rot), J, 64);                              \
+        const uint32_t rl = lane_xor<J>(rotl32v(lo, rot), lane);                                             \
+        const uint32_t rh = lane_xor<J>(rotl32v(hi, rot), lane);                                             \
         lo = (lo & keep) | (rl & ~keep);                                                                     \
         hi = (hi & keep) | (rh & ~keep);                                                                     \
     }
@@ -1738,6 +1761,9 @@ __device__ __forceinline__ uint64_t transpose64_lanes(uint64_t a64, uint32_t lan
     return ((uint64_t)hi << 32) | lo;
 }
 
+#ifdef BIGSI_HIP_TUNING
+__device__ uint32_t g_tr_skip = 0;      // experiment (BIGSI_HIP_TR_SKIP=1): move the tiles without transposing them
+#endif
 template <int RT>      // RT = 1: one 512-row tile per workgroup (64-byte filter runs); 2: two stacked tiles, their 128-byte filter runs loaded in one go
 __global__ __launch_bounds__(kBlock) void k_transpose_tiles(
     uint64_t *__restrict__ index, uint64_t stride_words, uint64_t m, uint64_t w_first /* first column word written; even */,
@@ -1798,6 +1824,9 @@ __global__ __launch_bounds__(kBlock) void k_transpose_tiles(
     }
     __syncthreads();
     // phase 2: the 36 unordered pairs {(cw, rc), (rc, cw)} of the 8 x 8 blocks, nine per wavefront
+#ifdef BIGSI_HIP_TUNING
+    if (!g_tr_skip)
+#endif
     for (uint32_t pi = wave; pi < 36; pi += kBlock / 64) {
         // pi -> (x, y) with x <= y: row y of the lower triangle starts at y (y + 1) / 2
         uint32_t y = 0;

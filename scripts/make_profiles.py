@@ -72,7 +72,8 @@ def main():
                                           "frac_of_8TBps": r["alg_bytes_per_launch"] / ns / PEAK}
                 summary[tag] = {"workload": d["config"]["workload"], "value_lookups_per_s": d["value"], "ms_per_step": d["ms_per_step"],
                                 "kernel": dom, "kernel_ns": ns, "GBps": r["alg_bytes_per_launch"] / ns, "frac": r["alg_bytes_per_launch"] / ns / PEAK,
-                                "k1_ms": r["kmerize_ms"], "k4_ms": r["compact_ms"]}
+                                "k1_ms": r["kmerize_ms"], "k4_ms": r["compact_ms"],
+                                "step_GBps": r.get("step_GBps"), "step_frac": r.get("step_frac"), "concurrent_launches": r.get("concurrent_launches", 1)}
         else:
             rec["measure_lines"] = lines
             summary[tag] = {"lines": [{k: v for k, v in l.items() if k in ("workload", "threshold", "n_seqs", "hits", "m", "cols", "GBps", "frac",
