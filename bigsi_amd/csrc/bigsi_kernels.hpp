@@ -1806,7 +1806,7 @@ __global__ __launch_bounds__(kBlock) void k_transpose_tiles(
         const uint64_t off = byte0 + part * 16;
         const bool ok = col < cols_here && off + 16 <= bstride && off < nb;
         const u64x2 *src = reinterpret_cast<const u64x2 *>(blooms + (w0 * 64 + (ok ? col : 0)) * bstride + (ok ? off : 0));
-        ld[it] = ok ? __builtin_nontemporal_load(src) : u64x2{0ull, 0ull};
+        ld[it] = ok ? __builtin_nontemporal_load(src) : u64x2{0ull, 0ull};      // (plain loads / stores measured the same)
     }
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t mycol = bit_of_col(lane);
@@ -1825,7 +1825,7 @@ __global__ __launch_bounds__(kBlock) void k_transpose_tiles(
     __syncthreads();
     // phase 2: the 36 unordered pairs {(cw, rc), (rc, cw)} of the 8 x 8 blocks, nine per wavefront
 #ifdef BIGSI_HIP_TUNING
-    if (!g_tr_skip)
+    if (!(g_tr_skip & 1u))
 #endif
     for (uint32_t pi = wave; pi < 36; pi += kBlock / 64) {
         // pi -> (x, y) with x <= y: row y of the lower triangle starts at y (y + 1) / 2
