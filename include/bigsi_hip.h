@@ -81,7 +81,12 @@ int bigsi_hip_set_num_hashes(bigsi_hip_index *ix, uint32_t num_hashes);
  * (bigsi/matrix/bitmatrix.py:67-75, bigsi/graph/index.py:54-60). */
 int bigsi_hip_reserve_cols(bigsi_hip_index *ix, uint64_t col_capacity);
 /* Run this index's kernels and copies on a caller-owned hipStream_t (e.g. torch's current stream, so
- * that RCCL collectives issued by the caller are ordered after them).  NULL restores the private stream. */
+ * that RCCL collectives issued by the caller are ordered after them).  NULL restores the private stream.
+ * STREAMS.  On its private stream(s) the library orders everything itself: bigsi_hip_batch_run is asynchronous; the fetch /
+ * presence calls of a batch wait for THAT batch's kernels only; batches of reads (the one-launch kernel: k = 31, < 64
+ * k-mers per query, hit lists only) are issued round-robin on three internal streams so that consecutive batches overlap;
+ * every call that changes the index, bigsi_hip_stats and bigsi_hip_synchronize wait for all of them.  With a caller-owned
+ * stream set, every kernel of the index goes to that one stream. */
 int bigsi_hip_set_stream(bigsi_hip_index *ix, void *hip_stream);
 int bigsi_hip_synchronize(bigsi_hip_index *ix);
 
