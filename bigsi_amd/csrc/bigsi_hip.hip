@@ -1008,12 +1008,13 @@ static int run_kmerize(bigsi_hip_batch *b, double threshold, bool force_global =
     }
     // dedupe table of the LDS route: 4 slots per position when that fits the LDS window (shorter probe chains), else 2
     const uint32_t hs_cap = (uint32_t)round_up(std::max<uint64_t>(b->max_pos, 1), 4);
+    const uint32_t sq_bytes = (uint32_t)round_up(b->max_len + 16, 16);
     uint32_t tab_mult = 4, tab_cap = 2;
     size_t lds = 0;
     for (;; tab_mult = 2) {
         tab_cap = 2;
         while (tab_cap < tab_mult * b->max_pos && tab_cap < (1u << 30)) tab_cap <<= 1;
-        lds = (size_t)tab_cap * 4 + 64 + (size_t)hs_cap * 4 + round_up(b->max_len + 16, 16);
+        lds = (size_t)tab_cap * 4 + 64 + (size_t)hs_cap * 4 + 2 * sq_bytes;      // table | scan | fingerprints | sequence | its complement
         if (lds <= 60 * 1024 || tab_mult == 2) break;
     }
     // fused single-launch K1 (dedupe table + sequence in LDS) when every query fits the default 64 KiB dynamic-LDS window
@@ -1031,7 +1032,7 @@ static int run_kmerize(bigsi_hip_batch *b, double threshold, bool force_global =
         TRY(ev_begin(ix, &ep, ks));
 #define BIGSI_K1_LDS(KF)                                                                                                        \
     hipLaunchKernelGGL((k_kmerize_lds<KF>), dim3(b->n_seqs), dim3(block), lds, ks, b->seqs.as<char>(), b->d_seq_off.as<uint64_t>(), \
-                       b->d_pos_off.as<uint64_t>(), b->k, ix->h, ix->m, threshold, tab_cap, tab_mult, hs_cap, b->first_pos.as<uint32_t>(), b->tmp.as<uint32_t>(), \
+                       b->d_pos_off.as<uint64_t>(), b->k, ix->h, ix->m, threshold, tab_cap, tab_mult, hs_cap, sq_bytes, b->first_pos.as<uint32_t>(), b->tmp.as<uint32_t>(), \
                        b->pos_unique.as<uint32_t>(), b->rep.as<uint32_t>(), b->rows.as<uint64_t>(), b->num_kmers.as<uint32_t>(),      \
                        b->num_unique.as<uint32_t>(), b->min_kmers.as<uint32_t>(), want_sorted ? b->rows_sorted.as<uint64_t>() : (uint64_t *)nullptr)
         if (b->k == 31) BIGSI_K1_LDS(31);

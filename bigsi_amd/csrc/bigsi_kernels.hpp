@@ -249,6 +249,70 @@ __device__ __forceinline__ bool kmer_equal(const char *a, const char *b, uint32_
     return true;
 }
 
+
+// ---- 31-mers on packed words (k_reads_fused, k_kmerize_lds<31>).  The sequence is staged in LDS as 32-bit words (`sw`), its
+// byte-wise complement (utils/fncts.py:12) likewise, 4 pad bytes in front (`cw`): a k-mer is eight words cut out with
+// v_alignbyte, its reverse complement the complement string read backwards, and the lexicographic comparison of
+// utils/fncts.py:51-54 an eight-word big-endian compare -- about 75 vector operations where the byte-wise form takes 450.
+__device__ __forceinline__ void kmer31_words(const uint32_t *sw, uint32_t p, uint32_t (&wf)[8])
+{
+    uint32_t d[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) d[i] = sw[(p >> 2) + i];
+#pragma unroll
+    for (int i = 0; i < 8; i++) wf[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], p & 3u);
+    wf[7] &= 0x00ffffffu;                                   // little-endian words, the last one holds 3 bytes
+}
+
+// equal k-mers have equal fingerprints; a match is always verified on the bytes / words
+__device__ __forceinline__ uint32_t kmer31_fingerprint(const uint32_t (&wf)[8])
+{
+    uint32_t fp = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) fp = (fp ^ wf[i]) * 0x9E3779B1u;
+    return fp ^ (fp >> 15);
+}
+
+// canonical form (the smaller of k-mer and reverse complement) and MurmurHash3_x86_32's per-word mix of it, which does
+// not depend on the seed: k1[0..6] full blocks, k1[7] the 3-byte tail
+__device__ __forceinline__ void kmer31_canonical_premix(const uint32_t (&wf)[8], const uint32_t *cw, uint32_t p, uint32_t (&k1)[8])
+{
+    // x[i] = complement bytes p+27-4i .. p+30-4i as one little-endian word = bytes 4i .. 4i+3 of the reverse complement with
+    // the FIRST in the top byte (the last word: 3 bytes + a zero)
+    uint32_t e[9], x[8];
+    const uint32_t base = ((p + 31u) >> 2) - 7u, sh = (p + 3u) & 3u;
+#pragma unroll
+    for (int i = 0; i < 9; i++) e[i] = cw[base + i];
+#pragma unroll
+    for (int i = 0; i < 8; i++) x[i] = __builtin_amdgcn_alignbyte(e[8 - i], e[7 - i], sh);
+    x[7] &= 0xffffff00u;
+    bool rc = false, decided = false;                      // reverse complement < k-mer ?
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t f = __builtin_bswap32(wf[i]);
+        const bool ne = f != x[i];
+        rc = (!decided && ne) ? x[i] < f : rc;
+        decided = decided || ne;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint32_t w = rc ? __builtin_bswap32(x[i]) : wf[i];
+        w *= 0xcc9e2d51u; w = rotl32(w, 15); w *= 0x1b873593u;
+        k1[i] = w;
+    }
+}
+
+__device__ __forceinline__ uint32_t murmur3_31_finish(const uint32_t (&k1)[8], uint32_t seed)
+{
+    uint32_t h1 = seed;
+#pragma unroll
+    for (int i = 0; i < 7; i++) { h1 ^= k1[i]; h1 = rotl32(h1, 13); h1 = h1 * 5u + 0xe6546b64u; }
+    h1 ^= k1[7];                                           // the 3 tail bytes
+    h1 ^= 31u;
+    h1 ^= h1 >> 16; h1 *= 0x85ebca6bu; h1 ^= h1 >> 13; h1 *= 0xc2b2ae35u; h1 ^= h1 >> 16;
+    return h1;
+}
+
 template <int KF>
 __global__ __launch_bounds__(kBlock) void k_kmer_insert(
     const char *__restrict__ seqs, const uint64_t *__restrict__ seq_off, const uint64_t *__restrict__ pos_off,
@@ -373,7 +437,7 @@ __device__ __forceinline__ uint32_t dedupe_hash(const char *km, uint32_t k)
 template <int KF>
 __global__ __launch_bounds__(1024) void k_kmerize_lds(
     const char *__restrict__ seqs, const uint64_t *__restrict__ seq_off, const uint64_t *__restrict__ pos_off,
-    uint32_t k, uint32_t h, uint64_t m, double threshold, uint32_t tab_cap, uint32_t tab_mult, uint32_t hs_cap, uint32_t *__restrict__ first_pos,
+    uint32_t k, uint32_t h, uint64_t m, double threshold, uint32_t tab_cap, uint32_t tab_mult, uint32_t hs_cap, uint32_t sq_bytes /* multiple of 16 */, uint32_t *__restrict__ first_pos,
     uint32_t *__restrict__ uidx, uint32_t *__restrict__ pos_unique, uint32_t *__restrict__ rep_out, uint64_t *__restrict__ rows,
     uint32_t *__restrict__ num_kmers, uint32_t *__restrict__ num_unique, uint32_t *__restrict__ min_kmers,
     uint64_t *__restrict__ rows_sorted /* non-null: also emit the query's row list in address order (what k_sort_rows does) */)
@@ -383,6 +447,7 @@ __global__ __launch_bounds__(1024) void k_kmerize_lds(
     uint32_t *scan = tab + tab_cap;                      // 16 entries
     uint32_t *hs = scan + 16;                            // hs[i]: 32-bit hash of the k-mer at position i (hs_cap entries)
     char *sq = reinterpret_cast<char *>(hs + hs_cap);    // the query's bytes
+    char *sc = sq + sq_bytes;                            // KF == 31: their complements, 4 pad bytes in front (kmer31_canonical_premix)
     const uint32_t q = blockIdx.x;
     const char *s = seqs + seq_off[q];
     const uint32_t len = (uint32_t)(seq_off[q + 1] - seq_off[q]);
@@ -392,9 +457,21 @@ __global__ __launch_bounds__(1024) void k_kmerize_lds(
     while (tsize < tab_mult * n) tsize <<= 1;            // load factor <= 1/tab_mult: short probe chains
     const uint32_t mask = tsize - 1;
     for (uint32_t i = threadIdx.x; i < tsize; i += blockDim.x) tab[i] = kEmpty;
-    for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) sq[i] = s[i];
+    for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
+        const char c = s[i];
+        sq[i] = c;
+        if (KF == 31) sc[4 + i] = (char)complement((uint8_t)c);
+    }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) hs[i] = dedupe_hash<KF>(sq + i, k);
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        if (KF == 31) {
+            uint32_t wf[8];
+            kmer31_words(reinterpret_cast<const uint32_t *>(sq), i, wf);
+            hs[i] = kmer31_fingerprint(wf);
+        } else {
+            hs[i] = dedupe_hash<KF>(sq + i, k);
+        }
+    }
     __syncthreads();
     // two positions hold the same k-mer iff their bytes are equal; the stored hashes settle almost every comparison with
     // one LDS word instead of a divergent byte loop
@@ -439,7 +516,12 @@ __global__ __launch_bounds__(1024) void k_kmerize_lds(
             fp[j] = i;
             ux[i] = j;
             uint64_t *dst = qrows + (uint64_t)j * h;
-            if (KF > 0) {
+            if (KF == 31) {
+                uint32_t wf[8], k1[8];
+                kmer31_words(reinterpret_cast<const uint32_t *>(sq), i, wf);
+                kmer31_canonical_premix(wf, reinterpret_cast<const uint32_t *>(sc), i, k1);
+                for (uint32_t sd = 0; sd < h; sd++) dst[sd] = row_of_hash(murmur3_31_finish(k1, sd), m);
+            } else if (KF > 0) {
                 RegKmer<KF> reg;
                 reg.load(sq + i);
                 uint32_t w[(KF + 3) / 4 > 0 ? (KF + 3) / 4 : 1];
@@ -1040,20 +1122,10 @@ __global__ __launch_bounds__(kBlock) void k_reads_fused(
         __syncthreads();
         BIGSI_PHASE(4);
         const bool live = lane < n;
-        uint32_t wf[8];                                    // the k-mer at position `lane`, little-endian words (last: 3 bytes)
-        if (wave == wave_a || wave == wave_b) {
-            uint32_t d[9];
-#pragma unroll
-            for (int i = 0; i < 9; i++) d[i] = s_seq[(lane >> 2) + i];
-#pragma unroll
-            for (int i = 0; i < 8; i++) wf[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], lane & 3u);
-            wf[7] &= 0x00ffffffu;
-        }
+        uint32_t wf[8];                                    // the k-mer at position `lane` (kmer31_words)
+        if (wave == wave_a || wave == wave_b) kmer31_words(s_seq, lane, wf);
         if (wave == wave_a) {
-            uint32_t fp = 0;                               // fingerprint: equal k-mers have equal ones; a match is verified word by word
-#pragma unroll
-            for (int i = 0; i < 8; i++) fp = (fp ^ wf[i]) * 0x9E3779B1u;
-            fp = live ? (fp ^ (fp >> 15)) & fp_mask : 0u;
+            const uint32_t fp = live ? kmer31_fingerprint(wf) & fp_mask : 0u;
             BIGSI_PHASE(5);
             // rep = the first position holding this lane's k-mer.  Branch-free pass: the lowest lane with the same fingerprint
             // (independent v_readlane / compare / select triples, highest lane first so that the lowest match is kept; a serial
@@ -1110,40 +1182,11 @@ __global__ __launch_bounds__(kBlock) void k_reads_fused(
             BIGSI_PHASE(7);
         }
         if (wave == wave_b) {
-            // reverse complement, big-endian: x[i] = complement bytes p+27-4i .. p+30-4i as one little-endian word, i.e. bytes
-            // 4i .. 4i+3 of the reverse complement with the FIRST in the top byte (the last word holds 3 bytes + a zero)
-            uint32_t e[9], x[8];
-            const uint32_t base = ((lane + 31u) >> 2) - 7u, sh = (lane + 3u) & 3u;
+            uint32_t k1[8];
+            kmer31_canonical_premix(wf, s_cmp, lane, k1);
 #pragma unroll
-            for (int i = 0; i < 9; i++) e[i] = s_cmp[base + i];
-#pragma unroll
-            for (int i = 0; i < 8; i++) x[i] = __builtin_amdgcn_alignbyte(e[8 - i], e[7 - i], sh);
-            x[7] &= 0xffffff00u;
-            bool rc = false, decided = false;              // reverse complement < k-mer ?
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const uint32_t f = __builtin_bswap32(wf[i]);
-                const bool ne = f != x[i];
-                rc = (!decided && ne) ? x[i] < f : rc;
-                decided = decided || ne;
-            }
-            uint32_t k1[8];                                // MurmurHash3_x86_32: the per-word mix does not depend on the seed
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                uint32_t w = rc ? __builtin_bswap32(x[i]) : wf[i];
-                w *= 0xcc9e2d51u; w = rotl32(w, 15); w *= 0x1b873593u;
-                k1[i] = w;
-            }
-#pragma unroll
-            for (int sd = 0; sd < H; sd++) {
-                uint32_t h1 = (uint32_t)sd;
-#pragma unroll
-                for (int i = 0; i < 7; i++) { h1 ^= k1[i]; h1 = rotl32(h1, 13); h1 = h1 * 5u + 0xe6546b64u; }
-                h1 ^= k1[7];                               // the 3 tail bytes
-                h1 ^= (uint32_t)KF;
-                h1 ^= h1 >> 16; h1 *= 0x85ebca6bu; h1 ^= h1 >> 13; h1 *= 0xc2b2ae35u; h1 ^= h1 >> 16;
-                if (live) s_hrow[lane * H + sd] = row_of_hash(h1, m);
-            }
+            for (int sd = 0; sd < H; sd++)
+                if (live) s_hrow[lane * H + sd] = row_of_hash(murmur3_31_finish(k1, (uint32_t)sd), m);
         }
         __syncthreads();
         if (threadIdx.x < s_u * H) {                      // rows of the unique k-mers, first-occurrence order (u * H <= 252)
