@@ -328,16 +328,20 @@ static int transpose_device(bigsi_hip_index *ix, uint64_t col0, uint64_t n, cons
     };
     const uint64_t c_lo = std::min(end, round_up(col0, 128)), n_words = (end - c_lo) / 64, c_hi = c_lo + n_words * 64;
     static const int tiled = env_int("BIGSI_HIP_TRANSPOSE_TILED", 1);
-    static const int tr_rg = env_int("BIGSI_HIP_TR_RG", 2), tr_cg = env_int("BIGSI_HIP_TR_CG", 2);      // A/B in DESIGN.md section 7
-    static const int tr_double = env_int("BIGSI_HIP_TR_DOUBLE", 1);
-    const uint64_t rt = tr_double ? 2 : 1;
-    const uint64_t sup_blocks = ceil_div(ceil_div(ix->m, kTransposeTile * rt), kTransposeSuper) * ceil_div(ceil_div(n_words, 8), kTransposeSuper) *
-                                (uint64_t)(kTransposeSuper * kTransposeSuper);
+    static const int tr_rg = env_int("BIGSI_HIP_TR_RG", 4), tr_cg = env_int("BIGSI_HIP_TR_CG", 1);      // A/B in DESIGN.md section 7
+    static const int tr_double = env_int("BIGSI_HIP_TR_DOUBLE", 1), tr_wide = env_int("BIGSI_HIP_TR_WIDE", 1);
+    const uint64_t rt = tr_double ? 2 : 1, ct = tr_wide ? 2 : 1;
+    // supertiles of 1024 tiles: 32 wide, narrower (and higher) when the matrix has fewer tile columns than that
+    const uint64_t tiles_c = ceil_div(n_words, 8 * ct);
+    uint32_t sup_w = kTransposeSuper;
+    while (sup_w > 1 && sup_w / 2 >= tiles_c) sup_w /= 2;
+    const uint32_t sup_h = (uint32_t)(kTransposeSuper * kTransposeSuper) / sup_w, cg_eff = std::min<uint32_t>((uint32_t)tr_cg, sup_w);
+    const uint64_t sup_blocks = ceil_div(ceil_div(ix->m, kTransposeTile * rt), sup_h) * ceil_div(tiles_c, sup_w) * (uint64_t)(kTransposeSuper * kTransposeSuper);
     if (!tiled || n_words == 0 || bstride % 16 || ((uintptr_t)d_blooms & 15u) || sup_blocks > 0x7FFFFFFFull) return slow(col0, n);
     TRY(slow(col0, c_lo - col0));
 #define BIGSI_TR_ARGS                                                                                                          \
-    dim3((unsigned)sup_blocks), dim3(kBlock), 0, ix->stream, ix->d_index, ix->stride_words, ix->m, c_lo / 64, n_words,                \
-        d_blooms + (c_lo - col0) * bstride, bstride, nb, (uint32_t)tr_rg, (uint32_t)tr_cg
+    dim3((unsigned)sup_blocks), dim3(kBlock * (unsigned)ct), 0, ix->stream, ix->d_index, ix->stride_words, ix->m, c_lo / 64, n_words,  \
+        d_blooms + (c_lo - col0) * bstride, bstride, nb, (uint32_t)tr_rg, cg_eff, sup_w
 #ifdef BIGSI_HIP_TUNING
     {
         static const int skip = env_int("BIGSI_HIP_TR_SKIP", 0);
@@ -345,8 +349,12 @@ static int transpose_device(bigsi_hip_index *ix, uint64_t col0, uint64_t n, cons
         if (!set) { const uint32_t v = (uint32_t)skip; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_tr_skip), &v, 4)); set = true; }
     }
 #endif
-    if (tr_double) hipLaunchKernelGGL((k_transpose_tiles<2>), BIGSI_TR_ARGS);
-    else hipLaunchKernelGGL((k_transpose_tiles<1>), BIGSI_TR_ARGS);
+#define COMMA ,
+    if (tr_double && tr_wide) hipLaunchKernelGGL((k_transpose_tiles<2 COMMA 2>), BIGSI_TR_ARGS);
+    else if (tr_double) hipLaunchKernelGGL((k_transpose_tiles<2 COMMA 1>), BIGSI_TR_ARGS);
+    else if (tr_wide) hipLaunchKernelGGL((k_transpose_tiles<1 COMMA 2>), BIGSI_TR_ARGS);
+    else hipLaunchKernelGGL((k_transpose_tiles<1 COMMA 1>), BIGSI_TR_ARGS);
+#undef COMMA
 #undef BIGSI_TR_ARGS
     HIP_TRY(hipGetLastError());
     return slow(c_hi, end - c_hi);

@@ -1807,35 +1807,45 @@ __device__ __forceinline__ uint64_t transpose64_lanes(uint64_t a64, uint32_t lan
 #ifdef BIGSI_HIP_TUNING
 __device__ uint32_t g_tr_skip = 0;      // experiment (BIGSI_HIP_TR_SKIP=1): move the tiles without transposing them
 #endif
-template <int RT>      // RT = 1: one 512-row tile per workgroup (64-byte filter runs); 2: two stacked tiles, their 128-byte filter runs loaded in one go
-__global__ __launch_bounds__(kBlock) void k_transpose_tiles(
+// RT = 1: one 512-row tile per workgroup (64-byte filter runs); 2: two stacked tiles, their 128-byte filter runs loaded in one go.
+// CT = 1: 512 columns per workgroup (64-byte row runs); 2: two tiles side by side, each handled by its own 256 threads in its
+// own LDS buffer, their rows stored together as 128-byte runs (half as many DRAM row activations on the write side).
+template <int RT, int CT>
+__global__ __launch_bounds__(kBlock * CT) void k_transpose_tiles(
     uint64_t *__restrict__ index, uint64_t stride_words, uint64_t m, uint64_t w_first /* first column word written; even */,
     uint64_t n_words /* whole 64-column words to write */, const uint8_t *__restrict__ blooms /* filter of column 64 * w_first */,
     uint64_t bstride /* bytes between filters; multiple of 16 */, uint64_t nb /* valid bytes of a filter: ceil(m / 8) */,
-    uint32_t rg, uint32_t cg /* tiles per XCD group along rows / columns: powers of two, rg * cg <= 128 */)
+    uint32_t rg, uint32_t cg /* tiles per XCD group along rows / columns: powers of two, rg * cg <= 128, cg <= sup_w */,
+    uint32_t sup_w /* supertile width in tiles: a power of two <= 32 */)
 {
-    // ONE tile buffer: line L holds, before the transpose, the 64 row-bytes of column L and, after it, the 64 column-bytes
-    // of row L.  Block (cw, rc) of 64 x 64 bits sits at lines [64 cw, +64), bytes [8 rc, +8) and its transpose belongs at
-    // lines [64 rc, +64), bytes [8 cw, +8) -- the place of block (rc, cw) -- so blocks are transposed in mirrored pairs, each
-    // written where the other was read (37 KB of LDS instead of 74: four workgroups per CU keep loads, butterflies and
-    // stores of different tiles overlapping).
-    __shared__ __attribute__((aligned(16))) uint8_t tile[kTransposeTile * kTransposePitch];
-    // workgroup -> tile in SUPERTILES of 32 x 32 tiles: the ~1000 workgroups resident at any time then read 2 KB runs of
-    // each filter and write 2 KB runs of each row (DRAM-page sized), instead of 64-byte pieces strided by a whole row or filter
-    const uint64_t tiles_c = (n_words + 7) / 8, sup_c = (tiles_c + kTransposeSuper - 1) / kTransposeSuper;
+    // ONE buffer per 512 x 512 tile: line L holds, before the transpose, the 64 row-bytes of column L and, after it, the 64
+    // column-bytes of row L.  Block (cw, rc) of 64 x 64 bits sits at lines [64 cw, +64), bytes [8 rc, +8) and its transpose
+    // belongs at lines [64 rc, +64), bytes [8 cw, +8) -- the place of block (rc, cw) -- so blocks are transposed in mirrored
+    // pairs, each written where the other was read (37 KB of LDS per tile instead of 74).
+    __shared__ __attribute__((aligned(16))) uint8_t tiles[CT][kTransposeTile * kTransposePitch];
+    constexpr uint32_t kWordsPerBlock = 8 * CT;
+    // workgroup -> tile in SUPERTILES of 1024 tiles, sup_w wide (32, or fewer when the matrix has fewer tile columns: no
+    // workgroups wasted on tiles beyond its edge) and 1024 / sup_w high: the ~1000 workgroups resident at any time then read
+    // long runs of each filter and write long runs of each row, instead of short pieces strided by a whole row or filter
+    const uint64_t tiles_c = (n_words + kWordsPerBlock - 1) / kWordsPerBlock, sup_c = (tiles_c + sup_w - 1) / sup_w;
+    const uint32_t sup_h = (uint32_t)(kTransposeSuper * kTransposeSuper) / sup_w;
     const uint64_t sup = blockIdx.x / (kTransposeSuper * kTransposeSuper);
     const uint32_t within = blockIdx.x % (kTransposeSuper * kTransposeSuper);
     // inside a supertile: groups of rg x cg neighbouring tiles go to the SAME XCD (block b runs on XCD b % 8), one right after
     // the other: row-neighbours share the 128-byte lines of the filters, column-neighbours those of the rows, and with
     // consecutive blocks they landed in different L2s (FETCH_SIZE showed every filter line read about twice)
     const uint32_t gsz = rg * cg, xcd = within & 7u, sl = within >> 3, t = sl % gsz, g = (sl / gsz) * 8u + xcd;
-    const uint32_t gpr = kTransposeSuper / cg;      // groups per supertile row of groups
-    const uint64_t tile_r = (sup / sup_c) * kTransposeSuper + (g / gpr) * rg + t % rg;
-    const uint64_t tile_c = (sup % sup_c) * kTransposeSuper + (g % gpr) * cg + t / rg;
+    const uint32_t gpr = sup_w / cg;                // groups per supertile row of groups
+    const uint64_t tile_r = (sup / sup_c) * sup_h + (g / gpr) * rg + t % rg;
+    const uint64_t tile_c = (sup % sup_c) * sup_w + (g % gpr) * cg + t / rg;
     if (tile_r * kTransposeTile * RT >= m || tile_c >= tiles_c) return;
     const uint64_t byte0 = tile_r * (kTransposeTile / 8) * RT;
-    const uint64_t w0 = tile_c * 8;
-    const uint32_t words_here = (uint32_t)(n_words - w0 < 8 ? n_words - w0 : 8), cols_here = words_here * 64;
+    const uint64_t w0 = tile_c * kWordsPerBlock;
+    const uint32_t words_here = (uint32_t)(n_words - w0 < kWordsPerBlock ? n_words - w0 : kWordsPerBlock);
+    // this thread's 512-column tile (of the workgroup's CT) and its place among that tile's 256 threads
+    const uint32_t ct = threadIdx.x / kBlock, tid = threadIdx.x % kBlock;
+    uint8_t *tile = tiles[ct];
+    const uint32_t cols_here = words_here > 8 * ct ? min(words_here - 8 * ct, 8u) * 64u : 0u;
     // phase 1: 64 bytes of each column's filter -> tile[col][0..64) (columns beyond the last word: zeros).  A 16-byte load
     // that starts inside the filter's pitch is always in bounds (pitch and offsets are multiples of 16); bytes past
     // ceil(m / 8), like bits past m inside the last byte, belong to rows >= m, which phase 3 never stores.
@@ -1845,13 +1855,13 @@ __global__ __launch_bounds__(kBlock) void k_transpose_tiles(
     u64x2 ld[kLoads];
 #pragma unroll
     for (int it = 0; it < kLoads; it++) {
-        const uint32_t item = it * kBlock + threadIdx.x, col = item / kParts, part = item % kParts;
+        const uint32_t item = it * kBlock + tid, col = item / kParts, part = item % kParts;
         const uint64_t off = byte0 + part * 16;
         const bool ok = col < cols_here && off + 16 <= bstride && off < nb;
-        const u64x2 *src = reinterpret_cast<const u64x2 *>(blooms + (w0 * 64 + (ok ? col : 0)) * bstride + (ok ? off : 0));
+        const u64x2 *src = reinterpret_cast<const u64x2 *>(blooms + ((w0 + 8 * ct) * 64 + (ok ? col : 0)) * bstride + (ok ? off : 0));
         ld[it] = ok ? __builtin_nontemporal_load(src) : u64x2{0ull, 0ull};      // (plain loads / stores measured the same)
     }
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
     const uint32_t mycol = bit_of_col(lane);
 #pragma unroll
     for (int half = 0; half < RT; half++) {
@@ -1859,7 +1869,7 @@ __global__ __launch_bounds__(kBlock) void k_transpose_tiles(
     if (half) __syncthreads();                          // phase 3 of the first tile has read the buffer
 #pragma unroll
     for (int it = 0; it < kLoads; it++) {
-        const uint32_t item = it * kBlock + threadIdx.x, col = item / kParts, part = item % kParts;
+        const uint32_t item = it * kBlock + tid, col = item / kParts, part = item % kParts;
         if ((int)(part >> 2) != half) continue;
         uint64_t *d = reinterpret_cast<uint64_t *>(tile + col * kTransposePitch + (part & 3u) * 16);
         d[0] = ld[it].x;
@@ -1887,13 +1897,13 @@ __global__ __launch_bounds__(kBlock) void k_transpose_tiles(
         if (x != y) *reinterpret_cast<uint64_t *>(pa + lane * kTransposePitch) = vb;
     }
     __syncthreads();
-    // phase 3: tile[row][0 .. 8 * words_here) -> the rows' words [w_first + w0, +words_here)
+    // phase 3: tiles[..][row][0 .. 64) -> the rows' words [w_first + w0, +words_here): 4 * CT lanes per row, 16 bytes each
 #pragma unroll
     for (int it = 0; it < kTransposeTile * 4 / kBlock; it++) {
-        const uint32_t item = it * kBlock + threadIdx.x, row = item >> 2, part = item & 3u;
+        const uint32_t item = it * (kBlock * CT) + threadIdx.x, row = item / (4 * CT), part = item % (4 * CT);
         const uint64_t r = r0 + row;
         if (r >= m || part * 2 >= words_here) continue;
-        const uint64_t *sp = reinterpret_cast<const uint64_t *>(tile + row * kTransposePitch + part * 16);
+        const uint64_t *sp = reinterpret_cast<const uint64_t *>(tiles[part >> 2] + row * kTransposePitch + (part & 3u) * 16);
         uint64_t *dst = index + r * stride_words + w_first + w0 + part * 2;
         if (part * 2 + 1 < words_here) __builtin_nontemporal_store(u64x2{sp[0], sp[1]}, reinterpret_cast<u64x2 *>(dst));
         else dst[0] = sp[0];

@@ -199,7 +199,10 @@ def transpose():
     (bigsi_hip_insert_columns_device), kernel time from the library's events; bytes = filters in + rows out."""
     import torch
     L = _lib.lib()
-    for m, ncols in ((10_000_000, 8192), (1_000_000, 100_000), (1_000_000, 100_000 - 37)):
+    shapes = ((10_000_000, 8192), (1_000_000, 100_000), (1_000_000, 100_000 - 37))
+    if os.environ.get("BIGSI_TR_SHAPES"):          # e.g. "4000000x16384,2000000x32768"
+        shapes = tuple(tuple(int(x) for x in sh.split("x")) for sh in os.environ["BIGSI_TR_SHAPES"].split(","))
+    for m, ncols in shapes:
         st = get_storage({"storage-engine": "hip-hbm", "k": 31, "m": m, "h": 3,
                           "storage-config": {"name": "tr", "device": 0, "max_cols": ncols}})
         st.delete_all()
