@@ -1215,3 +1215,54 @@ def test_one_launch_read_path_beyond_one_section(hip):
     fused.close()
     plain.close()
     st.delete_all()
+
+
+def test_read_batches_on_library_streams_keep_their_order(hip):
+    """Batches of reads run on three library streams (consecutive batches overlap).  What must still hold: a batch answers for the
+    index as it was when the batch was launched even if the index is changed right after the (asynchronous) launch; a batch
+    re-run after the change sees it; interleaving read batches with a gene-length batch on the index stream, reloading a batch
+    while others are in flight, and stats / synchronize all give what a one-stream run gives."""
+    from bigsi_amd import _lib
+    m, n_cols, h, seed = 30011, 3000, 3, 7
+    c, st = synth_index(hip, m, n_cols, h, seed, draws=1)
+    rng = np.random.default_rng(3)
+    reads = [random_seqs(rng, 1500, 61, 61) for _ in range(6)]
+    genes = random_seqs(rng, 8, 900, 1200)
+    ref = []
+    for rs in reads:                                    # reference answers, one batch at a time, fully synchronised
+        b = st.new_batch(rs, 31)
+        b.run(0.3, sparse_counts=True, k1_global=True)
+        ref.append([x.copy() for x in b.hits()])
+        b.close()
+    batches = [st.new_batch(rs, 31) for rs in reads]
+    gene = st.new_batch(genes, 31)
+    check = _lib.check
+    L = _lib.lib()
+    check(L.bigsi_hip_set_profiling(st.handle, 3))
+    for i, b in enumerate(batches):                     # six one-launch runs in flight, a long batch in between
+        b.run(0.3, sparse_counts=True)
+        assert b.info().one_launch == 1
+        if i == 2:
+            gene.run(0.3, sparse_counts=True)
+    # change the index while they may still be running: every read of batch 0 now matches sample 5 in full
+    st.insert_kmers(5, reads[0], 31)
+    for b, want in zip(batches, ref):                   # ... but the launched runs answered for the index as it was
+        assert all(np.array_equal(x, y) for x, y in zip(b.hits(), want))
+    s_ = _lib.Stats()
+    check(L.bigsi_hip_stats(st.handle, _lib.C.byref(s_), 1))
+    assert s_.and_launches_total >= 7 and 1 <= s_.and_launches < s_.and_launches_total      # every third run timed
+    check(L.bigsi_hip_set_profiling(st.handle, 0))
+    batches[0].run(0.3, sparse_counts=True)             # a re-run sees the inserted k-mers
+    off, col, cnt = batches[0].hits()
+    for i in range(0, 1500, 97):
+        lo, hi = int(off[i]), int(off[i + 1])
+        assert 5 in col[lo:hi] and cnt[lo:hi][list(col[lo:hi]).index(5)] == 31
+    batches[1].reload(reads[2], 31)                     # reload + run while others could be in flight
+    batches[3].run(0.3, sparse_counts=True)
+    batches[1].run(0.3, sparse_counts=True)
+    batches[2].run(0.3, sparse_counts=True)             # the same reads, same (changed) index
+    got, want = batches[1].hits(), batches[2].hits()
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+    for b in batches + [gene]:
+        b.close()
+    st.delete_all()
