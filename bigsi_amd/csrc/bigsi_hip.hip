@@ -140,6 +140,10 @@ static void recycle_events(bigsi_hip_index *ix)
 extern "C" int bigsi_hip_close(bigsi_hip_index *ix)
 {
     if (!ix) return BIGSI_OK;
+    if (ix->search_ws) {
+        bigsi_hip_batch_destroy(ix->search_ws);
+        ix->search_ws = nullptr;
+    }
     hipError_t e = hipSetDevice(ix->device);
     e = hipStreamSynchronize(ix->stream);
     if (ix->pre_stream) e = hipStreamSynchronize(ix->pre_stream);

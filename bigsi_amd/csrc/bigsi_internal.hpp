@@ -83,6 +83,7 @@ struct bigsi_hip_index {
     hipStream_t rd_stream[kReadStreams] = {};      // k_reads_fused launches alternate over these (created at the first one)
     uint32_t rd_next = 0;
     bool rd_pending = false;      // something may still be running on them
+    struct bigsi_hip_batch *search_ws = nullptr;      // bigsi_hip_search_batch's workspace, created at its first call
     uint64_t m = 0, n_cols = 0, cap_cols = 0, stride_words = 0;
     uint32_t h = 0;
     uint64_t *d_index = nullptr;

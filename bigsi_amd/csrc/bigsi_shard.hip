@@ -95,12 +95,19 @@ extern "C" int bigsi_hip_search_batch(bigsi_hip_index *ix, const char *seqs, con
                                       uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t hit_capacity)
 {
     if (!hit_offsets) return fail(BIGSI_ERR_INVALID, "hit_offsets is NULL");
-    bigsi_hip_batch *b = nullptr;
-    TRY(bigsi_hip_batch_create(ix, seqs, offsets, n_seqs, k, &b));
+    if (!ix) return fail(BIGSI_ERR_INVALID, "NULL index");
+    // the index keeps ONE workspace for this entry point (a caller in a loop pays its ~20 device allocations once; the
+    // workspace goes with the index, or right away if a call fails)
+    if (!ix->search_ws) TRY(bigsi_hip_batch_create(ix, seqs, offsets, n_seqs, k, &ix->search_ws));
+    else TRY(bigsi_hip_batch_reload(ix->search_ws, seqs, offsets, n_seqs, k));
+    bigsi_hip_batch *b = ix->search_ws;
     int rc = bigsi_hip_batch_run(b, threshold, (flags & ~BIGSI_RUN_SKIP_COMPACT) | BIGSI_RUN_SPARSE_COUNTS);
     if (rc == BIGSI_OK) rc = bigsi_hip_batch_fetch_unique(b, num_kmers, num_unique, min_kmers);
     if (rc == BIGSI_OK) rc = bigsi_hip_batch_fetch_hits(b, hit_offsets, colours, counts, hit_capacity);
-    bigsi_hip_batch_destroy(b);      // leaves the thread's error message of a failed call above in place
+    if (rc != BIGSI_OK && rc != BIGSI_ERR_CAPACITY) {      // (a too small hit buffer is the caller's to retry: offsets are filled in)
+        ix->search_ws = nullptr;
+        bigsi_hip_batch_destroy(b);      // leaves the thread's error message of the failed call above in place
+    }
     return rc;
 }
 
@@ -297,6 +304,7 @@ struct bigsi_hip_group {
     uint64_t m = 0, n_cols = 0, cap_cols = 0, shard_cols = 0;
     uint32_t h = 0;
     bool rccl = false;
+    bigsi_hip_group_batch *search_ws = nullptr;      // bigsi_hip_group_search_batch's workspace
     uint32_t n() const { return (uint32_t)ix.size(); }
     // columns of the whole index that live on shard i, for a given total
     uint64_t cols_of(uint32_t i, uint64_t total) const
@@ -378,6 +386,7 @@ extern "C" int bigsi_hip_group_open(uint64_t num_rows, uint64_t num_cols, uint64
 extern "C" int bigsi_hip_group_close(bigsi_hip_group *g)
 {
     if (!g) return BIGSI_OK;
+    if (g->search_ws) bigsi_hip_group_batch_destroy(g->search_ws);
     for (auto *c : g->comm) bigsi_hip_comm_destroy(c);
     for (auto *ix : g->ix) bigsi_hip_close(ix);
     delete g;
@@ -861,11 +870,16 @@ extern "C" int bigsi_hip_group_search_batch(bigsi_hip_group *g, const char *seqs
                                             uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t hit_capacity)
 {
     if (!hit_offsets) return fail(BIGSI_ERR_INVALID, "hit_offsets is NULL");
-    bigsi_hip_group_batch *gb = nullptr;
-    TRY(bigsi_hip_group_batch_create(g, seqs, offsets, n_seqs, k, &gb));
+    if (!g) return fail(BIGSI_ERR_INVALID, "NULL group");
+    if (!g->search_ws) TRY(bigsi_hip_group_batch_create(g, seqs, offsets, n_seqs, k, &g->search_ws));      // kept, as for one index
+    else TRY(bigsi_hip_group_batch_reload(g->search_ws, seqs, offsets, n_seqs, k));
+    bigsi_hip_group_batch *gb = g->search_ws;
     int rc = bigsi_hip_group_batch_run(gb, threshold, flags);
     if (rc == BIGSI_OK) rc = bigsi_hip_group_batch_fetch_unique(gb, num_kmers, num_unique, min_kmers);
     if (rc == BIGSI_OK) rc = bigsi_hip_group_batch_fetch_hits(gb, hit_offsets, colours, counts, hit_capacity);
-    bigsi_hip_group_batch_destroy(gb);
+    if (rc != BIGSI_OK && rc != BIGSI_ERR_CAPACITY) {
+        g->search_ws = nullptr;
+        bigsi_hip_group_batch_destroy(gb);
+    }
     return rc;
 }

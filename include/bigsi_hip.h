@@ -259,8 +259,9 @@ int bigsi_hip_batch_fetch_gathered_hits(bigsi_hip_batch *b, uint64_t *hit_offset
 
 /* ================================================================== CORE: one-call search
  * The whole of BIGSI.search for a batch of sequences in ONE call (what a non-Python binder of this boundary needs):
- * create + run + fetch_unique + fetch_hits + destroy.  Outputs as in fetch_unique / fetch_hits; any of num_kmers /
- * num_unique / min_kmers may be NULL.  BIGSI_ERR_CAPACITY (hit_offsets filled) when hit_capacity is too small. */
+ * load + run + fetch_unique + fetch_hits on a workspace the index keeps from call to call (its device buffers are allocated
+ * once and only grow).  Outputs as in fetch_unique / fetch_hits; any of num_kmers / num_unique / min_kmers may be NULL.
+ * BIGSI_ERR_CAPACITY (hit_offsets filled) when hit_capacity is too small. */
 int bigsi_hip_search_batch(bigsi_hip_index *ix, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k,
                            double threshold, uint32_t flags, uint32_t *num_kmers, uint32_t *num_unique, uint32_t *min_kmers,
                            uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t hit_capacity);

@@ -1095,6 +1095,23 @@ def test_storage_search_batch_entry_point(hip):
                 for x, f in zip(col, cnt):
                     r = by_name[names[int(x)]]
                     assert (int(f), nu) == (r["num_kmers_found"], r["num_kmers"])
+        # the entry point keeps its workspace inside the index: calls of other sizes and k, an invalid call in between,
+        # and an index change must each give what a fresh batch gives
+        qs = g["queries"]
+        for batch_qs, k2 in ((qs[:3], g["k"]), (qs[:40] * 3, g["k"]), ([q[:25] for q in qs[:5]], 11), (qs[:1], g["k"])):
+            got = b.storage.search_batch(batch_qs, k2, 0.4)
+            fresh = b.storage.new_batch(batch_qs, k2)
+            fresh.run(0.4, sparse_counts=True)
+            _, nu, _ = fresh.unique()
+            off, col, cnt = fresh.hits()
+            for i, (nk_i, nu_i, col_i, cnt_i) in enumerate(got):
+                assert nu_i == nu[i] and np.array_equal(col_i, col[int(off[i]):int(off[i + 1])]) and np.array_equal(cnt_i, cnt[int(off[i]):int(off[i + 1])])
+            fresh.close()
+            with pytest.raises(Exception):
+                b.storage.search_batch(batch_qs, 0, 0.4)              # k = 0: refused, the workspace is dropped and rebuilt
+        b.insert(bigsi_amd.BIGSI.bloom(c, [qs[0][i:i + g["k"]] for i in range(len(qs[0]) - g["k"] + 1)]), "extra")
+        nk, nu, col, cnt = b.storage.search_batch(qs[:1], g["k"], 1.0)[0]
+        assert b.sample_to_colour("extra") in col
     finally:
         b.delete()
 
