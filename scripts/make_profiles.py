@@ -107,11 +107,32 @@ def main():
         traffic[key] = {"kernel": k, "traffic_bytes_per_launch": fetch + write, "fetch_bytes_corrected": fetch, "write_bytes": write,
                         "source": "profiles/r02_c3_pmc.json (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes; FETCH_SIZE doubled per "
                                   "MI355X_MICROARCH.md, calibrated on k_fill_synth's WRITE_SIZE = index bytes)"}
+    # the one-launch read kernel on BASELINE configs[1]
+    try:
+        fe = json.load(open(os.path.join(SRC, "pmc_c2_FETCH_SIZE.json")))
+        wr = json.load(open(os.path.join(SRC, "pmc_c2_WRITE_SIZE.json")))
+        name = [k for k in fe if "k_reads_fused" in k]
+        if name:
+            k = name[0]
+            fetch, write = fe[k]["FETCH_SIZE"]["avg"] * 1024 * 2, wr[k]["WRITE_SIZE"]["avg"] * 1024
+            traffic["rows=1000000 cols=10000 hashes=3 batch=1000 qlen=61 k=31 threshold=1.0 draws=2"] = {
+                "kernel": k, "traffic_bytes_per_launch": fetch + write, "fetch_bytes_corrected": fetch, "write_bytes": write,
+                "source": "profiles/r02_c2_pmc.json (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes; FETCH_SIZE doubled per "
+                          "MI355X_MICROARCH.md, which calibrates that factor on wide streaming reads: 1.25 KB rows fetch whole 128-byte lines)"}
+            with open(os.path.join(DST, "r02_c2_pmc.json"), "w") as f:
+                json.dump({"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python bench.py --workload c2 --steps 64 --warmup 8 "
+                                      "--cpu-seconds 0 --no-verify (one counter per pass; scripts/profile_all.sh)",
+                           "units": "KiB per dispatch, averaged over the dispatches of a kernel",
+                           "kernels": {kk: {"FETCH_SIZE_avg_kib": fe.get(kk, {}).get("FETCH_SIZE", {}).get("avg"), "WRITE_SIZE_avg_kib": wr.get(kk, {}).get("WRITE_SIZE", {}).get("avg"),
+                                            "dispatches": fe.get(kk, {}).get("FETCH_SIZE", {}).get("dispatches")} for kk in sorted(set(fe) | set(wr)) if kk.startswith("bigsi::")}}, f, indent=1)
+    except OSError:
+        pass
     if pmc:
         with open(os.path.join(DST, "r02_c3_pmc.json"), "w") as f:
             json.dump({"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python bench.py --steps 2 --warmup 1 --cpu-seconds 0 "
                                   "--no-verify [--threshold 0.4]  (one counter per pass; scripts/profile_all.sh)",
                        "units": "KiB per dispatch, averaged over the dispatches of a kernel", "runs": pmc}, f, indent=1)
+    if traffic:
         old = {}
         try:
             old = json.load(open(os.path.join(DST, "pmc_traffic.json")))

@@ -36,6 +36,13 @@ for thr in 1.0 0.4; do
     rm -rf $P/raw_pmc
   done
 done
+# the same two counters for the one-launch read kernel (BASELINE configs[1])
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $P/raw_pmc -o pmc_c2_${c} -- python bench.py --workload c2 --steps 64 --warmup 8 $B --no-verify > $P/pmc_c2_${c}.stdout 2> $P/pmc_c2_${c}.stderr
+  f=$(find $P/raw_pmc -name "pmc_c2_${c}_counter_collection.csv" | head -1)
+  [ -n "$f" ] && python scripts/make_profiles.py --pmc-reduce "$f" $P/pmc_c2_${c}.json
+  rm -rf $P/raw_pmc
+done
 python bench.py --steps 20 --warmup 5 > $P/r02_bench_default.stdout 2> $P/r02_bench_default.stderr
 python bench.py --steps 20 --warmup 5 --threshold 0.4 > $P/r02_bench_t04.stdout 2> $P/r02_bench_t04.stderr
 ls $P | wc -l
