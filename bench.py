@@ -329,6 +329,16 @@ def main():
         elapsed = float(t.item())
     check(_lib.lib().bigsi_hip_stats(st.handle, _lib.C.byref(stats), 1))
 
+    # one-launch read kernels bound their waits and mark a launch in which a workgroup gave up (repeated when its hit lists are
+    # fetched): fetch every staged batch's last run, so that such a launch -- none has ever been seen -- would be counted
+    repeated = 0
+    if batches[0].info().one_launch:
+        for b_ in batches:
+            b_.hits()
+        rs = _lib.Stats()
+        check(_lib.lib().bigsi_hip_stats(st.handle, _lib.C.byref(rs), 0))
+        repeated = int(rs.read_launches_repeated)
+
     # ---------------- results of the first staged batch, algorithmic bytes, verification
     # (its last run: step index (k * nb) for the largest such index below warmup + steps)
     batch = batches[0]
@@ -475,7 +485,7 @@ def main():
                          # step's k-merising and compaction under its neighbours' row fetches), so each kernel's own duration
                          # -- `kernel_ms`, what `achieved` is priced on -- spans its neighbours too and exceeds the step time.
                          "step_GBps": alg_bytes / (ms_per_step * 1e-3) / 1e9, "step_frac": alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "concurrent_launches": 3 if batch.info().one_launch else 1,
+                         "concurrent_launches": 3 if batch.info().one_launch else 1, "read_launches_repeated": repeated,
                          "rank": 0,
                          # per step, from warmup steps 2..W: K1 (+ row sort on the exact path); K4
                          "kmerize_ms": warm.kmerize_ms / (args.warmup - 1) if args.warmup > 1 else None,

@@ -21,6 +21,7 @@ RUN_SPARSE_COUNTS = 8
 RUN_NO_SORT = 16
 RUN_EARLY_EXIT = 32
 RUN_WEAK_FINGERPRINT = 64
+RUN_NO_WAITING = 128
 BLOOM_RAW = 1
 
 
@@ -56,7 +57,7 @@ class Stats(C.Structure):
                 ("compact_launches", C.c_uint64), ("compact_ms", C.c_double),
                 ("presence_launches", C.c_uint64), ("presence_ms", C.c_double), ("presence_bytes", C.c_uint64),
                 ("transpose_launches", C.c_uint64), ("transpose_ms", C.c_double),
-                ("and_launches_total", C.c_uint64)]
+                ("and_launches_total", C.c_uint64), ("read_launches_repeated", C.c_uint64)]
 
 
 _P = C.c_void_p

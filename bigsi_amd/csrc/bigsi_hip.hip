@@ -58,6 +58,16 @@ static int read_stream(bigsi_hip_index *ix, hipStream_t *out)
     return BIGSI_OK;
 }
 
+// end of a batch run on the index stream: what later read-kernel launches wait for.  Only once read streams exist (an index
+// that serves gene-length queries alone never pays for the record).
+static int mark_main(bigsi_hip_index *ix)
+{
+    if (!ix->rd_stream[0] || ix->stream != ix->own_stream) return BIGSI_OK;
+    if (!ix->main_ev) HIP_TRY(hipEventCreateWithFlags(&ix->main_ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ix->main_ev, ix->stream));
+    return BIGSI_OK;
+}
+
 static int quiesce_reads(bigsi_hip_index *ix)
 {
     if (!ix->rd_pending) return BIGSI_OK;
@@ -149,6 +159,7 @@ extern "C" int bigsi_hip_close(bigsi_hip_index *ix)
     if (ix->pre_stream) e = hipStreamSynchronize(ix->pre_stream);
     for (auto st : ix->rd_stream)
         if (st) { e = hipStreamSynchronize(st); e = hipStreamDestroy(st); }
+    if (ix->main_ev) e = hipEventDestroy(ix->main_ev);
     recycle_events(ix);
     for (auto &p : ix->ev_free) { e = hipEventDestroy(p.a); e = hipEventDestroy(p.b); }
     ix->stage.release();
@@ -582,10 +593,12 @@ extern "C" int bigsi_hip_stats(bigsi_hip_index *ix, bigsi_hip_stats_t *out, int 
     TRY(sum(ix->ev_tr, &out->transpose_launches, &out->transpose_ms));
     out->presence_bytes = ix->presence_bytes;
     out->and_launches_total = ix->and_total;
+    out->read_launches_repeated = ix->fused_repeats;
     if (reset) {
         recycle_events(ix);
         ix->presence_bytes = 0;
         ix->and_total = 0;
+        ix->fused_repeats = 0;
     }
     return BIGSI_OK;
 }
@@ -913,14 +926,18 @@ extern "C" int bigsi_hip_debug_phases(bigsi_hip_index *ix, uint64_t *out, uint32
 }
 #endif
 
-static int launch_reads_fused(bigsi_hip_batch *b, hipStream_t st = nullptr)
+static int launch_reads_fused(bigsi_hip_batch *b, hipStream_t st = nullptr, uint64_t spin_timeout = kSpinTimeout)
 {
     const uint32_t fp_mask = b->weak_fp ? 1u : ~0u;
     if (!st) st = b->ix->stream;
+    b->fused_settled = false;
     bigsi_hip_index *ix = b->ix;
     HitBufs &hb = b->hits;
     TRY(b->bitmaps.reserve((size_t)b->n_seqs * b->wv_pad * 8));
-    TRY(hb.hit_off.reserve((b->n_seqs + 1) * 8ull));
+    if (hb.hit_off.cap < (b->n_seqs + 2) * 8ull) {        // offsets, total, and the word a launch that gave up waiting marks
+        TRY(hb.hit_off.reserve((b->n_seqs + 2) * 8ull));
+        HIP_TRY(hipMemsetAsync(hb.hit_off.p, 0, hb.hit_off.cap, st));      // (fresh memory must not look like a mark)
+    }
     if (hb.cap == 0 && !hb.xcol) {
         const uint64_t want = 1u << 16;
         TRY(hb.hit_col.reserve(want * 4));
@@ -937,6 +954,7 @@ static int launch_reads_fused(bigsi_hip_batch *b, hipStream_t st = nullptr)
     }
     if (++hb.gen >= (1u << 20)) {
         HIP_TRY(hipMemsetAsync(hb.lb_state.p, 0, hb.lb_state.cap, st));
+        HIP_TRY(hipMemsetAsync(hb.hit_off.p, 0, hb.hit_off.cap, st));
         hb.gen = 1;
     }
 #define BIGSI_READS_ARGS                                                                                                          \
@@ -944,7 +962,7 @@ static int launch_reads_fused(bigsi_hip_batch *b, hipStream_t st = nullptr)
         b->seqs.as<char>(), b->d_seq_off.as<uint64_t>(), b->d_pos_off.as<uint64_t>(), b->n_seqs, b->first_pos.as<uint32_t>(),         \
         b->pos_unique.as<uint32_t>(), b->rep.as<uint32_t>(), b->rows.as<uint64_t>(), b->num_kmers.as<uint32_t>(),                      \
         b->num_unique.as<uint32_t>(), b->min_kmers.as<uint32_t>(), b->bitmaps.as<uint64_t>(), b->wv_pad, hb.lb_state.as<uint64_t>(),  \
-        hb.gen, hb.hit_off.as<uint64_t>(), hb.col(), hb.cnt(), hb.capacity(), fp_mask
+        hb.gen, hb.hit_off.as<uint64_t>(), hb.col(), hb.cnt(), hb.capacity(), fp_mask, spin_timeout
 #define COMMA ,
 #define BIGSI_READS(H)                                                                              \
     if (b->exact) hipLaunchKernelGGL((k_reads_fused<H COMMA true>), BIGSI_READS_ARGS);                \
@@ -1139,11 +1157,13 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
         b->dirty = true;
         hipStream_t st = ix->stream;
         TRY(read_stream(ix, &st));
+        // (the compaction kernel of a gene-length batch waits between workgroups too: such a run is over before read kernels start)
+        if (ix->main_ev && st != ix->stream) HIP_TRY(hipStreamWaitEvent(st, ix->main_ev, 0));
         if (b->done && b->run_stream != st) HIP_TRY(hipStreamWaitEvent(st, b->done, 0));      // this batch's previous run
         if (b->g_done && b->gstream && b->gstream != st) HIP_TRY(hipStreamWaitEvent(st, b->g_done, 0));
         TRY(ev_begin(ix, &fe, st, true));
         b->weak_fp = (flags & BIGSI_RUN_WEAK_FINGERPRINT) != 0;
-        TRY(launch_reads_fused(b, st));
+        TRY(launch_reads_fused(b, st, (flags & BIGSI_RUN_NO_WAITING) ? 0 : kSpinTimeout));
         TRY(ev_end(ix, &fe, ix->ev_and, st));
         b->run_h = ix->h;
         b->fused_run = true;
@@ -1159,8 +1179,9 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
         return BIGSI_OK;
     }
 
-    // (a previous run of this batch on one of the read streams must be over before K1 rewrites its arrays)
-    if (b->done && b->run_stream && b->run_stream != ix->stream) HIP_TRY(hipStreamWaitEvent(ix->stream, b->done, 0));
+    // read kernels of other batches still in flight on the read streams: over before this run's kernels start (its hit
+    // compaction waits between workgroups, as they do; each kind has the device to its own launches)
+    TRY(quiesce_reads(ix));
     b->run_stream = ix->stream;
     // K1e: address-ordered copy of the row lists for K2 (BIGSI_HIP_SORT_ROWS=0 streams them in hash order instead)
     static const int sort_rows = env_int("BIGSI_HIP_SORT_ROWS", 1);
@@ -1280,6 +1301,7 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
     if (!b->done) HIP_TRY(hipEventCreateWithFlags(&b->done, hipEventDisableTiming));
     if (!b->compacted) {
         HIP_TRY(hipEventRecord(b->done, ix->stream));
+        TRY(mark_main(ix));
         b->ran = true;
         b->dirty = false;
         return BIGSI_OK;
@@ -1290,6 +1312,7 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
     TRY(compact(b, b->hits, src, 1, ix->n_cols, false));
     TRY(ev_end(ix, &ep, ix->ev_cp));
     HIP_TRY(hipEventRecord(b->done, ix->stream));
+    TRY(mark_main(ix));
     b->ran = true;
     b->dirty = false;
     return BIGSI_OK;
@@ -1381,6 +1404,29 @@ static int compact(bigsi_hip_batch *b, HitBufs &hb, const void *src, uint32_t n_
     return compact_ex(b, hb, src, !b->exact, nullptr, n_shards, shard_cols, write_only, gst);
 }
 
+// k_reads_fused bounds its waits (see there): a launch in which some workgroup gave up -- possible only with launches of other
+// batches in flight beside it -- has marked hit_off[n_seqs + 1] with its generation and is repeated here with the device to
+// itself, before anything reads the hit lists.  The batch's `done` event has been waited for.
+static int fused_settle(bigsi_hip_batch *b)
+{
+    if (!b->fused_run || b->fused_settled) return BIGSI_OK;
+    HitBufs &hb = b->hits;
+    hipStream_t st = b->run_stream ? b->run_stream : b->ix->stream;
+    for (int attempt = 0; attempt < 4; attempt++) {
+        uint64_t mark = 0;
+        HIP_TRY(hipMemcpy(&mark, hb.hit_off.as<uint64_t>() + b->n_seqs + 1, 8, hipMemcpyDeviceToHost));
+        if (mark != hb.gen) {
+            b->fused_settled = true;
+            return BIGSI_OK;
+        }
+        b->ix->fused_repeats++;
+        HIP_TRY(hipDeviceSynchronize());
+        TRY(launch_reads_fused(b, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return fail(BIGSI_ERR_HIP, "the one-launch read kernel did not complete in four attempts");
+}
+
 // synchronise, make sure the hit lists fit (grow + rewrite if the write pass overflowed), copy them out
 static int fetch_hits_from(bigsi_hip_batch *b, HitBufs &hb, const void *src, uint32_t n_shards, uint64_t shard_cols,
                            uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t capacity)
@@ -1389,6 +1435,7 @@ static int fetch_hits_from(bigsi_hip_batch *b, HitBufs &hb, const void *src, uin
     std::vector<uint64_t> off(b->n_seqs + 1);
     // local hit lists were produced before b->done (already waited for); gathered ones on the gather stream
     if (&hb == &b->ghits || !b->compacted) HIP_TRY(hipStreamSynchronize(st));
+    if (&hb == &b->hits) TRY(fused_settle(b));
     HIP_TRY(hipMemcpy(off.data(), hb.hit_off.p, (b->n_seqs + 1) * 8ull, hipMemcpyDeviceToHost));
     const uint64_t total = off[b->n_seqs];
     if (hb.xcol && total > hb.xcap) {
@@ -1402,6 +1449,8 @@ static int fetch_hits_from(bigsi_hip_batch *b, HitBufs &hb, const void *src, uin
         if (&hb == &b->hits && b->fused_run) {      // counters lived in registers: the whole pass again, on the stream it ran on
             st = b->run_stream ? b->run_stream : st;
             TRY(launch_reads_fused(b, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            TRY(fused_settle(b));
         } else {
             TRY(compact(b, hb, src, n_shards, shard_cols, true));
         }
@@ -1450,6 +1499,7 @@ extern "C" int bigsi_hip_batch_get_info(bigsi_hip_batch *b, bigsi_hip_batch_info
     out->count_bytes = b->count_bytes;
     for (uint32_t v : b->h_num_unique) out->total_unique += v;
     uint64_t total = 0;
+    TRY(fused_settle(b));
     if (b->compacted) HIP_TRY(hipMemcpy(&total, b->hits.hit_off.as<uint64_t>() + b->n_seqs, 8, hipMemcpyDeviceToHost));
     out->total_hits = total;
     out->bitmap_stride_bytes = b->wv_pad * 8;

@@ -83,6 +83,8 @@ struct bigsi_hip_index {
     hipStream_t rd_stream[kReadStreams] = {};      // k_reads_fused launches alternate over these (created at the first one)
     uint32_t rd_next = 0;
     bool rd_pending = false;      // something may still be running on them
+    hipEvent_t main_ev = nullptr; // end of the last batch run on the index stream (mark_main)
+    uint64_t fused_repeats = 0;   // one-launch read kernels repeated because a workgroup gave up waiting (bigsi_hip_stats)
     struct bigsi_hip_batch *search_ws = nullptr;      // bigsi_hip_search_batch's workspace, created at its first call
     uint64_t m = 0, n_cols = 0, cap_cols = 0, stride_words = 0;
     uint32_t h = 0;
@@ -136,6 +138,7 @@ struct bigsi_hip_batch {
     bool pos_query_loaded = false;    // pos_query holds this load's position -> sequence map
     bool local_from_counts = false;   // the last counting run was row-sliced: hits come from thresholding the counters
     hipStream_t run_stream = nullptr;   // the stream `done` was last recorded on
+    bool fused_settled = false;         // the last one-launch run is known to have completed (fused_settle)
     bool weak_fp = false;         // BIGSI_RUN_WEAK_FINGERPRINT of the last one-launch run (a re-launch after a regrow repeats it)
     bool fused_run = false;           // the last run was the one-launch read kernel (k_reads_fused)
     bool elements = false;            // k-mers were given explicitly (bigsi_hip_batch_create_elements): K1 = k_rows_raw

@@ -1076,6 +1076,7 @@ __device__ uint64_t g_phase[1024 * 8];
 #endif
 constexpr int kReadsSection = 1024;           // queries whose hit totals a workgroup of k_reads_fused sums directly
 constexpr uint32_t kReadsMaxSeqs = 1u << 20;  // queries per launch of k_reads_fused at most
+constexpr uint64_t kSpinTimeout = 2000000;    // 20 ms of the 100 MHz wall clock: when a workgroup of k_reads_fused stops waiting
 template <int H, bool EXACT>
 __global__ __launch_bounds__(kBlock) void k_reads_fused(
     const uint64_t *__restrict__ index, uint64_t stride_words, uint32_t wv, uint64_t n_cols, uint64_t m, double threshold,
@@ -1084,7 +1085,7 @@ __global__ __launch_bounds__(kBlock) void k_reads_fused(
     uint32_t *__restrict__ num_kmers, uint32_t *__restrict__ num_unique, uint32_t *__restrict__ min_kmers,
     uint64_t *__restrict__ out_bits, uint64_t out_stride_words,
     uint64_t *__restrict__ state, uint32_t gen, uint64_t *__restrict__ hit_off, uint32_t *__restrict__ hit_col, uint32_t *__restrict__ hit_cnt,
-    uint64_t capacity, uint32_t fp_mask /* ~0; 1 = BIGSI_RUN_WEAK_FINGERPRINT */)
+    uint64_t capacity, uint32_t fp_mask /* ~0; 1 = BIGSI_RUN_WEAK_FINGERPRINT */, uint64_t spin_timeout /* in 10 ns ticks */)
 {
     constexpr int KF = 31, P = 6;
     __shared__ uint64_t s_rows[64 * H], s_hrow[64 * H];   // row ids: of the unique k-mers / of every position, per seed
@@ -1278,10 +1279,19 @@ __global__ __launch_bounds__(kBlock) void k_reads_fused(
     // has not started); the section's last workgroup also publishes the running total for the next section, a chain of
     // n_seqs / kReadsSection links that runs far ahead of the row fetches.  state: [n_seqs totals | one running total per section]
     const uint32_t first = q & ~(uint32_t)(kReadsSection - 1), section = q / kReadsSection;
+    // Waiting is bounded.  A waiter's predecessors have started whenever this launch has the device to itself; with launches of
+    // several batches in flight (the library's read streams) workgroups of one launch can, in principle, fill the slots that
+    // the predecessor of another launch's waiters needs, and the other way round.  A workgroup that has waited kSpinTimeout
+    // (20 ms; the waits are tens of microseconds) gives up: it marks the launch (hit_off[n_seqs + 1] = generation) and leaves
+    // without writing hits -- its total IS published, nobody waits for it -- and the host repeats such a launch alone before
+    // anything reads the hit lists (fused_settle).
+    const uint64_t t_wait = wall_clock64();
+    bool gave_up = false;
     auto wait_for = [&](const uint64_t *w) -> uint64_t {
         for (;;) {
             const uint64_t word = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((uint32_t)(word >> 44) == gen && (word & ((1ull << 44) - 1)) != 0) return (word & ((1ull << 44) - 1)) - 1;
+            if (gave_up || wall_clock64() - t_wait > spin_timeout) { gave_up = true; return 0; }
             __builtin_amdgcn_s_sleep(1);
         }
     };
@@ -1289,6 +1299,10 @@ __global__ __launch_bounds__(kBlock) void k_reads_fused(
     uint64_t part = 0;
     for (uint32_t j = first + threadIdx.x; j < q; j += kBlock) part += wait_for(&state[j]);
     if (threadIdx.x == 0 && section) part += wait_for(&state[n_seqs + section]);
+    if (__syncthreads_or(gave_up ? 1 : 0)) {
+        if (threadIdx.x == 0) hit_off[n_seqs + 1] = gen;
+        return;
+    }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
     if ((threadIdx.x & 63u) == 0) lds64[threadIdx.x >> 6] = part;

@@ -159,6 +159,8 @@ int bigsi_hip_lookup_raw(bigsi_hip_index *ix, const char *blob, const uint64_t *
 #define BIGSI_RUN_NO_SORT 16u    /* stream each query's rows in hash order instead of address order */
 #define BIGSI_RUN_EARLY_EXIT 32u /* exact path: stop fetching a query's rows for a column segment once its running AND is
                                     all zero (fewer bytes than the reference reads, hence opt-in) */
+#define BIGSI_RUN_NO_WAITING 128u /* one-launch read path: workgroups give up waiting for their predecessors' hit totals at once,
+                                     so that the launch is marked incomplete and repeated (otherwise a 20 ms timeout) */
 #define BIGSI_RUN_WEAK_FINGERPRINT 64u /* one-launch read path: 1-bit k-mer fingerprints, so that the dedupe takes its exact
                                           pairwise route (otherwise reached only on a 2^-32 fingerprint collision) */
 
@@ -356,6 +358,8 @@ typedef struct {
     uint64_t transpose_launches; /* bigsi_hip_insert_columns_device calls (the build transpose, filters resident) */
     double transpose_ms;
     uint64_t and_launches_total; /* row-AND launches since the last reset, timed or not (and_launches counts the timed ones) */
+    uint64_t read_launches_repeated; /* one-launch read kernels that were run again because a workgroup gave up waiting for
+                                        the hit totals of the queries before it (possible only beside launches of other batches) */
 } bigsi_hip_stats_t;
 /* record HIP events around the kernels of batch_run: 0 off, 1 around K1 / K2 / K4 each, 2 around the row-AND kernel only,
  * n > 2 around the row-AND kernel of every n-th run (an event record costs the stream 5-7 us, which is a fifth of a

@@ -1229,6 +1229,16 @@ def test_one_launch_read_path_beyond_one_section(hip):
         if thr == 1.0:
             for i in (0, 1023, 1024, 2047, 2048, 2599):
                 assert (7 * i + 3) % n_cols in fc[int(fo[i]):int(fo[i + 1])]
+        # the bounded wait: with the timeout at zero every workgroup that would wait gives up, the launch is marked
+        # incomplete and repeated before the hit lists are read -- same answers, and the repeat is counted
+        from bigsi_amd import _lib
+        s_ = _lib.Stats()
+        _lib.check(_lib.lib().bigsi_hip_stats(st.handle, _lib.C.byref(s_), 1))
+        fused.run(thr, sparse_counts=True, no_waiting=True)
+        go, gc, gn = fused.hits()
+        assert np.array_equal(go, po) and np.array_equal(gc, pc) and np.array_equal(gn, pn), thr
+        _lib.check(_lib.lib().bigsi_hip_stats(st.handle, _lib.C.byref(s_), 1))
+        assert s_.read_launches_repeated >= 1
     fused.close()
     plain.close()
     st.delete_all()
