@@ -434,10 +434,10 @@ extern "C" int bigsi_hip_append_index(bigsi_hip_index *dst, const bigsi_hip_inde
     TRY(use_device(dst));
     TRY(quiesce_reads(dst));
     HIP_TRY(hipStreamSynchronize(src->stream));
-    const uint64_t per_row = ceil_div(dst->n_cols + src->n_cols, 8) - (dst->n_cols >> 3);
-    const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(dst->m * per_row, kBlock), 256 * 32);
-    hipLaunchKernelGGL(k_append_columns, dim3(grid), dim3(kBlock), 0, dst->stream, (uint8_t *)dst->d_index, dst->stride_words * 8, dst->n_cols,
-                       (const uint8_t *)src->d_index, src->stride_words * 8, src->n_cols, dst->m);
+    const uint64_t per_row = ceil_div(dst->n_cols + src->n_cols, 64) - (dst->n_cols >> 6);
+    const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(dst->m * per_row, kBlock), 256 * 64);
+    hipLaunchKernelGGL(k_append_columns, dim3(grid), dim3(kBlock), 0, dst->stream, dst->d_index, dst->stride_words, dst->n_cols,
+                       src->d_index, src->stride_words, src->n_cols, dst->m);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(dst->stream));
     dst->n_cols += src->n_cols;

@@ -1929,25 +1929,32 @@ __global__ __launch_bounds__(kBlock * CT) void k_transpose_tiles(
 // device to device.  One thread per (row, destination byte); bits are MSB-first inside a byte, so a column offset that
 // is not a multiple of 8 is a bit shift across source bytes.
 __global__ __launch_bounds__(kBlock) void k_append_columns(
-    uint8_t *__restrict__ dst, uint64_t dst_stride, uint64_t n1, const uint8_t *__restrict__ src, uint64_t src_stride,
+    uint64_t *__restrict__ dst, uint64_t dst_stride_words, uint64_t n1, const uint64_t *__restrict__ src, uint64_t src_stride_words,
     uint64_t n2, uint64_t m)
 {
-    const uint64_t j0 = n1 >> 3, j1 = (n1 + n2 + 7) >> 3, per_row = j1 - j0;
+    // one thread per (row, destination word): in plain column order (by_column) the appended columns are the source row shifted
+    // up by n1 % 64 bits -- two source words funnel into one destination word; the first destination word keeps its own
+    // low columns.  (The first version moved one byte per thread, bit by bit.)
+    const uint64_t j0 = n1 >> 6, j1 = (n1 + n2 + 63) >> 6, per_row = j1 - j0;
+    const uint32_t sh = (uint32_t)(n1 & 63u);
+    const uint64_t src_words = (n2 + 63) >> 6;
     const uint64_t total = m * per_row;
     for (uint64_t item = (uint64_t)blockIdx.x * kBlock + threadIdx.x; item < total; item += (uint64_t)gridDim.x * kBlock) {
-        const uint64_t r = item / per_row, j = j0 + item % per_row;
-        uint8_t *d = dst + r * dst_stride + j;
-        const uint8_t *sr = src + r * src_stride;
-        uint32_t v = 0;
-        for (uint32_t t = 0; t < 8; t++) {
-            const uint64_t c = j * 8 + t;
-            uint32_t bit;
-            if (c < n1) bit = (*d >> (7 - t)) & 1u;
-            else if (c < n1 + n2) { const uint64_t sc = c - n1; bit = (sr[sc >> 3] >> (7 - (sc & 7))) & 1u; }
-            else bit = 0;
-            v |= bit << (7 - t);
+        const uint64_t r = item / per_row, q = item % per_row, j = j0 + q;
+        const uint64_t *sr = src + r * src_stride_words;
+        const uint64_t cur = q < src_words ? by_column(sr[q]) : 0ull;
+        uint64_t v;
+        if (sh == 0) {
+            v = cur;
+        } else {
+            const uint64_t prev = q > 0 ? by_column(sr[q - 1]) : 0ull;
+            v = (prev >> (64u - sh)) | (cur << sh);
         }
-        *d = (uint8_t)v;
+        const uint64_t end = n1 + n2;                      // columns at or beyond it stay zero
+        if (end < (j + 1) * 64) v &= (end & 63u) ? ((1ull << (end & 63u)) - 1) : ~0ull;
+        uint64_t *d = dst + r * dst_stride_words + j;
+        if (q == 0 && sh) v |= by_column(*d) & ((1ull << sh) - 1);
+        *d = by_column(v);
     }
 }
 
