@@ -261,10 +261,11 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
         `batch_kmers` k-mers (about 540 x 1 kbp, or ~17000 reads of 61 bp: 4 ms of device work on a 125 GB index, enough to hide the
         per-batch host work; measured 117 M lookups/s with 2^18 and 124 M with 2^19 k-mers per batch at C3)."""
         assert threshold <= 1
-        pending, slot, chunk, held = None, 0, [], 0
+        from itertools import islice
+        pending, slot, k = None, 0, self.kmer_size
 
         def submit(chunk, slot):
-            if not all(s.isascii() for s in chunk):      # rare: answered at once through search_batch's non-ASCII route
+            if not "".join(chunk).isascii():             # rare: answered at once through search_batch's non-ASCII route
                 return _Done(self.search_batch(chunk, threshold, score)), chunk
             batch = self._workspace(slot, chunk)
             self._launch(batch, threshold)
@@ -273,19 +274,29 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
         def done(p):
             return p[0].results if isinstance(p[0], _Done) else self._collect(p[0], len(p[1]), threshold, score)
 
-        for s in seqs:
-            chunk.append(s)
-            held += max(len(s) - self.kmer_size + 1, 1)
-            if (len(chunk) == batch_size) if batch_size else (held >= batch_kmers):
-                nxt = submit(chunk, slot)
-                if pending is not None:
-                    yield from zip(pending[1], done(pending))
-                pending, slot, chunk, held = nxt, slot ^ 1, [], 0
-        if chunk:
+        # sequences are taken from the iterable in slices (C speed: millions of reads go through here); without a
+        # batch_size the slice length follows the k-mers per sequence seen so far, so that a batch holds ~batch_kmers of them
+        it = iter(seqs)
+        take = batch_size if batch_size else 64
+        while True:
+            chunk = list(islice(it, take))
+            if not chunk:
+                break
+            if not batch_size:
+                held = sum(map(len, chunk)) - (k - 1) * len(chunk)
+                while held < batch_kmers:                # top the slice up to a full batch
+                    per = max(held // len(chunk), 1)
+                    more = list(islice(it, max((batch_kmers - held + per - 1) // per, 1)))
+                    if not more:
+                        break
+                    chunk += more
+                    held = sum(map(len, chunk)) - (k - 1) * len(chunk)
+                    held = max(held, len(chunk))
+                take = len(chunk)
             nxt = submit(chunk, slot)
             if pending is not None:
                 yield from zip(pending[1], done(pending))
-            pending = nxt
+            pending, slot = nxt, slot ^ 1
         if pending is not None:
             yield from zip(pending[1], done(pending))
 
