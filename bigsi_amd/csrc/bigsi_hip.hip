@@ -51,9 +51,11 @@ static int read_stream(bigsi_hip_index *ix, hipStream_t *out)
 {
     *out = ix->stream;
     if (ix->stream != ix->own_stream) return BIGSI_OK;       // the caller's own stream (bigsi_hip_set_stream): everything stays on it
+    static const int n_streams = std::min(env_int("BIGSI_HIP_READ_STREAMS", kReadStreams), kReadStreams);      // A/B: 1 = no overlap
+    if (n_streams <= 1) return BIGSI_OK;
     if (!ix->rd_stream[0])
         for (auto &st : ix->rd_stream) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    *out = ix->rd_stream[ix->rd_next++ % kReadStreams];
+    *out = ix->rd_stream[ix->rd_next++ % (uint32_t)n_streams];
     ix->rd_pending = true;
     return BIGSI_OK;
 }

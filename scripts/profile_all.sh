@@ -14,6 +14,7 @@ run r02_c3_256x1kbp     -- python bench.py --steps 200 --warmup 10 $B --batch 25
 run r02_c3_256x1kbp_t04 -- python bench.py --steps 200 --warmup 10 $B --batch 256 --threshold 0.4
 run r02_c2              -- python bench.py --workload c2 --steps 4000 --warmup 100 $B
 run r02_c2_t04          -- python bench.py --workload c2 --steps 4000 --warmup 100 $B --threshold 0.4
+run r02_c2_one_stream BIGSI_HIP_LIB=$PWD/bigsi_amd/libbigsi_hip_tuning.so BIGSI_HIP_READ_STREAMS=1 -- python bench.py --workload c2 --steps 4000 --warmup 100 $B
 run r02_c2_unfused BIGSI_HIP_LIB=$PWD/bigsi_amd/libbigsi_hip_tuning.so BIGSI_HIP_FUSE_READS=0 -- python bench.py --workload c2 --steps 4000 --warmup 100 $B
 run r02_c2_32k_reads    -- python bench.py --workload c2 --steps 200 --warmup 16 $B --batch 32768 --distinct-batches 8
 run r02_c4_shard        -- python bench.py --workload c4 --shard-of 8 --gpus 1 --steps 200 --warmup 10 $B
