@@ -1046,7 +1046,7 @@ static int run_kmerize(bigsi_hip_batch *b, double threshold, bool force_global =
     for (;; tab_mult = 2) {
         tab_cap = 2;
         while (tab_cap < tab_mult * b->max_pos && tab_cap < (1u << 30)) tab_cap <<= 1;
-        lds = (size_t)tab_cap * 4 + 64 + (size_t)hs_cap * 4 + 2 * sq_bytes;      // table | scan | fingerprints | sequence | its complement
+        lds = (size_t)(tab_cap + tab_cap / 32 + 4) * 4 + 64 + (size_t)hs_cap * 4 + 2 * sq_bytes;      // table (+ sort pad) | scan | fingerprints | sequence | its complement
         if (lds <= 60 * 1024 || tab_mult == 2) break;
     }
     // fused single-launch K1 (dedupe table + sequence in LDS) when every query fits the default 64 KiB dynamic-LDS window

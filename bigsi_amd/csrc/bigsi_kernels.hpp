@@ -417,6 +417,13 @@ __global__ __launch_bounds__(kBlock) void k_kmer_rows(
     }
 }
 
+#ifdef BIGSI_HIP_TUNING
+// tuning builds only: per-workgroup timestamps of the phases of k_reads_fused / k_kmerize_lds (100 MHz wall clock), read by bigsi_hip_debug_phases
+__device__ uint64_t g_phase[1024 * 8];
+#define BIGSI_PHASE(i) do { if (threadIdx.x == 0) g_phase[(blockIdx.x & 1023u) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define BIGSI_PHASE(i) do { } while (0)
+#endif
 // K1 fused: ONE launch for batches whose longest query has at most kLdsMaxPos k-mer positions (a 4 kbp query; reads
 // and gene-length queries).  One workgroup per query; the sequence and the dedupe table live in LDS (ds_cmpst / ds_min
 // instead of L2 atomics), and the workgroup goes insert -> resolve -> ordered compaction -> hash without leaving the CU.
@@ -444,7 +451,7 @@ __global__ __launch_bounds__(1024) void k_kmerize_lds(
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *scan = tab + tab_cap;                      // 16 entries
+    uint32_t *scan = tab + tab_cap + tab_cap / 32 + 4;   // 16 entries (the table is followed by the pad words of the row sort)
     uint32_t *hs = scan + 16;                            // hs[i]: 32-bit hash of the k-mer at position i (hs_cap entries)
     char *sq = reinterpret_cast<char *>(hs + hs_cap);    // the query's bytes
     char *sc = sq + sq_bytes;                            // KF == 31: their complements, 4 pad bytes in front (kmer31_canonical_premix)
@@ -456,13 +463,25 @@ __global__ __launch_bounds__(1024) void k_kmerize_lds(
     uint32_t tsize = 2;
     while (tsize < tab_mult * n) tsize <<= 1;            // load factor <= 1/tab_mult: short probe chains
     const uint32_t mask = tsize - 1;
+    BIGSI_PHASE(0);
     for (uint32_t i = threadIdx.x; i < tsize; i += blockDim.x) tab[i] = kEmpty;
-    for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
-        const char c = s[i];
-        sq[i] = c;
-        if (KF == 31) sc[4 + i] = (char)complement((uint8_t)c);
+    for (uint32_t base = 0; base < len; base += 4 * blockDim.x) {       // four loads in flight per thread and pass
+        char c[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const uint32_t i = base + e * blockDim.x + threadIdx.x;
+            c[e] = i < len ? s[i] : (char)0;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const uint32_t i = base + e * blockDim.x + threadIdx.x;
+            if (i >= len) continue;
+            sq[i] = c[e];
+            if (KF == 31) sc[4 + i] = (char)complement((uint8_t)c[e]);
+        }
     }
     __syncthreads();
+    BIGSI_PHASE(1);
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
         if (KF == 31) {
             uint32_t wf[8];
@@ -473,6 +492,7 @@ __global__ __launch_bounds__(1024) void k_kmerize_lds(
         }
     }
     __syncthreads();
+    BIGSI_PHASE(2);
     // two positions hold the same k-mer iff their bytes are equal; the stored hashes settle almost every comparison with
     // one LDS word instead of a divergent byte loop
     uint32_t my_slot = 0;                                // where this thread's FIRST position ended up
@@ -488,8 +508,11 @@ __global__ __launch_bounds__(1024) void k_kmerize_lds(
         if (i == threadIdx.x) my_slot = slot;
     }
     __syncthreads();
+    BIGSI_PHASE(3);
     uint32_t *fp = first_pos + P, *ux = uidx + P, *pu = pos_unique + P, *rp = rep_out + P;
     uint64_t *qrows = rows + P * h;
+    // (one scan over threads that each take several CONSECUTIVE positions -- fewer barriers -- measured slower: 0.37 against
+    // 0.29 ms per 8192 queries; the strided positions keep the LDS reads and the global writes of a wavefront together)
     uint32_t u = 0;
     for (uint32_t base = 0; base < n; base += blockDim.x) {
         const uint32_t i = base + threadIdx.x;
@@ -535,6 +558,7 @@ __global__ __launch_bounds__(1024) void k_kmerize_lds(
         u += tot;
     }
     __syncthreads();
+    BIGSI_PHASE(4);
     if (rows_sorted) {
         // K1e fused: counting sort of the u*h row ids by their top bits, the dedupe table's LDS reused as the histogram
         // (tsize >= 2n buckets: about one row per bucket at h <= 4).  Order inside a bucket depends on atomics; K2's result does not.
@@ -542,26 +566,53 @@ __global__ __launch_bounds__(1024) void k_kmerize_lds(
         while (((m - 1) >> shift) >= (uint64_t)tsize) shift++;
         const uint32_t R = u * h;
         uint64_t *qsorted = rows_sorted + P * h;
-        for (uint32_t i = threadIdx.x; i < tsize; i += blockDim.x) tab[i] = 0;
+        // (phase timestamps: this sort was 23 of a workgroup's 52 us -- two passes of dependent read-backs of the row ids
+        // from L2, and 16-way bank conflicts where a thread walks its 16 consecutive buckets.  Now a thread reads its row
+        // ids once, all loads in flight together, and keeps them in registers for the second pass; bucket b lives at word
+        // b + b / 32, which spreads the threads' bucket runs over the banks.)
+        auto at = [](uint32_t b) { return b + (b >> 5); };
+        for (uint32_t i = threadIdx.x; i < tsize + (tsize >> 5) + 1; i += blockDim.x) tab[i] = 0;
         __syncthreads();
-        for (uint32_t r = threadIdx.x; r < R; r += blockDim.x) atomicAdd(&tab[qrows[r] >> shift], 1u);
+        constexpr int kSortRegs = 16;
+        const bool in_regs = R <= (uint32_t)kSortRegs * blockDim.x;
+        uint64_t mine[kSortRegs];
+        if (in_regs) {
+#pragma unroll
+            for (int t = 0; t < kSortRegs; t++) {
+                const uint32_t r = threadIdx.x + (uint32_t)t * blockDim.x;
+                mine[t] = r < R ? qrows[r] : ~0ull;
+            }
+#pragma unroll
+            for (int t = 0; t < kSortRegs; t++)
+                if (mine[t] != ~0ull) atomicAdd(&tab[at((uint32_t)(mine[t] >> shift))], 1u);
+        } else {
+            for (uint32_t r = threadIdx.x; r < R; r += blockDim.x) atomicAdd(&tab[at((uint32_t)(qrows[r] >> shift))], 1u);
+        }
         __syncthreads();
         const uint32_t per = (tsize + blockDim.x - 1) / blockDim.x, b0 = threadIdx.x * per;
         uint32_t sum = 0, tot;
-        for (uint32_t j = 0; j < per; j++) sum += b0 + j < tsize ? tab[b0 + j] : 0u;
+        for (uint32_t j = 0; j < per; j++) sum += b0 + j < tsize ? tab[at(b0 + j)] : 0u;
         uint32_t run = block_exclusive_scan(sum, &tot, scan);
         for (uint32_t j = 0; j < per && b0 + j < tsize; j++) {
-            const uint32_t v = tab[b0 + j];
-            tab[b0 + j] = run;
+            const uint32_t v = tab[at(b0 + j)];
+            tab[at(b0 + j)] = run;
             run += v;
         }
         __syncthreads();
-        for (uint32_t r = threadIdx.x; r < R; r += blockDim.x) {
-            const uint64_t row = qrows[r];
-            qsorted[atomicAdd(&tab[row >> shift], 1u)] = row;
+        if (in_regs) {
+#pragma unroll
+            for (int t = 0; t < kSortRegs; t++)
+                if (mine[t] != ~0ull) qsorted[atomicAdd(&tab[at((uint32_t)(mine[t] >> shift))], 1u)] = mine[t];
+        } else {
+            for (uint32_t r = threadIdx.x; r < R; r += blockDim.x) {
+                const uint64_t row = qrows[r];
+                qsorted[atomicAdd(&tab[at((uint32_t)(row >> shift))], 1u)] = row;
+            }
         }
     }
+    BIGSI_PHASE(5);
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) pu[i] = ux[rp[i]];
+    BIGSI_PHASE(6);
     if (threadIdx.x == 0) {
         num_kmers[q] = n;
         num_unique[q] = u;
@@ -1067,13 +1118,6 @@ __global__ __launch_bounds__(kBlock) void k_hits_fused(
 // global memory for lookup / presence / fetch_rows), the row ids go to the other wavefronts through LDS, all of them
 // stream and AND (or count) the rows, and the hit list is written through k_hits_fused's scan -- the workgroup publishes its
 // total and sums those of the queries before it (the grid is co-resident by construction).  Same results, one launch.
-#ifdef BIGSI_HIP_TUNING
-// tuning builds only: per-workgroup timestamps of k_reads_fused's phases (100 MHz wall clock), read by bigsi_hip_debug_phases
-__device__ uint64_t g_phase[1024 * 8];
-#define BIGSI_PHASE(i) do { if (threadIdx.x == 0) g_phase[(blockIdx.x & 1023u) * 8 + (i)] = wall_clock64(); } while (0)
-#else
-#define BIGSI_PHASE(i) do { } while (0)
-#endif
 constexpr int kReadsSection = 1024;           // queries whose hit totals a workgroup of k_reads_fused sums directly
 constexpr uint32_t kReadsMaxSeqs = 1u << 20;  // queries per launch of k_reads_fused at most
 constexpr uint64_t kSpinTimeout = 2000000;    // 20 ms of the 100 MHz wall clock: when a workgroup of k_reads_fused stops waiting
