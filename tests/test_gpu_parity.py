@@ -1293,3 +1293,32 @@ def test_read_batches_on_library_streams_keep_their_order(hip):
     for b in batches + [gene]:
         b.close()
     st.delete_all()
+
+
+def test_k1_row_sort_in_registers_and_beyond(hip):
+    """The exact path's row lists are sorted by address inside K1.  Batches of >= 1024 queries use 256-thread workgroups, which
+    sort up to 16 row ids per thread from registers and longer lists (here a 3000-bp query at h = 4: 11 880 rows) through the
+    general loop; both must leave the AND results untouched: hits equal the thresholded counting route (which does not sort)
+    and the oracle's bitmaps."""
+    from oracle.ref_model import SynthOracle
+    m, n_cols, h, seed = 65537, 700, 4, 41
+    c, st = synth_index(hip, m, n_cols, h, seed, draws=1)
+    orc = SynthOracle(seed, 0, m, n_cols, h, 31, 1)
+    rng = np.random.default_rng(8)
+    lens = [40] * 1020 + [3000, 1000, 300, 31, 2500, 64, 900, 1800]
+    seqs = ["".join(rng.choice(list("ACGT"), size=L)) for L in lens]
+    for i in (1020, 1021, 1024, 1027):
+        st.insert_kmers((13 * i) % n_cols, [seqs[i]], 31)
+        orc.insert_kmers((13 * i) % n_cols, seqs[i])
+    batch = st.new_batch(seqs, 31)
+    batch.run(1.0)
+    off, col, cnt = [x.copy() for x in batch.hits()]
+    for i in (0, 500, 1020, 1021, 1022, 1023, 1024, 1025, 1026, 1027):
+        u, bm = orc.exact_bitmap(seqs[i])
+        assert np.array_equal(batch.bitmap(i), bm), i
+        assert (13 * i) % n_cols in col[int(off[i]):int(off[i + 1])] or i not in (1020, 1021, 1024, 1027)
+    batch.run(1.0, force_counts=True)                    # the counting route: unsorted row lists
+    off2, col2, cnt2 = batch.hits()
+    assert np.array_equal(off, off2) and np.array_equal(col, col2) and np.array_equal(cnt, cnt2)
+    batch.close()
+    st.delete_all()
