@@ -863,6 +863,7 @@ struct CountLaunch {
     uint64_t *hit_bitmap;
     uint32_t sparse, slices;
     bool deep;                  // software-pipelined row loads (small grids; h = 3 or 4 only)
+    uint32_t early_exit;        // BIGSI_RUN_EARLY_EXIT on a hits-only, one-slice run
 };
 
 template <int P, typename CountT>
@@ -873,7 +874,7 @@ static void launch_count_wide(bigsi_hip_batch *b, const CountLaunch &c, uint32_t
 #define BIGSI_COUNT_ARGS                                                                                                      \
     dim3(grid), dim3(c.block), 0, ix->stream, ix->d_index, ix->stride_words, (uint32_t)b->wv, c.k2_rows, b->d_pos_off.as<uint64_t>(), \
         b->num_unique.as<uint32_t>(), ix->h, q0, q1, c.tiles, (CountT *)c.out, c.out_stride, b->min_kmers.as<uint32_t>(), ix->n_cols,  \
-        c.hit_bitmap, b->wv_pad, c.sparse, c.slices
+        c.hit_bitmap, b->wv_pad, c.sparse, c.slices, c.early_exit
 #define COMMA ,
 #define BIGSI_LAUNCH_COUNT(H) hipLaunchKernelGGL((k_and_count<P, H, CountT>), BIGSI_COUNT_ARGS)
 #define BIGSI_LAUNCH_COUNT_DEEP(H)                                                                        \
@@ -1292,7 +1293,8 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
         const uint64_t grid_waves = (uint64_t)b->n_seqs * tiles * (and_block / 64);
         // (only with >= 12 planes, i.e. queries of >= 1024 k-mers: at 10 planes the ALU phase is short and it measured -2 %)
         const bool deep = deep_env >= 0 ? deep_env != 0 : (slices == 1 && P >= 12 && grid_waves < 3 * 1024);
-        const CountLaunch cl{k2_rows, (unsigned)and_block, tiles, out, cstride, hb, sparse, slices, deep};
+        const uint32_t early = ((flags & BIGSI_RUN_EARLY_EXIT) && sparse && slices == 1) ? 1u : 0u;
+        const CountLaunch cl{k2_rows, (unsigned)and_block, tiles, out, cstride, hb, sparse, slices, deep && !early, early};
         for (uint32_t q0 = 0; q0 < b->n_seqs; q0 += chunk_q, n_launches++)
             launch_count(b, P, cl, q0, (uint32_t)std::min<uint64_t>((uint64_t)q0 + chunk_q, b->n_seqs));
         HIP_TRY(hipGetLastError());

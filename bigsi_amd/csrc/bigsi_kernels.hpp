@@ -849,7 +849,8 @@ __global__ __launch_bounds__(kBlock) void k_and_count(
     uint32_t h_rt, uint32_t q0, uint32_t n_seqs, uint32_t tiles, CountT *__restrict__ out, uint64_t out_stride /* counters per query */,
     const uint32_t *__restrict__ min_kmers, uint64_t n_cols, uint64_t *__restrict__ hit_bitmap /* [seq][bm_stride] or null */,
     uint64_t bm_stride, uint32_t sparse /* 1: store counters only for words that contain a hit */,
-    uint32_t slices /* > 1: counters were preset to zero, slices add into them atomically; no fused threshold */)
+    uint32_t slices /* > 1: counters were preset to zero, slices add into them atomically; no fused threshold */,
+    uint32_t early_exit /* 1 (only with sparse, one slice): a wavefront stops fetching once none of its 8192 columns can reach min_kmers */)
 {
     const TileMap tm = map_block(blockIdx.x, q0, n_seqs, tiles, slices);
     if (!tm.valid) return;
@@ -876,6 +877,28 @@ __global__ __launch_bounds__(kBlock) void k_and_count(
             pl[0][p] ^= c0; pl[1][p] ^= c1;
             c0 = t0; c1 = t1;
         }
+    };
+
+    // opt-in (BIGSI_RUN_EARLY_EXIT): with `left` k-mers still to come, a column whose count is below min_kmers - left cannot
+    // become a hit any more; when that holds for every column of the wavefront's segment the remaining rows need not be read
+    // (same hit lists, fewer bytes than the reference reads -- hence not the default).  One bit-sliced comparison per 32 k-mers.
+    const uint32_t thr_exit = early_exit ? min_kmers[tm.q] : 0u;
+    auto hopeless = [&](uint32_t left) -> bool {
+        if (thr_exit <= left) return false;
+        const uint32_t need = thr_exit - left;
+        uint64_t any = 0;
+#pragma unroll
+        for (int v = 0; v < kVec; v++) {
+            uint64_t gt = 0, eq = ~0ull;
+            if (P < 32 && (need >> (P & 31)) != 0) eq = 0;
+#pragma unroll
+            for (int p = P - 1; p >= 0; p--) {
+                if ((need >> p) & 1u) eq &= pl[v][p];
+                else { gt |= eq & pl[v][p]; eq &= ~pl[v][p]; }
+            }
+            any |= gt | eq;
+        }
+        return __ballot(any != 0) == 0ull;
     };
 
     uint32_t j = j0;
@@ -911,6 +934,7 @@ __global__ __launch_bounds__(kBlock) void k_and_count(
             }
         } else {
             for (; j + KM <= u; j += KM) {
+                if (early_exit && ((j - j0) & 31u) < (uint32_t)KM && j > j0 && hopeless(u - j)) { j = u; break; }
                 u64x2 v[KM * (H > 0 ? H : 1)];
 #pragma unroll
                 for (int s = 0; s < KM * H; s++) v[s] = load_row_seg(index, qrows[(uint64_t)j * H + s], stride_words, w0);

@@ -157,8 +157,10 @@ int bigsi_hip_lookup_raw(bigsi_hip_index *ix, const char *blob, const uint64_t *
 /* test / A-B flags: same results, different route (tests/test_gpu_parity.py, scripts/ab_*.py); not for production callers */
 #define BIGSI_RUN_K1_GLOBAL 4u   /* take the multi-launch K1 (global-memory dedupe table) whatever the query lengths */
 #define BIGSI_RUN_NO_SORT 16u    /* stream each query's rows in hash order instead of address order */
-#define BIGSI_RUN_EARLY_EXIT 32u /* exact path: stop fetching a query's rows for a column segment once its running AND is
-                                    all zero (fewer bytes than the reference reads, hence opt-in) */
+#define BIGSI_RUN_EARLY_EXIT 32u /* stop fetching a query's rows for a column segment once its result is settled: exact, the
+                                    running AND is all zero; thresholded (with SPARSE_COUNTS), no sample of the segment can reach
+                                    min_kmers with the k-mers that are left.  Same hit lists, fewer bytes than the reference
+                                    reads -- hence opt-in (config key `early_exit` of the host shim) */
 #define BIGSI_RUN_NO_WAITING 128u /* one-launch read path: workgroups give up waiting for their predecessors' hit totals at once,
                                      so that the launch is marked incomplete and repeated (otherwise a 20 ms timeout) */
 #define BIGSI_RUN_WEAK_FINGERPRINT 64u /* one-launch read path: 1-bit k-mer fingerprints, so that the dedupe takes its exact

@@ -857,6 +857,22 @@ def test_early_exit_gives_identical_results(hip):
     for j, i in enumerate((0, 1, 17, 299)):
         assert np.array_equal(batch.bitmap(i), ref_bm[j])
     assert int(ref[0][-1]) == 6
+    # thresholded searches: a wavefront stops once no column of its segment can reach min_kmers any more -- partial plants
+    # (60 % and 35 % of a query's k-mers), thresholds on both sides of them, same hit lists and counts as without the flag
+    st.insert_kmers(77, [seqs[5][: 30 + int(0.6 * (len(seqs[5]) - 30))]], 31)
+    st.insert_kmers(4242, [seqs[6][: 30 + int(0.35 * (len(seqs[6]) - 30))]], 31)
+    for thr in (0.9, 0.5, 0.3, 0.05, 0.0):
+        batch.run(thr, sparse_counts=True)
+        want = [x.copy() for x in batch.hits()]
+        batch.run(thr, sparse_counts=True, early_exit=True)
+        for a, b in zip(want, batch.hits()):
+            assert np.array_equal(a, b), thr
+        if thr == 0.5:
+            off = want[0]
+            assert 77 in want[1][int(off[5]):int(off[6])] and 4242 not in want[1][int(off[6]):int(off[7])]
+    batch.run(1.0, force_counts=True, sparse_counts=True, early_exit=True)      # the exact answer through the counting kernel
+    for a, b in zip(ref, batch.hits()):
+        assert np.array_equal(a, b)
     small = st.new_batch(seqs[:2], 31)                                  # sliced (atomicAnd) path
     small.run(1.0, early_exit=True)
     off, col, _ = small.hits()
