@@ -99,6 +99,10 @@ def test_group_vs_oracle(devices, total):
             lo, hi = int(off[i]), int(off[i + 1])
             assert np.array_equal(col[lo:hi], want), (thr, i, col[lo:hi][:5], want[:5])
             assert np.array_equal(cnt[lo:hi], wc[want].astype(np.uint32)), (thr, i)
+        ref_lists = (off.copy(), col.copy(), cnt.copy())
+        batch.run(thr, early_exit=True)                  # opt-in early exit on every shard: the same gathered hit lists
+        for a, b_ in zip(ref_lists, batch.hits()):
+            assert np.array_equal(a, b_), thr
         if thr == 0.3:      # presence strings, each produced on the shard that owns the column
             i = 0
             hits = col[int(off[0]):int(off[1])]
