@@ -265,7 +265,11 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
         pending, slot, k = None, 0, self.kmer_size
 
         def submit(chunk, slot):
-            if not "".join(chunk).isascii():             # rare: answered at once through search_batch's non-ASCII route
+            try:
+                plain = "".join(chunk).isascii()           # one pass at C speed
+            except TypeError:                             # (bytes among the sequences)
+                plain = all(s.isascii() for s in chunk)
+            if not plain:                                 # rare: answered at once through search_batch's non-ASCII route
                 return _Done(self.search_batch(chunk, threshold, score)), chunk
             batch = self._workspace(slot, chunk)
             self._launch(batch, threshold)

@@ -487,7 +487,7 @@ class ShardedBIGSI(object):
             """Submit `chunk`; yield the results of the batch before it (or, for a chunk holding non-ASCII sequences -- which
             rebinds the exchange -- drain the pipeline and answer the chunk at once)."""
             nonlocal pending, slot
-            if not "".join(chunk).isascii():
+            if not all(s.isascii() for s in chunk):
                 if pending is not None:
                     yield from zip(pending[1], self._collect(pending[0], len(pending[1]), threshold, score))
                     pending = None
