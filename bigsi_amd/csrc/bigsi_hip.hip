@@ -1436,11 +1436,20 @@ static int fetch_hits_from(bigsi_hip_batch *b, HitBufs &hb, const void *src, uin
                            uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t capacity)
 {
     hipStream_t st = (&hb == &b->ghits && b->gstream) ? b->gstream : b->ix->stream;
-    std::vector<uint64_t> off(b->n_seqs + 1);
+    std::vector<uint64_t> off(b->n_seqs + 2);
     // local hit lists were produced before b->done (already waited for); gathered ones on the gather stream
     if (&hb == &b->ghits || !b->compacted) HIP_TRY(hipStreamSynchronize(st));
-    if (&hb == &b->hits) TRY(fused_settle(b));
-    HIP_TRY(hipMemcpy(off.data(), hb.hit_off.p, (b->n_seqs + 1) * 8ull, hipMemcpyDeviceToHost));
+    // (a one-launch read run: the word after the offsets tells whether the launch completed -- it comes with the same copy)
+    const bool fused = &hb == &b->hits && b->fused_run;
+    HIP_TRY(hipMemcpy(off.data(), hb.hit_off.p, (b->n_seqs + (fused ? 2 : 1)) * 8ull, hipMemcpyDeviceToHost));
+    if (fused && !b->fused_settled) {
+        if (off[b->n_seqs + 1] == hb.gen) {
+            TRY(fused_settle(b));
+            HIP_TRY(hipMemcpy(off.data(), hb.hit_off.p, (b->n_seqs + 1) * 8ull, hipMemcpyDeviceToHost));
+        } else {
+            b->fused_settled = true;
+        }
+    }
     const uint64_t total = off[b->n_seqs];
     if (hb.xcol && total > hb.xcap) {
         if (hit_offsets) memcpy(hit_offsets, off.data(), (b->n_seqs + 1) * 8ull);
