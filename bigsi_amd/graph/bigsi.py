@@ -167,9 +167,12 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
         assert threshold <= 1
         return self.search_batch([seq], threshold, score)[0]
 
-    def _workspace(self, slot, seqs):
-        """Batch workspace `slot` of this index object, staged with `seqs` (created once, then only reloaded)."""
-        ws = self.__dict__.setdefault("_workspaces", {})
+    def _workspace(self, slot, seqs, ws=None):
+        """Batch workspace `slot` (of `ws`, else of this index object), staged with `seqs` (created once, then only reloaded).
+        search() / search_batch() use the object's slot 0; every stream generator brings its own dict, so that a search()
+        made while a stream is being consumed cannot reload a batch the stream still has in flight."""
+        if ws is None:
+            ws = self.__dict__.setdefault("_workspaces", {})
         batch = ws.get(slot)
         if batch is None or batch.b is None or batch.storage.res is not self.storage.res:
             batch = ws[slot] = self.storage.new_batch(seqs, self.kmer_size)
@@ -261,8 +264,7 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
         `batch_kmers` k-mers (about 540 x 1 kbp, or ~17000 reads of 61 bp: 4 ms of device work on a 125 GB index, enough to hide the
         per-batch host work; measured 117 M lookups/s with 2^18 and 124 M with 2^19 k-mers per batch at C3)."""
         assert threshold <= 1
-        from itertools import islice
-        pending, slot, k = None, 0, self.kmer_size
+        k, ws = self.kmer_size, {}
 
         def submit(chunk, slot):
             try:
@@ -271,7 +273,7 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
                 plain = all(s.isascii() for s in chunk)
             if not plain:                                 # rare: answered at once through search_batch's non-ASCII route
                 return _Done(self.search_batch(chunk, threshold, score)), chunk
-            batch = self._workspace(slot, chunk)
+            batch = self._workspace(slot, chunk, ws)
             self._launch(batch, threshold)
             return batch, chunk
 
@@ -282,6 +284,16 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
         # batch_size the slice length follows the k-mers per sequence seen so far, so that a batch holds ~batch_kmers of them
         it = iter(seqs)
         take = batch_size if batch_size else 64
+        try:
+            yield from self._stream_loop(it, take, batch_size, batch_kmers, k, submit, done)
+        finally:
+            for b_ in ws.values():
+                b_.close()
+
+    @staticmethod
+    def _stream_loop(it, take, batch_size, batch_kmers, k, submit, done):
+        from itertools import islice
+        pending, slot = None, 0
         while True:
             chunk = list(islice(it, take))
             if not chunk:
@@ -303,6 +315,42 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
             pending, slot = nxt, slot ^ 1
         if pending is not None:
             yield from zip(pending[1], done(pending))
+
+    def search_stream_arrays(self, seqs, threshold=1.0, batch_size=1 << 15):
+        """The device's own answer, batch by batch, for callers to whom a Python dict per hit is too slow (millions of reads):
+        yields (chunk, num_unique, hit_offsets, colours, counts) -- the sequences of the batch, their unique k-mer counts
+        (uint32[n]), and its hit lists: sequence i matched colours[hit_offsets[i]:hit_offsets[i+1]] with that many of its
+        k-mers (ascending colour; every colour < num_samples, deleted samples included: map names with colour_to_sample).
+        Same two-deep pipeline as search_stream.  Not part of the reference's API."""
+        assert threshold <= 1
+        from itertools import islice
+        it, pending, slot, ws = iter(seqs), None, 0, {}
+
+        def finish(p):
+            batch, chunk = p
+            _, nu, _ = batch.unique()
+            off, colours, counts = batch.hits()
+            keep = colours < self.num_samples            # (columns beyond the last sample exist only as padding)
+            if not keep.all():
+                csum = np.concatenate([[0], np.cumsum(keep)])
+                off, colours, counts = csum[off.astype(np.int64)].astype(np.uint64), colours[keep], counts[keep]
+            return chunk, nu[:len(chunk)].copy(), off, colours, counts
+
+        try:
+            while True:
+                chunk = list(islice(it, batch_size))
+                if not chunk:
+                    break
+                batch = self._workspace(slot, chunk, ws)
+                self._launch(batch, threshold)
+                if pending is not None:
+                    yield finish(pending)
+                pending, slot = (batch, chunk), slot ^ 1
+            if pending is not None:
+                yield finish(pending)
+        finally:
+            for b_ in ws.values():
+                b_.close()
 
     def _assemble(self, first_hit, colours, counts, u, exact, strings):
         """Result dicts of one sequence from its slice of the batch's hit lists; `strings` = (text, offsets) of the batch's

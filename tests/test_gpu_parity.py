@@ -1338,3 +1338,22 @@ def test_k1_row_sort_in_registers_and_beyond(hip):
     assert np.array_equal(off, off2) and np.array_equal(col, col2) and np.array_equal(cnt, cnt2)
     batch.close()
     st.delete_all()
+
+
+def test_search_stream_arrays_equals_search(hip):
+    """The array-level stream (an extension for bulk callers) carries exactly what search() turns into dicts."""
+    g = load_golden("g7_random.json")
+    c = cfg(g["k"], g["m"], g["h"])
+    b = hip.BIGSI.build_from_sequences(c, {nm: list(sq) for nm, sq in zip(g["sample_names"], g["sample_seqs"])})
+    qs = g["queries"][:37]
+    for thr in (1.0, 0.4):
+        seen = 0
+        for chunk, nu, off, col, cnt in b.search_stream_arrays(qs, thr, batch_size=10):
+            for i, q in enumerate(chunk):
+                want = b.search(q, thr)
+                got = sorted(zip(cnt[int(off[i]):int(off[i + 1])].tolist(), col[int(off[i]):int(off[i + 1])].tolist()), key=lambda t: (-t[0], t[1]))
+                assert [(r["num_kmers_found"], r["sample_name"]) for r in want] == [(f, b.colour_to_sample(cc)) for f, cc in got]
+                assert all(r["num_kmers"] == int(nu[i]) for r in want)
+                seen += 1
+        assert seen == len(qs)
+    b.delete()
