@@ -478,7 +478,9 @@ class ShardedBIGSI(object):
 
     def search_stream(self, seqs, threshold=1.0, score=False, batch_size=None, batch_kmers=1 << 19):
         """Generator over (sequence, results), two workspaces deep like BIGSI.search_stream: while the GPUs run (and exchange)
-        batch i+1, the host fetches and assembles batch i.  Every rank iterates it in step (SPMD)."""
+        batch i+1, the host fetches and assembles batch i.  Every rank iterates it in step (SPMD).  The two workspaces are the
+        object's own (they are bound to the exchange): finish consuming the stream before calling search() / search_batch()
+        on the same object."""
         assert threshold <= 1
         pending, slot, chunk, held = None, 0, [], 0
         k = self.local.kmer_size
