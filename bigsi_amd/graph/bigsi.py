@@ -321,7 +321,7 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
         yields (chunk, num_unique, hit_offsets, colours, counts) -- the sequences of the batch, their unique k-mer counts
         (uint32[n]), and its hit lists: sequence i matched colours[hit_offsets[i]:hit_offsets[i+1]] with that many of its
         k-mers (ascending colour; every colour < num_samples, deleted samples included: map names with colour_to_sample).
-        Same two-deep pipeline as search_stream.  Not part of the reference's API."""
+        Same two-deep pipeline as search_stream; ASCII sequences only (ValueError otherwise).  Not part of the reference's API."""
         assert threshold <= 1
         from itertools import islice
         it, pending, slot, ws = iter(seqs), None, 0, {}
