@@ -1236,16 +1236,26 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
         slices = std::max<uint32_t>(slices, 1);
     }
     b->local_from_counts = false;
-    // large batches go out as several launches of about k2_blocks workgroups (all co-resident, sweeping the address-ordered
-    // row lists together); queries per launch a multiple of 8 (the blockIdx -> XCD map)
-    static const int k2_blocks = env_int("BIGSI_HIP_K2_BLOCKS", 1024);
+    // large exact batches go out as several launches, each a whole number of workgroups per CU (launches of 384 or 640
+    // workgroups measured 0.72-0.78 of peak, 512 / 768 / 1024: 0.82-0.85) with about 1600-2000 LIVE wavefronts: all co-resident,
+    // sweeping the address-ordered row lists together, and no more bytes in flight than the memory system schedules well --
+    // 10 M x 100 k (13 live wavefronts per query in 4 workgroups): 512 workgroups per launch 0.853 of peak, 1024: 0.819, 256:
+    // 0.68; a 12.5 k-sample shard (2 live wavefronts per workgroup): 1024 workgroups 0.773, 512: 0.581.  Queries per launch
+    // a multiple of 8 (the blockIdx -> XCD map).  The counting kernel measured -4 ... 0 % chunked and stays one launch.
+    static const int k2_blocks = env_int("BIGSI_HIP_K2_BLOCKS", 0);          // > 0: workgroups per launch, fixed
+    static const int k2_waves = env_int("BIGSI_HIP_K2_WAVES", 1600);         // live wavefronts a launch should reach at least
     const uint64_t blocks_per_q = (uint64_t)tiles * slices;
     uint32_t chunk_q = b->n_seqs;
     {
         const uint64_t total_blocks = ceil_div(b->n_seqs, 8) * 8 * blocks_per_q;
         if (total_blocks > 0x7FFFFFFFull) return fail(BIGSI_ERR_INVALID, "batch too large for one launch (%llu workgroups)", (unsigned long long)total_blocks);
-        if (k2_blocks > 0 && b->exact && total_blocks > 2ull * (uint64_t)k2_blocks)
-            chunk_q = (uint32_t)std::max<uint64_t>(8, ((uint64_t)k2_blocks / blocks_per_q) / 8 * 8);
+        uint64_t kb = k2_blocks > 0 ? (uint64_t)k2_blocks : 0;
+        if (!kb && slices == 1) {
+            const uint64_t waves_per_q = ceil_div(b->wv, 64 * kVec);      // wavefronts of a query that hold columns
+            kb = round_up(ceil_div((uint64_t)k2_waves * blocks_per_q, waves_per_q), 256);
+        }
+        if (kb > 0 && b->exact && total_blocks >= 2 * kb)
+            chunk_q = (uint32_t)std::max<uint64_t>(8, (kb / blocks_per_q) / 8 * 8);
     }
     uint32_t n_launches = 0;
     if (b->exact) {
