@@ -1817,9 +1817,9 @@ __global__ __launch_bounds__(kBlock) void k_insert_columns(
 }
 
 // The transpose as a bandwidth kernel (full 64-column words; k_insert_columns above keeps the ragged edges).
-// A workgroup moves a tile of 512 rows x 512 columns: 64 bytes of each of 512 filters in, 64 bytes of each of 512 rows out,
-// both as whole 64-byte runs (16 bytes per lane, four lanes per run), so every sector that crosses the memory interface is
-// used in full and nothing is read-modified-written.  In between, the tile is 64 blocks of 64 x 64 bits; a wavefront
+// A tile is 512 rows x 512 columns: 64 bytes of each of 512 filters in, 64 bytes of each of 512 rows out, as whole runs
+// (16 bytes per lane), so every sector that crosses the memory interface is used in full and nothing is read-modified-written;
+// a workgroup moves 2 x 2 tiles, which makes the runs 128 bytes on both sides (RT, CT below).  In between, the tile is 64 blocks of 64 x 64 bits; a wavefront
 // transposes a block in registers -- lane l holds the 64 row bits of one column, six butterfly steps (exchange with lane
 // l ^ j, j = 32 .. 1) leave lane i holding the 64 column bits of row i -- reading its operands from and writing its results
 // to LDS (pitch 72 bytes: conflict-free 8-byte accesses for 32 lanes at a stride of one LDS row).
@@ -1837,8 +1837,8 @@ constexpr int kTransposeTile = 512, kTransposePitch = 72, kTransposeSuper = 32;
 // modifiers of a v_mov), ^ 16 and ^ 32 gfx950's v_permlane16_swap / v_permlane32_swap (each checked lane by lane on the
 // hardware) instead of 11 ds_bpermute through the CU's one LDS crossbar.  Neither this nor a variant with 8 x 8 bit blocks in
 // registers (2x fewer VALU operations) moved the kernel: with the butterflies skipped altogether (BIGSI_HIP_TR_SKIP=1 in a
-// tuning build) it runs at the same 3.1 TB/s -- the bound is the access pattern, 128-byte reads and 64-byte writes at large
-// strides, half of what the HBM gives a copy (6.3 TB/s).
+// tuning build) it runs at the same rate -- the bound is the access pattern: 128-byte runs at large strides on both sides
+// (RT = CT = 2 below) move 3.5-4.1 TB/s, 64-byte runs 3.1, against the 6.3 TB/s the HBM gives a copy.
 __device__ __forceinline__ uint32_t rotl32v(uint32_t x, uint32_t r) { return __builtin_amdgcn_alignbit(x, x, (32u - r) & 31u); }
 
 template <int J> __device__ __forceinline__ uint32_t lane_xor(uint32_t x, uint32_t lane)
