@@ -115,6 +115,36 @@ def test_scoring_vs_golden():
     assert kat["score"]["length"] == 1174 and kat["score"]["score"] == 1064.89
 
 
+def test_scoring_fast_tallies_equal_the_two_step_form_and_the_oracle():
+    """Scorer.score tallies runs on big integers + one regular expression (filtered_run_tallies); that must be
+    tabulate_score(remove_short_ones(s)) for every string, and the scores must equal the oracle's restatement of score.py."""
+    import random
+    from bigsi_amd.scoring import Scorer, filtered_run_tallies, remove_short_ones, tabulate_score
+    from oracle.ref_model import Scorer as OracleScorer
+    rng = random.Random(20)
+    strings = ["", "0", "1", "00", "11", "10", "111", "110", "011", "101", "0000", "1111", "1101", "1011"]
+    for n in (3, 4, 5, 7, 8, 31, 61, 63, 64, 65, 128, 970, 3970):
+        for p in (0.0, 0.1, 0.5, 0.9, 0.97, 1.0):
+            for _ in range(6):
+                a = ["1" if rng.random() < p else "0" for _ in range(n)]
+                for _ in range(rng.randrange(3)):          # gaps a SNP would leave: ~31 absent k-mers in a row
+                    g0 = rng.randrange(n)
+                    a[g0:g0 + rng.randrange(1, 70)] = "0" * len(a[g0:g0 + rng.randrange(1, 70)])
+                strings.append("".join(a)[:n])
+    for s in strings:
+        ss = remove_short_ones(s)
+        assert filtered_run_tallies(s) == (len(ss), tabulate_score(ss)), s
+    for db in (0, 3, 500000):
+        mine, ref = Scorer(db), OracleScorer(db)
+        for s in strings:
+            if not s:
+                continue
+            assert_result_equal(mine.score(s), ref.score(s), "db=%d %s" % (db, s[:40]))
+    for bad in ("012", "1 1", "0b1", "+11", "1_1"):
+        with pytest.raises(ValueError):
+            filtered_run_tallies(bad)
+
+
 def test_threshold_and_percent_arithmetic():
     from bigsi_amd.graph.bigsi import BigsiQueryResult
     from bigsi_amd.utils import min_kmers_for
