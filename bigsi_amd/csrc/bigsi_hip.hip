@@ -1188,7 +1188,8 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
     b->run_stream = ix->stream;
     // K1e: address-ordered copy of the row lists for K2 (BIGSI_HIP_SORT_ROWS=0 streams them in hash order instead)
     static const int sort_rows = env_int("BIGSI_HIP_SORT_ROWS", 1);
-    const bool want_sorted = sort_rows && b->exact && !(flags & BIGSI_RUN_NO_SORT) && b->total_pos && b->max_pos * ix->h >= 1024;
+    static const int sort_min_rows = env_int("BIGSI_HIP_SORT_MIN_ROWS", 1024);
+    const bool want_sorted = sort_rows && b->exact && !(flags & BIGSI_RUN_NO_SORT) && b->total_pos && b->max_pos * ix->h >= (uint64_t)sort_min_rows;
     // K1 (its LDS route emits the sorted list itself; the other routes leave that to k_sort_rows below)
     EventPair ep{};
     bool sorted_by_k1 = false;
