@@ -712,8 +712,9 @@ __global__ __launch_bounds__(kBlock) void k_kmerize_wave(
 
 // ------------------------------------------------------------------------------ K1e: visit rows in address order
 // AND (and +1-per-k-mer) are order-free, so each query's row list is bucket-sorted by row id before K2 streams it: all
-// resident workgroups then sweep the index from low to high addresses together instead of scattering over 125 GB, which
-// measured +4 % on the row-AND kernel (DRAM page / TLB locality; perfectly sequential rows would give +10 %).
+// resident workgroups then sweep the index from low to high addresses together instead of scattering over 125 GB: with
+// launches small enough to be co-resident (bigsi_hip_batch_run) the row-AND kernel runs at 0.857 of peak against 0.79 for
+// rows in hash order, whatever the launch size (DRAM page / TLB locality).
 // kSortBuckets buckets over [0, m) (about two per row of a 1 kbp query, i.e. nearly a full sort): LDS histogram -> scan -> scatter.  `group` = 1 sorts rows individually (exact path),
 // `group` = h keeps each k-mer's h rows together and sorts k-mers by their first row (counting path).
 // The order inside a bucket depends on atomics; the results of K2 do not.

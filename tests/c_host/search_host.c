@@ -1,0 +1,113 @@
+/* A host of the C ABI that is not Python: plain C99, no torch, no HIP headers -- what a cgo / JNI / N-API binder of
+ * include/bigsi_hip.h would compile to.  It builds a small index from the FASTA-like input it is given (sample sequences
+ * -> bigsi_hip_insert_kmers, i.e. BIGSI.bloom + build, bigsi/graph/bigsi.py:150-155,92-112), runs every query through the
+ * ONE-CALL entry point bigsi_hip_search_batch (BIGSI.search, bigsi/graph/bigsi.py:174-242) exactly and at a threshold, and
+ * prints the hit lists as text.  tests/test_gpu_parity.py::test_c_host_of_the_abi runs it and compares the text with the
+ * oracle; the CPU suite checks that it compiles as C against the header and links against the library.
+ *
+ * input (stdin):  m h k n_samples n_queries threshold
+ *                 then n_samples lines  "<n_seqs> seq seq ..."   (sample i = column i)
+ *                 then n_queries lines  "seq"
+ * output:         per pass ("exact" / "threshold"), per query:  q <i> kmers <n> unique <u> min <mk> hits <c>:<count> ...
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "bigsi_hip.h"
+
+#define CHECK(call)                                                                             \
+    do {                                                                                        \
+        int rc_ = (call);                                                                       \
+        if (rc_ != BIGSI_OK) {                                                                  \
+            fprintf(stderr, "%s -> %d: %s\n", #call, rc_, bigsi_hip_last_error());              \
+            return 1;                                                                           \
+        }                                                                                       \
+    } while (0)
+
+enum { MAX_SEQ = 1 << 16 };
+
+static int run_pass(bigsi_hip_index *ix, const char *name, const char *blob, const uint64_t *off, uint32_t nq, uint32_t k, double thr)
+{
+    uint32_t *nk = malloc(nq * sizeof *nk), *nu = malloc(nq * sizeof *nu), *mk = malloc(nq * sizeof *mk);
+    uint64_t *ho = malloc((nq + 1) * sizeof *ho);
+    uint64_t cap = 4;                       /* deliberately small: the CAPACITY protocol is part of the boundary */
+    uint32_t *col = malloc(cap * sizeof *col), *cnt = malloc(cap * sizeof *cnt);
+    int rc;
+    if (!nk || !nu || !mk || !ho || !col || !cnt) return 1;
+    for (;;) {
+        rc = bigsi_hip_search_batch(ix, blob, off, nq, k, thr, 0u, nk, nu, mk, ho, col, cnt, cap);
+        if (rc != BIGSI_ERR_CAPACITY) break;
+        cap = ho[nq];                       /* hit_offsets are filled even then: the total says how much to bring */
+        col = realloc(col, cap * sizeof *col);
+        cnt = realloc(cnt, cap * sizeof *cnt);
+        if (!col || !cnt) return 1;
+    }
+    if (rc != BIGSI_OK) {
+        fprintf(stderr, "bigsi_hip_search_batch -> %d: %s\n", rc, bigsi_hip_last_error());
+        return 1;
+    }
+    printf("pass %s\n", name);
+    for (uint32_t q = 0; q < nq; q++) {
+        printf("q %u kmers %u unique %u min %u hits", q, nk[q], nu[q], mk[q]);
+        for (uint64_t t = ho[q]; t < ho[q + 1]; t++) printf(" %u:%u", col[t], cnt[t]);
+        printf("\n");
+    }
+    free(nk); free(nu); free(mk); free(ho); free(col); free(cnt);
+    return 0;
+}
+
+int main(void)
+{
+    unsigned long long m;
+    unsigned h, k, n_samples, nq;
+    double thr;
+    static char buf[MAX_SEQ];
+    if (scanf("%llu %u %u %u %u %lf", &m, &h, &k, &n_samples, &nq, &thr) != 6) return 2;
+    int n_dev = 0;
+    CHECK(bigsi_hip_device_count(&n_dev));
+    if (n_dev < 1) { fprintf(stderr, "no device\n"); return 3; }
+    bigsi_hip_index *ix = NULL;
+    CHECK(bigsi_hip_open(m, 0, n_samples, h, 0, &ix));
+    for (unsigned s = 0; s < n_samples; s++) {
+        unsigned ns;
+        if (scanf("%u", &ns) != 1) return 2;
+        char *blob = NULL;
+        uint64_t *off = malloc((ns + 1) * sizeof *off), len = 0;
+        off[0] = 0;
+        for (unsigned i = 0; i < ns; i++) {
+            if (scanf("%65535s", buf) != 1) return 2;
+            size_t l = strlen(buf);
+            blob = realloc(blob, len + l + 1);
+            memcpy(blob + len, buf, l);
+            len += l;
+            off[i + 1] = len;
+        }
+        CHECK(bigsi_hip_set_num_cols(ix, s + 1));            /* BitMatrix.insert_column appends: bitmatrix.py:67-75 */
+        CHECK(bigsi_hip_insert_kmers(ix, s, blob ? blob : "", off, ns, k));
+        free(blob); free(off);
+    }
+    char *qblob = NULL;
+    uint64_t *qoff = malloc((nq + 1) * sizeof *qoff), qlen = 0;
+    qoff[0] = 0;
+    for (unsigned i = 0; i < nq; i++) {
+        if (scanf("%65535s", buf) != 1) return 2;
+        size_t l = strlen(buf);
+        qblob = realloc(qblob, qlen + l + 1);
+        memcpy(qblob + qlen, buf, l);
+        qlen += l;
+        qoff[i + 1] = qlen;
+    }
+    bigsi_hip_info info;
+    CHECK(bigsi_hip_get_info(ix, &info));
+    printf("index rows %llu cols %llu hashes %u row_bytes %llu\n", (unsigned long long)info.num_rows, (unsigned long long)info.num_cols,
+           info.num_hashes, (unsigned long long)info.row_bytes);
+    if (run_pass(ix, "exact", qblob, qoff, nq, k, 1.0)) return 1;
+    if (run_pass(ix, "threshold", qblob, qoff, nq, k, thr)) return 1;
+    /* error behaviour reaches a C host as a code + message, never as an abort */
+    if (bigsi_hip_search_batch(ix, qblob, qoff, 0, k, 1.0, 0u, NULL, NULL, NULL, NULL, NULL, NULL, 0) == BIGSI_OK) return 4;
+    printf("error %s\n", bigsi_hip_last_error()[0] ? "reported" : "silent");
+    free(qblob); free(qoff);
+    CHECK(bigsi_hip_close(ix));
+    return 0;
+}

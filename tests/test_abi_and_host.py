@@ -32,6 +32,30 @@ def test_library_exports_every_declared_symbol():
     _lib.lib()
 
 
+def build_c_host(tmp_path):
+    """tests/c_host/search_host.c compiled as strict C99 against include/bigsi_hip.h and linked to the in-tree library."""
+    import subprocess
+    from bigsi_amd import _lib
+    exe = str(tmp_path / "search_host")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           "-o", exe, os.path.join(ROOT, "tests", "c_host", "search_host.c"),
+                           "-L", os.path.dirname(_lib.LIB_PATH), "-lbigsi_hip", "-Wl,-rpath," + os.path.dirname(_lib.LIB_PATH)])
+    return exe
+
+
+def test_header_is_plain_c_and_a_c_host_links(tmp_path):
+    """The boundary is a C ABI: the header must compile as C (not only as C++) and a host without Python or HIP headers must
+    link against the library alone.  Without a device that host fails loudly -- an error code and message, no fallback."""
+    import subprocess
+    import torch
+    exe = build_c_host(tmp_path)
+    if torch.cuda.is_available():
+        return                                  # what it computes is checked by the gpu suite
+    r = subprocess.run([exe], input="1009 3 31 1 1 0.5\n1 ACGTACGTACGTACGTACGTACGTACGTACGTACGT\nACGTACGTACGTACGTACGTACGTACGTACGTACGT\n",
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "bigsi_hip_device_count" in r.stderr and r.stdout == ""
+
+
 def test_header_cites_reference_lines():
     src = open(os.path.join(ROOT, "include", "bigsi_hip.h")).read()
     assert len(re.findall(r"bigsi/[\w/]+\.py:\d+", src)) >= 25

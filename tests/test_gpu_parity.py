@@ -2,7 +2,7 @@
 unmodified reference (tests/golden) and the CPU oracle (oracle/) on seeded inputs.  Bit-exact for everything
 integer / byte / index; float score fields as stated in conftest.py.  Needs a real MI355X: `pytest -m gpu`."""
 import itertools
-
+import math
 import os
 
 import numpy as np
@@ -1090,6 +1090,48 @@ def test_fuzz_api_vs_oracle_model(hip, seed):
             assert {x: v.to01() for x, v in lk.items()} == want_lk
     finally:
         b.delete()
+
+
+def test_c_host_of_the_abi(hip, tmp_path):
+    """A host that is not Python (tests/c_host/search_host.c: C99, links libbigsi_hip.so only) builds the G7 index through
+    bigsi_hip_insert_kmers and searches through the one-call bigsi_hip_search_batch; its printed hit lists must be the
+    reference's G7 results (exact and threshold 0.4), including the grow-and-retry protocol for the hit buffers."""
+    import subprocess
+    from test_abi_and_host import build_c_host
+    g = load_golden("g7_random.json")
+    names = g["sample_names"]
+    exe = build_c_host(tmp_path)
+    lines = ["%d %d %d %d %d 0.4" % (g["m"], g["h"], g["k"], len(names), len(g["queries"]))]
+    lines += ["%d %s" % (len(seqs), " ".join(seqs)) for seqs in g["sample_seqs"]]
+    lines += list(g["queries"])
+    r = subprocess.run([exe], input="\n".join(lines) + "\n", capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    out = r.stdout.splitlines()
+    assert out[0] == "index rows %d cols %d hashes %d row_bytes %d" % (g["m"], len(names), g["h"], -(-len(names) // 8))
+    assert out[-1] == "error reported"
+    passes, cur = {}, None
+    for ln in out[1:-1]:
+        f = ln.split()
+        if f[0] == "pass":
+            cur = passes.setdefault(f[1], {})
+        else:
+            cur[int(f[1])] = (int(f[3]), int(f[5]), int(f[7]), [tuple(map(int, x.split(":"))) for x in f[9:]])
+    checked = 0
+    for name, thr in (("exact", 1.0), ("threshold", 0.4)):
+        assert sorted(passes[name]) == list(range(len(g["queries"])))
+        for srch in g["searches"]:
+            if srch["threshold"] != thr or srch["score"] or "results" not in srch["out"]:
+                continue
+            nk, nu, mk, hits = passes[name][srch["q"]]
+            want = srch["out"]["results"]
+            assert [c for c, _ in hits] == sorted(c for c, _ in hits)
+            assert sorted((names[c], n) for c, n in hits) == sorted((w["sample_name"], w["num_kmers_found"]) for w in want), (name, srch["q"])
+            for w in want:
+                assert w["num_kmers"] == nu
+            assert nk == len(g["queries"][srch["q"]]) - g["k"] + 1
+            assert mk == math.ceil(nu * thr)
+            checked += 1
+    assert checked >= 60
 
 
 def test_storage_search_batch_entry_point(hip):
