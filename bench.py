@@ -333,7 +333,7 @@ def main():
     # fetched): fetch every staged batch's last run, so that such a launch -- none has ever been seen -- would be counted
     repeated = 0
     if batches[0].info().one_launch:
-        for b_ in batches:
+        for b_ in batches[:step_no[0]]:        # (a short run may not have reached every staged batch)
             b_.hits()
         rs = _lib.Stats()
         check(_lib.lib().bigsi_hip_stats(st.handle, _lib.C.byref(rs), 0))
@@ -387,8 +387,11 @@ def main():
     if world == 1 and not args.force_dist:
         # a serving loop: two workspaces, reloaded per batch; while one batch runs, the host uploads the next one and
         # downloads the hit lists of the one before (what BIGSI.search_stream does)
-        reps = 8
+        reps = 8 if w["batch"] * w["qlen"] >= (1 << 20) else 200      # (small batches: enough repetitions to time)
         ws = [st.new_batch(seqs, args.k) for _ in range(2)]
+        for w_ in ws:                                                  # both workspaces warm
+            w_.run(thr, sparse_counts=True)
+            w_.hits()
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
         for i in range(reps):

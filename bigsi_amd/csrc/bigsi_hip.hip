@@ -614,6 +614,15 @@ static uint64_t pow2_at_least(uint64_t x)
 }
 
 // (re)load a batch object with sequences: host-side prefix arrays, grow-only device buffers, H2D copies
+// num_kmers | num_unique | min_kmers of the batch's n_seqs sequences, side by side in b->uniq (host_counts: one download)
+static void point_uniq(bigsi_hip_batch *b)
+{
+    uint32_t *u = b->uniq.as<uint32_t>();
+    b->num_kmers.point(u, b->n_seqs * 4ull);
+    b->num_unique.point(u + b->n_seqs, b->n_seqs * 4ull);
+    b->min_kmers.point(u + 2ull * b->n_seqs, b->n_seqs * 4ull);
+}
+
 static int batch_load(bigsi_hip_batch *b, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k)
 {
     bigsi_hip_index *ix = b->ix;
@@ -640,28 +649,38 @@ static int batch_load(bigsi_hip_batch *b, const char *seqs, const uint64_t *offs
     const uint64_t T = std::max<uint64_t>(b->total_pos, 1);
     int rc = BIGSI_OK;
     auto R = [&](DevBuf &d, size_t bytes) { if (rc == BIGSI_OK) rc = d.reserve(bytes); };
-    R(b->seqs, std::max<uint64_t>(nbytes, 1));
-    R(b->d_seq_off, (n_seqs + 1) * 8ull);
-    R(b->d_pos_off, (n_seqs + 1) * 8ull);
-    R(b->d_tab_off, (n_seqs + 1) * 8ull);
+    // upload arena: [seq_off | pos_off | tab_off | sequence bytes]; the three offset tables go up as ONE copy, together with the
+    // sequences when those are short (a batch of reads: one copy instead of four), else the sequences straight from the caller
+    const size_t ob = (n_seqs + 1) * 8ull;
+    R(b->upload, 3 * ob + std::max<uint64_t>(nbytes, 1));
     R(b->first_pos, T * 4);
     R(b->pos_unique, T * 4);
     R(b->tmp, T * 4);
     R(b->rep, T * 4);
     R(b->rows, T * ix->h * 8);
-    R(b->num_kmers, n_seqs * 4ull);
-    R(b->num_unique, n_seqs * 4ull);
-    R(b->min_kmers, n_seqs * 4ull);
+    R(b->uniq, 3ull * n_seqs * 4);
+    if (rc == BIGSI_OK) {
+        uint8_t *u = b->upload.as<uint8_t>();
+        b->d_seq_off.point(u, ob);
+        b->d_pos_off.point(u + ob, ob);
+        b->d_tab_off.point(u + 2 * ob, ob);
+        b->seqs.point(u + 3 * ob, std::max<uint64_t>(nbytes, 1));
+        point_uniq(b);
+    }
     auto H2D = [&](void *dst, const void *src, size_t bytes) {
         if (rc == BIGSI_OK && bytes) {
             hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ix->pre_stream);
             if (e != hipSuccess) rc = fail(BIGSI_ERR_HIP, "H2D copy: %s", hipGetErrorString(e));
         }
     };
-    H2D(b->seqs.p, seqs ? seqs + base : nullptr, nbytes);
-    H2D(b->d_seq_off.p, b->seq_off.data(), (n_seqs + 1) * 8ull);
-    H2D(b->d_pos_off.p, b->pos_off.data(), (n_seqs + 1) * 8ull);
-    H2D(b->d_tab_off.p, b->tab_off.data(), (n_seqs + 1) * 8ull);
+    const bool packed = nbytes <= (64u << 10);
+    b->h_upload.resize(3 * ob + (packed ? nbytes : 0));
+    memcpy(b->h_upload.data(), b->seq_off.data(), ob);
+    memcpy(b->h_upload.data() + ob, b->pos_off.data(), ob);
+    memcpy(b->h_upload.data() + 2 * ob, b->tab_off.data(), ob);
+    if (packed && nbytes) memcpy(b->h_upload.data() + 3 * ob, seqs + base, nbytes);
+    H2D(b->upload.p, b->h_upload.data(), b->h_upload.size());
+    if (!packed) H2D(b->seqs.p, seqs + base, nbytes);
     b->pos_query_loaded = false;
     if (rc == BIGSI_OK) {
         hipError_t e = hipStreamSynchronize(ix->pre_stream);  // the host vectors above are read by the copies
@@ -771,9 +790,8 @@ extern "C" int bigsi_hip_batch_create_elements(bigsi_hip_index *ix, const char *
     R(b->pos_unique, T * 4);
     R(b->rep, T * 4);
     R(b->rows, T * ix->h * 8);
-    R(b->num_kmers, n_seqs * 4ull);
-    R(b->num_unique, n_seqs * 4ull);
-    R(b->min_kmers, n_seqs * 4ull);
+    R(b->uniq, 3ull * n_seqs * 4);
+    if (rc == BIGSI_OK) point_uniq(b);
     auto H2D = [&](void *dst, const void *src, size_t bytes) {
         if (rc == BIGSI_OK && bytes) {
             hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ix->pre_stream);
@@ -821,7 +839,7 @@ extern "C" int bigsi_hip_batch_destroy(bigsi_hip_batch *b)
     if (b->done) e = hipEventSynchronize(b->done);           // a run on one of the read streams
     if (b->gstream && b->g_done) e = hipEventSynchronize(b->g_done);
     (void)e;
-    for (DevBuf *d : {&b->pres_desc, &b->elem_seq_off, &b->pres_in, &b->pres_bits, &b->pres_out, &b->rows_sorted, &b->pos_query, &b->hsh, &b->rep, &b->seqs, &b->d_seq_off, &b->d_pos_off, &b->d_tab_off, &b->tab, &b->first_pos, &b->pos_unique, &b->tmp, &b->rows,
+    for (DevBuf *d : {&b->uniq, &b->upload, &b->pres_desc, &b->elem_seq_off, &b->pres_in, &b->pres_bits, &b->pres_out, &b->rows_sorted, &b->pos_query, &b->hsh, &b->rep, &b->seqs, &b->d_seq_off, &b->d_pos_off, &b->d_tab_off, &b->tab, &b->first_pos, &b->pos_unique, &b->tmp, &b->rows,
                       &b->num_kmers, &b->num_unique, &b->min_kmers, &b->bitmaps, &b->counts, &b->scratch})
         d->release();
     b->hits.release();
@@ -1501,10 +1519,12 @@ static int need_run(bigsi_hip_batch *b)
 static int host_counts(bigsi_hip_batch *b)
 {
     if (b->host_counts_valid) return BIGSI_OK;
-    b->h_num_unique.resize(b->n_seqs);
-    b->h_num_kmers.resize(b->n_seqs);
-    HIP_TRY(hipMemcpy(b->h_num_unique.data(), b->num_unique.p, b->n_seqs * 4ull, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(b->h_num_kmers.data(), b->num_kmers.p, b->n_seqs * 4ull, hipMemcpyDeviceToHost));
+    const size_t n = b->n_seqs;
+    b->h_uniq.resize(3 * n);
+    HIP_TRY(hipMemcpy(b->h_uniq.data(), b->uniq.p, 3 * n * 4, hipMemcpyDeviceToHost));       // (point_uniq)
+    b->h_num_kmers.assign(b->h_uniq.begin(), b->h_uniq.begin() + n);
+    b->h_num_unique.assign(b->h_uniq.begin() + n, b->h_uniq.begin() + 2 * n);
+    b->h_min_kmers.assign(b->h_uniq.begin() + 2 * n, b->h_uniq.end());
     b->host_counts_valid = true;
     return BIGSI_OK;
 }
@@ -1541,7 +1561,7 @@ extern "C" int bigsi_hip_batch_fetch_unique(bigsi_hip_batch *b, uint32_t *num_km
     TRY(host_counts(b));
     if (num_kmers) memcpy(num_kmers, b->h_num_kmers.data(), b->n_seqs * 4ull);
     if (num_unique) memcpy(num_unique, b->h_num_unique.data(), b->n_seqs * 4ull);
-    if (min_kmers) HIP_TRY(hipMemcpy(min_kmers, b->min_kmers.p, b->n_seqs * 4ull, hipMemcpyDeviceToHost));
+    if (min_kmers) memcpy(min_kmers, b->h_min_kmers.data(), b->n_seqs * 4ull);
     return BIGSI_OK;
 }
 

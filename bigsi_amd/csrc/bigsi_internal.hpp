@@ -49,8 +49,10 @@ static inline int env_int(const char *name, int dflt)
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    bool view = false;          // points into another DevBuf (point()): never allocates, never frees
     int reserve(size_t bytes)
     {
+        if (view) return fail(BIGSI_ERR_STATE, "internal: reserve() on a buffer view");
         if (bytes <= cap) return BIGSI_OK;
         if (p) { hipError_t e = hipFree(p); (void)e; p = nullptr; cap = 0; }
         size_t want = std::max<size_t>(bytes, 256);
@@ -58,9 +60,15 @@ struct DevBuf {
         cap = want;
         return BIGSI_OK;
     }
+    void point(void *q, size_t bytes)
+    {
+        p = q;
+        cap = bytes;
+        view = true;
+    }
     void release()
     {
-        if (p) { hipError_t e = hipFree(p); (void)e; }
+        if (p && !view) { hipError_t e = hipFree(p); (void)e; }
         p = nullptr;
         cap = 0;
     }
@@ -127,6 +135,12 @@ struct bigsi_hip_batch {
     std::vector<uint64_t> seq_off, pos_off, tab_off;
     uint64_t total_pos = 0, max_pos = 0, max_len = 0;
     DevBuf seqs, d_seq_off, d_pos_off, d_tab_off, tab, first_pos, pos_unique, tmp, rows, num_kmers, num_unique, min_kmers;
+    // few, larger copies (a host-side call is mostly the latency of its copies): num_kmers | num_unique | min_kmers are views
+    // into `uniq` (ONE download); in a sequence batch d_seq_off | d_pos_off | d_tab_off | seqs are views into `upload`
+    // (one or two uploads)
+    DevBuf uniq, upload;
+    std::vector<uint8_t> h_upload;
+    std::vector<uint32_t> h_uniq;
     DevBuf pos_query, hsh, rep;   // per k-mer position: owning sequence, dedupe hash, class representative
     DevBuf rows_sorted;           // the row ids K2 streams: each query's list in address order (k_sort_rows)
     DevBuf bitmaps, counts, scratch;
@@ -158,7 +172,7 @@ struct bigsi_hip_batch {
     uint64_t g_shard_cols = 0;
     uint32_t g_own = 0;
     bool g_masks = false;          // the gathered buffer holds hit masks of a counting run (counts come from this rank's counters)
-    std::vector<uint32_t> h_num_unique, h_num_kmers;
+    std::vector<uint32_t> h_num_unique, h_num_kmers, h_min_kmers;
     bool host_counts_valid = false;
     // column-shard exchange (bigsi_shard.hip)
     uint64_t result_cols = 0;      // > 0: width of the per-sample result vectors (the group's shard_cols), so that every shard of

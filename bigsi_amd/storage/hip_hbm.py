@@ -221,6 +221,7 @@ class _Resident(object):
 
 class HipHbmStorage(BaseStorage):
     fused = True      # BIGSI.search/lookup may call search_batch / lookup_kmers
+    _search_cap = 1 << 12     # hit entries search_batch brings buffers for (grows to what a call needed)
 
     def __init__(self, storage_config=None):
         self.storage_config = dict(storage_config or {})
@@ -430,15 +431,27 @@ class HipHbmStorage(BaseStorage):
         thresholded: every colour with count >= ceil(num_unique * threshold), graph/bigsi.py:179,241-242).  Names,
         ordering by count, percentages and scores stay with the caller."""
         assert threshold <= 1                                   # graph/bigsi.py:176
-        batch = QueryBatch(self, list(seqs), k)
-        try:
-            batch.run(threshold, sparse_counts=True)
-            nk, nu, _ = batch.unique()
-            off, col, cnt = batch.hits()
-            return [(int(nk[i]), int(nu[i]), col[int(off[i]):int(off[i + 1])].copy(), cnt[int(off[i]):int(off[i + 1])].copy())
-                    for i in range(batch.n)]
-        finally:
-            batch.close()
+        seqs = list(seqs)
+        n = len(seqs)
+        if n == 0:
+            return []
+        # the C ABI's one-call entry point (bigsi_hip_search_batch / bigsi_hip_group_search_batch): the index keeps the
+        # workspace, so a call is two uploads, the kernels and three downloads -- no device allocation
+        blob, soff = _lib.pack_seqs(seqs)
+        fn = getattr(_lib.lib(), "bigsi_hip_group_search_batch" if self.res.is_group else "bigsi_hip_search_batch")
+        nk, nu = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        off = np.zeros(n + 1, np.uint64)
+        cap = self._search_cap
+        while True:
+            col, cnt = np.zeros(cap, np.uint32), np.zeros(cap, np.uint32)
+            rc = fn(self.handle, blob, _lib.ptr(soff), n, int(k), float(threshold), 0, _lib.ptr(nk), _lib.ptr(nu), None,
+                    _lib.ptr(off), _lib.ptr(col), _lib.ptr(cnt), cap)
+            if rc != _lib.ERR_CAPACITY:
+                break
+            cap = self._search_cap = int(off[-1])             # offsets are filled in: bring that much next time
+        check(rc)
+        o, nk, nu = off.tolist(), nk.tolist(), nu.tolist()
+        return [(nk[i], nu[i], col[o[i]:o[i + 1]], cnt[o[i]:o[i + 1]]) for i in range(n)]
 
 
 class QueryBatch(object):
