@@ -1207,7 +1207,10 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
     // K1e: address-ordered copy of the row lists for K2 (BIGSI_HIP_SORT_ROWS=0 streams them in hash order instead)
     static const int sort_rows = env_int("BIGSI_HIP_SORT_ROWS", 1);
     static const int sort_min_rows = env_int("BIGSI_HIP_SORT_MIN_ROWS", 1024);
-    const bool want_sorted = sort_rows && b->exact && !(flags & BIGSI_RUN_NO_SORT) && b->total_pos && b->max_pos * ix->h >= (uint64_t)sort_min_rows;
+    // (not for the few queries of a latency-bound call either: their row lists are cut into slices over many workgroups -- see
+    // `slices` below -- and the ordering buys nothing, it only lengthens the chain of kernels: 10 us of a 65 us single query)
+    const bool few = (uint64_t)b->n_seqs * ceil_div(b->wv, 64 * kVec) < 1024 && !b->ext_bitmaps && !b->ext_counts;
+    const bool want_sorted = sort_rows && b->exact && !few && !(flags & BIGSI_RUN_NO_SORT) && b->total_pos && b->max_pos * ix->h >= (uint64_t)sort_min_rows;
     // K1 (its LDS route emits the sorted list itself; the other routes leave that to k_sort_rows below)
     EventPair ep{};
     bool sorted_by_k1 = false;
