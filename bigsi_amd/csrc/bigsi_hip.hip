@@ -1188,7 +1188,6 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
         TRY(ev_end(ix, &fe, ix->ev_and, st));
         b->run_h = ix->h;
         b->fused_run = true;
-        b->local_from_counts = false;
         b->count_bytes = 2;
         b->sparse_counts = !b->exact;
         b->compacted = true;
@@ -1209,7 +1208,11 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
     static const int sort_min_rows = env_int("BIGSI_HIP_SORT_MIN_ROWS", 1024);
     // (not for the few queries of a latency-bound call either: their row lists are cut into slices over many workgroups -- see
     // `slices` below -- and the ordering buys nothing, it only lengthens the chain of kernels: 10 us of a 65 us single query)
-    const bool few = (uint64_t)b->n_seqs * ceil_div(b->wv, 64 * kVec) < 1024 && !b->ext_bitmaps && !b->ext_counts;
+    // caller-owned result buffers (a shard's slot of a gather buffer): a bitmap can be preset and sliced like the batch's own
+    // (the counting path then cuts its hit mask from the summed counters, k_mask_from_counts); caller-owned counters are
+    // written in place, without presets
+    const bool sliceable = !b->ext_counts;
+    const bool few = (uint64_t)b->n_seqs * ceil_div(b->wv, 64 * kVec) < 1024 && sliceable;
     const bool want_sorted = sort_rows && b->exact && !few && !(flags & BIGSI_RUN_NO_SORT) && b->total_pos && b->max_pos * ix->h >= (uint64_t)sort_min_rows;
     // K1 (its LDS route emits the sorted list itself; the other routes leave that to k_sort_rows below)
     EventPair ep{};
@@ -1256,10 +1259,9 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
         // (one 1 kbp query on 100 k samples, its slices spread over all XCDs (map_block): exact 35 / 14.7 / 16.6 / 22.9 us at
         // 16 / 64 / 128 / 256 slices, counting 59 / 31 / 30 / 32 us; beyond that the atomics that combine the slices show)
         else if (waves < 1024) slices = (uint32_t)std::min<uint64_t>({64, ceil_div(2048, std::max<uint64_t>(waves, 1)), std::max<uint64_t>(b->max_pos / 16, 1)});
-        if (b->ext_bitmaps || b->ext_counts) slices = 1;      // gathered buffers are written in place, without presets
+        if (!sliceable) slices = 1;
         slices = std::max<uint32_t>(slices, 1);
     }
-    b->local_from_counts = false;
     // large exact batches go out as several launches, each a whole number of workgroups per CU (launches of 384 or 640
     // workgroups measured 0.72-0.78 of peak, 512 / 768 / 1024: 0.82-0.85) with about 1600-2000 LIVE wavefronts: all co-resident,
     // sweeping the address-ordered row lists together, and no more bytes in flight than the memory system schedules well --
@@ -1315,10 +1317,7 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
         uint64_t *hb = b->ext_bitmaps ? (uint64_t *)b->ext_bitmaps : b->bitmaps.as<uint64_t>();
         b->sparse_counts = (flags & BIGSI_RUN_SPARSE_COUNTS) && !b->ext_counts && slices == 1;
         const uint32_t sparse = b->sparse_counts ? 1u : 0u;
-        if (slices > 1) {
-            HIP_TRY(hipMemsetAsync(out, 0, (size_t)b->n_seqs * cstride * b->count_bytes, ix->stream));
-            b->local_from_counts = true;      // K4 thresholds the summed counters
-        }
+        if (slices > 1) HIP_TRY(hipMemsetAsync(out, 0, (size_t)b->n_seqs * cstride * b->count_bytes, ix->stream));
         TRY(ev_begin(ix, &ep, nullptr, true));
         // fewer than ~3 wavefronts per SIMD in the whole grid (e.g. 128 gene-length queries): the software-pipelined loop,
         // whose wavefronts load the next k-mers' rows while adding the current ones (5.6 -> 6.3 TB/s at 128 x 2-4 kbp; with a
@@ -1331,6 +1330,15 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
         const CountLaunch cl{k2_rows, (unsigned)and_block, tiles, out, cstride, hb, sparse, slices, deep && !early, early};
         for (uint32_t q0 = 0; q0 < b->n_seqs; q0 += chunk_q, n_launches++)
             launch_count(b, P, cl, q0, (uint32_t)std::min<uint64_t>((uint64_t)q0 + chunk_q, b->n_seqs));
+        if (slices > 1) {        // partial counts were summed by the slices: the hit mask from the totals
+            const uint64_t items = (uint64_t)b->n_seqs * b->wv;
+            if (b->count_bytes == 2)
+                hipLaunchKernelGGL((k_mask_from_counts<uint16_t>), dim3((unsigned)ceil_div(items, kBlock)), dim3(kBlock), 0, ix->stream, (const uint16_t *)out,
+                                   cstride, b->min_kmers.as<uint32_t>(), ix->n_cols, hb, b->wv_pad, (uint32_t)b->wv, b->n_seqs);
+            else
+                hipLaunchKernelGGL((k_mask_from_counts<uint32_t>), dim3((unsigned)ceil_div(items, kBlock)), dim3(kBlock), 0, ix->stream, (const uint32_t *)out,
+                                   cstride, b->min_kmers.as<uint32_t>(), ix->n_cols, hb, b->wv_pad, (uint32_t)b->wv, b->n_seqs);
+        }
         HIP_TRY(hipGetLastError());
         TRY(ev_end(ix, &ep, ix->ev_and, nullptr, n_launches));
     }
@@ -1429,8 +1437,6 @@ static int compact_ex(bigsi_hip_batch *b, HitBufs &hb, const void *src, bool fro
 // this shard's own result (n_shards == 1): always a bitmap; gathered buffers: bitmaps (exact) or counters (counting)
 static int compact(bigsi_hip_batch *b, HitBufs &hb, const void *src, uint32_t n_shards, uint64_t shard_cols, bool write_only)
 {
-    if (&hb == &b->hits && b->local_from_counts && !b->exact)
-        return compact_ex(b, hb, b->counts.p, true, nullptr, 1, shard_cols, write_only, b->ix->stream);
     if (&hb == &b->hits) {
         const void *bm = b->ext_bitmaps ? b->ext_bitmaps : b->bitmaps.p;
         const void *counters = b->exact ? nullptr : (b->ext_counts ? b->ext_counts : b->counts.p);
@@ -1627,7 +1633,6 @@ extern "C" int bigsi_hip_batch_compact_gathered_masks(bigsi_hip_batch *b, const 
     if (!d_gathered_masks || n_shards == 0 || own_shard >= n_shards) return fail(BIGSI_ERR_INVALID, "bad gathered buffer / shard");
     if ((uint64_t)n_shards * shard_cols > 0xFFFFFFFFull) return fail(BIGSI_ERR_INVALID, "more than 2^32-1 colours in total");
     if (b->exact) return bigsi_hip_batch_compact_gathered(b, d_gathered_masks, n_shards, shard_cols);
-    if (b->sparse_counts == false && b->local_from_counts) return fail(BIGSI_ERR_STATE, "row-sliced run: no hit masks were produced");
     b->g_src = d_gathered_masks;
     b->g_shards = n_shards;
     b->g_shard_cols = shard_cols;

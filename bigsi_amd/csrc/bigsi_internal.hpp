@@ -150,7 +150,6 @@ struct bigsi_hip_batch {
     // state of the last run
     bool ran = false, exact = false, compacted = false, sparse_counts = false;
     bool pos_query_loaded = false;    // pos_query holds this load's position -> sequence map
-    bool local_from_counts = false;   // the last counting run was row-sliced: hits come from thresholding the counters
     hipStream_t run_stream = nullptr;   // the stream `done` was last recorded on
     bool fused_settled = false;         // the last one-launch run is known to have completed (fused_settle)
     bool weak_fp = false;         // BIGSI_RUN_WEAK_FINGERPRINT of the last one-launch run (a re-launch after a regrow repeats it)
