@@ -1244,7 +1244,21 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
     // K2
     static const int and_block_env = [] { int v = env_int("BIGSI_HIP_AND_BLOCK", 256); return (v >= 64 && v <= 1024 && v % 64 == 0) ? v : 256; }();
     // the counting kernels are compiled for at most 256 threads per workgroup (register budget of the plane arrays)
-    const int and_block = b->exact ? and_block_env : std::min(and_block_env, 256);
+    // one wavefront per workgroup for batches of a few thousand wavefronts (80 ... 300 gene-length queries on 100 k samples):
+    // they are a single launch, a CU's share of it is what bounds it, and 4-wavefront workgroups leave the CUs unevenly loaded
+    // (320 / 576 / 800 workgroups on 256 CUs: 0.69 / 0.68 / 0.71 of peak against 0.81 / 0.76 / 0.76 with 64 threads); the large
+    // launches, sized in whole workgroups per CU, keep 256 threads (0.85 against 0.79)
+    // (exact batches large enough for the launch rule below to cut them -- from 256 such queries on -- are not "mid")
+    const uint64_t all_waves = (uint64_t)b->n_seqs * ceil_div(b->wv, 64 * kVec);
+    bool mid = and_block_env == 256 && all_waves >= 1024 && all_waves < 4096;
+    if (mid) {
+        const uint64_t t256 = ceil_div(b->wv, 256 * kVec), wq = ceil_div(b->wv, 64 * kVec);
+        const uint64_t blocks256 = ceil_div(b->n_seqs, 8) * 8 * t256, kb256 = round_up(ceil_div(1600 * t256, wq), 256);
+        // ... nor are batches that already are a whole number of 4-wavefront workgroups per CU (256 queries on a 62.5 k-sample
+        // shard: 512 workgroups, 0.80-0.82 either way)
+        if (blocks256 % 256 == 0 || (b->exact && blocks256 >= 2 * kb256)) mid = false;
+    }
+    const int and_block = mid ? 64 : b->exact ? and_block_env : std::min(and_block_env, 256);
     static const int and_unroll = env_int("BIGSI_HIP_AND_UNROLL", 8);
     const uint32_t tiles = (uint32_t)ceil_div(b->wv, (uint64_t)and_block * kVec);
     // planes needed for the largest possible count = max k-mers of any sequence in the batch
