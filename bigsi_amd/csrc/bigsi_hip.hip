@@ -1306,12 +1306,27 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
         static const int and_nt = env_int("BIGSI_HIP_AND_NT", 1);     // 0: plain loads (A/B against non-temporal)
         for (uint32_t q0 = 0; q0 < b->n_seqs; q0 += chunk_q, n_launches++) {
             const uint32_t q1 = std::min<uint64_t>((uint64_t)q0 + chunk_q, b->n_seqs);
-            const unsigned grid = (unsigned)(ceil_div(q1 - q0, 8) * 8 * blocks_per_q);
+            unsigned grid = (unsigned)(ceil_div(q1 - q0, 8) * 8 * blocks_per_q), l_block = (unsigned)and_block;
+            uint32_t l_tiles = tiles, l_slices = slices;
+            if (chunk_q < b->n_seqs && q1 - q0 < chunk_q && and_block == 256) {
+                // the last launch of a batch that is not a multiple of the launch size is a batch of its own kind: with a few
+                // thousand wavefronts one-wavefront workgroups (see `mid` above), with fewer the sliced launch of a small batch
+                const uint64_t waves_r = (uint64_t)(q1 - q0) * ceil_div(b->wv, 64 * kVec);
+                if (waves_r < 1024) {
+                    l_slices = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({64, ceil_div(2048, std::max<uint64_t>(waves_r, 1)), std::max<uint64_t>(b->max_pos / 16, 1)}));
+                    if (l_slices > 1) HIP_TRY(hipMemsetAsync(out + (uint64_t)q0 * b->wv_pad, 0xFF, (size_t)(q1 - q0) * b->wv_pad * 8, ix->stream));
+                    grid = (unsigned)(ceil_div(q1 - q0, 8) * 8 * (uint64_t)tiles * l_slices);
+                } else if (grid % 256 != 0) {
+                    l_block = 64;
+                    l_tiles = (uint32_t)ceil_div(b->wv, 64 * kVec);
+                    grid = (unsigned)(ceil_div(q1 - q0, 8) * 8 * (uint64_t)l_tiles);
+                }
+            }
 #define COMMA ,
 #define BIGSI_LAUNCH_EXACT(U)                                                                                                  \
-    hipLaunchKernelGGL((k_and_exact<U>), dim3(grid), dim3(and_block), 0, ix->stream, ix->d_index, ix->stride_words, (uint32_t)b->wv, \
+    hipLaunchKernelGGL((k_and_exact<U>), dim3(grid), dim3(l_block), 0, ix->stream, ix->d_index, ix->stride_words, (uint32_t)b->wv, \
                        ix->n_cols, k2_rows, b->d_pos_off.as<uint64_t>(), b->num_unique.as<uint32_t>(), ix->h, q0,    \
-                       q1, tiles, out, b->wv_pad, slices, (flags & BIGSI_RUN_EARLY_EXIT) ? 1u : 0u)
+                       q1, l_tiles, out, b->wv_pad, l_slices, (flags & BIGSI_RUN_EARLY_EXIT) ? 1u : 0u)
             if (and_unroll == 4) BIGSI_LAUNCH_EXACT(4);
             else if (and_unroll == 16) BIGSI_LAUNCH_EXACT(16);
             else if (!and_nt) BIGSI_LAUNCH_EXACT(8 COMMA false);

@@ -1006,6 +1006,47 @@ def test_fuzz_random_shapes_vs_oracle(hip, seed):
     st.delete_all()
 
 
+@pytest.mark.parametrize("n_queries, kind", [(4000, "sliced tail"), (4784, "one-wavefront tail"), (3584, "no tail")])
+def test_exact_batches_beyond_one_launch_and_their_last_launch(hip, n_queries, kind):
+    """A large exact batch goes out as several co-resident launches; the last one, when the batch is not a multiple of the
+    launch size, is launched like a batch of its own size (sliced with atomics below ~1000 wavefronts, one-wavefront
+    workgroups otherwise).  8192 columns = one wavefront per query: 1792 queries per launch.  Sampled queries of every
+    launch, and all of the last one's first and final queries, against the oracle."""
+    from bigsi_amd.storage import get_storage
+    from oracle.ref_model import SynthOracle
+    m, n_cols, h, k, seed = 100003, 8192, 3, 31, 77
+    st = get_storage(cfg(k, m, h, max_cols=n_cols))
+    st.delete_all()
+    for key, v in (("number_of_rows", m), ("number_of_cols", n_cols), ("ksi:bloomfilter_size", m), ("ksi:num_hashes", h)):
+        st.set_integer(key, v)
+    st.fill_synthetic(seed, 0, 1)
+    orc = SynthOracle(seed, 0, m, n_cols, h, k, 1)
+    rng = np.random.default_rng(n_queries)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    seqs = [lut[r].tobytes().decode("ascii") for r in rng.integers(0, 4, size=(n_queries, 100), dtype=np.uint8)]
+    check = sorted(set([0, 1, 1791, 1792, 3583, n_queries - 1, n_queries - 2] + list(range(3584, min(3584 + 12, n_queries))) +
+                       rng.integers(0, n_queries, 16).tolist()))
+    check = [i for i in check if i < n_queries]
+    for j, i in enumerate(check[:6]):                      # plant: some checked queries are found in a sample
+        st.insert_kmers(100 + j, [seqs[i]], k)
+        orc.insert_kmers(100 + j, seqs[i])
+    batch = st.new_batch(seqs, k)
+    batch.run(1.0)
+    _, nu, _ = batch.unique()
+    off, col, cnt = batch.hits()
+    found = 0
+    for i in check:
+        u, want_cnt = orc.counts(seqs[i])
+        want = np.flatnonzero(want_cnt >= u)
+        lo, hi = int(off[i]), int(off[i + 1])
+        assert nu[i] == u and np.array_equal(col[lo:hi], want), (kind, i)
+        assert np.array_equal(cnt[lo:hi], np.full(hi - lo, u, np.uint32)), (kind, i)
+        found += hi - lo
+    assert found >= 6
+    batch.close()
+    st.delete_all()
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("BIGSI_API_FUZZ_SEEDS", "16"))))
 def test_fuzz_api_vs_oracle_model(hip, seed):
     """The whole API against the oracle's restatement of BIGSI.search (pinned to the reference by test_oracle_golden.py):
