@@ -1006,6 +1006,43 @@ def test_fuzz_random_shapes_vs_oracle(hip, seed):
     st.delete_all()
 
 
+@pytest.mark.parametrize("qlen", [200, 1100])
+def test_batches_of_a_few_thousand_wavefronts(hip, qlen):
+    """300 queries x 5 wavefronts (33 000 columns): one unsliced launch that is not a whole number of 4-wavefront workgroups
+    per CU, so the row-AND kernels run with one-wavefront workgroups (qlen 1100: 12 counter planes and the pipelined counting
+    loop as well).  Exact and thresholded, sampled queries against the oracle."""
+    from bigsi_amd.storage import get_storage
+    from oracle.ref_model import SynthOracle
+    m, n_cols, h, k, seed, nq = 65537, 33000, 3, 31, 91, 300
+    st = get_storage(cfg(k, m, h, max_cols=n_cols))
+    st.delete_all()
+    for key, v in (("number_of_rows", m), ("number_of_cols", n_cols), ("ksi:bloomfilter_size", m), ("ksi:num_hashes", h)):
+        st.set_integer(key, v)
+    st.fill_synthetic(seed, 0, 1)
+    orc = SynthOracle(seed, 0, m, n_cols, h, k, 1)
+    rng = np.random.default_rng(qlen)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    seqs = [lut[r].tobytes().decode("ascii") for r in rng.integers(0, 4, size=(nq, qlen), dtype=np.uint8)]
+    check = sorted(set([0, 1, 7, 8, nq - 1] + rng.integers(0, nq, 8).tolist()))
+    for j, i in enumerate(check[:4]):
+        st.insert_kmers(64 * j + 3, [seqs[i]], k)
+        orc.insert_kmers(64 * j + 3, seqs[i])
+    batch = st.new_batch(seqs, k)
+    for thr, sparse in ((1.0, False), (0.3, True), (0.3, False)):
+        batch.run(thr, sparse_counts=sparse)
+        _, nu, mk = batch.unique()
+        off, col, cnt = batch.hits()
+        for i in check:
+            u, want_cnt = orc.counts(seqs[i])
+            want = np.flatnonzero(want_cnt >= (u if thr == 1.0 else mk[i]))
+            lo, hi = int(off[i]), int(off[i + 1])
+            assert nu[i] == u and np.array_equal(col[lo:hi], want), (qlen, thr, i)
+            assert np.array_equal(cnt[lo:hi], want_cnt[want].astype(np.uint32)), (qlen, thr, i)
+        assert int(off[nq]) >= 4
+    batch.close()
+    st.delete_all()
+
+
 @pytest.mark.parametrize("n_queries, kind", [(4000, "sliced tail"), (4784, "one-wavefront tail"), (3584, "no tail")])
 def test_exact_batches_beyond_one_launch_and_their_last_launch(hip, n_queries, kind):
     """A large exact batch goes out as several co-resident launches; the last one, when the batch is not a multiple of the
