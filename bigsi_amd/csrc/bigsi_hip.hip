@@ -1804,6 +1804,12 @@ extern "C" int bigsi_hip_batch_presence_hits(bigsi_hip_batch *b, const uint64_t 
     if (n_hits && !colours) return fail(BIGSI_ERR_INVALID, "colours is NULL");
     if (n_hits > 0xFFFFFFF0ull) return fail(BIGSI_ERR_INVALID, "too many hits for one call");
     TRY(host_counts(b));
+    // K5 runs on one of the library's read streams, not on the index stream: it depends on this batch's results only (need_run
+    // has waited for them; everything that changes the index is synchronous), and behind the index stream it -- and the caller,
+    // who waits for the strings -- would queue up behind the row-AND kernel of the NEXT batch (a scored search two batches
+    // deep, bench workload c5: the step was the kernel + 17 %)
+    hipStream_t ps = ix->stream;
+    TRY(read_stream(ix, &ps));
     // host side: string offsets, per-sequence colour order, word pairs
     std::vector<uint32_t> hit_seq(n_hits), hit_q(n_hits), perm(n_hits), order;      // hit_seq: k-mers of the hit's sequence (its string length); hit_q: which sequence
     std::vector<uint64_t> hit_pos0(n_hits);
@@ -1876,15 +1882,15 @@ extern "C" int bigsi_hip_batch_presence_hits(bigsi_hip_batch *b, const uint64_t 
     uint32_t *d_marks = b->pres_desc.as<uint32_t>();
     uint2 *d_listed = reinterpret_cast<uint2 *>(b->pres_desc.as<uint8_t>() + round_up(max_pieces * 4, 256));
     uint32_t *d_listed_n = reinterpret_cast<uint32_t *>(b->pres_desc.as<uint8_t>() + round_up(max_pieces * 4, 256) + max_pieces * 8);
-    HIP_TRY(hipMemsetAsync(d_listed_n, 0, 4, ix->stream));
-    HIP_TRY(hipMemcpyAsync(b->pres_in.p, stage.data(), in_bytes, hipMemcpyHostToDevice, ix->stream));
+    HIP_TRY(hipMemsetAsync(d_listed_n, 0, 4, ps));
+    HIP_TRY(hipMemcpyAsync(b->pres_in.p, stage.data(), in_bytes, hipMemcpyHostToDevice, ps));
     const uint8_t *din = b->pres_in.as<uint8_t>();
     EventPair ep{};
-    TRY(ev_begin(ix, &ep));
+    TRY(ev_begin(ix, &ep, ps));
     const dim3 grid_a((unsigned)ceil_div(std::max<uint32_t>(max_pairs, 1), kBlock), (unsigned)ceil_div(std::max<uint32_t>(max_u, 1), 16), nq);
     static const int k5_waves = env_int("BIGSI_HIP_K5_WAVES", 2);
 #define BIGSI_PRESENCE_ARGS                                                                                                        \
-    grid_a, dim3(kBlock), 0, ix->stream, ix->d_index, ix->stride_words, b->rows.as<uint64_t>(), b->d_pos_off.as<uint64_t>(),            \
+    grid_a, dim3(kBlock), 0, ps, ix->d_index, ix->stride_words, b->rows.as<uint64_t>(), b->d_pos_off.as<uint64_t>(),            \
         b->num_unique.as<uint32_t>(), ix->h, (const uint64_t *)(din + o_pair_off), (const PresencePair *)(din + o_pairs),              \
         b->pres_bits.as<uint16_t>(), n_chunks
 #define COMMA ,
@@ -1908,24 +1914,24 @@ extern "C" int bigsi_hip_batch_presence_hits(bigsi_hip_batch *b, const uint64_t 
         const uint64_t groups = ceil_div(n_hits, kPresenceHits * kPresenceRounds), blocks = ceil_div(groups * pieces, kBlock);
         if (blocks > 0x7FFFFFFFull || groups > 0x7FFFFFFFull)
             return fail(BIGSI_ERR_INVALID, "presence request too large for one launch");
-        hipLaunchKernelGGL(k_presence_pieces, dim3(nq), dim3(kBlock), 0, ix->stream, b->pos_unique.as<uint32_t>(), b->d_pos_off.as<uint64_t>(),
+        hipLaunchKernelGGL(k_presence_pieces, dim3(nq), dim3(kBlock), 0, ps, b->pos_unique.as<uint32_t>(), b->d_pos_off.as<uint64_t>(),
                            b->num_kmers.as<uint32_t>(), d_marks, d_listed_n, d_listed);
 #define BIGSI_EXPAND_ARGS                                                                                                          \
-    dim3((unsigned)blocks), dim3(kBlock), 0, ix->stream, b->pres_bits.as<uint16_t>(), n_chunks, n_hits, pieces,                          \
+    dim3((unsigned)blocks), dim3(kBlock), 0, ps, b->pres_bits.as<uint16_t>(), n_chunks, n_hits, pieces,                          \
         (const uint32_t *)(din + o_seq), (const uint64_t *)(din + o_pos0), (const uint64_t *)(din + o_str), b->pres_out.as<uint8_t>(),    \
         (const uint32_t *)(din + o_q), d_marks
         if (pieces >= 64) hipLaunchKernelGGL(k_presence_expand<true>, BIGSI_EXPAND_ARGS);
         else hipLaunchKernelGGL(k_presence_expand<false>, BIGSI_EXPAND_ARGS);
 #undef BIGSI_EXPAND_ARGS
-        hipLaunchKernelGGL(k_presence_expand_listed, dim3(1024), dim3(kBlock), 0, ix->stream, b->pres_bits.as<uint16_t>(), n_chunks, d_listed_n, d_listed,
+        hipLaunchKernelGGL(k_presence_expand_listed, dim3(1024), dim3(kBlock), 0, ps, b->pres_bits.as<uint16_t>(), n_chunks, d_listed_n, d_listed,
                            (const uint64_t *)(din + o_hoff), b->d_pos_off.as<uint64_t>(), b->num_kmers.as<uint32_t>(), b->pos_unique.as<uint32_t>(),
                            (const uint64_t *)(din + o_str), b->pres_out.as<uint8_t>());
     }
     HIP_TRY(hipGetLastError());
-    TRY(ev_end(ix, &ep, ix->ev_pr));
+    TRY(ev_end(ix, &ep, ix->ev_pr, ps));
     if (ep.a) ix->presence_bytes += alg;
-    HIP_TRY(hipMemcpyAsync(out, b->pres_out.p, str, hipMemcpyDeviceToHost, ix->stream));
-    HIP_TRY(hipStreamSynchronize(ix->stream));       // `stage` and the caller's buffers
+    HIP_TRY(hipMemcpyAsync(out, b->pres_out.p, str, hipMemcpyDeviceToHost, ps));
+    HIP_TRY(hipStreamSynchronize(ps));       // `stage` and the caller's buffers
     return BIGSI_OK;
 }
 
