@@ -60,7 +60,7 @@ rows = f"""| workload (`profiles/…`) | lookups/s | ms/step | dominant kernel, 
 | C2 threshold 0.4 (`r02_c2_t04`) | {M('r02_c2_t04')} (1197–1217 M unprofiled) | {ms('r02_c2_t04',4)} (0.0255–0.0259) | `k_reads_fused<3,false>` {kus('r02_c2_t04'):.1f} µs, three overlapping | {stb('r02_c2_t04')} TB/s per step | {sfr('r02_c2_t04')} |
 | C2 index, 32 768 reads per step, one launch (`r02_c2_32k_reads`) | {M('r02_c2_32k_reads')} | {ms('r02_c2_32k_reads')} | `k_reads_fused<3,true>` {kus('r02_c2_32k_reads')/1e3:.2f} ms, three overlapping | {stb('r02_c2_32k_reads')} TB/s per step | {sfr('r02_c2_32k_reads')} |
 | C4 per-GPU shard 25 M × 62.5 k, h=3 (195 GB; `r02_c4_shard`) | {M('r02_c4_shard')} | {ms('r02_c4_shard')} | `k_and_exact` {kus('r02_c4_shard')/1e3:.3f} ms | {tb('r02_c4_shard')} TB/s | {fr('r02_c4_shard')} |
-| C5 = that shard at threshold 0.4 **with score=True in the step**: hit lists to the host + K5 presence strings of 259 planted hits per batch, one batch behind the launches (`r02_c5_shard`) | {M('r02_c5_shard')} | {ms('r02_c5_shard')} | `k_and_count<10,3>` {kus('r02_c5_shard')/1e3:.3f} ms (+ K5: bits {pk(c5,'presence_bits')['avg_ns']/1e3:.0f}, marks {pk(c5,'presence_pieces')['avg_ns']/1e3:.0f}, strings {pk(c5,'presence_expand<')['avg_ns']/1e3:.0f}, listed pieces {pk(c5,'expand_listed')['avg_ns']/1e3:.0f} µs) | {tb('r02_c5_shard')} TB/s | {fr('r02_c5_shard')} |
+| C5 = that shard at threshold 0.4 **with score=True in the step**: hit lists to the host + K5 presence strings of 259 planted hits per batch, one batch behind the launches, K5 on a read stream beside the next batch's row-AND kernel (`r02_c5_shard`) | {M('r02_c5_shard')} | {ms('r02_c5_shard')} | `k_and_count<10,3>` {kus('r02_c5_shard')/1e3:.3f} ms (+ K5: bits {pk(c5,'presence_bits')['avg_ns']/1e3:.0f}, marks {pk(c5,'presence_pieces')['avg_ns']/1e3:.0f}, strings {pk(c5,'presence_expand<')['avg_ns']/1e3:.0f}, listed pieces {pk(c5,'expand_listed')['avg_ns']/1e3:.0f} µs while that kernel runs; alone 26 / 5 / 9 / 4 µs) | {tb('r02_c5_shard')} TB/s | {fr('r02_c5_shard')} |
 | north-star per-GPU shard 10 M × 62.5 k, h=3 exact / 0.4 / h=4 (`r02_northstar_shard*`) | {M('r02_northstar_shard')} / {M('r02_northstar_shard_t04')} / {M('r02_northstar_shard_h4')} | {ms('r02_northstar_shard')} / {ms('r02_northstar_shard_t04')} / {ms('r02_northstar_shard_h4')} | {kus('r02_northstar_shard')/1e3:.3f} / {kus('r02_northstar_shard_t04')/1e3:.3f} / {kus('r02_northstar_shard_h4')/1e3:.3f} ms | {tb('r02_northstar_shard')} / {tb('r02_northstar_shard_t04')} / {tb('r02_northstar_shard_h4')} TB/s | {fr('r02_northstar_shard')} / {fr('r02_northstar_shard_t04')} / {fr('r02_northstar_shard_h4')} |
 | one GPU's share of the default 8-GPU run: 10 M × 12.5 k, 8192 × 1 kbp (`r02_c3_strong8_shard`, with the 1-rank RCCL exchange `…_rccl1`) | {M('r02_c3_strong8_shard')} / {M('r02_c3_strong8_rccl1')} (against its shard) | {ms('r02_c3_strong8_shard',2)} / {ms('r02_c3_strong8_rccl1',2)} | `k_and_exact` {kus('r02_c3_strong8_shard')/1e3:.2f} / {kus('r02_c3_strong8_rccl1')/1e3:.2f} ms × 8; K1 {g('r02_c3_strong8_shard')['k1_ms']:.2f} ms | {tb('r02_c3_strong8_shard')} / {tb('r02_c3_strong8_rccl1')} TB/s | {fr('r02_c3_strong8_shard')} / {fr('r02_c3_strong8_rccl1')} |
 | long queries on the C3 index, exact / 0.4 (`r02_long_queries`): 256 × 2 kbp (P=12) | {lq[('c3_q2000bp',1.0)]['lookups_per_s']/1e6:.1f} / {lq[('c3_q2000bp',0.4)]['lookups_per_s']/1e6:.1f} M | {lq[('c3_q2000bp',1.0)]['step_ms']:.2f} / {lq[('c3_q2000bp',0.4)]['step_ms']:.2f} | | {lq[('c3_q2000bp',1.0)]['GBps']/1e3:.2f} / {lq[('c3_q2000bp',0.4)]['GBps']/1e3:.2f} TB/s | {lq[('c3_q2000bp',1.0)]['frac']:.3f} / {lq[('c3_q2000bp',0.4)]['frac']:.3f} |
