@@ -1360,7 +1360,7 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
         for (uint32_t q0 = 0; q0 < b->n_seqs; q0 += chunk_q, n_launches++)
             launch_count(b, P, cl, q0, (uint32_t)std::min<uint64_t>((uint64_t)q0 + chunk_q, b->n_seqs));
         if (slices > 1) {        // partial counts were summed by the slices: the hit mask from the totals
-            const uint64_t items = (uint64_t)b->n_seqs * b->wv;
+            const uint64_t items = (uint64_t)b->n_seqs * b->wv * 8;      // one thread per mask byte
             if (b->count_bytes == 2)
                 hipLaunchKernelGGL((k_mask_from_counts<uint16_t>), dim3((unsigned)ceil_div(items, kBlock)), dim3(kBlock), 0, ix->stream, (const uint16_t *)out,
                                    cstride, b->min_kmers.as<uint32_t>(), ix->n_cols, hb, b->wv_pad, (uint32_t)b->wv, b->n_seqs);

@@ -1419,23 +1419,29 @@ __global__ __launch_bounds__(kBlock) void k_reads_fused(
 }
 
 // A row-sliced counting run (small batches) cannot threshold inside k_and_count -- every slice holds partial counts -- so
-// the hit mask (count >= min_kmers, graph/bigsi.py:241-242; row bit order) is cut from the summed counters afterwards: one
-// thread per 64-column word.  The mask is what K4 compacts and what column shards exchange.
+// the hit mask (count >= min_kmers, graph/bigsi.py:241-242; row byte format: column c at bit 7 - (c & 7) of byte c >> 3)
+// is cut from the summed counters afterwards: one thread per mask byte = 8 consecutive counters, so that a wavefront reads
+// its counters as one contiguous run (a thread per 64-column word: 11 us for one query's 100 k counters).  The mask is
+// what K4 compacts and what column shards exchange.
 template <typename CountT>
 __global__ __launch_bounds__(kBlock) void k_mask_from_counts(
     const CountT *__restrict__ counts, uint64_t cstride /* counters per query */, const uint32_t *__restrict__ min_kmers,
     uint64_t n_cols, uint64_t *__restrict__ mask, uint64_t bm_stride, uint32_t wv, uint32_t n_seqs)
 {
-    const uint64_t item = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (item >= (uint64_t)n_seqs * wv) return;
-    const uint32_t q = (uint32_t)(item / wv), w = (uint32_t)(item % wv);
+    const uint64_t item = (uint64_t)blockIdx.x * kBlock + threadIdx.x, per_q = (uint64_t)wv * 8;
+    if (item >= (uint64_t)n_seqs * per_q) return;
+    const uint32_t q = (uint32_t)(item / per_q);
+    const uint64_t byte = item % per_q, c0 = byte * 8;
     const uint32_t thr = min_kmers[q];
-    const CountT *c = counts + (uint64_t)q * cstride + (uint64_t)w * 64;
-    uint64_t bits = 0;
-#pragma unroll 8
-    for (uint32_t j = 0; j < 64; j++)
-        if ((uint64_t)w * 64 + j < n_cols && (uint32_t)c[j] >= thr) bits |= 1ull << bit_of_col(j);
-    mask[(uint64_t)q * bm_stride + w] = bits;
+    const CountT *c = counts + (uint64_t)q * cstride + c0;
+    CountT v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = c[j];                      // 16 (32) contiguous, aligned bytes: cstride is a multiple of 64
+    uint32_t bits = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+        if (c0 + j < n_cols && (uint32_t)v[j] >= thr) bits |= 0x80u >> j;
+    reinterpret_cast<uint8_t *>(mask + (uint64_t)q * bm_stride)[byte] = (uint8_t)bits;
 }
 
 // counting: a hit is a column with count >= min_kmers[q] (graph/bigsi.py:241-242); column < shard_cols only.
