@@ -20,8 +20,9 @@ exchange included -- every rank looks every k-mer up in its shard, so the shard-
     c2            BASELINE configs[1]: 1M x 10k, h=3, 1000 x 61-mers, a different batch every step (32 staged batches cycle)
     c4            BASELINE configs[3]: 25M x 500k, h=3 (1.56 TB: needs 8 GPUs), 256 x 1 kbp queries per step
     c5            BASELINE configs[4]: c4 at threshold 0.4 with score=True: every step also brings the hit lists to the host and
-                  extracts the presence strings of all hits (K5), one batch behind the launches -- 16 queries x 16 planted
-                  samples per shard and batch
+                  runs the whole scored path for them -- K5 + K6 on the device (presence bits, run tallies, the rounded score chain),
+                  closed-form score fields, presence strings and result dicts on the host -- one batch behind the launches;
+                  16 queries x 16 planted samples per shard and batch
     northstar     BASELINE north_star: 10M x 500k, h=3 (625 GB: needs >= 4 GPUs)
 `--shard-of P` runs, on fewer GPUs, the first N of the P column shards of the workload (e.g. `--workload c4 --shard-of 8
 --gpus 1` is what one GPU of the 8-GPU C4 run does; value is then the rate against that part of the index and says so).
@@ -258,6 +259,8 @@ def main():
             st.insert_kmers(c, [all_seqs[bi][qi][:plant_len]], args.k)
     if args.one_device and world > 1 and args.backend == "nccl":
         raise SystemExit("--one-device needs --backend gloo: RCCL refuses two ranks on one device")
+    if w["score"] and nb < 2:
+        raise SystemExit("score=True workloads need at least two staged batches (--distinct-batches)")
     sh = ShardedSearch(st, shard_cols, device=dev, force_gather=args.force_dist, slots=max(2, nb))
     # the steps cycle through `nb` staged batches (a serving loop's workspaces): with >= 2 the exchange of one batch overlaps
     # the row-AND kernel of the next, and with many (c2) the rows of a step are not what the last steps left in the caches
@@ -274,32 +277,80 @@ def main():
     step_no = [0]
 
     def own_hits(batch):
-        """this rank's share of the batch's (global) hit lists: offsets + local colours, for K5 on the owning GPU"""
+        """this rank's share of the batch's (global) hit lists: offsets, local colours and counts, for K5 / K6 on the owning GPU"""
         off, colours, counts = sh.fetch(batch)
         owned = (colours.astype(np.int64) // shard_cols) == rank
         csum = np.concatenate([[0], np.cumsum(owned)])
         off_own = csum[off.astype(np.int64)].astype(np.uint64)
-        return off_own, (colours[owned].astype(np.int64) - rank * shard_cols).astype(np.uint32)
+        return off_own, (colours[owned].astype(np.int64) - rank * shard_cols).astype(np.uint32), counts[owned]
 
-    pending = [None]
+    # score=True (BASELINE configs[4]: "per-kmer score accumulation (bigsi/scoring)"): every step runs the WHOLE of
+    # BIGSI.search(score=True) for the hits whose columns this rank owns, three batches deep:
+    #   step k:  launch batch k  |  hit lists of batch k-1 to the host, K5 + K6 for them queued on the index stream BEHIND batch k
+    #            (bigsi_hip_batch_score_hits_begin, BIGSI_SCORE_ORDERED)  |  results of batch k-2: K6's records and presence bits from
+    #            pinned staging, closed-form score fields for all hits at once (scoring.score_columns), presence strings and the
+    #            reference's result dicts (graph/bigsi.py:105-114 + 232-239) in its order (count descending, colour ascending).
+    # The device part is K5 (presence bits of the hits) + K6 (remove_short_ones / tabulate_score / calculate_score with Python's
+    # round(), percent_kmers_found); queued in stream order it runs alone, a tenth of what it takes beside a row-AND kernel.
+    fetched, begun = [None], [None]
+    scored = {"results": None, "hits": 0, "batches": 0, "begin_s": 0.0, "finish_s": 0.0, "end_s": 0.0}
+    names = ["s%d" % (rank * shard_cols + c) for c in range(my_cols)] if w["score"] else None
+    from bigsi_amd.scoring import SCORE_KEYS
+    result_keys = ("percent_kmers_found", "num_kmers", "num_kmers_found", "sample_name") + SCORE_KEYS + ("kmer-presence",)
+
+    def score_begin():
+        """hit lists of the batch launched one step ago -> host; its K5 + K6 queued behind the batch just launched"""
+        if fetched[0] is None:
+            return
+        b_, fetched[0] = fetched[0], None
+        t_a = time.perf_counter()
+        off_own, col_own, cnt_own = own_hits(b_)
+        nk_, nu_, _ = b_.unique()
+        b_.score_hits_begin(off_own, col_own, None if exact else cnt_own, nk_, ordered=True)
+        begun[0] = (b_, off_own, col_own, cnt_own, nk_, nu_)
+        scored["begin_s"] += time.perf_counter() - t_a
+
+    def score_finish(job):
+        """the scored result dicts of the batch whose K5 + K6 were queued one step ago"""
+        if job is None:
+            return
+        from bigsi_amd.graph.bigsi import scored_rows
+        b_, off_own, col_own, cnt_own, nk_, nu_ = job
+        t_a = time.perf_counter()
+        rec, pbits, boff = b_.score_hits_end()
+        scored["end_s"] += time.perf_counter() - t_a
+        o64 = off_own.astype(np.int64)
+        rows = scored_rows(rec, pbits, boff, np.repeat(nk_[: w["batch"]].astype(np.int64), np.diff(o64)), total_cols)
+        results = [[] for _ in range(w["batch"])]
+        for i in np.flatnonzero(np.diff(o64)).tolist():
+            lo, hi = int(o64[i]), int(o64[i + 1])
+            c_, f_ = col_own[lo:hi], cnt_own[lo:hi]
+            keep = np.flatnonzero(c_ < my_cols)
+            order = keep if exact else keep[np.argsort(-f_[keep].astype(np.int64), kind="stable")]
+            u = int(nu_[i])
+            results[i] = [dict(zip(result_keys, (rows[lo + t][0], u, u if exact else int(f_[t]), names[int(c_[t])]) + rows[lo + t][1] + (rows[lo + t][2],)))
+                          for t in order.tolist()]
+        scored["results"], scored["hits"], scored["batches"] = results, scored["hits"] + len(rows), scored["batches"] + 1
+        scored["finish_s"] += time.perf_counter() - t_a
 
     def collect():
-        """score=True: what BIGSI.score needs from the device for the batch launched one step ago -- its hit lists come back to
-        the host and the presence strings of every hit are extracted (K5) on the rank that owns the hit's column."""
-        if pending[0] is not None:
-            off_own, col_own = own_hits(pending[0])
-            pending[0].presence_hits(off_own, col_own, pending[0].unique()[0])
-            pending[0] = None
+        """drain the scoring pipeline (end of the timed region)"""
+        job, begun[0] = begun[0], None
+        score_finish(job)
+        score_begin()
+        job, begun[0] = begun[0], None
+        score_finish(job)
 
     def step():
-        """One pass of the path over the next staged batch.  score=True workloads (configs[4]) are two batches deep: the next
-        batch is launched first, then the previous one is collected, so the host's share overlaps the row-AND kernel."""
+        """One pass of the path over the next staged batch (score=True: plus the scoring stages of the two batches before it)."""
         batch = batches[step_no[0] % len(batches)]
         step_no[0] += 1
         sh.step(batches, thr)
         if w["score"]:
-            collect()
-            pending[0] = batch
+            job, begun[0] = begun[0], None      # queued one step ago, behind the previous launch: done (or nearly) by now
+            score_begin()                       # the batch launched one step ago: its K5 + K6 go behind the launch just made
+            fetched[0] = batch
+            score_finish(job)                   # (with two staged batches this is the object just run again: its results are staged on the host)
 
     warm = _lib.Stats()
     for i in range(args.warmup):
@@ -364,22 +415,34 @@ def main():
         dist.all_reduce(t)
         per_rank_gbs = [float(x) for x in t.tolist()]
 
-    # score=True (configs[4]): the K5 leg of a step once more, timed on its own (events + wall clock) and checked
+    # score=True (configs[4]): the scoring leg of a step once more on the first staged batch, its device part timed on its own
+    # (events), and the assembled results checked against the oracle's restatement of graph/bigsi.py:211-239 + scoring/score.py
     presence = None
     if w["score"]:
-        off_own, col_own = own_hits(batch)
+        in_region = dict(scored)
+        off_own, col_own, cnt_own = own_hits(batch)
         check(_lib.lib().bigsi_hip_set_profiling(st.handle, 1))
+        batch.score_hits(off_own, col_own, None if exact else cnt_own, nk)       # (the first synchronous call creates the score stream)
         check(_lib.lib().bigsi_hip_stats(st.handle, _lib.C.byref(_lib.Stats()), 1))
         t1 = time.perf_counter()
-        blob, starts, lens = batch.presence_hits(off_own, col_own, nk)
+        rec, pbits, boff = batch.score_hits(off_own, col_own, None if exact else cnt_own, nk)
         call_ms = (time.perf_counter() - t1) * 1e3
         ps = _lib.Stats()
         check(_lib.lib().bigsi_hip_stats(st.handle, _lib.C.byref(ps), 1))
-        for j, qi in enumerate(planted):                          # the planted sample's string shows the planted k-mers
-            t = int(off_own[qi]) + int(np.searchsorted(col_own[int(off_own[qi]):int(off_own[qi + 1])], plant_col(j, rank, my_cols)))
-            assert int((blob[int(starts[t]):int(starts[t] + lens[t])] == ord("1")).sum()) >= plant_len - args.k + 1
-        presence = {"strings": int(col_own.size), "string_bytes": int(lens.sum()), "kernels_ms": ps.presence_ms, "call_ms": call_ms,
-                    "alg_bytes": int(ps.presence_bytes), "GBps": ps.presence_bytes / max(ps.presence_ms, 1e-9) / 1e6}
+        fetched[0] = batch
+        collect()
+        presence = {"hits_per_batch": int(col_own.size), "presence_bits_bytes": int(boff[-1]), "score_record_bytes": int(rec.nbytes),
+                    "kernels_ms": ps.presence_ms, "score_hits_call_ms": call_ms,
+                    "alg_bytes": int(ps.presence_bytes), "GBps": ps.presence_bytes / max(ps.presence_ms, 1e-9) / 1e6,
+                    "in_timed_region": {"batches_scored": in_region["batches"], "hits_scored": in_region["hits"],
+                                        "begin_ms_per_batch": in_region["begin_s"] / max(in_region["batches"], 1) * 1e3,
+                                        "finish_ms_per_batch": in_region["finish_s"] / max(in_region["batches"], 1) * 1e3,
+                                        "of_which_waiting_for_the_device_ms": in_region["end_s"] / max(in_region["batches"], 1) * 1e3,
+                                        "host_us_per_hit": (in_region["begin_s"] + in_region["finish_s"]) / max(in_region["hits"], 1) * 1e6},
+                    "what": "every step also runs the whole of BIGSI.search(score=True), three batches deep: hit lists of the previous batch "
+                            "to the host and K5 + K6 for them queued behind the batch just launched (presence bits, remove_short_ones / "
+                            "tabulate_score / calculate_score with Python's round(), percent_kmers_found); for the batch before that: "
+                            "closed-form score fields, presence strings and the reference's result dicts in its order"}
 
     # PCIe-inclusive rate of the host-buffer boundary (never `value`): sequences in host memory -> batch_reload (H2D) ->
     # run -> fetch_hits (D2H), a few repetitions outside the timed region
@@ -442,6 +505,34 @@ def main():
             assert u == nu[qi] and np.array_equal(colours[lo:hi][sel], want), "oracle mismatch on query %d" % qi
             assert np.array_equal(counts[lo:hi][sel], cnt[want].astype(np.uint32)), "oracle count mismatch on query %d" % qi
         verified = "planted round trip on %d shard(s) + %d queries bit-exact (colours and counts) vs oracle" % (world, len(sample))
+        if w["score"]:
+            # the result dicts of two planted queries of the first staged batch, whole lists, against the oracle's scorer
+            from oracle import coracle
+            from oracle.ref_model import Scorer as OracleScorer
+            osc, n_checked = OracleScorer(total_cols), 0
+            for qi in (0, min(15, w["batch"] - 1)):
+                kmers, uniq, rows_q = orc.per_kmer_rows(seqs[qi])
+                cnt = coracle.unpack_and_sum(rows_q)[:my_cols]
+                u = len(uniq)
+                want_cols = [int(c) for c in np.flatnonzero(cnt >= (u if exact else int(np.ceil(u * thr))))]
+                if not exact:
+                    want_cols.sort(key=lambda c: -int(cnt[c]))
+                qbits = np.unpackbits(rows_q, axis=1)
+                idx = {km: t for t, km in enumerate(uniq)}
+                got = scored["results"][qi]
+                assert [r["sample_name"] for r in got] == ["s%d" % c for c in want_cols], "scored hit list of query %d differs from the oracle" % qi
+                for r, c in zip(got, want_cols):
+                    col = "".join("1" if qbits[idx[km], c] else "0" for km in kmers)
+                    want = {"percent_kmers_found": round(100 * float(cnt[c]) / u, 2), "num_kmers": u, "num_kmers_found": int(cnt[c]), "sample_name": "s%d" % c}
+                    want.update(osc.score(col))
+                    want["kmer-presence"] = col
+                    assert list(r) == list(want)
+                    for key, v in want.items():
+                        ok = abs(r[key] - v) <= 1e-12 * abs(v) + 2.5e-16 if key in ("evalue", "pvalue") else r[key] == v
+                        assert ok, "score field %s of query %d sample %d: %r vs oracle %r" % (key, qi, c, r[key], v)
+                    n_checked += 1
+            assert n_checked >= 16
+            verified += "; %d scored result dicts (all 22 keys, order included) equal to the oracle's restatement of BIGSI.score" % n_checked
 
     line = None
     if rank == 0:
@@ -463,7 +554,7 @@ def main():
                                 " of which this run holds %d of %d column shards (%d samples)" % (world, parts, total_cols)
                                 if args.scaling == "strong" else " = %d samples per GPU, weak scaling" % shard_cols),
                                w["hashes"], w["batch"], w["qlen"], nb, args.k, thr, "exact" if exact else "counts",
-                               ", score=True presence extraction" if w["score"] else ""),
+                               ", score=True: K5 + K6 + host assembly of every hit's scored result dict inside the step" if w["score"] else ""),
                 "workload_key": args.workload, "rows": w["rows"], "cols_per_gpu": shard_cols, "total_cols": total_cols,
                 "index_gb_per_gpu": info.index_bytes / 1e9, "hashes": w["hashes"], "batch": w["batch"], "qlen": w["qlen"],
                 "unique_kmers_per_batch": total_unique, "hits_first_batch": int(off[-1]),

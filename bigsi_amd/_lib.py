@@ -23,6 +23,7 @@ RUN_EARLY_EXIT = 32
 RUN_WEAK_FINGERPRINT = 64
 RUN_NO_WAITING = 128
 BLOOM_RAW = 1
+SCORE_ORDERED = 1
 
 
 class BigsiHipError(RuntimeError):
@@ -104,6 +105,11 @@ SIGNATURES = {
     "bigsi_hip_batch_presence": (_i32, [_P, _u32, _P, _u32, _P]),
     "bigsi_hip_batch_presence_hits": (_i32, [_P, _P, _P, _P, _u64, _P]),
     "bigsi_hip_group_batch_presence_hits": (_i32, [_P, _P, _P, _P, _u64, _P]),
+    "bigsi_hip_batch_score_hits": (_i32, [_P, _P, _P, _P, _P, _u64, _P, _P]),
+    "bigsi_hip_group_batch_score_hits": (_i32, [_P, _P, _P, _P, _P, _u64, _P, _P]),
+    "bigsi_hip_batch_score_hits_begin": (_i32, [_P, _P, _P, _P, _u32, _P]),
+    "bigsi_hip_batch_score_hits_end": (_i32, [_P, _P, _u64, _P]),
+    "bigsi_hip_score_presence": (_i32, [_i32, _P, _P, _P, _P, _P, _u64, _P]),
     "bigsi_hip_batch_set_gather_stream": (_i32, [_P, _P]),
     "bigsi_hip_batch_compact_gathered": (_i32, [_P, _P, _u32, _u64]),
     "bigsi_hip_batch_compact_gathered_masks": (_i32, [_P, _P, _u32, _u64, _u32]),

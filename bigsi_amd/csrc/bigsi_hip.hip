@@ -70,6 +70,23 @@ static int mark_main(bigsi_hip_index *ix)
     return BIGSI_OK;
 }
 
+// K5 / K6 (scored searches) run on a stream of their own with the HIGHEST priority: they are a few small kernels whose result
+// the host waits for while the NEXT batch's row-AND kernel fills the device, and at equal priority their workgroups queue up
+// behind that kernel's (bench workload c5: 0.37 ms of waiting for 0.05 ms of work).  Every call that uses it synchronises it
+// before returning, so nothing is ever pending here.
+static int score_stream(bigsi_hip_index *ix, hipStream_t *out)
+{
+    *out = ix->stream;
+    if (ix->stream != ix->own_stream) return BIGSI_OK;       // the caller's own stream: everything stays on it
+    if (!ix->sc_stream) {
+        int least = 0, greatest = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_TRY(hipStreamCreateWithPriority(&ix->sc_stream, hipStreamNonBlocking, greatest));
+    }
+    *out = ix->sc_stream;
+    return BIGSI_OK;
+}
+
 static int quiesce_reads(bigsi_hip_index *ix)
 {
     if (!ix->rd_pending) return BIGSI_OK;
@@ -161,6 +178,7 @@ extern "C" int bigsi_hip_close(bigsi_hip_index *ix)
     if (ix->pre_stream) e = hipStreamSynchronize(ix->pre_stream);
     for (auto st : ix->rd_stream)
         if (st) { e = hipStreamSynchronize(st); e = hipStreamDestroy(st); }
+    if (ix->sc_stream) { e = hipStreamSynchronize(ix->sc_stream); e = hipStreamDestroy(ix->sc_stream); }
     if (ix->main_ev) e = hipEventDestroy(ix->main_ev);
     recycle_events(ix);
     for (auto &p : ix->ev_free) { e = hipEventDestroy(p.a); e = hipEventDestroy(p.b); }
@@ -845,6 +863,9 @@ extern "C" int bigsi_hip_batch_destroy(bigsi_hip_batch *b)
     b->hits.release();
     b->ghits.release();
     b->gbuf.release();
+    if (b->job.done) { e = hipEventSynchronize(b->job.done); e = hipEventDestroy(b->job.done); (void)e; }
+    if (b->job.h_in) { e = hipHostFree(b->job.h_in); (void)e; }
+    if (b->job.h_out) { e = hipHostFree(b->job.h_out); (void)e; }
     if (b->done) { e = hipEventDestroy(b->done); (void)e; }
     if (b->k1_done) { e = hipEventDestroy(b->k1_done); (void)e; }
     if (b->g_done) { e = hipEventDestroy(b->g_done); (void)e; }
@@ -1161,6 +1182,7 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
     TRY(use_device(ix));
     b->ran = false;
     b->host_counts_valid = false;
+    b->run_serial++;
     b->threshold = threshold;
     b->exact = (threshold == 1.0) && !(flags & BIGSI_RUN_FORCE_COUNTS);
     // result vectors as wide as the index, or as the shard width agreed by a group of column shards (uneven shards then
@@ -1793,31 +1815,51 @@ extern "C" int bigsi_hip_batch_presence(bigsi_hip_batch *b, uint32_t seq, const 
 
 // K5 at scale: the presence strings of all hits of the batch (see k_presence_bits).  The host sorts each sequence's hits by
 // colour and groups them into 128-column word pairs (a few microseconds per thousand hits); the device does the rest.
-extern "C" int bigsi_hip_batch_presence_hits(bigsi_hip_batch *b, const uint64_t *hit_offsets, const uint32_t *colours, uint8_t *out,
-                                             uint64_t out_capacity, uint64_t *string_offsets)
+// K5 / K6 for the hits of a batch, in two halves so that a serving loop can overlap them with other work:
+//   presence_begin  host: string / bit offsets, per-sequence colour order, word pairs -> pinned staging; device (asynchronous):
+//                   upload, k_presence_bits, then either the ASCII strings (k_presence_expand*, K5) or the packed presence bits
+//                   + score records (k_presence_score, K6), download into pinned staging, completion event.
+//   presence_end    waits for that event and copies the staged results into the caller's buffers.
+// The kernels go to the library's score stream (highest priority: the host is waiting for them while the next batch's row-AND
+// kernel fills the device) or, BIGSI_SCORE_ORDERED, to the index stream behind whatever is already queued there: alone on
+// the device they take a tenth of the time they take beside a row-AND kernel, and a loop three batches deep never waits for
+// them (bench workload c5).
+static_assert(sizeof(bigsi_hip_hit_score) == sizeof(bigsi_score::HitScore) && sizeof(bigsi_hip_hit_score) == 64, "score record layout");
+
+static int pinned_reserve(void **p, size_t *cap, size_t bytes)
+{
+    if (bytes <= *cap) return BIGSI_OK;
+    if (*p) { hipError_t e = hipHostFree(*p); (void)e; *p = nullptr; *cap = 0; }
+    const size_t want = std::max<size_t>(bytes + bytes / 4, 4096);
+    HIP_TRY(hipHostMalloc(p, want, hipHostMallocDefault));
+    *cap = want;
+    return BIGSI_OK;
+}
+
+static int presence_begin(bigsi_hip_batch *b, const uint64_t *hit_offsets, const uint32_t *colours, const uint32_t *counts, bool packed,
+                          bool ordered, uint64_t out_capacity, bool check_capacity, uint64_t *string_offsets)
 {
     TRY(need_run(b));
     if (!hit_offsets || !string_offsets) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    PresJob &job = b->job;
+    if (job.pending) return fail(BIGSI_ERR_STATE, "a score / presence request of this batch is still pending (call the matching _end)");
     bigsi_hip_index *ix = b->ix;
     const uint32_t nq = b->n_seqs;
     const uint64_t n_hits = hit_offsets[nq] - hit_offsets[0], h0 = hit_offsets[0];
     if (n_hits && !colours) return fail(BIGSI_ERR_INVALID, "colours is NULL");
     if (n_hits > 0xFFFFFFF0ull) return fail(BIGSI_ERR_INVALID, "too many hits for one call");
     TRY(host_counts(b));
-    // K5 runs on one of the library's read streams, not on the index stream: it depends on this batch's results only (need_run
-    // has waited for them; everything that changes the index is synchronous), and behind the index stream it -- and the caller,
-    // who waits for the strings -- would queue up behind the row-AND kernel of the NEXT batch (a scored search two batches
-    // deep, bench workload c5: the step was the kernel + 17 %)
     hipStream_t ps = ix->stream;
-    TRY(read_stream(ix, &ps));
+    if (!ordered) TRY(score_stream(ix, &ps));
     // host side: string offsets, per-sequence colour order, word pairs
-    std::vector<uint32_t> hit_seq(n_hits), hit_q(n_hits), perm(n_hits), order;      // hit_seq: k-mers of the hit's sequence (its string length); hit_q: which sequence
-    std::vector<uint64_t> hit_pos0(n_hits);
-    std::vector<uint64_t> pair_off(nq + 1, 0);
-    for (uint64_t t = 0; t < n_hits; t++) perm[t] = (uint32_t)t;
+    std::vector<uint32_t> &hit_seq = job.hit_seq, &hit_q = job.hit_q, &perm = job.perm, &order = job.order;      // hit_seq: k-mers of the hit's sequence (its string length); hit_q: which sequence
+    std::vector<uint64_t> &hit_pos0 = job.hit_pos0;
     std::vector<PresencePair> pairs;
+    hit_seq.resize(n_hits); hit_q.resize(n_hits); perm.resize(n_hits); hit_pos0.resize(n_hits);
+    pairs.clear();
+    for (uint64_t t = 0; t < n_hits; t++) perm[t] = (uint32_t)t;
     uint64_t str = 0, alg = 0;
-    uint32_t max_u = 0, max_n = 0, max_pairs = 0;
+    uint32_t max_u = 0, max_n = 0;
     for (uint32_t q = 0; q < nq; q++) {
         if (hit_offsets[q + 1] < hit_offsets[q]) return fail(BIGSI_ERR_INVALID, "hit_offsets must be non-decreasing");
         const uint64_t lo = hit_offsets[q] - h0, hi = hit_offsets[q + 1] - h0;
@@ -1827,71 +1869,103 @@ extern "C" int bigsi_hip_batch_presence_hits(bigsi_hip_batch *b, const uint64_t 
             hit_q[t] = q;
             hit_pos0[t] = b->pos_off[q];
             string_offsets[t] = str;
-            str += round_up(b->h_num_kmers[q], 16);       // every string starts on a 16-byte boundary (16-character stores)
+            // every string starts on a 16-byte boundary (16-character stores); packed: whole 8-byte words
+            str += packed ? round_up(b->h_num_kmers[q], 64) / 8 : round_up(b->h_num_kmers[q], 16);
         }
-        pair_off[q] = pairs.size();
         if (hi == lo || b->h_num_kmers[q] == 0) continue;
-        order.resize(hi - lo);
-        for (uint64_t t = lo; t < hi; t++) order[t - lo] = (uint32_t)t;
-        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return colours[h0 + x] < colours[h0 + y]; });
+        const size_t first_pair = pairs.size();
+        // the hit lists fetch_hits returns are in colour order already: sort only what is not
+        bool sorted = true;
+        for (uint64_t t = lo + 1; t < hi && sorted; t++) sorted = colours[h0 + t - 1] < colours[h0 + t];
+        if (!sorted) {
+            order.resize(hi - lo);
+            for (uint64_t t = lo; t < hi; t++) order[t - lo] = (uint32_t)t;
+            std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return colours[h0 + x] < colours[h0 + y]; });
+        }
         uint64_t words = 0, last_word = ~0ull;
-        for (size_t r = 0; r < order.size(); r++) {
-            const uint32_t c = colours[h0 + order[r]];
-            if (r && c == colours[h0 + order[r - 1]]) return fail(BIGSI_ERR_INVALID, "colour %u listed twice for sequence %u", c, q);
+        for (uint64_t r = 0; r < hi - lo; r++) {
+            const uint32_t src = sorted ? (uint32_t)(lo + r) : order[r];
+            const uint32_t c = colours[h0 + src];
+            if (r && c == colours[h0 + (sorted ? (uint32_t)(lo + r - 1) : order[r - 1])])
+                return fail(BIGSI_ERR_INVALID, "colour %u listed twice for sequence %u", c, q);
             const uint32_t wp = c >> 7;
-            if (pairs.size() == pair_off[q] || pairs.back().wpair != wp) pairs.push_back(PresencePair{wp, (uint32_t)(lo + r), 0ull, 0ull});
+            if (pairs.size() == first_pair || pairs.back().wpair != wp) pairs.push_back(PresencePair{wp, (uint32_t)(lo + r), 0ull, 0ull, q, 0u});
             const uint64_t bit = 1ull << bit_of_col(c & 63u);
             if (c & 64u) pairs.back().mask_hi |= bit;
             else pairs.back().mask_lo |= bit;
-            perm[lo + r] = order[r];
+            perm[lo + r] = src;
             if ((uint64_t)(c >> 6) != last_word) { words++; last_word = c >> 6; }
         }
         max_u = std::max(max_u, b->h_num_unique[q]);
         max_n = std::max(max_n, b->h_num_kmers[q]);
-        max_pairs = std::max<uint32_t>(max_pairs, (uint32_t)(pairs.size() - pair_off[q]));
-        alg += (uint64_t)b->h_num_unique[q] * b->run_h * words * 8 + (hi - lo) * b->h_num_kmers[q];
+        alg += (uint64_t)b->h_num_unique[q] * b->run_h * words * 8 +
+               (hi - lo) * (packed ? round_up(b->h_num_kmers[q], 64) / 8 + sizeof(bigsi_hip_hit_score) : (uint64_t)b->h_num_kmers[q]);
     }
-    pair_off[nq] = pairs.size();
     string_offsets[n_hits] = str;
-    if (str > out_capacity) return fail(BIGSI_ERR_CAPACITY, "string buffer holds %llu bytes, %llu needed", (unsigned long long)out_capacity, (unsigned long long)str);
-    if (n_hits == 0 || str == 0) return BIGSI_OK;
-    if (!out) return fail(BIGSI_ERR_INVALID, "out is NULL");
-    if (b->run_h != ix->h) return fail(BIGSI_ERR_STATE, "num_hashes changed since the batch was run");
-    // device buffers: [pair_off | str_off | hit_seq | perm | pairs] in one upload
-    const size_t o_pair_off = 0, o_str = round_up(o_pair_off + (nq + 1) * 8ull, 256), o_seq = round_up(o_str + (n_hits + 1) * 8, 256);
+    if (check_capacity && str > out_capacity)
+        return fail(BIGSI_ERR_CAPACITY, "%s buffer holds %llu bytes, %llu needed", packed ? "bit" : "string", (unsigned long long)out_capacity, (unsigned long long)str);
+    job.packed = packed;
+    job.n_hits = n_hits;
+    job.str = str;
+    job.o_scores = round_up(str, 256);
+    job.device_work = false;
+    job.pending = true;
+    if (n_hits == 0 || str == 0) return BIGSI_OK;          // (hits of sequences without k-mers: nothing to extract, all-zero records)
+    if (b->run_h != ix->h) { job.pending = false; return fail(BIGSI_ERR_STATE, "num_hashes changed since the batch was run"); }
+    job.pending = false;                                   // (set again once everything is enqueued)
+    // device input: [str_off | hit_seq | perm | hit_pos0 | pairs | hit_q | found | unique] in one upload from pinned memory
+    const size_t o_str = 0, o_seq = round_up(o_str + (n_hits + 1) * 8, 256);
     const size_t o_perm = round_up(o_seq + n_hits * 4, 256), o_pos0 = round_up(o_perm + n_hits * 4, 256), o_pairs = round_up(o_pos0 + n_hits * 8, 256);
     const size_t o_q = round_up(o_pairs + pairs.size() * sizeof(PresencePair), 256), o_hoff = round_up(o_q + n_hits * 4, 256);
-    const size_t in_bytes = o_hoff + (nq + 1) * 8ull;
-    std::vector<uint8_t> stage(in_bytes);
-    memcpy(stage.data() + o_pair_off, pair_off.data(), (nq + 1) * 8ull);
+    // (K6) per rank: k-mers the hit found, unique k-mers of its sequence
+    const size_t o_found = round_up(o_hoff + (nq + 1) * 8ull, 256), o_uniq = round_up(o_found + (packed ? n_hits * 4 : 0), 256);
+    const size_t in_bytes = packed ? o_uniq + n_hits * 4 : o_hoff + (nq + 1) * 8ull;
+    TRY(pinned_reserve(&job.h_in, &job.h_in_cap, in_bytes));
+    uint8_t *stage = static_cast<uint8_t *>(job.h_in);
     // the device works in rank order (each sequence's hits by colour): string offset of the hit with that rank; the other per-hit
     // values (k-mers, map start, sequence) are the same for all hits of a sequence, whose hits keep their index range
-    for (uint64_t r = 0; r < n_hits; r++) reinterpret_cast<uint64_t *>(stage.data() + o_str)[r] = string_offsets[perm[r]];
-    memcpy(stage.data() + o_seq, hit_seq.data(), n_hits * 4);
-    memcpy(stage.data() + o_perm, perm.data(), n_hits * 4);
-    memcpy(stage.data() + o_pos0, hit_pos0.data(), n_hits * 8);
-    memcpy(stage.data() + o_pairs, pairs.data(), pairs.size() * sizeof(PresencePair));
-    memcpy(stage.data() + o_q, hit_q.data(), n_hits * 4);
-    for (uint32_t q = 0; q <= nq; q++) reinterpret_cast<uint64_t *>(stage.data() + o_hoff)[q] = hit_offsets[q] - h0;
+    for (uint64_t r = 0; r < n_hits; r++) reinterpret_cast<uint64_t *>(stage + o_str)[r] = string_offsets[perm[r]];
+    memcpy(stage + o_seq, hit_seq.data(), n_hits * 4);
+    memcpy(stage + o_perm, perm.data(), n_hits * 4);
+    memcpy(stage + o_pos0, hit_pos0.data(), n_hits * 8);
+    memcpy(stage + o_pairs, pairs.data(), pairs.size() * sizeof(PresencePair));
+    memcpy(stage + o_q, hit_q.data(), n_hits * 4);
+    for (uint32_t q = 0; q <= nq; q++) reinterpret_cast<uint64_t *>(stage + o_hoff)[q] = hit_offsets[q] - h0;
+    if (packed)
+        for (uint64_t r = 0; r < n_hits; r++) {
+            const uint32_t u = b->h_num_unique[hit_q[r]];
+            reinterpret_cast<uint32_t *>(stage + o_uniq)[r] = u;
+            reinterpret_cast<uint32_t *>(stage + o_found)[r] = counts ? counts[h0 + perm[r]] : u;
+        }
     const uint32_t n_chunks = (uint32_t)ceil_div(std::max<uint32_t>(max_u, 1), 16);
+    const size_t out_bytes = packed ? job.o_scores + n_hits * sizeof(bigsi_hip_hit_score) : str;
+    TRY(pinned_reserve(&job.h_out, &job.h_out_cap, out_bytes));
     TRY(b->pres_in.reserve(in_bytes));
     TRY(b->pres_bits.reserve((size_t)round_up(n_hits, 32) * n_chunks * 2 + 16));
-    TRY(b->pres_out.reserve(str));
+    TRY(b->pres_out.reserve(out_bytes));
     const uint64_t max_pieces = (b->total_pos >> 4) + nq + 1;      // marks | list of unmarked pieces | their number
     TRY(b->pres_desc.reserve(round_up(max_pieces * 4, 256) + max_pieces * 8 + 256));
     uint32_t *d_marks = b->pres_desc.as<uint32_t>();
     uint2 *d_listed = reinterpret_cast<uint2 *>(b->pres_desc.as<uint8_t>() + round_up(max_pieces * 4, 256));
     uint32_t *d_listed_n = reinterpret_cast<uint32_t *>(b->pres_desc.as<uint8_t>() + round_up(max_pieces * 4, 256) + max_pieces * 8);
-    HIP_TRY(hipMemsetAsync(d_listed_n, 0, 4, ps));
-    HIP_TRY(hipMemcpyAsync(b->pres_in.p, stage.data(), in_bytes, hipMemcpyHostToDevice, ps));
+    if (!job.done) HIP_TRY(hipEventCreateWithFlags(&job.done, hipEventDisableTiming));
+    HIP_TRY(hipMemcpyAsync(b->pres_in.p, stage, in_bytes, hipMemcpyHostToDevice, ps));
     const uint8_t *din = b->pres_in.as<uint8_t>();
     EventPair ep{};
     TRY(ev_begin(ix, &ep, ps));
-    const dim3 grid_a((unsigned)ceil_div(std::max<uint32_t>(max_pairs, 1), kBlock), (unsigned)ceil_div(std::max<uint32_t>(max_u, 1), 16), nq);
+    if (b->marks_of_run != b->run_serial || b->marks_at != b->pres_desc.p) {
+        // the piece marks depend on K1's position -> unique k-mer map alone: once per run of the batch, not once per call
+        HIP_TRY(hipMemsetAsync(d_listed_n, 0, 4, ps));
+        hipLaunchKernelGGL(k_presence_pieces, dim3(nq), dim3(kBlock), 0, ps, b->pos_unique.as<uint32_t>(), b->d_pos_off.as<uint64_t>(),
+                           b->num_kmers.as<uint32_t>(), d_marks, d_listed_n, d_listed);
+        b->marks_of_run = b->run_serial;
+        b->marks_at = b->pres_desc.p;
+    }
+    const dim3 grid_a((unsigned)ceil_div(std::max<uint64_t>(pairs.size(), 1), kBlock), (unsigned)ceil_div(std::max<uint32_t>(max_u, 1), 16), 1);
     static const int k5_waves = env_int("BIGSI_HIP_K5_WAVES", 2);
 #define BIGSI_PRESENCE_ARGS                                                                                                        \
     grid_a, dim3(kBlock), 0, ps, ix->d_index, ix->stride_words, b->rows.as<uint64_t>(), b->d_pos_off.as<uint64_t>(),            \
-        b->num_unique.as<uint32_t>(), ix->h, (const uint64_t *)(din + o_pair_off), (const PresencePair *)(din + o_pairs),              \
+        b->num_unique.as<uint32_t>(), ix->h, (uint64_t)pairs.size(), (const PresencePair *)(din + o_pairs),                            \
         b->pres_bits.as<uint16_t>(), n_chunks
 #define COMMA ,
 #define BIGSI_PRESENCE(H)                                                                          \
@@ -1909,29 +1983,123 @@ extern "C" int bigsi_hip_batch_presence_hits(bigsi_hip_batch *b, const uint64_t 
 #undef BIGSI_PRESENCE_ARGS
 #undef COMMA
     HIP_TRY(hipGetLastError());
-    {
+    if (packed) {
+        // K6: position-ordered bits of every hit and its score record (written at the hit's place in the caller's order)
+        hipLaunchKernelGGL(k_presence_score, dim3((unsigned)ceil_div(n_hits, kBlock)), dim3(kBlock), 0, ps, b->pres_bits.as<uint16_t>(), n_chunks, n_hits,
+                           (const uint32_t *)(din + o_seq), (const uint64_t *)(din + o_pos0), (const uint32_t *)(din + o_q), d_marks,
+                           b->pos_unique.as<uint32_t>(), (const uint64_t *)(din + o_str), b->pres_out.as<uint8_t>(),
+                           (const uint32_t *)(din + o_found), (const uint32_t *)(din + o_uniq), (const uint32_t *)(din + o_perm),
+                           reinterpret_cast<bigsi_score::HitScore *>(b->pres_out.as<uint8_t>() + job.o_scores));
+    } else {
         const uint32_t pieces = (uint32_t)pow2_at_least(ceil_div(std::max<uint32_t>(max_n, 1), 16));      // power of two: shifts, not divisions
         const uint64_t groups = ceil_div(n_hits, kPresenceHits * kPresenceRounds), blocks = ceil_div(groups * pieces, kBlock);
         if (blocks > 0x7FFFFFFFull || groups > 0x7FFFFFFFull)
             return fail(BIGSI_ERR_INVALID, "presence request too large for one launch");
-        hipLaunchKernelGGL(k_presence_pieces, dim3(nq), dim3(kBlock), 0, ps, b->pos_unique.as<uint32_t>(), b->d_pos_off.as<uint64_t>(),
-                           b->num_kmers.as<uint32_t>(), d_marks, d_listed_n, d_listed);
 #define BIGSI_EXPAND_ARGS                                                                                                          \
     dim3((unsigned)blocks), dim3(kBlock), 0, ps, b->pres_bits.as<uint16_t>(), n_chunks, n_hits, pieces,                          \
         (const uint32_t *)(din + o_seq), (const uint64_t *)(din + o_pos0), (const uint64_t *)(din + o_str), b->pres_out.as<uint8_t>(),    \
         (const uint32_t *)(din + o_q), d_marks
         if (pieces >= 64) hipLaunchKernelGGL(k_presence_expand<true>, BIGSI_EXPAND_ARGS);
         else hipLaunchKernelGGL(k_presence_expand<false>, BIGSI_EXPAND_ARGS);
-#undef BIGSI_EXPAND_ARGS
         hipLaunchKernelGGL(k_presence_expand_listed, dim3(1024), dim3(kBlock), 0, ps, b->pres_bits.as<uint16_t>(), n_chunks, d_listed_n, d_listed,
                            (const uint64_t *)(din + o_hoff), b->d_pos_off.as<uint64_t>(), b->num_kmers.as<uint32_t>(), b->pos_unique.as<uint32_t>(),
                            (const uint64_t *)(din + o_str), b->pres_out.as<uint8_t>());
+#undef BIGSI_EXPAND_ARGS
     }
     HIP_TRY(hipGetLastError());
     TRY(ev_end(ix, &ep, ix->ev_pr, ps));
     if (ep.a) ix->presence_bytes += alg;
-    HIP_TRY(hipMemcpyAsync(out, b->pres_out.p, str, hipMemcpyDeviceToHost, ps));
-    HIP_TRY(hipStreamSynchronize(ps));       // `stage` and the caller's buffers
+    // one download: [strings or bits | (score records)] are contiguous in pres_out
+    HIP_TRY(hipMemcpyAsync(job.h_out, b->pres_out.p, out_bytes, hipMemcpyDeviceToHost, ps));
+    HIP_TRY(hipEventRecord(job.done, ps));
+    job.device_work = true;
+    job.pending = true;
+    return BIGSI_OK;
+}
+
+static int presence_end(bigsi_hip_batch *b, uint8_t *out, uint64_t out_capacity, bigsi_hip_hit_score *scores)
+{
+    if (!b) return fail(BIGSI_ERR_INVALID, "NULL batch");
+    PresJob &job = b->job;
+    if (!job.pending) return fail(BIGSI_ERR_STATE, "no score / presence request of this batch is pending");
+    TRY(use_device(b->ix));
+    if (job.device_work) HIP_TRY(hipEventSynchronize(job.done));
+    job.pending = false;
+    if (job.packed && !scores) return fail(BIGSI_ERR_INVALID, "scores is NULL");
+    if (job.str > out_capacity)
+        return fail(BIGSI_ERR_CAPACITY, "%s buffer holds %llu bytes, %llu needed", job.packed ? "bit" : "string", (unsigned long long)out_capacity, (unsigned long long)job.str);
+    if (job.n_hits == 0) return BIGSI_OK;
+    if (!job.device_work) {
+        if (job.packed) memset(scores, 0, job.n_hits * sizeof(bigsi_hip_hit_score));
+        return BIGSI_OK;
+    }
+    if (!out) return fail(BIGSI_ERR_INVALID, "out is NULL");
+    memcpy(out, job.h_out, job.str);
+    if (job.packed) memcpy(scores, static_cast<const uint8_t *>(job.h_out) + job.o_scores, job.n_hits * sizeof(bigsi_hip_hit_score));
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_batch_presence_hits(bigsi_hip_batch *b, const uint64_t *hit_offsets, const uint32_t *colours, uint8_t *out,
+                                             uint64_t out_capacity, uint64_t *string_offsets)
+{
+    TRY(presence_begin(b, hit_offsets, colours, nullptr, false, false, out_capacity, true, string_offsets));
+    return presence_end(b, out, out_capacity, nullptr);
+}
+
+extern "C" int bigsi_hip_batch_score_hits(bigsi_hip_batch *b, const uint64_t *hit_offsets, const uint32_t *colours, const uint32_t *counts,
+                                          uint8_t *bits, uint64_t bits_capacity, uint64_t *bit_offsets, bigsi_hip_hit_score *scores)
+{
+    if (!scores) return fail(BIGSI_ERR_INVALID, "scores is NULL");
+    TRY(presence_begin(b, hit_offsets, colours, counts, true, false, bits_capacity, true, bit_offsets));
+    return presence_end(b, bits, bits_capacity, scores);
+}
+
+extern "C" int bigsi_hip_batch_score_hits_begin(bigsi_hip_batch *b, const uint64_t *hit_offsets, const uint32_t *colours, const uint32_t *counts,
+                                                uint32_t flags, uint64_t *bit_offsets)
+{
+    return presence_begin(b, hit_offsets, colours, counts, true, (flags & BIGSI_SCORE_ORDERED) != 0, 0, false, bit_offsets);
+}
+
+extern "C" int bigsi_hip_batch_score_hits_end(bigsi_hip_batch *b, uint8_t *bits, uint64_t bits_capacity, bigsi_hip_hit_score *scores)
+{
+    if (!scores) return fail(BIGSI_ERR_INVALID, "scores is NULL");
+    return presence_end(b, bits, bits_capacity, scores);
+}
+
+// Scorer.score for presence strings the caller already holds as bits: no index involved (one upload, K6's scoring kernel,
+// one download).
+extern "C" int bigsi_hip_score_presence(int device, const uint8_t *bits, const uint64_t *bit_offsets, const uint32_t *num_kmers,
+                                        const uint32_t *found, const uint32_t *unique, uint64_t n, bigsi_hip_hit_score *scores)
+{
+    if (n == 0) return BIGSI_OK;
+    if (!bits || !bit_offsets || !num_kmers || !scores) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    if (n > 0x7FFFFFFFull * kBlock) return fail(BIGSI_ERR_INVALID, "too many strings for one call");
+    uint64_t end = 0;
+    for (uint64_t t = 0; t < n; t++) {
+        if (bit_offsets[t] & 7u) return fail(BIGSI_ERR_INVALID, "bit_offsets[%llu] is not a multiple of 8", (unsigned long long)t);
+        end = std::max(end, bit_offsets[t] + round_up(num_kmers[t], 64) / 8);
+    }
+    HIP_TRY(hipSetDevice(device));
+    const size_t o_off = round_up(end, 256), o_n = round_up(o_off + n * 8, 256), o_f = round_up(o_n + n * 4, 256), o_u = round_up(o_f + n * 4, 256);
+    const size_t o_out = round_up(o_u + n * 4, 256), total = o_out + n * sizeof(bigsi_hip_hit_score);
+    std::vector<uint8_t> stage(o_out, 0);
+    memcpy(stage.data(), bits, end);
+    memcpy(stage.data() + o_off, bit_offsets, n * 8);
+    memcpy(stage.data() + o_n, num_kmers, n * 4);
+    if (found) memcpy(stage.data() + o_f, found, n * 4);
+    if (unique) memcpy(stage.data() + o_u, unique, n * 4);
+    uint8_t *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, total));
+    hipError_t e = hipMemcpy(d, stage.data(), o_out, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_score_packed, dim3((unsigned)ceil_div(n, kBlock)), dim3(kBlock), 0, 0, d, (const uint64_t *)(d + o_off), n,
+                           (const uint32_t *)(d + o_n), found ? (const uint32_t *)(d + o_f) : nullptr, unique ? (const uint32_t *)(d + o_u) : nullptr,
+                           (const uint32_t *)nullptr, reinterpret_cast<bigsi_score::HitScore *>(d + o_out));
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(scores, d + o_out, n * sizeof(bigsi_hip_hit_score), hipMemcpyDeviceToHost);
+    hipError_t e2 = hipFree(d); (void)e2;
+    if (e != hipSuccess) return fail(BIGSI_ERR_HIP, "bigsi_hip_score_presence: %s", hipGetErrorString(e));
     return BIGSI_OK;
 }
 

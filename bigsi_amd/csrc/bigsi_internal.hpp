@@ -90,6 +90,7 @@ struct bigsi_hip_index {
     hipStream_t pre_stream = nullptr;
     hipStream_t rd_stream[kReadStreams] = {};      // k_reads_fused launches alternate over these (created at the first one)
     uint32_t rd_next = 0;
+    hipStream_t sc_stream = nullptr;               // K5 / K6 of scored searches: highest priority (score_stream)
     bool rd_pending = false;      // something may still be running on them
     hipEvent_t main_ev = nullptr; // end of the last batch run on the index stream (mark_main)
     uint64_t fused_repeats = 0;   // one-launch read kernels repeated because a workgroup gave up waiting (bigsi_hip_stats)
@@ -129,6 +130,19 @@ struct HitBufs {
     }
 };
 
+// one K5 / K6 request of a batch between its _begin and its _end (bigsi_hip.hip: presence_begin / presence_end): host vectors
+// and pinned staging are kept from call to call
+struct PresJob {
+    bool pending = false, packed = false, device_work = false;
+    uint64_t n_hits = 0, str = 0;        // hits, bytes of strings / presence bits
+    size_t o_scores = 0;                 // where the score records start in the staged output
+    hipEvent_t done = nullptr;
+    void *h_in = nullptr, *h_out = nullptr;      // pinned
+    size_t h_in_cap = 0, h_out_cap = 0;
+    std::vector<uint32_t> hit_seq, hit_q, perm, order;
+    std::vector<uint64_t> hit_pos0;
+};
+
 struct bigsi_hip_batch {
     bigsi_hip_index *ix = nullptr;
     uint32_t n_seqs = 0, k = 0;
@@ -144,6 +158,9 @@ struct bigsi_hip_batch {
     DevBuf pos_query, hsh, rep;   // per k-mer position: owning sequence, dedupe hash, class representative
     DevBuf rows_sorted;           // the row ids K2 streams: each query's list in address order (k_sort_rows)
     DevBuf bitmaps, counts, scratch;
+    uint64_t run_serial = 0, marks_of_run = ~0ull;   // K1 runs of this batch; the run whose piece marks pres_desc holds
+    const void *marks_at = nullptr;                  // ... and where (pres_desc may have been reallocated since)
+    PresJob job;                                     // the K5 / K6 request in flight, its host vectors and pinned staging
     DevBuf pres_in, pres_bits, pres_out, pres_desc;   // K5 at scale (presence_hits): host-built pair lists, presence bits, strings, piece marks
     void *ext_bitmaps = nullptr, *ext_counts = nullptr;
     HitBufs hits, ghits;

@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "bigsi_score.hpp"
+
 namespace bigsi {
 
 constexpr uint32_t kEmpty = 0xFFFFFFFFu;
@@ -1571,22 +1573,28 @@ struct PresencePair {
     uint32_t wpair;          // word pair: columns [128 * wpair, +128)
     uint32_t base;           // rank, among the query's hits sorted by colour, of the pair's first hit (global index into perm)
     uint64_t mask_lo, mask_hi;   // hit bits of the two words (row bit order)
+    uint32_t q;              // the query the pair belongs to
+    uint32_t reserved;
 };
 
 
+// The grid is flat over the call's pairs (x) and 16-k-mer chunks (y): a thresholded search of a few hundred queries of which a
+// dozen have hits -- BASELINE configs[4] as benchmarked -- used to launch (pairs of the fullest query / 256) x chunks x queries
+// workgroups, nearly all of them empty, and waited for slots beside the next batch's row-AND kernel (166 us against 26 us alone).
 template <int H, int WAVES = 2>      // WAVES = 2: the compiler keeps all 16 x h loads of a thread in flight (~200 VGPRs), measured faster than 4
 __global__ __launch_bounds__(kBlock, WAVES) void k_presence_bits(
     const uint64_t *__restrict__ index, uint64_t stride_words, const uint64_t *__restrict__ rows, const uint64_t *__restrict__ pos_off,
-    const uint32_t *__restrict__ num_unique, uint32_t h_rt, const uint64_t *__restrict__ pair_off, const PresencePair *__restrict__ pairs,
+    const uint32_t *__restrict__ num_unique, uint32_t h_rt, uint64_t n_pairs, const PresencePair *__restrict__ pairs,
     uint16_t *__restrict__ bits /* presence_bits_at(rank, chunk) */, uint32_t bits_stride)
 {
     const uint32_t h = H > 0 ? (uint32_t)H : h_rt;
-    const uint32_t q = blockIdx.z, jc = blockIdx.y;
+    const uint32_t jc = blockIdx.y;
+    const uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (p >= n_pairs) return;
+    const uint32_t q = pairs[p].q;
     const uint32_t u = num_unique[q];
     const uint32_t j0 = jc * 16u;
     if (j0 >= u) return;
-    const uint64_t p = pair_off[q] + (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (p >= pair_off[q + 1]) return;
     const PresencePair pr = pairs[p];
     const uint64_t *qrows = rows + pos_off[q] * h;
     const uint32_t woff = pr.wpair * 2u;
@@ -1597,10 +1605,11 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_presence_bits(
 #pragma unroll
         for (int t0 = 0; t0 < 16; t0 += 4) {
             u64x2 tmp[4 * (H > 0 ? H : 1)];
+            constexpr int HH = H > 0 ? H : 1;
 #pragma unroll
             for (int x = 0; x < 4 * H; x++) {
-                const uint32_t j = j0 + t0 + x / H;
-                tmp[x] = j < u ? load_row_seg(index, qrows[(uint64_t)j * H + x % H], stride_words, woff) : zero;   // j < u is wave-uniform
+                const uint32_t j = j0 + t0 + x / HH;
+                tmp[x] = j < u ? load_row_seg(index, qrows[(uint64_t)j * H + x % HH], stride_words, woff) : zero;
             }
 #pragma unroll
             for (int t = 0; t < 4; t++) {
@@ -1760,6 +1769,76 @@ __global__ __launch_bounds__(kBlock) void k_presence_expand(
             *reinterpret_cast<uint4 *>(out + so[u] + piece * 16u) = uint4{o[0], o[1], o[2], o[3]};
         }
     }
+}
+
+// ------------------------------------------------------------------------------ K6: BIGSI.score on the device
+// graph/bigsi.py:232-239 + scoring/score.py:7-107.  The reference turns every hit's column of the n x N matrix into a
+// '0'/'1' string and scores it in Python.  Here a hit never becomes a string on the device: k_presence_score gathers the
+// hit's presence bits into position order -- ONE BIT per k-mer position, in the reference's own bit order
+// (bitarray.tobytes() of the presence string), 8x fewer bytes over PCIe than the ASCII strings of k_presence_expand -- and
+// runs remove_short_ones / tabulate_score / calculate_score on those bits (bigsi_score.hpp: integer run
+// scans + IEEE doubles with Python's round()).  One thread per hit throughout: a hit is ~n / 8 bytes and a few dozen runs,
+// and the presence-bit tiles ([tile of 32 ranks][chunk][rank % 32], presence_bits_at) make the threads of a wavefront read
+// consecutive 16-bit words.
+//
+// position-ordered presence bits of every hit AND its score record: thread = rank; piece = 16 positions; marked pieces
+// (k_presence_pieces) are 16 consecutive presence bits of the hit, listed ones walk the position -> unique k-mer map (uniform
+// over a sequence's hits).  The thread then scores the words it has just written (its own stores: visible to it).
+__global__ __launch_bounds__(kBlock) void k_presence_score(
+    const uint16_t *__restrict__ bits, uint32_t bits_stride, uint64_t n_hits, const uint32_t *__restrict__ hit_n,
+    const uint64_t *__restrict__ hit_pos0, const uint32_t *__restrict__ hit_seq, const uint32_t *__restrict__ desc,
+    const uint32_t *__restrict__ pos_unique, const uint64_t *__restrict__ out_off /* per rank: byte offset, multiple of 8 */,
+    uint8_t *out, const uint32_t *__restrict__ found, const uint32_t *__restrict__ unique, const uint32_t *__restrict__ dest,
+    bigsi_score::HitScore *__restrict__ scores)
+{
+    const uint64_t rank = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (rank >= n_hits) return;
+    const uint32_t n = hit_n[rank], pieces = (n + 15u) >> 4;
+    const uint64_t pos0 = hit_pos0[rank];
+    const uint32_t *d = desc + (pos0 >> 4) + hit_seq[rank];
+    const uint32_t *pu = pos_unique + pos0;
+    const uint16_t *mine = bits + presence_bits_at(rank, 0, bits_stride);      // chunk c of this rank: mine[32 * c]
+    uint64_t *dst = reinterpret_cast<uint64_t *>(out + out_off[rank]);
+    uint64_t acc = 0;
+    for (uint32_t piece = 0; piece < pieces; piece++) {
+        const uint32_t mark = d[piece], j0 = mark & 0x7fffffffu, cnt = min(16u, n - piece * 16u);
+        uint32_t x16 = 0;
+        if (mark >> 31) {
+            const uint32_t c = j0 >> 4, r = j0 & 15u;
+            const uint32_t lo = mine[32u * c], hi = r ? (uint32_t)mine[32u * min(c + 1u, bits_stride - 1u)] : 0u;
+            x16 = (lo | (hi << 16)) >> r;
+        } else {
+            for (uint32_t t = 0; t < cnt; t++) {
+                const uint32_t j = pu[piece * 16u + t];
+                x16 |= (((uint32_t)mine[32u * (j >> 4)] >> (j & 15u)) & 1u) << t;
+            }
+        }
+        x16 &= (1u << cnt) - 1u;
+        acc |= (uint64_t)x16 << (16u * (piece & 3u));
+        if ((piece & 3u) == 3u || piece + 1u == pieces) {
+            dst[piece >> 2] = by_column(acc);          // position p -> byte p / 8, mask 0x80 >> (p % 8)
+            acc = 0;
+        }
+    }
+    bigsi_score::HitScore rec;
+    const uint64_t *w = dst;
+    bigsi_score::score_hit([w](uint32_t k) { return by_column(w[k]); }, n, found[rank], unique[rank], &rec);
+    scores[dest[rank]] = rec;
+}
+
+// scores of every hit from its packed presence bits (row / bitarray order, 8-byte aligned, ceil(n / 64) words each):
+// thread = hit; the record of hit t goes to out[dest ? dest[t] : t]
+__global__ __launch_bounds__(kBlock) void k_score_packed(
+    const uint8_t *__restrict__ packed, const uint64_t *__restrict__ off, uint64_t n_hits, const uint32_t *__restrict__ hit_n,
+    const uint32_t *__restrict__ found, const uint32_t *__restrict__ unique, const uint32_t *__restrict__ dest,
+    bigsi_score::HitScore *__restrict__ out)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= n_hits) return;
+    const uint64_t *w = reinterpret_cast<const uint64_t *>(packed + off[t]);
+    bigsi_score::HitScore rec;
+    bigsi_score::score_hit([w](uint32_t k) { return by_column(w[k]); }, hit_n[t], found ? found[t] : 0u, unique ? unique[t] : 0u, &rec);
+    out[dest ? dest[t] : t] = rec;
 }
 
 // ------------------------------------------------------------------------------ storage contract helpers

@@ -865,6 +865,65 @@ extern "C" int bigsi_hip_group_batch_presence_hits(bigsi_hip_group_batch *gb, co
     return BIGSI_OK;
 }
 
+// K6 over a group: every shard scores the hits whose columns it owns (packed presence bits + score records), the host puts them
+// in the caller's order
+extern "C" int bigsi_hip_group_batch_score_hits(bigsi_hip_group_batch *gb, const uint64_t *hit_offsets, const uint32_t *colours, const uint32_t *counts,
+                                                uint8_t *bits, uint64_t bits_capacity, uint64_t *bit_offsets, bigsi_hip_hit_score *scores)
+{
+    if (!gb) return fail(BIGSI_ERR_INVALID, "NULL batch");
+    if (!gb->ran) return fail(BIGSI_ERR_STATE, "bigsi_hip_group_batch_run has not completed for this batch");
+    if (!hit_offsets || !bit_offsets || !scores) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    bigsi_hip_group *g = gb->g;
+    const uint32_t nq = gb->b[0]->n_seqs;
+    const uint64_t h0 = hit_offsets[0], n_hits = hit_offsets[nq] - h0;
+    if (n_hits && !colours) return fail(BIGSI_ERR_INVALID, "colours is NULL");
+    std::vector<uint32_t> nk(nq);
+    TRY(bigsi_hip_batch_fetch_unique(gb->b[0], nk.data(), nullptr, nullptr));
+    uint64_t need_all = 0;
+    for (uint32_t q = 0; q < nq; q++)
+        for (uint64_t t = hit_offsets[q] - h0; t < hit_offsets[q + 1] - h0; t++) {
+            if (colours[h0 + t] >= g->n_cols) return fail(BIGSI_ERR_RANGE, "colour %u >= num_cols", colours[h0 + t]);
+            bit_offsets[t] = need_all;
+            need_all += round_up(nk[q], 64) / 8;
+        }
+    bit_offsets[n_hits] = need_all;
+    if (need_all > bits_capacity) return fail(BIGSI_ERR_CAPACITY, "bit buffer holds %llu bytes, %llu needed", (unsigned long long)bits_capacity, (unsigned long long)need_all);
+    if (n_hits == 0) return BIGSI_OK;
+    if (need_all && !bits) return fail(BIGSI_ERR_INVALID, "bits is NULL");
+    std::vector<uint64_t> off(nq + 1), soff;
+    std::vector<uint32_t> local, lcnt, where;
+    std::vector<uint8_t> part;
+    std::vector<bigsi_hip_hit_score> prec;
+    for (uint32_t i = 0; i < g->n(); i++) {
+        local.clear();
+        lcnt.clear();
+        where.clear();
+        for (uint32_t q = 0; q < nq; q++) {
+            off[q] = local.size();
+            for (uint64_t t = hit_offsets[q] - h0; t < hit_offsets[q + 1] - h0; t++)
+                if (colours[h0 + t] / g->shard_cols == i) {
+                    local.push_back((uint32_t)(colours[h0 + t] - (uint64_t)i * g->shard_cols));
+                    if (counts) lcnt.push_back(counts[h0 + t]);
+                    where.push_back((uint32_t)t);
+                }
+        }
+        off[nq] = local.size();
+        if (local.empty()) continue;
+        uint64_t need = 0;
+        for (uint32_t t : where) need += bit_offsets[t + 1] - bit_offsets[t];
+        part.resize(std::max<uint64_t>(need, 8));
+        soff.resize(local.size() + 1);
+        prec.resize(local.size());
+        TRY(bigsi_use_device(gb->b[i]->ix));
+        TRY(bigsi_hip_batch_score_hits(gb->b[i], off.data(), local.data(), counts ? lcnt.data() : nullptr, part.data(), part.size(), soff.data(), prec.data()));
+        for (size_t r = 0; r < where.size(); r++) {
+            memcpy(bits + bit_offsets[where[r]], part.data() + soff[r], soff[r + 1] - soff[r]);
+            scores[where[r]] = prec[r];
+        }
+    }
+    return BIGSI_OK;
+}
+
 extern "C" int bigsi_hip_group_search_batch(bigsi_hip_group *g, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k,
                                             double threshold, uint32_t flags, uint32_t *num_kmers, uint32_t *num_unique, uint32_t *min_kmers,
                                             uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t hit_capacity)

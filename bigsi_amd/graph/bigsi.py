@@ -29,6 +29,44 @@ def validate_build_params(bloomfilters, samples):
         raise ValueError("There must be the same number of bloomfilters and sample names")
 
 
+# host memory one slice of scored hits may take as characters (the presence strings are the bulk of a scored result)
+SCORE_SLICE_CHARS = 256 << 20
+
+
+def scored_rows(rec, bits, boff, lengths, db_size):
+    """Host half of a scored search: K6's records + presence bits (QueryBatch.score_hits / score_hits_end) -> one tuple per hit,
+    (percent_kmers_found, the 17 fields of Scorer.score in the reference's key order, presence string); `lengths` = k-mer
+    positions of every hit's sequence."""
+    from ..scoring import score_columns, unpack_presence
+    text = unpack_presence(bits, boff)
+    starts = (boff[:-1].astype(np.int64) * 8).tolist()
+    strings = [text[a:a + n] for a, n in zip(starts, np.asarray(lengths).tolist())]
+    return list(zip(rec["percent_kmers_found"].tolist(), zip(*score_columns(rec, db_size)), strings))
+
+
+def score_hit_rows(batch, off, colours, counts, num_kmers, n_seqs, db_size, slice_chars=None):
+    """graph/bigsi.py:232-239 for every hit of a batch: the device extracts each hit's presence bits and runs
+    remove_short_ones / tabulate_score / calculate_score on them (K6, QueryBatch.score_hits); the host derives the closed-form
+    fields for all hits at once (scoring.score_columns) and expands the bits into the "kmer-presence" strings.  Returns one
+    tuple per hit, in hit-list order: (percent_kmers_found, the 17 score fields in the reference's key order, presence string).
+    Hits are processed in slices of at most `slice_chars` characters, so a low threshold on a wide index cannot ask for tens of
+    GB of host memory at once."""
+    slice_chars = slice_chars or SCORE_SLICE_CHARS
+    off64 = off.astype(np.int64)
+    per_hit = np.repeat(np.asarray(num_kmers[:n_seqs], dtype=np.int64), np.diff(off64[:n_seqs + 1]))
+    first, total = int(off64[0]), int(off64[n_seqs])
+    ends = np.cumsum((per_hit + 63) // 64 * 64)
+    rows, lo = [], 0
+    while first + lo < total:
+        base = int(ends[lo - 1]) if lo else 0
+        hi = max(int(np.searchsorted(ends, base + slice_chars, side="right")), lo + 1)
+        part = np.clip(off, first + lo, first + hi).astype(np.uint64)          # the same hit lists, restricted to hits [lo, hi)
+        rec, bits, boff = batch.score_hits(part, colours, counts, num_kmers)
+        rows.extend(scored_rows(rec, bits, boff, per_hit[lo:hi], db_size))
+        lo = hi
+    return rows
+
+
 class BigsiQueryResult(object):
     """One hit; `todict()` key order is part of the contract (tests/graph/test_end_to_end.py:114-124)."""
 
@@ -200,18 +238,19 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
             raise UnboundLocalError("local variable 'cumsum' referenced before assignment")
         out = [[] for _ in range(n_seqs)]
         off64 = off.astype(np.int64)
-        strings = None
+        scored = None
         if score:
-            # graph/bigsi.py:232-237 for every hit of the batch in ONE device pass (K5): strings[t] belongs to hit t of `colours`
             if ((np.diff(off64[:n_seqs + 1]) > 0) & (num_kmers[:n_seqs] == 1)).any():
                 # the reference builds a 1-D matrix from a single row and then indexes it with two subscripts
                 raise IndexError("too many indices for array: array is 1-dimensional, but 2 were indexed")
-            blob, starts, lens = batch.presence_hits(off, colours, num_kmers)
-            strings = (blob.tobytes().decode("latin-1"), starts, lens)
+            scored = self._score_hits(batch, off, colours, None if exact else counts, num_kmers, n_seqs)
         for i in np.flatnonzero(np.diff(off64[:n_seqs + 1])).tolist():      # only the sequences that have hits
             lo, hi = int(off64[i]), int(off64[i + 1])
-            out[i] = self._assemble(lo, colours[lo:hi], counts[lo:hi], int(nu[i]), exact, strings)
+            out[i] = self._assemble(lo, colours[lo:hi], counts[lo:hi], int(nu[i]), exact, scored)
         return out
+
+    def _score_hits(self, batch, off, colours, counts, num_kmers, n_seqs):
+        return score_hit_rows(batch, off, colours, counts, num_kmers, n_seqs, self.scorer.DB_SIZE)
 
     def _elements_of(self, seq):
         """A non-ASCII query as the device takes it: its unique k-mers (k CHARACTERS each, utils/fncts.py:63-65) in
@@ -352,25 +391,32 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
             for b_ in ws.values():
                 b_.close()
 
-    def _assemble(self, first_hit, colours, counts, u, exact, strings):
-        """Result dicts of one sequence from its slice of the batch's hit lists; `strings` = (text, offsets) of the batch's
-        presence strings (score=True: text, starts, lengths), indexed by position in the hit lists, `first_hit` = position of this slice's first hit."""
+    def _assemble(self, first_hit, colours, counts, u, exact, scored):
+        """Result dicts of one sequence from its slice of the batch's hit lists; `scored` (score=True) = _score_hits' per-hit
+        tuples, indexed by position in the hit lists, `first_hit` = position of this slice's first hit."""
+        from ..scoring import SCORE_KEYS
         idx = np.arange(len(colours))
         if exact:
             # exact_filter (graph/bigsi.py:192-205): every set bit, ascending; a colour without a name is a KeyError
-            results = [BigsiQueryResult(int(c), self.colour_to_sample(int(c)), u, u) for c in colours]
+            order = idx
+            found = [u] * len(colours)
         else:
             # inexact_filter (:211-230): only colours < num_samples are zipped in; stable sort by count, descending
             keep = colours < self.num_samples
             colours, counts, idx = colours[keep], counts[keep], idx[keep]
             order = np.argsort(-counts.astype(np.int64), kind="stable")
-            idx = idx[order]
-            results = [BigsiQueryResult(int(colours[j]), self.colour_to_sample(int(colours[j])), int(counts[j]), u) for j in order]
-        if strings is not None and results:
-            text, starts, lens = strings
-            for r, t in zip(results, idx.tolist()):
-                col = text[int(starts[first_hit + t]):int(starts[first_hit + t] + lens[first_hit + t])]
-                sd = self.scorer.score(col)
-                sd["kmer-presence"] = col
-                r.add_score(sd)
-        return [r.todict() for r in results if r.sample_name != DELETION_SPECIAL_SAMPLE_NAME]
+            colours, idx = colours[order], idx[order]
+            found = counts[order].tolist()
+        names = [self.colour_to_sample(c) for c in colours.tolist()]
+        if scored is None:
+            results = [BigsiQueryResult(0, name, f, u) for name, f in zip(names, found)]
+            return [r.todict() for r in results if r.sample_name != DELETION_SPECIAL_SAMPLE_NAME]
+        # BigsiQueryResult.todict (graph/bigsi.py:105-114) + add_score, written out: percent and scores come from the device
+        keys = ("percent_kmers_found", "num_kmers", "num_kmers_found", "sample_name") + SCORE_KEYS + ("kmer-presence",)
+        out = []
+        for name, f, t in zip(names, found, idx.tolist()):
+            if name == DELETION_SPECIAL_SAMPLE_NAME:
+                continue
+            pct, fields, col = scored[first_hit + t]
+            out.append(dict(zip(keys, (pct, u, f, name) + fields + (col,))))
+        return out

@@ -439,22 +439,24 @@ class ShardedBIGSI(object):
                 raise IndexError("too many indices for array: array is 1-dimensional, but 2 were indexed")
             out.append((res, pos))
         if score:
-            # graph/bigsi.py:232-237 for every hit of the batch: ONE K5 pass on each rank over the hits whose columns it owns
-            # (bigsi_hip_batch_presence_hits), then one exchange of (hit positions, strings) so that every rank can score
+            # graph/bigsi.py:232-239 for every hit of the batch: ONE K5 + K6 pass on each rank over the hits whose columns it owns
+            # (bigsi_hip_batch_score_hits), then one exchange of (hit positions, scored rows)
             owned = (colours.astype(np.int64) // self.shard_cols) == rank
             csum = np.concatenate([[0], np.cumsum(owned)])
             off_own = csum[off.astype(np.int64)].astype(np.uint64)
             col_own = (colours[owned].astype(np.int64) - rank * self.shard_cols).astype(np.uint32)
-            blob, starts, lens = batch.presence_hits(off_own, col_own, num_kmers)
-            text = blob.tobytes().decode("latin-1")
-            mine = (np.flatnonzero(owned), [text[int(a):int(a + n)] for a, n in zip(starts, lens)])
-            strings = {}
-            for where, strs in self._gather(mine):
-                strings.update(zip(where.tolist(), strs))
+            cnt_own = None if exact else counts[owned]
+            from .graph.bigsi import score_hit_rows
+            from .scoring import SCORE_KEYS
+            # K6 on the rank that owns the hit's column: presence bits, run tallies and the rounded score chain on the device
+            mine = (np.flatnonzero(owned), score_hit_rows(batch, off_own, col_own, cnt_own, num_kmers, n_seqs, self.scorer.DB_SIZE))
+            scored = {}
+            for where, rows in self._gather(mine):
+                scored.update(zip(where.tolist(), rows))
             for res, pos in out:
                 for r, t in zip(res, pos.tolist()):
-                    col = strings[t]
-                    sd = self.scorer.score(col)
+                    _, fields, col = scored[t]
+                    sd = dict(zip(SCORE_KEYS, fields))
                     sd["kmer-presence"] = col
                     r.add_score(sd)
         return [[r.todict() for r in res if r.sample_name != DELETION_SPECIAL_SAMPLE_NAME] for res, _ in out]

@@ -154,3 +154,65 @@ class Scorer(object):
         if p > 0:
             return round(np.log10(p), 2)
         return round(log_evalue, 2)      # p underflowed to 0: the reference falls back to log_evalue
+
+
+# ------------------------------------------------------------------------------------------- K6: scores from the device
+# bigsi_hip_batch_score_hits / bigsi_hip_score_presence (include/bigsi_hip.h) return, per hit, what calculate_score computes
+# (score.py:54-94) -- run on the device bit-equal to CPython, csrc/bigsi_score.hpp -- plus the hit's presence string as bits.
+# What is left of Scorer.score (score.py:96-121) is closed-form arithmetic on those records, done here for all hits of a batch
+# at once with numpy (element-wise IEEE operations and the same np.exp / np.log10 / np.round the scalar code above calls, so
+# the values are the ones Scorer.score returns: tests/test_abi_and_host.py pins the two against each other).
+HIT_SCORE_DTYPE = np.dtype([("score", "<f8"), ("min_score", "<f8"), ("max_score", "<f8"), ("percent_kmers_found", "<f8"),
+                            ("max_mismatches", "<i8"), ("min_mismatches", "<i8"), ("mismatches", "<i8"),
+                            ("num_kmers", "<u4"), ("reserved", "<u4")])
+SCORE_KEYS = ("score", "min_score", "max_score", "max_mismatches", "min_mismatches", "mismatches", "max_nident", "nident",
+              "min_nident", "pident", "max_pident", "min_pident", "length", "evalue", "pvalue", "log_evalue", "log_pvalue")
+
+
+def pack_presence(strings):
+    """Presence strings -> the bit layout of the C ABI: (bits uint8[], byte offsets uint64[n + 1], lengths uint32[n]);
+    string t = bitarray(strings[t]).tobytes() zero-padded to whole 8-byte words at bits[offsets[t]:]."""
+    lens = np.array([len(s) for s in strings], dtype=np.uint32)
+    off = np.zeros(len(strings) + 1, np.uint64)
+    off[1:] = np.cumsum((lens.astype(np.int64) + 63) // 64 * 8)
+    bits = np.zeros(max(int(off[-1]), 8), np.uint8)
+    for t, s in enumerate(strings):
+        if s.count("0") + s.count("1") != len(s):
+            raise ValueError("presence string must consist of '0' and '1'")
+        if s:
+            b = np.packbits(np.frombuffer(s.encode("ascii"), np.uint8) - ord("0"))
+            bits[int(off[t]):int(off[t]) + b.size] = b
+    return bits, off, lens
+
+
+def unpack_presence(bits, offsets):
+    """The inverse for a whole batch in three C-speed passes: one str holding every hit's '0'/'1' characters, such that hit t's
+    string is text[8 * offsets[t] : 8 * offsets[t] + num_kmers[t]].  (unpackbits, an in-place OR with a uint8 -- a Python int
+    there costs a type-promoting pass, 16x slower -- and ONE decode straight from the array's memory: 60 us per 259 hits of
+    970 positions, 0.29 us per hit at 26 k hits; `.tobytes().decode("latin-1")` alone took three times that.)"""
+    chars = np.unpackbits(bits[: int(offsets[-1])])
+    np.bitwise_or(chars, np.uint8(ord("0")), out=chars)
+    return str(memoryview(chars), "ascii")
+
+
+def score_columns(rec, db_size):
+    """The 17 fields of Scorer.score (score.py:96-121) for every record of `rec` (HIT_SCORE_DTYPE), as one Python list per key of
+    SCORE_KEYS.  A record with num_kmers == 0 divides by zero in the reference (score.py:99-100): ZeroDivisionError."""
+    n = rec["num_kmers"].astype(np.int64)
+    if n.size and not n.all():
+        raise ZeroDivisionError("division by zero")
+    seq_len = n + (_K - 1)
+    fl = seq_len.astype(np.float64)
+    max_nident, nident, min_nident = seq_len - rec["min_mismatches"], seq_len - rec["mismatches"], seq_len - rec["max_mismatches"]
+    score = rec["score"]
+    with np.errstate(over="ignore", under="ignore", divide="ignore"):
+        evalue = K_UNGAPPED * db_size * fl * np.exp(-LAMBDA_UNGAPPED * score)             # score.py:125-129
+        pvalue = 1 - np.exp(-evalue)                                                       # :131-132
+        m = db_size if db_size != 0 else 1
+        log_evalue = np.round(np.round(np.log10(K_UNGAPPED * m * fl) - LAMBDA_UNGAPPED * score, 2), 2)   # :134-141 and :117-119
+        p = 1 - np.exp(-np.power(10.0, log_evalue))                                        # :143-151
+        log_pvalue = np.round(np.round(np.where(p > 0, np.log10(np.where(p > 0, p, 1.0)), log_evalue), 2), 2)
+    cols = [score, rec["min_score"], rec["max_score"], rec["max_mismatches"], rec["min_mismatches"], rec["mismatches"],
+            max_nident, nident, min_nident, 100 * nident.astype(np.float64) / fl, 100 * max_nident.astype(np.float64) / fl,
+            100 * min_nident.astype(np.float64) / fl, seq_len, evalue, pvalue, log_evalue, log_pvalue]
+    return [c.tolist() for c in cols]

@@ -584,6 +584,51 @@ class QueryBatch(object):
         return blob, soff[:-1].astype(np.int64), lens
 
 
+    def score_hits(self, off, colours, counts, num_kmers):
+        """BIGSI.score for the hits of EVERY sequence on the device (K6, bigsi_hip_batch_score_hits): `off`, `colours`, `counts` as
+        hits() returns them (counts None: an exact search).  Returns (records, bits, bit_offsets): records[t]
+        (scoring.HIT_SCORE_DTYPE) holds what calculate_score computes for hit t plus its percent_kmers_found; hit t's presence
+        string is bits[bit_offsets[t]:] read as a bitarray of num_kmers positions (scoring.unpack_presence)."""
+        from ..scoring import HIT_SCORE_DTYPE
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        colours = np.ascontiguousarray(colours, dtype=np.uint32)
+        counts = None if counts is None else np.ascontiguousarray(counts, dtype=np.uint32)
+        n_hits = int(off[self.n] - off[0])
+        words = (np.asarray(num_kmers[: self.n], dtype=np.int64) + 63) // 64
+        need = int((words * np.diff(off[: self.n + 1]).astype(np.int64)).sum()) * 8
+        bits = np.zeros(max(need, 8), np.uint8)
+        boff = np.zeros(n_hits + 1, np.uint64)
+        rec = np.zeros(max(n_hits, 1), HIT_SCORE_DTYPE)
+        check(self._fn("score_hits")(self.b, _lib.ptr(off), _lib.ptr(colours) if n_hits else None, _lib.ptr(counts) if n_hits else None,
+                                     _lib.ptr(bits), bits.size, _lib.ptr(boff), _lib.ptr(rec)))
+        return rec[:n_hits], bits, boff
+
+
+    def score_hits_begin(self, off, colours, counts, num_kmers, ordered=False):
+        """First half of score_hits (bigsi_hip_batch_score_hits_begin): queues K5 + K6 for the given hit lists and returns at once.
+        ordered=True puts the kernels on the index's stream behind the runs already issued (BIGSI_SCORE_ORDERED: a throughput
+        loop three batches deep), otherwise on the library's high-priority score stream.  Single index only."""
+        self._single_only("score_hits_begin()")
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        colours = np.ascontiguousarray(colours, dtype=np.uint32)
+        counts = None if counts is None else np.ascontiguousarray(counts, dtype=np.uint32)
+        n_hits = int(off[self.n] - off[0])
+        boff = np.zeros(n_hits + 1, np.uint64)
+        check(_lib.lib().bigsi_hip_batch_score_hits_begin(self.b, _lib.ptr(off), _lib.ptr(colours) if n_hits else None,
+                                                          _lib.ptr(counts) if n_hits else None, _lib.SCORE_ORDERED if ordered else 0, _lib.ptr(boff)))
+        self._score_job = (n_hits, boff)
+
+    def score_hits_end(self):
+        """Second half: waits for the request and returns (records, bits, bit_offsets) as score_hits does."""
+        from ..scoring import HIT_SCORE_DTYPE
+        n_hits, boff = self._score_job
+        self._score_job = None
+        bits = np.zeros(max(int(boff[-1]), 8), np.uint8)
+        rec = np.zeros(max(n_hits, 1), HIT_SCORE_DTYPE)
+        check(_lib.lib().bigsi_hip_batch_score_hits_end(self.b, _lib.ptr(bits), bits.size, _lib.ptr(rec)))
+        return rec[:n_hits], bits, boff
+
+
 class ElementBatch(QueryBatch):
     """QueryBatch over explicit k-mers: same run / unique / hits / presence interface, no reload."""
 

@@ -239,6 +239,44 @@ int bigsi_hip_batch_presence(bigsi_hip_batch *b, uint32_t seq, const uint32_t *c
 int bigsi_hip_batch_presence_hits(bigsi_hip_batch *b, const uint64_t *hit_offsets, const uint32_t *colours, uint8_t *out,
                                   uint64_t out_capacity, uint64_t *string_offsets);
 
+/* CORE: BIGSI.score on the device (K6).  Replaces, for every hit of the batch, BIGSI.score's column -> string -> Scorer.score
+ * chain (bigsi/graph/bigsi.py:232-239, bigsi/scoring/score.py:7-107): remove_short_ones, tabulate_score and
+ * Scorer.calculate_score (its three scores with Python's round(x, 2) after every gap, the SNP totals, math.ceil / floor) run on
+ * the device in IEEE doubles, bit-equal to CPython; so does BigsiQueryResult's percent_kmers_found (graph/bigsi.py:97-99).
+ * The caller derives the remaining Scorer.score fields in closed form (score.py:104-121: nident / pident from the mismatch
+ * counts, evalue / pvalue / log_* from `score` through exp / log10 -- kept on the host because no two libm agree bit for bit). */
+typedef struct {
+    double score, min_score, max_score;  /* score.py:86-88                                         */
+    double percent_kmers_found;          /* round(100 * float(found) / num_unique, 2)               */
+    int64_t max_mismatches, min_mismatches, mismatches; /* score.py:89-93                           */
+    uint32_t num_kmers;                  /* n: length of the hit's presence string                 */
+    uint32_t reserved;
+} bigsi_hip_hit_score;
+/* hit_offsets / colours as for bigsi_hip_batch_presence_hits; counts[t] = k-mers hit t found (what fetch_hits returned; NULL:
+ * every hit found all unique k-mers of its sequence, i.e. an exact search).  scores[t] is the record of hit t.  The presence
+ * string itself comes back as BITS: hit t's n positions start at bits[bit_offsets[t]] (a multiple of 8 bytes), position p in
+ * byte p / 8 under mask 0x80 >> (p % 8) -- bitarray(presence_string).tobytes(), zero-padded to whole 8-byte words;
+ * bit_offsets gets hit_offsets[n_seqs] - hit_offsets[0] + 1 entries, the last one the bytes needed.
+ * BIGSI_ERR_CAPACITY (bit_offsets filled) when bits_capacity is smaller. */
+int bigsi_hip_batch_score_hits(bigsi_hip_batch *b, const uint64_t *hit_offsets, const uint32_t *colours, const uint32_t *counts,
+                               uint8_t *bits, uint64_t bits_capacity, uint64_t *bit_offsets, bigsi_hip_hit_score *scores);
+/* The same in two halves, for serving loops: _begin takes the hit lists, fills bit_offsets (so the caller can size `bits`:
+ * bit_offsets[n_hits] bytes) and queues the device work; _end waits for it and copies the results out.  Between the two the
+ * caller is free to do anything else -- including running the batch again: the results are staged in host memory the
+ * batch owns (not after bigsi_hip_batch_reload / destroy).  One request per batch at a time.
+ * BIGSI_SCORE_ORDERED queues the kernels on the index's stream BEHIND the runs already issued there instead of on the library's
+ * high-priority score stream beside them: the request then completes later but costs a tenth of the device time (the kernels
+ * do not compete with a row-AND kernel for the memory system) -- the choice of a throughput loop three batches deep. */
+#define BIGSI_SCORE_ORDERED 1u
+int bigsi_hip_batch_score_hits_begin(bigsi_hip_batch *b, const uint64_t *hit_offsets, const uint32_t *colours, const uint32_t *counts,
+                                     uint32_t flags, uint64_t *bit_offsets);
+int bigsi_hip_batch_score_hits_end(bigsi_hip_batch *b, uint8_t *bits, uint64_t bits_capacity, bigsi_hip_hit_score *scores);
+/* Scorer.score (bigsi/scoring/score.py:96-121, the part listed above) for n presence strings the caller holds as bits in the
+ * layout bigsi_hip_batch_score_hits returns (string t: num_kmers[t] positions at bits + bit_offsets[t], multiple of 8).  found /
+ * unique feed percent_kmers_found and may be NULL.  Needs no index. */
+int bigsi_hip_score_presence(int device, const uint8_t *bits, const uint64_t *bit_offsets, const uint32_t *num_kmers,
+                             const uint32_t *found, const uint32_t *unique, uint64_t n, bigsi_hip_hit_score *scores);
+
 /* EXCHANGE-BY-CALLER.  Multi-GPU assembly: compact hits from result buffers gathered from n_shards column shards (device pointer,
  * layout [shard][seq][stride] with this batch's strides; colour = shard * shard_cols + local column).
  * compact_gathered* are asynchronous, also for the host: they are queued (on the gather stream, below) behind this batch's
@@ -342,6 +380,8 @@ int bigsi_hip_group_batch_fetch_hits(bigsi_hip_group_batch *gb, uint64_t *hit_of
 int bigsi_hip_group_batch_presence(bigsi_hip_group_batch *gb, uint32_t seq, const uint32_t *colours, uint32_t n_colours, uint8_t *out);
 int bigsi_hip_group_batch_presence_hits(bigsi_hip_group_batch *gb, const uint64_t *hit_offsets, const uint32_t *colours, uint8_t *out,
                                         uint64_t out_capacity, uint64_t *string_offsets);
+int bigsi_hip_group_batch_score_hits(bigsi_hip_group_batch *gb, const uint64_t *hit_offsets, const uint32_t *colours, const uint32_t *counts,
+                                     uint8_t *bits, uint64_t bits_capacity, uint64_t *bit_offsets, bigsi_hip_hit_score *scores);
 int bigsi_hip_group_search_batch(bigsi_hip_group *g, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k,
                                  double threshold, uint32_t flags, uint32_t *num_kmers, uint32_t *num_unique, uint32_t *min_kmers,
                                  uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t hit_capacity);

@@ -324,3 +324,101 @@ def test_plan_shards_and_bench_workloads():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "northstar", "--gpus", "1"], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "more than one MI355X holds" in r.stderr
+
+
+# --------------------------------------------------------------------------------------------- K6's arithmetic, pinned on the CPU
+# bigsi_amd/csrc/bigsi_score.hpp is the text the device compiles for K6 (k_score_packed); here the same header is compiled as host
+# C++ (tests/c_host/score_host.cpp, contraction off) and pinned to CPython's round(), to the reference's golden scores (G5) and to
+# the scalar restatement of scoring/score.py.  The -m gpu suite runs the same cases through the device build.
+def build_score_host(tmp_path):
+    import ctypes
+    import subprocess
+    so = str(tmp_path / "libscore_host.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-Wextra", "-Werror",
+                           "-o", so, os.path.join(ROOT, "tests", "c_host", "score_host.cpp")])
+    return ctypes.CDLL(so)
+
+
+def score_strings_on_host(lib, strings, found=None, unique=None):
+    import ctypes
+    from bigsi_amd.scoring import HIT_SCORE_DTYPE, pack_presence
+    bits, off, lens = pack_presence(strings)
+    rec = np.zeros(len(strings), HIT_SCORE_DTYPE)
+    p = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)      # noqa: E731
+    lib.score_host_packed(p(bits), p(off), p(lens), p(found), p(unique), ctypes.c_uint64(len(strings)), p(rec))
+    return rec
+
+
+def adversarial_round_inputs():
+    rng = np.random.default_rng(0)
+    return np.ascontiguousarray(np.concatenate([
+        rng.uniform(-5000, 5000, 100000), rng.integers(-500000, 500000, 100000) / 1000.0, rng.integers(-500000, 500000, 100000) / 200.0,
+        (rng.integers(-5000000, 5000000, 100000) + 0.5) / 100.0,        # x.xx5: the decimal half-way cases, none exactly representable
+        rng.integers(-40000, 40000, 50000) / 8.0,                       # exact binary ties (x.125, x.375, ...): half to even
+        np.array([2.675, 0.125, 0.375, -0.125, 1.005, 1e-9, -1e-9, 0.0, -0.0, 0.005, 0.015, 0.025, 1064.885, 96.045, 1e12 + 0.005])]),
+        dtype=np.float64)
+
+
+def score_strings():
+    import random
+    rng = random.Random(5)
+    strings = ["0", "1", "00", "11", "10", "01", "111", "110", "011", "101", "000", "0000", "1111", "1101", "1011"]
+    for n in (3, 4, 5, 7, 8, 31, 61, 63, 64, 65, 66, 127, 128, 129, 130, 191, 192, 193, 970, 3970):
+        for p in (0.0, 0.05, 0.5, 0.9, 0.97, 1.0):
+            for _ in range(4):
+                a = ["1" if rng.random() < p else "0" for _ in range(n)]
+                for _ in range(rng.randrange(4)):          # gaps a SNP would leave: ~31 absent k-mers in a row
+                    g0, ln = rng.randrange(n), rng.randrange(1, 70)
+                    a[g0:g0 + ln] = ["0"] * len(a[g0:g0 + ln])
+                strings.append("".join(a)[:n])
+    return strings
+
+
+def test_k6_round_is_cpythons_round(tmp_path):
+    import ctypes
+    lib = build_score_host(tmp_path)
+    xs = adversarial_round_inputs()
+    out = np.zeros_like(xs)
+    lib.score_host_round2(xs.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(xs.size), out.ctypes.data_as(ctypes.c_void_p))
+    want = np.array([round(float(x), 2) for x in xs])
+    assert np.array_equal(out, want) and np.array_equal(np.signbit(out), np.signbit(want))
+    assert (np.round(xs, 2) != want).any()          # (the obvious x*100 -> rint -> /100 is NOT Python's round)
+
+
+def check_records_against_golden_and_scalar(score_fn):
+    """score_fn(strings, found, unique) -> HIT_SCORE_DTYPE records.  All 438 cases of G5 (the reference's own Scorer.score outputs,
+    incl. its known answer bigsi/tests/scoring.py:10-31) and seeded strings against the scalar restatement, every field exact."""
+    from bigsi_amd.scoring import SCORE_KEYS, Scorer, score_columns, unpack_presence, pack_presence
+    g = load_golden("g5_scoring.json")
+    checked = 0
+    for db in sorted({r["db_size"] for r in g["cases"]}):
+        good = [r for r in g["cases"] if r["db_size"] == db and "raises" not in r]
+        cols = score_columns(score_fn([r["s"] for r in good], None, None), db)
+        for i, r in enumerate(good):
+            assert_result_equal(dict(zip(SCORE_KEYS, [c[i] for c in cols])), unjson(r["score"]), "db=%d %s" % (db, r["s"][:20]))
+            checked += 1
+    assert checked == 438
+    strings = score_strings()
+    rng = np.random.default_rng(3)
+    unique = rng.integers(1, 4000, len(strings)).astype(np.uint32)
+    found = (rng.random(len(strings)) * (unique + 1)).astype(np.uint32).clip(0, unique)
+    rec = score_fn(strings, found, unique)
+    assert rec["percent_kmers_found"].tolist() == [round(100 * float(f) / u, 2) for f, u in zip(found.tolist(), unique.tolist())]
+    assert rec["num_kmers"].tolist() == [len(s) for s in strings]
+    for db in (0, 1, 500000):
+        sc, cols = Scorer(db), score_columns(rec, db)
+        for i, s in enumerate(strings):
+            want, got = sc.score(s), dict(zip(SCORE_KEYS, [c[i] for c in cols]))
+            assert list(got) == list(want)
+            for k in want:
+                assert (got[k] == want[k] or (got[k] != got[k] and want[k] != want[k])) and math.copysign(1, got[k]) == math.copysign(1, want[k]), (db, s[:30], len(s), k, got[k], want[k])
+    bits, off, _ = pack_presence(strings)
+    text = unpack_presence(bits, off)
+    assert all(text[8 * int(off[i]):8 * int(off[i]) + len(s)] == s for i, s in enumerate(strings))
+    with pytest.raises(ZeroDivisionError):
+        score_columns(score_fn([""], None, None), 4)
+
+
+def test_k6_scoring_header_vs_golden_scores_and_scalar_scorer(tmp_path):
+    lib = build_score_host(tmp_path)
+    check_records_against_golden_and_scalar(lambda strings, found, unique: score_strings_on_host(lib, strings, found, unique))

@@ -1,0 +1,162 @@
+"""K6 -- BIGSI.score on the device (bigsi_hip_batch_score_hits / bigsi_hip_score_presence, csrc/bigsi_score.hpp) -- against
+the reference's golden scores (tests/golden/g5_scoring.json: the reference's own Scorer.score outputs), CPython's round(), the
+scalar restatement of scoring/score.py, and the presence strings the single-sequence kernel (k_presence) and the oracle give.
+Everything exact except evalue / pvalue (tolerances of conftest.py).  Needs a real MI355X: `pytest -m gpu`."""
+import itertools
+
+import numpy as np
+import pytest
+
+from conftest import assert_results_equal
+
+pytestmark = pytest.mark.gpu
+
+_counter = itertools.count()
+
+
+def cfg(k, m, h, **sc):
+    sc.setdefault("name", "k6_%d" % next(_counter))
+    return {"storage-engine": "hip-hbm", "storage-config": sc, "k": k, "m": m, "h": h}
+
+
+def device_score(strings, found=None, unique=None):
+    from bigsi_amd import _lib
+    from bigsi_amd.scoring import HIT_SCORE_DTYPE, pack_presence
+    bits, off, lens = pack_presence(strings)
+    rec = np.zeros(max(len(strings), 1), HIT_SCORE_DTYPE)
+    _lib.check(_lib.lib().bigsi_hip_score_presence(0, _lib.ptr(bits), _lib.ptr(off), _lib.ptr(lens), _lib.ptr(found), _lib.ptr(unique),
+                                                   len(strings), _lib.ptr(rec)))
+    return rec[:len(strings)]
+
+
+def test_k6_device_scores_equal_golden_scores_and_scalar_scorer():
+    """All 438 golden Scorer.score cases (incl. the reference's known answer bigsi/tests/scoring.py:10-31) and ~500 seeded strings
+    (lengths around the 64-position word edges, gaps of SNP length) through k_score_packed: tallies, the rounded score chain,
+    SNP totals and percent_kmers_found bit-equal."""
+    from test_abi_and_host import check_records_against_golden_and_scalar
+    check_records_against_golden_and_scalar(device_score)
+
+
+def test_k6_round_on_the_device_is_cpythons_round():
+    """py_round2 as compiled for gfx950, seen through percent_kmers_found = round(100 * found / unique, 2) for every
+    0 <= found <= unique <= 1200 (720 k quotients; the x.xx5 cases among them are the hard ones) and through single-gap strings,
+    whose scores are round(n - gap + gap', 2)-style chains over every gap length up to 700."""
+    uniq = np.repeat(np.arange(1, 1201, dtype=np.uint32), np.arange(2, 1202))
+    found = np.concatenate([np.arange(u + 1, dtype=np.uint32) for u in range(1, 1201)])
+    rec = device_score(["1"] * uniq.size, found, uniq)
+    want = [round(100 * float(f) / u, 2) for f, u in zip(found.tolist(), uniq.tolist())]
+    assert rec["percent_kmers_found"].tolist() == want
+    from bigsi_amd.scoring import SCORE_KEYS, Scorer, score_columns
+    strings = ["1" * a + "0" * g + "1" * b for g in range(1, 700, 3) for a, b in ((40, 40), (3, 500), (0, 37))]
+    cols = score_columns(device_score(strings), 1000)
+    sc = Scorer(1000)
+    for i, s in enumerate(strings):
+        want = sc.score(s)
+        assert {k: c[i] for k, c in zip(SCORE_KEYS, cols)} == want, s[:50]
+
+
+def build_index(hip_cfg, samples):
+    from bigsi_amd import BIGSI
+    return BIGSI.build_from_sequences(hip_cfg, samples)
+
+
+def rand_seq(rng, n, alphabet="ACGT"):
+    return "".join(rng.choice(list(alphabet), size=n))
+
+
+@pytest.mark.parametrize("devices", [None, [0, 0, 0]])
+def test_k6_score_hits_equals_strings_and_scalar_scorer(devices):
+    """bigsi_hip_batch_score_hits on a small index whose samples share pieces of the queries: the packed bits must be the
+    presence strings of k_presence (one sequence at a time, the round-1 kernel) and the records the scalar Scorer's values for
+    those strings.  Queries with repeated k-mers (listed pieces), lengths that end inside a 16-position piece / a 64-position
+    word, one sequence without hits.  devices = [0, 0, 0]: the same through a three-shard group (each shard scores its hits)."""
+    from bigsi_amd.scoring import SCORE_KEYS, Scorer, score_columns, unpack_presence
+    rng = np.random.default_rng(11)
+    k, m, h = 31, 50021, 3
+    queries = [rand_seq(rng, 1000), rand_seq(rng, 31 + 15), rand_seq(rng, 31 + 16), rand_seq(rng, 31 + 63), rand_seq(rng, 31 + 64),
+               rand_seq(rng, 300, "AC"), rand_seq(rng, 200) * 3, rand_seq(rng, 2500), rand_seq(rng, 97)]
+    samples = {}
+    for c in range(150):
+        q = queries[c % (len(queries) - 1)]                    # the last query matches nothing
+        lo = int(rng.integers(0, max(len(q) - 60, 1)))
+        samples["s%d" % c] = [q[lo:lo + int(rng.integers(31, len(q)))], rand_seq(rng, 400)] + ([q[:45]] if c % 3 == 0 else []) + ([q] if c % 4 == 1 else [])
+    sc = {"max_cols": 150}
+    if devices:
+        sc["devices"] = devices
+    index = build_index(cfg(k, m, h, **sc), samples)
+    batch = index.storage.new_batch(queries, k)
+    scalar = Scorer(150)
+    for thr in (0.05, 1.0):
+        batch.run(thr)
+        nk, nu, _ = batch.unique()
+        off, colours, counts = batch.hits()
+        assert int(off[-1]) > (30 if thr == 1.0 else 100)
+        rec, bits, boff = batch.score_hits(off, colours, None if thr == 1.0 else counts, nk)
+        text = unpack_presence(bits, boff)
+        cols = score_columns(rec, 150)
+        t = 0
+        for i in range(len(queries)):
+            hits = colours[int(off[i]):int(off[i + 1])]
+            strs = batch.presence(i, hits, int(nk[i]))
+            for c, s in zip(hits.tolist(), strs):
+                assert text[8 * int(boff[t]):8 * int(boff[t]) + int(nk[i])] == s, (thr, i, c)
+                assert {key: col[t] for key, col in zip(SCORE_KEYS, cols)} == scalar.score(s), (thr, i, c)
+                f = int(nu[i]) if thr == 1.0 else int(counts[t])
+                assert rec["percent_kmers_found"][t] == round(100 * float(f) / int(nu[i]), 2) and rec["num_kmers"][t] == nk[i]
+                t += 1
+        assert t == int(off[-1])
+        # any subset / order of a sequence's colours, and hit lists that start past zero (what a sliced caller passes)
+        part = np.clip(off, 7, int(off[-1]) - 5).astype(np.uint64)
+        rec2, bits2, boff2 = batch.score_hits(part, colours, None if thr == 1.0 else counts, nk)
+        assert np.array_equal(rec2, rec[7:int(off[-1]) - 5])
+        assert unpack_presence(bits2, boff2) == text[8 * int(boff[7]):8 * int(boff[int(off[-1]) - 5])]
+    batch.close()
+    index.delete()
+
+
+def test_k6_search_with_scores_in_slices_equals_scalar_assembly():
+    """BIGSI.search_batch(score=True) assembles its dicts from K6's records; with a tiny slice budget (several device passes per
+    batch, slices cutting through a sequence's hits) the results must equal the round-2 assembly: presence string per hit ->
+    scalar Scorer.score -> dict, in the reference's order (count descending, colour ascending), deleted samples dropped."""
+    import bigsi_amd.graph.bigsi as gb
+    from bigsi_amd.scoring import Scorer
+    rng = np.random.default_rng(12)
+    k, m, h = 31, 30011, 3
+    queries = [rand_seq(rng, 400), rand_seq(rng, 61), rand_seq(rng, 700)]
+    samples = {"s%d" % c: [queries[c % 3][: int(rng.integers(40, len(queries[c % 3])))], rand_seq(rng, 300)] + ([queries[c % 3]] if c % 5 < 2 else [])
+               for c in range(40)}
+    index = build_index(cfg(k, m, h, max_cols=64), samples)
+    index.delete_sample("s4")
+    old = gb.SCORE_SLICE_CHARS
+    try:
+        results = {}
+        for budget in (old, 2000):
+            gb.SCORE_SLICE_CHARS = budget
+            results[budget] = {thr: index.search_batch(queries, thr, score=True) for thr in (1.0, 0.3)}
+    finally:
+        gb.SCORE_SLICE_CHARS = old
+    scalar = Scorer(index.scorer.DB_SIZE)
+    batch = index.storage.new_batch(queries, k)
+    for thr in (1.0, 0.3):
+        batch.run(thr)
+        nk, nu, _ = batch.unique()
+        off, colours, counts = batch.hits()
+        for i in range(len(queries)):
+            lo, hi = int(off[i]), int(off[i + 1])
+            hits = sorted(zip(colours[lo:hi].tolist(), counts[lo:hi].tolist()), key=lambda x: -x[1]) if thr != 1.0 else list(zip(colours[lo:hi].tolist(), counts[lo:hi].tolist()))
+            want = []
+            for c, f in hits:
+                name = index.colour_to_sample(c)
+                if name == "D3L3T3D":
+                    continue
+                s = batch.presence(i, np.array([c], np.uint32), int(nk[i]))[0]
+                d = {"percent_kmers_found": round(100 * float(f) / int(nu[i]), 2), "num_kmers": int(nu[i]), "num_kmers_found": f, "sample_name": name}
+                d.update(scalar.score(s))
+                d["kmer-presence"] = s
+                want.append(d)
+            assert len(want) >= (3 if thr == 1.0 else 8), (thr, i, len(want))
+            for budget in results:
+                assert_results_equal(results[budget][thr][i], want, "thr=%r q%d budget=%d" % (thr, i, budget))
+                assert [list(r) for r in results[budget][thr][i]] == [list(w) for w in want]
+    batch.close()
+    index.delete()
