@@ -83,6 +83,9 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample (0 = skip)")
     p.add_argument("--cpu-rows", type=int, default=200_000)
     p.add_argument("--no-verify", action="store_true")
+    p.add_argument("--also", default="auto", choices=["auto", "all", "none"],
+                   help="after the headline, run short legs of the other BASELINE configurations and report them under config.also "
+                        "(auto: only for the default single-GPU c3 run)")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for several ranks on one GPU)")
     p.add_argument("--one-device", action="store_true", help="every rank uses device 0 (dry runs of the N>1 path on a 1-GPU box; needs --backend gloo)")
     p.add_argument("--force-dist", action="store_true",
@@ -166,6 +169,56 @@ def cpu_baseline(args, w, cols_cpu, exact):
                      "cores": r["pool"]["threads"], "host_threads": r["host_threads"],
                      "sample": "fork pool over query sequences (the reference's bulk_search parallelism), %d workers, median of %d runs of %.1f s"
                                % (r["pool"]["threads"], len(r["pool"]["rates"]), r["pool"]["seconds"])}}
+
+
+ALSO_LEGS = [
+    # (key, what, arguments): every leg is this script again in a fresh process, >= 1 s of timed steps, verified against the oracle
+    ("c3_t04", "configs[2] at threshold 0.4 (bit-sliced counting kernel)", ["--workload", "c3", "--threshold", "0.4", "--steps", "16", "--warmup", "3"]),
+    ("c2", "configs[1]: 1M x 10k, 1000 x 61-mers per step", ["--workload", "c2", "--steps", "50000", "--warmup", "200"]),
+    ("c2_t04", "configs[1] at threshold 0.4", ["--workload", "c2", "--threshold", "0.4", "--steps", "50000", "--warmup", "200"]),
+    ("c4_shard", "configs[3]: one GPU's shard (1 of 8) of 25M x 500k", ["--workload", "c4", "--shard-of", "8", "--steps", "1200", "--warmup", "10"]),
+    ("c5_shard", "configs[4]: the same shard at threshold 0.4 with score=True (K5 + K6 + host assembly in the step)",
+     ["--workload", "c5", "--shard-of", "8", "--steps", "1000", "--warmup", "10"]),
+    ("northstar_shard", "north_star shape 10M x 500k: one GPU's shard (1 of 8)", ["--workload", "northstar", "--shard-of", "8", "--steps", "1200", "--warmup", "10"]),
+]
+
+
+def run_also_legs():
+    """The other BASELINE configurations, one fresh process each (the headline's index has been freed), condensed."""
+    out = {}
+    for key, what, extra in ALSO_LEGS:
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--cpu-seconds", "0", "--also", "none"] + extra
+        t0 = time.time()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            rf, cf = d["roofline"], d["config"]
+            out[key] = {"what": what, "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+                        "timed_s": d["ms_per_step"] * d["steps"] / 1e3,
+                        "roofline": {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "kernel_ms", "alg_bytes_per_launch",
+                                                           "launches_per_step", "step_GBps", "step_frac", "concurrent_launches", "traffic",
+                                                           "traffic_measured_in_run", "read_launches_repeated")},
+                        "verified": cf.get("verified"), "host_visible": cf.get("host_visible"),
+                        "presence": cf.get("presence"), "clocks": cf.get("clocks"), "wall_s": time.time() - t0, "args": " ".join(extra)}
+        except Exception as e:  # noqa: BLE001 -- a leg that fails is reported as such, the headline stands
+            out[key] = {"what": what, "error": "%s: %s" % (type(e).__name__, str(e)[:300]), "args": " ".join(extra)}
+    return out
+
+
+def smi_snapshot(device):
+    """Clocks / power / temperature of the device as rocm-smi reports them (explains box-to-box spread of the bandwidth figures)."""
+    try:
+        r = subprocess.run(["rocm-smi", "-d", str(device), "--showclocks", "--showpower", "--showtemp", "--json"], capture_output=True, text=True, timeout=20)
+        d = json.loads(r.stdout)
+        card = d[sorted(d)[0]]
+        keep = {}
+        for k, v in card.items():
+            kl = k.lower()
+            if any(t in kl for t in ("sclk", "mclk", "fclk", "socclk", "power", "temperature")):
+                keep[k] = v
+        return keep
+    except Exception as e:  # noqa: BLE001
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:120])}
 
 
 def main():
@@ -368,12 +421,15 @@ def main():
     stats = _lib.Stats()
 
     sync_all()
+    clocks_before = smi_snapshot(local_rank) if rank == 0 else None
+    sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     collect()                      # the last batch's share, inside the timed region
     sync_all()
     elapsed = time.perf_counter() - t0
+    clocks_after = smi_snapshot(local_rank) if rank == 0 else None
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -467,6 +523,10 @@ def main():
         pcie_rate = total_unique * reps / (time.perf_counter() - t1)
         for w_ in ws:
             w_.close()
+
+    host_visible = {"two_workspace_loop_kmer_lookups_per_s": pcie_rate,
+                    "what": "sequences in host memory -> upload -> run -> hit lists in host memory (SURVEY 8d(1)); never `value`, which is "
+                            "quoted with the batch resident in HBM"}
 
     # HBM traffic of this kernel on this workload, when a PMC pass for it has been committed (PMC counters cannot be
     # collected from inside the timed run; see profiles/)
@@ -568,9 +628,11 @@ def main():
                 "rccl_ranks": cr[1] if cr else None,
                 "index_fill_s": fill_s, "verified": verified, "presence": presence,
                 "pcie_inclusive_kmer_lookups_per_s": pcie_rate,
+                "host_visible": host_visible,
+                "clocks": {"before_timed_region": clocks_before, "after_timed_region": clocks_after, "source": "rocm-smi --showclocks --showpower --showtemp"},
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic": traffic, "traffic_source": traffic_src, "traffic_measured_in_run": False,
                          "kernel": "k_reads_fused (K1 + row-AND + K4 in one launch)" if batch.info().one_launch else "k_and_exact" if exact else "k_and_count",
                          "alg_bytes_per_launch": alg_bytes_launch, "kernel_ms": and_ms, "launches_timed": int(stats.and_launches),
                          "launches_per_step": launches_per_step, "alg_bytes_per_step": alg_bytes,
@@ -591,6 +653,10 @@ def main():
         b_.close()
     sh.close()
     st.delete_all()
+    if rank == 0 and world == 1 and not use_dist and (args.also == "all" or (args.also == "auto" and args.workload == "c3" and not args.custom
+                                                                             and not args.shard_of and args.scaling == "strong")):
+        # the other BASELINE configurations, each a short run of this script in a fresh process now that the index is freed
+        line["config"]["also"] = run_also_legs()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -173,6 +173,8 @@ extern "C" int bigsi_hip_close(bigsi_hip_index *ix)
         bigsi_hip_batch_destroy(ix->search_ws);
         ix->search_ws = nullptr;
     }
+    for (auto &w : ix->stream_ws)
+        if (w) { bigsi_hip_batch_destroy(w); w = nullptr; }
     hipError_t e = hipSetDevice(ix->device);
     e = hipStreamSynchronize(ix->stream);
     if (ix->pre_stream) e = hipStreamSynchronize(ix->pre_stream);
@@ -641,9 +643,16 @@ static void point_uniq(bigsi_hip_batch *b)
     b->min_kmers.point(u + 2ull * b->n_seqs, b->n_seqs * 4ull);
 }
 
-static int batch_load(bigsi_hip_batch *b, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k)
+static int pinned_reserve(void **p, size_t *cap, size_t bytes);
+
+// `deferred`: the offset tables and the sequences are staged in pinned memory the batch owns and go up at the start of the next
+// run, on the stream that run uses -- no copy, no synchronisation here (the one-call and streaming entry points: a call is then
+// one asynchronous upload, the kernels, one export kernel and ONE wait).  Otherwise (create / reload) the copy is made now on
+// the upload stream and waited for.
+static int batch_load(bigsi_hip_batch *b, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k, bool deferred = false)
 {
     bigsi_hip_index *ix = b->ix;
+    b->upload_deferred = false;
     const uint64_t base = offsets[0], nbytes = offsets[n_seqs] - base;
     b->n_seqs = n_seqs;
     b->k = k;
@@ -691,6 +700,20 @@ static int batch_load(bigsi_hip_batch *b, const char *seqs, const uint64_t *offs
             if (e != hipSuccess) rc = fail(BIGSI_ERR_HIP, "H2D copy: %s", hipGetErrorString(e));
         }
     };
+    if (deferred && rc == BIGSI_OK) {
+        const size_t bytes = 3 * ob + nbytes;
+        rc = pinned_reserve(&b->pin_up, &b->pin_up_cap, bytes);
+        if (rc != BIGSI_OK) return rc;
+        uint8_t *h = static_cast<uint8_t *>(b->pin_up);
+        memcpy(h, b->seq_off.data(), ob);
+        memcpy(h + ob, b->pos_off.data(), ob);
+        memcpy(h + 2 * ob, b->tab_off.data(), ob);
+        if (nbytes) memcpy(h + 3 * ob, seqs + base, nbytes);
+        b->pin_up_bytes = bytes;
+        b->upload_deferred = true;
+        b->pos_query_loaded = false;
+        return BIGSI_OK;
+    }
     const bool packed = nbytes <= (64u << 10);
     b->h_upload.resize(3 * ob + (packed ? nbytes : 0));
     memcpy(b->h_upload.data(), b->seq_off.data(), ob);
@@ -864,6 +887,9 @@ extern "C" int bigsi_hip_batch_destroy(bigsi_hip_batch *b)
     b->ghits.release();
     b->gbuf.release();
     if (b->job.done) { e = hipEventSynchronize(b->job.done); e = hipEventDestroy(b->job.done); (void)e; }
+    if (b->pin_up) { e = hipHostFree(b->pin_up); (void)e; }
+    if (b->pin_out) { e = hipHostFree(b->pin_out); (void)e; }
+    if (b->exp_done) { e = hipEventDestroy(b->exp_done); (void)e; }
     if (b->job.h_in) { e = hipHostFree(b->job.h_in); (void)e; }
     if (b->job.h_out) { e = hipHostFree(b->job.h_out); (void)e; }
     if (b->done) { e = hipEventDestroy(b->done); (void)e; }
@@ -1172,6 +1198,15 @@ static int k1_publish(bigsi_hip_batch *b)
     return BIGSI_OK;
 }
 
+// a deferred load (batch_load): the staged tables and sequences go up now, ahead of this run's first kernel on its stream
+static int flush_upload(bigsi_hip_batch *b, hipStream_t st)
+{
+    if (!b->upload_deferred) return BIGSI_OK;
+    HIP_TRY(hipMemcpyAsync(b->upload.p, b->pin_up, b->pin_up_bytes, hipMemcpyHostToDevice, st));
+    b->upload_deferred = false;
+    return BIGSI_OK;
+}
+
 extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_t flags)
 {
     if (!b) return fail(BIGSI_ERR_INVALID, "NULL batch");
@@ -1204,6 +1239,7 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
         if (ix->main_ev && st != ix->stream) HIP_TRY(hipStreamWaitEvent(st, ix->main_ev, 0));
         if (b->done && b->run_stream != st) HIP_TRY(hipStreamWaitEvent(st, b->done, 0));      // this batch's previous run
         if (b->g_done && b->gstream && b->gstream != st) HIP_TRY(hipStreamWaitEvent(st, b->g_done, 0));
+        TRY(flush_upload(b, st));
         TRY(ev_begin(ix, &fe, st, true));
         b->weak_fp = (flags & BIGSI_RUN_WEAK_FINGERPRINT) != 0;
         TRY(launch_reads_fused(b, st, (flags & BIGSI_RUN_NO_WAITING) ? 0 : kSpinTimeout));
@@ -1239,6 +1275,7 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
     // K1 (its LDS route emits the sorted list itself; the other routes leave that to k_sort_rows below)
     EventPair ep{};
     bool sorted_by_k1 = false;
+    TRY(flush_upload(b, k1_stream(ix)));
     TRY(run_kmerize(b, threshold, (flags & BIGSI_RUN_K1_GLOBAL) != 0, want_sorted, &sorted_by_k1));
     b->dirty = true;        // until `done` is recorded at the end
     const uint64_t *k2_rows = sorted_by_k1 ? b->rows_sorted.as<uint64_t>() : b->rows.as<uint64_t>();
@@ -1433,24 +1470,19 @@ static int compact_ex(bigsi_hip_batch *b, HitBufs &hb, const void *src, bool fro
         hb.cap = want;
     }
     if (!from_counts) {
-        // bit vectors (the AND bitmap / the fused count >= min_kmers mask): ONE launch -- count, chained scan, ordered write
-        // (k_hits_fused).  `write_only` (the lists overflowed and were grown) simply runs it again.
-        // items per workgroup such that the grid stays below what the chip holds at once (see k_hits_fused)
+        // bit vectors (the AND bitmap / the fused count >= min_kmers mask): group totals, then prefix + ordered write
+        // (k_hits_totals, k_hits_write: no waiting between workgroups).  `write_only` (the lists overflowed and were grown)
+        // runs the write pass again: the totals are still there.
         static const int k4_groups = env_int("BIGSI_HIP_K4_GROUPS", (int)kHitsMaxGroups);
         const uint64_t max_groups = (uint64_t)std::min<int>(std::max(k4_groups, 1), (int)kHitsMaxGroups);
         const uint32_t ipb = (uint32_t)ceil_div(nchunks, max_groups);
         const uint64_t ngroups = ceil_div(nchunks, ipb);
-        if (hb.lb_state.cap < kHitsMaxGroups * 8) {
-            TRY(hb.lb_state.reserve(kHitsMaxGroups * 8));
-            HIP_TRY(hipMemsetAsync(hb.lb_state.p, 0, hb.lb_state.cap, st));       // fresh memory: generation 0 everywhere
-            hb.gen = 0;
-        }
-        if (++hb.gen >= (1u << 20)) {      // the 20-bit generation wraps: make every stale word unmistakably old again
-            HIP_TRY(hipMemsetAsync(hb.lb_state.p, 0, hb.lb_state.cap, st));
-            hb.gen = 1;
-        }
-        hipLaunchKernelGGL(k_hits_fused, dim3((unsigned)ngroups), dim3(kBlock), 0, st, (const uint64_t *)src, b->wv_pad, (uint32_t)b->wv, b->n_seqs,
-                           n_shards, chunks, shard_cols, b->num_unique.as<uint32_t>(), ipb, hb.lb_state.as<uint64_t>(), hb.gen,
+        TRY(hb.chunk_hits.reserve(kHitsMaxGroups * 4));
+        if (!write_only)
+            hipLaunchKernelGGL(k_hits_totals, dim3((unsigned)ngroups), dim3(kBlock), 0, st, (const uint64_t *)src, b->wv_pad, (uint32_t)b->wv, b->n_seqs,
+                               n_shards, chunks, ipb, hb.chunk_hits.as<uint32_t>());
+        hipLaunchKernelGGL(k_hits_write, dim3((unsigned)ngroups), dim3(kBlock), 0, st, (const uint64_t *)src, b->wv_pad, (uint32_t)b->wv, b->n_seqs,
+                           n_shards, chunks, shard_cols, b->num_unique.as<uint32_t>(), ipb, hb.chunk_hits.as<uint32_t>(),
                            hb.hit_off.as<uint64_t>(), hb.col(), hb.cnt(), hb.capacity(), counters, b->count_bytes, b->wv_pad * 64, own_shard);
         HIP_TRY(hipGetLastError());
         return BIGSI_OK;
@@ -2100,6 +2132,87 @@ extern "C" int bigsi_hip_score_presence(int device, const uint8_t *bits, const u
     if (e == hipSuccess) e = hipMemcpy(scores, d + o_out, n * sizeof(bigsi_hip_hit_score), hipMemcpyDeviceToHost);
     hipError_t e2 = hipFree(d); (void)e2;
     if (e != hipSuccess) return fail(BIGSI_ERR_HIP, "bigsi_hip_score_presence: %s", hipGetErrorString(e));
+    return BIGSI_OK;
+}
+
+// ------------------------------------------------------------------------------ one-call / streaming searches: stage, export, collect
+int bigsi_batch_stage(bigsi_hip_index *ix, bigsi_hip_batch **pb, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k)
+{
+    TRY(check_batch_args(ix, seqs, offsets, n_seqs, k));
+    TRY(use_device(ix));
+    bigsi_hip_batch *b = *pb;
+    if (!b) {
+        b = new (std::nothrow) bigsi_hip_batch();
+        if (!b) return fail(BIGSI_ERR_NOMEM, "host allocation failed");
+        b->ix = ix;
+        *pb = b;
+    } else {
+        if (b->elements) return fail(BIGSI_ERR_STATE, "a batch of explicit k-mers cannot be reloaded: create a new one");
+        TRY(batch_quiesce(b));                                         // this batch's earlier run ...
+        if (b->exp_done) HIP_TRY(hipEventSynchronize(b->exp_done));    // ... and the export of its results
+    }
+    return batch_load(b, seqs, offsets, n_seqs, k, true);
+}
+
+int bigsi_batch_export(bigsi_hip_batch *b)
+{
+    if (!b || !b->ran) return fail(BIGSI_ERR_STATE, "bigsi_hip_batch_run has not completed for this batch");
+    if (!b->compacted) return fail(BIGSI_ERR_STATE, "internal: export of a run without hit lists");
+    HitBufs &hb = b->hits;
+    hipStream_t st = b->run_stream ? b->run_stream : b->ix->stream;
+    const uint32_t n = b->n_seqs;
+    const uint64_t spec = std::min<uint64_t>(std::max<uint64_t>(1024, 2ull * n), std::min<uint64_t>(hb.capacity(), 1u << 20));
+    const size_t o_uniq = (n + 2ull) * 8, o_col = o_uniq + ((3ull * n + 1) & ~1ull) * 4, bytes = o_col + 8 * spec;
+    TRY(pinned_reserve(&b->pin_out, &b->pin_out_cap, bytes));
+    if (!b->exp_done) HIP_TRY(hipEventCreateWithFlags(&b->exp_done, hipEventDisableTiming));
+    b->exp_spec = (uint32_t)spec;
+    const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(std::max<uint64_t>(3ull * n, spec), kBlock), 64);
+    hipLaunchKernelGGL(k_export_results, dim3(grid), dim3(kBlock), 0, st, hb.hit_off.as<uint64_t>(), n, b->fused_run ? 1u : 0u, b->uniq.as<uint32_t>(),
+                       hb.col(), hb.cnt(), (uint32_t)spec, static_cast<uint64_t *>(b->pin_out));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(b->exp_done, st));
+    return BIGSI_OK;
+}
+
+// outputs as bigsi_hip_batch_fetch_unique + fetch_hits (hit_offsets relative to this batch, n_seqs + 1 entries)
+int bigsi_batch_collect(bigsi_hip_batch *b, uint32_t *num_kmers, uint32_t *num_unique, uint32_t *min_kmers, uint64_t *hit_offsets,
+                        uint32_t *colours, uint32_t *counts, uint64_t capacity)
+{
+    if (!b || !b->exp_done) return fail(BIGSI_ERR_STATE, "internal: nothing exported");
+    TRY(use_device(b->ix));
+    HIP_TRY(hipEventSynchronize(b->exp_done));
+    HitBufs &hb = b->hits;
+    const uint32_t n = b->n_seqs;
+    const uint64_t *off = static_cast<const uint64_t *>(b->pin_out);
+    const uint64_t total = off[n];
+    const bool gave_up = b->fused_run && !b->fused_settled && off[n + 1] == hb.gen;
+    if (gave_up || total > hb.capacity()) {
+        // rare: a read launch that was abandoned, or hit lists that outgrew the device buffers -- the general route repeats the
+        // launch / regrows the lists
+        TRY(bigsi_hip_batch_fetch_unique(b, num_kmers, num_unique, min_kmers));
+        return bigsi_hip_batch_fetch_hits(b, hit_offsets, colours, counts, capacity);
+    }
+    if (b->fused_run) b->fused_settled = true;
+    const uint32_t *u32 = reinterpret_cast<const uint32_t *>(off + n + 2);
+    b->h_uniq.assign(u32, u32 + 3ull * n);
+    b->h_num_kmers.assign(u32, u32 + n);
+    b->h_num_unique.assign(u32 + n, u32 + 2ull * n);
+    b->h_min_kmers.assign(u32 + 2ull * n, u32 + 3ull * n);
+    b->host_counts_valid = true;
+    if (num_kmers) memcpy(num_kmers, u32, n * 4ull);
+    if (num_unique) memcpy(num_unique, u32 + n, n * 4ull);
+    if (min_kmers) memcpy(min_kmers, u32 + 2ull * n, n * 4ull);
+    if (hit_offsets) memcpy(hit_offsets, off, (n + 1ull) * 8);
+    if (total > capacity)
+        return fail(BIGSI_ERR_CAPACITY, "hit buffers hold %llu entries, %llu needed", (unsigned long long)capacity, (unsigned long long)total);
+    const uint32_t *pcol = u32 + ((3ull * n + 1) & ~1ull), *pcnt = pcol + b->exp_spec;
+    const uint64_t m = std::min<uint64_t>(total, b->exp_spec);
+    if (m && colours) memcpy(colours, pcol, m * 4);
+    if (m && counts) memcpy(counts, pcnt, m * 4);
+    if (total > m) {          // more hits than the export carried along: the rest by plain copies
+        if (colours) HIP_TRY(hipMemcpy(colours + m, hb.col() + m, (total - m) * 4, hipMemcpyDeviceToHost));
+        if (counts) HIP_TRY(hipMemcpy(counts + m, hb.cnt() + m, (total - m) * 4, hipMemcpyDeviceToHost));
+    }
     return BIGSI_OK;
 }
 

@@ -95,6 +95,7 @@ struct bigsi_hip_index {
     hipEvent_t main_ev = nullptr; // end of the last batch run on the index stream (mark_main)
     uint64_t fused_repeats = 0;   // one-launch read kernels repeated because a workgroup gave up waiting (bigsi_hip_stats)
     struct bigsi_hip_batch *search_ws = nullptr;      // bigsi_hip_search_batch's workspace, created at its first call
+    struct bigsi_hip_batch *stream_ws[3] = {};        // bigsi_hip_search_stream's three workspaces
     uint64_t m = 0, n_cols = 0, cap_cols = 0, stride_words = 0;
     uint32_t h = 0;
     uint64_t *d_index = nullptr;
@@ -114,7 +115,8 @@ struct bigsi_hip_comm;
 // ------------------------------------------------------------------------------ batches
 struct HitBufs {
     DevBuf chunk_hits, chunk_off, hit_off, hit_col, hit_cnt, overflow;
-    // one-launch K4 (k_hits_fused): one state word per workgroup, tagged with the launch's generation
+    // k_reads_fused's hit scan: one state word per workgroup, tagged with the launch's generation (K4 proper keeps its group
+    // totals in chunk_hits)
     DevBuf lb_state;
     uint32_t gen = 0;           // generation tag of the state words of the last launch (20 bits, 0 = never used)
     uint64_t cap = 0;   // hits the col/cnt buffers can hold
@@ -160,6 +162,12 @@ struct bigsi_hip_batch {
     DevBuf bitmaps, counts, scratch;
     uint64_t run_serial = 0, marks_of_run = ~0ull;   // K1 runs of this batch; the run whose piece marks pres_desc holds
     const void *marks_at = nullptr;                  // ... and where (pres_desc may have been reallocated since)
+    // deferred loads and exported results (the one-call and streaming entry points): pinned staging the batch owns
+    void *pin_up = nullptr, *pin_out = nullptr;
+    size_t pin_up_cap = 0, pin_out_cap = 0, pin_up_bytes = 0;
+    bool upload_deferred = false;                    // pin_up holds tables + sequences that the next run uploads on its stream
+    hipEvent_t exp_done = nullptr;                   // end of the export kernel
+    uint32_t exp_spec = 0;                           // hits the export carried along speculatively
     PresJob job;                                     // the K5 / K6 request in flight, its host vectors and pinned staging
     DevBuf pres_in, pres_bits, pres_out, pres_desc;   // K5 at scale (presence_hits): host-built pair lists, presence bits, strings, piece marks
     void *ext_bitmaps = nullptr, *ext_counts = nullptr;
@@ -201,6 +209,12 @@ struct bigsi_hip_batch {
 
 
 // internal entry points of bigsi_hip.hip used by bigsi_shard.hip
+// one-call / streaming searches: stage a load without copying (created on first use: *pb may be NULL), queue the export of a
+// run's results into pinned memory, wait for it and hand the results out
+int bigsi_batch_stage(bigsi_hip_index *ix, bigsi_hip_batch **pb, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k);
+int bigsi_batch_export(bigsi_hip_batch *b);
+int bigsi_batch_collect(bigsi_hip_batch *b, uint32_t *num_kmers, uint32_t *num_unique, uint32_t *min_kmers, uint64_t *hit_offsets,
+                        uint32_t *colours, uint32_t *counts, uint64_t capacity);
 int bigsi_use_device(const bigsi_hip_index *ix);
 // write pass of the gathered compaction again after the hit buffers grew (fetch_gathered_hits); defined in bigsi_shard.hip
 int bigsi_reduce_gathered_counts(bigsi_hip_batch *b);

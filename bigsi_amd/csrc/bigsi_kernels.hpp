@@ -1047,7 +1047,7 @@ __global__ __launch_bounds__(kBlock) void k_and_count(
 // ------------------------------------------------------------------------------ K4: threshold + compaction
 // Result buffers are laid out [shard][seq][stride] (n_shards = 1 for a single GPU; > 1 for buffers gathered from column
 // shards); hits come out as (colour, count) in (seq, shard, column) order.  Bit vectors -- every production path -- take
-// ONE launch (k_hits_fused); dense counter buffers take three passes: (a) hits per 2048-column chunk, (b) exclusive scan
+// two launches (k_hits_totals, k_hits_write); dense counter buffers take three passes: (a) hits per 2048-column chunk, (b) exclusive scan
 // over chunks, (c) ordered write.  Colours ascend within a sequence
 // (exact_filter's np.where order, graph/bigsi.py:193-204; inexact_filter's dict order before its stable sort, :215-229).
 constexpr uint32_t kAllShards = 0xFFFFFFFFu;
@@ -1058,23 +1058,50 @@ __device__ __forceinline__ uint64_t chunk_index(uint32_t q, uint32_t shard, uint
     return ((uint64_t)q * n_shards + shard) * chunks + chunk;
 }
 
-// K4 in ONE launch for bit-vector inputs (the AND bitmap of an exact search, the hit mask of a thresholded one): count,
-// scan and ordered write fused.  Workgroup g owns the `ipb` consecutive items [g * ipb, +ipb) of the (seq, shard, chunk)
-// order; the host picks ipb so that the grid never exceeds kHitsMaxGroups workgroups -- fewer than the chip holds at once
-// (256 CUs x 8 of these workgroups), so every workgroup becomes resident no matter in which order the hardware dispatches
-// them or what else is draining from the CUs, and waiting for the others' totals cannot deadlock.
-//   pass 1  the group's hit total -> published as ONE 64-bit word {generation, total + 1} by an agent-scope store (flag and
-//           payload in one granule: never seen apart; words of earlier launches carry another generation and read as
-//           "not yet": no memset between launches);
-//   scan    every thread polls the words of a share of the PRECEDING groups (all loads in flight at once) and the
-//           workgroup sums them: the exclusive prefix, one round trip instead of a chain of look-back steps;
-//   pass 2  item by item (the words come back out of L2), ordered write of (colour, count).
+// K4 for bit-vector inputs (the AND bitmap of an exact search, the hit mask of a thresholded one) in TWO launches and no
+// waiting between workgroups.  Workgroup g owns the `ipb` consecutive items [g * ipb, +ipb) of the (seq, shard, chunk) order;
+// the host picks ipb so that the grid is at most kHitsMaxGroups workgroups.
+//   k_hits_totals  the group's hit total -> totals[g];
+//   k_hits_write   every thread loads a share of the totals of the PRECEDING groups (plain loads: the launch boundary has made
+//                  them visible), the workgroup sums them -- the exclusive prefix in one round trip -- and writes its items'
+//                  (colour, count) in order (the words come back out of L2).
+// Round 2 fused the two into one launch whose workgroups published their totals and spun on those of their predecessors:
+// 7 us instead of 14 at BASELINE configs[1], but correct only while every workgroup of the grid was resident -- an assumption
+// about the dispatcher and about whatever else runs on the device (other streams, other processes) that nothing enforces.
+// The launch boundary costs ~5 us per batch (0.5 % of a 1 ms step at configs[3] / [4]; batches of reads do not come here, they
+// write their hits from k_reads_fused) and removes the only unbounded wait the library had.
 constexpr uint32_t kHitsMaxGroups = 1024;
 __device__ __forceinline__ uint64_t lb_pack(uint32_t gen, uint64_t value) { return ((uint64_t)gen << 44) | (value + 1); }
+constexpr uint64_t kLbPoison = (1ull << 44) - 1;      // value field of a state word that says "the launch is being abandoned"
 
-__global__ __launch_bounds__(kBlock) void k_hits_fused(
+__device__ __forceinline__ uint64_t hits_word(const uint64_t *__restrict__ bitmaps, uint64_t stride_words, uint32_t wv, uint32_t n_seqs,
+                                              uint32_t n_shards, uint32_t chunks, uint64_t ci, uint32_t *w_out)
+{
+    const uint32_t chunk = (uint32_t)(ci % chunks);
+    const uint64_t sq = ci / chunks;
+    const uint32_t shard = (uint32_t)(sq % n_shards), q = (uint32_t)(sq / n_shards);
+    const uint32_t w = chunk * kBlock + threadIdx.x;   // one 64-column word per thread
+    *w_out = w;
+    return w < wv ? bitmaps[((uint64_t)shard * n_seqs + q) * stride_words + w] : 0ull;
+}
+
+__global__ __launch_bounds__(kBlock) void k_hits_totals(
     const uint64_t *__restrict__ bitmaps, uint64_t stride_words, uint32_t wv, uint32_t n_seqs, uint32_t n_shards, uint32_t chunks,
-    uint64_t shard_cols, const uint32_t *__restrict__ num_unique, uint32_t ipb, uint64_t *__restrict__ state, uint32_t gen,
+    uint32_t ipb, uint32_t *__restrict__ totals)
+{
+    __shared__ uint32_t lds[16];
+    const uint64_t grp = blockIdx.x, n_items = (uint64_t)n_seqs * n_shards * chunks;
+    const uint64_t i0 = grp * ipb, i1 = i0 + ipb < n_items ? i0 + ipb : n_items;
+    uint32_t mine = 0, w_unused;
+    for (uint64_t ci = i0; ci < i1; ci++) mine += (uint32_t)__popcll(hits_word(bitmaps, stride_words, wv, n_seqs, n_shards, chunks, ci, &w_unused));
+    uint32_t gtot;
+    block_exclusive_scan(mine, &gtot, lds);
+    if (threadIdx.x == 0) totals[grp] = gtot;
+}
+
+__global__ __launch_bounds__(kBlock) void k_hits_write(
+    const uint64_t *__restrict__ bitmaps, uint64_t stride_words, uint32_t wv, uint32_t n_seqs, uint32_t n_shards, uint32_t chunks,
+    uint64_t shard_cols, const uint32_t *__restrict__ num_unique, uint32_t ipb, const uint32_t *__restrict__ totals,
     uint64_t *__restrict__ hit_off, uint32_t *__restrict__ hit_col, uint32_t *__restrict__ hit_cnt, uint64_t capacity,
     const void *__restrict__ counters, uint32_t counter_bytes, uint64_t counter_stride, uint32_t own_shard)
 {
@@ -1082,31 +1109,9 @@ __global__ __launch_bounds__(kBlock) void k_hits_fused(
     __shared__ uint64_t lds64[kBlock / 64];
     const uint64_t grp = blockIdx.x, n_items = (uint64_t)n_seqs * n_shards * chunks;
     const uint64_t i0 = grp * ipb, i1 = i0 + ipb < n_items ? i0 + ipb : n_items;
-    auto word_of = [&](uint64_t ci, uint32_t *w_out) -> uint64_t {
-        const uint32_t chunk = (uint32_t)(ci % chunks);
-        const uint64_t sq = ci / chunks;
-        const uint32_t shard = (uint32_t)(sq % n_shards), q = (uint32_t)(sq / n_shards);
-        const uint32_t w = chunk * kBlock + threadIdx.x;   // one 64-column word per thread
-        *w_out = w;
-        return w < wv ? bitmaps[((uint64_t)shard * n_seqs + q) * stride_words + w] : 0ull;
-    };
-    // pass 1: the group's total
-    uint32_t mine = 0, w_unused;
-    for (uint64_t ci = i0; ci < i1; ci++) mine += (uint32_t)__popcll(word_of(ci, &w_unused));
-    uint32_t gtot;
-    block_exclusive_scan(mine, &gtot, lds);
-    if (threadIdx.x == 0) __hip_atomic_store(&state[grp], lb_pack(gen, gtot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // scan: totals of all preceding groups
+    // totals of all preceding groups
     uint64_t part = 0;
-    for (uint64_t j = threadIdx.x; j < grp; j += kBlock) {
-        uint64_t word;
-        for (;;) {
-            word = __hip_atomic_load(&state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((uint32_t)(word >> 44) == gen && (word & ((1ull << 44) - 1)) != 0) break;
-            __builtin_amdgcn_s_sleep(1);
-        }
-        part += (word & ((1ull << 44) - 1)) - 1;
-    }
+    for (uint64_t j = threadIdx.x; j < grp; j += kBlock) part += totals[j];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
     if ((threadIdx.x & 63u) == 0) lds64[threadIdx.x >> 6] = part;
@@ -1114,11 +1119,11 @@ __global__ __launch_bounds__(kBlock) void k_hits_fused(
     uint64_t base = 0;
 #pragma unroll
     for (int i = 0; i < kBlock / 64; i++) base += lds64[i];
-    if (threadIdx.x == 0 && i1 == n_items) hit_off[n_seqs] = base + gtot;
-    // pass 2: ordered write
+    if (threadIdx.x == 0 && i1 == n_items) hit_off[n_seqs] = base + totals[grp];
+    // ordered write
     for (uint64_t ci = i0; ci < i1; ci++) {
         uint32_t w;
-        const uint64_t bits = word_of(ci, &w);
+        const uint64_t bits = hits_word(bitmaps, stride_words, wv, n_seqs, n_shards, chunks, ci, &w);
         const uint32_t cnt = (uint32_t)__popcll(bits);
         uint32_t tot;
         const uint32_t pre = block_exclusive_scan(cnt, &tot, lds);
@@ -1151,7 +1156,7 @@ __global__ __launch_bounds__(kBlock) void k_hits_fused(
 // fits one workgroup's lanes (<= 512 words) and the batch has at most kHitsMaxGroups queries, ONE workgroup per query does
 // the whole path: wavefront 0 k-merises / dedupes / hashes exactly as k_kmerize_wave does (and leaves the same arrays in
 // global memory for lookup / presence / fetch_rows), the row ids go to the other wavefronts through LDS, all of them
-// stream and AND (or count) the rows, and the hit list is written through k_hits_fused's scan -- the workgroup publishes its
+// stream and AND (or count) the rows, and the hit list is written through a publish-and-sum scan -- the workgroup publishes its
 // total and sums those of the queries before it (the grid is co-resident by construction).  Same results, one launch.
 constexpr int kReadsSection = 1024;           // queries whose hit totals a workgroup of k_reads_fused sums directly
 constexpr uint32_t kReadsMaxSeqs = 1u << 20;  // queries per launch of k_reads_fused at most
@@ -1369,7 +1374,10 @@ __global__ __launch_bounds__(kBlock) void k_reads_fused(
     auto wait_for = [&](const uint64_t *w) -> uint64_t {
         for (;;) {
             const uint64_t word = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((uint32_t)(word >> 44) == gen && (word & ((1ull << 44) - 1)) != 0) return (word & ((1ull << 44) - 1)) - 1;
+            if ((uint32_t)(word >> 44) == gen && (word & ((1ull << 44) - 1)) != 0) {
+                if ((word & ((1ull << 44) - 1)) == kLbPoison) { gave_up = true; return 0; }      // a section before this one gave up: so do we, at once
+                return (word & ((1ull << 44) - 1)) - 1;
+            }
             if (gave_up || wall_clock64() - t_wait > spin_timeout) { gave_up = true; return 0; }
             __builtin_amdgcn_s_sleep(1);
         }
@@ -1379,7 +1387,13 @@ __global__ __launch_bounds__(kBlock) void k_reads_fused(
     for (uint32_t j = first + threadIdx.x; j < q; j += kBlock) part += wait_for(&state[j]);
     if (threadIdx.x == 0 && section) part += wait_for(&state[n_seqs + section]);
     if (__syncthreads_or(gave_up ? 1 : 0)) {
-        if (threadIdx.x == 0) hit_off[n_seqs + 1] = gen;
+        if (threadIdx.x == 0) {
+            hit_off[n_seqs + 1] = gen;
+            // the section's last workgroup owes the later sections a running total: hand them a poison word instead, so that they
+            // leave at once rather than each waiting out its own timeout (the launch is repeated anyway)
+            if (q + 1 == first + kReadsSection)
+                __hip_atomic_store(&state[n_seqs + section + 1], ((uint64_t)gen << 44) | kLbPoison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         return;
     }
 #pragma unroll
@@ -1839,6 +1853,26 @@ __global__ __launch_bounds__(kBlock) void k_score_packed(
     bigsi_score::HitScore rec;
     bigsi_score::score_hit([w](uint32_t k) { return by_column(w[k]); }, hit_n[t], found ? found[t] : 0u, unique ? unique[t] : 0u, &rec);
     out[dest ? dest[t] : t] = rec;
+}
+
+// ------------------------------------------------------------------------------ results of a run -> pinned host memory
+// What BIGSI.search needs back from a run -- per query: k-mers, unique k-mers, min_kmers, hit offsets; the first `spec` hits --
+// written by ONE small kernel straight into a block of pinned host memory the batch owns:
+//   [hit_off: n_seqs + 2 uint64 | num_kmers, num_unique, min_kmers: 3 n_seqs uint32 | pad to 8 | colours: spec uint32 | counts: spec uint32]
+// instead of three or four device-to-host copies, each with its own ~10 us of latency and a synchronisation: a call then waits
+// ONCE, for this kernel's event.  Word n_seqs + 1 of hit_off is the mark of a one-launch read run that gave up (0 otherwise).
+__global__ __launch_bounds__(kBlock) void k_export_results(
+    const uint64_t *__restrict__ hit_off, uint32_t n_seqs, uint32_t with_mark, const uint32_t *__restrict__ uniq,
+    const uint32_t *__restrict__ col, const uint32_t *__restrict__ cnt, uint32_t spec, uint64_t *out)
+{
+    const uint32_t tid = blockIdx.x * kBlock + threadIdx.x, nt = gridDim.x * kBlock;
+    const uint64_t total = hit_off[n_seqs];
+    const uint32_t m = (uint32_t)(total < spec ? total : spec);
+    for (uint32_t i = tid; i < n_seqs + 2u; i += nt) out[i] = i <= n_seqs ? hit_off[i] : (with_mark ? hit_off[i] : 0ull);
+    uint32_t *o32 = reinterpret_cast<uint32_t *>(out + n_seqs + 2u);
+    for (uint32_t i = tid; i < 3u * n_seqs; i += nt) o32[i] = uniq[i];
+    uint32_t *ocol = o32 + ((3u * n_seqs + 1u) & ~1u), *ocnt = ocol + spec;
+    for (uint32_t i = tid; i < m; i += nt) { ocol[i] = col[i]; ocnt[i] = cnt[i]; }
 }
 
 // ------------------------------------------------------------------------------ storage contract helpers

@@ -90,6 +90,9 @@ int need_rccl(RcclApi **out)
     } while (0)
 
 // ------------------------------------------------------------------------------ one-call search
+// The workspace stages tables + sequences in pinned memory; the run uploads them on its own stream, ahead of its first kernel;
+// a small kernel exports what the caller gets back into pinned memory; the host waits ONCE.  (Round 2: two synchronous uploads
+// and three synchronous downloads -- 77-84 us for one read, 138 us for 1000 reads of 61 bp, of which the kernels were 10-25.)
 extern "C" int bigsi_hip_search_batch(bigsi_hip_index *ix, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k,
                                       double threshold, uint32_t flags, uint32_t *num_kmers, uint32_t *num_unique, uint32_t *min_kmers,
                                       uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t hit_capacity)
@@ -98,17 +101,89 @@ extern "C" int bigsi_hip_search_batch(bigsi_hip_index *ix, const char *seqs, con
     if (!ix) return fail(BIGSI_ERR_INVALID, "NULL index");
     // the index keeps ONE workspace for this entry point (a caller in a loop pays its ~20 device allocations once; the
     // workspace goes with the index, or right away if a call fails)
-    if (!ix->search_ws) TRY(bigsi_hip_batch_create(ix, seqs, offsets, n_seqs, k, &ix->search_ws));
-    else TRY(bigsi_hip_batch_reload(ix->search_ws, seqs, offsets, n_seqs, k));
+    TRY(bigsi_batch_stage(ix, &ix->search_ws, seqs, offsets, n_seqs, k));
     bigsi_hip_batch *b = ix->search_ws;
     int rc = bigsi_hip_batch_run(b, threshold, (flags & ~BIGSI_RUN_SKIP_COMPACT) | BIGSI_RUN_SPARSE_COUNTS);
-    if (rc == BIGSI_OK) rc = bigsi_hip_batch_fetch_unique(b, num_kmers, num_unique, min_kmers);
-    if (rc == BIGSI_OK) rc = bigsi_hip_batch_fetch_hits(b, hit_offsets, colours, counts, hit_capacity);
+    if (rc == BIGSI_OK) rc = bigsi_batch_export(b);
+    if (rc == BIGSI_OK) rc = bigsi_batch_collect(b, num_kmers, num_unique, min_kmers, hit_offsets, colours, counts, hit_capacity);
     if (rc != BIGSI_OK && rc != BIGSI_ERR_CAPACITY) {      // (a too small hit buffer is the caller's to retry: offsets are filled in)
         ix->search_ws = nullptr;
         bigsi_hip_batch_destroy(b);      // leaves the thread's error message of the failed call above in place
     }
     return rc;
+}
+
+// BIGSI.search for ANY number of sequences in one call (bulk_search, bigsi/__main__.py:261-314, pays per query what this pays
+// per call): the library cuts the input into device batches of about 2^19 k-mer positions, keeps three workspaces in flight --
+// while one batch runs, the next is staged and uploaded and the results of the one before are exported and copied out -- and
+// writes every sequence's results at its place in the caller's arrays (hit_offsets are global: n_seqs + 1 entries).
+// BIGSI_ERR_CAPACITY (hit_offsets complete, colours / counts filled as far as they fit) when hit_capacity is too small.
+extern "C" int bigsi_hip_search_stream(bigsi_hip_index *ix, const char *seqs, const uint64_t *offsets, uint64_t n_seqs, uint32_t k,
+                                       double threshold, uint32_t flags, uint32_t *num_kmers, uint32_t *num_unique, uint32_t *min_kmers,
+                                       uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t hit_capacity)
+{
+    if (!ix || !offsets || !hit_offsets) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    if (k == 0) return fail(BIGSI_ERR_INVALID, "k must be > 0");
+    hit_offsets[0] = 0;
+    if (n_seqs == 0) return BIGSI_OK;
+    constexpr int kSlots = 3;
+    constexpr uint64_t kChunkPositions = 1ull << 19, kChunkSeqs = 1ull << 15;
+    struct Chunk { uint64_t first; uint32_t n; };
+    Chunk inflight[kSlots] = {};
+    bool busy[kSlots] = {};
+    uint64_t total = 0;              // hits so far (global offset of the next chunk's first hit)
+    bool overflow = false;
+    std::vector<uint64_t> rel;
+    auto collect = [&](int s) -> int {
+        const Chunk c = inflight[s];
+        busy[s] = false;
+        rel.resize(c.n + 1ull);
+        const uint64_t room = total < hit_capacity ? hit_capacity - total : 0;
+        int rc = bigsi_batch_collect(ix->stream_ws[s], num_kmers ? num_kmers + c.first : nullptr, num_unique ? num_unique + c.first : nullptr,
+                                     min_kmers ? min_kmers + c.first : nullptr, rel.data(), colours ? colours + total : nullptr,
+                                     counts ? counts + total : nullptr, overflow ? 0 : room);
+        if (rc == BIGSI_ERR_CAPACITY) { overflow = true; rc = BIGSI_OK; }
+        if (rc != BIGSI_OK) return rc;
+        for (uint32_t i = 1; i <= c.n; i++) hit_offsets[c.first + i] = total + rel[i];
+        total += rel[c.n];
+        return BIGSI_OK;
+    };
+    int rc = BIGSI_OK;
+    uint64_t next = 0;
+    int slot = 0;
+    while (next < n_seqs && rc == BIGSI_OK) {
+        // the next chunk: up to kChunkPositions k-mer positions, at least one sequence
+        uint64_t end = next, pos = 0;
+        while (end < n_seqs && end - next < kChunkSeqs) {
+            if (offsets[end + 1] < offsets[end]) return fail(BIGSI_ERR_INVALID, "offsets must be non-decreasing");
+            const uint64_t len = offsets[end + 1] - offsets[end], n = len >= k ? len - k + 1 : 0;
+            if (end > next && pos + n > kChunkPositions) break;
+            pos += std::max<uint64_t>(n, 1);
+            end++;
+        }
+        if (busy[slot]) rc = collect(slot);                    // this workspace's previous chunk (two chunks ago)
+        if (rc != BIGSI_OK) break;
+        rc = bigsi_batch_stage(ix, &ix->stream_ws[slot], seqs, offsets + next, (uint32_t)(end - next), k);
+        if (rc == BIGSI_OK) rc = bigsi_hip_batch_run(ix->stream_ws[slot], threshold, (flags & ~BIGSI_RUN_SKIP_COMPACT) | BIGSI_RUN_SPARSE_COUNTS);
+        if (rc == BIGSI_OK) rc = bigsi_batch_export(ix->stream_ws[slot]);
+        if (rc != BIGSI_OK) break;
+        inflight[slot] = Chunk{next, (uint32_t)(end - next)};
+        busy[slot] = true;
+        next = end;
+        slot = (slot + 1) % kSlots;
+    }
+    // drain in submission order
+    for (int i = 0; i < kSlots && rc == BIGSI_OK; i++) {
+        const int s2 = (slot + i) % kSlots;
+        if (busy[s2]) rc = collect(s2);
+    }
+    if (rc != BIGSI_OK) {
+        for (auto &w : ix->stream_ws)
+            if (w) { bigsi_hip_batch_destroy(w); w = nullptr; }
+        return rc;
+    }
+    if (overflow) return fail(BIGSI_ERR_CAPACITY, "hit buffers hold %llu entries, %llu needed", (unsigned long long)hit_capacity, (unsigned long long)total);
+    return BIGSI_OK;
 }
 
 // ------------------------------------------------------------------------------ communicators

@@ -331,7 +331,7 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
 
     @staticmethod
     def _stream_loop(it, take, batch_size, batch_kmers, k, submit, done):
-        from itertools import islice
+        from itertools import chain, islice
         pending, slot = None, 0
         while True:
             chunk = list(islice(it, take))
@@ -347,6 +347,15 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
                     chunk += more
                     held = sum(map(len, chunk)) - (k - 1) * len(chunk)
                     held = max(held, len(chunk))
+                if held > batch_kmers and len(chunk) > 1:
+                    # the slice length follows the sequences seen so far; when they grow along the stream (reads first, genomes
+                    # later) a slice can hold thousands of times the target: cut it at the sequence that reaches batch_kmers and
+                    # hand the rest back to the iterator, so that a batch never exceeds the target by more than one sequence
+                    csum = np.cumsum(np.maximum(np.fromiter(map(len, chunk), dtype=np.int64, count=len(chunk)) - (k - 1), 1))
+                    cut = int(np.searchsorted(csum, batch_kmers, side="left")) + 1
+                    if cut < len(chunk):
+                        it = chain(chunk[cut:], it)
+                        chunk = chunk[:cut]
                 take = len(chunk)
             nxt = submit(chunk, slot)
             if pending is not None:

@@ -228,6 +228,12 @@ class HipHbmStorage(BaseStorage):
         self.name = self.storage_config.get("name", "default")
         _lib.lib()    # fail loudly, here, if the HIP library has not been built
         res = _RESIDENT.get(self.name)
+        if res is not None and self.storage_config.get("replace"):
+            # storage-config {"replace": true}: whatever is resident under this name is dropped first (what building over an
+            # existing BerkeleyDB file does in the reference) -- the way to give a long-lived process a different index under
+            # the same name without recreating the old config just to delete it
+            HipHbmStorage.drop(self.name)
+            res = None
         if res is not None and res.ix is None and not res.kv and not res.pending:
             res.__init__(self.storage_config)       # an emptied (deleted) store: the name is free to describe something else
         elif res is not None:
@@ -290,6 +296,16 @@ class HipHbmStorage(BaseStorage):
             return True
         except KeyError:
             return False
+
+    @staticmethod
+    def drop(name="default"):
+        """Free the resident index called `name` (device memory and host keys; its snapshot file, if any, stays) whatever
+        configuration it was created with.  True if there was one."""
+        res = _RESIDENT.pop(name, None)
+        if res is None:
+            return False
+        res.free()
+        return True
 
     def delete_all(self):
         """BaseStorage.delete_all (bigsi/storage/base.py:132-133; berkeleydb.py removes the file): the resident index AND its
@@ -446,7 +462,7 @@ class HipHbmStorage(BaseStorage):
             col, cnt = np.zeros(cap, np.uint32), np.zeros(cap, np.uint32)
             rc = fn(self.handle, blob, _lib.ptr(soff), n, int(k), float(threshold), 0, _lib.ptr(nk), _lib.ptr(nu), None,
                     _lib.ptr(off), _lib.ptr(col), _lib.ptr(cnt), cap)
-            if rc != _lib.ERR_CAPACITY:
+            if rc != _lib.ERR_CAPACITY or int(off[-1]) <= cap:      # (any other CAPACITY error -- a result wider than the row stride -- is not ours to retry)
                 break
             cap = self._search_cap = int(off[-1])             # offsets are filled in: bring that much next time
         check(rc)
@@ -526,7 +542,7 @@ class QueryBatch(object):
             col = np.zeros(cap, np.uint32)
             cnt = np.zeros(cap, np.uint32)
             rc = self._fn("fetch_hits")(self.b, _lib.ptr(off), _lib.ptr(col), _lib.ptr(cnt), cap)
-            if rc == _lib.ERR_CAPACITY:
+            if rc == _lib.ERR_CAPACITY and int(off[-1]) > cap:
                 cap = int(off[-1])
                 continue
             check(rc)

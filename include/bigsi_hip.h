@@ -308,6 +308,16 @@ int bigsi_hip_search_batch(bigsi_hip_index *ix, const char *seqs, const uint64_t
                            double threshold, uint32_t flags, uint32_t *num_kmers, uint32_t *num_unique, uint32_t *min_kmers,
                            uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t hit_capacity);
 
+/* BIGSI.search for ANY number of sequences in one call -- what bulk_search (bigsi/__main__.py:261-314) does with a fork pool and one
+ * BIGSI.search per query.  The library cuts the input into device batches (about 2^19 k-mer positions each), keeps three
+ * workspaces in flight -- while one batch runs, the next is staged and uploaded and the results of the one before are exported and
+ * copied out: pinned staging, asynchronous copies, one wait per batch -- and writes each sequence's results at its place in the
+ * caller's arrays.  Outputs as bigsi_hip_search_batch with n_seqs-long arrays; hit_offsets (n_seqs + 1 entries) index colours /
+ * counts globally.  BIGSI_ERR_CAPACITY (hit_offsets complete, lists filled as far as they fit) when hit_capacity is too small. */
+int bigsi_hip_search_stream(bigsi_hip_index *ix, const char *seqs, const uint64_t *offsets, uint64_t n_seqs, uint32_t k,
+                            double threshold, uint32_t flags, uint32_t *num_kmers, uint32_t *num_unique, uint32_t *min_kmers,
+                            uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t hit_capacity);
+
 /* ================================================================== MULTI-GPU: column shards, the exchange (RCCL over xGMI)
  * An index too wide for one GPU is split by COLUMN RANGE: shard g holds all num_rows rows of columns
  * [g * shard_cols, (g+1) * shard_cols).  Every shard runs K1-K3 on the same queries; the only exchange is one

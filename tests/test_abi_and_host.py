@@ -422,3 +422,22 @@ def check_records_against_golden_and_scalar(score_fn):
 def test_k6_scoring_header_vs_golden_scores_and_scalar_scorer(tmp_path):
     lib = build_score_host(tmp_path)
     check_records_against_golden_and_scalar(lambda strings, found, unique: score_strings_on_host(lib, strings, found, unique))
+
+
+def test_search_stream_batches_stay_bounded_when_sequences_grow_along_the_stream():
+    """search_stream sizes its slices by the sequences seen so far; reads followed by genome-length sequences used to give a
+    batch of ~1e9 k-mers (tens of GB of row ids).  Every batch must stay within batch_kmers + one sequence, order preserved."""
+    from bigsi_amd.graph.bigsi import BIGSI
+    sizes = []
+
+    def submit(chunk, slot):
+        sizes.append(sum(max(len(s) - 30, 1) for s in chunk))
+        return None, chunk
+
+    seqs = ["A" * 61] * 40000 + ["C" * 100000] * 300 + ["G" * 61] * 1000 + ["T" * 5000] * 300
+    out = list(BIGSI._stream_loop(iter(seqs), 64, None, 1 << 19, 31, submit, lambda p: [[] for _ in p[1]]))
+    assert [s for s, _ in out] == seqs
+    assert max(sizes) <= (1 << 19) + 100000 and len(sizes) < 200
+    sizes.clear()
+    out = list(BIGSI._stream_loop(iter(seqs[:1000]), 10, 10, 1 << 19, 31, submit, lambda p: [[] for _ in p[1]]))     # explicit batch_size: untouched
+    assert len(sizes) == 100 and [s for s, _ in out] == seqs[:1000]

@@ -1477,3 +1477,67 @@ def test_search_stream_arrays_equals_search(hip):
                 seen += 1
         assert seen == len(qs)
     b.delete()
+
+
+def test_k4_of_several_indexes_beside_a_saturating_row_and_kernel(hip):
+    """K4 (threshold + compaction) used to publish workgroup totals and spin on its predecessors' -- correct only while its whole
+    grid was resident.  It is two launches without any waiting now; this runs what would have been the dangerous mix: one index
+    streaming a long exact batch (every CU busy) while three other indexes -- each with a stream of its own -- compact
+    thresholded batches with thousands of hits at the same time.  All hit lists against the oracle."""
+    from oracle.ref_model import SynthOracle
+    rng = np.random.default_rng(21)
+    big_c, big = synth_index(hip, 400_000, 60_000, 3, 5)
+    long_seqs = random_seqs(rng, 1500, 1000, 1000)
+    big_batch = big.new_batch(long_seqs, 31)
+    small = []
+    for j in range(3):
+        m, n_cols, h = 30_011 + 1000 * j, 20_000 + 777 * j, 3
+        c, st = synth_index(hip, m, n_cols, h, 30 + j, draws=1)
+        seqs = random_seqs(rng, 40, 45, 120)
+        small.append((st, SynthOracle(30 + j, 0, m, n_cols, h, 31, 1), seqs, st.new_batch(seqs, 31)))
+    for rounds in range(3):
+        big_batch.run(1.0)                                     # ~10 ms of row streaming on the big index's stream
+        for st, orc, seqs, batch in small:
+            batch.run(0.3)                                     # P=6/10 counting + K4 with many hits, beside it
+        for st, orc, seqs, batch in small:
+            _, nu, mk = batch.unique()
+            off, colours, counts = batch.hits()
+            assert int(off[-1]) > 1000
+            for i, s in enumerate(seqs):
+                u, cnt = orc.counts(s)
+                want = np.flatnonzero(cnt >= mk[i])
+                lo, hi = int(off[i]), int(off[i + 1])
+                assert nu[i] == u and np.array_equal(colours[lo:hi], want) and np.array_equal(counts[lo:hi], cnt[want].astype(np.uint32)), (rounds, i)
+        off, colours, _ = big_batch.hits()
+        assert int(off[-1]) == 0 or colours.size == int(off[-1])
+    big_batch.close()
+    big.delete_all()
+    for st, _, _, batch in small:
+        batch.close()
+        st.delete_all()
+
+
+def test_replace_and_drop_free_a_resident_index_of_another_shape(hip):
+    """One name = one resident index, and a second config under the same name must describe the same thing (BigsiHipError);
+    storage-config {"replace": true} and HipHbmStorage.drop(name) are the ways out for a long-lived process."""
+    from bigsi_amd._lib import BigsiHipError
+    from bigsi_amd.storage import get_storage
+    from bigsi_amd.storage.hip_hbm import HipHbmStorage
+    a = cfg(31, 1009, 3, name="same_name", max_cols=64)
+    st = get_storage(a)
+    st.delete_all()
+    for key, v in (("number_of_rows", 1009), ("number_of_cols", 10), ("ksi:bloomfilter_size", 1009), ("ksi:num_hashes", 3)):
+        st.set_integer(key, v)
+    st.fill_synthetic(1, 0, 1)
+    b = cfg(31, 2003, 4, name="same_name", max_cols=64)
+    b["storage-config"]["m"], b["storage-config"]["h"] = 2003, 4
+    a["storage-config"]["m"], a["storage-config"]["h"] = 1009, 3
+    st2 = get_storage(a)
+    assert st2.get_integer("number_of_rows") == 1009
+    with pytest.raises(BigsiHipError):
+        get_storage(b)
+    b["storage-config"]["replace"] = True
+    st3 = get_storage(b)
+    with pytest.raises(KeyError):
+        st3.get_integer("number_of_rows")                       # a fresh, empty store under the old name
+    assert HipHbmStorage.drop("same_name") is True and HipHbmStorage.drop("same_name") is False
