@@ -524,9 +524,47 @@ def main():
         for w_ in ws:
             w_.close()
 
-    host_visible = {"two_workspace_loop_kmer_lookups_per_s": pcie_rate,
-                    "what": "sequences in host memory -> upload -> run -> hit lists in host memory (SURVEY 8d(1)); never `value`, which is "
-                            "quoted with the batch resident in HBM"}
+    # host-visible figures of the C boundary (wall time of the call, host sequences in, host hit lists out; never
+    # `value`, which is quoted with the batch resident in HBM):
+    #   stream     ONE bigsi_hip_search_stream call over several of the step's batches (the library pipelines its own chunks)
+    #   one_call   bigsi_hip_search_batch latency for the step's first batch (if it is a batch of reads) and for a single query
+    host_visible = {"two_workspace_loop_kmer_lookups_per_s": pcie_rate}
+    if world == 1 and not args.force_dist:
+        lib_ = _lib.lib()
+        want = 64 if w["batch"] * w["qlen"] < (1 << 17) else (8 if w["batch"] * w["qlen"] < (1 << 20) else 2)
+        many = [s_ for i in range(want) for s_ in all_seqs[i % nb]]
+        blob, soff = _lib.pack_seqs(many)
+        n_many = len(many)
+        hnk, hnu, hoff = np.zeros(n_many, np.uint32), np.zeros(n_many, np.uint32), np.zeros(n_many + 1, np.uint64)
+        hcap = max(int(off[-1]) * want * 2, 1 << 16)
+        hcol, hcnt = np.zeros(hcap, np.uint32), np.zeros(hcap, np.uint32)
+
+        def stream_call():
+            t_ = time.perf_counter()
+            check(lib_.bigsi_hip_search_stream(st.handle, blob, _lib.ptr(soff), n_many, args.k, float(thr), 0, _lib.ptr(hnk), _lib.ptr(hnu), None,
+                                               _lib.ptr(hoff), _lib.ptr(hcol), _lib.ptr(hcnt), hcap))
+            return time.perf_counter() - t_
+        stream_call()
+        times = sorted(stream_call() for _ in range(5))
+        assert np.array_equal(hnu[: w["batch"]], nu) and int(hoff[w["batch"]]) == int(off[-1])      # the first batch again, same answers
+        host_visible["stream"] = {"kmer_lookups_per_s": float(hnu.sum()) / times[len(times) // 2], "best": float(hnu.sum()) / times[0],
+                                  "sequences": n_many, "sequence_bytes": len(blob), "hits": int(hoff[-1]), "call_ms": times[len(times) // 2] * 1e3,
+                                  "entry": "bigsi_hip_search_stream (one call; median of 5)"}
+
+        def one_call(seq_list, reps):
+            bl, so = _lib.pack_seqs(seq_list)
+            n_ = len(seq_list)
+            a_, b_, c_ = np.zeros(n_, np.uint32), np.zeros(n_, np.uint32), np.zeros(n_ + 1, np.uint64)
+            ts = []
+            for _ in range(reps + 3):
+                t_ = time.perf_counter()
+                check(lib_.bigsi_hip_search_batch(st.handle, bl, _lib.ptr(so), n_, args.k, float(thr), 0, _lib.ptr(a_), _lib.ptr(b_), None,
+                                                  _lib.ptr(c_), _lib.ptr(hcol), _lib.ptr(hcnt), hcap))
+                ts.append(time.perf_counter() - t_)
+            return float(np.median(ts[3:]) * 1e6)
+        host_visible["one_call_us"] = {"single_query": one_call(seqs[1:2], 100), "entry": "bigsi_hip_search_batch (the C call, median of 100)"}
+        if w["batch"] * w["qlen"] < (1 << 17):
+            host_visible["one_call_us"]["whole_batch_of_%d" % w["batch"]] = one_call(seqs, 100)
 
     # HBM traffic of this kernel on this workload, when a PMC pass for it has been committed (PMC counters cannot be
     # collected from inside the timed run; see profiles/)

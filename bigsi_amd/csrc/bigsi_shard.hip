@@ -114,7 +114,7 @@ extern "C" int bigsi_hip_search_batch(bigsi_hip_index *ix, const char *seqs, con
 }
 
 // BIGSI.search for ANY number of sequences in one call (bulk_search, bigsi/__main__.py:261-314, pays per query what this pays
-// per call): the library cuts the input into device batches of about 2^19 k-mer positions, keeps three workspaces in flight --
+// per call): the library cuts the input into device batches of about 2^20 k-mer positions, keeps three workspaces in flight --
 // while one batch runs, the next is staged and uploaded and the results of the one before are exported and copied out -- and
 // writes every sequence's results at its place in the caller's arrays (hit_offsets are global: n_seqs + 1 entries).
 // BIGSI_ERR_CAPACITY (hit_offsets complete, colours / counts filled as far as they fit) when hit_capacity is too small.
@@ -127,7 +127,7 @@ extern "C" int bigsi_hip_search_stream(bigsi_hip_index *ix, const char *seqs, co
     hit_offsets[0] = 0;
     if (n_seqs == 0) return BIGSI_OK;
     constexpr int kSlots = 3;
-    constexpr uint64_t kChunkPositions = 1ull << 19, kChunkSeqs = 1ull << 15;
+    constexpr uint64_t kChunkPositions = 1ull << 20, kChunkSeqs = 1ull << 15;
     struct Chunk { uint64_t first; uint32_t n; };
     Chunk inflight[kSlots] = {};
     bool busy[kSlots] = {};

@@ -470,6 +470,33 @@ class HipHbmStorage(BaseStorage):
         return [(nk[i], nu[i], col[o[i]:o[i + 1]], cnt[o[i]:o[i + 1]]) for i in range(n)]
 
 
+    def search_many(self, seqs, k, threshold=1.0):
+        """bigsi_hip_search_stream: any number of sequences in ONE call -- the library cuts them into device batches and keeps three
+        in flight (upload / kernels / export overlap).  Returns (num_kmers, num_unique, hit_offsets, colours, counts): sequence i
+        matched colours[hit_offsets[i]:hit_offsets[i+1]] (ascending) with that many of its unique k-mers.  Single index only."""
+        assert threshold <= 1
+        seqs = seqs if isinstance(seqs, (list, tuple)) else list(seqs)
+        n = len(seqs)
+        nk, nu = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        off = np.zeros(n + 1, np.uint64)
+        if n == 0:
+            return nk, nu, off, np.zeros(0, np.uint32), np.zeros(0, np.uint32)
+        if self.res.is_group:
+            raise BigsiHipError(_lib.ERR_STATE, "search_many is not available on a multi-GPU index")
+        blob, soff = _lib.pack_seqs(seqs)
+        cap = max(self._search_cap, 1 << 12)
+        while True:
+            col, cnt = np.zeros(cap, np.uint32), np.zeros(cap, np.uint32)
+            rc = _lib.lib().bigsi_hip_search_stream(self.handle, blob, _lib.ptr(soff), n, int(k), float(threshold), 0, _lib.ptr(nk), _lib.ptr(nu), None,
+                                                    _lib.ptr(off), _lib.ptr(col), _lib.ptr(cnt), cap)
+            if rc != _lib.ERR_CAPACITY or int(off[-1]) <= cap:
+                break
+            cap = self._search_cap = int(off[-1])
+        check(rc)
+        total = int(off[-1])
+        return nk, nu, off, col[:total], cnt[:total]
+
+
 class QueryBatch(object):
     """A batch of query sequences staged on the device (bigsi_hip_batch)."""
 

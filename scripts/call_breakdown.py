@@ -36,12 +36,40 @@ def breakdown(st, label, nq, qlen, thr, reps=200):
     for i in range(reps):
         st.search_batch(sets[i % 8], 31, thr)
     print("%-28s thr=%.1f  search_batch (one call, Python wrapper included) %6.1f us" % (label, thr, (time.perf_counter() - t0) / reps * 1e6))
+    # the C entry point alone (arguments prepared once: what a non-Python binder pays)
+    from bigsi_amd import _lib
+    packs = [_lib.pack_seqs(s_) for s_ in sets]
+    nk, nu, off = np.zeros(nq, np.uint32), np.zeros(nq, np.uint32), np.zeros(nq + 1, np.uint64)
+    col, cnt = np.zeros(1 << 16, np.uint32), np.zeros(1 << 16, np.uint32)
+    fn = _lib.lib().bigsi_hip_search_batch
+    t0 = time.perf_counter()
+    for i in range(reps):
+        blob, soff = packs[i % 8]
+        _lib.check(fn(st.handle, blob, _lib.ptr(soff), nq, 31, float(thr), 0, _lib.ptr(nk), _lib.ptr(nu), None, _lib.ptr(off), _lib.ptr(col), _lib.ptr(cnt), col.size))
+    print("%-28s thr=%.1f  bigsi_hip_search_batch (the C call alone)            %6.1f us" % (label, thr, (time.perf_counter() - t0) / reps * 1e6))
     b.close()
 
 st = index(1_000_000, 10_000, 3)
 for thr in (1.0, 0.4):
     breakdown(st, "C2 index, 1 x 61 bp", 1, 61, thr)
     breakdown(st, "C2 index, 1000 x 61 bp", 1000, 61, thr)
+# host-visible streaming rate: 64 x 1000 reads in ONE bigsi_hip_search_stream call (host sequences in, host hit lists out)
+rng = np.random.default_rng(1)
+lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+many = [lut[r].tobytes().decode() for r in rng.integers(0, 4, size=(64_000, 61), dtype=np.uint8)]
+from bigsi_amd import _lib
+blob, soff = _lib.pack_seqs(many)
+nk, nu, off = np.zeros(len(many), np.uint32), np.zeros(len(many), np.uint32), np.zeros(len(many) + 1, np.uint64)
+col, cnt = np.zeros(1 << 20, np.uint32), np.zeros(1 << 20, np.uint32)
+for thr in (1.0, 0.4):
+    best = 1e9
+    for _ in range(6):
+        t0 = time.perf_counter()
+        _lib.check(_lib.lib().bigsi_hip_search_stream(st.handle, blob, _lib.ptr(soff), len(many), 31, thr, 0, _lib.ptr(nk), _lib.ptr(nu), None,
+                                                      _lib.ptr(off), _lib.ptr(col), _lib.ptr(cnt), col.size))
+        best = min(best, time.perf_counter() - t0)
+    print("C2 index, 64000 x 61 bp in one bigsi_hip_search_stream call thr=%.1f: %.2f ms = %.0f M k-mer lookups/s host-visible (%d hits)"
+          % (thr, best * 1e3, float(nu.sum()) / best / 1e6, int(off[-1])))
 st.delete_all()
 st = index(10_000_000, 100_000, 4)
 for thr in (1.0, 0.4):

@@ -1541,3 +1541,58 @@ def test_replace_and_drop_free_a_resident_index_of_another_shape(hip):
     with pytest.raises(KeyError):
         st3.get_integer("number_of_rows")                       # a fresh, empty store under the old name
     assert HipHbmStorage.drop("same_name") is True and HipHbmStorage.drop("same_name") is False
+
+
+def test_search_stream_entry_point_equals_batch_runs(hip):
+    """bigsi_hip_search_stream (any number of sequences in one call, three workspaces in flight, pinned staging + export kernel):
+    reads (the one-launch kernel, several chunks), gene-length queries (chunks cut by k-mer positions), a mix with sequences
+    shorter than k, and a hit buffer that is too small at first -- all equal to plain batch runs and to the oracle; the one-call
+    bigsi_hip_search_batch goes through the same staging and must agree too."""
+    from oracle.ref_model import SynthOracle
+    m, n_cols, h = 200_003, 9_000, 3
+    c, st = synth_index(hip, m, n_cols, h, 44, draws=1)
+    orc = SynthOracle(44, 0, m, n_cols, h, 31, 1)
+    rng = np.random.default_rng(8)
+    reads = random_seqs(rng, 70_000, 61, 61)                  # > 2 chunks of 2^15 sequences
+    genes = random_seqs(rng, 1300, 900, 1100)                 # > 2 chunks of 2^19 positions
+    mixed = random_seqs(rng, 300, 10, 200) + ["ACGT", ""] + random_seqs(rng, 50, 1000, 3000)
+    for col_, s_ in ((5, reads[3]), (8999, reads[40_000]), (77, genes[700]), (4000, mixed[320])):
+        st.insert_kmers(col_, [s_], 31)
+        orc.insert_kmers(col_, s_)
+    for seqs, thr in ((reads, 1.0), (reads[:40_000], 0.6), (genes, 1.0), (genes[:600], 0.45), (mixed, 0.5)):
+        st._search_cap = 4                                   # force the grow-and-retry protocol
+        nk, nu, off, col, cnt = st.search_many(seqs, 31, thr)
+        assert off[0] == 0 and int(off[-1]) == col.size == cnt.size
+        # against plain batches of 5000 sequences
+        pos = 0
+        for lo in range(0, len(seqs), 5000):
+            part = seqs[lo:lo + 5000]
+            b = st.new_batch(part, 31)
+            b.run(thr, sparse_counts=True)
+            bnk, bnu, _ = b.unique()
+            boff, bcol, bcnt = b.hits()
+            b.close()
+            assert np.array_equal(nk[lo:lo + len(part)], bnk) and np.array_equal(nu[lo:lo + len(part)], bnu)
+            assert np.array_equal(off[lo:lo + len(part) + 1].astype(np.int64) - int(off[lo]), boff.astype(np.int64))
+            assert np.array_equal(col[int(off[lo]):int(off[lo + len(part)])], bcol) and np.array_equal(cnt[int(off[lo]):int(off[lo + len(part)])], bcnt)
+            pos += len(part)
+        # sampled against the oracle
+        for i in list(range(0, len(seqs), max(len(seqs) // 25, 1))) + [len(seqs) - 1]:
+            u, want_cnt = orc.counts(seqs[i])
+            assert nu[i] == u
+            if u == 0:                  # (no k-mers: the reference raises; the device's answer is whatever plain batches give, checked above)
+                continue
+            want = np.flatnonzero(want_cnt >= (u if thr == 1.0 else int(np.ceil(u * thr))))
+            assert np.array_equal(col[int(off[i]):int(off[i + 1])], want), (thr, i)
+            assert np.array_equal(cnt[int(off[i]):int(off[i + 1])], want_cnt[want].astype(np.uint32))
+    assert int(off[-1]) > 0
+    # planted reads are found
+    nk, nu, off, col, cnt = st.search_many(reads, 31, 1.0)
+    assert 5 in col[int(off[3]):int(off[4])].tolist() and 8999 in col[int(off[40_000]):int(off[40_001])].tolist()
+    # the one-call entry point: same staging, one workspace
+    for part, thr in ((reads[:1000], 1.0), (reads[:1], 1.0), (genes[699:702], 0.45), (mixed, 0.5)):
+        res = st.search_batch(part, 31, thr)
+        nk2, nu2, off2, col2, cnt2 = st.search_many(part, 31, thr)
+        for i, (a, b_, c_, d_) in enumerate(res):
+            assert a == nk2[i] and b_ == nu2[i] and np.array_equal(c_, col2[int(off2[i]):int(off2[i + 1])]) and np.array_equal(d_, cnt2[int(off2[i]):int(off2[i + 1])])
+    st.delete_all()
