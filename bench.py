@@ -152,23 +152,34 @@ def self_launch(args):
 
 
 def cpu_baseline(args, w, cols_cpu, exact):
-    """oracle/cpu_baseline.py in a fresh subprocess (its fork pool must not inherit a HIP context): the C oracle
-    (reference-shaped port) on ONE core -- the reported `value` -- plus, for context, the reference's own
-    process-pool-over-sequences parallelism (bulk_search) on every physical core, best / median of three runs."""
-    cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--rows", str(min(w["rows"], args.cpu_rows)),
-           "--cols", str(cols_cpu), "--hashes", str(w["hashes"]), "--k", str(args.k), "--and-draws", str(args.and_draws),
-           "--seed", str(SEED), "--batch", str(min(w["batch"], 256)), "--qlen", str(w["qlen"]), "--exact", str(int(exact)),
-           "--seconds", str(max(args.cpu_seconds / 3.0, 1.0)), "--pool-runs", "3", "--pool-seconds", str(max(args.cpu_seconds / 6.0, 1.0))]
-    r = json.loads(subprocess.run(cmd, check=True, capture_output=True, text=True, timeout=900).stdout.strip().splitlines()[-1])
-    return {"value": r["one_core"]["rate"], "unit": "kmer_lookups/s", "cores": 1, "kind": "port",
-            "sample": "%d unique k-mer lookups in %.1f s cycling over %d of the bench's queries, on a %d-row x %d-sample slice of the same "
-                      "synthetic index (full row width of one GPU's shard, rows reduced to fit host RAM); oracle/bigsi_oracle.c orc_query; rows "
-                      "served from RAM instead of BerkeleyDB" % (r["one_core"]["lookups"], r["one_core"]["seconds"], min(w["batch"], 256),
-                                                                r["rows"], r["cols"]),
-            "pool": {"value": r["pool"]["rate_median"], "best": r["pool"]["rate_best"], "runs": r["pool"]["rates"],
-                     "cores": r["pool"]["threads"], "host_threads": r["host_threads"],
+    """The CPU baseline beside the number (never the target), each leg in a fresh subprocess (fork pools must not inherit a HIP
+    context), on the GPU run's synthetic index at full row width with the rows reduced to fit host RAM:
+      * THROUGH THE PRODUCT BOUNDARY: libbigsi_cpu.so (include/bigsi_cpu.h, the CPU twin of the C ABI) -- reference-shaped on ONE core
+        (the reported `value`), the reference's process-pool-over-sequences parallelism (bulk_search) on every physical core, and
+        its word-parallel mode on one core ("best CPU");
+      * the oracle's C port (oracle/bigsi_oracle.c, test infrastructure), one core and pool, as a cross-check of the twin."""
+    rows, batch = min(w["rows"], args.cpu_rows), min(w["batch"], 256)
+    common = ["--rows", str(rows), "--cols", str(cols_cpu), "--hashes", str(w["hashes"]), "--k", str(args.k), "--and-draws", str(args.and_draws),
+              "--seed", str(SEED), "--batch", str(batch), "--qlen", str(w["qlen"]), "--exact", str(int(exact))]
+    sec = max(args.cpu_seconds / 4.0, 1.0)
+    t = json.loads(subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "cpu_twin_baseline.py")] + common +
+                                  ["--threshold", str(w["threshold"]), "--seconds", str(sec), "--pool-runs", "2"],
+                                  check=True, capture_output=True, text=True, timeout=900).stdout.strip().splitlines()[-1])
+    r = json.loads(subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py")] + common +
+                                  ["--seconds", str(sec), "--pool-runs", "2", "--pool-seconds", str(max(args.cpu_seconds / 6.0, 1.0))],
+                                  check=True, capture_output=True, text=True, timeout=900).stdout.strip().splitlines()[-1])
+    what = "%d-row x %d-sample slice of the same synthetic index (full row width of one GPU's shard, rows reduced to fit host RAM), cycling over %d of the bench's queries; rows served from RAM instead of BerkeleyDB" % (rows, cols_cpu, batch)
+    return {"value": t["one_core"]["rate"], "unit": "kmer_lookups/s", "cores": 1, "kind": "port",
+            "through": "libbigsi_cpu.so: bigsi_cpu_search_batch, the CPU twin of the C ABI (include/bigsi_cpu.h), reference-shaped (per-k-mer string "
+                       "canonicalisation, MurmurHash3 x h, one copy per fetched row, byte-wise AND, unpack-to-int32-and-add)",
+            "sample": "%d unique k-mer lookups in %.1f s on a %s" % (t["one_core"]["lookups"], t["one_core"]["seconds"], what),
+            "pool": {"value": t["pool"]["rate_median"], "best": t["pool"]["rate_best"], "runs": t["pool"]["rates"], "cores": t["pool"]["threads"],
+                     "host_threads": t["host_threads"],
                      "sample": "fork pool over query sequences (the reference's bulk_search parallelism), %d workers, median of %d runs of %.1f s"
-                               % (r["pool"]["threads"], len(r["pool"]["rates"]), r["pool"]["seconds"])}}
+                               % (t["pool"]["threads"], len(t["pool"]["rates"]), t["pool"]["seconds"])},
+            "word_parallel_one_core": {"value": t["word_parallel_one_core"]["rate"], "what": "BIGSI_CPU_WORD_PARALLEL: 64-bit words of the resident rows, no copies"},
+            "oracle_port": {"value": r["one_core"]["rate"], "pool": r["pool"]["rate_median"], "pool_cores": r["pool"]["threads"],
+                            "what": "oracle/bigsi_oracle.c orc_query (test infrastructure), same slice and queries: cross-check of the twin"}}
 
 
 ALSO_LEGS = [

@@ -1,0 +1,9 @@
+#!/bin/bash
+# Build libbigsi_cpu.so (include/bigsi_cpu.h): the CPU twin of the CORE layer of the C ABI, in-tree next to libbigsi_hip.so.
+# Plain g++; contraction off because csrc/bigsi_score.hpp reproduces CPython's arithmetic operation by operation.
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+ROOT="$(cd "$HERE/../.." && pwd)"
+OUT="$HERE/../libbigsi_cpu.so"
+"${CXX:-g++}" -O2 -std=c++17 -ffp-contract=off -fPIC -shared -Wall -Wextra -Werror -I"$ROOT/include" -o "$OUT" "$HERE/bigsi_cpu.cpp"
+echo "built $OUT"

@@ -1,0 +1,303 @@
+"""libbigsi_cpu.so (include/bigsi_cpu.h): the CPU twin of the CORE layer of the C ABI, pinned to the golden vectors produced by
+RUNNING the reference (tests/golden: G1 hashes / canonical forms, G2 lookups, G3 searches incl. degenerate queries, G5 scores,
+G7 random index, G8 storage bytes) -- no GPU needed.  The same C host (tests/c_host/search_host.c) is built against the twin,
+unchanged, and must print the reference's G7 results; the gpu suite builds it against libbigsi_hip.so and compares the same text."""
+import ctypes as C
+import math
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, load_golden
+
+LIB = os.path.join(ROOT, "bigsi_amd", "libbigsi_cpu.so")
+WORD_PARALLEL = 1 << 16
+BLOOM_RAW = 1
+ERR_CAPACITY = -5
+
+
+@pytest.fixture(scope="module")
+def cpu():
+    assert os.path.exists(LIB), "libbigsi_cpu.so has not been built (run __graft_entry__.build())"
+    L = C.CDLL(LIB)
+    L.bigsi_cpu_last_error.restype = C.c_char_p
+    return L
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def pack(seqs):
+    data = [s.encode("ascii") for s in seqs]
+    off = np.zeros(len(data) + 1, np.uint64)
+    off[1:] = np.cumsum([len(d) for d in data])
+    return b"".join(data), off
+
+
+class Index(object):
+    def __init__(self, L, m, h, cap):
+        self.L, self.ix = L, C.c_void_p()
+        assert L.bigsi_cpu_open(C.c_uint64(m), C.c_uint64(0), C.c_uint64(cap), C.c_uint32(h), 0, C.byref(self.ix)) == 0
+        self.m, self.h = m, h
+
+    def ok(self, rc):
+        assert rc == 0, self.L.bigsi_cpu_last_error()
+
+    def add_sample(self, col, seqs, k):
+        self.ok(self.L.bigsi_cpu_set_num_cols(self.ix, C.c_uint64(col + 1)))
+        blob, off = pack(seqs)
+        self.ok(self.L.bigsi_cpu_insert_kmers(self.ix, C.c_uint64(col), blob, ptr(off), C.c_uint32(len(seqs)), C.c_uint32(k)))
+
+    def rows(self, rb):
+        ids = np.arange(self.m, dtype=np.uint64)
+        out = np.zeros((self.m, rb), np.uint8)
+        self.ok(self.L.bigsi_cpu_get_rows(self.ix, ptr(ids), C.c_uint64(self.m), ptr(out), C.c_uint64(rb)))
+        return out
+
+    def search(self, seqs, k, thr, flags=0, stream=False):
+        blob, off = pack(seqs)
+        n = len(seqs)
+        nk, nu, mk = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        ho = np.zeros(n + 1, np.uint64)
+        cap = 2
+        fn = self.L.bigsi_cpu_search_stream if stream else self.L.bigsi_cpu_search_batch
+        while True:
+            col, cnt = np.zeros(cap, np.uint32), np.zeros(cap, np.uint32)
+            rc = fn(self.ix, blob, ptr(off), C.c_uint64(n) if stream else C.c_uint32(n), C.c_uint32(k), C.c_double(thr), C.c_uint32(flags),
+                    ptr(nk), ptr(nu), ptr(mk), ptr(ho), ptr(col), ptr(cnt), C.c_uint64(cap))
+            if rc == ERR_CAPACITY and int(ho[-1]) > cap:
+                cap = int(ho[-1])
+                continue
+            self.ok(rc)
+            return nk, nu, mk, ho, col[:int(ho[-1])], cnt[:int(ho[-1])]
+
+    def close(self):
+        self.ok(self.L.bigsi_cpu_close(self.ix))
+
+
+def test_twin_exports_the_core_layer_with_the_hip_signatures(cpu):
+    """Every bigsi_cpu_* declaration of include/bigsi_cpu.h is exported, and each has the parameter list of its bigsi_hip_*
+    namesake in include/bigsi_hip.h (handle type aside)."""
+    import re
+    strip = lambda t: re.sub(r"/\*.*?\*/", "", t, flags=re.S)      # noqa: E731
+    cpu_h, hip_h = strip(open(os.path.join(ROOT, "include", "bigsi_cpu.h")).read()), strip(open(os.path.join(ROOT, "include", "bigsi_hip.h")).read())
+    decl = lambda src, prefix: {m.group(1): re.sub(r"\s+", " ", m.group(2)).strip() for m in re.finditer(r"\b%s(\w+)\s*\(([^;{]*?)\)\s*;" % prefix, src)}      # noqa: E731
+    c, h = decl(cpu_h, "bigsi_cpu_"), decl(hip_h, "bigsi_hip_")
+    assert len(c) >= 23
+    for name, params in c.items():
+        assert hasattr(cpu, "bigsi_cpu_" + name), name
+        if name == "presence":          # the HIP library offers this per batch (bigsi_hip_batch_presence)
+            continue
+        assert name in h, name
+        assert params.replace("bigsi_cpu_index", "bigsi_hip_index") == h[name], (name, params, h[name])
+
+
+def test_twin_g1_hashes_and_canonical_forms(cpu):
+    g = load_golden("g1_hash.json")
+    done = 0
+    for rec in g["generate_hashes"]:
+        if rec["m"] > 1 << 26:
+            continue
+        s = rec["s"].encode("utf-8")
+        if len(s) != len(rec["s"]):
+            continue                                       # (non-ASCII text is the element route of the HIP host shim)
+        out = np.zeros((rec["m"] + 7) // 8, np.uint8)
+        assert cpu.bigsi_cpu_bloom(0, s, C.c_uint64(1), C.c_uint32(len(s)), C.c_uint64(rec["m"]), C.c_uint32(rec["h"]), C.c_uint32(BLOOM_RAW), ptr(out)) == 0
+        assert set(np.flatnonzero(np.unpackbits(out)[:rec["m"]]).tolist()) == set(rec["set"]), rec
+        done += 1
+    assert done > 300
+    for rec in g["canonical"]:
+        s, c = rec["s"].encode("ascii"), rec["canonical"].encode("ascii")
+        a, b = np.zeros(1000, np.uint8), np.zeros(1000, np.uint8)
+        assert cpu.bigsi_cpu_bloom(0, s, C.c_uint64(1), C.c_uint32(len(s)), C.c_uint64(7993), C.c_uint32(4), C.c_uint32(0), ptr(a)) == 0
+        assert cpu.bigsi_cpu_bloom(0, c, C.c_uint64(1), C.c_uint32(len(c)), C.c_uint64(7993), C.c_uint32(4), C.c_uint32(BLOOM_RAW), ptr(b)) == 0
+        assert np.array_equal(a, b), rec
+
+
+def test_twin_g2_lookup_and_g8_storage_bytes(cpu):
+    for g in load_golden("g2_lookup.json"):
+        ix = Index(cpu, g["m"], g["h"], 64)
+        for c, s in enumerate(g["samples"]):
+            ix.add_sample(c, [s] if isinstance(s, str) else list(s), g["k"])
+        rb = (len(g["samples"]) + 7) // 8
+        assert [bytes(r).hex() for r in ix.rows(rb)] == g["rows"]
+        for lk in g["lookups"]:
+            kmers = [lk["kmers"]] if isinstance(lk["kmers"], str) else list(lk["kmers"])
+            if any(len(km) != g["k"] for km in kmers):
+                continue
+            out = np.zeros((len(kmers), rb), np.uint8)
+            ix.ok(cpu.bigsi_cpu_lookup(ix.ix, "".join(kmers).encode(), C.c_uint32(g["k"]), C.c_uint64(len(kmers)), ptr(out)))
+            for km, r in zip(kmers, out):
+                bits = "".join(map(str, np.unpackbits(r)))
+                want = lk["result"][km]
+                assert bits[:len(want)] == want and not bits[len(want):].strip("0"), (km, bits, want)
+        ix.close()
+    g = load_golden("g8_storage.json")
+    ix = Index(cpu, 5, 3, 64)
+    ix.ok(cpu.bigsi_cpu_set_num_cols(ix.ix, C.c_uint64(12)))
+    data = np.frombuffer(bytes.fromhex(g["bitarray_bytes"]["stored_hex"]), np.uint8).copy()
+    ids = np.array([3], np.uint64)
+    ix.ok(cpu.bigsi_cpu_set_rows(ix.ix, ptr(ids), C.c_uint64(1), ptr(data), C.c_uint64(data.size)))
+    back = np.zeros(2, np.uint8)
+    ix.ok(cpu.bigsi_cpu_get_rows(ix.ix, ptr(ids), C.c_uint64(1), ptr(back), C.c_uint64(2)))
+    assert "".join(map(str, np.unpackbits(back))) == g["bitarray_bytes"]["get_bitarray"]
+    ix.close()
+
+
+@pytest.mark.parametrize("flags", [0, WORD_PARALLEL])
+def test_twin_g3_searches_including_degenerate_queries(cpu, flags):
+    g = load_golden("g3_search.json")
+    names = list(g["samples"])
+    ix = Index(cpu, g["m"], g["h"], 64)
+    for c, nm in enumerate(names):
+        ix.add_sample(c, [g["samples"][nm]], g["k"])
+    assert [bytes(r).hex() for r in ix.rows(1)] == g["rows"]
+    checked = 0
+    for case in g["searches"]:
+        if "results" not in case["out"] or not isinstance(case["threshold"], (int, float)) or case["threshold"] > 1:
+            continue
+        seq = case["seq"]
+        if not seq.isascii() or len(seq) < g["k"]:
+            continue
+        nk, nu, mk, ho, col, cnt = ix.search([seq], g["k"], float(case["threshold"]), flags)
+        want = case["out"]["results"]
+        got = list(zip(col.tolist(), cnt.tolist()))
+        if float(case["threshold"]) != 1.0:
+            got.sort(key=lambda x: -x[1])                  # the reference's stable sort: count descending, colour ascending
+        assert [(names[c], f) for c, f in got] == [(w["sample_name"], w["num_kmers_found"]) for w in want], case
+        for w in want:
+            assert w["num_kmers"] == nu[0]
+        assert mk[0] == math.ceil(int(nu[0]) * float(case["threshold"]))
+        checked += 1
+    assert checked > 100
+    ix.close()
+
+
+@pytest.mark.parametrize("flags", [0, WORD_PARALLEL])
+def test_twin_g7_random_index_rows_lookups_searches_presence(cpu, flags):
+    g = load_golden("g7_random.json")
+    z = np.load(os.path.join(GOLDEN, "g7_random.npz"))
+    k, m, h, n = g["k"], g["m"], g["h"], g["n_cols"]
+    ix = Index(cpu, m, h, n)
+    for c, seqs in enumerate(g["sample_seqs"]):
+        ix.add_sample(c, list(seqs), k)
+    rb = (n + 7) // 8
+    assert np.array_equal(ix.rows(rb), z["rows"])
+    for rec in g["lookups"]:
+        kmers = sorted(rec["lookup"])
+        out = np.zeros((len(kmers), rb), np.uint8)
+        ix.ok(cpu.bigsi_cpu_lookup(ix.ix, "".join(kmers).encode(), C.c_uint32(k), C.c_uint64(len(kmers)), ptr(out)))
+        assert {km: bytes(r).hex() for km, r in zip(kmers, out)} == rec["lookup"]
+    queries = g["queries"]
+    for thr in sorted({s["threshold"] for s in g["searches"]}):
+        nk, nu, mk, ho, col, cnt = ix.search(queries, k, float(thr), flags, stream=True)
+        for s in g["searches"]:
+            if s["threshold"] != thr or "results" not in s["out"]:
+                continue
+            q = s["q"]
+            got = list(zip(col[int(ho[q]):int(ho[q + 1])].tolist(), cnt[int(ho[q]):int(ho[q + 1])].tolist()))
+            if thr != 1.0:
+                got.sort(key=lambda x: -x[1])
+                assert np.array_equal(np.sort(col[int(ho[q]):int(ho[q + 1])]), np.flatnonzero(z["counts"][q][:n] >= mk[q]))
+            want = s["out"]["results"]
+            assert [(g["sample_names"][c], f) for c, f in got] == [(w["sample_name"], w["num_kmers_found"]) for w in want], (thr, q)
+            if s["score"] and want:
+                cols = np.array([g["sample_names"].index(w["sample_name"]) for w in want], np.uint32)
+                out = np.zeros((cols.size, int(nk[q])), np.uint8)
+                ix.ok(cpu.bigsi_cpu_presence(ix.ix, queries[q].encode(), C.c_uint64(len(queries[q])), C.c_uint32(k), ptr(cols), C.c_uint32(cols.size), ptr(out)))
+                assert [bytes(r).decode() for r in out] == [w["kmer-presence"] for w in want]
+    ix.close()
+
+
+def test_twin_scores_equal_the_golden_scores(cpu):
+    """bigsi_cpu_score_presence: the scoring header the device compiles for K6, behind the twin's boundary, against G5."""
+    from test_abi_and_host import check_records_against_golden_and_scalar
+    from bigsi_amd.scoring import HIT_SCORE_DTYPE, pack_presence
+
+    def score(strings, found, unique):
+        bits, off, lens = pack_presence(strings)
+        rec = np.zeros(max(len(strings), 1), HIT_SCORE_DTYPE)
+        assert cpu.bigsi_cpu_score_presence(0, ptr(bits), ptr(off), ptr(lens), ptr(found), ptr(unique), C.c_uint64(len(strings)), ptr(rec)) == 0
+        return rec[:len(strings)]
+    check_records_against_golden_and_scalar(score)
+
+
+def test_twin_synthetic_fill_is_the_devices_generator(cpu):
+    """bigsi_cpu_fill_synthetic must produce the rows bigsi_hip_fill_synthetic produces (the CPU baseline runs on a slice of the
+    GPU's index): compared here with the oracle's mirror of the device generator, which the gpu suite pins to the device."""
+    from oracle import coracle
+    for n_cols, draws, shard in ((130, 2, 0), (64, 1, 3), (1000, 2, 1), (7, 3, 0)):
+        ix = Index(cpu, 50, 3, n_cols)
+        ix.ok(cpu.bigsi_cpu_set_num_cols(ix.ix, C.c_uint64(n_cols)))
+        ix.ok(cpu.bigsi_cpu_fill_synthetic(ix.ix, C.c_uint64(99), C.c_uint64(shard), C.c_uint32(draws)))
+        assert np.array_equal(ix.rows((n_cols + 7) // 8), coracle.synth_fill(99, shard, 0, 50, n_cols, draws))
+        ix.close()
+
+
+def parse_c_host_output(text):
+    out = text.splitlines()
+    passes, cur = {}, None
+    for ln in out[1:-1]:
+        f = ln.split()
+        if f[0] == "pass":
+            cur = passes.setdefault(f[1], {})
+        else:
+            cur[int(f[1])] = (int(f[3]), int(f[5]), int(f[7]), [tuple(map(int, x.split(":"))) for x in f[9:]])
+    return out[0], passes, out[-1]
+
+
+def check_c_host_against_g7(text):
+    g = load_golden("g7_random.json")
+    names = g["sample_names"]
+    head, passes, tail = parse_c_host_output(text)
+    assert head == "index rows %d cols %d hashes %d row_bytes %d" % (g["m"], len(names), g["h"], -(-len(names) // 8))
+    assert tail == "error reported"
+    checked = 0
+    for name, thr in (("exact", 1.0), ("threshold", 0.4)):
+        assert sorted(passes[name]) == list(range(len(g["queries"])))
+        for srch in g["searches"]:
+            if srch["threshold"] != thr or srch["score"] or "results" not in srch["out"]:
+                continue
+            nk, nu, mk, hits = passes[name][srch["q"]]
+            want = srch["out"]["results"]
+            assert [c for c, _ in hits] == sorted(c for c, _ in hits)
+            assert sorted((names[c], n) for c, n in hits) == sorted((w["sample_name"], w["num_kmers_found"]) for w in want), (name, srch["q"])
+            for w in want:
+                assert w["num_kmers"] == nu
+            assert nk == len(g["queries"][srch["q"]]) - g["k"] + 1
+            assert mk == math.ceil(nu * thr)
+            checked += 1
+    assert checked >= 40
+    return checked
+
+
+def c_host_input():
+    g = load_golden("g7_random.json")
+    lines = ["%d %d %d %d %d 0.4" % (g["m"], g["h"], g["k"], len(g["sample_names"]), len(g["queries"]))]
+    lines += ["%d %s" % (len(seqs), " ".join(seqs)) for seqs in g["sample_seqs"]]
+    lines += list(g["queries"])
+    return "\n".join(lines) + "\n"
+
+
+def test_the_c_host_builds_against_the_twin_unchanged_and_reproduces_g7(cpu, tmp_path):
+    """tests/c_host/search_host.c -- written against include/bigsi_hip.h -- compiled with -DBIGSI_USE_CPU_TWIN -include bigsi_cpu.h
+    and linked to libbigsi_cpu.so: the reference's G7 results on a box without a GPU."""
+    exe = str(tmp_path / "search_host_cpu")
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-DBIGSI_USE_CPU_TWIN", "-include", os.path.join(inc, "bigsi_cpu.h"),
+                           "-o", exe, os.path.join(ROOT, "tests", "c_host", "search_host.c"), "-L", os.path.dirname(LIB), "-lbigsi_cpu",
+                           "-Wl,-rpath," + os.path.dirname(LIB)])
+    r = subprocess.run([exe], input=c_host_input(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    check_c_host_against_g7(r.stdout)
+
+
+def test_product_never_loads_the_twin():
+    for base, _, files in os.walk(os.path.join(ROOT, "bigsi_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                txt = open(os.path.join(base, f)).read()
+                assert "libbigsi_cpu" not in txt and "bigsi_cpu_" not in txt, f
