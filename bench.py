@@ -333,6 +333,28 @@ def main():
     sh.prepare(batches, exact, count_bytes)
     check(_lib.lib().bigsi_hip_set_profiling(st.handle, 1))
 
+    # N > 1: before anything is timed, every rank says which physical GPU it drives; the run refuses ranks that share one (unless
+    # asked to: --one-device dry runs), a communicator whose size is not N, and -- with RCCL -- GPUs that cannot reach each other
+    ranks_info = None
+    if use_dist:
+        props = torch.cuda.get_device_properties(local_rank)
+        bus = ("%04x:%02x:%02x" % (props.pci_domain_id, props.pci_bus_id, props.pci_device_id)) if hasattr(props, "pci_bus_id") else "device%d" % local_rank
+        gathered = [None] * world
+        dist.all_gather_object(gathered, {"rank": rank, "device": local_rank, "pci_bus_id": bus, "gpu": props.name,
+                                          "hbm_gb": round(props.total_memory / 1e9, 1)})
+        shared = len({g["pci_bus_id"] for g in gathered}) != world
+        if shared and not (args.one_device or os.environ.get("BIGSI_BENCH_DEVICE")):
+            raise SystemExit("bench.py: ranks share a GPU: %r" % [(g["rank"], g["pci_bus_id"]) for g in gathered])
+        peers = [g["device"] for g in gathered if g["device"] != local_rank and g["device"] < torch.cuda.device_count()]
+        peer_ok = all(torch.cuda.can_device_access_peer(local_rank, d_) for d_ in peers)
+        cr_ = sh.comm_ranks()
+        if sh.exchange == "rccl":
+            if not cr_ or cr_[1] != world:
+                raise SystemExit("bench.py: the RCCL communicator reports %r ranks, %d expected" % (cr_, world))
+            if world > 1 and not shared and not peer_ok:
+                raise SystemExit("bench.py: device %d cannot access its peers %r" % (local_rank, peers))
+        ranks_info = {"ranks": gathered, "distinct_gpus": not shared, "peer_access_from_rank0": peer_ok if peers else None}
+
     def sync_all():
         if use_dist:
             dist.barrier()
@@ -674,7 +696,7 @@ def main():
                                                       " + ncclAllGather of 1 bit/sample (library-owned RCCL communicator)"
                                                       if sh.exchange == "rccl" else " + torch.distributed(%s) all-gather" % args.backend),
                 "backend": args.backend if use_dist else None, "exchange": sh.exchange if use_dist else None,
-                "rccl_ranks": cr[1] if cr else None,
+                "rccl_ranks": cr[1] if cr else None, "ranks": ranks_info,
                 "index_fill_s": fill_s, "verified": verified, "presence": presence,
                 "pcie_inclusive_kmer_lookups_per_s": pcie_rate,
                 "host_visible": host_visible,

@@ -1,4 +1,4 @@
-"""Condense gpurun_out/prof (scripts/profile_all.sh) into profiles/r02_*: per workload one JSON (the command's own line(s),
+"""Condense gpurun_out/prof (scripts/profile_all.sh) into profiles/<round>_* (ROUND, default r03): per workload one JSON (the command's own line(s),
 the rocprofv3 average duration of the dominant kernel from the SAME run, algorithmic bytes, fraction of the 8 TB/s HBM peak)
 plus the kernel-stats CSV it came from; and profiles/pmc_traffic.json from the PMC passes.
 
@@ -15,6 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
 PEAK = 8000.0
+R = os.environ.get("ROUND", "r03")      # prefix of this round's files
 
 
 def short(name):
@@ -54,7 +55,7 @@ def json_lines(tag):
 def main():
     os.makedirs(DST, exist_ok=True)
     summary = {}
-    for path in sorted(glob.glob(os.path.join(SRC, "r02_*_kernel_stats.csv"))):
+    for path in sorted(glob.glob(os.path.join(SRC, R + "_*_kernel_stats.csv"))):
         tag = os.path.basename(path)[: -len("_kernel_stats.csv")]
         ks, lines = kernel_stats(tag), json_lines(tag)
         rec = {"command": "scripts/profile_all.sh: " + tag, "kernels": {k: v for k, v in ks.items() if k.startswith("bigsi::")}}
@@ -81,7 +82,7 @@ def main():
         with open(os.path.join(DST, tag + ".json"), "w") as f:
             json.dump(rec, f, indent=1)
         shutil.copy(path, os.path.join(DST, tag + "_kernel_stats.csv"))
-    for name in ("r02_bench_default", "r02_bench_t04"):
+    for name in (R + "_bench_default", R + "_bench_t04"):
         lines = json_lines(name)
         if lines:
             with open(os.path.join(DST, name + ".json"), "w") as f:
@@ -105,7 +106,7 @@ def main():
         write = wr[k]["WRITE_SIZE"]["avg"] * 1024
         key = "rows=10000000 cols=100000 hashes=4 batch=8192 qlen=1000 k=31 threshold=%s draws=2" % thr
         traffic[key] = {"kernel": k, "traffic_bytes_per_launch": fetch + write, "fetch_bytes_corrected": fetch, "write_bytes": write,
-                        "source": "profiles/r02_c3_pmc.json (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes; FETCH_SIZE doubled per "
+                        "source": "profiles/" + R + "_c3_pmc.json (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes; FETCH_SIZE doubled per "
                                   "MI355X_MICROARCH.md, calibrated on k_fill_synth's WRITE_SIZE = index bytes)"}
     # the one-launch read kernel on BASELINE configs[1]
     try:
@@ -117,9 +118,9 @@ def main():
             fetch, write = fe[k]["FETCH_SIZE"]["avg"] * 1024 * 2, wr[k]["WRITE_SIZE"]["avg"] * 1024
             traffic["rows=1000000 cols=10000 hashes=3 batch=1000 qlen=61 k=31 threshold=1.0 draws=2"] = {
                 "kernel": k, "traffic_bytes_per_launch": fetch + write, "fetch_bytes_corrected": fetch, "write_bytes": write,
-                "source": "profiles/r02_c2_pmc.json (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes; FETCH_SIZE doubled per "
+                "source": "profiles/" + R + "_c2_pmc.json (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes; FETCH_SIZE doubled per "
                           "MI355X_MICROARCH.md, which calibrates that factor on wide streaming reads: 1.25 KB rows fetch whole 128-byte lines)"}
-            with open(os.path.join(DST, "r02_c2_pmc.json"), "w") as f:
+            with open(os.path.join(DST, R + "_c2_pmc.json"), "w") as f:
                 json.dump({"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python bench.py --workload c2 --steps 64 --warmup 8 "
                                       "--cpu-seconds 0 --no-verify (one counter per pass; scripts/profile_all.sh)",
                            "units": "KiB per dispatch, averaged over the dispatches of a kernel",
@@ -128,7 +129,7 @@ def main():
     except OSError:
         pass
     if pmc:
-        with open(os.path.join(DST, "r02_c3_pmc.json"), "w") as f:
+        with open(os.path.join(DST, R + "_c3_pmc.json"), "w") as f:
             json.dump({"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python bench.py --steps 2 --warmup 1 --cpu-seconds 0 "
                                   "--no-verify [--threshold 0.4]  (one counter per pass; scripts/profile_all.sh)",
                        "units": "KiB per dispatch, averaged over the dispatches of a kernel", "runs": pmc}, f, indent=1)
@@ -141,7 +142,10 @@ def main():
         old.update(traffic)
         with open(os.path.join(DST, "pmc_traffic.json"), "w") as f:
             json.dump(old, f, indent=1)
-    with open(os.path.join(DST, "r02_summary.json"), "w") as f:
+    for name in (R + "_row_probe.txt", R + "_call_breakdown.txt"):
+        if os.path.exists(os.path.join(SRC, name)):
+            shutil.copy(os.path.join(SRC, name), os.path.join(DST, name))
+    with open(os.path.join(DST, R + "_summary.json"), "w") as f:
         json.dump(summary, f, indent=1)
     for k, v in summary.items():
         if "frac" in v:

@@ -2,31 +2,38 @@
 # Everything DESIGN.md section 5 quotes, measured in one go on a GPU box: each workload under `rocprofv3 --kernel-trace --stats`
 # (per-kernel durations; the command's own JSON -- HIP-event figures of the SAME run -- lands next to the CSV), the PMC passes
 # for the dominant kernel (one counter per pass, as the hardware guide prescribes), and the unprofiled default bench line.
-# scripts/make_profiles.py then condenses gpurun_out/prof into profiles/r02_*.
+# scripts/make_profiles.py then condenses gpurun_out/prof into profiles/<round>_* (ROUND=r03 by default).
 cd "${GRAFT_REPO_ROOT:-.}"
+R=${ROUND:-r03}
 P=gpurun_out/prof
 mkdir -p $P
-B="--cpu-seconds 0"
+B="--cpu-seconds 0 --also none"
 run() { scripts/prof.sh "$@" > /dev/null; }
-run r02_c3_exact        -- python bench.py --steps 20 --warmup 5 $B
-run r02_c3_t04          -- python bench.py --steps 20 --warmup 5 $B --threshold 0.4
-run r02_c3_256x1kbp     -- python bench.py --steps 200 --warmup 10 $B --batch 256
-run r02_c3_256x1kbp_t04 -- python bench.py --steps 200 --warmup 10 $B --batch 256 --threshold 0.4
-run r02_c2              -- python bench.py --workload c2 --steps 4000 --warmup 100 $B
-run r02_c2_t04          -- python bench.py --workload c2 --steps 4000 --warmup 100 $B --threshold 0.4
-run r02_c2_one_stream BIGSI_HIP_LIB=$PWD/bigsi_amd/libbigsi_hip_tuning.so BIGSI_HIP_READ_STREAMS=1 -- python bench.py --workload c2 --steps 4000 --warmup 100 $B
-run r02_c2_unfused BIGSI_HIP_LIB=$PWD/bigsi_amd/libbigsi_hip_tuning.so BIGSI_HIP_FUSE_READS=0 -- python bench.py --workload c2 --steps 4000 --warmup 100 $B
-run r02_c2_32k_reads    -- python bench.py --workload c2 --steps 200 --warmup 16 $B --batch 32768 --distinct-batches 8
-run r02_c4_shard        -- python bench.py --workload c4 --shard-of 8 --gpus 1 --steps 200 --warmup 10 $B
-run r02_c5_shard        -- python bench.py --workload c5 --shard-of 8 --gpus 1 --steps 200 --warmup 10 $B
-run r02_northstar_shard -- python bench.py --workload northstar --shard-of 8 --gpus 1 --steps 200 --warmup 10 $B
-run r02_northstar_shard_t04 -- python bench.py --workload northstar --shard-of 8 --gpus 1 --steps 200 --warmup 10 $B --threshold 0.4
-run r02_northstar_shard_h4  -- python bench.py --workload northstar --shard-of 8 --gpus 1 --steps 200 --warmup 10 $B --hashes 4
-run r02_c3_strong8_shard    -- python bench.py --workload c3 --shard-of 8 --gpus 1 --steps 40 --warmup 5 $B
-run r02_c3_strong8_rccl1    -- python bench.py --workload c3 --shard-of 8 --gpus 1 --steps 40 --warmup 5 $B --force-dist
-run r02_long_queries    -- python scripts/measure.py p16
-run r02_k5              -- python scripts/measure.py k5
-run r02_transpose       -- python scripts/measure.py transpose
+run ${R}_c3_exact        -- python bench.py --steps 20 --warmup 5 $B
+run ${R}_c3_t04          -- python bench.py --steps 20 --warmup 5 $B --threshold 0.4
+run ${R}_c3_256x1kbp     -- python bench.py --steps 200 --warmup 10 $B --batch 256
+run ${R}_c3_256x1kbp_t04 -- python bench.py --steps 200 --warmup 10 $B --batch 256 --threshold 0.4
+run ${R}_c2              -- python bench.py --workload c2 --steps 4000 --warmup 100 $B
+run ${R}_c2_t04          -- python bench.py --workload c2 --steps 4000 --warmup 100 $B --threshold 0.4
+run ${R}_c2_one_stream BIGSI_HIP_LIB=$PWD/bigsi_amd/libbigsi_hip_tuning.so BIGSI_HIP_READ_STREAMS=1 -- python bench.py --workload c2 --steps 4000 --warmup 100 $B
+run ${R}_c2_unfused BIGSI_HIP_LIB=$PWD/bigsi_amd/libbigsi_hip_tuning.so BIGSI_HIP_FUSE_READS=0 -- python bench.py --workload c2 --steps 4000 --warmup 100 $B
+run ${R}_c2_32k_reads    -- python bench.py --workload c2 --steps 200 --warmup 16 $B --batch 32768 --distinct-batches 8
+run ${R}_c4_shard        -- python bench.py --workload c4 --shard-of 8 --gpus 1 --steps 200 --warmup 10 $B
+run ${R}_c5_shard        -- python bench.py --workload c5 --shard-of 8 --gpus 1 --steps 200 --warmup 10 $B
+run ${R}_northstar_shard -- python bench.py --workload northstar --shard-of 8 --gpus 1 --steps 200 --warmup 10 $B
+run ${R}_northstar_shard_t04 -- python bench.py --workload northstar --shard-of 8 --gpus 1 --steps 200 --warmup 10 $B --threshold 0.4
+run ${R}_northstar_shard_h4  -- python bench.py --workload northstar --shard-of 8 --gpus 1 --steps 200 --warmup 10 $B --hashes 4
+run ${R}_c3_strong8_shard    -- python bench.py --workload c3 --shard-of 8 --gpus 1 --steps 40 --warmup 5 $B
+run ${R}_c3_strong8_rccl1    -- python bench.py --workload c3 --shard-of 8 --gpus 1 --steps 40 --warmup 5 $B --force-dist
+run ${R}_long_queries    -- python scripts/measure.py p16
+run ${R}_k5              -- python scripts/measure.py k5
+run ${R}_transpose       -- python scripts/measure.py transpose
+# what the memory system gives the row-AND access pattern with no BIGSI code in the way (scripts/probe/row_probe.hip)
+{ for a in "" "--vmm"; do scripts/probe/row_probe --gb 125 --row-bytes 12500 --rows-per-query 3880 --queries 768 $a; done
+  scripts/probe/row_probe --gb 16 --row-bytes 12500 --rows-per-query 3880 --queries 768
+  scripts/probe/row_probe --gb 125 --row-bytes 7813 --rows-per-query 2900 --queries 1024
+  scripts/probe/row_probe --gb 1.25 --row-bytes 1250 --rows-per-query 93 --queries 8192 --wgs 2048; } > $P/${R}_row_probe.txt 2>&1
+python scripts/call_breakdown.py > $P/${R}_call_breakdown.txt 2>/dev/null
 # PMC: HBM traffic of the row-AND kernels (FETCH_SIZE / WRITE_SIZE in separate passes)
 export TMPDIR=/tmp
 for thr in 1.0 0.4; do
@@ -44,6 +51,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
   [ -n "$f" ] && python scripts/make_profiles.py --pmc-reduce "$f" $P/pmc_c2_${c}.json
   rm -rf $P/raw_pmc
 done
-python bench.py --steps 20 --warmup 5 > $P/r02_bench_default.stdout 2> $P/r02_bench_default.stderr
-python bench.py --steps 20 --warmup 5 --threshold 0.4 > $P/r02_bench_t04.stdout 2> $P/r02_bench_t04.stderr
+python bench.py --steps 20 --warmup 5 > $P/${R}_bench_default.stdout 2> $P/${R}_bench_default.stderr      # the driver's command: headline + every other config as config.also legs + the CPU baseline
+python bench.py --steps 20 --warmup 5 --threshold 0.4 --also none > $P/${R}_bench_t04.stdout 2> $P/${R}_bench_t04.stderr
 ls $P | wc -l

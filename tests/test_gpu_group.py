@@ -273,3 +273,64 @@ def test_one_rank_rccl_communicator(threshold):
         b.close()
     sh.close()
     st.delete_all()
+
+
+def test_group_at_c4_column_geometry_eight_shards_with_scores():
+    """BASELINE configs[3] / [4]'s exchange at its REAL column geometry on the one GPU a test box has: 500 000 samples as eight
+    shards of 62 528 columns (977 words each; rows cut to 1 M so that the eight shards share one device: 63 GB), through the
+    group entry points -- every shard runs K1-K3 on the queries, the masks are exchanged and compacted, counts reduced, and
+    with score=True each hit is scored (K5 + K6) on the shard that owns its column.  Exact and threshold 0.4, against the
+    oracle's per-shard restatement: global colours, counts, order, presence strings, all 17 score fields."""
+    from bigsi_amd import BIGSI
+    from oracle import coracle
+    from oracle.ref_model import Scorer
+    m, total, h, seed = 1_000_000, 500_000, 3, 20260928
+    cfg, st = group_storage(m, total, h, [0] * 8, seed, draws=2)
+    inf = st.res.info()
+    assert inf.n_shards == 8 and inf.shard_cols == 62_528          # ceil(500000 / 8) rounded up to 64 columns
+    sc, orcs = shard_oracles(st, m, h, seed, 2)
+    assert [o.n_cols for o in orcs] == [62_528] * 7 + [500_000 - 7 * 62_528]
+    rng = np.random.default_rng(3)
+    seqs = rand_seqs(rng, 24, 1000, 1000)
+    planted = {}
+    for j in range(6):                                   # each planted query into one sample of EVERY shard, partly
+        for g in range(8):
+            c = g * sc + (7919 * (8 * j + g) + 11) % orcs[g].n_cols
+            part = seqs[j] if g == 7 else seqs[j][: 450 + 70 * g]          # (the last shard's sample holds the whole query: an exact hit)
+            st.insert_kmers(c, [part], 31)
+            orcs[g].insert_kmers(c % sc, part)
+            planted.setdefault(j, []).append(c)
+    names = {c: "s%d" % c for cs in planted.values() for c in cs}
+    st.set_integer("metadata:colour_count", total)
+    index = BIGSI(cfg)
+    index.colour_to_sample = lambda c: names.get(int(c), "s%d" % int(c))          # (500 000 metadata records are not what is tested here)
+    scorer = Scorer(index.scorer.DB_SIZE)
+    for thr in (1.0, 0.4):
+        got = index.search_batch(seqs, thr, score=True)
+        n_hits = 0
+        for i, s in enumerate(seqs):
+            u, wc = whole_counts(orcs, sc, s)
+            valid = np.zeros(wc.size, bool)
+            for g, o in enumerate(orcs):
+                valid[g * sc: g * sc + o.n_cols] = True
+            want = [int(c) for c in np.flatnonzero(valid & (wc >= (u if thr == 1.0 else int(np.ceil(u * thr)))))]
+            if thr != 1.0:
+                want.sort(key=lambda c: -int(wc[c]))
+            assert [r["sample_name"] for r in got[i]] == ["s%d" % c for c in want], (thr, i)
+            if i < 6:
+                assert set(planted[i]) <= set(want) if thr != 1.0 else True
+            for r, c in zip(got[i], want):
+                kmers, uniq, rows = orcs[c // sc].per_kmer_rows(s)
+                bits = np.unpackbits(rows, axis=1)[:, c % sc]
+                idx = {km: t for t, km in enumerate(uniq)}
+                col = "".join("1" if bits[idx[km]] else "0" for km in kmers)
+                assert r["kmer-presence"] == col and r["num_kmers"] == u and r["num_kmers_found"] == int(wc[c])
+                assert r["percent_kmers_found"] == round(100 * float(wc[c]) / u, 2)
+                for key, v in scorer.score(col).items():
+                    if key in ("evalue", "pvalue"):
+                        assert r[key] == pytest.approx(v, rel=1e-12, abs=2.5e-16)
+                    else:
+                        assert r[key] == v, (thr, i, c, key)
+                n_hits += 1
+        assert n_hits >= (6 if thr == 1.0 else 48), (thr, n_hits)
+    index.delete()
