@@ -83,6 +83,9 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample (0 = skip)")
     p.add_argument("--cpu-rows", type=int, default=200_000)
     p.add_argument("--no-verify", action="store_true")
+    p.add_argument("--score-queue", default="beside", choices=["ordered", "beside"],
+                   help="score=True workloads: K5 + K6 of a batch queued on the index stream behind the next batch's kernels (ordered) or on "
+                        "the library's high-priority score stream beside them (beside)")
     p.add_argument("--also", default="auto", choices=["auto", "all", "none"],
                    help="after the headline, run short legs of the other BASELINE configurations and report them under config.also "
                         "(auto: only for the default single-GPU c3 run)")
@@ -372,12 +375,14 @@ def main():
 
     # score=True (BASELINE configs[4]: "per-kmer score accumulation (bigsi/scoring)"): every step runs the WHOLE of
     # BIGSI.search(score=True) for the hits whose columns this rank owns, three batches deep:
-    #   step k:  launch batch k  |  hit lists of batch k-1 to the host, K5 + K6 for them queued on the index stream BEHIND batch k
-    #            (bigsi_hip_batch_score_hits_begin, BIGSI_SCORE_ORDERED)  |  results of batch k-2: K6's records and presence bits from
-    #            pinned staging, closed-form score fields for all hits at once (scoring.score_columns), presence strings and the
-    #            reference's result dicts (graph/bigsi.py:105-114 + 232-239) in its order (count descending, colour ascending).
+    #   step k:  launch batch k  |  hit lists of batch k-1 to the host, K5 + K6 for them queued (bigsi_hip_batch_score_hits_begin)  |
+    #            results of batch k-2: K6's records and presence bits from pinned staging, closed-form score fields for all hits at
+    #            once (scoring.score_columns), presence strings and the reference's result dicts (graph/bigsi.py:105-114 + 232-239)
+    #            in its order (count descending, colour ascending).
     # The device part is K5 (presence bits of the hits) + K6 (remove_short_ones / tabulate_score / calculate_score with Python's
-    # round(), percent_kmers_found); queued in stream order it runs alone, a tenth of what it takes beside a row-AND kernel.
+    # round(), percent_kmers_found).  --score-queue beside (default): on the library's high-priority score stream, beside batch k's
+    # row-AND kernel -- 0.4 ms of mostly waiting for memory, but off the critical path: 1.03 ms per step measured; ordered: on the
+    # index stream behind batch k -- 0.1 ms, but every step pays it: 1.14 ms.
     fetched, begun = [None], [None]
     scored = {"results": None, "hits": 0, "batches": 0, "begin_s": 0.0, "finish_s": 0.0, "end_s": 0.0}
     names = ["s%d" % (rank * shard_cols + c) for c in range(my_cols)] if w["score"] else None
@@ -392,7 +397,7 @@ def main():
         t_a = time.perf_counter()
         off_own, col_own, cnt_own = own_hits(b_)
         nk_, nu_, _ = b_.unique()
-        b_.score_hits_begin(off_own, col_own, None if exact else cnt_own, nk_, ordered=True)
+        b_.score_hits_begin(off_own, col_own, None if exact else cnt_own, nk_, ordered=args.score_queue == "ordered")
         begun[0] = (b_, off_own, col_own, cnt_own, nk_, nu_)
         scored["begin_s"] += time.perf_counter() - t_a
 
@@ -528,8 +533,9 @@ def main():
                                         "finish_ms_per_batch": in_region["finish_s"] / max(in_region["batches"], 1) * 1e3,
                                         "of_which_waiting_for_the_device_ms": in_region["end_s"] / max(in_region["batches"], 1) * 1e3,
                                         "host_us_per_hit": (in_region["begin_s"] + in_region["finish_s"]) / max(in_region["hits"], 1) * 1e6},
+                    "score_queue": args.score_queue,
                     "what": "every step also runs the whole of BIGSI.search(score=True), three batches deep: hit lists of the previous batch "
-                            "to the host and K5 + K6 for them queued behind the batch just launched (presence bits, remove_short_ones / "
+                            "to the host and K5 + K6 for them queued beside / behind the batch just launched (presence bits, remove_short_ones / "
                             "tabulate_score / calculate_score with Python's round(), percent_kmers_found); for the batch before that: "
                             "closed-form score fields, presence strings and the reference's result dicts in its order"}
 

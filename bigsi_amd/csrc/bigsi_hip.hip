@@ -1239,6 +1239,8 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
         if (ix->main_ev && st != ix->stream) HIP_TRY(hipStreamWaitEvent(st, ix->main_ev, 0));
         if (b->done && b->run_stream != st) HIP_TRY(hipStreamWaitEvent(st, b->done, 0));      // this batch's previous run
         if (b->g_done && b->gstream && b->gstream != st) HIP_TRY(hipStreamWaitEvent(st, b->g_done, 0));
+        // a K5 / K6 request of this batch still in flight on another stream reads what K1 is about to rewrite
+        if (b->job.done && b->job.device_work) HIP_TRY(hipStreamWaitEvent(st, b->job.done, 0));
         TRY(flush_upload(b, st));
         TRY(ev_begin(ix, &fe, st, true));
         b->weak_fp = (flags & BIGSI_RUN_WEAK_FINGERPRINT) != 0;
@@ -1275,6 +1277,7 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
     // K1 (its LDS route emits the sorted list itself; the other routes leave that to k_sort_rows below)
     EventPair ep{};
     bool sorted_by_k1 = false;
+    if (b->job.done && b->job.device_work) HIP_TRY(hipStreamWaitEvent(k1_stream(ix), b->job.done, 0));      // (as on the read path above)
     TRY(flush_upload(b, k1_stream(ix)));
     TRY(run_kmerize(b, threshold, (flags & BIGSI_RUN_K1_GLOBAL) != 0, want_sorted, &sorted_by_k1));
     b->dirty = true;        // until `done` is recorded at the end

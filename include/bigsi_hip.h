@@ -264,9 +264,11 @@ int bigsi_hip_batch_score_hits(bigsi_hip_batch *b, const uint64_t *hit_offsets, 
  * bit_offsets[n_hits] bytes) and queues the device work; _end waits for it and copies the results out.  Between the two the
  * caller is free to do anything else -- including running the batch again: the results are staged in host memory the
  * batch owns (not after bigsi_hip_batch_reload / destroy).  One request per batch at a time.
- * BIGSI_SCORE_ORDERED queues the kernels on the index's stream BEHIND the runs already issued there instead of on the library's
- * high-priority score stream beside them: the request then completes later but costs a tenth of the device time (the kernels
- * do not compete with a row-AND kernel for the memory system) -- the choice of a throughput loop three batches deep. */
+ * By default the kernels run on the library's high-priority score stream BESIDE whatever the index stream is doing (next to a
+ * row-AND kernel they spend most of their time waiting for memory: 0.4 ms instead of 0.1 ms for a few hundred hits -- which
+ * does not matter to a loop three batches deep, that collects the results a step later: 1.03 ms per step at BASELINE configs[4]).
+ * BIGSI_SCORE_ORDERED queues them on the index's stream BEHIND the runs already issued there: a tenth of the device time, but
+ * on that stream's critical path (1.14 ms per step in the same loop); the choice when the device has nothing else to do. */
 #define BIGSI_SCORE_ORDERED 1u
 int bigsi_hip_batch_score_hits_begin(bigsi_hip_batch *b, const uint64_t *hit_offsets, const uint32_t *colours, const uint32_t *counts,
                                      uint32_t flags, uint64_t *bit_offsets);

@@ -160,3 +160,38 @@ def test_k6_search_with_scores_in_slices_equals_scalar_assembly():
                 assert [list(r) for r in results[budget][thr][i]] == [list(w) for w in want]
     batch.close()
     index.delete()
+
+
+@pytest.mark.parametrize("ordered", [False, True])
+def test_k6_begin_end_equals_the_synchronous_call_even_when_the_batch_runs_again(ordered):
+    """bigsi_hip_batch_score_hits_begin / _end: the request may be collected after the batch has been RUN AGAIN (a serving loop
+    three batches deep does exactly that) -- the re-run is ordered behind the request on the device, the results are staged on the
+    host.  Same records and bits as the synchronous call, on the score stream and on the index stream."""
+    rng = np.random.default_rng(13)
+    k, m, h = 31, 40009, 3
+    queries = [rand_seq(rng, 500), rand_seq(rng, 95), rand_seq(rng, 1200)]
+    samples = {"s%d" % c: [queries[c % 3][: int(rng.integers(60, len(queries[c % 3])))], rand_seq(rng, 200)] for c in range(90)}
+    index = build_index(cfg(k, m, h, max_cols=128), samples)
+    batch = index.storage.new_batch(queries, k)
+    other = index.storage.new_batch([rand_seq(rng, 3000) for _ in range(64)], k)
+    batch.run(0.2)
+    nk, nu, _ = batch.unique()
+    off, colours, counts = batch.hits()
+    assert int(off[-1]) > 30
+    want = batch.score_hits(off, colours, counts, nk)
+    for rounds in range(4):
+        batch.score_hits_begin(off, colours, counts, nk, ordered=ordered)
+        other.run(0.5)                                   # something else on the index stream
+        batch.run(0.9 if rounds % 2 else 0.2)            # the same batch again: K1 rewrites what the request reads
+        got = batch.score_hits_end()
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[2], want[2]) and np.array_equal(got[1][: int(got[2][-1])], want[1][: int(want[2][-1])])
+        batch.run(0.2)
+        o2, c2, n2 = batch.hits()
+        assert np.array_equal(o2, off) and np.array_equal(c2, colours) and np.array_equal(n2, counts)
+    with pytest.raises(Exception):
+        batch.score_hits_begin(off, colours, counts, nk)
+        batch.score_hits_begin(off, colours, counts, nk)          # one request per batch at a time
+    batch.score_hits_end()
+    batch.close()
+    other.close()
+    index.delete()
