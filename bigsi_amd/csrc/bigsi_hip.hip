@@ -1931,6 +1931,7 @@ static int presence_begin(bigsi_hip_batch *b, const uint64_t *hit_offsets, const
             perm[lo + r] = src;
             if ((uint64_t)(c >> 6) != last_word) { words++; last_word = c >> 6; }
         }
+        while (pairs.size() & 63u) pairs.push_back(PresencePair{0xFFFFFFFFu, 0u, 0ull, 0ull, q, 0u});      // whole wavefronts per query (k_presence_bits)
         max_u = std::max(max_u, b->h_num_unique[q]);
         max_n = std::max(max_n, b->h_num_kmers[q]);
         alg += (uint64_t)b->h_num_unique[q] * b->run_h * words * 8 +

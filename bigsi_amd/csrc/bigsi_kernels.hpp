@@ -1592,7 +1592,7 @@ struct PresencePair {
 };
 
 
-// The grid is flat over the call's pairs (x) and 16-k-mer chunks (y): a thresholded search of a few hundred queries of which a
+// The grid is flat over the call's pairs (x; each query's pairs padded to a multiple of 64) and 16-k-mer chunks (y): a thresholded search of a few hundred queries of which a
 // dozen have hits -- BASELINE configs[4] as benchmarked -- used to launch (pairs of the fullest query / 256) x chunks x queries
 // workgroups, nearly all of them empty, and waited for slots beside the next batch's row-AND kernel (166 us against 26 us alone).
 template <int H, int WAVES = 2>      // WAVES = 2: the compiler keeps all 16 x h loads of a thread in flight (~200 VGPRs), measured faster than 4
@@ -1605,10 +1605,13 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_presence_bits(
     const uint32_t jc = blockIdx.y;
     const uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (p >= n_pairs) return;
-    const uint32_t q = pairs[p].q;
+    // the host pads every query's pairs to whole wavefronts, so the query -- and with it the k-mer count and every row id of the
+    // chunk -- is the same for all 64 lanes: scalar loads (per-lane row ids cost this kernel 70 % at 261 k hits)
+    const uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane((int)pairs[p & ~63ull].q);
     const uint32_t u = num_unique[q];
     const uint32_t j0 = jc * 16u;
     if (j0 >= u) return;
+    if (pairs[p].wpair == 0xFFFFFFFFu) return;          // padding
     const PresencePair pr = pairs[p];
     const uint64_t *qrows = rows + pos_off[q] * h;
     const uint32_t woff = pr.wpair * 2u;
