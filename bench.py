@@ -86,6 +86,9 @@ def parse():
     p.add_argument("--score-queue", default="beside", choices=["ordered", "beside"],
                    help="score=True workloads: K5 + K6 of a batch queued on the index stream behind the next batch's kernels (ordered) or on "
                         "the library's high-priority score stream beside them (beside)")
+    p.add_argument("--host-visible", type=int, default=1, choices=[0, 1],
+                   help="0: skip the host-visible measurements after the timed region (profiled runs: rocprofv3's per-kernel averages then "
+                        "cover launches of the timed shape only)")
     p.add_argument("--also", default="auto", choices=["auto", "all", "none"],
                    help="after the headline, run short legs of the other BASELINE configurations and report them under config.also "
                         "(auto: only for the default single-GPU c3 run)")
@@ -568,7 +571,7 @@ def main():
     #   stream     ONE bigsi_hip_search_stream call over several of the step's batches (the library pipelines its own chunks)
     #   one_call   bigsi_hip_search_batch latency for the step's first batch (if it is a batch of reads) and for a single query
     host_visible = {"two_workspace_loop_kmer_lookups_per_s": pcie_rate}
-    if world == 1 and not args.force_dist:
+    if world == 1 and not args.force_dist and args.host_visible:
         lib_ = _lib.lib()
         want = 64 if w["batch"] * w["qlen"] < (1 << 17) else (8 if w["batch"] * w["qlen"] < (1 << 20) else 2)
         many = [s_ for i in range(want) for s_ in all_seqs[i % nb]]

@@ -51,7 +51,7 @@ static int read_stream(bigsi_hip_index *ix, hipStream_t *out)
 {
     *out = ix->stream;
     if (ix->stream != ix->own_stream) return BIGSI_OK;       // the caller's own stream (bigsi_hip_set_stream): everything stays on it
-    static const int n_streams = std::min(env_int("BIGSI_HIP_READ_STREAMS", kReadStreams), kReadStreams);      // A/B: 1 = no overlap
+    static const int n_streams = std::min(env_int("BIGSI_HIP_READ_STREAMS", kReadStreamsUsed), kReadStreams);      // A/B: 1 = no overlap
     if (n_streams <= 1) return BIGSI_OK;
     if (!ix->rd_stream[0])
         for (auto &st : ix->rd_stream) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -743,6 +743,7 @@ static int batch_quiesce(bigsi_hip_batch *b)
         HIP_TRY(hipEventSynchronize(b->done));
     }
     if (b->g_done) HIP_TRY(hipEventSynchronize(b->g_done));
+    if (b->job.done && b->job.device_work) HIP_TRY(hipEventSynchronize(b->job.done));      // a K5 / K6 request still reading this batch's arrays
     return BIGSI_OK;
 }
 

@@ -80,7 +80,8 @@ struct EventPair {
     uint32_t launches = 1;      // kernel launches bracketed by the pair (large batches go out as several K2 launches)
 };
 
-constexpr int kReadStreams = 3;
+constexpr int kReadStreams = 4;            // streams created; kReadStreamsUsed of them take launches (tuning builds: BIGSI_HIP_READ_STREAMS)
+constexpr int kReadStreamsUsed = 3;
 
 struct bigsi_hip_index {
     int device = 0;

@@ -224,11 +224,17 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
         batch.run(threshold, sparse_counts=True, early_exit=bool(self.config.get("early_exit", False)))
 
     def _collect(self, batch, n_seqs, threshold, score):
+        return self._collect_end(self._collect_begin(batch, n_seqs, threshold, score))
+
+    def _collect_begin(self, batch, n_seqs, threshold, score, deferred=False):
+        """First half of a batch's collection: per-query counts and hit lists to the host, the reference's errors for degenerate
+        queries, and -- score=True -- the scored hits: at once (K6 through the synchronous call), or `deferred`: only queued
+        (bigsi_hip_batch_score_hits_begin) for _collect_end to pick up, so that a stream can launch its next batch in between."""
         num_kmers, num_unique, _ = batch.unique()
         off, colours, counts = batch.hits()
         exact = threshold == 1.0
         if num_unique[:n_seqs].all() and int(off[n_seqs]) == 0:
-            return [[] for _ in range(n_seqs)]             # the common bulk case: nothing found anywhere in the batch
+            return None, n_seqs                           # the common bulk case: nothing found anywhere in the batch
         nu = num_unique[:n_seqs]
         if not nu.all():
             # the reference fails on a query without k-mers: reduce() over nothing on the exact branch
@@ -236,14 +242,29 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
             if exact:
                 raise TypeError("reduce() of empty sequence with no initial value")
             raise UnboundLocalError("local variable 'cumsum' referenced before assignment")
-        out = [[] for _ in range(n_seqs)]
         off64 = off.astype(np.int64)
         scored = None
         if score:
             if ((np.diff(off64[:n_seqs + 1]) > 0) & (num_kmers[:n_seqs] == 1)).any():
                 # the reference builds a 1-D matrix from a single row and then indexes it with two subscripts
                 raise IndexError("too many indices for array: array is 1-dimensional, but 2 were indexed")
-            scored = self._score_hits(batch, off, colours, None if exact else counts, num_kmers, n_seqs)
+            per_hit = np.repeat(num_kmers[:n_seqs].astype(np.int64), np.diff(off64[:n_seqs + 1]))
+            if deferred and not batch.group and int(((per_hit + 63) // 64 * 64).sum()) <= SCORE_SLICE_CHARS:
+                batch.score_hits_begin(off, colours, None if exact else counts, num_kmers)
+                scored = ("pending", per_hit)
+            else:
+                scored = self._score_hits(batch, off, colours, None if exact else counts, num_kmers, n_seqs)
+        return (batch, off64, colours, counts, nu, exact, scored), n_seqs
+
+    def _collect_end(self, begun):
+        state, n_seqs = begun
+        if state is None:
+            return [[] for _ in range(n_seqs)]
+        batch, off64, colours, counts, nu, exact, scored = state
+        if isinstance(scored, tuple) and scored[0] == "pending":
+            rec, bits, boff = batch.score_hits_end()
+            scored = scored_rows(rec, bits, boff, scored[1], self.scorer.DB_SIZE)
+        out = [[] for _ in range(n_seqs)]
         for i in np.flatnonzero(np.diff(off64[:n_seqs + 1])).tolist():      # only the sequences that have hits
             lo, hi = int(off64[i]), int(off64[i + 1])
             out[i] = self._assemble(lo, colours[lo:hi], counts[lo:hi], int(nu[i]), exact, scored)
@@ -311,28 +332,39 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
             except TypeError:                             # (bytes among the sequences)
                 plain = all(s.isascii() for s in chunk)
             if not plain:                                 # rare: answered at once through search_batch's non-ASCII route
-                return _Done(self.search_batch(chunk, threshold, score)), chunk
+                return [_Done(self.search_batch(chunk, threshold, score)), chunk]
             batch = self._workspace(slot, chunk, ws)
             self._launch(batch, threshold)
-            return batch, chunk
+            return [batch, chunk]
+
+        def begin(p):
+            # score=True, three batches deep: the scored hits of the batch launched one step ago are only QUEUED here (K5 + K6 beside
+            # the batch just launched); done() picks them up a step later
+            if not isinstance(p[0], _Done):
+                p.append(self._collect_begin(p[0], len(p[1]), threshold, score, deferred=True))
 
         def done(p):
-            return p[0].results if isinstance(p[0], _Done) else self._collect(p[0], len(p[1]), threshold, score)
+            if isinstance(p[0], _Done):
+                return p[0].results
+            return self._collect_end(p[2]) if len(p) > 2 else self._collect(p[0], len(p[1]), threshold, score)
 
         # sequences are taken from the iterable in slices (C speed: millions of reads go through here); without a
         # batch_size the slice length follows the k-mers per sequence seen so far, so that a batch holds ~batch_kmers of them
         it = iter(seqs)
         take = batch_size if batch_size else 64
         try:
-            yield from self._stream_loop(it, take, batch_size, batch_kmers, k, submit, done)
+            yield from self._stream_loop(it, take, batch_size, batch_kmers, k, submit, done, begin if score else None, 3 if score else 2)
         finally:
             for b_ in ws.values():
                 b_.close()
 
     @staticmethod
-    def _stream_loop(it, take, batch_size, batch_kmers, k, submit, done):
+    def _stream_loop(it, take, batch_size, batch_kmers, k, submit, done, begin=None, depth=2):
+        """submit(chunk, slot) launches a batch on workspace `slot` (of `depth`) and returns its handle; `depth` - 1 batches later
+        done(handle) yields its results.  With `begin`, begin(handle) is called once the NEXT batch has been launched (the middle
+        stage of a pipeline three deep: work queued beside that batch, collected by done() a step later)."""
         from itertools import chain, islice
-        pending, slot = None, 0
+        flight, slot = [], 0
         while True:
             chunk = list(islice(it, take))
             if not chunk:
@@ -357,12 +389,21 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
                         it = chain(chunk[cut:], it)
                         chunk = chunk[:cut]
                 take = len(chunk)
+            if len(flight) == depth:                     # the workspace about to be reused: its results first
+                p = flight.pop(0)
+                yield from zip(p[1], done(p))
             nxt = submit(chunk, slot)
-            if pending is not None:
-                yield from zip(pending[1], done(pending))
-            pending, slot = nxt, slot ^ 1
-        if pending is not None:
-            yield from zip(pending[1], done(pending))
+            slot = (slot + 1) % depth
+            if begin is not None and flight:
+                begin(flight[-1])
+            flight.append(nxt)
+            if len(flight) == depth:
+                p = flight.pop(0)
+                yield from zip(p[1], done(p))
+        if begin is not None and flight:
+            begin(flight[-1])
+        for p in flight:
+            yield from zip(p[1], done(p))
 
     def search_stream_arrays(self, seqs, threshold=1.0, batch_size=1 << 15):
         """The device's own answer, batch by batch, for callers to whom a Python dict per hit is too slow (millions of reads):

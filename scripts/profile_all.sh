@@ -7,7 +7,7 @@ cd "${GRAFT_REPO_ROOT:-.}"
 R=${ROUND:-r03}
 P=gpurun_out/prof
 mkdir -p $P
-B="--cpu-seconds 0 --also none"
+B="--cpu-seconds 0 --also none --host-visible 0"
 run() { scripts/prof.sh "$@" > /dev/null; }
 run ${R}_c3_exact        -- python bench.py --steps 20 --warmup 5 $B
 run ${R}_c3_t04          -- python bench.py --steps 20 --warmup 5 $B --threshold 0.4

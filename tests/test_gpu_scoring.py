@@ -195,3 +195,25 @@ def test_k6_begin_end_equals_the_synchronous_call_even_when_the_batch_runs_again
     batch.close()
     other.close()
     index.delete()
+
+
+def test_scored_search_stream_three_batches_deep_equals_search():
+    """BIGSI.search_stream(score=True) queues each batch's K5 + K6 beside the next batch and collects them a step later (three
+    workspaces); the results must be those of search(..., score=True) one query at a time, in order, for every batch size."""
+    rng = np.random.default_rng(14)
+    k, m, h = 31, 30011, 3
+    queries = [rand_seq(rng, int(n)) for n in rng.integers(61, 700, size=23)]
+    samples = {"s%d" % c: [queries[c % 23][: int(rng.integers(45, len(queries[c % 23])))], rand_seq(rng, 250)] + ([queries[c % 23]] if c % 4 == 0 else [])
+               for c in range(60)}
+    index = build_index(cfg(k, m, h, max_cols=64), samples)
+    for thr in (0.35, 1.0):
+        want = [index.search(q, thr, score=True) for q in queries]
+        assert sum(len(w) for w in want) > (20 if thr == 1.0 else 40)
+        for bs in (1, 2, 5, 23, 100):
+            got = list(index.search_stream(iter(queries), thr, score=True, batch_size=bs))
+            assert [s for s, _ in got] == queries
+            for (s, r), w in zip(got, want):
+                assert_results_equal(r, w, "thr=%r bs=%d" % (thr, bs))
+        got = list(index.search_stream(iter(queries), thr, score=True, batch_kmers=2000))
+        assert [r for _, r in got] == want
+    index.delete()
