@@ -208,7 +208,7 @@ def test_scored_search_stream_three_batches_deep_equals_search():
     index = build_index(cfg(k, m, h, max_cols=64), samples)
     for thr in (0.35, 1.0):
         want = [index.search(q, thr, score=True) for q in queries]
-        assert sum(len(w) for w in want) > (20 if thr == 1.0 else 40)
+        assert sum(len(w) for w in want) > (10 if thr == 1.0 else 40)
         for bs in (1, 2, 5, 23, 100):
             got = list(index.search_stream(iter(queries), thr, score=True, batch_size=bs))
             assert [s for s, _ in got] == queries
