@@ -277,8 +277,11 @@ def main():
     if args.one_device or os.environ.get("BIGSI_BENCH_DEVICE"):          # dry runs: several ranks sharing one GPU
         local_rank = int(os.environ.get("BIGSI_BENCH_DEVICE", "0"))
     if local_rank >= torch.cuda.device_count():
-        raise SystemExit("rank %d needs device %d but only %d GPU(s) are visible (--one-device --backend gloo shares one)"
-                         % (rank, local_rank, torch.cuda.device_count()))
+        if torch.cuda.device_count() == 1 and world > 1 and args.backend == "nccl":
+            local_rank = 0          # a launcher that shows every rank ONE device of its own (the PCI bus check below tells a shared GPU apart)
+        else:
+            raise SystemExit("rank %d needs device %d but only %d GPU(s) are visible (--one-device --backend gloo shares one)"
+                             % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
