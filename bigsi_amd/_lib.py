@@ -215,7 +215,7 @@ def pack_seqs(seqs):
         except UnicodeEncodeError:
             raise ValueError("query sequences must be ASCII for the hip-hbm backend")
         off = np.zeros(len(seqs) + 1, dtype=np.uint64)
-        off[1:] = np.cumsum(np.fromiter(map(len, seqs), dtype=np.uint64, count=len(seqs)))
+        np.cumsum(np.fromiter(map(len, seqs), dtype=np.uint64, count=len(seqs)), out=off[1:])
         return blob, off
     enc = []
     for s in seqs:

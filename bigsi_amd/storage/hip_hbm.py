@@ -466,8 +466,10 @@ class HipHbmStorage(BaseStorage):
                 break
             cap = self._search_cap = int(off[-1])             # offsets are filled in: bring that much next time
         check(rc)
-        o, nk, nu = off.tolist(), nk.tolist(), nu.tolist()
-        return [(nk[i], nu[i], col[o[i]:o[i + 1]], cnt[o[i]:o[i + 1]]) for i in range(n)]
+        # (most sequences of a bulk search match nothing: they share ONE pair of empty arrays instead of 2 slices each, which is
+        # where a 1000-read call spent its time once the C call was down to 0.07 ms)
+        o, e_col, e_cnt = off.tolist(), col[:0], cnt[:0]
+        return [(k_, u_, col[x:y], cnt[x:y]) if y > x else (k_, u_, e_col, e_cnt) for k_, u_, x, y in zip(nk.tolist(), nu.tolist(), o, o[1:])]
 
 
     def search_many(self, seqs, k, threshold=1.0):

@@ -1586,6 +1586,16 @@ def test_search_stream_entry_point_equals_batch_runs(hip):
             assert np.array_equal(col[int(off[i]):int(off[i + 1])], want), (thr, i)
             assert np.array_equal(cnt[int(off[i]):int(off[i + 1])], want_cnt[want].astype(np.uint32))
     assert int(off[-1]) > 0
+    # threshold 0: EVERY sample is a hit of every query (graph/bigsi.py:241-242) -- hit lists far beyond what the export kernel
+    # carries along and beyond the device buffers' first size: the regrow / plain-copy routes of the collection
+    few = reads[:700] + genes[:40]
+    st._search_cap = 4
+    nk, nu, off, col, cnt = st.search_many(few, 31, 0.0)
+    assert int(off[-1]) == len(few) * n_cols and np.array_equal(np.diff(off.astype(np.int64)), np.full(len(few), n_cols))
+    assert np.array_equal(col.reshape(len(few), n_cols), np.tile(np.arange(n_cols, dtype=np.uint32), (len(few), 1)))
+    for i in (0, 699, 700, 739):
+        u, want_cnt = orc.counts(few[i])
+        assert np.array_equal(cnt[int(off[i]):int(off[i + 1])], want_cnt.astype(np.uint32))
     # planted reads are found
     nk, nu, off, col, cnt = st.search_many(reads, 31, 1.0)
     assert 5 in col[int(off[3]):int(off[4])].tolist() and 8999 in col[int(off[40_000]):int(off[40_001])].tolist()
