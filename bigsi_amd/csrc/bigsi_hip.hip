@@ -1479,10 +1479,11 @@ static int compact_ex(bigsi_hip_batch *b, HitBufs &hb, const void *src, bool fro
         // runs the write pass again: the totals are still there.
         static const int k4_groups = env_int("BIGSI_HIP_K4_GROUPS", (int)kHitsMaxGroups);
         const uint64_t max_groups = (uint64_t)std::min<int>(std::max(k4_groups, 1), (int)kHitsMaxGroups);
-        const uint32_t ipb = (uint32_t)ceil_div(nchunks, max_groups);
+        // a handful of items (one or two gene-length queries: a latency-bound call) go to ONE workgroup, which needs nobody's totals
+        const uint32_t ipb = nchunks <= 16 ? (uint32_t)nchunks : (uint32_t)ceil_div(nchunks, max_groups);
         const uint64_t ngroups = ceil_div(nchunks, ipb);
         TRY(hb.chunk_hits.reserve(kHitsMaxGroups * 4));
-        if (!write_only)
+        if (!write_only && ngroups > 1)
             hipLaunchKernelGGL(k_hits_totals, dim3((unsigned)ngroups), dim3(kBlock), 0, st, (const uint64_t *)src, b->wv_pad, (uint32_t)b->wv, b->n_seqs,
                                n_shards, chunks, ipb, hb.chunk_hits.as<uint32_t>());
         hipLaunchKernelGGL(k_hits_write, dim3((unsigned)ngroups), dim3(kBlock), 0, st, (const uint64_t *)src, b->wv_pad, (uint32_t)b->wv, b->n_seqs,

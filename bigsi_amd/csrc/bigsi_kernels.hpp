@@ -1119,8 +1119,7 @@ __global__ __launch_bounds__(kBlock) void k_hits_write(
     uint64_t base = 0;
 #pragma unroll
     for (int i = 0; i < kBlock / 64; i++) base += lds64[i];
-    if (threadIdx.x == 0 && i1 == n_items) hit_off[n_seqs] = base + totals[grp];
-    // ordered write
+    // ordered write (the last group ends up with the grand total in `base`: a grid of ONE group needs no k_hits_totals at all)
     for (uint64_t ci = i0; ci < i1; ci++) {
         uint32_t w;
         const uint64_t bits = hits_word(bitmaps, stride_words, wv, n_seqs, n_shards, chunks, ci, &w);
@@ -1148,6 +1147,7 @@ __global__ __launch_bounds__(kBlock) void k_hits_write(
                 o++;
             }
     }
+    if (threadIdx.x == 0 && i1 == n_items) hit_off[n_seqs] = base;
 }
 
 // ------------------------------------------------------------------------------ reads: K1 + K2 + K4 in ONE launch

@@ -85,7 +85,9 @@ int bigsi_hip_reserve_cols(bigsi_hip_index *ix, uint64_t col_capacity);
  * STREAMS.  On its private stream(s) the library orders everything itself: bigsi_hip_batch_run is asynchronous; the fetch /
  * presence calls of a batch wait for THAT batch's kernels only; batches of reads (the one-launch kernel: k = 31, < 64
  * k-mers per query, hit lists only) are issued round-robin on three internal streams so that consecutive batches overlap;
- * every call that changes the index, bigsi_hip_stats and bigsi_hip_synchronize wait for all of them.  With a caller-owned
+ * every call that changes the index, bigsi_hip_stats and bigsi_hip_synchronize wait for all of them; the kernels of scored
+ * searches (bigsi_hip_batch_score_hits*, presence_hits) run on a fourth, high-priority stream beside whatever the others are
+ * doing, and a batch that is run again is ordered behind its own pending score request on the device.  With a caller-owned
  * stream set, every kernel of the index goes to that one stream. */
 int bigsi_hip_set_stream(bigsi_hip_index *ix, void *hip_stream);
 int bigsi_hip_synchronize(bigsi_hip_index *ix);
