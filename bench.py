@@ -576,7 +576,7 @@ def main():
     host_visible = {"two_workspace_loop_kmer_lookups_per_s": pcie_rate}
     if world == 1 and not args.force_dist and args.host_visible:
         lib_ = _lib.lib()
-        want = 64 if w["batch"] * w["qlen"] < (1 << 17) else (8 if w["batch"] * w["qlen"] < (1 << 20) else 2)
+        want = 256 if w["batch"] * w["qlen"] < (1 << 17) else (8 if w["batch"] * w["qlen"] < (1 << 20) else 2)
         many = [s_ for i in range(want) for s_ in all_seqs[i % nb]]
         blob, soff = _lib.pack_seqs(many)
         n_many = len(many)

@@ -56,7 +56,8 @@ for thr in (1.0, 0.4):
 # host-visible streaming rate: 64 x 1000 reads in ONE bigsi_hip_search_stream call (host sequences in, host hit lists out)
 rng = np.random.default_rng(1)
 lut = np.frombuffer(b"ACGT", dtype=np.uint8)
-many = [lut[r].tobytes().decode() for r in rng.integers(0, 4, size=(64_000, 61), dtype=np.uint8)]
+n_many = int(os.environ.get("BIGSI_STREAM_READS", "64000"))
+many = [lut[r].tobytes().decode() for r in rng.integers(0, 4, size=(n_many, 61), dtype=np.uint8)]
 from bigsi_amd import _lib
 blob, soff = _lib.pack_seqs(many)
 nk, nu, off = np.zeros(len(many), np.uint32), np.zeros(len(many), np.uint32), np.zeros(len(many) + 1, np.uint64)
@@ -68,8 +69,8 @@ for thr in (1.0, 0.4):
         _lib.check(_lib.lib().bigsi_hip_search_stream(st.handle, blob, _lib.ptr(soff), len(many), 31, thr, 0, _lib.ptr(nk), _lib.ptr(nu), None,
                                                       _lib.ptr(off), _lib.ptr(col), _lib.ptr(cnt), col.size))
         best = min(best, time.perf_counter() - t0)
-    print("C2 index, 64000 x 61 bp in one bigsi_hip_search_stream call thr=%.1f: %.2f ms = %.0f M k-mer lookups/s host-visible (%d hits)"
-          % (thr, best * 1e3, float(nu.sum()) / best / 1e6, int(off[-1])))
+    print("C2 index, %d x 61 bp in one bigsi_hip_search_stream call thr=%.1f: %.2f ms = %.0f M k-mer lookups/s host-visible (%d hits)"
+          % (len(many), thr, best * 1e3, float(nu.sum()) / best / 1e6, int(off[-1])))
 st.delete_all()
 st = index(10_000_000, 100_000, 4)
 for thr in (1.0, 0.4):
