@@ -1801,6 +1801,7 @@ __global__ __launch_bounds__(kBlock) void k_presence_expand(
 // position-ordered presence bits of every hit AND its score record: thread = rank; piece = 16 positions; marked pieces
 // (k_presence_pieces) are 16 consecutive presence bits of the hit, listed ones walk the position -> unique k-mer map (uniform
 // over a sequence's hits).  The thread then scores the words it has just written (its own stores: visible to it).
+constexpr int kScoreLdsWords = 16;          // presence words of a hit kept in LDS for the scoring passes (16 x 64 = 1024 positions)
 __global__ __launch_bounds__(kBlock) void k_presence_score(
     const uint16_t *__restrict__ bits, uint32_t bits_stride, uint64_t n_hits, const uint32_t *__restrict__ hit_n,
     const uint64_t *__restrict__ hit_pos0, const uint32_t *__restrict__ hit_seq, const uint32_t *__restrict__ desc,
@@ -1808,6 +1809,7 @@ __global__ __launch_bounds__(kBlock) void k_presence_score(
     uint8_t *out, const uint32_t *__restrict__ found, const uint32_t *__restrict__ unique, const uint32_t *__restrict__ dest,
     bigsi_score::HitScore *__restrict__ scores)
 {
+    __shared__ uint64_t lw[kScoreLdsWords][kBlock];       // [word][thread]: conflict-free
     const uint64_t rank = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (rank >= n_hits) return;
     const uint32_t n = hit_n[rank], pieces = (n + 15u) >> 4;
@@ -1816,30 +1818,46 @@ __global__ __launch_bounds__(kBlock) void k_presence_score(
     const uint32_t *pu = pos_unique + pos0;
     const uint16_t *mine = bits + presence_bits_at(rank, 0, bits_stride);      // chunk c of this rank: mine[32 * c]
     uint64_t *dst = reinterpret_cast<uint64_t *>(out + out_off[rank]);
-    uint64_t acc = 0;
-    for (uint32_t piece = 0; piece < pieces; piece++) {
-        const uint32_t mark = d[piece], j0 = mark & 0x7fffffffu, cnt = min(16u, n - piece * 16u);
-        uint32_t x16 = 0;
-        if (mark >> 31) {
-            const uint32_t c = j0 >> 4, r = j0 & 15u;
-            const uint32_t lo = mine[32u * c], hi = r ? (uint32_t)mine[32u * min(c + 1u, bits_stride - 1u)] : 0u;
-            x16 = (lo | (hi << 16)) >> r;
-        } else {
-            for (uint32_t t = 0; t < cnt; t++) {
-                const uint32_t j = pu[piece * 16u + t];
-                x16 |= (((uint32_t)mine[32u * (j >> 4)] >> (j & 15u)) & 1u) << t;
+    // four pieces = one 64-position word per round: the four marks, then the (up to) eight 16-bit chunks they point at, as
+    // independent loads -- two dependent levels per word instead of two per piece (a thread per hit is a chain of latencies)
+    for (uint32_t p0 = 0; p0 < pieces; p0 += 4u) {
+        uint32_t mark[4], lo[4], hi[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) mark[i] = p0 + i < pieces ? d[p0 + i] : 0x80000000u;      // (beyond the end: "marked", masked to nothing below)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t j0 = mark[i] & 0x7fffffffu, c = j0 >> 4, r = j0 & 15u;
+            const bool fast = (mark[i] >> 31) && p0 + i < pieces;
+            lo[i] = fast ? (uint32_t)mine[32u * c] : 0u;
+            hi[i] = fast && r ? (uint32_t)mine[32u * min(c + 1u, bits_stride - 1u)] : 0u;
+        }
+        uint64_t acc = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t piece = p0 + i;
+            if (piece >= pieces) break;
+            const uint32_t cnt = min(16u, n - piece * 16u);
+            uint32_t x16;
+            if (mark[i] >> 31) {
+                x16 = (lo[i] | (hi[i] << 16)) >> (mark[i] & 15u);
+            } else {                                    // a piece that touches a repeated k-mer: walk the position -> unique map
+                x16 = 0;
+                for (uint32_t t = 0; t < cnt; t++) {
+                    const uint32_t j = pu[piece * 16u + t];
+                    x16 |= (((uint32_t)mine[32u * (j >> 4)] >> (j & 15u)) & 1u) << t;
+                }
             }
+            x16 &= (1u << cnt) - 1u;
+            acc |= (uint64_t)x16 << (16 * i);
         }
-        x16 &= (1u << cnt) - 1u;
-        acc |= (uint64_t)x16 << (16u * (piece & 3u));
-        if ((piece & 3u) == 3u || piece + 1u == pieces) {
-            dst[piece >> 2] = by_column(acc);          // position p -> byte p / 8, mask 0x80 >> (p % 8)
-            acc = 0;
-        }
+        const uint64_t packed = by_column(acc);         // position p -> byte p / 8, mask 0x80 >> (p % 8)
+        dst[p0 >> 2] = packed;
+        if ((p0 >> 2) < (uint32_t)kScoreLdsWords) lw[p0 >> 2][threadIdx.x] = acc;
     }
     bigsi_score::HitScore rec;
     const uint64_t *w = dst;
-    bigsi_score::score_hit([w](uint32_t k) { return by_column(w[k]); }, n, found[rank], unique[rank], &rec);
+    const uint32_t tid = threadIdx.x;
+    bigsi_score::score_hit([w, tid](uint32_t k) { return k < (uint32_t)kScoreLdsWords ? lw[k][tid] : by_column(w[k]); }, n, found[rank], unique[rank], &rec);
     scores[dest[rank]] = rec;
 }
 
