@@ -1,0 +1,38 @@
+"""Application level, scored: BIGSI.search_stream(..., threshold=0.4, score=True) -- Python strings in, the reference's result dicts
+(22 keys per hit) out -- on one GPU's shard of BASELINE configs[4] (25 M x 62.5 k, h=3), 256-query batches with 16 x 16 planted
+partial matches per batch, as bench.py's c5 workload plants them.  Prints one JSON line."""
+import json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bigsi_amd import BIGSI
+from bigsi_amd.storage import get_storage
+
+m, n, h, k = 25_000_000, 62_500, 3, 31
+cfg = {"storage-engine": "hip-hbm", "storage-config": {"name": "ssp", "max_cols": n}, "k": k, "m": m, "h": h}
+st = get_storage(cfg); st.delete_all()
+for key, v in (("number_of_rows", m), ("number_of_cols", n), ("ksi:bloomfilter_size", m), ("ksi:num_hashes", h)):
+    st.set_integer(key, v)
+st.fill_synthetic(20260928, 0, 2)
+st.set_integer("metadata:colour_count", n)
+rng = np.random.default_rng(1)
+lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+n_batches = 24
+seqs = [lut[r].tobytes().decode() for r in rng.integers(0, 4, size=(256 * n_batches, 1000), dtype=np.uint8)]
+for bi in range(n_batches):
+    for qi in range(16):
+        for t in range(16):
+            st.insert_kmers((7919 * (16 * qi + t) + 11 + 101 * bi) % n, [seqs[256 * bi + qi][:710]], k)
+index = BIGSI(cfg)
+index.colour_to_sample = lambda c: "s%d" % c              # (62 500 metadata records are not what is measured)
+out = {}
+for score in (True, False):
+    list(index.search_stream(seqs[:512], 0.4, score=score, batch_size=256))      # warm
+    t0 = time.perf_counter()
+    res = list(index.search_stream(seqs, 0.4, score=score, batch_size=256))
+    dt = time.perf_counter() - t0
+    hits = sum(len(r) for _, r in res)
+    uniq = sum(len({s[i:i + k] for i in range(len(s) - k + 1)}) for s in seqs[:64]) / 64 * len(seqs)
+    out["score=%s" % score] = {"seconds": dt, "queries": len(seqs), "hits": hits, "ms_per_256_queries": dt / n_batches * 1e3,
+                               "kmer_lookups_per_s": uniq / dt, "keys_per_hit": len(res[0][1][0]) if res[0][1] else None}
+print(json.dumps(out))
+index.delete()
