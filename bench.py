@@ -343,7 +343,7 @@ def main():
     check(_lib.lib().bigsi_hip_set_profiling(st.handle, 1))
 
     # N > 1: before anything is timed, every rank says which physical GPU it drives; the run refuses ranks that share one (unless
-    # asked to: --one-device dry runs), a communicator whose size is not N, and -- with RCCL -- GPUs that cannot reach each other
+    # asked to: --one-device dry runs) and a communicator whose size is not N; whether the GPUs can reach each other directly is reported
     ranks_info = None
     if use_dist:
         props = torch.cuda.get_device_properties(local_rank)
@@ -360,8 +360,7 @@ def main():
         if sh.exchange == "rccl":
             if not cr_ or cr_[1] != world:
                 raise SystemExit("bench.py: the RCCL communicator reports %r ranks, %d expected" % (cr_, world))
-            if world > 1 and not shared and not peer_ok:
-                raise SystemExit("bench.py: device %d cannot access its peers %r" % (local_rank, peers))
+            # (no peer access is reported, not refused: RCCL then stages through host memory -- slower, still a measurement)
         ranks_info = {"ranks": gathered, "distinct_gpus": not shared, "peer_access_from_rank0": peer_ok if peers else None}
 
     def sync_all():
