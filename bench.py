@@ -216,7 +216,8 @@ def run_also_legs():
                                                            "launches_per_step", "step_GBps", "step_frac", "concurrent_launches", "traffic",
                                                            "traffic_measured_in_run", "read_launches_repeated")},
                         "verified": cf.get("verified"), "host_visible": cf.get("host_visible"),
-                        "presence": cf.get("presence"), "clocks": cf.get("clocks"), "wall_s": time.time() - t0, "args": " ".join(extra)}
+                        "presence": cf.get("presence"), "clocks": cf.get("clocks"), "index_contiguous": cf.get("index_contiguous"),
+                        "index_gb": cf.get("index_gb_per_gpu"), "wall_s": time.time() - t0, "args": " ".join(extra)}
         except Exception as e:  # noqa: BLE001 -- a leg that fails is reported as such, the headline stands
             out[key] = {"what": what, "error": "%s: %s" % (type(e).__name__, str(e)[:300]), "args": " ".join(extra)}
     return out
@@ -708,7 +709,7 @@ def main():
                                                       if sh.exchange == "rccl" else " + torch.distributed(%s) all-gather" % args.backend),
                 "backend": args.backend if use_dist else None, "exchange": sh.exchange if use_dist else None,
                 "rccl_ranks": cr[1] if cr else None, "ranks": ranks_info,
-                "index_fill_s": fill_s, "verified": verified, "presence": presence,
+                "index_fill_s": fill_s, "index_contiguous": bool(stats.index_contiguous), "verified": verified, "presence": presence,
                 "pcie_inclusive_kmer_lookups_per_s": pcie_rate,
                 "host_visible": host_visible,
                 "clocks": {"before_timed_region": clocks_before, "after_timed_region": clocks_after, "source": "rocm-smi --showclocks --showpower --showtemp"},

@@ -100,6 +100,7 @@ struct bigsi_hip_index {
     uint64_t m = 0, n_cols = 0, cap_cols = 0, stride_words = 0;
     uint32_t h = 0;
     uint64_t *d_index = nullptr;
+    bool contiguous = false;      // d_index is physically contiguous memory (index_malloc)
     DevBuf stage, stage_ids;
     // profiling
     int profiling = 0;            // 0 off, 1 every kernel group of a run, 2 the row-AND kernel only

@@ -416,6 +416,8 @@ typedef struct {
     uint64_t and_launches_total; /* row-AND launches since the last reset, timed or not (and_launches counts the timed ones) */
     uint64_t read_launches_repeated; /* one-launch read kernels that were run again because a workgroup gave up waiting for
                                         the hit totals of the queries before it (possible only beside launches of other batches) */
+    uint64_t index_contiguous;       /* 1: the matrix got physically contiguous device memory (hipDeviceMallocContiguous: largest
+                                        page-table fragments), 0: the ordinary allocation it falls back to */
 } bigsi_hip_stats_t;
 /* record HIP events around the kernels of batch_run: 0 off, 1 around K1 / K2 / K4 each, 2 around the row-AND kernel only,
  * n > 2 around the row-AND kernel of every n-th run (an event record costs the stream 5-7 us, which is a fifth of a

@@ -9,7 +9,8 @@
 //   random   uniform over the matrix, in draw order
 //   sorted   the same ids sorted per query (what K1e's bucket sort gives k_and_exact)
 //   banded   random ids drawn from a window of <band_mb> MB that advances with the launch (locality without order)
-// Allocation: hipMalloc, or --vmm: hipMemCreate + hipMemMap in chunks of the recommended granularity (page-table fragment size).
+// Allocation: hipMalloc, --vmm: hipMemCreate + hipMemMap in chunks of the recommended granularity (page-table fragment size), or
+// --contig: hipExtMallocWithFlags(hipDeviceMallocContiguous).
 // Prints GB/s = bytes of all rows streamed / median launch time (hipEvents around each launch).
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -57,7 +58,7 @@ int main(int argc, char **argv)
     double gb = 16;
     uint64_t row_bytes = 12500, rows_per_query = 3880, band_mb = 4096;
     uint32_t n_queries = 1024, wgs = 512;
-    bool vmm = false;
+    bool vmm = false, contig = false;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto val = [&]() { return std::string(argv[++i]); };
@@ -68,6 +69,7 @@ int main(int argc, char **argv)
         else if (a == "--wgs") wgs = atoi(val().c_str());
         else if (a == "--band-mb") band_mb = strtoull(val().c_str(), nullptr, 10);
         else if (a == "--vmm") vmm = true;
+        else if (a == "--contig") contig = true;
     }
     const uint64_t pitch = (row_bytes + 127) / 128 * 128, n_rows = (uint64_t)(gb * 1e9) / pitch, bytes = n_rows * pitch;
     const uint32_t segs = (uint32_t)((pitch + 1023) / 1024);
@@ -93,6 +95,8 @@ int main(int argc, char **argv)
         acc.flags = hipMemAccessFlagsProtReadWrite;
         CK(hipMemSetAccess(va, total, &acc, 1));
         d = (uint8_t *)va;
+    } else if (contig) {
+        CK(hipExtMallocWithFlags((void **)&d, bytes, hipDeviceMallocContiguous));      // physically contiguous: the largest page-table fragments
     } else {
         CK(hipMalloc((void **)&d, bytes));
     }
@@ -100,7 +104,7 @@ int main(int argc, char **argv)
     CK(hipDeviceSynchronize());
     printf("matrix %.1f GB: %llu rows x %llu B (pitch %llu, %u segments); %u queries x %llu rows; launches of %u workgroups; alloc %s",
            bytes / 1e9, (unsigned long long)n_rows, (unsigned long long)row_bytes, (unsigned long long)pitch, segs, n_queries,
-           (unsigned long long)rows_per_query, wgs, vmm ? "vmm" : "hipMalloc");
+           (unsigned long long)rows_per_query, wgs, vmm ? "vmm" : contig ? "hipExtMallocWithFlags(contiguous)" : "hipMalloc");
     if (vmm) printf(" (granularity min %zu rec %zu)", gran_min, gran_rec);
     printf("\n");
     uint64_t *d_rows;
