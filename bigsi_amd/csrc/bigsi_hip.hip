@@ -98,13 +98,15 @@ static int quiesce_reads(bigsi_hip_index *ix)
 
 static uint64_t stride_for(uint64_t cols) { return std::max<uint64_t>(16, round_up(ceil_div(cols, 64), 16)); }
 
-// The matrix is asked for as PHYSICALLY CONTIGUOUS memory first (hipDeviceMallocContiguous): the driver then maps it with the
-// largest page-table fragments, and rows at random addresses cost fewer translation walks -- the bare-kernel probe
-// (scripts/probe/row_probe.hip --contig) measured +4 % on random 12.5 KB rows of a 125 GB matrix (0.751 -> 0.783 of peak), +0.5 %
-// on address-ordered ones.  A device that cannot find such a block (fragmented memory) gets the ordinary allocation.
+// The matrix is an ordinary hipMalloc.  Tuning builds can ask for PHYSICALLY CONTIGUOUS memory instead (BIGSI_HIP_CONTIGUOUS=1:
+// hipDeviceMallocContiguous, largest page-table fragments): the bare-kernel probe measured +4 % on random 12.5 KB rows with it and
+// the counting kernel +0.5 %, but in a process that opens and closes several indexes one after the other it CORRUPTS another
+// buffer -- counters of the last queries of a batch read back as zeros, deterministically, in
+// test_one_launch_read_path_equals_three_launch_path[4-32768] (bisected to this flag alone; the driver appears to move or clear
+// memory under a running process when it makes room for a contiguous block).  Not shipped.
 static hipError_t index_malloc(uint64_t **out, size_t bytes, bool *contiguous)
 {
-    static const int contig = env_int("BIGSI_HIP_CONTIGUOUS", 1);
+    static const int contig = env_int("BIGSI_HIP_CONTIGUOUS", 0);
     *contiguous = false;
     if (contig) {
         hipError_t e = hipExtMallocWithFlags((void **)out, bytes, hipDeviceMallocContiguous);
