@@ -184,6 +184,8 @@ def cpu_baseline(args, w, cols_cpu, exact):
                      "sample": "fork pool over query sequences (the reference's bulk_search parallelism), %d workers, median of %d runs of %.1f s"
                                % (t["pool"]["threads"], len(t["pool"]["rates"]), t["pool"]["seconds"])},
             "word_parallel_one_core": {"value": t["word_parallel_one_core"]["rate"], "what": "BIGSI_CPU_WORD_PARALLEL: 64-bit words of the resident rows, no copies"},
+            "word_parallel_pool": {"value": t["word_parallel_pool"]["rate"], "cores": t["word_parallel_pool"]["threads"],
+                                   "what": "the same in the fork pool: the best this host's CPUs do on the path"},
             "oracle_port": {"value": r["one_core"]["rate"], "pool": r["pool"]["rate_median"], "pool_cores": r["pool"]["threads"],
                             "what": "oracle/bigsi_oracle.c orc_query (test infrastructure), same slice and queries: cross-check of the twin"}}
 

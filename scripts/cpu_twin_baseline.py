@@ -5,7 +5,7 @@ cores by bench.py's cpu_baseline leg (a subprocess: its fork pool must not inher
      AND, unpack-to-int32-and-add: bigsi_cpu_search_batch) for --seconds;
   2. the same in a fork pool of one worker per physical core over query sequences -- the reference's only parallelism
      (bulk_search, bigsi/__main__.py:273-287);
-  3. one core, BIGSI_CPU_WORD_PARALLEL (64-bit words of the resident rows, no copies): the "best CPU" line.
+  3. BIGSI_CPU_WORD_PARALLEL (64-bit words of the resident rows, no copies) on one core and in the same fork pool: the "best CPU" lines.
 The index is the GPU run's synthetic index (same generator, same seed) at full row width but only --rows rows, so that it fits
 host RAM; per-lookup work is identical.  Rows are served from RAM, which favours the CPU over the reference's BerkeleyDB.
 Prints one JSON object."""
@@ -81,7 +81,11 @@ def main():
         for _ in range(max(1, a.pool_runs)):
             res = pool.map(_work, [(w, a.seconds, 0) for w in range(a.threads)])
             rates.append(sum(r[0] for r in res) / max(r[1] for r in res))
+    with mp.get_context("fork").Pool(a.threads) as pool:     # the "best CPU" line: word-parallel mode on every physical core
+        res = pool.map(_work, [(w, a.seconds, 1 << 16) for w in range(a.threads)])
+        wp_pool = sum(r[0] for r in res) / max(r[1] for r in res)
     print(json.dumps({"one_core": {"lookups": one_done, "seconds": one_t, "rate": one_done / one_t},
+                      "word_parallel_pool": {"threads": a.threads, "rate": wp_pool},
                       "word_parallel_one_core": {"lookups": wp_done, "seconds": wp_t, "rate": wp_done / wp_t},
                       "pool": {"threads": a.threads, "seconds": a.seconds, "rates": rates, "rate_median": float(np.median(rates)), "rate_best": max(rates)},
                       "rows": a.rows, "cols": a.cols, "fill_seconds": fill_s, "host_threads": os.cpu_count()}))
