@@ -217,26 +217,38 @@ def run_also_legs():
                         "roofline": {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "kernel_ms", "alg_bytes_per_launch",
                                                            "launches_per_step", "step_GBps", "step_frac", "concurrent_launches", "traffic",
                                                            "traffic_measured_in_run", "read_launches_repeated")},
-                        "verified": cf.get("verified"), "host_visible": cf.get("host_visible"),
-                        "presence": cf.get("presence"), "clocks": cf.get("clocks"), "index_contiguous": cf.get("index_contiguous"),
-                        "index_gb": cf.get("index_gb_per_gpu"), "wall_s": time.time() - t0, "args": " ".join(extra)}
+                        "verified": cf.get("verified"), "host_visible": {"stream_kmer_lookups_per_s": ((cf.get("host_visible") or {}).get("stream") or {}).get("kmer_lookups_per_s"),
+                                                                   "stream_sequences": ((cf.get("host_visible") or {}).get("stream") or {}).get("sequences"),
+                                                                   "one_call_us": {k_: v_ for k_, v_ in ((cf.get("host_visible") or {}).get("one_call_us") or {}).items() if k_ != "entry"},
+                                                                   "two_workspace_loop_kmer_lookups_per_s": (cf.get("host_visible") or {}).get("two_workspace_loop_kmer_lookups_per_s")},
+                        "scored": {k_: v_ for k_, v_ in (cf.get("presence") or {}).items() if k_ != "what"} or None,
+                        "clocks_after": (cf.get("clocks") or {}).get("after_timed_region"),
+                        "index_gb": cf.get("index_gb_per_gpu"), "wall_s": round(time.time() - t0, 1), "args": " ".join(extra)}
         except Exception as e:  # noqa: BLE001 -- a leg that fails is reported as such, the headline stands
             out[key] = {"what": what, "error": "%s: %s" % (type(e).__name__, str(e)[:300]), "args": " ".join(extra)}
     return out
 
 
 def smi_snapshot(device):
-    """Clocks / power / temperature of the device as rocm-smi reports them (explains box-to-box spread of the bandwidth figures)."""
+    """Clocks / power / temperature of the device as rocm-smi reports them (explains box-to-box spread of the bandwidth figures):
+    {sclk_mhz, mclk_mhz, fclk_mhz, power_w, temp_junction_c, temp_memory_c}."""
+    import re
     try:
         r = subprocess.run(["rocm-smi", "-d", str(device), "--showclocks", "--showpower", "--showtemp", "--json"], capture_output=True, text=True, timeout=20)
         d = json.loads(r.stdout)
         card = d[sorted(d)[0]]
-        keep = {}
+        out = {}
         for k, v in card.items():
             kl = k.lower()
-            if any(t in kl for t in ("sclk", "mclk", "fclk", "socclk", "power", "temperature")):
-                keep[k] = v
-        return keep
+            num = re.search(r"-?\d+(\.\d+)?", str(v))
+            if not num:
+                continue
+            val = float(num.group(0))
+            for tag, name in (("sclk clock speed", "sclk_mhz"), ("mclk clock speed", "mclk_mhz"), ("fclk clock speed", "fclk_mhz"), ("power", "power_w"),
+                              ("sensor junction", "temp_junction_c"), ("sensor memory", "temp_memory_c")):
+                if tag in kl and name not in out:
+                    out[name] = val
+        return out
     except Exception as e:  # noqa: BLE001
         return {"error": "%s: %s" % (type(e).__name__, str(e)[:120])}
 
@@ -714,7 +726,7 @@ def main():
                 "index_fill_s": fill_s, "index_contiguous": bool(stats.index_contiguous), "verified": verified, "presence": presence,
                 "pcie_inclusive_kmer_lookups_per_s": pcie_rate,
                 "host_visible": host_visible,
-                "clocks": {"before_timed_region": clocks_before, "after_timed_region": clocks_after, "source": "rocm-smi --showclocks --showpower --showtemp"},
+                "clocks": {"before_timed_region": clocks_before, "after_timed_region": clocks_after},
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "traffic_measured_in_run": False,
