@@ -9,6 +9,7 @@
  *                 then n_samples lines  "<n_seqs> seq seq ..."   (sample i = column i)
  *                 then n_queries lines  "seq"
  * output:         per pass ("exact" / "threshold"), per query:  q <i> kmers <n> unique <u> min <mk> hits <c>:<count> ...
+ *                 then "stream <pass> identical": bigsi_hip_search_stream over the same queries gave the same arrays
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -52,6 +53,23 @@ static int run_pass(bigsi_hip_index *ix, const char *name, const char *blob, con
         printf("q %u kmers %u unique %u min %u hits", q, nk[q], nu[q], mk[q]);
         for (uint64_t t = ho[q]; t < ho[q + 1]; t++) printf(" %u:%u", col[t], cnt[t]);
         printf("\n");
+    }
+    /* the streaming entry point (any number of sequences in one call: bulk_search, bigsi/__main__.py:261-314) must give the same */
+    {
+        uint32_t *nk2 = malloc(nq * sizeof *nk2), *nu2 = malloc(nq * sizeof *nu2), *mk2 = malloc(nq * sizeof *mk2);
+        uint64_t *ho2 = malloc((nq + 1) * sizeof *ho2);
+        uint32_t *col2 = malloc((cap ? cap : 1) * sizeof *col2), *cnt2 = malloc((cap ? cap : 1) * sizeof *cnt2);
+        if (!nk2 || !nu2 || !mk2 || !ho2 || !col2 || !cnt2) return 1;
+        rc = bigsi_hip_search_stream(ix, blob, off, nq, k, thr, 0u, nk2, nu2, mk2, ho2, col2, cnt2, cap);
+        if (rc != BIGSI_OK) {
+            fprintf(stderr, "bigsi_hip_search_stream -> %d: %s\n", rc, bigsi_hip_last_error());
+            return 1;
+        }
+        int same = memcmp(nk, nk2, nq * sizeof *nk) == 0 && memcmp(nu, nu2, nq * sizeof *nu) == 0 && memcmp(mk, mk2, nq * sizeof *mk) == 0 &&
+                   memcmp(ho, ho2, (nq + 1) * sizeof *ho) == 0 && memcmp(col, col2, ho[nq] * sizeof *col) == 0 &&
+                   memcmp(cnt, cnt2, ho[nq] * sizeof *cnt) == 0;
+        printf("stream %s %s\n", name, same ? "identical" : "DIFFERENT");
+        free(nk2); free(nu2); free(mk2); free(ho2); free(col2); free(cnt2);
     }
     free(nk); free(nu); free(mk); free(ho); free(col); free(cnt);
     return 0;

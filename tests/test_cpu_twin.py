@@ -239,13 +239,17 @@ def test_twin_synthetic_fill_is_the_devices_generator(cpu):
 
 def parse_c_host_output(text):
     out = text.splitlines()
-    passes, cur = {}, None
+    passes, cur, streams = {}, None, []
     for ln in out[1:-1]:
         f = ln.split()
         if f[0] == "pass":
             cur = passes.setdefault(f[1], {})
+        elif f[0] == "stream":                     # bigsi_hip_search_stream over the same queries
+            assert f[2] == "identical", ln
+            streams.append(f[1])
         else:
             cur[int(f[1])] = (int(f[3]), int(f[5]), int(f[7]), [tuple(map(int, x.split(":"))) for x in f[9:]])
+    assert streams == ["exact", "threshold"]
     return out[0], passes, out[-1]
 
 

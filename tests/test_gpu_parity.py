@@ -1187,13 +1187,17 @@ def test_c_host_of_the_abi(hip, tmp_path):
     out = r.stdout.splitlines()
     assert out[0] == "index rows %d cols %d hashes %d row_bytes %d" % (g["m"], len(names), g["h"], -(-len(names) // 8))
     assert out[-1] == "error reported"
-    passes, cur = {}, None
+    passes, cur, streams = {}, None, []
     for ln in out[1:-1]:
         f = ln.split()
         if f[0] == "pass":
             cur = passes.setdefault(f[1], {})
+        elif f[0] == "stream":                     # bigsi_hip_search_stream over the same queries
+            assert f[2] == "identical", ln
+            streams.append(f[1])
         else:
             cur[int(f[1])] = (int(f[3]), int(f[5]), int(f[7]), [tuple(map(int, x.split(":"))) for x in f[9:]])
+    assert streams == ["exact", "threshold"]
     checked = 0
     for name, thr in (("exact", 1.0), ("threshold", 0.4)):
         assert sorted(passes[name]) == list(range(len(g["queries"])))
