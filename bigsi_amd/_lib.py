@@ -118,6 +118,7 @@ SIGNATURES = {
     "bigsi_hip_batch_set_result_cols": (_i32, [_P, _u64]),
     "bigsi_hip_search_batch": (_i32, [_P, C.c_char_p, _P, _u32, _u32, _dbl, _u32, _P, _P, _P, _P, _P, _P, _u64]),
     "bigsi_hip_search_stream": (_i32, [_P, C.c_char_p, _P, _u64, _u32, _dbl, _u32, _P, _P, _P, _P, _P, _P, _u64]),
+    "bigsi_hip_search_stream_scored": (_i32, [_P, C.c_char_p, _P, _u64, _u32, _dbl, _u32, _P, _P, _P, _P, _P, _P, _u64, _P, _u64, _P, _P, _P]),
     "bigsi_hip_comm_unique_id": (_i32, [_P]),
     "bigsi_hip_comm_init_rank": (_i32, [_i32, _P, _i32, _i32, C.POINTER(_P)]),
     "bigsi_hip_comm_destroy": (_i32, [_P]),

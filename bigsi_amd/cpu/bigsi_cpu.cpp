@@ -615,4 +615,58 @@ int bigsi_cpu_score_presence(int, const uint8_t *bits, const uint64_t *bit_offse
     return BIGSI_OK;
 }
 
+// BIGSI.search(..., score=True) for any number of sequences (the twin of bigsi_hip_search_stream_scored): the hit lists of
+// bigsi_cpu_search_stream, then per sequence with hits its presence bits (graph/bigsi.py:232-237, one test per k-mer position,
+// colour and hash) and Scorer.score's record (bigsi_score.hpp, the code the device compiles).
+int bigsi_cpu_search_stream_scored(bigsi_cpu_index *ix, const char *seqs, const uint64_t *offsets, uint64_t n_seqs, uint32_t k,
+                                   double threshold, uint32_t flags, uint32_t *num_kmers, uint32_t *num_unique, uint32_t *min_kmers,
+                                   uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t hit_capacity, uint8_t *bits,
+                                   uint64_t bits_capacity, uint64_t *bit_offsets, bigsi_hip_hit_score *scores, uint64_t *bits_needed)
+{
+    if (!bit_offsets) return fail(BIGSI_ERR_INVALID, "bit_offsets is NULL");
+    if (hit_capacity && (!colours || !scores)) return fail(BIGSI_ERR_INVALID, "colours / scores is NULL");
+    bit_offsets[0] = 0;
+    if (bits_needed) *bits_needed = 0;
+    std::vector<uint32_t> nk_own, nu_own;
+    if (!num_kmers) { nk_own.resize(n_seqs); num_kmers = nk_own.data(); }
+    if (!num_unique) { nu_own.resize(n_seqs); num_unique = nu_own.data(); }
+    const int rc = bigsi_cpu_search_stream(ix, seqs, offsets, n_seqs, k, threshold, flags, num_kmers, num_unique, min_kmers, hit_offsets, colours,
+                                           counts, hit_capacity);
+    if (rc != BIGSI_OK && rc != BIGSI_ERR_CAPACITY) return rc;
+    uint64_t need = 0;
+    for (uint64_t i = 0; i < n_seqs; i++) need += (hit_offsets[i + 1] - hit_offsets[i]) * (((uint64_t)num_kmers[i] + 63) / 64 * 8);
+    if (bits_needed) *bits_needed = need;
+    if (rc == BIGSI_ERR_CAPACITY) return rc;
+    const bool fits = need <= bits_capacity && (bits || need == 0);
+    std::vector<uint8_t> text;
+    uint64_t at = 0;
+    for (uint64_t i = 0; i < n_seqs; i++) {
+        const uint64_t lo = hit_offsets[i], hi = hit_offsets[i + 1], n = num_kmers[i], bytes = (n + 63) / 64 * 8;
+        if (hi == lo) continue;
+        if (fits && n) {
+            text.resize((hi - lo) * n);
+            TRY(bigsi_cpu_presence(ix, seqs + offsets[i], offsets[i + 1] - offsets[i], k, colours + lo, (uint32_t)(hi - lo), text.data()));
+        }
+        for (uint64_t t = lo; t < hi; t++) {
+            bit_offsets[t] = at;
+            if (fits) {
+                memset(&scores[t], 0, sizeof scores[t]);
+                if (n) {
+                    uint8_t *p = bits + at;
+                    memset(p, 0, bytes);
+                    const uint8_t *s = text.data() + (t - lo) * n;
+                    for (uint64_t j = 0; j < n; j++)
+                        if (s[j] == '1') p[j >> 3] |= (uint8_t)(0x80u >> (j & 7));
+                    bigsi_score::score_hit([p](uint32_t kk) { uint64_t w; memcpy(&w, p + 8ull * kk, 8); return bigsi_score::lsb_first(w); }, (uint32_t)n,
+                                           counts ? counts[t] : num_unique[i], num_unique[i], reinterpret_cast<bigsi_score::HitScore *>(&scores[t]));
+                }
+            }
+            at += bytes;
+        }
+    }
+    bit_offsets[hit_offsets[n_seqs]] = at;
+    if (!fits) return fail(BIGSI_ERR_CAPACITY, "bit buffer holds %llu bytes, %llu needed", (unsigned long long)bits_capacity, (unsigned long long)need);
+    return BIGSI_OK;
+}
+
 }  // extern "C"

@@ -118,13 +118,28 @@ extern "C" int bigsi_hip_search_batch(bigsi_hip_index *ix, const char *seqs, con
 // while one batch runs, the next is staged and uploaded and the results of the one before are exported and copied out -- and
 // writes every sequence's results at its place in the caller's arrays (hit_offsets are global: n_seqs + 1 entries).
 // BIGSI_ERR_CAPACITY (hit_offsets complete, colours / counts filled as far as they fit) when hit_capacity is too small.
-extern "C" int bigsi_hip_search_stream(bigsi_hip_index *ix, const char *seqs, const uint64_t *offsets, uint64_t n_seqs, uint32_t k,
-                                       double threshold, uint32_t flags, uint32_t *num_kmers, uint32_t *num_unique, uint32_t *min_kmers,
-                                       uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t hit_capacity)
+//
+// With `so` (score=True): a chunk's hit lists are collected one chunk after its launch instead of two, its presence bits and
+// score records are requested at once (K5 + K6 on the score stream, beside the row-AND kernels of the chunk just launched)
+// and copied out one chunk later, just before its workspace is staged again.
+namespace {
+struct ScoredOut {
+    uint8_t *bits;
+    uint64_t bits_capacity;
+    uint64_t *bit_offsets;            // hit_capacity + 1 entries
+    bigsi_hip_hit_score *scores;      // hit_capacity entries
+    uint64_t *bits_needed;
+};
+
+int search_stream_impl(bigsi_hip_index *ix, const char *seqs, const uint64_t *offsets, uint64_t n_seqs, uint32_t k, double threshold,
+                       uint32_t flags, uint32_t *num_kmers, uint32_t *num_unique, uint32_t *min_kmers, uint64_t *hit_offsets,
+                       uint32_t *colours, uint32_t *counts, uint64_t hit_capacity, const ScoredOut *so)
 {
     if (!ix || !offsets || !hit_offsets) return fail(BIGSI_ERR_INVALID, "NULL argument");
     if (k == 0) return fail(BIGSI_ERR_INVALID, "k must be > 0");
+    if (so && (!so->bit_offsets || !so->bits_needed)) return fail(BIGSI_ERR_INVALID, "NULL argument");
     hit_offsets[0] = 0;
+    if (so) { so->bit_offsets[0] = 0; *so->bits_needed = 0; }
     if (n_seqs == 0) return BIGSI_OK;
     constexpr int kSlots = 3;
     // a batch = at most 2^20 k-mer positions (gene-length queries: ~1000 of 1 kbp) and at most kChunkSeqs sequences (reads): 2^14 of
@@ -133,25 +148,63 @@ extern "C" int bigsi_hip_search_stream(bigsi_hip_index *ix, const char *seqs, co
     // 1.32 G with 2^13 against 1.12 with 2^15)
     constexpr uint64_t kChunkPositions = 1ull << 20;
     const uint64_t kChunkSeqs = std::min<uint64_t>(1ull << 14, std::max<uint64_t>(1ull << 12, (n_seqs + 5) / 6));
-    struct Chunk { uint64_t first; uint32_t n; };
+    struct Chunk { uint64_t first; uint32_t n; uint64_t hit0, bit0; bool scoring; };
     Chunk inflight[kSlots] = {};
-    bool busy[kSlots] = {};
+    bool busy[kSlots] = {};          // launched, hit lists not collected yet
     uint64_t total = 0;              // hits so far (global offset of the next chunk's first hit)
-    bool overflow = false;
-    std::vector<uint64_t> rel;
+    uint64_t bits_total = 0;         // bytes of presence bits so far
+    bool overflow = false, bits_overflow = false;
+    std::vector<uint64_t> rel, rel_bits;
     auto collect = [&](int s) -> int {
-        const Chunk c = inflight[s];
+        Chunk &c = inflight[s];
         busy[s] = false;
         rel.resize(c.n + 1ull);
         const uint64_t room = total < hit_capacity ? hit_capacity - total : 0;
-        int rc = bigsi_batch_collect(ix->stream_ws[s], num_kmers ? num_kmers + c.first : nullptr, num_unique ? num_unique + c.first : nullptr,
+        uint32_t *nk = num_kmers ? num_kmers + c.first : nullptr;
+        int rc = bigsi_batch_collect(ix->stream_ws[s], nk, num_unique ? num_unique + c.first : nullptr,
                                      min_kmers ? min_kmers + c.first : nullptr, rel.data(), colours ? colours + total : nullptr,
                                      counts ? counts + total : nullptr, overflow ? 0 : room);
         if (rc == BIGSI_ERR_CAPACITY) { overflow = true; rc = BIGSI_OK; }
         if (rc != BIGSI_OK) return rc;
         for (uint32_t i = 1; i <= c.n; i++) hit_offsets[c.first + i] = total + rel[i];
+        c.hit0 = total;
+        c.bit0 = bits_total;
+        c.scoring = false;
+        if (so) {
+            if (!overflow && rel[c.n]) {
+                // the request: this chunk's hit lists as they lie in the caller's arrays
+                rel_bits.resize(rel[c.n] + 1);
+                rc = bigsi_hip_batch_score_hits_begin(ix->stream_ws[s], rel.data(), colours + total, counts ? counts + total : nullptr, 0, rel_bits.data());
+                if (rc != BIGSI_OK) return rc;
+                c.scoring = true;
+                for (uint64_t t = 0; t <= rel[c.n]; t++) so->bit_offsets[total + t] = bits_total + rel_bits[t];
+                bits_total += rel_bits[rel[c.n]];
+            } else if (rel[c.n]) {
+                // the lists did not fit: only the bytes their strings would need (whole 8-byte words per string)
+                uint32_t tmp = 0;
+                for (uint32_t i = 0; i < c.n; i++) {
+                    const uint64_t len = offsets[c.first + i + 1] - offsets[c.first + i];
+                    tmp = len >= k ? (uint32_t)(len - k + 1) : 0;
+                    bits_total += (rel[i + 1] - rel[i]) * (((uint64_t)tmp + 63) / 64 * 8);
+                }
+            }
+        }
         total += rel[c.n];
         return BIGSI_OK;
+    };
+    auto finish_score = [&](int s) -> int {
+        Chunk &c = inflight[s];
+        if (!c.scoring) return BIGSI_OK;
+        c.scoring = false;
+        const uint64_t need = so->bit_offsets[c.hit0 + (hit_offsets[c.first + c.n] - c.hit0)] - c.bit0;
+        if (c.bit0 + need > so->bits_capacity || !so->bits) {
+            // no room for this chunk's bits: finish the request into nothing (the batch has to be free for its next run)
+            bits_overflow = true;
+            std::vector<uint8_t> sink_bits(need + 8);
+            std::vector<bigsi_hip_hit_score> sink(hit_offsets[c.first + c.n] - c.hit0);
+            return bigsi_hip_batch_score_hits_end(ix->stream_ws[s], sink_bits.data(), need, sink.data());
+        }
+        return bigsi_hip_batch_score_hits_end(ix->stream_ws[s], so->bits + c.bit0, need, so->scores + c.hit0);
     };
     int rc = BIGSI_OK;
     uint64_t next = 0;
@@ -160,21 +213,28 @@ extern "C" int bigsi_hip_search_stream(bigsi_hip_index *ix, const char *seqs, co
         // the next chunk: up to kChunkPositions k-mer positions, at least one sequence
         uint64_t end = next, pos = 0;
         while (end < n_seqs && end - next < kChunkSeqs) {
-            if (offsets[end + 1] < offsets[end]) return fail(BIGSI_ERR_INVALID, "offsets must be non-decreasing");
+            if (offsets[end + 1] < offsets[end]) { rc = fail(BIGSI_ERR_INVALID, "offsets must be non-decreasing"); break; }
             const uint64_t len = offsets[end + 1] - offsets[end], n = len >= k ? len - k + 1 : 0;
             if (end > next && pos + n > kChunkPositions) break;
             pos += std::max<uint64_t>(n, 1);
             end++;
         }
-        if (busy[slot]) rc = collect(slot);                    // this workspace's previous chunk (two chunks ago)
+        if (rc != BIGSI_OK) break;
+        if (busy[slot]) rc = collect(slot);                    // this workspace's previous chunk (three chunks ago)
+        if (rc == BIGSI_OK && so) rc = finish_score(slot);
         if (rc != BIGSI_OK) break;
         rc = bigsi_batch_stage(ix, &ix->stream_ws[slot], seqs, offsets + next, (uint32_t)(end - next), k);
         if (rc == BIGSI_OK) rc = bigsi_hip_batch_run(ix->stream_ws[slot], threshold, (flags & ~BIGSI_RUN_SKIP_COMPACT) | BIGSI_RUN_SPARSE_COUNTS);
         if (rc == BIGSI_OK) rc = bigsi_batch_export(ix->stream_ws[slot]);
         if (rc != BIGSI_OK) break;
-        inflight[slot] = Chunk{next, (uint32_t)(end - next)};
+        inflight[slot] = Chunk{next, (uint32_t)(end - next), 0, 0, false};
         busy[slot] = true;
         next = end;
+        if (so) {
+            // the chunk before this one: hit lists out, scores requested (they run beside the chunk just launched)
+            const int prev = (slot + kSlots - 1) % kSlots;
+            if (busy[prev]) rc = collect(prev);
+        }
         slot = (slot + 1) % kSlots;
     }
     // drain in submission order
@@ -182,13 +242,40 @@ extern "C" int bigsi_hip_search_stream(bigsi_hip_index *ix, const char *seqs, co
         const int s2 = (slot + i) % kSlots;
         if (busy[s2]) rc = collect(s2);
     }
+    for (int i = 0; i < kSlots && rc == BIGSI_OK && so; i++) rc = finish_score((slot + i) % kSlots);
     if (rc != BIGSI_OK) {
         for (auto &w : ix->stream_ws)
             if (w) { bigsi_hip_batch_destroy(w); w = nullptr; }
         return rc;
     }
+    if (so) *so->bits_needed = bits_total;
     if (overflow) return fail(BIGSI_ERR_CAPACITY, "hit buffers hold %llu entries, %llu needed", (unsigned long long)hit_capacity, (unsigned long long)total);
+    if (bits_overflow) return fail(BIGSI_ERR_CAPACITY, "bit buffer holds %llu bytes, %llu needed", (unsigned long long)so->bits_capacity, (unsigned long long)bits_total);
     return BIGSI_OK;
+}
+}   // namespace
+
+extern "C" int bigsi_hip_search_stream(bigsi_hip_index *ix, const char *seqs, const uint64_t *offsets, uint64_t n_seqs, uint32_t k,
+                                       double threshold, uint32_t flags, uint32_t *num_kmers, uint32_t *num_unique, uint32_t *min_kmers,
+                                       uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t hit_capacity)
+{
+    return search_stream_impl(ix, seqs, offsets, n_seqs, k, threshold, flags, num_kmers, num_unique, min_kmers, hit_offsets, colours, counts,
+                              hit_capacity, nullptr);
+}
+
+// BIGSI.search(..., score=True) for any number of sequences in one call: as above, plus for every hit t (global index into
+// colours) its presence bits at bits + bit_offsets[t] (the layout of bigsi_hip_batch_score_hits) and its score record.
+extern "C" int bigsi_hip_search_stream_scored(bigsi_hip_index *ix, const char *seqs, const uint64_t *offsets, uint64_t n_seqs, uint32_t k,
+                                              double threshold, uint32_t flags, uint32_t *num_kmers, uint32_t *num_unique,
+                                              uint32_t *min_kmers, uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts,
+                                              uint64_t hit_capacity, uint8_t *bits, uint64_t bits_capacity, uint64_t *bit_offsets,
+                                              bigsi_hip_hit_score *scores, uint64_t *bits_needed)
+{
+    if (hit_capacity && (!colours || !scores)) return fail(BIGSI_ERR_INVALID, "colours / scores is NULL");
+    uint64_t needed = 0;
+    const ScoredOut so{bits, bits_capacity, bit_offsets, scores, bits_needed ? bits_needed : &needed};
+    return search_stream_impl(ix, seqs, offsets, n_seqs, k, threshold, flags, num_kmers, num_unique, min_kmers, hit_offsets, colours, counts,
+                              hit_capacity, &so);
 }
 
 // ------------------------------------------------------------------------------ communicators

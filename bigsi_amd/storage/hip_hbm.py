@@ -222,6 +222,7 @@ class _Resident(object):
 class HipHbmStorage(BaseStorage):
     fused = True      # BIGSI.search/lookup may call search_batch / lookup_kmers
     _search_cap = 1 << 12     # hit entries search_batch brings buffers for (grows to what a call needed)
+    _bits_cap = 1 << 16       # bytes of presence bits search_many_scored brings a buffer for
 
     def __init__(self, storage_config=None):
         self.storage_config = dict(storage_config or {})
@@ -497,6 +498,39 @@ class HipHbmStorage(BaseStorage):
         check(rc)
         total = int(off[-1])
         return nk, nu, off, col[:total], cnt[:total]
+
+    def search_many_scored(self, seqs, k, threshold=1.0):
+        """bigsi_hip_search_stream_scored: search_many plus, per hit, the presence bits and the score record of score=True
+        (bigsi/scoring/score.py:96-121), K5 + K6 of one device batch running beside the row-AND kernels of the next.  Returns
+        (num_kmers, num_unique, hit_offsets, colours, counts, bits, bit_offsets, scores): hit t's presence string is
+        scoring.unpack_presence(bits, bit_offsets, t, num_kmers of its sequence); scores is a HIT_SCORE_DTYPE array."""
+        from bigsi_amd.scoring import HIT_SCORE_DTYPE
+        assert threshold <= 1
+        seqs = seqs if isinstance(seqs, (list, tuple)) else list(seqs)
+        n = len(seqs)
+        nk, nu = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        off = np.zeros(n + 1, np.uint64)
+        if n == 0:
+            return nk, nu, off, np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.uint8), np.zeros(1, np.uint64), np.zeros(0, HIT_SCORE_DTYPE)
+        if self.res.is_group:
+            raise BigsiHipError(_lib.ERR_STATE, "search_many_scored is not available on a multi-GPU index")
+        blob, soff = _lib.pack_seqs(seqs)
+        cap, bcap = max(self._search_cap, 1 << 12), max(self._bits_cap, 1 << 16)
+        need = np.zeros(1, np.uint64)
+        while True:
+            col, cnt = np.zeros(cap, np.uint32), np.zeros(cap, np.uint32)
+            bits, boff, rec = np.zeros(bcap, np.uint8), np.zeros(cap + 1, np.uint64), np.zeros(cap, HIT_SCORE_DTYPE)
+            rc = _lib.lib().bigsi_hip_search_stream_scored(self.handle, blob, _lib.ptr(soff), n, int(k), float(threshold), 0, _lib.ptr(nk), _lib.ptr(nu),
+                                                           None, _lib.ptr(off), _lib.ptr(col), _lib.ptr(cnt), cap, _lib.ptr(bits), bcap,
+                                                           _lib.ptr(boff), _lib.ptr(rec), _lib.ptr(need))
+            if rc != _lib.ERR_CAPACITY or (int(off[-1]) <= cap and int(need[0]) <= bcap):
+                break
+            cap = self._search_cap = max(cap, int(off[-1]))
+            bcap = self._bits_cap = max(bcap, int(need[0]))
+        check(rc)
+        total = int(off[-1])
+        return nk, nu, off, col[:total], cnt[:total], bits[:int(need[0])], boff[:total + 1], rec[:total]
+
 
 
 class QueryBatch(object):

@@ -52,6 +52,10 @@ int bigsi_cpu_search_batch(bigsi_cpu_index *ix, const char *seqs, const uint64_t
 int bigsi_cpu_search_stream(bigsi_cpu_index *ix, const char *seqs, const uint64_t *offsets, uint64_t n_seqs, uint32_t k,
                             double threshold, uint32_t flags, uint32_t *num_kmers, uint32_t *num_unique, uint32_t *min_kmers,
                             uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t hit_capacity);
+int bigsi_cpu_search_stream_scored(bigsi_cpu_index *ix, const char *seqs, const uint64_t *offsets, uint64_t n_seqs, uint32_t k,
+                                   double threshold, uint32_t flags, uint32_t *num_kmers, uint32_t *num_unique, uint32_t *min_kmers,
+                                   uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t hit_capacity, uint8_t *bits,
+                                   uint64_t bits_capacity, uint64_t *bit_offsets, bigsi_hip_hit_score *scores, uint64_t *bits_needed);
 int bigsi_cpu_score_presence(int device, const uint8_t *bits, const uint64_t *bit_offsets, const uint32_t *num_kmers,
                              const uint32_t *found, const uint32_t *unique, uint64_t n, bigsi_hip_hit_score *scores);
 /* BIGSI.score's presence strings (bigsi/graph/bigsi.py:232-237) of ONE sequence for n_colours samples: n = len - k + 1 ASCII
@@ -89,6 +93,7 @@ int bigsi_cpu_presence(bigsi_cpu_index *ix, const char *seq, uint64_t len, uint3
 #define bigsi_hip_lookup bigsi_cpu_lookup
 #define bigsi_hip_search_batch bigsi_cpu_search_batch
 #define bigsi_hip_search_stream bigsi_cpu_search_stream
+#define bigsi_hip_search_stream_scored bigsi_cpu_search_stream_scored
 #define bigsi_hip_score_presence bigsi_cpu_score_presence
 #endif
 

@@ -322,6 +322,19 @@ int bigsi_hip_search_stream(bigsi_hip_index *ix, const char *seqs, const uint64_
                             double threshold, uint32_t flags, uint32_t *num_kmers, uint32_t *num_unique, uint32_t *min_kmers,
                             uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t hit_capacity);
 
+/* BIGSI.search(..., score=True) (bigsi/graph/bigsi.py:80-100 with bigsi/scoring/score.py:96-121) for any number of sequences
+ * in ONE call: bigsi_hip_search_stream plus, for every hit t (global index into colours), its presence bits at
+ * bits + bit_offsets[t] and its score record scores[t] (layout and fields of bigsi_hip_batch_score_hits).  The scoring kernels
+ * of one device batch run beside the row-AND kernels of the next.  bit_offsets: hit_capacity + 1 entries; scores:
+ * hit_capacity entries; *bits_needed (may be NULL) gets the bytes all presence bits take.  (A sequence without k-mers has, as in
+ * bigsi_hip_search_stream, no hits at threshold 1 and every column with count 0 below it; those hits get all-zero records.)
+ * BIGSI_ERR_CAPACITY when hit_capacity or bits_capacity is too small: hit_offsets and *bits_needed are complete then, so one
+ * retry with hit_offsets[n_seqs] entries and *bits_needed bytes succeeds (bits = NULL, bits_capacity = 0 is a sizing call). */
+int bigsi_hip_search_stream_scored(bigsi_hip_index *ix, const char *seqs, const uint64_t *offsets, uint64_t n_seqs, uint32_t k,
+                                   double threshold, uint32_t flags, uint32_t *num_kmers, uint32_t *num_unique, uint32_t *min_kmers,
+                                   uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t hit_capacity, uint8_t *bits,
+                                   uint64_t bits_capacity, uint64_t *bit_offsets, bigsi_hip_hit_score *scores, uint64_t *bits_needed);
+
 /* ================================================================== MULTI-GPU: column shards, the exchange (RCCL over xGMI)
  * An index too wide for one GPU is split by COLUMN RANGE: shard g holds all num_rows rows of columns
  * [g * shard_cols, (g+1) * shard_cols).  Every shard runs K1-K3 on the same queries; the only exchange is one

@@ -34,5 +34,16 @@ for score in (True, False):
     uniq = sum(len({s[i:i + k] for i in range(len(s) - k + 1)}) for s in seqs[:64]) / 64 * len(seqs)
     out["score=%s" % score] = {"seconds": dt, "queries": len(seqs), "hits": hits, "ms_per_256_queries": dt / n_batches * 1e3,
                                "kmer_lookups_per_s": uniq / dt, "keys_per_hit": len(res[0][1][0]) if res[0][1] else None}
+# the C boundary alone: bigsi_hip_search_stream_scored (sequences in; hit lists, presence bits and score records out), and the
+# unscored bigsi_hip_search_stream beside it
+for name, fn in (("c_stream_scored", index.storage.search_many_scored), ("c_stream", index.storage.search_many)):
+    fn(seqs[:512], k, 0.4)
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        r = fn(seqs, k, 0.4)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    out[name] = {"seconds": best, "hits": int(r[2][-1]), "ms_per_256_queries": best / n_batches * 1e3, "kmer_lookups_per_s": uniq / best}
 print(json.dumps(out))
 index.delete()

@@ -10,6 +10,7 @@
  *                 then n_queries lines  "seq"
  * output:         per pass ("exact" / "threshold"), per query:  q <i> kmers <n> unique <u> min <mk> hits <c>:<count> ...
  *                 then "stream <pass> identical": bigsi_hip_search_stream over the same queries gave the same arrays
+ *                 then "scored <pass> identical" and one "s ..." line per hit: bigsi_hip_search_stream_scored's records and bits
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -70,6 +71,40 @@ static int run_pass(bigsi_hip_index *ix, const char *name, const char *blob, con
                    memcmp(cnt, cnt2, ho[nq] * sizeof *cnt) == 0;
         printf("stream %s %s\n", name, same ? "identical" : "DIFFERENT");
         free(nk2); free(nu2); free(mk2); free(ho2); free(col2); free(cnt2);
+    }
+    /* score=True in one call (bigsi/graph/bigsi.py:80-100 + bigsi/scoring/score.py:96-121): a sizing call, then the real one */
+    {
+        uint64_t need = 0, one = 0;
+        uint64_t *ho3 = malloc((nq + 1) * sizeof *ho3);
+        if (!ho3) return 1;
+        rc = bigsi_hip_search_stream_scored(ix, blob, off, nq, k, thr, 0u, NULL, NULL, NULL, ho3, NULL, NULL, 0, NULL, 0, &one, NULL, &need);
+        if (rc != BIGSI_OK && rc != BIGSI_ERR_CAPACITY) {
+            fprintf(stderr, "bigsi_hip_search_stream_scored (sizing) -> %d: %s\n", rc, bigsi_hip_last_error());
+            return 1;
+        }
+        uint64_t n_hits = ho3[nq];
+        uint32_t *col3 = malloc((n_hits + 1) * sizeof *col3), *cnt3 = malloc((n_hits + 1) * sizeof *cnt3);
+        uint64_t *bo = malloc((n_hits + 1) * sizeof *bo);
+        uint8_t *bits = malloc(need + 8);
+        bigsi_hip_hit_score *rec = malloc((n_hits + 1) * sizeof *rec);
+        if (!col3 || !cnt3 || !bo || !bits || !rec) return 1;
+        rc = bigsi_hip_search_stream_scored(ix, blob, off, nq, k, thr, 0u, NULL, NULL, NULL, ho3, col3, cnt3, n_hits, bits, need, bo, rec, &need);
+        if (rc != BIGSI_OK) {
+            fprintf(stderr, "bigsi_hip_search_stream_scored -> %d: %s\n", rc, bigsi_hip_last_error());
+            return 1;
+        }
+        int same = memcmp(ho, ho3, (nq + 1) * sizeof *ho) == 0 && memcmp(col, col3, n_hits * sizeof *col) == 0 &&
+                   memcmp(cnt, cnt3, n_hits * sizeof *cnt) == 0;
+        printf("scored %s %s\n", name, same ? "identical" : "DIFFERENT");
+        for (uint32_t q = 0; q < nq; q++)
+            for (uint64_t t = ho3[q]; t < ho3[q + 1]; t++) {
+                /* s <query> <colour> <score> <min_score> <max_score> <mismatches> <min_mismatches> <max_mismatches> <percent> <presence> */
+                printf("s %u %u %.17g %.17g %.17g %lld %lld %lld %.17g ", q, col3[t], rec[t].score, rec[t].min_score, rec[t].max_score,
+                       (long long)rec[t].mismatches, (long long)rec[t].min_mismatches, (long long)rec[t].max_mismatches, rec[t].percent_kmers_found);
+                for (uint32_t i = 0; i < rec[t].num_kmers; i++) putchar((bits[bo[t] + (i >> 3)] >> (7 - (i & 7))) & 1 ? '1' : '0');
+                putchar('\n');
+            }
+        free(ho3); free(col3); free(cnt3); free(bo); free(bits); free(rec);
     }
     free(nk); free(nu); free(mk); free(ho); free(col); free(cnt);
     return 0;

@@ -239,7 +239,7 @@ def test_twin_synthetic_fill_is_the_devices_generator(cpu):
 
 def parse_c_host_output(text):
     out = text.splitlines()
-    passes, cur, streams = {}, None, []
+    passes, cur, streams, scored, cur_scored = {}, None, [], {}, None
     for ln in out[1:-1]:
         f = ln.split()
         if f[0] == "pass":
@@ -247,26 +247,41 @@ def parse_c_host_output(text):
         elif f[0] == "stream":                     # bigsi_hip_search_stream over the same queries
             assert f[2] == "identical", ln
             streams.append(f[1])
+        elif f[0] == "scored":                     # bigsi_hip_search_stream_scored: the same hit lists, then one line per hit
+            assert f[2] == "identical", ln
+            cur_scored = scored.setdefault(f[1], {})
+        elif f[0] == "s":
+            cur_scored[(int(f[1]), int(f[2]))] = {"score": float(f[3]), "min_score": float(f[4]), "max_score": float(f[5]), "mismatches": int(f[6]),
+                                                  "min_mismatches": int(f[7]), "max_mismatches": int(f[8]), "percent_kmers_found": float(f[9]),
+                                                  "kmer-presence": f[10] if len(f) > 10 else ""}
         else:
             cur[int(f[1])] = (int(f[3]), int(f[5]), int(f[7]), [tuple(map(int, x.split(":"))) for x in f[9:]])
-    assert streams == ["exact", "threshold"]
-    return out[0], passes, out[-1]
+    assert streams == ["exact", "threshold"] and sorted(scored) == ["exact", "threshold"]
+    return out[0], passes, out[-1], scored
 
 
-def check_c_host_against_g7(text):
+def check_c_host_against_g7(text, at_least=40):
+    """The C host's text against the reference's G7 outputs: hit lists of both passes, and -- score=True searches -- the fields of
+    Scorer.score the boundary computes and the presence strings."""
     g = load_golden("g7_random.json")
     names = g["sample_names"]
-    head, passes, tail = parse_c_host_output(text)
+    head, passes, tail, scored = parse_c_host_output(text)
     assert head == "index rows %d cols %d hashes %d row_bytes %d" % (g["m"], len(names), g["h"], -(-len(names) // 8))
     assert tail == "error reported"
-    checked = 0
+    checked = scored_hits = 0
     for name, thr in (("exact", 1.0), ("threshold", 0.4)):
         assert sorted(passes[name]) == list(range(len(g["queries"])))
         for srch in g["searches"]:
-            if srch["threshold"] != thr or srch["score"] or "results" not in srch["out"]:
+            if srch["threshold"] != thr or "results" not in srch["out"]:
+                continue
+            want = srch["out"]["results"]
+            if srch["score"]:
+                for w in want:
+                    got = scored[name][(srch["q"], names.index(w["sample_name"]))]
+                    assert got == {key: w[key] for key in got}, (name, srch["q"], w["sample_name"])
+                    scored_hits += 1
                 continue
             nk, nu, mk, hits = passes[name][srch["q"]]
-            want = srch["out"]["results"]
             assert [c for c, _ in hits] == sorted(c for c, _ in hits)
             assert sorted((names[c], n) for c, n in hits) == sorted((w["sample_name"], w["num_kmers_found"]) for w in want), (name, srch["q"])
             for w in want:
@@ -274,7 +289,9 @@ def check_c_host_against_g7(text):
             assert nk == len(g["queries"][srch["q"]]) - g["k"] + 1
             assert mk == math.ceil(nu * thr)
             checked += 1
-    assert checked >= 40
+        # every hit of the pass has a record
+        assert sorted(scored[name]) == sorted((q, c) for q, (_, _, _, hits) in passes[name].items() for c, _ in hits)
+    assert checked >= at_least and scored_hits >= 10, (checked, scored_hits)
     return checked
 
 

@@ -1173,7 +1173,8 @@ def test_fuzz_api_vs_oracle_model(hip, seed):
 def test_c_host_of_the_abi(hip, tmp_path):
     """A host that is not Python (tests/c_host/search_host.c: C99, links libbigsi_hip.so only) builds the G7 index through
     bigsi_hip_insert_kmers and searches through the one-call bigsi_hip_search_batch; its printed hit lists must be the
-    reference's G7 results (exact and threshold 0.4), including the grow-and-retry protocol for the hit buffers."""
+    reference's G7 results (exact and threshold 0.4), including the grow-and-retry protocol for the hit buffers; the records and
+    presence strings of bigsi_hip_search_stream_scored it prints must be the reference's score=True outputs."""
     import subprocess
     from test_abi_and_host import build_c_host
     g = load_golden("g7_random.json")
@@ -1184,36 +1185,8 @@ def test_c_host_of_the_abi(hip, tmp_path):
     lines += list(g["queries"])
     r = subprocess.run([exe], input="\n".join(lines) + "\n", capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
-    out = r.stdout.splitlines()
-    assert out[0] == "index rows %d cols %d hashes %d row_bytes %d" % (g["m"], len(names), g["h"], -(-len(names) // 8))
-    assert out[-1] == "error reported"
-    passes, cur, streams = {}, None, []
-    for ln in out[1:-1]:
-        f = ln.split()
-        if f[0] == "pass":
-            cur = passes.setdefault(f[1], {})
-        elif f[0] == "stream":                     # bigsi_hip_search_stream over the same queries
-            assert f[2] == "identical", ln
-            streams.append(f[1])
-        else:
-            cur[int(f[1])] = (int(f[3]), int(f[5]), int(f[7]), [tuple(map(int, x.split(":"))) for x in f[9:]])
-    assert streams == ["exact", "threshold"]
-    checked = 0
-    for name, thr in (("exact", 1.0), ("threshold", 0.4)):
-        assert sorted(passes[name]) == list(range(len(g["queries"])))
-        for srch in g["searches"]:
-            if srch["threshold"] != thr or srch["score"] or "results" not in srch["out"]:
-                continue
-            nk, nu, mk, hits = passes[name][srch["q"]]
-            want = srch["out"]["results"]
-            assert [c for c, _ in hits] == sorted(c for c, _ in hits)
-            assert sorted((names[c], n) for c, n in hits) == sorted((w["sample_name"], w["num_kmers_found"]) for w in want), (name, srch["q"])
-            for w in want:
-                assert w["num_kmers"] == nu
-            assert nk == len(g["queries"][srch["q"]]) - g["k"] + 1
-            assert mk == math.ceil(nu * thr)
-            checked += 1
-    assert checked >= 60
+    from test_cpu_twin import check_c_host_against_g7
+    check_c_host_against_g7(r.stdout, at_least=60)
 
 
 def test_storage_search_batch_entry_point(hip):

@@ -2,6 +2,7 @@
 the reference's golden scores (tests/golden/g5_scoring.json: the reference's own Scorer.score outputs), CPython's round(), the
 scalar restatement of scoring/score.py, and the presence strings the single-sequence kernel (k_presence) and the oracle give.
 Everything exact except evalue / pvalue (tolerances of conftest.py).  Needs a real MI355X: `pytest -m gpu`."""
+import contextlib
 import itertools
 
 import numpy as np
@@ -216,4 +217,98 @@ def test_scored_search_stream_three_batches_deep_equals_search():
                 assert_results_equal(r, w, "thr=%r bs=%d" % (thr, bs))
         got = list(index.search_stream(iter(queries), thr, score=True, batch_kmers=2000))
         assert [r for _, r in got] == want
+    index.delete()
+
+
+@pytest.mark.parametrize("threshold", [1.0, 0.3])
+def test_search_stream_scored_equals_batch_score_hits_over_many_device_batches(threshold):
+    """bigsi_hip_search_stream_scored -- score=True for any number of sequences in one C call: 20 000 reads (five device batches,
+    three workspaces, each batch's K5 + K6 beside the next batch's row-AND) with planted matches, genes among them (sequences of
+    several 64-position words), sequences shorter than k.  Hit lists equal search_stream's; every hit's bits and record equal
+    bigsi_hip_batch_score_hits on a batch of that hit's sequence alone for a sample, and the scalar Scorer for every hit; the
+    capacity protocol (a sizing call, then one retry with what it reported) returns the same."""
+    from bigsi_amd import _lib
+    from bigsi_amd.scoring import HIT_SCORE_DTYPE, SCORE_KEYS, Scorer, score_columns, unpack_presence
+    rng = np.random.default_rng(21 + int(threshold * 10))
+    k, m, h = 31, 200003, 3
+    genes = [rand_seq(rng, int(n)) for n in (1000, 450, 95, 31, 2000)]
+    samples = {}
+    for c in range(96):
+        g = genes[c % len(genes)]
+        cut = int(rng.integers(31, len(g) + 1))
+        samples["s%d" % c] = [g if c % 4 == 0 else g[:cut], rand_seq(rng, 500)]
+    index = build_index(cfg(k, m, h, max_cols=128), samples)
+    seqs = []
+    for i in range(20000):
+        r = i % 97
+        if r == 0:
+            seqs.append(genes[(i // 97) % len(genes)])
+        elif r == 1:
+            g = genes[0]
+            lo = int(rng.integers(0, len(g) - 61))
+            seqs.append(g[lo:lo + 61])
+        elif r == 2:
+            seqs.append(rand_seq(rng, int(rng.integers(0, 31))))       # shorter than k: no k-mers, no hits
+        else:
+            seqs.append(rand_seq(rng, 61))
+    st = index.storage
+    nk, nu, off, col, cnt, bits, boff, rec = st.search_many_scored(seqs, k, threshold)
+    nk2, nu2, off2, col2, cnt2 = st.search_many(seqs, k, threshold)
+    assert np.array_equal(nk, nk2) and np.array_equal(nu, nu2) and np.array_equal(off, off2) and np.array_equal(col, col2) and np.array_equal(cnt, cnt2)
+    n_hits = int(off[-1])
+    assert int((nk[np.repeat(np.arange(len(seqs)), np.diff(off).astype(np.int64))] > 0).sum()) > 4000 and boff.size == n_hits + 1 and rec.size == n_hits and int(boff[-1]) == bits.size
+    # every hit: the scalar scorer on its unpacked string
+    text = unpack_presence(bits, boff)
+    hit_seq = np.repeat(np.arange(len(seqs)), np.diff(off).astype(np.int64))
+    # (a sequence without k-mers: exact search -> no hits; thresholded -> count 0 >= ceil(0 * t) in every column, as in
+    # bigsi_hip_search_stream -- the host layer raises the reference's error for it, graph/bigsi.py -- with all-zero records
+    # and no bits)
+    empty = nk[hit_seq] == 0
+    assert (int(empty.sum()) == 0) == (threshold == 1.0)
+    assert not rec[empty].tobytes().strip(b"\0") and np.array_equal(boff[:-1][empty], boff[1:][empty])
+    with pytest.raises(ZeroDivisionError) if empty.any() else contextlib.nullcontext():
+        score_columns(rec, 96)                      # (score.py:99-100 divides by the k-mer count)
+    filled = np.where(empty, 1, rec["num_kmers"])
+    rec_nz = rec.copy()
+    rec_nz["num_kmers"] = filled
+    cols = score_columns(rec_nz, 96)
+    scalar = Scorer(96)
+    cache = {}
+    for t in np.flatnonzero(~empty).tolist():
+        i = int(hit_seq[t])
+        s = text[8 * int(boff[t]):8 * int(boff[t]) + int(nk[i])]
+        assert len(s) == int(nk[i])
+        if s not in cache:
+            cache[s] = scalar.score(s)
+        assert {key: c[t] for key, c in zip(SCORE_KEYS, cols)} == cache[s], (t, i)
+        assert rec["percent_kmers_found"][t] == round(100 * float(cnt[t]) / int(nu[i]), 2) and rec["num_kmers"][t] == nk[i]
+    # a sample of sequences with hits: the same bits and records from a one-sequence batch
+    with_hits = np.flatnonzero(np.diff(off).astype(np.int64))
+    for i in with_hits[:: max(1, with_hits.size // 60)].tolist():
+        b = st.new_batch([seqs[i]], k)
+        b.run(threshold)
+        o1, c1, n1 = b.hits()
+        lo, hi = int(off[i]), int(off[i + 1])
+        assert np.array_equal(c1, col[lo:hi]) and np.array_equal(n1, cnt[lo:hi])
+        r1, b1, bo1 = b.score_hits(o1, c1, n1, b.unique()[0])
+        assert np.array_equal(r1, rec[lo:hi])
+        assert np.array_equal(b1[: int(bo1[-1])], bits[int(boff[lo]):int(boff[hi])])
+        b.close()
+    # the capacity protocol by hand: sizing call -> CAPACITY with complete offsets and byte count -> one retry
+    blob, soff = _lib.pack_seqs(seqs)
+    o3, need = np.zeros(len(seqs) + 1, np.uint64), np.zeros(1, np.uint64)
+    rc = _lib.lib().bigsi_hip_search_stream_scored(st.handle, blob, _lib.ptr(soff), len(seqs), k, threshold, 0, None, None, None, _lib.ptr(o3),
+                                                   None, None, 0, None, 0, _lib.ptr(np.zeros(1, np.uint64)), None, _lib.ptr(need))
+    assert rc == _lib.ERR_CAPACITY and np.array_equal(o3, off) and int(need[0]) == bits.size
+    # hits fit, bits do not (half the bytes): CAPACITY again, lists complete
+    c3, n3 = np.zeros(n_hits, np.uint32), np.zeros(n_hits, np.uint32)
+    bo3, r3, b3 = np.zeros(n_hits + 1, np.uint64), np.zeros(n_hits, HIT_SCORE_DTYPE), np.zeros(bits.size // 2, np.uint8)
+    rc = _lib.lib().bigsi_hip_search_stream_scored(st.handle, blob, _lib.ptr(soff), len(seqs), k, threshold, 0, None, None, None, _lib.ptr(o3),
+                                                   _lib.ptr(c3), _lib.ptr(n3), n_hits, _lib.ptr(b3), b3.size, _lib.ptr(bo3), _lib.ptr(r3), _lib.ptr(need))
+    assert rc == _lib.ERR_CAPACITY and np.array_equal(c3, col) and np.array_equal(bo3, boff) and int(need[0]) == bits.size
+    b3 = np.zeros(bits.size, np.uint8)
+    rc = _lib.lib().bigsi_hip_search_stream_scored(st.handle, blob, _lib.ptr(soff), len(seqs), k, threshold, 0, None, None, None, _lib.ptr(o3),
+                                                   _lib.ptr(c3), _lib.ptr(n3), n_hits, _lib.ptr(b3), b3.size, _lib.ptr(bo3), _lib.ptr(r3), _lib.ptr(need))
+    _lib.check(rc)
+    assert np.array_equal(b3, bits) and np.array_equal(r3, rec) and np.array_equal(n3, cnt)
     index.delete()
