@@ -1002,8 +1002,62 @@ def test_fuzz_random_shapes_vs_oracle(hip, seed):
             assert np.array_equal(col[lo:hi], want), (seed, thr, i, n_cols, m, h, k)
             if u:
                 assert np.array_equal(cnt[lo:hi], want_cnt[want].astype(np.uint32)), (seed, thr, i)
+        if 0 < int(off[nq]) <= 200000:
+            _FUZZ_SCORED[0] += _fuzz_scored(st, orc, batch, seqs, k, thr, check, off, col, cnt, (seed, thr))
     batch.close()
     st.delete_all()
+
+
+_FUZZ_SCORED = [0]
+
+
+def test_fuzz_checked_scored_hits_too(hip):
+    """(runs after the campaign above) it compared presence strings and score records of a few hits per seed"""
+    if int(os.environ.get("BIGSI_FUZZ_SEEDS", "48")) >= 48 and _FUZZ_SCORED[0] >= 0:
+        print("scored hits checked by the fuzz campaign:", _FUZZ_SCORED[0])
+        assert _FUZZ_SCORED[0] >= 100
+
+
+def _fuzz_scored(st, orc, batch, seqs, k, thr, check, off, col, cnt, what):
+    """score=True over the same random shapes: K5's presence bits against the oracle's per-k-mer rows and K6's records against
+    the scalar restatement of scoring/score.py, for some hits of the checked sequences; the one-call
+    bigsi_hip_search_stream_scored must return exactly what the batch calls return."""
+    from bigsi_amd.scoring import SCORE_KEYS, score_columns, unpack_presence
+    from oracle.ref_model import Scorer as OracleScorer
+    nk, nu, _ = batch.unique()
+    rec, bits, boff = batch.score_hits(off, col, None if thr == 1.0 else cnt, nk)
+    text = unpack_presence(bits, boff)
+    hit_seq = np.repeat(np.arange(len(seqs)), np.diff(off.astype(np.int64)))
+    nonempty = nk[hit_seq] > 0
+    assert not rec[~nonempty].tobytes().strip(b"\0")
+    rec_nz = rec.copy()
+    rec_nz["num_kmers"] = np.where(nonempty, rec["num_kmers"], 1)
+    cols = score_columns(rec_nz, 1000)
+    scalar = OracleScorer(1000)
+    checked = 0
+    for i in check:
+        lo, hi = int(off[i]), int(off[i + 1])
+        if hi == lo or nk[i] == 0:
+            continue
+        kmers, uniq, rows = orc.per_kmer_rows(seqs[i])
+        where = {km: j for j, km in enumerate(uniq)}
+        idx = np.array([where[km] for km in kmers])
+        for t in sorted(set([lo, hi - 1, (lo + hi) // 2])):
+            c = int(col[t])
+            want = "".join("1" if x else "0" for x in (rows[idx, c >> 3] & (0x80 >> (c & 7))))
+            got = text[8 * int(boff[t]):8 * int(boff[t]) + int(nk[i])]
+            assert got == want, what + (i, c)
+            ref = scalar.score(want)
+            exact_keys = [key for key in SCORE_KEYS if key in ref and "value" not in key]      # (evalue / pvalue: libm's, conftest's tolerances)
+            assert len(exact_keys) >= 13
+            assert {key: col_[t] for key, col_ in zip(SCORE_KEYS, cols) if key in exact_keys} == {key: ref[key] for key in exact_keys}, what + (i, c)
+            assert rec["percent_kmers_found"][t] == round(100 * float(cnt[t]) / int(nu[i]), 2)
+            checked += 1
+    # the one-call entry point: the same arrays
+    nk2, nu2, off2, col2, cnt2, bits2, boff2, rec2 = st.search_many_scored(seqs, k, thr)
+    assert np.array_equal(off2, off) and np.array_equal(col2, col[: int(off[-1])]) and np.array_equal(nk2, nk[: len(seqs)])
+    assert np.array_equal(rec2, rec) and np.array_equal(boff2, boff) and np.array_equal(bits2, bits[: int(boff[-1])]), what
+    return checked
 
 
 @pytest.mark.parametrize("qlen", [200, 1100])
