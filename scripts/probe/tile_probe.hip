@@ -68,6 +68,82 @@ __global__ __launch_bounds__(kThreads) void k_move_runs(const uint8_t *__restric
     if (MODE == 1 && acc.x == 0x1234567ull) sink[0] = acc;      // (never true in practice: keeps the loads alive)
 }
 
+// the kernel's PHASE STRUCTURE on its (128, 128) tile, still without bit work: a workgroup of 512 threads loads the 1024 x 1024-bit tile
+// (16 pieces per lane, all in flight), passes it through 64 KB of LDS in two halves (write, barrier, read back, store: the barriers of
+// k_transpose_tiles<2,2>), two workgroups per CU.  PERSIST: workgroups loop over tiles and issue the NEXT tile's loads before the
+// last half's stores (software pipelining).
+template <bool PERSIST>
+__global__ __launch_bounds__(kThreads) void k_phased(const uint8_t *__restrict__ in, uint64_t pitch_in, uint8_t *__restrict__ out, uint64_t pitch_out,
+                                                     uint64_t m_bytes, uint64_t n_bytes, uint32_t tiles_r, uint32_t tiles_c, uint32_t super, uint64_t n_tiles_padded)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[73728];          // (the kernel's 2 x 36 KB: two workgroups per CU)
+    const uint32_t sup_w = super < tiles_c ? super : tiles_c;
+    uint32_t sup_h = super * super / sup_w;
+    if (sup_h > tiles_r) sup_h = tiles_r;
+    const uint32_t sup_c = (tiles_c + sup_w - 1) / sup_w;
+    const uint64_t per_sup = (uint64_t)sup_w * sup_h;
+    const uint64_t n_cols = n_bytes * 8, m_rows = m_bytes * 8;
+    u64x2 ld[16];
+    auto tile_of = [&](uint64_t b, uint64_t &tile_r, uint64_t &tile_c) {
+        const uint64_t sidx = b / per_sup;
+        const uint32_t within = (uint32_t)(b % per_sup);
+        tile_r = (sidx / sup_c) * sup_h + within / sup_w;
+        tile_c = (sidx % sup_c) * sup_w + within % sup_w;
+        return b < n_tiles_padded && tile_r < tiles_r && tile_c < tiles_c;
+    };
+    auto load_tile = [&](uint64_t tile_r, uint64_t tile_c) {
+#pragma unroll
+        for (int it = 0; it < 16; it++) {
+            const uint32_t p = it * kThreads + threadIdx.x, run = p >> 3, part = p & 7u;
+            const uint64_t col = tile_c * 1024 + run, off = tile_r * 128 + part * 16;
+            const bool ok = col < n_cols && off + 16 <= m_bytes;
+            ld[it] = ok ? __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(in + col * pitch_in + off)) : u64x2{0ull, 0ull};
+        }
+    };
+    uint64_t b = blockIdx.x, tile_r, tile_c;
+    bool have = tile_of(b, tile_r, tile_c);
+    if (have) load_tile(tile_r, tile_c);
+    while (b < n_tiles_padded) {
+        uint64_t nr = 0, nc = 0;
+        const uint64_t nb = b + gridDim.x;
+        const bool next = PERSIST && tile_of(nb, nr, nc);
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            if (half) __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 16; it++) {
+                const uint32_t p = it * kThreads + threadIdx.x, run = p >> 3, part = p & 7u;
+                if ((int)(part >> 2) != half) continue;
+                *reinterpret_cast<u64x2 *>(lds + (run * 4 + (part & 3u)) * 16) = ld[it];
+            }
+            __syncthreads();
+            if (half == 1 && next) load_tile(nr, nc);            // the registers are free: the next tile's loads overlap this half's stores
+            if (have) {
+#pragma unroll
+                for (int it = 0; it < 8; it++) {
+                    const uint32_t q = it * kThreads + threadIdx.x, row = q >> 3, part = q & 7u;
+                    const uint64_t r = tile_r * 1024 + half * 512 + row, off = tile_c * 128 + part * 16;
+                    const u64x2 v = *reinterpret_cast<const u64x2 *>(lds + q * 16);
+                    if (r < m_rows && off + 16 <= n_bytes) __builtin_nontemporal_store(v, reinterpret_cast<u64x2 *>(out + r * pitch_out + off));
+                }
+            }
+        }
+        if (!PERSIST) break;
+        __syncthreads();
+        b = nb;
+        have = next;
+        tile_r = nr;
+        tile_c = nc;
+        if (!next) {                       // (tiles beyond the matrix edge inside the last supertiles: keep walking)
+            bool any = false;
+            while (b < n_tiles_padded && !(any = tile_of(b, tile_r, tile_c))) b += gridDim.x;
+            if (!any) break;
+            have = true;
+            load_tile(tile_r, tile_c);
+        }
+    }
+}
+
 // calibration: a straight copy, 16 bytes per lane, U pieces in flight per lane, each workgroup a contiguous block of the buffer
 template <int U, bool NT>
 __global__ __launch_bounds__(256) void k_copy(const u64x2 *__restrict__ in, u64x2 *__restrict__ out, uint64_t n)
@@ -132,6 +208,30 @@ int main(int argc, char **argv)
         time_copy([&] { hipLaunchKernelGGL((k_copy<8, false>), dim3((uint32_t)((n16 + 2047) / 2048)), dim3(256), 0, 0, (const u64x2 *)in, (u64x2 *)out, n16); }, "8 in flight, plain");
         time_copy([&] { hipLaunchKernelGGL((k_copy<1, false>), dim3((uint32_t)((n16 + 255) / 256)), dim3(256), 0, 0, (const u64x2 *)in, (u64x2 *)out, n16); }, "1 in flight, plain");
         time_copy([&] { CK(hipMemcpyAsync(out, in, n16 * 16, hipMemcpyDeviceToDevice, 0)); }, "hipMemcpyAsync D2D");
+    }
+    {   // the kernel's phase structure on (128, 128), one tile per workgroup / persistent and pipelined
+        const uint32_t tiles_r = (uint32_t)((m_bytes + 127) / 128), tiles_c = (uint32_t)((n_bytes + 127) / 128);
+        const uint32_t sup_w = std::min(super, tiles_c), sup_h = std::min(super * super / sup_w, tiles_r);
+        const uint64_t blocks = (uint64_t)((tiles_r + sup_h - 1) / sup_h) * ((tiles_c + sup_w - 1) / sup_w) * sup_w * sup_h;
+        auto run = [&](bool persist, uint32_t grid, const char *name) {
+            std::vector<float> ms;
+            for (int rep = 0; rep < 3; rep++) {
+                CK(hipEventRecord(e0, 0));
+                if (persist) hipLaunchKernelGGL((k_phased<true>), dim3(grid), dim3(kThreads), 0, 0, in, pitch_in, out, pitch_out, m_bytes, n_bytes, tiles_r, tiles_c, super, blocks);
+                else hipLaunchKernelGGL((k_phased<false>), dim3(grid), dim3(kThreads), 0, 0, in, pitch_in, out, pitch_out, m_bytes, n_bytes, tiles_r, tiles_c, super, blocks);
+                CK(hipEventRecord(e1, 0));
+                CK(hipEventSynchronize(e1));
+                float t = 0;
+                CK(hipEventElapsedTime(&t, e0, e1));
+                ms.push_back(t);
+            }
+            std::sort(ms.begin(), ms.end());
+            printf("phased (128, 128) through LDS, %-42s %7.0f GB/s in + out\n", name, 2.0 * m_bytes * n_cols / (ms[1] * 1e-3) / 1e9);
+        };
+        run(false, (uint32_t)blocks, "one tile per workgroup (the kernel's form)");
+        run(true, 512, "persistent, 512 workgroups, pipelined");
+        run(true, 1024, "persistent, 1024 workgroups, pipelined");
+        run(true, 2048, "persistent, 2048 workgroups, pipelined");
     }
     {   // pieces in flight per lane (loads issued before the first store), read + write
         printf("read + write by pieces in flight per lane\n  (L_in, L_out)        1       2       4       8      16\n");
