@@ -220,7 +220,8 @@ def run_also_legs():
                         "verified": cf.get("verified"), "host_visible": {"stream_kmer_lookups_per_s": ((cf.get("host_visible") or {}).get("stream") or {}).get("kmer_lookups_per_s"),
                                                                    "stream_sequences": ((cf.get("host_visible") or {}).get("stream") or {}).get("sequences"),
                                                                    "one_call_us": {k_: v_ for k_, v_ in ((cf.get("host_visible") or {}).get("one_call_us") or {}).items() if k_ != "entry"},
-                                                                   "two_workspace_loop_kmer_lookups_per_s": (cf.get("host_visible") or {}).get("two_workspace_loop_kmer_lookups_per_s")},
+                                                                   "two_workspace_loop_kmer_lookups_per_s": (cf.get("host_visible") or {}).get("two_workspace_loop_kmer_lookups_per_s"),
+                                                                   "stream_scored_kmer_lookups_per_s": ((cf.get("host_visible") or {}).get("stream_scored") or {}).get("kmer_lookups_per_s")},
                         "scored": {k_: v_ for k_, v_ in (cf.get("presence") or {}).items() if k_ != "what"} or None,
                         "clocks_after": (cf.get("clocks") or {}).get("after_timed_region"),
                         "index_gb": cf.get("index_gb_per_gpu"), "wall_s": round(time.time() - t0, 1), "args": " ".join(extra)}
@@ -591,6 +592,8 @@ def main():
     if world == 1 and not args.force_dist and args.host_visible:
         lib_ = _lib.lib()
         want = 256 if w["batch"] * w["qlen"] < (1 << 17) else (8 if w["batch"] * w["qlen"] < (1 << 20) else 2)
+        if w["score"]:
+            want = max(want, 24)              # (six device batches of the library's own size: its pipeline in steady state)
         many = [s_ for i in range(want) for s_ in all_seqs[i % nb]]
         blob, soff = _lib.pack_seqs(many)
         n_many = len(many)
@@ -609,6 +612,29 @@ def main():
         host_visible["stream"] = {"kmer_lookups_per_s": float(hnu.sum()) / times[len(times) // 2], "best": float(hnu.sum()) / times[0],
                                   "sequences": n_many, "sequence_bytes": len(blob), "hits": int(hoff[-1]), "call_ms": times[len(times) // 2] * 1e3,
                                   "entry": "bigsi_hip_search_stream (one call; median of 5)"}
+
+        if w["score"]:
+            # score=True through the boundary alone: ONE bigsi_hip_search_stream_scored call (sequences in; hit lists, presence
+            # bits and score records out; each device batch's K5 + K6 beside the next batch's row-AND)
+            from bigsi_amd.scoring import HIT_SCORE_DTYPE
+            need = np.zeros(1, np.uint64)
+            n_hits_many = int(hoff[-1])
+            hboff, hrec = np.zeros(n_hits_many + 1, np.uint64), np.zeros(max(n_hits_many, 1), HIT_SCORE_DTYPE)
+            words = (hnk.astype(np.int64) + 63) // 64
+            hbits = np.zeros(max(int((words * np.diff(hoff).astype(np.int64)).sum()) * 8, 8), np.uint8)
+
+            def scored_call():
+                t_ = time.perf_counter()
+                check(lib_.bigsi_hip_search_stream_scored(st.handle, blob, _lib.ptr(soff), n_many, args.k, float(thr), 0, _lib.ptr(hnk), _lib.ptr(hnu),
+                                                          None, _lib.ptr(hoff), _lib.ptr(hcol), _lib.ptr(hcnt), n_hits_many, _lib.ptr(hbits), hbits.size,
+                                                          _lib.ptr(hboff), _lib.ptr(hrec), _lib.ptr(need)))
+                return time.perf_counter() - t_
+            scored_call()
+            times = sorted(scored_call() for _ in range(5))
+            assert int(need[0]) == hbits.size and int(hoff[-1]) == n_hits_many and (hrec["num_kmers"][:n_hits_many] > 0).all()
+            host_visible["stream_scored"] = {"kmer_lookups_per_s": float(hnu.sum()) / times[len(times) // 2], "best": float(hnu.sum()) / times[0],
+                                             "hits": n_hits_many, "bit_bytes": int(need[0]), "call_ms": times[len(times) // 2] * 1e3,
+                                             "entry": "bigsi_hip_search_stream_scored (one call; median of 5)"}
 
         def one_call(seq_list, reps):
             bl, so = _lib.pack_seqs(seq_list)
