@@ -225,6 +225,70 @@ def test_twin_scores_equal_the_golden_scores(cpu):
     check_records_against_golden_and_scalar(score)
 
 
+def scored_stream(L, ix, seqs, k, thr, flags=0):
+    """bigsi_cpu_search_stream_scored through its capacity protocol: a sizing call, then the call proper."""
+    from bigsi_amd.scoring import HIT_SCORE_DTYPE
+    blob, off = pack(seqs)
+    n = len(seqs)
+    nk, nu = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+    ho, need = np.zeros(n + 1, np.uint64), np.zeros(1, np.uint64)
+    args = (ix, blob, ptr(off), C.c_uint64(n), C.c_uint32(k), C.c_double(thr), C.c_uint32(flags), ptr(nk), ptr(nu), None, ptr(ho))
+    rc = L.bigsi_cpu_search_stream_scored(*args, None, None, C.c_uint64(0), None, C.c_uint64(0), ptr(np.zeros(1, np.uint64)), None, ptr(need))
+    total = int(ho[-1])
+    assert rc == (ERR_CAPACITY if total else 0), L.bigsi_cpu_last_error()
+    col, cnt = np.zeros(max(total, 1), np.uint32), np.zeros(max(total, 1), np.uint32)
+    bits, boff, rec = np.zeros(int(need[0]) + 8, np.uint8), np.zeros(total + 1, np.uint64), np.zeros(max(total, 1), HIT_SCORE_DTYPE)
+    rc = L.bigsi_cpu_search_stream_scored(*args, ptr(col), ptr(cnt), C.c_uint64(total), ptr(bits), C.c_uint64(int(need[0])), ptr(boff), ptr(rec), ptr(need))
+    assert rc == 0, L.bigsi_cpu_last_error()
+    return nk, nu, ho, col[:total], cnt[:total], bits[:int(need[0])], boff, rec[:total]
+
+
+@pytest.mark.parametrize("flags", [0, WORD_PARALLEL])
+def test_twin_scored_stream_equals_the_oracles_scored_search(cpu, flags):
+    """bigsi_cpu_search_stream_scored (score=True in one call) on a seeded index whose samples hold pieces of the queries: per hit,
+    the presence bits and every field of the record against the oracle's restatement of BIGSI.search(score=True)
+    (graph/bigsi.py:174-239, scoring/score.py) -- colours, counts, percent, the rounded score chain, SNP totals, presence string."""
+    from oracle.ref_model import OracleBIGSI, seq_to_kmers
+    from bigsi_amd.scoring import SCORE_KEYS, score_columns, unpack_presence
+    rng = np.random.default_rng(77)
+    k, m, h, n = 31, 20011, 3, 40
+    rand = lambda L_: "".join(rng.choice(list("ACGT"), size=L_))
+    genes = [rand(int(x)) for x in (600, 95, 33, 1300, 250)]
+    samples = []
+    for c in range(n):
+        g = genes[c % len(genes)]
+        lo = int(rng.integers(0, max(len(g) - 40, 1)))
+        samples.append([g[lo:lo + int(rng.integers(31, len(g) + 1))], rand(300)] + ([g] if c % 7 == 0 else []))
+    queries = genes + [rand(200), genes[0][:300] + rand(100) + genes[0][400:], genes[3][100:900]]
+    ix = Index(cpu, m, h, n)
+    for c, seqs in enumerate(samples):
+        ix.add_sample(c, seqs, k)
+    names = ["s%d" % c for c in range(n)]
+    orc = OracleBIGSI.build([OracleBIGSI.bloom([km for s_ in seqs for km in seq_to_kmers(s_, k)], m, h) for seqs in samples], names, k, m, h)
+    checked = 0
+    for thr in (1.0, 0.35):
+        nk, nu, ho, col, cnt, bits, boff, rec = scored_stream(cpu, ix.ix, queries, k, thr, flags)
+        text = unpack_presence(bits, boff)
+        cols = score_columns(rec, n)
+        for q, seq in enumerate(queries):
+            want = orc.search(seq, thr, score=True)
+            lo, hi = int(ho[q]), int(ho[q + 1])
+            order = list(range(lo, hi)) if thr == 1.0 else sorted(range(lo, hi), key=lambda t: -int(cnt[t]))
+            assert [names[int(col[t])] for t in order] == [w["sample_name"] for w in want], (thr, q)
+            for t, w in zip(order, want):
+                got = {"percent_kmers_found": float(rec["percent_kmers_found"][t]), "num_kmers": int(nu[q]), "num_kmers_found": int(cnt[t]),
+                       "sample_name": names[int(col[t])], "kmer-presence": text[8 * int(boff[t]):8 * int(boff[t]) + int(nk[q])]}
+                got.update({key: c_[t] for key, c_ in zip(SCORE_KEYS, cols)})
+                for key, v in w.items():
+                    if key in ("evalue", "pvalue"):
+                        assert abs(got[key] - v) <= 1e-12 * abs(v) + 2.5e-16, (thr, q, key)      # (libm's, conftest.py's tolerances)
+                    else:
+                        assert got[key] == v, (thr, q, key, got[key], v)
+                checked += 1
+    assert checked >= 40
+    ix.close()
+
+
 def test_twin_synthetic_fill_is_the_devices_generator(cpu):
     """bigsi_cpu_fill_synthetic must produce the rows bigsi_hip_fill_synthetic produces (the CPU baseline runs on a slice of the
     GPU's index): compared here with the oracle's mirror of the device generator, which the gpu suite pins to the device."""

@@ -4,6 +4,7 @@ scalar restatement of scoring/score.py, and the presence strings the single-sequ
 Everything exact except evalue / pvalue (tolerances of conftest.py).  Needs a real MI355X: `pytest -m gpu`."""
 import contextlib
 import itertools
+import os
 
 import numpy as np
 import pytest
@@ -311,4 +312,37 @@ def test_search_stream_scored_equals_batch_score_hits_over_many_device_batches(t
                                                    _lib.ptr(c3), _lib.ptr(n3), n_hits, _lib.ptr(b3), b3.size, _lib.ptr(bo3), _lib.ptr(r3), _lib.ptr(need))
     _lib.check(rc)
     assert np.array_equal(b3, bits) and np.array_equal(r3, rec) and np.array_equal(n3, cnt)
+    index.delete()
+
+
+@pytest.mark.parametrize("threshold", [1.0, 0.25])
+def test_search_stream_scored_equals_the_cpu_twins(threshold):
+    """The same index (filled through insert_kmers on both sides) and the same 3000 sequences through
+    bigsi_hip_search_stream_scored and the CPU twin's bigsi_cpu_search_stream_scored (reference-shaped loops, the scoring header
+    compiled for the host): every output array identical."""
+    import ctypes as C
+    import test_cpu_twin as tw
+    assert os.path.exists(tw.LIB), "libbigsi_cpu.so has not been built"
+    L = C.CDLL(tw.LIB)
+    L.bigsi_cpu_last_error.restype = C.c_char_p
+    rng = np.random.default_rng(31)
+    k, m, h, n = 31, 60013, 3, 70
+    genes = [rand_seq(rng, int(x)) for x in (900, 64 + 30, 128 + 30, 31 + 31, 1500)]
+    samples = {}
+    for c in range(n):
+        g = genes[c % len(genes)]
+        lo = int(rng.integers(0, max(len(g) - 50, 1)))
+        samples["s%d" % c] = [g[lo:lo + int(rng.integers(31, len(g) + 1))], rand_seq(rng, 200)] + ([g] if c % 6 == 0 else [])
+    index = build_index(cfg(k, m, h, max_cols=128), samples)
+    twin = tw.Index(L, m, h, 128)
+    for c in range(n):
+        twin.add_sample(c, samples["s%d" % c], k)
+    seqs = [genes[i % len(genes)] if i % 41 == 0 else genes[0][(7 * i) % 700:(7 * i) % 700 + 70] if i % 41 == 1 else rand_seq(rng, int(rng.integers(20, 90)))
+            for i in range(3000)]
+    got = index.storage.search_many_scored(seqs, k, threshold)
+    want = tw.scored_stream(L, twin.ix, seqs, k, threshold)
+    assert int(got[2][-1]) > (100 if threshold == 1.0 else 400)
+    for name, a, b in zip(("num_kmers", "num_unique", "hit_offsets", "colours", "counts", "bits", "bit_offsets", "records"), got, want):
+        assert np.array_equal(a, b), name
+    twin.close()
     index.delete()
