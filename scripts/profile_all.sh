@@ -8,6 +8,7 @@ R=${ROUND:-r03}
 P=gpurun_out/prof
 mkdir -p $P
 B="--cpu-seconds 0 --also none --host-visible 0"
+[ -f bigsi_amd/libbigsi_hip_tuning.so ] || bash bigsi_amd/csrc/build.sh tuning > /dev/null      # (two legs below A/B through it)
 run() { scripts/prof.sh "$@" > /dev/null; }
 run ${R}_c3_exact        -- python bench.py --steps 20 --warmup 5 $B
 run ${R}_c3_t04          -- python bench.py --steps 20 --warmup 5 $B --threshold 0.4
@@ -28,6 +29,7 @@ run ${R}_c3_strong8_rccl1    -- python bench.py --workload c3 --shard-of 8 --gpu
 run ${R}_long_queries    -- python scripts/measure.py p16
 run ${R}_k5              -- python scripts/measure.py k5
 run ${R}_transpose       -- python scripts/measure.py transpose
+run ${R}_scored_stream   -- python scripts/scored_stream_probe.py
 # what the memory system gives the row-AND access pattern with no BIGSI code in the way (scripts/probe/row_probe.hip)
 { for a in "" "--vmm"; do scripts/probe/row_probe --gb 125 --row-bytes 12500 --rows-per-query 3880 --queries 768 $a; done
   scripts/probe/row_probe --gb 16 --row-bytes 12500 --rows-per-query 3880 --queries 768
