@@ -58,7 +58,8 @@ class Stats(C.Structure):
                 ("compact_launches", C.c_uint64), ("compact_ms", C.c_double),
                 ("presence_launches", C.c_uint64), ("presence_ms", C.c_double), ("presence_bytes", C.c_uint64),
                 ("transpose_launches", C.c_uint64), ("transpose_ms", C.c_double),
-                ("and_launches_total", C.c_uint64), ("read_launches_repeated", C.c_uint64), ("index_contiguous", C.c_uint64)]
+                ("and_launches_total", C.c_uint64), ("read_launches_repeated", C.c_uint64), ("index_contiguous", C.c_uint64),
+                ("exchange_launches", C.c_uint64), ("exchange_ms", C.c_double)]
 
 
 _P = C.c_void_p

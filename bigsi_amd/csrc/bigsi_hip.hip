@@ -72,8 +72,8 @@ static int mark_main(bigsi_hip_index *ix)
 
 // K5 / K6 (scored searches) run on a stream of their own with the HIGHEST priority: they are a few small kernels whose result
 // the host waits for while the NEXT batch's row-AND kernel fills the device, and at equal priority their workgroups queue up
-// behind that kernel's (bench workload c5: 0.37 ms of waiting for 0.05 ms of work).  Every call that uses it synchronises it
-// before returning, so nothing is ever pending here.
+// behind that kernel's (bench workload c5: 0.37 ms of waiting for 0.05 ms of work).  A request may stay queued here after its
+// _begin returns (sc_pending): calls that change the index wait for it (quiesce_index).
 static int score_stream(bigsi_hip_index *ix, hipStream_t *out)
 {
     *out = ix->stream;
@@ -93,6 +93,18 @@ static int quiesce_reads(bigsi_hip_index *ix)
     for (auto st : ix->rd_stream)
         if (st) HIP_TRY(hipStreamSynchronize(st));
     ix->rd_pending = false;
+    return BIGSI_OK;
+}
+
+// Everything that reads the matrix on a stream other than the index stream is over: the read streams AND the score stream
+// (a K5 request between its _begin and its _end -- bigsi_hip_batch_score_hits_begin, the scored stream's chunks -- is
+// k_presence_bits reading d_index there).  Every entry point that changes the index, hands the stream back or reads the
+// profiling events calls this; batch runs call quiesce_reads only (scoring beside the next batch's row-AND is the point).
+static int quiesce_index(bigsi_hip_index *ix)
+{
+    TRY(quiesce_reads(ix));
+    if (ix->sc_pending && ix->sc_stream) HIP_TRY(hipStreamSynchronize(ix->sc_stream));
+    ix->sc_pending = false;
     return BIGSI_OK;
 }
 
@@ -179,7 +191,7 @@ extern "C" int bigsi_hip_open(uint64_t num_rows, uint64_t num_cols, uint64_t col
 
 static void recycle_events(bigsi_hip_index *ix)
 {
-    for (auto *v : {&ix->ev_and, &ix->ev_km, &ix->ev_cp, &ix->ev_pr, &ix->ev_tr}) {
+    for (auto *v : {&ix->ev_and, &ix->ev_km, &ix->ev_cp, &ix->ev_pr, &ix->ev_tr, &ix->ev_ex}) {
         for (auto &p : *v) ix->ev_free.push_back(p);
         v->clear();
     }
@@ -251,7 +263,7 @@ extern "C" int bigsi_hip_reserve_cols(bigsi_hip_index *ix, uint64_t col_capacity
     if (col_capacity <= ix->cap_cols) return BIGSI_OK;
     if (col_capacity > 0xFFFFFFFFull) return fail(BIGSI_ERR_INVALID, "col_capacity exceeds 2^32-1");
     TRY(use_device(ix));
-    TRY(quiesce_reads(ix));
+    TRY(quiesce_index(ix));
     const uint64_t ns = stride_for(col_capacity);
     uint64_t *nd = nullptr;
     bool nd_contig = false;
@@ -273,7 +285,7 @@ extern "C" int bigsi_hip_set_stream(bigsi_hip_index *ix, void *hip_stream)
 {
     if (!ix) return fail(BIGSI_ERR_INVALID, "NULL index");
     TRY(use_device(ix));
-    TRY(quiesce_reads(ix));
+    TRY(quiesce_index(ix));
     HIP_TRY(hipStreamSynchronize(ix->stream));
     ix->stream = hip_stream ? (hipStream_t)hip_stream : ix->own_stream;
     return BIGSI_OK;
@@ -283,7 +295,7 @@ extern "C" int bigsi_hip_synchronize(bigsi_hip_index *ix)
 {
     if (!ix) return fail(BIGSI_ERR_INVALID, "NULL index");
     TRY(use_device(ix));
-    TRY(quiesce_reads(ix));
+    TRY(quiesce_index(ix));
     HIP_TRY(hipStreamSynchronize(ix->pre_stream));
     HIP_TRY(hipStreamSynchronize(ix->stream));
     return BIGSI_OK;
@@ -301,7 +313,7 @@ extern "C" int bigsi_hip_set_rows(bigsi_hip_index *ix, const uint64_t *row_ids, 
     for (uint64_t i = 0; i < n; i++)
         if (row_ids[i] >= ix->m) return fail(BIGSI_ERR_RANGE, "row %llu out of range [0,%llu)", (unsigned long long)row_ids[i], (unsigned long long)ix->m);
     TRY(use_device(ix));
-    TRY(quiesce_reads(ix));
+    TRY(quiesce_index(ix));
     const uint64_t per = std::max<uint64_t>(1, kStageBytes / row_bytes);
     for (uint64_t i0 = 0; i0 < n; i0 += per) {
         const uint64_t c = std::min(per, n - i0);
@@ -343,7 +355,7 @@ extern "C" int bigsi_hip_clear(bigsi_hip_index *ix)
 {
     if (!ix) return fail(BIGSI_ERR_INVALID, "NULL index");
     TRY(use_device(ix));
-    TRY(quiesce_reads(ix));
+    TRY(quiesce_index(ix));
     HIP_TRY(hipMemsetAsync(ix->d_index, 0, (size_t)ix->m * ix->stride_words * 8, ix->stream));
     HIP_TRY(hipStreamSynchronize(ix->stream));
     return BIGSI_OK;
@@ -355,7 +367,7 @@ extern "C" int bigsi_hip_insert_column(bigsi_hip_index *ix, uint64_t col, const 
     if (col > ix->n_cols) return fail(BIGSI_ERR_RANGE, "column %llu beyond num_cols %llu", (unsigned long long)col, (unsigned long long)ix->n_cols);
     if (col >= ix->cap_cols) return fail(BIGSI_ERR_CAPACITY, "column %llu beyond col_capacity %llu", (unsigned long long)col, (unsigned long long)ix->cap_cols);
     TRY(use_device(ix));
-    TRY(quiesce_reads(ix));
+    TRY(quiesce_index(ix));
     const uint64_t nb = ceil_div(ix->m, 8);
     TRY(ix->stage.reserve(nb));
     HIP_TRY(hipMemcpyAsync(ix->stage.p, bloom, nb, hipMemcpyHostToDevice, ix->stream));
@@ -367,8 +379,8 @@ extern "C" int bigsi_hip_insert_column(bigsi_hip_index *ix, uint64_t col, const 
     return BIGSI_OK;
 }
 
-static int ev_begin(bigsi_hip_index *ix, EventPair *p, hipStream_t st = nullptr, bool row_and = false);
-static int ev_end(bigsi_hip_index *ix, EventPair *p, std::vector<EventPair> &dst, hipStream_t st = nullptr, uint32_t launches = 1);
+#define ev_begin bigsi_ev_begin
+#define ev_end bigsi_ev_end
 
 // n filters already on the device -> columns [col0, col0 + n): whole 64-column words through the tiled transpose
 // (k_transpose_tiles), the ragged head (up to the next multiple of 128 columns) and tail through k_insert_columns
@@ -433,7 +445,7 @@ extern "C" int bigsi_hip_insert_columns(bigsi_hip_index *ix, uint64_t col0, uint
     TRY(check_insert_columns(ix, col0, n, blooms, bloom_stride_bytes));
     if (n == 0) return BIGSI_OK;
     TRY(use_device(ix));
-    TRY(quiesce_reads(ix));
+    TRY(quiesce_index(ix));
     // filters are staged a slab at a time at a 16-byte pitch (vector loads): at least 512 of them when 2 GB allow it (one
     // transpose tile is 512 columns wide), otherwise about 256 MB worth
     const uint64_t nb = ceil_div(ix->m, 8), pitch = round_up(nb, 16);
@@ -456,7 +468,7 @@ extern "C" int bigsi_hip_insert_columns_device(bigsi_hip_index *ix, uint64_t col
     TRY(check_insert_columns(ix, col0, n, d_blooms, bloom_stride_bytes));
     if (n == 0) return BIGSI_OK;
     TRY(use_device(ix));
-    TRY(quiesce_reads(ix));
+    TRY(quiesce_index(ix));
     EventPair ep{};
     TRY(ev_begin(ix, &ep));
     TRY(transpose_device(ix, col0, n, (const uint8_t *)d_blooms, bloom_stride_bytes));
@@ -475,7 +487,7 @@ extern "C" int bigsi_hip_append_index(bigsi_hip_index *dst, const bigsi_hip_inde
     if (src->n_cols == 0) return BIGSI_OK;
     TRY(bigsi_hip_reserve_cols(dst, dst->n_cols + src->n_cols));
     TRY(use_device(dst));
-    TRY(quiesce_reads(dst));
+    TRY(quiesce_index(dst));
     HIP_TRY(hipStreamSynchronize(src->stream));
     const uint64_t per_row = ceil_div(dst->n_cols + src->n_cols, 64) - (dst->n_cols >> 6);
     const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(dst->m * per_row, kBlock), 256 * 64);
@@ -519,7 +531,7 @@ extern "C" int bigsi_hip_insert_kmers(bigsi_hip_index *ix, uint64_t col, const c
     if (n_seqs == 0) return BIGSI_OK;
     TRY(check_offsets(offsets, n_seqs));
     TRY(use_device(ix));
-    TRY(quiesce_reads(ix));
+    TRY(quiesce_index(ix));
     const uint64_t base = offsets[0], nbytes = offsets[n_seqs] - base;
     std::vector<uint64_t> rel(n_seqs + 1);
     for (uint32_t i = 0; i <= n_seqs; i++) rel[i] = offsets[i] - base;
@@ -539,7 +551,7 @@ extern "C" int bigsi_hip_fill_synthetic(bigsi_hip_index *ix, uint64_t seed, uint
     if (!ix) return fail(BIGSI_ERR_INVALID, "NULL index");
     if (and_draws == 0 || and_draws > 8) return fail(BIGSI_ERR_INVALID, "and_draws must be in [1,8]");
     TRY(use_device(ix));
-    TRY(quiesce_reads(ix));
+    TRY(quiesce_index(ix));
     hipLaunchKernelGGL(k_fill_synth, dim3(256 * 16), dim3(kBlock), 0, ix->stream, ix->d_index, ix->m, ix->stride_words, ix->n_cols, seed, shard, and_draws);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ix->stream));
@@ -573,7 +585,7 @@ extern "C" int bigsi_hip_bloom(int device, const char *kmers, uint64_t u, uint32
 }
 
 // ------------------------------------------------------------------------------ profiling events
-static int ev_begin(bigsi_hip_index *ix, EventPair *p, hipStream_t st, bool row_and)
+int bigsi_ev_begin(bigsi_hip_index *ix, EventPair *p, hipStream_t st, bool row_and)
 {
     if (!st) st = ix->stream;
     *p = EventPair{};
@@ -591,7 +603,7 @@ static int ev_begin(bigsi_hip_index *ix, EventPair *p, hipStream_t st, bool row_
     return BIGSI_OK;
 }
 
-static int ev_end(bigsi_hip_index *ix, EventPair *p, std::vector<EventPair> &dst, hipStream_t st, uint32_t launches)
+int bigsi_ev_end(bigsi_hip_index *ix, EventPair *p, std::vector<EventPair> &dst, hipStream_t st, uint32_t launches)
 {
     if (&dst == &ix->ev_and) ix->and_total += launches;
     if (!p->a) return BIGSI_OK;          // not being timed
@@ -615,7 +627,7 @@ extern "C" int bigsi_hip_stats(bigsi_hip_index *ix, bigsi_hip_stats_t *out, int 
 {
     if (!ix || !out) return fail(BIGSI_ERR_INVALID, "NULL argument");
     TRY(use_device(ix));
-    TRY(quiesce_reads(ix));
+    TRY(quiesce_index(ix));
     HIP_TRY(hipStreamSynchronize(ix->pre_stream));
     HIP_TRY(hipStreamSynchronize(ix->stream));
     auto sum = [&](std::vector<EventPair> &v, uint64_t *n, double *ms) -> int {
@@ -624,6 +636,7 @@ extern "C" int bigsi_hip_stats(bigsi_hip_index *ix, bigsi_hip_stats_t *out, int 
         for (auto &p : v) {
             *n += p.launches;
             float t = 0;
+            HIP_TRY(hipEventSynchronize(p.b));      // (pairs recorded on a communicator's or a caller's stream)
             HIP_TRY(hipEventElapsedTime(&t, p.a, p.b));
             *ms += t;
         }
@@ -634,6 +647,7 @@ extern "C" int bigsi_hip_stats(bigsi_hip_index *ix, bigsi_hip_stats_t *out, int 
     TRY(sum(ix->ev_cp, &out->compact_launches, &out->compact_ms));
     TRY(sum(ix->ev_pr, &out->presence_launches, &out->presence_ms));
     TRY(sum(ix->ev_tr, &out->transpose_launches, &out->transpose_ms));
+    TRY(sum(ix->ev_ex, &out->exchange_launches, &out->exchange_ms));
     out->presence_bytes = ix->presence_bytes;
     out->index_contiguous = ix->contiguous ? 1 : 0;
     out->and_launches_total = ix->and_total;
@@ -2009,6 +2023,7 @@ static int presence_begin(bigsi_hip_batch *b, const uint64_t *hit_offsets, const
     uint2 *d_listed = reinterpret_cast<uint2 *>(b->pres_desc.as<uint8_t>() + round_up(max_pieces * 4, 256));
     uint32_t *d_listed_n = reinterpret_cast<uint32_t *>(b->pres_desc.as<uint8_t>() + round_up(max_pieces * 4, 256) + max_pieces * 8);
     if (!job.done) HIP_TRY(hipEventCreateWithFlags(&job.done, hipEventDisableTiming));
+    if (ps == ix->sc_stream) ix->sc_pending = true;      // from here on something of this index may be queued there
     HIP_TRY(hipMemcpyAsync(b->pres_in.p, stage, in_bytes, hipMemcpyHostToDevice, ps));
     const uint8_t *din = b->pres_in.as<uint8_t>();
     EventPair ep{};
@@ -2072,6 +2087,7 @@ static int presence_begin(bigsi_hip_batch *b, const uint64_t *hit_offsets, const
     // one download: [strings or bits | (score records)] are contiguous in pres_out
     HIP_TRY(hipMemcpyAsync(job.h_out, b->pres_out.p, out_bytes, hipMemcpyDeviceToHost, ps));
     HIP_TRY(hipEventRecord(job.done, ps));
+    if (ps == ix->sc_stream) ix->sc_pending = true;
     job.device_work = true;
     job.pending = true;
     return BIGSI_OK;
@@ -2083,17 +2099,19 @@ static int presence_end(bigsi_hip_batch *b, uint8_t *out, uint64_t out_capacity,
     PresJob &job = b->job;
     if (!job.pending) return fail(BIGSI_ERR_STATE, "no score / presence request of this batch is pending");
     TRY(use_device(b->ix));
-    if (job.device_work) HIP_TRY(hipEventSynchronize(job.done));
-    job.pending = false;
+    // arguments first: a call that fails on them leaves the request pending (its results stay staged in job.h_out), so the
+    // caller can repeat _end with a larger buffer
     if (job.packed && !scores) return fail(BIGSI_ERR_INVALID, "scores is NULL");
     if (job.str > out_capacity)
         return fail(BIGSI_ERR_CAPACITY, "%s buffer holds %llu bytes, %llu needed", job.packed ? "bit" : "string", (unsigned long long)out_capacity, (unsigned long long)job.str);
+    if (job.n_hits && job.device_work && !out) return fail(BIGSI_ERR_INVALID, "out is NULL");
+    if (job.device_work) HIP_TRY(hipEventSynchronize(job.done));
+    job.pending = false;
     if (job.n_hits == 0) return BIGSI_OK;
     if (!job.device_work) {
         if (job.packed) memset(scores, 0, job.n_hits * sizeof(bigsi_hip_hit_score));
         return BIGSI_OK;
     }
-    if (!out) return fail(BIGSI_ERR_INVALID, "out is NULL");
     memcpy(out, job.h_out, job.str);
     if (job.packed) memcpy(scores, static_cast<const uint8_t *>(job.h_out) + job.o_scores, job.n_hits * sizeof(bigsi_hip_hit_score));
     return BIGSI_OK;

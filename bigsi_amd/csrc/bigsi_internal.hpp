@@ -2,6 +2,8 @@
 // (bigsi_hip.hip: single-shard C ABI; bigsi_shard.hip: RCCL exchange, device groups, one-call search).
 #pragma once
 #include "bigsi_hip.h"
+#include "bigsi_hip_group.h"
+#include "bigsi_hip_testing.h"
 
 #include <hip/hip_runtime.h>
 
@@ -93,6 +95,7 @@ struct bigsi_hip_index {
     uint32_t rd_next = 0;
     hipStream_t sc_stream = nullptr;               // K5 / K6 of scored searches: highest priority (score_stream)
     bool rd_pending = false;      // something may still be running on them
+    bool sc_pending = false;      // a K5 / K6 request may still be queued on sc_stream (it reads d_index): quiesce_index
     hipEvent_t main_ev = nullptr; // end of the last batch run on the index stream (mark_main)
     uint64_t fused_repeats = 0;   // one-launch read kernels repeated because a workgroup gave up waiting (bigsi_hip_stats)
     struct bigsi_hip_batch *search_ws = nullptr;      // bigsi_hip_search_batch's workspace, created at its first call
@@ -106,7 +109,7 @@ struct bigsi_hip_index {
     int profiling = 0;            // 0 off, 1 every kernel group of a run, 2 the row-AND kernel only
     uint32_t prof_every = 1, prof_tick = 0;      // level 2 sampled: every prof_every-th run is timed
     uint64_t and_total = 0;       // row-AND launches since the last stats reset, timed or not
-    std::vector<EventPair> ev_and, ev_km, ev_cp, ev_pr, ev_tr, ev_free;
+    std::vector<EventPair> ev_and, ev_km, ev_cp, ev_pr, ev_tr, ev_ex, ev_free;
     uint64_t presence_bytes = 0;   // algorithmic bytes of the timed presence_hits calls
     uint64_t wv() const { return ceil_div(n_cols, 64); }
     uint64_t rb() const { return ceil_div(n_cols, 8); }
@@ -218,5 +221,8 @@ int bigsi_batch_export(bigsi_hip_batch *b);
 int bigsi_batch_collect(bigsi_hip_batch *b, uint32_t *num_kmers, uint32_t *num_unique, uint32_t *min_kmers, uint64_t *hit_offsets,
                         uint32_t *colours, uint32_t *counts, uint64_t capacity);
 int bigsi_use_device(const bigsi_hip_index *ix);
+// profiling events (bigsi_hip_set_profiling): a pair around a group of launches on `st` (null: the index stream), collected in `dst`
+int bigsi_ev_begin(bigsi_hip_index *ix, EventPair *p, hipStream_t st = nullptr, bool row_and = false);
+int bigsi_ev_end(bigsi_hip_index *ix, EventPair *p, std::vector<EventPair> &dst, hipStream_t st = nullptr, uint32_t launches = 1);
 // write pass of the gathered compaction again after the hit buffers grew (fetch_gathered_hits); defined in bigsi_shard.hip
 int bigsi_reduce_gathered_counts(bigsi_hip_batch *b);

@@ -457,10 +457,15 @@ extern "C" int bigsi_hip_batch_run_sharded(bigsi_hip_batch *b, double threshold,
     RcclApi *api = nullptr;
     TRY(need_rccl(&api));
     HIP_TRY(hipStreamWaitEvent(c->stream, b->done, 0));
+    // the exchange as the communicator's stream sees it (bigsi_hip_stats: exchange_ms): all-gather + gathered compaction +
+    // count all-reduce, from the moment this batch's kernels are over
+    EventPair xe{};
+    TRY(bigsi_ev_begin(b->ix, &xe, c->stream));
     // in place: this rank's slot is where its kernels wrote
     NCCL_TRY(api, api->AllGather(b->ext_bitmaps, gather_base(b), slot_bytes(b), ncclUint8, c->comm, c->stream));
     TRY(compact_after_gather(b));
     if (!b->exact) TRY(bigsi_reduce_gathered_counts(b));
+    TRY(bigsi_ev_end(b->ix, &xe, b->ix->ev_ex, c->stream));
     return BIGSI_OK;
 }
 

@@ -19,11 +19,11 @@
  *       CORE       index lifecycle + storage contract + bigsi_hip_lookup + bigsi_hip_search_batch (the whole of
  *                  BIGSI.search for a batch in ONE call) + bigsi_hip_batch_presence_hits: enough for any host.
  *       BATCHES    bigsi_hip_batch_*: staged workspaces and asynchronous runs for serving loops.
- *       MULTI-GPU  bigsi_hip_comm_* / batch_set_comm / batch_run_sharded (one process per GPU) and bigsi_hip_group_*
- *                  (one process, N GPUs): the RCCL exchange is issued by the library.
- *       EXCHANGE-BY-CALLER  set_stream, batch_set_outputs / set_result_cols / set_gather_stream / compact_gathered*,
- *                  set_gathered_hit_outputs: for hosts that bring their own collective (gloo in the tests).
- *       MEASUREMENT  fill_synthetic, insert_columns_device, set_profiling, stats, the BIGSI_RUN_* test flags.
+ *       MULTI-GPU  bigsi_hip_comm_* / batch_set_comm / batch_run_sharded (one process per GPU): the RCCL exchange is issued by
+ *                  the library.  One process driving N GPUs: bigsi_hip_group_* in include/bigsi_hip_group.h.
+ *       MEASUREMENT  fill_synthetic, insert_columns_device, set_profiling, stats.
+ *     Not advertised here (exported all the same, declared in include/bigsi_hip_testing.h): hooks for hosts that bring their own
+ *     collective (torch.distributed over gloo on a one-GPU test box) and the BIGSI_RUN_* flags that force an A/B route.
  *     The library reads no environment variables (tuning knobs exist only in builds made with -DBIGSI_HIP_TUNING).
  *   - ROW FORMAT: a row is the reference's `bitarray.tobytes()` (bigsi/storage/base.py:85-99):
  *     ceil(num_cols/8) bytes, column c at byte c/8 under mask 0x80 >> (c%8), zero pad bits.
@@ -80,16 +80,12 @@ int bigsi_hip_set_num_hashes(bigsi_hip_index *ix, uint32_t num_hashes);
 /* Grow the row stride on the device so that insert / merge can append columns
  * (bigsi/matrix/bitmatrix.py:67-75, bigsi/graph/index.py:54-60). */
 int bigsi_hip_reserve_cols(bigsi_hip_index *ix, uint64_t col_capacity);
-/* Run this index's kernels and copies on a caller-owned hipStream_t (e.g. torch's current stream, so
- * that RCCL collectives issued by the caller are ordered after them).  NULL restores the private stream.
- * STREAMS.  On its private stream(s) the library orders everything itself: bigsi_hip_batch_run is asynchronous; the fetch /
+/* STREAMS.  On its private stream(s) the library orders everything itself: bigsi_hip_batch_run is asynchronous; the fetch /
  * presence calls of a batch wait for THAT batch's kernels only; batches of reads (the one-launch kernel: k = 31, < 64
  * k-mers per query, hit lists only) are issued round-robin on three internal streams so that consecutive batches overlap;
  * every call that changes the index, bigsi_hip_stats and bigsi_hip_synchronize wait for all of them; the kernels of scored
  * searches (bigsi_hip_batch_score_hits*, presence_hits) run on a fourth, high-priority stream beside whatever the others are
- * doing, and a batch that is run again is ordered behind its own pending score request on the device.  With a caller-owned
- * stream set, every kernel of the index goes to that one stream. */
-int bigsi_hip_set_stream(bigsi_hip_index *ix, void *hip_stream);
+ * doing, and a batch that is run again is ordered behind its own pending score request on the device.  (A caller-owned stream: bigsi_hip_testing.h.) */
 int bigsi_hip_synchronize(bigsi_hip_index *ix);
 
 /* ================================================================== CORE: storage contract
@@ -156,18 +152,10 @@ int bigsi_hip_lookup_raw(bigsi_hip_index *ix, const char *blob, const uint64_t *
 #define BIGSI_RUN_SKIP_COMPACT 2u /* stop after K2/K3: the caller compacts a gathered buffer instead (multi-GPU) */
 #define BIGSI_RUN_SPARSE_COUNTS 8u /* counting path: store per-sample counters only where a sample reaches min_kmers
                                       (hit lists are complete; fetch_counts is unavailable for that run) */
-/* test / A-B flags: same results, different route (tests/test_gpu_parity.py, scripts/ab_*.py); not for production callers */
-#define BIGSI_RUN_K1_GLOBAL 4u   /* take the multi-launch K1 (global-memory dedupe table) whatever the query lengths */
-#define BIGSI_RUN_NO_SORT 16u    /* stream each query's rows in hash order instead of address order */
 #define BIGSI_RUN_EARLY_EXIT 32u /* stop fetching a query's rows for a column segment once its result is settled: exact, the
                                     running AND is all zero; thresholded (with SPARSE_COUNTS), no sample of the segment can reach
                                     min_kmers with the k-mers that are left.  Same hit lists, fewer bytes than the reference
                                     reads -- hence opt-in (config key `early_exit` of the host shim) */
-#define BIGSI_RUN_NO_WAITING 128u /* one-launch read path: workgroups give up waiting for their predecessors' hit totals at once,
-                                     so that the launch is marked incomplete and repeated (otherwise a 20 ms timeout) */
-#define BIGSI_RUN_WEAK_FINGERPRINT 64u /* one-launch read path: 1-bit k-mer fingerprints, so that the dedupe takes its exact
-                                          pairwise route (otherwise reached only on a 2^-32 fingerprint collision) */
-
 int bigsi_hip_batch_create(bigsi_hip_index *ix, const char *seqs, const uint64_t *offsets, uint32_t n_seqs,
                            uint32_t k, bigsi_hip_batch **out);
 /* A batch whose k-mers are given explicitly ("elements"), for sequences that are not byte strings of k-byte windows: the
@@ -206,14 +194,6 @@ typedef struct {
     uint32_t reserved;
 } bigsi_hip_batch_info;
 int bigsi_hip_batch_get_info(bigsi_hip_batch *b, bigsi_hip_batch_info *out); /* synchronises */
-
-/* Write the per-sample result of later runs into caller-owned device memory (e.g. this rank's slot of an
- * RCCL all-gather buffer) instead of the batch's own buffers.  Either may be NULL (= keep own buffer). */
-int bigsi_hip_batch_set_outputs(bigsi_hip_batch *b, void *d_bitmaps, void *d_counts);
-/* Width, in columns, of the per-sample result vectors of later runs (default 0 = the index's num_cols).  The shards of one
- * index all set the group's shard width here, so that uneven shards still exchange buffers of ONE geometry (strides, word
- * counts); needs cols <= col_capacity.  Columns beyond the shard's own num_cols read as zero. */
-int bigsi_hip_batch_set_result_cols(bigsi_hip_batch *b, uint64_t cols);
 
 /* per sequence: number of k-mers n (with duplicates), unique query k-mers u = len(set(kmers))
  * (graph/bigsi.py:177-179) and min_kmers.  Any pointer may be NULL. */
@@ -281,26 +261,8 @@ int bigsi_hip_batch_score_hits_end(bigsi_hip_batch *b, uint8_t *bits, uint64_t b
 int bigsi_hip_score_presence(int device, const uint8_t *bits, const uint64_t *bit_offsets, const uint32_t *num_kmers,
                              const uint32_t *found, const uint32_t *unique, uint64_t n, bigsi_hip_hit_score *scores);
 
-/* EXCHANGE-BY-CALLER.  Multi-GPU assembly: compact hits from result buffers gathered from n_shards column shards (device pointer,
- * layout [shard][seq][stride] with this batch's strides; colour = shard * shard_cols + local column).
- * compact_gathered* are asynchronous, also for the host: they are queued (on the gather stream, below) behind this batch's
- * run through an event, never by waiting for it -- call them after the RCCL all-gather, which the caller issues on the
- * same stream; fetch_gathered_hits synchronises and copies out, same format as fetch_hits. */
-/* Run this batch's gathered compaction (and the copies of fetch_gathered_hits) on a caller-owned hipStream_t -- typically
- * the stream the collective is issued under, so that all-gather + compaction of one batch overlap the row-AND kernels of
- * the next batch on the index's stream.  NULL = the index's stream. */
-int bigsi_hip_batch_set_gather_stream(bigsi_hip_batch *b, void *hip_stream);
-int bigsi_hip_batch_compact_gathered(bigsi_hip_batch *b, const void *d_gathered, uint32_t n_shards, uint64_t shard_cols);
-/* Thresholded search over column shards without moving per-sample counters: the counting kernel also leaves each
- * shard's hit mask (1 bit per sample: count >= min_kmers) in the bitmap output (bigsi_hip_batch_set_outputs), which is what
- * gets all-gathered.  compact_gathered_masks compacts the gathered masks -- identically on every rank -- and fills each
- * hit's count from THIS rank's counters when the hit lies in shard `own_shard`, 0 otherwise; the caller then sums the
- * count arrays of all ranks (one fixed-size all-reduce over the buffer given to set_gathered_hit_outputs). */
-int bigsi_hip_batch_compact_gathered_masks(bigsi_hip_batch *b, const void *d_gathered_masks, uint32_t n_shards, uint64_t shard_cols,
-                                           uint32_t own_shard);
-/* Put the gathered hit lists (colours, counts: uint32[capacity] each) into caller-owned device memory.  With caller-owned
- * buffers fetch_gathered_hits reports BIGSI_ERR_CAPACITY instead of growing them. */
-int bigsi_hip_batch_set_gathered_hit_outputs(bigsi_hip_batch *b, void *d_colours, void *d_counts, uint64_t capacity);
+/* MULTI-GPU: the hit lists of a sharded run (bigsi_hip_batch_run_sharded below), identical on every rank: synchronises and copies out,
+ * same format as fetch_hits with global colours = shard * shard_cols + local column. */
 int bigsi_hip_batch_fetch_gathered_hits(bigsi_hip_batch *b, uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t capacity);
 
 /* ================================================================== CORE: one-call search
@@ -322,7 +284,7 @@ int bigsi_hip_search_stream(bigsi_hip_index *ix, const char *seqs, const uint64_
                             double threshold, uint32_t flags, uint32_t *num_kmers, uint32_t *num_unique, uint32_t *min_kmers,
                             uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t hit_capacity);
 
-/* BIGSI.search(..., score=True) (bigsi/graph/bigsi.py:80-100 with bigsi/scoring/score.py:96-121) for any number of sequences
+/* BIGSI.search(..., score=True) (bigsi/graph/bigsi.py:174-190, 232-239 with bigsi/scoring/score.py:96-116) for any number of sequences
  * in ONE call: bigsi_hip_search_stream plus, for every hit t (global index into colours), its presence bits at
  * bits + bit_offsets[t] and its score record scores[t] (layout and fields of bigsi_hip_batch_score_hits).  The scoring kernels
  * of one device batch run beside the row-AND kernels of the next.  bit_offsets: hit_capacity + 1 entries; scores:
@@ -361,57 +323,8 @@ int bigsi_hip_batch_set_comm(bigsi_hip_batch *b, bigsi_hip_comm *c, uint64_t sha
  * shard * shard_cols + local column), identical on every rank. */
 int bigsi_hip_batch_run_sharded(bigsi_hip_batch *b, double threshold, uint32_t flags);
 
-/* One process driving several GPUs: a group owns one column shard per device and a communicator per shard
- * (ncclCommInitAll); every call below fans out to the devices, collectives are issued inside ncclGroupStart/End.
- * This is what the `hip-hbm` backend opens for storage-config {"devices": [0, 1, ...]}: one get_storage() call
- * (bigsi/storage/__init__.py:3-19) reaches every GPU of the node.  shard_cols = ceil(col_capacity / n_dev) rounded up to
- * 64 columns, fixed for the life of the group; colour c lives on shard c / shard_cols.  A device may be listed more than
- * once (testing on a one-GPU box): its shards then exchange through shared device memory instead of RCCL. */
-typedef struct bigsi_hip_group bigsi_hip_group;
-typedef struct bigsi_hip_group_batch bigsi_hip_group_batch;
-int bigsi_hip_group_open(uint64_t num_rows, uint64_t num_cols, uint64_t col_capacity, uint32_t num_hashes,
-                         const int *device_ids, int n_dev, bigsi_hip_group **out);
-int bigsi_hip_group_close(bigsi_hip_group *g);
-typedef struct {
-    uint64_t num_rows, num_cols, col_capacity, shard_cols, row_bytes, index_bytes; /* whole index; index_bytes summed over devices */
-    uint32_t num_hashes, n_shards;
-    uint32_t rccl; /* 1: shards exchange through RCCL; 0: shared device memory (repeated device ids) */
-} bigsi_hip_group_info;
-int bigsi_hip_group_get_info(const bigsi_hip_group *g, bigsi_hip_group_info *out);
-/* the shard on device_ids[i], for the single-index entry points above (bulk fills, profiling, statistics) */
-int bigsi_hip_group_shard(bigsi_hip_group *g, uint32_t i, bigsi_hip_index **out);
-int bigsi_hip_group_set_num_cols(bigsi_hip_group *g, uint64_t num_cols);
-int bigsi_hip_group_set_num_hashes(bigsi_hip_group *g, uint32_t num_hashes);
-int bigsi_hip_group_synchronize(bigsi_hip_group *g);
-int bigsi_hip_group_clear(bigsi_hip_group *g);
-/* storage contract over whole rows (row_bytes = bytes of a row of the WHOLE index, as bigsi_hip_set_rows / get_rows) */
-int bigsi_hip_group_set_rows(bigsi_hip_group *g, const uint64_t *row_ids, uint64_t n, const uint8_t *bytes, uint64_t row_bytes);
-int bigsi_hip_group_get_rows(bigsi_hip_group *g, const uint64_t *row_ids, uint64_t n, uint8_t *out, uint64_t row_bytes);
-int bigsi_hip_group_insert_columns(bigsi_hip_group *g, uint64_t col0, uint64_t n, const uint8_t *blooms, uint64_t bloom_stride_bytes);
-int bigsi_hip_group_get_column(bigsi_hip_group *g, uint64_t col, uint8_t *out);
-int bigsi_hip_group_insert_kmers(bigsi_hip_group *g, uint64_t col, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k);
-int bigsi_hip_group_fill_synthetic(bigsi_hip_group *g, uint64_t seed, uint32_t and_draws); /* shard i = fill_synthetic(seed, i) */
-int bigsi_hip_group_lookup(bigsi_hip_group *g, const char *kmers, uint32_t k, uint64_t u, uint8_t *out_rows);
-int bigsi_hip_group_lookup_raw(bigsi_hip_group *g, const char *blob, const uint64_t *elem_offsets, uint64_t u, uint8_t *out_rows);
-/* fused query path over all shards; same meaning as the bigsi_hip_batch_* calls, colours are global */
-int bigsi_hip_group_batch_create(bigsi_hip_group *g, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k,
-                                 bigsi_hip_group_batch **out);
-int bigsi_hip_group_batch_create_elements(bigsi_hip_group *g, const char *blob, const uint64_t *elem_offsets,
-                                          const uint64_t *seq_elem_offsets, const uint32_t *pos_unique,
-                                          const uint64_t *seq_pos_offsets, uint32_t n_seqs, bigsi_hip_group_batch **out);
-int bigsi_hip_group_batch_reload(bigsi_hip_group_batch *gb, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k);
-int bigsi_hip_group_batch_destroy(bigsi_hip_group_batch *gb);
-int bigsi_hip_group_batch_run(bigsi_hip_group_batch *gb, double threshold, uint32_t flags); /* asynchronous */
-int bigsi_hip_group_batch_fetch_unique(bigsi_hip_group_batch *gb, uint32_t *num_kmers, uint32_t *num_unique, uint32_t *min_kmers);
-int bigsi_hip_group_batch_fetch_hits(bigsi_hip_group_batch *gb, uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t capacity);
-int bigsi_hip_group_batch_presence(bigsi_hip_group_batch *gb, uint32_t seq, const uint32_t *colours, uint32_t n_colours, uint8_t *out);
-int bigsi_hip_group_batch_presence_hits(bigsi_hip_group_batch *gb, const uint64_t *hit_offsets, const uint32_t *colours, uint8_t *out,
-                                        uint64_t out_capacity, uint64_t *string_offsets);
-int bigsi_hip_group_batch_score_hits(bigsi_hip_group_batch *gb, const uint64_t *hit_offsets, const uint32_t *colours, const uint32_t *counts,
-                                     uint8_t *bits, uint64_t bits_capacity, uint64_t *bit_offsets, bigsi_hip_hit_score *scores);
-int bigsi_hip_group_search_batch(bigsi_hip_group *g, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k,
-                                 double threshold, uint32_t flags, uint32_t *num_kmers, uint32_t *num_unique, uint32_t *min_kmers,
-                                 uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t hit_capacity);
+/* One process driving several GPUs (storage-config {"devices": [0, 1, ...]}): include/bigsi_hip_group.h -- a group owns one
+ * column shard per device and issues the same exchange for all of them (ncclCommInitAll, ncclGroupStart/End). */
 
 /* ================================================================== MEASUREMENT */
 typedef struct {
@@ -431,6 +344,8 @@ typedef struct {
                                         the hit totals of the queries before it (possible only beside launches of other batches) */
     uint64_t index_contiguous;       /* 1: the matrix got physically contiguous device memory (hipDeviceMallocContiguous: largest
                                         page-table fragments), 0: the ordinary allocation it falls back to */
+    uint64_t exchange_launches;      /* bigsi_hip_batch_run_sharded calls timed (profiling level 1) */
+    double exchange_ms;              /* their all-gather + gathered compaction + count all-reduce, by events on the communicator's stream */
 } bigsi_hip_stats_t;
 /* record HIP events around the kernels of batch_run: 0 off, 1 around K1 / K2 / K4 each, 2 around the row-AND kernel only,
  * n > 2 around the row-AND kernel of every n-th run (an event record costs the stream 5-7 us, which is a fifth of a

@@ -12,10 +12,29 @@ from conftest import ROOT, assert_result_equal, load_golden, unjson
 
 
 # --------------------------------------------------------------------------------------------- C ABI
-def header_functions():
+HIP_HEADERS = ("bigsi_hip.h", "bigsi_hip_group.h", "bigsi_hip_testing.h")      # advertised boundary | device groups | test hooks
+
+
+def header_functions(headers=HIP_HEADERS):
+    names = set()
+    for h in headers:
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names |= set(re.findall(r"\b(bigsi_hip_\w+)\s*\(", src))
+    return sorted(names)
+
+
+def test_public_header_stays_small():
+    """include/bigsi_hip.h is core + batches + the one-process-per-GPU exchange + stats; caller-managed exchange hooks and the
+    flags that force an A/B route live in bigsi_hip_testing.h, device groups in bigsi_hip_group.h."""
+    public = header_functions(("bigsi_hip.h",))
+    assert len(public) <= 60, len(public)
+    hidden = set(header_functions(("bigsi_hip_testing.h",)))
+    assert {"bigsi_hip_set_stream", "bigsi_hip_batch_set_outputs", "bigsi_hip_batch_compact_gathered"} <= hidden
+    assert not hidden & set(public)
     src = open(os.path.join(ROOT, "include", "bigsi_hip.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(bigsi_hip_\w+)\s*\(", src)))
+    for flag in ("BIGSI_RUN_K1_GLOBAL", "BIGSI_RUN_NO_WAITING", "BIGSI_RUN_WEAK_FINGERPRINT", "BIGSI_RUN_NO_SORT"):
+        assert "#define " + flag not in src
 
 
 def test_library_exports_every_declared_symbol():
