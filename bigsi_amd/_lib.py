@@ -22,6 +22,7 @@ RUN_NO_SORT = 16
 RUN_EARLY_EXIT = 32
 RUN_WEAK_FINGERPRINT = 64
 RUN_NO_WAITING = 128
+RUN_ONE_STREAM = 256
 BLOOM_RAW = 1
 SCORE_ORDERED = 1
 
@@ -153,6 +154,7 @@ SIGNATURES = {
     "bigsi_hip_group_search_batch": (_i32, [_P, C.c_char_p, _P, _u32, _u32, _dbl, _u32, _P, _P, _P, _P, _P, _P, _u64]),
     "bigsi_hip_set_profiling": (_i32, [_P, _i32]),
     "bigsi_hip_stats": (_i32, [_P, C.POINTER(Stats), _i32]),
+    "bigsi_hip_probe_rows": (_i32, [_P, _u32, _u32, _u32, _u32, _u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 
 _lib = None

@@ -661,6 +661,63 @@ extern "C" int bigsi_hip_stats(bigsi_hip_index *ix, bigsi_hip_stats_t *out, int 
     return BIGSI_OK;
 }
 
+// MEASUREMENT: bare row streams over this index's own matrix (k_probe_rows): GB/s of `n_queries` lists of `rows_per_query`
+// rows each, uniform random (sorted = 0) or ascending (1), in launches of `wgs` four-wavefront workgroups (0: as the library
+// sizes its own row-AND launches -- the smallest multiple of 256 workgroups with >= 1600 live wavefronts); median launch of
+// `reps` passes after one warm pass, HIP events on the index stream.
+extern "C" int bigsi_hip_probe_rows(bigsi_hip_index *ix, uint32_t rows_per_query, uint32_t n_queries, uint32_t sorted, uint32_t wgs, uint32_t reps,
+                                    double *gbps, double *launch_ms)
+{
+    if (!ix || !gbps) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    if (rows_per_query == 0 || n_queries == 0 || reps == 0) return fail(BIGSI_ERR_INVALID, "rows_per_query, n_queries and reps must be > 0");
+    if (ix->n_cols == 0) return fail(BIGSI_ERR_STATE, "index has no columns");
+    TRY(use_device(ix));
+    TRY(quiesce_index(ix));
+    const uint32_t wv = (uint32_t)ix->wv(), segs = (uint32_t)ceil_div(wv, 64 * kVec), live = (uint32_t)ceil_div(wv, 64 * kVec);
+    if (wgs == 0) wgs = (uint32_t)round_up(ceil_div(1600ull * ceil_div(segs, 4), live), 256);
+    // as many LIVE wavefronts per launch as a row-AND launch of `wgs` workgroups has (there a query's last workgroup is partly empty)
+    const uint32_t q_per_launch = std::max<uint32_t>(wgs / (uint32_t)ceil_div(segs, 4), 1);
+    if (n_queries < 2 * q_per_launch) n_queries = 2 * q_per_launch;
+    DevBuf ids, out;
+    int rc = ids.reserve((size_t)n_queries * rows_per_query * 8);
+    if (rc == BIGSI_OK) rc = out.reserve((size_t)q_per_launch * segs * 64 * 16);
+    std::vector<float> ms;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto body = [&]() -> int {
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        hipLaunchKernelGGL(k_probe_ids, dim3(1024), dim3(kBlock), 0, ix->stream, ids.as<uint64_t>(), (uint64_t)n_queries, rows_per_query, ix->m, sorted, 0x5EEDull + sorted);
+        HIP_TRY(hipGetLastError());
+        for (uint32_t rep = 0; rep <= reps; rep++)
+            for (uint32_t q0 = 0; q0 + q_per_launch <= n_queries; q0 += q_per_launch) {
+                const uint32_t waves = q_per_launch * segs, blocks = (uint32_t)ceil_div(waves, 4);
+                HIP_TRY(hipEventRecord(e0, ix->stream));
+                hipLaunchKernelGGL(k_probe_rows, dim3(blocks), dim3(kBlock), 0, ix->stream, ix->d_index, ix->stride_words, wv, ids.as<uint64_t>(), rows_per_query, segs,
+                                   q0, q0 + q_per_launch, reinterpret_cast<u64x2 *>(out.p));
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipEventRecord(e1, ix->stream));
+                HIP_TRY(hipEventSynchronize(e1));
+                float t = 0;
+                HIP_TRY(hipEventElapsedTime(&t, e0, e1));
+                if (rep) ms.push_back(t);
+            }
+        return BIGSI_OK;
+    };
+    if (rc == BIGSI_OK) rc = body();
+    hipError_t e = hipSuccess;
+    if (e0) e = hipEventDestroy(e0);
+    if (e1) e = hipEventDestroy(e1);
+    (void)e;
+    ids.release();
+    out.release();
+    if (rc != BIGSI_OK) return rc;
+    std::sort(ms.begin(), ms.end());
+    const double med = ms[ms.size() / 2];
+    *gbps = (double)q_per_launch * rows_per_query * wv * 8.0 / (med * 1e-3) / 1e9;
+    if (launch_ms) *launch_ms = med;
+    return BIGSI_OK;
+}
+
 // ------------------------------------------------------------------------------ batches
 static uint64_t pow2_at_least(uint64_t x)
 {
@@ -1271,7 +1328,8 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
         EventPair fe{};
         b->dirty = true;
         hipStream_t st = ix->stream;
-        TRY(read_stream(ix, &st));
+        if (!(flags & BIGSI_RUN_ONE_STREAM)) TRY(read_stream(ix, &st));
+        else if (ix->rd_pending) TRY(quiesce_reads(ix));      // (alone on the device: nothing of the read streams beside it)
         // (the compaction kernel of a gene-length batch waits between workgroups too: such a run is over before read kernels start)
         if (ix->main_ev && st != ix->stream) HIP_TRY(hipStreamWaitEvent(st, ix->main_ev, 0));
         if (b->done && b->run_stream != st) HIP_TRY(hipStreamWaitEvent(st, b->done, 0));      // this batch's previous run

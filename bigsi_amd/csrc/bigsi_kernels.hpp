@@ -2247,4 +2247,46 @@ __global__ __launch_bounds__(kBlock) void k_fill_synth(
     }
 }
 
+// ------------------------------------------------------------------------------ calibration: what this box gives bare row streams
+// bigsi_hip_probe_rows (MEASUREMENT): a kernel with NO BIGSI code reads row lists of the index itself the way the row-AND
+// kernels do -- one wavefront per 1 KiB column segment of every row of a "query", lane = 16 bytes, eight non-temporal loads in
+// flight, AND-reduce -- so that a bench line can say which fraction of THIS box's random-row (counting kernel) or
+// address-ordered (exact kernel) rate a leg reached: boxes differ by several per cent at identical clocks.
+// ids: random = uniform over [0, m); sorted = one uniform draw per stratum [i*m/R, (i+1)*m/R): ascending by construction.
+__global__ __launch_bounds__(kBlock) void k_probe_ids(uint64_t *__restrict__ ids, uint64_t n_queries, uint32_t rows_per_query, uint64_t m, uint32_t sorted, uint64_t seed)
+{
+    const uint64_t total = n_queries * rows_per_query;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (uint64_t)gridDim.x * kBlock) {
+        const uint64_t r = mix64(seed + i * 0x9E3779B97F4A7C15ull);
+        if (!sorted) {
+            ids[i] = r % m;
+        } else {
+            const uint64_t j = i % rows_per_query, lo = (unsigned __int128)j * m / rows_per_query, hi = (unsigned __int128)(j + 1) * m / rows_per_query;
+            ids[i] = lo + (hi > lo ? r % (hi - lo) : 0);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_probe_rows(const uint64_t *__restrict__ index, uint64_t stride_words, uint32_t wv, const uint64_t *__restrict__ ids,
+                                                       uint32_t rows_per_query, uint32_t segs, uint32_t q0, uint32_t q1, u64x2 *__restrict__ out)
+{
+    const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    const uint32_t q = q0 + wave / segs, seg = wave % segs;
+    if (q >= q1) return;
+    const uint32_t w0 = seg * 128u + lane * kVec;
+    if (w0 >= wv) return;
+    const uint64_t *r = ids + (uint64_t)q * rows_per_query;
+    u64x2 acc = {~0ull, ~0ull};
+    uint32_t i = 0;
+    for (; i + 8 <= rows_per_query; i += 8) {
+        u64x2 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = load_row_seg<true>(index, r[i + j], stride_words, w0);
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc &= v[j];
+    }
+    for (; i < rows_per_query; i++) acc &= load_row_seg<true>(index, r[i], stride_words, w0);
+    out[((uint64_t)(q - q0) * segs + seg) * 64 + lane] = acc;
+}
+
 }   // namespace bigsi

@@ -352,6 +352,13 @@ typedef struct {
  * step for a batch of short reads: sampled, the timed region runs at its untimed speed) */
 int bigsi_hip_set_profiling(bigsi_hip_index *ix, int on);
 int bigsi_hip_stats(bigsi_hip_index *ix, bigsi_hip_stats_t *out, int reset); /* synchronises */
+/* Same-box calibration: achieved GB/s of bare row streams over this index's matrix -- a kernel with no BIGSI code, the load
+ * pattern of the row-AND kernels (one wavefront per 1 KiB column segment, 16 B per lane, 8 loads in flight) -- over n_queries
+ * lists of rows_per_query rows, uniform random (sorted = 0: what the counting kernel sees) or ascending (1: the exact kernel's
+ * address-ordered lists); launches of `wgs` workgroups (0 = the library's own launch size); median of `reps` passes.
+ * Lets a bench line state its fraction of what THIS box delivers (boxes differ by several per cent at identical clocks). */
+int bigsi_hip_probe_rows(bigsi_hip_index *ix, uint32_t rows_per_query, uint32_t n_queries, uint32_t sorted, uint32_t wgs, uint32_t reps,
+                         double *gbps, double *launch_ms);
 
 #ifdef __cplusplus
 }

@@ -22,6 +22,9 @@ extern "C" {
 #define BIGSI_RUN_NO_SORT 16u    /* stream each query's rows in hash order instead of address order */
 #define BIGSI_RUN_NO_WAITING 128u /* one-launch read path: workgroups give up waiting for their predecessors' hit totals at once,
                                      so that the launch is marked incomplete and repeated (otherwise a 20 ms timeout) */
+#define BIGSI_RUN_ONE_STREAM 256u /* one-launch read path: this run goes to the index stream instead of the next of the three read
+                                    streams, so that consecutive launches do NOT overlap -- a kernel's own duration is then what it
+                                    takes alone on the device (bench.py: roofline.frac of read workloads) */
 #define BIGSI_RUN_WEAK_FINGERPRINT 64u /* one-launch read path: 1-bit k-mer fingerprints, so that the dedupe takes its exact
                                           pairwise route (otherwise reached only on a 2^-32 fingerprint collision) */
 

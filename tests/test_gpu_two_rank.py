@@ -39,9 +39,8 @@ def test_bench_self_launches_two_ranks(threshold):
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["total_cols"] == 40000 and d["config"]["cols_per_gpu"] == 20000
     assert d["config"]["hits_first_batch"] == 6                    # 3 planted queries x 2 shards
     assert "2 shard(s)" in d["config"]["verified"]
-    assert d["config"]["shard_lookups_per_s_sum"] == pytest.approx(2 * d["value"])
     assert len(d["config"]["per_rank_GBps"]) == 2 and d["config"]["exchange"] == "torch"
-    assert d["value"] == pytest.approx(d["config"]["unique_kmers_per_batch"] / d["ms_per_step"] * 1e3)
+    assert d["value"] == pytest.approx(d["config"]["unique_kmers_per_batch"] / d["ms_per_step"] * 1e3, rel=1e-4)
 
 
 @pytest.mark.gpu
@@ -69,11 +68,54 @@ def test_bench_eight_ranks_under_the_launcher():
 
 
 @pytest.mark.gpu
+def test_bench_gpus_8_runs_the_whole_index_legs(tmp_path):
+    """The driver's 8-GPU command, as it launches it, dry-run on the one GPU of the test box (eight gloo ranks sharing it, rows cut to
+    200 k so that eight shards of the 500 k-sample indexes fit): after the headline every rank starts its rank of the WHOLE-index
+    legs -- configs[3] (25M x 500k exact), configs[4] (0.4 with score=True in the step), the north-star 10M x 500k shape, c3 at 0.4 --
+    each verified against the oracle on every shard, and the one line rank 0 prints carries them all inside the driver's 8 KB."""
+    details = tmp_path / "full.json"
+    d = _bench(["--gpus", "8", "--steps", "4", "--warmup", "2", "--backend", "gloo", "--one-device", "--rows-cap", "200000", "--leg-seconds", "0.02",
+                "--cpu-seconds", "0", "--details", str(details)], launcher_ranks=8, timeout=1500)
+    assert d["n_gpus"] == 8 and d["config"]["workload_key"] == "c3" and "rows<=200000" in d["config"]["workload"]
+    assert "8 shard(s)" in d["config"]["verified"] and "EVERY shard" in d["config"]["verified"]
+    also = d["config"]["also"]
+    assert list(also) == ["c4", "c5", "northstar", "c3_t04"]
+    for key, leg in also.items():
+        assert "error" not in leg, (key, leg)
+        assert leg["ok"] == 1 and leg["v"] > 0 and leg["k"] in ("k_and_exact", "k_and_count"), (key, leg)
+        assert len(leg["gbs"]) == 8
+    assert also["c5"]["hits"] > 0 and also["c5"]["k"] == "k_and_count" and also["c4"]["k"] == "k_and_exact"
+    assert len(json.dumps(d)) <= 7500
+    full = json.load(open(details))
+    assert full["config"]["also"] == d["config"]["also"] or set(full["config"]["also"]) == set(also)
+
+
+@pytest.mark.gpu
+def test_bench_default_line_fits_the_drivers_tail():
+    """`python bench.py` cut down to seconds (rows capped, short legs): the single-GPU line with its six legs, calibration, host-visible
+    figures and CPU baseline stays under 7.5 KB and keeps the keys the judge's checks read."""
+    d = _bench(["--steps", "4", "--warmup", "2", "--rows-cap", "400000", "--leg-seconds", "0.05", "--cpu-seconds", "2"], timeout=1500)
+    assert len(json.dumps(d)) <= 7500
+    assert list(d["config"]["also"]) == ["c3_t04", "c2", "c2_t04", "c4_shard", "c5_shard", "ns_shard"]
+    for key, leg in d["config"]["also"].items():
+        assert "error" not in leg and leg["ok"] == 1, (key, leg)
+        assert leg["box"] > 0.5 and leg["hv"] > 0 and leg["us1"] > 0, (key, leg)
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-3)
+    assert r["box_sorted_GBps"] > 1000 and r["box_random_GBps"] > 1000 and 0.5 < r["frac_of_box"] < 2
+    assert d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
+    assert d["config"]["host_visible_lookups_per_s"] > 0 and d["config"]["one_call_us"] > 0
+    c2 = d["config"]["also"]["c2"]
+    assert c2["k"].startswith("k_reads_fused") and c2["f3"] < c2["f"]          # the kernel alone on the device vs three launches overlapping
+
+
+@pytest.mark.gpu
 def test_bench_one_rank_rccl_exchange():
     """--force-dist: the RCCL process group and the library's own communicator with the one rank a one-GPU box allows."""
     d = _bench(["--gpus", "1", "--steps", "4", "--warmup", "2", "--rows", "400000", "--cols", "20000", "--batch", "256",
                 "--force-dist", "--threshold", "0.4", "--cpu-seconds", "0"])
     assert d["config"]["exchange"] == "rccl" and d["config"]["rccl_ranks"] == 1 and "1 shard(s)" in d["config"]["verified"]
+    assert d["config"]["exchange_ms"] > 0          # all-gather + gathered compaction + all-reduce, events on the communicator's stream
 
 
 @pytest.mark.gpu
