@@ -737,6 +737,7 @@ static void point_uniq(bigsi_hip_batch *b)
 }
 
 static int pinned_reserve(void **p, size_t *cap, size_t bytes);
+static int export_wait(bigsi_hip_batch *b);
 
 // `deferred`: the offset tables and the sequences are staged in pinned memory the batch owns and go up at the start of the next
 // run, on the stream that run uses -- no copy, no synchronisation here (the one-call and streaming entry points: a call is then
@@ -972,6 +973,7 @@ extern "C" int bigsi_hip_batch_destroy(bigsi_hip_batch *b)
     e = hipStreamSynchronize(b->ix->pre_stream);
     e = hipStreamSynchronize(b->ix->stream);
     if (b->done) e = hipEventSynchronize(b->done);           // a run on one of the read streams
+    if (b->exp_serial && b->exp_stream) e = hipStreamSynchronize(b->exp_stream);      // an export still writing into pin_out
     if (b->gstream && b->g_done) e = hipEventSynchronize(b->g_done);
     (void)e;
     for (DevBuf *d : {&b->uniq, &b->upload, &b->pres_desc, &b->elem_seq_off, &b->pres_in, &b->pres_bits, &b->pres_out, &b->rows_sorted, &b->pos_query, &b->hsh, &b->rep, &b->seqs, &b->d_seq_off, &b->d_pos_off, &b->d_tab_off, &b->tab, &b->first_pos, &b->pos_unique, &b->tmp, &b->rows,
@@ -983,6 +985,8 @@ extern "C" int bigsi_hip_batch_destroy(bigsi_hip_batch *b)
     if (b->job.done) { e = hipEventSynchronize(b->job.done); e = hipEventDestroy(b->job.done); (void)e; }
     if (b->pin_up) { e = hipHostFree(b->pin_up); (void)e; }
     if (b->pin_out) { e = hipHostFree(b->pin_out); (void)e; }
+    if (b->pin_flag) { e = hipHostFree(b->pin_flag); (void)e; }
+    b->exp_count.release();
     if (b->exp_done) { e = hipEventDestroy(b->exp_done); (void)e; }
     if (b->job.h_in) { e = hipHostFree(b->job.h_in); (void)e; }
     if (b->job.h_out) { e = hipHostFree(b->job.h_out); (void)e; }
@@ -1151,8 +1155,17 @@ static hipStream_t k1_stream(const bigsi_hip_index *ix)
 }
 
 // K1 for the whole batch (h may have changed since create: the rows buffer is sized for it here)
-static int run_kmerize(bigsi_hip_batch *b, double threshold, bool force_global = false, bool want_sorted = false, bool *sorted = nullptr)
+struct Preset {              // result words K1 sets for the sliced row-AND launches of a small batch (see k_kmerize_lds)
+    uint64_t *p = nullptr;
+    uint64_t words = 0, value = 0;
+    bool done = false;       // the K1 route taken did it (the others leave it to a memset)
+};
+
+static int run_kmerize(bigsi_hip_batch *b, double threshold, bool force_global = false, bool want_sorted = false, bool *sorted = nullptr,
+                       Preset *preset = nullptr)
 {
+    uint64_t *ps_p = preset ? preset->p : nullptr;
+    const uint64_t ps_words = preset ? preset->words : 0, ps_value = preset ? preset->value : 0;
     bigsi_hip_index *ix = b->ix;
     EventPair ep{};
     hipStream_t ks = k1_stream(ix);
@@ -1189,10 +1202,11 @@ static int run_kmerize(bigsi_hip_batch *b, double threshold, bool force_global =
     hipLaunchKernelGGL((k_kmerize_wave<KF>), dim3(grid), dim3(kBlock), 0, ks, b->seqs.as<char>(), b->d_seq_off.as<uint64_t>(),     \
                        b->d_pos_off.as<uint64_t>(), b->k, ix->h, ix->m, threshold, b->n_seqs, b->first_pos.as<uint32_t>(),                \
                        b->pos_unique.as<uint32_t>(), b->rep.as<uint32_t>(), b->rows.as<uint64_t>(), b->num_kmers.as<uint32_t>(),           \
-                       b->num_unique.as<uint32_t>(), b->min_kmers.as<uint32_t>())
+                       b->num_unique.as<uint32_t>(), b->min_kmers.as<uint32_t>(), ps_p, ps_words, ps_value)
         if (b->k == 31) BIGSI_K1_WAVE(31);
         else BIGSI_K1_WAVE(0);
 #undef BIGSI_K1_WAVE
+        if (preset) preset->done = ps_p != nullptr;
         HIP_TRY(hipGetLastError());
         TRY(ev_end(ix, &ep, ix->ev_km, ks));
         b->run_h = ix->h;
@@ -1226,10 +1240,12 @@ static int run_kmerize(bigsi_hip_batch *b, double threshold, bool force_global =
     hipLaunchKernelGGL((k_kmerize_lds<KF>), dim3(b->n_seqs), dim3(block), lds, ks, b->seqs.as<char>(), b->d_seq_off.as<uint64_t>(), \
                        b->d_pos_off.as<uint64_t>(), b->k, ix->h, ix->m, threshold, tab_cap, tab_mult, hs_cap, sq_bytes, b->first_pos.as<uint32_t>(), b->tmp.as<uint32_t>(), \
                        b->pos_unique.as<uint32_t>(), b->rep.as<uint32_t>(), b->rows.as<uint64_t>(), b->num_kmers.as<uint32_t>(),      \
-                       b->num_unique.as<uint32_t>(), b->min_kmers.as<uint32_t>(), want_sorted ? b->rows_sorted.as<uint64_t>() : (uint64_t *)nullptr)
+                       b->num_unique.as<uint32_t>(), b->min_kmers.as<uint32_t>(), want_sorted ? b->rows_sorted.as<uint64_t>() : (uint64_t *)nullptr, \
+                       ps_p, ps_words, ps_value)
         if (b->k == 31) BIGSI_K1_LDS(31);
         else BIGSI_K1_LDS(0);
 #undef BIGSI_K1_LDS
+        if (preset) preset->done = ps_p != nullptr;
         HIP_TRY(hipGetLastError());
         TRY(ev_end(ix, &ep, ix->ev_km, ks));
         b->run_h = ix->h;
@@ -1369,12 +1385,38 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
     const bool sliceable = !b->ext_counts;
     const bool few = (uint64_t)b->n_seqs * ceil_div(b->wv, 64 * kVec) < 1024 && sliceable;
     const bool want_sorted = sort_rows && b->exact && !few && !(flags & BIGSI_RUN_NO_SORT) && b->total_pos && b->max_pos * ix->h >= (uint64_t)sort_min_rows;
+    // small batches: cut every query's row list into slices so that ~2k wavefronts are in flight (see map_block)
+    static const int slices_env = env_int("BIGSI_HIP_SLICES", 0);
+    uint32_t slices = 1;
+    {
+        const uint64_t waves = (uint64_t)b->n_seqs * ceil_div(b->wv, 64 * kVec);
+        if (slices_env > 0) slices = (uint32_t)slices_env;
+        // (one 1 kbp query on 100 k samples, its slices spread over all XCDs (map_block): exact 35 / 14.7 / 16.6 / 22.9 us at
+        // 16 / 64 / 128 / 256 slices, counting 59 / 31 / 30 / 32 us; beyond that the atomics that combine the slices show)
+        else if (waves < 1024) slices = (uint32_t)std::min<uint64_t>({64, ceil_div(2048, std::max<uint64_t>(waves, 1)), std::max<uint64_t>(b->max_pos / 16, 1)});
+        if (!sliceable) slices = 1;
+        slices = std::max<uint32_t>(slices, 1);
+    }
+    // planes needed for the largest possible count = max k-mers of any sequence in the batch
+    const uint64_t maxu = b->max_pos;
+    const int P = maxu < (1ull << 6) ? 6 : maxu < (1ull << 10) ? 10 : maxu < (1ull << 12) ? 12 : maxu < (1ull << 16) ? 16 : 32;
+    // the sliced launches combine into preset result words (all ones for the AND, zero counters): K1 sets them on its way
+    Preset preset;
+    if (slices > 1 && b->exact) {
+        uint64_t *out = (uint64_t *)b->ext_bitmaps;
+        if (!out) { TRY(b->bitmaps.reserve((size_t)b->n_seqs * b->wv_pad * 8)); out = b->bitmaps.as<uint64_t>(); }
+        preset.p = out; preset.words = b->wv_pad; preset.value = ~0ull;
+    } else if (slices > 1) {
+        const uint32_t cb = P <= 16 ? 2 : 4;
+        TRY(b->counts.reserve((size_t)b->n_seqs * b->wv_pad * 64 * cb));
+        preset.p = b->counts.as<uint64_t>(); preset.words = b->wv_pad * 8 * cb; preset.value = 0;
+    }
     // K1 (its LDS route emits the sorted list itself; the other routes leave that to k_sort_rows below)
     EventPair ep{};
     bool sorted_by_k1 = false;
     if (b->job.done && b->job.device_work) HIP_TRY(hipStreamWaitEvent(k1_stream(ix), b->job.done, 0));      // (as on the read path above)
     TRY(flush_upload(b, k1_stream(ix)));
-    TRY(run_kmerize(b, threshold, (flags & BIGSI_RUN_K1_GLOBAL) != 0, want_sorted, &sorted_by_k1));
+    TRY(run_kmerize(b, threshold, (flags & BIGSI_RUN_K1_GLOBAL) != 0, want_sorted, &sorted_by_k1, &preset));
     b->dirty = true;        // until `done` is recorded at the end
     const uint64_t *k2_rows = sorted_by_k1 ? b->rows_sorted.as<uint64_t>() : b->rows.as<uint64_t>();
     // exact path only: there every row can move freely (+4.7 % C3, +7.6 % C4-shard, interleaved A/B); on the counting path a
@@ -1418,21 +1460,6 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
     const int and_block = mid ? 64 : b->exact ? and_block_env : std::min(and_block_env, 256);
     static const int and_unroll = env_int("BIGSI_HIP_AND_UNROLL", 8);
     const uint32_t tiles = (uint32_t)ceil_div(b->wv, (uint64_t)and_block * kVec);
-    // planes needed for the largest possible count = max k-mers of any sequence in the batch
-    const uint64_t maxu = b->max_pos;
-    const int P = maxu < (1ull << 6) ? 6 : maxu < (1ull << 10) ? 10 : maxu < (1ull << 12) ? 12 : maxu < (1ull << 16) ? 16 : 32;
-    // small batches: cut every query's row list into slices so that ~2k wavefronts are in flight (see map_block)
-    static const int slices_env = env_int("BIGSI_HIP_SLICES", 0);
-    uint32_t slices = 1;
-    {
-        const uint64_t waves = (uint64_t)b->n_seqs * ceil_div(b->wv, 64 * kVec);
-        if (slices_env > 0) slices = (uint32_t)slices_env;
-        // (one 1 kbp query on 100 k samples, its slices spread over all XCDs (map_block): exact 35 / 14.7 / 16.6 / 22.9 us at
-        // 16 / 64 / 128 / 256 slices, counting 59 / 31 / 30 / 32 us; beyond that the atomics that combine the slices show)
-        else if (waves < 1024) slices = (uint32_t)std::min<uint64_t>({64, ceil_div(2048, std::max<uint64_t>(waves, 1)), std::max<uint64_t>(b->max_pos / 16, 1)});
-        if (!sliceable) slices = 1;
-        slices = std::max<uint32_t>(slices, 1);
-    }
     // large exact batches go out as several launches, each a whole number of workgroups per CU (launches of 384 or 640
     // workgroups measured 0.72-0.78 of peak, 512 / 768 / 1024: 0.82-0.85) with about 1600-2000 LIVE wavefronts: all co-resident,
     // sweeping the address-ordered row lists together, and no more bytes in flight than the memory system schedules well --
@@ -1458,7 +1485,7 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
     if (b->exact) {
         uint64_t *out = (uint64_t *)b->ext_bitmaps;
         if (!out) { TRY(b->bitmaps.reserve((size_t)b->n_seqs * b->wv_pad * 8)); out = b->bitmaps.as<uint64_t>(); }
-        if (slices > 1) HIP_TRY(hipMemsetAsync(out, 0xFF, (size_t)b->n_seqs * b->wv_pad * 8, ix->stream));
+        if (slices > 1 && !preset.done) HIP_TRY(hipMemsetAsync(out, 0xFF, (size_t)b->n_seqs * b->wv_pad * 8, ix->stream));
         TRY(ev_begin(ix, &ep, nullptr, true));
         static const int and_nt = env_int("BIGSI_HIP_AND_NT", 1);     // 0: plain loads (A/B against non-temporal)
         for (uint32_t q0 = 0; q0 < b->n_seqs; q0 += chunk_q, n_launches++) {
@@ -1503,7 +1530,7 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
         uint64_t *hb = b->ext_bitmaps ? (uint64_t *)b->ext_bitmaps : b->bitmaps.as<uint64_t>();
         b->sparse_counts = (flags & BIGSI_RUN_SPARSE_COUNTS) && !b->ext_counts && slices == 1;
         const uint32_t sparse = b->sparse_counts ? 1u : 0u;
-        if (slices > 1) HIP_TRY(hipMemsetAsync(out, 0, (size_t)b->n_seqs * cstride * b->count_bytes, ix->stream));
+        if (slices > 1 && !preset.done) HIP_TRY(hipMemsetAsync(out, 0, (size_t)b->n_seqs * cstride * b->count_bytes, ix->stream));
         TRY(ev_begin(ix, &ep, nullptr, true));
         // fewer than ~3 wavefronts per SIMD in the whole grid (e.g. 128 gene-length queries): the software-pipelined loop,
         // whose wavefronts load the next k-mers' rows while adding the current ones (5.6 -> 6.3 TB/s at 128 x 2-4 kbp; with a
@@ -1962,7 +1989,7 @@ static int pinned_reserve(void **p, size_t *cap, size_t bytes)
     if (bytes <= *cap) return BIGSI_OK;
     if (*p) { hipError_t e = hipHostFree(*p); (void)e; *p = nullptr; *cap = 0; }
     const size_t want = std::max<size_t>(bytes + bytes / 4, 4096);
-    HIP_TRY(hipHostMalloc(p, want, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(p, want, hipHostMallocCoherent | hipHostMallocMapped));      // (kernels write results / read small inputs here directly)
     *cap = want;
     return BIGSI_OK;
 }
@@ -2253,7 +2280,7 @@ int bigsi_batch_stage(bigsi_hip_index *ix, bigsi_hip_batch **pb, const char *seq
     } else {
         if (b->elements) return fail(BIGSI_ERR_STATE, "a batch of explicit k-mers cannot be reloaded: create a new one");
         TRY(batch_quiesce(b));                                         // this batch's earlier run ...
-        if (b->exp_done) HIP_TRY(hipEventSynchronize(b->exp_done));    // ... and the export of its results
+        if (b->exp_serial) TRY(export_wait(b));                        // ... and the export of its results
     }
     return batch_load(b, seqs, offsets, n_seqs, k, true);
 }
@@ -2268,13 +2295,51 @@ int bigsi_batch_export(bigsi_hip_batch *b)
     const uint64_t spec = std::min<uint64_t>(std::max<uint64_t>(1024, 2ull * n), std::min<uint64_t>(hb.capacity(), 1u << 20));
     const size_t o_uniq = (n + 2ull) * 8, o_col = o_uniq + ((3ull * n + 1) & ~1ull) * 4, bytes = o_col + 8 * spec;
     TRY(pinned_reserve(&b->pin_out, &b->pin_out_cap, bytes));
-    if (!b->exp_done) HIP_TRY(hipEventCreateWithFlags(&b->exp_done, hipEventDisableTiming));
+    // completion: the kernel's last workgroup writes the export's serial into a pinned word the host spins on (no event record, no
+    // hipEventSynchronize: a 1 kbp query's call is ~57 us, of which an event wait is several).  BIGSI_HIP_EXPORT_FLAG=0 (tuning
+    // builds): the event, as before.
+    static const int use_flag = env_int("BIGSI_HIP_EXPORT_FLAG", 1);
+    if (use_flag && !b->pin_flag) {
+        HIP_TRY(hipHostMalloc((void **)&b->pin_flag, 64, hipHostMallocCoherent | hipHostMallocMapped));
+        *b->pin_flag = 0;
+        TRY(b->exp_count.reserve(256));
+        HIP_TRY(hipMemsetAsync(b->exp_count.p, 0, 256, st));
+    }
+    if (!use_flag && !b->exp_done) HIP_TRY(hipEventCreateWithFlags(&b->exp_done, hipEventDisableTiming));
     b->exp_spec = (uint32_t)spec;
-    const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(std::max<uint64_t>(3ull * n, spec), kBlock), 64);
-    hipLaunchKernelGGL(k_export_results, dim3(grid), dim3(kBlock), 0, st, hb.hit_off.as<uint64_t>(), n, b->fused_run ? 1u : 0u, b->uniq.as<uint32_t>(),
-                       hb.col(), hb.cnt(), (uint32_t)spec, static_cast<uint64_t *>(b->pin_out));
+    b->exp_serial++;
+    b->exp_flagged = use_flag != 0;
+    b->exp_stream = st;
+    // the hits it carries along speculatively are few: one workgroup unless the batch is large (one workgroup needs no counter)
+    const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(std::max<uint64_t>(3ull * n, spec), 4 * kBlock), 64);
+    hipLaunchKernelGGL(k_export_results, dim3(std::max(grid, 1u)), dim3(kBlock), 0, st, hb.hit_off.as<uint64_t>(), n, b->fused_run ? 1u : 0u, b->uniq.as<uint32_t>(),
+                       hb.col(), hb.cnt(), (uint32_t)spec, static_cast<uint64_t *>(b->pin_out), b->exp_count.as<uint32_t>(),
+                       (volatile uint64_t *)(use_flag ? b->pin_flag : nullptr), b->exp_serial);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(b->exp_done, st));
+    if (!use_flag) HIP_TRY(hipEventRecord(b->exp_done, st));
+    return BIGSI_OK;
+}
+
+// host-side wait for the last export of the batch: spin on the pinned flag for a while (a latency-bound call is over in tens of
+// microseconds), then block on the stream (a throughput batch takes milliseconds: no point burning a core)
+static int export_wait(bigsi_hip_batch *b)
+{
+    if (!b->exp_serial) return fail(BIGSI_ERR_STATE, "internal: nothing exported");
+    if (!b->exp_flagged) {
+        HIP_TRY(hipEventSynchronize(b->exp_done));
+        return BIGSI_OK;
+    }
+    volatile uint64_t *f = b->pin_flag;
+    const uint64_t want = b->exp_serial;
+    for (uint32_t spins = 0; *f != want; spins++) {
+        __builtin_ia32_pause();
+        if (spins >= 20000) {                    // ~0.5 ms
+            HIP_TRY(hipStreamSynchronize(b->exp_stream));
+            if (*f != want) return fail(BIGSI_ERR_HIP, "internal: export finished without raising its flag");
+            break;
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
     return BIGSI_OK;
 }
 
@@ -2282,9 +2347,9 @@ int bigsi_batch_export(bigsi_hip_batch *b)
 int bigsi_batch_collect(bigsi_hip_batch *b, uint32_t *num_kmers, uint32_t *num_unique, uint32_t *min_kmers, uint64_t *hit_offsets,
                         uint32_t *colours, uint32_t *counts, uint64_t capacity)
 {
-    if (!b || !b->exp_done) return fail(BIGSI_ERR_STATE, "internal: nothing exported");
+    if (!b) return fail(BIGSI_ERR_STATE, "internal: nothing exported");
     TRY(use_device(b->ix));
-    HIP_TRY(hipEventSynchronize(b->exp_done));
+    TRY(export_wait(b));
     HitBufs &hb = b->hits;
     const uint32_t n = b->n_seqs;
     const uint64_t *off = static_cast<const uint64_t *>(b->pin_out);

@@ -171,7 +171,12 @@ struct bigsi_hip_batch {
     void *pin_up = nullptr, *pin_out = nullptr;
     size_t pin_up_cap = 0, pin_out_cap = 0, pin_up_bytes = 0;
     bool upload_deferred = false;                    // pin_up holds tables + sequences that the next run uploads on its stream
-    hipEvent_t exp_done = nullptr;                   // end of the export kernel
+    hipEvent_t exp_done = nullptr;                   // end of the export kernel (only when the flag below is not used)
+    uint64_t *pin_flag = nullptr;                    // coherent pinned word the export kernel's last workgroup writes exp_serial to
+    uint64_t exp_serial = 0;                         // serial of the last export queued (0: none)
+    bool exp_flagged = false;                        // the last export signals through pin_flag (the host spins on it)
+    hipStream_t exp_stream = nullptr;                // the stream it was queued on
+    DevBuf exp_count;                                // the export kernel's finished-workgroups counter
     uint32_t exp_spec = 0;                           // hits the export carried along speculatively
     PresJob job;                                     // the K5 / K6 request in flight, its host vectors and pinned staging
     DevBuf pres_in, pres_bits, pres_out, pres_desc;   // K5 at scale (presence_hits): host-built pair lists, presence bits, strings, piece marks

@@ -449,9 +449,16 @@ __global__ __launch_bounds__(1024) void k_kmerize_lds(
     uint32_t k, uint32_t h, uint64_t m, double threshold, uint32_t tab_cap, uint32_t tab_mult, uint32_t hs_cap, uint32_t sq_bytes /* multiple of 16 */, uint32_t *__restrict__ first_pos,
     uint32_t *__restrict__ uidx, uint32_t *__restrict__ pos_unique, uint32_t *__restrict__ rep_out, uint64_t *__restrict__ rows,
     uint32_t *__restrict__ num_kmers, uint32_t *__restrict__ num_unique, uint32_t *__restrict__ min_kmers,
-    uint64_t *__restrict__ rows_sorted /* non-null: also emit the query's row list in address order (what k_sort_rows does) */)
+    uint64_t *__restrict__ rows_sorted /* non-null: also emit the query's row list in address order (what k_sort_rows does) */,
+    uint64_t *__restrict__ preset /* non-null: the query's `preset_words` result words are set to preset_value here -- what the sliced
+                                     (latency-bound) row-AND launches combine into with atomics; saves a memset launch per call */,
+    uint64_t preset_words, uint64_t preset_value)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    if (preset) {
+        uint64_t *pq = preset + (uint64_t)blockIdx.x * preset_words;
+        for (uint64_t i = threadIdx.x; i < preset_words; i += blockDim.x) pq[i] = preset_value;
+    }
     uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
     uint32_t *scan = tab + tab_cap + tab_cap / 32 + 4;   // 16 entries (the table is followed by the pad words of the row sort)
     uint32_t *hs = scan + 16;                            // hs[i]: 32-bit hash of the k-mer at position i (hs_cap entries)
@@ -657,11 +664,16 @@ __global__ __launch_bounds__(kBlock) void k_kmerize_wave(
     const char *__restrict__ seqs, const uint64_t *__restrict__ seq_off, const uint64_t *__restrict__ pos_off,
     uint32_t k, uint32_t h, uint64_t m, double threshold, uint32_t n_seqs, uint32_t *__restrict__ first_pos,
     uint32_t *__restrict__ pos_unique, uint32_t *__restrict__ rep_out, uint64_t *__restrict__ rows,
-    uint32_t *__restrict__ num_kmers, uint32_t *__restrict__ num_unique, uint32_t *__restrict__ min_kmers)
+    uint32_t *__restrict__ num_kmers, uint32_t *__restrict__ num_unique, uint32_t *__restrict__ min_kmers,
+    uint64_t *__restrict__ preset, uint64_t preset_words, uint64_t preset_value /* as k_kmerize_lds */)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t q = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     if (q >= n_seqs) return;                       // whole wavefront leaves together
+    if (preset) {
+        uint64_t *pq = preset + (uint64_t)q * preset_words;
+        for (uint64_t i = lane; i < preset_words; i += 64) pq[i] = preset_value;
+    }
     const char *s = seqs + seq_off[q];
     const uint32_t len = (uint32_t)(seq_off[q + 1] - seq_off[q]);
     const uint32_t n = len >= k ? len - k + 1 : 0u;      // <= 64 by the launch condition
@@ -1882,9 +1894,12 @@ __global__ __launch_bounds__(kBlock) void k_score_packed(
 //   [hit_off: n_seqs + 2 uint64 | num_kmers, num_unique, min_kmers: 3 n_seqs uint32 | pad to 8 | colours: spec uint32 | counts: spec uint32]
 // instead of three or four device-to-host copies, each with its own ~10 us of latency and a synchronisation: a call then waits
 // ONCE, for this kernel's event.  Word n_seqs + 1 of hit_off is the mark of a one-launch read run that gave up (0 otherwise).
+// The LAST workgroup to finish then raises a flag word in (coherent) pinned memory, which is what the host spins on: no event
+// record, no hipEventSynchronize -- scripts/probe/latency_probe.hip prices the difference.
 __global__ __launch_bounds__(kBlock) void k_export_results(
     const uint64_t *__restrict__ hit_off, uint32_t n_seqs, uint32_t with_mark, const uint32_t *__restrict__ uniq,
-    const uint32_t *__restrict__ col, const uint32_t *__restrict__ cnt, uint32_t spec, uint64_t *out)
+    const uint32_t *__restrict__ col, const uint32_t *__restrict__ cnt, uint32_t spec, uint64_t *out,
+    uint32_t *__restrict__ done_count /* device word, zero between launches */, volatile uint64_t *flag, uint64_t serial)
 {
     const uint32_t tid = blockIdx.x * kBlock + threadIdx.x, nt = gridDim.x * kBlock;
     const uint64_t total = hit_off[n_seqs];
@@ -1894,6 +1909,16 @@ __global__ __launch_bounds__(kBlock) void k_export_results(
     for (uint32_t i = tid; i < 3u * n_seqs; i += nt) o32[i] = uniq[i];
     uint32_t *ocol = o32 + ((3u * n_seqs + 1u) & ~1u), *ocnt = ocol + spec;
     for (uint32_t i = tid; i < m; i += nt) { ocol[i] = col[i]; ocnt[i] = cnt[i]; }
+    if (!flag) return;
+    __threadfence_system();                     // this thread's stores to host memory are out ...
+    __syncthreads();                            // ... and so are the workgroup's
+    if (threadIdx.x == 0) {
+        if (gridDim.x == 1 || atomicAdd(done_count, 1u) == gridDim.x - 1u) {
+            if (gridDim.x > 1) *done_count = 0;
+            __threadfence_system();
+            *flag = serial;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------ storage contract helpers
@@ -2270,7 +2295,10 @@ __global__ __launch_bounds__(kBlock) void k_probe_ids(uint64_t *__restrict__ ids
 __global__ __launch_bounds__(kBlock) void k_probe_rows(const uint64_t *__restrict__ index, uint64_t stride_words, uint32_t wv, const uint64_t *__restrict__ ids,
                                                        uint32_t rows_per_query, uint32_t segs, uint32_t q0, uint32_t q1, u64x2 *__restrict__ out)
 {
-    const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    // (the wavefront's number is wave-uniform, which the compiler cannot see in threadIdx.x >> 6: without the readfirstlane the row
+    // ids arrive through per-lane vector loads instead of scalar loads -- 6 % of the probe's rate; scripts/probe/row_probe.hip has
+    // that handicap, which is why round 3's "bare kernel" figures sat BELOW k_and_exact)
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6))), lane = threadIdx.x & 63u;
     const uint32_t q = q0 + wave / segs, seg = wave % segs;
     if (q >= q1) return;
     const uint32_t w0 = seg * 128u + lane * kVec;
