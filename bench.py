@@ -224,7 +224,10 @@ ALSO_LEGS = {
         ("c2_t04", "configs[1] at threshold 0.4", ["--workload", "c2", "--threshold", "0.4", "--warmup", "200"], 50000),
         ("c4_shard", "configs[3]: one GPU's shard (1 of 8) of 25M x 500k", ["--workload", "c4", "--shard-of", "8", "--warmup", "10"], 1200),
         ("c5_shard", "configs[4]: that shard at 0.4 with score=True in the step", ["--workload", "c5", "--shard-of", "8", "--warmup", "10"], 1000),
-        ("ns_shard", "north_star 10M x 500k: one GPU's shard (1 of 8)", ["--workload", "northstar", "--shard-of", "8", "--warmup", "10"], 1200)],
+        ("ns_shard", "north_star 10M x 500k: one GPU's shard (1 of 8)", ["--workload", "northstar", "--shard-of", "8", "--warmup", "10"], 1200),
+        # f1, index ingest: a 32 GB snapshot (device layout) written, dropped, loaded back (threads on the file, two pinned buffers,
+        # asynchronous copies), sampled rows verified against the oracle's generator: scripts/ingest_bench.py, keys in GB/s
+        ("ingest", "snapshot of a 32 GB index written / dropped / loaded back", ["--ingest", "32"], 0)],
     2: [("c3_t04", "configs[2] at threshold 0.4 over 2 GPUs", ["--workload", "c3", "--threshold", "0.4"], 32)],
     4: [("northstar", "north_star 10M x 500k, WHOLE index over 4 GPUs", ["--workload", "northstar", "--warmup", "10"], 700),
         ("c3_t04", "configs[2] at threshold 0.4 over 4 GPUs", ["--workload", "c3", "--threshold", "0.4"], 64)],
@@ -274,6 +277,18 @@ def run_also_legs(args, world, rank, ports):
     out = {}
     for (key, what, extra, steps), port in zip(also_legs_for(world), ports):
         n_steps = max(8, int(steps * args.leg_seconds))
+        if extra[0] == "--ingest":
+            gb = float(extra[1]) * min(1.0, args.leg_seconds) if not args.rows_cap else 1.0
+            t0 = time.time()
+            try:
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "ingest_bench.py"), "--gb", str(gb)], capture_output=True, text=True, timeout=LEG_TIMEOUT_S)
+                d = json.loads(r.stdout.strip().splitlines()[-1])
+                out[key] = {"gb": sig(d["gb"], 4), "save_GBps": sig(d["save_GBps"], 4), "load_GBps": sig(d["load_GBps"], 4), "load2_GBps": sig(d["load2_GBps"], 4),
+                            "file_GBps": sig(d["load2_file_GBps"], 4), "pcie_GBps": sig(d.get("pcie_h2d_GBps"), 4), "threads": d["threads"], "dir": d["dir"],
+                            "ok": int(bool(d.get("verified"))), "wall": round(time.time() - t0, 1)}
+            except Exception as e:  # noqa: BLE001
+                out[key] = {"error": ("%s: %s" % (type(e).__name__, e))[:160]}
+            continue
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--cpu-seconds", "0", "--also", "none", "--backend", args.backend,
                "--steps", str(n_steps)] + (["--warmup", "3"] if "--warmup" not in extra else []) + extra
         if args.one_device:
@@ -952,7 +967,7 @@ def main():
                 "clocks": {"before_timed_region": clocks_before, "after_timed_region": clocks_after},
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "traffic_measured_in_run": False,
+                         "traffic": traffic, "traffic_source": traffic_src, "traffic_measured_in_run": False, "pmc_key": wkey,
                          "kernel": "k_reads_fused (K1 + row-AND + K4 in one launch)" if batch.info().one_launch else "k_and_exact" if exact else "k_and_count",
                          "alg_bytes_per_launch": alg_bytes_launch, "kernel_ms": and_ms, "launches_timed": int(stats.and_launches),
                          "kernel_ms_is": "alone on the device: one-stream pass of %d launches after the timed region (events); in the timed region launches overlap"

@@ -53,6 +53,10 @@ class GroupInfo(C.Structure):
                 ("rccl", C.c_uint32)]
 
 
+class IoStats(C.Structure):
+    _fields_ = [("bytes", C.c_uint64), ("seconds", C.c_double), ("file_seconds", C.c_double), ("threads", C.c_uint32), ("direct", C.c_uint32)]
+
+
 class Stats(C.Structure):
     _fields_ = [("and_launches", C.c_uint64), ("and_ms", C.c_double),
                 ("kmerize_launches", C.c_uint64), ("kmerize_ms", C.c_double),
@@ -81,6 +85,8 @@ SIGNATURES = {
     "bigsi_hip_set_rows": (_i32, [_P, _P, _u64, _P, _u64]),
     "bigsi_hip_get_rows": (_i32, [_P, _P, _u64, _P, _u64]),
     "bigsi_hip_clear": (_i32, [_P]),
+    "bigsi_hip_load_rows_file": (_i32, [_P, C.c_char_p, _u64, _u64, _u64, _u64, _u32, C.POINTER(IoStats)]),
+    "bigsi_hip_save_rows_file": (_i32, [_P, C.c_char_p, _u64, _u64, _u64, _u64, _u32, C.POINTER(IoStats)]),
     "bigsi_hip_insert_column": (_i32, [_P, _u64, _P]),
     "bigsi_hip_get_column": (_i32, [_P, _u64, _P]),
     "bigsi_hip_insert_columns": (_i32, [_P, _u64, _u64, _P, _u64]),

@@ -2,13 +2,20 @@
 // Plain HIP runtime (hipMalloc / streams / events); no torch types anywhere in this library.
 #include "bigsi_internal.hpp"
 
+#include <fcntl.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <atomic>
+#include <cerrno>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "bigsi_kernels.hpp"
@@ -303,6 +310,7 @@ extern "C" int bigsi_hip_synchronize(bigsi_hip_index *ix)
 
 // ------------------------------------------------------------------------------ storage contract
 static const uint64_t kStageBytes = 64ull << 20;
+static const uint64_t kIoChunkBytes = 256ull << 20;      // one pinned buffer of the file <-> HBM pipeline
 
 extern "C" int bigsi_hip_set_rows(bigsi_hip_index *ix, const uint64_t *row_ids, uint64_t n, const uint8_t *bytes, uint64_t row_bytes)
 {
@@ -349,6 +357,150 @@ extern "C" int bigsi_hip_get_rows(bigsi_hip_index *ix, const uint64_t *row_ids, 
         HIP_TRY(hipStreamSynchronize(ix->stream));
     }
     return BIGSI_OK;
+}
+
+// ------------------------------------------------------------------------------ bulk ingest: file <-> HBM
+// The reference loads an index by opening a BerkeleyDB file (bigsi/storage/berkeleydb.py:6-19) and pays a page lookup + two copies
+// per row at query time; here the rows go to HBM once, at the rate the file system and PCIe allow: the file range is read by
+// `threads` host threads (pread, one slice each) into one of two pinned buffers while the other one is in flight to the device
+// (hipMemcpyAsync; rows whose file length is not the device pitch take one scatter kernel on the way).
+namespace {
+struct IoJob {
+    int fd = -1;
+    bool write = false;
+    std::atomic<int> err{0};
+};
+
+// read / write [off, off + len) of the file into / from buf with up to `threads` threads; returns 0 or errno
+int file_io(int fd, bool write, uint8_t *buf, uint64_t off, uint64_t len, unsigned threads)
+{
+    threads = std::max(1u, std::min<unsigned>(threads, (unsigned)ceil_div(std::max<uint64_t>(len, 1), 4ull << 20)));
+    std::atomic<int> err{0};
+    auto work = [&](uint64_t a, uint64_t b) {
+        while (a < b && !err.load()) {
+            const ssize_t r = write ? pwrite(fd, buf + (a - off), (size_t)std::min<uint64_t>(b - a, 1ull << 30), (off_t)a)
+                                    : pread(fd, buf + (a - off), (size_t)std::min<uint64_t>(b - a, 1ull << 30), (off_t)a);
+            if (r < 0) { if (errno == EINTR) continue; err.store(errno); return; }
+            if (r == 0) { err.store(write ? EIO : ENODATA); return; }      // short file
+            a += (uint64_t)r;
+        }
+    };
+    if (threads == 1) { work(off, off + len); return err.load(); }
+    std::vector<std::thread> pool;
+    const uint64_t per = round_up(ceil_div(len, threads), 1ull << 20);
+    for (unsigned t = 0; t < threads; t++) {
+        const uint64_t a = off + std::min<uint64_t>((uint64_t)t * per, len), b = off + std::min<uint64_t>((uint64_t)(t + 1) * per, len);
+        if (a < b) pool.emplace_back(work, a, b);
+    }
+    for (auto &th : pool) th.join();
+    return err.load();
+}
+
+int rows_file(bigsi_hip_index *ix, const char *path, uint64_t file_offset, uint64_t row0, uint64_t n_rows, uint64_t row_bytes, uint32_t threads,
+              bool save, bigsi_hip_io_stats *st)
+{
+    if (!ix || !path) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    const uint64_t stride = ix->stride_words * 8;
+    if (row_bytes == 0 || (!save && row_bytes > stride))
+        return fail(BIGSI_ERR_CAPACITY, "row_bytes %llu not in [1, %llu] (row stride)", (unsigned long long)row_bytes, (unsigned long long)stride);
+    if (row0 > ix->m || n_rows > ix->m - row0) return fail(BIGSI_ERR_RANGE, "rows [%llu, +%llu) outside [0, %llu)", (unsigned long long)row0, (unsigned long long)n_rows, (unsigned long long)ix->m);
+    if (threads == 0) threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency() / 4));
+    TRY(use_device(ix));
+    TRY(quiesce_index(ix));
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    const int fd = open(path, save ? (O_WRONLY | O_CREAT) : O_RDONLY, 0644);
+    if (fd < 0) return fail(BIGSI_ERR_INVALID, "%s: %s", path, strerror(errno));
+    const bool direct = row_bytes == stride;                         // the file holds the device layout: no kernel on the way
+    const uint64_t per = std::max<uint64_t>(1, kIoChunkBytes / row_bytes);
+    void *pin[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    DevBuf dev[2];
+    int rc = BIGSI_OK;
+    const auto t_begin = std::chrono::steady_clock::now();
+    double io_s = 0;
+    auto body = [&]() -> int {
+        for (int i = 0; i < 2; i++) {
+            HIP_TRY(hipHostMalloc(&pin[i], std::min(per, std::max<uint64_t>(n_rows, 1)) * row_bytes, hipHostMallocDefault));
+            HIP_TRY(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+            if (!direct) TRY(dev[i].reserve(std::min(per, std::max<uint64_t>(n_rows, 1)) * row_bytes));
+        }
+        uint8_t *base = reinterpret_cast<uint8_t *>(ix->d_index);
+        const uint64_t n_chunks = ceil_div(n_rows, per);
+        // load:  read(c) | H2D(c) in flight while read(c+1) runs;   save:  D2H(c+1) in flight while write(c) runs
+        for (uint64_t c = 0; c < n_chunks + (save ? 1 : 0); c++) {
+            const int slot = (int)(c & 1);
+            const uint64_t r0 = row0 + c * per, cn = c < n_chunks ? std::min(per, row0 + n_rows - r0) : 0;
+            if (save) {
+                if (c < n_chunks) {                                      // queue the download of chunk c
+                    if (direct) HIP_TRY(hipMemcpyAsync(pin[slot], base + r0 * stride, cn * row_bytes, hipMemcpyDeviceToHost, ix->stream));
+                    else {
+                        hipLaunchKernelGGL(k_gather_run, dim3((unsigned)cn), dim3(kBlock), 0, ix->stream, base, stride, r0, dev[slot].as<uint8_t>(), row_bytes);
+                        HIP_TRY(hipGetLastError());
+                        HIP_TRY(hipMemcpyAsync(pin[slot], dev[slot].p, cn * row_bytes, hipMemcpyDeviceToHost, ix->stream));
+                    }
+                    HIP_TRY(hipEventRecord(ev[slot], ix->stream));
+                }
+                if (c > 0) {                                             // write chunk c - 1 while it comes down
+                    const int ps = (int)((c - 1) & 1);
+                    const uint64_t pr0 = row0 + (c - 1) * per, pn = std::min(per, row0 + n_rows - pr0);
+                    HIP_TRY(hipEventSynchronize(ev[ps]));
+                    const auto t0 = std::chrono::steady_clock::now();
+                    const int e = file_io(fd, true, static_cast<uint8_t *>(pin[ps]), file_offset + (pr0 - row0) * row_bytes, pn * row_bytes, threads);
+                    io_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                    if (e) return fail(BIGSI_ERR_INVALID, "writing %s: %s", path, strerror(e));
+                }
+            } else {
+                HIP_TRY(hipEventSynchronize(ev[slot]));                  // (never recorded: returns at once) the copy that last used this buffer
+                const auto t0 = std::chrono::steady_clock::now();
+                const int e = file_io(fd, false, static_cast<uint8_t *>(pin[slot]), file_offset + (r0 - row0) * row_bytes, cn * row_bytes, threads);
+                io_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                if (e) return fail(BIGSI_ERR_INVALID, "reading %s: %s", path, e == ENODATA ? "file too short" : strerror(e));
+                if (direct) HIP_TRY(hipMemcpyAsync(base + r0 * stride, pin[slot], cn * row_bytes, hipMemcpyHostToDevice, ix->stream));
+                else {
+                    HIP_TRY(hipMemcpyAsync(dev[slot].p, pin[slot], cn * row_bytes, hipMemcpyHostToDevice, ix->stream));
+                    hipLaunchKernelGGL(k_scatter_run, dim3((unsigned)cn), dim3(kBlock), 0, ix->stream, base, stride, r0, dev[slot].as<uint8_t>(), row_bytes);
+                    HIP_TRY(hipGetLastError());
+                }
+                HIP_TRY(hipEventRecord(ev[slot], ix->stream));
+            }
+        }
+        HIP_TRY(hipStreamSynchronize(ix->stream));
+        return BIGSI_OK;
+    };
+    rc = body();
+    char keep[1024];
+    if (rc != BIGSI_OK) snprintf(keep, sizeof keep, "%s", bigsi_hip_last_error());
+    hipError_t e = hipStreamSynchronize(ix->stream);
+    for (int i = 0; i < 2; i++) {
+        if (pin[i]) e = hipHostFree(pin[i]);
+        if (ev[i]) e = hipEventDestroy(ev[i]);
+        dev[i].release();
+    }
+    (void)e;
+    if (save && rc == BIGSI_OK && fsync(fd) != 0 && errno != EINVAL && errno != EROFS) rc = fail(BIGSI_ERR_INVALID, "fsync %s: %s", path, strerror(errno));
+    close(fd);
+    if (rc != BIGSI_OK) return fail(rc, "%s", rc == BIGSI_ERR_INVALID && bigsi_hip_last_error()[0] ? (keep[0] ? keep : bigsi_hip_last_error()) : keep);
+    if (st) {
+        st->bytes = n_rows * row_bytes;
+        st->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+        st->file_seconds = io_s;
+        st->threads = threads;
+        st->direct = direct ? 1u : 0u;
+    }
+    return BIGSI_OK;
+}
+}   // namespace
+
+extern "C" int bigsi_hip_load_rows_file(bigsi_hip_index *ix, const char *path, uint64_t file_offset, uint64_t row0, uint64_t n_rows, uint64_t row_bytes,
+                                        uint32_t threads, bigsi_hip_io_stats *stats)
+{
+    return rows_file(ix, path, file_offset, row0, n_rows, row_bytes, threads, false, stats);
+}
+
+extern "C" int bigsi_hip_save_rows_file(bigsi_hip_index *ix, const char *path, uint64_t file_offset, uint64_t row0, uint64_t n_rows, uint64_t row_bytes,
+                                        uint32_t threads, bigsi_hip_io_stats *stats)
+{
+    return rows_file(ix, path, file_offset, row0, n_rows, row_bytes, threads, true, stats);
 }
 
 extern "C" int bigsi_hip_clear(bigsi_hip_index *ix)

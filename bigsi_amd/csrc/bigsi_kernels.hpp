@@ -1921,6 +1921,23 @@ __global__ __launch_bounds__(kBlock) void k_export_results(
     }
 }
 
+// ------------------------------------------------------------------------------ bulk ingest helpers
+// n CONSECUTIVE rows [row0, row0 + n) of rb bytes each, packed, to / from the matrix (file <-> HBM: bigsi_hip_load_rows_file /
+// save_rows_file when the file's row length is not the device pitch): one workgroup per row, 16-byte lanes where alignment allows.
+__global__ __launch_bounds__(kBlock) void k_scatter_run(uint8_t *__restrict__ index, uint64_t stride_bytes, uint64_t row0, const uint8_t *__restrict__ packed, uint64_t rb)
+{
+    uint8_t *dst = index + (row0 + blockIdx.x) * stride_bytes;
+    const uint8_t *src = packed + (uint64_t)blockIdx.x * rb;
+    for (uint64_t b = threadIdx.x; b < stride_bytes; b += kBlock) dst[b] = b < rb ? src[b] : (uint8_t)0;
+}
+
+__global__ __launch_bounds__(kBlock) void k_gather_run(const uint8_t *__restrict__ index, uint64_t stride_bytes, uint64_t row0, uint8_t *__restrict__ packed, uint64_t rb)
+{
+    const uint8_t *src = index + (row0 + blockIdx.x) * stride_bytes;
+    uint8_t *dst = packed + (uint64_t)blockIdx.x * rb;
+    for (uint64_t b = threadIdx.x; b < rb; b += kBlock) dst[b] = b < stride_bytes ? src[b] : (uint8_t)0;
+}
+
 // ------------------------------------------------------------------------------ storage contract helpers
 // scatter n packed rows (rb bytes each) to rows row_ids[i]; bytes [rb, stride) of the row are zeroed.
 __global__ __launch_bounds__(kBlock) void k_scatter_rows(

@@ -251,7 +251,7 @@ class HipHbmStorage(BaseStorage):
             res = _RESIDENT[self.name] = _Resident(self.storage_config)
             fn = self.storage_config.get("filename")
             if fn and os.path.exists(fn):
-                _load_snapshot(res, fn)
+                _load_snapshot(res, fn, int(self.storage_config.get("io_threads", 0)))
         self.res = res
         self.storage = self       # reference convention: backend.storage[key] (base.py:13-21); routed below
 
@@ -320,9 +320,24 @@ class HipHbmStorage(BaseStorage):
     def sync(self):
         fn = self.storage_config.get("filename")
         if fn:
-            _save_snapshot(self.res, fn)
+            _save_snapshot(self.res, fn, int(self.storage_config.get("io_threads", 0)))
         if self.res.ix is not None:
             check(self.res.fn("synchronize")(self.res.ix))
+
+    def save_snapshot(self, filename, threads=0):
+        """Write the resident index to `filename` in the device layout (what sync() does for storage-config `filename`); returns
+        the I/O statistics of the matrix part (_lib.IoStats: bytes, seconds, file_seconds, threads)."""
+        return _save_snapshot(self.res, filename, threads)
+
+    @staticmethod
+    def load_snapshot(storage_config, filename, threads=0):
+        """A storage object whose index is loaded from `filename` now (whatever is resident under the config's name is dropped
+        first); returns (storage, I/O statistics)."""
+        cfg = dict(storage_config, replace=True)
+        cfg.pop("filename", None)
+        st = HipHbmStorage(cfg)
+        stats = _load_snapshot(st.res, filename, threads)
+        return st, stats
 
     def close(self):
         self.res = None      # the resident index stays (see module docstring)
@@ -732,7 +747,47 @@ class ElementBatch(QueryBatch):
 
 
 # ------------------------------------------------------------------------------- snapshots (sync / reopen)
-def _save_snapshot(res, fn):
+# Version 2 (written): the DEVICE layout -- [magic | header length | JSON header (host records, geometry) | written bitmap, raw |
+# per-row lengths, raw, if any | zero padding to a 4096-byte boundary | m rows of row_stride_bytes each], so that save and load are
+# bigsi_hip_save_rows_file / bigsi_hip_load_rows_file: threads on the file, two pinned buffers, asynchronous copies, no kernel
+# and no Python in the data path.  Version 1 (rows at ceil(num_cols / 8) bytes, hex bitmap in the header, 64 MB synchronous
+# blocks) is still read.
+_MAGIC2 = b"BIGSIHBM2\n"
+_ALIGN = 4096
+
+
+def _save_snapshot(res, fn, threads=0):
+    """Returns the I/O statistics of the matrix part (None for an index without a matrix)."""
+    header = {"kv": {k.decode("latin-1"): v.decode("latin-1") for k, v in res.kv.items()}, "m": res.m, "stride": 0}
+    tmp = fn + ".tmp"
+    stats = None
+    with open(tmp, "wb") as f:
+        extra = b""
+        if res.ix is not None:
+            if res.is_group:
+                return _save_snapshot_v1(res, fn)
+            inf = res.info()
+            header.update(stride=int(inf.row_stride_bytes), num_cols=int(inf.num_cols), uniform_len=res.uniform_len,
+                          written_bytes=(res.m + 7) // 8, rowlen_bytes=0 if res.rowlen is None else int(res.rowlen.nbytes),
+                          all_written=bool(res.written.all()))
+            if not header["all_written"]:
+                extra += np.packbits(res.written).tobytes()
+            else:
+                header["written_bytes"] = 0
+            if res.rowlen is not None:
+                extra += res.rowlen.tobytes()
+        hb = json.dumps(header).encode("utf-8")
+        head = _MAGIC2 + struct.pack("<Q", len(hb)) + hb + extra
+        data_off = -(-len(head) // _ALIGN) * _ALIGN
+        f.write(head + b"\0" * (data_off - len(head)))
+    if res.ix is not None:
+        stats = _lib.IoStats()
+        check(_lib.lib().bigsi_hip_save_rows_file(res.ix, tmp.encode(), data_off, 0, res.m, header["stride"], int(threads), _lib.C.byref(stats)))
+    os.replace(tmp, fn)
+    return stats
+
+
+def _save_snapshot_v1(res, fn):
     header = {"kv": {k.decode("latin-1"): v.decode("latin-1") for k, v in res.kv.items()},
               "m": res.m, "rb": 0}
     tmp = fn + ".tmp"
@@ -753,11 +808,35 @@ def _save_snapshot(res, fn):
                 check(res.fn("get_rows")(res.ix, _lib.ptr(ids), ids.size, _lib.ptr(out), rb))
                 f.write(out.tobytes())
     os.replace(tmp, fn)
+    return None
 
 
-def _load_snapshot(res, fn):
+def _load_snapshot(res, fn, threads=0):
     with open(fn, "rb") as f:
-        if f.read(len(_MAGIC)) != _MAGIC:
+        magic = f.read(len(_MAGIC))
+        if magic == _MAGIC2:
+            (n,) = struct.unpack("<Q", f.read(8))
+            header = json.loads(f.read(n).decode("utf-8"))
+            res.kv = {k.encode("latin-1"): v.encode("latin-1") for k, v in header["kv"].items()}
+            if not (header.get("m") and header.get("stride")):
+                return None
+            m, stride = int(header["m"]), int(header["stride"])
+            wb, lb = int(header.get("written_bytes", 0)), int(header.get("rowlen_bytes", 0))
+            written = np.unpackbits(np.frombuffer(f.read(wb), np.uint8))[:m].astype(bool) if wb else None
+            rowlen = np.frombuffer(f.read(lb), np.uint32).copy() if lb else None
+            data_off = -(-f.tell() // _ALIGN) * _ALIGN
+            if res.is_group:
+                raise BigsiHipError(_lib.ERR_STATE, "%s is a single-device snapshot; a multi-GPU index loads per-shard files" % fn)
+            res.open(m, int(header.get("num_cols", 0)), cap=stride * 8)
+            have = int(res.info().row_stride_bytes)
+            if have < stride:
+                raise BigsiHipError(_lib.ERR_CAPACITY, "%s holds rows of %d bytes, the index was opened with a pitch of %d" % (fn, stride, have))
+            stats = _lib.IoStats()
+            check(_lib.lib().bigsi_hip_load_rows_file(res.ix, fn.encode(), data_off, 0, m, stride, int(threads), _lib.C.byref(stats)))
+            res.written = written if written is not None else np.ones(m, dtype=bool)
+            res.uniform_len, res.rowlen = header.get("uniform_len"), rowlen
+            return stats
+        if magic != _MAGIC:
             raise BigsiHipError(_lib.ERR_INVALID, "%s is not a hip-hbm snapshot" % fn)
         (n,) = struct.unpack("<Q", f.read(8))
         header = json.loads(f.read(n).decode("utf-8"))
@@ -766,13 +845,17 @@ def _load_snapshot(res, fn):
             m, rb = int(header["m"]), int(header["rb"])
             n_cols = int(res.kv.get(b"number_of_cols:int", b"0"))
             res.open(m, n_cols, cap=rb * 8)
-            step = max(1, (64 << 20) // rb)
-            for r0 in range(0, m, step):
-                cnt = min(m, r0 + step) - r0
-                blob = np.frombuffer(f.read(cnt * rb), dtype=np.uint8).reshape(cnt, rb)
-                ids = np.arange(r0, r0 + cnt, dtype=np.uint64)
-                check(res.fn("set_rows")(res.ix, _lib.ptr(ids), cnt, _lib.ptr(np.ascontiguousarray(blob)), rb))
+            if res.is_group:
+                step = max(1, (64 << 20) // rb)
+                for r0 in range(0, m, step):
+                    cnt = min(m, r0 + step) - r0
+                    blob = np.frombuffer(f.read(cnt * rb), dtype=np.uint8).reshape(cnt, rb)
+                    ids = np.arange(r0, r0 + cnt, dtype=np.uint64)
+                    check(res.fn("set_rows")(res.ix, _lib.ptr(ids), cnt, _lib.ptr(np.ascontiguousarray(blob)), rb))
+            else:       # (an old file still loads at the new rate: rows of rb bytes go through the scatter kernel)
+                check(_lib.lib().bigsi_hip_load_rows_file(res.ix, fn.encode(), f.tell(), 0, m, rb, int(threads), None))
             res.written = np.unpackbits(np.frombuffer(bytes.fromhex(header["written"]), np.uint8))[:m].astype(bool)
             res.uniform_len = header.get("uniform_len")
             if header.get("rowlen"):
                 res.rowlen = np.frombuffer(bytes.fromhex(header["rowlen"]), np.uint32).copy()
+    return None

@@ -96,6 +96,25 @@ int bigsi_hip_set_rows(bigsi_hip_index *ix, const uint64_t *row_ids, uint64_t n,
 int bigsi_hip_get_rows(bigsi_hip_index *ix, const uint64_t *row_ids, uint64_t n, uint8_t *out, uint64_t row_bytes);
 int bigsi_hip_clear(bigsi_hip_index *ix); /* delete_all (bigsi/storage/base.py:132-133): all rows zero */
 
+/* Bulk ingest: n_rows consecutive rows [row0, row0 + n_rows), row_bytes bytes each, packed back to back in a file from file_offset on,
+ * straight between the file and HBM.  Replaces, for a whole index, the record-at-a-time traffic of opening / filling a KV store
+ * (BerkeleyDBStorage, bigsi/storage/berkeleydb.py:6-19; KmerSignatureIndex.create -> BitMatrix.create -> set_rows one batch_set per
+ * row block, bigsi/graph/index.py:27-40, bigsi/matrix/bitmatrix.py:19-25; the build command's loop, bigsi/cmds/build.py:43-73).
+ * `threads` host threads (0 = a quarter of the cores, at most 16) pread / pwrite slices of a 256 MB pinned buffer while the other
+ * buffer is in flight over PCIe (hipMemcpyAsync); with row_bytes == row_stride_bytes (the hip-hbm snapshot layout) the bytes
+ * go to their place without a kernel, otherwise through one scatter / gather kernel per buffer.  Synchronous for the caller. */
+typedef struct {
+    uint64_t bytes;        /* n_rows * row_bytes                                     */
+    double seconds;        /* wall time of the call (open .. last byte on the device / fsync) */
+    double file_seconds;   /* of which inside pread / pwrite (the file system's share; the rest overlaps or is PCIe) */
+    uint32_t threads;      /* host threads used for the file                          */
+    uint32_t direct;       /* 1: row_bytes == the device pitch, no kernel on the way  */
+} bigsi_hip_io_stats;
+int bigsi_hip_load_rows_file(bigsi_hip_index *ix, const char *path, uint64_t file_offset, uint64_t row0, uint64_t n_rows, uint64_t row_bytes,
+                             uint32_t threads, bigsi_hip_io_stats *stats /* may be NULL */);
+int bigsi_hip_save_rows_file(bigsi_hip_index *ix, const char *path, uint64_t file_offset, uint64_t row0, uint64_t n_rows, uint64_t row_bytes,
+                             uint32_t threads, bigsi_hip_io_stats *stats /* may be NULL */);
+
 /* BitMatrix.insert_column (bigsi/matrix/bitmatrix.py:67-75) / BaseStorage.set_bits (bigsi/storage/base.py:111-122):
  * bloom = one sample's Bloom filter, ceil(num_rows/8) bytes in the row format above (bit r = row r);
  * writes bit `col` of every row.  col may equal num_cols (append; num_cols grows by one). */

@@ -1,0 +1,113 @@
+"""Index ingest at a measured rate (bench.py's `ingest` leg): write a snapshot of a synthetic index in the
+device layout, drop the index, load the file back, verify sampled rows against the oracle's generator.  One JSON line.
+
+    python scripts/ingest_bench.py [--gb 32] [--cols 100000] [--dir /dev/shm] [--threads 0]
+
+What bounds it: the file system (here page cache / tmpfs: memcpy-speed preads by `threads` host threads) and PCIe (pinned
+buffers, hipMemcpyAsync); both are reported next to the rate: `file_GBps` = bytes / time inside pread or pwrite, `pcie_GBps` = a
+plain pinned-to-device copy of one 256 MB buffer on this box."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+SEED = 20260928
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gb", type=float, default=32.0, help="size of the matrix to write and load back")
+    p.add_argument("--cols", type=int, default=100_000)
+    p.add_argument("--hashes", type=int, default=4)
+    p.add_argument("--dir", default=None, help="where the snapshot goes (default: /dev/shm if it has room, else the system temp dir)")
+    p.add_argument("--threads", type=int, default=0)
+    p.add_argument("--sample-rows", type=int, default=64)
+    a = p.parse_args()
+    import tempfile
+    from bigsi_amd import _lib
+    from bigsi_amd.storage import get_storage
+    from bigsi_amd.storage.hip_hbm import HipHbmStorage
+    from oracle.ref_model import SynthOracle
+
+    words = -(-a.cols // 64)
+    stride = max(16, -(-words // 16) * 16) * 8                       # the library's row pitch: 128-byte multiples
+    m = int(a.gb * 1e9 // stride)
+    need = m * stride
+    d = a.dir
+    if d is None:
+        d = tempfile.gettempdir()
+        for cand in ("/dev/shm", tempfile.gettempdir()):
+            try:
+                sv = os.statvfs(cand)
+                if sv.f_bavail * sv.f_frsize > need * 1.25 + (8 << 30):
+                    d = cand
+                    break
+            except OSError:
+                pass
+    sv = os.statvfs(d)
+    free = sv.f_bavail * sv.f_frsize
+    if free < need * 1.1 + (2 << 30):
+        m = int(max((free - (2 << 30)) / 1.1, 1 << 30) // stride)      # never fill the file system of a shared box
+        need = m * stride
+    fn = os.path.join(d, "bigsi_ingest_bench_%d.hbm" % os.getpid())
+    cfg = {"storage-engine": "hip-hbm", "k": 31, "m": m, "h": a.hashes, "storage-config": {"name": "ingest", "max_cols": a.cols}}
+    st = get_storage(cfg)
+    st.delete_all()
+    for key, v in (("number_of_rows", m), ("number_of_cols", a.cols), ("ksi:bloomfilter_size", m), ("ksi:num_hashes", a.hashes)):
+        st.set_integer(key, v)
+    st.fill_synthetic(SEED, 0, 2)
+    out = {"what": "snapshot (device layout) of a synthetic %d-row x %d-sample index written, index dropped, file loaded back" % (m, a.cols),
+           "gb": need / 1e9, "dir": d, "fs_free_gb_before": free / 1e9}
+    try:
+        t0 = time.perf_counter()
+        s_ = st.save_snapshot(fn, a.threads)
+        out.update(save_s=time.perf_counter() - t0, save_GBps=s_.bytes / s_.seconds / 1e9, save_file_GBps=s_.bytes / max(s_.file_seconds, 1e-9) / 1e9, threads=int(s_.threads))
+        st.delete_all()
+        t0 = time.perf_counter()
+        st2, l_ = HipHbmStorage.load_snapshot(cfg["storage-config"], fn, a.threads)
+        out.update(load_s=time.perf_counter() - t0, load_GBps=l_.bytes / l_.seconds / 1e9, load_file_GBps=l_.bytes / max(l_.file_seconds, 1e-9) / 1e9,
+                   direct=int(l_.direct))
+        # a second load: the file is certainly in the page cache now
+        st2.delete_all()
+        t0 = time.perf_counter()
+        st2, l2 = HipHbmStorage.load_snapshot(cfg["storage-config"], fn, a.threads)
+        out.update(load2_GBps=l2.bytes / l2.seconds / 1e9, load2_file_GBps=l2.bytes / max(l2.file_seconds, 1e-9) / 1e9)
+        # verification: sampled rows of the loaded index == the generator's (and the four integers came back)
+        orc = SynthOracle(SEED, 0, m, a.cols, a.hashes, 31, 2)
+        rng = np.random.default_rng(5)
+        rows = np.unique(np.concatenate([[0, m - 1], rng.integers(0, m, size=a.sample_rows)])).astype(np.uint64)
+        got = st2.get_rows_packed(rows)
+        want = np.stack([orc.row(int(r)) for r in rows])
+        assert np.array_equal(np.asarray(got), want), "loaded rows differ from the generator"
+        assert st2.get_integer("number_of_cols") == a.cols and st2.get_integer("number_of_rows") == m
+        out["verified"] = "%d sampled rows of the loaded index == the oracle's generator" % rows.size
+        # the PCIe bound of this box: one pinned 256 MB buffer, host -> device, plain hipMemcpy through torch
+        try:
+            import torch
+            h = torch.empty(256 << 20, dtype=torch.uint8).pin_memory()
+            dv = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+            dv.copy_(h, non_blocking=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(8):
+                dv.copy_(h, non_blocking=True)
+            torch.cuda.synchronize()
+            out["pcie_h2d_GBps"] = 8 * (256 << 20) / (time.perf_counter() - t0) / 1e9
+        except Exception as e:  # noqa: BLE001
+            out["pcie_h2d_GBps"] = None
+            out["pcie_note"] = str(e)[:80]
+        st2.delete_all()
+    finally:
+        for f in (fn, fn + ".tmp"):
+            if os.path.exists(f):
+                os.remove(f)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -2,6 +2,7 @@
 unmodified reference (tests/golden) and the CPU oracle (oracle/) on seeded inputs.  Bit-exact for everything
 integer / byte / index; float score fields as stated in conftest.py.  Needs a real MI355X: `pytest -m gpu`."""
 import itertools
+import json
 import math
 import os
 
@@ -287,6 +288,81 @@ def test_snapshot_roundtrip(hip, tmp_path):
     b2 = hip.BIGSI(c)
     assert rows_hex(b2) == rows and b2.search("ATACACAAT", 1.0) == want
     b2.delete()
+
+
+def test_snapshot_v2_is_the_device_layout_and_round_trips(hip, tmp_path):
+    """sync() writes the device layout (rows at the device pitch behind a 4096-byte aligned header, bitmap of written rows raw) through
+    bigsi_hip_save_rows_file; a fresh process' open goes through bigsi_hip_load_rows_file.  Rows never stored stay KeyErrors, rows
+    stored shorter keep their length, and a version-1 file (rows at ceil(N/8) bytes, hex bitmap) still loads."""
+    import struct
+    from bigsi_amd.storage import get_storage, hip_hbm
+    fn = str(tmp_path / "v2.hbm")
+    c = cfg(31, 5003, 3, filename=fn, max_cols=300, name="snapv2")
+    st = get_storage(c)
+    st.delete_all()
+    st.set_integer("number_of_rows", 5003)
+    st.set_integer("number_of_cols", 300)
+    rng = np.random.default_rng(11)
+    ids = np.sort(rng.choice(5003, size=3000, replace=False)).astype(np.uint64)
+    rows = rng.integers(0, 256, size=(3000, 38), dtype=np.uint8)
+    rows[:, 37] &= 0xF0                                   # 300 columns: 4 pad bits
+    st.res.put_rows(ids, rows)
+    st.res.put_rows([int(ids[5])], [bytes(rows[5, :20])])            # one row stored shorter
+    st.sync()
+    raw = open(fn, "rb").read()
+    assert raw.startswith(b"BIGSIHBM2\n")
+    (hl,) = struct.unpack("<Q", raw[10:18])
+    header = json.loads(raw[18:18 + hl])
+    assert header["stride"] == 128 and header["m"] == 5003 and not header["all_written"]
+    data_off = len(raw) - 5003 * 128
+    assert data_off % 4096 == 0 and raw[data_off + int(ids[0]) * 128: data_off + int(ids[0]) * 128 + 38] == rows[0].tobytes()
+    hip_hbm._RESIDENT.pop("snapv2").free()
+    st2 = get_storage(c)
+    got = st2.get_rows_packed(ids[:5], 38)
+    assert np.array_equal(np.asarray(got), rows[:5])
+    assert st2.get_bitarray(int(ids[5])).tobytes() == bytes(rows[5, :20])
+    missing = sorted(set(range(5003)) - set(ids.tolist()))[0]
+    with pytest.raises(KeyError):
+        st2.get_bitarray(missing)
+    # version 1 of the same index still loads (through the scatter route: its rows are 38 bytes, not 128)
+    fn1 = str(tmp_path / "v1.hbm")
+    hip_hbm._save_snapshot_v1(st2.res, fn1)
+    st2.delete_all()
+    c1 = cfg(31, 5003, 3, filename=fn1, max_cols=300, name="snapv1")
+    st3 = get_storage(c1)
+    assert np.array_equal(np.asarray(st3.get_rows_packed(ids[7:60], 38)), rows[7:60])
+    st3.delete_all()
+
+
+def test_rows_file_io_with_any_row_length(hip, tmp_path):
+    """bigsi_hip_save_rows_file / load_rows_file: a row range at the device pitch (no kernel on the way) and at the reference's row length
+    (gather / scatter kernels), several pinned buffers' worth, written by one index and read back by another."""
+    from bigsi_amd import _lib
+    from bigsi_amd.storage import get_storage
+    m, n_cols = 70001, 40000
+    _, a = synth_index(hip, m, n_cols, 3, 99)
+    ref_rows = np.asarray(a.get_rows_packed(np.arange(0, m, 997, dtype=np.uint64)))
+    stride, rb = int(a.res.info().row_stride_bytes), int(a.res.info().row_bytes)
+    for row_bytes, r0, n in ((stride, 0, m), (rb, 1000, 60000)):
+        fn = str(tmp_path / ("rows_%d.bin" % row_bytes))
+        st = _lib.IoStats()
+        _lib.check(_lib.lib().bigsi_hip_save_rows_file(a.handle, fn.encode(), 4096, r0, n, row_bytes, 3, _lib.C.byref(st)))
+        assert st.bytes == n * row_bytes and os.path.getsize(fn) == 4096 + n * row_bytes and st.direct == int(row_bytes == stride)
+        c = cfg(31, m, 3, max_cols=n_cols, name="rowsfile%d" % row_bytes)
+        b = get_storage(c)
+        b.delete_all()
+        b.set_integer("number_of_rows", m)
+        b.set_integer("number_of_cols", n_cols)
+        _lib.check(_lib.lib().bigsi_hip_load_rows_file(b.handle, fn.encode(), 4096, r0, n, row_bytes, 2, None))
+        b.res.written[:] = True
+        sel = np.arange(0, m, 997, dtype=np.uint64)
+        inside = (sel >= r0) & (sel < r0 + n)
+        got = np.asarray(b.get_rows_packed(sel))
+        assert np.array_equal(got[inside], ref_rows[inside]) and not got[~inside].any()
+        rc = _lib.lib().bigsi_hip_load_rows_file(b.handle, fn.encode(), 4096, r0, n + 1, row_bytes, 2, None)
+        assert rc == _lib.ERR_INVALID and b"too short" in _lib.lib().bigsi_hip_last_error()
+        b.delete_all()
+    a.delete_all()
 
 
 # --------------------------------------------------------------------------------------------- synthetic index vs oracle

@@ -96,9 +96,12 @@ def test_bench_default_line_fits_the_drivers_tail():
     figures and CPU baseline stays under 7.5 KB and keeps the keys the judge's checks read."""
     d = _bench(["--steps", "4", "--warmup", "2", "--rows-cap", "400000", "--leg-seconds", "0.05", "--cpu-seconds", "2"], timeout=1500)
     assert len(json.dumps(d)) <= 7500
-    assert list(d["config"]["also"]) == ["c3_t04", "c2", "c2_t04", "c4_shard", "c5_shard", "ns_shard"]
+    assert list(d["config"]["also"]) == ["c3_t04", "c2", "c2_t04", "c4_shard", "c5_shard", "ns_shard", "ingest"]
     for key, leg in d["config"]["also"].items():
         assert "error" not in leg and leg["ok"] == 1, (key, leg)
+        if key == "ingest":
+            assert leg["load_GBps"] > 1 and leg["save_GBps"] > 0.5 and leg["gb"] > 0.5, leg
+            continue
         assert leg["box"] > 0.5 and leg["hv"] > 0 and leg["us1"] > 0, (key, leg)
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-3)
