@@ -45,6 +45,8 @@ extern "C" int bigsi_hip_device_count(int *out)
 
 int bigsi_use_device(const bigsi_hip_index *ix)
 {
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur == ix->device) return BIGSI_OK;      // (a thread-local read: every entry point comes through here)
     HIP_TRY(hipSetDevice(ix->device));
     return BIGSI_OK;
 }
@@ -310,6 +312,7 @@ extern "C" int bigsi_hip_synchronize(bigsi_hip_index *ix)
 
 // ------------------------------------------------------------------------------ storage contract
 static const uint64_t kStageBytes = 64ull << 20;
+static const uint64_t kZeroCopyBytes = 256ull << 10;     // inputs of a one-call search up to this size are read by K1 from pinned memory
 static const uint64_t kIoChunkBytes = 256ull << 20;      // one pinned buffer of the file <-> HBM pipeline
 
 extern "C" int bigsi_hip_set_rows(bigsi_hip_index *ix, const uint64_t *row_ids, uint64_t n, const uint8_t *bytes, uint64_t row_bytes)
@@ -899,6 +902,7 @@ static int batch_load(bigsi_hip_batch *b, const char *seqs, const uint64_t *offs
 {
     bigsi_hip_index *ix = b->ix;
     b->upload_deferred = false;
+    b->zero_copy = false;
     const uint64_t base = offsets[0], nbytes = offsets[n_seqs] - base;
     b->n_seqs = n_seqs;
     b->k = k;
@@ -980,12 +984,14 @@ static int batch_load(bigsi_hip_batch *b, const char *seqs, const uint64_t *offs
 // `done`, gathered compaction on the gather stream)
 static int batch_quiesce(bigsi_hip_batch *b)
 {
+    if (b->idle) return BIGSI_OK;      // its last export was collected and nothing has been queued since
+    if (b->done_stale && !b->dirty && b->run_stream) HIP_TRY(hipStreamSynchronize(b->run_stream));
     if (b->dirty) {
         HIP_TRY(hipStreamSynchronize(b->ix->pre_stream));
         HIP_TRY(hipStreamSynchronize(b->ix->stream));
         TRY(quiesce_reads(b->ix));
         b->dirty = false;
-    } else if (b->done) {
+    } else if (b->done && !b->done_stale) {
         HIP_TRY(hipEventSynchronize(b->done));
     }
     if (b->g_done) HIP_TRY(hipEventSynchronize(b->g_done));
@@ -1244,6 +1250,27 @@ extern "C" int bigsi_hip_debug_phases(bigsi_hip_index *ix, uint64_t *out, uint32
 }
 #endif
 
+// Where K1 reads a load's tables and sequences.  Normally the device copies (create / reload / a flushed deferred load).  A one-call
+// search whose input is small reads them straight from the pinned staging (zero copy: scripts/probe/latency_probe.hip prices a 64 KB
+// hipMemcpyAsync ahead of a kernel at 23 us against 9.5 us of direct reads) and writes the device copy of pos_off -- all the later
+// kernels need of them -- on its way.
+struct K1Src {
+    const char *seqs;
+    const uint64_t *seq_off, *pos_off;
+    uint64_t *pos_off_out;
+};
+
+static K1Src k1_src(const bigsi_hip_batch *b)
+{
+    if (b->zero_copy) {
+        const uint8_t *h = static_cast<const uint8_t *>(b->pin_up);
+        const size_t ob = (b->n_seqs + 1) * 8ull;
+        return K1Src{reinterpret_cast<const char *>(h + 3 * ob), reinterpret_cast<const uint64_t *>(h), reinterpret_cast<const uint64_t *>(h + ob),
+                     b->d_pos_off.as<uint64_t>()};
+    }
+    return K1Src{b->seqs.as<char>(), b->d_seq_off.as<uint64_t>(), b->d_pos_off.as<uint64_t>(), nullptr};
+}
+
 static int launch_reads_fused(bigsi_hip_batch *b, hipStream_t st = nullptr, uint64_t spin_timeout = kSpinTimeout)
 {
     const uint32_t fp_mask = b->weak_fp ? 1u : ~0u;
@@ -1275,12 +1302,13 @@ static int launch_reads_fused(bigsi_hip_batch *b, hipStream_t st = nullptr, uint
         HIP_TRY(hipMemsetAsync(hb.hit_off.p, 0, hb.hit_off.cap, st));
         hb.gen = 1;
     }
+    const K1Src src = k1_src(b);
 #define BIGSI_READS_ARGS                                                                                                          \
     dim3(b->n_seqs), dim3(kBlock), 0, st, ix->d_index, ix->stride_words, (uint32_t)b->wv, ix->n_cols, ix->m, b->threshold,              \
-        b->seqs.as<char>(), b->d_seq_off.as<uint64_t>(), b->d_pos_off.as<uint64_t>(), b->n_seqs, b->first_pos.as<uint32_t>(),         \
+        src.seqs, src.seq_off, src.pos_off, b->n_seqs, b->first_pos.as<uint32_t>(),                                                       \
         b->pos_unique.as<uint32_t>(), b->rep.as<uint32_t>(), b->rows.as<uint64_t>(), b->num_kmers.as<uint32_t>(),                      \
         b->num_unique.as<uint32_t>(), b->min_kmers.as<uint32_t>(), b->bitmaps.as<uint64_t>(), b->wv_pad, hb.lb_state.as<uint64_t>(),  \
-        hb.gen, hb.hit_off.as<uint64_t>(), hb.col(), hb.cnt(), hb.capacity(), fp_mask, spin_timeout
+        hb.gen, hb.hit_off.as<uint64_t>(), hb.col(), hb.cnt(), hb.capacity(), fp_mask, spin_timeout, src.pos_off_out
 #define COMMA ,
 #define BIGSI_READS(H)                                                                              \
     if (b->exact) hipLaunchKernelGGL((k_reads_fused<H COMMA true>), BIGSI_READS_ARGS);                \
@@ -1304,6 +1332,34 @@ static hipStream_t k1_stream(const bigsi_hip_index *ix)
 {
     static const int overlap = env_int("BIGSI_HIP_K1_OVERLAP", 0);
     return overlap ? ix->pre_stream : ix->stream;
+}
+
+enum K1Route { K1_ELEMENTS, K1_WAVE, K1_LDS, K1_GLOBAL };
+struct K1Plan {
+    K1Route route;
+    uint32_t hs_cap = 0, sq_bytes = 0, tab_mult = 4, tab_cap = 2;
+    size_t lds = 0;
+};
+
+static K1Plan k1_plan(const bigsi_hip_batch *b, bool force_global)
+{
+    K1Plan p;
+    static const int k1_global = env_int("BIGSI_HIP_K1_GLOBAL", 0);
+    static const int k1_wave = env_int("BIGSI_HIP_K1_WAVE", 1);
+    if (b->elements) { p.route = K1_ELEMENTS; return p; }
+    if (!force_global && !k1_global && k1_wave && b->max_pos <= 64) { p.route = K1_WAVE; return p; }
+    // dedupe table of the LDS route: 4 slots per position when that fits the LDS window (shorter probe chains), else 2
+    p.hs_cap = (uint32_t)round_up(std::max<uint64_t>(b->max_pos, 1), 4);
+    p.sq_bytes = (uint32_t)round_up(b->max_len + 16, 16);
+    for (;; p.tab_mult = 2) {
+        p.tab_cap = 2;
+        while (p.tab_cap < p.tab_mult * b->max_pos && p.tab_cap < (1u << 30)) p.tab_cap <<= 1;
+        p.lds = (size_t)(p.tab_cap + p.tab_cap / 32 + 4) * 4 + 64 + (size_t)p.hs_cap * 4 + 2 * p.sq_bytes;      // table (+ sort pad) | scan | fingerprints | sequence | its complement
+        if (p.lds <= 60 * 1024 || p.tab_mult == 2) break;
+    }
+    // fused single-launch K1 (dedupe table + sequence in LDS) when every query fits the default 64 KiB dynamic-LDS window
+    p.route = (!force_global && !k1_global && b->max_pos <= kLdsMaxPos && p.lds <= 60 * 1024) ? K1_LDS : K1_GLOBAL;
+    return p;
 }
 
 // K1 for the whole batch (h may have changed since create: the rows buffer is sized for it here)
@@ -1334,7 +1390,9 @@ static int run_kmerize(bigsi_hip_batch *b, double threshold, bool force_global =
     // (on the index stream itself the callers' own ordering applies, as for every other entry point)
     if (b->g_done && b->gstream && b->gstream != ks) HIP_TRY(hipStreamWaitEvent(ks, b->g_done, 0));
     TRY(b->rows.reserve(std::max<uint64_t>(b->total_pos, 1) * ix->h * 8));
-    if (b->elements) {       // explicit k-mers: only the hashing is left of K1
+    const K1Plan plan = k1_plan(b, force_global);
+    const K1Src src = k1_src(b);
+    if (plan.route == K1_ELEMENTS) {       // explicit k-mers: only the hashing is left of K1
         TRY(ev_begin(ix, &ep, ks));
         hipLaunchKernelGGL(k_rows_raw, dim3(b->n_seqs), dim3(kBlock), 0, ks, b->seqs.as<char>(), b->d_seq_off.as<uint64_t>(), b->elem_seq_off.as<uint64_t>(),
                            b->d_pos_off.as<uint64_t>(), ix->h, ix->m, threshold, b->rows.as<uint64_t>(), b->num_kmers.as<uint32_t>(),
@@ -1344,17 +1402,15 @@ static int run_kmerize(bigsi_hip_batch *b, double threshold, bool force_global =
         b->run_h = ix->h;
         return BIGSI_OK;
     }
-    static const int k1_global = env_int("BIGSI_HIP_K1_GLOBAL", 0);
-    static const int k1_wave = env_int("BIGSI_HIP_K1_WAVE", 1);
-    if (!force_global && !k1_global && k1_wave && b->max_pos <= 64) {
+    if (plan.route == K1_WAVE) {
         // probe / read-length queries: one wavefront per query, no LDS, no atomics
         TRY(ev_begin(ix, &ep, ks));
         const unsigned grid = (unsigned)ceil_div(b->n_seqs, kBlock / 64);
 #define BIGSI_K1_WAVE(KF)                                                                                                      \
-    hipLaunchKernelGGL((k_kmerize_wave<KF>), dim3(grid), dim3(kBlock), 0, ks, b->seqs.as<char>(), b->d_seq_off.as<uint64_t>(),     \
-                       b->d_pos_off.as<uint64_t>(), b->k, ix->h, ix->m, threshold, b->n_seqs, b->first_pos.as<uint32_t>(),                \
+    hipLaunchKernelGGL((k_kmerize_wave<KF>), dim3(grid), dim3(kBlock), 0, ks, src.seqs, src.seq_off,                               \
+                       src.pos_off, b->k, ix->h, ix->m, threshold, b->n_seqs, b->first_pos.as<uint32_t>(),                               \
                        b->pos_unique.as<uint32_t>(), b->rep.as<uint32_t>(), b->rows.as<uint64_t>(), b->num_kmers.as<uint32_t>(),           \
-                       b->num_unique.as<uint32_t>(), b->min_kmers.as<uint32_t>(), ps_p, ps_words, ps_value)
+                       b->num_unique.as<uint32_t>(), b->min_kmers.as<uint32_t>(), ps_p, ps_words, ps_value, src.pos_off_out)
         if (b->k == 31) BIGSI_K1_WAVE(31);
         else BIGSI_K1_WAVE(0);
 #undef BIGSI_K1_WAVE
@@ -1364,19 +1420,9 @@ static int run_kmerize(bigsi_hip_batch *b, double threshold, bool force_global =
         b->run_h = ix->h;
         return BIGSI_OK;
     }
-    // dedupe table of the LDS route: 4 slots per position when that fits the LDS window (shorter probe chains), else 2
-    const uint32_t hs_cap = (uint32_t)round_up(std::max<uint64_t>(b->max_pos, 1), 4);
-    const uint32_t sq_bytes = (uint32_t)round_up(b->max_len + 16, 16);
-    uint32_t tab_mult = 4, tab_cap = 2;
-    size_t lds = 0;
-    for (;; tab_mult = 2) {
-        tab_cap = 2;
-        while (tab_cap < tab_mult * b->max_pos && tab_cap < (1u << 30)) tab_cap <<= 1;
-        lds = (size_t)(tab_cap + tab_cap / 32 + 4) * 4 + 64 + (size_t)hs_cap * 4 + 2 * sq_bytes;      // table (+ sort pad) | scan | fingerprints | sequence | its complement
-        if (lds <= 60 * 1024 || tab_mult == 2) break;
-    }
-    // fused single-launch K1 (dedupe table + sequence in LDS) when every query fits the default 64 KiB dynamic-LDS window
-    if (!force_global && !k1_global && b->max_pos <= kLdsMaxPos && lds <= 60 * 1024) {
+    const uint32_t hs_cap = plan.hs_cap, sq_bytes = plan.sq_bytes, tab_mult = plan.tab_mult, tab_cap = plan.tab_cap;
+    const size_t lds = plan.lds;
+    if (plan.route == K1_LDS) {
         // one thread per position for small batches (latency); once there are several queries per CU anyway, smaller
         // workgroups that loop over the positions let more queries overlap their barrier-separated phases
         static const int k1_block_env = env_int("BIGSI_HIP_K1_BLOCK", 0);
@@ -1389,11 +1435,11 @@ static int run_kmerize(bigsi_hip_batch *b, double threshold, bool force_global =
         }
         TRY(ev_begin(ix, &ep, ks));
 #define BIGSI_K1_LDS(KF)                                                                                                        \
-    hipLaunchKernelGGL((k_kmerize_lds<KF>), dim3(b->n_seqs), dim3(block), lds, ks, b->seqs.as<char>(), b->d_seq_off.as<uint64_t>(), \
-                       b->d_pos_off.as<uint64_t>(), b->k, ix->h, ix->m, threshold, tab_cap, tab_mult, hs_cap, sq_bytes, b->first_pos.as<uint32_t>(), b->tmp.as<uint32_t>(), \
+    hipLaunchKernelGGL((k_kmerize_lds<KF>), dim3(b->n_seqs), dim3(block), lds, ks, src.seqs, src.seq_off,                         \
+                       src.pos_off, b->k, ix->h, ix->m, threshold, tab_cap, tab_mult, hs_cap, sq_bytes, b->first_pos.as<uint32_t>(), b->tmp.as<uint32_t>(), \
                        b->pos_unique.as<uint32_t>(), b->rep.as<uint32_t>(), b->rows.as<uint64_t>(), b->num_kmers.as<uint32_t>(),      \
                        b->num_unique.as<uint32_t>(), b->min_kmers.as<uint32_t>(), want_sorted ? b->rows_sorted.as<uint64_t>() : (uint64_t *)nullptr, \
-                       ps_p, ps_words, ps_value)
+                       ps_p, ps_words, ps_value, src.pos_off_out)
         if (b->k == 31) BIGSI_K1_LDS(31);
         else BIGSI_K1_LDS(0);
 #undef BIGSI_K1_LDS
@@ -1461,15 +1507,21 @@ static int k1_publish(bigsi_hip_batch *b)
 }
 
 // a deferred load (batch_load): the staged tables and sequences go up now, ahead of this run's first kernel on its stream
-static int flush_upload(bigsi_hip_batch *b, hipStream_t st)
+static int flush_upload(bigsi_hip_batch *b, hipStream_t st, bool k1_reads_host = false)
 {
     if (!b->upload_deferred) return BIGSI_OK;
-    HIP_TRY(hipMemcpyAsync(b->upload.p, b->pin_up, b->pin_up_bytes, hipMemcpyHostToDevice, st));
+    // a one-call search with a small input: this run's K1 (one of the single-launch routes) reads pin_up itself
+    static const int zc_env = env_int("BIGSI_HIP_ZERO_COPY", 1);
+    b->zero_copy = zc_env && k1_reads_host && b->one_call && b->pin_up_bytes <= kZeroCopyBytes;
+    if (!b->zero_copy) HIP_TRY(hipMemcpyAsync(b->upload.p, b->pin_up, b->pin_up_bytes, hipMemcpyHostToDevice, st));
     b->upload_deferred = false;
     return BIGSI_OK;
 }
 
-extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_t flags)
+// `one_call`: the caller is bigsi_hip_search_batch, which waits for this run through the export's flag on the same stream: the
+// completion event is not recorded (one HIP call less on a path whose device work is a few microseconds); everything that would
+// wait for it waits for the stream instead (done_stale).
+int bigsi_batch_run(bigsi_hip_batch *b, double threshold, uint32_t flags, bool one_call)
 {
     if (!b) return fail(BIGSI_ERR_INVALID, "NULL batch");
     if (!(threshold <= 1.0)) return fail(BIGSI_ERR_INVALID, "threshold must be <= 1 (bigsi/graph/bigsi.py:176), got %g", threshold);
@@ -1477,6 +1529,8 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
     // (a shard of a wider index may be empty: its result vectors, result_cols wide, are then all zero)
     if (ix->n_cols == 0 && b->result_cols == 0) return fail(BIGSI_ERR_STATE, "index has no columns");
     TRY(use_device(ix));
+    const bool was_idle = b->idle;      // nothing of this batch in flight (collected since its last run): no waits to queue
+    b->idle = false;
     b->ran = false;
     b->host_counts_valid = false;
     b->run_serial++;
@@ -1500,11 +1554,14 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
         else if (ix->rd_pending) TRY(quiesce_reads(ix));      // (alone on the device: nothing of the read streams beside it)
         // (the compaction kernel of a gene-length batch waits between workgroups too: such a run is over before read kernels start)
         if (ix->main_ev && st != ix->stream) HIP_TRY(hipStreamWaitEvent(st, ix->main_ev, 0));
-        if (b->done && b->run_stream != st) HIP_TRY(hipStreamWaitEvent(st, b->done, 0));      // this batch's previous run
-        if (b->g_done && b->gstream && b->gstream != st) HIP_TRY(hipStreamWaitEvent(st, b->g_done, 0));
-        // a K5 / K6 request of this batch still in flight on another stream reads what K1 is about to rewrite
-        if (b->job.done && b->job.device_work) HIP_TRY(hipStreamWaitEvent(st, b->job.done, 0));
-        TRY(flush_upload(b, st));
+        if (!was_idle) {
+            if (b->done_stale && b->run_stream && b->run_stream != st) HIP_TRY(hipStreamSynchronize(b->run_stream));
+            else if (b->done && b->run_stream != st) HIP_TRY(hipStreamWaitEvent(st, b->done, 0));      // this batch's previous run
+            if (b->g_done && b->gstream && b->gstream != st) HIP_TRY(hipStreamWaitEvent(st, b->g_done, 0));
+            // a K5 / K6 request of this batch still in flight on another stream reads what K1 is about to rewrite
+            if (b->job.done && b->job.device_work) HIP_TRY(hipStreamWaitEvent(st, b->job.done, 0));
+        }
+        TRY(flush_upload(b, st, true));
         TRY(ev_begin(ix, &fe, st, true));
         b->weak_fp = (flags & BIGSI_RUN_WEAK_FINGERPRINT) != 0;
         TRY(launch_reads_fused(b, st, (flags & BIGSI_RUN_NO_WAITING) ? 0 : kSpinTimeout));
@@ -1514,8 +1571,11 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
         b->count_bytes = 2;
         b->sparse_counts = !b->exact;
         b->compacted = true;
-        if (!b->done) HIP_TRY(hipEventCreateWithFlags(&b->done, hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(b->done, st));
+        b->done_stale = one_call;
+        if (!one_call) {
+            if (!b->done) HIP_TRY(hipEventCreateWithFlags(&b->done, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(b->done, st));
+        }
         b->run_stream = st;
         b->ran = true;
         b->dirty = false;
@@ -1566,8 +1626,12 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
     // K1 (its LDS route emits the sorted list itself; the other routes leave that to k_sort_rows below)
     EventPair ep{};
     bool sorted_by_k1 = false;
-    if (b->job.done && b->job.device_work) HIP_TRY(hipStreamWaitEvent(k1_stream(ix), b->job.done, 0));      // (as on the read path above)
-    TRY(flush_upload(b, k1_stream(ix)));
+    if (!was_idle && b->job.done && b->job.device_work) HIP_TRY(hipStreamWaitEvent(k1_stream(ix), b->job.done, 0));      // (as on the read path above)
+    if (!was_idle && b->done_stale && b->run_stream && b->run_stream != ix->stream) HIP_TRY(hipStreamSynchronize(b->run_stream));      // (a read run of this workspace)
+    {
+        const K1Route route = k1_plan(b, (flags & BIGSI_RUN_K1_GLOBAL) != 0).route;
+        TRY(flush_upload(b, k1_stream(ix), route == K1_WAVE || route == K1_LDS));
+    }
     TRY(run_kmerize(b, threshold, (flags & BIGSI_RUN_K1_GLOBAL) != 0, want_sorted, &sorted_by_k1, &preset));
     b->dirty = true;        // until `done` is recorded at the end
     const uint64_t *k2_rows = sorted_by_k1 ? b->rows_sorted.as<uint64_t>() : b->rows.as<uint64_t>();
@@ -1710,6 +1774,7 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
 
     b->compacted = !(flags & BIGSI_RUN_SKIP_COMPACT);
     if (!b->done) HIP_TRY(hipEventCreateWithFlags(&b->done, hipEventDisableTiming));
+    b->done_stale = false;
     if (!b->compacted) {
         HIP_TRY(hipEventRecord(b->done, ix->stream));
         TRY(mark_main(ix));
@@ -1722,12 +1787,15 @@ extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_
     const void *src = b->exact ? (b->ext_bitmaps ? b->ext_bitmaps : b->bitmaps.p) : (b->ext_counts ? b->ext_counts : b->counts.p);
     TRY(compact(b, b->hits, src, 1, ix->n_cols, false));
     TRY(ev_end(ix, &ep, ix->ev_cp));
-    HIP_TRY(hipEventRecord(b->done, ix->stream));
+    b->done_stale = one_call;
+    if (!one_call) HIP_TRY(hipEventRecord(b->done, ix->stream));
     TRY(mark_main(ix));
     b->ran = true;
     b->dirty = false;
     return BIGSI_OK;
 }
+
+extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_t flags) { return bigsi_batch_run(b, threshold, flags, false); }
 
 // three compaction passes over [shard][seq][stride]; write_only re-runs just the write pass (after growing buffers).
 // `from_counts`: src is a counter buffer gathered from several shards -> threshold while compacting (k_hits_count);
@@ -1884,7 +1952,9 @@ static int need_run(bigsi_hip_batch *b)
     if (!b) return fail(BIGSI_ERR_INVALID, "NULL batch");
     if (!b->ran) return fail(BIGSI_ERR_STATE, "bigsi_hip_batch_run has not completed for this batch");
     TRY(use_device(b->ix));
-    if (b->done) HIP_TRY(hipEventSynchronize(b->done));      // this batch's kernels; later batches may still be running
+    if (b->idle) return BIGSI_OK;
+    if (b->done_stale && b->run_stream) HIP_TRY(hipStreamSynchronize(b->run_stream));
+    else if (b->done) HIP_TRY(hipEventSynchronize(b->done));      // this batch's kernels; later batches may still be running
     return BIGSI_OK;
 }
 
@@ -2260,6 +2330,7 @@ static int presence_begin(bigsi_hip_batch *b, const uint64_t *hit_offsets, const
     uint2 *d_listed = reinterpret_cast<uint2 *>(b->pres_desc.as<uint8_t>() + round_up(max_pieces * 4, 256));
     uint32_t *d_listed_n = reinterpret_cast<uint32_t *>(b->pres_desc.as<uint8_t>() + round_up(max_pieces * 4, 256) + max_pieces * 8);
     if (!job.done) HIP_TRY(hipEventCreateWithFlags(&job.done, hipEventDisableTiming));
+    b->idle = false;
     if (ps == ix->sc_stream) ix->sc_pending = true;      // from here on something of this index may be queued there
     HIP_TRY(hipMemcpyAsync(b->pres_in.p, stage, in_bytes, hipMemcpyHostToDevice, ps));
     const uint8_t *din = b->pres_in.as<uint8_t>();
@@ -2514,6 +2585,7 @@ int bigsi_batch_collect(bigsi_hip_batch *b, uint32_t *num_kmers, uint32_t *num_u
         return bigsi_hip_batch_fetch_hits(b, hit_offsets, colours, counts, capacity);
     }
     if (b->fused_run) b->fused_settled = true;
+    b->idle = !b->job.pending;          // the export ran behind everything the run queued on its stream
     const uint32_t *u32 = reinterpret_cast<const uint32_t *>(off + n + 2);
     b->h_uniq.assign(u32, u32 + 3ull * n);
     b->h_num_kmers.assign(u32, u32 + n);

@@ -171,6 +171,10 @@ struct bigsi_hip_batch {
     void *pin_up = nullptr, *pin_out = nullptr;
     size_t pin_up_cap = 0, pin_out_cap = 0, pin_up_bytes = 0;
     bool upload_deferred = false;                    // pin_up holds tables + sequences that the next run uploads on its stream
+    bool one_call = false;                           // the index's bigsi_hip_search_batch workspace: nothing else ever touches it
+    bool zero_copy = false;                          // this load's tables + sequences are read by K1 straight from pin_up (no upload)
+    bool idle = false;                               // nothing of this batch is in flight (its last export was collected)
+    bool done_stale = false;                         // the last run did not record `done` (one-call route): wait on its stream instead
     hipEvent_t exp_done = nullptr;                   // end of the export kernel (only when the flag below is not used)
     uint64_t *pin_flag = nullptr;                    // coherent pinned word the export kernel's last workgroup writes exp_serial to
     uint64_t exp_serial = 0;                         // serial of the last export queued (0: none)
@@ -222,6 +226,7 @@ struct bigsi_hip_batch {
 // one-call / streaming searches: stage a load without copying (created on first use: *pb may be NULL), queue the export of a
 // run's results into pinned memory, wait for it and hand the results out
 int bigsi_batch_stage(bigsi_hip_index *ix, bigsi_hip_batch **pb, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k);
+int bigsi_batch_run(bigsi_hip_batch *b, double threshold, uint32_t flags, bool one_call);
 int bigsi_batch_export(bigsi_hip_batch *b);
 int bigsi_batch_collect(bigsi_hip_batch *b, uint32_t *num_kmers, uint32_t *num_unique, uint32_t *min_kmers, uint64_t *hit_offsets,
                         uint32_t *colours, uint32_t *counts, uint64_t capacity);

@@ -452,9 +452,15 @@ __global__ __launch_bounds__(1024) void k_kmerize_lds(
     uint64_t *__restrict__ rows_sorted /* non-null: also emit the query's row list in address order (what k_sort_rows does) */,
     uint64_t *__restrict__ preset /* non-null: the query's `preset_words` result words are set to preset_value here -- what the sliced
                                      (latency-bound) row-AND launches combine into with atomics; saves a memset launch per call */,
-    uint64_t preset_words, uint64_t preset_value)
+    uint64_t preset_words, uint64_t preset_value,
+    uint64_t *__restrict__ pos_off_out /* non-null: seqs / seq_off / pos_off are read straight from pinned host memory (a one-call
+                                          search: no upload); the device copy of pos_off the later kernels read is written here */)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    if (pos_off_out && threadIdx.x == 0) {
+        pos_off_out[blockIdx.x] = pos_off[blockIdx.x];
+        if (blockIdx.x + 1 == gridDim.x) pos_off_out[gridDim.x] = pos_off[gridDim.x];
+    }
     if (preset) {
         uint64_t *pq = preset + (uint64_t)blockIdx.x * preset_words;
         for (uint64_t i = threadIdx.x; i < preset_words; i += blockDim.x) pq[i] = preset_value;
@@ -665,11 +671,15 @@ __global__ __launch_bounds__(kBlock) void k_kmerize_wave(
     uint32_t k, uint32_t h, uint64_t m, double threshold, uint32_t n_seqs, uint32_t *__restrict__ first_pos,
     uint32_t *__restrict__ pos_unique, uint32_t *__restrict__ rep_out, uint64_t *__restrict__ rows,
     uint32_t *__restrict__ num_kmers, uint32_t *__restrict__ num_unique, uint32_t *__restrict__ min_kmers,
-    uint64_t *__restrict__ preset, uint64_t preset_words, uint64_t preset_value /* as k_kmerize_lds */)
+    uint64_t *__restrict__ preset, uint64_t preset_words, uint64_t preset_value, uint64_t *__restrict__ pos_off_out /* as k_kmerize_lds */)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t q = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     if (q >= n_seqs) return;                       // whole wavefront leaves together
+    if (pos_off_out && lane == 0) {
+        pos_off_out[q] = pos_off[q];
+        if (q + 1 == n_seqs) pos_off_out[n_seqs] = pos_off[n_seqs];
+    }
     if (preset) {
         uint64_t *pq = preset + (uint64_t)q * preset_words;
         for (uint64_t i = lane; i < preset_words; i += 64) pq[i] = preset_value;
@@ -1181,9 +1191,14 @@ __global__ __launch_bounds__(kBlock) void k_reads_fused(
     uint32_t *__restrict__ num_kmers, uint32_t *__restrict__ num_unique, uint32_t *__restrict__ min_kmers,
     uint64_t *__restrict__ out_bits, uint64_t out_stride_words,
     uint64_t *__restrict__ state, uint32_t gen, uint64_t *__restrict__ hit_off, uint32_t *__restrict__ hit_col, uint32_t *__restrict__ hit_cnt,
-    uint64_t capacity, uint32_t fp_mask /* ~0; 1 = BIGSI_RUN_WEAK_FINGERPRINT */, uint64_t spin_timeout /* in 10 ns ticks */)
+    uint64_t capacity, uint32_t fp_mask /* ~0; 1 = BIGSI_RUN_WEAK_FINGERPRINT */, uint64_t spin_timeout /* in 10 ns ticks */,
+    uint64_t *__restrict__ pos_off_out /* as k_kmerize_lds: inputs come straight from pinned host memory */)
 {
     constexpr int KF = 31, P = 6;
+    if (pos_off_out && threadIdx.x == 0) {
+        pos_off_out[blockIdx.x] = pos_off[blockIdx.x];
+        if (blockIdx.x + 1 == n_seqs) pos_off_out[n_seqs] = pos_off[n_seqs];
+    }
     __shared__ uint64_t s_rows[64 * H], s_hrow[64 * H];   // row ids: of the unique k-mers / of every position, per seed
     __shared__ uint32_t s_seq[24], s_cmp[25];             // the query's bytes (63 positions + 30 = 93 at most); their complements
     __shared__ uint8_t s_first[64];                       // position of the j-th unique k-mer

@@ -359,8 +359,9 @@ def test_rows_file_io_with_any_row_length(hip, tmp_path):
         inside = (sel >= r0) & (sel < r0 + n)
         got = np.asarray(b.get_rows_packed(sel))
         assert np.array_equal(got[inside], ref_rows[inside]) and not got[~inside].any()
-        rc = _lib.lib().bigsi_hip_load_rows_file(b.handle, fn.encode(), 4096, r0, n + 1, row_bytes, 2, None)
+        rc = _lib.lib().bigsi_hip_load_rows_file(b.handle, fn.encode(), 4096 + row_bytes, r0, n, row_bytes, 2, None)      # one row beyond the end of the file
         assert rc == _lib.ERR_INVALID and b"too short" in _lib.lib().bigsi_hip_last_error()
+        assert _lib.lib().bigsi_hip_load_rows_file(b.handle, fn.encode(), 4096, m - 1, 2, row_bytes, 2, None) == _lib.ERR_RANGE
         b.delete_all()
     a.delete_all()
 
