@@ -300,6 +300,10 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
     def search_batch(self, seqs, threshold=1.0, score=False):
         """search() for many sequences in one device batch; a list of result lists in input order."""
         assert threshold <= 1
+        with self._device_lock():          # (a search_stream being consumed has a worker thread on this index between yields)
+            return self._search_batch_locked(seqs, threshold, score)
+
+    def _search_batch_locked(self, seqs, threshold, score):
         seqs = list(seqs)
         if not seqs:
             return []
@@ -310,7 +314,7 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
             for i, r in zip(wide, self._search_wide([seqs[i] for i in wide], threshold, score)):
                 out[i] = r
             if rest:
-                for i, r in zip(rest, self.search_batch([seqs[i] for i in rest], threshold, score)):
+                for i, r in zip(rest, self._search_batch_locked([seqs[i] for i in rest], threshold, score)):
                     out[i] = r
             return out
         batch = self._workspace(0, seqs)
@@ -318,7 +322,101 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
         return self._collect(batch, len(seqs), threshold, score)
 
     def search_stream(self, seqs, threshold=1.0, score=False, batch_size=None, batch_kmers=1 << 19):
-        """Generator over (sequence, results) for an arbitrarily long iterable of sequences, two workspaces deep: while
+        """Generator over (sequence, results) for an arbitrarily long iterable of sequences (bulk_search, bigsi/__main__.py:261-314,
+        runs one BIGSI.search per query in a fork pool).  The sequences go through the C ABI's streaming entry points --
+        bigsi_hip_search_stream, or bigsi_hip_search_stream_scored with score=True: one call per slice of about 8 x `batch_kmers`
+        k-mers (or 16 x `batch_size` sequences), inside which the library keeps three device batches in flight and, scored, runs
+        K5 + K6 of one beside the row-AND of the next -- on a worker thread (the call holds no GIL), while this thread turns the
+        arrays of the slice before into the reference's result dicts.  Results, order and the reference's errors for degenerate
+        queries (raised when the offending sequence's turn comes, after everything before it was yielded) are those of search()
+        per sequence.  While a stream is being consumed the index handle is in use by the worker between yields: search() /
+        search_batch() / lookup() take the same lock and simply wait; do not modify the index.
+        A multi-GPU (devices=[...]) index streams through its batch objects instead (_search_stream_batches)."""
+        assert threshold <= 1
+        if self.storage.res.is_group:
+            yield from self._search_stream_batches(seqs, threshold, score, batch_size, batch_kmers)
+            return
+        from concurrent.futures import ThreadPoolExecutor
+        from ..storage.hip_hbm import TooManyHits
+        k, st, lock = self.kmer_size, self.storage, self._device_lock()
+
+        def work(chunk):
+            with lock:
+                try:
+                    try:
+                        plain = "".join(chunk).isascii()          # one pass at C speed
+                    except TypeError:                            # (bytes among the sequences)
+                        plain = all(s.isascii() for s in chunk)
+                    if not plain:                                # rare: answered through search_batch's non-ASCII route
+                        return "done", chunk, self._search_batch_locked(chunk, threshold, score)
+                    if not score:
+                        return "arrays", chunk, st.search_many(chunk, k, threshold)
+                    try:
+                        return "arrays", chunk, st.search_many_scored(chunk, k, threshold, max_bits=SCORE_SLICE_CHARS // 8)
+                    except TooManyHits:                          # (a low threshold on a wide index: the batch route scores in slices)
+                        return "done", chunk, self._search_batch_locked(chunk, threshold, score)
+                except Exception as e:  # noqa: BLE001 -- surfaces in stream order, from emit()
+                    return "error", chunk, e
+
+        take = batch_size * 16 if batch_size else 64
+        slices = self._slices(iter(seqs), take, take if batch_size else None, batch_kmers * 8, k)
+        with ThreadPoolExecutor(1) as pool:
+            pending = None
+            try:
+                for chunk in slices:
+                    nxt = pool.submit(work, chunk)
+                    if pending is not None:
+                        yield from self._emit(pending.result(), threshold, score)
+                    pending = nxt
+                if pending is not None:
+                    last, pending = pending, None
+                    yield from self._emit(last.result(), threshold, score)
+            finally:
+                if pending is not None:
+                    pending.result()                             # (the consumer stopped early: let the worker leave the index alone)
+
+    def _device_lock(self):
+        import threading
+        return self.storage.res.__dict__.setdefault("_lock", threading.RLock())
+
+    def _emit(self, res, threshold, score):
+        """(sequence, results) pairs of one slice from what the worker left: the reference's errors in stream order."""
+        kind, chunk, payload = res
+        if kind == "error":
+            raise payload
+        if kind == "done":
+            yield from zip(chunk, payload)
+            return
+        nk, nu, off, colours, counts = payload[:5]
+        exact = threshold == 1.0
+        off64 = off.astype(np.int64)
+        n_hits = np.diff(off64)
+        special = np.flatnonzero((n_hits > 0) | (nu == 0))
+        scored = None
+        if score and int(off64[-1]):
+            bits, boff, rec = payload[5:8]
+            scored = scored_rows(rec, bits, boff, np.repeat(nk.astype(np.int64), n_hits), self.scorer.DB_SIZE)
+        prev = 0
+        for i in special.tolist():
+            for s in chunk[prev:i]:
+                yield s, []
+            prev = i + 1
+            if nu[i] == 0:
+                # the reference fails on a query without k-mers: reduce() over nothing on the exact branch
+                # (utils/fncts.py:24-25), an unbound accumulator on the other (graph/bigsi.py:35-44)
+                if exact:
+                    raise TypeError("reduce() of empty sequence with no initial value")
+                raise UnboundLocalError("local variable 'cumsum' referenced before assignment")
+            if score and nk[i] == 1:
+                # the reference builds a 1-D matrix from a single row and then indexes it with two subscripts
+                raise IndexError("too many indices for array: array is 1-dimensional, but 2 were indexed")
+            lo, hi = int(off64[i]), int(off64[i + 1])
+            yield chunk[i], self._assemble(lo, colours[lo:hi], counts[lo:hi], int(nu[i]), exact, scored)
+        for s in chunk[prev:]:
+            yield s, []
+
+    def _search_stream_batches(self, seqs, threshold=1.0, score=False, batch_size=None, batch_kmers=1 << 19):
+        """search_stream over this object's own batch workspaces (what a multi-GPU index uses), two workspaces deep: while
         the GPU runs batch i+1 the host fetches and assembles batch i (fetches wait on the batch's own completion event, not
         on the stream).  A device batch closes after `batch_size` sequences if given, else once it holds about
         `batch_kmers` k-mers (about 540 x 1 kbp, or ~17000 reads of 61 bp: 4 ms of device work on a 125 GB index, enough to hide the
@@ -339,13 +437,19 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
 
         def begin(p):
             # score=True, three batches deep: the scored hits of the batch launched one step ago are only QUEUED here (K5 + K6 beside
-            # the batch just launched); done() picks them up a step later
+            # the batch just launched); done() picks them up a step later.  The reference's errors for degenerate queries are
+            # raised from here: kept for done(), so that they surface in stream order (after the results of the batch before)
             if not isinstance(p[0], _Done):
-                p.append(self._collect_begin(p[0], len(p[1]), threshold, score, deferred=True))
+                try:
+                    p.append(self._collect_begin(p[0], len(p[1]), threshold, score, deferred=True))
+                except Exception as e:  # noqa: BLE001
+                    p.append(e)
 
         def done(p):
             if isinstance(p[0], _Done):
                 return p[0].results
+            if len(p) > 2 and isinstance(p[2], Exception):
+                raise p[2]
             return self._collect_end(p[2]) if len(p) > 2 else self._collect(p[0], len(p[1]), threshold, score)
 
         # sequences are taken from the iterable in slices (C speed: millions of reads go through here); without a
@@ -359,36 +463,50 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
                 b_.close()
 
     @staticmethod
-    def _stream_loop(it, take, batch_size, batch_kmers, k, submit, done, begin=None, depth=2):
-        """submit(chunk, slot) launches a batch on workspace `slot` (of `depth`) and returns its handle; `depth` - 1 batches later
-        done(handle) yields its results.  With `begin`, begin(handle) is called once the NEXT batch has been launched (the middle
-        stage of a pipeline three deep: work queued beside that batch, collected by done() a step later)."""
-        from itertools import chain, islice
-        flight, slot = [], 0
+    def _slices(it, take, batch_size, batch_kmers, k):
+        """Cut an iterable of sequences into lists: `batch_size` sequences each if given, else about `batch_kmers` k-mers -- the slice
+        length follows the k-mers per sequence seen so far, and a slice that overshoots (reads first, genomes later) is cut at the
+        sequence that reaches the target, the rest held back for the next slice (a plain list: nothing is wrapped around the iterator)."""
+        from itertools import islice
+        held_back = []
+
+        def pull(n):
+            out = held_back[:n]
+            del held_back[:n]
+            if len(out) < n:
+                out += list(islice(it, n - len(out)))
+            return out
+
         while True:
-            chunk = list(islice(it, take))
+            chunk = pull(take)
             if not chunk:
-                break
+                return
             if not batch_size:
                 held = sum(map(len, chunk)) - (k - 1) * len(chunk)
                 while held < batch_kmers:                # top the slice up to a full batch
                     per = max(held // len(chunk), 1)
-                    more = list(islice(it, max((batch_kmers - held + per - 1) // per, 1)))
+                    more = pull(max((batch_kmers - held + per - 1) // per, 1))
                     if not more:
                         break
                     chunk += more
                     held = sum(map(len, chunk)) - (k - 1) * len(chunk)
                     held = max(held, len(chunk))
                 if held > batch_kmers and len(chunk) > 1:
-                    # the slice length follows the sequences seen so far; when they grow along the stream (reads first, genomes
-                    # later) a slice can hold thousands of times the target: cut it at the sequence that reaches batch_kmers and
-                    # hand the rest back to the iterator, so that a batch never exceeds the target by more than one sequence
                     csum = np.cumsum(np.maximum(np.fromiter(map(len, chunk), dtype=np.int64, count=len(chunk)) - (k - 1), 1))
                     cut = int(np.searchsorted(csum, batch_kmers, side="left")) + 1
                     if cut < len(chunk):
-                        it = chain(chunk[cut:], it)
+                        held_back[:0] = chunk[cut:]
                         chunk = chunk[:cut]
                 take = len(chunk)
+            yield chunk
+
+    @staticmethod
+    def _stream_loop(it, take, batch_size, batch_kmers, k, submit, done, begin=None, depth=2):
+        """submit(chunk, slot) launches a batch on workspace `slot` (of `depth`) and returns its handle; `depth` - 1 batches later
+        done(handle) yields its results.  With `begin`, begin(handle) is called once the NEXT batch has been launched (the middle
+        stage of a pipeline three deep: work queued beside that batch, collected by done() a step later)."""
+        flight, slot = [], 0
+        for chunk in BIGSI._slices(it, take, batch_size, batch_kmers, k):
             if len(flight) == depth:                     # the workspace about to be reused: its results first
                 p = flight.pop(0)
                 yield from zip(p[1], done(p))
@@ -404,6 +522,10 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
             begin(flight[-1])
         for p in flight:
             yield from zip(p[1], done(p))
+
+    def lookup(self, kmers, remove_trailing_zeros=True):
+        with self._device_lock():
+            return KmerSignatureIndex.lookup(self, kmers, remove_trailing_zeros)
 
     def search_stream_arrays(self, seqs, threshold=1.0, batch_size=1 << 15):
         """The device's own answer, batch by batch, for callers to whom a Python dict per hit is too slow (millions of reads):

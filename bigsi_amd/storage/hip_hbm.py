@@ -219,6 +219,10 @@ class _Resident(object):
             check(self.fn("set_num_hashes")(self.ix, int(value)))
 
 
+class TooManyHits(Exception):
+    """search_many_scored(max_bits=...): the presence bits of the hits would exceed the caller's limit (the caller scores in slices)."""
+
+
 class HipHbmStorage(BaseStorage):
     fused = True      # BIGSI.search/lookup may call search_batch / lookup_kmers
     _search_cap = 1 << 12     # hit entries search_batch brings buffers for (grows to what a call needed)
@@ -514,11 +518,11 @@ class HipHbmStorage(BaseStorage):
         total = int(off[-1])
         return nk, nu, off, col[:total], cnt[:total]
 
-    def search_many_scored(self, seqs, k, threshold=1.0):
+    def search_many_scored(self, seqs, k, threshold=1.0, max_bits=None):
         """bigsi_hip_search_stream_scored: search_many plus, per hit, the presence bits and the score record of score=True
         (bigsi/scoring/score.py:96-121), K5 + K6 of one device batch running beside the row-AND kernels of the next.  Returns
         (num_kmers, num_unique, hit_offsets, colours, counts, bits, bit_offsets, scores): hit t's presence string is
-        scoring.unpack_presence(bits, bit_offsets, t, num_kmers of its sequence); scores is a HIT_SCORE_DTYPE array."""
+        the slice of scoring.unpack_presence(bits, bit_offsets) that starts at character 8 * bit_offsets[t], num_kmers of its sequence long; scores is a HIT_SCORE_DTYPE array."""
         from bigsi_amd.scoring import HIT_SCORE_DTYPE
         assert threshold <= 1
         seqs = seqs if isinstance(seqs, (list, tuple)) else list(seqs)
@@ -540,6 +544,8 @@ class HipHbmStorage(BaseStorage):
                                                            _lib.ptr(boff), _lib.ptr(rec), _lib.ptr(need))
             if rc != _lib.ERR_CAPACITY or (int(off[-1]) <= cap and int(need[0]) <= bcap):
                 break
+            if max_bits is not None and int(need[0]) > max_bits:
+                raise TooManyHits(int(need[0]))
             cap = self._search_cap = max(cap, int(off[-1]))
             bcap = self._bits_cap = max(bcap, int(need[0]))
         check(rc)
