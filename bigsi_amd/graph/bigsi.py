@@ -380,7 +380,9 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
         return self.storage.res.__dict__.setdefault("_lock", threading.RLock())
 
     def _emit(self, res, threshold, score):
-        """(sequence, results) pairs of one slice from what the worker left: the reference's errors in stream order."""
+        """(sequence, results) pairs of one slice from what the worker left: the reference's errors in stream order.  Plain Python
+        over lists made once per slice (a numpy call per sequence costs more than the few hits a read has)."""
+        from ..scoring import SCORE_KEYS
         kind, chunk, payload = res
         if kind == "error":
             raise payload
@@ -391,27 +393,56 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
         exact = threshold == 1.0
         off64 = off.astype(np.int64)
         n_hits = np.diff(off64)
-        special = np.flatnonzero((n_hits > 0) | (nu == 0))
+        special = np.flatnonzero((n_hits > 0) | (nu == 0)).tolist()
+        if not special:
+            for s in chunk:
+                yield s, []
+            return
         scored = None
         if score and int(off64[-1]):
             bits, boff, rec = payload[5:8]
             scored = scored_rows(rec, bits, boff, np.repeat(nk.astype(np.int64), n_hits), self.scorer.DB_SIZE)
+        offs, nus, nks, cols, cnts = off64.tolist(), nu.tolist(), nk.tolist(), colours.tolist(), counts.tolist()
+        ns, name_of, deleted = self.num_samples, self.colour_to_sample, DELETION_SPECIAL_SAMPLE_NAME
+        names = {}
+        keys = ("percent_kmers_found", "num_kmers", "num_kmers_found", "sample_name") + SCORE_KEYS + ("kmer-presence",)
         prev = 0
-        for i in special.tolist():
+        for i in special:
             for s in chunk[prev:i]:
                 yield s, []
             prev = i + 1
-            if nu[i] == 0:
+            u = nus[i]
+            if u == 0:
                 # the reference fails on a query without k-mers: reduce() over nothing on the exact branch
                 # (utils/fncts.py:24-25), an unbound accumulator on the other (graph/bigsi.py:35-44)
                 if exact:
                     raise TypeError("reduce() of empty sequence with no initial value")
                 raise UnboundLocalError("local variable 'cumsum' referenced before assignment")
-            if score and nk[i] == 1:
+            if score and nks[i] == 1:
                 # the reference builds a 1-D matrix from a single row and then indexes it with two subscripts
                 raise IndexError("too many indices for array: array is 1-dimensional, but 2 were indexed")
-            lo, hi = int(off64[i]), int(off64[i + 1])
-            yield chunk[i], self._assemble(lo, colours[lo:hi], counts[lo:hi], int(nu[i]), exact, scored)
+            lo, hi = offs[i], offs[i + 1]
+            if exact:
+                # exact_filter (graph/bigsi.py:192-205): every set bit, ascending; a colour without a name is a KeyError
+                order = range(lo, hi)
+            else:
+                # inexact_filter (:211-230): only colours < num_samples are zipped in; stable sort by count, descending
+                order = sorted((t for t in range(lo, hi) if cols[t] < ns), key=lambda t: -cnts[t])
+            out = []
+            for t in order:
+                c = cols[t]
+                name = names.get(c)
+                if name is None:
+                    name = names[c] = name_of(c)
+                if name == deleted:
+                    continue
+                f = u if exact else cnts[t]
+                if scored is None:
+                    out.append({"percent_kmers_found": round(100 * float(f) / u, 2), "num_kmers": u, "num_kmers_found": f, "sample_name": name})
+                else:
+                    pct, fields, text = scored[t]
+                    out.append(dict(zip(keys, (pct, u, f, name) + fields + (text,))))
+            yield chunk[i], out
         for s in chunk[prev:]:
             yield s, []
 

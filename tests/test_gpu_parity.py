@@ -366,6 +366,59 @@ def test_rows_file_io_with_any_row_length(hip, tmp_path):
     a.delete_all()
 
 
+@pytest.mark.parametrize("n_cols,h", [(333, 2), (5000, 3), (70016, 4)])
+def test_one_query_in_one_launch_equals_the_general_route(hip, n_cols, h):
+    """bigsi_hip_search_batch of ONE gene-length query at threshold 1.0 takes k_query_one_exact (hashing inside the row-AND workgroups,
+    unique k-mers counted beside them, hits + export by the last workgroup): same numbers and hit lists as the batch route
+    (K1 -> K2 -> K4) for lengths on both sides of its limits, repeated k-mers, N and lowercase, planted and absent queries,
+    calls of other shapes in between (they use the same result words), and a query with more hits than the hit buffers hold."""
+    m = 200003
+    _, st = synth_index(hip, m, n_cols, h, 4242)
+    rng = np.random.default_rng(n_cols)
+    qs = random_seqs(rng, 6, 94, 1500) + ["".join(rng.choice(list("ACGT"), size=L)) for L in (93, 94, 95, 156, 157, 4062, 4063, 1000)]
+    rep = "".join(rng.choice(list("ACGT"), size=70))
+    qs += [rep * 9, qs[0][:300] + "N" + qs[0][300:], qs[1].lower(), qs[2][:200] + qs[2][:200]]
+    for i, q in enumerate(qs[:8]):
+        for c in rng.choice(n_cols, size=3, replace=False):
+            st.insert_kmers(int(c), [q], 31)
+
+    def general(seqs):
+        b = st.new_batch(seqs, 31)
+        b.run(1.0)
+        nk, nu, _ = b.unique()
+        off, col, cnt = b.hits()
+        b.close()
+        return [(int(nk[i]), int(nu[i]), col[int(off[i]):int(off[i + 1])].tolist(), cnt[int(off[i]):int(off[i + 1])].tolist()) for i in range(len(seqs))]
+
+    for rounds in range(2):
+        for i, q in enumerate(qs):
+            (k_, u_, col, cnt), = st.search_batch([q], 31, 1.0)
+            assert (k_, u_, col.tolist(), cnt.tolist()) == general([q])[0], (i, len(q))
+            if i % 5 == 4:          # another shape through the same workspace: two queries (general route), then thresholded, then reads
+                pair = st.search_batch([qs[0], qs[3]], 31, 1.0)
+                assert [(a, b_, c.tolist(), d.tolist()) for a, b_, c, d in pair] == general([qs[0], qs[3]])
+                st.search_batch([q], 31, 0.5)
+                st.search_batch([q[:61]], 31, 1.0)
+    assert sum(len(general([q])[0][2]) for q in qs[:8]) >= 24           # the planted samples are found
+    # more hits than the hit buffers hold (65 536): every row of a query set to all ones -> every column hits
+    if n_cols > 65536:
+        q = qs[3]
+        b = st.new_batch([q], 31)
+        b.run(1.0)
+        _, nu, _ = b.unique()
+        rows = np.unique(b.rows(0, nu[0]))
+        b.close()
+        full = np.full((rows.size, (n_cols + 7) // 8), 0xFF, np.uint8)
+        if n_cols % 8:
+            full[:, -1] = (0xFF << (8 - n_cols % 8)) & 0xFF
+        st.res.put_rows(rows.astype(np.uint64), full)
+        (k_, u_, col, cnt), = st.search_batch([q], 31, 1.0)
+        assert col.tolist() == list(range(n_cols)) and (cnt == u_).all() and u_ == int(nu[0])
+        (k2, u2, col2, cnt2), = st.search_batch([qs[4]], 31, 1.0)           # and the route works again afterwards
+        assert (k2, u2, col2.tolist(), cnt2.tolist()) == general([qs[4]])[0]
+    st.delete_all()
+
+
 # --------------------------------------------------------------------------------------------- synthetic index vs oracle
 def synth_index(hip, m, n_cols, h, seed, shard=0, draws=2):
     from bigsi_amd.storage import get_storage
