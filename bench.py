@@ -236,7 +236,7 @@ ALSO_LEGS = {
         ("northstar", "north_star 10M x 500k, WHOLE index over 8 GPUs", ["--workload", "northstar", "--warmup", "10"], 1200),
         ("c3_t04", "configs[2] at threshold 0.4 over 8 GPUs", ["--workload", "c3", "--threshold", "0.4"], 128)],
 }
-LEG_TIMEOUT_S = 420
+LEG_TIMEOUT_S = 300          # a leg that hangs (it never has) costs this much once: the legs after it are skipped
 
 
 def also_legs_for(world):
@@ -275,7 +275,11 @@ def run_also_legs(args, world, rank, ports):
     """The other BASELINE configurations: one fresh process per leg and rank (the headline's index has been freed, its process
     group closed).  Under a launcher every rank runs its rank of each leg; rank 0 returns the summaries."""
     out = {}
+    timed_out = False
     for (key, what, extra, steps), port in zip(also_legs_for(world), ports):
+        if timed_out:
+            out[key] = {"error": "skipped: an earlier leg timed out"}
+            continue
         n_steps = max(8, int(steps * args.leg_seconds))
         if extra[0] == "--ingest":
             gb = float(extra[1]) * min(1.0, args.leg_seconds) if not args.rows_cap else 1.0
@@ -308,6 +312,7 @@ def run_also_legs(args, world, rank, ports):
                 out[key] = leg_summary(json.loads(r.stdout.strip().splitlines()[-1]), what, extra, round(time.time() - t0, 1))
         except Exception as e:  # noqa: BLE001 -- a leg that fails is reported as such, the headline stands
             out[key] = {"error": ("%s: %s" % (type(e).__name__, e))[:160]}
+            timed_out = timed_out or isinstance(e, subprocess.TimeoutExpired)
     return out
 
 

@@ -1522,13 +1522,14 @@ __global__ __launch_bounds__(kBlock) void k_query_one_exact(
             }
             __syncthreads();
             if (live) {
+                // a latency-bound launch (a few dozen rows per workgroup): 16 loads in flight per lane, a quarter of the round trips
                 const uint32_t R = cnt * H;
-                for (uint32_t r = 0; r < R; r += 8) {
-                    u64x2 v[8];
+                for (uint32_t r = 0; r < R; r += 16) {
+                    u64x2 v[16];
 #pragma unroll
-                    for (int j = 0; j < 8; j++) v[j] = r + j < R ? load_row_seg<true>(index, s_hrow[r + j], stride_words, w0) : ones;
+                    for (int j = 0; j < 16; j++) v[j] = r + j < R ? load_row_seg<true>(index, s_hrow[r + j], stride_words, w0) : ones;
 #pragma unroll
-                    for (int j = 0; j < 8; j++) acc &= v[j];
+                    for (int j = 0; j < 16; j++) acc &= v[j];
                 }
             }
         }
@@ -1545,7 +1546,16 @@ __global__ __launch_bounds__(kBlock) void k_query_one_exact(
         while (tsize < 2 * n) tsize <<= 1;
         const uint32_t mask = tsize - 1;
         for (uint32_t i = threadIdx.x; i < tsize; i += kBlock) tab[i] = kEmpty;
-        for (uint32_t i = threadIdx.x; i < len + 40u && i < sizeof(sqw); i += kBlock) sq[i] = i < len ? seq[i] : (char)0;
+        // 16 bytes per lane: the query sits in pinned HOST memory, every load instruction is a PCIe round trip (the staging area is
+        // 16-byte aligned and a quarter larger than its contents: the last lane's read stays inside it)
+        {
+            const uint4 *src = reinterpret_cast<const uint4 *>(seq);
+            uint4 *dst = reinterpret_cast<uint4 *>(sqw);
+            const uint32_t nv = (len + 15u) / 16u;
+            for (uint32_t i = threadIdx.x; i < sizeof(sqw) / 16; i += kBlock) dst[i] = i < nv ? src[i] : uint4{0u, 0u, 0u, 0u};
+        }
+        __syncthreads();
+        for (uint32_t i = len + threadIdx.x; i < ((len + 15u) & ~15u); i += kBlock) sq[i] = (char)0;      // the bytes behind the query in its last 16
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
             uint32_t wf[8];
@@ -1583,30 +1593,40 @@ __global__ __launch_bounds__(kBlock) void k_query_one_exact(
     const uint32_t u = __hip_atomic_load(&uniq[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t *o32 = reinterpret_cast<uint32_t *>(pin_out + 3);
     uint32_t *ocol = o32 + 4, *ocnt = ocol + spec;
+    // every thread takes a run of CONSECUTIVE words (hits come out in colour order): all its loads in flight together, ONE scan
     uint64_t base = 0;
-    for (uint32_t c0 = 0; c0 < wv_pad; c0 += kBlock) {
-        const uint32_t w = c0 + threadIdx.x;
-        uint64_t bits = 0;
-        if (w < wv_pad) {
-            bits = __hip_atomic_load(&bitmap[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            bitmap[w] = ~0ull;                         // as the next call expects it
-            if (w >= wv) bits = 0;
+    for (uint32_t c0 = 0; c0 < wv_pad; c0 += kBlock * 8) {          // (8 words per thread and pass: 131 072 columns)
+        const uint32_t span = wv_pad - c0 < (uint32_t)kBlock * 8 ? wv_pad - c0 : (uint32_t)kBlock * 8;
+        const uint32_t per_t = (span + kBlock - 1) / kBlock, w_first = c0 + threadIdx.x * per_t;
+        uint64_t bits[8];
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t w = w_first + j;
+            const bool mine = (uint32_t)j < per_t && w < c0 + span;
+            bits[j] = mine ? __hip_atomic_load(&bitmap[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            if (mine) bitmap[w] = ~0ull;               // as the next call expects it
+            if (w >= wv) bits[j] = 0;
         }
-        const uint32_t cnt = (uint32_t)__popcll(bits);
+#pragma unroll
+        for (int j = 0; j < 8; j++) cnt += (uint32_t)__popcll(bits[j]);
         uint32_t tot;
         const uint32_t pre = block_exclusive_scan(cnt, &tot, lds);
         uint64_t o = base + pre;
         base += tot;
         if (cnt == 0 || o + cnt > capacity) continue;  // overflow: the host sees total > capacity and takes the general route
-        uint64_t mcol = by_column(bits);
-        while (mcol) {
-            const uint32_t c = (uint32_t)__builtin_ctzll(mcol);
-            mcol &= mcol - 1;
-            const uint32_t colour = w * 64u + c;
-            hit_col[o] = colour;
-            hit_cnt[o] = u;
-            if (o < spec) { ocol[o] = colour; ocnt[o] = u; }
-            o++;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            uint64_t mcol = by_column(bits[j]);
+            while (mcol) {
+                const uint32_t c = (uint32_t)__builtin_ctzll(mcol);
+                mcol &= mcol - 1;
+                const uint32_t colour = (w_first + j) * 64u + c;
+                hit_col[o] = colour;
+                hit_cnt[o] = u;
+                if (o < spec) { ocol[o] = colour; ocnt[o] = u; }
+                o++;
+            }
         }
     }
     if (threadIdx.x == 0) {
