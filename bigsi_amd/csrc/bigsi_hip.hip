@@ -891,7 +891,7 @@ static void point_uniq(bigsi_hip_batch *b)
     b->min_kmers.point(u + 2ull * b->n_seqs, b->n_seqs * 4ull);
 }
 
-static int pinned_reserve(void **p, size_t *cap, size_t bytes);
+static int pinned_reserve(void **p, size_t *cap, size_t bytes, bool device_cached = false);
 static int export_wait(bigsi_hip_batch *b);
 
 // `deferred`: the offset tables and the sequences are staged in pinned memory the batch owns and go up at the start of the next
@@ -952,7 +952,7 @@ static int batch_load(bigsi_hip_batch *b, const char *seqs, const uint64_t *offs
     };
     if (deferred && rc == BIGSI_OK) {
         const size_t bytes = 3 * ob + nbytes;
-        rc = pinned_reserve(&b->pin_up, &b->pin_up_cap, bytes);
+        rc = pinned_reserve(&b->pin_up, &b->pin_up_cap, bytes, true);
         if (rc != BIGSI_OK) return rc;
         uint8_t *h = static_cast<uint8_t *>(b->pin_up);
         memcpy(h, b->seq_off.data(), ob);
@@ -1532,7 +1532,7 @@ static bool one_query_fusable(const bigsi_hip_batch *b, uint32_t flags)
            !(flags & (BIGSI_RUN_SKIP_COMPACT | BIGSI_RUN_K1_GLOBAL | BIGSI_RUN_EARLY_EXIT | BIGSI_RUN_NO_SORT | BIGSI_RUN_FORCE_COUNTS));
 }
 
-static int pinned_reserve(void **p, size_t *cap, size_t bytes);
+
 static int export_setup(bigsi_hip_batch *b, hipStream_t st, uint64_t *spec_out);
 
 static int launch_query_one(bigsi_hip_batch *b, bool bitmap_ones)
@@ -2293,12 +2293,18 @@ extern "C" int bigsi_hip_batch_presence(bigsi_hip_batch *b, uint32_t seq, const 
 // them (bench workload c5).
 static_assert(sizeof(bigsi_hip_hit_score) == sizeof(bigsi_score::HitScore) && sizeof(bigsi_hip_hit_score) == 64, "score record layout");
 
-static int pinned_reserve(void **p, size_t *cap, size_t bytes)
+// pinned host memory the kernels touch directly.  Results and flags (kernel -> host while the kernel runs) are coherent
+// (fine-grained: every access crosses PCIe).  `device_cached` -- staged INPUTS, written by the host before the launch -- is
+// non-coherent memory: the GPU may keep what it read in its L2, so the 256 workgroups of k_query_one_exact that all read the query
+// cost a handful of PCIe reads instead of one each (as coherent memory the launch took 49 us, most of it waiting for ~400 small
+// PCIe reads; a kernel boundary is all the coherence an input needs).
+static int pinned_reserve(void **p, size_t *cap, size_t bytes, bool device_cached)
 {
     if (bytes <= *cap) return BIGSI_OK;
     if (*p) { hipError_t e = hipHostFree(*p); (void)e; *p = nullptr; *cap = 0; }
     const size_t want = std::max<size_t>(bytes + bytes / 4, 4096);
-    HIP_TRY(hipHostMalloc(p, want, hipHostMallocCoherent | hipHostMallocMapped));      // (kernels write results / read small inputs here directly)
+    static const int nc_env = env_int("BIGSI_HIP_INPUT_NONCOHERENT", 1);
+    HIP_TRY(hipHostMalloc(p, want, (device_cached && nc_env ? hipHostMallocNonCoherent : hipHostMallocCoherent) | hipHostMallocMapped));
     *cap = want;
     return BIGSI_OK;
 }

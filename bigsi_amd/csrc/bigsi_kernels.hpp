@@ -1141,10 +1141,30 @@ __global__ __launch_bounds__(kBlock) void k_hits_write(
     uint64_t base = 0;
 #pragma unroll
     for (int i = 0; i < kBlock / 64; i++) base += lds64[i];
-    // ordered write (the last group ends up with the grand total in `base`: a grid of ONE group needs no k_hits_totals at all)
+    // ordered write (the last group ends up with the grand total in `base`: a grid of ONE group needs no k_hits_totals at all).
+    // A group of a few items (a latency-bound call: one or two gene-length queries, all in ONE group) loads all its words first,
+    // so that the loop pays one memory round trip instead of one per item (8.3 -> ~3 us for one query on 100 k samples).
+    constexpr int kPre = 16;
+    uint64_t pre_bits[kPre];
+    const bool preloaded = i1 - i0 <= (uint64_t)kPre;
+    if (preloaded) {
+#pragma unroll
+        for (int j = 0; j < kPre; j++) {
+            uint32_t w_;
+            pre_bits[j] = i0 + j < i1 ? hits_word(bitmaps, stride_words, wv, n_seqs, n_shards, chunks, i0 + j, &w_) : 0ull;
+        }
+    }
     for (uint64_t ci = i0; ci < i1; ci++) {
         uint32_t w;
-        const uint64_t bits = hits_word(bitmaps, stride_words, wv, n_seqs, n_shards, chunks, ci, &w);
+        uint64_t bits;
+        if (preloaded) {
+            bits = 0;
+#pragma unroll
+            for (int j = 0; j < kPre; j++) bits = ci - i0 == (uint64_t)j ? pre_bits[j] : bits;
+            w = (uint32_t)(ci % chunks) * kBlock + threadIdx.x;
+        } else {
+            bits = hits_word(bitmaps, stride_words, wv, n_seqs, n_shards, chunks, ci, &w);
+        }
         const uint32_t cnt = (uint32_t)__popcll(bits);
         uint32_t tot;
         const uint32_t pre = block_exclusive_scan(cnt, &tot, lds);

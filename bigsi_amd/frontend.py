@@ -80,12 +80,30 @@ def bulk_search(bigsi, fasta, threshold=1.0, score=False, format="json", stream=
         # the reference's text -- json.dumps(list of records, indent=4) / the csv rows of every record -- written record by record: most
         # records of a bulk search have no results, and their text is a constant around the query (json.dumps with indent runs the
         # pure-Python encoder: ~20 us per record; this: ~0.3 us)
+        plain = ("percent_kmers_found", "num_kmers", "num_kmers_found", "sample_name")      # an unscored result's keys, in the reference's order
         if format == "csv":
-            return "\n".join(d_to_csv(search_record(s, threshold, r), False, False) if r else "" for s, r in pairs)
+            def rows(s, r):
+                if tuple(r[0]) != plain:
+                    return d_to_csv(search_record(s, threshold, r), False, False)
+                q = s.replace('"', '""')          # csv.writer, QUOTE_NONNUMERIC: strings quoted, quotes doubled; numbers as repr(); sorted keys
+                text = "".join('"%s",%d,%d,%r,"%s"\r\n' % (q, x["num_kmers"], x["num_kmers_found"], x["percent_kmers_found"], x["sample_name"].replace('"', '""')) for x in r)
+                return text[:-1]
+            return "\n".join(rows(s, r) if r else "" for s, r in pairs)
+        th, cit = json.dumps(threshold), json.dumps(CITATION)
         head = "    {\n        \"query\": "
-        tail = ",\n        \"threshold\": %s,\n        \"results\": [],\n        \"citation\": %s\n    }" % (json.dumps(threshold), json.dumps(CITATION))
-        parts = [head + json.dumps(s) + tail if not r else
-                 "\n".join("    " + line for line in json.dumps(search_record(s, threshold, r), indent=4).split("\n")) for s, r in pairs]
+        tail = ",\n        \"threshold\": %s,\n        \"results\": [],\n        \"citation\": %s\n    }" % (th, cit)
+        mid = ",\n        \"threshold\": %s,\n        \"results\": [\n" % th
+        end = "\n        ],\n        \"citation\": %s\n    }" % cit
+        one = ('            {\n                "percent_kmers_found": %r,\n                "num_kmers": %d,\n                "num_kmers_found": %d,\n'
+               '                "sample_name": %s\n            }')
+
+        def record(s, r):
+            if not r:
+                return head + json.dumps(s) + tail
+            if tuple(r[0]) != plain:                     # scored results: the general encoder, indented one level
+                return "\n".join("    " + line for line in json.dumps(search_record(s, threshold, r), indent=4).split("\n"))
+            return head + json.dumps(s) + mid + ",\n".join(one % (x["percent_kmers_found"], x["num_kmers"], x["num_kmers_found"], json.dumps(x["sample_name"])) for x in r) + end
+        parts = [record(s, r) for s, r in pairs]
         return "[\n" + ",\n".join(parts) + "\n]" if parts else "[]"
     dd = [search_record(s, threshold, r) for s, r in pairs]
     out = out or sys.stdout

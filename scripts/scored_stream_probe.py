@@ -16,7 +16,7 @@ st.fill_synthetic(20260928, 0, 2)
 st.set_integer("metadata:colour_count", n)
 rng = np.random.default_rng(1)
 lut = np.frombuffer(b"ACGT", dtype=np.uint8)
-n_batches = 24
+n_batches = 96          # 24 576 queries: six slices of the stream, so that its pipeline (C call of one slice beside the assembly of the one before) is in steady state
 seqs = [lut[r].tobytes().decode() for r in rng.integers(0, 4, size=(256 * n_batches, 1000), dtype=np.uint8)]
 for bi in range(n_batches):
     for qi in range(16):
