@@ -891,7 +891,7 @@ static void point_uniq(bigsi_hip_batch *b)
     b->min_kmers.point(u + 2ull * b->n_seqs, b->n_seqs * 4ull);
 }
 
-static int pinned_reserve(void **p, size_t *cap, size_t bytes, bool device_cached = false);
+static int pinned_reserve(void **p, size_t *cap, size_t bytes);
 static int export_wait(bigsi_hip_batch *b);
 
 // `deferred`: the offset tables and the sequences are staged in pinned memory the batch owns and go up at the start of the next
@@ -952,7 +952,7 @@ static int batch_load(bigsi_hip_batch *b, const char *seqs, const uint64_t *offs
     };
     if (deferred && rc == BIGSI_OK) {
         const size_t bytes = 3 * ob + nbytes;
-        rc = pinned_reserve(&b->pin_up, &b->pin_up_cap, bytes, true);
+        rc = pinned_reserve(&b->pin_up, &b->pin_up_cap, bytes);
         if (rc != BIGSI_OK) return rc;
         uint8_t *h = static_cast<uint8_t *>(b->pin_up);
         memcpy(h, b->seq_off.data(), ob);
@@ -1145,7 +1145,6 @@ extern "C" int bigsi_hip_batch_destroy(bigsi_hip_batch *b)
     if (b->pin_out) { e = hipHostFree(b->pin_out); (void)e; }
     if (b->pin_flag) { e = hipHostFree(b->pin_flag); (void)e; }
     b->exp_count.release();
-    b->one_ticket.release();
     if (b->exp_done) { e = hipEventDestroy(b->exp_done); (void)e; }
     if (b->job.h_in) { e = hipHostFree(b->job.h_in); (void)e; }
     if (b->job.h_out) { e = hipHostFree(b->job.h_out); (void)e; }
@@ -1521,67 +1520,6 @@ static int flush_upload(bigsi_hip_batch *b, hipStream_t st, bool k1_reads_host =
     return BIGSI_OK;
 }
 
-// ONE gene-length query, exact, from the one-call entry point: everything in one launch (k_query_one_exact)
-static bool one_query_fusable(const bigsi_hip_batch *b, uint32_t flags)
-{
-    static const int on = env_int("BIGSI_HIP_ONE_QUERY", 1);
-    const bigsi_hip_index *ix = b->ix;
-    return on && b->one_call && !b->no_one_query && b->upload_deferred && b->n_seqs == 1 && b->exact && b->k == 31 && ix->h >= 2 && ix->h <= 4 &&
-           b->max_pos >= 64 && b->max_pos <= kOneMaxPos && b->pin_up_bytes <= kZeroCopyBytes && !b->ext_bitmaps && !b->ext_counts &&
-           b->result_cols == 0 && b->wv <= 0x3FFFFFFFull &&
-           !(flags & (BIGSI_RUN_SKIP_COMPACT | BIGSI_RUN_K1_GLOBAL | BIGSI_RUN_EARLY_EXIT | BIGSI_RUN_NO_SORT | BIGSI_RUN_FORCE_COUNTS));
-}
-
-
-static int export_setup(bigsi_hip_batch *b, hipStream_t st, uint64_t *spec_out);
-
-static int launch_query_one(bigsi_hip_batch *b, bool bitmap_ones)
-{
-    bigsi_hip_index *ix = b->ix;
-    HitBufs &hb = b->hits;
-    hipStream_t st = ix->stream;
-    if (b->bitmaps.cap < (size_t)b->wv_pad * 8 || b->ones_words != b->wv_pad) bitmap_ones = false;      // fresh memory / another width
-    TRY(b->bitmaps.reserve((size_t)b->wv_pad * 8));
-    b->ones_words = b->wv_pad;
-    TRY(b->uniq.reserve(3 * 4));
-    TRY(hb.hit_off.reserve(3 * 8ull));
-    if (hb.cap == 0 && !hb.xcol) {
-        const uint64_t want = 1u << 16;
-        TRY(hb.hit_col.reserve(want * 4));
-        TRY(hb.hit_cnt.reserve(want * 4));
-        hb.cap = want;
-    }
-    if (!b->one_ticket.p) {
-        TRY(b->one_ticket.reserve(256));
-        HIP_TRY(hipMemsetAsync(b->one_ticket.p, 0, 256, st));
-    }
-    if (!bitmap_ones) HIP_TRY(hipMemsetAsync(b->bitmaps.p, 0xFF, (size_t)b->wv_pad * 8, st));      // (first call, or another route used the words)
-    uint64_t spec = 0;
-    TRY(export_setup(b, st, &spec));
-    // the row list cut into slices over all XCDs, as the sliced launches of a small batch (bigsi_batch_run: `slices`)
-    const uint32_t tiles = (uint32_t)ceil_div(b->wv, (uint64_t)kBlock * kVec);
-    const uint64_t waves = ceil_div(b->wv, 64 * kVec);
-    const uint32_t slices = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({64, ceil_div(2048, std::max<uint64_t>(waves, 1)), std::max<uint64_t>(b->max_pos / 16, 1)}));
-    const char *seq = static_cast<const char *>(b->pin_up) + 3 * (b->n_seqs + 1) * 8ull;      // zero copy: the staged bytes themselves
-    const uint32_t len = (uint32_t)b->max_len;
-    EventPair ep{};
-    TRY(ev_begin(ix, &ep, st, true));
-#define BIGSI_ONE(H)                                                                                                                 \
-    hipLaunchKernelGGL((k_query_one_exact<H>), dim3(tiles * slices + 1), dim3(kBlock), 0, st, ix->d_index, ix->stride_words, (uint32_t)b->wv, \
-                       (uint32_t)b->wv_pad, ix->n_cols, ix->m, seq, len, tiles, slices, b->bitmaps.as<uint64_t>(), b->one_ticket.as<uint32_t>(),  \
-                       b->uniq.as<uint32_t>(), hb.hit_off.as<uint64_t>(), hb.col(), hb.cnt(), hb.capacity(), static_cast<uint64_t *>(b->pin_out), \
-                       (uint32_t)spec, (volatile uint64_t *)b->pin_flag, b->exp_serial)
-    switch (ix->h) {
-    case 2: BIGSI_ONE(2); break;
-    case 3: BIGSI_ONE(3); break;
-    default: BIGSI_ONE(4); break;
-    }
-#undef BIGSI_ONE
-    HIP_TRY(hipGetLastError());
-    TRY(ev_end(ix, &ep, ix->ev_and, st));
-    return BIGSI_OK;
-}
-
 // `one_call`: the caller is bigsi_hip_search_batch, which waits for this run through the export's flag on the same stream: the
 // completion event is not recorded (one HIP call less on a path whose device work is a few microseconds); everything that would
 // wait for it waits for the stream instead (done_stale).
@@ -1608,29 +1546,6 @@ int bigsi_batch_run(bigsi_hip_batch *b, double threshold, uint32_t flags, bool o
     b->wv_pad = round_up(b->wv, 2);
 
     b->fused_run = false;
-    const bool bitmap_ones = b->bitmap_ones;
-    b->bitmap_ones = false;
-    b->self_exported = false;
-    if (one_call && one_query_fusable(b, flags)) {
-        TRY(quiesce_reads(ix));
-        if (!was_idle) TRY(batch_quiesce(b));           // (never the case on the one-call workspace: its last call was collected)
-        b->dirty = true;
-        b->upload_deferred = false;
-        b->zero_copy = true;                            // the kernel reads the staged bytes in place
-        TRY(launch_query_one(b, bitmap_ones));
-        b->bitmap_ones = true;
-        b->self_exported = true;
-        b->run_h = ix->h;
-        b->count_bytes = 2;
-        b->sparse_counts = false;
-        b->compacted = true;
-        b->done_stale = true;
-        b->run_stream = ix->stream;
-        TRY(mark_main(ix));
-        b->ran = true;
-        b->dirty = false;
-        return BIGSI_OK;
-    }
     if (reads_fusable(b, flags)) {
         // (K1 rewrites arrays the previous run of this batch may still be reading, on a read stream or the gather stream)
         TRY(b->rows.reserve(std::max<uint64_t>(b->total_pos, 1) * ix->h * 8));
@@ -2293,18 +2208,12 @@ extern "C" int bigsi_hip_batch_presence(bigsi_hip_batch *b, uint32_t seq, const 
 // them (bench workload c5).
 static_assert(sizeof(bigsi_hip_hit_score) == sizeof(bigsi_score::HitScore) && sizeof(bigsi_hip_hit_score) == 64, "score record layout");
 
-// pinned host memory the kernels touch directly.  Results and flags (kernel -> host while the kernel runs) are coherent
-// (fine-grained: every access crosses PCIe).  `device_cached` -- staged INPUTS, written by the host before the launch -- is
-// non-coherent memory: the GPU may keep what it read in its L2, so the 256 workgroups of k_query_one_exact that all read the query
-// cost a handful of PCIe reads instead of one each (as coherent memory the launch took 49 us, most of it waiting for ~400 small
-// PCIe reads; a kernel boundary is all the coherence an input needs).
-static int pinned_reserve(void **p, size_t *cap, size_t bytes, bool device_cached)
+static int pinned_reserve(void **p, size_t *cap, size_t bytes)
 {
     if (bytes <= *cap) return BIGSI_OK;
     if (*p) { hipError_t e = hipHostFree(*p); (void)e; *p = nullptr; *cap = 0; }
     const size_t want = std::max<size_t>(bytes + bytes / 4, 4096);
-    static const int nc_env = env_int("BIGSI_HIP_INPUT_NONCOHERENT", 1);
-    HIP_TRY(hipHostMalloc(p, want, (device_cached && nc_env ? hipHostMallocNonCoherent : hipHostMallocCoherent) | hipHostMallocMapped));
+    HIP_TRY(hipHostMalloc(p, want, hipHostMallocCoherent | hipHostMallocMapped));      // (kernels write results / read small inputs here directly)
     *cap = want;
     return BIGSI_OK;
 }
@@ -2601,33 +2510,10 @@ int bigsi_batch_stage(bigsi_hip_index *ix, bigsi_hip_batch **pb, const char *seq
     return batch_load(b, seqs, offsets, n_seqs, k, true);
 }
 
-// the pinned export block, the flag and the serial of an export about to be queued on `st`
-static int export_setup(bigsi_hip_batch *b, hipStream_t st, uint64_t *spec_out)
-{
-    HitBufs &hb = b->hits;
-    const uint32_t n = b->n_seqs;
-    const uint64_t spec = std::min<uint64_t>(std::max<uint64_t>(1024, 2ull * n), std::min<uint64_t>(hb.capacity(), 1u << 20));
-    const size_t o_uniq = (n + 2ull) * 8, o_col = o_uniq + ((3ull * n + 1) & ~1ull) * 4, bytes = o_col + 8 * spec;
-    TRY(pinned_reserve(&b->pin_out, &b->pin_out_cap, bytes));
-    if (!b->pin_flag) {
-        HIP_TRY(hipHostMalloc((void **)&b->pin_flag, 64, hipHostMallocCoherent | hipHostMallocMapped));
-        *b->pin_flag = 0;
-        TRY(b->exp_count.reserve(256));
-        HIP_TRY(hipMemsetAsync(b->exp_count.p, 0, 256, st));
-    }
-    b->exp_spec = (uint32_t)spec;
-    b->exp_serial++;
-    b->exp_flagged = true;
-    b->exp_stream = st;
-    *spec_out = spec;
-    return BIGSI_OK;
-}
-
 int bigsi_batch_export(bigsi_hip_batch *b)
 {
     if (!b || !b->ran) return fail(BIGSI_ERR_STATE, "bigsi_hip_batch_run has not completed for this batch");
     if (!b->compacted) return fail(BIGSI_ERR_STATE, "internal: export of a run without hit lists");
-    if (b->self_exported) return BIGSI_OK;            // k_query_one_exact wrote the block and raises the flag itself
     HitBufs &hb = b->hits;
     hipStream_t st = b->run_stream ? b->run_stream : b->ix->stream;
     const uint32_t n = b->n_seqs;
@@ -2694,14 +2580,6 @@ int bigsi_batch_collect(bigsi_hip_batch *b, uint32_t *num_kmers, uint32_t *num_u
     const uint64_t *off = static_cast<const uint64_t *>(b->pin_out);
     const uint64_t total = off[n];
     const bool gave_up = b->fused_run && !b->fused_settled && off[n + 1] == hb.gen;
-    if (b->self_exported && total > hb.capacity()) {
-        // the one-launch query route keeps no bitmap to compact again: grow the lists, let the caller repeat the call the general way
-        TRY(hb.hit_col.reserve(total * 4));
-        TRY(hb.hit_cnt.reserve(total * 4));
-        hb.cap = total;
-        b->idle = true;
-        return kRetryGeneral;
-    }
     if (gave_up || total > hb.capacity()) {
         // rare: a read launch that was abandoned, or hit lists that outgrew the device buffers -- the general route repeats the
         // launch / regrows the lists

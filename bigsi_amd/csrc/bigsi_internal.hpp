@@ -173,11 +173,6 @@ struct bigsi_hip_batch {
     bool upload_deferred = false;                    // pin_up holds tables + sequences that the next run uploads on its stream
     bool one_call = false;                           // the index's bigsi_hip_search_batch workspace: nothing else ever touches it
     bool zero_copy = false;                          // this load's tables + sequences are read by K1 straight from pin_up (no upload)
-    bool bitmap_ones = false;                        // the first query's result words are all ones (k_query_one_exact leaves them so)
-    uint64_t ones_words = 0;                         // ... that many of them
-    bool self_exported = false;                      // the last run wrote the pinned export block itself (k_query_one_exact)
-    bool no_one_query = false;                       // this call must take the general route (its hit lists outgrew the buffers)
-    DevBuf one_ticket;                               // k_query_one_exact's finished-workgroups counter
     bool idle = false;                               // nothing of this batch is in flight (its last export was collected)
     bool done_stale = false;                         // the last run did not record `done` (one-call route): wait on its stream instead
     hipEvent_t exp_done = nullptr;                   // end of the export kernel (only when the flag below is not used)
@@ -236,7 +231,6 @@ int bigsi_batch_export(bigsi_hip_batch *b);
 int bigsi_batch_collect(bigsi_hip_batch *b, uint32_t *num_kmers, uint32_t *num_unique, uint32_t *min_kmers, uint64_t *hit_offsets,
                         uint32_t *colours, uint32_t *counts, uint64_t capacity);
 int bigsi_use_device(const bigsi_hip_index *ix);
-constexpr int kRetryGeneral = -100;      // internal: a one-query run whose hits outgrew the buffers -- repeat the call on the general route
 // profiling events (bigsi_hip_set_profiling): a pair around a group of launches on `st` (null: the index stream), collected in `dst`
 int bigsi_ev_begin(bigsi_hip_index *ix, EventPair *p, hipStream_t st = nullptr, bool row_and = false);
 int bigsi_ev_end(bigsi_hip_index *ix, EventPair *p, std::vector<EventPair> &dst, hipStream_t st = nullptr, uint32_t launches = 1);

@@ -1141,30 +1141,10 @@ __global__ __launch_bounds__(kBlock) void k_hits_write(
     uint64_t base = 0;
 #pragma unroll
     for (int i = 0; i < kBlock / 64; i++) base += lds64[i];
-    // ordered write (the last group ends up with the grand total in `base`: a grid of ONE group needs no k_hits_totals at all).
-    // A group of a few items (a latency-bound call: one or two gene-length queries, all in ONE group) loads all its words first,
-    // so that the loop pays one memory round trip instead of one per item (8.3 -> ~3 us for one query on 100 k samples).
-    constexpr int kPre = 16;
-    uint64_t pre_bits[kPre];
-    const bool preloaded = i1 - i0 <= (uint64_t)kPre;
-    if (preloaded) {
-#pragma unroll
-        for (int j = 0; j < kPre; j++) {
-            uint32_t w_;
-            pre_bits[j] = i0 + j < i1 ? hits_word(bitmaps, stride_words, wv, n_seqs, n_shards, chunks, i0 + j, &w_) : 0ull;
-        }
-    }
+    // ordered write (the last group ends up with the grand total in `base`: a grid of ONE group needs no k_hits_totals at all)
     for (uint64_t ci = i0; ci < i1; ci++) {
         uint32_t w;
-        uint64_t bits;
-        if (preloaded) {
-            bits = 0;
-#pragma unroll
-            for (int j = 0; j < kPre; j++) bits = ci - i0 == (uint64_t)j ? pre_bits[j] : bits;
-            w = (uint32_t)(ci % chunks) * kBlock + threadIdx.x;
-        } else {
-            bits = hits_word(bitmaps, stride_words, wv, n_seqs, n_shards, chunks, ci, &w);
-        }
+        const uint64_t bits = hits_word(bitmaps, stride_words, wv, n_seqs, n_shards, chunks, ci, &w);
         const uint32_t cnt = (uint32_t)__popcll(bits);
         uint32_t tot;
         const uint32_t pre = block_exclusive_scan(cnt, &tot, lds);
@@ -1478,188 +1458,6 @@ __global__ __launch_bounds__(kBlock) void k_reads_fused(
             }
             o++;
         }
-    }
-}
-
-// ------------------------------------------------------------------------------ ONE gene-length query, exact, in ONE launch
-// The serving call (the reference's `search` endpoint, bigsi/__main__.py:195-209, is one BIGSI.search per request): one 1 kbp
-// query against 100 k samples used to be K1 (9.7 us, ONE workgroup busy) -> sliced row-AND (14.6) -> K4 (4.3) -> export (2.3)
-// plus the gaps between them.  Here every workgroup of the row-AND derives the row ids of ITS slice of the query itself -- a
-// wavefront canonicalises and hashes the slice's <= 63 positions with the packed-word code of k_reads_fused -- and streams them at
-// once; the AND does not care about duplicate k-mers (x & x = x), so no workgroup waits for a dedupe.  The number of unique k-mers
-// (graph/bigsi.py:179: what every exact hit reports) is counted meanwhile by one extra workgroup (LDS table, as k_kmerize_lds).
-// The LAST workgroup to finish (a ticket: nobody waits for anybody) compacts the hits, writes them and the per-query numbers to the
-// device arrays and straight into the pinned export block, restores the bitmap to all ones for the next call, and raises the
-// host's flag.  The other K1 outputs (row lists, position maps) are NOT produced: only bigsi_hip_search_batch's own workspace,
-// which nothing else can reach, takes this route.
-constexpr uint32_t kOneWindow = 63;                  // positions a workgroup hashes per round (one wavefront, lane = position)
-constexpr uint32_t kOneMaxPos = kOneWindow * 64;     // 4032 k-mer positions
-template <int H>
-__global__ __launch_bounds__(kBlock) void k_query_one_exact(
-    const uint64_t *__restrict__ index, uint64_t stride_words, uint32_t wv, uint32_t wv_pad, uint64_t n_cols, uint64_t m,
-    const char *__restrict__ seq /* pinned host memory or device */, uint32_t len, uint32_t tiles, uint32_t slices,
-    uint64_t *__restrict__ bitmap /* wv_pad words: all ones on entry, all ones again on exit */, uint32_t *__restrict__ ticket,
-    uint32_t *__restrict__ uniq /* num_kmers | num_unique | min_kmers */, uint64_t *__restrict__ hit_off /* 3 words */,
-    uint32_t *__restrict__ hit_col, uint32_t *__restrict__ hit_cnt, uint64_t capacity, uint64_t *pin_out, uint32_t spec,
-    volatile uint64_t *flag, uint64_t serial)
-{
-    constexpr int KF = 31;
-    __shared__ uint32_t tab[2 * 4096];               // dedupe workgroup: positions by k-mer, load <= 1/2
-    __shared__ uint32_t hs[kOneMaxPos];              // ... fingerprints
-    __shared__ uint32_t sqw[(kOneMaxPos + 64) / 4];  // ... the query's bytes
-    __shared__ uint64_t s_hrow[64 * H];
-    __shared__ uint32_t s_seq[24], s_cmp[26];
-    __shared__ uint32_t lds[16];
-    __shared__ uint32_t s_last;
-    const uint32_t n = len - (KF - 1);               // >= 64 by the launch condition
-    const uint32_t n_stream = tiles * slices;
-    if (blockIdx.x < n_stream) {
-        // consecutive workgroups -- different XCDs -- take the slices of one column tile (map_block's rule for sliced launches)
-        const uint32_t tile = blockIdx.x / slices, slice = blockIdx.x - tile * slices;
-        const uint32_t per = (n + slices - 1) / slices, p0 = slice * per, p1 = p0 + per < n ? p0 + per : n;
-        const uint32_t w0 = (tile * kBlock + threadIdx.x) * kVec, lane = threadIdx.x & 63u;
-        const bool live = w0 < wv;
-        const u64x2 ones = {~0ull, ~0ull};
-        u64x2 acc = ones;
-        for (uint32_t base = p0; base < p1; base += kOneWindow) {
-            const uint32_t cnt = p1 - base < kOneWindow ? p1 - base : kOneWindow;
-            __syncthreads();                          // the round before is done with the staging arrays
-            if (threadIdx.x < 26) s_cmp[threadIdx.x] = 0;
-            if (threadIdx.x < 24) s_seq[threadIdx.x] = 0;
-            __syncthreads();
-            if (threadIdx.x < cnt + (KF - 1)) {       // <= 93 bytes
-                const uint8_t c = (uint8_t)seq[base + threadIdx.x];
-                reinterpret_cast<uint8_t *>(s_seq)[threadIdx.x] = c;
-                reinterpret_cast<uint8_t *>(s_cmp)[4 + threadIdx.x] = complement(c);
-            }
-            __syncthreads();
-            if (threadIdx.x < cnt) {                  // wavefront 0: lane = position
-                uint32_t wf[8], k1[8];
-                kmer31_words(s_seq, lane, wf);
-                kmer31_canonical_premix(wf, s_cmp, lane, k1);
-#pragma unroll
-                for (int sd = 0; sd < H; sd++) s_hrow[lane * H + sd] = row_of_hash(murmur3_31_finish(k1, (uint32_t)sd), m);
-            }
-            __syncthreads();
-            if (live) {
-                // a latency-bound launch (a few dozen rows per workgroup): 16 loads in flight per lane, a quarter of the round trips
-                const uint32_t R = cnt * H;
-                for (uint32_t r = 0; r < R; r += 16) {
-                    u64x2 v[16];
-#pragma unroll
-                    for (int j = 0; j < 16; j++) v[j] = r + j < R ? load_row_seg<true>(index, s_hrow[r + j], stride_words, w0) : ones;
-#pragma unroll
-                    for (int j = 0; j < 16; j++) acc &= v[j];
-                }
-            }
-        }
-        if (live && p0 < p1) {
-            acc.x &= valid_mask(w0, n_cols);
-            acc.y &= valid_mask((uint64_t)w0 + 1, n_cols);
-            atomicAnd((unsigned long long *)(bitmap + w0), (unsigned long long)acc.x);
-            atomicAnd((unsigned long long *)(bitmap + w0 + 1), (unsigned long long)acc.y);      // (w0 even, wv_pad even: in range)
-        }
-    } else {
-        // ---- how many different k-mers (query strings, not canonical forms: graph/index.py:45): an LDS table of first positions
-        char *sq = reinterpret_cast<char *>(sqw);
-        uint32_t tsize = 2;
-        while (tsize < 2 * n) tsize <<= 1;
-        const uint32_t mask = tsize - 1;
-        for (uint32_t i = threadIdx.x; i < tsize; i += kBlock) tab[i] = kEmpty;
-        // 16 bytes per lane: the query sits in pinned HOST memory, every load instruction is a PCIe round trip (the staging area is
-        // 16-byte aligned and a quarter larger than its contents: the last lane's read stays inside it)
-        {
-            const uint4 *src = reinterpret_cast<const uint4 *>(seq);
-            uint4 *dst = reinterpret_cast<uint4 *>(sqw);
-            const uint32_t nv = (len + 15u) / 16u;
-            for (uint32_t i = threadIdx.x; i < sizeof(sqw) / 16; i += kBlock) dst[i] = i < nv ? src[i] : uint4{0u, 0u, 0u, 0u};
-        }
-        __syncthreads();
-        for (uint32_t i = len + threadIdx.x; i < ((len + 15u) & ~15u); i += kBlock) sq[i] = (char)0;      // the bytes behind the query in its last 16
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
-            uint32_t wf[8];
-            kmer31_words(sqw, i, wf);
-            hs[i] = kmer31_fingerprint(wf);
-        }
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
-            const uint32_t hv = hs[i];
-            uint32_t slot = hv & mask;
-            for (;;) {
-                const uint32_t cur = atomicCAS(&tab[slot], kEmpty, i);
-                if (cur == kEmpty) break;
-                if (hs[cur] == hv && kmer_equal(sq + cur, sq + i, KF)) break;      // the same k-mer: its slot is taken already
-                slot = (slot + 1) & mask;
-            }
-        }
-        __syncthreads();
-        uint32_t mine = 0, u;
-        for (uint32_t i = threadIdx.x; i < tsize; i += kBlock) mine += tab[i] != kEmpty ? 1u : 0u;
-        block_exclusive_scan(mine, &u, lds);
-        if (threadIdx.x == 0) {
-            uniq[0] = n;
-            uniq[1] = u;
-            uniq[2] = u;                               // min_kmers = ceil(u * 1.0)
-        }
-    }
-    // ---- the last workgroup to get here finishes the call
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
-    __syncthreads();
-    if (!s_last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    const uint32_t u = __hip_atomic_load(&uniq[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint32_t *o32 = reinterpret_cast<uint32_t *>(pin_out + 3);
-    uint32_t *ocol = o32 + 4, *ocnt = ocol + spec;
-    // every thread takes a run of CONSECUTIVE words (hits come out in colour order): all its loads in flight together, ONE scan
-    uint64_t base = 0;
-    for (uint32_t c0 = 0; c0 < wv_pad; c0 += kBlock * 8) {          // (8 words per thread and pass: 131 072 columns)
-        const uint32_t span = wv_pad - c0 < (uint32_t)kBlock * 8 ? wv_pad - c0 : (uint32_t)kBlock * 8;
-        const uint32_t per_t = (span + kBlock - 1) / kBlock, w_first = c0 + threadIdx.x * per_t;
-        uint64_t bits[8];
-        uint32_t cnt = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const uint32_t w = w_first + j;
-            const bool mine = (uint32_t)j < per_t && w < c0 + span;
-            bits[j] = mine ? __hip_atomic_load(&bitmap[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-            if (mine) bitmap[w] = ~0ull;               // as the next call expects it
-            if (w >= wv) bits[j] = 0;
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j++) cnt += (uint32_t)__popcll(bits[j]);
-        uint32_t tot;
-        const uint32_t pre = block_exclusive_scan(cnt, &tot, lds);
-        uint64_t o = base + pre;
-        base += tot;
-        if (cnt == 0 || o + cnt > capacity) continue;  // overflow: the host sees total > capacity and takes the general route
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            uint64_t mcol = by_column(bits[j]);
-            while (mcol) {
-                const uint32_t c = (uint32_t)__builtin_ctzll(mcol);
-                mcol &= mcol - 1;
-                const uint32_t colour = (w_first + j) * 64u + c;
-                hit_col[o] = colour;
-                hit_cnt[o] = u;
-                if (o < spec) { ocol[o] = colour; ocnt[o] = u; }
-                o++;
-            }
-        }
-    }
-    if (threadIdx.x == 0) {
-        hit_off[0] = 0; hit_off[1] = base; hit_off[2] = 0;
-        pin_out[0] = 0; pin_out[1] = base; pin_out[2] = 0;
-        o32[0] = n; o32[1] = u; o32[2] = u;
-        *ticket = 0;
-    }
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence_system();
-        *flag = serial;
     }
 }
 

@@ -105,17 +105,9 @@ extern "C" int bigsi_hip_search_batch(bigsi_hip_index *ix, const char *seqs, con
     TRY(bigsi_batch_stage(ix, &ix->search_ws, seqs, offsets, n_seqs, k));
     bigsi_hip_batch *b = ix->search_ws;
     b->one_call = true;      // (a small input is then read by K1 straight from the pinned staging, and the run records no event)
-    b->no_one_query = false;
     int rc = bigsi_batch_run(b, threshold, (flags & ~BIGSI_RUN_SKIP_COMPACT) | BIGSI_RUN_SPARSE_COUNTS, true);
     if (rc == BIGSI_OK) rc = bigsi_batch_export(b);
     if (rc == BIGSI_OK) rc = bigsi_batch_collect(b, num_kmers, num_unique, min_kmers, hit_offsets, colours, counts, hit_capacity);
-    if (rc == kRetryGeneral) {      // one query with more hits than the hit buffers held (they have grown): once more, the general way
-        rc = bigsi_batch_stage(ix, &ix->search_ws, seqs, offsets, n_seqs, k);
-        b->no_one_query = true;
-        if (rc == BIGSI_OK) rc = bigsi_batch_run(b, threshold, (flags & ~BIGSI_RUN_SKIP_COMPACT) | BIGSI_RUN_SPARSE_COUNTS, true);
-        if (rc == BIGSI_OK) rc = bigsi_batch_export(b);
-        if (rc == BIGSI_OK) rc = bigsi_batch_collect(b, num_kmers, num_unique, min_kmers, hit_offsets, colours, counts, hit_capacity);
-    }
     if (rc != BIGSI_OK && rc != BIGSI_ERR_CAPACITY) {      // (a too small hit buffer is the caller's to retry: offsets are filled in)
         ix->search_ws = nullptr;
         bigsi_hip_batch_destroy(b);      // leaves the thread's error message of the failed call above in place

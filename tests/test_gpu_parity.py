@@ -367,11 +367,12 @@ def test_rows_file_io_with_any_row_length(hip, tmp_path):
 
 
 @pytest.mark.parametrize("n_cols,h", [(333, 2), (5000, 3), (70016, 4)])
-def test_one_query_in_one_launch_equals_the_general_route(hip, n_cols, h):
-    """bigsi_hip_search_batch of ONE gene-length query at threshold 1.0 takes k_query_one_exact (hashing inside the row-AND workgroups,
-    unique k-mers counted beside them, hits + export by the last workgroup): same numbers and hit lists as the batch route
-    (K1 -> K2 -> K4) for lengths on both sides of its limits, repeated k-mers, N and lowercase, planted and absent queries,
-    calls of other shapes in between (they use the same result words), and a query with more hits than the hit buffers hold."""
+def test_one_call_searches_of_one_query_equal_the_batch_route(hip, n_cols, h):
+    """bigsi_hip_search_batch -- the serving call: staged input read by K1 in place (zero copy), no completion event, the export
+    kernel's flag -- for ONE query at a time: same numbers and hit lists as the batch objects (create / run / fetch) for lengths on both
+    sides of the K1 routes' limits, repeated k-mers, N and lowercase, planted and absent queries, calls of other shapes in between
+    (pairs, thresholded, batches of reads cut from the query: other bytes in the same staging area every call), and a query with
+    more hits than the hit buffers hold."""
     m = 200003
     _, st = synth_index(hip, m, n_cols, h, 4242)
     rng = np.random.default_rng(n_cols)
@@ -394,7 +395,7 @@ def test_one_query_in_one_launch_equals_the_general_route(hip, n_cols, h):
         for i, q in enumerate(qs):
             (k_, u_, col, cnt), = st.search_batch([q], 31, 1.0)
             assert (k_, u_, col.tolist(), cnt.tolist()) == general([q])[0], (i, len(q))
-            if i % 5 == 4:          # another shape through the same workspace: two queries (general route), then thresholded, then reads
+            if i % 5 == 4:          # other shapes through the same workspace: two queries, thresholded, reads
                 pair = st.search_batch([qs[0], qs[3]], 31, 1.0)
                 assert [(a, b_, c.tolist(), d.tolist()) for a, b_, c, d in pair] == general([qs[0], qs[3]])
                 st.search_batch([q], 31, 0.5)
@@ -418,7 +419,7 @@ def test_one_query_in_one_launch_equals_the_general_route(hip, n_cols, h):
         st.res.put_rows(rows.astype(np.uint64), full)
         (k_, u_, col, cnt), = st.search_batch([q], 31, 1.0)
         assert col.tolist() == list(range(n_cols)) and (cnt == u_).all() and u_ == int(nu[0])
-        (k2, u2, col2, cnt2), = st.search_batch([qs[4]], 31, 1.0)           # and the route works again afterwards
+        (k2, u2, col2, cnt2), = st.search_batch([qs[4]], 31, 1.0)           # and the workspace works again afterwards
         assert (k2, u2, col2.tolist(), cnt2.tolist()) == general([qs[4]])[0]
     st.delete_all()
 
