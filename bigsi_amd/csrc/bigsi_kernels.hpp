@@ -1096,15 +1096,28 @@ constexpr uint32_t kHitsMaxGroups = 1024;
 __device__ __forceinline__ uint64_t lb_pack(uint32_t gen, uint64_t value) { return ((uint64_t)gen << 44) | (value + 1); }
 constexpr uint64_t kLbPoison = (1ull << 44) - 1;      // value field of a state word that says "the launch is being abandoned"
 
-__device__ __forceinline__ uint64_t hits_word(const uint64_t *__restrict__ bitmaps, uint64_t stride_words, uint32_t wv, uint32_t n_seqs,
-                                              uint32_t n_shards, uint32_t chunks, uint64_t ci, uint32_t *w_out)
+// item ci of the (seq, shard, chunk) order; the host keeps the number of items below 2^31, so the divisions are 32-bit ones
+// (a 64-bit division is a ~100-instruction routine on this hardware: three of them per item were most of K4's time on a
+// latency-bound call -- 8.3 us for the seven items of one query on 100 k samples)
+struct HitItem {
+    uint32_t chunk, shard, q;
+};
+__device__ __forceinline__ HitItem hit_item(uint64_t ci, uint32_t n_shards, uint32_t chunks)
 {
-    const uint32_t chunk = (uint32_t)(ci % chunks);
-    const uint64_t sq = ci / chunks;
-    const uint32_t shard = (uint32_t)(sq % n_shards), q = (uint32_t)(sq / n_shards);
-    const uint32_t w = chunk * kBlock + threadIdx.x;   // one 64-column word per thread
+    const uint32_t c32 = (uint32_t)ci, sq = c32 / chunks;
+    HitItem it;
+    it.chunk = c32 - sq * chunks;
+    it.shard = n_shards == 1 ? 0u : sq % n_shards;
+    it.q = n_shards == 1 ? sq : sq / n_shards;
+    return it;
+}
+
+__device__ __forceinline__ uint64_t hits_word(const uint64_t *__restrict__ bitmaps, uint64_t stride_words, uint32_t wv, uint32_t n_seqs,
+                                              const HitItem &it, uint32_t *w_out)
+{
+    const uint32_t w = it.chunk * kBlock + threadIdx.x;   // one 64-column word per thread
     *w_out = w;
-    return w < wv ? bitmaps[((uint64_t)shard * n_seqs + q) * stride_words + w] : 0ull;
+    return w < wv ? bitmaps[((uint64_t)it.shard * n_seqs + it.q) * stride_words + w] : 0ull;
 }
 
 __global__ __launch_bounds__(kBlock) void k_hits_totals(
@@ -1115,7 +1128,7 @@ __global__ __launch_bounds__(kBlock) void k_hits_totals(
     const uint64_t grp = blockIdx.x, n_items = (uint64_t)n_seqs * n_shards * chunks;
     const uint64_t i0 = grp * ipb, i1 = i0 + ipb < n_items ? i0 + ipb : n_items;
     uint32_t mine = 0, w_unused;
-    for (uint64_t ci = i0; ci < i1; ci++) mine += (uint32_t)__popcll(hits_word(bitmaps, stride_words, wv, n_seqs, n_shards, chunks, ci, &w_unused));
+    for (uint64_t ci = i0; ci < i1; ci++) mine += (uint32_t)__popcll(hits_word(bitmaps, stride_words, wv, n_seqs, hit_item(ci, n_shards, chunks), &w_unused));
     uint32_t gtot;
     block_exclusive_scan(mine, &gtot, lds);
     if (threadIdx.x == 0) totals[grp] = gtot;
@@ -1144,13 +1157,12 @@ __global__ __launch_bounds__(kBlock) void k_hits_write(
     // ordered write (the last group ends up with the grand total in `base`: a grid of ONE group needs no k_hits_totals at all)
     for (uint64_t ci = i0; ci < i1; ci++) {
         uint32_t w;
-        const uint64_t bits = hits_word(bitmaps, stride_words, wv, n_seqs, n_shards, chunks, ci, &w);
+        const HitItem it = hit_item(ci, n_shards, chunks);
+        const uint64_t bits = hits_word(bitmaps, stride_words, wv, n_seqs, it, &w);
         const uint32_t cnt = (uint32_t)__popcll(bits);
         uint32_t tot;
         const uint32_t pre = block_exclusive_scan(cnt, &tot, lds);
-        const uint32_t chunk = (uint32_t)(ci % chunks);
-        const uint64_t sq = ci / chunks;
-        const uint32_t shard = (uint32_t)(sq % n_shards), q = (uint32_t)(sq / n_shards);
+        const uint32_t chunk = it.chunk, shard = it.shard, q = it.q;
         if (threadIdx.x == 0 && chunk == 0 && shard == 0) hit_off[q] = base;
         uint64_t o = base + pre;
         base += tot;
@@ -1473,8 +1485,9 @@ __global__ __launch_bounds__(kBlock) void k_mask_from_counts(
 {
     const uint64_t item = (uint64_t)blockIdx.x * kBlock + threadIdx.x, per_q = (uint64_t)wv * 8;
     if (item >= (uint64_t)n_seqs * per_q) return;
-    const uint32_t q = (uint32_t)(item / per_q);
-    const uint64_t byte = item % per_q, c0 = byte * 8;
+    // (32-bit division whenever the grid allows it: the 64-bit routine is ~100 instructions)
+    const uint32_t q = (item >> 32) == 0 ? (uint32_t)item / (uint32_t)per_q : (uint32_t)(item / per_q);
+    const uint64_t byte = item - (uint64_t)q * per_q, c0 = byte * 8;
     const uint32_t thr = min_kmers[q];
     const CountT *c = counts + (uint64_t)q * cstride + c0;
     CountT v[8];
