@@ -360,6 +360,12 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
 
         take = batch_size * 16 if batch_size else 64
         slices = self._slices(iter(seqs), take, take if batch_size else None, batch_kmers * 8, k)
+        # the worker needs the GIL a few times per slice (arguments in, arrays out) while this thread assembles dicts in pure Python
+        # and never lets go of it voluntarily: at the default 5 ms switch interval those handoffs cost a scored stream a third of its
+        # rate (128 -> 165+ M lookups/s on BASELINE configs[4]'s shard)
+        import sys
+        interval = sys.getswitchinterval()
+        sys.setswitchinterval(min(interval, 2e-4))
         with ThreadPoolExecutor(1) as pool:
             pending = None
             try:
@@ -372,6 +378,7 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
                     last, pending = pending, None
                     yield from self._emit(last.result(), threshold, score)
             finally:
+                sys.setswitchinterval(interval)
                 if pending is not None:
                     pending.result()                             # (the consumer stopped early: let the worker leave the index alone)
 
@@ -400,8 +407,23 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
             return
         scored = None
         if score and int(off64[-1]):
+            # the scored rows (closed-form fields, presence strings) of a slice are made 256 hits at a time, as they are needed: 4096
+            # hits of 970 positions at once are 4 MB of fresh strings per slice -- page faults and cache misses made that 7 us per hit
+            # where blocks that stay in the cache take 4
             bits, boff, rec = payload[5:8]
-            scored = scored_rows(rec, bits, boff, np.repeat(nk.astype(np.int64), n_hits), self.scorer.DB_SIZE)
+            lengths, db, blk = np.repeat(nk.astype(np.int64), n_hits), self.scorer.DB_SIZE, {"lo": 0, "rows": []}
+
+            class _Blocks(object):
+                def __getitem__(self_, t):
+                    lo = blk["lo"]
+                    if not lo <= t < lo + len(blk["rows"]):
+                        lo = t - t % 256
+                        hi = min(lo + 256, len(lengths))
+                        b0 = int(boff[lo])
+                        blk["rows"] = scored_rows(rec[lo:hi], bits[b0:int(boff[hi])], boff[lo:hi + 1] - boff[lo], lengths[lo:hi], db)
+                        blk["lo"] = lo
+                    return blk["rows"][t - lo]
+            scored = _Blocks()
         offs, nus, nks, cols, cnts = off64.tolist(), nu.tolist(), nk.tolist(), colours.tolist(), counts.tolist()
         ns, name_of, deleted = self.num_samples, self.colour_to_sample, DELETION_SPECIAL_SAMPLE_NAME
         names = {}

@@ -34,6 +34,14 @@ for score in (True, False):
     uniq = sum(len({s[i:i + k] for i in range(len(s) - k + 1)}) for s in seqs[:64]) / 64 * len(seqs)
     out["score=%s" % score] = {"seconds": dt, "queries": len(seqs), "hits": hits, "ms_per_256_queries": dt / n_batches * 1e3,
                                "kmer_lookups_per_s": uniq / dt, "keys_per_hit": len(res[0][1][0]) if res[0][1] else None}
+# the batch-object pipeline (round 3's route: begin / end per device batch, three deep, everything on the caller's thread)
+for score in (True, False):
+    list(index._search_stream_batches(seqs[:512], 0.4, score=score, batch_size=256))
+    t0 = time.perf_counter()
+    res2 = list(index._search_stream_batches(seqs, 0.4, score=score, batch_size=256))
+    dt = time.perf_counter() - t0
+    out["batches score=%s" % score] = {"seconds": dt, "ms_per_256_queries": dt / n_batches * 1e3, "kmer_lookups_per_s": uniq / dt}
+assert res2 == res
 # the C boundary alone: bigsi_hip_search_stream_scored (sequences in; hit lists, presence bits and score records out), and the
 # unscored bigsi_hip_search_stream beside it
 for name, fn in (("c_stream_scored", index.storage.search_many_scored), ("c_stream", index.storage.search_many)):
