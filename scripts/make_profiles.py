@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
 PEAK = 8000.0
-R = os.environ.get("ROUND", "r03")      # prefix of this round's files
+R = os.environ.get("ROUND", "r04")      # prefix of this round's files
 
 
 def short(name):
@@ -142,6 +142,25 @@ def main():
         old.update(traffic)
         with open(os.path.join(DST, "pmc_traffic.json"), "w") as f:
             json.dump(old, f, indent=1)
+    # round 4: scripts/pmc_all.py leaves its own reduced tables (every quoted kernel): merge / copy them
+    try:
+        new = json.load(open(os.path.join(SRC, "pmc", "pmc_traffic.json")))
+        for v in new.values():
+            v["source"] = v["source"].replace("profiles/pmc_kernels.json", "profiles/%s_pmc_kernels.json" % R)
+        old = {}
+        try:
+            old = json.load(open(os.path.join(DST, "pmc_traffic.json")))
+        except OSError:
+            pass
+        old.update(new)
+        with open(os.path.join(DST, "pmc_traffic.json"), "w") as f:
+            json.dump(old, f, indent=1)
+        shutil.copy(os.path.join(SRC, "pmc", "pmc_kernels.json"), os.path.join(DST, R + "_pmc_kernels.json"))
+    except OSError:
+        pass
+    for name in (R + "_latency_probe.txt", R + "_frontend_probe.json", R + "_bench_default_full.json"):
+        if os.path.exists(os.path.join(SRC, name)):
+            shutil.copy(os.path.join(SRC, name), os.path.join(DST, name))
     for name in (R + "_row_probe.txt", R + "_call_breakdown.txt"):
         if os.path.exists(os.path.join(SRC, name)):
             shutil.copy(os.path.join(SRC, name), os.path.join(DST, name))

@@ -4,10 +4,10 @@
 # for the dominant kernel (one counter per pass, as the hardware guide prescribes), and the unprofiled default bench line.
 # scripts/make_profiles.py then condenses gpurun_out/prof into profiles/<round>_* (ROUND=r03 by default).
 cd "${GRAFT_REPO_ROOT:-.}"
-R=${ROUND:-r03}
+R=${ROUND:-r04}
 P=gpurun_out/prof
 mkdir -p $P
-B="--cpu-seconds 0 --also none --host-visible 0"
+B="--cpu-seconds 0 --also none --host-visible 0 --alone-steps 0"      # (rocprofv3 averages then cover launches of the timed shape only)
 [ -f bigsi_amd/libbigsi_hip_tuning.so ] || bash bigsi_amd/csrc/build.sh tuning > /dev/null      # (two legs below A/B through it)
 run() { scripts/prof.sh "$@" > /dev/null; }
 run ${R}_c3_exact        -- python bench.py --steps 20 --warmup 5 $B
@@ -16,7 +16,8 @@ run ${R}_c3_256x1kbp     -- python bench.py --steps 200 --warmup 10 $B --batch 2
 run ${R}_c3_256x1kbp_t04 -- python bench.py --steps 200 --warmup 10 $B --batch 256 --threshold 0.4
 run ${R}_c2              -- python bench.py --workload c2 --steps 4000 --warmup 100 $B
 run ${R}_c2_t04          -- python bench.py --workload c2 --steps 4000 --warmup 100 $B --threshold 0.4
-run ${R}_c2_one_stream BIGSI_HIP_LIB=$PWD/bigsi_amd/libbigsi_hip_tuning.so BIGSI_HIP_READ_STREAMS=1 -- python bench.py --workload c2 --steps 4000 --warmup 100 $B
+run ${R}_c2_one_stream   -- python bench.py --workload c2 --steps 4000 --warmup 100 $B --one-stream      # the read kernel alone on the device: what roofline.frac of read workloads is priced on
+run ${R}_c2_t04_one_stream -- python bench.py --workload c2 --steps 4000 --warmup 100 $B --one-stream --threshold 0.4
 run ${R}_c2_unfused BIGSI_HIP_LIB=$PWD/bigsi_amd/libbigsi_hip_tuning.so BIGSI_HIP_FUSE_READS=0 -- python bench.py --workload c2 --steps 4000 --warmup 100 $B
 run ${R}_c2_32k_reads    -- python bench.py --workload c2 --steps 200 --warmup 16 $B --batch 32768 --distinct-batches 8
 run ${R}_c4_shard        -- python bench.py --workload c4 --shard-of 8 --gpus 1 --steps 200 --warmup 10 $B
@@ -36,23 +37,11 @@ run ${R}_scored_stream   -- python scripts/scored_stream_probe.py
   scripts/probe/row_probe --gb 125 --row-bytes 7813 --rows-per-query 2900 --queries 1024
   scripts/probe/row_probe --gb 1.25 --row-bytes 1250 --rows-per-query 93 --queries 8192 --wgs 2048; } > $P/${R}_row_probe.txt 2>&1
 python scripts/call_breakdown.py > $P/${R}_call_breakdown.txt 2>/dev/null
-# PMC: HBM traffic of the row-AND kernels (FETCH_SIZE / WRITE_SIZE in separate passes)
+scripts/probe/latency_probe > $P/${R}_latency_probe.txt 2>&1
+python scripts/frontend_probe.py > $P/${R}_frontend_probe.json 2>/dev/null
+# PMC: HBM traffic of every quoted kernel (FETCH_SIZE / WRITE_SIZE in separate passes, --kernel-trace only)
 export TMPDIR=/tmp
-for thr in 1.0 0.4; do
-  for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $P/raw_pmc -o pmc_${c}_$thr -- python bench.py --steps 2 --warmup 1 $B --no-verify --threshold $thr > $P/pmc_${c}_$thr.stdout 2> $P/pmc_${c}_$thr.stderr
-    f=$(find $P/raw_pmc -name "pmc_${c}_${thr}_counter_collection.csv" | head -1)
-    [ -n "$f" ] && python scripts/make_profiles.py --pmc-reduce "$f" $P/pmc_${c}_$thr.json
-    rm -rf $P/raw_pmc
-  done
-done
-# the same two counters for the one-launch read kernel (BASELINE configs[1])
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $P/raw_pmc -o pmc_c2_${c} -- python bench.py --workload c2 --steps 64 --warmup 8 $B --no-verify > $P/pmc_c2_${c}.stdout 2> $P/pmc_c2_${c}.stderr
-  f=$(find $P/raw_pmc -name "pmc_c2_${c}_counter_collection.csv" | head -1)
-  [ -n "$f" ] && python scripts/make_profiles.py --pmc-reduce "$f" $P/pmc_c2_${c}.json
-  rm -rf $P/raw_pmc
-done
-python bench.py --steps 20 --warmup 5 > $P/${R}_bench_default.stdout 2> $P/${R}_bench_default.stderr      # the driver's command: headline + every other config as config.also legs + the CPU baseline
+python scripts/pmc_all.py $P/pmc > $P/${R}_pmc_all.log 2>&1
+python bench.py --steps 20 --warmup 5 --details $P/${R}_bench_default_full.json > $P/${R}_bench_default.stdout 2> $P/${R}_bench_default.stderr      # the driver's command: headline + every other config as config.also legs + the CPU baseline
 python bench.py --steps 20 --warmup 5 --threshold 0.4 --also none > $P/${R}_bench_t04.stdout 2> $P/${R}_bench_t04.stderr
 ls $P | wc -l
