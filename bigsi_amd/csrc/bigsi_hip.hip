@@ -1134,6 +1134,7 @@ extern "C" int bigsi_hip_batch_destroy(bigsi_hip_batch *b)
     if (b->exp_serial && b->exp_stream) e = hipStreamSynchronize(b->exp_stream);      // an export still writing into pin_out
     if (b->gstream && b->g_done) e = hipEventSynchronize(b->g_done);
     (void)e;
+    b->planes.release();
     for (DevBuf *d : {&b->uniq, &b->upload, &b->pres_desc, &b->elem_seq_off, &b->pres_in, &b->pres_bits, &b->pres_out, &b->rows_sorted, &b->pos_query, &b->hsh, &b->rep, &b->seqs, &b->d_seq_off, &b->d_pos_off, &b->d_tab_off, &b->tab, &b->first_pos, &b->pos_unique, &b->tmp, &b->rows,
                       &b->num_kmers, &b->num_unique, &b->min_kmers, &b->bitmaps, &b->counts, &b->scratch})
         d->release();
@@ -1185,6 +1186,8 @@ struct CountLaunch {
     uint32_t sparse, slices;
     bool deep;                  // software-pipelined row loads (small grids; h = 3 or 4 only)
     uint32_t early_exit;        // BIGSI_RUN_EARLY_EXIT on a hits-only, one-slice run
+    uint64_t *partial;          // slices > 1: bit-sliced partial counts of every slice (k_count_combine adds them up)
+    uint32_t planes_out;
 };
 
 template <int P, typename CountT>
@@ -1195,7 +1198,7 @@ static void launch_count_wide(bigsi_hip_batch *b, const CountLaunch &c, uint32_t
 #define BIGSI_COUNT_ARGS                                                                                                      \
     dim3(grid), dim3(c.block), 0, ix->stream, ix->d_index, ix->stride_words, (uint32_t)b->wv, c.k2_rows, b->d_pos_off.as<uint64_t>(), \
         b->num_unique.as<uint32_t>(), ix->h, q0, q1, c.tiles, (CountT *)c.out, c.out_stride, b->min_kmers.as<uint32_t>(), ix->n_cols,  \
-        c.hit_bitmap, b->wv_pad, c.sparse, c.slices, c.early_exit
+        c.hit_bitmap, b->wv_pad, c.sparse, c.slices, c.early_exit, c.partial, c.planes_out
 #define COMMA ,
 #define BIGSI_LAUNCH_COUNT(H) hipLaunchKernelGGL((k_and_count<P, H, CountT>), BIGSI_COUNT_ARGS)
 #define BIGSI_LAUNCH_COUNT_DEEP(H)                                                                        \
@@ -1594,7 +1597,7 @@ int bigsi_batch_run(bigsi_hip_batch *b, double threshold, uint32_t flags, bool o
     // (not for the few queries of a latency-bound call either: their row lists are cut into slices over many workgroups -- see
     // `slices` below -- and the ordering buys nothing, it only lengthens the chain of kernels: 10 us of a 65 us single query)
     // caller-owned result buffers (a shard's slot of a gather buffer): a bitmap can be preset and sliced like the batch's own
-    // (the counting path then cuts its hit mask from the summed counters, k_mask_from_counts); caller-owned counters are
+    // (the counting path then cuts its hit mask from the slices' summed partial counts, k_count_combine); caller-owned counters are
     // written in place, without presets
     const bool sliceable = !b->ext_counts;
     const bool few = (uint64_t)b->n_seqs * ceil_div(b->wv, 64 * kVec) < 1024 && sliceable;
@@ -1620,10 +1623,6 @@ int bigsi_batch_run(bigsi_hip_batch *b, double threshold, uint32_t flags, bool o
         uint64_t *out = (uint64_t *)b->ext_bitmaps;
         if (!out) { TRY(b->bitmaps.reserve((size_t)b->n_seqs * b->wv_pad * 8)); out = b->bitmaps.as<uint64_t>(); }
         preset.p = out; preset.words = b->wv_pad; preset.value = ~0ull;
-    } else if (slices > 1) {
-        const uint32_t cb = P <= 16 ? 2 : 4;
-        TRY(b->counts.reserve((size_t)b->n_seqs * b->wv_pad * 64 * cb));
-        preset.p = b->counts.as<uint64_t>(); preset.words = b->wv_pad * 8 * cb; preset.value = 0;
     }
     // K1 (its LDS route emits the sorted list itself; the other routes leave that to k_sort_rows below)
     EventPair ep{};
@@ -1746,9 +1745,18 @@ int bigsi_batch_run(bigsi_hip_batch *b, double threshold, uint32_t flags, bool o
         // the kernel also leaves the thresholded hit bitmap (count >= min_kmers), which is what K4 compacts on a single GPU
         TRY(b->bitmaps.reserve((size_t)b->n_seqs * b->wv_pad * 8));
         uint64_t *hb = b->ext_bitmaps ? (uint64_t *)b->ext_bitmaps : b->bitmaps.as<uint64_t>();
-        b->sparse_counts = (flags & BIGSI_RUN_SPARSE_COUNTS) && !b->ext_counts && slices == 1;
+        b->sparse_counts = (flags & BIGSI_RUN_SPARSE_COUNTS) && !b->ext_counts;
         const uint32_t sparse = b->sparse_counts ? 1u : 0u;
-        if (slices > 1 && !preset.done) HIP_TRY(hipMemsetAsync(out, 0, (size_t)b->n_seqs * cstride * b->count_bytes, ix->stream));
+        // a sliced (small) batch: every slice leaves its partial counts bit-sliced in scratch memory -- as many planes as a slice's
+        // k-mers need -- and k_count_combine adds them up, thresholds and expands (no presets, no atomics)
+        uint32_t planes_out = 0;
+        uint64_t *partial = nullptr;
+        if (slices > 1) {
+            const uint64_t per_slice = ceil_div(std::max<uint64_t>(b->max_pos, 1), slices);
+            while (planes_out < (uint32_t)P && (per_slice >> planes_out) != 0) planes_out++;
+            TRY(b->planes.reserve((size_t)b->n_seqs * slices * planes_out * b->wv_pad * 8));
+            partial = b->planes.as<uint64_t>();
+        }
         TRY(ev_begin(ix, &ep, nullptr, true));
         // fewer than ~3 wavefronts per SIMD in the whole grid (e.g. 128 gene-length queries): the software-pipelined loop,
         // whose wavefronts load the next k-mers' rows while adding the current ones (5.6 -> 6.3 TB/s at 128 x 2-4 kbp; with a
@@ -1758,17 +1766,22 @@ int bigsi_batch_run(bigsi_hip_batch *b, double threshold, uint32_t flags, bool o
         // (only with >= 12 planes, i.e. queries of >= 1024 k-mers: at 10 planes the ALU phase is short and it measured -2 %)
         const bool deep = deep_env >= 0 ? deep_env != 0 : (slices == 1 && P >= 12 && grid_waves < 3 * 1024);
         const uint32_t early = ((flags & BIGSI_RUN_EARLY_EXIT) && sparse && slices == 1) ? 1u : 0u;
-        const CountLaunch cl{k2_rows, (unsigned)and_block, tiles, out, cstride, hb, sparse, slices, deep && !early, early};
+        const CountLaunch cl{k2_rows, (unsigned)and_block, tiles, out, cstride, hb, sparse, slices, deep && !early, early, partial, planes_out};
         for (uint32_t q0 = 0; q0 < b->n_seqs; q0 += chunk_q, n_launches++)
             launch_count(b, P, cl, q0, (uint32_t)std::min<uint64_t>((uint64_t)q0 + chunk_q, b->n_seqs));
-        if (slices > 1) {        // partial counts were summed by the slices: the hit mask from the totals
-            const uint64_t items = (uint64_t)b->n_seqs * b->wv * 8;      // one thread per mask byte
-            if (b->count_bytes == 2)
-                hipLaunchKernelGGL((k_mask_from_counts<uint16_t>), dim3((unsigned)ceil_div(items, kBlock)), dim3(kBlock), 0, ix->stream, (const uint16_t *)out,
-                                   cstride, b->min_kmers.as<uint32_t>(), ix->n_cols, hb, b->wv_pad, (uint32_t)b->wv, b->n_seqs);
-            else
-                hipLaunchKernelGGL((k_mask_from_counts<uint32_t>), dim3((unsigned)ceil_div(items, kBlock)), dim3(kBlock), 0, ix->stream, (const uint32_t *)out,
-                                   cstride, b->min_kmers.as<uint32_t>(), ix->n_cols, hb, b->wv_pad, (uint32_t)b->wv, b->n_seqs);
+        if (slices > 1) {        // the slices' partial counts -> totals, hit mask, counters
+            const unsigned grid = (unsigned)(b->n_seqs * ceil_div(b->wv, kBlock));
+#define BIGSI_COMBINE(PP, T)                                                                                                          \
+    hipLaunchKernelGGL((k_count_combine<PP, T>), dim3(grid), dim3(kBlock), 0, ix->stream, partial, slices, planes_out, b->wv_pad, (uint32_t)b->wv, \
+                       b->n_seqs, b->num_unique.as<uint32_t>(), b->min_kmers.as<uint32_t>(), ix->n_cols, hb, (T *)out, cstride, sparse)
+            switch (P) {
+            case 6: BIGSI_COMBINE(6, uint16_t); break;
+            case 10: BIGSI_COMBINE(10, uint16_t); break;
+            case 12: BIGSI_COMBINE(12, uint16_t); break;
+            case 16: BIGSI_COMBINE(16, uint16_t); break;
+            default: BIGSI_COMBINE(32, uint32_t); break;
+            }
+#undef BIGSI_COMBINE
         }
         HIP_TRY(hipGetLastError());
         TRY(ev_end(ix, &ep, ix->ev_and, nullptr, n_launches));

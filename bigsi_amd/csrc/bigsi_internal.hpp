@@ -165,6 +165,7 @@ struct bigsi_hip_batch {
     DevBuf pos_query, hsh, rep;   // per k-mer position: owning sequence, dedupe hash, class representative
     DevBuf rows_sorted;           // the row ids K2 streams: each query's list in address order (k_sort_rows)
     DevBuf bitmaps, counts, scratch;
+    DevBuf planes;                // sliced counting runs: every slice's bit-sliced partial counts (k_count_combine)
     uint64_t run_serial = 0, marks_of_run = ~0ull;   // K1 runs of this batch; the run whose piece marks pres_desc holds
     const void *marks_at = nullptr;                  // ... and where (pres_desc may have been reallocated since)
     // deferred loads and exported results (the one-call and streaming entry points): pinned staging the batch owns

@@ -882,8 +882,11 @@ __global__ __launch_bounds__(kBlock) void k_and_count(
     uint32_t h_rt, uint32_t q0, uint32_t n_seqs, uint32_t tiles, CountT *__restrict__ out, uint64_t out_stride /* counters per query */,
     const uint32_t *__restrict__ min_kmers, uint64_t n_cols, uint64_t *__restrict__ hit_bitmap /* [seq][bm_stride] or null */,
     uint64_t bm_stride, uint32_t sparse /* 1: store counters only for words that contain a hit */,
-    uint32_t slices /* > 1: counters were preset to zero, slices add into them atomically; no fused threshold */,
-    uint32_t early_exit /* 1 (only with sparse, one slice): a wavefront stops fetching once none of its 8192 columns can reach min_kmers */)
+    uint32_t slices /* > 1: a small batch, every query's k-mers cut into slices handled by different workgroups */,
+    uint32_t early_exit /* 1 (only with sparse, one slice): a wavefront stops fetching once none of its 8192 columns can reach min_kmers */,
+    uint64_t *__restrict__ partial /* slices > 1: where a slice leaves the low `planes_out` planes of its partial counts, bit-sliced as
+                                      they are -- [query][slice][plane][bm_stride words]; k_count_combine adds the slices up */,
+    uint32_t planes_out)
 {
     const TileMap tm = map_block(blockIdx.x, q0, n_seqs, tiles, slices);
     if (!tm.valid) return;
@@ -994,13 +997,21 @@ __global__ __launch_bounds__(kBlock) void k_and_count(
         add(a);
     }
 
+    if (slices > 1) {
+        // a slice of a small batch: its partial counts stay bit-sliced -- a slice of s k-mers needs ceil(log2(s + 1)) planes, 5 for the
+        // 16 k-mers of a 1 kbp query's slice -- and go to scratch memory as coalesced 16-byte stores; k_count_combine adds the slices of
+        // a word with bit-sliced adders, thresholds and expands.  (Round 3 expanded every slice's planes to integers and added them
+        // with packed atomics: 31 us for one 1 kbp query on 100 k samples, against 14 us for the exact AND of the same rows.)
+        uint64_t *o = partial + ((uint64_t)tm.q * slices + tm.slice) * planes_out * bm_stride + w0;
+#pragma unroll
+        for (int p = 0; p < P; p++)
+            if ((uint32_t)p < planes_out) *reinterpret_cast<u64x2 *>(o + (uint64_t)p * bm_stride) = u64x2{pl[0][p], pl[1][p]};
+        return;
+    }
     // threshold in bit-sliced form (graph/bigsi.py:241-242: count >= min_kmers): MSB-first comparator over the planes,
     // ~2 bit-ops per plane per word; the threshold is wave-uniform so its bit tests are scalar branches
     uint64_t ge[kVec];
-    if (slices > 1) {
-#pragma unroll
-        for (int v = 0; v < kVec; v++) ge[v] = ~0ull;      // partial counts: thresholding happens in K4, from the summed counters
-    } else {
+    {
         const uint32_t thr = min_kmers[tm.q];
 #pragma unroll
         for (int v = 0; v < kVec; v++) {
@@ -1037,20 +1048,7 @@ __global__ __launch_bounds__(kBlock) void k_and_count(
                 for (int p = 0; p < P; p++) x |= (uint32_t)((pl[v][p] >> bit) & 1ull) << p;
                 c[jj] = (CountT)x;
             }
-            if (slices > 1) {
-                // partial sums never exceed the query's k-mer count, so packed uint16 pairs cannot carry into each other
-                if (sizeof(CountT) == 2) {
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const uint32_t pk = (uint32_t)c[2 * i] | ((uint32_t)c[2 * i + 1] << 16);
-                        if (pk) atomicAdd(reinterpret_cast<uint32_t *>(o + 8 * b) + i, pk);
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 8; i++)
-                        if (c[i]) atomicAdd(reinterpret_cast<uint32_t *>(o + 8 * b) + i, (uint32_t)c[i]);
-                }
-            } else if (sizeof(CountT) == 2) {
+            if (sizeof(CountT) == 2) {
                 uint4 pk;
                 pk.x = (uint32_t)c[0] | ((uint32_t)c[1] << 16); pk.y = (uint32_t)c[2] | ((uint32_t)c[3] << 16);
                 pk.z = (uint32_t)c[4] | ((uint32_t)c[5] << 16); pk.w = (uint32_t)c[6] | ((uint32_t)c[7] << 16);
@@ -1065,6 +1063,73 @@ __global__ __launch_bounds__(kBlock) void k_and_count(
     }
 }
 
+
+// The slices of a small counting batch added up: thread = one 64-column word of one query.  Every slice's partial count of the word
+// (planes_in bit planes) is added into P accumulator planes with a bit-sliced ripple-carry adder (~5 bit-ops per plane), then the
+// word is thresholded (count >= min_kmers, graph/bigsi.py:241-242) into the hit mask that K4 compacts and column shards exchange, and
+// its counters are expanded -- all of them, or (sparse) only those of words that hold a hit.
+template <int P, typename CountT>
+__global__ __launch_bounds__(kBlock) void k_count_combine(
+    const uint64_t *__restrict__ partial, uint32_t slices, uint32_t planes_in, uint64_t bm_stride, uint32_t wv, uint32_t n_seqs,
+    const uint32_t *__restrict__ num_unique, const uint32_t *__restrict__ min_kmers, uint64_t n_cols, uint64_t *__restrict__ hit_bitmap,
+    CountT *__restrict__ out, uint64_t out_stride, uint32_t sparse)
+{
+    const uint32_t per_q = (wv + kBlock - 1) / kBlock, q = blockIdx.x / per_q, w = (blockIdx.x - q * per_q) * kBlock + threadIdx.x;
+    if (q >= n_seqs || w >= wv) return;
+    // (slices that hold no k-mer of this query wrote nothing: the same rule as k_and_count's early return)
+    const uint32_t uall = num_unique[q], per = (uall + slices - 1) / slices;
+    const uint32_t live = per ? (uall + per - 1) / per : 0u;
+    uint64_t acc[P];
+#pragma unroll
+    for (int p = 0; p < P; p++) acc[p] = 0;
+    const uint64_t *src = partial + (uint64_t)q * slices * planes_in * bm_stride + w;
+    for (uint32_t s = 0; s < live; s++, src += (uint64_t)planes_in * bm_stride) {
+        uint64_t carry = 0;
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            const uint64_t x = (uint32_t)p < planes_in ? src[(uint64_t)p * bm_stride] : 0ull;
+            const uint64_t a = acc[p], t = a ^ x;
+            acc[p] = t ^ carry;
+            carry = (a & x) | (carry & t);
+        }
+    }
+    const uint32_t thr = min_kmers[q];
+    uint64_t gt = 0, eq = ~0ull;
+    if (P < 32 && (thr >> (P & 31)) != 0) eq = 0;
+#pragma unroll
+    for (int p = P - 1; p >= 0; p--) {
+        if ((thr >> p) & 1u) eq &= acc[p];
+        else { gt |= eq & acc[p]; eq &= ~acc[p]; }
+    }
+    const uint64_t ge = (gt | eq) & valid_mask(w, n_cols);
+    hit_bitmap[(uint64_t)q * bm_stride + w] = ge;
+    if (sparse && ge == 0) return;
+    CountT *o = out + (uint64_t)q * out_stride + (uint64_t)w * 64;
+    constexpr int kByteUnroll = P > 16 ? 1 : 8;
+#pragma unroll kByteUnroll
+    for (int b = 0; b < 8; b++) {
+        CountT c[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; jj++) {
+            const int bit = 8 * b + 7 - jj;
+            uint32_t x = 0;
+#pragma unroll
+            for (int p = 0; p < P; p++) x |= (uint32_t)((acc[p] >> bit) & 1ull) << p;
+            c[jj] = (CountT)x;
+        }
+        if (sizeof(CountT) == 2) {
+            uint4 pk;
+            pk.x = (uint32_t)c[0] | ((uint32_t)c[1] << 16); pk.y = (uint32_t)c[2] | ((uint32_t)c[3] << 16);
+            pk.z = (uint32_t)c[4] | ((uint32_t)c[5] << 16); pk.w = (uint32_t)c[6] | ((uint32_t)c[7] << 16);
+            *reinterpret_cast<uint4 *>(o + 8 * b) = pk;
+        } else {
+            uint4 lo{(uint32_t)c[0], (uint32_t)c[1], (uint32_t)c[2], (uint32_t)c[3]};
+            uint4 hi{(uint32_t)c[4], (uint32_t)c[5], (uint32_t)c[6], (uint32_t)c[7]};
+            *reinterpret_cast<uint4 *>(o + 8 * b) = lo;
+            *reinterpret_cast<uint4 *>(o + 8 * b + 4) = hi;
+        }
+    }
+}
 
 // ------------------------------------------------------------------------------ K4: threshold + compaction
 // Result buffers are laid out [shard][seq][stride] (n_shards = 1 for a single GPU; > 1 for buffers gathered from column
@@ -1473,34 +1538,6 @@ __global__ __launch_bounds__(kBlock) void k_reads_fused(
     }
 }
 
-// A row-sliced counting run (small batches) cannot threshold inside k_and_count -- every slice holds partial counts -- so
-// the hit mask (count >= min_kmers, graph/bigsi.py:241-242; row byte format: column c at bit 7 - (c & 7) of byte c >> 3)
-// is cut from the summed counters afterwards: one thread per mask byte = 8 consecutive counters, so that a wavefront reads
-// its counters as one contiguous run (a thread per 64-column word: 11 us for one query's 100 k counters).  The mask is
-// what K4 compacts and what column shards exchange.
-template <typename CountT>
-__global__ __launch_bounds__(kBlock) void k_mask_from_counts(
-    const CountT *__restrict__ counts, uint64_t cstride /* counters per query */, const uint32_t *__restrict__ min_kmers,
-    uint64_t n_cols, uint64_t *__restrict__ mask, uint64_t bm_stride, uint32_t wv, uint32_t n_seqs)
-{
-    const uint64_t item = (uint64_t)blockIdx.x * kBlock + threadIdx.x, per_q = (uint64_t)wv * 8;
-    if (item >= (uint64_t)n_seqs * per_q) return;
-    // (32-bit division whenever the grid allows it: the 64-bit routine is ~100 instructions)
-    const uint32_t q = (item >> 32) == 0 ? (uint32_t)item / (uint32_t)per_q : (uint32_t)(item / per_q);
-    const uint64_t byte = item - (uint64_t)q * per_q, c0 = byte * 8;
-    const uint32_t thr = min_kmers[q];
-    const CountT *c = counts + (uint64_t)q * cstride + c0;
-    CountT v[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) v[j] = c[j];                      // 16 (32) contiguous, aligned bytes: cstride is a multiple of 64
-    uint32_t bits = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++)
-        if (c0 + j < n_cols && (uint32_t)v[j] >= thr) bits |= 0x80u >> j;
-    reinterpret_cast<uint8_t *>(mask + (uint64_t)q * bm_stride)[byte] = (uint8_t)bits;
-}
-
-// counting: a hit is a column with count >= min_kmers[q] (graph/bigsi.py:241-242); column < shard_cols only.
 template <typename CountT, bool WRITE>
 __global__ __launch_bounds__(kBlock) void k_hits_count(
     const CountT *__restrict__ counts, uint64_t stride, uint32_t /*wv: unused, keeps both K4 signatures alike*/,
