@@ -1770,7 +1770,7 @@ int bigsi_batch_run(bigsi_hip_batch *b, double threshold, uint32_t flags, bool o
         for (uint32_t q0 = 0; q0 < b->n_seqs; q0 += chunk_q, n_launches++)
             launch_count(b, P, cl, q0, (uint32_t)std::min<uint64_t>((uint64_t)q0 + chunk_q, b->n_seqs));
         if (slices > 1) {        // the slices' partial counts -> totals, hit mask, counters
-            const unsigned grid = (unsigned)(b->n_seqs * ceil_div(b->wv, kBlock));
+            const unsigned grid = (unsigned)(b->n_seqs * ceil_div(b->wv, kBlock / 8));      // 32 words per workgroup, 8 slice groups per word
 #define BIGSI_COMBINE(PP, T)                                                                                                          \
     hipLaunchKernelGGL((k_count_combine<PP, T>), dim3(grid), dim3(kBlock), 0, ix->stream, partial, slices, planes_out, b->wv_pad, (uint32_t)b->wv, \
                        b->n_seqs, b->num_unique.as<uint32_t>(), b->min_kmers.as<uint32_t>(), ix->n_cols, hb, (T *)out, cstride, sparse)

@@ -1064,35 +1064,73 @@ __global__ __launch_bounds__(kBlock) void k_and_count(
 }
 
 
-// The slices of a small counting batch added up: thread = one 64-column word of one query.  Every slice's partial count of the word
-// (planes_in bit planes) is added into P accumulator planes with a bit-sliced ripple-carry adder (~5 bit-ops per plane), then the
-// word is thresholded (count >= min_kmers, graph/bigsi.py:241-242) into the hit mask that K4 compacts and column shards exchange, and
-// its counters are expanded -- all of them, or (sparse) only those of words that hold a hit.
+// The slices of a small counting batch added up.  A workgroup owns 32 consecutive 64-column words of one query; its 256 threads are
+// 8 groups of 32 (thread = word x group), group g adding the slices g, g + 8, ... of its word with a bit-sliced ripple-carry adder
+// (~5 bit-ops per plane), four slices' planes loaded at a time so that a thread has 4 x planes_in loads in flight (one thread per
+// word walking all 60 slices of a 1 kbp query was 38 us of dependent round trips).  The eight partial sums meet in LDS; the word is
+// thresholded (count >= min_kmers, graph/bigsi.py:241-242) into the hit mask that K4 compacts and column shards exchange, and its
+// counters are expanded -- all of them, or (sparse) only those of words that hold a hit -- every group taking one byte (8 columns).
 template <int P, typename CountT>
 __global__ __launch_bounds__(kBlock) void k_count_combine(
     const uint64_t *__restrict__ partial, uint32_t slices, uint32_t planes_in, uint64_t bm_stride, uint32_t wv, uint32_t n_seqs,
     const uint32_t *__restrict__ num_unique, const uint32_t *__restrict__ min_kmers, uint64_t n_cols, uint64_t *__restrict__ hit_bitmap,
     CountT *__restrict__ out, uint64_t out_stride, uint32_t sparse)
 {
-    const uint32_t per_q = (wv + kBlock - 1) / kBlock, q = blockIdx.x / per_q, w = (blockIdx.x - q * per_q) * kBlock + threadIdx.x;
-    if (q >= n_seqs || w >= wv) return;
+    constexpr int G = 8, W = kBlock / G;                 // groups, words per workgroup
+    __shared__ uint64_t red[G][P][W];
+    const uint32_t wl = threadIdx.x & (W - 1), g = threadIdx.x / W;
+    const uint32_t per_q = (wv + W - 1) / W, q = blockIdx.x / per_q, w = (blockIdx.x - q * per_q) * W + wl;
+    if (q >= n_seqs) return;                             // (whole workgroup)
+    const bool live_w = w < wv;
     // (slices that hold no k-mer of this query wrote nothing: the same rule as k_and_count's early return)
     const uint32_t uall = num_unique[q], per = (uall + slices - 1) / slices;
     const uint32_t live = per ? (uall + per - 1) / per : 0u;
     uint64_t acc[P];
 #pragma unroll
     for (int p = 0; p < P; p++) acc[p] = 0;
-    const uint64_t *src = partial + (uint64_t)q * slices * planes_in * bm_stride + w;
-    for (uint32_t s = 0; s < live; s++, src += (uint64_t)planes_in * bm_stride) {
-        uint64_t carry = 0;
+    const uint64_t slice_words = (uint64_t)planes_in * bm_stride;
+    const uint64_t *base = partial + (uint64_t)q * slices * slice_words + w;
+    if (live_w) {
+        for (uint32_t s0 = g; s0 < live; s0 += 4 * G) {
+            uint64_t x[4][P];
 #pragma unroll
-        for (int p = 0; p < P; p++) {
-            const uint64_t x = (uint32_t)p < planes_in ? src[(uint64_t)p * bm_stride] : 0ull;
-            const uint64_t a = acc[p], t = a ^ x;
-            acc[p] = t ^ carry;
-            carry = (a & x) | (carry & t);
+            for (int k = 0; k < 4; k++)
+#pragma unroll
+                for (int p = 0; p < P; p++)
+                    x[k][p] = (s0 + k * G < live && (uint32_t)p < planes_in) ? base[(uint64_t)(s0 + k * G) * slice_words + (uint64_t)p * bm_stride] : 0ull;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                uint64_t carry = 0;
+#pragma unroll
+                for (int p = 0; p < P; p++) {
+                    const uint64_t a = acc[p], t = a ^ x[k][p];
+                    acc[p] = t ^ carry;
+                    carry = (a & x[k][p]) | (carry & t);
+                }
+            }
         }
     }
+#pragma unroll
+    for (int p = 0; p < P; p++) red[g][p][wl] = acc[p];
+    __syncthreads();
+    if (g == 0) {                                        // the eight partial sums of a word -> its total, into red[0]
+#pragma unroll 1
+        for (int k = 1; k < G; k++) {
+            uint64_t carry = 0;
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                const uint64_t x = red[k][p][wl], a = acc[p], t = a ^ x;
+                acc[p] = t ^ carry;
+                carry = (a & x) | (carry & t);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < P; p++) red[0][p][wl] = acc[p];
+    }
+    __syncthreads();
+    if (!live_w) return;
+#pragma unroll
+    for (int p = 0; p < P; p++) acc[p] = red[0][p][wl];
     const uint32_t thr = min_kmers[q];
     uint64_t gt = 0, eq = ~0ull;
     if (P < 32 && (thr >> (P & 31)) != 0) eq = 0;
@@ -1102,32 +1140,29 @@ __global__ __launch_bounds__(kBlock) void k_count_combine(
         else { gt |= eq & acc[p]; eq &= ~acc[p]; }
     }
     const uint64_t ge = (gt | eq) & valid_mask(w, n_cols);
-    hit_bitmap[(uint64_t)q * bm_stride + w] = ge;
+    if (g == 0) hit_bitmap[(uint64_t)q * bm_stride + w] = ge;
     if (sparse && ge == 0) return;
-    CountT *o = out + (uint64_t)q * out_stride + (uint64_t)w * 64;
-    constexpr int kByteUnroll = P > 16 ? 1 : 8;
-#pragma unroll kByteUnroll
-    for (int b = 0; b < 8; b++) {
-        CountT c[8];
+    // group g expands byte g of the word: columns 8g .. 8g + 7 (column 8b + jj sits at bit 8b + 7 - jj)
+    CountT *o = out + (uint64_t)q * out_stride + (uint64_t)w * 64 + 8 * g;
+    CountT c[8];
 #pragma unroll
-        for (int jj = 0; jj < 8; jj++) {
-            const int bit = 8 * b + 7 - jj;
-            uint32_t x = 0;
+    for (int jj = 0; jj < 8; jj++) {
+        const uint32_t bit = 8 * g + 7 - jj;
+        uint32_t x = 0;
 #pragma unroll
-            for (int p = 0; p < P; p++) x |= (uint32_t)((acc[p] >> bit) & 1ull) << p;
-            c[jj] = (CountT)x;
-        }
-        if (sizeof(CountT) == 2) {
-            uint4 pk;
-            pk.x = (uint32_t)c[0] | ((uint32_t)c[1] << 16); pk.y = (uint32_t)c[2] | ((uint32_t)c[3] << 16);
-            pk.z = (uint32_t)c[4] | ((uint32_t)c[5] << 16); pk.w = (uint32_t)c[6] | ((uint32_t)c[7] << 16);
-            *reinterpret_cast<uint4 *>(o + 8 * b) = pk;
-        } else {
-            uint4 lo{(uint32_t)c[0], (uint32_t)c[1], (uint32_t)c[2], (uint32_t)c[3]};
-            uint4 hi{(uint32_t)c[4], (uint32_t)c[5], (uint32_t)c[6], (uint32_t)c[7]};
-            *reinterpret_cast<uint4 *>(o + 8 * b) = lo;
-            *reinterpret_cast<uint4 *>(o + 8 * b + 4) = hi;
-        }
+        for (int p = 0; p < P; p++) x |= (uint32_t)((acc[p] >> bit) & 1ull) << p;
+        c[jj] = (CountT)x;
+    }
+    if (sizeof(CountT) == 2) {
+        uint4 pk;
+        pk.x = (uint32_t)c[0] | ((uint32_t)c[1] << 16); pk.y = (uint32_t)c[2] | ((uint32_t)c[3] << 16);
+        pk.z = (uint32_t)c[4] | ((uint32_t)c[5] << 16); pk.w = (uint32_t)c[6] | ((uint32_t)c[7] << 16);
+        *reinterpret_cast<uint4 *>(o) = pk;
+    } else {
+        uint4 lo{(uint32_t)c[0], (uint32_t)c[1], (uint32_t)c[2], (uint32_t)c[3]};
+        uint4 hi{(uint32_t)c[4], (uint32_t)c[5], (uint32_t)c[6], (uint32_t)c[7]};
+        *reinterpret_cast<uint4 *>(o) = lo;
+        *reinterpret_cast<uint4 *>(o + 4) = hi;
     }
 }
 
