@@ -1261,6 +1261,7 @@ struct K1Src {
     const char *seqs;
     const uint64_t *seq_off, *pos_off;
     uint64_t *pos_off_out;
+    uint32_t one_len;          // > 0: the batch is one sequence of this length, read in place (no offset tables to fetch)
 };
 
 static K1Src k1_src(const bigsi_hip_batch *b)
@@ -1269,9 +1270,9 @@ static K1Src k1_src(const bigsi_hip_batch *b)
         const uint8_t *h = static_cast<const uint8_t *>(b->pin_up);
         const size_t ob = (b->n_seqs + 1) * 8ull;
         return K1Src{reinterpret_cast<const char *>(h + 3 * ob), reinterpret_cast<const uint64_t *>(h), reinterpret_cast<const uint64_t *>(h + ob),
-                     b->d_pos_off.as<uint64_t>()};
+                     b->d_pos_off.as<uint64_t>(), b->n_seqs == 1 && b->max_len ? (uint32_t)b->max_len : 0u};
     }
-    return K1Src{b->seqs.as<char>(), b->d_seq_off.as<uint64_t>(), b->d_pos_off.as<uint64_t>(), nullptr};
+    return K1Src{b->seqs.as<char>(), b->d_seq_off.as<uint64_t>(), b->d_pos_off.as<uint64_t>(), nullptr, 0u};
 }
 
 static int launch_reads_fused(bigsi_hip_batch *b, hipStream_t st = nullptr, uint64_t spin_timeout = kSpinTimeout)
@@ -1311,7 +1312,7 @@ static int launch_reads_fused(bigsi_hip_batch *b, hipStream_t st = nullptr, uint
         src.seqs, src.seq_off, src.pos_off, b->n_seqs, b->first_pos.as<uint32_t>(),                                                       \
         b->pos_unique.as<uint32_t>(), b->rep.as<uint32_t>(), b->rows.as<uint64_t>(), b->num_kmers.as<uint32_t>(),                      \
         b->num_unique.as<uint32_t>(), b->min_kmers.as<uint32_t>(), b->bitmaps.as<uint64_t>(), b->wv_pad, hb.lb_state.as<uint64_t>(),  \
-        hb.gen, hb.hit_off.as<uint64_t>(), hb.col(), hb.cnt(), hb.capacity(), fp_mask, spin_timeout, src.pos_off_out
+        hb.gen, hb.hit_off.as<uint64_t>(), hb.col(), hb.cnt(), hb.capacity(), fp_mask, spin_timeout, src.pos_off_out, src.one_len
 #define COMMA ,
 #define BIGSI_READS(H)                                                                              \
     if (b->exact) hipLaunchKernelGGL((k_reads_fused<H COMMA true>), BIGSI_READS_ARGS);                \
@@ -1444,7 +1445,7 @@ static int run_kmerize(bigsi_hip_batch *b, double threshold, bool force_global =
                        src.pos_off, b->k, ix->h, ix->m, threshold, tab_cap, tab_mult, hs_cap, sq_bytes, b->first_pos.as<uint32_t>(), b->tmp.as<uint32_t>(), \
                        b->pos_unique.as<uint32_t>(), b->rep.as<uint32_t>(), b->rows.as<uint64_t>(), b->num_kmers.as<uint32_t>(),      \
                        b->num_unique.as<uint32_t>(), b->min_kmers.as<uint32_t>(), want_sorted ? b->rows_sorted.as<uint64_t>() : (uint64_t *)nullptr, \
-                       ps_p, ps_words, ps_value, src.pos_off_out)
+                       ps_p, ps_words, ps_value, src.pos_off_out, src.one_len)
         if (b->k == 31) BIGSI_K1_LDS(31);
         else BIGSI_K1_LDS(0);
 #undef BIGSI_K1_LDS

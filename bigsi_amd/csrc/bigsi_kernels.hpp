@@ -454,12 +454,18 @@ __global__ __launch_bounds__(1024) void k_kmerize_lds(
                                      (latency-bound) row-AND launches combine into with atomics; saves a memset launch per call */,
     uint64_t preset_words, uint64_t preset_value,
     uint64_t *__restrict__ pos_off_out /* non-null: seqs / seq_off / pos_off are read straight from pinned host memory (a one-call
-                                          search: no upload); the device copy of pos_off the later kernels read is written here */)
+                                          search: no upload); the device copy of pos_off the later kernels read is written here */,
+    uint32_t one_len /* > 0: the batch is ONE sequence of this length (its offset tables need not be read: a PCIe round trip less) */)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     if (pos_off_out && threadIdx.x == 0) {
-        pos_off_out[blockIdx.x] = pos_off[blockIdx.x];
-        if (blockIdx.x + 1 == gridDim.x) pos_off_out[gridDim.x] = pos_off[gridDim.x];
+        if (one_len) {
+            pos_off_out[0] = 0;
+            pos_off_out[1] = one_len >= k ? one_len - k + 1 : 0u;
+        } else {
+            pos_off_out[blockIdx.x] = pos_off[blockIdx.x];
+            if (blockIdx.x + 1 == gridDim.x) pos_off_out[gridDim.x] = pos_off[gridDim.x];
+        }
     }
     if (preset) {
         uint64_t *pq = preset + (uint64_t)blockIdx.x * preset_words;
@@ -471,10 +477,10 @@ __global__ __launch_bounds__(1024) void k_kmerize_lds(
     char *sq = reinterpret_cast<char *>(hs + hs_cap);    // the query's bytes
     char *sc = sq + sq_bytes;                            // KF == 31: their complements, 4 pad bytes in front (kmer31_canonical_premix)
     const uint32_t q = blockIdx.x;
-    const char *s = seqs + seq_off[q];
-    const uint32_t len = (uint32_t)(seq_off[q + 1] - seq_off[q]);
+    const char *s = one_len ? seqs : seqs + seq_off[q];
+    const uint32_t len = one_len ? one_len : (uint32_t)(seq_off[q + 1] - seq_off[q]);
     const uint32_t n = len >= k ? len - k + 1 : 0u;
-    const uint64_t P = pos_off[q];
+    const uint64_t P = one_len ? 0ull : pos_off[q];
     uint32_t tsize = 2;
     while (tsize < tab_mult * n) tsize <<= 1;            // load factor <= 1/tab_mult: short probe chains
     const uint32_t mask = tsize - 1;
@@ -1344,12 +1350,18 @@ __global__ __launch_bounds__(kBlock) void k_reads_fused(
     uint64_t *__restrict__ out_bits, uint64_t out_stride_words,
     uint64_t *__restrict__ state, uint32_t gen, uint64_t *__restrict__ hit_off, uint32_t *__restrict__ hit_col, uint32_t *__restrict__ hit_cnt,
     uint64_t capacity, uint32_t fp_mask /* ~0; 1 = BIGSI_RUN_WEAK_FINGERPRINT */, uint64_t spin_timeout /* in 10 ns ticks */,
-    uint64_t *__restrict__ pos_off_out /* as k_kmerize_lds: inputs come straight from pinned host memory */)
+    uint64_t *__restrict__ pos_off_out /* as k_kmerize_lds: inputs come straight from pinned host memory */,
+    uint32_t one_len /* as k_kmerize_lds */)
 {
     constexpr int KF = 31, P = 6;
     if (pos_off_out && threadIdx.x == 0) {
-        pos_off_out[blockIdx.x] = pos_off[blockIdx.x];
-        if (blockIdx.x + 1 == n_seqs) pos_off_out[n_seqs] = pos_off[n_seqs];
+        if (one_len) {
+            pos_off_out[0] = 0;
+            pos_off_out[1] = one_len >= (uint32_t)KF ? one_len - KF + 1 : 0u;
+        } else {
+            pos_off_out[blockIdx.x] = pos_off[blockIdx.x];
+            if (blockIdx.x + 1 == n_seqs) pos_off_out[n_seqs] = pos_off[n_seqs];
+        }
     }
     __shared__ uint64_t s_rows[64 * H], s_hrow[64 * H];   // row ids: of the unique k-mers / of every position, per seed
     __shared__ uint32_t s_seq[24], s_cmp[25];             // the query's bytes (63 positions + 30 = 93 at most); their complements
@@ -1369,10 +1381,10 @@ __global__ __launch_bounds__(kBlock) void k_reads_fused(
     {
         const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
         const uint32_t wave_a = (q >> 8) & 3u, wave_b = (wave_a + 2u) & 3u;
-        const char *s = seqs + seq_off[q];
-        const uint32_t len = (uint32_t)(seq_off[q + 1] - seq_off[q]);
+        const char *s = one_len ? seqs : seqs + seq_off[q];
+        const uint32_t len = one_len ? one_len : (uint32_t)(seq_off[q + 1] - seq_off[q]);
         const uint32_t n = len >= KF ? len - KF + 1 : 0u;      // < 64 by the launch condition
-        const uint64_t P0 = pos_off[q];
+        const uint64_t P0 = one_len ? 0ull : pos_off[q];
         if (threadIdx.x < 100) {                           // s_cmp carries 4 pad bytes in front (the word at byte p - 1 is read)
             const uint32_t t = threadIdx.x;
             const uint8_t c = t < len ? (uint8_t)s[t] : (uint8_t)0;
