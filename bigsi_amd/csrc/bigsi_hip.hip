@@ -471,8 +471,9 @@ int rows_file(bigsi_hip_index *ix, const char *path, uint64_t file_offset, uint6
         return BIGSI_OK;
     };
     rc = body();
-    char keep[1024];
-    if (rc != BIGSI_OK) snprintf(keep, sizeof keep, "%s", bigsi_hip_last_error());
+    if (save && rc == BIGSI_OK && fsync(fd) != 0 && errno != EINVAL && errno != EROFS) rc = fail(BIGSI_ERR_INVALID, "fsync %s: %s", path, strerror(errno));
+    char keep[1024] = "";
+    if (rc != BIGSI_OK) snprintf(keep, sizeof keep, "%s", bigsi_hip_last_error());      // (the clean-up below must not overwrite the message)
     hipError_t e = hipStreamSynchronize(ix->stream);
     for (int i = 0; i < 2; i++) {
         if (pin[i]) e = hipHostFree(pin[i]);
@@ -480,9 +481,8 @@ int rows_file(bigsi_hip_index *ix, const char *path, uint64_t file_offset, uint6
         dev[i].release();
     }
     (void)e;
-    if (save && rc == BIGSI_OK && fsync(fd) != 0 && errno != EINVAL && errno != EROFS) rc = fail(BIGSI_ERR_INVALID, "fsync %s: %s", path, strerror(errno));
     close(fd);
-    if (rc != BIGSI_OK) return fail(rc, "%s", rc == BIGSI_ERR_INVALID && bigsi_hip_last_error()[0] ? (keep[0] ? keep : bigsi_hip_last_error()) : keep);
+    if (rc != BIGSI_OK) return fail(rc, "%s", keep);
     if (st) {
         st->bytes = n_rows * row_bytes;
         st->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
