@@ -21,7 +21,6 @@ RUN_SPARSE_COUNTS = 8
 RUN_NO_SORT = 16
 RUN_EARLY_EXIT = 32
 RUN_WEAK_FINGERPRINT = 64
-RUN_NO_WAITING = 128
 RUN_ONE_STREAM = 256
 BLOOM_RAW = 1
 SCORE_ORDERED = 1

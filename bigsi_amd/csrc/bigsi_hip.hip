@@ -1275,44 +1275,38 @@ static K1Src k1_src(const bigsi_hip_batch *b)
     return K1Src{b->seqs.as<char>(), b->d_seq_off.as<uint64_t>(), b->d_pos_off.as<uint64_t>(), nullptr, 0u};
 }
 
-static int launch_reads_fused(bigsi_hip_batch *b, hipStream_t st = nullptr, uint64_t spin_timeout = kSpinTimeout)
+static int launch_reads_fused(bigsi_hip_batch *b, hipStream_t st = nullptr)
 {
     const uint32_t fp_mask = b->weak_fp ? 1u : ~0u;
     if (!st) st = b->ix->stream;
-    b->fused_settled = false;
     bigsi_hip_index *ix = b->ix;
     HitBufs &hb = b->hits;
     TRY(b->bitmaps.reserve((size_t)b->n_seqs * b->wv_pad * 8));
-    if (hb.hit_off.cap < (b->n_seqs + 2) * 8ull) {        // offsets, total, and the word a launch that gave up waiting marks
-        TRY(hb.hit_off.reserve((b->n_seqs + 2) * 8ull));
-        HIP_TRY(hipMemsetAsync(hb.hit_off.p, 0, hb.hit_off.cap, st));      // (fresh memory must not look like a mark)
-    }
+    TRY(hb.hit_off.reserve((b->n_seqs + 2) * 8ull));          // (query-ordered offsets: filled by whoever orders the lists)
     if (hb.cap == 0 && !hb.xcol) {
         const uint64_t want = 1u << 16;
         TRY(hb.hit_col.reserve(want * 4));
         TRY(hb.hit_cnt.reserve(want * 4));
         hb.cap = want;
     }
-    {   // one word per query + one per section of kReadsSection queries (at least what the compaction kernels expect)
-        const uint64_t need = std::max<uint64_t>((uint64_t)b->n_seqs + b->n_seqs / kReadsSection + 2, kHitsMaxGroups) * 8;
-        if (hb.lb_state.cap < need) {
-            TRY(hb.lb_state.reserve(need));
-            HIP_TRY(hipMemsetAsync(hb.lb_state.p, 0, hb.lb_state.cap, st));
-            hb.gen = 0;
-        }
+    // per query: where its hits start in the hit buffers and how many they are; two allocation counters used alternately (a
+    // launch zeroes the one its successor will use: launches of one batch never overlap)
+    TRY(hb.q_start.reserve((size_t)b->n_seqs * 8));
+    TRY(hb.q_cnt.reserve((size_t)b->n_seqs * 4));
+    if (!hb.alloc.p) {
+        TRY(hb.alloc.reserve(256));
+        HIP_TRY(hipMemsetAsync(hb.alloc.p, 0, 256, st));
+        hb.gen = 0;
     }
-    if (++hb.gen >= (1u << 20)) {
-        HIP_TRY(hipMemsetAsync(hb.lb_state.p, 0, hb.lb_state.cap, st));
-        HIP_TRY(hipMemsetAsync(hb.hit_off.p, 0, hb.hit_off.cap, st));
-        hb.gen = 1;
-    }
+    hb.gen++;
     const K1Src src = k1_src(b);
 #define BIGSI_READS_ARGS                                                                                                          \
     dim3(b->n_seqs), dim3(kBlock), 0, st, ix->d_index, ix->stride_words, (uint32_t)b->wv, ix->n_cols, ix->m, b->threshold,              \
         src.seqs, src.seq_off, src.pos_off, b->n_seqs, b->first_pos.as<uint32_t>(),                                                       \
         b->pos_unique.as<uint32_t>(), b->rep.as<uint32_t>(), b->rows.as<uint64_t>(), b->num_kmers.as<uint32_t>(),                      \
-        b->num_unique.as<uint32_t>(), b->min_kmers.as<uint32_t>(), b->bitmaps.as<uint64_t>(), b->wv_pad, hb.lb_state.as<uint64_t>(),  \
-        hb.gen, hb.hit_off.as<uint64_t>(), hb.col(), hb.cnt(), hb.capacity(), fp_mask, spin_timeout, src.pos_off_out, src.one_len
+        b->num_unique.as<uint32_t>(), b->min_kmers.as<uint32_t>(), b->bitmaps.as<uint64_t>(), b->wv_pad, hb.q_start.as<uint64_t>(),   \
+        hb.q_cnt.as<uint32_t>(), hb.alloc.as<unsigned long long>(), hb.gen & 1u, hb.col(), hb.cnt(), hb.capacity(), fp_mask,            \
+        src.pos_off_out, src.one_len
 #define COMMA ,
 #define BIGSI_READS(H)                                                                              \
     if (b->exact) hipLaunchKernelGGL((k_reads_fused<H COMMA true>), BIGSI_READS_ARGS);                \
@@ -1570,7 +1564,7 @@ int bigsi_batch_run(bigsi_hip_batch *b, double threshold, uint32_t flags, bool o
         TRY(flush_upload(b, st, true));
         TRY(ev_begin(ix, &fe, st, true));
         b->weak_fp = (flags & BIGSI_RUN_WEAK_FINGERPRINT) != 0;
-        TRY(launch_reads_fused(b, st, (flags & BIGSI_RUN_NO_WAITING) ? 0 : kSpinTimeout));
+        TRY(launch_reads_fused(b, st));
         TRY(ev_end(ix, &fe, ix->ev_and, st));
         b->run_h = ix->h;
         b->fused_run = true;
@@ -1893,48 +1887,63 @@ static int compact(bigsi_hip_batch *b, HitBufs &hb, const void *src, uint32_t n_
     return compact_ex(b, hb, src, !b->exact, nullptr, n_shards, shard_cols, write_only, gst);
 }
 
-// k_reads_fused bounds its waits (see there): a launch in which some workgroup gave up -- possible only with launches of other
-// batches in flight beside it -- has marked hit_off[n_seqs + 1] with its generation and is repeated here with the device to
-// itself, before anything reads the hit lists.  The batch's `done` event has been waited for.
-static int fused_settle(bigsi_hip_batch *b)
+// A one-launch read run leaves every query's hits where its workgroup allocated them (k_reads_fused: no order between queries).
+// fetch_hits brings them to the host in QUERY order: the totals decide whether the lists fit (grow + launch again if not), the
+// per-query (start, count) pairs give the offsets, one download of the used part of the buffers and one pass over the queries
+// put every list at its place.  The batch's `done` event has been waited for.
+static int fetch_read_hits(bigsi_hip_batch *b, uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t capacity)
 {
-    if (!b->fused_run || b->fused_settled) return BIGSI_OK;
     HitBufs &hb = b->hits;
     hipStream_t st = b->run_stream ? b->run_stream : b->ix->stream;
-    for (int attempt = 0; attempt < 4; attempt++) {
-        uint64_t mark = 0;
-        HIP_TRY(hipMemcpy(&mark, hb.hit_off.as<uint64_t>() + b->n_seqs + 1, 8, hipMemcpyDeviceToHost));
-        if (mark != hb.gen) {
-            b->fused_settled = true;
-            return BIGSI_OK;
+    const uint32_t n = b->n_seqs;
+    unsigned long long total = 0;
+    for (int attempt = 0;; attempt++) {
+        HIP_TRY(hipMemcpy(&total, hb.alloc.as<unsigned long long>() + (hb.gen & 1u), 8, hipMemcpyDeviceToHost));
+        if (total <= hb.capacity()) break;
+        if (hb.xcol) {
+            if (hit_offsets) memset(hit_offsets, 0, (n + 1) * 8ull), hit_offsets[n] = total;
+            return fail(BIGSI_ERR_CAPACITY, "caller-owned hit buffers hold %llu entries, %llu needed", (unsigned long long)hb.xcap, total);
         }
-        b->ix->fused_repeats++;
-        HIP_TRY(hipDeviceSynchronize());
+        if (attempt) return fail(BIGSI_ERR_HIP, "internal: a read run overflowed hit buffers sized for its own total");
+        TRY(hb.hit_col.reserve(total * 4));          // counters lived in registers: the whole pass again, on the stream it ran on
+        TRY(hb.hit_cnt.reserve(total * 4));
+        hb.cap = total;
         TRY(launch_reads_fused(b, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
-    return fail(BIGSI_ERR_HIP, "the one-launch read kernel did not complete in four attempts");
+    std::vector<uint32_t> qc(n);
+    std::vector<uint64_t> off(n + 1), qs;
+    HIP_TRY(hipMemcpy(qc.data(), hb.q_cnt.p, n * 4ull, hipMemcpyDeviceToHost));
+    off[0] = 0;
+    for (uint32_t q = 0; q < n; q++) off[q + 1] = off[q] + qc[q];
+    if (off[n] != total) return fail(BIGSI_ERR_HIP, "internal: hit counts of a read run do not add up (%llu vs %llu)", (unsigned long long)off[n], total);
+    if (hit_offsets) memcpy(hit_offsets, off.data(), (n + 1) * 8ull);
+    if (total > capacity)
+        return fail(BIGSI_ERR_CAPACITY, "hit buffers hold %llu entries, %llu needed", (unsigned long long)capacity, total);
+    if (!total || (!colours && !counts)) return BIGSI_OK;
+    qs.resize(n);
+    HIP_TRY(hipMemcpy(qs.data(), hb.q_start.p, n * 8ull, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> ucol(colours ? total : 0), ucnt(counts ? total : 0);
+    if (colours) HIP_TRY(hipMemcpy(ucol.data(), hb.col(), total * 4, hipMemcpyDeviceToHost));
+    if (counts) HIP_TRY(hipMemcpy(ucnt.data(), hb.cnt(), total * 4, hipMemcpyDeviceToHost));
+    for (uint32_t q = 0; q < n; q++) {
+        if (!qc[q]) continue;
+        if (colours) memcpy(colours + off[q], ucol.data() + qs[q], qc[q] * 4ull);
+        if (counts) memcpy(counts + off[q], ucnt.data() + qs[q], qc[q] * 4ull);
+    }
+    return BIGSI_OK;
 }
 
 // synchronise, make sure the hit lists fit (grow + rewrite if the write pass overflowed), copy them out
 static int fetch_hits_from(bigsi_hip_batch *b, HitBufs &hb, const void *src, uint32_t n_shards, uint64_t shard_cols,
                            uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t capacity)
 {
+    if (&hb == &b->hits && b->fused_run) return fetch_read_hits(b, hit_offsets, colours, counts, capacity);
     hipStream_t st = (&hb == &b->ghits && b->gstream) ? b->gstream : b->ix->stream;
     std::vector<uint64_t> off(b->n_seqs + 2);
     // local hit lists were produced before b->done (already waited for); gathered ones on the gather stream
     if (&hb == &b->ghits || !b->compacted) HIP_TRY(hipStreamSynchronize(st));
-    // (a one-launch read run: the word after the offsets tells whether the launch completed -- it comes with the same copy)
-    const bool fused = &hb == &b->hits && b->fused_run;
-    HIP_TRY(hipMemcpy(off.data(), hb.hit_off.p, (b->n_seqs + (fused ? 2 : 1)) * 8ull, hipMemcpyDeviceToHost));
-    if (fused && !b->fused_settled) {
-        if (off[b->n_seqs + 1] == hb.gen) {
-            TRY(fused_settle(b));
-            HIP_TRY(hipMemcpy(off.data(), hb.hit_off.p, (b->n_seqs + 1) * 8ull, hipMemcpyDeviceToHost));
-        } else {
-            b->fused_settled = true;
-        }
-    }
+    HIP_TRY(hipMemcpy(off.data(), hb.hit_off.p, (b->n_seqs + 1) * 8ull, hipMemcpyDeviceToHost));
     const uint64_t total = off[b->n_seqs];
     if (hb.xcol && total > hb.xcap) {
         if (hit_offsets) memcpy(hit_offsets, off.data(), (b->n_seqs + 1) * 8ull);
@@ -1944,14 +1953,7 @@ static int fetch_hits_from(bigsi_hip_batch *b, HitBufs &hb, const void *src, uin
         TRY(hb.hit_col.reserve(total * 4));
         TRY(hb.hit_cnt.reserve(total * 4));
         hb.cap = total;
-        if (&hb == &b->hits && b->fused_run) {      // counters lived in registers: the whole pass again, on the stream it ran on
-            st = b->run_stream ? b->run_stream : st;
-            TRY(launch_reads_fused(b, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            TRY(fused_settle(b));
-        } else {
-            TRY(compact(b, hb, src, n_shards, shard_cols, true));
-        }
+        TRY(compact(b, hb, src, n_shards, shard_cols, true));
         if (&hb == &b->ghits && b->comm && !b->exact) TRY(bigsi_reduce_gathered_counts(b));   // every rank takes this branch: totals are identical
         HIP_TRY(hipStreamSynchronize(st));
     }
@@ -2001,8 +2003,8 @@ extern "C" int bigsi_hip_batch_get_info(bigsi_hip_batch *b, bigsi_hip_batch_info
     out->count_bytes = b->count_bytes;
     for (uint32_t v : b->h_num_unique) out->total_unique += v;
     uint64_t total = 0;
-    TRY(fused_settle(b));
-    if (b->compacted) HIP_TRY(hipMemcpy(&total, b->hits.hit_off.as<uint64_t>() + b->n_seqs, 8, hipMemcpyDeviceToHost));
+    if (b->fused_run) HIP_TRY(hipMemcpy(&total, b->hits.alloc.as<unsigned long long>() + (b->hits.gen & 1u), 8, hipMemcpyDeviceToHost));
+    else if (b->compacted) HIP_TRY(hipMemcpy(&total, b->hits.hit_off.as<uint64_t>() + b->n_seqs, 8, hipMemcpyDeviceToHost));
     out->total_hits = total;
     out->bitmap_stride_bytes = b->wv_pad * 8;
     out->counts_stride = b->wv_pad * 64;
@@ -2549,6 +2551,16 @@ int bigsi_batch_export(bigsi_hip_batch *b)
     b->exp_serial++;
     b->exp_flagged = use_flag != 0;
     b->exp_stream = st;
+    if (b->fused_run) {
+        // a read run: its export also puts the hit lists in query order (k_export_reads); workgroups own ranges of queries
+        const unsigned rgrid = (unsigned)std::min<uint64_t>(ceil_div(n, 4 * kBlock), 64);
+        hipLaunchKernelGGL(k_export_reads, dim3(std::max(rgrid, 1u)), dim3(kBlock), 0, st, hb.q_start.as<uint64_t>(), hb.q_cnt.as<uint32_t>(), n,
+                           b->uniq.as<uint32_t>(), hb.col(), hb.cnt(), (uint32_t)spec, static_cast<uint64_t *>(b->pin_out), b->exp_count.as<uint32_t>(),
+                           (volatile uint64_t *)(use_flag ? b->pin_flag : nullptr), b->exp_serial);
+        HIP_TRY(hipGetLastError());
+        if (!use_flag) HIP_TRY(hipEventRecord(b->exp_done, st));
+        return BIGSI_OK;
+    }
     // the hits it carries along speculatively are few: one workgroup unless the batch is large (one workgroup needs no counter)
     const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(std::max<uint64_t>(3ull * n, spec), 4 * kBlock), 64);
     hipLaunchKernelGGL(k_export_results, dim3(std::max(grid, 1u)), dim3(kBlock), 0, st, hb.hit_off.as<uint64_t>(), n, b->fused_run ? 1u : 0u, b->uniq.as<uint32_t>(),
@@ -2593,14 +2605,14 @@ int bigsi_batch_collect(bigsi_hip_batch *b, uint32_t *num_kmers, uint32_t *num_u
     const uint32_t n = b->n_seqs;
     const uint64_t *off = static_cast<const uint64_t *>(b->pin_out);
     const uint64_t total = off[n];
-    const bool gave_up = b->fused_run && !b->fused_settled && off[n + 1] == hb.gen;
-    if (gave_up || total > hb.capacity()) {
-        // rare: a read launch that was abandoned, or hit lists that outgrew the device buffers -- the general route repeats the
-        // launch / regrows the lists
+    if (total > hb.capacity() || (b->fused_run && total > b->exp_spec)) {
+        // rare: hit lists that outgrew the device buffers (the general route regrows them and repeats the launch), or a read
+        // run with more hits than its export carried along (their query order is made on the host)
         TRY(bigsi_hip_batch_fetch_unique(b, num_kmers, num_unique, min_kmers));
-        return bigsi_hip_batch_fetch_hits(b, hit_offsets, colours, counts, capacity);
+        const int rc2 = bigsi_hip_batch_fetch_hits(b, hit_offsets, colours, counts, capacity);
+        b->idle = !b->job.pending;
+        return rc2;
     }
-    if (b->fused_run) b->fused_settled = true;
     b->idle = !b->job.pending;          // the export ran behind everything the run queued on its stream
     const uint32_t *u32 = reinterpret_cast<const uint32_t *>(off + n + 2);
     b->h_uniq.assign(u32, u32 + 3ull * n);

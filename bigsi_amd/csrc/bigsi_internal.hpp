@@ -97,7 +97,7 @@ struct bigsi_hip_index {
     bool rd_pending = false;      // something may still be running on them
     bool sc_pending = false;      // a K5 / K6 request may still be queued on sc_stream (it reads d_index): quiesce_index
     hipEvent_t main_ev = nullptr; // end of the last batch run on the index stream (mark_main)
-    uint64_t fused_repeats = 0;   // one-launch read kernels repeated because a workgroup gave up waiting (bigsi_hip_stats)
+    uint64_t fused_repeats = 0;   // (rounds 2-3: read launches repeated after a bounded wait ran out; nothing waits any more: stays 0)
     struct bigsi_hip_batch *search_ws = nullptr;      // bigsi_hip_search_batch's workspace, created at its first call
     struct bigsi_hip_batch *stream_ws[3] = {};        // bigsi_hip_search_stream's three workspaces
     uint64_t m = 0, n_cols = 0, cap_cols = 0, stride_words = 0;
@@ -120,10 +120,10 @@ struct bigsi_hip_comm;
 // ------------------------------------------------------------------------------ batches
 struct HitBufs {
     DevBuf chunk_hits, chunk_off, hit_off, hit_col, hit_cnt, overflow;
-    // k_reads_fused's hit scan: one state word per workgroup, tagged with the launch's generation (K4 proper keeps its group
-    // totals in chunk_hits)
-    DevBuf lb_state;
-    uint32_t gen = 0;           // generation tag of the state words of the last launch (20 bits, 0 = never used)
+    // k_reads_fused: per query where its hits start in col / cnt and how many they are (no order between queries), and the two
+    // allocation counters its launches use alternately
+    DevBuf q_start, q_cnt, alloc;
+    uint32_t gen = 0;           // launches so far: the last one used allocation counter gen & 1
     uint64_t cap = 0;   // hits the col/cnt buffers can hold
     uint32_t *xcol = nullptr, *xcnt = nullptr;   // caller-owned hit buffers (e.g. torch tensors that are then all-reduced)
     uint64_t xcap = 0;
@@ -133,7 +133,7 @@ struct HitBufs {
     void release()
     {
         chunk_hits.release(); chunk_off.release(); hit_off.release(); hit_col.release(); hit_cnt.release(); overflow.release();
-        lb_state.release();
+        q_start.release(); q_cnt.release(); alloc.release();
     }
 };
 
@@ -191,7 +191,6 @@ struct bigsi_hip_batch {
     bool ran = false, exact = false, compacted = false, sparse_counts = false;
     bool pos_query_loaded = false;    // pos_query holds this load's position -> sequence map
     hipStream_t run_stream = nullptr;   // the stream `done` was last recorded on
-    bool fused_settled = false;         // the last one-launch run is known to have completed (fused_settle)
     bool weak_fp = false;         // BIGSI_RUN_WEAK_FINGERPRINT of the last one-launch run (a re-launch after a regrow repeats it)
     bool fused_run = false;           // the last run was the one-launch read kernel (k_reads_fused)
     bool elements = false;            // k-mers were given explicitly (bigsi_hip_batch_create_elements): K1 = k_rows_raw

@@ -1199,8 +1199,6 @@ __device__ __forceinline__ uint64_t chunk_index(uint32_t q, uint32_t shard, uint
 // The launch boundary costs ~5 us per batch (0.5 % of a 1 ms step at configs[3] / [4]; batches of reads do not come here, they
 // write their hits from k_reads_fused) and removes the only unbounded wait the library had.
 constexpr uint32_t kHitsMaxGroups = 1024;
-__device__ __forceinline__ uint64_t lb_pack(uint32_t gen, uint64_t value) { return ((uint64_t)gen << 44) | (value + 1); }
-constexpr uint64_t kLbPoison = (1ull << 44) - 1;      // value field of a state word that says "the launch is being abandoned"
 
 // item ci of the (seq, shard, chunk) order; the host keeps the number of items below 2^31, so the divisions are 32-bit ones
 // (a 64-bit division is a ~100-instruction routine on this hardware: three of them per item were most of K4's time on a
@@ -1332,15 +1330,13 @@ __global__ __launch_bounds__(kBlock) void k_hits_write(
 
 // ------------------------------------------------------------------------------ reads: K1 + K2 + K4 in ONE launch
 // A batch of reads against a narrow index (BASELINE configs[1]: 1000 x 61-mers, 10 000 samples) is three short kernels
-// and three launch boundaries: 7 + 24 + 7 us of kernels in a 43 us step.  When every query has < 64 k-mer positions, a row
-// fits one workgroup's lanes (<= 512 words) and the batch has at most kHitsMaxGroups queries, ONE workgroup per query does
-// the whole path: wavefront 0 k-merises / dedupes / hashes exactly as k_kmerize_wave does (and leaves the same arrays in
-// global memory for lookup / presence / fetch_rows), the row ids go to the other wavefronts through LDS, all of them
-// stream and AND (or count) the rows, and the hit list is written through a publish-and-sum scan -- the workgroup publishes its
-// total and sums those of the queries before it (the grid is co-resident by construction).  Same results, one launch.
-constexpr int kReadsSection = 1024;           // queries whose hit totals a workgroup of k_reads_fused sums directly
+// and three launch boundaries: 7 + 24 + 7 us of kernels in a 43 us step.  When every query has < 64 k-mer positions and a row
+// fits one workgroup's lanes (<= 512 words), ONE workgroup per query does the whole path: two wavefronts k-merise / dedupe /
+// hash (and leave the same arrays in global memory as the K1 kernels, for lookup / presence / fetch_rows), the row ids go to
+// the other wavefronts through LDS, all of them stream and AND (or count) the rows, and the workgroup writes its query's hits
+// to entries of the hit buffers it allocates with one atomic add (round 4: no order between queries, no waiting; see the
+// kernel's last section).  Same results, one launch.
 constexpr uint32_t kReadsMaxSeqs = 1u << 20;  // queries per launch of k_reads_fused at most
-constexpr uint64_t kSpinTimeout = 2000000;    // 20 ms of the 100 MHz wall clock: when a workgroup of k_reads_fused stops waiting
 template <int H, bool EXACT>
 __global__ __launch_bounds__(kBlock) void k_reads_fused(
     const uint64_t *__restrict__ index, uint64_t stride_words, uint32_t wv, uint64_t n_cols, uint64_t m, double threshold,
@@ -1348,8 +1344,10 @@ __global__ __launch_bounds__(kBlock) void k_reads_fused(
     uint32_t *__restrict__ first_pos, uint32_t *__restrict__ pos_unique, uint32_t *__restrict__ rep_out, uint64_t *__restrict__ rows,
     uint32_t *__restrict__ num_kmers, uint32_t *__restrict__ num_unique, uint32_t *__restrict__ min_kmers,
     uint64_t *__restrict__ out_bits, uint64_t out_stride_words,
-    uint64_t *__restrict__ state, uint32_t gen, uint64_t *__restrict__ hit_off, uint32_t *__restrict__ hit_col, uint32_t *__restrict__ hit_cnt,
-    uint64_t capacity, uint32_t fp_mask /* ~0; 1 = BIGSI_RUN_WEAK_FINGERPRINT */, uint64_t spin_timeout /* in 10 ns ticks */,
+    uint64_t *__restrict__ q_start, uint32_t *__restrict__ q_cnt /* per query: where its hits lie in hit_col / hit_cnt, how many */,
+    unsigned long long *__restrict__ alloc /* two words: hits allocated so far by this launch [slot] / by the launch before [slot ^ 1] */,
+    uint32_t slot, uint32_t *__restrict__ hit_col, uint32_t *__restrict__ hit_cnt,
+    uint64_t capacity, uint32_t fp_mask /* ~0; 1 = BIGSI_RUN_WEAK_FINGERPRINT */,
     uint64_t *__restrict__ pos_off_out /* as k_kmerize_lds: inputs come straight from pinned host memory */,
     uint32_t one_len /* as k_kmerize_lds */)
 {
@@ -1545,65 +1543,28 @@ __global__ __launch_bounds__(kBlock) void k_reads_fused(
         o[0] = hitw[0];
         if (w0 + 1 < out_stride_words) o[1] = hitw[1];
     }
-    // ---- K4: this query's hits after those of the queries before it
+    // ---- K4: this query's hits, at a place of their own.  The workgroup takes `tot` consecutive entries of the batch's hit buffers
+    // with ONE atomic add and leaves (start, count) for its query; the lists of different queries lie in whatever order the
+    // workgroups got there, and whoever reads them -- the export kernel of the one-call / streaming searches, the host for
+    // fetch_hits -- puts them in query order from the counts.  Nobody waits for anybody: rounds 2 and 3 wrote the lists in query
+    // order through a publish-and-sum scan whose workgroups spun on the totals of their predecessors (bounded by a timeout and
+    // a host-side repeat, but leaning on dispatch order for progress, and 3 us of every 29 us launch).
     const uint32_t mine = (uint32_t)(__popcll(hitw[0]) + __popcll(hitw[1]));
     uint32_t tot;
     const uint32_t pre = block_exclusive_scan(mine, &tot, lds);
-    // two levels: inside its section of kReadsSection queries a workgroup sums the totals of the queries before it (one pass over
-    // at most 1023 words: they are published unconditionally, in dispatch order, so nothing here can wait for a workgroup that
-    // has not started); the section's last workgroup also publishes the running total for the next section, a chain of
-    // n_seqs / kReadsSection links that runs far ahead of the row fetches.  state: [n_seqs totals | one running total per section]
-    const uint32_t first = q & ~(uint32_t)(kReadsSection - 1), section = q / kReadsSection;
-    // Waiting is bounded.  A waiter's predecessors have started whenever this launch has the device to itself; with launches of
-    // several batches in flight (the library's read streams) workgroups of one launch can, in principle, fill the slots that
-    // the predecessor of another launch's waiters needs, and the other way round.  A workgroup that has waited kSpinTimeout
-    // (20 ms; the waits are tens of microseconds) gives up: it marks the launch (hit_off[n_seqs + 1] = generation) and leaves
-    // without writing hits -- its total IS published, nobody waits for it -- and the host repeats such a launch alone before
-    // anything reads the hit lists (fused_settle).
-    const uint64_t t_wait = wall_clock64();
-    bool gave_up = false;
-    auto wait_for = [&](const uint64_t *w) -> uint64_t {
-        for (;;) {
-            const uint64_t word = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((uint32_t)(word >> 44) == gen && (word & ((1ull << 44) - 1)) != 0) {
-                if ((word & ((1ull << 44) - 1)) == kLbPoison) { gave_up = true; return 0; }      // a section before this one gave up: so do we, at once
-                return (word & ((1ull << 44) - 1)) - 1;
-            }
-            if (gave_up || wall_clock64() - t_wait > spin_timeout) { gave_up = true; return 0; }
-            __builtin_amdgcn_s_sleep(1);
-        }
-    };
-    if (threadIdx.x == 0) __hip_atomic_store(&state[q], lb_pack(gen, tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint64_t part = 0;
-    for (uint32_t j = first + threadIdx.x; j < q; j += kBlock) part += wait_for(&state[j]);
-    if (threadIdx.x == 0 && section) part += wait_for(&state[n_seqs + section]);
-    if (__syncthreads_or(gave_up ? 1 : 0)) {
-        if (threadIdx.x == 0) {
-            hit_off[n_seqs + 1] = gen;
-            // the section's last workgroup owes the later sections a running total: hand them a poison word instead, so that they
-            // leave at once rather than each waiting out its own timeout (the launch is repeated anyway)
-            if (q + 1 == first + kReadsSection)
-                __hip_atomic_store(&state[n_seqs + section + 1], ((uint64_t)gen << 44) | kLbPoison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        return;
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
-    if ((threadIdx.x & 63u) == 0) lds64[threadIdx.x >> 6] = part;
-    __syncthreads();
-    uint64_t base = 0;
-#pragma unroll
-    for (int i = 0; i < kBlock / 64; i++) base += lds64[i];
-    if (threadIdx.x == 0 && q + 1 == first + kReadsSection)
-        __hip_atomic_store(&state[n_seqs + section + 1], lb_pack(gen, base + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (threadIdx.x == 0) {
-        hit_off[q] = base;
-        if (q + 1 == n_seqs) hit_off[n_seqs] = base + tot;
+        const uint64_t start = tot ? (uint64_t)atomicAdd(alloc + slot, (unsigned long long)tot) : 0ull;
+        lds64[0] = start;
+        q_start[q] = start;
+        q_cnt[q] = tot;
+        if (q == 0) alloc[slot ^ 1u] = 0;          // the next launch of this batch (launches of one batch never overlap) starts from zero
     }
+    __syncthreads();
     BIGSI_PHASE(3);
     if (mine == 0) return;
-    uint64_t o = base + pre;
-    if (o + mine > capacity) return;                    // the host sees total > capacity, grows the lists and launches again
+    const uint64_t start = lds64[0];
+    if (start + tot > capacity) return;              // the host sees total > capacity, grows the lists and launches again
+    uint64_t o = start + pre;
 #pragma unroll
     for (int v = 0; v < kVec; v++) {
         uint64_t mcol = by_column(hitw[v]);
@@ -2064,6 +2025,59 @@ __global__ __launch_bounds__(kBlock) void k_export_results(
     if (!flag) return;
     __threadfence_system();                     // this thread's stores to host memory are out ...
     __syncthreads();                            // ... and so are the workgroup's
+    if (threadIdx.x == 0) {
+        if (gridDim.x == 1 || atomicAdd(done_count, 1u) == gridDim.x - 1u) {
+            if (gridDim.x > 1) *done_count = 0;
+            __threadfence_system();
+            *flag = serial;
+        }
+    }
+}
+
+// The same for a one-launch read run, whose hit lists lie in allocation order (k_reads_fused): workgroup g owns a contiguous range
+// of queries, sums the hit counts of the queries before its range (plain loads: the launch boundary has published them), scans
+// its own, writes the offsets and copies every query's hits to their place in query order.  No workgroup waits for another.
+__global__ __launch_bounds__(kBlock) void k_export_reads(
+    const uint64_t *__restrict__ q_start, const uint32_t *__restrict__ q_cnt, uint32_t n_seqs, const uint32_t *__restrict__ uniq,
+    const uint32_t *__restrict__ col, const uint32_t *__restrict__ cnt, uint32_t spec, uint64_t *out,
+    uint32_t *__restrict__ done_count, volatile uint64_t *flag, uint64_t serial)
+{
+    __shared__ uint32_t lds[16];
+    __shared__ uint64_t lds64[kBlock / 64];
+    const uint32_t per_g = (n_seqs + gridDim.x - 1) / gridDim.x, q0 = blockIdx.x * per_g < n_seqs ? blockIdx.x * per_g : n_seqs;
+    const uint32_t q1 = q0 + per_g < n_seqs ? q0 + per_g : n_seqs;
+    uint64_t part = 0;
+    for (uint32_t j = threadIdx.x; j < q0; j += kBlock) part += q_cnt[j];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+    if ((threadIdx.x & 63u) == 0) lds64[threadIdx.x >> 6] = part;
+    __syncthreads();
+    uint64_t base = 0;
+#pragma unroll
+    for (int i = 0; i < kBlock / 64; i++) base += lds64[i];
+    uint32_t *o32 = reinterpret_cast<uint32_t *>(out + n_seqs + 2u);
+    uint32_t *ocol = o32 + ((3u * n_seqs + 1u) & ~1u), *ocnt = ocol + spec;
+    for (uint32_t qb = q0; qb < q1; qb += kBlock) {
+        const uint32_t q = qb + threadIdx.x;
+        const uint32_t c = q < q1 ? q_cnt[q] : 0u;
+        uint32_t tot;
+        const uint32_t pre = block_exclusive_scan(c, &tot, lds);
+        const uint64_t off = base + pre;
+        base += tot;
+        if (q < q1) {
+            out[q] = off;
+            const uint64_t src = c ? q_start[q] : 0ull;
+            for (uint32_t j = 0; j < c && off + j < spec; j++) { ocol[off + j] = col[src + j]; ocnt[off + j] = cnt[src + j]; }
+        }
+    }
+    if ((q1 == n_seqs && q0 < n_seqs) || (n_seqs == 0 && blockIdx.x == 0)) {
+        if (threadIdx.x == 0) { out[n_seqs] = base; out[n_seqs + 1] = 0; }
+    }
+    const uint32_t tid = blockIdx.x * kBlock + threadIdx.x, nt = gridDim.x * kBlock;
+    for (uint32_t i = tid; i < 3u * n_seqs; i += nt) o32[i] = uniq[i];
+    if (!flag) return;
+    __threadfence_system();
+    __syncthreads();
     if (threadIdx.x == 0) {
         if (gridDim.x == 1 || atomicAdd(done_count, 1u) == gridDim.x - 1u) {
             if (gridDim.x > 1) *done_count = 0;

@@ -596,11 +596,10 @@ class QueryBatch(object):
             pass
 
     def run(self, threshold, force_counts=False, skip_compact=False, k1_global=False, sparse_counts=False, early_exit=False,
-            weak_fingerprint=False, no_waiting=False, one_stream=False):
+            weak_fingerprint=False, one_stream=False):
         flags = ((_lib.RUN_ONE_STREAM if one_stream else 0) | (_lib.RUN_FORCE_COUNTS if force_counts else 0) | (_lib.RUN_SKIP_COMPACT if skip_compact else 0) |
                  (_lib.RUN_K1_GLOBAL if k1_global else 0) | (_lib.RUN_SPARSE_COUNTS if sparse_counts else 0) |
-                 (_lib.RUN_EARLY_EXIT if early_exit else 0) | (_lib.RUN_WEAK_FINGERPRINT if weak_fingerprint else 0) |
-                 (_lib.RUN_NO_WAITING if no_waiting else 0))
+                 (_lib.RUN_EARLY_EXIT if early_exit else 0) | (_lib.RUN_WEAK_FINGERPRINT if weak_fingerprint else 0))
         if self.group:
             flags &= ~(_lib.RUN_SKIP_COMPACT | _lib.RUN_SPARSE_COUNTS)      # the group run sets what it needs itself
         check(self._fn("run")(self.b, float(threshold), flags))

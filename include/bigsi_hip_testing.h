@@ -20,8 +20,7 @@ extern "C" {
 /* test / A-B flags: same results, different route (tests/test_gpu_parity.py, scripts/ab_*.py); not for production callers */
 #define BIGSI_RUN_K1_GLOBAL 4u   /* take the multi-launch K1 (global-memory dedupe table) whatever the query lengths */
 #define BIGSI_RUN_NO_SORT 16u    /* stream each query's rows in hash order instead of address order */
-#define BIGSI_RUN_NO_WAITING 128u /* one-launch read path: workgroups give up waiting for their predecessors' hit totals at once,
-                                     so that the launch is marked incomplete and repeated (otherwise a 20 ms timeout) */
+/* (128u was BIGSI_RUN_NO_WAITING in rounds 2-3: the read kernel's bounded wait between workgroups; the kernel no longer waits) */
 #define BIGSI_RUN_ONE_STREAM 256u /* one-launch read path: this run goes to the index stream instead of the next of the three read
                                     streams, so that consecutive launches do NOT overlap -- a kernel's own duration is then what it
                                     takes alone on the device (bench.py: roofline.frac of read workloads) */

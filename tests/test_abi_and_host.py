@@ -33,7 +33,7 @@ def test_public_header_stays_small():
     assert {"bigsi_hip_set_stream", "bigsi_hip_batch_set_outputs", "bigsi_hip_batch_compact_gathered"} <= hidden
     assert not hidden & set(public)
     src = open(os.path.join(ROOT, "include", "bigsi_hip.h")).read()
-    for flag in ("BIGSI_RUN_K1_GLOBAL", "BIGSI_RUN_NO_WAITING", "BIGSI_RUN_WEAK_FINGERPRINT", "BIGSI_RUN_NO_SORT"):
+    for flag in ("BIGSI_RUN_K1_GLOBAL", "BIGSI_RUN_ONE_STREAM", "BIGSI_RUN_WEAK_FINGERPRINT", "BIGSI_RUN_NO_SORT"):
         assert "#define " + flag not in src
 
 
