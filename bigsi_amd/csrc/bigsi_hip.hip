@@ -1244,6 +1244,16 @@ static bool reads_fusable(const bigsi_hip_batch *b, uint32_t flags)
 }
 
 #ifdef BIGSI_HIP_TUNING
+uint64_t g_call_trace[16];
+uint64_t g_call_last;
+// tuning builds only: host time per phase of bigsi_hip_search_batch since the last reset (ns sums: stage, run, export, wait,
+// collect; out[15] = calls)
+extern "C" int bigsi_hip_debug_call_trace(uint64_t *out, int reset)
+{
+    if (out) memcpy(out, g_call_trace, sizeof g_call_trace);
+    if (reset) memset(g_call_trace, 0, sizeof g_call_trace);
+    return BIGSI_OK;
+}
 // tuning builds only (not declared in include/bigsi_hip.h): the phase timestamps of the last k_reads_fused launch, 8 per workgroup
 extern "C" int bigsi_hip_debug_phases(bigsi_hip_index *ix, uint64_t *out, uint32_t n_groups)
 {
@@ -1513,7 +1523,15 @@ static int flush_upload(bigsi_hip_batch *b, hipStream_t st, bool k1_reads_host =
     // a one-call search with a small input: this run's K1 (one of the single-launch routes) reads pin_up itself
     static const int zc_env = env_int("BIGSI_HIP_ZERO_COPY", 1);
     b->zero_copy = zc_env && k1_reads_host && b->one_call && b->pin_up_bytes <= kZeroCopyBytes;
-    if (!b->zero_copy) HIP_TRY(hipMemcpyAsync(b->upload.p, b->pin_up, b->pin_up_bytes, hipMemcpyHostToDevice, st));
+    // ... unless many workgroups would each fetch their own few bytes over the link: then one small kernel copies the staging
+    // with wide loads first (k_stage_in), and K1 reads the device arrays
+    static const int stage_min = env_int("BIGSI_HIP_STAGE_KERNEL_MIN", 8 << 10);
+    if (b->zero_copy && b->n_seqs > 1 && b->pin_up_bytes >= (size_t)stage_min) {
+        const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(b->pin_up_bytes, (uint64_t)kBlock * 16), 64);
+        hipLaunchKernelGGL(k_stage_in, dim3(grid), dim3(kBlock), 0, st, static_cast<const uint8_t *>(b->pin_up), b->upload.as<uint8_t>(), (uint64_t)b->pin_up_bytes);
+        HIP_TRY(hipGetLastError());
+        b->zero_copy = false;
+    } else if (!b->zero_copy) HIP_TRY(hipMemcpyAsync(b->upload.p, b->pin_up, b->pin_up_bytes, hipMemcpyHostToDevice, st));
     b->upload_deferred = false;
     return BIGSI_OK;
 }
@@ -2526,12 +2544,10 @@ int bigsi_batch_stage(bigsi_hip_index *ix, bigsi_hip_batch **pb, const char *seq
     return batch_load(b, seqs, offsets, n_seqs, k, true);
 }
 
-int bigsi_batch_export(bigsi_hip_batch *b)
+// the pinned block an export writes, the flag its last workgroup raises, and the export's serial number
+static int export_prepare(bigsi_hip_batch *b, hipStream_t st)
 {
-    if (!b || !b->ran) return fail(BIGSI_ERR_STATE, "bigsi_hip_batch_run has not completed for this batch");
-    if (!b->compacted) return fail(BIGSI_ERR_STATE, "internal: export of a run without hit lists");
     HitBufs &hb = b->hits;
-    hipStream_t st = b->run_stream ? b->run_stream : b->ix->stream;
     const uint32_t n = b->n_seqs;
     const uint64_t spec = std::min<uint64_t>(std::max<uint64_t>(1024, 2ull * n), std::min<uint64_t>(hb.capacity(), 1u << 20));
     const size_t o_uniq = (n + 2ull) * 8, o_col = o_uniq + ((3ull * n + 1) & ~1ull) * 4, bytes = o_col + 8 * spec;
@@ -2551,9 +2567,24 @@ int bigsi_batch_export(bigsi_hip_batch *b)
     b->exp_serial++;
     b->exp_flagged = use_flag != 0;
     b->exp_stream = st;
+    return BIGSI_OK;
+}
+
+int bigsi_batch_export(bigsi_hip_batch *b)
+{
+    if (!b || !b->ran) return fail(BIGSI_ERR_STATE, "bigsi_hip_batch_run has not completed for this batch");
+    if (!b->compacted) return fail(BIGSI_ERR_STATE, "internal: export of a run without hit lists");
+    HitBufs &hb = b->hits;
+    hipStream_t st = b->run_stream ? b->run_stream : b->ix->stream;
+    const uint32_t n = b->n_seqs;
+    TRY(export_prepare(b, st));
+    const uint64_t spec = b->exp_spec;
+    const bool use_flag = b->exp_flagged;
     if (b->fused_run) {
         // a read run: its export also puts the hit lists in query order (k_export_reads); workgroups own ranges of queries
-        const unsigned rgrid = (unsigned)std::min<uint64_t>(ceil_div(n, 4 * kBlock), 64);
+        // (queries per workgroup, A/B at 1000 reads in one call: 1024 -> 51.2 us, 256 -> 47.7, 64 -> 47.8)
+        static const int per_wg = env_int("BIGSI_HIP_EXPORT_READS_PER_WG", kBlock);
+        const unsigned rgrid = (unsigned)std::min<uint64_t>(ceil_div(n, (uint64_t)std::max(per_wg, 1)), 64);
         hipLaunchKernelGGL(k_export_reads, dim3(std::max(rgrid, 1u)), dim3(kBlock), 0, st, hb.q_start.as<uint64_t>(), hb.q_cnt.as<uint32_t>(), n,
                            b->uniq.as<uint32_t>(), hb.col(), hb.cnt(), (uint32_t)spec, static_cast<uint64_t *>(b->pin_out), b->exp_count.as<uint32_t>(),
                            (volatile uint64_t *)(use_flag ? b->pin_flag : nullptr), b->exp_serial);
@@ -2601,6 +2632,7 @@ int bigsi_batch_collect(bigsi_hip_batch *b, uint32_t *num_kmers, uint32_t *num_u
     if (!b) return fail(BIGSI_ERR_STATE, "internal: nothing exported");
     TRY(use_device(b->ix));
     TRY(export_wait(b));
+    CALL_MARK(4);
     HitBufs &hb = b->hits;
     const uint32_t n = b->n_seqs;
     const uint64_t *off = static_cast<const uint64_t *>(b->pin_out);

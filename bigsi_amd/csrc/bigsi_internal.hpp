@@ -47,6 +47,17 @@ static inline int env_int(const char *name, int dflt)
 #endif
 }
 
+// tuning builds: host timestamps inside bigsi_hip_search_batch (scripts/call_breakdown.py), summed per phase; nothing in the product
+#ifdef BIGSI_HIP_TUNING
+#include <time.h>
+extern uint64_t g_call_trace[16];      // [i] = ns spent up to mark i since the mark before, summed over calls; [15] = calls
+extern uint64_t g_call_last;
+static inline uint64_t call_now() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (uint64_t)t.tv_sec * 1000000000ull + (uint64_t)t.tv_nsec; }
+#define CALL_MARK(i) do { const uint64_t n_ = call_now(); if ((i) == 0) g_call_trace[15]++; else g_call_trace[i] += n_ - g_call_last; g_call_last = n_; } while (0)
+#else
+#define CALL_MARK(i) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------------------ device buffer with growth
 struct DevBuf {
     void *p = nullptr;

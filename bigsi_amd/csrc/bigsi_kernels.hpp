@@ -1561,27 +1561,27 @@ __global__ __launch_bounds__(kBlock) void k_reads_fused(
     }
     __syncthreads();
     BIGSI_PHASE(3);
-    if (mine == 0) return;
     const uint64_t start = lds64[0];
-    if (start + tot > capacity) return;              // the host sees total > capacity, grows the lists and launches again
-    uint64_t o = start + pre;
+    if (mine != 0 && start + tot <= capacity) {      // (else the host sees total > capacity, grows the lists and launches again)
+        uint64_t o = start + pre;
 #pragma unroll
-    for (int v = 0; v < kVec; v++) {
-        uint64_t mcol = by_column(hitw[v]);
-        while (mcol) {
-            const uint32_t c = (uint32_t)__builtin_ctzll(mcol);
-            mcol &= mcol - 1;
-            hit_col[o] = (uint32_t)(((uint64_t)w0 + v) * 64 + c);
-            if (EXACT) {
-                hit_cnt[o] = u;
-            } else {
-                const uint32_t bp = bit_of_col(c);
-                uint32_t x = 0;
+        for (int v = 0; v < kVec; v++) {
+            uint64_t mcol = by_column(hitw[v]);
+            while (mcol) {
+                const uint32_t c = (uint32_t)__builtin_ctzll(mcol);
+                mcol &= mcol - 1;
+                hit_col[o] = (uint32_t)(((uint64_t)w0 + v) * 64 + c);
+                if (EXACT) {
+                    hit_cnt[o] = u;
+                } else {
+                    const uint32_t bp = bit_of_col(c);
+                    uint32_t x = 0;
 #pragma unroll
-                for (int p = 0; p < P; p++) x |= (uint32_t)((pl[v][p] >> bp) & 1ull) << p;
-                hit_cnt[o] = x;
+                    for (int p = 0; p < P; p++) x |= (uint32_t)((pl[v][p] >> bp) & 1ull) << p;
+                    hit_cnt[o] = x;
+                }
+                o++;
             }
-            o++;
         }
     }
 }
@@ -2085,6 +2085,19 @@ __global__ __launch_bounds__(kBlock) void k_export_reads(
             *flag = serial;
         }
     }
+}
+
+// A one-call search's tables + sequences from the pinned staging to their device arrays: wide coalesced reads over the host link
+// (a few hundred requests for 85 KB) in place of the thousands of 64-byte ones k_reads_fused's 1000 workgroups would issue each
+// for its own offsets and sequence (measured: 1000 reads of 61 bp in one call 54.8 -> 51.9 us), and of a hipMemcpyAsync whose
+// DMA start-up is ~13 us.
+__global__ __launch_bounds__(kBlock) void k_stage_in(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, uint64_t bytes)
+{
+    const uint64_t n16 = bytes / 16, tid = (uint64_t)blockIdx.x * kBlock + threadIdx.x, nt = (uint64_t)gridDim.x * kBlock;
+    const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+    uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+    for (uint64_t i = tid; i < n16; i += nt) d4[i] = s4[i];
+    for (uint64_t i = n16 * 16 + tid; i < bytes; i += nt) dst[i] = src[i];
 }
 
 // ------------------------------------------------------------------------------ bulk ingest helpers

@@ -101,13 +101,18 @@ extern "C" int bigsi_hip_search_batch(bigsi_hip_index *ix, const char *seqs, con
     if (!ix) return fail(BIGSI_ERR_INVALID, "NULL index");
     // the index keeps ONE workspace for this entry point (a caller in a loop pays its ~20 device allocations once; the
     // workspace goes with the index, or right away if a call fails)
+    CALL_MARK(0);
     if (ix->search_ws) ix->search_ws->one_call = true;
     TRY(bigsi_batch_stage(ix, &ix->search_ws, seqs, offsets, n_seqs, k));
+    CALL_MARK(1);
     bigsi_hip_batch *b = ix->search_ws;
     b->one_call = true;      // (a small input is then read by K1 straight from the pinned staging, and the run records no event)
     int rc = bigsi_batch_run(b, threshold, (flags & ~BIGSI_RUN_SKIP_COMPACT) | BIGSI_RUN_SPARSE_COUNTS, true);
+    CALL_MARK(2);
     if (rc == BIGSI_OK) rc = bigsi_batch_export(b);
+    CALL_MARK(3);
     if (rc == BIGSI_OK) rc = bigsi_batch_collect(b, num_kmers, num_unique, min_kmers, hit_offsets, colours, counts, hit_capacity);
+    CALL_MARK(5);
     if (rc != BIGSI_OK && rc != BIGSI_ERR_CAPACITY) {      // (a too small hit buffer is the caller's to retry: offsets are filled in)
         ix->search_ws = nullptr;
         bigsi_hip_batch_destroy(b);      // leaves the thread's error message of the failed call above in place

@@ -45,11 +45,19 @@ def breakdown(st, label, nq, qlen, thr, reps=200):
     # argument conversion (numpy .ctypes.data: ~1 us per pointer) outside the timed loop: what a C / C++ / Go binder pays is the call
     argv = [(st.handle, blob, _lib.ptr(soff), nq, 31, float(thr), 0, _lib.ptr(nk), _lib.ptr(nu), None, _lib.ptr(off), _lib.ptr(col), _lib.ptr(cnt), col.size) for blob, soff in packs]
     ts = []
+    trace = getattr(_lib.lib(), "bigsi_hip_debug_call_trace", None) if "tuning" in os.environ.get("BIGSI_HIP_LIB", "") else None
+    if trace:
+        trace(None, 1)
     for i in range(reps):
         t0 = time.perf_counter()
         rc = fn(*argv[i % 8])
         ts.append(time.perf_counter() - t0)
         _lib.check(rc)
+    if trace:          # tuning library: where inside the call the host's time goes
+        tr = (_lib.C.c_uint64 * 16)()
+        trace(tr, 1)
+        print("%-28s thr=%.1f  inside the call (host clock): " % (label, thr) +
+              "  ".join("%s %.1f" % (nm, tr[j] / tr[15] / 1e3) for j, nm in ((1, "stage"), (2, "run"), (3, "export"), (4, "wait"), (5, "collect"))) + " us")
     ts.sort()
     print("%-28s thr=%.1f  bigsi_hip_search_batch (the C call alone)            %6.1f us median  (p10 %.1f, p90 %.1f, mean %.1f)"
           % (label, thr, ts[len(ts) // 2] * 1e6, ts[len(ts) // 10] * 1e6, ts[len(ts) * 9 // 10] * 1e6, sum(ts) / len(ts) * 1e6))
