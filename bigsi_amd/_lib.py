@@ -160,6 +160,10 @@ SIGNATURES = {
     "bigsi_hip_set_profiling": (_i32, [_P, _i32]),
     "bigsi_hip_stats": (_i32, [_P, C.POINTER(Stats), _i32]),
     "bigsi_hip_probe_rows": (_i32, [_P, _u32, _u32, _u32, _u32, _u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "bigsi_hip_fasta_pack": (_i32, [_P, _u64, _P, _P, _u64, C.POINTER(_u64)]),
+    "bigsi_hip_format_results": (_i32, [_i32, _P, _P, _u64, C.c_char_p, C.c_char_p, _i32, _P, _P, _P, _P, _P, _P, _P, _u64, _u32,
+                                         C.POINTER(_P), C.POINTER(_u64)]),
+    "bigsi_hip_free_text": (None, [_P]),
 }
 
 _lib = None
@@ -208,6 +212,34 @@ def ptr(a):
         return None
     assert a.flags["C_CONTIGUOUS"]
     return a.ctypes.data
+
+
+def fasta_pack(data):
+    """bigsi_hip_fasta_pack over the bytes of a FASTA file: (uint8 blob, uint64 offsets[n+1]) of its sequences, or None when the
+    text is not plain ASCII (the caller's Python route then reads the file)."""
+    n_max = data.count(b">")
+    blob, off = np.empty(max(len(data), 1), np.uint8), np.empty(n_max + 1, np.uint64)
+    n = C.c_uint64(0)
+    rc = lib().bigsi_hip_fasta_pack(data, len(data), ptr(blob), ptr(off), n_max, C.byref(n))
+    if rc == ERR_INVALID:
+        return None
+    check(rc)
+    return blob[:int(off[n.value])], off[:n.value + 1]
+
+
+def format_results(fmt, blob, soff, threshold, citation_json, nu, off, col, cnt, names, name_off, deleted, threads=0):
+    """bigsi_hip_format_results -> str (the reference's bulk_search text of an unscored search); BigsiHipError(ERR_STATE) where the
+    reference raises instead of answering."""
+    import json
+    text, size = C.c_void_p(), C.c_uint64(0)
+    n = len(soff) - 1
+    check(lib().bigsi_hip_format_results(int(fmt), ptr(blob) if not isinstance(blob, bytes) else blob, ptr(soff), n, json.dumps(threshold).encode(),
+                                         citation_json.encode(), 1 if threshold == 1.0 else 0, ptr(nu), ptr(off), ptr(col), ptr(cnt), names, ptr(name_off),
+                                         ptr(deleted), len(name_off) - 1, int(threads), C.byref(text), C.byref(size)))
+    try:
+        return str(memoryview((C.c_char * size.value).from_address(text.value)), "ascii") if size.value else ""
+    finally:
+        lib().bigsi_hip_free_text(text)
 
 
 def pack_seqs(seqs):

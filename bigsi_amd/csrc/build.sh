@@ -17,5 +17,5 @@ fi
 "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared \
     -Wall -Wextra -Wno-unused-parameter \
     -I"$ROOT/include" -I/opt/rocm/include $FLAGS \
-    -o "$OUT" "$HERE/bigsi_hip.hip" "$HERE/bigsi_shard.hip" -ldl
+    -o "$OUT" "$HERE/bigsi_hip.hip" "$HERE/bigsi_shard.hip" "$HERE/bigsi_text.cpp" -ldl -lpthread
 echo "built $OUT"

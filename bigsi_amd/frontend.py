@@ -67,9 +67,56 @@ def search(bigsi, seq, threshold=1.0, score=False, format="json"):
     return d_to_csv(d) if format == "csv" else json.dumps(d, indent=4)
 
 
+def _bulk_text_native(bigsi, fasta, threshold, format):
+    """The text of an unscored bulk search without a Python object per record: bigsi_hip_fasta_pack -> bigsi_hip_search_stream ->
+    bigsi_hip_format_results (include/bigsi_hip.h, "FRONT-END TEXT").  None when this route does not apply -- text that is not
+    plain ASCII (file or sample names), a multi-GPU index, a record on which the reference raises: the per-record route below
+    then does what it always did."""
+    import numpy as np
+    from . import _lib
+    from .graph.metadata import DELETION_SPECIAL_SAMPLE_NAME
+    st = getattr(bigsi, "storage", None)
+    if st is None or not hasattr(st, "search_many_packed") or st.res.is_group or not isinstance(fasta, str):
+        return None
+    with open(fasta, "rb") as f:
+        packed = _lib.fasta_pack(f.read())
+    if packed is None:
+        return None
+    blob, soff = packed
+    with bigsi._device_lock():
+        nk, nu, off, col, cnt = st.search_many_packed(blob, soff, bigsi.kmer_size, threshold)
+    if len(nu) and int(nu.min()) == 0:
+        return None
+    ns = bigsi.num_samples
+    used = np.unique(col)
+    used = used[used < ns].tolist()
+    try:
+        names = [bigsi.colour_to_sample(c) for c in used]
+        enc = [nm.encode("ascii") for nm in names]
+    except (KeyError, UnicodeEncodeError):
+        return None
+    name_off, deleted = np.zeros(ns + 1, np.uint64), np.zeros(max(ns, 1), np.uint8)
+    if used:
+        lens = np.zeros(ns, np.uint64)
+        lens[used] = [len(e) for e in enc]
+        np.cumsum(lens, out=name_off[1:])
+        deleted[[c for c, nm in zip(used, names) if nm == DELETION_SPECIAL_SAMPLE_NAME]] = 1
+    try:
+        return _lib.format_results(1 if format == "csv" else 0, blob, soff, threshold, json.dumps(CITATION), nu, off, col, cnt, b"".join(enc) + b"\0",
+                                   name_off, deleted)
+    except _lib.BigsiHipError as e:
+        if e.code == _lib.ERR_STATE:
+            return None
+        raise
+
+
 def bulk_search(bigsi, fasta, threshold=1.0, score=False, format="json", stream=False, out=None):
     """All records of a FASTA file in one device batch.  Returns the combined text (stream=False) or prints one record
     per line as the reference's streaming branch does and returns None."""
+    if not stream and not score and hasattr(bigsi, "_device_lock"):
+        text = _bulk_text_native(bigsi, fasta, threshold, format)
+        if text is not None:
+            return text
     seqs = [s for _, s in read_fasta(fasta)]
     if hasattr(bigsi, "search_stream"):       # the C ABI's streaming searches; the text of one slice is assembled while the next one runs
         size = getattr(bigsi, "config", {}).get("batch_size")          # default: slices of ~4M k-mers

@@ -506,10 +506,25 @@ class HipHbmStorage(BaseStorage):
         if self.res.is_group:
             raise BigsiHipError(_lib.ERR_STATE, "search_many is not available on a multi-GPU index")
         blob, soff = _lib.pack_seqs(seqs)
+        return self.search_many_packed(blob, soff, k, threshold)
+
+    def search_many_packed(self, blob, soff, k, threshold=1.0):
+        """search_many for sequences that are already packed: `blob` (bytes or a uint8 array) holds sequence i at
+        soff[i]:soff[i+1] (uint64, n + 1 entries) -- what bigsi_hip_fasta_pack leaves."""
+        import ctypes as C
+        assert threshold <= 1
+        n = len(soff) - 1
+        nk, nu = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        off = np.zeros(n + 1, np.uint64)
+        if n == 0:
+            return nk, nu, off, np.zeros(0, np.uint32), np.zeros(0, np.uint32)
+        if self.res.is_group:
+            raise BigsiHipError(_lib.ERR_STATE, "search_many is not available on a multi-GPU index")
+        text = blob if isinstance(blob, bytes) else C.cast(_lib.ptr(blob), C.c_char_p)
         cap = max(self._search_cap, 1 << 12)
         while True:
             col, cnt = np.zeros(cap, np.uint32), np.zeros(cap, np.uint32)
-            rc = _lib.lib().bigsi_hip_search_stream(self.handle, blob, _lib.ptr(soff), n, int(k), float(threshold), 0, _lib.ptr(nk), _lib.ptr(nu), None,
+            rc = _lib.lib().bigsi_hip_search_stream(self.handle, text, _lib.ptr(soff), n, int(k), float(threshold), 0, _lib.ptr(nk), _lib.ptr(nu), None,
                                                     _lib.ptr(off), _lib.ptr(col), _lib.ptr(cnt), cap)
             if rc != _lib.ERR_CAPACITY or int(off[-1]) <= cap:
                 break

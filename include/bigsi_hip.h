@@ -379,6 +379,32 @@ int bigsi_hip_stats(bigsi_hip_index *ix, bigsi_hip_stats_t *out, int reset); /* 
 int bigsi_hip_probe_rows(bigsi_hip_index *ix, uint32_t rows_per_query, uint32_t n_queries, uint32_t sorted, uint32_t wgs, uint32_t reps,
                          double *gbps, double *launch_ms);
 
+/* ================================================================== FRONT-END TEXT (host only)
+ * What `bigsi bulk_search` reads and returns (bigsi/__main__.py:41-72, 261-314: pyfasta records in, json.dumps(records, indent=4)
+ * or csv.writer rows out), over the arrays of bigsi_hip_search_stream instead of a Python object per record and per result.
+ *
+ * bigsi_hip_fasta_pack: the sequences of a FASTA text (header lines start with '>' after stripping; the stripped lines of a record
+ * concatenated; '\r', '\n' and "\r\n" all end a line) packed as the search entry points take them: record i =
+ * out_seqs[out_offsets[i] .. out_offsets[i+1]).  out_seqs needs n_bytes bytes at most, out_offsets n_records + 1 entries: call
+ * once with out_seqs = out_offsets = NULL for the count.  BIGSI_ERR_INVALID for a byte >= 0x80 (the caller's own text route
+ * then decides what the file's encoding means).
+ *
+ * bigsi_hip_format_results: the text of an unscored bulk search.  format 0 = the JSON list (threshold_text / citation_text: the
+ * JSON of those two values, written into every record), 1 = the CSV rows of every record joined by '\n' (no header; each
+ * record's last '\n' dropped, as the reference does).  exact != 0: threshold == 1.0 (every hit reports all num_unique k-mers,
+ * ascending colours); else hits below n_names in a stable sort by count, descending.  names / name_offsets: sample name of
+ * colour c = names[name_offsets[c] .. name_offsets[c+1]) (only colours that occur need a non-empty name); name_deleted[c] != 0
+ * drops the sample (graph/bigsi.py:186-190).  percent_kmers_found is repr(round(100 * float(found) / num_kmers, 2)).
+ * BIGSI_ERR_STATE when the reference would raise instead of answering (a record without k-mers; exact hit on a colour without
+ * a name): the caller's per-record route raises its exception in record order.  *out_text is malloc'ed, NUL-terminated,
+ * *out_bytes long: release it with bigsi_hip_free_text.  threads = 0: up to 16 host threads. */
+int bigsi_hip_fasta_pack(const char *text, uint64_t n_bytes, char *out_seqs, uint64_t *out_offsets, uint64_t max_records, uint64_t *n_records);
+int bigsi_hip_format_results(int format, const char *seqs, const uint64_t *offsets, uint64_t n_seqs, const char *threshold_text,
+                             const char *citation_text, int exact, const uint32_t *num_unique, const uint64_t *hit_offsets,
+                             const uint32_t *colours, const uint32_t *counts, const char *names, const uint64_t *name_offsets,
+                             const uint8_t *name_deleted, uint64_t n_names, uint32_t threads, char **out_text, uint64_t *out_bytes);
+void bigsi_hip_free_text(char *text);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,6 +69,26 @@ for tag, reads in (("no_hits", rand_reads), ("8_hits_per_read", hit_reads)):
         t0 = time.perf_counter()
         n_fa = len(frontend.read_fasta(fn))
         rec["read_fasta_reads_per_s"] = n_fa / (time.perf_counter() - t0)
+        # the stages of the native text route (frontend._bulk_text_native), each on its own
+        from bigsi_amd import _lib
+        stages = {}
+        t0 = time.perf_counter()
+        with open(fn, "rb") as f:
+            data = f.read()
+        stages["file_read_ms"] = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
+        blob_, soff_ = _lib.fasta_pack(data)
+        stages["fasta_pack_ms"] = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
+        nk_, nu_, off_, col_, cnt_ = st.search_many_packed(blob_, soff_, k, 1.0)
+        stages["search_stream_ms"] = (time.perf_counter() - t0) * 1e3
+        name_off_ = np.arange(n_cols + 1, dtype=np.uint64) * 11
+        names_ = b"".join(b"sample%05d" % c for c in range(n_cols)) + b"\0"
+        for fmt_, key in ((0, "format_json_ms"), (1, "format_csv_ms")):
+            t0 = time.perf_counter()
+            text = _lib.format_results(fmt_, blob_, soff_, 1.0, json.dumps(frontend.CITATION), nu_, off_, col_, cnt_, names_, name_off_, np.zeros(n_cols, np.uint8))
+            stages[key] = (time.perf_counter() - t0) * 1e3
+        rec["native_route_stages"] = stages
         # the text equals the reference's (json.dumps of the record list, indent=4) on a sample of the file
         small = fasta_of(reads[:300])
         want = json.dumps([frontend.search_record(s, 1.0, r) for s, r in zip(reads[:300], b.search_batch(reads[:300], 1.0))], indent=4)

@@ -121,3 +121,64 @@ def test_frontend_end_to_end_on_device(tmp_path):
         assert n_all > 40
     finally:
         b.delete()
+
+
+@pytest.mark.gpu
+def test_bulk_search_native_text_route_is_the_per_record_routes_text(tmp_path, monkeypatch):
+    """bulk_search's unscored text comes from bigsi_hip_fasta_pack -> bigsi_hip_search_stream -> bigsi_hip_format_results; forcing
+    the per-record Python route on the same file must give the same characters: 3000 reads of which every tenth was added to a few
+    samples (one of them deleted afterwards, one named with characters JSON and CSV escape), exact and thresholded, both formats.
+    A file with a record the reference raises on, and a non-ASCII file, fall through to the per-record route."""
+    import numpy as np
+    import bigsi_amd
+    from bigsi_amd import frontend
+    rng = np.random.default_rng(11)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    reads = [lut[r].tobytes().decode() for r in rng.integers(0, 4, size=(3000, 70), dtype=np.uint8)]
+    cfg = {"storage-engine": "hip-hbm", "storage-config": {"name": "native_text"}, "k": 31, "m": 200003, "h": 3}
+    names = ["s%02d" % i for i in range(12)]
+    names[4] = 'odd "name", \\ with\ttab'
+    groups = [[] for _ in names]
+    for i in range(0, len(reads), 10):
+        r = reads[i]
+        kms = [r[j:j + 31] for j in range(len(r) - 30)]
+        for t in range(1 + i % 4):
+            c = (i // 10 + 5 * t) % len(names)
+            groups[c].extend(kms if t % 2 == 0 else kms[:25])      # whole reads in some samples, part of them in others
+    b = bigsi_amd.BIGSI.build(cfg, [bigsi_amd.BIGSI.bloom(cfg, ks or ["A" * 31]) for ks in groups], names)
+    try:
+        b.delete_sample(names[7])
+        fa = tmp_path / "reads.fa"
+        fa.write_text("".join(">r%d some text\n%s\n%s\n" % (i, r[:40], r[40:]) for i, r in enumerate(reads)))
+        taken = []
+        real = frontend._bulk_text_native
+        monkeypatch.setattr(frontend, "_bulk_text_native", lambda *a: taken.append(real(*a)) or taken[-1])
+        for fmt in ("json", "csv"):
+            for thr in (1.0, 0.6, 0.0):
+                taken.clear()
+                got = frontend.bulk_search(b, str(fa), thr, False, fmt)
+                assert taken and taken[0] is not None and got is taken[0]
+                monkeypatch.setattr(frontend, "_bulk_text_native", lambda *a: None)
+                want = frontend.bulk_search(b, str(fa), thr, False, fmt)
+                monkeypatch.setattr(frontend, "_bulk_text_native", lambda *a: taken.append(real(*a)) or taken[-1])
+                assert got == want, (fmt, thr)
+                if fmt == "json" and thr == 1.0:
+                    recs = json.loads(got)
+                    assert len(recs) == len(reads) and sum(len(r["results"]) for r in recs) >= 300
+                    assert any(x["sample_name"] == names[4] for r in recs for x in r["results"])
+                    assert not any(x["sample_name"] == names[7] for r in recs for x in r["results"])
+        # a record too short to have k-mers: the reference raises, and so does bulk_search (through the per-record route)
+        short = tmp_path / "short.fa"
+        short.write_text(">a\n%s\n>b\nACGT\n" % reads[0])
+        taken.clear()
+        with pytest.raises(TypeError):
+            frontend.bulk_search(b, str(short), 1.0)
+        assert taken == [None]
+        # non-ASCII text in the file: not this route's business
+        odd = tmp_path / "odd.fa"
+        odd.write_text(">a\n%s\n>b\n%sé%s\n" % (reads[0], reads[1][:35], reads[1][35:]), encoding="utf-8")
+        taken.clear()
+        text = frontend.bulk_search(b, str(odd), 1.0)
+        assert taken == [None] and len(json.loads(text)) == 2
+    finally:
+        b.delete()

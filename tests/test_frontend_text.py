@@ -1,0 +1,130 @@
+"""The host-side text helpers of the batch front-end (include/bigsi_hip.h "FRONT-END TEXT": bigsi_hip_fasta_pack,
+bigsi_hip_format_results) against the Python route they stand in for -- frontend.read_fasta, json.dumps(records, indent=4),
+frontend.d_to_csv -- which golden G9 pins to the reference's own output.  No device needed: the functions are host code."""
+import json
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+from bigsi_amd import _lib, frontend
+
+pytestmark = pytest.mark.skipif(not os.path.exists(_lib.LIB_PATH), reason="libbigsi_hip.so not built")
+
+FASTAS = [
+    ">r1\nACGT\n>r2\nGGCC\n",
+    ">r1 desc\r\nACGT\r\nTTAA\r\n\r\n>r2\r\n  GG CC \t\r\n",
+    "junk before the first header\nACGT\n>a\nAC\n\n\nGT\n>empty\n>b\nTT",
+    "",
+    "\n\n",
+    ">only\n",
+    ">x\rAC\rGT\r>y\rTT\r",
+    "  >indented header\n\x0bACGT\x1c\n>z\n>\nAA\n",
+]
+
+
+@pytest.mark.parametrize("text", FASTAS)
+def test_fasta_pack_gives_read_fastas_sequences(text):
+    fn = tempfile.mktemp(suffix=".fa")
+    with open(fn, "w", newline="") as f:
+        f.write(text)
+    try:
+        want = [s for _, s in frontend.read_fasta(fn)]
+        with open(fn, "rb") as f:
+            blob, off = _lib.fasta_pack(f.read())
+    finally:
+        os.remove(fn)
+    raw = blob.tobytes().decode()
+    got = [raw[int(off[i]):int(off[i + 1])] for i in range(len(off) - 1)]
+    assert got == want
+
+
+def test_fasta_pack_leaves_non_ascii_text_to_the_caller():
+    assert _lib.fasta_pack(">r\nAC\xc3\xa9GT\n".encode("latin-1")) is None
+
+
+def _python_text(fmt, seqs, threshold, nu, off, col, cnt, names, deleted):
+    """the per-record route of frontend.bulk_search over the same arrays"""
+    exact = threshold == 1.0
+    recs = []
+    for i, s in enumerate(seqs):
+        ts = [t for t in range(int(off[i]), int(off[i + 1])) if col[t] < len(names)]
+        if not exact:
+            ts = sorted(ts, key=lambda t: -int(cnt[t]))
+        r = []
+        for t in ts:
+            if deleted[col[t]]:
+                continue
+            f = int(nu[i]) if exact else int(cnt[t])
+            r.append({"percent_kmers_found": round(100 * float(f) / int(nu[i]), 2), "num_kmers": int(nu[i]), "num_kmers_found": f, "sample_name": names[col[t]]})
+        recs.append(frontend.search_record(s, threshold, r))
+    if fmt == "json":
+        return json.dumps(recs, indent=4)
+    return "\n".join(frontend.d_to_csv(d, False, False) if d["results"] else "" for d in recs)
+
+
+@pytest.mark.parametrize("fmt", ["json", "csv"])
+@pytest.mark.parametrize("threshold", [1.0, 0.4, 0.0])
+@pytest.mark.parametrize("n", [0, 1, 7, 9000])
+def test_format_results_is_the_python_routes_text(fmt, threshold, n):
+    rng = np.random.default_rng(n + int(threshold * 10))
+    alphabet = list("ACGTN") + ['"', "\\", "\t", "\n", "\r", "\x01", "\x1f", "/", " ", "\x7f", "a"]
+    seqs = ["".join(rng.choice(alphabet, size=int(rng.integers(0, 40)), p=[0.18] * 5 + [0.1 / 11] * 11)) for _ in range(n)]
+    n_names = 37
+    names = ["s%d" % c if c % 5 else 'na"me\\%d,\t' % c for c in range(n_names)]
+    deleted = np.zeros(n_names, np.uint8)
+    deleted[[3, 20]] = 1
+    nu = rng.integers(1, 3000, size=n).astype(np.uint32)
+    n_hits = np.where(rng.random(n) < 0.7, 0, rng.integers(1, 12, size=n)) if n else np.zeros(0, np.int64)
+    off = np.zeros(n + 1, np.uint64)
+    np.cumsum(n_hits, out=off[1:])
+    total = int(off[-1])
+    col = np.zeros(total, np.uint32)
+    cnt = np.zeros(total, np.uint32)
+    for i in range(n):
+        lo, hi = int(off[i]), int(off[i + 1])
+        # ascending colours as the device leaves them; some beyond the named samples (pad columns of a threshold-0 search)
+        col[lo:hi] = np.sort(rng.choice(n_names + (0 if threshold == 1.0 else 6), size=hi - lo, replace=False))
+        cnt[lo:hi] = rng.integers(0, int(nu[i]) + 1, size=hi - lo) // (1 if rng.random() < 0.5 else 7) * (1 if rng.random() < 0.5 else 7) % (int(nu[i]) + 1)
+    blob, soff = _lib.pack_seqs(seqs) if n else (b"", np.zeros(1, np.uint64))
+    enc = [nm.encode() for nm in names]
+    name_off = np.zeros(n_names + 1, np.uint64)
+    np.cumsum([len(e) for e in enc], out=name_off[1:])
+    for threads in (1, 0):
+        got = _lib.format_results(1 if fmt == "csv" else 0, blob, soff, threshold, json.dumps(frontend.CITATION), nu, off, col, cnt, b"".join(enc) + b"\0",
+                                  name_off, deleted, threads=threads)
+        assert got == _python_text(fmt, seqs, threshold, nu, off, col, cnt, names, deleted)
+
+
+def test_format_results_percentages_are_pythons_round_and_repr():
+    """every (found, num_kmers) pair up to 400 k-mers plus the half-way cases of larger queries, one hit per record"""
+    pairs = [(f, u) for u in range(1, 401) for f in range(0, u + 1)]
+    pairs += [(f, u) for u in (800, 970, 1600, 4000, 8000, 65535) for f in range(0, u + 1, max(1, u // 997))]
+    n = len(pairs)
+    nu = np.array([u for _, u in pairs], np.uint32)
+    cnt = np.array([f for f, _ in pairs], np.uint32)
+    col = np.zeros(n, np.uint32)
+    off = np.arange(n + 1, dtype=np.uint64)
+    seqs = ["A"] * n
+    blob, soff = _lib.pack_seqs(seqs)
+    text = _lib.format_results(1, blob, soff, 0.5, json.dumps(frontend.CITATION), nu, off, col, cnt, b"s\0", np.array([0, 1], np.uint64), np.zeros(1, np.uint8))
+    rows = text.split("\n")
+    assert len(rows) == n
+    for (f, u), row in zip(pairs, rows):
+        assert row == '"A",%d,%d,%r,"s"\r' % (u, f, round(100 * float(f) / u, 2)), (f, u)
+
+
+def test_format_results_leaves_the_references_errors_to_the_caller():
+    blob, soff = _lib.pack_seqs(["ACGT", "AC"])
+    nu, off = np.array([2, 0], np.uint32), np.zeros(3, np.uint64)
+    empty = np.zeros(0, np.uint32)
+    with pytest.raises(_lib.BigsiHipError) as e:
+        _lib.format_results(0, blob, soff, 1.0, "\"c\"", nu, off, empty, empty, b"\0", np.zeros(1, np.uint64), np.zeros(1, np.uint8))
+    assert e.value.code == _lib.ERR_STATE
+    # an exact hit on a colour without a name: KeyError in the reference
+    nu, off = np.array([2, 2], np.uint32), np.array([0, 1, 1], np.uint64)
+    with pytest.raises(_lib.BigsiHipError) as e:
+        _lib.format_results(0, blob, soff, 1.0, "\"c\"", nu, off, np.array([5], np.uint32), np.array([2], np.uint32), b"ab\0", np.array([0, 1, 2], np.uint64),
+                            np.zeros(2, np.uint8))
+    assert e.value.code == _lib.ERR_STATE
