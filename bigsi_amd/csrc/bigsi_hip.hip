@@ -2271,6 +2271,7 @@ static int presence_begin(bigsi_hip_batch *b, const uint64_t *hit_offsets, const
     std::vector<uint32_t> &hit_seq = job.hit_seq, &hit_q = job.hit_q, &perm = job.perm, &order = job.order;      // hit_seq: k-mers of the hit's sequence (its string length); hit_q: which sequence
     std::vector<uint64_t> &hit_pos0 = job.hit_pos0;
     std::vector<PresencePair> pairs;
+    std::vector<PresenceWave> waves;          // (k_presence_bits: a wavefront = up to 64 pairs of one query)
     hit_seq.resize(n_hits); hit_q.resize(n_hits); perm.resize(n_hits); hit_pos0.resize(n_hits);
     pairs.clear();
     for (uint64_t t = 0; t < n_hits; t++) perm[t] = (uint32_t)t;
@@ -2312,7 +2313,7 @@ static int presence_begin(bigsi_hip_batch *b, const uint64_t *hit_offsets, const
             perm[lo + r] = src;
             if ((uint64_t)(c >> 6) != last_word) { words++; last_word = c >> 6; }
         }
-        while (pairs.size() & 63u) pairs.push_back(PresencePair{0xFFFFFFFFu, 0u, 0ull, 0ull, q, 0u});      // whole wavefronts per query (k_presence_bits)
+        for (size_t f = first_pair; f < pairs.size(); f += 64) waves.push_back(PresenceWave{(uint32_t)f, (uint32_t)std::min<size_t>(64, pairs.size() - f)});
         max_u = std::max(max_u, b->h_num_unique[q]);
         max_n = std::max(max_n, b->h_num_kmers[q]);
         alg += (uint64_t)b->h_num_unique[q] * b->run_h * words * 8 +
@@ -2333,7 +2334,8 @@ static int presence_begin(bigsi_hip_batch *b, const uint64_t *hit_offsets, const
     // device input: [str_off | hit_seq | perm | hit_pos0 | pairs | hit_q | found | unique] in one upload from pinned memory
     const size_t o_str = 0, o_seq = round_up(o_str + (n_hits + 1) * 8, 256);
     const size_t o_perm = round_up(o_seq + n_hits * 4, 256), o_pos0 = round_up(o_perm + n_hits * 4, 256), o_pairs = round_up(o_pos0 + n_hits * 8, 256);
-    const size_t o_q = round_up(o_pairs + pairs.size() * sizeof(PresencePair), 256), o_hoff = round_up(o_q + n_hits * 4, 256);
+    const size_t o_waves = round_up(o_pairs + pairs.size() * sizeof(PresencePair), 256);
+    const size_t o_q = round_up(o_waves + waves.size() * sizeof(PresenceWave), 256), o_hoff = round_up(o_q + n_hits * 4, 256);
     // (K6) per rank: k-mers the hit found, unique k-mers of its sequence
     const size_t o_found = round_up(o_hoff + (nq + 1) * 8ull, 256), o_uniq = round_up(o_found + (packed ? n_hits * 4 : 0), 256);
     const size_t in_bytes = packed ? o_uniq + n_hits * 4 : o_hoff + (nq + 1) * 8ull;
@@ -2346,6 +2348,7 @@ static int presence_begin(bigsi_hip_batch *b, const uint64_t *hit_offsets, const
     memcpy(stage + o_perm, perm.data(), n_hits * 4);
     memcpy(stage + o_pos0, hit_pos0.data(), n_hits * 8);
     memcpy(stage + o_pairs, pairs.data(), pairs.size() * sizeof(PresencePair));
+    memcpy(stage + o_waves, waves.data(), waves.size() * sizeof(PresenceWave));
     memcpy(stage + o_q, hit_q.data(), n_hits * 4);
     for (uint32_t q = 0; q <= nq; q++) reinterpret_cast<uint64_t *>(stage + o_hoff)[q] = hit_offsets[q] - h0;
     if (packed)
@@ -2380,11 +2383,11 @@ static int presence_begin(bigsi_hip_batch *b, const uint64_t *hit_offsets, const
         b->marks_of_run = b->run_serial;
         b->marks_at = b->pres_desc.p;
     }
-    const dim3 grid_a((unsigned)ceil_div(std::max<uint64_t>(pairs.size(), 1), kBlock), (unsigned)ceil_div(std::max<uint32_t>(max_u, 1), 16), 1);
+    const dim3 grid_a((unsigned)ceil_div(std::max<uint64_t>(waves.size(), 1), kBlock / 64), (unsigned)ceil_div(std::max<uint32_t>(max_u, 1), 16), 1);
     static const int k5_waves = env_int("BIGSI_HIP_K5_WAVES", 2);
 #define BIGSI_PRESENCE_ARGS                                                                                                        \
     grid_a, dim3(kBlock), 0, ps, ix->d_index, ix->stride_words, b->rows.as<uint64_t>(), b->d_pos_off.as<uint64_t>(),            \
-        b->num_unique.as<uint32_t>(), ix->h, (uint64_t)pairs.size(), (const PresencePair *)(din + o_pairs),                            \
+        b->num_unique.as<uint32_t>(), ix->h, (uint32_t)waves.size(), (const PresenceWave *)(din + o_waves), (const PresencePair *)(din + o_pairs),   \
         b->pres_bits.as<uint16_t>(), n_chunks
 #define COMMA ,
 #define BIGSI_PRESENCE(H)                                                                          \

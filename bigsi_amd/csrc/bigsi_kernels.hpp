@@ -1715,29 +1715,37 @@ struct PresencePair {
     uint32_t q;              // the query the pair belongs to
     uint32_t reserved;
 };
+// one wavefront of k_presence_bits: `count` (<= 64) consecutive pairs of ONE query, from pairs[first] on
+struct PresenceWave {
+    uint32_t first, count;
+};
 
 
-// The grid is flat over the call's pairs (x; each query's pairs padded to a multiple of 64) and 16-k-mer chunks (y): a thresholded search of a few hundred queries of which a
+// The grid is flat over wavefronts of pairs (x; a wavefront takes up to 64 pairs of one query: PresenceWave) and 16-k-mer chunks (y): a thresholded search of a few hundred queries of which a
 // dozen have hits -- BASELINE configs[4] as benchmarked -- used to launch (pairs of the fullest query / 256) x chunks x queries
 // workgroups, nearly all of them empty, and waited for slots beside the next batch's row-AND kernel (166 us against 26 us alone).
 template <int H, int WAVES = 2>      // WAVES = 2: the compiler keeps all 16 x h loads of a thread in flight (~200 VGPRs), measured faster than 4
 __global__ __launch_bounds__(kBlock, WAVES) void k_presence_bits(
     const uint64_t *__restrict__ index, uint64_t stride_words, const uint64_t *__restrict__ rows, const uint64_t *__restrict__ pos_off,
-    const uint32_t *__restrict__ num_unique, uint32_t h_rt, uint64_t n_pairs, const PresencePair *__restrict__ pairs,
-    uint16_t *__restrict__ bits /* presence_bits_at(rank, chunk) */, uint32_t bits_stride)
+    const uint32_t *__restrict__ num_unique, uint32_t h_rt, uint32_t n_waves, const PresenceWave *__restrict__ waves,
+    const PresencePair *__restrict__ pairs, uint16_t *__restrict__ bits /* presence_bits_at(rank, chunk) */, uint32_t bits_stride)
 {
     const uint32_t h = H > 0 ? (uint32_t)H : h_rt;
     const uint32_t jc = blockIdx.y;
-    const uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (p >= n_pairs) return;
-    // the host pads every query's pairs to whole wavefronts, so the query -- and with it the k-mer count and every row id of the
-    // chunk -- is the same for all 64 lanes: scalar loads (per-lane row ids cost this kernel 70 % at 261 k hits)
-    const uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane((int)pairs[p & ~63ull].q);
+    // a wavefront's pairs all belong to one query (the host cuts the pair list that way: round 3 padded every query's pairs to 64
+    // entries instead -- 2 KB of upload per query with hits, nearly all of it padding for reads), so the query -- and with it the
+    // k-mer count and every row id of the chunk -- is the same for all 64 lanes: scalar loads (per-lane row ids cost this kernel
+    // 70 % at 261 k hits)
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)));
+    if (w >= n_waves) return;
+    const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)waves[w].first);
+    const uint32_t count = (uint32_t)__builtin_amdgcn_readfirstlane((int)waves[w].count);
+    const uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane((int)pairs[first].q);
     const uint32_t u = num_unique[q];
     const uint32_t j0 = jc * 16u;
     if (j0 >= u) return;
-    if (pairs[p].wpair == 0xFFFFFFFFu) return;          // padding
-    const PresencePair pr = pairs[p];
+    if ((threadIdx.x & 63u) >= count) return;
+    const PresencePair pr = pairs[first + (threadIdx.x & 63u)];
     const uint64_t *qrows = rows + pos_off[q] * h;
     const uint32_t woff = pr.wpair * 2u;
     const u64x2 zero = {0ull, 0ull};
