@@ -59,6 +59,14 @@ for tag, reads in (("no_hits", rand_reads), ("8_hits_per_read", hit_reads)):
     t0 = time.perf_counter()
     nk, nu, off, col, cnt = st.search_many(reads, k, 1.0)
     rec["search_many_arrays"] = {"reads_per_s": n_reads / (time.perf_counter() - t0), "hits": int(off[-1])}
+    if tag != "no_hits":
+        # score=True on reads (K5 + K6 inside the stream): 200 k reads with 8 hits each, arrays out
+        sub = reads[:200_000]
+        st.search_many_scored(sub[:20000], k, 1.0)
+        t0 = time.perf_counter()
+        r_ = st.search_many_scored(sub, k, 1.0)
+        dt = time.perf_counter() - t0
+        rec["search_many_scored_arrays"] = {"reads_per_s": len(sub) / dt, "scored_hits_per_s": int(r_[2][-1]) / dt}
     fn = fasta_of(reads)
     try:
         for fmt in ("json", "csv"):
