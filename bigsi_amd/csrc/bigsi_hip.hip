@@ -1285,7 +1285,10 @@ static K1Src k1_src(const bigsi_hip_batch *b)
     return K1Src{b->seqs.as<char>(), b->d_seq_off.as<uint64_t>(), b->d_pos_off.as<uint64_t>(), nullptr, 0u};
 }
 
-static int launch_reads_fused(bigsi_hip_batch *b, hipStream_t st = nullptr)
+static int export_prepare(bigsi_hip_batch *b, hipStream_t st);
+
+// `inline_export`: a one-call search of ONE read -- the kernel's only workgroup writes the caller's block and raises the flag itself
+static int launch_reads_fused(bigsi_hip_batch *b, hipStream_t st = nullptr, bool inline_export = false)
 {
     const uint32_t fp_mask = b->weak_fp ? 1u : ~0u;
     if (!st) st = b->ix->stream;
@@ -1309,6 +1312,12 @@ static int launch_reads_fused(bigsi_hip_batch *b, hipStream_t st = nullptr)
         hb.gen = 0;
     }
     hb.gen++;
+    b->exported_inline = false;
+    if (inline_export) {
+        TRY(export_prepare(b, st));
+        if (b->exp_flagged) b->exported_inline = true;
+        else b->exp_serial--;          // (tuning builds with the event route: the export kernel as usual)
+    }
     const K1Src src = k1_src(b);
 #define BIGSI_READS_ARGS                                                                                                          \
     dim3(b->n_seqs), dim3(kBlock), 0, st, ix->d_index, ix->stride_words, (uint32_t)b->wv, ix->n_cols, ix->m, b->threshold,              \
@@ -1316,7 +1325,8 @@ static int launch_reads_fused(bigsi_hip_batch *b, hipStream_t st = nullptr)
         b->pos_unique.as<uint32_t>(), b->rep.as<uint32_t>(), b->rows.as<uint64_t>(), b->num_kmers.as<uint32_t>(),                      \
         b->num_unique.as<uint32_t>(), b->min_kmers.as<uint32_t>(), b->bitmaps.as<uint64_t>(), b->wv_pad, hb.q_start.as<uint64_t>(),   \
         hb.q_cnt.as<uint32_t>(), hb.alloc.as<unsigned long long>(), hb.gen & 1u, hb.col(), hb.cnt(), hb.capacity(), fp_mask,            \
-        src.pos_off_out, src.one_len
+        src.pos_off_out, src.one_len, b->exported_inline ? static_cast<uint64_t *>(b->pin_out) : nullptr, b->exp_spec,                          \
+        (volatile uint64_t *)b->pin_flag, b->exp_serial
 #define COMMA ,
 #define BIGSI_READS(H)                                                                              \
     if (b->exact) hipLaunchKernelGGL((k_reads_fused<H COMMA true>), BIGSI_READS_ARGS);                \
@@ -1562,6 +1572,7 @@ int bigsi_batch_run(bigsi_hip_batch *b, double threshold, uint32_t flags, bool o
     b->wv_pad = round_up(b->wv, 2);
 
     b->fused_run = false;
+    b->exported_inline = false;
     if (reads_fusable(b, flags)) {
         // (K1 rewrites arrays the previous run of this batch may still be reading, on a read stream or the gather stream)
         TRY(b->rows.reserve(std::max<uint64_t>(b->total_pos, 1) * ix->h * 8));
@@ -1582,7 +1593,8 @@ int bigsi_batch_run(bigsi_hip_batch *b, double threshold, uint32_t flags, bool o
         TRY(flush_upload(b, st, true));
         TRY(ev_begin(ix, &fe, st, true));
         b->weak_fp = (flags & BIGSI_RUN_WEAK_FINGERPRINT) != 0;
-        TRY(launch_reads_fused(b, st));
+        static const int inline_env = env_int("BIGSI_HIP_INLINE_EXPORT", 1);
+        TRY(launch_reads_fused(b, st, one_call && inline_env && b->n_seqs == 1));
         TRY(ev_end(ix, &fe, ix->ev_and, st));
         b->run_h = ix->h;
         b->fused_run = true;
@@ -2577,6 +2589,7 @@ int bigsi_batch_export(bigsi_hip_batch *b)
 {
     if (!b || !b->ran) return fail(BIGSI_ERR_STATE, "bigsi_hip_batch_run has not completed for this batch");
     if (!b->compacted) return fail(BIGSI_ERR_STATE, "internal: export of a run without hit lists");
+    if (b->exported_inline) return BIGSI_OK;          // (one read: its kernel wrote the block and raises the flag)
     HitBufs &hb = b->hits;
     hipStream_t st = b->run_stream ? b->run_stream : b->ix->stream;
     const uint32_t n = b->n_seqs;

@@ -184,6 +184,7 @@ struct bigsi_hip_batch {
     size_t pin_up_cap = 0, pin_out_cap = 0, pin_up_bytes = 0;
     bool upload_deferred = false;                    // pin_up holds tables + sequences that the next run uploads on its stream
     bool one_call = false;                           // the index's bigsi_hip_search_batch workspace: nothing else ever touches it
+    bool exported_inline = false;   // the last run's read kernel wrote the export block itself (one read in a one-call search)
     bool zero_copy = false;                          // this load's tables + sequences are read by K1 straight from pin_up (no upload)
     bool idle = false;                               // nothing of this batch is in flight (its last export was collected)
     bool done_stale = false;                         // the last run did not record `done` (one-call route): wait on its stream instead

@@ -1349,7 +1349,10 @@ __global__ __launch_bounds__(kBlock) void k_reads_fused(
     uint32_t slot, uint32_t *__restrict__ hit_col, uint32_t *__restrict__ hit_cnt,
     uint64_t capacity, uint32_t fp_mask /* ~0; 1 = BIGSI_RUN_WEAK_FINGERPRINT */,
     uint64_t *__restrict__ pos_off_out /* as k_kmerize_lds: inputs come straight from pinned host memory */,
-    uint32_t one_len /* as k_kmerize_lds */)
+    uint32_t one_len /* as k_kmerize_lds */,
+    uint64_t *exp_out /* non-null: a one-call search of ONE read -- the workgroup also writes the caller's block in pinned memory
+                         (k_export_reads' layout) and raises the flag the host spins on: no export kernel, no launch boundary */,
+    uint32_t exp_spec, volatile uint64_t *exp_flag, uint64_t exp_serial)
 {
     constexpr int KF = 31, P = 6;
     if (pos_off_out && threadIdx.x == 0) {
@@ -1570,20 +1573,39 @@ __global__ __launch_bounds__(kBlock) void k_reads_fused(
             while (mcol) {
                 const uint32_t c = (uint32_t)__builtin_ctzll(mcol);
                 mcol &= mcol - 1;
-                hit_col[o] = (uint32_t)(((uint64_t)w0 + v) * 64 + c);
-                if (EXACT) {
-                    hit_cnt[o] = u;
-                } else {
+                const uint32_t colour = (uint32_t)(((uint64_t)w0 + v) * 64 + c);
+                uint32_t x = u;
+                if (!EXACT) {
                     const uint32_t bp = bit_of_col(c);
-                    uint32_t x = 0;
+                    x = 0;
 #pragma unroll
                     for (int p = 0; p < P; p++) x |= (uint32_t)((pl[v][p] >> bp) & 1ull) << p;
-                    hit_cnt[o] = x;
+                }
+                hit_col[o] = colour;
+                hit_cnt[o] = x;
+                if (exp_out && o < exp_spec) {             // (one query: its list starts at 0)
+                    uint32_t *ocol = reinterpret_cast<uint32_t *>(exp_out + 3) + 4;      // offsets (2) | 0 | counts (3, padded to 4) | colours | counts
+                    ocol[o] = colour;
+                    ocol[exp_spec + o] = x;
                 }
                 o++;
             }
         }
     }
+    if (!exp_out) return;
+    if (threadIdx.x == 0) {
+        exp_out[0] = 0;
+        exp_out[1] = tot;
+        exp_out[2] = 0;
+        uint32_t *o32 = reinterpret_cast<uint32_t *>(exp_out + 3);
+        const uint32_t len = one_len ? one_len : (uint32_t)(seq_off[1] - seq_off[0]);
+        o32[0] = len >= (uint32_t)KF ? len - KF + 1 : 0u;
+        o32[1] = s_u;
+        o32[2] = s_min;
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) *exp_flag = exp_serial;
 }
 
 template <typename CountT, bool WRITE>

@@ -367,6 +367,44 @@ def test_rows_file_io_with_any_row_length(hip, tmp_path):
 
 
 @pytest.mark.parametrize("n_cols,h", [(333, 2), (5000, 3), (70016, 4)])
+def test_one_call_searches_of_one_read_equal_the_batch_route(hip, n_cols, h):
+    """ONE read per bigsi_hip_search_batch call: the read kernel's only workgroup writes the caller's block itself and raises the
+    flag (no export kernel).  Reads of 31..93 bp, planted in a few samples or not, exact and thresholded -- threshold 0.0 returns
+    every sample: more hits than the block carries (1024) and, on the widest index, than the hit buffers hold (65 536), which take
+    the fetch route and the regrow route -- against the batch objects; other shapes through the same workspace in between."""
+    m = 200003
+    _, st = synth_index(hip, m, n_cols, h, 777)
+    rng = np.random.default_rng(n_cols + 1)
+    reads = ["".join(rng.choice(list("ACGT"), size=L)) for L in (31, 32, 61, 61, 75, 93, 93, 40)]
+    reads += [reads[2][:45] + "N" + reads[2][46:], reads[3].lower(), reads[4][:35] + reads[4][:35]]
+    for i, q in enumerate(reads[:6]):
+        for c in rng.choice(n_cols, size=4, replace=False):
+            st.insert_kmers(int(c), [q if i % 2 == 0 else q[:50]], 31)
+
+    def general(seqs, thr):
+        b = st.new_batch(seqs, 31)
+        b.run(thr, sparse_counts=thr < 1.0)
+        nk, nu, _ = b.unique()
+        off, col, cnt = b.hits()
+        b.close()
+        return [(int(nk[i]), int(nu[i]), col[int(off[i]):int(off[i + 1])].tolist(), cnt[int(off[i]):int(off[i + 1])].tolist()) for i in range(len(seqs))]
+
+    found = 0
+    for rounds in range(2):
+        for thr in (1.0, 0.5, 0.0):
+            for i, q in enumerate(reads):
+                (k_, u_, col, cnt), = st.search_batch([q], 31, thr)
+                want = general([q], thr)[0]
+                assert (k_, u_, col.tolist(), cnt.tolist()) == want, (thr, i, len(q))
+                found += len(want[2]) if thr == 1.0 else 0
+                if i % 4 == 3:
+                    got = st.search_batch(reads[:5], 31, thr)
+                    assert [(a, b_, c.tolist(), d.tolist()) for a, b_, c, d in got] == general(reads[:5], thr), (thr, i)
+    assert found >= 2 * 3 * 4
+    st.delete_all()
+
+
+@pytest.mark.parametrize("n_cols,h", [(333, 2), (5000, 3), (70016, 4)])
 def test_one_call_searches_of_one_query_equal_the_batch_route(hip, n_cols, h):
     """bigsi_hip_search_batch -- the serving call: staged input read by K1 in place (zero copy), no completion event, the export
     kernel's flag -- for ONE query at a time: same numbers and hit lists as the batch objects (create / run / fetch) for lengths on both
