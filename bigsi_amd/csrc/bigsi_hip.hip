@@ -1328,8 +1328,15 @@ static int launch_reads_fused(bigsi_hip_batch *b, hipStream_t st = nullptr, bool
         src.pos_off_out, src.one_len, b->exported_inline ? static_cast<uint64_t *>(b->pin_out) : nullptr, b->exp_spec,                          \
         (volatile uint64_t *)b->pin_flag, b->exp_serial
 #define COMMA ,
+    // rows of at most kBlock words, counting: one word per lane (8-byte loads: half the registers -- 8 wavefronts per SIMD instead
+    // of 4 -- and twice the lanes that hold columns).  Interleaved A/B at C2: counting 1377 -> 1523 M lookups/s; the exact kernel
+    // (6 -> 8 wavefronts per SIMD) 1563 -> 1534 M: stays at two words per lane
+    static const int vec1_exact = env_int("BIGSI_HIP_READS_VEC1_EXACT", 0), vec1_count = env_int("BIGSI_HIP_READS_VEC1_COUNT", 1);
+    const bool narrow = b->wv <= (uint64_t)kBlock;
 #define BIGSI_READS(H)                                                                              \
-    if (b->exact) hipLaunchKernelGGL((k_reads_fused<H COMMA true>), BIGSI_READS_ARGS);                \
+    if (b->exact && narrow && vec1_exact) hipLaunchKernelGGL((k_reads_fused<H COMMA true COMMA 1>), BIGSI_READS_ARGS);   \
+    else if (b->exact) hipLaunchKernelGGL((k_reads_fused<H COMMA true>), BIGSI_READS_ARGS);                \
+    else if (narrow && vec1_count) hipLaunchKernelGGL((k_reads_fused<H COMMA false COMMA 1>), BIGSI_READS_ARGS);       \
     else hipLaunchKernelGGL((k_reads_fused<H COMMA false>), BIGSI_READS_ARGS)
     switch (ix->h) {
     case 2: BIGSI_READS(2); break;

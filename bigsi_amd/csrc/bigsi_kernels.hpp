@@ -829,6 +829,27 @@ __device__ __forceinline__ u64x2 load_row_seg(const uint64_t *__restrict__ index
     return *p;
 }
 
+// VEC consecutive 64-column words of a row, streamed: 2 = one 16-byte load (every row kernel's unit), 1 = one 8-byte load
+// (k_reads_fused on rows of <= kBlock words: half the registers per lane, twice the lanes that hold columns)
+template <int VEC>
+struct RowWords;
+template <>
+struct RowWords<2> {
+    u64x2 v;
+    static __device__ __forceinline__ RowWords load(const uint64_t *__restrict__ index, uint64_t row, uint64_t stride_words, uint32_t w0) { return RowWords{load_row_seg(index, row, stride_words, w0)}; }
+    static __device__ __forceinline__ RowWords fill(uint64_t x) { return RowWords{u64x2{x, x}}; }
+    __device__ __forceinline__ RowWords &operator&=(const RowWords &o) { v &= o.v; return *this; }
+    __device__ __forceinline__ uint64_t word(int e) const { return e ? v.y : v.x; }
+};
+template <>
+struct RowWords<1> {
+    uint64_t v;
+    static __device__ __forceinline__ RowWords load(const uint64_t *__restrict__ index, uint64_t row, uint64_t stride_words, uint32_t w0) { return RowWords{__builtin_nontemporal_load(index + row * stride_words + w0)}; }
+    static __device__ __forceinline__ RowWords fill(uint64_t x) { return RowWords{x}; }
+    __device__ __forceinline__ RowWords &operator&=(const RowWords &o) { v &= o.v; return *this; }
+    __device__ __forceinline__ uint64_t word(int) const { return v; }
+};
+
 // ------------------------------------------------------------------------------ K2 + K3a: exact
 // AND of every row of every unique k-mer of the query (graph/index.py:75-80 then graph/bigsi.py:192-195):
 // out[q][w] for w < wv.  Sequences without k-mers produce an all-zero bitmap (the host shim raises for them).
@@ -1337,7 +1358,7 @@ __global__ __launch_bounds__(kBlock) void k_hits_write(
 // to entries of the hit buffers it allocates with one atomic add (round 4: no order between queries, no waiting; see the
 // kernel's last section).  Same results, one launch.
 constexpr uint32_t kReadsMaxSeqs = 1u << 20;  // queries per launch of k_reads_fused at most
-template <int H, bool EXACT>
+template <int H, bool EXACT, int VEC = kVec /* 64-column words per lane: 2 (16-byte loads) or 1 (8-byte loads; rows of <= kBlock words) */>
 __global__ __launch_bounds__(kBlock) void k_reads_fused(
     const uint64_t *__restrict__ index, uint64_t stride_words, uint32_t wv, uint64_t n_cols, uint64_t m, double threshold,
     const char *__restrict__ seqs, const uint64_t *__restrict__ seq_off, const uint64_t *__restrict__ pos_off, uint32_t n_seqs,
@@ -1479,56 +1500,60 @@ __global__ __launch_bounds__(kBlock) void k_reads_fused(
     // already moves 5.7 TB/s of 1.25 KB rows, and the HBM is the limit, not the round trips.)
     const uint32_t u = s_u;
     BIGSI_PHASE(1);
-    const uint32_t w0 = threadIdx.x * kVec;
+    const uint32_t w0 = threadIdx.x * VEC;
     const bool live = w0 < wv;
-    uint64_t hitw[kVec] = {0ull, 0ull};
-    uint64_t pl[kVec][P];
+    uint64_t hitw[VEC];
+    uint64_t pl[VEC][P];
+#pragma unroll
+    for (int v = 0; v < VEC; v++) hitw[v] = 0ull;
     if (EXACT) {
         constexpr int UNR = 16;
         const uint32_t R = u * H;
-        const u64x2 ones = {~0ull, ~0ull};
-        u64x2 acc = ones;
+        RowWords<VEC> acc = RowWords<VEC>::fill(~0ull);
         if (live) {
             for (uint32_t r = 0; r < R; r += UNR) {
-                u64x2 v[UNR];
+                RowWords<VEC> v[UNR];
 #pragma unroll
-                for (int j = 0; j < UNR; j++) v[j] = r + j < R ? load_row_seg(index, s_rows[r + j], stride_words, w0) : ones;
+                for (int j = 0; j < UNR; j++) v[j] = r + j < R ? RowWords<VEC>::load(index, s_rows[r + j], stride_words, w0) : RowWords<VEC>::fill(~0ull);
 #pragma unroll
                 for (int j = 0; j < UNR; j++) acc &= v[j];
             }
-            if (R == 0) acc = u64x2{0ull, 0ull};
-            hitw[0] = acc.x & valid_mask(w0, n_cols);
-            hitw[1] = acc.y & valid_mask(w0 + 1, n_cols);
+            if (R == 0) acc = RowWords<VEC>::fill(0ull);
+#pragma unroll
+            for (int v = 0; v < VEC; v++) hitw[v] = acc.word(v) & valid_mask((uint64_t)w0 + v, n_cols);
         }
     } else {
 #pragma unroll
-        for (int v = 0; v < kVec; v++)
+        for (int v = 0; v < VEC; v++)
 #pragma unroll
             for (int p = 0; p < P; p++) pl[v][p] = 0;
         if (live) {
             constexpr int KM = H <= 2 ? 8 : H == 3 ? 6 : 4;
-            const u64x2 zero = {0ull, 0ull};
             for (uint32_t j = 0; j < u; j += KM) {
-                u64x2 v[KM * H];
+                RowWords<VEC> v[KM * H];
 #pragma unroll
-                for (int t = 0; t < KM * H; t++) v[t] = j + t / H < u ? load_row_seg(index, s_rows[(j + t / H) * H + t % H], stride_words, w0) : zero;
+                for (int t = 0; t < KM * H; t++)
+                    v[t] = j + t / H < u ? RowWords<VEC>::load(index, s_rows[(j + t / H) * H + t % H], stride_words, w0) : RowWords<VEC>::fill(0ull);
 #pragma unroll
                 for (int g = 0; g < KM; g++) {
-                    u64x2 a = v[g * H];
+                    RowWords<VEC> a = v[g * H];
 #pragma unroll
                     for (int t = 1; t < H; t++) a &= v[g * H + t];
-                    uint64_t c0 = a.x, c1 = a.y;
 #pragma unroll
-                    for (int p = 0; p < P; p++) {
-                        const uint64_t t0 = pl[0][p] & c0, t1 = pl[1][p] & c1;
-                        pl[0][p] ^= c0; pl[1][p] ^= c1;
-                        c0 = t0; c1 = t1;
+                    for (int e = 0; e < VEC; e++) {
+                        uint64_t c = a.word(e);
+#pragma unroll
+                        for (int p = 0; p < P; p++) {
+                            const uint64_t t0 = pl[e][p] & c;
+                            pl[e][p] ^= c;
+                            c = t0;
+                        }
                     }
                 }
             }
             const uint32_t thr = s_min;
 #pragma unroll
-            for (int v = 0; v < kVec; v++) {
+            for (int v = 0; v < VEC; v++) {
                 uint64_t gt = 0, eq = ~0ull;
                 if ((thr >> P) != 0) eq = 0;
 #pragma unroll
@@ -1543,8 +1568,9 @@ __global__ __launch_bounds__(kBlock) void k_reads_fused(
     BIGSI_PHASE(2);
     if (live) {
         uint64_t *o = out_bits + (uint64_t)q * out_stride_words + w0;
-        o[0] = hitw[0];
-        if (w0 + 1 < out_stride_words) o[1] = hitw[1];
+#pragma unroll
+        for (int v = 0; v < VEC; v++)
+            if (w0 + v < out_stride_words) o[v] = hitw[v];
     }
     // ---- K4: this query's hits, at a place of their own.  The workgroup takes `tot` consecutive entries of the batch's hit buffers
     // with ONE atomic add and leaves (start, count) for its query; the lists of different queries lie in whatever order the
@@ -1552,7 +1578,9 @@ __global__ __launch_bounds__(kBlock) void k_reads_fused(
     // fetch_hits -- puts them in query order from the counts.  Nobody waits for anybody: rounds 2 and 3 wrote the lists in query
     // order through a publish-and-sum scan whose workgroups spun on the totals of their predecessors (bounded by a timeout and
     // a host-side repeat, but leaning on dispatch order for progress, and 3 us of every 29 us launch).
-    const uint32_t mine = (uint32_t)(__popcll(hitw[0]) + __popcll(hitw[1]));
+    uint32_t mine = 0;
+#pragma unroll
+    for (int v = 0; v < VEC; v++) mine += (uint32_t)__popcll(hitw[v]);
     uint32_t tot;
     const uint32_t pre = block_exclusive_scan(mine, &tot, lds);
     if (threadIdx.x == 0) {
@@ -1568,7 +1596,7 @@ __global__ __launch_bounds__(kBlock) void k_reads_fused(
     if (mine != 0 && start + tot <= capacity) {      // (else the host sees total > capacity, grows the lists and launches again)
         uint64_t o = start + pre;
 #pragma unroll
-        for (int v = 0; v < kVec; v++) {
+        for (int v = 0; v < VEC; v++) {
             uint64_t mcol = by_column(hitw[v]);
             while (mcol) {
                 const uint32_t c = (uint32_t)__builtin_ctzll(mcol);
