@@ -161,7 +161,7 @@ def main():
     for name in (R + "_latency_probe.txt", R + "_frontend_probe.json", R + "_bench_default_full.json"):
         if os.path.exists(os.path.join(SRC, name)):
             shutil.copy(os.path.join(SRC, name), os.path.join(DST, name))
-    for name in (R + "_row_probe.txt", R + "_call_breakdown.txt"):
+    for name in (R + "_row_probe.txt", R + "_call_breakdown.txt", R + "_call_trace.txt", R + "_k1_phases.txt"):
         if os.path.exists(os.path.join(SRC, name)):
             shutil.copy(os.path.join(SRC, name), os.path.join(DST, name))
     with open(os.path.join(DST, R + "_summary.json"), "w") as f:

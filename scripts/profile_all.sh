@@ -37,6 +37,8 @@ run ${R}_scored_stream   -- python scripts/scored_stream_probe.py
   scripts/probe/row_probe --gb 125 --row-bytes 7813 --rows-per-query 2900 --queries 1024
   scripts/probe/row_probe --gb 1.25 --row-bytes 1250 --rows-per-query 93 --queries 8192 --wgs 2048; } > $P/${R}_row_probe.txt 2>&1
 python scripts/call_breakdown.py > $P/${R}_call_breakdown.txt 2>/dev/null
+BIGSI_HIP_LIB=$PWD/bigsi_amd/libbigsi_hip_tuning.so python scripts/call_breakdown.py 2>/dev/null | grep "inside the call" > $P/${R}_call_trace.txt      # host clock inside the one-call entry point (tuning build)
+BIGSI_HIP_LIB=$PWD/bigsi_amd/libbigsi_hip_tuning.so python scripts/ab_k1_phases.py > $P/${R}_k1_phases.txt 2>/dev/null
 scripts/probe/latency_probe > $P/${R}_latency_probe.txt 2>&1
 python scripts/frontend_probe.py > $P/${R}_frontend_probe.json 2>/dev/null
 # PMC: HBM traffic of every quoted kernel (FETCH_SIZE / WRITE_SIZE in separate passes, --kernel-trace only)
