@@ -1,0 +1,138 @@
+// CPython extension: the reference's result dicts (BigsiQueryResult.todict, graph/bigsi.py:91-126, with the score fields of
+// scoring/score.py:96-121 when score=True) built straight from the arrays a streaming search returns -- what BIGSI.search_stream
+// otherwise does in a Python loop per hit (2-4 us per dict; here ~0.3-0.8).  Host code only; the values are the ones the Python
+// route computes (tests/test_results_ext.py holds the two routes equal), the percent through the same py_round2 as the device's
+// scorer.  Built by bigsi_amd/pyext_build.sh (g++, -ffp-contract=off) next to the package; graph/bigsi.py uses it when importable.
+#define PY_SSIZE_T_CLEAN
+#include <Python.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <vector>
+
+#include "csrc/bigsi_score.hpp"
+
+namespace {
+
+struct Buf {
+    Py_buffer b{};
+    bool held = false;
+    ~Buf() { if (held) PyBuffer_Release(&b); }
+    bool get(PyObject *o, const char *what, Py_ssize_t itemsize)
+    {
+        if (PyObject_GetBuffer(o, &b, PyBUF_C_CONTIGUOUS | PyBUF_FORMAT) != 0) return false;
+        held = true;
+        if (b.itemsize != itemsize) {
+            PyErr_Format(PyExc_TypeError, "%s: items of %zd bytes expected, got %zd", what, itemsize, b.itemsize);
+            return false;
+        }
+        return true;
+    }
+    Py_ssize_t n() const { return b.len / b.itemsize; }
+};
+
+struct Column {
+    Buf buf;
+    bool is_float = false;
+};
+
+// build(nu, off, cols, cnts, exact, names, keys, columns, text, text_start, text_len, lo, hi) -> [results of sequence lo, ..., hi - 1]
+//   nu uint32[n], off int64[n + 1], cols / cnts uint32[hits]: what bigsi_hip_search_stream returns (hits of a sequence ascending by colour)
+//   names: list, names[c] = sample name of colour c, or None for a deleted sample (dropped); colours beyond the list are dropped on
+//          the thresholded route (inexact_filter zips with range(num_samples)) -- the caller checks the exact route's KeyError itself
+//   keys: the dict keys in order: 4 (percent_kmers_found, num_kmers, num_kmers_found, sample_name), or those + 17 score keys + "kmer-presence"
+//   columns: None, or 18 arrays over the hits: percent_kmers_found, then the 17 score fields (float64 or int64 each)
+//   text / text_start / text_len: the presence characters of all hits as one str, hit t = text[text_start[t] : text_start[t] + text_len[t]]
+PyObject *build(PyObject *, PyObject *args)
+{
+    PyObject *o_nu, *o_off, *o_cols, *o_cnts, *names, *keys, *columns, *text, *o_tstart, *o_tlen;
+    int exact;
+    Py_ssize_t lo, hi;
+    if (!PyArg_ParseTuple(args, "OOOOpOOOOOOnn", &o_nu, &o_off, &o_cols, &o_cnts, &exact, &names, &keys, &columns, &text, &o_tstart, &o_tlen, &lo, &hi))
+        return nullptr;
+    Buf nu, off, cols, cnts, tstart, tlen;
+    if (!nu.get(o_nu, "nu", 4) || !off.get(o_off, "off", 8) || !cols.get(o_cols, "cols", 4) || !cnts.get(o_cnts, "cnts", 4)) return nullptr;
+    if (!PyList_Check(names) || !PyTuple_Check(keys)) { PyErr_SetString(PyExc_TypeError, "names must be a list, keys a tuple"); return nullptr; }
+    const bool scored = columns != Py_None;
+    const Py_ssize_t n_keys = PyTuple_GET_SIZE(keys), n_seqs = nu.n();
+    if (n_keys != (scored ? 22 : 4)) { PyErr_SetString(PyExc_ValueError, "4 keys, or 22 with score columns"); return nullptr; }
+    if (lo < 0 || hi < lo || hi > n_seqs || off.n() < n_seqs + 1) { PyErr_SetString(PyExc_ValueError, "bad sequence range"); return nullptr; }
+    const uint32_t *p_nu = static_cast<const uint32_t *>(nu.b.buf), *p_col = static_cast<const uint32_t *>(cols.b.buf), *p_cnt = static_cast<const uint32_t *>(cnts.b.buf);
+    const int64_t *p_off = static_cast<const int64_t *>(off.b.buf);
+    const Py_ssize_t n_hits = cols.n(), n_names = PyList_GET_SIZE(names);
+    if (p_off[hi] > n_hits || cnts.n() < n_hits) { PyErr_SetString(PyExc_ValueError, "hit offsets beyond the hit arrays"); return nullptr; }
+    std::vector<Column> col(scored ? 18 : 0);
+    const int64_t *p_tstart = nullptr, *p_tlen = nullptr;
+    if (scored) {
+        if (!PyTuple_Check(columns) || PyTuple_GET_SIZE(columns) != 18 || !PyUnicode_Check(text)) { PyErr_SetString(PyExc_TypeError, "columns: a tuple of 18 arrays; text: a str"); return nullptr; }
+        for (int i = 0; i < 18; i++) {
+            if (!col[i].buf.get(PyTuple_GET_ITEM(columns, i), "score column", 8)) return nullptr;
+            const char *f = col[i].buf.b.format ? col[i].buf.b.format : "";
+            while (*f == '<' || *f == '=' || *f == '@') f++;
+            if (*f == 'd') col[i].is_float = true;
+            else if (*f != 'l' && *f != 'q') { PyErr_Format(PyExc_TypeError, "score column %d: float64 or int64 expected, got '%s'", i, col[i].buf.b.format); return nullptr; }
+            if (col[i].buf.n() < n_hits) { PyErr_SetString(PyExc_ValueError, "score column shorter than the hit arrays"); return nullptr; }
+        }
+        if (!tstart.get(o_tstart, "text_start", 8) || !tlen.get(o_tlen, "text_len", 8)) return nullptr;
+        if (tstart.n() < n_hits || tlen.n() < n_hits) { PyErr_SetString(PyExc_ValueError, "text offsets shorter than the hit arrays"); return nullptr; }
+        p_tstart = static_cast<const int64_t *>(tstart.b.buf);
+        p_tlen = static_cast<const int64_t *>(tlen.b.buf);
+    }
+    PyObject *out = PyList_New(hi - lo);
+    if (!out) return nullptr;
+    std::vector<int64_t> order;
+    for (Py_ssize_t i = lo; i < hi; i++) {
+        const uint32_t u = p_nu[i];
+        order.clear();
+        for (int64_t t = p_off[i]; t < p_off[i + 1]; t++) {
+            const uint32_t c = p_col[t];
+            if ((Py_ssize_t)c >= n_names || PyList_GET_ITEM(names, c) == Py_None) continue;
+            order.push_back(t);
+        }
+        if (!exact && order.size() > 1)          // inexact_filter: stable sort by count, descending (graph/bigsi.py:215-229)
+            std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return p_cnt[a] > p_cnt[b]; });
+        PyObject *res = PyList_New((Py_ssize_t)order.size());
+        if (!res) { Py_DECREF(out); return nullptr; }
+        PyList_SET_ITEM(out, i - lo, res);
+        if (order.empty()) continue;
+        PyObject *py_u = PyLong_FromUnsignedLong(u);
+        if (!py_u) { Py_DECREF(out); return nullptr; }
+        for (size_t r = 0; r < order.size(); r++) {
+            const int64_t t = order[r];
+            const uint32_t f = exact ? u : p_cnt[t];
+            PyObject *d = _PyDict_NewPresized(n_keys);      // (no growth steps on the way to 22 keys)
+            if (!d) { Py_DECREF(py_u); Py_DECREF(out); return nullptr; }
+            PyList_SET_ITEM(res, (Py_ssize_t)r, d);
+            bool ok = true;
+            auto put = [&](Py_ssize_t k, PyObject *v) {      // steals v
+                if (!v) { ok = false; return; }
+                if (ok && PyDict_SetItem(d, PyTuple_GET_ITEM(keys, k), v) != 0) ok = false;
+                Py_DECREF(v);
+            };
+            // percent_kmers_found = round(100 * float(found) / num_kmers, 2) (graph/bigsi.py:97-99); a scored search carries K6's value
+            put(0, PyFloat_FromDouble(scored ? static_cast<const double *>(col[0].buf.b.buf)[t] : bigsi_score::py_round2(100.0 * (double)f / (double)u)));
+            Py_INCREF(py_u);
+            put(1, py_u);
+            put(2, PyLong_FromUnsignedLong(f));
+            PyObject *nm = PyList_GET_ITEM(names, p_col[t]);
+            Py_INCREF(nm);
+            put(3, nm);
+            if (scored) {
+                for (int j = 1; j < 18 && ok; j++)
+                    put(3 + j, col[j].is_float ? PyFloat_FromDouble(static_cast<const double *>(col[j].buf.b.buf)[t])
+                                               : PyLong_FromLongLong(static_cast<const int64_t *>(col[j].buf.b.buf)[t]));
+                put(21, PyUnicode_Substring(text, (Py_ssize_t)p_tstart[t], (Py_ssize_t)(p_tstart[t] + p_tlen[t])));
+            }
+            if (!ok) { Py_DECREF(py_u); Py_DECREF(out); return nullptr; }
+        }
+        Py_DECREF(py_u);
+    }
+    return out;
+}
+
+PyMethodDef methods[] = {{"build", build, METH_VARARGS, "result dicts of the sequences [lo, hi) of a streaming search (see _results.cpp)"}, {nullptr, nullptr, 0, nullptr}};
+PyModuleDef module = {PyModuleDef_HEAD_INIT, "_results", "result dicts of BIGSI.search_stream, built in C++", -1, methods, nullptr, nullptr, nullptr, nullptr};
+
+}   // namespace
+
+PyMODINIT_FUNC PyInit__results(void) { return PyModule_Create(&module); }

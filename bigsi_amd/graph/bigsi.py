@@ -17,6 +17,11 @@ from ..utils import seq_to_kmers
 from .index import KmerSignatureIndex
 from .metadata import DELETION_SPECIAL_SAMPLE_NAME, SampleMetadata
 
+try:          # the C++ assembly of result dicts (bigsi_amd/_results.cpp, built by bigsi_amd/pyext_build.sh); the loop in _emit is its definition
+    from .. import _results
+except ImportError:
+    _results = None
+
 logger = logging.getLogger(__name__)
 
 DEFAULT_NPROC = 4
@@ -386,7 +391,61 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
         import threading
         return self.storage.res.__dict__.setdefault("_lock", threading.RLock())
 
-    def _emit(self, res, threshold, score):
+    def _emit_native(self, res, nk, nu, off64, n_hits, colours, counts, threshold, score):
+        """_emit's loop in the C++ extension (bigsi_amd/_results.cpp): the same dicts, built from the arrays without a Python
+        statement per hit.  What stays here: the reference's errors (raised when the offending sequence's turn comes), the sample
+        names of the colours that occur (looked up once per slice), the closed-form score columns (numpy, all hits at once)."""
+        from ..scoring import SCORE_KEYS, score_columns, unpack_presence
+        _, chunk, payload = res
+        exact = threshold == 1.0
+        ns = self.num_samples
+        # where the reference raises: a query without k-mers (either branch); score=True on a one-k-mer query that has hits
+        bad = nu == 0
+        if score:
+            bad = bad | ((nk == 1) & (n_hits > 0))
+        stop = int(np.argmax(bad)) if bad.any() else len(chunk)
+        total = int(off64[stop])
+        cols = np.ascontiguousarray(colours[:total])
+        names = [None] * ns
+        for c in np.unique(cols).tolist():
+            if c < ns:
+                name = self.colour_to_sample(c)
+                names[c] = None if name == DELETION_SPECIAL_SAMPLE_NAME else name
+            elif exact:
+                names = None          # a colour without a name on the exact route: KeyError in the reference, in stream order
+                break
+        if names is None:
+            yield from self._emit(res, threshold, score, native=False)
+            return
+        keys = ("percent_kmers_found", "num_kmers", "num_kmers_found", "sample_name")
+        columns = text = tstart = tlen = None
+        if score and total:
+            bits, boff, rec = payload[5:8]
+            rec = rec[:total]
+            columns = tuple([np.ascontiguousarray(rec["percent_kmers_found"])] +
+                            [np.ascontiguousarray(c) for c in score_columns(rec, self.scorer.DB_SIZE, as_arrays=True)])
+            text = unpack_presence(bits[:int(boff[total])], boff[:total + 1])
+            tstart = boff[:total].astype(np.int64) * 8
+            tlen = np.repeat(nk[:stop].astype(np.int64), n_hits[:stop])
+            keys = keys + SCORE_KEYS + ("kmer-presence",)
+        elif score:
+            keys = keys + SCORE_KEYS + ("kmer-presence",)
+            columns = tuple(np.zeros(0, np.float64) for _ in range(18))
+            text, tstart, tlen = "", np.zeros(0, np.int64), np.zeros(0, np.int64)
+        cnts = np.ascontiguousarray(counts[:total]) if len(counts) >= total else np.zeros(total, np.uint32)
+        # (blocks of sequences: the consumer gets its first results before the whole slice is assembled)
+        step = 4096
+        for lo in range(0, stop, step):
+            hi = min(stop, lo + step)
+            yield from zip(chunk[lo:hi], _results.build(nu, off64, cols, cnts, exact, names, keys, columns, text, tstart, tlen, lo, hi))
+        if stop < len(chunk):
+            if nu[stop] == 0:
+                if exact:
+                    raise TypeError("reduce() of empty sequence with no initial value")
+                raise UnboundLocalError("local variable 'cumsum' referenced before assignment")
+            raise IndexError("too many indices for array: array is 1-dimensional, but 2 were indexed")
+
+    def _emit(self, res, threshold, score, native=True):
         """(sequence, results) pairs of one slice from what the worker left: the reference's errors in stream order.  Plain Python
         over lists made once per slice (a numpy call per sequence costs more than the few hits a read has)."""
         from ..scoring import SCORE_KEYS
@@ -404,6 +463,9 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
         if not special:
             for s in chunk:
                 yield s, []
+            return
+        if _results is not None and native:
+            yield from self._emit_native(res, nk, nu, off64, n_hits, colours, counts, threshold, score)
             return
         scored = None
         if score and int(off64[-1]):

@@ -195,7 +195,7 @@ def unpack_presence(bits, offsets):
     return str(memoryview(chars), "ascii")
 
 
-def score_columns(rec, db_size):
+def score_columns(rec, db_size, as_arrays=False):
     """The 17 fields of Scorer.score (score.py:96-121) for every record of `rec` (HIT_SCORE_DTYPE), as one Python list per key of
     SCORE_KEYS.  A record with num_kmers == 0 divides by zero in the reference (score.py:99-100): ZeroDivisionError."""
     n = rec["num_kmers"].astype(np.int64)
@@ -215,4 +215,4 @@ def score_columns(rec, db_size):
     cols = [score, rec["min_score"], rec["max_score"], rec["max_mismatches"], rec["min_mismatches"], rec["mismatches"],
             max_nident, nident, min_nident, 100 * nident.astype(np.float64) / fl, 100 * max_nident.astype(np.float64) / fl,
             100 * min_nident.astype(np.float64) / fl, seq_len, evalue, pvalue, log_evalue, log_pvalue]
-    return [c.tolist() for c in cols]
+    return cols if as_arrays else [c.tolist() for c in cols]

@@ -1,0 +1,116 @@
+"""bigsi_amd/_results.cpp (the C++ assembly of BIGSI.search_stream's result dicts) against the Python loop it stands in for
+(BIGSI._emit with native=False), over synthetic stream payloads: same dicts, same key order, same value types, same errors at the
+same place in the stream.  Host code only: no device needed."""
+import types
+
+import numpy as np
+import pytest
+
+from bigsi_amd.graph import bigsi as bigsi_mod
+from bigsi_amd.graph.metadata import DELETION_SPECIAL_SAMPLE_NAME
+from bigsi_amd.scoring import HIT_SCORE_DTYPE
+
+pytestmark = pytest.mark.skipif(bigsi_mod._results is None, reason="bigsi_amd/_results extension not built (bigsi_amd/pyext_build.sh)")
+
+NS = 41
+NAMES = ["s%d" % c for c in range(NS)]
+NAMES[5] = NAMES[17] = DELETION_SPECIAL_SAMPLE_NAME
+
+
+class Stub(object):
+    num_samples = NS
+    scorer = types.SimpleNamespace(DB_SIZE=NS)
+    _emit = bigsi_mod.BIGSI._emit
+    _emit_native = bigsi_mod.BIGSI._emit_native
+
+    def colour_to_sample(self, c):
+        if c >= NS:
+            raise KeyError(c)
+        return NAMES[c]
+
+
+def payload(rng, n, score, threshold, degenerate=None, beyond=False):
+    nk = rng.integers(1 if not score else 2, 200, size=n).astype(np.uint32)
+    nu = np.minimum(nk, rng.integers(1, 200, size=n)).astype(np.uint32)
+    n_hits = np.where(rng.random(n) < 0.5, 0, rng.integers(1, 9, size=n))
+    if degenerate is not None:
+        i, kind = degenerate
+        if kind == "empty":
+            nk[i] = nu[i] = 0
+            n_hits[i] = 0
+        else:
+            nk[i] = nu[i] = 1
+            n_hits[i] = 2
+    off = np.zeros(n + 1, np.uint64)
+    np.cumsum(n_hits, out=off[1:])
+    total = int(off[-1])
+    col, cnt = np.zeros(total, np.uint32), np.zeros(total, np.uint32)
+    for i in range(n):
+        lo, hi = int(off[i]), int(off[i + 1])
+        col[lo:hi] = np.sort(rng.choice(NS + (6 if beyond else 0), size=hi - lo, replace=False))
+        cnt[lo:hi] = rng.integers(0, int(nu[i]) + 1, size=hi - lo) if threshold < 1 else nu[i]
+        if hi - lo > 2:
+            cnt[lo + 1] = cnt[lo]          # ties: the stable sort keeps colour order
+    out = [nk, nu, off, col, cnt]
+    if score:
+        per_hit = np.repeat(nk.astype(np.int64), n_hits)
+        boff = np.zeros(total + 1, np.uint64)
+        np.cumsum((per_hit + 63) // 64 * 8, out=boff[1:])
+        bits = rng.integers(0, 256, size=int(boff[-1]), dtype=np.uint8)
+        rec = np.zeros(total, HIT_SCORE_DTYPE)
+        rec["num_kmers"] = per_hit
+        for f in ("score", "min_score", "max_score"):
+            rec[f] = np.round(rng.random(total) * 300 - 20, 2)
+        rec["percent_kmers_found"] = np.round(rng.random(total) * 100, 2)
+        for f in ("max_mismatches", "min_mismatches", "mismatches"):
+            rec[f] = rng.integers(0, 40, size=total)
+        out += [bits, boff, rec]
+    return tuple(out)
+
+
+def both(rng, n, score, threshold, **kw):
+    chunk = ["q%d" % i for i in range(n)]
+    res = ("arrays", chunk, payload(rng, n, score, threshold, **kw))
+    outs = []
+    for native in (True, False):
+        got, err = [], None
+        try:
+            for pair in Stub()._emit(res, threshold, score, native=native):
+                got.append(pair)
+        except Exception as e:  # noqa: BLE001 -- compared below
+            err = e
+        outs.append((got, err))
+    return outs
+
+
+@pytest.mark.parametrize("score", [False, True])
+@pytest.mark.parametrize("threshold", [1.0, 0.4])
+@pytest.mark.parametrize("n", [1, 9, 5000])
+def test_native_dicts_are_the_python_loops(score, threshold, n):
+    rng = np.random.default_rng(n + 7 * score + int(10 * threshold))
+    (a, ea), (b, eb) = both(rng, n, score, threshold, beyond=threshold < 1)
+    assert ea is None and eb is None
+    assert len(a) == len(b) == n and sum(len(r) for _, r in a) > 0 or n == 1
+    for (sa, ra), (sb, rb) in zip(a, b):
+        assert sa == sb and ra == rb
+        for da, db in zip(ra, rb):
+            assert list(da.keys()) == list(db.keys())
+            assert [type(v) for v in da.values()] == [type(v) for v in db.values()]
+    if score:
+        assert any(len(d) == 22 for _, r in a for d in r) or n == 1
+    assert not any(d["sample_name"] == DELETION_SPECIAL_SAMPLE_NAME for _, r in a for d in r)
+
+
+@pytest.mark.parametrize("score,threshold,kind,exc", [(False, 1.0, "empty", TypeError), (False, 0.5, "empty", UnboundLocalError),
+                                                      (True, 1.0, "empty", TypeError), (True, 0.5, "one", IndexError), (True, 1.0, "one", IndexError)])
+def test_native_route_raises_the_references_errors_in_stream_order(score, threshold, kind, exc):
+    rng = np.random.default_rng(3)
+    (a, ea), (b, eb) = both(rng, 300, score, threshold, degenerate=(123, kind))
+    assert type(ea) is exc and type(eb) is exc and str(ea) == str(eb)
+    assert len(a) == len(b) == 123 and a == b
+
+
+def test_a_colour_without_a_name_on_the_exact_route_is_the_python_loops_keyerror():
+    rng = np.random.default_rng(5)
+    (a, ea), (b, eb) = both(rng, 200, False, 1.0, beyond=True)
+    assert type(ea) is KeyError and type(eb) is KeyError and a == b
