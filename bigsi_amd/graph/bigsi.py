@@ -326,7 +326,7 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
         self._launch(batch, threshold)
         return self._collect(batch, len(seqs), threshold, score)
 
-    def search_stream(self, seqs, threshold=1.0, score=False, batch_size=None, batch_kmers=1 << 19):
+    def search_stream(self, seqs, threshold=1.0, score=False, batch_size=None, batch_kmers=1 << 19, pause_gc=True):
         """Generator over (sequence, results) for an arbitrarily long iterable of sequences (bulk_search, bigsi/__main__.py:261-314,
         runs one BIGSI.search per query in a fork pool).  The sequences go through the C ABI's streaming entry points --
         bigsi_hip_search_stream, or bigsi_hip_search_stream_scored with score=True: one call per slice of about 8 x `batch_kmers`
@@ -335,7 +335,8 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
         arrays of the slice before into the reference's result dicts.  Results, order and the reference's errors for degenerate
         queries (raised when the offending sequence's turn comes, after everything before it was yielded) are those of search()
         per sequence.  While a stream is being consumed the index handle is in use by the worker between yields: search() /
-        search_batch() / lookup() take the same lock and simply wait; do not modify the index.
+        search_batch() / lookup() take the same lock and simply wait; do not modify the index.  `pause_gc` (default on): full
+        passes of Python's cyclic garbage collector are deferred until the stream ends (see below); pass False to leave it alone.
         A multi-GPU (devices=[...]) index streams through its batch objects instead (_search_stream_batches)."""
         assert threshold <= 1
         if self.storage.res.is_group:
@@ -345,19 +346,26 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
         from ..storage.hip_hbm import TooManyHits
         k, st, lock = self.kmer_size, self.storage, self._device_lock()
 
-        def work(chunk):
+        from .. import _lib
+
+        def pack(chunk):
+            """(blob, offsets) of an all-ASCII slice -- packed on the CALLER's thread, so that the worker goes from one C call straight
+            into the next -- or None: the slice then takes search_batch's route for non-ASCII text."""
+            try:
+                blob, soff = _lib.pack_seqs(chunk)
+            except ValueError:
+                return None
+            return (blob, soff) if blob.isascii() else None          # (bytes among the sequences may hold anything)
+
+        def work(chunk, packed):
             with lock:
                 try:
-                    try:
-                        plain = "".join(chunk).isascii()          # one pass at C speed
-                    except TypeError:                            # (bytes among the sequences)
-                        plain = all(s.isascii() for s in chunk)
-                    if not plain:                                # rare: answered through search_batch's non-ASCII route
+                    if packed is None:                           # rare: answered through search_batch's non-ASCII route
                         return "done", chunk, self._search_batch_locked(chunk, threshold, score)
                     if not score:
-                        return "arrays", chunk, st.search_many(chunk, k, threshold)
+                        return "arrays", chunk, st.search_many_packed(packed[0], packed[1], k, threshold)
                     try:
-                        return "arrays", chunk, st.search_many_scored(chunk, k, threshold, max_bits=SCORE_SLICE_CHARS // 8)
+                        return "arrays", chunk, st.search_many_scored(None, k, threshold, max_bits=SCORE_SLICE_CHARS // 8, packed=packed)
                     except TooManyHits:                          # (a low threshold on a wide index: the batch route scores in slices)
                         return "done", chunk, self._search_batch_locked(chunk, threshold, score)
                 except Exception as e:  # noqa: BLE001 -- surfaces in stream order, from emit()
@@ -368,22 +376,35 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
         # the worker needs the GIL a few times per slice (arguments in, arrays out) while this thread assembles dicts in pure Python
         # and never lets go of it voluntarily: at the default 5 ms switch interval those handoffs cost a scored stream a third of its
         # rate (128 -> 165+ M lookups/s on BASELINE configs[4]'s shard)
+        import gc
         import sys
         interval = sys.getswitchinterval()
         sys.setswitchinterval(min(interval, 2e-4))
+        # The stream makes two containers per sequence (the pair, the result list); every ~35 000 of them the cyclic collector
+        # starts a FULL collection, which walks every object of the process -- with torch and numpy imported ~40 ms, GIL held, the
+        # worker stuck at the end of its C call: a quarter of a scored stream's time (163 -> 120 ms per 24 576 queries of 1 kbp).
+        # While the stream runs, full collections wait: the collector is off, and the two young generations are collected at every
+        # slice boundary (cheap: only what was made since), so that cyclic garbage of the consumer does not pile up unseen.
+        gc_was_on = bool(pause_gc) and gc.isenabled()
+        if gc_was_on:
+            gc.disable()
         with ThreadPoolExecutor(1) as pool:
             pending = None
             try:
                 for chunk in slices:
-                    nxt = pool.submit(work, chunk)
+                    nxt = pool.submit(work, chunk, pack(chunk))
                     if pending is not None:
                         yield from self._emit(pending.result(), threshold, score)
+                        if gc_was_on:
+                            gc.collect(1)
                     pending = nxt
                 if pending is not None:
                     last, pending = pending, None
                     yield from self._emit(last.result(), threshold, score)
             finally:
                 sys.setswitchinterval(interval)
+                if gc_was_on:
+                    gc.enable()
                 if pending is not None:
                     pending.result()                             # (the consumer stopped early: let the worker leave the index alone)
 

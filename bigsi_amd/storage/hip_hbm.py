@@ -533,22 +533,24 @@ class HipHbmStorage(BaseStorage):
         total = int(off[-1])
         return nk, nu, off, col[:total], cnt[:total]
 
-    def search_many_scored(self, seqs, k, threshold=1.0, max_bits=None):
+    def search_many_scored(self, seqs, k, threshold=1.0, max_bits=None, packed=None):
         """bigsi_hip_search_stream_scored: search_many plus, per hit, the presence bits and the score record of score=True
         (bigsi/scoring/score.py:96-121), K5 + K6 of one device batch running beside the row-AND kernels of the next.  Returns
         (num_kmers, num_unique, hit_offsets, colours, counts, bits, bit_offsets, scores): hit t's presence string is
-        the slice of scoring.unpack_presence(bits, bit_offsets) that starts at character 8 * bit_offsets[t], num_kmers of its sequence long; scores is a HIT_SCORE_DTYPE array."""
+        the slice of scoring.unpack_presence(bits, bit_offsets) that starts at character 8 * bit_offsets[t], num_kmers of its sequence long; scores is a HIT_SCORE_DTYPE array.
+        `packed` = (blob, offsets) of the sequences if the caller has packed them already (_lib.pack_seqs; `seqs` is then not read)."""
         from bigsi_amd.scoring import HIT_SCORE_DTYPE
         assert threshold <= 1
-        seqs = seqs if isinstance(seqs, (list, tuple)) else list(seqs)
-        n = len(seqs)
+        if packed is None:
+            seqs = seqs if isinstance(seqs, (list, tuple)) else list(seqs)
+        n = len(seqs) if packed is None else len(packed[1]) - 1
         nk, nu = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
         off = np.zeros(n + 1, np.uint64)
         if n == 0:
             return nk, nu, off, np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.uint8), np.zeros(1, np.uint64), np.zeros(0, HIT_SCORE_DTYPE)
         if self.res.is_group:
             raise BigsiHipError(_lib.ERR_STATE, "search_many_scored is not available on a multi-GPU index")
-        blob, soff = _lib.pack_seqs(seqs)
+        blob, soff = packed if packed is not None else _lib.pack_seqs(seqs)
         cap, bcap = max(self._search_cap, 1 << 12), max(self._bits_cap, 1 << 16)
         need = np.zeros(1, np.uint64)
         while True:

@@ -26,20 +26,28 @@ index = BIGSI(cfg)
 index.colour_to_sample = lambda c: "s%d" % c              # (62 500 metadata records are not what is measured)
 out = {}
 for score in (True, False):
-    list(index.search_stream(seqs[:512], 0.4, score=score, batch_size=256))      # warm
-    t0 = time.perf_counter()
-    res = list(index.search_stream(seqs, 0.4, score=score, batch_size=256))
-    dt = time.perf_counter() - t0
+    list(index.search_stream(seqs[:8192], 0.4, score=score, batch_size=256))     # warm: two whole slices, so that the hit / bit buffers have their steady-state size (a first slice that outgrows them is answered twice)
+    dt = None
+    for _ in range(3):          # best of three, as the C boundary below
+        res = None
+        t0 = time.perf_counter()
+        res = list(index.search_stream(seqs, 0.4, score=score, batch_size=256))
+        d_ = time.perf_counter() - t0
+        dt = d_ if dt is None else min(dt, d_)
     hits = sum(len(r) for _, r in res)
     uniq = sum(len({s[i:i + k] for i in range(len(s) - k + 1)}) for s in seqs[:64]) / 64 * len(seqs)
     out["score=%s" % score] = {"seconds": dt, "queries": len(seqs), "hits": hits, "ms_per_256_queries": dt / n_batches * 1e3,
                                "kmer_lookups_per_s": uniq / dt, "keys_per_hit": len(res[0][1][0]) if res[0][1] else None}
 # the batch-object pipeline (round 3's route: begin / end per device batch, three deep, everything on the caller's thread)
 for score in (True, False):
-    list(index._search_stream_batches(seqs[:512], 0.4, score=score, batch_size=256))
-    t0 = time.perf_counter()
-    res2 = list(index._search_stream_batches(seqs, 0.4, score=score, batch_size=256))
-    dt = time.perf_counter() - t0
+    list(index._search_stream_batches(seqs[:8192], 0.4, score=score, batch_size=256))
+    dt = None
+    for _ in range(3):
+        res2 = None
+        t0 = time.perf_counter()
+        res2 = list(index._search_stream_batches(seqs, 0.4, score=score, batch_size=256))
+        d_ = time.perf_counter() - t0
+        dt = d_ if dt is None else min(dt, d_)
     out["batches score=%s" % score] = {"seconds": dt, "ms_per_256_queries": dt / n_batches * 1e3, "kmer_lookups_per_s": uniq / dt}
 assert res2 == res
 # the C boundary alone: bigsi_hip_search_stream_scored (sequences in; hit lists, presence bits and score records out), and the
