@@ -596,6 +596,14 @@ def main():
         rec, pbits, boff = b_.score_hits_end()
         scored["end_s"] += time.perf_counter() - t_a
         o64 = off_own.astype(np.int64)
+        from bigsi_amd.graph import bigsi as _front
+        if _front._results is not None:
+            # what BIGSI.search_stream does with these arrays: the dicts assembled by the C++ extension (bigsi_amd/_results.cpp)
+            nb = w["batch"]
+            results = list(_front.native_result_lists(nk_[:nb], nu_[:nb], o64[:nb + 1], col_own, cnt_own, exact, names[:my_cols], (rec, pbits, boff), total_cols))
+            scored["results"], scored["hits"], scored["batches"] = results, scored["hits"] + int(o64[nb]), scored["batches"] + 1
+            scored["finish_s"] += time.perf_counter() - t_a
+            return
         rows = scored_rows(rec, pbits, boff, np.repeat(nk_[: w["batch"]].astype(np.int64), np.diff(o64)), total_cols)
         results = [[] for _ in range(w["batch"])]
         for i in np.flatnonzero(np.diff(o64)).tolist():

@@ -72,6 +72,36 @@ def score_hit_rows(batch, off, colours, counts, num_kmers, n_seqs, db_size, slic
     return rows
 
 
+def native_result_lists(nk, nu, off64, cols, counts, exact, names, scored, db_size, block=4096):
+    """Generator over the result lists of the sequences 0 .. len(nu) - 1 of a search, built by the C++ extension (bigsi_amd/_results.cpp)
+    from the arrays the C ABI returns: nk / nu uint32 per sequence, off64 int64 hit offsets, cols / counts uint32 per hit (ascending
+    colours per sequence), names[c] = sample name or None (deleted: dropped), scored = None or (records, bits, bit_offsets) of K6
+    (QueryBatch.score_hits_end / search_many_scored).  Same dicts as BIGSI._emit's Python loop and as search(); the caller deals with
+    the queries the reference raises on.  `block` sequences are assembled per call of the extension."""
+    from ..scoring import SCORE_KEYS, score_columns, unpack_presence
+    n, total = len(nu), int(off64[len(nu)])
+    keys = ("percent_kmers_found", "num_kmers", "num_kmers_found", "sample_name")
+    columns = text = tstart = tlen = None
+    if scored is not None:
+        keys = keys + SCORE_KEYS + ("kmer-presence",)
+        rec, bits, boff = scored
+        if total:
+            rec = rec[:total]
+            columns = tuple([np.ascontiguousarray(rec["percent_kmers_found"])] + [np.ascontiguousarray(c) for c in score_columns(rec, db_size, as_arrays=True)])
+            text = unpack_presence(bits[:int(boff[total])], boff[:total + 1])
+            tstart = boff[:total].astype(np.int64) * 8
+            tlen = np.repeat(np.asarray(nk[:n], dtype=np.int64), np.diff(off64[:n + 1]))
+        else:
+            columns = tuple(np.zeros(0, np.float64) for _ in range(18))
+            text, tstart, tlen = "", np.zeros(0, np.int64), np.zeros(0, np.int64)
+    nu = np.ascontiguousarray(nu, dtype=np.uint32)
+    off64 = np.ascontiguousarray(off64, dtype=np.int64)
+    cols = np.ascontiguousarray(cols[:total], dtype=np.uint32)
+    cnts = np.ascontiguousarray(counts[:total], dtype=np.uint32) if counts is not None and len(counts) >= total else np.zeros(total, np.uint32)
+    for lo in range(0, n, block):
+        yield from _results.build(nu, off64, cols, cnts, bool(exact), names, keys, columns, text, tstart, tlen, lo, min(n, lo + block))
+
+
 class BigsiQueryResult(object):
     """One hit; `todict()` key order is part of the contract (tests/graph/test_end_to_end.py:114-124)."""
 
@@ -416,7 +446,6 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
         """_emit's loop in the C++ extension (bigsi_amd/_results.cpp): the same dicts, built from the arrays without a Python
         statement per hit.  What stays here: the reference's errors (raised when the offending sequence's turn comes), the sample
         names of the colours that occur (looked up once per slice), the closed-form score columns (numpy, all hits at once)."""
-        from ..scoring import SCORE_KEYS, score_columns, unpack_presence
         _, chunk, payload = res
         exact = threshold == 1.0
         ns = self.num_samples
@@ -438,27 +467,9 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
         if names is None:
             yield from self._emit(res, threshold, score, native=False)
             return
-        keys = ("percent_kmers_found", "num_kmers", "num_kmers_found", "sample_name")
-        columns = text = tstart = tlen = None
-        if score and total:
-            bits, boff, rec = payload[5:8]
-            rec = rec[:total]
-            columns = tuple([np.ascontiguousarray(rec["percent_kmers_found"])] +
-                            [np.ascontiguousarray(c) for c in score_columns(rec, self.scorer.DB_SIZE, as_arrays=True)])
-            text = unpack_presence(bits[:int(boff[total])], boff[:total + 1])
-            tstart = boff[:total].astype(np.int64) * 8
-            tlen = np.repeat(nk[:stop].astype(np.int64), n_hits[:stop])
-            keys = keys + SCORE_KEYS + ("kmer-presence",)
-        elif score:
-            keys = keys + SCORE_KEYS + ("kmer-presence",)
-            columns = tuple(np.zeros(0, np.float64) for _ in range(18))
-            text, tstart, tlen = "", np.zeros(0, np.int64), np.zeros(0, np.int64)
-        cnts = np.ascontiguousarray(counts[:total]) if len(counts) >= total else np.zeros(total, np.uint32)
+        scored = (payload[7][:total], payload[5], payload[6]) if score else None
         # (blocks of sequences: the consumer gets its first results before the whole slice is assembled)
-        step = 4096
-        for lo in range(0, stop, step):
-            hi = min(stop, lo + step)
-            yield from zip(chunk[lo:hi], _results.build(nu, off64, cols, cnts, exact, names, keys, columns, text, tstart, tlen, lo, hi))
+        yield from zip(chunk[:stop], native_result_lists(nk[:stop], nu[:stop], off64[:stop + 1], cols, counts, exact, names, scored, self.scorer.DB_SIZE))
         if stop < len(chunk):
             if nu[stop] == 0:
                 if exact:
