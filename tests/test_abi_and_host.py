@@ -62,6 +62,15 @@ def build_c_host(tmp_path):
     return exe
 
 
+def test_bulk_search_c_host_compiles_as_c99(tmp_path):
+    """tests/c_host/bulk_host.c (bulk_search in three C calls; run by the gpu suite) is strict C99 against the public header."""
+    import subprocess
+    from bigsi_amd import _lib
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           "-o", str(tmp_path / "bulk_host"), os.path.join(ROOT, "tests", "c_host", "bulk_host.c"),
+                           "-L", os.path.dirname(_lib.LIB_PATH), "-lbigsi_hip", "-Wl,-rpath," + os.path.dirname(_lib.LIB_PATH)])
+
+
 def test_header_is_plain_c_and_a_c_host_links(tmp_path):
     """The boundary is a C ABI: the header must compile as C (not only as C++) and a host without Python or HIP headers must
     link against the library alone.  Without a device that host fails loudly -- an error code and message, no fallback."""

@@ -182,3 +182,33 @@ def test_bulk_search_native_text_route_is_the_per_record_routes_text(tmp_path, m
         assert taken == [None] and len(json.loads(text)) == 2
     finally:
         b.delete()
+
+
+@pytest.mark.gpu
+def test_c_host_bulk_search_prints_the_references_text(tmp_path):
+    """tests/c_host/bulk_host.c -- C99, links libbigsi_hip.so only -- does `bigsi bulk_search` in three calls of the C ABI
+    (bigsi_hip_fasta_pack, bigsi_hip_search_stream, bigsi_hip_format_results); what it prints for golden G9's index and FASTA files
+    must be the reference's own bulk_search output, byte for byte, JSON and CSV, at every threshold G9 holds."""
+    import os
+    import subprocess
+    from bigsi_amd import _lib, frontend
+    g = load_golden("g9_frontend.json")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "bulk_host")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), "-o", exe,
+                           os.path.join(root, "tests", "c_host", "bulk_host.c"), "-L", os.path.dirname(_lib.LIB_PATH), "-lbigsi_hip",
+                           "-Wl,-rpath," + os.path.dirname(_lib.LIB_PATH)])
+    index = "%d %d %d %d\n" % (g["m"], g["h"], g["k"], len(g["samples"]))
+    index += "".join("%s\n%d %s\n" % (name, len(kmers), " ".join(kmers)) for name, kmers in g["samples"].items())
+    n = 0
+    for c in g["cases"]:
+        if c["cmd"] != "bulk_search" or c["score"] or c["stream"]:
+            continue
+        fa = tmp_path / (c["fasta"] + ".fasta")
+        fa.write_text(g["fasta_text"][c["fasta"]])
+        r = subprocess.run([exe, str(fa), repr(c["threshold"]), c["format"], json.dumps(c["threshold"]), json.dumps(frontend.CITATION)],
+                           input=index.encode(), capture_output=True, timeout=300)
+        assert r.returncode == 0, r.stderr.decode()
+        assert r.stdout.decode() == c["out"], (c["fasta"], c["threshold"], c["format"])
+        n += 1
+    assert n >= 4
