@@ -1188,6 +1188,7 @@ struct CountLaunch {
     uint32_t early_exit;        // BIGSI_RUN_EARLY_EXIT on a hits-only, one-slice run
     uint64_t *partial;          // slices > 1: bit-sliced partial counts of every slice (k_count_combine adds them up)
     uint32_t planes_out;
+    int vec;                    // 64-column words per lane: 2, or 1 (h = 3 / 4, one slice, not pipelined): `tiles` is computed for it
 };
 
 template <int P, typename CountT>
@@ -1201,9 +1202,14 @@ static void launch_count_wide(bigsi_hip_batch *b, const CountLaunch &c, uint32_t
         c.hit_bitmap, b->wv_pad, c.sparse, c.slices, c.early_exit, c.partial, c.planes_out
 #define COMMA ,
 #define BIGSI_LAUNCH_COUNT(H) hipLaunchKernelGGL((k_and_count<P, H, CountT>), BIGSI_COUNT_ARGS)
+#ifdef BIGSI_HIP_TUNING      // (the one-word-per-lane form: an A/B variant, not in the product library -- DESIGN.md section 7)
+#define BIGSI_LAUNCH_COUNT_VEC1(H) if (c.vec == 1) hipLaunchKernelGGL((k_and_count<P COMMA H COMMA CountT COMMA 1 COMMA 1>), BIGSI_COUNT_ARGS); else
+#else
+#define BIGSI_LAUNCH_COUNT_VEC1(H)
+#endif
 #define BIGSI_LAUNCH_COUNT_DEEP(H)                                                                        \
     if (c.deep) hipLaunchKernelGGL((k_and_count<P COMMA H COMMA CountT COMMA 2>), BIGSI_COUNT_ARGS);       \
-    else hipLaunchKernelGGL((k_and_count<P, H, CountT>), BIGSI_COUNT_ARGS)
+    else BIGSI_LAUNCH_COUNT_VEC1(H) hipLaunchKernelGGL((k_and_count<P, H, CountT>), BIGSI_COUNT_ARGS)
     switch (ix->h) {
     case 1: BIGSI_LAUNCH_COUNT(1); break;
     case 2: BIGSI_LAUNCH_COUNT(2); break;
@@ -1214,6 +1220,7 @@ static void launch_count_wide(bigsi_hip_batch *b, const CountLaunch &c, uint32_t
     }
 #undef BIGSI_LAUNCH_COUNT
 #undef BIGSI_LAUNCH_COUNT_DEEP
+#undef BIGSI_LAUNCH_COUNT_VEC1
 #undef BIGSI_COUNT_ARGS
 #undef COMMA
 }
@@ -1798,7 +1805,14 @@ int bigsi_batch_run(bigsi_hip_batch *b, double threshold, uint32_t flags, bool o
         // (only with >= 12 planes, i.e. queries of >= 1024 k-mers: at 10 planes the ALU phase is short and it measured -2 %)
         const bool deep = deep_env >= 0 ? deep_env != 0 : (slices == 1 && P >= 12 && grid_waves < 3 * 1024);
         const uint32_t early = ((flags & BIGSI_RUN_EARLY_EXIT) && sparse && slices == 1) ? 1u : 0u;
-        const CountLaunch cl{k2_rows, (unsigned)and_block, tiles, out, cstride, hb, sparse, slices, deep && !early, early, partial, planes_out};
+        // one word per lane (8-byte loads, half the plane registers: 8 instead of 4-5 wavefronts per SIMD) -- tuning builds only:
+        // interleaved A/B +-0 at C3 (h = 4), -3.5 % on the north-star shard, -2 % on the C5 shard (h = 3): these kernels are at the
+        // memory system's random-row rate, not short of wavefronts (unlike the read kernel, where the same change is +10 %)
+        static const int count_vec1 = env_int("BIGSI_HIP_COUNT_VEC1", 0);
+        const int vec = (count_vec1 && slices == 1 && !(deep && !early) && (ix->h == 3 || ix->h == 4) && P <= 16) ? 1 : 2;
+        const uint32_t ctiles = vec == 1 ? (uint32_t)ceil_div(b->wv, (uint64_t)and_block) : tiles;
+        if (ceil_div(b->n_seqs, 8) * 8 * (uint64_t)ctiles * slices > 0x7FFFFFFFull) return fail(BIGSI_ERR_INVALID, "batch too large for one launch");
+        const CountLaunch cl{k2_rows, (unsigned)and_block, ctiles, out, cstride, hb, sparse, slices, deep && !early, early, partial, planes_out, vec};
         for (uint32_t q0 = 0; q0 < b->n_seqs; q0 += chunk_q, n_launches++)
             launch_count(b, P, cl, q0, (uint32_t)std::min<uint64_t>((uint64_t)q0 + chunk_q, b->n_seqs));
         if (slices > 1) {        // the slices' partial counts -> totals, hit mask, counters

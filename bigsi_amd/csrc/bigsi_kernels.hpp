@@ -902,7 +902,8 @@ __global__ __launch_bounds__(1024) void k_and_exact(
 // ripple-carry add of the AND-ed word costs 3 bit-ops per plane, far below what the HBM stream leaves the VALU
 // (see DESIGN.md).  Planes are expanded to integers once per (query, segment) and stored as CountT.
 template <int P, int H, typename CountT, int KMX = 1 /* 2: software-pipelined loads, for grids too small to fill the SIMDs
-    with wavefronts (128 x 4 kbp queries = 2 wavefronts per SIMD: 5.6 -> 6.3 TB/s) */>
+    with wavefronts (128 x 4 kbp queries = 2 wavefronts per SIMD: 5.6 -> 6.3 TB/s) */,
+          int VEC = kVec /* 64-column words per lane: 2 (16-byte loads), or 1 (8-byte loads: half the plane registers per lane) */>
 __global__ __launch_bounds__(kBlock) void k_and_count(
     const uint64_t *__restrict__ index, uint64_t stride_words, uint32_t wv,
     const uint64_t *__restrict__ rows, const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ num_unique,
@@ -917,7 +918,7 @@ __global__ __launch_bounds__(kBlock) void k_and_count(
 {
     const TileMap tm = map_block(blockIdx.x, q0, n_seqs, tiles, slices);
     if (!tm.valid) return;
-    const uint32_t w0 = (tm.tile * blockDim.x + threadIdx.x) * kVec;
+    const uint32_t w0 = (tm.tile * blockDim.x + threadIdx.x) * VEC;
     if (w0 >= wv) return;
     const uint32_t h = H > 0 ? (uint32_t)H : h_rt;
     const uint32_t uall = num_unique[tm.q];
@@ -926,19 +927,24 @@ __global__ __launch_bounds__(kBlock) void k_and_count(
     const uint32_t u = j0 + per < uall ? j0 + per : uall;      // this slice covers unique k-mers [j0, u)
     if (slices > 1 && j0 >= u) return;
     const uint64_t *qrows = rows + pos_off[tm.q] * h;
-    uint64_t pl[kVec][P];
+    uint64_t pl[VEC][P];
 #pragma unroll
-    for (int v = 0; v < kVec; v++)
+    for (int v = 0; v < VEC; v++)
 #pragma unroll
         for (int p = 0; p < P; p++) pl[v][p] = 0;
 
-    auto add = [&](u64x2 a) {
-        uint64_t c0 = a.x, c1 = a.y;
+    auto add = [&](const RowWords<VEC> &a) {
+        uint64_t c[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; e++) c[e] = a.word(e);
 #pragma unroll
         for (int p = 0; p < P; p++) {
-            uint64_t t0 = pl[0][p] & c0, t1 = pl[1][p] & c1;
-            pl[0][p] ^= c0; pl[1][p] ^= c1;
-            c0 = t0; c1 = t1;
+#pragma unroll
+            for (int e = 0; e < VEC; e++) {          // (the words' carry chains interleaved: independent instructions side by side)
+                const uint64_t t = pl[e][p] & c[e];
+                pl[e][p] ^= c[e];
+                c[e] = t;
+            }
         }
     };
 
@@ -951,7 +957,7 @@ __global__ __launch_bounds__(kBlock) void k_and_count(
         const uint32_t need = thr_exit - left;
         uint64_t any = 0;
 #pragma unroll
-        for (int v = 0; v < kVec; v++) {
+        for (int v = 0; v < VEC; v++) {
             uint64_t gt = 0, eq = ~0ull;
             if (P < 32 && (need >> (P & 31)) != 0) eq = 0;
 #pragma unroll
@@ -972,20 +978,20 @@ __global__ __launch_bounds__(kBlock) void k_and_count(
         if (KMX == 2) {
             // software pipeline: the loads of the NEXT KM k-mers are issued before the bit-sliced adds of the current ones, so
             // a wavefront keeps the memory system busy through its own ALU phase (matters when few wavefronts share a SIMD)
-            u64x2 cur[KM * (H > 0 ? H : 1)], nxt[KM * (H > 0 ? H : 1)];
+            RowWords<VEC> cur[KM * (H > 0 ? H : 1)], nxt[KM * (H > 0 ? H : 1)];
             if (j + KM <= u) {
 #pragma unroll
-                for (int s = 0; s < KM * H; s++) cur[s] = load_row_seg(index, qrows[(uint64_t)j * H + s], stride_words, w0);
+                for (int s = 0; s < KM * H; s++) cur[s] = RowWords<VEC>::load(index, qrows[(uint64_t)j * H + s], stride_words, w0);
             }
             for (; j + KM <= u; j += KM) {
                 const bool more = j + 2 * KM <= u;       // wave-uniform
                 if (more) {
 #pragma unroll
-                    for (int s = 0; s < KM * H; s++) nxt[s] = load_row_seg(index, qrows[(uint64_t)(j + KM) * H + s], stride_words, w0);
+                    for (int s = 0; s < KM * H; s++) nxt[s] = RowWords<VEC>::load(index, qrows[(uint64_t)(j + KM) * H + s], stride_words, w0);
                 }
 #pragma unroll
                 for (int g = 0; g < KM; g++) {
-                    u64x2 a = cur[g * H];
+                    RowWords<VEC> a = cur[g * H];
 #pragma unroll
                     for (int s = 1; s < H; s++) a &= cur[g * H + s];
                     add(a);
@@ -998,12 +1004,12 @@ __global__ __launch_bounds__(kBlock) void k_and_count(
         } else {
             for (; j + KM <= u; j += KM) {
                 if (early_exit && ((j - j0) & 31u) < (uint32_t)KM && j > j0 && hopeless(u - j)) { j = u; break; }
-                u64x2 v[KM * (H > 0 ? H : 1)];
+                RowWords<VEC> v[KM * (H > 0 ? H : 1)];
 #pragma unroll
-                for (int s = 0; s < KM * H; s++) v[s] = load_row_seg(index, qrows[(uint64_t)j * H + s], stride_words, w0);
+                for (int s = 0; s < KM * H; s++) v[s] = RowWords<VEC>::load(index, qrows[(uint64_t)j * H + s], stride_words, w0);
 #pragma unroll
                 for (int g = 0; g < KM; g++) {
-                    u64x2 a = v[g * H];
+                    RowWords<VEC> a = v[g * H];
 #pragma unroll
                     for (int s = 1; s < H; s++) a &= v[g * H + s];
                     add(a);
@@ -1013,14 +1019,15 @@ __global__ __launch_bounds__(kBlock) void k_and_count(
     }
     for (; j < u; j++) {     // tail k-mers, and every k-mer when h is a run-time value (h > 5): rows in groups of four loads
         const uint64_t *kr = qrows + (uint64_t)j * h;
-        u64x2 a = {~0ull, ~0ull};
+        RowWords<VEC> a = RowWords<VEC>::fill(~0ull);
         uint32_t s = 0;
         for (; s + 4 <= h; s += 4) {
-            const u64x2 l0 = load_row_seg(index, kr[s], stride_words, w0), l1 = load_row_seg(index, kr[s + 1], stride_words, w0);
-            const u64x2 l2 = load_row_seg(index, kr[s + 2], stride_words, w0), l3 = load_row_seg(index, kr[s + 3], stride_words, w0);
-            a &= (l0 & l1) & (l2 & l3);
+            RowWords<VEC> l0 = RowWords<VEC>::load(index, kr[s], stride_words, w0), l1 = RowWords<VEC>::load(index, kr[s + 1], stride_words, w0);
+            const RowWords<VEC> l2 = RowWords<VEC>::load(index, kr[s + 2], stride_words, w0), l3 = RowWords<VEC>::load(index, kr[s + 3], stride_words, w0);
+            l0 &= l2; l1 &= l3; l0 &= l1;
+            a &= l0;
         }
-        for (; s < h; s++) a &= load_row_seg(index, kr[s], stride_words, w0);
+        for (; s < h; s++) a &= RowWords<VEC>::load(index, kr[s], stride_words, w0);
         add(a);
     }
 
@@ -1032,16 +1039,19 @@ __global__ __launch_bounds__(kBlock) void k_and_count(
         uint64_t *o = partial + ((uint64_t)tm.q * slices + tm.slice) * planes_out * bm_stride + w0;
 #pragma unroll
         for (int p = 0; p < P; p++)
-            if ((uint32_t)p < planes_out) *reinterpret_cast<u64x2 *>(o + (uint64_t)p * bm_stride) = u64x2{pl[0][p], pl[1][p]};
+            if ((uint32_t)p < planes_out) {
+                if (VEC == 2) *reinterpret_cast<u64x2 *>(o + (uint64_t)p * bm_stride) = u64x2{pl[0][p], pl[VEC - 1][p]};
+                else o[(uint64_t)p * bm_stride] = pl[0][p];
+            }
         return;
     }
     // threshold in bit-sliced form (graph/bigsi.py:241-242: count >= min_kmers): MSB-first comparator over the planes,
     // ~2 bit-ops per plane per word; the threshold is wave-uniform so its bit tests are scalar branches
-    uint64_t ge[kVec];
+    uint64_t ge[VEC];
     {
         const uint32_t thr = min_kmers[tm.q];
 #pragma unroll
-        for (int v = 0; v < kVec; v++) {
+        for (int v = 0; v < VEC; v++) {
             uint64_t gt = 0, eq = ~0ull;
             if (P < 32 && (thr >> (P & 31)) != 0) eq = 0;     // threshold above any representable count
 #pragma unroll
@@ -1056,7 +1066,7 @@ __global__ __launch_bounds__(kBlock) void k_and_count(
 
     // expand: column 8b+jj of word w sits at bit 8b+7-jj; 8 consecutive counters per store
 #pragma unroll
-    for (int v = 0; v < kVec; v++) {
+    for (int v = 0; v < VEC; v++) {
         const uint64_t cbase = ((uint64_t)w0 + v) * 64;
         if (cbase >= out_stride) break;
         if (sparse && ge[v] == 0) continue;
