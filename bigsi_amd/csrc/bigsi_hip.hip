@@ -1188,6 +1188,7 @@ struct CountLaunch {
     uint32_t early_exit;        // BIGSI_RUN_EARLY_EXIT on a hits-only, one-slice run
     uint64_t *partial;          // slices > 1: bit-sliced partial counts of every slice (k_count_combine adds them up)
     uint32_t planes_out;
+    bool half;                  // half the row loads in flight per lane (k_and_count<..., 3>)
     int vec;                    // 64-column words per lane: 2, or 1 (h = 3 / 4, one slice, not pipelined): `tiles` is computed for it
 };
 
@@ -1203,7 +1204,10 @@ static void launch_count_wide(bigsi_hip_batch *b, const CountLaunch &c, uint32_t
 #define COMMA ,
 #define BIGSI_LAUNCH_COUNT(H) hipLaunchKernelGGL((k_and_count<P, H, CountT>), BIGSI_COUNT_ARGS)
 #ifdef BIGSI_HIP_TUNING      // (the one-word-per-lane form: an A/B variant, not in the product library -- DESIGN.md section 7)
-#define BIGSI_LAUNCH_COUNT_VEC1(H) if (c.vec == 1) hipLaunchKernelGGL((k_and_count<P COMMA H COMMA CountT COMMA 1 COMMA 1>), BIGSI_COUNT_ARGS); else
+#define BIGSI_LAUNCH_COUNT_VEC1(H)                                                                                          \
+    if (c.vec == 1) hipLaunchKernelGGL((k_and_count<P COMMA H COMMA CountT COMMA 1 COMMA 1>), BIGSI_COUNT_ARGS);          \
+    else if (c.half) hipLaunchKernelGGL((k_and_count<P COMMA H COMMA CountT COMMA 3>), BIGSI_COUNT_ARGS);                  \
+    else
 #else
 #define BIGSI_LAUNCH_COUNT_VEC1(H)
 #endif
@@ -1714,7 +1718,11 @@ int bigsi_batch_run(bigsi_hip_batch *b, double threshold, uint32_t flags, bool o
         if (blocks256 % 256 == 0 || (b->exact && blocks256 >= 2 * kb256)) mid = false;
     }
     const int and_block = mid ? 64 : b->exact ? and_block_env : std::min(and_block_env, 256);
-    static const int and_unroll = env_int("BIGSI_HIP_AND_UNROLL", 8);
+    // row loads a lane keeps in flight: 8, or 4 when the launch holds so many live wavefronts that 8 would put more bytes in flight
+    // than the memory system schedules well -- interleaved A/B, 256 queries per launch on 62.5 k-sample shards (977-word rows, 2048
+    // live wavefronts): 4 -> +3.3 % (C4 shard 263 -> 272 M lookups/s) / +2.2 % (north-star shard), 6 -> +1.5 %, 2 -> -17 %; C3 (1664 live
+    // wavefronts per launch): 8 stays (6: -1 %, 4: -5 %).  BIGSI_HIP_AND_UNROLL (tuning builds) forces one.
+    static const int and_unroll_env = env_int("BIGSI_HIP_AND_UNROLL", 0);
     const uint32_t tiles = (uint32_t)ceil_div(b->wv, (uint64_t)and_block * kVec);
     // large exact batches go out as several launches, each a whole number of workgroups per CU (launches of 384 or 640
     // workgroups measured 0.72-0.78 of peak, 512 / 768 / 1024: 0.82-0.85) with about 1600-2000 LIVE wavefronts: all co-resident,
@@ -1767,8 +1775,14 @@ int bigsi_batch_run(bigsi_hip_batch *b, double threshold, uint32_t flags, bool o
     hipLaunchKernelGGL((k_and_exact<U>), dim3(grid), dim3(l_block), 0, ix->stream, ix->d_index, ix->stride_words, (uint32_t)b->wv, \
                        ix->n_cols, k2_rows, b->d_pos_off.as<uint64_t>(), b->num_unique.as<uint32_t>(), ix->h, q0,    \
                        q1, l_tiles, out, b->wv_pad, l_slices, (flags & BIGSI_RUN_EARLY_EXIT) ? 1u : 0u)
+            const uint64_t live_waves = (uint64_t)(q1 - q0) * ceil_div(b->wv, 64 * kVec) * l_slices;
+            const int and_unroll = and_unroll_env ? and_unroll_env : (live_waves >= 1920 && l_slices == 1 ? 4 : 8);
             if (and_unroll == 4) BIGSI_LAUNCH_EXACT(4);
+#ifdef BIGSI_HIP_TUNING
+            else if (and_unroll == 2) BIGSI_LAUNCH_EXACT(2);
+            else if (and_unroll == 6) BIGSI_LAUNCH_EXACT(6);
             else if (and_unroll == 16) BIGSI_LAUNCH_EXACT(16);
+#endif
             else if (!and_nt) BIGSI_LAUNCH_EXACT(8 COMMA false);
             else BIGSI_LAUNCH_EXACT(8);
 #undef BIGSI_LAUNCH_EXACT
@@ -1812,7 +1826,11 @@ int bigsi_batch_run(bigsi_hip_batch *b, double threshold, uint32_t flags, bool o
         const int vec = (count_vec1 && slices == 1 && !(deep && !early) && (ix->h == 3 || ix->h == 4) && P <= 16) ? 1 : 2;
         const uint32_t ctiles = vec == 1 ? (uint32_t)ceil_div(b->wv, (uint64_t)and_block) : tiles;
         if (ceil_div(b->n_seqs, 8) * 8 * (uint64_t)ctiles * slices > 0x7FFFFFFFull) return fail(BIGSI_ERR_INVALID, "batch too large for one launch");
-        const CountLaunch cl{k2_rows, (unsigned)and_block, ctiles, out, cstride, hb, sparse, slices, deep && !early, early, partial, planes_out, vec};
+        // half the row loads in flight per lane (tuning builds; what gives the EXACT kernel +2-3 % on 62.5 k-sample shards): -5 % on the
+        // north-star shard at 0.4, +-0 on the C5 shard and at C3 -- the counting kernel keeps 8-12
+        static const int count_half = env_int("BIGSI_HIP_COUNT_HALF", 0);
+        const bool half = count_half == 1 && slices == 1 && !(deep && !early) && (ix->h == 3 || ix->h == 4);
+        const CountLaunch cl{k2_rows, (unsigned)and_block, ctiles, out, cstride, hb, sparse, slices, deep && !early, early, partial, planes_out, half, vec};
         for (uint32_t q0 = 0; q0 < b->n_seqs; q0 += chunk_q, n_launches++)
             launch_count(b, P, cl, q0, (uint32_t)std::min<uint64_t>((uint64_t)q0 + chunk_q, b->n_seqs));
         if (slices > 1) {        // the slices' partial counts -> totals, hit mask, counters

@@ -974,7 +974,8 @@ __global__ __launch_bounds__(kBlock) void k_and_count(
     if (H > 0) {
         // KM k-mers per iteration so that 8-12 independent row loads are in flight per lane whatever h is (h=3: 12 loads
         // measured +1.9 % over 6; h=4: 8 vs 16 no difference)
-        constexpr int KM = H == 1 ? 8 : H <= 3 ? 4 : 2;
+        constexpr int KM0 = H == 1 ? 8 : H <= 3 ? 4 : 2;
+        constexpr int KM = KMX == 3 ? (KM0 > 1 ? KM0 / 2 : 1) : KM0;      // KMX == 3: half the loads in flight per lane (launches with > ~1900 live wavefronts)
         if (KMX == 2) {
             // software pipeline: the loads of the NEXT KM k-mers are issued before the bit-sliced adds of the current ones, so
             // a wavefront keeps the memory system busy through its own ALU phase (matters when few wavefronts share a SIMD)
