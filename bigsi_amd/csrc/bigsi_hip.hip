@@ -1718,10 +1718,12 @@ int bigsi_batch_run(bigsi_hip_batch *b, double threshold, uint32_t flags, bool o
         if (blocks256 % 256 == 0 || (b->exact && blocks256 >= 2 * kb256)) mid = false;
     }
     const int and_block = mid ? 64 : b->exact ? and_block_env : std::min(and_block_env, 256);
-    // row loads a lane keeps in flight: 8, or 4 when the launch holds so many live wavefronts that 8 would put more bytes in flight
-    // than the memory system schedules well -- interleaved A/B, 256 queries per launch on 62.5 k-sample shards (977-word rows, 2048
-    // live wavefronts): 4 -> +3.3 % (C4 shard 263 -> 272 M lookups/s) / +2.2 % (north-star shard), 6 -> +1.5 %, 2 -> -17 %; C3 (1664 live
-    // wavefronts per launch): 8 stays (6: -1 %, 4: -5 %).  BIGSI_HIP_AND_UNROLL (tuning builds) forces one.
+    // row loads a lane keeps in flight: 8, or 4 when 8 would put more bytes in flight on the chip (queries of the launch x row bytes x
+    // loads) than the memory system schedules well -- the optimum measured at 8-13 MB.  Interleaved A/B: 256 queries per launch on
+    // 62.5 k-sample shards (7.8 KB rows: 16 MB at 8 loads): 4 -> +3.3 % (C4 shard 263 -> 272 M lookups/s) / +2.2 % (north-star shard),
+    // 6 -> +1.5 %, 2 -> -17 %; unchunked C3 launches of 160-248 queries (16-25 MB): 4 -> +2 ... +9 %.  At 12.8 MB 8 stays: C3's 128-query
+    // launches (4: -5 %) and C3 split over 2 / 4 / 8 GPUs -- 256 x 6.3 KB, 512 x 3.1 KB, 1024 x 1.6 KB rows per launch (4: -7 / -10 /
+    // -7 %).  BIGSI_HIP_AND_UNROLL (tuning builds) forces one.
     static const int and_unroll_env = env_int("BIGSI_HIP_AND_UNROLL", 0);
     const uint32_t tiles = (uint32_t)ceil_div(b->wv, (uint64_t)and_block * kVec);
     // large exact batches go out as several launches, each a whole number of workgroups per CU (launches of 384 or 640
@@ -1775,8 +1777,8 @@ int bigsi_batch_run(bigsi_hip_batch *b, double threshold, uint32_t flags, bool o
     hipLaunchKernelGGL((k_and_exact<U>), dim3(grid), dim3(l_block), 0, ix->stream, ix->d_index, ix->stride_words, (uint32_t)b->wv, \
                        ix->n_cols, k2_rows, b->d_pos_off.as<uint64_t>(), b->num_unique.as<uint32_t>(), ix->h, q0,    \
                        q1, l_tiles, out, b->wv_pad, l_slices, (flags & BIGSI_RUN_EARLY_EXIT) ? 1u : 0u)
-            const uint64_t live_waves = (uint64_t)(q1 - q0) * ceil_div(b->wv, 64 * kVec) * l_slices;
-            const int and_unroll = and_unroll_env ? and_unroll_env : (live_waves >= 1920 && l_slices == 1 ? 4 : 8);
+            const uint64_t in_flight_at_8 = (uint64_t)(q1 - q0) * b->wv * 8 * 8;
+            const int and_unroll = and_unroll_env ? and_unroll_env : (in_flight_at_8 > (29ull << 19) /* 14.5 MB */ && l_slices == 1 ? 4 : 8);
             if (and_unroll == 4) BIGSI_LAUNCH_EXACT(4);
 #ifdef BIGSI_HIP_TUNING
             else if (and_unroll == 2) BIGSI_LAUNCH_EXACT(2);
