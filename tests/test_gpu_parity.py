@@ -1124,6 +1124,28 @@ def test_search_stream_pipelined_equals_one_by_one(hip):
             assert [s for s, _ in got] == qs
             assert [r for _, r in got] == want, (thr, score, bs)
     assert list(b.search_stream([], 1.0)) == []
+    # the stream defers full garbage-collector passes while it runs (pause_gc): the collector is off between its first and its
+    # last yield and back as it was afterwards -- whether the stream is consumed, abandoned half way, or ends in one of the
+    # reference's errors -- and a caller that had it off keeps it off; pause_gc=False never touches it
+    import gc
+    assert gc.isenabled()
+    it = b.search_stream(iter(qs), 1.0, batch_size=5)
+    next(it)
+    assert not gc.isenabled()
+    it.close()
+    assert gc.isenabled()
+    with pytest.raises(TypeError):
+        list(b.search_stream(qs[:7] + ["ACGT"] + qs[7:], 1.0, batch_size=5))      # a query without k-mers: reduce() of nothing
+    assert gc.isenabled()
+    it = b.search_stream(iter(qs), 1.0, batch_size=5, pause_gc=False)
+    next(it)
+    assert gc.isenabled()
+    it.close()
+    gc.disable()
+    try:
+        assert len(list(b.search_stream(iter(qs), 0.4, batch_size=16))) == len(qs) and not gc.isenabled()
+    finally:
+        gc.enable()
     b.delete()
 
 
