@@ -217,14 +217,14 @@ def ptr(a):
 def fasta_pack(data):
     """bigsi_hip_fasta_pack over the bytes of a FASTA file: (uint8 blob, uint64 offsets[n+1]) of its sequences, or None when the
     text is not plain ASCII (the caller's Python route then reads the file)."""
-    n_max = data.count(b">")
-    blob, off = np.empty(max(len(data), 1), np.uint8), np.empty(n_max + 1, np.uint64)
     n = C.c_uint64(0)
-    rc = lib().bigsi_hip_fasta_pack(data, len(data), ptr(blob), ptr(off), n_max, C.byref(n))
+    rc = lib().bigsi_hip_fasta_pack(data, len(data), None, None, 0, C.byref(n))          # the sizing call
     if rc == ERR_INVALID:
         return None
     check(rc)
-    return blob[:int(off[n.value])], off[:n.value + 1]
+    blob, off = np.empty(max(len(data), 1), np.uint8), np.empty(n.value + 1, np.uint64)
+    check(lib().bigsi_hip_fasta_pack(data, len(data), ptr(blob), ptr(off), n.value, C.byref(n)))
+    return blob[:int(off[n.value])], off
 
 
 def format_results(fmt, blob, soff, threshold, citation_json, nu, off, col, cnt, names, name_off, deleted, threads=0):

@@ -194,35 +194,25 @@ void run_blocks(uint64_t n_blocks, uint32_t threads, F f)
     for (auto &th : pool) th.join();
 }
 
-}   // namespace
 
-// bigsi_hip.h: the sequences of a FASTA text, packed for the search entry points.  Line ends are found 16 bytes at a time (SSE2, the
-// x86-64 baseline: a million 61-bp reads are a 64 MB file, and a byte loop over it took longer than the search itself).
-extern "C" int bigsi_hip_fasta_pack(const char *text, uint64_t n_bytes, char *out_seqs, uint64_t *out_offsets, uint64_t max_records, uint64_t *n_records)
+// One chunk of a FASTA text (it starts right after a line end, or at 0): its lines, stripped as str.strip() would, handed to
+// `header()` (a line that starts with '>') or `bases(a, b)` (any other non-empty line).  Line ends ('\n', '\r') are found 16 bytes at
+// a time (SSE2, the x86-64 baseline: a million 61-bp reads are a 64 MB file, and a byte loop over it took longer than the search).
+// Returns non-zero if a byte >= 0x80 was seen.
+template <typename H, typename B>
+int scan_fasta(const char *text, uint64_t lo, uint64_t hi, H header, B bases)
 {
-    if ((n_bytes && !text) || !n_records) return fail(BIGSI_ERR_INVALID, "NULL argument");
-    uint64_t n = 0, w = 0, start = 0;
-    bool in_record = false, overflow = false;
-    auto line = [&](uint64_t a, uint64_t b) {      // [a, b): one line without its terminator, stripped as str.strip() would
+    uint64_t start = lo, pos = lo;
+    int high = 0;
+    auto line = [&](uint64_t a, uint64_t b) {
         while (a < b && is_space((unsigned char)text[a])) a++;
         while (b > a && is_space((unsigned char)text[b - 1])) b--;
         if (a == b) return;
-        if (text[a] == '>') {
-            if (out_offsets) {
-                if (n >= max_records) { overflow = true; return; }
-                out_offsets[n] = w;
-            }
-            n++;
-            in_record = true;
-        } else if (in_record) {
-            if (out_seqs) memcpy(out_seqs + w, text + a, b - a);
-            w += b - a;
-        }
+        if (text[a] == '>') header();
+        else bases(a, b);
     };
-    uint64_t pos = 0;
-    int high = 0;
     const __m128i lf = _mm_set1_epi8('\n'), cr = _mm_set1_epi8('\r');
-    for (; pos + 16 <= n_bytes; pos += 16) {
+    for (; pos + 16 <= hi; pos += 16) {
         const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i *>(text + pos));
         high |= _mm_movemask_epi8(v);
         unsigned m = (unsigned)_mm_movemask_epi8(_mm_or_si128(_mm_cmpeq_epi8(v, lf), _mm_cmpeq_epi8(v, cr)));
@@ -233,16 +223,63 @@ extern "C" int bigsi_hip_fasta_pack(const char *text, uint64_t n_bytes, char *ou
             start = e + 1;
         }
     }
-    for (; pos < n_bytes; pos++) {
+    for (; pos < hi; pos++) {
         const unsigned char c = (unsigned char)text[pos];
         high |= c & 0x80;
         if (c == '\n' || c == '\r') { line(start, pos); start = pos + 1; }
     }
-    if (start < n_bytes) line(start, n_bytes);
-    if (high) return fail(BIGSI_ERR_INVALID, "not plain ASCII");
-    if (overflow) return fail(BIGSI_ERR_CAPACITY, "more than %llu records", (unsigned long long)max_records);
-    if (out_offsets) out_offsets[n] = w;      // (n + 1 entries; sized by a first call with out_offsets == NULL, or by counting '>')
+    if (start < hi) line(start, hi);
+    return high;
+}
+
+}   // namespace
+
+// bigsi_hip.h: the sequences of a FASTA text, packed for the search entry points.  The text is cut into chunks at line ends and scanned
+// twice by a few host threads: once to count every chunk's records and sequence bytes (the bytes before a chunk's first header belong
+// to the last record of the chunks before it), once to write them at their places.
+extern "C" int bigsi_hip_fasta_pack(const char *text, uint64_t n_bytes, char *out_seqs, uint64_t *out_offsets, uint64_t max_records, uint64_t *n_records)
+{
+    if ((n_bytes && !text) || !n_records) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    const uint32_t threads = (uint32_t)std::min<uint64_t>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())), n_bytes / (4u << 20) + 1);
+    const uint64_t n_chunks = threads;
+    std::vector<uint64_t> cut(n_chunks + 1, n_bytes);
+    cut[0] = 0;
+    for (uint64_t c = 1; c < n_chunks; c++) {          // a chunk starts right after a line end
+        uint64_t p = std::max(cut[c - 1], n_bytes / n_chunks * c);
+        while (p < n_bytes && text[p] != '\n' && text[p] != '\r') p++;
+        cut[c] = p < n_bytes ? p + 1 : n_bytes;
+    }
+    struct Tally { uint64_t records = 0, lead = 0, body = 0; int high = 0; };
+    std::vector<Tally> tally(n_chunks);
+    run_blocks(n_chunks, threads, [&](uint64_t c) {
+        Tally t;
+        t.high = scan_fasta(text, cut[c], cut[c + 1], [&] { t.records++; }, [&](uint64_t a, uint64_t b) { (t.records ? t.body : t.lead) += b - a; });
+        tally[c] = t;
+    });
+    uint64_t n = 0, w = 0;
+    std::vector<uint64_t> rec0(n_chunks), w0(n_chunks);
+    for (uint64_t c = 0; c < n_chunks; c++) {
+        if (tally[c].high) return fail(BIGSI_ERR_INVALID, "not plain ASCII");
+        rec0[c] = n;
+        w0[c] = w;
+        w += (n ? tally[c].lead : 0) + tally[c].body;      // (bases before the text's first header belong to no record)
+        n += tally[c].records;
+    }
     *n_records = n;
+    if (!out_offsets && !out_seqs) return BIGSI_OK;      // (the sizing call: n + 1 offsets, at most n_bytes sequence bytes)
+    if (out_offsets && n > max_records) return fail(BIGSI_ERR_CAPACITY, "%llu records, room for %llu", (unsigned long long)n, (unsigned long long)max_records);
+    run_blocks(n_chunks, threads, [&](uint64_t c) {
+        uint64_t r = rec0[c], at = w0[c];
+        bool in_record = r > 0;
+        scan_fasta(text, cut[c], cut[c + 1],
+                   [&] { if (out_offsets) out_offsets[r] = at; r++; in_record = true; },
+                   [&](uint64_t a, uint64_t b) {
+                       if (!in_record) return;
+                       if (out_seqs) memcpy(out_seqs + at, text + a, b - a);
+                       at += b - a;
+                   });
+    });
+    if (out_offsets) out_offsets[n] = w;
     return BIGSI_OK;
 }
 

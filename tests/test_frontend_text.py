@@ -40,6 +40,42 @@ def test_fasta_pack_gives_read_fastas_sequences(text):
     assert got == want
 
 
+def test_fasta_pack_of_a_text_cut_into_chunks():
+    """A text large enough for several chunks / host threads (one per 4 MB): records of one to five lines of random lengths, some
+    empty, CRLF and bare CR line ends here and there, bases before the first header, so that chunk boundaries fall inside records,
+    between them and next to blank lines -- against read_fasta."""
+    rng = np.random.default_rng(9)
+    parts = ["ACGTACGT\nTTTT\n"]                       # bases that belong to no record
+    size = len(parts[0])
+    i = 0
+    while size < 13 << 20:
+        lines = [">rec%d %s" % (i, "x" * int(rng.integers(0, 30)))]
+        for _ in range(int(rng.integers(0, 6))):
+            lines.append("".join(rng.choice(list("ACGTN"), size=int(rng.integers(1, 2000)))))
+            if rng.random() < 0.1:
+                lines.append("" if rng.random() < 0.5 else "   ")
+        end = "\r\n" if i % 7 == 0 else "\r" if i % 11 == 0 else "\n"
+        text = end.join(lines) + end
+        parts.append(text)
+        size += len(text)
+        i += 1
+    data = "".join(parts)
+    fn = tempfile.mktemp(suffix=".fa")
+    with open(fn, "w", newline="") as f:
+        f.write(data)
+    try:
+        want = [s for _, s in frontend.read_fasta(fn)]
+        blob, off = _lib.fasta_pack(data.encode())
+    finally:
+        os.remove(fn)
+    assert len(off) - 1 == len(want) == i
+    raw = blob.tobytes().decode()
+    assert int(off[-1]) == len(raw) == sum(len(s) for s in want)
+    assert all(raw[int(off[j]):int(off[j + 1])] == want[j] for j in range(len(want)))
+    # a non-ASCII byte in a late chunk is still seen
+    assert _lib.fasta_pack(data.encode() + ">z\nAC\xc3\xa9GT\n".encode("latin-1")) is None
+
+
 def test_fasta_pack_leaves_non_ascii_text_to_the_caller():
     assert _lib.fasta_pack(">r\nAC\xc3\xa9GT\n".encode("latin-1")) is None
 
