@@ -231,11 +231,28 @@ def format_results(fmt, blob, soff, threshold, citation_json, nu, off, col, cnt,
     """bigsi_hip_format_results -> str (the reference's bulk_search text of an unscored search); BigsiHipError(ERR_STATE) where the
     reference raises instead of answering."""
     import json
-    text, size = C.c_void_p(), C.c_uint64(0)
     n = len(soff) - 1
-    check(lib().bigsi_hip_format_results(int(fmt), ptr(blob) if not isinstance(blob, bytes) else blob, ptr(soff), n, json.dumps(threshold).encode(),
-                                         citation_json.encode(), 1 if threshold == 1.0 else 0, ptr(nu), ptr(off), ptr(col), ptr(cnt), names, ptr(name_off),
-                                         ptr(deleted), len(name_off) - 1, int(threads), C.byref(text), C.byref(size)))
+    args = (int(fmt), ptr(blob) if not isinstance(blob, bytes) else blob, ptr(soff), n, json.dumps(threshold).encode(), citation_json.encode(),
+            1 if threshold == 1.0 else 0, ptr(nu), ptr(off), ptr(col), ptr(cnt), names, ptr(name_off), ptr(deleted), len(name_off) - 1, int(threads))
+    try:
+        from . import _results          # (the CPython extension: it can hand out a str whose body the library fills in place)
+    except ImportError:
+        _results = None
+    if _results is not None:
+        # the sizing call (a zero-byte buffer of the caller's), then the text written straight into a new str: a bulk search of a
+        # million reads is 200 MB of JSON, whose malloc + decode + free took three times as long as formatting it
+        probe = C.create_string_buffer(1)
+        text, size = C.c_void_p(C.addressof(probe)), C.c_uint64(0)
+        rc = lib().bigsi_hip_format_results(*args, C.byref(text), C.byref(size))
+        if rc != ERR_CAPACITY:
+            check(rc)
+            return ""                    # (an empty text fits a zero-byte buffer)
+        s, address = _results.ascii_str(size.value)
+        text, cap = C.c_void_p(address), C.c_uint64(size.value)
+        check(lib().bigsi_hip_format_results(*args, C.byref(text), C.byref(cap)))
+        return s
+    text, size = C.c_void_p(), C.c_uint64(0)
+    check(lib().bigsi_hip_format_results(*args, C.byref(text), C.byref(size)))
     try:
         return str(memoryview((C.c_char * size.value).from_address(text.value)), "ascii") if size.value else ""
     finally:

@@ -130,7 +130,21 @@ PyObject *build(PyObject *, PyObject *args)
     return out;
 }
 
-PyMethodDef methods[] = {{"build", build, METH_VARARGS, "result dicts of the sequences [lo, hi) of a streaming search (see _results.cpp)"}, {nullptr, nullptr, 0, nullptr}};
+// ascii_str(n) -> (s, address): a new str of n ASCII characters whose body (n bytes at `address`) the caller fills before anything
+// reads s -- bigsi_hip_format_results writes the text of a bulk search straight into it (no bytes -> str copy of a few hundred MB)
+PyObject *ascii_str(PyObject *, PyObject *args)
+{
+    Py_ssize_t n;
+    if (!PyArg_ParseTuple(args, "n", &n)) return nullptr;
+    if (n < 0) { PyErr_SetString(PyExc_ValueError, "negative length"); return nullptr; }
+    PyObject *s = PyUnicode_New(n, 127);
+    if (!s) return nullptr;
+    return Py_BuildValue("(Nn)", s, (Py_ssize_t)(uintptr_t)PyUnicode_DATA(s));
+}
+
+PyMethodDef methods[] = {{"build", build, METH_VARARGS, "result dicts of the sequences [lo, hi) of a streaming search (see _results.cpp)"},
+                         {"ascii_str", ascii_str, METH_VARARGS, "(str of n ASCII characters to be filled, address of its body)"},
+                         {nullptr, nullptr, 0, nullptr}};
 PyModuleDef module = {PyModuleDef_HEAD_INIT, "_results", "result dicts of BIGSI.search_stream, built in C++", -1, methods, nullptr, nullptr, nullptr, nullptr};
 
 }   // namespace

@@ -293,8 +293,9 @@ extern "C" int bigsi_hip_format_results(int format, const char *seqs, const uint
     if (format == 0 && (!threshold_text || !citation_text)) return fail(BIGSI_ERR_INVALID, "NULL argument");
     const uint64_t n_hits = n_seqs ? hit_offsets[n_seqs] : 0;
     if (n_hits && (!colours || (!exact && !counts) || (n_names && (!names || !name_offsets || !name_deleted)))) return fail(BIGSI_ERR_INVALID, "NULL argument");
-    *out_text = nullptr;
-    *out_bytes = 0;
+    char *const caller_buf = *out_text;             // non-NULL: the caller's own buffer of *out_bytes bytes (e.g. the body of a string object)
+    const uint64_t caller_cap = *out_bytes;
+    if (!caller_buf) *out_bytes = 0;
     // what the reference does not answer with text is the caller's to raise (in the order of the records)
     for (uint64_t r = 0; r < n_seqs; r++)
         if (num_unique[r] == 0) return fail(BIGSI_ERR_STATE, "record %llu has no k-mers: the reference raises (graph/bigsi.py:35-44, utils/fncts.py:24-25)", (unsigned long long)r);
@@ -316,7 +317,11 @@ extern "C" int bigsi_hip_format_results(int format, const char *seqs, const uint
     at[0] = head;
     for (uint64_t b = 0; b < n_blocks; b++) at[b + 1] += at[b];
     const uint64_t total = at[n_blocks] + tail;
-    char *text = static_cast<char *>(malloc(total + 1));
+    if (caller_buf && caller_cap < total) {
+        *out_bytes = total;
+        return fail(BIGSI_ERR_CAPACITY, "the text is %llu bytes, the buffer holds %llu", (unsigned long long)total, (unsigned long long)caller_cap);
+    }
+    char *text = caller_buf ? caller_buf : static_cast<char *>(malloc(total + 1));
     if (!text) return fail(BIGSI_ERR_NOMEM, "no memory for %llu bytes of text", (unsigned long long)total);
     if (format == 0) {
         if (n_seqs) { memcpy(text, "[\n", 2); memcpy(text + total - 2, "\n]", 2); }
@@ -327,7 +332,7 @@ extern "C" int bigsi_hip_format_results(int format, const char *seqs, const uint
         std::vector<uint64_t> order;
         format_records(j, b * per, std::min(n_seqs, (b + 1) * per), s, order);
     });
-    text[total] = 0;
+    if (!caller_buf || caller_cap > total) text[total] = 0;
     *out_text = text;
     *out_bytes = total;
     return BIGSI_OK;

@@ -396,8 +396,10 @@ int bigsi_hip_probe_rows(bigsi_hip_index *ix, uint32_t rows_per_query, uint32_t 
  * colour c = names[name_offsets[c] .. name_offsets[c+1]) (only colours that occur need a non-empty name); name_deleted[c] != 0
  * drops the sample (graph/bigsi.py:186-190).  percent_kmers_found is repr(round(100 * float(found) / num_kmers, 2)).
  * BIGSI_ERR_STATE when the reference would raise instead of answering (a record without k-mers; exact hit on a colour without
- * a name): the caller's per-record route raises its exception in record order.  *out_text is malloc'ed, NUL-terminated,
- * *out_bytes long: release it with bigsi_hip_free_text.  threads = 0: up to 16 host threads. */
+ * a name): the caller's per-record route raises its exception in record order.  *out_text == NULL on entry: the text is malloc'ed,
+ * NUL-terminated, *out_bytes long: release it with bigsi_hip_free_text.  *out_text != NULL: the caller's own buffer of *out_bytes
+ * bytes (the body of a string object of the host language, say: no copy afterwards); BIGSI_ERR_CAPACITY with the size needed in
+ * *out_bytes if it is too small -- a call with a zero-byte buffer is the sizing call.  threads = 0: up to 16 host threads. */
 int bigsi_hip_fasta_pack(const char *text, uint64_t n_bytes, char *out_seqs, uint64_t *out_offsets, uint64_t max_records, uint64_t *n_records);
 int bigsi_hip_format_results(int format, const char *seqs, const uint64_t *offsets, uint64_t n_seqs, const char *threshold_text,
                              const char *citation_text, int exact, const uint32_t *num_unique, const uint64_t *hit_offsets,
