@@ -164,3 +164,36 @@ def test_format_results_leaves_the_references_errors_to_the_caller():
         _lib.format_results(0, blob, soff, 1.0, "\"c\"", nu, off, np.array([5], np.uint32), np.array([2], np.uint32), b"ab\0", np.array([0, 1, 2], np.uint64),
                             np.zeros(2, np.uint8))
     assert e.value.code == _lib.ERR_STATE
+
+
+def test_format_results_into_the_callers_buffer():
+    """*out_text != NULL on entry: the text goes into the caller's buffer.  A zero-byte buffer is the sizing call (BIGSI_ERR_CAPACITY
+    and the size), a buffer one byte short is refused the same way, the exact size and a larger one hold the same characters as the
+    malloc'ed route; _lib.format_results (which fills the body of the str it returns when the extension is built) gives them too."""
+    import ctypes as C
+    seqs = ["ACGT" * 9, 'A"C\\G', "TTTTT"]
+    blob, soff = _lib.pack_seqs(seqs)
+    nu, off = np.array([6, 2, 1], np.uint32), np.array([0, 2, 2, 3], np.uint64)
+    col, cnt = np.array([0, 1, 1], np.uint32), np.array([6, 3, 1], np.uint32)
+    names, name_off, deleted = b"s0s1\0", np.array([0, 2, 4], np.uint64), np.zeros(2, np.uint8)
+    L = _lib.lib()
+    for fmt in (0, 1):
+        args = (fmt, blob, _lib.ptr(soff), 3, b"0.5", b'"c"', 0, _lib.ptr(nu), _lib.ptr(off), _lib.ptr(col), _lib.ptr(cnt), names, _lib.ptr(name_off),
+                _lib.ptr(deleted), 2, 1)
+        text, size = C.c_void_p(), C.c_uint64(0)
+        _lib.check(L.bigsi_hip_format_results(*args, C.byref(text), C.byref(size)))
+        want = C.string_at(text.value, size.value)
+        L.bigsi_hip_free_text(text)
+        assert len(want) > 20
+        for cap in (0, len(want) - 1):
+            buf = C.create_string_buffer(max(cap, 1))
+            text, size = C.c_void_p(C.addressof(buf)), C.c_uint64(cap)
+            assert L.bigsi_hip_format_results(*args, C.byref(text), C.byref(size)) == _lib.ERR_CAPACITY and size.value == len(want)
+        for cap in (len(want), len(want) + 5):
+            buf = C.create_string_buffer(b"\xff" * (cap + 1), cap + 1)
+            text, size = C.c_void_p(C.addressof(buf)), C.c_uint64(cap)
+            _lib.check(L.bigsi_hip_format_results(*args, C.byref(text), C.byref(size)))
+            assert size.value == len(want) and buf.raw[:len(want)] == want and text.value == C.addressof(buf)
+            assert buf.raw[cap:cap + 1] == b"\xff"                       # nothing written beyond the buffer
+        got = _lib.format_results(fmt, blob, soff, 0.5, '"c"', nu, off, col, cnt, names, name_off, deleted, threads=1)
+        assert got == want.decode()
