@@ -1344,7 +1344,18 @@ static int launch_reads_fused(bigsi_hip_batch *b, hipStream_t st = nullptr, bool
     // (6 -> 8 wavefronts per SIMD) 1563 -> 1534 M: stays at two words per lane
     static const int vec1_exact = env_int("BIGSI_HIP_READS_VEC1_EXACT", 0), vec1_count = env_int("BIGSI_HIP_READS_VEC1_COUNT", 1);
     const bool narrow = b->wv <= (uint64_t)kBlock;
+#ifdef BIGSI_HIP_TUNING
+    static const int reads_unr = env_int("BIGSI_HIP_READS_UNROLL", 16);
+#define BIGSI_READS_UNR(H)                                                                                                          \
+    if (b->exact && reads_unr == 8) hipLaunchKernelGGL((k_reads_fused<H COMMA true COMMA kVec COMMA 8>), BIGSI_READS_ARGS);           \
+    else if (b->exact && reads_unr == 12) hipLaunchKernelGGL((k_reads_fused<H COMMA true COMMA kVec COMMA 12>), BIGSI_READS_ARGS);    \
+    else if (b->exact && reads_unr == 24) hipLaunchKernelGGL((k_reads_fused<H COMMA true COMMA kVec COMMA 24>), BIGSI_READS_ARGS);    \
+    else
+#else
+#define BIGSI_READS_UNR(H)
+#endif
 #define BIGSI_READS(H)                                                                              \
+    BIGSI_READS_UNR(H)                                                                              \
     if (b->exact && narrow && vec1_exact) hipLaunchKernelGGL((k_reads_fused<H COMMA true COMMA 1>), BIGSI_READS_ARGS);   \
     else if (b->exact) hipLaunchKernelGGL((k_reads_fused<H COMMA true>), BIGSI_READS_ARGS);                \
     else if (narrow && vec1_count) hipLaunchKernelGGL((k_reads_fused<H COMMA false COMMA 1>), BIGSI_READS_ARGS);       \
@@ -1355,6 +1366,7 @@ static int launch_reads_fused(bigsi_hip_batch *b, hipStream_t st = nullptr, bool
     default: BIGSI_READS(4); break;
     }
 #undef BIGSI_READS
+#undef BIGSI_READS_UNR
 #undef BIGSI_READS_ARGS
 #undef COMMA
     HIP_TRY(hipGetLastError());

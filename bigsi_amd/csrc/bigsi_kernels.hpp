@@ -1369,7 +1369,8 @@ __global__ __launch_bounds__(kBlock) void k_hits_write(
 // to entries of the hit buffers it allocates with one atomic add (round 4: no order between queries, no waiting; see the
 // kernel's last section).  Same results, one launch.
 constexpr uint32_t kReadsMaxSeqs = 1u << 20;  // queries per launch of k_reads_fused at most
-template <int H, bool EXACT, int VEC = kVec /* 64-column words per lane: 2 (16-byte loads) or 1 (8-byte loads; rows of <= kBlock words) */>
+template <int H, bool EXACT, int VEC = kVec /* 64-column words per lane: 2 (16-byte loads) or 1 (8-byte loads; rows of <= kBlock words) */,
+          int UNR_EXACT = 16 /* row loads a lane keeps in flight on the exact route */>
 __global__ __launch_bounds__(kBlock) void k_reads_fused(
     const uint64_t *__restrict__ index, uint64_t stride_words, uint32_t wv, uint64_t n_cols, uint64_t m, double threshold,
     const char *__restrict__ seqs, const uint64_t *__restrict__ seq_off, const uint64_t *__restrict__ pos_off, uint32_t n_seqs,
@@ -1518,7 +1519,7 @@ __global__ __launch_bounds__(kBlock) void k_reads_fused(
 #pragma unroll
     for (int v = 0; v < VEC; v++) hitw[v] = 0ull;
     if (EXACT) {
-        constexpr int UNR = 16;
+        constexpr int UNR = UNR_EXACT;
         const uint32_t R = u * H;
         RowWords<VEC> acc = RowWords<VEC>::fill(~0ull);
         if (live) {
