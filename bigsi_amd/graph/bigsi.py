@@ -299,6 +299,12 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
         if isinstance(scored, tuple) and scored[0] == "pending":
             rec, bits, boff = batch.score_hits_end()
             scored = scored_rows(rec, bits, boff, scored[1], self.scorer.DB_SIZE)
+        if _results is not None and scored is None:
+            # unscored: the dicts straight from the arrays (bigsi_amd/_results.cpp), as search_stream builds them
+            total = int(off64[n_seqs])
+            names = self._names_of(colours[:total], exact)
+            if names is not None:
+                return list(native_result_lists(None, nu[:n_seqs], off64[:n_seqs + 1], colours, counts, exact, names, None, self.scorer.DB_SIZE))
         out = [[] for _ in range(n_seqs)]
         for i in np.flatnonzero(np.diff(off64[:n_seqs + 1])).tolist():      # only the sequences that have hits
             lo, hi = int(off64[i]), int(off64[i + 1])
@@ -442,6 +448,20 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
         import threading
         return self.storage.res.__dict__.setdefault("_lock", threading.RLock())
 
+    def _names_of(self, cols, exact):
+        """names[c] for the C++ assembly of result dicts: the sample name of every colour that occurs in `cols` (looked up once),
+        None for a deleted sample (its hits are dropped).  Returns None instead when the exact route meets a colour without a name:
+        a KeyError in the reference, which the Python loop raises at the right place."""
+        ns = self.num_samples
+        names = [None] * ns
+        for c in np.unique(cols).tolist():
+            if c < ns:
+                name = self.colour_to_sample(c)
+                names[c] = None if name == DELETION_SPECIAL_SAMPLE_NAME else name
+            elif exact:
+                return None
+        return names
+
     def _emit_native(self, res, nk, nu, off64, n_hits, colours, counts, threshold, score):
         """_emit's loop in the C++ extension (bigsi_amd/_results.cpp): the same dicts, built from the arrays without a Python
         statement per hit.  What stays here: the reference's errors (raised when the offending sequence's turn comes), the sample
@@ -456,14 +476,7 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
         stop = int(np.argmax(bad)) if bad.any() else len(chunk)
         total = int(off64[stop])
         cols = np.ascontiguousarray(colours[:total])
-        names = [None] * ns
-        for c in np.unique(cols).tolist():
-            if c < ns:
-                name = self.colour_to_sample(c)
-                names[c] = None if name == DELETION_SPECIAL_SAMPLE_NAME else name
-            elif exact:
-                names = None          # a colour without a name on the exact route: KeyError in the reference, in stream order
-                break
+        names = self._names_of(cols, exact)
         if names is None:
             yield from self._emit(res, threshold, score, native=False)
             return

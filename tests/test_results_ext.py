@@ -22,6 +22,7 @@ class Stub(object):
     scorer = types.SimpleNamespace(DB_SIZE=NS)
     _emit = bigsi_mod.BIGSI._emit
     _emit_native = bigsi_mod.BIGSI._emit_native
+    _names_of = bigsi_mod.BIGSI._names_of
 
     def colour_to_sample(self, c):
         if c >= NS:
