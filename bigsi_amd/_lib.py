@@ -163,6 +163,8 @@ SIGNATURES = {
     "bigsi_hip_fasta_pack": (_i32, [_P, _u64, _P, _P, _u64, C.POINTER(_u64)]),
     "bigsi_hip_format_results": (_i32, [_i32, _P, _P, _u64, C.c_char_p, C.c_char_p, _i32, _P, _P, _P, _P, _P, _P, _P, _u64, _u32,
                                          C.POINTER(_P), C.POINTER(_u64)]),
+    "bigsi_hip_format_results_scored": (_i32, [_i32, _P, _P, _u64, C.c_char_p, C.c_char_p, _i32, _P, _P, _P, _P, _P, _P, _P, _u64, _P, _u32,
+                                                C.POINTER(_P), C.POINTER(_u64)]),
     "bigsi_hip_free_text": (None, [_P]),
 }
 
@@ -227,32 +229,44 @@ def fasta_pack(data):
     return blob[:int(off[n.value])], off
 
 
-def format_results(fmt, blob, soff, threshold, citation_json, nu, off, col, cnt, names, name_off, deleted, threads=0):
-    """bigsi_hip_format_results -> str (the reference's bulk_search text of an unscored search); BigsiHipError(ERR_STATE) where the
-    reference raises instead of answering."""
+class ScoredText(C.Structure):
+    """bigsi_hip_scored_text (include/bigsi_hip.h): what bigsi_hip_format_results_scored needs per hit beside the hit lists"""
+    _fields_ = [("scores", C.c_void_p), ("bits", C.c_void_p), ("bit_offsets", C.c_void_p), ("evalue", C.c_void_p), ("pvalue", C.c_void_p),
+                ("log_evalue", C.c_void_p), ("log_pvalue", C.c_void_p), ("k", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+def format_results(fmt, blob, soff, threshold, citation_json, nu, off, col, cnt, names, name_off, deleted, threads=0, scored=None):
+    """bigsi_hip_format_results(_scored) -> str (the reference's bulk_search text); BigsiHipError(ERR_STATE) where the reference raises
+    instead of answering.  scored = (records, bits, bit_offsets, evalue, pvalue, log_evalue, log_pvalue, k): per-hit arrays of a
+    score=True search (K6's records and presence bits, the closed-form columns of scoring.score_columns)."""
     import json
     n = len(soff) - 1
+    sc = None
+    if scored is not None:
+        keep = [np.ascontiguousarray(a) for a in scored[:7]]          # (alive until the calls below have returned)
+        sc = ScoredText(*([ptr(a) for a in keep] + [int(scored[7]), 0]))
     args = (int(fmt), ptr(blob) if not isinstance(blob, bytes) else blob, ptr(soff), n, json.dumps(threshold).encode(), citation_json.encode(),
-            1 if threshold == 1.0 else 0, ptr(nu), ptr(off), ptr(col), ptr(cnt), names, ptr(name_off), ptr(deleted), len(name_off) - 1, int(threads))
+            1 if threshold == 1.0 else 0, ptr(nu), ptr(off), ptr(col), ptr(cnt), names, ptr(name_off), ptr(deleted), len(name_off) - 1,
+            C.addressof(sc) if sc is not None else None, int(threads))
     try:
         from . import _results          # (the CPython extension: it can hand out a str whose body the library fills in place)
     except ImportError:
         _results = None
-    if _results is not None:
+    if _results is not None and scored is None:          # (scored text is formatted once, into blocks: its sizing call would format it all)
         # the sizing call (a zero-byte buffer of the caller's), then the text written straight into a new str: a bulk search of a
         # million reads is 200 MB of JSON, whose malloc + decode + free took three times as long as formatting it
         probe = C.create_string_buffer(1)
         text, size = C.c_void_p(C.addressof(probe)), C.c_uint64(0)
-        rc = lib().bigsi_hip_format_results(*args, C.byref(text), C.byref(size))
+        rc = lib().bigsi_hip_format_results_scored(*args, C.byref(text), C.byref(size))
         if rc != ERR_CAPACITY:
             check(rc)
             return ""                    # (an empty text fits a zero-byte buffer)
         s, address = _results.ascii_str(size.value)
         text, cap = C.c_void_p(address), C.c_uint64(size.value)
-        check(lib().bigsi_hip_format_results(*args, C.byref(text), C.byref(cap)))
+        check(lib().bigsi_hip_format_results_scored(*args, C.byref(text), C.byref(cap)))
         return s
     text, size = C.c_void_p(), C.c_uint64(0)
-    check(lib().bigsi_hip_format_results(*args, C.byref(text), C.byref(size)))
+    check(lib().bigsi_hip_format_results_scored(*args, C.byref(text), C.byref(size)))
     try:
         return str(memoryview((C.c_char * size.value).from_address(text.value)), "ascii") if size.value else ""
     finally:

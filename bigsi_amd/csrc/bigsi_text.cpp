@@ -7,8 +7,11 @@
 #include <emmintrin.h>
 
 #include <algorithm>
+#include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -40,6 +43,12 @@ struct WriteSink {
         while (n) *p++ = tmp[--n];
     }
 };
+struct StringSink {          // (scored text: formatting a float costs more than copying it, so a block is formatted once, into a string)
+    std::string t;
+    inline void put(const char *s, size_t len) { t.append(s, len); }
+    inline void put_c(char c) { t.push_back(c); }
+    inline void put_u32(uint32_t v) { char tmp[12]; const int n = snprintf(tmp, sizeof tmp, "%u", v); t.append(tmp, (size_t)n); }
+};
 #define PUT_LIT(sink, lit) (sink).put(lit, sizeof(lit) - 1)
 
 // repr(round(100 * float(found) / num_kmers, 2)) (graph/bigsi.py:97-99): the rounded value is the double nearest to a decimal of
@@ -53,6 +62,100 @@ inline void put_percent(S &s, uint32_t found, uint32_t num)
     s.put_c('.');
     if (frac % 10 == 0) s.put_c((char)('0' + frac / 10));
     else { s.put_c((char)('0' + frac / 10)); s.put_c((char)('0' + frac % 10)); }
+}
+
+// repr(x) of a Python float (what json.dumps and csv.writer print): the shortest decimal string that reads back as x -- found as the
+// first of the correctly rounded 15-, 16- and 17-digit decimals that does (the closest n-digit decimal round-trips whenever an
+// n-digit one does) -- laid out as float_repr_style 'short' does: exponent form when the decimal point would sit more than 16
+// digits right of the first digit or 4 or more zeros left of it, else plain digits with at least one decimal place
+// (Python/pystrtod.c: format_float_short, 'r').  `json`: Infinity / NaN as json.dumps writes them (csv: inf / nan).
+template <typename S>
+inline void put_repr(S &s, double x, bool json)
+{
+    if (x != x) { if (json) PUT_LIT(s, "NaN"); else PUT_LIT(s, "nan"); return; }
+    if (x == HUGE_VAL || x == -HUGE_VAL) {
+        if (x < 0) s.put_c('-');
+        if (json) PUT_LIT(s, "Infinity"); else PUT_LIT(s, "inf");
+        return;
+    }
+    if (x == 0.0) { if (signbit(x)) PUT_LIT(s, "-0.0"); else PUT_LIT(s, "0.0"); return; }
+    {
+        // most fields of a score record are decimals of at most two places (rounded scores, percentages, 0.0 / 1.0 / 100.0): if
+        // c / 100 is x for the integer c nearest to 100 x, "c / 100" written out is the shortest decimal that reads back as x (two
+        // decimals that both do are closer together than 0.01 unless they are the same number)
+        const double c = rint(x * 100.0);
+        if (fabs(c) < 1e13 && c / 100.0 == x) {
+            uint64_t m = (uint64_t)fabs(c);
+            if (x < 0) s.put_c('-');
+            char tmp[24];
+            int n = 0;
+            uint64_t whole = m / 100;
+            do { tmp[n++] = (char)('0' + whole % 10); whole /= 10; } while (whole);
+            while (n) s.put_c(tmp[--n]);
+            s.put_c('.');
+            const uint32_t frac = (uint32_t)(m % 100);
+            s.put_c((char)('0' + frac / 10));
+            if (frac % 10) s.put_c((char)('0' + frac % 10));
+            return;
+        }
+    }
+    char buf[40];
+    // (a normal double is within 1.2e-16 of any decimal that reads back as it, so a shorter one shows as trailing zeros of the 15-digit
+    // rounding; subnormals are spaced wider than that and are tried from one digit up)
+    for (int digits = fabs(x) >= 2.2250738585072014e-308 ? 15 : 1;; digits++) {
+        snprintf(buf, sizeof buf, "%.*e", digits - 1, x);
+        if (digits == 17 || strtod(buf, nullptr) == x) break;
+    }
+    // buf = [-]d.ddddde[+-]XX
+    const char *p = buf;
+    if (*p == '-') { s.put_c('-'); p++; }
+    char dg[20];
+    int nd = 0;
+    dg[nd++] = *p++;
+    if (*p == '.') { p++; while (*p != 'e') dg[nd++] = *p++; }
+    while (nd > 1 && dg[nd - 1] == '0') nd--;
+    const int decpt = atoi(p + 1) + 1;          // the value is 0.d1d2... x 10^decpt
+    if (decpt <= -4 || decpt > 16) {
+        s.put_c(dg[0]);
+        if (nd > 1) { s.put_c('.'); s.put(dg + 1, (size_t)nd - 1); }
+        s.put_c('e');
+        int e = decpt - 1;
+        if (e < 0) { s.put_c('-'); e = -e; } else s.put_c('+');
+        if (e < 10) s.put_c('0');
+        s.put_u32((uint32_t)e);
+    } else if (decpt <= 0) {
+        PUT_LIT(s, "0.");
+        for (int i = 0; i < -decpt; i++) s.put_c('0');
+        s.put(dg, (size_t)nd);
+    } else if (decpt >= nd) {
+        s.put(dg, (size_t)nd);
+        for (int i = nd; i < decpt; i++) s.put_c('0');
+        PUT_LIT(s, ".0");
+    } else {
+        s.put(dg, (size_t)decpt);
+        s.put_c('.');
+        s.put(dg + decpt, (size_t)(nd - decpt));
+    }
+}
+
+template <typename S>
+inline void put_i64(S &s, int64_t v)
+{
+    char tmp[24];
+    const int n = snprintf(tmp, sizeof tmp, "%lld", (long long)v);
+    s.put(tmp, (size_t)n);
+}
+
+// the presence string of a hit ('0' / '1' per k-mer position) from its bits (bitarray(s).tobytes(): position p under 0x80 >> (p % 8))
+template <typename S>
+inline void put_presence(S &s, const uint8_t *bits, uint32_t n)
+{
+    char tmp[64];
+    for (uint32_t p0 = 0; p0 < n; p0 += 64) {
+        const uint32_t m = n - p0 < 64 ? n - p0 : 64;
+        for (uint32_t i = 0; i < m; i++) tmp[i] = (char)('0' + ((bits[(p0 + i) >> 3] >> (7 - ((p0 + i) & 7))) & 1));
+        s.put(tmp, m);
+    }
 }
 
 // json.dumps of an ASCII string: quotes, backslashes, control characters and DEL escaped
@@ -110,6 +213,32 @@ struct Job {
     const uint64_t *name_offsets;
     const uint8_t *name_deleted;
     uint64_t n_names;
+    const bigsi_hip_scored_text *sc;      // score=True: per-hit records, presence bits and the caller's closed-form columns (else NULL)
+};
+
+// the 17 fields of Scorer.score (scoring/score.py:96-121) + "kmer-presence" of hit t, as `field(key index, writer)` calls in the
+// reference's key order: score, min_score, max_score, max_mismatches, min_mismatches, mismatches, max_nident, nident, min_nident,
+// pident, max_pident, min_pident, length, evalue, pvalue, log_evalue, log_pvalue
+struct ScoredHit {
+    double f[10];        // score, min_score, max_score, pident, max_pident, min_pident, evalue, pvalue, log_evalue, log_pvalue
+    int64_t i[7];        // max_mismatches, min_mismatches, mismatches, max_nident, nident, min_nident, length
+    double percent;
+    const uint8_t *bits;
+    uint32_t n;
+    ScoredHit(const bigsi_hip_scored_text &sc, uint64_t t)
+    {
+        const bigsi_hip_hit_score &r = sc.scores[t];
+        const int64_t len = (int64_t)r.num_kmers + (int64_t)sc.k - 1;
+        const double fl = (double)len;
+        i[0] = r.max_mismatches; i[1] = r.min_mismatches; i[2] = r.mismatches;
+        i[3] = len - r.min_mismatches; i[4] = len - r.mismatches; i[5] = len - r.max_mismatches; i[6] = len;
+        f[0] = r.score; f[1] = r.min_score; f[2] = r.max_score;
+        f[3] = 100.0 * (double)i[4] / fl; f[4] = 100.0 * (double)i[3] / fl; f[5] = 100.0 * (double)i[5] / fl;      // score.py:110-112
+        f[6] = sc.evalue[t]; f[7] = sc.pvalue[t]; f[8] = sc.log_evalue[t]; f[9] = sc.log_pvalue[t];
+        percent = r.percent_kmers_found;
+        bits = sc.bits + sc.bit_offsets[t];
+        n = r.num_kmers;
+    }
 };
 
 // the records [r0, r1) of a search, each after its separator (every record but the very first has one)
@@ -138,6 +267,37 @@ void format_records(const Job &j, uint64_t r0, uint64_t r1, S &s, std::vector<ui
                 const uint32_t c = j.colours[t], f = j.exact ? u : j.counts[t];
                 put_csv_string(s, q, qlen);
                 s.put_c(',');
+                if (j.sc) {
+                    // d_to_csv: the result's values in sorted-key order (__main__.py:41-63): evalue, kmer-presence, length, log_evalue,
+                    // log_pvalue, max_mismatches, max_nident, max_pident, max_score, min_mismatches, min_nident, min_pident, min_score,
+                    // mismatches, nident, num_kmers, num_kmers_found, percent_kmers_found, pident, pvalue, sample_name, score
+                    const ScoredHit h(*j.sc, t);
+                    put_repr(s, h.f[6], false); s.put_c(',');
+                    s.put_c('"'); put_presence(s, h.bits, h.n); s.put_c('"'); s.put_c(',');
+                    put_i64(s, h.i[6]); s.put_c(',');
+                    put_repr(s, h.f[8], false); s.put_c(',');
+                    put_repr(s, h.f[9], false); s.put_c(',');
+                    put_i64(s, h.i[0]); s.put_c(',');
+                    put_i64(s, h.i[3]); s.put_c(',');
+                    put_repr(s, h.f[4], false); s.put_c(',');
+                    put_repr(s, h.f[2], false); s.put_c(',');
+                    put_i64(s, h.i[1]); s.put_c(',');
+                    put_i64(s, h.i[5]); s.put_c(',');
+                    put_repr(s, h.f[5], false); s.put_c(',');
+                    put_repr(s, h.f[1], false); s.put_c(',');
+                    put_i64(s, h.i[2]); s.put_c(',');
+                    put_i64(s, h.i[4]); s.put_c(',');
+                    s.put_u32(u); s.put_c(',');
+                    s.put_u32(f); s.put_c(',');
+                    put_repr(s, h.percent, false); s.put_c(',');
+                    put_repr(s, h.f[3], false); s.put_c(',');
+                    put_repr(s, h.f[7], false); s.put_c(',');
+                    put_csv_string(s, j.names + j.name_offsets[c], j.name_offsets[c + 1] - j.name_offsets[c]); s.put_c(',');
+                    put_repr(s, h.f[0], false);
+                    s.put_c('\r');
+                    if (i + 1 < order.size()) s.put_c('\n');
+                    continue;
+                }
                 s.put_u32(u);
                 s.put_c(',');
                 s.put_u32(f);
@@ -163,13 +323,26 @@ void format_records(const Job &j, uint64_t r0, uint64_t r1, S &s, std::vector<ui
                 const uint64_t t = order[i];
                 const uint32_t c = j.colours[t], f = j.exact ? u : j.counts[t];
                 PUT_LIT(s, "            {\n                \"percent_kmers_found\": ");
-                put_percent(s, f, u);
+                if (j.sc) put_repr(s, j.sc->scores[t].percent_kmers_found, true);
+                else put_percent(s, f, u);
                 PUT_LIT(s, ",\n                \"num_kmers\": ");
                 s.put_u32(u);
                 PUT_LIT(s, ",\n                \"num_kmers_found\": ");
                 s.put_u32(f);
                 PUT_LIT(s, ",\n                \"sample_name\": ");
                 put_json_string(s, j.names + j.name_offsets[c], j.name_offsets[c + 1] - j.name_offsets[c]);
+                if (j.sc) {
+                    static const char *const fkeys[10] = {"score", "min_score", "max_score", "pident", "max_pident", "min_pident", "evalue", "pvalue", "log_evalue", "log_pvalue"};
+                    static const char *const ikeys[7] = {"max_mismatches", "min_mismatches", "mismatches", "max_nident", "nident", "min_nident", "length"};
+                    const ScoredHit h(*j.sc, t);
+                    auto key = [&](const char *k) { PUT_LIT(s, ",\n                \""); s.put(k, strlen(k)); PUT_LIT(s, "\": "); };
+                    for (int x = 0; x < 3; x++) { key(fkeys[x]); put_repr(s, h.f[x], true); }
+                    for (int x = 0; x < 6; x++) { key(ikeys[x]); put_i64(s, h.i[x]); }
+                    for (int x = 3; x < 6; x++) { key(fkeys[x]); put_repr(s, h.f[x], true); }
+                    key(ikeys[6]); put_i64(s, h.i[6]);
+                    for (int x = 6; x < 10; x++) { key(fkeys[x]); put_repr(s, h.f[x], true); }
+                    key("kmer-presence"); s.put_c('"'); put_presence(s, h.bits, h.n); s.put_c('"');
+                }
                 PUT_LIT(s, "\n            }");
                 if (i + 1 < order.size()) PUT_LIT(s, ",\n");
             }
@@ -288,11 +461,23 @@ extern "C" int bigsi_hip_format_results(int format, const char *seqs, const uint
                                         const uint32_t *colours, const uint32_t *counts, const char *names, const uint64_t *name_offsets,
                                         const uint8_t *name_deleted, uint64_t n_names, uint32_t threads, char **out_text, uint64_t *out_bytes)
 {
+    return bigsi_hip_format_results_scored(format, seqs, offsets, n_seqs, threshold_text, citation_text, exact, num_unique, hit_offsets, colours, counts,
+                                           names, name_offsets, name_deleted, n_names, nullptr, threads, out_text, out_bytes);
+}
+
+extern "C" int bigsi_hip_format_results_scored(int format, const char *seqs, const uint64_t *offsets, uint64_t n_seqs, const char *threshold_text,
+                                               const char *citation_text, int exact, const uint32_t *num_unique, const uint64_t *hit_offsets,
+                                               const uint32_t *colours, const uint32_t *counts, const char *names, const uint64_t *name_offsets,
+                                               const uint8_t *name_deleted, uint64_t n_names, const bigsi_hip_scored_text *scored, uint32_t threads,
+                                               char **out_text, uint64_t *out_bytes)
+{
     if (!out_text || !out_bytes || (format != 0 && format != 1)) return fail(BIGSI_ERR_INVALID, "bad argument");
     if (n_seqs && (!seqs || !offsets || !num_unique || !hit_offsets)) return fail(BIGSI_ERR_INVALID, "NULL argument");
     if (format == 0 && (!threshold_text || !citation_text)) return fail(BIGSI_ERR_INVALID, "NULL argument");
     const uint64_t n_hits = n_seqs ? hit_offsets[n_seqs] : 0;
     if (n_hits && (!colours || (!exact && !counts) || (n_names && (!names || !name_offsets || !name_deleted)))) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    if (scored && n_hits && (!scored->scores || !scored->bits || !scored->bit_offsets || !scored->evalue || !scored->pvalue || !scored->log_evalue || !scored->log_pvalue))
+        return fail(BIGSI_ERR_INVALID, "NULL score column");
     char *const caller_buf = *out_text;             // non-NULL: the caller's own buffer of *out_bytes bytes (e.g. the body of a string object)
     const uint64_t caller_cap = *out_bytes;
     if (!caller_buf) *out_bytes = 0;
@@ -302,14 +487,25 @@ extern "C" int bigsi_hip_format_results(int format, const char *seqs, const uint
     if (exact)
         for (uint64_t t = 0; t < n_hits; t++)
             if (colours[t] >= n_names) return fail(BIGSI_ERR_STATE, "colour %u has no sample name: the reference raises KeyError", colours[t]);
+    if (scored)          // score=True on a one-k-mer query that has hits: IndexError in the reference (graph/bigsi.py:47-56, 236)
+        for (uint64_t t = 0; t < n_hits; t++)
+            if (scored->scores[t].num_kmers < 2) return fail(BIGSI_ERR_STATE, "a scored hit of a query with %u k-mer(s): the reference raises", scored->scores[t].num_kmers);
     Job j{format, seqs, offsets, threshold_text, threshold_text ? strlen(threshold_text) : 0, citation_text, citation_text ? strlen(citation_text) : 0,
-          exact != 0, num_unique, hit_offsets, colours, counts, names, name_offsets, name_deleted, n_names};
+          exact != 0, num_unique, hit_offsets, colours, counts, names, name_offsets, name_deleted, n_names, n_hits ? scored : nullptr};
     const uint64_t per = 4096, n_blocks = (n_seqs + per - 1) / per;
     if (threads == 0) threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
     std::vector<uint64_t> at(n_blocks + 1, 0);
+    std::vector<std::string> parts(j.sc ? n_blocks : 0);
     run_blocks(n_blocks, threads, [&](uint64_t b) {
-        CountSink s;
         std::vector<uint64_t> order;
+        if (j.sc) {
+            StringSink s;
+            format_records(j, b * per, std::min(n_seqs, (b + 1) * per), s, order);
+            parts[b].swap(s.t);
+            at[b + 1] = parts[b].size();
+            return;
+        }
+        CountSink s;
         format_records(j, b * per, std::min(n_seqs, (b + 1) * per), s, order);
         at[b + 1] = s.n;
     });
@@ -328,6 +524,7 @@ extern "C" int bigsi_hip_format_results(int format, const char *seqs, const uint
         else memcpy(text, "[]", 2);
     }
     run_blocks(n_blocks, threads, [&](uint64_t b) {
+        if (j.sc) { memcpy(text + at[b], parts[b].data(), parts[b].size()); return; }
         WriteSink s{text + at[b]};
         std::vector<uint64_t> order;
         format_records(j, b * per, std::min(n_seqs, (b + 1) * per), s, order);

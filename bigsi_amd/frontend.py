@@ -67,11 +67,11 @@ def search(bigsi, seq, threshold=1.0, score=False, format="json"):
     return d_to_csv(d) if format == "csv" else json.dumps(d, indent=4)
 
 
-def _bulk_text_native(bigsi, fasta, threshold, format):
-    """The text of an unscored bulk search without a Python object per record: bigsi_hip_fasta_pack -> bigsi_hip_search_stream ->
-    bigsi_hip_format_results (include/bigsi_hip.h, "FRONT-END TEXT").  None when this route does not apply -- text that is not
-    plain ASCII (file or sample names), a multi-GPU index, a record on which the reference raises: the per-record route below
-    then does what it always did."""
+def _bulk_text_native(bigsi, fasta, threshold, format, score=False):
+    """The text of a bulk search without a Python object per record: bigsi_hip_fasta_pack -> bigsi_hip_search_stream(_scored) ->
+    bigsi_hip_format_results(_scored) (include/bigsi_hip.h, "FRONT-END TEXT").  None when this route does not apply -- text that is
+    not plain ASCII (file or sample names), a multi-GPU index, a record on which the reference raises, more scored hits than one
+    call should hold: the per-record route below then does what it always did."""
     import numpy as np
     from . import _lib
     from .graph.metadata import DELETION_SPECIAL_SAMPLE_NAME
@@ -83,10 +83,25 @@ def _bulk_text_native(bigsi, fasta, threshold, format):
     if packed is None:
         return None
     blob, soff = packed
+    scored = None
     with bigsi._device_lock():
-        nk, nu, off, col, cnt = st.search_many_packed(blob, soff, bigsi.kmer_size, threshold)
+        if score:
+            from .graph.bigsi import SCORE_SLICE_CHARS
+            from .scoring import score_columns
+            from .storage.hip_hbm import TooManyHits
+            try:
+                nk, nu, off, col, cnt, bits, boff, rec = st.search_many_scored(None, bigsi.kmer_size, threshold, max_bits=SCORE_SLICE_CHARS // 8, packed=(blob, soff))
+            except TooManyHits:
+                return None
+        else:
+            nk, nu, off, col, cnt = st.search_many_packed(blob, soff, bigsi.kmer_size, threshold)
     if len(nu) and int(nu.min()) == 0:
         return None
+    if score:
+        if len(rec) and int(rec["num_kmers"].min()) < 2:
+            return None                       # (a scored hit of a one-k-mer query: IndexError in the reference, in record order)
+        c_ = score_columns(rec, bigsi.scorer.DB_SIZE, as_arrays=True)          # evalue, pvalue, log_evalue, log_pvalue: numpy's exp / log10
+        scored = (rec, bits, boff, c_[13], c_[14], c_[15], c_[16], 31)
     ns = bigsi.num_samples
     used = np.unique(col)
     used = used[used < ns].tolist()
@@ -103,7 +118,7 @@ def _bulk_text_native(bigsi, fasta, threshold, format):
         deleted[[c for c, nm in zip(used, names) if nm == DELETION_SPECIAL_SAMPLE_NAME]] = 1
     try:
         return _lib.format_results(1 if format == "csv" else 0, blob, soff, threshold, json.dumps(CITATION), nu, off, col, cnt, b"".join(enc) + b"\0",
-                                   name_off, deleted)
+                                   name_off, deleted, scored=scored)
     except _lib.BigsiHipError as e:
         if e.code == _lib.ERR_STATE:
             return None
@@ -113,8 +128,8 @@ def _bulk_text_native(bigsi, fasta, threshold, format):
 def bulk_search(bigsi, fasta, threshold=1.0, score=False, format="json", stream=False, out=None):
     """All records of a FASTA file in one device batch.  Returns the combined text (stream=False) or prints one record
     per line as the reference's streaming branch does and returns None."""
-    if not stream and not score and hasattr(bigsi, "_device_lock"):
-        text = _bulk_text_native(bigsi, fasta, threshold, format)
+    if not stream and hasattr(bigsi, "_device_lock"):
+        text = _bulk_text_native(bigsi, fasta, threshold, format, score)
         if text is not None:
             return text
     seqs = [s for _, s in read_fasta(fasta)]

@@ -551,6 +551,9 @@ class HipHbmStorage(BaseStorage):
         if self.res.is_group:
             raise BigsiHipError(_lib.ERR_STATE, "search_many_scored is not available on a multi-GPU index")
         blob, soff = packed if packed is not None else _lib.pack_seqs(seqs)
+        if not isinstance(blob, bytes):
+            import ctypes as C
+            blob = C.cast(_lib.ptr(blob), C.c_char_p)          # (a uint8 array, e.g. what bigsi_hip_fasta_pack left)
         cap, bcap = max(self._search_cap, 1 << 12), max(self._bits_cap, 1 << 16)
         need = np.zeros(1, np.uint64)
         while True:

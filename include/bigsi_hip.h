@@ -405,6 +405,26 @@ int bigsi_hip_format_results(int format, const char *seqs, const uint64_t *offse
                              const char *citation_text, int exact, const uint32_t *num_unique, const uint64_t *hit_offsets,
                              const uint32_t *colours, const uint32_t *counts, const char *names, const uint64_t *name_offsets,
                              const uint8_t *name_deleted, uint64_t n_names, uint32_t threads, char **out_text, uint64_t *out_bytes);
+/* The same for score=True (bulk_search --score): every result carries the 17 fields of Scorer.score and "kmer-presence"
+ * (bigsi/scoring/score.py:96-121, graph/bigsi.py:232-239) after the four above, in the reference's key order (CSV: sorted keys).
+ * `scored` (per hit, in the order of colours / counts): K6's records and presence bits as bigsi_hip_batch_score_hits /
+ * bigsi_hip_search_stream_scored return them, and the four closed-form columns the caller's own math library computes (score.py:
+ * 125-151: no two libm agree bit for bit on exp / log10); nident / pident / length are derived here.  Floats are written as
+ * Python's repr() writes them (shortest round-trip decimal).  BIGSI_ERR_STATE also for a scored hit of a one-k-mer query (IndexError
+ * in the reference).  scored == NULL: bigsi_hip_format_results. */
+typedef struct {
+    const bigsi_hip_hit_score *scores;
+    const uint8_t *bits;
+    const uint64_t *bit_offsets;
+    const double *evalue, *pvalue, *log_evalue, *log_pvalue;
+    uint32_t k; /* length = num_kmers + k - 1 */
+    uint32_t reserved;
+} bigsi_hip_scored_text;
+int bigsi_hip_format_results_scored(int format, const char *seqs, const uint64_t *offsets, uint64_t n_seqs, const char *threshold_text,
+                                    const char *citation_text, int exact, const uint32_t *num_unique, const uint64_t *hit_offsets,
+                                    const uint32_t *colours, const uint32_t *counts, const char *names, const uint64_t *name_offsets,
+                                    const uint8_t *name_deleted, uint64_t n_names, const bigsi_hip_scored_text *scored, uint32_t threads,
+                                    char **out_text, uint64_t *out_bytes);
 void bigsi_hip_free_text(char *text);
 
 #ifdef __cplusplus

@@ -97,6 +97,24 @@ for tag, reads in (("no_hits", rand_reads), ("8_hits_per_read", hit_reads)):
             text = _lib.format_results(fmt_, blob_, soff_, 1.0, json.dumps(frontend.CITATION), nu_, off_, col_, cnt_, names_, name_off_, np.zeros(n_cols, np.uint8))
             stages[key] = (time.perf_counter() - t0) * 1e3
         rec["native_route_stages"] = stages
+        if tag != "no_hits":
+            # score=True as text: 200 k reads with 8 scored hits each through the native route; the per-record route on 2000 for scale
+            sfn = fasta_of(reads[:200_000])
+            for fmt in ("json", "csv"):
+                t0 = time.perf_counter()
+                text = frontend.bulk_search(b, sfn, 1.0, True, fmt)
+                dt = time.perf_counter() - t0
+                rec["bulk_search_scored_%s" % fmt] = {"reads_per_s": 200_000 / dt, "scored_hits_per_s": 1_600_000 / dt, "text_MB": len(text) / 1e6, "text_MBps": len(text) / 1e6 / dt}
+            os.remove(sfn)
+            sfn = fasta_of(reads[:2000])
+            native = frontend._bulk_text_native
+            frontend._bulk_text_native = lambda *a: None
+            t0 = time.perf_counter()
+            slow = frontend.bulk_search(b, sfn, 1.0, True, "json")
+            rec["bulk_search_scored_json_per_record_route"] = {"reads_per_s": 2000 / (time.perf_counter() - t0)}
+            frontend._bulk_text_native = native
+            assert frontend.bulk_search(b, sfn, 1.0, True, "json") == slow
+            os.remove(sfn)
         # the text equals the reference's (json.dumps of the record list, indent=4) on a sample of the file
         small = fasta_of(reads[:300])
         want = json.dumps([frontend.search_record(s, 1.0, r) for s, r in zip(reads[:300], b.search_batch(reads[:300], 1.0))], indent=4)

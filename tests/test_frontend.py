@@ -125,7 +125,8 @@ def test_frontend_end_to_end_on_device(tmp_path):
 
 @pytest.mark.gpu
 def test_bulk_search_native_text_route_is_the_per_record_routes_text(tmp_path, monkeypatch):
-    """bulk_search's unscored text comes from bigsi_hip_fasta_pack -> bigsi_hip_search_stream -> bigsi_hip_format_results; forcing
+    """bulk_search's text (score=True too: bigsi_hip_search_stream_scored -> bigsi_hip_format_results_scored) comes from
+    bigsi_hip_fasta_pack -> bigsi_hip_search_stream -> bigsi_hip_format_results; forcing
     the per-record Python route on the same file must give the same characters: 3000 reads of which every tenth was added to a few
     samples (one of them deleted afterwards, one named with characters JSON and CSV escape), exact and thresholded, both formats.
     A file with a record the reference raises on, and a non-ASCII file, fall through to the per-record route."""
@@ -154,14 +155,16 @@ def test_bulk_search_native_text_route_is_the_per_record_routes_text(tmp_path, m
         real = frontend._bulk_text_native
         monkeypatch.setattr(frontend, "_bulk_text_native", lambda *a: taken.append(real(*a)) or taken[-1])
         for fmt in ("json", "csv"):
-            for thr in (1.0, 0.6, 0.0):
+            for thr, score in ((1.0, False), (0.6, False), (0.0, False), (1.0, True), (0.6, True), (0.0, True)):
                 taken.clear()
-                got = frontend.bulk_search(b, str(fa), thr, False, fmt)
+                got = frontend.bulk_search(b, str(fa), thr, score, fmt)
                 assert taken and taken[0] is not None and got is taken[0]
                 monkeypatch.setattr(frontend, "_bulk_text_native", lambda *a: None)
-                want = frontend.bulk_search(b, str(fa), thr, False, fmt)
+                want = frontend.bulk_search(b, str(fa), thr, score, fmt)
                 monkeypatch.setattr(frontend, "_bulk_text_native", lambda *a: taken.append(real(*a)) or taken[-1])
-                assert got == want, (fmt, thr)
+                assert got == want, (fmt, thr, score)
+                if score and fmt == "json" and thr == 0.6:
+                    assert sum(len(x) == 22 for r in json.loads(got) for x in r["results"]) >= 300
                 if fmt == "json" and thr == 1.0:
                     recs = json.loads(got)
                     assert len(recs) == len(reads) and sum(len(r["results"]) for r in recs) >= 300

@@ -197,3 +197,117 @@ def test_format_results_into_the_callers_buffer():
             assert buf.raw[cap:cap + 1] == b"\xff"                       # nothing written beyond the buffer
         got = _lib.format_results(fmt, blob, soff, 0.5, '"c"', nu, off, col, cnt, names, name_off, deleted, threads=1)
         assert got == want.decode()
+
+
+def _scored_inputs(rng, n, threshold):
+    """synthetic arrays of a score=True search: hit lists, K6 records, presence bits, the closed-form columns"""
+    from bigsi_amd.scoring import HIT_SCORE_DTYPE, score_columns
+    nk = rng.integers(2, 150, size=n).astype(np.uint32)
+    nu = np.minimum(nk, rng.integers(1, 150, size=n)).astype(np.uint32)
+    n_hits = np.where(rng.random(n) < 0.5, 0, rng.integers(1, 6, size=n)) if n else np.zeros(0, np.int64)
+    off = np.zeros(n + 1, np.uint64)
+    np.cumsum(n_hits, out=off[1:])
+    total = int(off[-1])
+    col, cnt = np.zeros(total, np.uint32), np.zeros(total, np.uint32)
+    for i in range(n):
+        lo, hi = int(off[i]), int(off[i + 1])
+        col[lo:hi] = np.sort(rng.choice(20, size=hi - lo, replace=False))
+        cnt[lo:hi] = rng.integers(0, int(nu[i]) + 1, size=hi - lo) if threshold < 1 else nu[i]
+    per_hit = np.repeat(nk.astype(np.int64), n_hits)
+    boff = np.zeros(total + 1, np.uint64)
+    np.cumsum((per_hit + 63) // 64 * 8, out=boff[1:])
+    bits = rng.integers(0, 256, size=int(boff[-1]), dtype=np.uint8)
+    rec = np.zeros(total, HIT_SCORE_DTYPE)
+    rec["num_kmers"] = per_hit
+    for f in ("score", "min_score", "max_score"):
+        rec[f] = np.round(rng.random(total) * 300 - 40, 2)
+    rec["percent_kmers_found"] = np.round(rng.random(total) * 100, 2)
+    for f in ("max_mismatches", "min_mismatches", "mismatches"):
+        rec[f] = rng.integers(0, 25, size=total)
+    cols = score_columns(rec, 20, as_arrays=True)
+    return nk, nu, off, col, cnt, bits, boff, rec, cols
+
+
+@pytest.mark.parametrize("fmt", ["json", "csv"])
+@pytest.mark.parametrize("threshold", [1.0, 0.4])
+@pytest.mark.parametrize("n", [0, 1, 6, 5000])
+def test_scored_text_is_the_python_routes_text(fmt, threshold, n):
+    """bigsi_hip_format_results_scored against json.dumps / d_to_csv of the dicts the Python route builds from the same arrays:
+    the 22 keys in the reference's order (CSV: sorted), floats as repr() writes them, presence strings from the bits."""
+    from bigsi_amd.scoring import SCORE_KEYS, unpack_presence
+    rng = np.random.default_rng(3 * n + int(10 * threshold))
+    alphabet = list("ACGT")
+    seqs = ["".join(rng.choice(alphabet, size=int(rng.integers(1, 30)))) for _ in range(n)]
+    nk, nu, off, col, cnt, bits, boff, rec, cols = _scored_inputs(rng, n, threshold)
+    n_names = 17                                        # colours 17..19 have no name (dropped on the thresholded route)
+    if threshold == 1.0:
+        col[:] = col % n_names
+        for i in range(n):                              # (keep each sequence's colours distinct and ascending)
+            lo, hi = int(off[i]), int(off[i + 1])
+            col[lo:hi] = np.sort(rng.choice(n_names, size=hi - lo, replace=False))
+    names = ["s%d" % c if c % 4 else 'n"%d,' % c for c in range(n_names)]
+    deleted = np.zeros(n_names, np.uint8)
+    deleted[2] = 1
+    text_all = unpack_presence(bits, boff) if len(boff) > 1 else ""
+    lists = [c.tolist() for c in cols]
+    recs = []
+    for i, s in enumerate(seqs):
+        ts = [t for t in range(int(off[i]), int(off[i + 1])) if col[t] < n_names]
+        if threshold < 1:
+            ts = sorted(ts, key=lambda t: -int(cnt[t]))
+        r = []
+        for t in ts:
+            if deleted[col[t]]:
+                continue
+            f = int(nu[i]) if threshold == 1.0 else int(cnt[t])
+            d = {"percent_kmers_found": float(rec["percent_kmers_found"][t]), "num_kmers": int(nu[i]), "num_kmers_found": f, "sample_name": names[col[t]]}
+            d.update({k_: lists[j][t] for j, k_ in enumerate(SCORE_KEYS)})
+            d["kmer-presence"] = text_all[8 * int(boff[t]): 8 * int(boff[t]) + int(rec["num_kmers"][t])]
+            r.append(d)
+        recs.append(frontend.search_record(s, threshold, r))
+    want = json.dumps(recs, indent=4) if fmt == "json" else "\n".join(frontend.d_to_csv(d, False, False) if d["results"] else "" for d in recs)
+    blob, soff = _lib.pack_seqs(seqs) if n else (b"", np.zeros(1, np.uint64))
+    enc = [nm.encode() for nm in names]
+    name_off = np.zeros(n_names + 1, np.uint64)
+    np.cumsum([len(e) for e in enc], out=name_off[1:])
+    scored = (rec, bits if len(bits) else np.zeros(8, np.uint8), boff, cols[13], cols[14], cols[15], cols[16], 31)
+    for threads in (1, 0):
+        got = _lib.format_results(1 if fmt == "csv" else 0, blob, soff, threshold, json.dumps(frontend.CITATION), nu, off, col, cnt, b"".join(enc) + b"\0",
+                                  name_off, deleted, threads=threads, scored=scored)
+        assert got == want
+
+
+def test_scored_text_writes_floats_as_pythons_repr():
+    """repr() of 60 000 doubles -- random bit patterns, every power of ten from 1e-30 to 1e30 and its neighbours, the 1e16 / 1e-4
+    switches to exponent form, integers, two-decimal values, subnormals, zeros, infinities, NaN -- through the evalue column of one
+    scored hit per record (CSV: inf / nan; JSON: Infinity / NaN as json.dumps writes them)."""
+    from bigsi_amd.scoring import HIT_SCORE_DTYPE
+    rng = np.random.default_rng(8)
+    xs = rng.integers(0, 2 ** 63, size=40000, dtype=np.uint64).view(np.float64).tolist()
+    xs += (rng.random(6000) * 10.0 ** rng.integers(-20, 20, size=6000)).tolist()
+    xs += np.round(rng.random(4000) * 1000 - 500, 2).tolist()
+    for e in range(-30, 31):
+        p = float("1e%d" % e)
+        xs += [p, np.nextafter(p, 0), np.nextafter(p, np.inf), -p, 3 * p, p / 3]
+    xs += [0.0001, 0.00001, 0.00012345, 9999999999999998.0, 1e16, 1.2345e16, 123456789012345678.0, 1.0, -1.0, 100.0, 0.1, 0.2, 0.3, 1 / 3, 2 / 3, 5e-324,
+           2.2250738585072014e-308, 1.7976931348623157e308, 0.0, -0.0, float("inf"), float("-inf"), float("nan"), 1e22, 1e23, 4.35, 0.285, 2.675]
+    xs = [float(x) for x in xs if x == x and abs(x) != float("inf")] + [float("inf"), float("-inf"), float("nan")]
+    n = len(xs)
+    rec = np.zeros(n, HIT_SCORE_DTYPE)
+    rec["num_kmers"] = 8
+    rec["score"] = 1.0
+    off = np.arange(n + 1, dtype=np.uint64)
+    col, cnt, nu = np.zeros(n, np.uint32), np.full(n, 8, np.uint32), np.full(n, 8, np.uint32)
+    bits, boff = np.zeros(8 * n, np.uint8), np.arange(n + 1, dtype=np.uint64) * 8
+    blob, soff = _lib.pack_seqs(["A"] * n)
+    ev = np.array(xs, np.float64)
+    z = np.zeros(n, np.float64)
+    scored = (rec, bits, boff, ev, z, z, z, 31)
+    text = _lib.format_results(1, blob, soff, 1.0, '"c"', nu, off, col, cnt, b"s\0", np.array([0, 1], np.uint64), np.zeros(1, np.uint8), scored=scored)
+    rows = text.split("\n")
+    assert len(rows) == n
+    for x, row in zip(xs, rows):
+        assert row.split(",")[1] == repr(x), (x.hex() if x == x else x, row.split(",")[1])
+    text = _lib.format_results(0, blob[-3:], soff[:4], 1.0, '"c"', nu[-3:], off[:4], col[-3:], cnt[-3:], b"s\0", np.array([0, 1], np.uint64), np.zeros(1, np.uint8),
+                               scored=(rec[-3:], bits[-24:], boff[:4], ev[-3:], z[-3:], z[-3:], z[-3:], 31))
+    assert [r_["results"][0]["evalue"] for r_ in json.loads(text)][:2] == [float("inf"), float("-inf")] and '"evalue": NaN' in text
