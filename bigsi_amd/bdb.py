@@ -131,6 +131,8 @@ def import_index(path, dst, block_bytes=64 << 20):
         rb = max((n + 7) // 8, 1)
         per = max(1, block_bytes // rb)
         ids, blobs = [], []
+        from .migrate import RowUploader
+        up = RowUploader(dst.res)          # block i travels to the device while the pages of block i + 1 are parsed
 
         def flush():
             if ids:
@@ -140,7 +142,7 @@ def import_index(path, dst, block_bytes=64 << 20):
                     block[j, : a.size] = a
                 if n % 8:
                     block[:, rb - 1] &= (0xFF << (8 - n % 8)) & 0xFF
-                dst.res.put_rows(np.array(ids, dtype=np.uint64), block)
+                up.put(np.array(ids, dtype=np.uint64), block)
                 del ids[:], blobs[:]
 
         for k, v in db.items(want_key=lambda k: bool(row_key.match(k))):
@@ -150,7 +152,10 @@ def import_index(path, dst, block_bytes=64 << 20):
                 blobs.append(v)
                 if len(ids) >= per:
                     flush()
-        flush()
+        try:
+            flush()
+        finally:
+            up.close()
         dst.set_integer("number_of_cols", n)
         for k, v in small.items():
             if k not in (b"number_of_rows:int", b"number_of_cols:int", b"ksi:bloomfilter_size:int", b"ksi:num_hashes:int"):

@@ -10,7 +10,35 @@ import numpy as np
 INDEX_INTS = ("number_of_rows", "number_of_cols", "ksi:bloomfilter_size", "ksi:num_hashes")
 
 
-def migrate_index(src, dst, block_rows=None):
+class RowUploader(object):
+    """Two-deep upload of row blocks: put(ids, block) hands the block to a worker thread (the copy to the device holds no GIL) and
+    returns once the block before it is on the device, so that the caller assembles block i + 1 -- reading and parsing records of the
+    source store, which is Python work -- while block i travels.  Used by migrate_index and bdb.import_index."""
+
+    def __init__(self, res, overlap=True):
+        from concurrent.futures import ThreadPoolExecutor
+        self.res, self.pending = res, None
+        self.pool = ThreadPoolExecutor(1) if overlap else None
+
+    def put(self, ids, block):
+        if self.pool is None:
+            self.res.put_rows(ids, block)
+            return
+        if self.pending is not None:
+            self.pending.result()
+        self.pending = self.pool.submit(self.res.put_rows, ids, block)
+
+    def close(self):
+        try:
+            if self.pending is not None:
+                self.pending.result()
+        finally:
+            self.pending = None
+            if self.pool is not None:
+                self.pool.shutdown()
+
+
+def migrate_index(src, dst, block_rows=None, overlap=True):
     """Returns (num_rows, num_cols, num_samples)."""
     m = src.get_integer("number_of_rows")
     n = src.get_integer("number_of_cols")
@@ -20,18 +48,12 @@ def migrate_index(src, dst, block_rows=None):
     dst.set_integer("number_of_rows", m)
     rb = (n + 7) // 8
     step = block_rows or max(1, (64 << 20) // max(rb, 1))
-    for r0 in range(0, m, step):
-        ids = list(range(r0, min(m, r0 + step)))
-        keys = [src.convert_key_to_bytes(src.convert_to_bitarray_key(i)) if hasattr(src, "convert_key_to_bytes")
-                else ("%d:bitarray" % i).encode() for i in ids]
-        raws = src.batch_get(keys)
-        block = np.zeros((len(ids), max(rb, 1)), dtype=np.uint8)
-        for j, raw in enumerate(raws):       # rows may be stored shorter or longer than ceil(n/8): pad / trim
-            a = np.frombuffer(bytes(raw), dtype=np.uint8)[:rb]
-            block[j, : a.size] = a
-        if n % 8:
-            block[:, rb - 1] &= (0xFF << (8 - n % 8)) & 0xFF      # columns beyond number_of_cols are not part of the index
-        dst.set_rows_packed(r0, block)
+    up = RowUploader(dst.res, overlap) if hasattr(dst, "res") else None
+    try:
+        _copy_rows(src, dst, up, m, n, rb, step)
+    finally:
+        if up is not None:
+            up.close()
     dst.set_integer("number_of_cols", n)
     try:
         ns = src.get_integer("metadata:colour_count")
@@ -48,3 +70,21 @@ def migrate_index(src, dst, block_rows=None):
         dst.set_integer("metadata:colour_count", ns)
     dst.sync()
     return m, n, ns
+
+
+def _copy_rows(src, dst, up, m, n, rb, step):
+    for r0 in range(0, m, step):
+        ids = list(range(r0, min(m, r0 + step)))
+        keys = [src.convert_key_to_bytes(src.convert_to_bitarray_key(i)) if hasattr(src, "convert_key_to_bytes")
+                else ("%d:bitarray" % i).encode() for i in ids]
+        raws = src.batch_get(keys)
+        block = np.zeros((len(ids), max(rb, 1)), dtype=np.uint8)
+        for j, raw in enumerate(raws):       # rows may be stored shorter or longer than ceil(n/8): pad / trim
+            a = np.frombuffer(bytes(raw), dtype=np.uint8)[:rb]
+            block[j, : a.size] = a
+        if n % 8:
+            block[:, rb - 1] &= (0xFF << (8 - n % 8)) & 0xFF      # columns beyond number_of_cols are not part of the index
+        if up is not None:
+            up.put(np.arange(r0, r0 + len(ids), dtype=np.uint64), block)
+        else:
+            dst.set_rows_packed(r0, block)
