@@ -2337,6 +2337,11 @@ static int presence_begin(bigsi_hip_batch *b, const uint64_t *hit_offsets, const
     std::vector<uint64_t> &hit_pos0 = job.hit_pos0;
     std::vector<PresencePair> pairs;
     std::vector<PresenceWave> waves;          // (k_presence_bits: a wavefront = up to 64 pairs of one query)
+    std::vector<PresenceWave> few;            // (k_presence_bits_sparse: queries with few pairs, one entry each: lanes = k-mers there)
+    // (tuning builds: queries with at most this many pairs go to k_presence_bits_sparse.  Interleaved A/B on the C5 shard, 259 hits in
+    // 256 queries per batch: 245.5 -> 239.5 M lookups/s -- the kernel that wastes no lanes issues its requests faster and takes more
+    // from the row-AND kernel it runs beside (0.974 -> 0.997 ms) than the one-live-lane form that trickles them.  Off.)
+    static const int sparse_max = env_int("BIGSI_HIP_K5_SPARSE_MAX", 0);
     hit_seq.resize(n_hits); hit_q.resize(n_hits); perm.resize(n_hits); hit_pos0.resize(n_hits);
     pairs.clear();
     for (uint64_t t = 0; t < n_hits; t++) perm[t] = (uint32_t)t;
@@ -2378,7 +2383,8 @@ static int presence_begin(bigsi_hip_batch *b, const uint64_t *hit_offsets, const
             perm[lo + r] = src;
             if ((uint64_t)(c >> 6) != last_word) { words++; last_word = c >> 6; }
         }
-        for (size_t f = first_pair; f < pairs.size(); f += 64) waves.push_back(PresenceWave{(uint32_t)f, (uint32_t)std::min<size_t>(64, pairs.size() - f)});
+        if (sparse_max > 0 && pairs.size() - first_pair <= (size_t)sparse_max) few.push_back(PresenceWave{(uint32_t)first_pair, (uint32_t)(pairs.size() - first_pair)});
+        else for (size_t f = first_pair; f < pairs.size(); f += 64) waves.push_back(PresenceWave{(uint32_t)f, (uint32_t)std::min<size_t>(64, pairs.size() - f)});
         max_u = std::max(max_u, b->h_num_unique[q]);
         max_n = std::max(max_n, b->h_num_kmers[q]);
         alg += (uint64_t)b->h_num_unique[q] * b->run_h * words * 8 +
@@ -2400,7 +2406,8 @@ static int presence_begin(bigsi_hip_batch *b, const uint64_t *hit_offsets, const
     const size_t o_str = 0, o_seq = round_up(o_str + (n_hits + 1) * 8, 256);
     const size_t o_perm = round_up(o_seq + n_hits * 4, 256), o_pos0 = round_up(o_perm + n_hits * 4, 256), o_pairs = round_up(o_pos0 + n_hits * 8, 256);
     const size_t o_waves = round_up(o_pairs + pairs.size() * sizeof(PresencePair), 256);
-    const size_t o_q = round_up(o_waves + waves.size() * sizeof(PresenceWave), 256), o_hoff = round_up(o_q + n_hits * 4, 256);
+    const size_t o_few = o_waves + waves.size() * sizeof(PresenceWave);
+    const size_t o_q = round_up(o_few + few.size() * sizeof(PresenceWave), 256), o_hoff = round_up(o_q + n_hits * 4, 256);
     // (K6) per rank: k-mers the hit found, unique k-mers of its sequence
     const size_t o_found = round_up(o_hoff + (nq + 1) * 8ull, 256), o_uniq = round_up(o_found + (packed ? n_hits * 4 : 0), 256);
     const size_t in_bytes = packed ? o_uniq + n_hits * 4 : o_hoff + (nq + 1) * 8ull;
@@ -2414,6 +2421,7 @@ static int presence_begin(bigsi_hip_batch *b, const uint64_t *hit_offsets, const
     memcpy(stage + o_pos0, hit_pos0.data(), n_hits * 8);
     memcpy(stage + o_pairs, pairs.data(), pairs.size() * sizeof(PresencePair));
     memcpy(stage + o_waves, waves.data(), waves.size() * sizeof(PresenceWave));
+    memcpy(stage + o_few, few.data(), few.size() * sizeof(PresenceWave));
     memcpy(stage + o_q, hit_q.data(), n_hits * 4);
     for (uint32_t q = 0; q <= nq; q++) reinterpret_cast<uint64_t *>(stage + o_hoff)[q] = hit_offsets[q] - h0;
     if (packed)
@@ -2458,7 +2466,7 @@ static int presence_begin(bigsi_hip_batch *b, const uint64_t *hit_offsets, const
 #define BIGSI_PRESENCE(H)                                                                          \
     if (k5_waves == 4) hipLaunchKernelGGL((k_presence_bits<H COMMA 4>), BIGSI_PRESENCE_ARGS);        \
     else hipLaunchKernelGGL((k_presence_bits<H COMMA 2>), BIGSI_PRESENCE_ARGS)
-    switch (ix->h) {
+    if (!waves.empty()) switch (ix->h) {
     case 1: BIGSI_PRESENCE(1); break;
     case 2: BIGSI_PRESENCE(2); break;
     case 3: BIGSI_PRESENCE(3); break;
@@ -2469,6 +2477,25 @@ static int presence_begin(bigsi_hip_batch *b, const uint64_t *hit_offsets, const
 #undef BIGSI_PRESENCE
 #undef BIGSI_PRESENCE_ARGS
 #undef COMMA
+#ifdef BIGSI_HIP_TUNING
+    if (!few.empty()) {
+        // queries with few pairs: lanes = unique k-mers (k_presence_bits_sparse)
+        const dim3 grid_s((unsigned)few.size(), (unsigned)ceil_div(std::max<uint32_t>(max_u, 1), kBlock), 1);
+#define BIGSI_PRESENCE_SPARSE(H)                                                                                                        \
+    hipLaunchKernelGGL((k_presence_bits_sparse<H>), grid_s, dim3(kBlock), 0, ps, ix->d_index, ix->stride_words, b->rows.as<uint64_t>(),   \
+                       b->d_pos_off.as<uint64_t>(), b->num_unique.as<uint32_t>(), ix->h, (const PresenceWave *)(din + o_few),             \
+                       (const PresencePair *)(din + o_pairs), b->pres_bits.as<uint16_t>(), n_chunks)
+        switch (ix->h) {
+        case 1: BIGSI_PRESENCE_SPARSE(1); break;
+        case 2: BIGSI_PRESENCE_SPARSE(2); break;
+        case 3: BIGSI_PRESENCE_SPARSE(3); break;
+        case 4: BIGSI_PRESENCE_SPARSE(4); break;
+        case 5: BIGSI_PRESENCE_SPARSE(5); break;
+        default: BIGSI_PRESENCE_SPARSE(0); break;
+        }
+#undef BIGSI_PRESENCE_SPARSE
+    }
+#endif
     HIP_TRY(hipGetLastError());
     if (packed) {
         // K6: position-ordered bits of every hit and its score record (written at the hit's place in the caller's order)

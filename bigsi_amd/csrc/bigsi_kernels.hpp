@@ -1861,6 +1861,66 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_presence_bits(
     }
 }
 
+// The same bits for queries with FEW pairs (a thresholded search whose queries have a hit or two each -- BASELINE configs[4]: 259 hits in
+// 256 queries): there a wavefront of the kernel above has one live lane, and 259 hits cost 15 800 wavefronts of 48 loads each.
+// Here lane = unique k-mer: a wavefront takes 64 consecutive k-mers of one query (their row ids: coalesced loads), and for every
+// pair of the query ANDs the h rows' 16-byte word pair of its k-mer; a hit's 64 presence bits are one ballot, stored as four
+// 16-bit chunks.  Same layout out (presence_bits_at), h loads per (k-mer, pair) as before, a sixteenth of the instructions.
+template <int H>
+__global__ __launch_bounds__(kBlock) void k_presence_bits_sparse(
+    const uint64_t *__restrict__ index, uint64_t stride_words, const uint64_t *__restrict__ rows, const uint64_t *__restrict__ pos_off,
+    const uint32_t *__restrict__ num_unique, uint32_t h_rt, const PresenceWave *__restrict__ queries /* one per query: all its pairs */,
+    const PresencePair *__restrict__ pairs, uint16_t *__restrict__ bits, uint32_t bits_stride)
+{
+    constexpr int HH = H > 0 ? H : 1;
+    const uint32_t h = H > 0 ? (uint32_t)H : h_rt;
+    const uint32_t jb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.y * (kBlock / 64) + (threadIdx.x >> 6))), lane = threadIdx.x & 63u;
+    const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)queries[blockIdx.x].first);
+    const uint32_t count = (uint32_t)__builtin_amdgcn_readfirstlane((int)queries[blockIdx.x].count);
+    const uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane((int)pairs[first].q);
+    const uint32_t u = num_unique[q];
+    if (jb * 64u >= u) return;
+    const uint32_t j = jb * 64u + lane;
+    const bool live = j < u;
+    const uint64_t *qrows = rows + pos_off[q] * h;
+    uint64_t r[HH];
+    if (H > 0) {
+#pragma unroll
+        for (int sidx = 0; sidx < HH; sidx++) r[sidx] = live ? qrows[(uint64_t)j * H + sidx] : 0ull;
+    }
+    const u64x2 zero = {0ull, 0ull};
+    for (uint32_t p = 0; p < count; p++) {
+        const uint32_t wpair = (uint32_t)__builtin_amdgcn_readfirstlane((int)pairs[first + p].wpair);
+        uint32_t rank = (uint32_t)__builtin_amdgcn_readfirstlane((int)pairs[first + p].base);
+        const uint64_t mask_lo = pairs[first + p].mask_lo, mask_hi = pairs[first + p].mask_hi;
+        const uint32_t woff = wpair * 2u;
+        u64x2 v = zero;
+        if (live) {
+            if (H > 0) {
+                v = load_row_seg(index, r[0], stride_words, woff);
+#pragma unroll
+                for (int sidx = 1; sidx < HH; sidx++) v &= load_row_seg(index, r[sidx], stride_words, woff);
+            } else {
+                v = load_row_seg(index, qrows[(uint64_t)j * h], stride_words, woff);
+                for (uint32_t sidx = 1; sidx < h; sidx++) v &= load_row_seg(index, qrows[(uint64_t)j * h + sidx], stride_words, woff);
+            }
+        }
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            uint64_t m = by_column(half ? mask_hi : mask_lo);
+            const uint64_t word = half ? v.y : v.x;
+            while (m) {
+                const uint32_t c = (uint32_t)__builtin_ctzll(m);
+                m &= m - 1;
+                const uint64_t ball = __ballot(((word >> bit_of_col(c)) & 1ull) != 0);      // bit L: k-mer 64 * jb + L is present in this hit's sample
+                const uint32_t chunk = 4u * jb + lane;
+                if (lane < 4u && chunk * 16u < u) bits[presence_bits_at(rank, chunk, bits_stride)] = (uint16_t)(ball >> (16u * lane));
+                rank++;
+            }
+        }
+    }
+}
+
 // strings: 16 characters per thread, one 16-byte store (every string starts at a multiple of 16 bytes);
 // character i of hit t = '0' + bit (unique k-mer of position i) of the hit's presence bits.  Thread -> (hit, 16-character
 // piece), `pieces` (a power of two) pieces per hit, flattened over the grid.  A thread needs the position -> unique k-mer map
