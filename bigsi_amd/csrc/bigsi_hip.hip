@@ -88,9 +88,18 @@ static int score_stream(bigsi_hip_index *ix, hipStream_t *out)
     *out = ix->stream;
     if (ix->stream != ix->own_stream) return BIGSI_OK;       // the caller's own stream: everything stays on it
     if (!ix->sc_stream) {
-        int least = 0, greatest = 0;
-        HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        HIP_TRY(hipStreamCreateWithPriority(&ix->sc_stream, hipStreamNonBlocking, greatest));
+        // (tuning builds: BIGSI_HIP_SCORE_CUS = n > 0 confines the stream to n compute units instead -- a CU-masked stream has no priority)
+        static const int score_cus = env_int("BIGSI_HIP_SCORE_CUS", 0);
+        if (score_cus > 0) {
+            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            static const int stride = std::max(env_int("BIGSI_HIP_SCORE_CU_STRIDE", 1), 1);
+            for (int i = 0, c = 0; i < score_cus && c < 256; i++, c += stride) mask[c / 32] |= 1u << (c % 32);
+            HIP_TRY(hipExtStreamCreateWithCUMask(&ix->sc_stream, 8, mask));
+        } else {
+            int least = 0, greatest = 0;
+            HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            HIP_TRY(hipStreamCreateWithPriority(&ix->sc_stream, hipStreamNonBlocking, greatest));
+        }
     }
     *out = ix->sc_stream;
     return BIGSI_OK;
