@@ -2691,7 +2691,7 @@ int bigsi_batch_export(bigsi_hip_batch *b)
         static const int per_wg = env_int("BIGSI_HIP_EXPORT_READS_PER_WG", kBlock);
         const unsigned rgrid = (unsigned)std::min<uint64_t>(ceil_div(n, (uint64_t)std::max(per_wg, 1)), 64);
         hipLaunchKernelGGL(k_export_reads, dim3(std::max(rgrid, 1u)), dim3(kBlock), 0, st, hb.q_start.as<uint64_t>(), hb.q_cnt.as<uint32_t>(), n,
-                           b->uniq.as<uint32_t>(), hb.col(), hb.cnt(), (uint32_t)spec, static_cast<uint64_t *>(b->pin_out), b->exp_count.as<uint32_t>(),
+                           b->uniq.as<uint32_t>(), hb.col(), hb.cnt(), hb.capacity(), (uint32_t)spec, static_cast<uint64_t *>(b->pin_out), b->exp_count.as<uint32_t>(),
                            (volatile uint64_t *)(use_flag ? b->pin_flag : nullptr), b->exp_serial);
         HIP_TRY(hipGetLastError());
         if (!use_flag) HIP_TRY(hipEventRecord(b->exp_done, st));

@@ -2169,8 +2169,8 @@ __global__ __launch_bounds__(kBlock) void k_export_results(
 // its own, writes the offsets and copies every query's hits to their place in query order.  No workgroup waits for another.
 __global__ __launch_bounds__(kBlock) void k_export_reads(
     const uint64_t *__restrict__ q_start, const uint32_t *__restrict__ q_cnt, uint32_t n_seqs, const uint32_t *__restrict__ uniq,
-    const uint32_t *__restrict__ col, const uint32_t *__restrict__ cnt, uint32_t spec, uint64_t *out,
-    uint32_t *__restrict__ done_count, volatile uint64_t *flag, uint64_t serial)
+    const uint32_t *__restrict__ col, const uint32_t *__restrict__ cnt, uint64_t capacity /* entries col / cnt hold */, uint32_t spec,
+    uint64_t *out, uint32_t *__restrict__ done_count, volatile uint64_t *flag, uint64_t serial)
 {
     __shared__ uint32_t lds[16];
     __shared__ uint64_t lds64[kBlock / 64];
@@ -2196,8 +2196,11 @@ __global__ __launch_bounds__(kBlock) void k_export_reads(
         base += tot;
         if (q < q1) {
             out[q] = off;
+            // (a list the read kernel could not place -- the buffers were full: its start lies beyond them, nothing was written;
+            // the total then exceeds the capacity and the host takes the route that grows the buffers)
             const uint64_t src = c ? q_start[q] : 0ull;
-            for (uint32_t j = 0; j < c && off + j < spec; j++) { ocol[off + j] = col[src + j]; ocnt[off + j] = cnt[src + j]; }
+            if (src + c <= capacity)
+                for (uint32_t j = 0; j < c && off + j < spec; j++) { ocol[off + j] = col[src + j]; ocnt[off + j] = cnt[src + j]; }
         }
     }
     if ((q1 == n_seqs && q0 < n_seqs) || (n_seqs == 0 && blockIdx.x == 0)) {

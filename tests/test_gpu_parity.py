@@ -1608,6 +1608,41 @@ def test_one_launch_read_path_places_hits_without_an_order_between_workgroups(hi
     st.delete_all()
 
 
+@pytest.mark.parametrize("n_cols", [100, 4097, 16383, 16384, 16385, 20000, 32768])
+@pytest.mark.parametrize("h", [2, 3, 4])
+def test_read_kernel_widths_around_its_lane_layouts(hip, n_cols, h):
+    """k_reads_fused over row widths on both sides of its layouts: rows of at most 256 words take one word per lane on the counting
+    route (8-byte loads), wider ones -- up to the kernel's 512 -- two; the exact route always two.  Reads of 31..93 bp, some planted in
+    a few samples, at thresholds 1.0 / 0.7 / 0.3 / 0.0, through batch objects and the one-call search, against the three-launch route."""
+    m = 60013
+    _, st = synth_index(hip, m, n_cols, h, 1000 + n_cols + h, draws=1)
+    rng = np.random.default_rng(n_cols * 7 + h)
+    reads = random_seqs(rng, 300, 31, 93)
+    for i in range(0, 300, 9):
+        for c in rng.choice(n_cols, size=min(5, n_cols), replace=False):
+            st.insert_kmers(int(c), [reads[i] if i % 2 else reads[i][:55]], 31)
+    fused, plain = st.new_batch(reads, 31), st.new_batch(reads, 31)
+    found = 0
+    for thr in (1.0, 0.7, 0.3, 0.0):
+        fused.run(thr, sparse_counts=True)
+        assert fused.info().one_launch == 1
+        plain.run(thr, sparse_counts=True, k1_global=True)
+        assert plain.info().one_launch == 0
+        fo, fc, fn = fused.hits()
+        po, pc, pn = plain.hits()
+        assert np.array_equal(fo, po) and np.array_equal(fc, pc) and np.array_equal(fn, pn), thr
+        assert all(np.array_equal(x, y) for x, y in zip(fused.unique(), plain.unique()))
+        found += int(po[-1]) if thr == 1.0 else 0
+        if thr in (1.0, 0.3):
+            got = st.search_batch(reads[:40], 31, thr)
+            for i, (nk, nu, col, cnt) in enumerate(got):
+                assert col.tolist() == pc[int(po[i]):int(po[i + 1])].tolist() and cnt.tolist() == pn[int(po[i]):int(po[i + 1])].tolist(), (thr, i)
+    assert found >= 30
+    fused.close()
+    plain.close()
+    st.delete_all()
+
+
 def test_read_batches_on_library_streams_keep_their_order(hip):
     """Batches of reads run on three library streams (consecutive batches overlap).  What must still hold: a batch answers for the
     index as it was when the batch was launched even if the index is changed right after the (asynchronous) launch; a batch
