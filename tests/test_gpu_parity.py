@@ -1634,9 +1634,15 @@ def test_read_kernel_widths_around_its_lane_layouts(hip, n_cols, h):
         assert all(np.array_equal(x, y) for x, y in zip(fused.unique(), plain.unique()))
         found += int(po[-1]) if thr == 1.0 else 0
         if thr in (1.0, 0.3):
-            got = st.search_batch(reads[:40], 31, thr)
+            # 40 reads: read in place from the pinned staging (zero copy); all 300 at 1.0: ~20 KB, copied in by k_stage_in first
+            got = st.search_batch(reads[:40] if thr < 1.0 else reads, 31, thr)
             for i, (nk, nu, col, cnt) in enumerate(got):
                 assert col.tolist() == pc[int(po[i]):int(po[i + 1])].tolist() and cnt.tolist() == pn[int(po[i]):int(po[i + 1])].tolist(), (thr, i)
+        if thr in (0.3, 0.0):
+            # the streaming entry point over the same reads: at these thresholds a device batch's lists outgrow the hit buffers the
+            # workspace starts with (and what the export carries along): the regrow route, inside the stream
+            nk_, nu_, so, sc, sn = st.search_many(reads, 31, thr)
+            assert np.array_equal(so, po) and np.array_equal(sc, pc) and np.array_equal(sn, pn), thr
     assert found >= 30
     fused.close()
     plain.close()
