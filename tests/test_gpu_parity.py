@@ -1600,6 +1600,16 @@ def test_one_launch_read_path_places_hits_without_an_order_between_workgroups(hi
         if thr > 0.0:
             nk, nu, off, col, cnt = st.search_many(seqs, 31, thr)
             assert np.array_equal(off, po) and np.array_equal(col, pc) and np.array_equal(cnt, pn), thr
+    # 40 000 reads in ONE call: one launch of the read kernel, the export's 64 workgroups own 625 queries each
+    many = random_seqs(rng, 40000, 31, 61)
+    for i in (0, 624, 625, 20000, 39999):
+        many[i] = seqs[0]                         # (planted above: its sample must come back at these places)
+    got = st.search_batch(many, 31, 1.0)
+    nk, nu, off, col, cnt = st.search_many(many, 31, 1.0)
+    assert len(got) == 40000 and int(off[-1]) >= 5
+    for i in list(range(0, 40000, 997)) + [0, 624, 625, 20000, 39999]:
+        assert got[i][2].tolist() == col[int(off[i]):int(off[i + 1])].tolist() and got[i][3].tolist() == cnt[int(off[i]):int(off[i + 1])].tolist(), i
+    assert (7 * 0 + 3) % n_cols in got[625][2] and (7 * 0 + 3) % n_cols in got[39999][2]
     s_ = _lib.Stats()
     _lib.check(_lib.lib().bigsi_hip_stats(st.handle, _lib.C.byref(s_), 1))
     assert s_.read_launches_repeated == 0          # nothing waits, nothing is repeated
