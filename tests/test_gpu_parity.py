@@ -1659,6 +1659,47 @@ def test_read_kernel_widths_around_its_lane_layouts(hip, n_cols, h):
     st.delete_all()
 
 
+def test_read_run_hit_buffers_too_small_for_the_caller(hip):
+    """The CAPACITY protocol on the read routes, whose lists the device holds in no particular order: fetch_hits of a read batch and
+    the one-call search of many reads / of one read with a caller's buffer one entry short fill the offsets (the total says what to
+    bring), return BIGSI_ERR_CAPACITY, and give the full lists on the next call with room."""
+    from bigsi_amd import _lib
+    m, n_cols, h = 30011, 700, 3
+    _, st = synth_index(hip, m, n_cols, h, 41, draws=1)
+    rng = np.random.default_rng(41)
+    reads = random_seqs(rng, 50, 40, 93)
+    for i in range(0, 50, 3):
+        for c in rng.choice(n_cols, size=3, replace=False):
+            st.insert_kmers(int(c), [reads[i]], 31)
+    L = _lib.lib()
+    b = st.new_batch(reads, 31)
+    b.run(1.0, sparse_counts=True)
+    assert b.info().one_launch == 1
+    off_ok, col_ok, cnt_ok = b.hits()
+    total = int(off_ok[-1])
+    assert total >= 17 * 3
+    off = np.zeros(len(reads) + 1, np.uint64)
+    col, cnt = np.zeros(total, np.uint32), np.zeros(total, np.uint32)
+    assert L.bigsi_hip_batch_fetch_hits(b.b, _lib.ptr(off), _lib.ptr(col), _lib.ptr(cnt), total - 1) == _lib.ERR_CAPACITY
+    assert np.array_equal(off, off_ok)
+    _lib.check(L.bigsi_hip_batch_fetch_hits(b.b, _lib.ptr(off), _lib.ptr(col), _lib.ptr(cnt), total))
+    assert np.array_equal(col, col_ok) and np.array_equal(cnt, cnt_ok)
+    b.close()
+    for qs in (reads, reads[:1], reads[3:4]):
+        blob, soff = _lib.pack_seqs(qs)
+        n = len(qs)
+        want = [(col_ok[int(off_ok[i]):int(off_ok[i + 1])].tolist()) for i in (range(n) if n > 1 else [reads.index(qs[0])])]
+        t = sum(len(w) for w in want)
+        nk, nu, off = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(n + 1, np.uint64)
+        col, cnt = np.zeros(max(t, 1), np.uint32), np.zeros(max(t, 1), np.uint32)
+        assert t >= 3
+        rc = L.bigsi_hip_search_batch(st.handle, blob, _lib.ptr(soff), n, 31, 1.0, 0, _lib.ptr(nk), _lib.ptr(nu), None, _lib.ptr(off), _lib.ptr(col), _lib.ptr(cnt), t - 1)
+        assert rc == _lib.ERR_CAPACITY and int(off[-1]) == t
+        _lib.check(L.bigsi_hip_search_batch(st.handle, blob, _lib.ptr(soff), n, 31, 1.0, 0, _lib.ptr(nk), _lib.ptr(nu), None, _lib.ptr(off), _lib.ptr(col), _lib.ptr(cnt), t))
+        assert [col[int(off[i]):int(off[i + 1])].tolist() for i in range(n)] == want
+    st.delete_all()
+
+
 def test_read_batches_on_library_streams_keep_their_order(hip):
     """Batches of reads run on three library streams (consecutive batches overlap).  What must still hold: a batch answers for the
     index as it was when the batch was launched even if the index is changed right after the (asynchronous) launch; a batch
