@@ -359,8 +359,8 @@ typedef struct {
     uint64_t transpose_launches; /* bigsi_hip_insert_columns_device calls (the build transpose, filters resident) */
     double transpose_ms;
     uint64_t and_launches_total; /* row-AND launches since the last reset, timed or not (and_launches counts the timed ones) */
-    uint64_t read_launches_repeated; /* one-launch read kernels that were run again because a workgroup gave up waiting for
-                                        the hit totals of the queries before it (possible only beside launches of other batches) */
+    uint64_t read_launches_repeated; /* always 0 since round 4 (rounds 2-3: read launches repeated after a bounded wait between
+                                        workgroups ran out; no workgroup of any kernel waits for another any more); kept for the layout */
     uint64_t index_contiguous;       /* 1: the matrix got physically contiguous device memory (hipDeviceMallocContiguous: largest
                                         page-table fragments), 0: the ordinary allocation it falls back to */
     uint64_t exchange_launches;      /* bigsi_hip_batch_run_sharded calls timed (profiling level 1) */
