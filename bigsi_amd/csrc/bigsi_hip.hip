@@ -2653,7 +2653,9 @@ static int export_prepare(bigsi_hip_batch *b, hipStream_t st)
 {
     HitBufs &hb = b->hits;
     const uint32_t n = b->n_seqs;
-    const uint64_t spec = std::min<uint64_t>(std::max<uint64_t>(1024, 2ull * n), std::min<uint64_t>(hb.capacity(), 1u << 20));
+    // (room in the pinned block for the hit lists the export carries along: 16 per sequence -- a read stream whose reads match a
+    // handful of samples each then never takes the slower fetch route; the block is only written as far as there are hits)
+    const uint64_t spec = std::min<uint64_t>(std::max<uint64_t>(1024, 16ull * n), std::min<uint64_t>(hb.capacity(), 1u << 20));
     const size_t o_uniq = (n + 2ull) * 8, o_col = o_uniq + ((3ull * n + 1) & ~1ull) * 4, bytes = o_col + 8 * spec;
     TRY(pinned_reserve(&b->pin_out, &b->pin_out_cap, bytes));
     // completion: the kernel's last workgroup writes the export's serial into a pinned word the host spins on (no event record, no

@@ -149,12 +149,13 @@ int search_stream_impl(bigsi_hip_index *ix, const char *seqs, const uint64_t *of
     if (so) { so->bit_offsets[0] = 0; *so->bits_needed = 0; }
     if (n_seqs == 0) return BIGSI_OK;
     constexpr int kSlots = 3;
-    // a batch = at most 2^20 k-mer positions (gene-length queries: ~1000 of 1 kbp) and at most kChunkSeqs sequences (reads): 2^14 of
-    // them per launch measured best for long inputs (1.39 G lookups/s host-visible over 512 k reads of 61 bp; 2^15: 1.36, 2^13: 1.31),
-    // fewer when the input is short, so that at least six batches overlap their staging, kernels and collection (64 k reads:
-    // 1.32 G with 2^13 against 1.12 with 2^15)
+    // a batch = at most 2^20 k-mer positions (gene-length queries: ~1000 of 1 kbp) and at most kChunkSeqs sequences (reads).  With the
+    // read kernel that ordered its hit lists inside the launch (rounds 2-3) 2^14 reads per launch measured best; the wait-free kernel
+    // of round 4 prefers smaller launches, more of them in flight: host-visible over 1 M reads of 61 bp 1.04 / 1.41 / 1.51 / 1.45 G
+    // lookups/s at 1024 / 2048 / 4096 / 16384 reads per batch, over 64 k reads 1.01 / 1.36 / 1.39 / 1.27 G (interleaved, twice each)
     constexpr uint64_t kChunkPositions = 1ull << 20;
-    const uint64_t kChunkSeqs = std::min<uint64_t>(1ull << 14, std::max<uint64_t>(1ull << 12, (n_seqs + 5) / 6));
+    static const int chunk_seqs_env = env_int("BIGSI_HIP_STREAM_SEQS", 0);
+    const uint64_t kChunkSeqs = chunk_seqs_env > 0 ? (uint64_t)chunk_seqs_env : 4096;
     struct Chunk { uint64_t first; uint32_t n; uint64_t hit0, bit0; bool scoring; };
     Chunk inflight[kSlots] = {};
     bool busy[kSlots] = {};          // launched, hit lists not collected yet
