@@ -110,7 +110,7 @@ struct bigsi_hip_index {
     hipEvent_t main_ev = nullptr; // end of the last batch run on the index stream (mark_main)
     uint64_t fused_repeats = 0;   // (rounds 2-3: read launches repeated after a bounded wait ran out; nothing waits any more: stays 0)
     struct bigsi_hip_batch *search_ws = nullptr;      // bigsi_hip_search_batch's workspace, created at its first call
-    struct bigsi_hip_batch *stream_ws[3] = {};        // bigsi_hip_search_stream's three workspaces
+    struct bigsi_hip_batch *stream_ws[6] = {};        // bigsi_hip_search_stream's workspaces (four in use; up to six in tuning builds)
     uint64_t m = 0, n_cols = 0, cap_cols = 0, stride_words = 0;
     uint32_t h = 0;
     uint64_t *d_index = nullptr;

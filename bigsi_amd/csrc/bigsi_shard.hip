@@ -148,7 +148,10 @@ int search_stream_impl(bigsi_hip_index *ix, const char *seqs, const uint64_t *of
     hit_offsets[0] = 0;
     if (so) { so->bit_offsets[0] = 0; *so->bits_needed = 0; }
     if (n_seqs == 0) return BIGSI_OK;
-    constexpr int kSlots = 3;
+    constexpr int kMaxSlots = 6;
+    // device batches in flight (1 M reads of 61 bp, host-visible, interleaved: 2 -> 1.14, 3 -> 1.47-1.50, 4 -> 1.51-1.53, 6 -> 1.49-1.51 G
+    // lookups/s; gene-length and scored streams +-0)
+    static const int kSlots = std::min(std::max(env_int("BIGSI_HIP_STREAM_SLOTS", 4), 2), kMaxSlots);
     // a batch = at most 2^20 k-mer positions (gene-length queries: ~1000 of 1 kbp) and at most kChunkSeqs sequences (reads).  With the
     // read kernel that ordered its hit lists inside the launch (rounds 2-3) 2^14 reads per launch measured best; the wait-free kernel
     // of round 4 prefers smaller launches, more of them in flight: host-visible over 1 M reads of 61 bp 1.04 / 1.41 / 1.51 / 1.45 G
@@ -157,8 +160,8 @@ int search_stream_impl(bigsi_hip_index *ix, const char *seqs, const uint64_t *of
     static const int chunk_seqs_env = env_int("BIGSI_HIP_STREAM_SEQS", 0);
     const uint64_t kChunkSeqs = chunk_seqs_env > 0 ? (uint64_t)chunk_seqs_env : 4096;
     struct Chunk { uint64_t first; uint32_t n; uint64_t hit0, bit0; bool scoring; };
-    Chunk inflight[kSlots] = {};
-    bool busy[kSlots] = {};          // launched, hit lists not collected yet
+    Chunk inflight[kMaxSlots] = {};
+    bool busy[kMaxSlots] = {};       // launched, hit lists not collected yet
     uint64_t total = 0;              // hits so far (global offset of the next chunk's first hit)
     uint64_t bits_total = 0;         // bytes of presence bits so far
     bool overflow = false, bits_overflow = false;

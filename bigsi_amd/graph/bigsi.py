@@ -366,7 +366,7 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
         """Generator over (sequence, results) for an arbitrarily long iterable of sequences (bulk_search, bigsi/__main__.py:261-314,
         runs one BIGSI.search per query in a fork pool).  The sequences go through the C ABI's streaming entry points --
         bigsi_hip_search_stream, or bigsi_hip_search_stream_scored with score=True: one call per slice of about 8 x `batch_kmers`
-        k-mers (or 16 x `batch_size` sequences), inside which the library keeps three device batches in flight and, scored, runs
+        k-mers (or 16 x `batch_size` sequences), inside which the library keeps four device batches in flight and, scored, runs
         K5 + K6 of one beside the row-AND of the next -- on a worker thread (the call holds no GIL), while this thread turns the
         arrays of the slice before into the reference's result dicts.  Results, order and the reference's errors for degenerate
         queries (raised when the offending sequence's turn comes, after everything before it was yielded) are those of search()

@@ -493,7 +493,7 @@ class HipHbmStorage(BaseStorage):
 
 
     def search_many(self, seqs, k, threshold=1.0):
-        """bigsi_hip_search_stream: any number of sequences in ONE call -- the library cuts them into device batches and keeps three
+        """bigsi_hip_search_stream: any number of sequences in ONE call -- the library cuts them into device batches and keeps four
         in flight (upload / kernels / export overlap).  Returns (num_kmers, num_unique, hit_offsets, colours, counts): sequence i
         matched colours[hit_offsets[i]:hit_offsets[i+1]] (ascending) with that many of its unique k-mers.  Single index only."""
         assert threshold <= 1

@@ -294,7 +294,7 @@ int bigsi_hip_search_batch(bigsi_hip_index *ix, const char *seqs, const uint64_t
                            uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t hit_capacity);
 
 /* BIGSI.search for ANY number of sequences in one call -- what bulk_search (bigsi/__main__.py:261-314) does with a fork pool and one
- * BIGSI.search per query.  The library cuts the input into device batches (about 2^20 k-mer positions each), keeps three
+ * BIGSI.search per query.  The library cuts the input into device batches (about 2^20 k-mer positions each), keeps four
  * workspaces in flight -- while one batch runs, the next is staged and uploaded and the results of the one before are exported and
  * copied out: pinned staging, asynchronous copies, one wait per batch -- and writes each sequence's results at its place in the
  * caller's arrays.  Outputs as bigsi_hip_search_batch with n_seqs-long arrays; hit_offsets (n_seqs + 1 entries) index colours /
