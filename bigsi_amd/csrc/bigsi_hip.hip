@@ -1674,7 +1674,10 @@ int bigsi_batch_run(bigsi_hip_batch *b, double threshold, uint32_t flags, bool o
         if (slices_env > 0) slices = (uint32_t)slices_env;
         // (one 1 kbp query on 100 k samples, its slices spread over all XCDs (map_block): exact 35 / 14.7 / 16.6 / 22.9 us at
         // 16 / 64 / 128 / 256 slices, counting 59 / 31 / 30 / 32 us; beyond that the atomics that combine the slices show)
-        else if (waves < 1024) slices = (uint32_t)std::min<uint64_t>({64, ceil_div(2048, std::max<uint64_t>(waves, 1)), std::max<uint64_t>(b->max_pos / 16, 1)});
+        // (counting, round 4: a slice of ~10 k-mers leaves 4 bit-sliced planes instead of 5 for k_count_combine to add up -- one
+        // 1 kbp query on 100 k samples at 0.4, the whole call: 60 slices 50.3 us, 96: 47.0, 128: 49.0; exact: 60 -> 36.3, 96 -> 35.8, 128 -> 41)
+        else if (waves < 1024 && b->exact) slices = (uint32_t)std::min<uint64_t>({64, ceil_div(2048, std::max<uint64_t>(waves, 1)), std::max<uint64_t>(b->max_pos / 16, 1)});
+        else if (waves < 1024) slices = (uint32_t)std::min<uint64_t>({96, ceil_div(2048, std::max<uint64_t>(waves, 1)), std::max<uint64_t>(b->max_pos / 10, 1)});
         if (!sliceable) slices = 1;
         slices = std::max<uint32_t>(slices, 1);
     }
