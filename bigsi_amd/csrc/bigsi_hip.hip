@@ -1363,8 +1363,14 @@ static int launch_reads_fused(bigsi_hip_batch *b, hipStream_t st = nullptr, bool
 #else
 #define BIGSI_READS_UNR(H)
 #endif
+    // a handful of reads (a latency-bound call): the exact route splits each query's rows over the two halves of its workgroup
+    static const int split_max = env_int("BIGSI_HIP_READS_SPLIT_MAX", 64);
+    const bool split = b->wv <= (uint64_t)kBlock && (int)b->n_seqs <= split_max;
 #define BIGSI_READS(H)                                                                              \
     BIGSI_READS_UNR(H)                                                                              \
+    if (split && b->exact) hipLaunchKernelGGL((k_reads_fused<H COMMA true COMMA kVec COMMA 16 COMMA true>), BIGSI_READS_ARGS);     \
+    else if (split) hipLaunchKernelGGL((k_reads_fused<H COMMA false COMMA kVec COMMA 16 COMMA true>), BIGSI_READS_ARGS);          \
+    else                                                                                            \
     if (b->exact && narrow && vec1_exact) hipLaunchKernelGGL((k_reads_fused<H COMMA true COMMA 1>), BIGSI_READS_ARGS);   \
     else if (b->exact) hipLaunchKernelGGL((k_reads_fused<H COMMA true>), BIGSI_READS_ARGS);                \
     else if (narrow && vec1_count) hipLaunchKernelGGL((k_reads_fused<H COMMA false COMMA 1>), BIGSI_READS_ARGS);       \

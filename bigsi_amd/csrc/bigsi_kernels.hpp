@@ -1370,7 +1370,9 @@ __global__ __launch_bounds__(kBlock) void k_hits_write(
 // kernel's last section).  Same results, one launch.
 constexpr uint32_t kReadsMaxSeqs = 1u << 20;  // queries per launch of k_reads_fused at most
 template <int H, bool EXACT, int VEC = kVec /* 64-column words per lane: 2 (16-byte loads) or 1 (8-byte loads; rows of <= kBlock words) */,
-          int UNR_EXACT = 16 /* row loads a lane keeps in flight on the exact route */>
+          int UNR_EXACT = 16 /* row loads a lane keeps in flight on the exact route */,
+          bool SPLIT = false /* exact route, rows of <= 256 words, a handful of queries (a latency-bound call): the two halves of the
+                                workgroup stream half of the query's rows each and meet in LDS -- half the chain of dependent round trips */>
 __global__ __launch_bounds__(kBlock) void k_reads_fused(
     const uint64_t *__restrict__ index, uint64_t stride_words, uint32_t wv, uint64_t n_cols, uint64_t m, double threshold,
     const char *__restrict__ seqs, const uint64_t *__restrict__ seq_off, const uint64_t *__restrict__ pos_off, uint32_t n_seqs,
@@ -1512,8 +1514,8 @@ __global__ __launch_bounds__(kBlock) void k_reads_fused(
     // already moves 5.7 TB/s of 1.25 KB rows, and the HBM is the limit, not the round trips.)
     const uint32_t u = s_u;
     BIGSI_PHASE(1);
-    const uint32_t w0 = threadIdx.x * VEC;
-    const bool live = w0 < wv;
+    const uint32_t w0 = (SPLIT ? (threadIdx.x & (kBlock / 2 - 1)) : threadIdx.x) * VEC;
+    const bool live = (!SPLIT || threadIdx.x < kBlock / 2) && w0 < wv;      // the lanes that own the query's words from here on
     uint64_t hitw[VEC];
     uint64_t pl[VEC][P];
 #pragma unroll
@@ -1522,8 +1524,24 @@ __global__ __launch_bounds__(kBlock) void k_reads_fused(
         constexpr int UNR = UNR_EXACT;
         const uint32_t R = u * H;
         RowWords<VEC> acc = RowWords<VEC>::fill(~0ull);
+        if (SPLIT) {
+            __shared__ RowWords<VEC> s_half[kBlock / 2];
+            const uint32_t upper = threadIdx.x / (kBlock / 2), Rh = (R + 1) / 2, ra = upper ? Rh : 0u, rb = upper ? R : Rh;
+            if (w0 < wv) {
+                for (uint32_t r = ra; r < rb; r += UNR) {
+                    RowWords<VEC> v[UNR];
+#pragma unroll
+                    for (int j = 0; j < UNR; j++) v[j] = r + j < rb ? RowWords<VEC>::load(index, s_rows[r + j], stride_words, w0) : RowWords<VEC>::fill(~0ull);
+#pragma unroll
+                    for (int j = 0; j < UNR; j++) acc &= v[j];
+                }
+            }
+            if (upper) s_half[threadIdx.x - kBlock / 2] = acc;
+            __syncthreads();
+            if (live) acc &= s_half[threadIdx.x];
+        }
         if (live) {
-            for (uint32_t r = 0; r < R; r += UNR) {
+            for (uint32_t r = 0; !SPLIT && r < R; r += UNR) {
                 RowWords<VEC> v[UNR];
 #pragma unroll
                 for (int j = 0; j < UNR; j++) v[j] = r + j < R ? RowWords<VEC>::load(index, s_rows[r + j], stride_words, w0) : RowWords<VEC>::fill(~0ull);
@@ -1539,13 +1557,16 @@ __global__ __launch_bounds__(kBlock) void k_reads_fused(
         for (int v = 0; v < VEC; v++)
 #pragma unroll
             for (int p = 0; p < P; p++) pl[v][p] = 0;
-        if (live) {
+        // SPLIT: the upper half of the workgroup counts the k-mers [uh, u), the lower half [0, uh); the partial counts meet in LDS
+        const uint32_t upper_c = SPLIT ? threadIdx.x / (kBlock / 2) : 0u, uh = SPLIT ? (u + 1) / 2 : u;
+        const uint32_t ja = upper_c ? uh : 0u, jb = SPLIT ? (upper_c ? u : uh) : u;
+        if (SPLIT ? w0 < wv : live) {
             constexpr int KM = H <= 2 ? 8 : H == 3 ? 6 : 4;
-            for (uint32_t j = 0; j < u; j += KM) {
+            for (uint32_t j = ja; j < jb; j += KM) {
                 RowWords<VEC> v[KM * H];
 #pragma unroll
                 for (int t = 0; t < KM * H; t++)
-                    v[t] = j + t / H < u ? RowWords<VEC>::load(index, s_rows[(j + t / H) * H + t % H], stride_words, w0) : RowWords<VEC>::fill(0ull);
+                    v[t] = j + t / H < jb ? RowWords<VEC>::load(index, s_rows[(j + t / H) * H + t % H], stride_words, w0) : RowWords<VEC>::fill(0ull);
 #pragma unroll
                 for (int g = 0; g < KM; g++) {
                     RowWords<VEC> a = v[g * H];
@@ -1563,6 +1584,30 @@ __global__ __launch_bounds__(kBlock) void k_reads_fused(
                     }
                 }
             }
+        }
+        if (SPLIT) {
+            __shared__ uint64_t s_pl[P][VEC][kBlock / 2];
+            if (upper_c) {
+#pragma unroll
+                for (int p = 0; p < P; p++)
+#pragma unroll
+                    for (int e = 0; e < VEC; e++) s_pl[p][e][threadIdx.x - kBlock / 2] = pl[e][p];
+            }
+            __syncthreads();
+            if (live) {          // bit-sliced ripple-carry add of the two partial counts (their sum is at most u < 2^P)
+#pragma unroll
+                for (int e = 0; e < VEC; e++) {
+                    uint64_t carry = 0;
+#pragma unroll
+                    for (int p = 0; p < P; p++) {
+                        const uint64_t a = pl[e][p], b2 = s_pl[p][e][threadIdx.x];
+                        pl[e][p] = a ^ b2 ^ carry;
+                        carry = (a & b2) | (carry & (a ^ b2));
+                    }
+                }
+            }
+        }
+        if (live) {
             const uint32_t thr = s_min;
 #pragma unroll
             for (int v = 0; v < VEC; v++) {
