@@ -1205,7 +1205,9 @@ template <int P, typename CountT>
 static void launch_count_wide(bigsi_hip_batch *b, const CountLaunch &c, uint32_t q0, uint32_t q1)
 {
     bigsi_hip_index *ix = b->ix;
-    const unsigned grid = (unsigned)(ceil_div(q1 - q0, 8) * 8 * (uint64_t)c.tiles * c.slices);
+    // (sliced launches map workgroups to queries in plain order -- map_block -- and need no padding to 8 queries: a single sliced query
+    // used to launch 8 x its workgroups, seven eighths of them leaving at once)
+    const unsigned grid = (unsigned)((c.slices > 1 ? (uint64_t)(q1 - q0) : ceil_div(q1 - q0, 8) * 8) * (uint64_t)c.tiles * c.slices);
 #define BIGSI_COUNT_ARGS                                                                                                      \
     dim3(grid), dim3(c.block), 0, ix->stream, ix->d_index, ix->stride_words, (uint32_t)b->wv, c.k2_rows, b->d_pos_off.as<uint64_t>(), \
         b->num_unique.as<uint32_t>(), ix->h, q0, q1, c.tiles, (CountT *)c.out, c.out_stride, b->min_kmers.as<uint32_t>(), ix->n_cols,  \
@@ -1786,7 +1788,7 @@ int bigsi_batch_run(bigsi_hip_batch *b, double threshold, uint32_t flags, bool o
         static const int and_nt = env_int("BIGSI_HIP_AND_NT", 1);     // 0: plain loads (A/B against non-temporal)
         for (uint32_t q0 = 0; q0 < b->n_seqs; q0 += chunk_q, n_launches++) {
             const uint32_t q1 = std::min<uint64_t>((uint64_t)q0 + chunk_q, b->n_seqs);
-            unsigned grid = (unsigned)(ceil_div(q1 - q0, 8) * 8 * blocks_per_q), l_block = (unsigned)and_block;
+            unsigned grid = (unsigned)((slices > 1 ? (uint64_t)(q1 - q0) : ceil_div(q1 - q0, 8) * 8) * blocks_per_q), l_block = (unsigned)and_block;
             uint32_t l_tiles = tiles, l_slices = slices;
             if (chunk_q < b->n_seqs && q1 - q0 < chunk_q && and_block == 256) {
                 // the last launch of a batch that is not a multiple of the launch size is a batch of its own kind: with a few
@@ -1795,7 +1797,7 @@ int bigsi_batch_run(bigsi_hip_batch *b, double threshold, uint32_t flags, bool o
                 if (waves_r < 1024) {
                     l_slices = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({64, ceil_div(2048, std::max<uint64_t>(waves_r, 1)), std::max<uint64_t>(b->max_pos / 16, 1)}));
                     if (l_slices > 1) HIP_TRY(hipMemsetAsync(out + (uint64_t)q0 * b->wv_pad, 0xFF, (size_t)(q1 - q0) * b->wv_pad * 8, ix->stream));
-                    grid = (unsigned)(ceil_div(q1 - q0, 8) * 8 * (uint64_t)tiles * l_slices);
+                    grid = (unsigned)((l_slices > 1 ? (uint64_t)(q1 - q0) : ceil_div(q1 - q0, 8) * 8) * (uint64_t)tiles * l_slices);
                 } else if (grid % 256 != 0) {
                     l_block = 64;
                     l_tiles = (uint32_t)ceil_div(b->wv, 64 * kVec);
@@ -1938,9 +1940,19 @@ static int compact_ex(bigsi_hip_batch *b, HitBufs &hb, const void *src, bool fro
         if (!write_only && ngroups > 1)
             hipLaunchKernelGGL(k_hits_totals, dim3((unsigned)ngroups), dim3(kBlock), 0, st, (const uint64_t *)src, b->wv_pad, (uint32_t)b->wv, b->n_seqs,
                                n_shards, chunks, ipb, hb.chunk_hits.as<uint32_t>());
+        // a one-call search whose compaction is ONE workgroup (a gene-length query or two): that workgroup exports the results itself
+        static const int k4_export = env_int("BIGSI_HIP_K4_EXPORT", 1);
+        const bool inline_export = k4_export && b->one_call && &hb == &b->hits && !write_only && ngroups == 1 && n_shards == 1 && chunks <= 16 && st == b->ix->stream;
+        if (inline_export) {
+            TRY(export_prepare(b, st));
+            if (b->exp_flagged) b->exported_inline = true;
+            else b->exp_serial--;          // (tuning builds with the event route: the export kernel as usual)
+        }
         hipLaunchKernelGGL(k_hits_write, dim3((unsigned)ngroups), dim3(kBlock), 0, st, (const uint64_t *)src, b->wv_pad, (uint32_t)b->wv, b->n_seqs,
                            n_shards, chunks, shard_cols, b->num_unique.as<uint32_t>(), ipb, hb.chunk_hits.as<uint32_t>(),
-                           hb.hit_off.as<uint64_t>(), hb.col(), hb.cnt(), hb.capacity(), counters, b->count_bytes, b->wv_pad * 64, own_shard);
+                           hb.hit_off.as<uint64_t>(), hb.col(), hb.cnt(), hb.capacity(), counters, b->count_bytes, b->wv_pad * 64, own_shard,
+                           b->exported_inline && inline_export ? static_cast<uint64_t *>(b->pin_out) : nullptr, b->exp_spec, b->uniq.as<uint32_t>(),
+                           (volatile uint64_t *)b->pin_flag, b->exp_serial);
         HIP_TRY(hipGetLastError());
         return BIGSI_OK;
     }

@@ -1274,7 +1274,11 @@ __global__ __launch_bounds__(kBlock) void k_hits_write(
     const uint64_t *__restrict__ bitmaps, uint64_t stride_words, uint32_t wv, uint32_t n_seqs, uint32_t n_shards, uint32_t chunks,
     uint64_t shard_cols, const uint32_t *__restrict__ num_unique, uint32_t ipb, const uint32_t *__restrict__ totals,
     uint64_t *__restrict__ hit_off, uint32_t *__restrict__ hit_col, uint32_t *__restrict__ hit_cnt, uint64_t capacity,
-    const void *__restrict__ counters, uint32_t counter_bytes, uint64_t counter_stride, uint32_t own_shard)
+    const void *__restrict__ counters, uint32_t counter_bytes, uint64_t counter_stride, uint32_t own_shard,
+    uint64_t *exp_out /* non-null (single-workgroup launches of a one-call search only): this launch also writes the caller's block in
+                         pinned memory (k_export_results' layout) and raises the flag the host spins on -- no export kernel, one launch
+                         boundary less on a call that is a chain of them */,
+    uint32_t exp_spec, const uint32_t *__restrict__ exp_uniq, volatile uint64_t *exp_flag, uint64_t exp_serial)
 {
     __shared__ uint32_t lds[16];
     __shared__ uint64_t lds64[kBlock / 64];
@@ -1295,11 +1299,15 @@ __global__ __launch_bounds__(kBlock) void k_hits_write(
             }
             uint32_t tot;
             const uint32_t pre = block_exclusive_scan(cnt, &tot, lds);
-            if (threadIdx.x == 0) hit_off[q] = base;
+            if (threadIdx.x == 0) {
+                hit_off[q] = base;
+                if (exp_out) exp_out[q] = base;
+            }
             uint64_t o = base + pre;
             base += tot;
             if (cnt == 0 || o + cnt > capacity) continue;
             const uint32_t uq = num_unique[q];
+            uint32_t *ocol = exp_out ? reinterpret_cast<uint32_t *>(exp_out + n_seqs + 2u) + ((3u * n_seqs + 1u) & ~1u) : nullptr;
 #pragma unroll
             for (int j = 0; j < 16; j++) {
                 uint64_t mcol = by_column(bits[j]);
@@ -1307,15 +1315,25 @@ __global__ __launch_bounds__(kBlock) void k_hits_write(
                 while (mcol) {
                     const uint32_t c = (uint32_t)__builtin_ctzll(mcol);
                     mcol &= mcol - 1;
+                    const uint32_t found = !counters ? uq
+                                           : counter_bytes == 2 ? (uint32_t) reinterpret_cast<const uint16_t *>(counters)[cnt0 + c]
+                                                                : reinterpret_cast<const uint32_t *>(counters)[cnt0 + c];
                     hit_col[o] = (uint32_t)(col0 + c);
-                    hit_cnt[o] = !counters ? uq
-                                 : counter_bytes == 2 ? (uint32_t) reinterpret_cast<const uint16_t *>(counters)[cnt0 + c]
-                                                      : reinterpret_cast<const uint32_t *>(counters)[cnt0 + c];
+                    hit_cnt[o] = found;
+                    if (ocol && o < exp_spec) { ocol[o] = (uint32_t)(col0 + c); ocol[exp_spec + o] = found; }
                     o++;
                 }
             }
         }
         if (threadIdx.x == 0) hit_off[n_seqs] = base;
+        if (exp_out) {
+            if (threadIdx.x == 0) { exp_out[n_seqs] = base; exp_out[n_seqs + 1] = 0; }
+            uint32_t *o32 = reinterpret_cast<uint32_t *>(exp_out + n_seqs + 2u);
+            for (uint32_t i = threadIdx.x; i < 3u * n_seqs; i += kBlock) o32[i] = exp_uniq[i];
+            __threadfence_system();
+            __syncthreads();
+            if (threadIdx.x == 0) *exp_flag = exp_serial;
+        }
         return;
     }
     const uint64_t grp = blockIdx.x, n_items = (uint64_t)n_seqs * n_shards * chunks;
