@@ -96,6 +96,10 @@ def parse():
     p.add_argument("--and-draws", type=int, default=2, help="bit density of the synthetic index = 2^-draws")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample (0 = skip)")
     p.add_argument("--cpu-rows", type=int, default=200_000)
+    p.add_argument("--dense", type=int, default=0, choices=[0, 1],
+                   help="the hit-dense variant of the workload (what real thresholded searches produce; the plain workloads carry ~1 hit per query): "
+                        "gene-length queries: the first 16 queries of every batch are held, up to 15 SNPs apart, by 1 %% of the shard's samples "
+                        "(~625 hits per query at 62.5 k samples, ~10 k per batch); reads: every read is held by 8 samples")
     p.add_argument("--no-verify", action="store_true")
     p.add_argument("--score-queue", default="beside", choices=["ordered", "beside"],
                    help="score=True workloads: K5 + K6 of a batch queued on the index stream behind the next batch's kernels (ordered) or on "
@@ -134,6 +138,40 @@ def parse():
 def rand_seqs(rng, n, qlen):
     lut = np.frombuffer(b"ACGT", dtype=np.uint8)
     return [lut[r].tobytes().decode("ascii") for r in rng.integers(0, 4, size=(n, qlen), dtype=np.uint8)]
+
+
+# ------------------------------------------------------------------------------------------------ hit-dense variants (--dense 1)
+DENSE_QUERIES, DENSE_COL_FRACTION, DENSE_MAX_SNPS, DENSE_READ_HITS = 16, 0.01, 15, 8
+
+
+def dense_gene_plants(w, nb, g, cols_g, k):
+    """Gene-length workloads: the first DENSE_QUERIES queries of every staged batch are shared -- 0 to DENSE_MAX_SNPS SNPs apart, so
+    that the presence strings carry the gaps the scorer is about -- by DENSE_COL_FRACTION of the shard's samples.  Yields
+    (batch, query, cols int64[], segs) with segs[j] = [(a, b), ...]: the stretches of the query that sample cols[j] holds."""
+    for bi in range(nb):
+        for qi in range(min(DENSE_QUERIES, w["batch"])):
+            rng = np.random.default_rng([SEED, 77, g, bi, qi])
+            cols = np.sort(rng.choice(cols_g, size=max(1, int(cols_g * DENSE_COL_FRACTION)), replace=False))
+            segs = []
+            for _ in cols:
+                n_snps = int(rng.integers(0, DENSE_MAX_SNPS + 1))
+                cuts = [-1] + np.sort(rng.choice(w["qlen"], size=n_snps, replace=False)).tolist() + [w["qlen"]]
+                segs.append([(a + 1, b) for a, b in zip(cuts[:-1], cuts[1:]) if b - a - 1 >= k])
+            yield bi, qi, cols, segs
+
+
+def seg_masks(segs, n_kmers, k):
+    """bool[len(segs), n_kmers]: k-mer position i lies inside one of sample j's stretches"""
+    out = np.zeros((len(segs), n_kmers), dtype=bool)
+    for j, sg in enumerate(segs):
+        for a, b in sg:
+            out[j, a:b - k + 1] = True
+    return out
+
+
+def dense_read_cols(bi, r, g, cols_g):
+    """Read workloads: the DENSE_READ_HITS samples that hold read r of staged batch bi (whole)."""
+    return [(7919 * (DENSE_READ_HITS * r + t) + 101 * bi + 13 * g) % cols_g for t in range(DENSE_READ_HITS)]
 
 
 # ------------------------------------------------------------------------------------------------ self launch
@@ -225,6 +263,10 @@ ALSO_LEGS = {
         ("c4_shard", "configs[3]: one GPU's shard (1 of 8) of 25M x 500k", ["--workload", "c4", "--shard-of", "8", "--warmup", "10"], 1200),
         ("c5_shard", "configs[4]: that shard at 0.4 with score=True in the step", ["--workload", "c5", "--shard-of", "8", "--warmup", "10"], 1000),
         ("ns_shard", "north_star 10M x 500k: one GPU's shard (1 of 8)", ["--workload", "northstar", "--shard-of", "8", "--warmup", "10"], 1200),
+        # the hit-dense regime (every other leg carries ~1 hit per query: K4, the hit export, K5 / K6 and the host assembly idle there)
+        ("c5_dense", "configs[4] shard, 16 of 256 queries held by 1 % of the samples (~10 k scored hits per batch)",
+         ["--workload", "c5", "--shard-of", "8", "--dense", "1", "--warmup", "6"], 150),
+        ("c2_dense", "configs[1], every read held by 8 samples", ["--workload", "c2", "--dense", "1", "--warmup", "200"], 30000),
         # f1, index ingest: a 32 GB snapshot (device layout) written, dropped, loaded back (threads on the file, two pinned buffers,
         # asynchronous copies), sampled rows verified against the oracle's generator: scripts/ingest_bench.py, keys in GB/s
         ("ingest", "snapshot of a 32 GB index written / dropped / loaded back", ["--ingest", "32"], 0)],
@@ -262,10 +304,14 @@ def leg_summary(d, what, extra, wall_s):
            "sf": rf.get("step_frac"), "box": rf.get("frac_of_box"), "tr": rf.get("traffic_ratio"), "ok": int(bool(cf.get("verified"))),
            "hv": cf.get("host_visible_lookups_per_s"), "us1": cf.get("one_call_us"), "gb": cf.get("index_gb_per_gpu"), "wall": wall_s}
     for k_src, k_dst in (("exchange_ms", "x_ms"), ("rccl_ranks", "ranks"), ("per_rank_GBps", "gbs"), ("scored_hits", "hits"), ("scored_us_per_hit", "us_hit"),
-                         ("hv_scored_lookups_per_s", "hvs"), ("distinct_gpus", "gpus_distinct"), ("one_call_us_batch", "usb"), ("frac_overlapped", "f3")):
+                         ("hv_scored_lookups_per_s", "hvs"), ("distinct_gpus", "gpus_distinct"), ("one_call_us_batch", "usb"), ("frac_overlapped", "f3"),
+                         ("hits_per_s", "hps"), ("hv_hits_per_s", "hvh"), ("hv_scored_hits_per_s", "hvsh"), ("dicts_per_s", "dps"), ("k5_traffic_ratio", "tr5"),
+                         ("k56_ms", "k56"), ("k56_GBps", "k56g")):
         v = cf.get(k_src, rf.get(k_src))
         if v is not None:
             out[k_dst] = v
+    if cf.get("dense"):
+        out["k4"] = rf.get("compact_ms")
     if rf.get("read_launches_repeated"):
         out["rep"] = rf["read_launches_repeated"]
     return {k_: v_ for k_, v_ in out.items() if v_ is not None}
@@ -358,6 +404,13 @@ def condense(full):
         "scored_hits": (pres.get("in_timed_region") or {}).get("hits_scored"), "scored_us_per_hit": sig((pres.get("in_timed_region") or {}).get("host_us_per_hit"), 3),
         "sclk_mclk_w": "%s/%s/%s" % tuple((cf.get("clocks") or {}).get("after_timed_region", {}).get(k_) for k_ in ("sclk_mhz", "mclk_mhz", "power_w")) if cf.get("clocks") else None,
         "fill_s": sig(cf.get("index_fill_s"), 3),
+        # hit-dense variants: hits per second of the step, through ONE (scored) stream call, and as the reference's result dicts
+        "dense": cut(cf.get("dense"), 100), "hits_per_s": sig(cf.get("hits_per_s"), 4),
+        "hv_hits_per_s": sig((hv.get("stream") or {}).get("hits") / ((hv.get("stream") or {}).get("call_ms") * 1e-3), 4) if cf.get("dense") and hv.get("stream") else None,
+        "hv_scored_hits_per_s": sig((hv.get("stream_scored") or {}).get("hits_per_s"), 4) if cf.get("dense") else None,
+        "dicts_per_s": sig((hv.get("scored_dicts") or hv.get("dicts") or {}).get("dicts_per_s"), 4),
+        "k5_traffic_ratio": sig(cf.get("k5_traffic_ratio"), 4),
+        "k56_ms": sig(pres.get("kernels_ms"), 4) if cf.get("dense") else None, "k56_GBps": sig(pres.get("GBps"), 4) if cf.get("dense") else None,
     }
     roof = {"bound": "hbm", "achieved": sig(rf["achieved"]), "peak": rf["peak"], "unit": "GB/s", "frac": sig(rf["frac"], 4),
             "traffic": sig(rf.get("traffic"), 6), "traffic_ratio": sig(rf["traffic"] / rf["alg_bytes_per_launch"], 4) if rf.get("traffic") else None,
@@ -507,7 +560,29 @@ def main():
     def score_plants(g, cols_g):
         return [(bi, qi, (7919 * (16 * qi + t) + 11 + 13 * g + 101 * bi) % cols_g) for bi in range(nb) for qi in range(min(16, w["batch"])) for t in range(16)]
 
-    if w["score"]:
+    gene_dense = bool(args.dense) and n_kmers >= 256
+    read_dense = bool(args.dense) and not gene_dense
+    dense_s = 0.0
+    if gene_dense:
+        t0 = time.time()
+        for bi, qi, cols_d, segs_d in dense_gene_plants(w, nb, rank, my_cols, args.k):
+            sq = all_seqs[bi][qi]
+            for c, sg in zip(cols_d.tolist(), segs_d):
+                if sg:
+                    st.insert_kmers(c, [sq[a:b] for a, b in sg], args.k)
+        dense_s = time.time() - t0
+    elif read_dense:
+        t0 = time.time()
+        by_col = {}
+        for bi in range(nb):
+            for r_, sq in enumerate(all_seqs[bi]):
+                for c in dense_read_cols(bi, r_, rank, my_cols):
+                    by_col.setdefault(c, []).append(sq)
+        for c, sqs in by_col.items():
+            st.insert_kmers(c, sqs, args.k)
+        del by_col
+        dense_s = time.time() - t0
+    elif w["score"]:
         for bi, qi, c in score_plants(rank, my_cols):
             st.insert_kmers(c, [all_seqs[bi][qi][:plant_len]], args.k)
     if args.one_device and world > 1 and args.backend == "nccl":
@@ -570,7 +645,7 @@ def main():
     # index stream behind batch k -- 0.1 ms, but every step pays it: 1.14 ms.
     fetched, begun = [None], [None]
     scored = {"results": None, "hits": 0, "batches": 0, "begin_s": 0.0, "finish_s": 0.0, "end_s": 0.0}
-    names = ["s%d" % (rank * shard_cols + c) for c in range(my_cols)] if w["score"] else None
+    names = ["s%d" % (rank * shard_cols + c) for c in range(my_cols)] if w["score"] or args.dense else None
     from bigsi_amd.scoring import SCORE_KEYS
     result_keys = ("percent_kmers_found", "num_kmers", "num_kmers_found", "sample_name") + SCORE_KEYS + ("kmer-presence",)
 
@@ -817,6 +892,15 @@ def main():
                                   "sequences": n_many, "sequence_bytes": len(blob), "hits": int(hoff[-1]), "call_ms": times[len(times) // 2] * 1e3,
                                   "entry": "bigsi_hip_search_stream (one call; median of 5)"}
 
+        from bigsi_amd.graph import bigsi as _front
+        if args.dense and not w["score"] and _front._results is not None:
+            # the reference's result dicts for the stream's hits (what BIGSI.search_stream yields), assembled from its arrays
+            t_ = time.perf_counter()
+            res_ = list(_front.native_result_lists(hnk, hnu, hoff.astype(np.int64), hcol, hcnt, exact, names, None, total_cols))
+            dt_ = time.perf_counter() - t_
+            assert sum(len(r_) for r_ in res_) == int(hoff[-1])
+            host_visible["dicts"] = {"dicts_per_s": int(hoff[-1]) / dt_, "after_the_call_dicts_per_s": int(hoff[-1]) / (dt_ + times[len(times) // 2])}
+            del res_
         if w["score"]:
             # score=True through the boundary alone: ONE bigsi_hip_search_stream_scored call (sequences in; hit lists, presence
             # bits and score records out; each device batch's K5 + K6 beside the next batch's row-AND)
@@ -837,8 +921,17 @@ def main():
             times = sorted(scored_call() for _ in range(5))
             assert int(need[0]) == hbits.size and int(hoff[-1]) == n_hits_many and (hrec["num_kmers"][:n_hits_many] > 0).all()
             host_visible["stream_scored"] = {"kmer_lookups_per_s": float(hnu.sum()) / times[len(times) // 2], "best": float(hnu.sum()) / times[0],
-                                             "hits": n_hits_many, "bit_bytes": int(need[0]), "call_ms": times[len(times) // 2] * 1e3,
+                                             "hits": n_hits_many, "hits_per_s": n_hits_many / times[len(times) // 2],
+                                             "bit_bytes": int(need[0]), "call_ms": times[len(times) // 2] * 1e3,
                                              "entry": "bigsi_hip_search_stream_scored (one call; median of 5)"}
+            if _front._results is not None:
+                # ... and as the reference's scored result dicts (22 keys + the presence string per hit), from the call's arrays
+                t_ = time.perf_counter()
+                res_ = list(_front.native_result_lists(hnk, hnu, hoff.astype(np.int64), hcol, hcnt, exact, names, (hrec, hbits, hboff), total_cols))
+                dt_ = time.perf_counter() - t_
+                assert sum(len(r_) for r_ in res_) == n_hits_many
+                host_visible["scored_dicts"] = {"dicts_per_s": n_hits_many / dt_, "after_the_call_dicts_per_s": n_hits_many / (dt_ + times[len(times) // 2])}
+                del res_
 
         def one_call(seq_list, reps):
             bl, so = _lib.pack_seqs(seq_list)
@@ -861,13 +954,18 @@ def main():
     # HBM traffic of this kernel on this workload, when a PMC pass for it has been committed (PMC counters cannot be
     # collected from inside the timed run; see profiles/)
     traffic, traffic_src = None, None
-    wkey = "rows=%d cols=%d hashes=%d batch=%d qlen=%d k=%d threshold=%s draws=%d" % (
-        w["rows"], my_cols, w["hashes"], w["batch"], w["qlen"], args.k, repr(float(thr)), args.and_draws)
+    wkey = "rows=%d cols=%d hashes=%d batch=%d qlen=%d k=%d threshold=%s draws=%d%s" % (
+        w["rows"], my_cols, w["hashes"], w["batch"], w["qlen"], args.k, repr(float(thr)), args.and_draws, " dense=1" if args.dense else "")
+    k5_ratio = None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             ent = json.load(f).get(wkey)
         if ent:
             traffic, traffic_src = ent["traffic_bytes_per_launch"], ent["source"]
+            k5 = (ent.get("other_kernels") or {}).get("k_presence_bits")
+            if k5 and ent.get("presence_alg_bytes_per_call"):
+                # K5's HBM traffic over the algorithmic bytes of the whole K5 + K6 call (unique k-mers x h x 8 per distinct hit word + bits + records)
+                k5_ratio = k5["traffic_bytes_per_launch"] / ent["presence_alg_bytes_per_call"]
     except OSError:
         pass
 
@@ -886,10 +984,22 @@ def main():
             orc = SynthOracle(SEED, rank, w["rows"], my_cols, w["hashes"], args.k, args.and_draws)
             for j, qi in enumerate(planted):
                 orc.insert_kmers(plant_col(j, rank, my_cols), seqs[qi][:plant_len])
-            if w["score"]:
+            sample = sorted(set([planted[0], 1 % w["batch"], w["batch"] // 2, w["batch"] - 1]))
+            scored_sample = (0, min(15, w["batch"] - 1)) if w["score"] else ()
+            if args.dense:
+                # every plant of every staged batch counts (rows collide), but only the rows the checked queries read are kept
+                only = np.unique(np.concatenate([orc.rows_of(seqs[qi]).ravel() for qi in set(sample) | set(scored_sample)]))
+                if gene_dense:
+                    for bi, qi, cols_d, segs_d in dense_gene_plants(w, nb, rank, my_cols, args.k):
+                        orc.insert_kmer_masks(orc.rows_of(all_seqs[bi][qi]), cols_d, seg_masks(segs_d, n_kmers, args.k), only)
+                else:
+                    ones = np.ones((DENSE_READ_HITS, n_kmers), dtype=bool)
+                    for bi in range(nb):
+                        for r_, sq in enumerate(all_seqs[bi]):
+                            orc.insert_kmer_masks(orc.rows_of(sq), dense_read_cols(bi, r_, rank, my_cols), ones, only)
+            elif w["score"]:
                 for bi, qi, c in score_plants(rank, my_cols):
                     orc.insert_kmers(c, all_seqs[bi][qi][:plant_len])
-            sample = sorted(set([planted[0], 1 % w["batch"], w["batch"] // 2, w["batch"] - 1]))
             for qi in sample:
                 u, cnt = orc.counts(seqs[qi])
                 want = np.flatnonzero(cnt >= (u if exact else mk[qi]))
@@ -903,7 +1013,7 @@ def main():
                 from oracle import coracle
                 from oracle.ref_model import Scorer as OracleScorer
                 osc = OracleScorer(total_cols)
-                for qi in (0, min(15, w["batch"] - 1)):
+                for qi in scored_sample:
                     kmers, uniq, rows_q = orc.per_kmer_rows(seqs[qi])
                     cnt = coracle.unpack_and_sum(rows_q)[:my_cols]
                     u = len(uniq)
@@ -969,6 +1079,12 @@ def main():
                 "workload_key": args.workload, "rows": w["rows"], "cols_per_gpu": shard_cols, "total_cols": total_cols,
                 "index_gb_per_gpu": info.index_bytes / 1e9, "hashes": w["hashes"], "batch": w["batch"], "qlen": w["qlen"],
                 "unique_kmers_per_batch": total_unique, "hits_first_batch": int(off[-1]),
+                "dense": None if not args.dense else
+                ("first %d queries of every batch held, 0-%d SNPs apart, by %g %% of the shard's samples" % (DENSE_QUERIES, DENSE_MAX_SNPS, 100 * DENSE_COL_FRACTION)
+                 if gene_dense else "every read held by %d samples" % DENSE_READ_HITS),
+                "dense_plant_s": dense_s if args.dense else None,
+                "hits_per_s": int(off[-1]) / (elapsed / args.steps) if args.dense else None,
+                "k5_traffic_ratio": k5_ratio,
                 "value_is": "unique query k-mers per second against the %d samples held by this run, exchange included" % total_cols,
                 "shard_lookups_per_s_sum": rate * world,
                 "aggregate_GBps": sum(per_rank_gbs), "per_rank_GBps": per_rank_gbs,

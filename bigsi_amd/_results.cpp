@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstring>
 #include <vector>
 
 #include "csrc/bigsi_score.hpp"
@@ -130,6 +131,172 @@ PyObject *build(PyObject *, PyObject *args)
     return out;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// build_scored: the same lists for score=True, straight from what K6 returns -- 64-byte score records + packed presence bits --
+// without the intermediate numpy columns, the one big text str and a substring per hit of build() above (1.7 us per hit there,
+// most of it outside the dict: 18 column arrays made, 18 x indexed, a 1 KB substring copied out of a 10 MB str).  Per hit:
+//   * the integer / quotient fields of Scorer.score (score.py:99-111) from the record: plain IEEE arithmetic, the same
+//     expressions as scoring.score_columns (this file is compiled with -ffp-contract=off);
+//   * evalue, pvalue, log_evalue, log_pvalue arrive as four float64 arrays: numpy's exp / log10 (what the reference calls) are
+//     not reproducible by libm bit for bit, so they stay numpy's (scoring.score_transcendentals);
+//   * "kmer-presence": the hit's n bits (bitarray order: position p = byte p / 8, mask 0x80 >> p % 8) -> n characters, 8 at a
+//     time through a 256-entry table, written into the new str's own body;
+//   * the dict is a COPY of a 22-key template (one allocation + memcpy of the key table: CPython clones a combined table whose
+//     entries are all live) whose values are then replaced in key order -- no probing for free slots, no growth;
+//   * small non-negative integers (lengths, identities, mismatch counts: < 2^14 for anything up to 16 kbp) come from a table of
+//     ready-made int objects.
+// build_scored(nu, off, cols, cnts, exact, names, keys, rec, bits, boff, trans, db_size_unused, lo, hi)
+//   rec: buffer of 64-byte records (HIT_SCORE_DTYPE), bits uint8[], boff uint64[hits + 1] (byte offsets, multiples of 8),
+//   trans: tuple of 4 float64 arrays over the hits
+struct IntCache {
+    std::vector<PyObject *> v;
+    ~IntCache() { /* objects are immortal for the life of the module */ }
+    PyObject *get(int64_t x)      // new reference
+    {
+        if (x >= 0 && x < (int64_t)(1 << 14)) {
+            if (v.empty()) v.assign(1 << 14, nullptr);
+            PyObject *&o = v[(size_t)x];
+            if (!o) { o = PyLong_FromLongLong(x); if (!o) return nullptr; }
+            Py_INCREF(o);
+            return o;
+        }
+        return PyLong_FromLongLong(x);
+    }
+};
+IntCache g_ints;
+
+struct Rec {                 // bigsi_score::HitScore / HIT_SCORE_DTYPE
+    double score, min_score, max_score, percent;
+    int64_t max_mm, min_mm, mm;
+    uint32_t n, reserved;
+};
+static_assert(sizeof(Rec) == 64, "score record layout");
+
+uint64_t g_lut[256];
+bool g_lut_ready = false;
+void lut_init()
+{
+    for (int b = 0; b < 256; b++) {
+        uint64_t w = 0;
+        for (int i = 0; i < 8; i++) w |= (uint64_t)('0' + ((b >> (7 - i)) & 1)) << (8 * i);      // character i = bit 0x80 >> i (little-endian store)
+        g_lut[b] = w;
+    }
+    g_lut_ready = true;
+}
+
+PyObject *presence_str(const uint8_t *bits, uint32_t n)
+{
+    PyObject *s = PyUnicode_New((Py_ssize_t)n, 127);
+    if (!s) return nullptr;
+    uint8_t *dst = static_cast<uint8_t *>(PyUnicode_DATA(s));
+    const uint32_t full = n >> 3;
+    for (uint32_t i = 0; i < full; i++) memcpy(dst + 8 * (size_t)i, &g_lut[bits[i]], 8);
+    if (n & 7u) memcpy(dst + 8 * (size_t)full, &g_lut[bits[full]], n & 7u);
+    return s;
+}
+
+PyObject *build_scored(PyObject *, PyObject *args)
+{
+    PyObject *o_nu, *o_off, *o_cols, *o_cnts, *names, *keys, *o_rec, *o_bits, *o_boff, *trans;
+    int exact;
+    Py_ssize_t lo, hi;
+    if (!PyArg_ParseTuple(args, "OOOOpOOOOOOnn", &o_nu, &o_off, &o_cols, &o_cnts, &exact, &names, &keys, &o_rec, &o_bits, &o_boff, &trans, &lo, &hi))
+        return nullptr;
+    Buf nu, off, cols, cnts, rec, bits, boff, tr[4];
+    if (!nu.get(o_nu, "nu", 4) || !off.get(o_off, "off", 8) || !cols.get(o_cols, "cols", 4) || !cnts.get(o_cnts, "cnts", 4)) return nullptr;
+    if (!rec.get(o_rec, "rec", 64) || !bits.get(o_bits, "bits", 1) || !boff.get(o_boff, "boff", 8)) return nullptr;
+    if (!PyList_Check(names) || !PyTuple_Check(keys) || PyTuple_GET_SIZE(keys) != 22) { PyErr_SetString(PyExc_TypeError, "names must be a list, keys a tuple of 22"); return nullptr; }
+    if (!PyTuple_Check(trans) || PyTuple_GET_SIZE(trans) != 4) { PyErr_SetString(PyExc_TypeError, "trans: a tuple of 4 float64 arrays"); return nullptr; }
+    const Py_ssize_t n_seqs = nu.n(), n_hits = cols.n(), n_names = PyList_GET_SIZE(names);
+    for (int i = 0; i < 4; i++) {
+        if (!tr[i].get(PyTuple_GET_ITEM(trans, i), "trans", 8)) return nullptr;
+        const char *f = tr[i].b.format ? tr[i].b.format : "";
+        while (*f == '<' || *f == '=' || *f == '@') f++;
+        if (*f != 'd' || tr[i].n() < n_hits) { PyErr_SetString(PyExc_TypeError, "trans: float64 arrays over the hits expected"); return nullptr; }
+    }
+    if (lo < 0 || hi < lo || hi > n_seqs || off.n() < n_seqs + 1) { PyErr_SetString(PyExc_ValueError, "bad sequence range"); return nullptr; }
+    const uint32_t *p_nu = static_cast<const uint32_t *>(nu.b.buf), *p_col = static_cast<const uint32_t *>(cols.b.buf), *p_cnt = static_cast<const uint32_t *>(cnts.b.buf);
+    const int64_t *p_off = static_cast<const int64_t *>(off.b.buf);
+    const Rec *p_rec = static_cast<const Rec *>(rec.b.buf);
+    const uint8_t *p_bits = static_cast<const uint8_t *>(bits.b.buf);
+    const uint64_t *p_boff = static_cast<const uint64_t *>(boff.b.buf);
+    const double *p_tr[4];
+    for (int i = 0; i < 4; i++) p_tr[i] = static_cast<const double *>(tr[i].b.buf);
+    if (p_off[hi] > n_hits || cnts.n() < n_hits || rec.n() < n_hits || boff.n() < n_hits + 1) { PyErr_SetString(PyExc_ValueError, "hit offsets beyond the hit arrays"); return nullptr; }
+    if (n_hits && p_boff[n_hits] > (uint64_t)bits.n()) { PyErr_SetString(PyExc_ValueError, "bit offsets beyond the bits"); return nullptr; }
+    if (!g_lut_ready) lut_init();
+    PyObject *k[22];
+    for (int i = 0; i < 22; i++) k[i] = PyTuple_GET_ITEM(keys, i);
+    PyObject *tmpl = PyDict_New();
+    if (!tmpl) return nullptr;
+    for (int i = 0; i < 22; i++)
+        if (PyDict_SetItem(tmpl, k[i], Py_None) != 0) { Py_DECREF(tmpl); return nullptr; }
+    PyObject *out = PyList_New(hi - lo);
+    if (!out) { Py_DECREF(tmpl); return nullptr; }
+    std::vector<int64_t> order;
+    bool ok = true;
+    for (Py_ssize_t i = lo; i < hi && ok; i++) {
+        const uint32_t u = p_nu[i];
+        order.clear();
+        for (int64_t t = p_off[i]; t < p_off[i + 1]; t++) {
+            const uint32_t c = p_col[t];
+            if ((Py_ssize_t)c >= n_names || PyList_GET_ITEM(names, c) == Py_None) continue;
+            order.push_back(t);
+        }
+        if (!exact && order.size() > 1)          // inexact_filter: stable sort by count, descending (graph/bigsi.py:215-229)
+            std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return p_cnt[a] > p_cnt[b]; });
+        PyObject *res = PyList_New((Py_ssize_t)order.size());
+        if (!res) { ok = false; break; }
+        PyList_SET_ITEM(out, i - lo, res);
+        if (order.empty()) continue;
+        PyObject *py_u = g_ints.get(u);
+        if (!py_u) { ok = false; break; }
+        for (size_t r = 0; r < order.size() && ok; r++) {
+            const int64_t t = order[r];
+            const Rec &rc = p_rec[t];
+            const uint32_t f = exact ? u : p_cnt[t];
+            PyObject *d = PyDict_Copy(tmpl);
+            if (!d) { ok = false; break; }
+            PyList_SET_ITEM(res, (Py_ssize_t)r, d);
+            auto put = [&](int kk, PyObject *v) {      // steals v
+                if (!v) { ok = false; return; }
+                if (ok && PyDict_SetItem(d, k[kk], v) != 0) ok = false;
+                Py_DECREF(v);
+            };
+            if (rc.n == 0) { PyErr_SetString(PyExc_ZeroDivisionError, "division by zero"); ok = false; break; }      // score.py:99-100
+            const int64_t seq_len = (int64_t)rc.n + 30;                  // n + k - 1, k = 31 (score.py:61,99)
+            const double fl = (double)seq_len;
+            const int64_t max_nident = seq_len - rc.min_mm, nident = seq_len - rc.mm, min_nident = seq_len - rc.max_mm;
+            put(0, PyFloat_FromDouble(rc.percent));
+            Py_INCREF(py_u);
+            put(1, py_u);
+            put(2, g_ints.get(f));
+            PyObject *nm = PyList_GET_ITEM(names, p_col[t]);
+            Py_INCREF(nm);
+            put(3, nm);
+            put(4, PyFloat_FromDouble(rc.score));
+            put(5, PyFloat_FromDouble(rc.min_score));
+            put(6, PyFloat_FromDouble(rc.max_score));
+            put(7, g_ints.get(rc.max_mm));
+            put(8, g_ints.get(rc.min_mm));
+            put(9, g_ints.get(rc.mm));
+            put(10, g_ints.get(max_nident));
+            put(11, g_ints.get(nident));
+            put(12, g_ints.get(min_nident));
+            put(13, PyFloat_FromDouble(100.0 * (double)nident / fl));           // pident = 100 * float(nident) / seq_len (score.py:106-111)
+            put(14, PyFloat_FromDouble(100.0 * (double)max_nident / fl));
+            put(15, PyFloat_FromDouble(100.0 * (double)min_nident / fl));
+            put(16, g_ints.get(seq_len));
+            for (int j = 0; j < 4; j++) put(17 + j, PyFloat_FromDouble(p_tr[j][t]));
+            put(21, presence_str(p_bits + p_boff[t], rc.n));
+        }
+        Py_DECREF(py_u);
+    }
+    Py_DECREF(tmpl);
+    if (!ok) { Py_DECREF(out); return nullptr; }
+    return out;
+}
+
 // ascii_str(n) -> (s, address): a new str of n ASCII characters whose body (n bytes at `address`) the caller fills before anything
 // reads s -- bigsi_hip_format_results writes the text of a bulk search straight into it (no bytes -> str copy of a few hundred MB)
 PyObject *ascii_str(PyObject *, PyObject *args)
@@ -143,6 +310,7 @@ PyObject *ascii_str(PyObject *, PyObject *args)
 }
 
 PyMethodDef methods[] = {{"build", build, METH_VARARGS, "result dicts of the sequences [lo, hi) of a streaming search (see _results.cpp)"},
+                         {"build_scored", build_scored, METH_VARARGS, "the same for score=True, from K6's records and presence bits"},
                          {"ascii_str", ascii_str, METH_VARARGS, "(str of n ASCII characters to be filled, address of its body)"},
                          {nullptr, nullptr, 0, nullptr}};
 PyModuleDef module = {PyModuleDef_HEAD_INIT, "_results", "result dicts of BIGSI.search_stream, built in C++", -1, methods, nullptr, nullptr, nullptr, nullptr};

@@ -78,28 +78,27 @@ def native_result_lists(nk, nu, off64, cols, counts, exact, names, scored, db_si
     colours per sequence), names[c] = sample name or None (deleted: dropped), scored = None or (records, bits, bit_offsets) of K6
     (QueryBatch.score_hits_end / search_many_scored).  Same dicts as BIGSI._emit's Python loop and as search(); the caller deals with
     the queries the reference raises on.  `block` sequences are assembled per call of the extension."""
-    from ..scoring import SCORE_KEYS, score_columns, unpack_presence
+    from ..scoring import SCORE_KEYS, score_transcendentals
     n, total = len(nu), int(off64[len(nu)])
     keys = ("percent_kmers_found", "num_kmers", "num_kmers_found", "sample_name")
-    columns = text = tstart = tlen = None
-    if scored is not None:
-        keys = keys + SCORE_KEYS + ("kmer-presence",)
-        rec, bits, boff = scored
-        if total:
-            rec = rec[:total]
-            columns = tuple([np.ascontiguousarray(rec["percent_kmers_found"])] + [np.ascontiguousarray(c) for c in score_columns(rec, db_size, as_arrays=True)])
-            text = unpack_presence(bits[:int(boff[total])], boff[:total + 1])
-            tstart = boff[:total].astype(np.int64) * 8
-            tlen = np.repeat(np.asarray(nk[:n], dtype=np.int64), np.diff(off64[:n + 1]))
-        else:
-            columns = tuple(np.zeros(0, np.float64) for _ in range(18))
-            text, tstart, tlen = "", np.zeros(0, np.int64), np.zeros(0, np.int64)
     nu = np.ascontiguousarray(nu, dtype=np.uint32)
     off64 = np.ascontiguousarray(off64, dtype=np.int64)
     cols = np.ascontiguousarray(cols[:total], dtype=np.uint32)
     cnts = np.ascontiguousarray(counts[:total], dtype=np.uint32) if counts is not None and len(counts) >= total else np.zeros(total, np.uint32)
+    if scored is not None:
+        # K6's records and presence bits go to the extension as they are; only the four fields that need numpy's exp / log10 are
+        # computed here, for all hits at once (scoring.score_transcendentals)
+        keys = keys + SCORE_KEYS + ("kmer-presence",)
+        rec, bits, boff = scored
+        rec = np.ascontiguousarray(rec[:total])
+        trans = tuple(np.ascontiguousarray(c, dtype=np.float64) for c in score_transcendentals(rec, db_size))
+        bits = np.ascontiguousarray(bits, dtype=np.uint8)
+        boff = np.ascontiguousarray(boff[:total + 1], dtype=np.uint64)
+        for lo in range(0, n, block):
+            yield from _results.build_scored(nu, off64, cols, cnts, bool(exact), names, keys, rec, bits, boff, trans, lo, min(n, lo + block))
+        return
     for lo in range(0, n, block):
-        yield from _results.build(nu, off64, cols, cnts, bool(exact), names, keys, columns, text, tstart, tlen, lo, min(n, lo + block))
+        yield from _results.build(nu, off64, cols, cnts, bool(exact), names, keys, None, None, None, None, lo, min(n, lo + block))
 
 
 class BigsiQueryResult(object):

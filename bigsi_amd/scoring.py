@@ -195,6 +195,25 @@ def unpack_presence(bits, offsets):
     return str(memoryview(chars), "ascii")
 
 
+def score_transcendentals(rec, db_size):
+    """(evalue, pvalue, log_evalue, log_pvalue) of score_columns below for every record, as four float64 arrays: the fields that go
+    through numpy's exp / log10 (score.py:125-151), for the C++ result builder (bigsi_amd/_results.cpp: build_scored), which derives
+    everything else from the records itself."""
+    n = rec["num_kmers"].astype(np.int64)
+    if n.size and not n.all():
+        raise ZeroDivisionError("division by zero")
+    fl = (n + (_K - 1)).astype(np.float64)
+    score = rec["score"]
+    with np.errstate(over="ignore", under="ignore", divide="ignore"):
+        evalue = K_UNGAPPED * db_size * fl * np.exp(-LAMBDA_UNGAPPED * score)
+        pvalue = 1 - np.exp(-evalue)
+        m = db_size if db_size != 0 else 1
+        log_evalue = np.round(np.round(np.log10(K_UNGAPPED * m * fl) - LAMBDA_UNGAPPED * score, 2), 2)
+        p = 1 - np.exp(-np.power(10.0, log_evalue))
+        log_pvalue = np.round(np.round(np.where(p > 0, np.log10(np.where(p > 0, p, 1.0)), log_evalue), 2), 2)
+    return evalue, pvalue, log_evalue, log_pvalue
+
+
 def score_columns(rec, db_size, as_arrays=False):
     """The 17 fields of Scorer.score (score.py:96-121) for every record of `rec` (HIT_SCORE_DTYPE), as one Python list per key of
     SCORE_KEYS.  A record with num_kmers == 0 divides by zero in the reference (score.py:99-100): ZeroDivisionError."""

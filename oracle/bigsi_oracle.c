@@ -91,6 +91,13 @@ void orc_kmer_rows(const uint8_t *kmer, uint64_t k, uint32_t h, uint64_t m, uint
     if (canon != stackbuf) free(canon);
 }
 
+/* the same for every k-mer position of a sequence (seq_to_kmers, utils/fncts.py:63-65): rows_out[i*h + s] */
+void orc_seq_rows(const uint8_t *seq, uint64_t len, uint64_t k, uint32_t h, uint64_t m, uint64_t *rows_out)
+{
+    if (len < k) return;
+    for (uint64_t i = 0; i + k <= len; i++) orc_kmer_rows(seq + i, k, h, m, rows_out + i * h);
+}
+
 /* ----------------------------------------------------- unique query k-mers */
 
 typedef struct { const uint8_t *seq; uint64_t k; } cmp_ctx;

@@ -31,6 +31,7 @@ def lib():
         L.orc_reverse_comp.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p]
         L.orc_canonical.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p]
         L.orc_kmer_rows.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p]
+        L.orc_seq_rows.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p]
         L.orc_unique_kmers.restype = C.c_uint32
         L.orc_unique_kmers.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
         L.orc_and_rows.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]
@@ -83,6 +84,16 @@ def kmer_rows(kmer, h, m):
     out = np.zeros(h, dtype=np.uint64)
     lib().orc_kmer_rows(b, len(b), h, m, out.ctypes.data)
     return [int(x) for x in out]
+
+
+def seq_rows(seq, k, h, m):
+    """uint64[n, h]: the h rows of every k-mer position of seq (one C call)."""
+    b = _b(seq)
+    n = max(len(b) - k + 1, 0)
+    out = np.zeros((n, h), dtype=np.uint64)
+    if n:
+        lib().orc_seq_rows(b, len(b), k, h, m, out.ctypes.data)
+    return out
 
 
 def unique_kmers(seq, k):

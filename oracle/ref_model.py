@@ -224,10 +224,35 @@ class SynthOracle:
             for r in coracle.kmer_rows(km, self.h, self.m):
                 self.planted.setdefault(r, set()).add(colour)
 
+    def insert_kmer_masks(self, rows_of_kmers, cols, masks, only_rows=None):
+        """The same for many samples at once: k-mer i of a sequence (rows_of_kmers[i] = its h rows, from kmer_rows) is added to
+        sample cols[j] where masks[j][i]; only_rows (a uint64 array) keeps the bookkeeping to the rows a later check will read."""
+        masks = np.asarray(masks, dtype=bool)
+        cols = np.asarray(cols)
+        rows_of_kmers = np.asarray(rows_of_kmers, dtype=np.uint64)
+        if only_rows is not None:
+            keep = np.isin(rows_of_kmers, only_rows)
+            todo = np.flatnonzero(keep.any(axis=1))
+        else:
+            keep, todo = None, range(len(rows_of_kmers))
+        for i in todo:
+            sel = cols[masks[:, i]].tolist()
+            if not sel:
+                continue
+            for s_, r in enumerate(rows_of_kmers[i].tolist()):
+                if keep is None or keep[i, s_]:
+                    self.planted.setdefault(r, set()).update(sel)
+
+    def rows_of(self, seq):
+        """uint64[n, h]: the h rows of every k-mer position of seq (duplicates included)."""
+        return coracle.seq_rows(seq, self.k, self.h, self.m)
+
     def row(self, r):
         out = coracle.synth_row(self.seed, self.shard, r, self.n_cols, self.and_draws)
-        for c in self.planted.get(r, ()):
-            out[c >> 3] |= 0x80 >> (c & 7)
+        cols = self.planted.get(r)
+        if cols:
+            c = np.fromiter(cols, dtype=np.int64, count=len(cols))
+            np.bitwise_or.at(out, c >> 3, (0x80 >> (c & 7)).astype(np.uint8))
         return out
 
     def per_kmer_rows(self, seq):
