@@ -73,6 +73,11 @@ def main(argv=None):
     sp.add_argument("bloomfilter")
     sp.add_argument("sample")
     common(sub.add_parser("delete"))
+    sp = common(sub.add_parser("hold", help="load the index and keep it resident in HBM for OTHER processes: writes an attach file (hipIpc handle + "
+                                            "metadata); `search` / `bulk_search` with storage-config {attach: FILE} then open it in milliseconds"))
+    sp.add_argument("--handle", default=None, help="the attach file (default: storage-config `export`, else <filename>.attach)")
+    sp.add_argument("--seconds", type=float, default=None, help="exit after this long (default: until SIGTERM / SIGINT)")
+    sp.add_argument("--until-eof", action="store_true", help="also exit when stdin ends (a parent process that holds the other end of a pipe)")
     sp = common(sub.add_parser("import-bdb", help="load an existing BerkeleyDB index (v0.3 file, or a v0.1 directory with graph + metadata) into HBM"))
     sp.add_argument("path")
     a = p.parse_args(argv)
@@ -123,7 +128,44 @@ def main(argv=None):
             print("rows=%d cols=%d" % bdb.import_index(a.path, dst))
     elif a.cmd == "delete":
         get_storage(config).delete_all()
+    elif a.cmd == "hold":
+        hold(config, a.handle, a.seconds, a.until_eof)
     return 0
+
+
+def hold(config, handle=None, seconds=None, until_eof=False):
+    """The process that keeps an index resident for others (the reference's store is a file every request and pool worker opens
+    again, bigsi/__main__.py:75-80, 204-205; a 125 GB matrix should be ingested once).  Prints one line when the attach file is
+    in place, then waits -- for SIGTERM / SIGINT, `seconds`, or (until_eof) the end of stdin -- removes the file and exits."""
+    import signal
+    import threading
+    import time
+    index = BIGSI(config)
+    sc = config.get("storage-config", {})
+    path = handle or sc.get("export") or ((sc.get("filename") or "bigsi-%s" % sc.get("name", "default")) + ".attach")
+    index.storage.export_attach(path)
+    print(json.dumps({"result": "holding", "attach": os.path.abspath(path), "pid": os.getpid(), "num_samples": index.num_samples}), flush=True)
+    stop = threading.Event()
+    for sig in (signal.SIGTERM, signal.SIGINT):
+        signal.signal(sig, lambda *_: stop.set())
+
+    def until_eof():
+        try:
+            while sys.stdin.read(4096):
+                pass
+        except (OSError, ValueError):
+            return
+        stop.set()
+    if until_eof:
+        threading.Thread(target=until_eof, daemon=True).start()
+    t0 = time.time()
+    while not stop.wait(0.2):
+        if seconds is not None and time.time() - t0 >= seconds:
+            break
+    try:
+        os.remove(path)
+    except OSError:
+        pass
 
 
 def build_inputs(a):

@@ -75,6 +75,9 @@ SIGNATURES = {
     "bigsi_hip_device_count": (_i32, [C.POINTER(C.c_int)]),
     "bigsi_hip_open": (_i32, [_u64, _u64, _u64, _u32, _i32, C.POINTER(_P)]),
     "bigsi_hip_close": (_i32, [_P]),
+    "bigsi_hip_export_ipc": (_i32, [_P, _P]),
+    "bigsi_hip_open_ipc": (_i32, [_P, _u64, _u64, _u64, _u32, _i32, C.POINTER(_P)]),
+    "bigsi_hip_open_view": (_i32, [_P, C.POINTER(_P)]),
     "bigsi_hip_get_info": (_i32, [_P, C.POINTER(Info)]),
     "bigsi_hip_set_num_cols": (_i32, [_P, _u64]),
     "bigsi_hip_set_num_hashes": (_i32, [_P, _u32]),

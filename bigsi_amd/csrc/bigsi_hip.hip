@@ -148,8 +148,17 @@ static hipError_t index_malloc(uint64_t **out, size_t bytes, bool *contiguous)
 }
 
 // ------------------------------------------------------------------------------ lifecycle
-extern "C" int bigsi_hip_open(uint64_t num_rows, uint64_t num_cols, uint64_t col_capacity, uint32_t num_hashes, int device,
-                              bigsi_hip_index **out)
+int bigsi_writable(const bigsi_hip_index *ix)
+{
+    if (ix && ix->attach != bigsi_hip_index::kOwner)
+        return fail(BIGSI_ERR_STATE, "this handle does not own its matrix (%s): it is read-only", ix->attach == bigsi_hip_index::kIpc ? "attached over hipIpc" : "a view");
+    return BIGSI_OK;
+}
+
+// the matrix of a new handle: allocated and zeroed here (ipc == nullptr && view == nullptr), another process's allocation mapped
+// into this one (ipc), or another handle's pointer (view)
+static int open_impl(uint64_t num_rows, uint64_t num_cols, uint64_t col_capacity, uint32_t num_hashes, int device, const hipIpcMemHandle_t *ipc,
+                     const bigsi_hip_index *view, bigsi_hip_index **out)
 {
     if (!out) return fail(BIGSI_ERR_INVALID, "out is NULL");
     *out = nullptr;
@@ -187,6 +196,29 @@ extern "C" int bigsi_hip_open(uint64_t num_rows, uint64_t num_cols, uint64_t col
         return fail(BIGSI_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
     const size_t bytes = (size_t)ix->m * ix->stride_words * 8;
+    if (view) {
+        ix->d_index = view->d_index;
+        ix->attach = bigsi_hip_index::kView;
+        ix->view_of = const_cast<bigsi_hip_index *>(view);
+        ix->view_of->views++;
+        *out = ix;
+        return BIGSI_OK;
+    }
+    if (ipc) {
+        void *p = nullptr;
+        e = hipIpcOpenMemHandle(&p, *ipc, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            hipError_t e2 = hipStreamDestroy(ix->own_stream); (void)e2;
+            e2 = hipStreamDestroy(ix->pre_stream);
+            delete ix;
+            return fail(BIGSI_ERR_HIP, "hipIpcOpenMemHandle: %s (the owner must be another live process on this device; HSA_ENABLE_IPC_MODE_LEGACY=0 on hosts whose "
+                                       "driver only does dmabuf IPC)", hipGetErrorString(e));
+        }
+        ix->d_index = static_cast<uint64_t *>(p);
+        ix->attach = bigsi_hip_index::kIpc;
+        *out = ix;
+        return BIGSI_OK;
+    }
     e = index_malloc(&ix->d_index, bytes, &ix->contiguous);
     if (e != hipSuccess) {
         hipError_t e2 = hipStreamDestroy(ix->own_stream); (void)e2;
@@ -207,6 +239,59 @@ extern "C" int bigsi_hip_open(uint64_t num_rows, uint64_t num_cols, uint64_t col
     return BIGSI_OK;
 }
 
+extern "C" int bigsi_hip_open(uint64_t num_rows, uint64_t num_cols, uint64_t col_capacity, uint32_t num_hashes, int device,
+                              bigsi_hip_index **out)
+{
+    return open_impl(num_rows, num_cols, col_capacity, num_hashes, device, nullptr, nullptr, out);
+}
+
+// ------------------------------------------------------------------------------ an index shared between processes / threads
+// The reference opens its store once per request and once per pool worker (bigsi/__main__.py:75-80, 204-205;
+// storage/berkeleydb.py:12-19): the data lives in a file, any process can open it.  Here the data lives in ONE process's HBM
+// allocation; these three give other handles onto it without a second copy:
+//   export_ipc   the owner's matrix as a 64-byte hipIpc handle (any byte channel carries it: a file, a socket)
+//   open_ipc     another PROCESS maps that allocation: a read-only handle with streams / workspaces of its own.  The caller passes
+//                the owner's geometry (rows, columns, column capacity, hashes: bigsi_hip_get_info there).  The owner must stay
+//                alive and must not close / re-stride (reserve_cols) the index while handles are attached.
+//   open_view    another THREAD of the owner's process: the same, without the mapping (hipIpc does not open a handle in the
+//                process that made it).  The owner handle must outlive its views.
+static_assert(sizeof(hipIpcMemHandle_t) == BIGSI_IPC_HANDLE_BYTES, "hipIpc handle size");
+
+extern "C" int bigsi_hip_export_ipc(bigsi_hip_index *ix, uint8_t *handle)
+{
+    if (!ix || !handle) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    BIGSI_ENTER(ix);
+    if (ix->attach != bigsi_hip_index::kOwner) return fail(BIGSI_ERR_STATE, "only the handle that owns the matrix can export it");
+    TRY(use_device(ix));
+    TRY(quiesce_index(ix));
+    HIP_TRY(hipStreamSynchronize(ix->stream));       // whatever filled the matrix is visible to the process that maps it next
+    hipIpcMemHandle_t h;
+    HIP_TRY(hipIpcGetMemHandle(&h, ix->d_index));
+    memcpy(handle, &h, sizeof h);
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_open_ipc(const uint8_t *handle, uint64_t num_rows, uint64_t num_cols, uint64_t col_capacity, uint32_t num_hashes,
+                                  int device, bigsi_hip_index **out)
+{
+    if (!handle) return fail(BIGSI_ERR_INVALID, "handle is NULL");
+    if (num_cols > col_capacity) return fail(BIGSI_ERR_INVALID, "num_cols %llu exceeds the owner's column capacity %llu", (unsigned long long)num_cols, (unsigned long long)col_capacity);
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, sizeof h);
+    return open_impl(num_rows, num_cols, col_capacity, num_hashes, device, &h, nullptr, out);
+}
+
+extern "C" int bigsi_hip_open_view(bigsi_hip_index *owner, bigsi_hip_index **out)
+{
+    if (!owner || !out) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    BIGSI_ENTER(owner);
+    TRY(use_device(owner));
+    TRY(quiesce_index(owner));
+    HIP_TRY(hipStreamSynchronize(owner->stream));    // (streams of different handles are not ordered with each other)
+    TRY(open_impl(owner->m, owner->n_cols, owner->cap_cols, owner->h, owner->device, nullptr, owner, out));
+    return BIGSI_OK;
+}
+
 static void recycle_events(bigsi_hip_index *ix)
 {
     for (auto *v : {&ix->ev_and, &ix->ev_km, &ix->ev_cp, &ix->ev_pr, &ix->ev_tr, &ix->ev_ex}) {
@@ -218,6 +303,12 @@ static void recycle_events(bigsi_hip_index *ix)
 extern "C" int bigsi_hip_close(bigsi_hip_index *ix)
 {
     if (!ix) return BIGSI_OK;
+    {
+        BusyGuard g(ix);
+        if (!g.ok) return fail(BIGSI_ERR_STATE, "bigsi_hip_close: the handle is in use by another host thread");
+        g.release();      // (the guard must not outlive the handle; whoever closes a handle owns it)
+    }
+    if (ix->views.load() > 0) return fail(BIGSI_ERR_STATE, "bigsi_hip_close: %d view(s) of this index are still open (close them first)", ix->views.load());
     if (ix->search_ws) {
         bigsi_hip_batch_destroy(ix->search_ws);
         ix->search_ws = nullptr;
@@ -235,7 +326,9 @@ extern "C" int bigsi_hip_close(bigsi_hip_index *ix)
     for (auto &p : ix->ev_free) { e = hipEventDestroy(p.a); e = hipEventDestroy(p.b); }
     ix->stage.release();
     ix->stage_ids.release();
-    if (ix->d_index) e = hipFree(ix->d_index);
+    if (ix->view_of) ix->view_of->views--;
+    if (ix->d_index && ix->attach == bigsi_hip_index::kOwner) e = hipFree(ix->d_index);
+    else if (ix->d_index && ix->attach == bigsi_hip_index::kIpc) e = hipIpcCloseMemHandle(ix->d_index);
     if (ix->own_stream) e = hipStreamDestroy(ix->own_stream);
     if (ix->pre_stream) e = hipStreamDestroy(ix->pre_stream);
     (void)e;
@@ -259,6 +352,7 @@ extern "C" int bigsi_hip_get_info(const bigsi_hip_index *ix, bigsi_hip_info *out
 
 extern "C" int bigsi_hip_set_num_cols(bigsi_hip_index *ix, uint64_t num_cols)
 {
+    BIGSI_ENTER(ix);
     if (!ix) return fail(BIGSI_ERR_INVALID, "NULL index");
     if (num_cols > ix->cap_cols)
         return fail(BIGSI_ERR_CAPACITY, "num_cols %llu exceeds col_capacity %llu (call bigsi_hip_reserve_cols)",
@@ -269,6 +363,7 @@ extern "C" int bigsi_hip_set_num_cols(bigsi_hip_index *ix, uint64_t num_cols)
 
 extern "C" int bigsi_hip_set_num_hashes(bigsi_hip_index *ix, uint32_t num_hashes)
 {
+    BIGSI_ENTER(ix);
     if (!ix) return fail(BIGSI_ERR_INVALID, "NULL index");
     if (num_hashes == 0) return fail(BIGSI_ERR_INVALID, "num_hashes must be > 0");
     ix->h = num_hashes;
@@ -277,9 +372,12 @@ extern "C" int bigsi_hip_set_num_hashes(bigsi_hip_index *ix, uint32_t num_hashes
 
 extern "C" int bigsi_hip_reserve_cols(bigsi_hip_index *ix, uint64_t col_capacity)
 {
+    BIGSI_ENTER(ix);
+    TRY(bigsi_writable(ix));
     if (!ix) return fail(BIGSI_ERR_INVALID, "NULL index");
     if (col_capacity <= ix->cap_cols) return BIGSI_OK;
     if (col_capacity > 0xFFFFFFFFull) return fail(BIGSI_ERR_INVALID, "col_capacity exceeds 2^32-1");
+    if (ix->views.load() > 0) return fail(BIGSI_ERR_STATE, "bigsi_hip_reserve_cols: re-striding would move the matrix under %d open view(s)", ix->views.load());
     TRY(use_device(ix));
     TRY(quiesce_index(ix));
     const uint64_t ns = stride_for(col_capacity);
@@ -301,6 +399,7 @@ extern "C" int bigsi_hip_reserve_cols(bigsi_hip_index *ix, uint64_t col_capacity
 
 extern "C" int bigsi_hip_set_stream(bigsi_hip_index *ix, void *hip_stream)
 {
+    BIGSI_ENTER(ix);
     if (!ix) return fail(BIGSI_ERR_INVALID, "NULL index");
     TRY(use_device(ix));
     TRY(quiesce_index(ix));
@@ -311,6 +410,7 @@ extern "C" int bigsi_hip_set_stream(bigsi_hip_index *ix, void *hip_stream)
 
 extern "C" int bigsi_hip_synchronize(bigsi_hip_index *ix)
 {
+    BIGSI_ENTER(ix);
     if (!ix) return fail(BIGSI_ERR_INVALID, "NULL index");
     TRY(use_device(ix));
     TRY(quiesce_index(ix));
@@ -326,6 +426,8 @@ static const uint64_t kIoChunkBytes = 256ull << 20;      // one pinned buffer of
 
 extern "C" int bigsi_hip_set_rows(bigsi_hip_index *ix, const uint64_t *row_ids, uint64_t n, const uint8_t *bytes, uint64_t row_bytes)
 {
+    BIGSI_ENTER(ix);
+    TRY(bigsi_writable(ix));
     if (!ix || (n && (!row_ids || !bytes))) return fail(BIGSI_ERR_INVALID, "NULL argument");
     if (row_bytes == 0 || row_bytes > ix->stride_words * 8)
         return fail(BIGSI_ERR_CAPACITY, "row_bytes %llu not in [1, %llu] (row stride)", (unsigned long long)row_bytes,
@@ -351,6 +453,7 @@ extern "C" int bigsi_hip_set_rows(bigsi_hip_index *ix, const uint64_t *row_ids, 
 
 extern "C" int bigsi_hip_get_rows(bigsi_hip_index *ix, const uint64_t *row_ids, uint64_t n, uint8_t *out, uint64_t row_bytes)
 {
+    BIGSI_ENTER(ix);
     if (!ix || (n && (!row_ids || !out))) return fail(BIGSI_ERR_INVALID, "NULL argument");
     if (row_bytes == 0) return fail(BIGSI_ERR_INVALID, "row_bytes is 0");
     for (uint64_t i = 0; i < n; i++)
@@ -506,17 +609,22 @@ int rows_file(bigsi_hip_index *ix, const char *path, uint64_t file_offset, uint6
 extern "C" int bigsi_hip_load_rows_file(bigsi_hip_index *ix, const char *path, uint64_t file_offset, uint64_t row0, uint64_t n_rows, uint64_t row_bytes,
                                         uint32_t threads, bigsi_hip_io_stats *stats)
 {
+    BIGSI_ENTER(ix);
+    TRY(bigsi_writable(ix));
     return rows_file(ix, path, file_offset, row0, n_rows, row_bytes, threads, false, stats);
 }
 
 extern "C" int bigsi_hip_save_rows_file(bigsi_hip_index *ix, const char *path, uint64_t file_offset, uint64_t row0, uint64_t n_rows, uint64_t row_bytes,
                                         uint32_t threads, bigsi_hip_io_stats *stats)
 {
+    BIGSI_ENTER(ix);
     return rows_file(ix, path, file_offset, row0, n_rows, row_bytes, threads, true, stats);
 }
 
 extern "C" int bigsi_hip_clear(bigsi_hip_index *ix)
 {
+    BIGSI_ENTER(ix);
+    TRY(bigsi_writable(ix));
     if (!ix) return fail(BIGSI_ERR_INVALID, "NULL index");
     TRY(use_device(ix));
     TRY(quiesce_index(ix));
@@ -527,6 +635,8 @@ extern "C" int bigsi_hip_clear(bigsi_hip_index *ix)
 
 extern "C" int bigsi_hip_insert_column(bigsi_hip_index *ix, uint64_t col, const uint8_t *bloom)
 {
+    BIGSI_ENTER(ix);
+    TRY(bigsi_writable(ix));
     if (!ix || !bloom) return fail(BIGSI_ERR_INVALID, "NULL argument");
     if (col > ix->n_cols) return fail(BIGSI_ERR_RANGE, "column %llu beyond num_cols %llu", (unsigned long long)col, (unsigned long long)ix->n_cols);
     if (col >= ix->cap_cols) return fail(BIGSI_ERR_CAPACITY, "column %llu beyond col_capacity %llu", (unsigned long long)col, (unsigned long long)ix->cap_cols);
@@ -606,6 +716,8 @@ static int check_insert_columns(bigsi_hip_index *ix, uint64_t col0, uint64_t n, 
 
 extern "C" int bigsi_hip_insert_columns(bigsi_hip_index *ix, uint64_t col0, uint64_t n, const uint8_t *blooms, uint64_t bloom_stride_bytes)
 {
+    BIGSI_ENTER(ix);
+    TRY(bigsi_writable(ix));
     TRY(check_insert_columns(ix, col0, n, blooms, bloom_stride_bytes));
     if (n == 0) return BIGSI_OK;
     TRY(use_device(ix));
@@ -629,6 +741,8 @@ extern "C" int bigsi_hip_insert_columns(bigsi_hip_index *ix, uint64_t col0, uint
 
 extern "C" int bigsi_hip_insert_columns_device(bigsi_hip_index *ix, uint64_t col0, uint64_t n, const void *d_blooms, uint64_t bloom_stride_bytes)
 {
+    BIGSI_ENTER(ix);
+    TRY(bigsi_writable(ix));
     TRY(check_insert_columns(ix, col0, n, d_blooms, bloom_stride_bytes));
     if (n == 0) return BIGSI_OK;
     TRY(use_device(ix));
@@ -644,6 +758,8 @@ extern "C" int bigsi_hip_insert_columns_device(bigsi_hip_index *ix, uint64_t col
 
 extern "C" int bigsi_hip_append_index(bigsi_hip_index *dst, const bigsi_hip_index *src)
 {
+    BIGSI_ENTER(dst);
+    TRY(bigsi_writable(dst));
     if (!dst || !src) return fail(BIGSI_ERR_INVALID, "NULL argument");
     if (dst == src) return fail(BIGSI_ERR_INVALID, "cannot append an index to itself");
     if (dst->m != src->m) return fail(BIGSI_ERR_INVALID, "row counts differ (%llu vs %llu)", (unsigned long long)dst->m, (unsigned long long)src->m);
@@ -665,6 +781,7 @@ extern "C" int bigsi_hip_append_index(bigsi_hip_index *dst, const bigsi_hip_inde
 
 extern "C" int bigsi_hip_get_column(bigsi_hip_index *ix, uint64_t col, uint8_t *out)
 {
+    BIGSI_ENTER(ix);
     if (!ix || !out) return fail(BIGSI_ERR_INVALID, "NULL argument");
     if (col >= ix->cap_cols) return fail(BIGSI_ERR_RANGE, "column %llu beyond col_capacity", (unsigned long long)col);
     TRY(use_device(ix));
@@ -689,6 +806,8 @@ static int check_offsets(const uint64_t *offsets, uint32_t n_seqs)
 
 extern "C" int bigsi_hip_insert_kmers(bigsi_hip_index *ix, uint64_t col, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k)
 {
+    BIGSI_ENTER(ix);
+    TRY(bigsi_writable(ix));
     if (!ix || !offsets || (n_seqs && !seqs && offsets[n_seqs] > offsets[0])) return fail(BIGSI_ERR_INVALID, "NULL argument");
     if (k == 0) return fail(BIGSI_ERR_INVALID, "k must be > 0");
     if (col >= ix->n_cols) return fail(BIGSI_ERR_RANGE, "column %llu >= num_cols %llu", (unsigned long long)col, (unsigned long long)ix->n_cols);
@@ -712,6 +831,8 @@ extern "C" int bigsi_hip_insert_kmers(bigsi_hip_index *ix, uint64_t col, const c
 
 extern "C" int bigsi_hip_fill_synthetic(bigsi_hip_index *ix, uint64_t seed, uint64_t shard, uint32_t and_draws)
 {
+    BIGSI_ENTER(ix);
+    TRY(bigsi_writable(ix));
     if (!ix) return fail(BIGSI_ERR_INVALID, "NULL index");
     if (and_draws == 0 || and_draws > 8) return fail(BIGSI_ERR_INVALID, "and_draws must be in [1,8]");
     TRY(use_device(ix));
@@ -780,6 +901,7 @@ int bigsi_ev_end(bigsi_hip_index *ix, EventPair *p, std::vector<EventPair> &dst,
 
 extern "C" int bigsi_hip_set_profiling(bigsi_hip_index *ix, int on)
 {
+    BIGSI_ENTER(ix);
     if (!ix) return fail(BIGSI_ERR_INVALID, "NULL index");
     ix->profiling = on >= 2 ? 2 : (on != 0);
     ix->prof_every = on > 2 ? (uint32_t)on : 1u;
@@ -789,6 +911,7 @@ extern "C" int bigsi_hip_set_profiling(bigsi_hip_index *ix, int on)
 
 extern "C" int bigsi_hip_stats(bigsi_hip_index *ix, bigsi_hip_stats_t *out, int reset)
 {
+    BIGSI_ENTER(ix);
     if (!ix || !out) return fail(BIGSI_ERR_INVALID, "NULL argument");
     TRY(use_device(ix));
     TRY(quiesce_index(ix));
@@ -832,6 +955,7 @@ extern "C" int bigsi_hip_stats(bigsi_hip_index *ix, bigsi_hip_stats_t *out, int 
 extern "C" int bigsi_hip_probe_rows(bigsi_hip_index *ix, uint32_t rows_per_query, uint32_t n_queries, uint32_t sorted, uint32_t wgs, uint32_t reps,
                                     double *gbps, double *launch_ms)
 {
+    BIGSI_ENTER(ix);
     if (!ix || !gbps) return fail(BIGSI_ERR_INVALID, "NULL argument");
     if (rows_per_query == 0 || n_queries == 0 || reps == 0) return fail(BIGSI_ERR_INVALID, "rows_per_query, n_queries and reps must be > 0");
     if (ix->n_cols == 0) return fail(BIGSI_ERR_STATE, "index has no columns");
@@ -1020,6 +1144,7 @@ static int check_batch_args(bigsi_hip_index *ix, const char *seqs, const uint64_
 
 extern "C" int bigsi_hip_batch_create(bigsi_hip_index *ix, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k, bigsi_hip_batch **out)
 {
+    BIGSI_ENTER(ix);
     if (!out) return fail(BIGSI_ERR_INVALID, "out is NULL");
     *out = nullptr;
     TRY(check_batch_args(ix, seqs, offsets, n_seqs, k));
@@ -1036,6 +1161,7 @@ extern "C" int bigsi_hip_batch_create(bigsi_hip_index *ix, const char *seqs, con
 extern "C" int bigsi_hip_batch_create_elements(bigsi_hip_index *ix, const char *blob, const uint64_t *elem_offsets, const uint64_t *seq_elem_offsets,
                                                const uint32_t *pos_unique, const uint64_t *seq_pos_offsets, uint32_t n_seqs, bigsi_hip_batch **out)
 {
+    BIGSI_ENTER(ix);
     if (!out) return fail(BIGSI_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (!ix || !elem_offsets || !seq_elem_offsets || !seq_pos_offsets) return fail(BIGSI_ERR_INVALID, "NULL argument");
@@ -1124,6 +1250,7 @@ extern "C" int bigsi_hip_batch_create_elements(bigsi_hip_index *ix, const char *
 
 extern "C" int bigsi_hip_batch_reload(bigsi_hip_batch *b, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k)
 {
+    BIGSI_ENTER(b ? b->ix : nullptr);
     if (!b) return fail(BIGSI_ERR_INVALID, "NULL batch");
     if (b->elements) return fail(BIGSI_ERR_STATE, "a batch of explicit k-mers cannot be reloaded: create a new one");
     TRY(check_batch_args(b->ix, seqs, offsets, n_seqs, k));
@@ -1135,6 +1262,7 @@ extern "C" int bigsi_hip_batch_reload(bigsi_hip_batch *b, const char *seqs, cons
 
 extern "C" int bigsi_hip_batch_destroy(bigsi_hip_batch *b)
 {
+    BIGSI_ENTER(b ? b->ix : nullptr);
     if (!b) return BIGSI_OK;
     hipError_t e = hipSetDevice(b->ix->device);
     e = hipStreamSynchronize(b->ix->pre_stream);
@@ -1167,6 +1295,7 @@ extern "C" int bigsi_hip_batch_destroy(bigsi_hip_batch *b)
 
 extern "C" int bigsi_hip_batch_set_result_cols(bigsi_hip_batch *b, uint64_t cols)
 {
+    BIGSI_ENTER(b ? b->ix : nullptr);
     if (!b) return fail(BIGSI_ERR_INVALID, "NULL batch");
     if (cols > b->ix->cap_cols)
         return fail(BIGSI_ERR_CAPACITY, "result width %llu exceeds col_capacity %llu (call bigsi_hip_reserve_cols)", (unsigned long long)cols,
@@ -1177,6 +1306,7 @@ extern "C" int bigsi_hip_batch_set_result_cols(bigsi_hip_batch *b, uint64_t cols
 
 extern "C" int bigsi_hip_batch_set_outputs(bigsi_hip_batch *b, void *d_bitmaps, void *d_counts)
 {
+    BIGSI_ENTER(b ? b->ix : nullptr);
     if (!b) return fail(BIGSI_ERR_INVALID, "NULL batch");
     b->ext_bitmaps = d_bitmaps;
     b->ext_counts = d_counts;
@@ -1279,6 +1409,7 @@ extern "C" int bigsi_hip_debug_call_trace(uint64_t *out, int reset)
 // tuning builds only (not declared in include/bigsi_hip.h): the phase timestamps of the last k_reads_fused launch, 8 per workgroup
 extern "C" int bigsi_hip_debug_phases(bigsi_hip_index *ix, uint64_t *out, uint32_t n_groups)
 {
+    BIGSI_ENTER(ix);
     HIP_TRY(hipStreamSynchronize(ix->stream));
     HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), std::min<uint32_t>(n_groups, 1024u) * 64ull));
     return BIGSI_OK;
@@ -1333,7 +1464,9 @@ static int launch_reads_fused(bigsi_hip_batch *b, hipStream_t st = nullptr, bool
         HIP_TRY(hipMemsetAsync(hb.alloc.p, 0, 256, st));
         hb.gen = 0;
     }
-    hb.gen++;
+    // (the generation advances only once the launch is queued: a launch that fails -- export_prepare, hipGetLastError -- leaves the
+    // counters as the last successful launch left them, i.e. this slot still zeroed for the retry)
+    const uint32_t gen_next = hb.gen + 1;
     b->exported_inline = false;
     if (inline_export) {
         TRY(export_prepare(b, st));
@@ -1346,7 +1479,7 @@ static int launch_reads_fused(bigsi_hip_batch *b, hipStream_t st = nullptr, bool
         src.seqs, src.seq_off, src.pos_off, b->n_seqs, b->first_pos.as<uint32_t>(),                                                       \
         b->pos_unique.as<uint32_t>(), b->rep.as<uint32_t>(), b->rows.as<uint64_t>(), b->num_kmers.as<uint32_t>(),                      \
         b->num_unique.as<uint32_t>(), b->min_kmers.as<uint32_t>(), b->bitmaps.as<uint64_t>(), b->wv_pad, hb.q_start.as<uint64_t>(),   \
-        hb.q_cnt.as<uint32_t>(), hb.alloc.as<unsigned long long>(), hb.gen & 1u, hb.col(), hb.cnt(), hb.capacity(), fp_mask,            \
+        hb.q_cnt.as<uint32_t>(), hb.alloc.as<unsigned long long>(), gen_next & 1u, hb.col(), hb.cnt(), hb.capacity(), fp_mask,          \
         src.pos_off_out, src.one_len, b->exported_inline ? static_cast<uint64_t *>(b->pin_out) : nullptr, b->exp_spec,                          \
         (volatile uint64_t *)b->pin_flag, b->exp_serial
 #define COMMA ,
@@ -1387,6 +1520,7 @@ static int launch_reads_fused(bigsi_hip_batch *b, hipStream_t st = nullptr, bool
 #undef BIGSI_READS_ARGS
 #undef COMMA
     HIP_TRY(hipGetLastError());
+    hb.gen = gen_next;
     return BIGSI_OK;
 }
 
@@ -1908,7 +2042,11 @@ int bigsi_batch_run(bigsi_hip_batch *b, double threshold, uint32_t flags, bool o
     return BIGSI_OK;
 }
 
-extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_t flags) { return bigsi_batch_run(b, threshold, flags, false); }
+extern "C" int bigsi_hip_batch_run(bigsi_hip_batch *b, double threshold, uint32_t flags)
+{
+    BIGSI_ENTER(b ? b->ix : nullptr);
+    return bigsi_batch_run(b, threshold, flags, false);
+}
 
 // three compaction passes over [shard][seq][stride]; write_only re-runs just the write pass (after growing buffers).
 // `from_counts`: src is a counter buffer gathered from several shards -> threshold while compacting (k_hits_count);
@@ -2104,6 +2242,7 @@ static int host_counts(bigsi_hip_batch *b)
 
 extern "C" int bigsi_hip_batch_get_info(bigsi_hip_batch *b, bigsi_hip_batch_info *out)
 {
+    BIGSI_ENTER(b ? b->ix : nullptr);
     if (!b || !out) return fail(BIGSI_ERR_INVALID, "NULL argument");
     memset(out, 0, sizeof *out);
     out->n_seqs = b->n_seqs;
@@ -2130,6 +2269,7 @@ extern "C" int bigsi_hip_batch_get_info(bigsi_hip_batch *b, bigsi_hip_batch_info
 
 extern "C" int bigsi_hip_batch_fetch_unique(bigsi_hip_batch *b, uint32_t *num_kmers, uint32_t *num_unique, uint32_t *min_kmers)
 {
+    BIGSI_ENTER(b ? b->ix : nullptr);
     TRY(need_run(b));
     TRY(host_counts(b));
     if (num_kmers) memcpy(num_kmers, b->h_num_kmers.data(), b->n_seqs * 4ull);
@@ -2140,6 +2280,7 @@ extern "C" int bigsi_hip_batch_fetch_unique(bigsi_hip_batch *b, uint32_t *num_km
 
 extern "C" int bigsi_hip_batch_fetch_hits(bigsi_hip_batch *b, uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t capacity)
 {
+    BIGSI_ENTER(b ? b->ix : nullptr);
     TRY(need_run(b));
     const void *src = b->exact ? (b->ext_bitmaps ? b->ext_bitmaps : b->bitmaps.p) : (b->ext_counts ? b->ext_counts : b->counts.p);
     if (!b->compacted) {   // the run skipped K4: do it now
@@ -2170,6 +2311,7 @@ static int gather_end(bigsi_hip_batch *b, hipStream_t st)
 
 extern "C" int bigsi_hip_batch_compact_gathered(bigsi_hip_batch *b, const void *d_gathered, uint32_t n_shards, uint64_t shard_cols)
 {
+    BIGSI_ENTER(b ? b->ix : nullptr);
     if (!b) return fail(BIGSI_ERR_INVALID, "NULL batch");
     hipStream_t gst = b->gstream ? b->gstream : b->ix->stream;
     TRY(gather_begin(b, gst));
@@ -2190,6 +2332,7 @@ extern "C" int bigsi_hip_batch_compact_gathered(bigsi_hip_batch *b, const void *
 extern "C" int bigsi_hip_batch_compact_gathered_masks(bigsi_hip_batch *b, const void *d_gathered_masks, uint32_t n_shards, uint64_t shard_cols,
                                                       uint32_t own_shard)
 {
+    BIGSI_ENTER(b ? b->ix : nullptr);
     if (!b) return fail(BIGSI_ERR_INVALID, "NULL batch");
     TRY(gather_begin(b, b->gstream ? b->gstream : b->ix->stream));
     if (!d_gathered_masks || n_shards == 0 || own_shard >= n_shards) return fail(BIGSI_ERR_INVALID, "bad gathered buffer / shard");
@@ -2212,6 +2355,7 @@ extern "C" int bigsi_hip_batch_compact_gathered_masks(bigsi_hip_batch *b, const 
 
 extern "C" int bigsi_hip_batch_set_gathered_hit_outputs(bigsi_hip_batch *b, void *d_colours, void *d_counts, uint64_t capacity)
 {
+    BIGSI_ENTER(b ? b->ix : nullptr);
     if (!b) return fail(BIGSI_ERR_INVALID, "NULL batch");
     if ((d_colours == nullptr) != (d_counts == nullptr)) return fail(BIGSI_ERR_INVALID, "give both buffers or neither");
     b->ghits.xcol = (uint32_t *)d_colours;
@@ -2222,6 +2366,7 @@ extern "C" int bigsi_hip_batch_set_gathered_hit_outputs(bigsi_hip_batch *b, void
 
 extern "C" int bigsi_hip_batch_set_gather_stream(bigsi_hip_batch *b, void *hip_stream)
 {
+    BIGSI_ENTER(b ? b->ix : nullptr);
     if (!b) return fail(BIGSI_ERR_INVALID, "NULL batch");
     b->gstream = (hipStream_t)hip_stream;
     return BIGSI_OK;
@@ -2229,6 +2374,7 @@ extern "C" int bigsi_hip_batch_set_gather_stream(bigsi_hip_batch *b, void *hip_s
 
 extern "C" int bigsi_hip_batch_fetch_gathered_hits(bigsi_hip_batch *b, uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t capacity)
 {
+    BIGSI_ENTER(b ? b->ix : nullptr);
     TRY(need_run(b));
     if (!b->g_src) return fail(BIGSI_ERR_STATE, "bigsi_hip_batch_compact_gathered has not been called");
     return fetch_hits_from(b, b->ghits, b->g_src, b->g_shards, b->g_shard_cols, hit_offsets, colours, counts, capacity);
@@ -2236,6 +2382,7 @@ extern "C" int bigsi_hip_batch_fetch_gathered_hits(bigsi_hip_batch *b, uint64_t 
 
 extern "C" int bigsi_hip_batch_fetch_counts(bigsi_hip_batch *b, uint32_t seq, uint32_t *out)
 {
+    BIGSI_ENTER(b ? b->ix : nullptr);
     TRY(need_run(b));
     if (!out) return fail(BIGSI_ERR_INVALID, "out is NULL");
     if (b->exact) return fail(BIGSI_ERR_STATE, "the last run took the exact path; re-run with BIGSI_RUN_FORCE_COUNTS or threshold < 1");
@@ -2255,6 +2402,7 @@ extern "C" int bigsi_hip_batch_fetch_counts(bigsi_hip_batch *b, uint32_t seq, ui
 
 extern "C" int bigsi_hip_batch_fetch_bitmap(bigsi_hip_batch *b, uint32_t seq, uint8_t *out)
 {
+    BIGSI_ENTER(b ? b->ix : nullptr);
     TRY(need_run(b));
     if (!out) return fail(BIGSI_ERR_INVALID, "out is NULL");
     if (!b->exact) return fail(BIGSI_ERR_STATE, "the last run took the counting path");
@@ -2266,6 +2414,7 @@ extern "C" int bigsi_hip_batch_fetch_bitmap(bigsi_hip_batch *b, uint32_t seq, ui
 
 extern "C" int bigsi_hip_batch_fetch_rows(bigsi_hip_batch *b, uint32_t seq, uint64_t *rows, uint64_t capacity)
 {
+    BIGSI_ENTER(b ? b->ix : nullptr);
     TRY(need_run(b));
     if (seq >= b->n_seqs) return fail(BIGSI_ERR_RANGE, "sequence %u out of range", seq);
     TRY(host_counts(b));
@@ -2277,6 +2426,7 @@ extern "C" int bigsi_hip_batch_fetch_rows(bigsi_hip_batch *b, uint32_t seq, uint
 
 extern "C" int bigsi_hip_batch_lookup(bigsi_hip_batch *b, uint32_t seq, uint32_t *first_pos, uint8_t *out_rows, uint64_t capacity_rows)
 {
+    BIGSI_ENTER(b ? b->ix : nullptr);
     TRY(need_run(b));
     if (seq >= b->n_seqs) return fail(BIGSI_ERR_RANGE, "sequence %u out of range", seq);
     TRY(host_counts(b));
@@ -2300,6 +2450,7 @@ extern "C" int bigsi_hip_batch_lookup(bigsi_hip_batch *b, uint32_t seq, uint32_t
 
 extern "C" int bigsi_hip_batch_presence(bigsi_hip_batch *b, uint32_t seq, const uint32_t *colours, uint32_t n_colours, uint8_t *out)
 {
+    BIGSI_ENTER(b ? b->ix : nullptr);
     TRY(need_run(b));
     if (seq >= b->n_seqs) return fail(BIGSI_ERR_RANGE, "sequence %u out of range", seq);
     if (n_colours == 0) return BIGSI_OK;
@@ -2589,6 +2740,7 @@ static int presence_end(bigsi_hip_batch *b, uint8_t *out, uint64_t out_capacity,
 extern "C" int bigsi_hip_batch_presence_hits(bigsi_hip_batch *b, const uint64_t *hit_offsets, const uint32_t *colours, uint8_t *out,
                                              uint64_t out_capacity, uint64_t *string_offsets)
 {
+    BIGSI_ENTER(b ? b->ix : nullptr);
     TRY(presence_begin(b, hit_offsets, colours, nullptr, false, false, out_capacity, true, string_offsets));
     return presence_end(b, out, out_capacity, nullptr);
 }
@@ -2596,6 +2748,7 @@ extern "C" int bigsi_hip_batch_presence_hits(bigsi_hip_batch *b, const uint64_t 
 extern "C" int bigsi_hip_batch_score_hits(bigsi_hip_batch *b, const uint64_t *hit_offsets, const uint32_t *colours, const uint32_t *counts,
                                           uint8_t *bits, uint64_t bits_capacity, uint64_t *bit_offsets, bigsi_hip_hit_score *scores)
 {
+    BIGSI_ENTER(b ? b->ix : nullptr);
     if (!scores) return fail(BIGSI_ERR_INVALID, "scores is NULL");
     TRY(presence_begin(b, hit_offsets, colours, counts, true, false, bits_capacity, true, bit_offsets));
     return presence_end(b, bits, bits_capacity, scores);
@@ -2604,11 +2757,13 @@ extern "C" int bigsi_hip_batch_score_hits(bigsi_hip_batch *b, const uint64_t *hi
 extern "C" int bigsi_hip_batch_score_hits_begin(bigsi_hip_batch *b, const uint64_t *hit_offsets, const uint32_t *colours, const uint32_t *counts,
                                                 uint32_t flags, uint64_t *bit_offsets)
 {
+    BIGSI_ENTER(b ? b->ix : nullptr);
     return presence_begin(b, hit_offsets, colours, counts, true, (flags & BIGSI_SCORE_ORDERED) != 0, 0, false, bit_offsets);
 }
 
 extern "C" int bigsi_hip_batch_score_hits_end(bigsi_hip_batch *b, uint8_t *bits, uint64_t bits_capacity, bigsi_hip_hit_score *scores)
 {
+    BIGSI_ENTER(b ? b->ix : nullptr);
     if (!scores) return fail(BIGSI_ERR_INVALID, "scores is NULL");
     return presence_end(b, bits, bits_capacity, scores);
 }
@@ -2801,6 +2956,7 @@ int bigsi_batch_collect(bigsi_hip_batch *b, uint32_t *num_kmers, uint32_t *num_u
 // row ids land contiguously (u x h) and one k_lookup launch covers them all.
 extern "C" int bigsi_hip_lookup(bigsi_hip_index *ix, const char *kmers, uint32_t k, uint64_t u, uint8_t *out_rows)
 {
+    BIGSI_ENTER(ix);
     if (!ix || (u && (!kmers || !out_rows))) return fail(BIGSI_ERR_INVALID, "NULL argument");
     if (k == 0) return fail(BIGSI_ERR_INVALID, "k must be > 0");
     if (u == 0) return BIGSI_OK;
@@ -2834,6 +2990,7 @@ extern "C" int bigsi_hip_lookup(bigsi_hip_index *ix, const char *kmers, uint32_t
 // its own one-position sequence of an element batch, k_rows_raw hashes them, one k_lookup launch ANDs their rows.
 extern "C" int bigsi_hip_lookup_raw(bigsi_hip_index *ix, const char *blob, const uint64_t *elem_offsets, uint64_t u, uint8_t *out_rows)
 {
+    BIGSI_ENTER(ix);
     if (!ix || (u && (!elem_offsets || !out_rows))) return fail(BIGSI_ERR_INVALID, "NULL argument");
     if (u == 0) return BIGSI_OK;
     if (u > 0x7FFFFFFFull) return fail(BIGSI_ERR_INVALID, "too many k-mers for one call");

@@ -8,8 +8,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <cstdlib>
+#include <thread>
 #include <vector>
 
 // ------------------------------------------------------------------------------ errors
@@ -115,6 +117,17 @@ struct bigsi_hip_index {
     uint32_t h = 0;
     uint64_t *d_index = nullptr;
     bool contiguous = false;      // d_index is physically contiguous memory (index_malloc)
+    // A handle that does not own its matrix: attached to another process's index over hipIpc (bigsi_hip_open_ipc: closed with
+    // hipIpcCloseMemHandle) or a second handle of this process onto an open index (bigsi_hip_open_view: nothing to free).  Such a
+    // handle is READ-ONLY: every entry point that writes the matrix fails with BIGSI_ERR_STATE (bigsi_writable).
+    enum Attach { kOwner = 0, kIpc = 1, kView = 2 } attach = kOwner;
+    // one handle = one host thread at a time (include/bigsi_hip.h): enforced, not just documented -- every entry point that takes
+    // the handle (or a batch of it) holds this for the duration of the call; a second thread gets BIGSI_ERR_STATE instead of a
+    // race.  Re-entrant for the owning thread (entry points call each other).
+    bigsi_hip_index *view_of = nullptr;      // kView: the owner
+    std::atomic<int> views{0};               // live views of this (owning) handle
+    std::atomic<std::thread::id> busy_owner{};
+    uint32_t busy_depth = 0;
     DevBuf stage, stage_ids;
     // profiling
     int profiling = 0;            // 0 off, 1 every kernel group of a run, 2 the row-AND kernel only
@@ -125,6 +138,35 @@ struct bigsi_hip_index {
     uint64_t wv() const { return ceil_div(n_cols, 64); }
     uint64_t rb() const { return ceil_div(n_cols, 8); }
 };
+
+struct BusyGuard {
+    bigsi_hip_index *ix;
+    bool ok = true;
+    explicit BusyGuard(const bigsi_hip_index *cix) : ix(const_cast<bigsi_hip_index *>(cix))
+    {
+        if (!ix) return;
+        const std::thread::id me = std::this_thread::get_id();
+        std::thread::id cur{};
+        if (ix->busy_owner.compare_exchange_strong(cur, me, std::memory_order_acquire)) { ix->busy_depth = 1; return; }
+        if (cur == me) { ix->busy_depth++; return; }
+        ok = false;
+        ix = nullptr;
+    }
+    void release()
+    {
+        if (ix && --ix->busy_depth == 0) ix->busy_owner.store(std::thread::id{}, std::memory_order_release);
+        ix = nullptr;
+    }
+    ~BusyGuard() { release(); }
+    BusyGuard(const BusyGuard &) = delete;
+    BusyGuard &operator=(const BusyGuard &) = delete;
+};
+#define BIGSI_ENTER(ixp)                                                                                                          \
+    BusyGuard busy_guard_(ixp);                                                                                                   \
+    if (!busy_guard_.ok)                                                                                                          \
+        return fail(BIGSI_ERR_STATE, "this index handle is in use by another host thread (one handle = one thread at a time; "  \
+                                     "bigsi_hip_open_view gives every thread a handle of its own onto the same matrix)")
+int bigsi_writable(const bigsi_hip_index *ix);      // BIGSI_OK, or BIGSI_ERR_STATE for an attached / view handle
 
 struct bigsi_hip_comm;
 

@@ -97,6 +97,7 @@ extern "C" int bigsi_hip_search_batch(bigsi_hip_index *ix, const char *seqs, con
                                       double threshold, uint32_t flags, uint32_t *num_kmers, uint32_t *num_unique, uint32_t *min_kmers,
                                       uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t hit_capacity)
 {
+    BIGSI_ENTER(ix);
     if (!hit_offsets) return fail(BIGSI_ERR_INVALID, "hit_offsets is NULL");
     if (!ix) return fail(BIGSI_ERR_INVALID, "NULL index");
     // the index keeps ONE workspace for this entry point (a caller in a loop pays its ~20 device allocations once; the
@@ -270,6 +271,7 @@ extern "C" int bigsi_hip_search_stream(bigsi_hip_index *ix, const char *seqs, co
                                        double threshold, uint32_t flags, uint32_t *num_kmers, uint32_t *num_unique, uint32_t *min_kmers,
                                        uint64_t *hit_offsets, uint32_t *colours, uint32_t *counts, uint64_t hit_capacity)
 {
+    BIGSI_ENTER(ix);
     return search_stream_impl(ix, seqs, offsets, n_seqs, k, threshold, flags, num_kmers, num_unique, min_kmers, hit_offsets, colours, counts,
                               hit_capacity, nullptr);
 }
@@ -282,6 +284,7 @@ extern "C" int bigsi_hip_search_stream_scored(bigsi_hip_index *ix, const char *s
                                               uint64_t hit_capacity, uint8_t *bits, uint64_t bits_capacity, uint64_t *bit_offsets,
                                               bigsi_hip_hit_score *scores, uint64_t *bits_needed)
 {
+    BIGSI_ENTER(ix);
     if (hit_capacity && (!colours || !scores)) return fail(BIGSI_ERR_INVALID, "colours / scores is NULL");
     uint64_t needed = 0;
     const ScoredOut so{bits, bits_capacity, bit_offsets, scores, bits_needed ? bits_needed : &needed};
@@ -380,6 +383,7 @@ extern "C" int bigsi_hip_comm_info(const bigsi_hip_comm *c, int *rank, int *worl
 // ------------------------------------------------------------------------------ a batch on one shard of a sharded index
 extern "C" int bigsi_hip_batch_set_comm(bigsi_hip_batch *b, bigsi_hip_comm *c, uint64_t shard_cols)
 {
+    BIGSI_ENTER(b ? b->ix : nullptr);
     if (!b) return fail(BIGSI_ERR_INVALID, "NULL batch");
     if (!c) {
         if (b->comm) {      // an exchange of this batch may still be in flight on the communicator's stream
@@ -458,6 +462,7 @@ int bigsi_reduce_gathered_counts(bigsi_hip_batch *b)
 
 extern "C" int bigsi_hip_batch_run_sharded(bigsi_hip_batch *b, double threshold, uint32_t flags)
 {
+    BIGSI_ENTER(b ? b->ix : nullptr);
     if (!b) return fail(BIGSI_ERR_INVALID, "NULL batch");
     bigsi_hip_comm *c = b->comm;
     if (!c) return fail(BIGSI_ERR_STATE, "no communicator attached (bigsi_hip_batch_set_comm)");

@@ -22,7 +22,8 @@ def read_fasta(path_or_file):
             while lines and not lines[-1].strip():
                 lines.pop()
             heads, seqs = lines[0::2], lines[1::2]
-            if len(lines) % 2 == 0 and all(h.startswith(">") for h in heads) and not any(s_.startswith(">") or not s_.strip() for s_ in seqs):
+            # (tested on the stripped lines, as the loop below and bigsi_hip_fasta_pack do: "  >b" is a header there)
+            if len(lines) % 2 == 0 and all(h.lstrip().startswith(">") for h in heads) and not any(s_.lstrip().startswith(">") or not s_.strip() for s_ in seqs):
                 return [(h.strip()[1:], s_.strip()) for h, s_ in zip(heads, seqs)]
             f = iter(lines)
         recs, name, buf = [], None, []
@@ -84,6 +85,8 @@ def _bulk_text_native(bigsi, fasta, threshold, format, score=False):
         return None
     blob, soff = packed
     scored = None
+    if len(soff) > 1 and int(np.diff(soff.astype(np.int64)).min()) < bigsi.kmer_size:
+        return None                           # a record without k-mers: the reference raises in record order (no device pass wasted on it)
     with bigsi._device_lock():
         if score:
             from .graph.bigsi import SCORE_SLICE_CHARS

@@ -94,11 +94,57 @@ def native_result_lists(nk, nu, off64, cols, counts, exact, names, scored, db_si
         trans = tuple(np.ascontiguousarray(c, dtype=np.float64) for c in score_transcendentals(rec, db_size))
         bits = np.ascontiguousarray(bits, dtype=np.uint8)
         boff = np.ascontiguousarray(boff[:total + 1], dtype=np.uint64)
-        for lo in range(0, n, block):
-            yield from _results.build_scored(nu, off64, cols, cnts, bool(exact), names, keys, rec, bits, boff, trans, lo, min(n, lo + block))
+        # (blocks of ~8 k hits: a block's dicts -- ~2 KB each with the presence string -- are then made in memory the consumer has just
+        # released; 240 k hits built in one go measured 1.5x slower per dict, all of it page faults)
+        lo = 0
+        while lo < n:
+            hi = min(n, lo + block, max(lo + 1, int(np.searchsorted(off64, off64[lo] + 8192, side="right")) - 1))
+            yield from _results.build_scored(nu, off64, cols, cnts, bool(exact), names, keys, rec, bits, boff, trans, lo, hi)
+            lo = hi
         return
     for lo in range(0, n, block):
         yield from _results.build(nu, off64, cols, cnts, bool(exact), names, keys, None, None, None, None, lo, min(n, lo + block))
+
+
+class _StreamTuning(object):
+    """The two interpreter-wide settings a running search_stream changes -- a short thread switch interval, the cyclic collector's
+    automatic passes paused -- owned by ALL live streams together: the first stream in saves and sets, the last one out restores,
+    under a lock, so that streams in several threads (or nested ones) cannot restore each other's values out of order."""
+    lock = __import__("threading").Lock()
+    users = 0
+    gc_users = 0
+    interval = None
+    gc_was_on = False
+
+    @classmethod
+    def enter(cls, pause_gc):
+        import gc
+        import sys
+        with cls.lock:
+            if cls.users == 0:
+                cls.interval = sys.getswitchinterval()
+                sys.setswitchinterval(min(cls.interval, 2e-4))
+            cls.users += 1
+            if pause_gc:
+                if cls.gc_users == 0:
+                    cls.gc_was_on = gc.isenabled()
+                    if cls.gc_was_on:
+                        gc.disable()
+                cls.gc_users += 1
+            return bool(pause_gc) and cls.gc_was_on
+
+    @classmethod
+    def leave(cls, pause_gc):
+        import gc
+        import sys
+        with cls.lock:
+            cls.users -= 1
+            if cls.users == 0 and cls.interval is not None:
+                sys.setswitchinterval(cls.interval)
+            if pause_gc:
+                cls.gc_users -= 1
+                if cls.gc_users == 0 and cls.gc_was_on:
+                    gc.enable()
 
 
 class BigsiQueryResult(object):
@@ -372,6 +418,8 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
         per sequence.  While a stream is being consumed the index handle is in use by the worker between yields: search() /
         search_batch() / lookup() take the same lock and simply wait; do not modify the index.  `pause_gc` (default on): full
         passes of Python's cyclic garbage collector are deferred until the stream ends (see below); pass False to leave it alone.
+        Exhaust the generator or .close() it: while it is suspended the process runs with the short switch interval and (pause_gc)
+        without automatic collections; several streams at once share the two settings and the last one to end restores them.
         A multi-GPU (devices=[...]) index streams through its batch objects instead (_search_stream_batches)."""
         assert threshold <= 1
         if self.storage.res.is_group:
@@ -412,17 +460,15 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
         # and never lets go of it voluntarily: at the default 5 ms switch interval those handoffs cost a scored stream a third of its
         # rate (128 -> 165+ M lookups/s on BASELINE configs[4]'s shard)
         import gc
-        import sys
-        interval = sys.getswitchinterval()
-        sys.setswitchinterval(min(interval, 2e-4))
         # The stream makes two containers per sequence (the pair, the result list); every ~35 000 of them the cyclic collector
         # starts a FULL collection, which walks every object of the process -- with torch and numpy imported ~40 ms, GIL held, the
         # worker stuck at the end of its C call: a quarter of a scored stream's time (163 -> 120 ms per 24 576 queries of 1 kbp).
         # While the stream runs, full collections wait: the collector is off, and the two young generations are collected at every
         # slice boundary (cheap: only what was made since), so that cyclic garbage of the consumer does not pile up unseen.
-        gc_was_on = bool(pause_gc) and gc.isenabled()
-        if gc_was_on:
-            gc.disable()
+        # Both settings are process-wide: _StreamTuning shares them between all running streams (first in sets, last out restores).
+        # They are restored when the generator ends, is closed or is finalised -- a stream that is abandoned half-consumed should be
+        # .close()d (a suspended generator kept alive keeps them in force).
+        gc_was_on = _StreamTuning.enter(pause_gc)
         with ThreadPoolExecutor(1) as pool:
             pending = None
             try:
@@ -437,9 +483,7 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
                     last, pending = pending, None
                     yield from self._emit(last.result(), threshold, score)
             finally:
-                sys.setswitchinterval(interval)
-                if gc_was_on:
-                    gc.enable()
+                _StreamTuning.leave(pause_gc)
                 if pending is not None:
                     pending.result()                             # (the consumer stopped early: let the worker leave the index alone)
 
@@ -449,13 +493,16 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
 
     def _names_of(self, cols, exact):
         """names[c] for the C++ assembly of result dicts: the sample name of every colour that occurs in `cols` (looked up once),
-        None for a deleted sample (its hits are dropped).  Returns None instead when the exact route meets a colour without a name:
-        a KeyError in the reference, which the Python loop raises at the right place."""
+        None for a deleted sample (its hits are dropped).  Returns None instead when a colour has no name (beyond num_samples on the
+        exact route, or below it with no metadata record): a KeyError in the reference, which the Python loop raises at the right place."""
         ns = self.num_samples
         names = [None] * ns
         for c in np.unique(cols).tolist():
             if c < ns:
-                name = self.colour_to_sample(c)
+                try:
+                    name = self.colour_to_sample(c)
+                except KeyError:          # a colour below num_samples without a name: the per-record Python loop raises it when its turn comes
+                    return None
                 names[c] = None if name == DELETION_SPECIAL_SAMPLE_NAME else name
             elif exact:
                 return None

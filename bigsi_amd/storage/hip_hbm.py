@@ -20,6 +20,12 @@ storage-config keys
                  top-level config); otherwise rows are buffered until `number_of_rows` is stored
     max_cols     initial column capacity (grown on demand by re-striding on the device).  default 1024
     filename     optional snapshot file written by sync() and loaded when the index is not resident
+    export       path of an ATTACH FILE this process keeps up to date (written when the index is opened from its snapshot and by
+                 every sync()): the hipIpc handle of the resident matrix + its geometry + the host-side records.  While this
+                 process lives, any other process opens the same index from it in milliseconds and without a second copy in HBM
+    attach       path of such a file: this storage is a READ-ONLY handle onto the index another process holds resident
+                 (`python -m bigsi_amd hold` is that process).  Takes precedence over `filename` when the file exists and its owner
+                 is alive; otherwise the index is loaded as usual
 """
 import json
 import os
@@ -53,6 +59,7 @@ class _Resident(object):
         self.uniform_len = None      # byte length every stored row was given (None: as wide as the index is now)
         self.rowlen = None           # np.uint32[m] once rows of differing lengths have been stored
         self.batches = weakref.WeakSet()   # live QueryBatch objects: they hold the index handle and must die before it
+        self.attached = False        # the matrix belongs to another process (storage-config `attach`): read-only
 
     @property
     def is_group(self):
@@ -113,7 +120,7 @@ class _Resident(object):
         if self.ix is not None:
             check(self.fn("close")(self.ix))
         self.ix, self.m, self.written, self.rowlen = None, None, None, None
-        self.kv, self.pending = {}, {}
+        self.kv, self.pending, self.attached = {}, {}, False
 
     # ---- rows
     def put_rows(self, row_ids, blobs):
@@ -253,9 +260,13 @@ class HipHbmStorage(BaseStorage):
                                                         "give the other index its own storage-config name" % (self.name, key, a, b))
         if res is None:
             res = _RESIDENT[self.name] = _Resident(self.storage_config)
-            fn = self.storage_config.get("filename")
-            if fn and os.path.exists(fn):
+            fn, att = self.storage_config.get("filename"), self.storage_config.get("attach")
+            if att and _attach(res, att):
+                pass                                   # a handle onto the index another process holds resident
+            elif fn and os.path.exists(fn):
                 _load_snapshot(res, fn, int(self.storage_config.get("io_threads", 0)))
+                if self.storage_config.get("export"):
+                    _export_attach(res, self.storage_config["export"])
         self.res = res
         self.storage = self       # reference convention: backend.storage[key] (base.py:13-21); routed below
 
@@ -315,18 +326,29 @@ class HipHbmStorage(BaseStorage):
     def delete_all(self):
         """BaseStorage.delete_all (bigsi/storage/base.py:132-133; berkeleydb.py removes the file): the resident index AND its
         snapshot file go, so that a later process does not find the deleted index again."""
+        attached = self.res.attached
         self.res.free()
         fn = self.storage_config.get("filename")
+        if attached:
+            return            # (a handle onto somebody else's index: detaching is all this process may do to it)
         for f in ((fn, fn + ".tmp") if fn else ()):
             if os.path.exists(f):
                 os.remove(f)
 
     def sync(self):
         fn = self.storage_config.get("filename")
-        if fn:
+        if fn and not self.res.attached:
             _save_snapshot(self.res, fn, int(self.storage_config.get("io_threads", 0)))
         if self.res.ix is not None:
             check(self.res.fn("synchronize")(self.res.ix))
+        if self.storage_config.get("export") and not self.res.attached and self.res.ix is not None:
+            _export_attach(self.res, self.storage_config["export"])
+
+    def export_attach(self, path):
+        """Write the attach file of this resident index to `path` (storage-config `export` does it at every sync()): another
+        process then opens the index with storage-config {"attach": path} -- bigsi_hip_open_ipc, milliseconds, no second copy in
+        HBM -- for as long as THIS process lives and keeps the index."""
+        _export_attach(self.res, path)
 
     def save_snapshot(self, filename, threads=0):
         """Write the resident index to `filename` in the device layout (what sync() does for storage-config `filename`); returns
@@ -779,6 +801,62 @@ class ElementBatch(QueryBatch):
 # blocks) is still read.
 _MAGIC2 = b"BIGSIHBM2\n"
 _ALIGN = 4096
+_ATTACH_FORMAT = "bigsi-hip-attach-1"
+
+
+def _export_attach(res, path):
+    """The attach file (JSON): hipIpc handle of the matrix, geometry, the host-side records (index integers, sample metadata),
+    which rows have been written.  Written to a temporary name and renamed: a reader never sees half a file."""
+    if res.is_group:
+        raise BigsiHipError(_lib.ERR_STATE, "a multi-GPU (devices=[...]) index cannot be exported for attach: attach to the shards' own processes")
+    if res.attached:
+        raise BigsiHipError(_lib.ERR_STATE, "an attached index cannot be re-exported (only its owner can)")
+    if not res.ensure_open():
+        raise BigsiHipError(_lib.ERR_STATE, "nothing resident to export")
+    handle = (_lib.C.c_uint8 * 64)()
+    check(_lib.lib().bigsi_hip_export_ipc(res.ix, handle))
+    inf = res.info()
+    doc = {"format": _ATTACH_FORMAT, "handle": bytes(handle).hex(), "pid": os.getpid(), "device": res.device,
+           "m": int(inf.num_rows), "num_cols": int(inf.num_cols), "col_capacity": int(inf.col_capacity), "num_hashes": int(inf.num_hashes),
+           "kv": {k.decode("latin-1"): v.decode("latin-1") for k, v in res.kv.items()}, "uniform_len": res.uniform_len,
+           "written": None if res.written.all() else np.packbits(res.written).tobytes().hex(),
+           "rowlen": None if res.rowlen is None else res.rowlen.tobytes().hex()}
+    tmp = "%s.tmp%d" % (path, os.getpid())
+    with open(tmp, "w") as f:
+        json.dump(doc, f)
+    os.replace(tmp, path)
+
+
+def _attach(res, path):
+    """Open `res` as a read-only handle onto the index described by the attach file; False (and nothing changed) when there is
+    no such file or its owner is gone -- the caller then loads the index the usual way."""
+    try:
+        with open(path) as f:
+            doc = json.load(f)
+    except (OSError, ValueError):
+        return False
+    if doc.get("format") != _ATTACH_FORMAT:
+        raise BigsiHipError(_lib.ERR_INVALID, "%s is not a hip-hbm attach file" % path)
+    try:
+        os.kill(int(doc["pid"]), 0)
+    except ProcessLookupError:
+        return False                                  # a stale file: the owner has exited and its allocation with it
+    except PermissionError:
+        pass                                          # alive, another user's
+    if int(doc["pid"]) == os.getpid():
+        raise BigsiHipError(_lib.ERR_STATE, "%s was exported by this very process: use the resident index (same storage-config name)" % path)
+    if res.is_group:
+        raise BigsiHipError(_lib.ERR_STATE, "storage-config `attach` and `devices` exclude each other")
+    handle = (_lib.C.c_uint8 * 64).from_buffer_copy(bytes.fromhex(doc["handle"]))
+    out = _lib.C.c_void_p()
+    device = int(res.cfg.get("device", doc.get("device", 0)))
+    check(_lib.lib().bigsi_hip_open_ipc(handle, int(doc["m"]), int(doc["num_cols"]), int(doc["col_capacity"]), int(doc["num_hashes"]), device, _lib.C.byref(out)))
+    res.ix, res.m, res.device, res.attached = out, int(doc["m"]), device, True
+    res.kv = {k.encode("latin-1"): v.encode("latin-1") for k, v in doc["kv"].items()}
+    res.written = np.ones(res.m, dtype=bool) if not doc.get("written") else np.unpackbits(np.frombuffer(bytes.fromhex(doc["written"]), np.uint8))[: res.m].astype(bool)
+    res.uniform_len = doc.get("uniform_len")
+    res.rowlen = np.frombuffer(bytes.fromhex(doc["rowlen"]), np.uint32).copy() if doc.get("rowlen") else None
+    return True
 
 
 def _save_snapshot(res, fn, threads=0):

@@ -12,8 +12,9 @@
  *   - every function returns 0 (BIGSI_OK) or a negative BIGSI_ERR_* code; the message of the last
  *     failure on the calling thread is bigsi_hip_last_error().
  *   - the caller owns all host buffers; no call retains a host pointer after it returns.
- *   - one index / batch handle may be used from one host thread at a time; distinct handles are
- *     independent.  HIP contexts do not survive fork(): open after forking (bulk_search,
+ *   - one index / batch handle may be used from one host thread at a time -- ENFORCED: a call on a handle (or on a batch of
+ *     it) that another thread is inside fails with BIGSI_ERR_STATE, it does not race.  Distinct handles are independent, and
+ *     bigsi_hip_open_view gives every thread of a serving host its own handle onto the one resident matrix.  HIP contexts do not survive fork(): open after forking (bulk_search,
  *     bigsi/__main__.py:273-287, forks one worker per chunk).
  *   - LAYERS.  A binder needs only what its host does:
  *       CORE       index lifecycle + storage contract + bigsi_hip_lookup + bigsi_hip_search_batch (the whole of
@@ -21,7 +22,8 @@
  *       BATCHES    bigsi_hip_batch_*: staged workspaces and asynchronous runs for serving loops.
  *       MULTI-GPU  bigsi_hip_comm_* / batch_set_comm / batch_run_sharded (one process per GPU): the RCCL exchange is issued by
  *                  the library.  One process driving N GPUs: bigsi_hip_group_* in include/bigsi_hip_group.h.
- *       MEASUREMENT  fill_synthetic, insert_columns_device, set_profiling, stats.
+ *       SHARING    export_ipc / open_ipc (another process) and open_view (another thread): read-only handles onto ONE resident matrix.
+ *       MEASUREMENT  fill_synthetic, set_profiling, stats (calibration probe and device-resident filters: bigsi_hip_testing.h).
  *     Not advertised here (exported all the same, declared in include/bigsi_hip_testing.h): hooks for hosts that bring their own
  *     collective (torch.distributed over gloo on a one-GPU test box) and the BIGSI_RUN_* flags that force an A/B route.
  *     The library reads no environment variables (tuning knobs exist only in builds made with -DBIGSI_HIP_TUNING).
@@ -60,6 +62,24 @@ int bigsi_hip_open(uint64_t num_rows, uint64_t num_cols, uint64_t col_capacity, 
                    int device, bigsi_hip_index **out);
 int bigsi_hip_close(bigsi_hip_index *ix); /* BaseStorage.close, bigsi/storage/base.py:149-151 */
 /* Destroy every batch created on an index before closing it: batches hold the index handle. */
+
+/* ------------------------------------------------------------------ one resident matrix, several handles
+ * The reference's store is a file any process opens (per request, per pool worker: bigsi/__main__.py:75-80, 204-205,
+ * bigsi/storage/berkeleydb.py:12-19).  A resident index is one process's HBM allocation; these give OTHER handles onto it,
+ * without a second copy and without re-ingesting it:
+ *   export_ipc  the owner's matrix as BIGSI_IPC_HANDLE_BYTES opaque bytes (hipIpc), to be carried by any channel (a file ...).
+ *   open_ipc    in ANOTHER process: map that allocation; num_rows / num_cols / col_capacity / num_hashes are the owner's
+ *               (bigsi_hip_get_info there).  Milliseconds, whatever the index size.
+ *   open_view   in the OWNER's process: a second handle (own streams, own workspaces) for another host thread.
+ * Attached handles and views are READ-ONLY (calls that write the matrix fail with BIGSI_ERR_STATE) and are closed with
+ * bigsi_hip_close.  The owner must outlive them; while views exist it refuses bigsi_hip_close and bigsi_hip_reserve_cols
+ * (attached processes it cannot see: do not re-stride or close an exported index while others use it).  Writes the owner makes
+ * (set_rows, insert) are seen by the other handles' later calls once the owner's call has returned. */
+#define BIGSI_IPC_HANDLE_BYTES 64
+int bigsi_hip_export_ipc(bigsi_hip_index *ix, uint8_t *handle /* BIGSI_IPC_HANDLE_BYTES */);
+int bigsi_hip_open_ipc(const uint8_t *handle, uint64_t num_rows, uint64_t num_cols, uint64_t col_capacity, uint32_t num_hashes,
+                       int device, bigsi_hip_index **out);
+int bigsi_hip_open_view(bigsi_hip_index *owner, bigsi_hip_index **out);
 
 typedef struct {
     uint64_t num_rows;         /* m  = ksi:bloomfilter_size = number_of_rows */
@@ -123,9 +143,6 @@ int bigsi_hip_insert_column(bigsi_hip_index *ix, uint64_t col, const uint8_t *bl
  * filters (filter i at blooms + i*bloom_stride_bytes, ceil(num_rows/8) bytes each) become columns [col0, col0+n).
  * col0 <= num_cols; num_cols grows to col0+n if that is larger.  Needs col0+n <= col_capacity. */
 int bigsi_hip_insert_columns(bigsi_hip_index *ix, uint64_t col0, uint64_t n, const uint8_t *blooms, uint64_t bloom_stride_bytes);
-/* The same with the filters already in device memory (e.g. written there by a Bloom-construction kernel): no staging copy.
- * A 16-byte aligned pointer and pitch take the tiled transpose; anything else the column-at-a-time route. */
-int bigsi_hip_insert_columns_device(bigsi_hip_index *ix, uint64_t col0, uint64_t n, const void *d_blooms, uint64_t bloom_stride_bytes);
 /* KmerSignatureIndex.merge_indexes (bigsi/graph/index.py:54-60): append all columns of src after dst's, device to
  * device (same device, same num_rows); dst's capacity grows as needed. */
 int bigsi_hip_append_index(bigsi_hip_index *dst, const bigsi_hip_index *src);
@@ -371,13 +388,6 @@ typedef struct {
  * step for a batch of short reads: sampled, the timed region runs at its untimed speed) */
 int bigsi_hip_set_profiling(bigsi_hip_index *ix, int on);
 int bigsi_hip_stats(bigsi_hip_index *ix, bigsi_hip_stats_t *out, int reset); /* synchronises */
-/* Same-box calibration: achieved GB/s of bare row streams over this index's matrix -- a kernel with no BIGSI code, the load
- * pattern of the row-AND kernels (one wavefront per 1 KiB column segment, 16 B per lane, 8 loads in flight) -- over n_queries
- * lists of rows_per_query rows, uniform random (sorted = 0: what the counting kernel sees) or ascending (1: the exact kernel's
- * address-ordered lists); launches of `wgs` workgroups (0 = the library's own launch size); median of `reps` passes.
- * Lets a bench line state its fraction of what THIS box delivers (boxes differ by several per cent at identical clocks). */
-int bigsi_hip_probe_rows(bigsi_hip_index *ix, uint32_t rows_per_query, uint32_t n_queries, uint32_t sorted, uint32_t wgs, uint32_t reps,
-                         double *gbps, double *launch_ms);
 
 /* ================================================================== FRONT-END TEXT (host only)
  * What `bigsi bulk_search` reads and returns (bigsi/__main__.py:41-72, 261-314: pyfasta records in, json.dumps(records, indent=4)

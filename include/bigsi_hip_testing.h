@@ -61,6 +61,18 @@ int bigsi_hip_batch_compact_gathered_masks(bigsi_hip_batch *b, const void *d_gat
  * buffers fetch_gathered_hits reports BIGSI_ERR_CAPACITY instead of growing them. */
 int bigsi_hip_batch_set_gathered_hit_outputs(bigsi_hip_batch *b, void *d_colours, void *d_counts, uint64_t capacity);
 
+/* MEASUREMENT (bench.py, scripts/measure.py).
+ * bigsi_hip_insert_columns with the filters already in device memory (no staging copy: what prices the transpose kernel alone).
+ * A 16-byte aligned pointer and pitch take the tiled transpose; anything else the column-at-a-time route. */
+int bigsi_hip_insert_columns_device(bigsi_hip_index *ix, uint64_t col0, uint64_t n, const void *d_blooms, uint64_t bloom_stride_bytes);
+/* Same-box calibration: achieved GB/s of bare row streams over this index's matrix -- a kernel with no BIGSI code, the load
+ * pattern of the row-AND kernels (one wavefront per 1 KiB column segment, 16 B per lane, 8 loads in flight) -- over n_queries
+ * lists of rows_per_query rows, uniform random (sorted = 0: what the counting kernel sees) or ascending (1: the exact kernel's
+ * address-ordered lists); launches of `wgs` workgroups (0 = the library's own launch size); median of `reps` passes.
+ * Lets a bench line state its fraction of what THIS box delivers (boxes differ by several per cent at identical clocks). */
+int bigsi_hip_probe_rows(bigsi_hip_index *ix, uint32_t rows_per_query, uint32_t n_queries, uint32_t sorted, uint32_t wgs, uint32_t reps,
+                         double *gbps, double *launch_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,7 +40,7 @@ for scored in (None, (rec, bits, boff)):
         gc.collect()
         t = time.perf_counter()
         n_d = 0
-        for r in front.native_result_lists(nk, nu, off, cols, cnts, False, names, scored, ncols, block=16):      # consumed as a stream: a block's dicts are dropped before the next block is made
+        for r in front.native_result_lists(nk, nu, off, cols, cnts, False, names, scored, ncols):      # consumed as a stream: a block's dicts are dropped before the next block is made
             n_d += len(r)
         dt = time.perf_counter() - t
         assert n_d == total

@@ -21,6 +21,8 @@ FASTAS = [
     ">only\n",
     ">x\rAC\rGT\r>y\rTT\r",
     "  >indented header\n\x0bACGT\x1c\n>z\n>\nAA\n",
+    ">a\n >b\n",                      # a header in a sequence position: two empty records on every route (path, file object, C packer)
+    ">a\nACGT\n\t>b\nGG\n",
 ]
 
 
@@ -38,6 +40,8 @@ def test_fasta_pack_gives_read_fastas_sequences(text):
     raw = blob.tobytes().decode()
     got = [raw[int(off[i]):int(off[i + 1])] for i in range(len(off) - 1)]
     assert got == want
+    import io
+    assert [s for _, s in frontend.read_fasta(io.StringIO(text, newline=""))] == want      # a file object takes the per-line loop: same records
 
 
 def test_fasta_pack_of_a_text_cut_into_chunks():
