@@ -335,6 +335,9 @@ def run_also_legs(args, world, rank, ports):
                 d = json.loads(r.stdout.strip().splitlines()[-1])
                 out[key] = {"gb": sig(d["gb"], 4), "save_GBps": sig(d["save_GBps"], 4), "load_GBps": sig(d["load_GBps"], 4), "load2_GBps": sig(d["load2_GBps"], 4),
                             "file_GBps": sig(d["load2_file_GBps"], 4), "pcie_GBps": sig(d.get("pcie_h2d_GBps"), 4), "threads": d["threads"], "dir": d["dir"],
+                            # one file instead of 16 striped parts (the inode's write lock); a two-shard group's snapshot written / loaded
+                            "save1_GBps": sig(d.get("save_one_file_GBps"), 4), "grp_save_GBps": sig(d.get("group_save_GBps"), 4),
+                            "grp_load_GBps": sig(d.get("group_load_GBps"), 4), "grp_gb": sig(d.get("group_gb"), 3),
                             "ok": int(bool(d.get("verified"))), "wall": round(time.time() - t0, 1)}
             except Exception as e:  # noqa: BLE001
                 out[key] = {"error": ("%s: %s" % (type(e).__name__, e))[:160]}

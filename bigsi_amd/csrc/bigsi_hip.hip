@@ -3,6 +3,7 @@
 #include "bigsi_internal.hpp"
 
 #include <fcntl.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -15,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -422,7 +424,6 @@ extern "C" int bigsi_hip_synchronize(bigsi_hip_index *ix)
 // ------------------------------------------------------------------------------ storage contract
 static const uint64_t kStageBytes = 64ull << 20;
 static const uint64_t kZeroCopyBytes = 256ull << 10;     // inputs of a one-call search up to this size are read by K1 from pinned memory
-static const uint64_t kIoChunkBytes = 256ull << 20;      // one pinned buffer of the file <-> HBM pipeline
 
 extern "C" int bigsi_hip_set_rows(bigsi_hip_index *ix, const uint64_t *row_ids, uint64_t n, const uint8_t *bytes, uint64_t row_bytes)
 {
@@ -486,8 +487,9 @@ struct IoJob {
     std::atomic<int> err{0};
 };
 
+}   // namespace
 // read / write [off, off + len) of the file into / from buf with up to `threads` threads; returns 0 or errno
-int file_io(int fd, bool write, uint8_t *buf, uint64_t off, uint64_t len, unsigned threads)
+int bigsi_file_io(int fd, bool write, uint8_t *buf, uint64_t off, uint64_t len, unsigned threads)
 {
     threads = std::max(1u, std::min<unsigned>(threads, (unsigned)ceil_div(std::max<uint64_t>(len, 1), 4ull << 20)));
     std::atomic<int> err{0};
@@ -510,6 +512,108 @@ int file_io(int fd, bool write, uint8_t *buf, uint64_t off, uint64_t len, unsign
     for (auto &th : pool) th.join();
     return err.load();
 }
+// ---- BigsiRowsFile (bigsi_internal.hpp): one file, or a directory of striped part files
+static const uint64_t kStripeParts = 16, kStripeBytes = 4ull << 20;
+
+int BigsiRowsFile::open_(const char *path, bool save, uint64_t file_offset_, uint64_t row_bytes_, uint64_t n_rows)
+{
+    file_offset = file_offset_;
+    row_bytes = row_bytes_;
+    const size_t len = strlen(path);
+    striped = len > 0 && path[len - 1] == '/';
+    if (!striped) {
+        fd = open(path, save ? (O_WRONLY | O_CREAT) : O_RDONLY, 0644);
+        if (fd < 0) return fail(BIGSI_ERR_INVALID, "%s: %s", path, strerror(errno));
+        return BIGSI_OK;
+    }
+    const std::string dir(path);
+    const std::string lay = dir + "layout";
+    if (save) {
+        if (mkdir(dir.substr(0, len - 1).c_str(), 0755) != 0 && errno != EEXIST) return fail(BIGSI_ERR_INVALID, "mkdir %s: %s", path, strerror(errno));
+        parts = kStripeParts;
+        stripe_rows = std::max<uint64_t>(1, kStripeBytes / row_bytes);
+        FILE *f = fopen(lay.c_str(), "w");
+        if (!f) return fail(BIGSI_ERR_INVALID, "%s: %s", lay.c_str(), strerror(errno));
+        fprintf(f, "bigsi-rows-striped 1\nparts %llu\nstripe_rows %llu\nrow_bytes %llu\nrows %llu\nfile_offset %llu\n", (unsigned long long)parts,
+                (unsigned long long)stripe_rows, (unsigned long long)row_bytes, (unsigned long long)n_rows, (unsigned long long)file_offset);
+        fclose(f);
+    } else {
+        FILE *f = fopen(lay.c_str(), "r");
+        if (!f) return fail(BIGSI_ERR_INVALID, "%s: %s", lay.c_str(), strerror(errno));
+        unsigned long long ver = 0, p_ = 0, s_ = 0, rb_ = 0, rows_ = 0, fo_ = 0;
+        const int got = fscanf(f, "bigsi-rows-striped %llu parts %llu stripe_rows %llu row_bytes %llu rows %llu file_offset %llu", &ver, &p_, &s_, &rb_, &rows_, &fo_);
+        fclose(f);
+        if (got != 6 || ver != 1 || p_ == 0 || p_ > 4096 || s_ == 0) return fail(BIGSI_ERR_INVALID, "%s is not a striped rows layout", lay.c_str());
+        if (rb_ != row_bytes || fo_ != file_offset || rows_ < n_rows)
+            return fail(BIGSI_ERR_INVALID, "%s holds %llu rows of %llu bytes (offset %llu); asked for %llu rows of %llu bytes (offset %llu)", lay.c_str(), rows_, rb_, fo_,
+                        (unsigned long long)n_rows, (unsigned long long)row_bytes, (unsigned long long)file_offset);
+        parts = p_;
+        stripe_rows = s_;
+    }
+    for (uint64_t p = 0; p < parts; p++) {
+        char name[32];
+        snprintf(name, sizeof name, "part.%03llu", (unsigned long long)p);
+        const int f = open((dir + name).c_str(), save ? (O_WRONLY | O_CREAT) : O_RDONLY, 0644);
+        if (f < 0) { const int e = errno; close_(); return fail(BIGSI_ERR_INVALID, "%s%s: %s", path, name, strerror(e)); }
+        fds.push_back(f);
+    }
+    return BIGSI_OK;
+}
+
+uint64_t BigsiRowsFile::chunk_rows() const
+{
+    uint64_t per = std::max<uint64_t>(1, kBigsiIoChunkBytes / row_bytes);
+    if (striped && per > stripe_rows * parts) per -= per % (stripe_rows * parts);      // whole rounds over the parts: every part file gets the same share of a chunk
+    return per;
+}
+
+int BigsiRowsFile::io(bool write, uint8_t *buf, uint64_t rel_row, uint64_t n, unsigned threads) const
+{
+    if (!striped) return bigsi_file_io(fd, write, buf, file_offset + rel_row * row_bytes, n * row_bytes, threads);
+    // a thread owns the part files p == t (mod T): no two threads inside one inode
+    const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(threads, parts), ceil_div(n, stripe_rows)));
+    std::atomic<int> err{0};
+    auto work = [&](unsigned t) {
+        const uint64_t s0 = rel_row / stripe_rows, s1 = ceil_div(rel_row + n, stripe_rows);
+        for (uint64_t s = s0; s < s1 && !err.load(); s++) {
+            const uint64_t p = s % parts;
+            if (p % T != t) continue;
+            const uint64_t a = std::max(rel_row, s * stripe_rows), b = std::min(rel_row + n, (s + 1) * stripe_rows);
+            uint64_t off = file_offset + ((s / parts) * stripe_rows + (a - s * stripe_rows)) * row_bytes, left = (b - a) * row_bytes;
+            uint8_t *q = buf + (a - rel_row) * row_bytes;
+            while (left && !err.load()) {
+                const ssize_t r = write ? pwrite(fds[p], q, (size_t)left, (off_t)off) : pread(fds[p], q, (size_t)left, (off_t)off);
+                if (r < 0) { if (errno == EINTR) continue; err.store(errno); break; }
+                if (r == 0) { err.store(write ? EIO : ENODATA); break; }
+                q += r; off += (uint64_t)r; left -= (uint64_t)r;
+            }
+        }
+    };
+    if (T == 1) { work(0); return err.load(); }
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < T; t++) pool.emplace_back(work, t);
+    for (auto &th : pool) th.join();
+    return err.load();
+}
+
+int BigsiRowsFile::sync_all() const
+{
+    int e = 0;
+    if (fd >= 0 && fsync(fd) != 0 && errno != EINVAL && errno != EROFS) e = errno;
+    for (int f : fds)
+        if (fsync(f) != 0 && errno != EINVAL && errno != EROFS) e = errno;
+    return e;
+}
+
+void BigsiRowsFile::close_()
+{
+    if (fd >= 0) close(fd);
+    for (int f : fds) close(f);
+    fd = -1;
+    fds.clear();
+}
+
+namespace {
 
 int rows_file(bigsi_hip_index *ix, const char *path, uint64_t file_offset, uint64_t row0, uint64_t n_rows, uint64_t row_bytes, uint32_t threads,
               bool save, bigsi_hip_io_stats *st)
@@ -523,10 +627,10 @@ int rows_file(bigsi_hip_index *ix, const char *path, uint64_t file_offset, uint6
     TRY(use_device(ix));
     TRY(quiesce_index(ix));
     HIP_TRY(hipStreamSynchronize(ix->stream));
-    const int fd = open(path, save ? (O_WRONLY | O_CREAT) : O_RDONLY, 0644);
-    if (fd < 0) return fail(BIGSI_ERR_INVALID, "%s: %s", path, strerror(errno));
+    BigsiRowsFile rf;
+    TRY(rf.open_(path, save, file_offset, row_bytes, n_rows));
     const bool direct = row_bytes == stride;                         // the file holds the device layout: no kernel on the way
-    const uint64_t per = std::max<uint64_t>(1, kIoChunkBytes / row_bytes);
+    const uint64_t per = rf.chunk_rows();
     void *pin[2] = {nullptr, nullptr};
     hipEvent_t ev[2] = {nullptr, nullptr};
     DevBuf dev[2];
@@ -560,14 +664,14 @@ int rows_file(bigsi_hip_index *ix, const char *path, uint64_t file_offset, uint6
                     const uint64_t pr0 = row0 + (c - 1) * per, pn = std::min(per, row0 + n_rows - pr0);
                     HIP_TRY(hipEventSynchronize(ev[ps]));
                     const auto t0 = std::chrono::steady_clock::now();
-                    const int e = file_io(fd, true, static_cast<uint8_t *>(pin[ps]), file_offset + (pr0 - row0) * row_bytes, pn * row_bytes, threads);
+                    const int e = rf.io(true, static_cast<uint8_t *>(pin[ps]), pr0 - row0, pn, threads);
                     io_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                     if (e) return fail(BIGSI_ERR_INVALID, "writing %s: %s", path, strerror(e));
                 }
             } else {
                 HIP_TRY(hipEventSynchronize(ev[slot]));                  // (never recorded: returns at once) the copy that last used this buffer
                 const auto t0 = std::chrono::steady_clock::now();
-                const int e = file_io(fd, false, static_cast<uint8_t *>(pin[slot]), file_offset + (r0 - row0) * row_bytes, cn * row_bytes, threads);
+                const int e = rf.io(false, static_cast<uint8_t *>(pin[slot]), r0 - row0, cn, threads);
                 io_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                 if (e) return fail(BIGSI_ERR_INVALID, "reading %s: %s", path, e == ENODATA ? "file too short" : strerror(e));
                 if (direct) HIP_TRY(hipMemcpyAsync(base + r0 * stride, pin[slot], cn * row_bytes, hipMemcpyHostToDevice, ix->stream));
@@ -583,7 +687,7 @@ int rows_file(bigsi_hip_index *ix, const char *path, uint64_t file_offset, uint6
         return BIGSI_OK;
     };
     rc = body();
-    if (save && rc == BIGSI_OK && fsync(fd) != 0 && errno != EINVAL && errno != EROFS) rc = fail(BIGSI_ERR_INVALID, "fsync %s: %s", path, strerror(errno));
+    if (save && rc == BIGSI_OK) { const int e_ = rf.sync_all(); if (e_) rc = fail(BIGSI_ERR_INVALID, "fsync %s: %s", path, strerror(e_)); }
     char keep[1024] = "";
     if (rc != BIGSI_OK) snprintf(keep, sizeof keep, "%s", bigsi_hip_last_error());      // (the clean-up below must not overwrite the message)
     hipError_t e = hipStreamSynchronize(ix->stream);
@@ -593,7 +697,7 @@ int rows_file(bigsi_hip_index *ix, const char *path, uint64_t file_offset, uint6
         dev[i].release();
     }
     (void)e;
-    close(fd);
+    rf.close_();
     if (rc != BIGSI_OK) return fail(rc, "%s", keep);
     if (st) {
         st->bytes = n_rows * row_bytes;

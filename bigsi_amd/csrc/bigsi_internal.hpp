@@ -285,6 +285,26 @@ int bigsi_batch_export(bigsi_hip_batch *b);
 int bigsi_batch_collect(bigsi_hip_batch *b, uint32_t *num_kmers, uint32_t *num_unique, uint32_t *min_kmers, uint64_t *hit_offsets,
                         uint32_t *colours, uint32_t *counts, uint64_t capacity);
 int bigsi_use_device(const bigsi_hip_index *ix);
+// pread / pwrite of [off, off + len) with up to `threads` host threads (bigsi_hip.hip); 0 or errno
+int bigsi_file_io(int fd, bool write, uint8_t *buf, uint64_t off, uint64_t len, unsigned threads);
+constexpr uint64_t kBigsiIoChunkBytes = 256ull << 20;      // one pinned buffer of the file <-> HBM pipelines
+// The file side of load_rows_file / save_rows_file (single index and group).  `path` is a FILE (rows back to back from file_offset
+// on) or, when it ends in '/', a DIRECTORY holding the same rows striped RAID-0 fashion over kParts part files: writes to one
+// file are serialised by its inode lock and its page-cache tree -- 16 threads put 3.6-5.3 GB/s into ONE fresh tmpfs file
+// (pwrite or mmap alike) and 63 GB/s into 16 files (scripts/probe/tmpfs_write_probe.py, mmap_write_probe.cpp) -- so a save that is
+// to run at the PCIe rate needs several inodes.  Stripe s (rows [s * S, (s + 1) * S) of the range) lives in part s % P at
+// row offset (s / P) * S; `layout` in the directory records P, S, row_bytes and the row count, and a load reads it back.
+struct BigsiRowsFile {
+    bool striped = false;
+    int fd = -1;
+    std::vector<int> fds;
+    uint64_t parts = 0, stripe_rows = 0, row_bytes = 0, file_offset = 0;
+    int open_(const char *path, bool save, uint64_t file_offset_, uint64_t row_bytes_, uint64_t n_rows);     // BIGSI_OK or an error (message set)
+    uint64_t chunk_rows() const;                                           // rows per pinned buffer
+    int io(bool write, uint8_t *buf, uint64_t rel_row, uint64_t n, unsigned threads) const;      // rows [rel_row, +n) of the range; 0 or errno
+    int sync_all() const;
+    void close_();
+};
 // profiling events (bigsi_hip_set_profiling): a pair around a group of launches on `st` (null: the index stream), collected in `dst`
 int bigsi_ev_begin(bigsi_hip_index *ix, EventPair *p, hipStream_t st = nullptr, bool row_and = false);
 int bigsi_ev_end(bigsi_hip_index *ix, EventPair *p, std::vector<EventPair> &dst, hipStream_t st = nullptr, uint32_t launches = 1);

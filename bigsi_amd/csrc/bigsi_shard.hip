@@ -4,8 +4,12 @@
 #include "bigsi_internal.hpp"
 
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <unistd.h>
 #include <rccl/rccl.h>      // types and prototypes only: the library is loaded at run time
 
+#include <cerrno>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -682,6 +686,132 @@ extern "C" int bigsi_hip_group_get_rows(bigsi_hip_group *g, const uint64_t *row_
         for (uint64_t r = 0; r < n; r++) memcpy(out + r * row_bytes + lo, part.data() + r * w, w);
     }
     return BIGSI_OK;
+}
+
+// ------------------------------------------------------------------------------ a row range between ONE file and all shards
+// KmerSignatureIndex.create / BerkeleyDBStorage (bigsi/graph/index.py:27-40, bigsi/storage/berkeleydb.py:6-19) for an index that is
+// spread over several GPUs: the file holds WHOLE rows (row_bytes each, the reference's row format: what a snapshot, a converted
+// v0.3 store or the single-GPU snapshot of the same index holds); shard i owns bytes [i * shard_cols / 8, +shard_cols / 8) of every
+// row.  One pinned double buffer for the group (portable: every device's DMA engine reads it); host threads on the file while the
+// other buffer is in flight; every chunk goes out as ONE two-dimensional copy per shard (source pitch = row_bytes, destination
+// pitch = the shard's row stride) on that shard's own stream -- the rows are cut at the shard boundaries by the copy engines, not
+// by the CPU, and all devices' PCIe links carry their share of a chunk at the same time.
+static int group_rows_file(bigsi_hip_group *g, const char *path, uint64_t file_offset, uint64_t row0, uint64_t n_rows, uint64_t row_bytes, uint32_t threads,
+                           bool save, bigsi_hip_io_stats *st)
+{
+    if (!g || !path) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    const uint64_t sb = g->shard_cols / 8;
+    // (a LOAD may name rows longer than the group holds -- the 128-byte-multiple pitch of a single-GPU snapshot of the same index:
+    // the bytes past the last shard are padding and are skipped)
+    if (row_bytes == 0 || (save && row_bytes > sb * g->n()))
+        return fail(BIGSI_ERR_CAPACITY, "row_bytes %llu not in [1, %llu] (the group's column capacity)", (unsigned long long)row_bytes, (unsigned long long)(sb * g->n()));
+    if (row0 > g->m || n_rows > g->m - row0) return fail(BIGSI_ERR_RANGE, "rows [%llu, +%llu) outside [0, %llu)", (unsigned long long)row0, (unsigned long long)n_rows, (unsigned long long)g->m);
+    if (threads == 0) threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency() / 4));
+    const uint32_t used = (uint32_t)std::min<uint64_t>(ceil_div(row_bytes, sb), g->n());          // shards that hold bytes of these rows
+    for (uint32_t i = 0; i < g->n(); i++) {
+        if (!save) TRY(bigsi_writable(g->ix[i]));
+        TRY(bigsi_hip_synchronize(g->ix[i]));
+    }
+    BigsiRowsFile rf;
+    TRY(rf.open_(path, save, file_offset, row_bytes, n_rows));
+    const uint64_t per = rf.chunk_rows();
+    void *pin[2] = {nullptr, nullptr};
+    std::vector<hipEvent_t> ev[2];
+    const auto t_begin = std::chrono::steady_clock::now();
+    double io_s = 0;
+    auto wait_slot = [&](int slot) -> int {
+        for (uint32_t i = 0; i < used; i++) {
+            HIP_TRY(hipSetDevice(g->ix[i]->device));
+            HIP_TRY(hipEventSynchronize(ev[slot][i]));
+        }
+        return BIGSI_OK;
+    };
+    auto copies = [&](int slot, uint64_t r0, uint64_t cn) -> int {      // chunk [r0, r0 + cn) between pin[slot] and every shard
+        for (uint32_t i = 0; i < used; i++) {
+            bigsi_hip_index *ix = g->ix[i];
+            const uint64_t lo = (uint64_t)i * sb, w = std::min(sb, row_bytes - lo), stride = ix->stride_words * 8;
+            uint8_t *dev = reinterpret_cast<uint8_t *>(ix->d_index) + r0 * stride, *host = static_cast<uint8_t *>(pin[slot]) + lo;
+            HIP_TRY(hipSetDevice(ix->device));
+            if (save) HIP_TRY(hipMemcpy2DAsync(host, row_bytes, dev, stride, w, cn, hipMemcpyDeviceToHost, ix->stream));
+            else HIP_TRY(hipMemcpy2DAsync(dev, stride, host, row_bytes, w, cn, hipMemcpyHostToDevice, ix->stream));
+            HIP_TRY(hipEventRecord(ev[slot][i], ix->stream));
+        }
+        return BIGSI_OK;
+    };
+    auto body = [&]() -> int {
+        for (int s = 0; s < 2; s++) {
+            HIP_TRY(hipHostMalloc(&pin[s], std::min(per, std::max<uint64_t>(n_rows, 1)) * row_bytes, hipHostMallocPortable));
+            ev[s].assign(used, nullptr);
+            for (uint32_t i = 0; i < used; i++) {
+                HIP_TRY(hipSetDevice(g->ix[i]->device));
+                HIP_TRY(hipEventCreateWithFlags(&ev[s][i], hipEventDisableTiming));
+            }
+        }
+        const uint64_t n_chunks = ceil_div(n_rows, per);
+        // load:  read(c) | copies(c) in flight while read(c + 1) runs;   save:  copies(c + 1) in flight while write(c) runs
+        for (uint64_t c = 0; c < n_chunks + (save ? 1 : 0); c++) {
+            const int slot = (int)(c & 1);
+            const uint64_t r0 = row0 + c * per, cn = c < n_chunks ? std::min(per, row0 + n_rows - r0) : 0;
+            if (save) {
+                if (c < n_chunks) TRY(copies(slot, r0, cn));
+                if (c > 0) {
+                    const int ps = (int)((c - 1) & 1);
+                    const uint64_t pr0 = row0 + (c - 1) * per, pn = std::min(per, row0 + n_rows - pr0);
+                    TRY(wait_slot(ps));
+                    const auto t0 = std::chrono::steady_clock::now();
+                    const int e = rf.io(true, static_cast<uint8_t *>(pin[ps]), pr0 - row0, pn, threads);
+                    io_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                    if (e) return fail(BIGSI_ERR_INVALID, "writing %s: %s", path, strerror(e));
+                }
+            } else {
+                TRY(wait_slot(slot));                                    // the copies that last read this buffer
+                const auto t0 = std::chrono::steady_clock::now();
+                const int e = rf.io(false, static_cast<uint8_t *>(pin[slot]), r0 - row0, cn, threads);
+                io_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                if (e) return fail(BIGSI_ERR_INVALID, "reading %s: %s", path, e == ENODATA ? "file too short" : strerror(e));
+                TRY(copies(slot, r0, cn));
+            }
+        }
+        for (int s = 0; s < 2; s++) TRY(wait_slot(s));
+        return BIGSI_OK;
+    };
+    int rc = body();
+    if (save && rc == BIGSI_OK) { const int e_ = rf.sync_all(); if (e_) rc = fail(BIGSI_ERR_INVALID, "fsync %s: %s", path, strerror(e_)); }
+    char keep[1024] = "";
+    if (rc != BIGSI_OK) snprintf(keep, sizeof keep, "%s", bigsi_hip_last_error());
+    hipError_t e = hipSuccess;
+    for (uint32_t i = 0; i < g->n(); i++) {
+        e = hipSetDevice(g->ix[i]->device);
+        e = hipStreamSynchronize(g->ix[i]->stream);
+    }
+    for (int s = 0; s < 2; s++) {
+        for (uint32_t i = 0; i < (uint32_t)ev[s].size(); i++)
+            if (ev[s][i]) { e = hipSetDevice(g->ix[i]->device); e = hipEventDestroy(ev[s][i]); }
+        if (pin[s]) e = hipHostFree(pin[s]);
+    }
+    (void)e;
+    rf.close_();
+    if (rc != BIGSI_OK) return fail(rc, "%s", keep);
+    if (st) {
+        st->bytes = n_rows * row_bytes;
+        st->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+        st->file_seconds = io_s;
+        st->threads = threads;
+        st->direct = 1u;
+    }
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_group_load_rows_file(bigsi_hip_group *g, const char *path, uint64_t file_offset, uint64_t row0, uint64_t n_rows, uint64_t row_bytes,
+                                              uint32_t threads, bigsi_hip_io_stats *stats)
+{
+    return group_rows_file(g, path, file_offset, row0, n_rows, row_bytes, threads, false, stats);
+}
+
+extern "C" int bigsi_hip_group_save_rows_file(bigsi_hip_group *g, const char *path, uint64_t file_offset, uint64_t row0, uint64_t n_rows, uint64_t row_bytes,
+                                              uint32_t threads, bigsi_hip_io_stats *stats)
+{
+    return group_rows_file(g, path, file_offset, row0, n_rows, row_bytes, threads, true, stats);
 }
 
 extern "C" int bigsi_hip_group_insert_columns(bigsi_hip_group *g, uint64_t col0, uint64_t n, const uint8_t *blooms, uint64_t bloom_stride_bytes)

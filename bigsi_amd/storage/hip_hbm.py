@@ -30,6 +30,7 @@ storage-config keys
 import json
 import os
 import re
+import shutil
 import struct
 import weakref
 
@@ -334,6 +335,7 @@ class HipHbmStorage(BaseStorage):
         for f in ((fn, fn + ".tmp") if fn else ()):
             if os.path.exists(f):
                 os.remove(f)
+            shutil.rmtree(f + ".d", ignore_errors=True)
 
     def sync(self):
         fn = self.storage_config.get("filename")
@@ -801,6 +803,7 @@ class ElementBatch(QueryBatch):
 # blocks) is still read.
 _MAGIC2 = b"BIGSIHBM2\n"
 _ALIGN = 4096
+_STRIPE_FROM = 256 << 20      # matrices from this size on are saved as striped part files
 _ATTACH_FORMAT = "bigsi-hip-attach-1"
 
 
@@ -867,10 +870,15 @@ def _save_snapshot(res, fn, threads=0):
     with open(tmp, "wb") as f:
         extra = b""
         if res.ix is not None:
-            if res.is_group:
-                return _save_snapshot_v1(res, fn)
             inf = res.info()
-            header.update(stride=int(inf.row_stride_bytes), num_cols=int(inf.num_cols), uniform_len=res.uniform_len,
+            if res.is_group:
+                # a multi-GPU index: whole rows in the reference's row format at a pitch of 8-byte multiples (shard i owns bytes
+                # [i * shard_cols / 8, ...) of every row; bigsi_hip_group_save_rows_file gathers them with one 2-D copy per shard)
+                pitch = max(int(inf.row_bytes), int(res.uniform_len or 0), int(res.rowlen.max()) if res.rowlen is not None else 0, 1)
+                pitch = min(-(-pitch // 8) * 8, int(inf.col_capacity) // 8)
+            else:
+                pitch = int(inf.row_stride_bytes)
+            header.update(stride=pitch, num_cols=int(inf.num_cols), uniform_len=res.uniform_len,
                           written_bytes=(res.m + 7) // 8, rowlen_bytes=0 if res.rowlen is None else int(res.rowlen.nbytes),
                           all_written=bool(res.written.all()))
             if not header["all_written"]:
@@ -879,39 +887,29 @@ def _save_snapshot(res, fn, threads=0):
                 header["written_bytes"] = 0
             if res.rowlen is not None:
                 extra += res.rowlen.tobytes()
+            # a large matrix goes into a DIRECTORY of striped part files beside the header file (`fn`.d/): writes to one file are
+            # serialised by its inode -- 3.6-5 GB/s however many threads -- and 16 files take the PCIe rate (csrc: BigsiRowsFile)
+            header["striped"] = res.m * header["stride"] >= _STRIPE_FROM
         hb = json.dumps(header).encode("utf-8")
         head = _MAGIC2 + struct.pack("<Q", len(hb)) + hb + extra
         data_off = -(-len(head) // _ALIGN) * _ALIGN
         f.write(head + b"\0" * (data_off - len(head)))
     if res.ix is not None:
         stats = _lib.IoStats()
-        check(_lib.lib().bigsi_hip_save_rows_file(res.ix, tmp.encode(), data_off, 0, res.m, header["stride"], int(threads), _lib.C.byref(stats)))
+        if header["striped"]:
+            shutil.rmtree(tmp + ".d", ignore_errors=True)
+            check(res.fn("save_rows_file")(res.ix, (tmp + ".d/").encode(), 0, 0, res.m, header["stride"], int(threads), _lib.C.byref(stats)))
+            shutil.rmtree(fn + ".old.d", ignore_errors=True)
+            if os.path.isdir(fn + ".d"):
+                os.rename(fn + ".d", fn + ".old.d")
+            os.rename(tmp + ".d", fn + ".d")
+            shutil.rmtree(fn + ".old.d", ignore_errors=True)
+        else:
+            check(res.fn("save_rows_file")(res.ix, tmp.encode(), data_off, 0, res.m, header["stride"], int(threads), _lib.C.byref(stats)))
     os.replace(tmp, fn)
+    if not header.get("striped"):
+        shutil.rmtree(fn + ".d", ignore_errors=True)
     return stats
-
-
-def _save_snapshot_v1(res, fn):
-    header = {"kv": {k.decode("latin-1"): v.decode("latin-1") for k, v in res.kv.items()},
-              "m": res.m, "rb": 0}
-    tmp = fn + ".tmp"
-    with open(tmp, "wb") as f:
-        if res.ix is not None:
-            header["rb"] = max(int(res.info().row_bytes), int(res.uniform_len or 0), int(res.rowlen.max()) if res.rowlen is not None else 0, 1)
-            header["written"] = np.packbits(res.written).tobytes().hex()
-            header["uniform_len"] = res.uniform_len
-            if res.rowlen is not None:
-                header["rowlen"] = res.rowlen.tobytes().hex()
-        hb = json.dumps(header).encode("utf-8")
-        f.write(_MAGIC + struct.pack("<Q", len(hb)) + hb)
-        if res.ix is not None:
-            rb, step = header["rb"], max(1, (64 << 20) // header["rb"])
-            for r0 in range(0, res.m, step):
-                ids = np.arange(r0, min(res.m, r0 + step), dtype=np.uint64)
-                out = np.zeros((ids.size, rb), np.uint8)
-                check(res.fn("get_rows")(res.ix, _lib.ptr(ids), ids.size, _lib.ptr(out), rb))
-                f.write(out.tobytes())
-    os.replace(tmp, fn)
-    return None
 
 
 def _load_snapshot(res, fn, threads=0):
@@ -928,14 +926,17 @@ def _load_snapshot(res, fn, threads=0):
             written = np.unpackbits(np.frombuffer(f.read(wb), np.uint8))[:m].astype(bool) if wb else None
             rowlen = np.frombuffer(f.read(lb), np.uint32).copy() if lb else None
             data_off = -(-f.tell() // _ALIGN) * _ALIGN
-            if res.is_group:
-                raise BigsiHipError(_lib.ERR_STATE, "%s is a single-device snapshot; a multi-GPU index loads per-shard files" % fn)
-            res.open(m, int(header.get("num_cols", 0)), cap=stride * 8)
-            have = int(res.info().row_stride_bytes)
-            if have < stride:
-                raise BigsiHipError(_lib.ERR_CAPACITY, "%s holds rows of %d bytes, the index was opened with a pitch of %d" % (fn, stride, have))
+            # (a single-GPU snapshot loads into a group and the other way round: the file holds whole rows either way, at the
+            # writer's pitch; whatever the pitch pads beyond the columns is zero)
+            res.open(m, int(header.get("num_cols", 0)), cap=max(stride * 8 if not res.is_group else 0, int(header.get("num_cols", 0))))
+            have = int(res.info().col_capacity) // 8 if res.is_group else int(res.info().row_stride_bytes)
+            if have < (-(-int(header.get("num_cols", 0)) // 8) if res.is_group else stride):
+                raise BigsiHipError(_lib.ERR_CAPACITY, "%s holds rows of %d bytes, the index was opened with room for %d" % (fn, stride, have))
             stats = _lib.IoStats()
-            check(_lib.lib().bigsi_hip_load_rows_file(res.ix, fn.encode(), data_off, 0, m, stride, int(threads), _lib.C.byref(stats)))
+            if header.get("striped"):
+                check(res.fn("load_rows_file")(res.ix, (fn + ".d/").encode(), 0, 0, m, stride, int(threads), _lib.C.byref(stats)))
+            else:
+                check(res.fn("load_rows_file")(res.ix, fn.encode(), data_off, 0, m, stride, int(threads), _lib.C.byref(stats)))
             res.written = written if written is not None else np.ones(m, dtype=bool)
             res.uniform_len, res.rowlen = header.get("uniform_len"), rowlen
             return stats
@@ -948,15 +949,8 @@ def _load_snapshot(res, fn, threads=0):
             m, rb = int(header["m"]), int(header["rb"])
             n_cols = int(res.kv.get(b"number_of_cols:int", b"0"))
             res.open(m, n_cols, cap=rb * 8)
-            if res.is_group:
-                step = max(1, (64 << 20) // rb)
-                for r0 in range(0, m, step):
-                    cnt = min(m, r0 + step) - r0
-                    blob = np.frombuffer(f.read(cnt * rb), dtype=np.uint8).reshape(cnt, rb)
-                    ids = np.arange(r0, r0 + cnt, dtype=np.uint64)
-                    check(res.fn("set_rows")(res.ix, _lib.ptr(ids), cnt, _lib.ptr(np.ascontiguousarray(blob)), rb))
-            else:       # (an old file still loads at the new rate: rows of rb bytes go through the scatter kernel)
-                check(_lib.lib().bigsi_hip_load_rows_file(res.ix, fn.encode(), f.tell(), 0, m, rb, int(threads), None))
+            # (an old file still loads at the new rate: rows of rb bytes through the scatter kernel, or 2-D copies into a group)
+            check(res.fn("load_rows_file")(res.ix, fn.encode(), f.tell(), 0, m, rb, int(threads), None))
             res.written = np.unpackbits(np.frombuffer(bytes.fromhex(header["written"]), np.uint8))[:m].astype(bool)
             res.uniform_len = header.get("uniform_len")
             if header.get("rowlen"):

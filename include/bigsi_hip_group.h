@@ -46,6 +46,17 @@ int bigsi_hip_group_insert_columns(bigsi_hip_group *g, uint64_t col0, uint64_t n
 int bigsi_hip_group_get_column(bigsi_hip_group *g, uint64_t col, uint8_t *out);
 int bigsi_hip_group_insert_kmers(bigsi_hip_group *g, uint64_t col, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k);
 int bigsi_hip_group_fill_synthetic(bigsi_hip_group *g, uint64_t seed, uint32_t and_draws); /* shard i = fill_synthetic(seed, i) */
+/* bigsi_hip_load_rows_file / bigsi_hip_save_rows_file for a group (KmerSignatureIndex.create, bigsi/graph/index.py:27-40; the
+ * store a BerkeleyDBStorage opens, bigsi/storage/berkeleydb.py:6-19): rows [row0, row0 + n_rows) as WHOLE rows of row_bytes bytes
+ * each, in the reference's row format, at file_offset of `path`.  Shard i owns bytes [i * shard_cols / 8, +shard_cols / 8) of every
+ * row: each 256 MB chunk of the file goes out as one two-dimensional copy per shard from a pinned buffer every device reads, on the
+ * shards' own streams (all PCIe links busy at once), while host threads read the next chunk.  A load may name rows longer than the
+ * group's capacity (the padded pitch of a single-GPU snapshot of the same index): the excess is skipped.  Bytes of a shard's rows
+ * beyond row_bytes are left as they are (zero in an index that was just opened). */
+int bigsi_hip_group_load_rows_file(bigsi_hip_group *g, const char *path, uint64_t file_offset, uint64_t row0, uint64_t n_rows, uint64_t row_bytes,
+                                   uint32_t threads, bigsi_hip_io_stats *stats /* may be NULL */);
+int bigsi_hip_group_save_rows_file(bigsi_hip_group *g, const char *path, uint64_t file_offset, uint64_t row0, uint64_t n_rows, uint64_t row_bytes,
+                                   uint32_t threads, bigsi_hip_io_stats *stats /* may be NULL */);
 int bigsi_hip_group_lookup(bigsi_hip_group *g, const char *kmers, uint32_t k, uint64_t u, uint8_t *out_rows);
 int bigsi_hip_group_lookup_raw(bigsi_hip_group *g, const char *blob, const uint64_t *elem_offsets, uint64_t u, uint8_t *out_rows);
 /* fused query path over all shards; same meaning as the bigsi_hip_batch_* calls, colours are global */

@@ -27,6 +27,7 @@ def main():
     p.add_argument("--dir", default=None, help="where the snapshot goes (default: /dev/shm if it has room, else the system temp dir)")
     p.add_argument("--threads", type=int, default=0)
     p.add_argument("--sample-rows", type=int, default=64)
+    p.add_argument("--group-gb", type=float, default=8.0, help="size of the two-shard group whose snapshot is also written and loaded (0 = skip)")
     a = p.parse_args()
     import tempfile
     from bigsi_amd import _lib
@@ -101,11 +102,41 @@ def main():
         except Exception as e:  # noqa: BLE001
             out["pcie_h2d_GBps"] = None
             out["pcie_note"] = str(e)[:80]
+        # why the snapshot's matrix is a directory of 16 striped part files: the same save into ONE file (every pwrite of a file takes
+        # its inode lock, every new page goes into its one page-cache tree), a quarter of the rows
+        one = fn + ".one"
+        s1 = _lib.IoStats()
+        n1 = max(m // 4, 1)
+        _lib.check(_lib.lib().bigsi_hip_save_rows_file(st2.handle, one.encode(), 0, 0, n1, stride, a.threads, _lib.C.byref(s1)))
+        out["save_one_file_GBps"] = s1.bytes / s1.seconds / 1e9
+        os.remove(one)
         st2.delete_all()
+        # the same for an index spread over several GPUs of this process (storage-config devices=[...]; here two shards on this
+        # one device): whole rows, one 2-D copy per shard and 256 MB chunk (bigsi_hip_group_save / load_rows_file)
+        if a.group_gb > 0:
+            mg = int(a.group_gb * 1e9 // stride)
+            gcfg = {"storage-engine": "hip-hbm", "k": 31, "m": mg, "h": a.hashes, "storage-config": {"name": "ingest-group", "max_cols": a.cols, "devices": [0, 0]}}
+            sg = get_storage(gcfg)
+            sg.delete_all()
+            for key, v in (("number_of_rows", mg), ("number_of_cols", a.cols), ("ksi:bloomfilter_size", mg), ("ksi:num_hashes", a.hashes)):
+                sg.set_integer(key, v)
+            sg.fill_synthetic(SEED, 0, 2)
+            sg.res.written[:] = True
+            ids = np.arange(0, mg, max(mg // 50, 1), dtype=np.uint64)
+            before = np.asarray(sg.get_rows_packed(ids)).copy()
+            gs = sg.save_snapshot(fn + ".grp", a.threads)
+            sg.delete_all()
+            sg2, gl = HipHbmStorage.load_snapshot(gcfg["storage-config"], fn + ".grp", a.threads)
+            assert np.array_equal(np.asarray(sg2.get_rows_packed(ids)), before), "group snapshot round trip differs"
+            out.update(group_gb=gs.bytes / 1e9, group_save_GBps=gs.bytes / gs.seconds / 1e9, group_load_GBps=gl.bytes / gl.seconds / 1e9,
+                       group_load_file_GBps=gl.bytes / max(gl.file_seconds, 1e-9) / 1e9, group_shards=2)
+            sg2.delete_all()
     finally:
-        for f in (fn, fn + ".tmp"):
+        import shutil
+        for f in (fn, fn + ".tmp", fn + ".one", fn + ".grp", fn + ".grp.tmp"):
             if os.path.exists(f):
                 os.remove(f)
+            shutil.rmtree(f + ".d", ignore_errors=True)
     print(json.dumps(out))
 
 

@@ -9,6 +9,7 @@
   issued, on the library's own communicator stream.
 The N-rank RCCL run is the driver's scaling bench (bench.py --gpus N), which verifies planted hits on every shard."""
 import itertools
+import os
 
 import numpy as np
 import pytest
@@ -334,3 +335,90 @@ def test_group_at_c4_column_geometry_eight_shards_with_scores():
                 n_hits += 1
         assert n_hits >= (6 if thr == 1.0 else 48), (thr, n_hits)
     index.delete()
+
+
+def test_group_snapshot_round_trip_and_cross_loading(tmp_path):
+    """sync() of a multi-GPU index writes whole rows through bigsi_hip_group_save_rows_file (one 2-D copy per shard and chunk) and a
+    fresh open loads them through bigsi_hip_group_load_rows_file; the file also loads into a single-GPU index and a single-GPU
+    snapshot (rows at its padded 128-byte-multiple pitch) loads into a group: same rows, same answers."""
+    from bigsi_amd.storage import get_storage, hip_hbm
+    m, total, h, seed = 40_009, 1000, 3, 31
+    fn = str(tmp_path / "grp.hbm")
+    cfg, st = group_storage(m, total, h, [0, 0, 0], seed)
+    sc, orcs = shard_oracles(st, m, h, seed, 1)
+    rng = np.random.default_rng(2)
+    seqs = rand_seqs(rng, 6, 40, 200)
+    for j, c in enumerate((5, sc - 1, sc, 2 * sc + 7, total - 1)):
+        st.insert_kmers(c, [seqs[j]], 31)
+        orcs[c // sc].insert_kmers(c % sc, seqs[j])
+    st.set_string("metadata:5:string", "five")
+    ids = np.arange(0, m, 37, dtype=np.uint64)
+    st.res.written[:] = True
+    rows = np.asarray(st.get_rows_packed(ids)).copy()
+    stats = st.save_snapshot(fn)
+    assert stats is not None and stats.bytes == m * 128           # 1000 columns: 125 bytes, pitch of 8-byte multiples
+    assert open(fn, "rb").read(10) == b"BIGSIHBM2\n"
+
+    def answers(s_):
+        batch = s_.new_batch(seqs, 31)
+        out = []
+        for thr in (1.0, 0.4):
+            batch.run(thr)
+            off, colours, counts = batch.hits()
+            out.append((off.tolist(), colours[: int(off[-1])].tolist(), counts[: int(off[-1])].tolist()))
+        batch.close()
+        return out
+    want = answers(st)
+    for i, s in enumerate(seqs):          # ... which are the oracle's
+        u, cnt = whole_counts(orcs, sc, s)
+        lo, hi = want[0][0][i], want[0][0][i + 1]
+        assert want[0][1][lo:hi] == np.flatnonzero(cnt >= u).tolist()
+    st.delete_all()
+    # a group of another shape, and one GPU, from the same file
+    for devs in ([0, 0], [0, 0, 0, 0], None):
+        sc_ = {"name": "grpload%d" % next(_counter), "max_cols": total}
+        if devs:
+            sc_["devices"] = devs
+        s2, _ = hip_hbm.HipHbmStorage.load_snapshot(sc_, fn)
+        assert s2.get_string("metadata:5:string") == "five" and s2.get_integer("number_of_cols") == total
+        assert np.array_equal(np.asarray(s2.get_rows_packed(ids)), rows)
+        got = answers(s2)
+        assert got == want                 # (a colour is a column of the whole row, whatever the shard width)
+        if devs is None:
+            fn1 = str(tmp_path / "single.hbm")
+            s2.save_snapshot(fn1)          # rows at the single GPU's 128-byte pitch
+            s3, _ = hip_hbm.HipHbmStorage.load_snapshot({"name": "grpload%d" % next(_counter), "max_cols": total, "devices": [0, 0, 0]}, fn1)
+            assert np.array_equal(np.asarray(s3.get_rows_packed(ids)), rows) and answers(s3) == want
+            s3.delete_all()
+        s2.delete_all()
+
+
+def test_group_rows_file_rate(tmp_path):
+    """A 2-shard group on one device: 6 GB of whole rows saved and loaded back through the group entry points; the load runs at
+    the file <-> HBM rate of the single-GPU route (>= 15 GB/s from page cache), sampled rows identical."""
+    import shutil
+    from bigsi_amd import _lib
+    d = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 16e9 else str(tmp_path)
+    fn = os.path.join(d, "bigsi_group_rate_%d.bin" % os.getpid())
+    m, total = 480_000, 100_000
+    cfg, st = group_storage(m, total, 3, [0, 0], 5, draws=2)
+    try:
+        rb = 12_504
+        ids = np.arange(0, m, 4801, dtype=np.uint64)
+        st.res.written[:] = True
+        rows = np.asarray(st.get_rows_packed(ids, rb)).copy()
+        ss, ls = _lib.IoStats(), _lib.IoStats()
+        _lib.check(_lib.lib().bigsi_hip_group_save_rows_file(st.handle, fn.encode(), 4096, 0, m, rb, 0, _lib.C.byref(ss)))
+        assert os.path.getsize(fn) == 4096 + m * rb
+        _lib.check(_lib.lib().bigsi_hip_group_clear(st.handle))
+        assert not np.asarray(st.get_rows_packed(ids[:3], rb)).any()
+        _lib.check(_lib.lib().bigsi_hip_group_load_rows_file(st.handle, fn.encode(), 4096, 0, m, rb, 0, _lib.C.byref(ls)))
+        assert np.array_equal(np.asarray(st.get_rows_packed(ids, rb)), rows)
+        rate = ls.bytes / ls.seconds / 1e9
+        print("group rows file: save %.1f GB/s, load %.1f GB/s (file side %.1f GB/s, %d threads, %s)"
+              % (ss.bytes / ss.seconds / 1e9, rate, ls.bytes / max(ls.file_seconds, 1e-9) / 1e9, ls.threads, d))
+        assert rate >= 15.0, "group load ran at %.1f GB/s" % rate
+    finally:
+        if os.path.exists(fn):
+            os.remove(fn)
+        st.delete_all()

@@ -290,6 +290,25 @@ def test_snapshot_roundtrip(hip, tmp_path):
     b2.delete()
 
 
+def write_v1_snapshot(st, fn, rb):
+    """A version-1 snapshot file as rounds 1-3 wrote them (the product only reads them now): JSON header with the written-row bitmap in
+    hex, then every row at rb bytes."""
+    import struct
+    res = st.res
+    header = {"kv": {k.decode("latin-1"): v.decode("latin-1") for k, v in res.kv.items()}, "m": res.m, "rb": rb,
+              "written": np.packbits(res.written).tobytes().hex(), "uniform_len": res.uniform_len}
+    if res.rowlen is not None:
+        header["rowlen"] = res.rowlen.tobytes().hex()
+    hb = json.dumps(header).encode("utf-8")
+    with open(fn, "wb") as f:
+        f.write(b"BIGSIHBM1\n" + struct.pack("<Q", len(hb)) + hb)
+        ids = np.arange(res.m, dtype=np.uint64)
+        out = np.zeros((res.m, rb), np.uint8)
+        from bigsi_amd import _lib
+        _lib.check(res.fn("get_rows")(res.ix, _lib.ptr(ids), ids.size, _lib.ptr(out), rb))
+        f.write(out.tobytes())
+
+
 def test_snapshot_v2_is_the_device_layout_and_round_trips(hip, tmp_path):
     """sync() writes the device layout (rows at the device pitch behind a 4096-byte aligned header, bitmap of written rows raw) through
     bigsi_hip_save_rows_file; a fresh process' open goes through bigsi_hip_load_rows_file.  Rows never stored stay KeyErrors, rows
@@ -326,7 +345,7 @@ def test_snapshot_v2_is_the_device_layout_and_round_trips(hip, tmp_path):
         st2.get_bitarray(missing)
     # version 1 of the same index still loads (through the scatter route: its rows are 38 bytes, not 128)
     fn1 = str(tmp_path / "v1.hbm")
-    hip_hbm._save_snapshot_v1(st2.res, fn1)
+    write_v1_snapshot(st2, fn1, 38)
     st2.delete_all()
     c1 = cfg(31, 5003, 3, filename=fn1, max_cols=300, name="snapv1")
     st3 = get_storage(c1)
