@@ -100,6 +100,10 @@ def parse():
                    help="the hit-dense variant of the workload (what real thresholded searches produce; the plain workloads carry ~1 hit per query): "
                         "gene-length queries: the first 16 queries of every batch are held, up to 15 SNPs apart, by 1 %% of the shard's samples "
                         "(~625 hits per query at 62.5 k samples, ~10 k per batch); reads: every read is held by 8 samples")
+    p.add_argument("--early-exit", type=int, default=0, choices=[0, 1],
+                   help="run with the library's opt-in early exit (a wavefront stops fetching a query's rows for its column segment once no sample "
+                        "there can still reach the threshold): same hit lists, FEWER bytes than the reference reads -- reported as legs beside "
+                        "the plain figures, never as the headline; roofline figures of such a run price the ALGORITHMIC bytes, not the bytes read")
     p.add_argument("--no-verify", action="store_true")
     p.add_argument("--score-queue", default="beside", choices=["ordered", "beside"],
                    help="score=True workloads: K5 + K6 of a batch queued on the index stream behind the next batch's kernels (ordered) or on "
@@ -267,6 +271,8 @@ ALSO_LEGS = {
         ("c5_dense", "configs[4] shard, 16 of 256 queries held by 1 % of the samples (~10 k scored hits per batch)",
          ["--workload", "c5", "--shard-of", "8", "--dense", "1", "--warmup", "6"], 150),
         ("c2_dense", "configs[1], every read held by 8 samples", ["--workload", "c2", "--dense", "1", "--warmup", "200"], 30000),
+        # opt-in early exit on the hit-dense index (NOT the reference's byte count: `tr` = bytes read / algorithmic bytes says how much less)
+        ("c5_ee", "the c5_dense shard with early_exit (unscored step)", ["--workload", "c5", "--shard-of", "8", "--dense", "1", "--early-exit", "1", "--score", "0", "--warmup", "6"], 1500),
         # f1, index ingest: a 32 GB snapshot (device layout) written, dropped, loaded back (threads on the file, two pinned buffers,
         # asynchronous copies), sampled rows verified against the oracle's generator: scripts/ingest_bench.py, keys in GB/s
         ("ingest", "snapshot of a 32 GB index written / dropped / loaded back", ["--ingest", "32"], 0)],
@@ -306,7 +312,7 @@ def leg_summary(d, what, extra, wall_s):
     for k_src, k_dst in (("exchange_ms", "x_ms"), ("rccl_ranks", "ranks"), ("per_rank_GBps", "gbs"), ("scored_hits", "hits"), ("scored_us_per_hit", "us_hit"),
                          ("hv_scored_lookups_per_s", "hvs"), ("distinct_gpus", "gpus_distinct"), ("one_call_us_batch", "usb"), ("frac_overlapped", "f3"),
                          ("hits_per_s", "hps"), ("hv_hits_per_s", "hvh"), ("hv_scored_hits_per_s", "hvsh"), ("dicts_per_s", "dps"), ("k5_traffic_ratio", "tr5"),
-                         ("k56_ms", "k56"), ("k56_GBps", "k56g")):
+                         ("k56_ms", "k56"), ("k56_GBps", "k56g"), ("early_exit", "ee")):
         v = cf.get(k_src, rf.get(k_src))
         if v is not None:
             out[k_dst] = v
@@ -412,7 +418,7 @@ def condense(full):
         "hv_hits_per_s": sig((hv.get("stream") or {}).get("hits") / ((hv.get("stream") or {}).get("call_ms") * 1e-3), 4) if cf.get("dense") and hv.get("stream") else None,
         "hv_scored_hits_per_s": sig((hv.get("stream_scored") or {}).get("hits_per_s"), 4) if cf.get("dense") else None,
         "dicts_per_s": sig((hv.get("scored_dicts") or hv.get("dicts") or {}).get("dicts_per_s"), 4),
-        "k5_traffic_ratio": sig(cf.get("k5_traffic_ratio"), 4),
+        "k5_traffic_ratio": sig(cf.get("k5_traffic_ratio"), 4), "early_exit": 1 if cf.get("early_exit") else None,
         "k56_ms": sig(pres.get("kernels_ms"), 4) if cf.get("dense") else None, "k56_GBps": sig(pres.get("GBps"), 4) if cf.get("dense") else None,
     }
     roof = {"bound": "hbm", "achieved": sig(rf["achieved"]), "peak": rf["peak"], "unit": "GB/s", "frac": sig(rf["frac"], 4),
@@ -474,11 +480,84 @@ def smi_snapshot(device):
         return {"error": "%s: %s" % (type(e).__name__, str(e)[:120])}
 
 
+def _err_file(rank):
+    return os.path.join(tempfile.gettempdir(), "bigsi_bench_err_%s_%s.json" % (os.environ.get("MASTER_PORT", "0"), rank))
+
+
+def _nccl_tail(n=12):
+    """last lines of this process's RCCL log (NCCL_DEBUG=WARN is set for every multi-rank run: silent while all is well)"""
+    try:
+        with open(os.environ.get("BIGSI_NCCL_LOG", "")) as f:
+            return [l.rstrip()[:200] for l in f.readlines()[-n:]]
+    except OSError:
+        return []
+
+
+def failure_line(args, world, rank, exc, others=None):
+    """The ONE line of a run that failed: same top-level keys (value null), the error, the rank it came from, what the other ranks
+    reported and the tail of RCCL's log -- so that a first run on real multi-GPU hardware is diagnosable from the driver's record."""
+    import traceback
+    tb = traceback.extract_tb(exc.__traceback__) if getattr(exc, "__traceback__", None) else []
+    where = ["%s:%d %s" % (os.path.basename(f.filename), f.lineno, f.name) for f in tb[-3:]]
+    return {"metric": "kmer_lookups_per_s", "value": None, "unit": "kmer_lookups/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": None, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "rc": 1, "error": ("%s: %s" % (type(exc).__name__, exc))[:400], "failing_rank": rank, "where": where,
+            "nccl_debug_tail": _nccl_tail(), "other_ranks": others or [],
+            "config": {"workload_key": args.workload, "backend": args.backend, "env": {k_: os.environ.get(k_) for k_ in
+                       ("HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "LOCAL_RANK", "MASTER_PORT")}}}
+
+
 def main():
     args = parse()
-    w = args.w
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args)
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        # RCCL says why it failed only when asked to: WARN level into a per-process file, read back by failure_line
+        os.environ.setdefault("NCCL_DEBUG", "WARN")
+        os.environ.setdefault("BIGSI_NCCL_LOG", os.path.join(tempfile.gettempdir(), "bigsi_bench_nccl_%s_%d.log" % (os.environ.get("MASTER_PORT", "0"), rank)))
+        os.environ.setdefault("NCCL_DEBUG_FILE", os.environ["BIGSI_NCCL_LOG"])
+        try:
+            os.remove(_err_file(rank))
+        except OSError:
+            pass
+        if rank == 0:
+            # the launcher ends the surviving ranks with SIGTERM when one rank dies: rank 0 then still prints the line, with what
+            # the dead rank left behind
+            import signal
+
+            def on_term(*_):
+                others = []
+                for r_ in range(1, world):
+                    try:
+                        with open(_err_file(r_)) as f:
+                            others.append(json.load(f))
+                    except (OSError, ValueError):
+                        pass
+                print(json.dumps(failure_line(args, world, 0, RuntimeError("terminated by the launcher (another rank failed)"), others)), flush=True)
+                os._exit(1)
+            signal.signal(signal.SIGTERM, on_term)
+    try:
+        return run(args)
+    except (Exception, SystemExit) as e:  # noqa: BLE001
+        if isinstance(e, SystemExit) and e.code in (0, None):
+            raise
+        line = failure_line(args, world, rank, e)
+        if rank == 0:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+            print(json.dumps(line), flush=True)
+        else:
+            try:
+                with open(_err_file(rank), "w") as f:
+                    json.dump({k_: line[k_] for k_ in ("error", "failing_rank", "where", "nccl_debug_tail")}, f)
+            except OSError:
+                pass
+        raise
+
+
+def run(args):
+    w = args.w
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -518,6 +597,8 @@ def main():
         else:
             raise SystemExit("rank %d needs device %d but only %d GPU(s) are visible (--one-device --backend gloo shares one)"
                              % (rank, local_rank, torch.cuda.device_count()))
+    if os.environ.get("BIGSI_BENCH_FAIL_RANK") == str(rank):          # tests/test_gpu_two_rank.py: what the other ranks and the line do when a rank dies
+        raise RuntimeError("BIGSI_BENCH_FAIL_RANK=%d: this rank was told to fail" % rank)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
@@ -710,7 +791,7 @@ def main():
         if args.one_stream:
             batch.run(thr, sparse_counts=True, one_stream=True)
         else:
-            sh.step(batches, thr)
+            sh.step(batches, thr, early_exit=bool(args.early_exit))
         if w["score"]:
             job, begun[0] = begun[0], None      # queued one step ago, behind the previous launch: done (or nearly) by now
             score_begin()                       # the batch launched one step ago: its K5 + K6 go behind the launch just made
@@ -958,7 +1039,7 @@ def main():
     # collected from inside the timed run; see profiles/)
     traffic, traffic_src = None, None
     wkey = "rows=%d cols=%d hashes=%d batch=%d qlen=%d k=%d threshold=%s draws=%d%s" % (
-        w["rows"], my_cols, w["hashes"], w["batch"], w["qlen"], args.k, repr(float(thr)), args.and_draws, " dense=1" if args.dense else "")
+        w["rows"], my_cols, w["hashes"], w["batch"], w["qlen"], args.k, repr(float(thr)), args.and_draws, (" dense=1" if args.dense else "") + (" ee=1" if args.early_exit else ""))
     k5_ratio = None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
@@ -1086,6 +1167,7 @@ def main():
                 ("first %d queries of every batch held, 0-%d SNPs apart, by %g %% of the shard's samples" % (DENSE_QUERIES, DENSE_MAX_SNPS, 100 * DENSE_COL_FRACTION)
                  if gene_dense else "every read held by %d samples" % DENSE_READ_HITS),
                 "dense_plant_s": dense_s if args.dense else None,
+                "early_exit": bool(args.early_exit) or None,
                 "hits_per_s": int(off[-1]) / (elapsed / args.steps) if args.dense else None,
                 "k5_traffic_ratio": k5_ratio,
                 "value_is": "unique query k-mers per second against the %d samples held by this run, exchange included" % total_cols,

@@ -224,7 +224,7 @@ class ShardedSearch(object):
             if self.sg.dist.is_initialized():
                 self.sg.dist.all_reduce(self._hitbufs[s][1], group=self.sg.group)
 
-    def step(self, batches, threshold):
+    def step(self, batches, threshold, early_exit=False):
         """Asynchronous.  Alone: K1-K4 of the next batch.  Sharded: K1-K3, then all-gather of the per-sample vectors + K4
         over the gathered result on the communicator's stream."""
         if not isinstance(batches, (list, tuple)):
@@ -233,16 +233,16 @@ class ShardedSearch(object):
         batch = batches[s]
         self._i += 1
         if not self.gathering:
-            batch.run(threshold, sparse_counts=True)
+            batch.run(threshold, sparse_counts=True, early_exit=early_exit)
             return
         if self.exchange == "rccl":
-            check(_lib.lib().bigsi_hip_batch_run_sharded(batch.b, float(threshold), 0))
+            check(_lib.lib().bigsi_hip_batch_run_sharded(batch.b, float(threshold), _lib.RUN_EARLY_EXIT if early_exit else 0))
             return
         torch = self.torch
         with torch.cuda.stream(self.stream):
             if self._ev_free[s] is not None:
                 self.stream.wait_event(self._ev_free[s])        # this slot's previous exchange has released the buffer
-            batch.run(threshold, skip_compact=True, sparse_counts=True)
+            batch.run(threshold, skip_compact=True, sparse_counts=True, early_exit=early_exit)
             self._ev_run[s].record(self.stream)
         with torch.cuda.stream(self.comm_stream):
             self.comm_stream.wait_event(self._ev_run[s])

@@ -349,7 +349,7 @@ def test_bench_line_is_condensed_under_the_drivers_tail():
     # every world size the driver uses has its legs; 8 GPUs run the configurations that need 8 GPUs as WHOLE indexes
     assert [k for k, *_ in bench.also_legs_for(8)] == ["c4", "c5", "northstar", "c3_t04"] and [k for k, *_ in bench.also_legs_for(4)][0] == "northstar"
     assert all("--shard-of" not in extra for n in (2, 4, 8) for _, _, extra, _ in bench.also_legs_for(n))
-    assert [k for k, *_ in bench.also_legs_for(1)][-1] == "ingest" and len(bench.also_legs_for(1)) == 9 and {"c5_dense", "c2_dense"} <= {k for k, *_ in bench.also_legs_for(1)} and bench.also_legs_for(3)[0][0] == "c3_t04"
+    assert [k for k, *_ in bench.also_legs_for(1)][-1] == "ingest" and len(bench.also_legs_for(1)) == 10 and {"c5_dense", "c2_dense", "c5_ee"} <= {k for k, *_ in bench.also_legs_for(1)} and bench.also_legs_for(3)[0][0] == "c3_t04"
 
 
 def test_cortex_reader_vs_reference(tmp_path):
@@ -523,3 +523,16 @@ def test_search_stream_batches_stay_bounded_when_sequences_grow_along_the_stream
     sizes.clear()
     out = list(BIGSI._stream_loop(iter(seqs[:1000]), 10, 10, 1 << 19, 31, submit, lambda p: [[] for _ in p[1]]))     # explicit batch_size: untouched
     assert len(sizes) == 100 and [s for s, _ in out] == seqs[:1000]
+
+
+def test_bench_failure_leaves_a_json_line():
+    """A run that cannot go ahead (here: a workload that does not fit one GPU, refused before any device is touched) exits non-zero AND
+    prints the one JSON line with value null, rc 1 and the error -- the driver's record then says why."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c4", "--gpus", "1"], env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode != 0 and "more than one MI355X holds" in r.stderr
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["value"] is None and d["rc"] == 1 and d["n_gpus"] == 1 and "more than one MI355X holds" in d["error"] and d["where"]
