@@ -954,6 +954,9 @@ def run(args):
     host_visible = {"two_workspace_loop_kmer_lookups_per_s": pcie_rate}
     if world == 1 and not args.force_dist and args.host_visible:
         lib_ = _lib.lib()
+        # (the library's profiling events -- on since the timed region -- cost a stream 5-7 us per record: the latency figures
+        # below are those of a library nobody is profiling, as scripts/call_breakdown.py measures them)
+        check(lib_.bigsi_hip_set_profiling(st.handle, 0))
         want = 256 if w["batch"] * w["qlen"] < (1 << 17) else (8 if w["batch"] * w["qlen"] < (1 << 20) else 2)
         if w["score"]:
             want = max(want, 24)              # (six device batches of the library's own size: its pipeline in steady state)
@@ -979,12 +982,13 @@ def run(args):
         from bigsi_amd.graph import bigsi as _front
         if args.dense and not w["score"] and _front._results is not None:
             # the reference's result dicts for the stream's hits (what BIGSI.search_stream yields), assembled from its arrays
-            t_ = time.perf_counter()
-            res_ = list(_front.native_result_lists(hnk, hnu, hoff.astype(np.int64), hcol, hcnt, exact, names, None, total_cols))
+            # (consumed as BIGSI.search_stream's caller consumes them: a sequence's list is dropped before the next one is looked at)
+            t_, n_d = time.perf_counter(), 0
+            for r_ in _front.native_result_lists(hnk, hnu, hoff.astype(np.int64), hcol, hcnt, exact, names, None, total_cols):
+                n_d += len(r_)
             dt_ = time.perf_counter() - t_
-            assert sum(len(r_) for r_ in res_) == int(hoff[-1])
+            assert n_d == int(hoff[-1])
             host_visible["dicts"] = {"dicts_per_s": int(hoff[-1]) / dt_, "after_the_call_dicts_per_s": int(hoff[-1]) / (dt_ + times[len(times) // 2])}
-            del res_
         if w["score"]:
             # score=True through the boundary alone: ONE bigsi_hip_search_stream_scored call (sequences in; hit lists, presence
             # bits and score records out; each device batch's K5 + K6 beside the next batch's row-AND)
@@ -1010,12 +1014,12 @@ def run(args):
                                              "entry": "bigsi_hip_search_stream_scored (one call; median of 5)"}
             if _front._results is not None:
                 # ... and as the reference's scored result dicts (22 keys + the presence string per hit), from the call's arrays
-                t_ = time.perf_counter()
-                res_ = list(_front.native_result_lists(hnk, hnu, hoff.astype(np.int64), hcol, hcnt, exact, names, (hrec, hbits, hboff), total_cols))
+                t_, n_d = time.perf_counter(), 0
+                for r_ in _front.native_result_lists(hnk, hnu, hoff.astype(np.int64), hcol, hcnt, exact, names, (hrec, hbits, hboff), total_cols):
+                    n_d += len(r_)
                 dt_ = time.perf_counter() - t_
-                assert sum(len(r_) for r_ in res_) == n_hits_many
+                assert n_d == n_hits_many
                 host_visible["scored_dicts"] = {"dicts_per_s": n_hits_many / dt_, "after_the_call_dicts_per_s": n_hits_many / (dt_ + times[len(times) // 2])}
-                del res_
 
         def one_call(seq_list, reps):
             bl, so = _lib.pack_seqs(seq_list)
