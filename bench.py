@@ -481,7 +481,8 @@ def smi_snapshot(device):
 
 
 def _err_file(rank):
-    return os.path.join(tempfile.gettempdir(), "bigsi_bench_err_%s_%s.json" % (os.environ.get("MASTER_PORT", "0"), rank))
+    # (keyed by the launcher's pid -- the parent all ranks of one run share -- so that a file left by an earlier run is never this run's)
+    return os.path.join(tempfile.gettempdir(), "bigsi_bench_err_%s_%d_%s.json" % (os.environ.get("MASTER_PORT", "0"), os.getppid(), rank))
 
 
 def _nccl_tail(n=12):
@@ -522,21 +523,41 @@ def main():
         except OSError:
             pass
         if rank == 0:
-            # the launcher ends the surviving ranks with SIGTERM when one rank dies: rank 0 then still prints the line, with what
-            # the dead rank left behind
+            # When another rank dies, rank 0 is usually inside a collective (a C call: Python-level signal handlers do not run
+            # there) until the launcher kills it.  A watcher THREAD prints the line instead: it wakes when a rank has left its
+            # error file (polled) or when the launcher's SIGTERM arrives (the interpreter's C-level handler writes to a wake-up
+            # pipe at once, whatever the main thread is doing), collects what the other ranks left behind, prints, exits.
             import signal
+            import threading
+            import select
+            r_fd, w_fd = os.pipe()
+            os.set_blocking(w_fd, False)
+            signal.set_wakeup_fd(w_fd, warn_on_full_buffer=False)
+            signal.signal(signal.SIGTERM, lambda *_: None)
 
-            def on_term(*_):
-                others = []
+            def others_errors():
+                out_ = []
                 for r_ in range(1, world):
                     try:
                         with open(_err_file(r_)) as f:
-                            others.append(json.load(f))
+                            out_.append(json.load(f))
                     except (OSError, ValueError):
                         pass
-                print(json.dumps(failure_line(args, world, 0, RuntimeError("terminated by the launcher (another rank failed)"), others)), flush=True)
-                os._exit(1)
-            signal.signal(signal.SIGTERM, on_term)
+                return out_
+
+            def watch():
+                while True:
+                    ready, _, _ = select.select([r_fd], [], [], 0.5)
+                    others = others_errors()
+                    if ready or others:
+                        if not others:
+                            time.sleep(0.5)                  # (the dying rank may still be writing its file)
+                            others = others_errors()
+                        why = "terminated by the launcher" if ready else "rank %s failed" % ",".join(str(o.get("failing_rank")) for o in others)
+                        sys.stdout.write(json.dumps(failure_line(args, world, 0, RuntimeError(why + " (see other_ranks)"), others)) + "\n")
+                        sys.stdout.flush()
+                        os._exit(1)
+            threading.Thread(target=watch, daemon=True).start()
     try:
         return run(args)
     except (Exception, SystemExit) as e:  # noqa: BLE001
@@ -816,12 +837,22 @@ def run(args):
     sync_all()
     clocks_before = smi_snapshot(local_rank) if rank == 0 else None
     sync_all()
+    # score=True steps build thousands of result dicts: as in BIGSI.search_stream (pause_gc), automatic passes of the cyclic collector
+    # wait while the stream runs and the young generations are collected at batch boundaries (a full pass is ~40 ms with torch loaded)
+    import gc
+    gc_paused = bool(w["score"]) and gc.isenabled()
+    if gc_paused:
+        gc.disable()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i_ in range(args.steps):
         step()
+        if gc_paused and (i_ & 15) == 15:
+            gc.collect(1)
     collect()                      # the last batch's share, inside the timed region
     sync_all()
     elapsed = time.perf_counter() - t0
+    if gc_paused:
+        gc.enable()
     clocks_after = smi_snapshot(local_rank) if rank == 0 else None
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
