@@ -89,6 +89,7 @@ SIGNATURES = {
     "bigsi_hip_clear": (_i32, [_P]),
     "bigsi_hip_load_rows_file": (_i32, [_P, C.c_char_p, _u64, _u64, _u64, _u64, _u32, C.POINTER(IoStats)]),
     "bigsi_hip_save_rows_file": (_i32, [_P, C.c_char_p, _u64, _u64, _u64, _u64, _u32, C.POINTER(IoStats)]),
+    "bigsi_hip_bdb_small_records": (_i32, [C.c_char_p, _P, _u64, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64), _u32]),
     "bigsi_hip_insert_column": (_i32, [_P, _u64, _P]),
     "bigsi_hip_get_column": (_i32, [_P, _u64, _P]),
     "bigsi_hip_insert_columns": (_i32, [_P, _u64, _u64, _P, _u64]),

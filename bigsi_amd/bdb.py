@@ -109,15 +109,69 @@ def read_all(path):
         return dict(db.items())
 
 
-def import_index(path, dst, block_bytes=64 << 20):
+def small_records(path, threads=0):
+    """({key: value} of every record that is not a "<row>:bitarray" row, number of row records, longest row) of a BerkeleyDB hash
+    file, through the library's threaded page scan (bigsi_hip_bdb_small_records: no Python statement per record)."""
+    import ctypes as C
+
+    import numpy as np
+
+    from . import _lib
+    need, rows, widest = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+    L = _lib.lib()
+    _lib.check(L.bigsi_hip_bdb_small_records(path.encode(), None, 0, C.byref(need), C.byref(rows), C.byref(widest), int(threads)))
+    buf = np.zeros(max(int(need.value), 1), np.uint8)
+    _lib.check(L.bigsi_hip_bdb_small_records(path.encode(), _lib.ptr(buf), buf.size, C.byref(need), C.byref(rows), C.byref(widest), int(threads)))
+    raw, out, at = buf.tobytes(), {}, 0
+    while at < need.value:
+        kl, vl = struct.unpack_from("<II", raw, at)
+        out[raw[at + 8:at + 8 + kl]] = raw[at + 8 + kl:at + 8 + kl + vl]
+        at += 8 + kl + vl
+    return out, int(rows.value), int(widest.value)
+
+
+def import_index(path, dst, block_bytes=64 << 20, native=True, threads=0):
     """Load a v0.3-format BIGSI BerkeleyDB store (keys "<row>:bitarray", "<name>:int", "<name>:string",
-    bigsi/storage/base.py:29-36) into a hip-hbm storage.  Two sequential scans: the small records first (the device matrix
-    needs number_of_rows / number_of_cols before rows arrive), then the rows in blocks.  Returns (num_rows, num_cols)."""
+    bigsi/storage/base.py:29-36) into a hip-hbm storage.  Returns (num_rows, num_cols).
+
+    native (default): below Python -- the small records through bigsi_hip_bdb_small_records, the rows through
+    bigsi_hip_load_rows_file, which recognises the file, locates every row record with one threaded scan of the hash pages and
+    feeds the pinned double buffer of the file <-> HBM pipeline from wherever the rows lie.  A store that does not hold all m
+    rows, or native=False, takes the Python page walk below (the definition of the format here, and the test oracle of the
+    native reader): two sequential scans, small records first, then the rows in blocks."""
     import re
 
     import numpy as np
     row_key = re.compile(rb"^(\d+):bitarray$")
     dst.delete_all()
+    if native and hasattr(dst, "res") and not isinstance(path, bytes):
+        from . import _lib
+        small, n_row_records, widest = small_records(path, threads)
+        try:
+            m = int(small[b"number_of_rows:int"])
+            n = int(small[b"number_of_cols:int"])
+        except KeyError as e:
+            raise BdbFormatError("%s holds no %s record: not a BIGSI v0.3 index" % (path, e.args[0].decode()))
+        if n_row_records == m:
+            for k in (b"ksi:bloomfilter_size:int", b"ksi:num_hashes:int", b"number_of_rows:int"):
+                if k in small:
+                    dst[k] = small[k]
+            rb = max((n + 7) // 8, 1)
+            dst.set_integer("number_of_cols", n)              # (opens the matrix at its width; the rows below are cut / zero-extended to rb bytes)
+            res = dst.res
+            res.ensure_open()
+            _lib.check(res.fn("load_rows_file")(res.ix, path.encode(), 0, 0, m, rb, int(threads), None))
+            # (pad bits of a row's last byte are taken as stored -- zero in anything bitarray.tobytes() wrote; the kernels mask
+            # columns beyond number_of_cols out of every result anyway)
+            res.written[:] = True
+            res.lengths_reset()
+            res.uniform_len = rb
+            for k, v in small.items():
+                if k not in (b"number_of_rows:int", b"number_of_cols:int", b"ksi:bloomfilter_size:int", b"ksi:num_hashes:int"):
+                    dst[k] = v
+            dst.sync()
+            return m, n
+        dst.delete_all()
     with BdbHashFile(path) as db:
         small = {k: v for k, v in db.items(want_key=lambda k: not row_key.match(k))}
         try:

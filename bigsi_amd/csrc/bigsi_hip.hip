@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -328,6 +329,12 @@ extern "C" int bigsi_hip_close(bigsi_hip_index *ix)
     for (auto &p : ix->ev_free) { e = hipEventDestroy(p.a); e = hipEventDestroy(p.b); }
     ix->stage.release();
     ix->stage_ids.release();
+    for (int s_ = 0; s_ < 2; s_++) {
+        if (ix->pin_rows[s_]) e = hipHostFree(ix->pin_rows[s_]);
+        if (ix->pin_ev[s_]) e = hipEventDestroy(ix->pin_ev[s_]);
+        ix->dev_rows[s_].release();
+        ix->dev_ids[s_].release();
+    }
     if (ix->view_of) ix->view_of->views--;
     if (ix->d_index && ix->attach == bigsi_hip_index::kOwner) e = hipFree(ix->d_index);
     else if (ix->d_index && ix->attach == bigsi_hip_index::kIpc) e = hipIpcCloseMemHandle(ix->d_index);
@@ -437,18 +444,56 @@ extern "C" int bigsi_hip_set_rows(bigsi_hip_index *ix, const uint64_t *row_ids, 
         if (row_ids[i] >= ix->m) return fail(BIGSI_ERR_RANGE, "row %llu out of range [0,%llu)", (unsigned long long)row_ids[i], (unsigned long long)ix->m);
     TRY(use_device(ix));
     TRY(quiesce_index(ix));
-    const uint64_t per = std::max<uint64_t>(1, kStageBytes / row_bytes);
-    for (uint64_t i0 = 0; i0 < n; i0 += per) {
-        const uint64_t c = std::min(per, n - i0);
-        TRY(ix->stage.reserve(c * row_bytes));
-        TRY(ix->stage_ids.reserve(c * 8));
-        HIP_TRY(hipMemcpyAsync(ix->stage.p, bytes + i0 * row_bytes, c * row_bytes, hipMemcpyHostToDevice, ix->stream));
-        HIP_TRY(hipMemcpyAsync(ix->stage_ids.p, row_ids + i0, c * 8, hipMemcpyHostToDevice, ix->stream));
-        hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)c), dim3(kBlock), 0, ix->stream, (uint8_t *)ix->d_index,
+    const uint64_t kMaxChunkRows = 1ull << 20;      // (the pinned buffers keep room for this many row ids behind the row bytes)
+    const uint64_t per = std::min(kMaxChunkRows, std::max<uint64_t>(1, kStageBytes / row_bytes));
+    if (n * row_bytes < (4ull << 20)) {
+        // a few rows (the storage contract's own calls): one staged copy
+        TRY(ix->stage.reserve(n * row_bytes));
+        TRY(ix->stage_ids.reserve(n * 8));
+        HIP_TRY(hipMemcpyAsync(ix->stage.p, bytes, n * row_bytes, hipMemcpyHostToDevice, ix->stream));
+        HIP_TRY(hipMemcpyAsync(ix->stage_ids.p, row_ids, n * 8, hipMemcpyHostToDevice, ix->stream));
+        hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)n), dim3(kBlock), 0, ix->stream, (uint8_t *)ix->d_index,
                            ix->stride_words * 8, ix->m, ix->stage_ids.as<uint64_t>(), ix->stage.as<uint8_t>(), row_bytes);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(ix->stream));   // staging buffers are reused by the next chunk
+        HIP_TRY(hipStreamSynchronize(ix->stream));
+        return BIGSI_OK;
     }
+    // blocks of rows (importers: migrate_index, bdb.import_index): the caller's pageable memory goes into one of two pinned
+    // buffers on a few host threads while the other buffer's copy and scatter kernel are in flight (a hipMemcpy from pageable
+    // memory stages through the runtime's own small buffers on one thread: 7-8 GB/s)
+    for (int s_ = 0; s_ < 2; s_++) {
+        if (!ix->pin_rows[s_]) HIP_TRY(hipHostMalloc(&ix->pin_rows[s_], kStageBytes + kMaxChunkRows * 8, hipHostMallocDefault));
+        if (!ix->pin_ev[s_]) HIP_TRY(hipEventCreateWithFlags(&ix->pin_ev[s_], hipEventDisableTiming));
+        TRY(ix->dev_rows[s_].reserve(kStageBytes));
+        TRY(ix->dev_ids[s_].reserve(per * 8));
+    }
+    const unsigned T = std::min(8u, std::max(1u, std::thread::hardware_concurrency() / 8));
+    uint64_t chunk = 0;
+    for (uint64_t i0 = 0; i0 < n; i0 += per, chunk++) {
+        const int s_ = (int)(chunk & 1);
+        const uint64_t c = std::min(per, n - i0), nb = c * row_bytes;
+        HIP_TRY(hipEventSynchronize(ix->pin_ev[s_]));          // (never recorded: returns at once) the copy that last read this buffer
+        uint8_t *pin = static_cast<uint8_t *>(ix->pin_rows[s_]);
+        const uint8_t *src = bytes + i0 * row_bytes;
+        {
+            std::vector<std::thread> pool;
+            const uint64_t part = round_up(ceil_div(nb, T), 1 << 16);
+            for (unsigned t = 1; t < T; t++) {
+                const uint64_t a = std::min<uint64_t>((uint64_t)t * part, nb), b = std::min<uint64_t>((uint64_t)(t + 1) * part, nb);
+                if (a < b) pool.emplace_back([=]() { memcpy(pin + a, src + a, b - a); });
+            }
+            memcpy(pin, src, std::min(part, nb));
+            for (auto &th : pool) th.join();
+        }
+        memcpy(pin + kStageBytes, row_ids + i0, c * 8);
+        HIP_TRY(hipMemcpyAsync(ix->dev_rows[s_].p, pin, nb, hipMemcpyHostToDevice, ix->stream));
+        HIP_TRY(hipMemcpyAsync(ix->dev_ids[s_].p, pin + kStageBytes, c * 8, hipMemcpyHostToDevice, ix->stream));
+        hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)c), dim3(kBlock), 0, ix->stream, (uint8_t *)ix->d_index,
+                           ix->stride_words * 8, ix->m, ix->dev_ids[s_].as<uint64_t>(), ix->dev_rows[s_].as<uint8_t>(), row_bytes);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(ix->pin_ev[s_], ix->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(ix->stream));
     return BIGSI_OK;
 }
 
@@ -512,10 +557,198 @@ int bigsi_file_io(int fd, bool write, uint8_t *buf, uint64_t off, uint64_t len, 
     for (auto &th : pool) th.join();
     return err.load();
 }
+// ---- BigsiBdb (bigsi_internal.hpp): BerkeleyDB hash files without libdb
+static const uint32_t kBdbHashMagic = 0x061561;
+enum { kBdbPageOverflow = 7, kBdbPageHashMeta = 8, kBdbPageHash = 13, kBdbPageHashUnsorted = 2, kBdbHdr = 26, kBdbKeyData = 1, kBdbOffPage = 3 };
+
+bool BigsiBdb::is_bdb(int fd)
+{
+    uint8_t head[32];
+    if (pread(fd, head, sizeof head, 0) != (ssize_t)sizeof head) return false;
+    uint32_t magic;
+    memcpy(&magic, head + 12, 4);
+    return (magic == kBdbHashMagic || __builtin_bswap32(magic) == kBdbHashMagic) && head[25] == kBdbPageHashMeta;
+}
+
+int BigsiBdb::open_fd(int fd_)
+{
+    fd = fd_;
+    uint8_t head[72];
+    if (pread(fd, head, sizeof head, 0) != (ssize_t)sizeof head) return fail(BIGSI_ERR_INVALID, "too short for a BerkeleyDB file");
+    uint32_t magic;
+    memcpy(&magic, head + 12, 4);
+    swap = magic != kBdbHashMagic;
+    if (u32(head + 12) != kBdbHashMagic) return fail(BIGSI_ERR_INVALID, "not a BerkeleyDB hash file");
+    pagesize = u32(head + 20);
+    if (head[24] != 0) return fail(BIGSI_ERR_INVALID, "encrypted BerkeleyDB files are not supported");
+    if (pagesize < 512 || pagesize > 65536 || (pagesize & (pagesize - 1))) return fail(BIGSI_ERR_INVALID, "BerkeleyDB page size %u", pagesize);
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) return fail(BIGSI_ERR_INVALID, "fstat: %s", strerror(errno));
+    n_pages = (uint64_t)sb.st_size / pagesize;
+    return BIGSI_OK;
+}
+
+template <typename F> int BigsiBdb::scan(unsigned threads, F on_item) const
+{
+    const uint64_t pages_per_read = std::max<uint64_t>(1, (4ull << 20) / pagesize);
+    const uint64_t n_blocks = ceil_div(n_pages, pages_per_read);
+    threads = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(threads, n_blocks));
+    std::atomic<uint64_t> next{0};
+    std::atomic<int> err{0};
+    auto work = [&]() {
+        std::vector<uint8_t> buf(pages_per_read * pagesize);
+        for (;;) {
+            const uint64_t b = next.fetch_add(1);
+            if (b >= n_blocks || err.load()) return;
+            const uint64_t p0 = b * pages_per_read, np = std::min(pages_per_read, n_pages - p0);
+            uint64_t got = 0;
+            while (got < np * pagesize) {
+                const ssize_t r = pread(fd, buf.data() + got, (size_t)(np * pagesize - got), (off_t)(p0 * pagesize + got));
+                if (r < 0) { if (errno == EINTR) continue; err.store(errno); return; }
+                if (r == 0) { err.store(ENODATA); return; }
+                got += (uint64_t)r;
+            }
+            for (uint64_t i = 0; i < np; i++) {
+                const uint64_t pgno = p0 + i;
+                if (pgno == 0) continue;
+                const uint8_t *p = buf.data() + i * pagesize;
+                if (p[25] != kBdbPageHash && p[25] != kBdbPageHashUnsorted) continue;
+                const uint32_t n = u16(p + 20);
+                if (n == 0 || kBdbHdr + 2ull * n > pagesize) continue;
+                uint32_t end = pagesize;
+                for (uint32_t it = 0; it + 1 < n; it += 2) {
+                    const uint32_t ks = u16(p + kBdbHdr + 2 * it), vs = u16(p + kBdbHdr + 2 * (it + 1));
+                    const uint32_t kend = end, vend = ks;
+                    end = vs;
+                    if (ks >= kend || vs >= vend || kend > pagesize) { err.store(EILSEQ); return; }
+                    if (p[ks] != kBdbKeyData) continue;               // an overflow key (longer than a page) is no index record
+                    Loc l;
+                    if (p[vs] == kBdbKeyData) { l.kind = 1; l.at = pgno * pagesize + vs + 1; l.len = vend - vs - 1; }
+                    else if (p[vs] == kBdbOffPage) { if (vs + 12 > vend) { err.store(EILSEQ); return; } l.kind = 3; l.at = u32(p + vs + 4); l.len = u32(p + vs + 8); }
+                    else { err.store(ENOTSUP); return; }            // duplicate sets do not occur in BIGSI stores
+                    on_item(p + ks + 1, kend - ks - 1, l);
+                }
+            }
+        }
+    };
+    if (threads == 1) work();
+    else {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < threads; t++) pool.emplace_back(work);
+        for (auto &th : pool) th.join();
+    }
+    const int e = err.load();
+    if (e) return fail(BIGSI_ERR_INVALID, "BerkeleyDB file: %s", e == EILSEQ ? "corrupt hash page" : e == ENOTSUP ? "duplicate items are not supported" : e == ENODATA ? "file shorter than its page count" : strerror(e));
+    return BIGSI_OK;
+}
+
+int BigsiBdb::read_value(const Loc &l, uint8_t *dst, uint32_t want, std::vector<uint8_t> &page) const
+{
+    want = std::min(want, l.len);
+    if (l.kind == 1) {
+        uint32_t got = 0;
+        while (got < want) {
+            const ssize_t r = pread(fd, dst + got, want - got, (off_t)(l.at + got));
+            if (r < 0) { if (errno == EINTR) continue; return errno; }
+            if (r == 0) return ENODATA;
+            got += (uint32_t)r;
+        }
+        return 0;
+    }
+    // an overflow chain: every page carries hf_offset (bytes 22-23) bytes after the header, next_pgno (bytes 16-19) links the chain
+    page.resize(pagesize);
+    uint64_t pgno = l.at;
+    uint32_t got = 0;
+    while (got < want) {
+        if (pgno == 0 || pgno >= n_pages) return EILSEQ;
+        // (only as much of the page as is needed)
+        const uint32_t need = std::min<uint32_t>(pagesize, kBdbHdr + (want - got));
+        uint32_t have = 0;
+        while (have < need) {
+            const ssize_t r = pread(fd, page.data() + have, need - have, (off_t)(pgno * pagesize + have));
+            if (r < 0) { if (errno == EINTR) continue; return errno; }
+            if (r == 0) return ENODATA;
+            have += (uint32_t)r;
+        }
+        if (page[25] != kBdbPageOverflow) return EILSEQ;
+        const uint32_t used = std::min<uint32_t>(u16(page.data() + 22), pagesize - kBdbHdr), take = std::min(used, want - got);
+        if (take == 0) return EILSEQ;
+        memcpy(dst + got, page.data() + kBdbHdr, take);
+        got += take;
+        pgno = u32(page.data() + 16);
+    }
+    return 0;
+}
+
+// "<digits>:bitarray" -> row id (bigsi/storage/base.py:29-36); false for any other key
+static bool bdb_row_key(const uint8_t *key, uint32_t len, uint64_t *row)
+{
+    static const char tail[] = ":bitarray";
+    if (len < 10 || len > 29 || memcmp(key + len - 9, tail, 9) != 0) return false;
+    uint64_t r = 0;
+    for (uint32_t i = 0; i + 9 < len; i++) {
+        if (key[i] < '0' || key[i] > '9') return false;
+        r = r * 10 + (key[i] - '0');
+    }
+    *row = r;
+    return true;
+}
+
+// The records of a BerkeleyDB hash file that are NOT rows -- the index integers and the sample metadata, a few bytes each --
+// packed as [u32 key_len][u32 value_len][key][value]...; "<row>:bitarray" records are counted and measured only.
+extern "C" int bigsi_hip_bdb_small_records(const char *path, uint8_t *out, uint64_t capacity, uint64_t *needed, uint64_t *n_rows, uint64_t *max_row_bytes,
+                                           uint32_t threads)
+{
+    if (!path || !needed) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    if (threads == 0) threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency() / 4));
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(BIGSI_ERR_INVALID, "%s: %s", path, strerror(errno));
+    BigsiBdb db;
+    int rc = db.open_fd(fd);
+    struct Small { std::string key; BigsiBdb::Loc loc; };
+    std::vector<Small> small;
+    std::mutex mu;
+    std::atomic<uint64_t> rows{0}, widest{0};
+    if (rc == BIGSI_OK)
+        rc = db.scan(threads, [&](const uint8_t *key, uint32_t klen, const BigsiBdb::Loc &l) {
+            uint64_t r;
+            if (bdb_row_key(key, klen, &r)) {
+                rows++;
+                uint64_t w = widest.load();
+                while (l.len > w && !widest.compare_exchange_weak(w, l.len)) {}
+                return;
+            }
+            std::lock_guard<std::mutex> g(mu);
+            small.push_back(Small{std::string(reinterpret_cast<const char *>(key), klen), l});
+        });
+    uint64_t need = 0;
+    if (rc == BIGSI_OK) {
+        std::sort(small.begin(), small.end(), [](const Small &a, const Small &b) { return a.key < b.key; });      // (threads meet the pages in any order)
+        for (auto &s_ : small) need += 8 + s_.key.size() + s_.loc.len;
+        *needed = need;
+        if (n_rows) *n_rows = rows.load();
+        if (max_row_bytes) *max_row_bytes = widest.load();
+        if (out && capacity < need) rc = fail(BIGSI_ERR_CAPACITY, "buffer holds %llu bytes, %llu needed", (unsigned long long)capacity, (unsigned long long)need);
+        else if (out) {
+            std::vector<uint8_t> page;
+            uint8_t *q = out;
+            for (auto &s_ : small) {
+                const uint32_t kl = (uint32_t)s_.key.size(), vl = s_.loc.len;
+                memcpy(q, &kl, 4); memcpy(q + 4, &vl, 4); memcpy(q + 8, s_.key.data(), kl);
+                const int e = db.read_value(s_.loc, q + 8 + kl, vl, page);
+                if (e) { rc = fail(BIGSI_ERR_INVALID, "%s: reading the value of %s: %s", path, s_.key.c_str(), e == EILSEQ ? "corrupt overflow chain" : strerror(e)); break; }
+                q += 8 + kl + vl;
+            }
+        }
+    }
+    close(fd);
+    return rc;
+}
+
 // ---- BigsiRowsFile (bigsi_internal.hpp): one file, or a directory of striped part files
 static const uint64_t kStripeParts = 16, kStripeBytes = 4ull << 20;
 
-int BigsiRowsFile::open_(const char *path, bool save, uint64_t file_offset_, uint64_t row_bytes_, uint64_t n_rows)
+int BigsiRowsFile::open_(const char *path, bool save, uint64_t file_offset_, uint64_t row_bytes_, uint64_t n_rows, uint64_t row0, unsigned threads)
 {
     file_offset = file_offset_;
     row_bytes = row_bytes_;
@@ -524,6 +757,21 @@ int BigsiRowsFile::open_(const char *path, bool save, uint64_t file_offset_, uin
     if (!striped) {
         fd = open(path, save ? (O_WRONLY | O_CREAT) : O_RDONLY, 0644);
         if (fd < 0) return fail(BIGSI_ERR_INVALID, "%s: %s", path, strerror(errno));
+        if (!save && file_offset == 0 && BigsiBdb::is_bdb(fd)) {
+            // a v0.3 BerkeleyDB store: one scan of its hash pages locates the "<row>:bitarray" records of the range; io() then
+            // gathers rows from wherever they are (inline, or an overflow chain of pages)
+            bdb = true;
+            bdb_row0 = row0;
+            int rc = db.open_fd(fd);
+            if (rc == BIGSI_OK) {
+                loc.assign(n_rows, BigsiBdb::Loc{});
+                rc = db.scan(threads, [&](const uint8_t *key, uint32_t klen, const BigsiBdb::Loc &l) {
+                    uint64_t r;
+                    if (bdb_row_key(key, klen, &r) && r >= row0 && r - row0 < n_rows) loc[r - row0] = l;      // (one writer per row: a key occurs once)
+                });
+            }
+            if (rc != BIGSI_OK) { char keep[512]; snprintf(keep, sizeof keep, "%s", bigsi_hip_last_error()); close_(); return fail(rc, "%s: %s", path, keep); }
+        }
         return BIGSI_OK;
     }
     const std::string dir(path);
@@ -569,6 +817,34 @@ uint64_t BigsiRowsFile::chunk_rows() const
 
 int BigsiRowsFile::io(bool write, uint8_t *buf, uint64_t rel_row, uint64_t n, unsigned threads) const
 {
+    if (bdb) {
+        if (write) return EROFS;
+        // rows of the store, zero-extended (or cut) to row_bytes; a row the store does not hold reads as zeros
+        const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(threads, ceil_div(n, 64)));
+        std::atomic<int> err{0};
+        std::atomic<uint64_t> next{0};
+        auto work = [&]() {
+            std::vector<uint8_t> page;
+            for (;;) {
+                const uint64_t a = next.fetch_add(64);
+                if (a >= n || err.load()) return;
+                for (uint64_t i = a; i < std::min(n, a + 64); i++) {
+                    const BigsiBdb::Loc &l = loc[rel_row + i];
+                    uint8_t *dst = buf + i * row_bytes;
+                    const uint32_t take = l.kind ? (uint32_t)std::min<uint64_t>(l.len, row_bytes) : 0u;
+                    if (take) { const int e = db.read_value(l, dst, take, page); if (e) { err.store(e); return; } }
+                    if (take < row_bytes) memset(dst + take, 0, row_bytes - take);
+                }
+            }
+        };
+        if (T == 1) work();
+        else {
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < T; t++) pool.emplace_back(work);
+            for (auto &th : pool) th.join();
+        }
+        return err.load();
+    }
     if (!striped) return bigsi_file_io(fd, write, buf, file_offset + rel_row * row_bytes, n * row_bytes, threads);
     // a thread owns the part files p == t (mod T): no two threads inside one inode
     const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(threads, parts), ceil_div(n, stripe_rows)));
@@ -628,7 +904,7 @@ int rows_file(bigsi_hip_index *ix, const char *path, uint64_t file_offset, uint6
     TRY(quiesce_index(ix));
     HIP_TRY(hipStreamSynchronize(ix->stream));
     BigsiRowsFile rf;
-    TRY(rf.open_(path, save, file_offset, row_bytes, n_rows));
+    TRY(rf.open_(path, save, file_offset, row_bytes, n_rows, row0, threads));
     const bool direct = row_bytes == stride;                         // the file holds the device layout: no kernel on the way
     const uint64_t per = rf.chunk_rows();
     void *pin[2] = {nullptr, nullptr};

@@ -713,7 +713,7 @@ static int group_rows_file(bigsi_hip_group *g, const char *path, uint64_t file_o
         TRY(bigsi_hip_synchronize(g->ix[i]));
     }
     BigsiRowsFile rf;
-    TRY(rf.open_(path, save, file_offset, row_bytes, n_rows));
+    TRY(rf.open_(path, save, file_offset, row_bytes, n_rows, row0, threads));
     const uint64_t per = rf.chunk_rows();
     void *pin[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> ev[2];

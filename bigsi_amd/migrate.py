@@ -7,6 +7,11 @@ all m rows ("<row>:bitarray" records are already in the device's byte format, so
 time) and the sample metadata (metadata.py:82-112)."""
 import numpy as np
 
+try:          # host-side C++ helpers (bigsi_amd/_results.cpp, built by bigsi_amd/pyext_build.sh); the loops below are their definition
+    from . import _results as _ext
+except ImportError:
+    _ext = None
+
 INDEX_INTS = ("number_of_rows", "number_of_cols", "ksi:bloomfilter_size", "ksi:num_hashes")
 
 
@@ -47,7 +52,7 @@ def migrate_index(src, dst, block_rows=None, overlap=True):
     dst.set_integer("ksi:num_hashes", src.get_integer("ksi:num_hashes"))
     dst.set_integer("number_of_rows", m)
     rb = (n + 7) // 8
-    step = block_rows or max(1, (64 << 20) // max(rb, 1))
+    step = block_rows or max(1, (256 << 20) // max(rb, 1))
     up = RowUploader(dst.res, overlap) if hasattr(dst, "res") else None
     try:
         _copy_rows(src, dst, up, m, n, rb, step)
@@ -78,12 +83,18 @@ def _copy_rows(src, dst, up, m, n, rb, step):
         keys = [src.convert_key_to_bytes(src.convert_to_bitarray_key(i)) if hasattr(src, "convert_key_to_bytes")
                 else ("%d:bitarray" % i).encode() for i in ids]
         raws = src.batch_get(keys)
-        block = np.zeros((len(ids), max(rb, 1)), dtype=np.uint8)
-        for j, raw in enumerate(raws):       # rows may be stored shorter or longer than ceil(n/8): pad / trim
-            a = np.frombuffer(bytes(raw), dtype=np.uint8)[:rb]
-            block[j, : a.size] = a
-        if n % 8:
-            block[:, rb - 1] &= (0xFF << (8 - n % 8)) & 0xFF      # columns beyond number_of_cols are not part of the index
+        mask = (0xFF << (8 - n % 8)) & 0xFF if n % 8 else 0xFF      # columns beyond number_of_cols are not part of the index
+        if _ext is not None and isinstance(raws, list) and all(type(r_) in (bytes, bytearray) for r_ in raws[:4]):
+            # the rows of the block copied (cut / zero-extended to rb bytes) by a few threads below Python (bigsi_amd/_results.cpp)
+            block = np.empty((len(ids), max(rb, 1)), dtype=np.uint8)
+            _ext.pack_rows(raws, block, mask)
+        else:
+            block = np.zeros((len(ids), max(rb, 1)), dtype=np.uint8)
+            for j, raw in enumerate(raws):       # rows may be stored shorter or longer than ceil(n/8): pad / trim
+                a = np.frombuffer(bytes(raw), dtype=np.uint8)[:rb]
+                block[j, : a.size] = a
+            if n % 8:
+                block[:, rb - 1] &= mask
         if up is not None:
             up.put(np.arange(r0, r0 + len(ids), dtype=np.uint64), block)
         else:

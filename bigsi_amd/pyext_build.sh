@@ -6,5 +6,5 @@ HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 PY="${PYTHON:-python3}"
 INC="$($PY -c 'import sysconfig; print(sysconfig.get_paths()["include"])')"
 SUF="$($PY -c 'import sysconfig; print(sysconfig.get_config_var("EXT_SUFFIX"))')"
-g++ -O2 -std=c++17 -shared -fPIC -ffp-contract=off -Wall -Wextra -I"$INC" -I"$HERE" -o "$HERE/_results$SUF" "$HERE/_results.cpp"
+g++ -O2 -std=c++17 -shared -fPIC -pthread -ffp-contract=off -Wall -Wextra -I"$INC" -I"$HERE" -o "$HERE/_results$SUF" "$HERE/_results.cpp"
 echo "built $HERE/_results$SUF"

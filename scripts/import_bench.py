@@ -30,6 +30,7 @@ def main():
     p = argparse.ArgumentParser()
     p.add_argument("--gb", type=float, default=4.0)
     p.add_argument("--cols", type=int, default=500_000)
+    p.add_argument("--bdb-gb", type=float, default=2.0, help="rows written into a BerkeleyDB hash file (libdb through dbm.ndbm) and imported from it")
     a = p.parse_args()
     from bigsi_amd.migrate import migrate_index
     from bigsi_amd.storage import get_storage
@@ -50,6 +51,36 @@ def main():
         assert got[0].tobytes()[:rb] == rows[0] and got[2].tobytes()[:rb] == rows[m - 1]
         out.setdefault("overlapped_GBps" if overlap else "sequential_GBps", []).append(round(m * rb / dt / 1e9, 2))
         dst.delete_all()
+    # a BerkeleyDB hash store of the same rows, written by libdb itself (dbm.ndbm), imported below Python (bigsi_hip_load_rows_file on the file)
+    # and through the Python page walk
+    try:
+        import dbm.ndbm as ndbm
+        import tempfile
+        from bigsi_amd import bdb
+        if getattr(ndbm, "library", "") == "Berkeley DB":
+            d = tempfile.mkdtemp(prefix="bigsi_import_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+            mb = min(m, int(a.bdb_gb * 1e9 // rb))
+            db = ndbm.open(os.path.join(d, "store"), "n")
+            for key, v in (("number_of_rows:int", mb), ("number_of_cols:int", a.cols), ("ksi:bloomfilter_size:int", mb), ("ksi:num_hashes:int", 3)):
+                db[key] = str(v)
+            for i in range(mb):
+                db["%d:bitarray" % i] = rows[i]
+            db.close()
+            fn = os.path.join(d, "store.db")
+            out["bdb_file_gb"] = round(os.path.getsize(fn) / 1e9, 2)
+            for native in (True, False):
+                dst = get_storage({"storage-engine": "hip-hbm", "k": 31, "m": mb, "h": 3, "storage-config": {"name": "import_bench_bdb", "max_cols": a.cols}})
+                t0 = time.perf_counter()
+                bdb.import_index(fn, dst, native=native)
+                dt = time.perf_counter() - t0
+                got = np.asarray(dst.get_rows_packed(np.array([0, 1, mb - 1], np.uint64)))
+                assert got[0].tobytes()[:rb] == rows[0] and got[2].tobytes()[:rb] == rows[mb - 1]
+                out["bdb_native_GBps" if native else "bdb_python_GBps"] = round(mb * rb / dt / 1e9, 2)
+                dst.delete_all()
+            import shutil
+            shutil.rmtree(d, ignore_errors=True)
+    except ImportError:
+        pass
     print(json.dumps(out))
 
 

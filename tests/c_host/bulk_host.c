@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include "bigsi_hip.h"
+#include "bigsi_hip_text.h"
 
 #define CHECK(call)                                                                             \
     do {                                                                                        \

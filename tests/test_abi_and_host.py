@@ -12,7 +12,7 @@ from conftest import ROOT, assert_result_equal, load_golden, unjson
 
 
 # --------------------------------------------------------------------------------------------- C ABI
-HIP_HEADERS = ("bigsi_hip.h", "bigsi_hip_group.h", "bigsi_hip_testing.h")      # advertised boundary | device groups | test hooks
+HIP_HEADERS = ("bigsi_hip.h", "bigsi_hip_group.h", "bigsi_hip_text.h", "bigsi_hip_testing.h")      # core boundary | device groups | front-end text | test hooks
 
 
 def header_functions(headers=HIP_HEADERS):

@@ -105,3 +105,68 @@ def test_import_v03_file_and_v01_directory(tmp_path):
         for t in (1.0, 0.3):
             assert b1.search(s, t) == orc.search(s, t)
     b1.delete()
+
+
+def test_native_small_records_equal_the_python_page_walk(tmp_path):
+    """bigsi_hip_bdb_small_records (the library's threaded page scan, no device) against bigsi_amd/bdb.py on a file libdb wrote:
+    every non-row record, values in overflow chains included; the row records counted and measured."""
+    from bigsi_amd import _lib, bdb
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libbigsi_hip.so not built")
+    rng = np.random.default_rng(1)
+    rec = {b"number_of_rows:int": b"700", b"number_of_cols:int": b"40000", b"empty:string": b"", b"metadata:7:string": "séven".encode(),
+           b"blob:string": rng.integers(0, 256, size=30000, dtype=np.uint8).tobytes(), b"12:bitarrayX": b"not a row", b"x12:bitarray": b"nor this"}
+    for i in range(700):
+        rec[b"%d:bitarray" % i] = rng.integers(0, 256, size=int(rng.choice([3, 5000, 4071, 4096])), dtype=np.uint8).tobytes()
+    rec[b"K" * 9000] = b"long key"                          # an overflow KEY: no index record, skipped by both
+    fn = write_bdb(str(tmp_path / "s"), rec)
+    small, n_rows, widest = bdb.small_records(fn, threads=3)
+    want = {k: v for k, v in bdb.read_all(fn).items() if not (k.endswith(b":bitarray") and k[:-9].isdigit()) and len(k) < 4000}
+    assert small == want and n_rows == 700 and widest == 5000
+    with pytest.raises(_lib.BigsiHipError):
+        bdb.small_records(str(tmp_path / "nope"))
+    p = tmp_path / "junk"
+    p.write_bytes(b"\1" * 8192)
+    with pytest.raises(_lib.BigsiHipError):
+        bdb.small_records(str(p))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", [None, [0, 0, 0]])
+def test_native_import_equals_the_python_route(tmp_path, devices):
+    """import_index below Python (bigsi_hip_load_rows_file on the BerkeleyDB file itself: rows inline and in overflow chains, shorter
+    and longer than ceil(N/8)) == the Python page walk, on one GPU and over three shards; a store with a missing row falls back."""
+    from bigsi_amd import bdb
+    from bigsi_amd.storage import get_storage
+    rng = np.random.default_rng(2)
+    m, n = 3001, 70_001
+    rb = (n + 7) // 8
+    rows = rng.integers(0, 256, size=(m, rb), dtype=np.uint8)
+    rows[:, rb - 1] &= 0x80                                  # 70001 columns: 7 pad bits
+    rec = {b"number_of_rows:int": b"%d" % m, b"number_of_cols:int": b"%d" % n, b"ksi:bloomfilter_size:int": b"%d" % m, b"ksi:num_hashes:int": b"3",
+           b"metadata:colour_count:int": b"2", b"metadata:0:string": b"zero", b"metadata:zero:int": b"0"}
+    for r in range(m):
+        raw = rows[r].tobytes()
+        rec[b"%d:bitarray" % r] = raw[:100] if r % 50 == 7 else raw + b"\0\0\0" if r % 50 == 9 else raw      # some stored shorter / longer
+        if r % 50 == 7:
+            rows[r, 100:] = 0
+    fn = write_bdb(str(tmp_path / "big"), rec)
+    got = {}
+    for native in (True, False):
+        sc = {"name": "bdbnat%d%s" % (native, "g" if devices else ""), "max_cols": n}
+        if devices:
+            sc["devices"] = devices
+        st = get_storage({"storage-engine": "hip-hbm", "storage-config": sc, "k": 31, "m": m, "h": 3})
+        assert bdb.import_index(fn, st, native=native) == (m, n)
+        got[native] = np.asarray(st.get_rows_packed(np.arange(m), rb)).copy()
+        assert st.get_string("metadata:0:string") == "zero" and st.get_integer("number_of_cols") == n and st.get_integer("ksi:num_hashes") == 3
+        st.delete_all()
+    assert np.array_equal(got[True], rows) and np.array_equal(got[False], rows)
+    del rec[b"5:bitarray"]                                   # not every row present: the Python route (KeyError semantics per row) takes over
+    fn2 = write_bdb(str(tmp_path / "holey"), rec)
+    st = get_storage({"storage-engine": "hip-hbm", "storage-config": {"name": "bdbholey", "max_cols": n}, "k": 31, "m": m, "h": 3})
+    assert bdb.import_index(fn2, st) == (m, n)
+    with pytest.raises(KeyError):
+        st.get_bitarray(5)
+    assert st.get_bitarray(6).tobytes() == rows[6].tobytes()
+    st.delete_all()
