@@ -119,9 +119,12 @@ def small_records(path, threads=0):
     from . import _lib
     need, rows, widest = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
     L = _lib.lib()
-    _lib.check(L.bigsi_hip_bdb_small_records(path.encode(), None, 0, C.byref(need), C.byref(rows), C.byref(widest), int(threads)))
-    buf = np.zeros(max(int(need.value), 1), np.uint8)
-    _lib.check(L.bigsi_hip_bdb_small_records(path.encode(), _lib.ptr(buf), buf.size, C.byref(need), C.byref(rows), C.byref(widest), int(threads)))
+    buf = np.zeros(1 << 20, np.uint8)          # (an index's small records are a few KB: one scan of the file, a second only if they are not)
+    rc = L.bigsi_hip_bdb_small_records(path.encode(), _lib.ptr(buf), buf.size, C.byref(need), C.byref(rows), C.byref(widest), int(threads))
+    if rc == _lib.ERR_CAPACITY:
+        buf = np.zeros(int(need.value), np.uint8)
+        rc = L.bigsi_hip_bdb_small_records(path.encode(), _lib.ptr(buf), buf.size, C.byref(need), C.byref(rows), C.byref(widest), int(threads))
+    _lib.check(rc)
     raw, out, at = buf.tobytes(), {}, 0
     while at < need.value:
         kl, vl = struct.unpack_from("<II", raw, at)

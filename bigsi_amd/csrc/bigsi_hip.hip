@@ -595,7 +595,7 @@ template <typename F> int BigsiBdb::scan(unsigned threads, F on_item) const
     threads = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(threads, n_blocks));
     std::atomic<uint64_t> next{0};
     std::atomic<int> err{0};
-    auto work = [&]() {
+    auto work = [&](unsigned tid) {
         std::vector<uint8_t> buf(pages_per_read * pagesize);
         for (;;) {
             const uint64_t b = next.fetch_add(1);
@@ -626,15 +626,15 @@ template <typename F> int BigsiBdb::scan(unsigned threads, F on_item) const
                     if (p[vs] == kBdbKeyData) { l.kind = 1; l.at = pgno * pagesize + vs + 1; l.len = vend - vs - 1; }
                     else if (p[vs] == kBdbOffPage) { if (vs + 12 > vend) { err.store(EILSEQ); return; } l.kind = 3; l.at = u32(p + vs + 4); l.len = u32(p + vs + 8); }
                     else { err.store(ENOTSUP); return; }            // duplicate sets do not occur in BIGSI stores
-                    on_item(p + ks + 1, kend - ks - 1, l);
+                    on_item(tid, p + ks + 1, kend - ks - 1, l);
                 }
             }
         }
     };
-    if (threads == 1) work();
+    if (threads == 1) work(0);
     else {
         std::vector<std::thread> pool;
-        for (unsigned t = 0; t < threads; t++) pool.emplace_back(work);
+        for (unsigned t = 0; t < threads; t++) pool.emplace_back(work, t);
         for (auto &th : pool) th.join();
     }
     const int e = err.load();
@@ -656,26 +656,40 @@ int BigsiBdb::read_value(const Loc &l, uint8_t *dst, uint32_t want, std::vector<
         return 0;
     }
     // an overflow chain: every page carries hf_offset (bytes 22-23) bytes after the header, next_pgno (bytes 16-19) links the chain
-    page.resize(pagesize);
+    // libdb allocates the pages of a chain one after the other when it writes a large value into a growing file: a window of up to
+    // 16 pages is read at once and walked for as long as next_pgno is the page that follows (one system call per 64 KB instead of one
+    // per 4 KB page); a chain that jumps simply starts a new window
+    const uint32_t kWindow = 16;
+    page.resize((size_t)kWindow * pagesize);
     uint64_t pgno = l.at;
     uint32_t got = 0;
     while (got < want) {
         if (pgno == 0 || pgno >= n_pages) return EILSEQ;
-        // (only as much of the page as is needed)
-        const uint32_t need = std::min<uint32_t>(pagesize, kBdbHdr + (want - got));
-        uint32_t have = 0;
+        const uint32_t per_page = pagesize - kBdbHdr;
+        const uint64_t pages_left = ceil_div(want - got, per_page);
+        const uint32_t win = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(kWindow, pages_left), n_pages - pgno);
+        // (of the last page only as much as is needed)
+        const uint64_t need = (uint64_t)(win - 1) * pagesize + std::min<uint64_t>(pagesize, kBdbHdr + ((uint64_t)(want - got) - std::min<uint64_t>(want - got, (uint64_t)(win - 1) * per_page)));
+        uint64_t have = 0;
         while (have < need) {
-            const ssize_t r = pread(fd, page.data() + have, need - have, (off_t)(pgno * pagesize + have));
+            const ssize_t r = pread(fd, page.data() + have, (size_t)(need - have), (off_t)(pgno * pagesize + have));
             if (r < 0) { if (errno == EINTR) continue; return errno; }
             if (r == 0) return ENODATA;
-            have += (uint32_t)r;
+            have += (uint64_t)r;
         }
-        if (page[25] != kBdbPageOverflow) return EILSEQ;
-        const uint32_t used = std::min<uint32_t>(u16(page.data() + 22), pagesize - kBdbHdr), take = std::min(used, want - got);
-        if (take == 0) return EILSEQ;
-        memcpy(dst + got, page.data() + kBdbHdr, take);
-        got += take;
-        pgno = u32(page.data() + 16);
+        for (uint32_t i = 0; i < win && got < want; i++) {
+            const uint8_t *pg = page.data() + (size_t)i * pagesize;
+            if (pg[25] != kBdbPageOverflow) return EILSEQ;
+            const uint32_t used = std::min<uint32_t>(u16(pg + 22), per_page), take = std::min(used, want - got);
+            if (take == 0) return EILSEQ;
+            if ((uint64_t)i * pagesize + kBdbHdr + take > need) { pgno += i; goto next_window; }      // (a short page inside the window: the tail was not read)
+            memcpy(dst + got, pg + kBdbHdr, take);
+            got += take;
+            const uint64_t nxt = u32(pg + 16);
+            if (got < want && nxt != pgno + i + 1) { pgno = nxt; goto next_window; }
+            if (i + 1 == win) pgno = nxt;
+        }
+    next_window:;
     }
     return 0;
 }
@@ -694,6 +708,17 @@ static bool bdb_row_key(const uint8_t *key, uint32_t len, uint64_t *row)
     return true;
 }
 
+// bigsi_hip_bdb_small_records meets every row record on its way; an import calls bigsi_hip_load_rows_file on the same file next,
+// which would scan it again: the row locations of the LAST file scanned are kept (one entry, identified by device / inode / size /
+// mtime) and handed to the loader, which consumes them.
+struct BdbScanCache {
+    std::mutex mu;
+    bool valid = false;
+    dev_t dev = 0; ino_t ino = 0; off_t size = 0; struct timespec mtime {};
+    std::vector<std::pair<uint64_t, BigsiBdb::Loc>> rows;      // (row id, where)
+};
+static BdbScanCache g_bdb_cache;
+
 // The records of a BerkeleyDB hash file that are NOT rows -- the index integers and the sample metadata, a few bytes each --
 // packed as [u32 key_len][u32 value_len][key][value]...; "<row>:bitarray" records are counted and measured only.
 extern "C" int bigsi_hip_bdb_small_records(const char *path, uint8_t *out, uint64_t capacity, uint64_t *needed, uint64_t *n_rows, uint64_t *max_row_bytes,
@@ -709,18 +734,31 @@ extern "C" int bigsi_hip_bdb_small_records(const char *path, uint8_t *out, uint6
     std::vector<Small> small;
     std::mutex mu;
     std::atomic<uint64_t> rows{0}, widest{0};
+    std::vector<std::vector<std::pair<uint64_t, BigsiBdb::Loc>>> found(threads);      // row locations, per scanning thread
     if (rc == BIGSI_OK)
-        rc = db.scan(threads, [&](const uint8_t *key, uint32_t klen, const BigsiBdb::Loc &l) {
+        rc = db.scan(threads, [&](unsigned tid, const uint8_t *key, uint32_t klen, const BigsiBdb::Loc &l) {
             uint64_t r;
             if (bdb_row_key(key, klen, &r)) {
                 rows++;
                 uint64_t w = widest.load();
                 while (l.len > w && !widest.compare_exchange_weak(w, l.len)) {}
+                found[tid].emplace_back(r, l);
                 return;
             }
             std::lock_guard<std::mutex> g(mu);
             small.push_back(Small{std::string(reinterpret_cast<const char *>(key), klen), l});
         });
+    if (rc == BIGSI_OK) {
+        struct stat sb;
+        std::lock_guard<std::mutex> g(g_bdb_cache.mu);
+        g_bdb_cache.valid = false;
+        g_bdb_cache.rows.clear();
+        if (fstat(fd, &sb) == 0) {
+            for (auto &v : found) { g_bdb_cache.rows.insert(g_bdb_cache.rows.end(), v.begin(), v.end()); std::vector<std::pair<uint64_t, BigsiBdb::Loc>>().swap(v); }
+            g_bdb_cache.dev = sb.st_dev; g_bdb_cache.ino = sb.st_ino; g_bdb_cache.size = sb.st_size; g_bdb_cache.mtime = sb.st_mtim;
+            g_bdb_cache.valid = true;
+        }
+    }
     uint64_t need = 0;
     if (rc == BIGSI_OK) {
         std::sort(small.begin(), small.end(), [](const Small &a, const Small &b) { return a.key < b.key; });      // (threads meet the pages in any order)
@@ -765,10 +803,24 @@ int BigsiRowsFile::open_(const char *path, bool save, uint64_t file_offset_, uin
             int rc = db.open_fd(fd);
             if (rc == BIGSI_OK) {
                 loc.assign(n_rows, BigsiBdb::Loc{});
-                rc = db.scan(threads, [&](const uint8_t *key, uint32_t klen, const BigsiBdb::Loc &l) {
-                    uint64_t r;
-                    if (bdb_row_key(key, klen, &r) && r >= row0 && r - row0 < n_rows) loc[r - row0] = l;      // (one writer per row: a key occurs once)
-                });
+                bool cached = false;
+                {
+                    // the scan bigsi_hip_bdb_small_records has just made of this very file (same inode, size and mtime), if any
+                    struct stat sb;
+                    std::lock_guard<std::mutex> g(g_bdb_cache.mu);
+                    if (g_bdb_cache.valid && fstat(fd, &sb) == 0 && sb.st_dev == g_bdb_cache.dev && sb.st_ino == g_bdb_cache.ino && sb.st_size == g_bdb_cache.size &&
+                        sb.st_mtim.tv_sec == g_bdb_cache.mtime.tv_sec && sb.st_mtim.tv_nsec == g_bdb_cache.mtime.tv_nsec) {
+                        for (auto &e : g_bdb_cache.rows)
+                            if (e.first >= row0 && e.first - row0 < n_rows) loc[e.first - row0] = e.second;
+                        cached = true;
+                        if (row0 == 0 && n_rows >= g_bdb_cache.rows.size()) { g_bdb_cache.valid = false; std::vector<std::pair<uint64_t, BigsiBdb::Loc>>().swap(g_bdb_cache.rows); }      // consumed
+                    }
+                }
+                if (!cached)
+                    rc = db.scan(threads, [&](unsigned, const uint8_t *key, uint32_t klen, const BigsiBdb::Loc &l) {
+                        uint64_t r;
+                        if (bdb_row_key(key, klen, &r) && r >= row0 && r - row0 < n_rows) loc[r - row0] = l;      // (one writer per row: a key occurs once)
+                    });
             }
             if (rc != BIGSI_OK) { char keep[512]; snprintf(keep, sizeof keep, "%s", bigsi_hip_last_error()); close_(); return fail(rc, "%s: %s", path, keep); }
         }

@@ -78,7 +78,8 @@ def migrate_index(src, dst, block_rows=None, overlap=True):
 
 
 def _copy_rows(src, dst, up, m, n, rb, step):
-    for r0 in range(0, m, step):
+    blocks = [None, None]          # two blocks used alternately (the uploader holds one): a fresh 256 MB array per block is 65 k page faults
+    for bi, r0 in enumerate(range(0, m, step)):
         ids = list(range(r0, min(m, r0 + step)))
         keys = [src.convert_key_to_bytes(src.convert_to_bitarray_key(i)) if hasattr(src, "convert_key_to_bytes")
                 else ("%d:bitarray" % i).encode() for i in ids]
@@ -86,7 +87,9 @@ def _copy_rows(src, dst, up, m, n, rb, step):
         mask = (0xFF << (8 - n % 8)) & 0xFF if n % 8 else 0xFF      # columns beyond number_of_cols are not part of the index
         if _ext is not None and isinstance(raws, list) and all(type(r_) in (bytes, bytearray) for r_ in raws[:4]):
             # the rows of the block copied (cut / zero-extended to rb bytes) by a few threads below Python (bigsi_amd/_results.cpp)
-            block = np.empty((len(ids), max(rb, 1)), dtype=np.uint8)
+            if blocks[bi & 1] is None or blocks[bi & 1].shape[0] < len(ids):
+                blocks[bi & 1] = np.empty((len(ids), max(rb, 1)), dtype=np.uint8)
+            block = blocks[bi & 1][: len(ids)]
             _ext.pack_rows(raws, block, mask)
         else:
             block = np.zeros((len(ids), max(rb, 1)), dtype=np.uint8)

@@ -159,7 +159,7 @@ def test_native_import_equals_the_python_route(tmp_path, devices):
         st = get_storage({"storage-engine": "hip-hbm", "storage-config": sc, "k": 31, "m": m, "h": 3})
         assert bdb.import_index(fn, st, native=native) == (m, n)
         got[native] = np.asarray(st.get_rows_packed(np.arange(m), rb)).copy()
-        assert st.get_string("metadata:0:string") == "zero" and st.get_integer("number_of_cols") == n and st.get_integer("ksi:num_hashes") == 3
+        assert st.get_string("metadata:0") == "zero" and st.get_integer("number_of_cols") == n and st.get_integer("ksi:num_hashes") == 3
         st.delete_all()
     assert np.array_equal(got[True], rows) and np.array_equal(got[False], rows)
     del rec[b"5:bitarray"]                                   # not every row present: the Python route (KeyError semantics per row) takes over
