@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
 PEAK = 8000.0
-R = os.environ.get("ROUND", "r04")      # prefix of this round's files
+R = os.environ.get("ROUND", "r05")      # prefix of this round's files
 
 
 def short(name):
@@ -52,13 +52,43 @@ def json_lines(tag):
     return [json.loads(l) for l in open(path) if l.startswith("{")]
 
 
+def stamp():
+    """What the files of this round describe: the commit the snapshot was sent from and the library that ran (the .so travels with the
+    snapshot: the file here is the file there), plus the kernels that library holds -- tests/test_abi_and_host.py holds every kernel
+    name in profiles/<round>_*_kernel_stats.csv against the library built from the tree."""
+    import hashlib
+    import subprocess
+    so = os.path.join(ROOT, "bigsi_amd", "libbigsi_hip.so")
+    out = {"round": R}
+    try:
+        out["git_head"] = subprocess.run(["git", "rev-parse", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+        out["git_dirty"] = bool(subprocess.run(["git", "status", "--porcelain", "--", "bigsi_amd/csrc", "bench.py"], cwd=ROOT, capture_output=True, text=True).stdout.strip())
+    except OSError:
+        pass
+    try:
+        out["libbigsi_hip_so_sha256"] = hashlib.sha256(open(so, "rb").read()).hexdigest()
+    except OSError:
+        pass
+    return out
+
+
 def main():
     os.makedirs(DST, exist_ok=True)
     summary = {}
+    st = stamp()
+    try:          # the GPU box's own record of the library it ran (scripts/profile_all.sh)
+        ran = json.load(open(os.path.join(SRC, R + "_build.json")))
+        st["ran_so_sha256"] = ran.get("so_sha256")
+        assert ran.get("so_sha256") in (None, st.get("libbigsi_hip_so_sha256")), "the profiles were made with another build of libbigsi_hip.so than the one in the tree"
+    except OSError:
+        pass
+    with open(os.path.join(DST, R + "_stamp.json"), "w") as f:
+        json.dump(st, f, indent=1)
     for path in sorted(glob.glob(os.path.join(SRC, R + "_*_kernel_stats.csv"))):
         tag = os.path.basename(path)[: -len("_kernel_stats.csv")]
         ks, lines = kernel_stats(tag), json_lines(tag)
-        rec = {"command": "scripts/profile_all.sh: " + tag, "kernels": {k: v for k, v in ks.items() if k.startswith("bigsi::")}}
+        rec = {"command": "scripts/profile_all.sh: " + tag, "git_head": st.get("git_head"), "libbigsi_hip_so_sha256": st.get("libbigsi_hip_so_sha256"),
+               "kernels": {k: v for k, v in ks.items() if k.startswith("bigsi::")}}
         if lines and "roofline" in lines[-1]:              # a bench.py line
             d = lines[-1]
             r = d["roofline"]
@@ -161,7 +191,8 @@ def main():
     for name in (R + "_latency_probe.txt", R + "_frontend_probe.json", R + "_bench_default_full.json"):
         if os.path.exists(os.path.join(SRC, name)):
             shutil.copy(os.path.join(SRC, name), os.path.join(DST, name))
-    for name in (R + "_row_probe.txt", R + "_call_breakdown.txt", R + "_call_trace.txt", R + "_k1_phases.txt"):
+    for name in (R + "_row_probe.txt", R + "_call_breakdown.txt", R + "_call_trace.txt", R + "_k1_phases.txt", R + "_ingest.json", R + "_import.json", R + "_tmpfs_write_probe.txt",
+                 R + "_bench_default.json", R + "_results_bench.txt"):
         if os.path.exists(os.path.join(SRC, name)):
             shutil.copy(os.path.join(SRC, name), os.path.join(DST, name))
     with open(os.path.join(DST, R + "_summary.json"), "w") as f:

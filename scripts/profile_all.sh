@@ -4,12 +4,16 @@
 # for the dominant kernel (one counter per pass, as the hardware guide prescribes), and the unprofiled default bench line.
 # scripts/make_profiles.py then condenses gpurun_out/prof into profiles/<round>_* (ROUND=r03 by default).
 cd "${GRAFT_REPO_ROOT:-.}"
-R=${ROUND:-r04}
+R=${ROUND:-r05}
 P=gpurun_out/prof
 mkdir -p $P
 B="--cpu-seconds 0 --also none --host-visible 0 --alone-steps 0"      # (rocprofv3 averages then cover launches of the timed shape only)
 [ -f bigsi_amd/libbigsi_hip_tuning.so ] || bash bigsi_amd/csrc/build.sh tuning > /dev/null      # (two legs below A/B through it)
 run() { scripts/prof.sh "$@" > /dev/null; }
+python - <<PYEOF > $P/${R}_build.json
+import hashlib, json
+print(json.dumps({"so_sha256": hashlib.sha256(open("bigsi_amd/libbigsi_hip.so", "rb").read()).hexdigest()}))
+PYEOF
 run ${R}_c3_exact        -- python bench.py --steps 20 --warmup 5 $B
 run ${R}_c3_t04          -- python bench.py --steps 20 --warmup 5 $B --threshold 0.4
 run ${R}_c3_256x1kbp     -- python bench.py --steps 200 --warmup 10 $B --batch 256
@@ -27,6 +31,10 @@ run ${R}_northstar_shard_t04 -- python bench.py --workload northstar --shard-of 
 run ${R}_northstar_shard_h4  -- python bench.py --workload northstar --shard-of 8 --gpus 1 --steps 200 --warmup 10 $B --hashes 4
 run ${R}_c3_strong8_shard    -- python bench.py --workload c3 --shard-of 8 --gpus 1 --steps 40 --warmup 5 $B
 run ${R}_c3_strong8_rccl1    -- python bench.py --workload c3 --shard-of 8 --gpus 1 --steps 40 --warmup 5 $B --force-dist
+# the hit-dense regime (round 5): ~10 k scored hits per batch on the c5 shard, 8 hits per read on c2, early exit on the dense shard
+run ${R}_c5_dense        -- python bench.py --workload c5 --shard-of 8 --dense 1 --steps 60 --warmup 6 $B
+run ${R}_c2_dense        -- python bench.py --workload c2 --dense 1 --steps 4000 --warmup 100 $B
+run ${R}_c5_ee           -- python bench.py --workload c5 --shard-of 8 --dense 1 --early-exit 1 --score 0 --steps 200 --warmup 10 $B
 run ${R}_long_queries    -- python scripts/measure.py p16
 run ${R}_k5              -- python scripts/measure.py k5
 run ${R}_transpose       -- python scripts/measure.py transpose

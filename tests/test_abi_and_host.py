@@ -536,3 +536,50 @@ def test_bench_failure_leaves_a_json_line():
     assert r.returncode != 0 and "more than one MI355X holds" in r.stderr
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["value"] is None and d["rc"] == 1 and d["n_gpus"] == 1 and "more than one MI355X holds" in d["error"] and d["where"]
+
+
+def _library_kernels():
+    """short names (template arguments kept, parameter lists dropped) of the device kernels libbigsi_hip.so holds: the mangled names
+    sit in the embedded code object."""
+    import re
+    import subprocess
+    from bigsi_amd import _lib
+    raw = open(_lib.LIB_PATH, "rb").read()
+    mangled = sorted({m.group(0).decode() for m in re.finditer(rb"_ZN5bigsi[A-Za-z0-9_]+", raw)})
+    filt = "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"
+    if not os.path.exists(filt):
+        import shutil
+        filt = shutil.which("c++filt")
+    if not filt:
+        pytest.skip("no demangler on this machine")
+    out = subprocess.run([filt], input="\n".join(mangled), capture_output=True, text=True).stdout.splitlines()
+    return {l.split("(")[0].replace("void ", "").strip() for l in out if "bigsi::" in l}
+
+
+def test_profiles_of_this_round_describe_the_built_library():
+    """Every kernel a rocprofv3 summary of THIS round names (profiles/r05_*_kernel_stats.csv) is a kernel of the library the tree
+    builds -- a summary made before a kernel changed its template parameters names one that no longer exists -- and the round's stamp
+    (profiles/r05_stamp.json: commit and library hash the profiles were made with) is present."""
+    import csv
+    import glob
+    from bigsi_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libbigsi_hip.so not built")
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_*_kernel_stats.csv")))
+    if not files:
+        pytest.skip("no round-5 profiles yet")
+    have = _library_kernels()
+    assert len(have) > 30
+    norm = lambda s_: s_.replace(" ", "")      # noqa: E731 -- (demanglers differ in spacing)
+    have_n = {norm(h) for h in have}
+    missing = {}
+    for fn in files:
+        with open(fn) as f:
+            for r in csv.DictReader(f):
+                name = r["Name"].split("(")[0].replace("void ", "").strip()
+                if name.startswith("bigsi::") and norm(name) not in have_n:
+                    missing.setdefault(os.path.basename(fn), []).append(name)
+    assert not missing, "profiles name kernels the built library does not hold: %r" % missing
+    import json
+    st = json.load(open(os.path.join(ROOT, "profiles", "r05_stamp.json")))
+    assert len(st.get("git_head", "")) == 40 and len(st.get("libbigsi_hip_so_sha256", "")) == 64
