@@ -49,6 +49,11 @@ BIGSI_HIP_LIB=$PWD/bigsi_amd/libbigsi_hip_tuning.so python scripts/call_breakdow
 BIGSI_HIP_LIB=$PWD/bigsi_amd/libbigsi_hip_tuning.so python scripts/ab_k1_phases.py > $P/${R}_k1_phases.txt 2>/dev/null
 scripts/probe/latency_probe > $P/${R}_latency_probe.txt 2>&1
 python scripts/frontend_probe.py > $P/${R}_frontend_probe.json 2>/dev/null
+# round 5: file <-> HBM (striped snapshot, one-file save for comparison, two-shard group), importers, the tmpfs write probe, the dict builder
+python scripts/ingest_bench.py --gb 32 > $P/${R}_ingest.json 2>/dev/null
+python scripts/import_bench.py --gb 16 --bdb-gb 6 > $P/${R}_import.json 2>/dev/null
+{ python scripts/probe/tmpfs_write_probe.py 8 /dev/shm 16; g++ -O2 -pthread -o /tmp/mwp scripts/probe/mmap_write_probe.cpp && /tmp/mwp 8 /dev/shm 16; } > $P/${R}_tmpfs_write_probe.txt 2>&1
+{ python scripts/results_bench.py 625 64; python scripts/results_bench.py 8 20000 61; python scripts/results_bench.py 1 20000; } > $P/${R}_results_bench.txt 2>&1
 # PMC: HBM traffic of every quoted kernel (FETCH_SIZE / WRITE_SIZE in separate passes, --kernel-trace only)
 export TMPDIR=/tmp
 python scripts/pmc_all.py $P/pmc > $P/${R}_pmc_all.log 2>&1
