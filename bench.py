@@ -957,20 +957,20 @@ def run(args):
     # PCIe-inclusive rate of the host-buffer boundary (never `value`): sequences in host memory -> batch_reload (H2D) ->
     # run -> fetch_hits (D2H), a few repetitions outside the timed region
     pcie_rate = None
-    if world == 1 and not args.force_dist:
+    if world == 1 and not args.force_dist and args.host_visible:
         # a serving loop: two workspaces, reloaded per batch; while one batch runs, the host uploads the next one and
         # downloads the hit lists of the one before (what BIGSI.search_stream does)
         reps = 8 if w["batch"] * w["qlen"] >= (1 << 20) else 200      # (small batches: enough repetitions to time)
         ws = [st.new_batch(seqs, args.k) for _ in range(2)]
         for w_ in ws:                                                  # both workspaces warm
-            w_.run(thr, sparse_counts=True)
+            w_.run(thr, sparse_counts=True, early_exit=bool(args.early_exit))
             w_.hits()
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
         for i in range(reps):
             cur = ws[i % 2]
             cur.reload(all_seqs[i % nb])           # H2D of the sequences (waits for this workspace's previous batch only)
-            cur.run(thr, sparse_counts=True)
+            cur.run(thr, sparse_counts=True, early_exit=bool(args.early_exit))
             if i:
                 ws[(i - 1) % 2].hits()             # D2H of the previous batch's hit lists while `cur` runs
         ws[(reps - 1) % 2].hits()

@@ -23,7 +23,7 @@ off = np.zeros(nq + 1, np.int64)
 np.cumsum(nh, out=off[1:])
 total = int(off[-1])
 cols = np.concatenate([np.sort(rng.choice(ncols, hpq, replace=False)) for _ in range(nq)]).astype(np.uint32)
-cnts = rng.integers(400, npos, size=total).astype(np.uint32)
+cnts = rng.integers(min(400, npos // 2), npos, size=total).astype(np.uint32)
 rec = np.zeros(total, HIT_SCORE_DTYPE)
 rec["num_kmers"] = npos
 for f in ("score", "min_score", "max_score"):
