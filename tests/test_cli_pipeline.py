@@ -157,3 +157,59 @@ def test_sharded_build_and_search_commands(tmp_path):
             assert out == want, (c["cmd"], c["threshold"], c["format"], c.get("stream"))
         n += 1
     assert n >= 10, n
+
+
+@pytest.mark.gpu
+def test_hold_keeps_the_index_resident_for_other_processes(tmp_path):
+    """`python -m bigsi_amd hold` loads the index once and writes the attach file; `search` / `bulk_search` in OTHER processes whose
+    storage-config says `attach:` open that resident index (no snapshot load of their own: the file they name as `filename` does not
+    even exist) and print what a process with its own copy prints.  When the holder goes, its attach file goes with it."""
+    import time
+    g9 = load_golden("g9_frontend.json")
+    names = list(g9["samples"].keys())
+    cfg = {"storage-engine": "hip-hbm", "k": 31, "m": 1000, "h": 3, "storage-config": {"name": "held", "filename": str(tmp_path / "held.hbm")}}
+    cf = tmp_path / "owner.yaml"
+    cf.write_text(yaml.safe_dump(cfg))
+    blooms = []
+    for i, nme in enumerate(names):
+        kf = tmp_path / ("s%d.kmers" % i)
+        kf.write_text("\n".join(g9["samples"][nme]) + "\n")
+        cli(["bloom", str(kf), str(tmp_path / ("s%d.bloom" % i)), "--config", str(cf)], str(tmp_path))
+        blooms.append(str(tmp_path / ("s%d.bloom" % i)))
+    args = ["build", "--config", str(cf)]
+    for b, nme in zip(blooms, names):
+        args += ["-b", b, "-s", nme]
+    assert "success" in cli(args, str(tmp_path))
+    attach = str(tmp_path / "held.attach")
+    holder = subprocess.Popen([sys.executable, "-m", "bigsi_amd", "hold", "--config", str(cf), "--handle", attach, "--until-eof"], cwd=str(tmp_path),
+                              stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, env=dict(os.environ, PYTHONPATH=ROOT))
+    try:
+        line = holder.stdout.readline()
+        assert line, "hold exited: %r" % holder.poll()
+        info = json.loads(line)
+        assert info["result"] == "holding" and info["attach"] == attach and info["num_samples"] == len(names) and os.path.exists(attach)
+        acfg = dict(cfg, **{"storage-config": {"name": "client", "attach": attach, "filename": str(tmp_path / "no-such-snapshot.hbm")}})
+        af = tmp_path / "client.yaml"
+        af.write_text(yaml.safe_dump(acfg))
+        fasta = tmp_path / "tests.fasta"
+        fasta.write_text(g9["fasta_text"]["tests"])
+        n = 0
+        for c in g9["cases"]:
+            if c["cmd"] == "search" and n < 6:
+                extra = ["--score"] if c["score"] else []
+                out = cli(["search", c["seq"], "--threshold", str(c["threshold"]), "--format", c["format"], "--config", str(af)] + extra, str(tmp_path))
+                assert out == nl(c["out"] + "\n"), (c["seq"][:20], c["threshold"], c["format"])
+                n += 1
+            elif c["cmd"] != "search" and c["fasta"] == "tests" and not c["stream"] and not c["score"]:
+                out = cli(["bulk_search", str(fasta), "--threshold", str(c["threshold"]), "--format", c["format"], "--config", str(af)], str(tmp_path))
+                assert out == nl(c["out"] + "\n")
+                n += 1
+        assert n >= 8 and holder.poll() is None
+    finally:
+        holder.stdin.close()
+        t0 = time.time()
+        while holder.poll() is None and time.time() - t0 < 60:
+            time.sleep(0.1)
+        if holder.poll() is None:
+            holder.kill()
+    assert holder.returncode == 0 and not os.path.exists(attach)
