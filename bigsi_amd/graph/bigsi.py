@@ -34,6 +34,9 @@ def validate_build_params(bloomfilters, samples):
         raise ValueError("There must be the same number of bloomfilters and sample names")
 
 
+# sequences of a search_batch call up to this many bytes in all go through the C ABI's one-call entry point
+ONE_CALL_BYTES = 192 << 10
+
 # host memory one slice of scored hits may take as characters (the presence strings are the bulk of a scored result)
 SCORE_SLICE_CHARS = 256 << 20
 
@@ -403,9 +406,29 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
                 for i, r in zip(rest, self._search_batch_locked([seqs[i] for i in rest], threshold, score)):
                     out[i] = r
             return out
+        if not score and sum(map(len, seqs)) <= ONE_CALL_BYTES:
+            # unscored (the reference's `search` endpoint, bigsi/__main__.py:195-209): ONE call of the C ABI -- bigsi_hip_search_batch:
+            # zero-copy input, results written into pinned memory by the last kernel -- instead of reload + run + two fetches
+            # (a 1 kbp query against a 125 GB index: 35 us in the C call against ~90 through the batch object)
+            from .. import _lib
+            flags = _lib.RUN_EARLY_EXIT if self.config.get("early_exit", False) else 0
+            nk, nu, off, colours, counts = self.storage.search_batch_arrays(seqs, self.kmer_size, threshold, flags)
+            return self._collect_end(self._check_degenerate(None, len(seqs), threshold, nk, nu, off, colours, counts))
         batch = self._workspace(0, seqs)
         self._launch(batch, threshold)
         return self._collect(batch, len(seqs), threshold, score)
+
+    def _check_degenerate(self, batch, n_seqs, threshold, num_kmers, num_unique, off, colours, counts):
+        """The unscored half of _collect_begin on arrays: the reference's errors for queries without k-mers, the no-hit shortcut."""
+        exact = threshold == 1.0
+        if num_unique[:n_seqs].all() and int(off[n_seqs]) == 0:
+            return None, n_seqs
+        nu = num_unique[:n_seqs]
+        if not nu.all():
+            if exact:
+                raise TypeError("reduce() of empty sequence with no initial value")
+            raise UnboundLocalError("local variable 'cumsum' referenced before assignment")
+        return (batch, off.astype(np.int64), colours, counts, nu, exact, None), n_seqs
 
     def search_stream(self, seqs, threshold=1.0, score=False, batch_size=None, batch_kmers=1 << 19, pause_gc=True):
         """Generator over (sequence, results) for an arbitrarily long iterable of sequences (bulk_search, bigsi/__main__.py:261-314,

@@ -492,9 +492,19 @@ class HipHbmStorage(BaseStorage):
         ordering by count, percentages and scores stay with the caller."""
         assert threshold <= 1                                   # graph/bigsi.py:176
         seqs = list(seqs)
-        n = len(seqs)
-        if n == 0:
+        if not seqs:
             return []
+        nk, nu, off, col, cnt = self.search_batch_arrays(seqs, k, threshold)
+        # (most sequences of a bulk search match nothing: they share ONE pair of empty arrays instead of 2 slices each, which is
+        # where a 1000-read call spent its time once the C call was down to 0.07 ms)
+        o, e_col, e_cnt = off.tolist(), col[:0], cnt[:0]
+        return [(k_, u_, col[x:y], cnt[x:y]) if y > x else (k_, u_, e_col, e_cnt) for k_, u_, x, y in zip(nk.tolist(), nu.tolist(), o, o[1:])]
+
+    def search_batch_arrays(self, seqs, k, threshold=1.0, flags=0):
+        """The same call with its results as the C ABI leaves them: (num_kmers uint32[n], num_unique uint32[n], hit offsets
+        uint64[n + 1], colours uint32[hits], counts uint32[hits]).  BIGSI.search / search_batch take this route for unscored
+        queries: one C call (bigsi_hip_search_batch) instead of reload + run + two fetches."""
+        n = len(seqs)
         # the C ABI's one-call entry point (bigsi_hip_search_batch / bigsi_hip_group_search_batch): the index keeps the
         # workspace, so a call is two uploads, the kernels and three downloads -- no device allocation
         blob, soff = _lib.pack_seqs(seqs)
@@ -504,16 +514,13 @@ class HipHbmStorage(BaseStorage):
         cap = self._search_cap
         while True:
             col, cnt = np.zeros(cap, np.uint32), np.zeros(cap, np.uint32)
-            rc = fn(self.handle, blob, _lib.ptr(soff), n, int(k), float(threshold), 0, _lib.ptr(nk), _lib.ptr(nu), None,
+            rc = fn(self.handle, blob, _lib.ptr(soff), n, int(k), float(threshold), int(flags), _lib.ptr(nk), _lib.ptr(nu), None,
                     _lib.ptr(off), _lib.ptr(col), _lib.ptr(cnt), cap)
             if rc != _lib.ERR_CAPACITY or int(off[-1]) <= cap:      # (any other CAPACITY error -- a result wider than the row stride -- is not ours to retry)
                 break
             cap = self._search_cap = int(off[-1])             # offsets are filled in: bring that much next time
         check(rc)
-        # (most sequences of a bulk search match nothing: they share ONE pair of empty arrays instead of 2 slices each, which is
-        # where a 1000-read call spent its time once the C call was down to 0.07 ms)
-        o, e_col, e_cnt = off.tolist(), col[:0], cnt[:0]
-        return [(k_, u_, col[x:y], cnt[x:y]) if y > x else (k_, u_, e_col, e_cnt) for k_, u_, x, y in zip(nk.tolist(), nu.tolist(), o, o[1:])]
+        return nk, nu, off, col[: int(off[-1])], cnt[: int(off[-1])]
 
 
     def search_many(self, seqs, k, threshold=1.0):

@@ -583,3 +583,34 @@ def test_profiles_of_this_round_describe_the_built_library():
     import json
     st = json.load(open(os.path.join(ROOT, "profiles", "r05_stamp.json")))
     assert len(st.get("git_head", "")) == 40 and len(st.get("libbigsi_hip_so_sha256", "")) == 64
+
+
+def test_stream_tuning_is_shared_between_streams_and_restored_by_the_last_one():
+    """search_stream's two interpreter-wide settings (short switch interval, automatic GC paused) belong to all running streams together:
+    interleaved entries and exits from two streams restore the ORIGINAL values, whatever the order (a per-stream save / restore left the
+    process at the short interval, or with the collector off, for good)."""
+    import gc
+    import sys
+    from bigsi_amd.graph.bigsi import _StreamTuning as T
+    i0, g0 = sys.getswitchinterval(), gc.isenabled()
+    try:
+        gc.enable()
+        sys.setswitchinterval(0.005)
+        a = T.enter(True)                        # stream A
+        assert a and not gc.isenabled() and sys.getswitchinterval() <= 2.1e-4
+        b = T.enter(True)                        # stream B, nested / in another thread
+        assert b and not gc.isenabled()
+        T.leave(True)                            # A ends first: B still runs
+        assert not gc.isenabled() and sys.getswitchinterval() <= 2.1e-4
+        T.leave(True)                            # the last one out restores
+        assert gc.isenabled() and abs(sys.getswitchinterval() - 0.005) < 1e-9
+        c = T.enter(False)                       # a stream that leaves the collector alone
+        assert not c and gc.isenabled() and sys.getswitchinterval() <= 2.1e-4
+        d = T.enter(True)
+        T.leave(False)
+        assert not gc.isenabled()
+        T.leave(True)
+        assert gc.isenabled() and abs(sys.getswitchinterval() - 0.005) < 1e-9 and T.users == 0 and T.gc_users == 0
+    finally:
+        sys.setswitchinterval(i0)
+        (gc.enable if g0 else gc.disable)()
