@@ -614,3 +614,60 @@ def test_stream_tuning_is_shared_between_streams_and_restored_by_the_last_one():
     finally:
         sys.setswitchinterval(i0)
         (gc.enable if g0 else gc.disable)()
+
+
+def test_pack_rows_extension_is_the_python_loop():
+    """_results.pack_rows (row blocks of migrate_index packed by threads below Python) == the loop it replaces: rows cut or
+    zero-extended to rb bytes, the last byte masked."""
+    from bigsi_amd import migrate
+    if migrate._ext is None:
+        pytest.skip("bigsi_amd/_results extension not built")
+    rng = np.random.default_rng(3)
+    for n, rb, mask in ((1, 1, 0xFF), (7, 13, 0xF0), (300, 62500, 0x80), (2000, 1251, 0xFE)):
+        raws = [rng.integers(0, 256, size=int(rng.choice([0, 1, rb - 1, rb, rb + 5, max(rb // 2, 1)])), dtype=np.uint8).tobytes() for _ in range(n)]
+        raws[0] = bytearray(raws[0])
+        want = np.zeros((n, rb), np.uint8)
+        for j, raw in enumerate(raws):
+            a = np.frombuffer(bytes(raw), np.uint8)[:rb]
+            want[j, : a.size] = a
+        want[:, rb - 1] &= mask
+        got = np.full((n, rb), 0xAA, np.uint8)
+        migrate._ext.pack_rows(raws, got, mask)
+        assert np.array_equal(got, want), (n, rb)
+    with pytest.raises(TypeError):
+        migrate._ext.pack_rows(["not bytes"], np.zeros((1, 4), np.uint8), 0xFF)
+    with pytest.raises(ValueError):
+        migrate._ext.pack_rows([b"x", b"y"], np.zeros((1, 4), np.uint8), 0xFF)
+
+
+def test_dense_bench_plants_and_the_oracles_bulk_bookkeeping():
+    """bench.py --dense: a sample's stretches of a query <-> the k-mer positions planted (seg_masks), and the oracle's bulk
+    bookkeeping of such plants (SynthOracle.insert_kmer_masks, restricted to the rows a check reads) == insert_kmers per stretch."""
+    import bench
+    from oracle.ref_model import SynthOracle
+    k, qlen = 31, 400
+    w = {"batch": 20, "qlen": qlen}
+    plants = list(bench.dense_gene_plants(w, 2, 0, 5000, k))
+    assert len(plants) == 2 * 16 and all(len(c) == 50 and len(np.unique(c)) == 50 for _, _, c, _ in plants)
+    rng = np.random.default_rng(4)
+    seq = "".join(rng.choice(list("ACGT"), size=qlen))
+    _, _, cols, segs = plants[3]
+    masks = bench.seg_masks(segs, qlen - k + 1, k)
+    for j, sg in enumerate(segs):
+        inside = np.zeros(qlen - k + 1, bool)
+        for a, b in sg:
+            assert b - a >= k
+            inside[a:b - k + 1] = True
+        assert np.array_equal(masks[j], inside)
+    assert 0.3 < masks.mean() <= 1.0
+    a, b = SynthOracle(1, 0, 100003, 5000, 3, k, 2), SynthOracle(1, 0, 100003, 5000, 3, k, 2)
+    for c, sg in zip(cols.tolist(), segs):
+        for x, y in sg:
+            a.insert_kmers(c, seq[x:y])
+    b.insert_kmer_masks(b.rows_of(seq), cols, masks)
+    assert a.planted == b.planted
+    only = np.unique(b.rows_of(seq)[::7].ravel())
+    c_ = SynthOracle(1, 0, 100003, 5000, 3, k, 2)
+    c_.insert_kmer_masks(c_.rows_of(seq), cols, masks, only)
+    assert c_.planted == {r: v for r, v in a.planted.items() if r in set(only.tolist())}
+    assert sorted(bench.dense_read_cols(1, 5, 0, 10000)) == sorted(set(bench.dense_read_cols(1, 5, 0, 10000))) and len(bench.dense_read_cols(1, 5, 0, 10000)) == 8
