@@ -253,6 +253,10 @@ def cpu_baseline(args, w, cols_cpu, exact):
             "word_parallel_one_core": {"value": t["word_parallel_one_core"]["rate"], "what": "BIGSI_CPU_WORD_PARALLEL: 64-bit words of the resident rows, no copies"},
             "word_parallel_pool": {"value": t["word_parallel_pool"]["rate"], "cores": t["word_parallel_pool"]["threads"],
                                    "what": "the same in the fork pool: the best this host's CPUs do on the path"},
+            # the closest stand-in for north_star's "berkeleydb / CPU path" these hosts allow (no bsddb3, no libdb headers): the same
+            # reference-shaped searches with every row read from a BerkeleyDB hash file that libdb itself wrote (tmpfs: page cache)
+            "bdb_file": None if not t.get("bdb_file") else {"value": t["bdb_file"]["one_core"]["rate"], "pool": t["bdb_file"]["pool"]["rate"], "pool_cores": t["bdb_file"]["pool"]["threads"],
+                                                            "file_gb": t["bdb_file"]["file_gb"], "what": t["bdb_file"]["what"]},
             "oracle_port": {"value": r["one_core"]["rate"], "pool": r["pool"]["rate_median"], "pool_cores": r["pool"]["threads"],
                             "what": "oracle/bigsi_oracle.c orc_query (test infrastructure), same slice and queries: cross-check of the twin"}}
 
@@ -439,7 +443,9 @@ def condense(full):
                                 "through": "libbigsi_cpu.so bigsi_cpu_search_batch (CPU twin of the C ABI), reference-shaped",
                                 "pool_value": sig(cb["pool"]["value"]), "pool_cores": cb["pool"]["cores"],
                                 "best_cpu_value": sig(cb["word_parallel_pool"]["value"]), "best_cpu_cores": cb["word_parallel_pool"]["cores"],
-                                "oracle_port_value": sig(cb["oracle_port"]["value"])}
+                                "oracle_port_value": sig(cb["oracle_port"]["value"]),
+                                # rows read from a BerkeleyDB hash file libdb wrote (the twin's own page walk; no bsddb3 here): one core | fork pool
+                                "bdb_file_value": sig((cb.get("bdb_file") or {}).get("value")), "bdb_file_pool_value": sig((cb.get("bdb_file") or {}).get("pool"))}
     if cf.get("also"):
         line["config"]["also"] = {k_: {kk: sig(vv) if not isinstance(vv, list) else [sig(x, 4) for x in vv] for kk, vv in v_.items()} for k_, v_ in cf["also"].items()}
     # the cap is a contract with the driver's 8 KB tail: drop the least important keys first rather than lose the end of the line

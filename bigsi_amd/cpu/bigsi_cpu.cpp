@@ -30,6 +30,10 @@
 #include <unordered_map>
 #include <vector>
 
+#include <fcntl.h>
+#include <mutex>
+
+#include "../csrc/bigsi_bdb.hpp"
 #include "../csrc/bigsi_score.hpp"
 
 namespace {
@@ -133,10 +137,27 @@ uint64_t valid_word_mask(uint64_t w, uint64_t n_cols)
 
 }  // namespace
 
+// rows served from a BerkeleyDB hash FILE (bigsi_cpu_open_bdb) instead of a table in RAM: where every "<row>:bitarray" record lies
+struct BdbRows {
+    int fd = -1;
+    BigsiBdb db;
+    std::vector<BigsiBdb::Loc> loc;
+};
+
 struct bigsi_cpu_index {
     uint64_t m = 0, n_cols = 0, cap_cols = 0, stride = 0;      // stride: bytes per row, a multiple of 128 like the device's pitch
     uint32_t h = 0;
     uint8_t *rows = nullptr;
+    BdbRows *bdb = nullptr;      // non-null: no table in RAM, every row fetch reads the store's file (read-only index)
+    // row r's first rb bytes: the table's own memory, or -- BerkeleyDB store -- read into `tmp` (zero-extended), as a KV store's get does
+    const uint8_t *fetch(uint64_t r, uint64_t rb_, std::vector<uint8_t> &tmp, std::vector<uint8_t> &page) const
+    {
+        if (!bdb) return rows + r * stride;
+        tmp.assign(rb_, 0);
+        const BigsiBdb::Loc &l = bdb->loc[r];
+        if (l.kind) bdb->db.read_value(l, tmp.data(), (uint32_t)std::min<uint64_t>(l.len, rb_), page);
+        return tmp.data();
+    }
     uint64_t rb() const { return ceil_div(n_cols, 8); }
     uint8_t *row(uint64_t r) { return rows + r * stride; }
     const uint8_t *row(uint64_t r) const { return rows + r * stride; }
@@ -219,13 +240,20 @@ void search_reference_shaped(const bigsi_cpu_index *ix, const char *s, uint64_t 
     std::vector<uint64_t> kmer_rows((size_t)u * h);
     std::unordered_map<uint64_t, uint32_t> fetched;
     std::vector<std::vector<uint8_t>> row_copy;
+    std::vector<uint8_t> bdb_page;
     std::string canon;
     for (uint32_t j = 0; j < u; j++) {
         canonical(s + q.first_pos[j], k, canon);
         rows_of(canon, h, ix->m, &kmer_rows[(size_t)j * h]);
         for (uint32_t t = 0; t < h; t++) {
             const uint64_t r = kmer_rows[(size_t)j * h + t];
-            if (fetched.emplace(r, (uint32_t)row_copy.size()).second) row_copy.emplace_back(ix->row(r), ix->row(r) + rb);
+            if (fetched.emplace(r, (uint32_t)row_copy.size()).second) {
+                if (ix->bdb) {          // the store's get(): the record's bytes read from the file (an overflow chain of pages for wide rows)
+                    row_copy.emplace_back(rb, 0);
+                    const BigsiBdb::Loc &l = ix->bdb->loc[r];
+                    if (l.kind) ix->bdb->db.read_value(l, row_copy.back().data(), (uint32_t)std::min<uint64_t>(l.len, rb), bdb_page);
+                } else row_copy.emplace_back(ix->row(r), ix->row(r) + rb);
+            }
         }
     }
     std::vector<uint8_t> all;                        // exact: AND of every k-mer's row
@@ -352,7 +380,69 @@ int bigsi_cpu_close(bigsi_cpu_index *ix)
 {
     if (!ix) return BIGSI_OK;
     free(ix->rows);
+    if (ix->bdb) {
+        if (ix->bdb->fd >= 0) close(ix->bdb->fd);
+        delete ix->bdb;
+    }
     delete ix;
+    return BIGSI_OK;
+}
+
+// An index whose rows stay in the reference's own store: a BerkeleyDB HASH file (bigsi/storage/berkeleydb.py:6-19) holding the
+// "<row>:bitarray" records and the index integers of a v0.3 BIGSI index (bigsi/storage/base.py:29-36).  Nothing is loaded: every
+// row a search needs is read from the file when it is needed -- located by a table built with one scan of the hash pages (libdb
+// finds a record by hashing its key to a bucket page; the table stands in for that), then its bytes gathered from the page, or the
+// overflow chain of pages, they lie in.  The closest this package comes to the reference's "berkeleydb / CPU path" without libdb
+// (neither bsddb3 nor the db.h headers exist on these hosts): reference-shaped search, lookup, get_rows and presence only.
+int bigsi_cpu_open_bdb(const char *path, uint32_t threads, bigsi_cpu_index **out)
+{
+    if (!path || !out) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(BIGSI_ERR_INVALID, "%s: %s", path, strerror(errno));
+    BdbRows *b = new (std::nothrow) BdbRows();
+    bigsi_cpu_index *ix = new (std::nothrow) bigsi_cpu_index();
+    if (!b || !ix) { close(fd); delete b; delete ix; return fail(BIGSI_ERR_NOMEM, "host allocation failed"); }
+    b->fd = fd;
+    ix->bdb = b;
+    auto bail = [&](int code, const std::string &msg) { bigsi_cpu_close(ix); return fail(code, "%s: %s", path, msg.c_str()); };
+    if (b->db.open_fd(fd)) return bail(BIGSI_ERR_INVALID, b->db.error);
+    if (threads == 0) threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency() / 4));
+    // the small records first (number_of_rows, number_of_cols, ksi:num_hashes), the row locations in the same pass
+    std::mutex mu;
+    std::vector<std::pair<uint64_t, BigsiBdb::Loc>> rows;
+    std::vector<std::pair<std::string, BigsiBdb::Loc>> small;
+    if (b->db.scan(threads, [&](unsigned, const uint8_t *key, uint32_t klen, const BigsiBdb::Loc &l) {
+            uint64_t r;
+            std::lock_guard<std::mutex> g(mu);
+            if (bigsi_bdb_row_key(key, klen, &r)) rows.emplace_back(r, l);
+            else if (klen < 64) small.emplace_back(std::string(reinterpret_cast<const char *>(key), klen), l);
+        }))
+        return bail(BIGSI_ERR_INVALID, b->db.error);
+    auto integer = [&](const char *key, uint64_t *v) -> bool {
+        std::vector<uint8_t> page;
+        for (auto &s_ : small)
+            if (s_.first == key && s_.second.len < 32) {
+                char buf[32] = {0};
+                if (b->db.read_value(s_.second, reinterpret_cast<uint8_t *>(buf), s_.second.len, page)) return false;
+                char *end = nullptr;
+                *v = strtoull(buf, &end, 10);
+                return end != buf;
+            }
+        return false;
+    };
+    uint64_t m = 0, n = 0, h = 0;
+    if (!integer("number_of_rows:int", &m) || !integer("number_of_cols:int", &n) || !integer("ksi:num_hashes:int", &h) || m == 0 || h == 0)
+        return bail(BIGSI_ERR_INVALID, "no number_of_rows / number_of_cols / ksi:num_hashes records: not a BIGSI v0.3 index");
+    ix->m = m;
+    ix->n_cols = n;
+    ix->h = (uint32_t)h;
+    ix->stride = stride_for(std::max<uint64_t>(n, 1));
+    ix->cap_cols = ix->stride * 8;
+    b->loc.assign(m, BigsiBdb::Loc{});
+    for (auto &e : rows)
+        if (e.first < m) b->loc[e.first] = e.second;
+    *out = ix;
     return BIGSI_OK;
 }
 
@@ -388,6 +478,7 @@ int bigsi_cpu_set_num_hashes(bigsi_cpu_index *ix, uint32_t num_hashes)
 
 int bigsi_cpu_reserve_cols(bigsi_cpu_index *ix, uint64_t col_capacity)
 {
+    if (ix && ix->bdb) return fail(BIGSI_ERR_STATE, "this index serves its rows from a BerkeleyDB file (bigsi_cpu_open_bdb): read-only, search / lookup / get_rows / presence only");
     if (!ix) return fail(BIGSI_ERR_INVALID, "NULL index");
     if (col_capacity <= ix->cap_cols) return BIGSI_OK;
     const uint64_t stride = stride_for(col_capacity);
@@ -405,6 +496,7 @@ int bigsi_cpu_synchronize(bigsi_cpu_index *ix) { return ix ? BIGSI_OK : fail(BIG
 
 int bigsi_cpu_set_rows(bigsi_cpu_index *ix, const uint64_t *row_ids, uint64_t n, const uint8_t *bytes, uint64_t row_bytes)
 {
+    if (ix && ix->bdb) return fail(BIGSI_ERR_STATE, "this index serves its rows from a BerkeleyDB file (bigsi_cpu_open_bdb): read-only, search / lookup / get_rows / presence only");
     if (!ix || (n && (!row_ids || !bytes))) return fail(BIGSI_ERR_INVALID, "NULL argument");
     if (row_bytes > ix->stride) return fail(BIGSI_ERR_CAPACITY, "row_bytes %llu exceeds the row stride %llu", (unsigned long long)row_bytes, (unsigned long long)ix->stride);
     for (uint64_t i = 0; i < n; i++)
@@ -423,12 +515,14 @@ int bigsi_cpu_get_rows(bigsi_cpu_index *ix, const uint64_t *row_ids, uint64_t n,
     if (row_bytes > ix->stride) return fail(BIGSI_ERR_CAPACITY, "row_bytes %llu exceeds the row stride %llu", (unsigned long long)row_bytes, (unsigned long long)ix->stride);
     for (uint64_t i = 0; i < n; i++)
         if (row_ids[i] >= ix->m) return fail(BIGSI_ERR_RANGE, "row %llu out of range", (unsigned long long)row_ids[i]);
-    for (uint64_t i = 0; i < n; i++) memcpy(out + i * row_bytes, ix->row(row_ids[i]), row_bytes);
+    std::vector<uint8_t> tmp, page;
+    for (uint64_t i = 0; i < n; i++) memcpy(out + i * row_bytes, ix->fetch(row_ids[i], row_bytes, tmp, page), row_bytes);
     return BIGSI_OK;
 }
 
 int bigsi_cpu_clear(bigsi_cpu_index *ix)
 {
+    if (ix && ix->bdb) return fail(BIGSI_ERR_STATE, "this index serves its rows from a BerkeleyDB file (bigsi_cpu_open_bdb): read-only, search / lookup / get_rows / presence only");
     if (!ix) return fail(BIGSI_ERR_INVALID, "NULL index");
     memset(ix->rows, 0, ix->m * ix->stride);
     return BIGSI_OK;
@@ -441,6 +535,7 @@ int bigsi_cpu_insert_column(bigsi_cpu_index *ix, uint64_t col, const uint8_t *bl
 
 int bigsi_cpu_insert_columns(bigsi_cpu_index *ix, uint64_t col0, uint64_t n, const uint8_t *blooms, uint64_t bloom_stride_bytes)
 {
+    if (ix && ix->bdb) return fail(BIGSI_ERR_STATE, "this index serves its rows from a BerkeleyDB file (bigsi_cpu_open_bdb): read-only, search / lookup / get_rows / presence only");
     if (!ix || (n && !blooms)) return fail(BIGSI_ERR_INVALID, "NULL argument");
     if (col0 > ix->n_cols) return fail(BIGSI_ERR_RANGE, "col0 %llu beyond num_cols %llu", (unsigned long long)col0, (unsigned long long)ix->n_cols);
     if (col0 + n > ix->cap_cols) return fail(BIGSI_ERR_CAPACITY, "columns [%llu, %llu) exceed col_capacity %llu", (unsigned long long)col0, (unsigned long long)(col0 + n), (unsigned long long)ix->cap_cols);
@@ -461,6 +556,7 @@ int bigsi_cpu_insert_columns(bigsi_cpu_index *ix, uint64_t col0, uint64_t n, con
 
 int bigsi_cpu_get_column(bigsi_cpu_index *ix, uint64_t col, uint8_t *out)
 {
+    if (ix && ix->bdb) return fail(BIGSI_ERR_STATE, "this index serves its rows from a BerkeleyDB file (bigsi_cpu_open_bdb): read-only, search / lookup / get_rows / presence only");
     if (!ix || !out) return fail(BIGSI_ERR_INVALID, "NULL argument");
     if (col >= ix->n_cols) return fail(BIGSI_ERR_RANGE, "column %llu out of range", (unsigned long long)col);
     memset(out, 0, ceil_div(ix->m, 8));
@@ -471,6 +567,7 @@ int bigsi_cpu_get_column(bigsi_cpu_index *ix, uint64_t col, uint8_t *out)
 
 int bigsi_cpu_insert_kmers(bigsi_cpu_index *ix, uint64_t col, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k)
 {
+    if (ix && ix->bdb) return fail(BIGSI_ERR_STATE, "this index serves its rows from a BerkeleyDB file (bigsi_cpu_open_bdb): read-only, search / lookup / get_rows / presence only");
     if (!ix) return fail(BIGSI_ERR_INVALID, "NULL index");
     if (n_seqs == 0) return BIGSI_OK;
     TRY(check_seqs(seqs, offsets, n_seqs, k));
@@ -491,6 +588,7 @@ int bigsi_cpu_insert_kmers(bigsi_cpu_index *ix, uint64_t col, const char *seqs, 
 
 int bigsi_cpu_fill_synthetic(bigsi_cpu_index *ix, uint64_t seed, uint64_t shard, uint32_t and_draws)
 {
+    if (ix && ix->bdb) return fail(BIGSI_ERR_STATE, "this index serves its rows from a BerkeleyDB file (bigsi_cpu_open_bdb): read-only, search / lookup / get_rows / presence only");
     if (!ix) return fail(BIGSI_ERR_INVALID, "NULL index");
     const uint64_t base = mix64(seed + shard * 0x632BE59BD9B4E019ull), words = ix->stride / 8;
     for (uint64_t r = 0; r < ix->m; r++) {
@@ -530,13 +628,14 @@ int bigsi_cpu_lookup(bigsi_cpu_index *ix, const char *kmers, uint32_t k, uint64_
     const uint64_t rb = ix->rb();
     std::string canon;
     std::vector<uint64_t> r(ix->h);
+    std::vector<uint8_t> tmp, page;
     for (uint64_t i = 0; i < u; i++) {
         canonical(kmers + i * k, k, canon);
         rows_of(canon, ix->h, ix->m, r.data());
         uint8_t *o = out_rows + i * rb;
-        memcpy(o, ix->row(r[0]), rb);
+        memcpy(o, ix->fetch(r[0], rb, tmp, page), rb);
         for (uint32_t t = 1; t < ix->h; t++) {
-            const uint8_t *x = ix->row(r[t]);
+            const uint8_t *x = ix->fetch(r[t], rb, tmp, page);
             for (uint64_t b = 0; b < rb; b++) o[b] &= x[b];
         }
     }
@@ -552,6 +651,7 @@ int bigsi_cpu_search_stream(bigsi_cpu_index *ix, const char *seqs, const uint64_
     TRY(check_seqs(seqs, offsets, n_seqs, k));
     if (!(threshold <= 1.0)) return fail(BIGSI_ERR_INVALID, "threshold must be <= 1 (bigsi/graph/bigsi.py:176), got %g", threshold);
     if (ix->n_cols == 0) return fail(BIGSI_ERR_STATE, "index has no columns");
+    if (ix->bdb && (flags & BIGSI_CPU_WORD_PARALLEL)) return fail(BIGSI_ERR_STATE, "BIGSI_CPU_WORD_PARALLEL works on rows resident in RAM, not on a BerkeleyDB-backed index");
     Hits hits{hit_offsets, colours, counts, hit_capacity};
     QueryKmers q;
     for (uint64_t i = 0; i < n_seqs; i++) {
@@ -587,13 +687,14 @@ int bigsi_cpu_presence(bigsi_cpu_index *ix, const char *seq, uint64_t len, uint3
     const uint64_t n = len - k + 1;
     std::string canon;
     std::vector<uint64_t> r(ix->h);
+    std::vector<uint8_t> tmp, page;
     for (uint64_t i = 0; i < n; i++) {
         canonical(seq + i, k, canon);
         rows_of(canon, ix->h, ix->m, r.data());
         for (uint32_t j = 0; j < n_colours; j++) {
             const uint32_t c = colours[j];
             bool present = true;
-            for (uint32_t t = 0; t < ix->h && present; t++) present = (ix->row(r[t])[c >> 3] & (0x80u >> (c & 7))) != 0;
+            for (uint32_t t = 0; t < ix->h && present; t++) present = (ix->fetch(r[t], ix->rb(), tmp, page)[c >> 3] & (0x80u >> (c & 7))) != 0;
             out[(uint64_t)j * n + i] = present ? '1' : '0';
         }
     }

@@ -557,156 +557,8 @@ int bigsi_file_io(int fd, bool write, uint8_t *buf, uint64_t off, uint64_t len, 
     for (auto &th : pool) th.join();
     return err.load();
 }
-// ---- BigsiBdb (bigsi_internal.hpp): BerkeleyDB hash files without libdb
-static const uint32_t kBdbHashMagic = 0x061561;
-enum { kBdbPageOverflow = 7, kBdbPageHashMeta = 8, kBdbPageHash = 13, kBdbPageHashUnsorted = 2, kBdbHdr = 26, kBdbKeyData = 1, kBdbOffPage = 3 };
-
-bool BigsiBdb::is_bdb(int fd)
-{
-    uint8_t head[32];
-    if (pread(fd, head, sizeof head, 0) != (ssize_t)sizeof head) return false;
-    uint32_t magic;
-    memcpy(&magic, head + 12, 4);
-    return (magic == kBdbHashMagic || __builtin_bswap32(magic) == kBdbHashMagic) && head[25] == kBdbPageHashMeta;
-}
-
-int BigsiBdb::open_fd(int fd_)
-{
-    fd = fd_;
-    uint8_t head[72];
-    if (pread(fd, head, sizeof head, 0) != (ssize_t)sizeof head) return fail(BIGSI_ERR_INVALID, "too short for a BerkeleyDB file");
-    uint32_t magic;
-    memcpy(&magic, head + 12, 4);
-    swap = magic != kBdbHashMagic;
-    if (u32(head + 12) != kBdbHashMagic) return fail(BIGSI_ERR_INVALID, "not a BerkeleyDB hash file");
-    pagesize = u32(head + 20);
-    if (head[24] != 0) return fail(BIGSI_ERR_INVALID, "encrypted BerkeleyDB files are not supported");
-    if (pagesize < 512 || pagesize > 65536 || (pagesize & (pagesize - 1))) return fail(BIGSI_ERR_INVALID, "BerkeleyDB page size %u", pagesize);
-    struct stat sb;
-    if (fstat(fd, &sb) != 0) return fail(BIGSI_ERR_INVALID, "fstat: %s", strerror(errno));
-    n_pages = (uint64_t)sb.st_size / pagesize;
-    return BIGSI_OK;
-}
-
-template <typename F> int BigsiBdb::scan(unsigned threads, F on_item) const
-{
-    const uint64_t pages_per_read = std::max<uint64_t>(1, (4ull << 20) / pagesize);
-    const uint64_t n_blocks = ceil_div(n_pages, pages_per_read);
-    threads = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(threads, n_blocks));
-    std::atomic<uint64_t> next{0};
-    std::atomic<int> err{0};
-    auto work = [&](unsigned tid) {
-        std::vector<uint8_t> buf(pages_per_read * pagesize);
-        for (;;) {
-            const uint64_t b = next.fetch_add(1);
-            if (b >= n_blocks || err.load()) return;
-            const uint64_t p0 = b * pages_per_read, np = std::min(pages_per_read, n_pages - p0);
-            uint64_t got = 0;
-            while (got < np * pagesize) {
-                const ssize_t r = pread(fd, buf.data() + got, (size_t)(np * pagesize - got), (off_t)(p0 * pagesize + got));
-                if (r < 0) { if (errno == EINTR) continue; err.store(errno); return; }
-                if (r == 0) { err.store(ENODATA); return; }
-                got += (uint64_t)r;
-            }
-            for (uint64_t i = 0; i < np; i++) {
-                const uint64_t pgno = p0 + i;
-                if (pgno == 0) continue;
-                const uint8_t *p = buf.data() + i * pagesize;
-                if (p[25] != kBdbPageHash && p[25] != kBdbPageHashUnsorted) continue;
-                const uint32_t n = u16(p + 20);
-                if (n == 0 || kBdbHdr + 2ull * n > pagesize) continue;
-                uint32_t end = pagesize;
-                for (uint32_t it = 0; it + 1 < n; it += 2) {
-                    const uint32_t ks = u16(p + kBdbHdr + 2 * it), vs = u16(p + kBdbHdr + 2 * (it + 1));
-                    const uint32_t kend = end, vend = ks;
-                    end = vs;
-                    if (ks >= kend || vs >= vend || kend > pagesize) { err.store(EILSEQ); return; }
-                    if (p[ks] != kBdbKeyData) continue;               // an overflow key (longer than a page) is no index record
-                    Loc l;
-                    if (p[vs] == kBdbKeyData) { l.kind = 1; l.at = pgno * pagesize + vs + 1; l.len = vend - vs - 1; }
-                    else if (p[vs] == kBdbOffPage) { if (vs + 12 > vend) { err.store(EILSEQ); return; } l.kind = 3; l.at = u32(p + vs + 4); l.len = u32(p + vs + 8); }
-                    else { err.store(ENOTSUP); return; }            // duplicate sets do not occur in BIGSI stores
-                    on_item(tid, p + ks + 1, kend - ks - 1, l);
-                }
-            }
-        }
-    };
-    if (threads == 1) work(0);
-    else {
-        std::vector<std::thread> pool;
-        for (unsigned t = 0; t < threads; t++) pool.emplace_back(work, t);
-        for (auto &th : pool) th.join();
-    }
-    const int e = err.load();
-    if (e) return fail(BIGSI_ERR_INVALID, "BerkeleyDB file: %s", e == EILSEQ ? "corrupt hash page" : e == ENOTSUP ? "duplicate items are not supported" : e == ENODATA ? "file shorter than its page count" : strerror(e));
-    return BIGSI_OK;
-}
-
-int BigsiBdb::read_value(const Loc &l, uint8_t *dst, uint32_t want, std::vector<uint8_t> &page) const
-{
-    want = std::min(want, l.len);
-    if (l.kind == 1) {
-        uint32_t got = 0;
-        while (got < want) {
-            const ssize_t r = pread(fd, dst + got, want - got, (off_t)(l.at + got));
-            if (r < 0) { if (errno == EINTR) continue; return errno; }
-            if (r == 0) return ENODATA;
-            got += (uint32_t)r;
-        }
-        return 0;
-    }
-    // an overflow chain: every page carries hf_offset (bytes 22-23) bytes after the header, next_pgno (bytes 16-19) links the chain
-    // libdb allocates the pages of a chain one after the other when it writes a large value into a growing file: a window of up to
-    // 16 pages is read at once and walked for as long as next_pgno is the page that follows (one system call per 64 KB instead of one
-    // per 4 KB page); a chain that jumps simply starts a new window
-    const uint32_t kWindow = 16;
-    page.resize((size_t)kWindow * pagesize);
-    uint64_t pgno = l.at;
-    uint32_t got = 0;
-    while (got < want) {
-        if (pgno == 0 || pgno >= n_pages) return EILSEQ;
-        const uint32_t per_page = pagesize - kBdbHdr;
-        const uint64_t pages_left = ceil_div(want - got, per_page);
-        const uint32_t win = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(kWindow, pages_left), n_pages - pgno);
-        // (of the last page only as much as is needed)
-        const uint64_t need = (uint64_t)(win - 1) * pagesize + std::min<uint64_t>(pagesize, kBdbHdr + ((uint64_t)(want - got) - std::min<uint64_t>(want - got, (uint64_t)(win - 1) * per_page)));
-        uint64_t have = 0;
-        while (have < need) {
-            const ssize_t r = pread(fd, page.data() + have, (size_t)(need - have), (off_t)(pgno * pagesize + have));
-            if (r < 0) { if (errno == EINTR) continue; return errno; }
-            if (r == 0) return ENODATA;
-            have += (uint64_t)r;
-        }
-        for (uint32_t i = 0; i < win && got < want; i++) {
-            const uint8_t *pg = page.data() + (size_t)i * pagesize;
-            if (pg[25] != kBdbPageOverflow) return EILSEQ;
-            const uint32_t used = std::min<uint32_t>(u16(pg + 22), per_page), take = std::min(used, want - got);
-            if (take == 0) return EILSEQ;
-            if ((uint64_t)i * pagesize + kBdbHdr + take > need) { pgno += i; goto next_window; }      // (a short page inside the window: the tail was not read)
-            memcpy(dst + got, pg + kBdbHdr, take);
-            got += take;
-            const uint64_t nxt = u32(pg + 16);
-            if (got < want && nxt != pgno + i + 1) { pgno = nxt; goto next_window; }
-            if (i + 1 == win) pgno = nxt;
-        }
-    next_window:;
-    }
-    return 0;
-}
-
-// "<digits>:bitarray" -> row id (bigsi/storage/base.py:29-36); false for any other key
-static bool bdb_row_key(const uint8_t *key, uint32_t len, uint64_t *row)
-{
-    static const char tail[] = ":bitarray";
-    if (len < 10 || len > 29 || memcmp(key + len - 9, tail, 9) != 0) return false;
-    uint64_t r = 0;
-    for (uint32_t i = 0; i + 9 < len; i++) {
-        if (key[i] < '0' || key[i] > '9') return false;
-        r = r * 10 + (key[i] - '0');
-    }
-    *row = r;
-    return true;
-}
+// ---- BerkeleyDB hash files: csrc/bigsi_bdb.hpp (shared with the CPU twin)
+static inline bool bdb_row_key(const uint8_t *key, uint32_t len, uint64_t *row) { return bigsi_bdb_row_key(key, len, row); }
 
 // bigsi_hip_bdb_small_records meets every row record on its way; an import calls bigsi_hip_load_rows_file on the same file next,
 // which would scan it again: the row locations of the LAST file scanned are kept (one entry, identified by device / inode / size /
@@ -729,14 +581,13 @@ extern "C" int bigsi_hip_bdb_small_records(const char *path, uint8_t *out, uint6
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return fail(BIGSI_ERR_INVALID, "%s: %s", path, strerror(errno));
     BigsiBdb db;
-    int rc = db.open_fd(fd);
+    int rc = db.open_fd(fd) ? fail(BIGSI_ERR_INVALID, "%s: %s", path, db.error.c_str()) : BIGSI_OK;
     struct Small { std::string key; BigsiBdb::Loc loc; };
     std::vector<Small> small;
     std::mutex mu;
     std::atomic<uint64_t> rows{0}, widest{0};
     std::vector<std::vector<std::pair<uint64_t, BigsiBdb::Loc>>> found(threads);      // row locations, per scanning thread
-    if (rc == BIGSI_OK)
-        rc = db.scan(threads, [&](unsigned tid, const uint8_t *key, uint32_t klen, const BigsiBdb::Loc &l) {
+    if (rc == BIGSI_OK && db.scan(threads, [&](unsigned tid, const uint8_t *key, uint32_t klen, const BigsiBdb::Loc &l) {
             uint64_t r;
             if (bdb_row_key(key, klen, &r)) {
                 rows++;
@@ -747,7 +598,8 @@ extern "C" int bigsi_hip_bdb_small_records(const char *path, uint8_t *out, uint6
             }
             std::lock_guard<std::mutex> g(mu);
             small.push_back(Small{std::string(reinterpret_cast<const char *>(key), klen), l});
-        });
+        }))
+        rc = fail(BIGSI_ERR_INVALID, "%s: %s", path, db.error.c_str());
     if (rc == BIGSI_OK) {
         struct stat sb;
         std::lock_guard<std::mutex> g(g_bdb_cache.mu);
@@ -800,7 +652,7 @@ int BigsiRowsFile::open_(const char *path, bool save, uint64_t file_offset_, uin
             // gathers rows from wherever they are (inline, or an overflow chain of pages)
             bdb = true;
             bdb_row0 = row0;
-            int rc = db.open_fd(fd);
+            int rc = db.open_fd(fd) ? fail(BIGSI_ERR_INVALID, "%s", db.error.c_str()) : BIGSI_OK;
             if (rc == BIGSI_OK) {
                 loc.assign(n_rows, BigsiBdb::Loc{});
                 bool cached = false;
@@ -816,11 +668,11 @@ int BigsiRowsFile::open_(const char *path, bool save, uint64_t file_offset_, uin
                         if (row0 == 0 && n_rows >= g_bdb_cache.rows.size()) { g_bdb_cache.valid = false; std::vector<std::pair<uint64_t, BigsiBdb::Loc>>().swap(g_bdb_cache.rows); }      // consumed
                     }
                 }
-                if (!cached)
-                    rc = db.scan(threads, [&](unsigned, const uint8_t *key, uint32_t klen, const BigsiBdb::Loc &l) {
+                if (!cached && db.scan(threads, [&](unsigned, const uint8_t *key, uint32_t klen, const BigsiBdb::Loc &l) {
                         uint64_t r;
                         if (bdb_row_key(key, klen, &r) && r >= row0 && r - row0 < n_rows) loc[r - row0] = l;      // (one writer per row: a key occurs once)
-                    });
+                    }))
+                    rc = fail(BIGSI_ERR_INVALID, "%s", db.error.c_str());
             }
             if (rc != BIGSI_OK) { char keep[512]; snprintf(keep, sizeof keep, "%s", bigsi_hip_last_error()); close_(); return fail(rc, "%s: %s", path, keep); }
         }

@@ -300,31 +300,7 @@ constexpr uint64_t kBigsiIoChunkBytes = 256ull << 20;      // one pinned buffer 
 // (pwrite or mmap alike) and 63 GB/s into 16 files (scripts/probe/tmpfs_write_probe.py, mmap_write_probe.cpp) -- so a save that is
 // to run at the PCIe rate needs several inodes.  Stripe s (rows [s * S, (s + 1) * S) of the range) lives in part s % P at
 // row offset (s / P) * S; `layout` in the directory records P, S, row_bytes and the row count, and a load reads it back.
-// A BerkeleyDB hash file (the reference's default store: db.DB().open(filename, None, db.DB_HASH, ...), bigsi/storage/
-// berkeleydb.py:12-19), read without libdb: layout per Berkeley DB's public db_page.h (hash versions 7-10) -- a 26-byte page header,
-// item offsets growing up from it, items growing down from the page end, item type H_KEYDATA (1) = inline bytes, H_OFFPAGE (3) =
-// {first page, length} of an overflow chain (every row of an index with more than a few thousand samples).  Every key / data
-// pair lives on exactly one hash page, so one scan of all pages finds each record once (bigsi_amd/bdb.py is the same reader in
-// Python and the test oracle of this one).
-struct BigsiBdb {
-    struct Loc {               // where a record's value is
-        uint64_t at = 0;       // inline: byte offset in the file; overflow: first page of the chain
-        uint32_t len = 0;
-        uint8_t kind = 0;      // 0 absent, 1 inline, 3 overflow chain
-    };
-    int fd = -1;
-    bool swap = false;         // the file's byte order is not the host's
-    uint32_t pagesize = 0;
-    uint64_t n_pages = 0;
-    static bool is_bdb(int fd);
-    int open_fd(int fd_);                                                     // BIGSI_OK or an error (message set)
-    // one pass over all hash pages with `threads` threads; on_item(key, key_len, loc) for every record whose key is inline
-    // (overflow keys -- longer than a page -- are no index records and are skipped)
-    template <typename F> int scan(unsigned threads, F on_item) const;
-    int read_value(const Loc &l, uint8_t *dst, uint32_t want, std::vector<uint8_t> &page) const;      // first `want` bytes; 0 or errno
-    uint16_t u16(const uint8_t *p) const { uint16_t v; memcpy(&v, p, 2); return swap ? (uint16_t)((v >> 8) | (v << 8)) : v; }
-    uint32_t u32(const uint8_t *p) const { uint32_t v; memcpy(&v, p, 4); return swap ? __builtin_bswap32(v) : v; }
-};
+#include "bigsi_bdb.hpp"      // BigsiBdb: BerkeleyDB hash files without libdb (shared with libbigsi_cpu.so)
 
 struct BigsiRowsFile {
     bool striped = false;

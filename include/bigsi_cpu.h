@@ -31,6 +31,12 @@ const char *bigsi_cpu_last_error(void);
 int bigsi_cpu_device_count(int *out); /* always 1: the host */
 int bigsi_cpu_open(uint64_t num_rows, uint64_t num_cols, uint64_t col_capacity, uint32_t num_hashes, int device, bigsi_cpu_index **out);
 int bigsi_cpu_close(bigsi_cpu_index *ix);
+/* An index whose rows STAY in the reference's own store -- a BerkeleyDB hash file (bigsi/storage/berkeleydb.py:6-19) with the
+ * "<row>:bitarray" records and index integers of a v0.3 index (bigsi/storage/base.py:29-36): every row a search needs is read from
+ * the file when it is needed (an overflow chain of pages for wide rows), as the reference's `storage[key]` does; a table built by one
+ * scan of the hash pages stands in for libdb's bucket lookup (no libdb on these hosts).  Read-only: reference-shaped search_batch /
+ * search_stream, lookup, get_rows, presence.  What bench.py's cpu_baseline reports as its BerkeleyDB-file variant. */
+int bigsi_cpu_open_bdb(const char *path, uint32_t threads, bigsi_cpu_index **out);
 int bigsi_cpu_get_info(const bigsi_cpu_index *ix, bigsi_hip_info *out);
 int bigsi_cpu_set_num_cols(bigsi_cpu_index *ix, uint64_t num_cols);
 int bigsi_cpu_set_num_hashes(bigsi_cpu_index *ix, uint32_t num_hashes);

@@ -60,6 +60,7 @@ def main():
     p.add_argument("--seconds", type=float, default=3.0)
     p.add_argument("--threads", type=int, default=0)
     p.add_argument("--pool-runs", type=int, default=2)
+    p.add_argument("--bdb", type=int, default=1, help="also time the searches with the rows served from a BerkeleyDB hash file of the same index (0 = skip)")
     a = p.parse_args()
     if a.threads <= 0:
         a.threads = max(1, (os.cpu_count() or 2) // 2)
@@ -84,7 +85,53 @@ def main():
     with mp.get_context("fork").Pool(a.threads) as pool:     # the "best CPU" line: word-parallel mode on every physical core
         res = pool.map(_work, [(w, a.seconds, 1 << 16) for w in range(a.threads)])
         wp_pool = sum(r[0] for r in res) / max(r[1] for r in res)
-    print(json.dumps({"one_core": {"lookups": one_done, "seconds": one_t, "rate": one_done / one_t},
+    # the same searches with the rows served from a BerkeleyDB hash FILE -- the reference's own store (bigsi/storage/berkeleydb.py:6-19),
+    # written here by libdb itself (dbm.ndbm) into tmpfs, read by the twin's own page walk (no bsddb3 / libdb headers on these hosts:
+    # a table from one scan of the hash pages stands in for libdb's bucket lookup): bigsi_cpu_open_bdb
+    bdb = None
+    if a.bdb:
+        try:
+            import dbm.ndbm as ndbm
+            import shutil
+            import tempfile
+            if getattr(ndbm, "library", "") == "Berkeley DB":
+                d = tempfile.mkdtemp(prefix="bigsi_cpu_bdb_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+                try:
+                    t0 = time.time()
+                    rb = (a.cols + 7) // 8
+                    db = ndbm.open(os.path.join(d, "store"), "n")
+                    for key, v in (("number_of_rows:int", a.rows), ("number_of_cols:int", a.cols), ("ksi:bloomfilter_size:int", a.rows), ("ksi:num_hashes:int", a.hashes)):
+                        db[key] = str(v)
+                    step = max(1, (64 << 20) // rb)
+                    for r0 in range(0, a.rows, step):
+                        ids = np.arange(r0, min(a.rows, r0 + step), dtype=np.uint64)
+                        blk = np.zeros((ids.size, rb), np.uint8)
+                        assert L.bigsi_cpu_get_rows(ix, ptr(ids), C.c_uint64(ids.size), ptr(blk), C.c_uint64(rb)) == 0
+                        for j, r in enumerate(ids.tolist()):
+                            db["%d:bitarray" % r] = blk[j].tobytes()
+                    db.close()
+                    write_s = time.time() - t0
+                    fn = os.path.join(d, "store.db")
+                    bix = C.c_void_p()
+                    t0 = time.time()
+                    assert L.bigsi_cpu_open_bdb(fn.encode(), C.c_uint32(0), C.byref(bix)) == 0, L.bigsi_cpu_last_error()
+                    open_s = time.time() - t0
+                    ram_ix = _T["ix"]
+                    _T["ix"] = bix
+                    b_done, b_t = _work((0, max(a.seconds / 2, 1.0), 0))
+                    with mp.get_context("fork").Pool(a.threads) as pool:
+                        res = pool.map(_work, [(w, max(a.seconds / 2, 1.0), 0) for w in range(a.threads)])
+                        b_pool = sum(r[0] for r in res) / max(r[1] for r in res)
+                    _T["ix"] = ram_ix
+                    L.bigsi_cpu_close(bix)
+                    bdb = {"one_core": {"lookups": b_done, "seconds": b_t, "rate": b_done / b_t}, "pool": {"threads": a.threads, "rate": b_pool},
+                           "file_gb": os.path.getsize(fn) / 1e9, "write_seconds": write_s, "open_seconds": open_s, "dir": d,
+                           "what": "rows read from a BerkeleyDB hash file (written by libdb through dbm.ndbm into tmpfs; read by the twin's page walk: bigsi_cpu_open_bdb)"}
+                finally:
+                    shutil.rmtree(d, ignore_errors=True)
+        except ImportError:
+            pass
+    print(json.dumps({"one_core": {"lookups": one_done, "seconds": one_t, "rate": one_done / one_t}, "bdb_file": bdb,
                       "word_parallel_pool": {"threads": a.threads, "rate": wp_pool},
                       "word_parallel_one_core": {"lookups": wp_done, "seconds": wp_t, "rate": wp_done / wp_t},
                       "pool": {"threads": a.threads, "seconds": a.seconds, "rates": rates, "rate_median": float(np.median(rates)), "rate_best": max(rates)},

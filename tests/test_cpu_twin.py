@@ -89,8 +89,8 @@ def test_twin_exports_the_core_layer_with_the_hip_signatures(cpu):
     assert len(c) >= 23
     for name, params in c.items():
         assert hasattr(cpu, "bigsi_cpu_" + name), name
-        if name == "presence":          # the HIP library offers this per batch (bigsi_hip_batch_presence)
-            continue
+        if name in ("presence", "open_bdb"):          # the HIP library offers presence per batch (bigsi_hip_batch_presence); open_bdb: rows served from the
+            continue                                  # reference's own store file -- the GPU library LOADS such a file instead (bigsi_hip_load_rows_file)
         assert name in h, name
         assert params.replace("bigsi_cpu_index", "bigsi_hip_index") == h[name], (name, params, h[name])
 
@@ -210,6 +210,64 @@ def test_twin_g7_random_index_rows_lookups_searches_presence(cpu, flags):
                 ix.ok(cpu.bigsi_cpu_presence(ix.ix, queries[q].encode(), C.c_uint64(len(queries[q])), C.c_uint32(k), ptr(cols), C.c_uint32(cols.size), ptr(out)))
                 assert [bytes(r).decode() for r in out] == [w["kmer-presence"] for w in want]
     ix.close()
+
+
+def test_twin_over_a_berkeleydb_file_answers_like_the_twin_in_ram(cpu, tmp_path):
+    """bigsi_cpu_open_bdb: the G7 index written into a BerkeleyDB hash file by libdb itself (dbm.ndbm), wide enough rows for overflow
+    chains, opened WITHOUT loading it; searches, lookups, get_rows and presence strings read their rows from the file and equal the
+    reference's golden answers; writes and the word-parallel mode are refused."""
+    ndbm = pytest.importorskip("dbm.ndbm")
+    if getattr(ndbm, "library", "") != "Berkeley DB":
+        pytest.skip("dbm.ndbm is not backed by Berkeley DB here")
+    g = load_golden("g7_random.json")
+    z = np.load(os.path.join(GOLDEN, "g7_random.npz"))
+    k, m, h, n = g["k"], g["m"], g["h"], g["n_cols"]
+    rb = (n + 7) // 8
+    db = ndbm.open(str(tmp_path / "g7"), "n")
+    for key, v in (("number_of_rows:int", m), ("number_of_cols:int", n), ("ksi:bloomfilter_size:int", m), ("ksi:num_hashes:int", h)):
+        db[key] = str(v)
+    db["metadata:0:string"] = "s0"
+    for r in range(m):
+        db["%d:bitarray" % r] = z["rows"][r].tobytes() if r % 7 else z["rows"][r].tobytes() + b"\0" * 5000      # some records long enough for overflow chains
+    db.close()
+    ix = Index.__new__(Index)
+    ix.L, ix.ix, ix.m, ix.h = cpu, C.c_void_p(), m, h
+    assert cpu.bigsi_cpu_open_bdb(str(tmp_path / "g7.db").encode(), C.c_uint32(2), C.byref(ix.ix)) == 0, cpu.bigsi_cpu_last_error()
+    assert np.array_equal(ix.rows(rb), z["rows"])
+    for rec in g["lookups"][:6]:
+        kmers = sorted(rec["lookup"])
+        out = np.zeros((len(kmers), rb), np.uint8)
+        ix.ok(cpu.bigsi_cpu_lookup(ix.ix, "".join(kmers).encode(), C.c_uint32(k), C.c_uint64(len(kmers)), ptr(out)))
+        assert {km: bytes(r).hex() for km, r in zip(kmers, out)} == rec["lookup"]
+    queries = g["queries"]
+    checked = 0
+    for thr in sorted({s["threshold"] for s in g["searches"]}):
+        nk, nu, mk, ho, col, cnt = ix.search(queries, k, float(thr), 0, stream=True)
+        for s in g["searches"]:
+            if s["threshold"] != thr or "results" not in s["out"]:
+                continue
+            q = s["q"]
+            got = list(zip(col[int(ho[q]):int(ho[q + 1])].tolist(), cnt[int(ho[q]):int(ho[q + 1])].tolist()))
+            if thr != 1.0:
+                got.sort(key=lambda x: -x[1])
+            want = s["out"]["results"]
+            assert [(g["sample_names"][c], f) for c, f in got] == [(w["sample_name"], w["num_kmers_found"]) for w in want], (thr, q)
+            checked += 1
+            if s["score"] and want:
+                cols = np.array([g["sample_names"].index(w["sample_name"]) for w in want], np.uint32)
+                out = np.zeros((cols.size, int(nk[q])), np.uint8)
+                ix.ok(cpu.bigsi_cpu_presence(ix.ix, queries[q].encode(), C.c_uint64(len(queries[q])), C.c_uint32(k), ptr(cols), C.c_uint32(cols.size), ptr(out)))
+                assert [bytes(r).decode() for r in out] == [w["kmer-presence"] for w in want]
+    assert checked > 50
+    ids = np.zeros(1, np.uint64)
+    assert cpu.bigsi_cpu_set_rows(ix.ix, ptr(ids), C.c_uint64(1), ptr(np.zeros(rb, np.uint8)), C.c_uint64(rb)) == -6 and cpu.bigsi_cpu_clear(ix.ix) == -6
+    blob, off = pack(queries[:1])
+    nk1, ho1 = np.zeros(1, np.uint32), np.zeros(2, np.uint64)
+    assert cpu.bigsi_cpu_search_batch(ix.ix, blob, ptr(off), C.c_uint32(1), C.c_uint32(k), C.c_double(1.0), C.c_uint32(WORD_PARALLEL), ptr(nk1), ptr(nk1), None, ptr(ho1),
+                                      ptr(np.zeros(64, np.uint32)), ptr(np.zeros(64, np.uint32)), C.c_uint64(64)) == -6
+    ix.close()
+    bad = C.c_void_p()
+    assert cpu.bigsi_cpu_open_bdb(str(tmp_path / "missing.db").encode(), C.c_uint32(1), C.byref(bad)) == -1
 
 
 def test_twin_scores_equal_the_golden_scores(cpu):
