@@ -138,6 +138,8 @@ SIGNATURES = {
     "bigsi_hip_batch_run_sharded": (_i32, [_P, _dbl, _u32]),
     "bigsi_hip_group_open": (_i32, [_u64, _u64, _u64, _u32, C.POINTER(C.c_int), _i32, C.POINTER(_P)]),
     "bigsi_hip_group_close": (_i32, [_P]),
+    "bigsi_hip_group_export_ipc": (_i32, [_P, _P]),
+    "bigsi_hip_group_open_ipc": (_i32, [_P, _u64, _u64, _u64, _u32, C.POINTER(C.c_int), _i32, C.POINTER(_P)]),
     "bigsi_hip_group_load_rows_file": (_i32, [_P, C.c_char_p, _u64, _u64, _u64, _u64, _u32, C.POINTER(IoStats)]),
     "bigsi_hip_group_save_rows_file": (_i32, [_P, C.c_char_p, _u64, _u64, _u64, _u64, _u32, C.POINTER(IoStats)]),
     "bigsi_hip_group_get_info": (_i32, [_P, C.POINTER(GroupInfo)]),

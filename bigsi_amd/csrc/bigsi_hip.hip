@@ -382,9 +382,9 @@ extern "C" int bigsi_hip_set_num_hashes(bigsi_hip_index *ix, uint32_t num_hashes
 extern "C" int bigsi_hip_reserve_cols(bigsi_hip_index *ix, uint64_t col_capacity)
 {
     BIGSI_ENTER(ix);
-    TRY(bigsi_writable(ix));
     if (!ix) return fail(BIGSI_ERR_INVALID, "NULL index");
     if (col_capacity <= ix->cap_cols) return BIGSI_OK;
+    TRY(bigsi_writable(ix));          // (only a call that would really re-stride the matrix needs to own it)
     if (col_capacity > 0xFFFFFFFFull) return fail(BIGSI_ERR_INVALID, "col_capacity exceeds 2^32-1");
     if (ix->views.load() > 0) return fail(BIGSI_ERR_STATE, "bigsi_hip_reserve_cols: re-striding would move the matrix under %d open view(s)", ix->views.load());
     TRY(use_device(ix));

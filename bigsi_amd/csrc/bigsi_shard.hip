@@ -519,8 +519,32 @@ __global__ void k_add_counts(uint32_t *__restrict__ dst, const uint32_t *__restr
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) dst[i] += src[i];
 }
 
+static int group_open_impl(uint64_t num_rows, uint64_t num_cols, uint64_t col_capacity, uint32_t num_hashes, const int *device_ids, int n_dev,
+                           const uint8_t *ipc_handles, bigsi_hip_group **out);
+
 extern "C" int bigsi_hip_group_open(uint64_t num_rows, uint64_t num_cols, uint64_t col_capacity, uint32_t num_hashes,
                                     const int *device_ids, int n_dev, bigsi_hip_group **out)
+{
+    return group_open_impl(num_rows, num_cols, col_capacity, num_hashes, device_ids, n_dev, nullptr, out);
+}
+
+// A group onto matrices ANOTHER process holds resident (bigsi_hip_export_ipc / bigsi_hip_open_ipc, shard by shard): read-only, no copy.
+extern "C" int bigsi_hip_group_export_ipc(bigsi_hip_group *g, uint8_t *handles)
+{
+    if (!g || !handles) return fail(BIGSI_ERR_INVALID, "NULL argument");
+    for (uint32_t i = 0; i < g->n(); i++) TRY(bigsi_hip_export_ipc(g->ix[i], handles + (size_t)i * BIGSI_IPC_HANDLE_BYTES));
+    return BIGSI_OK;
+}
+
+extern "C" int bigsi_hip_group_open_ipc(const uint8_t *handles, uint64_t num_rows, uint64_t num_cols, uint64_t col_capacity, uint32_t num_hashes,
+                                        const int *device_ids, int n_dev, bigsi_hip_group **out)
+{
+    if (!handles) return fail(BIGSI_ERR_INVALID, "handles is NULL");
+    return group_open_impl(num_rows, num_cols, col_capacity, num_hashes, device_ids, n_dev, handles, out);
+}
+
+static int group_open_impl(uint64_t num_rows, uint64_t num_cols, uint64_t col_capacity, uint32_t num_hashes, const int *device_ids, int n_dev,
+                           const uint8_t *ipc_handles, bigsi_hip_group **out)
 {
     if (!out || !device_ids) return fail(BIGSI_ERR_INVALID, "NULL argument");
     *out = nullptr;
@@ -543,7 +567,8 @@ extern "C" int bigsi_hip_group_open(uint64_t num_rows, uint64_t num_cols, uint64
     int rc = BIGSI_OK;
     for (int i = 0; i < n_dev && rc == BIGSI_OK; i++) {
         bigsi_hip_index *ix = nullptr;
-        rc = bigsi_hip_open(num_rows, g->cols_of((uint32_t)i, num_cols), g->shard_cols, num_hashes, device_ids[i], &ix);
+        if (ipc_handles) rc = bigsi_hip_open_ipc(ipc_handles + (size_t)i * BIGSI_IPC_HANDLE_BYTES, num_rows, g->cols_of((uint32_t)i, num_cols), g->shard_cols, num_hashes, device_ids[i], &ix);
+        else rc = bigsi_hip_open(num_rows, g->cols_of((uint32_t)i, num_cols), g->shard_cols, num_hashes, device_ids[i], &ix);
         if (rc == BIGSI_OK) g->ix.push_back(ix);
     }
     for (int i = 0; i < n_dev && rc == BIGSI_OK; i++) {

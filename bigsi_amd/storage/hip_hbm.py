@@ -817,16 +817,15 @@ _ATTACH_FORMAT = "bigsi-hip-attach-1"
 def _export_attach(res, path):
     """The attach file (JSON): hipIpc handle of the matrix, geometry, the host-side records (index integers, sample metadata),
     which rows have been written.  Written to a temporary name and renamed: a reader never sees half a file."""
-    if res.is_group:
-        raise BigsiHipError(_lib.ERR_STATE, "a multi-GPU (devices=[...]) index cannot be exported for attach: attach to the shards' own processes")
     if res.attached:
         raise BigsiHipError(_lib.ERR_STATE, "an attached index cannot be re-exported (only its owner can)")
     if not res.ensure_open():
         raise BigsiHipError(_lib.ERR_STATE, "nothing resident to export")
-    handle = (_lib.C.c_uint8 * 64)()
-    check(_lib.lib().bigsi_hip_export_ipc(res.ix, handle))
     inf = res.info()
-    doc = {"format": _ATTACH_FORMAT, "handle": bytes(handle).hex(), "pid": os.getpid(), "device": res.device,
+    n_sh = int(inf.n_shards) if res.is_group else 1
+    handle = (_lib.C.c_uint8 * (64 * n_sh))()
+    check(res.fn("export_ipc")(res.ix, handle))          # (a group: one hipIpc handle per shard, in shard order)
+    doc = {"format": _ATTACH_FORMAT, "handle": bytes(handle).hex(), "pid": os.getpid(), "device": res.device, "devices": res.devices,
            "m": int(inf.num_rows), "num_cols": int(inf.num_cols), "col_capacity": int(inf.col_capacity), "num_hashes": int(inf.num_hashes),
            "kv": {k.decode("latin-1"): v.decode("latin-1") for k, v in res.kv.items()}, "uniform_len": res.uniform_len,
            "written": None if res.written.all() else np.packbits(res.written).tobytes().hex(),
@@ -855,12 +854,22 @@ def _attach(res, path):
         pass                                          # alive, another user's
     if int(doc["pid"]) == os.getpid():
         raise BigsiHipError(_lib.ERR_STATE, "%s was exported by this very process: use the resident index (same storage-config name)" % path)
-    if res.is_group:
-        raise BigsiHipError(_lib.ERR_STATE, "storage-config `attach` and `devices` exclude each other")
-    handle = (_lib.C.c_uint8 * 64).from_buffer_copy(bytes.fromhex(doc["handle"]))
+    raw = bytes.fromhex(doc["handle"])
+    handle = (_lib.C.c_uint8 * len(raw)).from_buffer_copy(raw)
     out = _lib.C.c_void_p()
     device = int(res.cfg.get("device", doc.get("device", 0)))
-    check(_lib.lib().bigsi_hip_open_ipc(handle, int(doc["m"]), int(doc["num_cols"]), int(doc["col_capacity"]), int(doc["num_hashes"]), device, _lib.C.byref(out)))
+    if doc.get("devices"):
+        # a multi-GPU index: one handle per shard; this process names its own devices (default: the owner's) in the same shard order
+        devs = [int(d) for d in (res.cfg.get("devices") or doc["devices"])]
+        if len(devs) * 64 != len(raw):
+            raise BigsiHipError(_lib.ERR_INVALID, "%s holds %d shard handle(s), storage-config `devices` names %d device(s)" % (path, len(raw) // 64, len(devs)))
+        res.devices = devs
+        arr = (_lib.C.c_int * len(devs))(*devs)
+        check(_lib.lib().bigsi_hip_group_open_ipc(handle, int(doc["m"]), int(doc["num_cols"]), int(doc["col_capacity"]), int(doc["num_hashes"]), arr, len(devs), _lib.C.byref(out)))
+    else:
+        if res.is_group:
+            raise BigsiHipError(_lib.ERR_STATE, "%s describes a single-GPU index; storage-config `devices` does not apply" % path)
+        check(_lib.lib().bigsi_hip_open_ipc(handle, int(doc["m"]), int(doc["num_cols"]), int(doc["col_capacity"]), int(doc["num_hashes"]), device, _lib.C.byref(out)))
     res.ix, res.m, res.device, res.attached = out, int(doc["m"]), device, True
     res.kv = {k.encode("latin-1"): v.encode("latin-1") for k, v in doc["kv"].items()}
     res.written = np.ones(res.m, dtype=bool) if not doc.get("written") else np.unpackbits(np.frombuffer(bytes.fromhex(doc["written"]), np.uint8))[: res.m].astype(bool)

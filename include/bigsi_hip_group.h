@@ -46,6 +46,12 @@ int bigsi_hip_group_insert_columns(bigsi_hip_group *g, uint64_t col0, uint64_t n
 int bigsi_hip_group_get_column(bigsi_hip_group *g, uint64_t col, uint8_t *out);
 int bigsi_hip_group_insert_kmers(bigsi_hip_group *g, uint64_t col, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k);
 int bigsi_hip_group_fill_synthetic(bigsi_hip_group *g, uint64_t seed, uint32_t and_draws); /* shard i = fill_synthetic(seed, i) */
+/* bigsi_hip_export_ipc / bigsi_hip_open_ipc for a group: n_shards handles of BIGSI_IPC_HANDLE_BYTES bytes each; the attaching process
+ * names its own devices (same shard order, same col_capacity / shard geometry as the owner: bigsi_hip_group_get_info there) and gets a
+ * read-only group with communicator, streams and workspaces of its own. */
+int bigsi_hip_group_export_ipc(bigsi_hip_group *g, uint8_t *handles /* n_shards x BIGSI_IPC_HANDLE_BYTES */);
+int bigsi_hip_group_open_ipc(const uint8_t *handles, uint64_t num_rows, uint64_t num_cols, uint64_t col_capacity, uint32_t num_hashes,
+                             const int *device_ids, int n_dev, bigsi_hip_group **out);
 /* bigsi_hip_load_rows_file / bigsi_hip_save_rows_file for a group (KmerSignatureIndex.create, bigsi/graph/index.py:27-40; the
  * store a BerkeleyDBStorage opens, bigsi/storage/berkeleydb.py:6-19): rows [row0, row0 + n_rows) as WHOLE rows of row_bytes bytes
  * each, in the reference's row format, at file_offset of `path`.  Shard i owns bytes [i * shard_cols / 8, +shard_cols / 8) of every

@@ -22,6 +22,12 @@ kmers = lambda s: [s[i:i + k] for i in range(len(s) - k + 1)]      # noqa: E731
 b = bigsi_amd.BIGSI.build(cfg, [bigsi_amd.BIGSI.bloom(cfg, kmers(a) + kmers(c)) for a, c in g["sample_seqs"]], g["sample_names"])
 b.storage.sync()                      # (writes the attach file: storage-config `export`)
 
+# the same G7 index spread over three shards of one process (a device group): exported shard by shard
+gcfg = {"storage-engine": "hip-hbm", "k": k, "m": m, "h": h,
+        "storage-config": {"name": "g7group", "devices": [0, 0, 0], "max_cols": len(g["sample_names"]), "export": os.path.join(out_dir, "g7group.attach")}}
+bg = bigsi_amd.BIGSI.build(gcfg, [bigsi_amd.BIGSI.bloom(cfg, kmers(a) + kmers(c)) for a, c in g["sample_seqs"]], g["sample_names"])
+bg.storage.sync()
+
 big = get_storage({"storage-engine": "hip-hbm", "k": 31, "m": big_rows, "h": 3,
                    "storage-config": {"name": "big", "max_cols": big_cols, "export": os.path.join(out_dir, "big.attach")}})
 big.delete_all()
@@ -46,4 +52,5 @@ for line in sys.stdin:
     elif cmd == "quit":
         break
 big.delete_all()
+bg.delete()
 b.delete()

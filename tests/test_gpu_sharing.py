@@ -122,6 +122,29 @@ def test_attached_bigsi_answers_golden_g7(owner):
     b.storage.delete_all()
 
 
+def test_attached_device_group_answers_golden_g7(owner):
+    """A multi-GPU index (here three shards of the owner process on one device) is exported shard by shard; this process attaches
+    to all of them (bigsi_hip_group_open_ipc) and the BIGSI object on top answers golden G7 -- exchange between the shards, scores
+    on the owning shard and all -- without a copy of its own; writes are refused."""
+    import bigsi_amd
+    from bigsi_amd import _lib
+    g = load_golden("g7_random.json")
+    k = g["k"]
+    b = bigsi_amd.BIGSI({"storage-engine": "hip-hbm", "k": k, "m": g["m"], "h": g["h"],
+                         "storage-config": {"name": "g7group-attached", "attach": os.path.join(owner["dir"], "g7group.attach")}})
+    res = b.storage.res
+    assert res.attached and res.is_group and int(res.info().n_shards) == 3 and b.num_samples == len(g["sample_names"])
+    for s in g["searches"]:
+        check_search(lambda: b.search(g["queries"][s["q"]], s["threshold"], s["score"]), s, "attached group q%d t=%r" % (s["q"], s["threshold"]))
+    multi = b.search_batch(g["queries"][:10], 0.4)
+    for qi in range(10):
+        assert multi[qi] == b.search(g["queries"][qi], 0.4)
+    with pytest.raises(_lib.BigsiHipError) as ei:
+        b.storage.insert_kmers(3, [g["queries"][0]], k)
+    assert ei.value.code == _lib.ERR_STATE
+    b.storage.delete_all()
+
+
 def test_stale_attach_file_falls_back_to_the_snapshot():
     """An attach file whose owner has exited is ignored: the index loads from its snapshot as if `attach` were not there."""
     import bigsi_amd
