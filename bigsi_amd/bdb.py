@@ -133,7 +133,7 @@ def small_records(path, threads=0):
     return out, int(rows.value), int(widest.value)
 
 
-def import_index(path, dst, block_bytes=64 << 20, native=True, threads=0):
+def import_index(path, dst, block_bytes=64 << 20, native=True, threads=0, timings=None):
     """Load a v0.3-format BIGSI BerkeleyDB store (keys "<row>:bitarray", "<name>:int", "<name>:string",
     bigsi/storage/base.py:29-36) into a hip-hbm storage.  Returns (num_rows, num_cols).
 
@@ -148,8 +148,12 @@ def import_index(path, dst, block_bytes=64 << 20, native=True, threads=0):
     row_key = re.compile(rb"^(\d+):bitarray$")
     dst.delete_all()
     if native and hasattr(dst, "res") and not isinstance(path, bytes):
+        import time
+
         from . import _lib
+        t0 = time.perf_counter()
         small, n_row_records, widest = small_records(path, threads)
+        t1 = time.perf_counter()
         try:
             m = int(small[b"number_of_rows:int"])
             n = int(small[b"number_of_cols:int"])
@@ -163,7 +167,11 @@ def import_index(path, dst, block_bytes=64 << 20, native=True, threads=0):
             dst.set_integer("number_of_cols", n)              # (opens the matrix at its width; the rows below are cut / zero-extended to rb bytes)
             res = dst.res
             res.ensure_open()
-            _lib.check(res.fn("load_rows_file")(res.ix, path.encode(), 0, 0, m, rb, int(threads), None))
+            t2 = time.perf_counter()
+            io = _lib.IoStats()
+            _lib.check(res.fn("load_rows_file")(res.ix, path.encode(), 0, 0, m, rb, int(threads), _lib.C.byref(io)))
+            if timings is not None:       # (scripts/import_bench.py: where an import's time goes)
+                timings.update(scan_s=t1 - t0, open_s=t2 - t1, load_s=time.perf_counter() - t2, load_file_s=io.file_seconds, threads=int(io.threads))
             # (pad bits of a row's last byte are taken as stored -- zero in anything bitarray.tobytes() wrote; the kernels mask
             # columns beyond number_of_cols out of every result anyway)
             res.written[:] = True

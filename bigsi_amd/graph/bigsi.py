@@ -332,9 +332,14 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
                 # the reference builds a 1-D matrix from a single row and then indexes it with two subscripts
                 raise IndexError("too many indices for array: array is 1-dimensional, but 2 were indexed")
             per_hit = np.repeat(num_kmers[:n_seqs].astype(np.int64), np.diff(off64[:n_seqs + 1]))
-            if deferred and not batch.group and int(((per_hit + 63) // 64 * 64).sum()) <= SCORE_SLICE_CHARS:
+            fits = int(((per_hit + 63) // 64 * 64).sum()) <= SCORE_SLICE_CHARS
+            if deferred and not batch.group and fits:
                 batch.score_hits_begin(off, colours, None if exact else counts, num_kmers)
                 scored = ("pending", per_hit)
+            elif _results is not None and fits and int(off[0]) == 0:
+                # K6's records and presence bits as arrays: _collect_end hands them to the C++ builder (bigsi_amd/_results.cpp:
+                # build_scored) instead of a tuple and a 22-key dict per hit made in Python
+                scored = ("arrays", batch.score_hits(off, colours, None if exact else counts, num_kmers), num_kmers)
             else:
                 scored = self._score_hits(batch, off, colours, None if exact else counts, num_kmers, n_seqs)
         return (batch, off64, colours, counts, nu, exact, scored), n_seqs
@@ -347,6 +352,14 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
         if isinstance(scored, tuple) and scored[0] == "pending":
             rec, bits, boff = batch.score_hits_end()
             scored = scored_rows(rec, bits, boff, scored[1], self.scorer.DB_SIZE)
+        elif isinstance(scored, tuple) and scored[0] == "arrays":
+            (rec, bits, boff), num_kmers = scored[1], scored[2]
+            total = int(off64[n_seqs])
+            names = self._names_of(colours[:total], exact)
+            if names is not None:
+                return list(native_result_lists(num_kmers[:n_seqs], nu[:n_seqs], off64[:n_seqs + 1], colours, counts, exact, names, (rec, bits, boff), self.scorer.DB_SIZE))
+            per_hit = np.repeat(num_kmers[:n_seqs].astype(np.int64), np.diff(off64[:n_seqs + 1]))
+            scored = scored_rows(rec, bits, boff, per_hit, self.scorer.DB_SIZE)          # (a colour without a name: the per-record loop raises the reference's KeyError in order)
         if _results is not None and scored is None:
             # unscored: the dicts straight from the arrays (bigsi_amd/_results.cpp), as search_stream builds them
             total = int(off64[n_seqs])

@@ -71,8 +71,11 @@ def main():
             for native in (True, False):
                 dst = get_storage({"storage-engine": "hip-hbm", "k": 31, "m": mb, "h": 3, "storage-config": {"name": "import_bench_bdb", "max_cols": a.cols}})
                 t0 = time.perf_counter()
-                bdb.import_index(fn, dst, native=native)
+                tm = {}
+                bdb.import_index(fn, dst, native=native, timings=tm)
                 dt = time.perf_counter() - t0
+                if native:
+                    out["bdb_native_phases_s"] = {k_: round(v_, 3) for k_, v_ in tm.items()}
                 got = np.asarray(dst.get_rows_packed(np.array([0, 1, mb - 1], np.uint64)))
                 assert got[0].tobytes()[:rb] == rows[0] and got[2].tobytes()[:rb] == rows[mb - 1]
                 out["bdb_native_GBps" if native else "bdb_python_GBps"] = round(mb * rb / dt / 1e9, 2)
