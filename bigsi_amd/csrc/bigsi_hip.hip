@@ -587,6 +587,9 @@ extern "C" int bigsi_hip_bdb_small_records(const char *path, uint8_t *out, uint6
     std::mutex mu;
     std::atomic<uint64_t> rows{0}, widest{0};
     std::vector<std::vector<std::pair<uint64_t, BigsiBdb::Loc>>> found(threads);      // row locations, per scanning thread
+    // (the scan is independent 4 MB reads + a few hundred bytes of parsing per page: it takes more threads than the file <-> HBM pipeline)
+    threads = std::max(threads, std::min(48u, std::max(1u, std::thread::hardware_concurrency() / 4)));
+    found.resize(threads);
     if (rc == BIGSI_OK && db.scan(threads, [&](unsigned tid, const uint8_t *key, uint32_t klen, const BigsiBdb::Loc &l) {
             uint64_t r;
             if (bdb_row_key(key, klen, &r)) {
@@ -668,7 +671,7 @@ int BigsiRowsFile::open_(const char *path, bool save, uint64_t file_offset_, uin
                         if (row0 == 0 && n_rows >= g_bdb_cache.rows.size()) { g_bdb_cache.valid = false; std::vector<std::pair<uint64_t, BigsiBdb::Loc>>().swap(g_bdb_cache.rows); }      // consumed
                     }
                 }
-                if (!cached && db.scan(threads, [&](unsigned, const uint8_t *key, uint32_t klen, const BigsiBdb::Loc &l) {
+                if (!cached && db.scan(std::max(threads, std::min(48u, std::max(1u, std::thread::hardware_concurrency() / 4))), [&](unsigned, const uint8_t *key, uint32_t klen, const BigsiBdb::Loc &l) {
                         uint64_t r;
                         if (bdb_row_key(key, klen, &r) && r >= row0 && r - row0 < n_rows) loc[r - row0] = l;      // (one writer per row: a key occurs once)
                     }))
