@@ -149,6 +149,36 @@ PyObject *build(PyObject *, PyObject *args)
 // build_scored(nu, off, cols, cnts, exact, names, keys, rec, bits, boff, trans, db_size_unused, lo, hi)
 //   rec: buffer of 64-byte records (HIT_SCORE_DTYPE), bits uint8[], boff uint64[hits + 1] (byte offsets, multiples of 8),
 //   trans: tuple of 4 float64 arrays over the hits
+// ---- values written straight into a freshly copied dict's entry table (CPython 3.10 only, verified before every use)
+// PyDict_Copy of the 22-key template clones its combined key table: entry i holds key i, in insertion order.  Replacing the 22 values
+// through PyDict_SetItem costs 22 hash-table lookups per hit (0.26 of the 0.70 us a scored dict takes); the values can instead be
+// stored into the entries directly -- what insertdict does once it has found the slot -- IF the object layout is the one this code
+// was written against.  That layout (Objects/dict-common.h of CPython 3.10: PyDictKeysObject {dk_refcnt, dk_size, dk_lookup,
+// dk_usable, dk_nentries, dk_indices[]}, entries {me_hash, me_key, me_value} behind dk_size one-byte indices) is not public, so:
+// compiled only for 3.10, enabled only when the running interpreter says 3.10, and before each dict is touched its table is CHECKED
+// read-only (combined table, 64 slots, 22 entries, entry i's key IS key i); anything unexpected -> the PyDict_SetItem route.
+#if PY_VERSION_HEX >= 0x030A0000 && PY_VERSION_HEX < 0x030B0000
+#define BIGSI_FAST_DICT 1
+struct KeyEntry310 { Py_hash_t me_hash; PyObject *me_key; PyObject *me_value; };
+struct Keys310 { Py_ssize_t dk_refcnt, dk_size; void *dk_lookup; Py_ssize_t dk_usable, dk_nentries; char dk_indices[1]; };
+bool g_fast_dict = true;           // _results.fast_dict(False) switches it off (A/B, tests)
+
+// the 22 value slots of `d` (a fresh PyDict_Copy of the template), or nullptr if the table is not what is expected
+inline KeyEntry310 *entries_of(PyObject *d, PyObject *const *k)
+{
+    PyDictObject *mp = reinterpret_cast<PyDictObject *>(d);
+    if (mp->ma_values != nullptr || mp->ma_used != 22) return nullptr;                    // a split table, or not our template
+    Keys310 *keys = reinterpret_cast<Keys310 *>(mp->ma_keys);
+    if (keys->dk_size != 64 || keys->dk_nentries != 22 || keys->dk_refcnt != 1) return nullptr;      // (22 entries need 64 slots: one-byte indices)
+    KeyEntry310 *e = reinterpret_cast<KeyEntry310 *>(keys->dk_indices + keys->dk_size);
+    for (int i = 0; i < 22; i++)
+        if (e[i].me_key != k[i] || e[i].me_value != Py_None) return nullptr;
+    return e;
+}
+#else
+#define BIGSI_FAST_DICT 0
+#endif
+
 struct IntCache {
     std::vector<PyObject *> v;
     ~IntCache() { /* objects are immortal for the life of the module */ }
@@ -236,6 +266,10 @@ PyObject *build_scored(PyObject *, PyObject *args)
     if (!out) { Py_DECREF(tmpl); return nullptr; }
     std::vector<int64_t> order;
     bool ok = true;
+#if BIGSI_FAST_DICT
+    static const bool is_310 = strncmp(Py_GetVersion(), "3.10.", 5) == 0;
+    const bool fast = g_fast_dict && is_310;
+#endif
     for (Py_ssize_t i = lo; i < hi && ok; i++) {
         const uint32_t u = p_nu[i];
         order.clear();
@@ -259,8 +293,18 @@ PyObject *build_scored(PyObject *, PyObject *args)
             PyObject *d = PyDict_Copy(tmpl);
             if (!d) { ok = false; break; }
             PyList_SET_ITEM(res, (Py_ssize_t)r, d);
+#if BIGSI_FAST_DICT
+            KeyEntry310 *slots = fast ? entries_of(d, k) : nullptr;
+#endif
             auto put = [&](int kk, PyObject *v) {      // steals v
                 if (!v) { ok = false; return; }
+#if BIGSI_FAST_DICT
+                if (slots) {                            // entry kk holds key kk and None: the value takes None's place
+                    slots[kk].me_value = v;
+                    Py_DECREF(Py_None);
+                    return;
+                }
+#endif
                 if (ok && PyDict_SetItem(d, k[kk], v) != 0) ok = false;
                 Py_DECREF(v);
             };
@@ -352,6 +396,19 @@ PyObject *pack_rows(PyObject *, PyObject *args)
     Py_RETURN_NONE;
 }
 
+// fast_dict(on) -> bool: switch the direct-store route of build_scored on / off (tests, A/B); returns whether it is compiled in and active
+PyObject *fast_dict(PyObject *, PyObject *args)
+{
+    int on = -1;
+    if (!PyArg_ParseTuple(args, "|p", &on)) return nullptr;
+#if BIGSI_FAST_DICT
+    if (on >= 0) g_fast_dict = on != 0;
+    return PyBool_FromLong(g_fast_dict && strncmp(Py_GetVersion(), "3.10.", 5) == 0);
+#else
+    Py_RETURN_FALSE;
+#endif
+}
+
 // ascii_str(n) -> (s, address): a new str of n ASCII characters whose body (n bytes at `address`) the caller fills before anything
 // reads s -- bigsi_hip_format_results writes the text of a bulk search straight into it (no bytes -> str copy of a few hundred MB)
 PyObject *ascii_str(PyObject *, PyObject *args)
@@ -366,6 +423,7 @@ PyObject *ascii_str(PyObject *, PyObject *args)
 
 PyMethodDef methods[] = {{"build", build, METH_VARARGS, "result dicts of the sequences [lo, hi) of a streaming search (see _results.cpp)"},
                          {"build_scored", build_scored, METH_VARARGS, "the same for score=True, from K6's records and presence bits"},
+                         {"fast_dict", fast_dict, METH_VARARGS, "fast_dict([on]) -> whether build_scored stores values straight into the copied dict's entries (CPython 3.10)"},
                          {"pack_rows", pack_rows, METH_VARARGS, "rows (list of bytes) -> uint8[n, rb] block, cut / zero-extended, threaded, without the GIL"},
                          {"ascii_str", ascii_str, METH_VARARGS, "(str of n ASCII characters to be filled, address of its body)"},
                          {nullptr, nullptr, 0, nullptr}};

@@ -708,7 +708,8 @@ int BigsiRowsFile::open_(const char *path, bool save, uint64_t file_offset_, uin
     for (uint64_t p = 0; p < parts; p++) {
         char name[32];
         snprintf(name, sizeof name, "part.%03llu", (unsigned long long)p);
-        const int f = open((dir + name).c_str(), save ? (O_WRONLY | O_CREAT) : O_RDONLY, 0644);
+        // (a part file of an earlier, longer save must not keep its tail: the parts of a save that starts at offset 0 are cut to size)
+        const int f = open((dir + name).c_str(), save ? (O_WRONLY | O_CREAT | (file_offset == 0 ? O_TRUNC : 0)) : O_RDONLY, 0644);
         if (f < 0) { const int e = errno; close_(); return fail(BIGSI_ERR_INVALID, "%s%s: %s", path, name, strerror(e)); }
         fds.push_back(f);
     }

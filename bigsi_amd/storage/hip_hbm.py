@@ -858,6 +858,25 @@ def _attach(res, path):
     handle = (_lib.C.c_uint8 * len(raw)).from_buffer_copy(raw)
     out = _lib.C.c_void_p()
     device = int(res.cfg.get("device", doc.get("device", 0)))
+    try:
+        _attach_open(res, path, doc, raw, handle, out, device)
+    except BigsiHipError as e:
+        if e.code != _lib.ERR_HIP:
+            raise
+        # the handle did not open -- typically a file whose owner died and whose pid now belongs to another process: as for a stale
+        # file, the index loads the usual way
+        import warnings
+        warnings.warn("%s: could not attach (%s); loading the index instead" % (path, e))
+        return False
+    res.ix, res.m, res.device, res.attached = out, int(doc["m"]), device, True
+    res.kv = {k.encode("latin-1"): v.encode("latin-1") for k, v in doc["kv"].items()}
+    res.written = np.ones(res.m, dtype=bool) if not doc.get("written") else np.unpackbits(np.frombuffer(bytes.fromhex(doc["written"]), np.uint8))[: res.m].astype(bool)
+    res.uniform_len = doc.get("uniform_len")
+    res.rowlen = np.frombuffer(bytes.fromhex(doc["rowlen"]), np.uint32).copy() if doc.get("rowlen") else None
+    return True
+
+
+def _attach_open(res, path, doc, raw, handle, out, device):
     if doc.get("devices"):
         # a multi-GPU index: one handle per shard; this process names its own devices (default: the owner's) in the same shard order
         devs = [int(d) for d in (res.cfg.get("devices") or doc["devices"])]
@@ -870,12 +889,6 @@ def _attach(res, path):
         if res.is_group:
             raise BigsiHipError(_lib.ERR_STATE, "%s describes a single-GPU index; storage-config `devices` does not apply" % path)
         check(_lib.lib().bigsi_hip_open_ipc(handle, int(doc["m"]), int(doc["num_cols"]), int(doc["col_capacity"]), int(doc["num_hashes"]), device, _lib.C.byref(out)))
-    res.ix, res.m, res.device, res.attached = out, int(doc["m"]), device, True
-    res.kv = {k.encode("latin-1"): v.encode("latin-1") for k, v in doc["kv"].items()}
-    res.written = np.ones(res.m, dtype=bool) if not doc.get("written") else np.unpackbits(np.frombuffer(bytes.fromhex(doc["written"]), np.uint8))[: res.m].astype(bool)
-    res.uniform_len = doc.get("uniform_len")
-    res.rowlen = np.frombuffer(bytes.fromhex(doc["rowlen"]), np.uint32).copy() if doc.get("rowlen") else None
-    return True
 
 
 def _save_snapshot(res, fn, threads=0):

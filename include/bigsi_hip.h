@@ -74,7 +74,9 @@ int bigsi_hip_close(bigsi_hip_index *ix); /* BaseStorage.close, bigsi/storage/ba
  * Attached handles and views are READ-ONLY (calls that write the matrix fail with BIGSI_ERR_STATE) and are closed with
  * bigsi_hip_close.  The owner must outlive them; while views exist it refuses bigsi_hip_close and bigsi_hip_reserve_cols
  * (attached processes it cannot see: do not re-stride or close an exported index while others use it).  Writes the owner makes
- * (set_rows, insert) are seen by the other handles' later calls once the owner's call has returned. */
+ * (set_rows, insert) are seen by the other handles' later calls once the owner's call has returned; the COLUMN COUNT of an
+ * attached handle or view is the one it was opened with (bigsi_hip_set_num_cols on that handle, or a fresh attach, to see
+ * samples the owner has appended since). */
 #define BIGSI_IPC_HANDLE_BYTES 64
 int bigsi_hip_export_ipc(bigsi_hip_index *ix, uint8_t *handle /* BIGSI_IPC_HANDLE_BYTES */);
 int bigsi_hip_open_ipc(const uint8_t *handle, uint64_t num_rows, uint64_t num_cols, uint64_t col_capacity, uint32_t num_hashes,

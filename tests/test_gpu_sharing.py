@@ -162,6 +162,17 @@ def test_stale_attach_file_falls_back_to_the_snapshot():
                           "storage-config": {"name": "stale-dst", "filename": os.path.join(d, "snap"), "attach": os.path.join(d, "gone.attach")}})
     assert not b2.storage.res.attached and b2.search("ATAC", 1.0) == want == [{"percent_kmers_found": 100.0, "num_kmers": 2, "num_kmers_found": 2, "sample_name": "a"}]
     b2.storage.res.free()
+    # ... and so is a file whose handle does not open (its owner died and the pid now belongs to some other live process -- here: init)
+    doc = json.load(open(os.path.join(d, "gone.attach")))
+    doc["pid"] = 1
+    with open(os.path.join(d, "reused.attach"), "w") as f:
+        json.dump(doc, f)
+    HipHbmStorage.drop("stale-dst")
+    with pytest.warns(UserWarning, match="could not attach"):
+        b3 = bigsi_amd.BIGSI({"storage-engine": "hip-hbm", "k": 3, "m": 1000, "h": 3,
+                              "storage-config": {"name": "stale-dst2", "filename": os.path.join(d, "snap"), "attach": os.path.join(d, "reused.attach")}})
+    assert not b3.storage.res.attached and b3.search("ATAC", 1.0) == want
+    b3.storage.res.free()
 
 
 # ----------------------------------------------------------------------------------------------- threads of one process

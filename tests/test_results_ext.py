@@ -115,3 +115,34 @@ def test_a_colour_without_a_name_on_the_exact_route_is_the_python_loops_keyerror
     rng = np.random.default_rng(5)
     (a, ea), (b, eb) = both(rng, 200, False, 1.0, beyond=True)
     assert type(ea) is KeyError and type(eb) is KeyError and a == b
+
+
+@pytest.mark.parametrize("threshold", [1.0, 0.4])
+def test_direct_value_stores_give_the_same_dicts(threshold):
+    """build_scored's CPython-3.10 route (values stored straight into the copied template's entries, after a read-only check of the
+    table) against its own PyDict_SetItem route: equal dicts, equal key order and value types, and the dicts stay ordinary dicts
+    (they can be changed, grown past their table, serialised)."""
+    import json
+    ext = bigsi_mod._results
+    was = ext.fast_dict()
+    rng = np.random.default_rng(11)
+    nk, nu, off, col, cnt, bits, boff, rec = payload(rng, 400, True, threshold)
+    names = [None if n_ == DELETION_SPECIAL_SAMPLE_NAME else n_ for n_ in NAMES]
+    out = {}
+    try:
+        for on in (True, False):
+            ext.fast_dict(on)
+            out[on] = list(bigsi_mod.native_result_lists(nk, nu, off.astype(np.int64), col, cnt, threshold == 1.0, names, (rec, bits, boff), NS))
+    finally:
+        ext.fast_dict(was)
+    a, b = out[True], out[False]
+    assert a == b and sum(len(r) for r in a) > 100
+    for ra, rb in zip(a, b):
+        for da, db in zip(ra, rb):
+            assert list(da) == list(db) and [type(v) for v in da.values()] == [type(v) for v in db.values()] and len(da) == 22
+    assert json.dumps(a) == json.dumps(b)
+    d = next(d_ for r in a for d_ in r)
+    for i in range(100):
+        d["extra%d" % i] = i                # grows past the 64-slot table: an ordinary resize
+    del d["score"]
+    assert len(d) == 121 and "score" not in d and d["extra99"] == 99 and list(d)[:3] == ["percent_kmers_found", "num_kmers", "num_kmers_found"]
