@@ -211,6 +211,7 @@ static int open_impl(uint64_t num_rows, uint64_t num_cols, uint64_t col_capacity
         void *p = nullptr;
         e = hipIpcOpenMemHandle(&p, *ipc, hipIpcMemLazyEnablePeerAccess);
         if (e != hipSuccess) {
+            (void)hipGetLastError();          // (the runtime's last-error slot is sticky: the next launch check of this thread must not inherit it)
             hipError_t e2 = hipStreamDestroy(ix->own_stream); (void)e2;
             e2 = hipStreamDestroy(ix->pre_stream);
             delete ix;
