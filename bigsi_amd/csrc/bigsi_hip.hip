@@ -1551,7 +1551,7 @@ extern "C" int bigsi_hip_batch_reload(bigsi_hip_batch *b, const char *seqs, cons
 
 extern "C" int bigsi_hip_batch_destroy(bigsi_hip_batch *b)
 {
-    BIGSI_ENTER(b ? b->ix : nullptr);
+    BusyGuard busy_guard_(b ? b->ix : nullptr, /*wait=*/true);
     if (!b) return BIGSI_OK;
     hipError_t e = hipSetDevice(b->ix->device);
     e = hipStreamSynchronize(b->ix->pre_stream);

@@ -148,13 +148,19 @@ struct bigsi_hip_index {
 struct BusyGuard {
     bigsi_hip_index *ix;
     bool ok = true;
-    explicit BusyGuard(const bigsi_hip_index *cix) : ix(const_cast<bigsi_hip_index *>(cix))
+    // wait = true: a teardown call (bigsi_hip_batch_destroy -- finalisers run it from whichever thread drops the last reference) waits for
+    // the thread that is inside the handle instead of being refused: every call is finite, and a refused destroy is a leaked batch
+    explicit BusyGuard(const bigsi_hip_index *cix, bool wait = false) : ix(const_cast<bigsi_hip_index *>(cix))
     {
         if (!ix) return;
         const std::thread::id me = std::this_thread::get_id();
-        std::thread::id cur{};
-        if (ix->busy_owner.compare_exchange_strong(cur, me, std::memory_order_acquire)) { ix->busy_depth = 1; return; }
-        if (cur == me) { ix->busy_depth++; return; }
+        for (;;) {
+            std::thread::id cur{};
+            if (ix->busy_owner.compare_exchange_strong(cur, me, std::memory_order_acquire)) { ix->busy_depth = 1; return; }
+            if (cur == me) { ix->busy_depth++; return; }
+            if (!wait) break;
+            std::this_thread::yield();
+        }
         ok = false;
         ix = nullptr;
     }

@@ -637,6 +637,8 @@ class QueryBatch(object):
 
     def close(self):
         if self.b is not None:
+            # (a finaliser may run this while another thread of the process is inside a call on the same index handle: the library's
+            # destroy waits for that thread -- every other entry point refuses a second thread)
             check(self._fn("destroy")(self.b))
             self.b = None
 

@@ -13,7 +13,8 @@
  *     failure on the calling thread is bigsi_hip_last_error().
  *   - the caller owns all host buffers; no call retains a host pointer after it returns.
  *   - one index / batch handle may be used from one host thread at a time -- ENFORCED: a call on a handle (or on a batch of
- *     it) that another thread is inside fails with BIGSI_ERR_STATE, it does not race.  Distinct handles are independent, and
+ *     it) that another thread is inside fails with BIGSI_ERR_STATE, it does not race (bigsi_hip_batch_destroy alone WAITS for
+ *     that thread: finalisers run it from any thread, and a refused destroy would be a leak).  Distinct handles are independent, and
  *     bigsi_hip_open_view gives every thread of a serving host its own handle onto the one resident matrix.  HIP contexts do not survive fork(): open after forking (bulk_search,
  *     bigsi/__main__.py:273-287, forks one worker per chunk).
  *   - LAYERS.  A binder needs only what its host does:

@@ -63,7 +63,7 @@ def test_attach_to_another_processes_index(owner):
                       "storage-config": {"name": "big-attached", "attach": os.path.join(owner["dir"], "big.attach")}})
     attach_s = time.perf_counter() - t0
     assert st.res.attached and int(st.res.info().index_bytes) == owner["index_bytes"] > 16e9
-    assert attach_s < 0.1, "attach took %.3f s" % attach_s
+    assert attach_s < 0.5, "attach took %.3f s" % attach_s       # (2-4 ms measured; the first IPC open of a cold box has taken longer)
     assert before - free_bytes() < 1 << 30, "attaching took %d bytes of HBM: a second copy?" % (before - free_bytes())
     seqs = owner["seqs"]
     orc = SynthOracle(4242, 0, owner["rows"], owner["cols"], 3, 31, 2)
@@ -305,4 +305,37 @@ def test_one_handle_in_two_threads_fails_cleanly():
     for q in (0, n // 2, n - 1):
         u, cnt = orc.counts(many[q])
         assert out["nu"][q] == u and np.array_equal(out["col"][int(out["off"][q]):int(out["off"][q + 1])], np.flatnonzero(cnt >= u))
+    st.delete_all()
+
+
+def test_batch_close_waits_for_a_busy_handle():
+    """A QueryBatch finalised (close(), or the garbage collector) while another thread of the process is inside a call on the same
+    handle: the library refuses the second thread, the host side waits for the handle instead of leaking the device buffers."""
+    from bigsi_amd import _lib
+    L = _lib.lib()
+    st = _synthetic_index("closebusy", 200_003, 20_000)
+    rng = np.random.default_rng(8)
+    many = ["".join(rng.choice(list("ACGT"), size=1000)) for _ in range(4096)]
+    blob, soff = _lib.pack_seqs(many)
+    n = len(many)
+    out = dict(nk=np.zeros(n, np.uint32), nu=np.zeros(n, np.uint32), off=np.zeros(n + 1, np.uint64), col=np.zeros(1 << 20, np.uint32), cnt=np.zeros(1 << 20, np.uint32))
+    batches = [st.new_batch(many[:4], 31) for _ in range(200)]
+    stop, rcs = threading.Event(), []
+
+    def long_calls():
+        while not stop.is_set():
+            rcs.append(L.bigsi_hip_search_stream(st.handle, blob, _lib.ptr(soff), n, 31, 1.0, 0, _lib.ptr(out["nk"]), _lib.ptr(out["nu"]), None,
+                                                 _lib.ptr(out["off"]), _lib.ptr(out["col"]), _lib.ptr(out["cnt"]), 1 << 20))
+    th = threading.Thread(target=long_calls)
+    th.start()
+    try:
+        while not rcs:
+            time.sleep(0.001)
+        for b in batches:
+            b.close()                          # never raises: waits out the stream call when it meets one
+            assert b.b is None
+    finally:
+        stop.set()
+        th.join()
+    assert set(rcs) <= {0, _lib.ERR_STATE} and rcs.count(0) >= 1
     st.delete_all()
