@@ -1714,6 +1714,15 @@ struct K1Src {
     const uint64_t *seq_off, *pos_off;
     uint64_t *pos_off_out;
     uint32_t one_len;          // > 0: the batch is one sequence of this length, read in place (no offset tables to fetch)
+    // one_len > 0: the same bytes as the host sees them -- short enough, they travel in the kernel arguments instead (SeqArg)
+    template <int N>
+    SeqArg<N> by_value() const
+    {
+        SeqArg<N> a;
+        memset(a.w, 0, sizeof a.w);
+        memcpy(a.w, seqs, one_len);
+        return a;
+    }
 };
 
 static K1Src k1_src(const bigsi_hip_batch *b)
@@ -1763,14 +1772,20 @@ static int launch_reads_fused(bigsi_hip_batch *b, hipStream_t st = nullptr, bool
         else b->exp_serial--;          // (tuning builds with the event route: the export kernel as usual)
     }
     const K1Src src = k1_src(b);
+    // one read read in place: its bytes go in the kernel arguments, not over the host link (SeqArg, bigsi_kernels.hpp)
+    static const int arg_env = env_int("BIGSI_HIP_SEQ_BY_ARG", 1);
+    const bool by_arg = arg_env && src.one_len && src.one_len <= kSeqArgRead;
+    SeqArg<kSeqArgRead> read_arg;
+    if (by_arg) read_arg = src.by_value<kSeqArgRead>();
+    else memset(read_arg.w, 0, sizeof read_arg.w);
 #define BIGSI_READS_ARGS                                                                                                          \
     dim3(b->n_seqs), dim3(kBlock), 0, st, ix->d_index, ix->stride_words, (uint32_t)b->wv, ix->n_cols, ix->m, b->threshold,              \
-        src.seqs, src.seq_off, src.pos_off, b->n_seqs, b->first_pos.as<uint32_t>(),                                                       \
+        by_arg ? (const char *)nullptr : src.seqs, src.seq_off, src.pos_off, b->n_seqs, b->first_pos.as<uint32_t>(),                        \
         b->pos_unique.as<uint32_t>(), b->rep.as<uint32_t>(), b->rows.as<uint64_t>(), b->num_kmers.as<uint32_t>(),                      \
         b->num_unique.as<uint32_t>(), b->min_kmers.as<uint32_t>(), b->bitmaps.as<uint64_t>(), b->wv_pad, hb.q_start.as<uint64_t>(),   \
         hb.q_cnt.as<uint32_t>(), hb.alloc.as<unsigned long long>(), gen_next & 1u, hb.col(), hb.cnt(), hb.capacity(), fp_mask,          \
         src.pos_off_out, src.one_len, b->exported_inline ? static_cast<uint64_t *>(b->pin_out) : nullptr, b->exp_spec,                          \
-        (volatile uint64_t *)b->pin_flag, b->exp_serial
+        (volatile uint64_t *)b->pin_flag, b->exp_serial, read_arg
 #define COMMA ,
     // rows of at most kBlock words, counting: one word per lane (8-byte loads: half the registers -- 8 wavefronts per SIMD instead
     // of 4 -- and twice the lanes that hold columns).  Interleaved A/B at C2: counting 1377 -> 1523 M lookups/s; the exact kernel
@@ -1839,9 +1854,11 @@ static K1Plan k1_plan(const bigsi_hip_batch *b, bool force_global)
     // dedupe table of the LDS route: 4 slots per position when that fits the LDS window (shorter probe chains), else 2
     p.hs_cap = (uint32_t)round_up(std::max<uint64_t>(b->max_pos, 1), 4);
     p.sq_bytes = (uint32_t)round_up(b->max_len + 16, 16);
-    static const int tab_mult_env = env_int("BIGSI_HIP_K1_TABMULT", 4);      // A/B: 2 = half the LDS per workgroup, longer probe chains
-    p.tab_mult = tab_mult_env == 2 ? 2u : 4u;
-    for (;; p.tab_mult = 2) {
+    // (a handful of queries -- a latency-bound call -- have the LDS to themselves: 8 slots per position, insert phase of one 1 kbp
+    // query 2.04 / 1.08 / 0.80 us at 2 / 4 / 8)
+    static const int tab_mult_env = env_int("BIGSI_HIP_K1_TABMULT", 0);      // A/B: 2 = half the LDS per workgroup, longer probe chains
+    p.tab_mult = tab_mult_env == 2 ? 2u : tab_mult_env == 4 ? 4u : (tab_mult_env == 8 || b->n_seqs <= 32) ? 8u : 4u;
+    for (;; p.tab_mult /= 2) {
         p.tab_cap = 2;
         while (p.tab_cap < p.tab_mult * b->max_pos && p.tab_cap < (1u << 30)) p.tab_cap <<= 1;
         p.lds = (size_t)(p.tab_cap + p.tab_cap / 32 + 4) * 4 + 64 + (size_t)p.hs_cap * 4 + 2 * p.sq_bytes;      // table (+ sort pad) | scan | fingerprints | sequence | its complement
@@ -1924,15 +1941,26 @@ static int run_kmerize(bigsi_hip_batch *b, double threshold, bool force_global =
             if (sorted) *sorted = true;
         }
         TRY(ev_begin(ix, &ep, ks));
-#define BIGSI_K1_LDS(KF)                                                                                                        \
-    hipLaunchKernelGGL((k_kmerize_lds<KF>), dim3(b->n_seqs), dim3(block), lds, ks, src.seqs, src.seq_off,                         \
+        // a handful of gene-length queries (a latency-bound call): the hashing of a query's unique k-mers is spread over several
+        // workgroups (k_kmerize_lds, `parts`)
+        static const int parts_env = env_int("BIGSI_HIP_K1_PARTS", 8);
+        const uint32_t parts = (parts_env > 1 && !(parts_env & (parts_env - 1)) && !want_sorted && b->max_pos <= block && b->max_pos >= 256 && (uint64_t)b->n_seqs * parts_env <= 256) ? (uint32_t)parts_env : 1u;
+#define BIGSI_K1_LDS_(KF, ARGB, SARG)                                                                                           \
+    hipLaunchKernelGGL((k_kmerize_lds<KF, ARGB>), dim3(b->n_seqs * parts), dim3(block), lds, ks, src.seqs, src.seq_off,           \
                        src.pos_off, b->k, ix->h, ix->m, threshold, tab_cap, tab_mult, hs_cap, sq_bytes, b->first_pos.as<uint32_t>(), b->tmp.as<uint32_t>(), \
                        b->pos_unique.as<uint32_t>(), b->rep.as<uint32_t>(), b->rows.as<uint64_t>(), b->num_kmers.as<uint32_t>(),      \
                        b->num_unique.as<uint32_t>(), b->min_kmers.as<uint32_t>(), want_sorted ? b->rows_sorted.as<uint64_t>() : (uint64_t *)nullptr, \
-                       ps_p, ps_words, ps_value, src.pos_off_out, src.one_len)
+                       ps_p, ps_words, ps_value, src.pos_off_out, src.one_len, parts, SARG)
+        // one sequence read in place (a one-call search): short enough, its bytes go in the kernel arguments (SeqArg)
+        static const int arg_env = env_int("BIGSI_HIP_SEQ_BY_ARG", 1);
+#define BIGSI_K1_LDS(KF)                                                                                   \
+    if (arg_env && src.one_len && src.one_len <= kSeqArgSmall) BIGSI_K1_LDS_(KF, kSeqArgSmall, src.by_value<kSeqArgSmall>());       \
+    else if (arg_env && src.one_len && src.one_len <= kSeqArgLarge) BIGSI_K1_LDS_(KF, kSeqArgLarge, src.by_value<kSeqArgLarge>());  \
+    else BIGSI_K1_LDS_(KF, 0, SeqArg<0>{})
         if (b->k == 31) BIGSI_K1_LDS(31);
         else BIGSI_K1_LDS(0);
 #undef BIGSI_K1_LDS
+#undef BIGSI_K1_LDS_
         if (preset) preset->done = ps_p != nullptr;
         HIP_TRY(hipGetLastError());
         TRY(ev_end(ix, &ep, ix->ev_km, ks));

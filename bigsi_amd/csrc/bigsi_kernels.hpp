@@ -150,6 +150,25 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *t
     return base + incl - v;
 }
 
+// the same for a FLAG per thread (0 / 1): the wavefront's part is a ballot and two mbcnt instead of six cross-lane shuffles (1.0 us
+// of a single query's K1 was the scan above).  No barrier after the LDS reads: the caller reuses `lds` only behind one of its own.
+__device__ __forceinline__ uint32_t block_exclusive_scan_flag(bool flag, uint32_t *total, uint32_t *lds /* >= blockDim.x/64 entries */)
+{
+    const uint64_t bal = __ballot(flag);
+    const uint32_t in_wave = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+    const uint32_t wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if ((threadIdx.x & 63u) == 0) lds[wave] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+    for (uint32_t w = 0; w < nw; w++) {
+        const uint32_t x = lds[w];
+        base += w < wave ? x : 0u;
+        tot += x;
+    }
+    *total = tot;
+    return base + in_wave;
+}
+
 // ------------------------------------------------------------------------------ K1: k-merise + dedupe + hash
 // Restates, per query sequence:
 //   seq_to_kmers (bigsi/utils/fncts.py:63-65)          every window of k bytes, no validation;
@@ -432,6 +451,19 @@ __device__ uint64_t g_phase[1024 * 8];
 // Same results as the four-kernel path above, which remains the route for longer queries.
 constexpr uint32_t kLdsMaxPos = 4096;
 
+// The bytes of ONE query passed BY VALUE in the kernel arguments (a one-call search of a single sequence).  The runtime writes a
+// launch's arguments into device-visible memory together with the packet, so the kernel's first loads are local instead of a round
+// trip over the host link: scripts/probe/latency_probe.hip, 1 KB read by one workgroup + flag: 15.1 us from pinned memory (E),
+// 9.9 us from the arguments (M); every KB of arguments costs the launch about 1 us, hence two sizes.
+template <int N>
+struct SeqArg {
+    uint32_t w[N / 4];
+};
+template <>
+struct SeqArg<0> {
+};
+constexpr uint32_t kSeqArgSmall = 1024, kSeqArgLarge = 3072, kSeqArgRead = 96;
+
 template <int KF>
 __device__ __forceinline__ uint32_t dedupe_hash(const char *km, uint32_t k)
 {
@@ -443,7 +475,29 @@ __device__ __forceinline__ uint32_t dedupe_hash(const char *km, uint32_t k)
     return fnv1a(km, k);
 }
 
+// the h rows of the k-mer at position i of a query staged in LDS (sq: its bytes; sc: KF == 31, their complements behind 4 pad bytes)
 template <int KF>
+// (seeds [sd0, sd1) only: dst[sd] for those)
+__device__ __forceinline__ void kmer_rows(const char *sq, const char *sc, uint32_t i, uint32_t k, uint32_t sd0, uint32_t sd1, uint64_t m, uint64_t *dst)
+{
+    if (KF == 31) {
+        uint32_t wf[8], k1[8];
+        kmer31_words(reinterpret_cast<const uint32_t *>(sq), i, wf);
+        kmer31_canonical_premix(wf, reinterpret_cast<const uint32_t *>(sc), i, k1);
+        for (uint32_t sd = sd0; sd < sd1; sd++) dst[sd] = row_of_hash(murmur3_31_finish(k1, sd), m);
+    } else if (KF > 0) {
+        RegKmer<KF> reg;
+        reg.load(sq + i);
+        uint32_t w[(KF + 3) / 4 > 0 ? (KF + 3) / 4 : 1];
+        reg.canonical_words(w);
+        for (uint32_t sd = sd0; sd < sd1; sd++) dst[sd] = row_of_hash(murmur3_words<KF>(w, sd), m);
+    } else {
+        const KmerView v{sq + i, k, use_revcomp(sq + i, k)};
+        for (uint32_t sd = sd0; sd < sd1; sd++) dst[sd] = row_of_hash(murmur3_32(v, sd), m);
+    }
+}
+
+template <int KF, int ARGB = 0 /* > 0: the one sequence of the batch is `sarg` (ARGB bytes of kernel arguments), not seqs */>
 __global__ __launch_bounds__(1024) void k_kmerize_lds(
     const char *__restrict__ seqs, const uint64_t *__restrict__ seq_off, const uint64_t *__restrict__ pos_off,
     uint32_t k, uint32_t h, uint64_t m, double threshold, uint32_t tab_cap, uint32_t tab_mult, uint32_t hs_cap, uint32_t sq_bytes /* multiple of 16 */, uint32_t *__restrict__ first_pos,
@@ -455,20 +509,27 @@ __global__ __launch_bounds__(1024) void k_kmerize_lds(
     uint64_t preset_words, uint64_t preset_value,
     uint64_t *__restrict__ pos_off_out /* non-null: seqs / seq_off / pos_off are read straight from pinned host memory (a one-call
                                           search: no upload); the device copy of pos_off the later kernels read is written here */,
-    uint32_t one_len /* > 0: the batch is ONE sequence of this length (its offset tables need not be read: a PCIe round trip less) */)
+    uint32_t one_len /* > 0: the batch is ONE sequence of this length (its offset tables need not be read: a PCIe round trip less) */,
+    uint32_t parts /* workgroups per query, a power of two (gridDim.x = queries * parts).  > 1 -- a handful of queries whose positions fit one pass of
+                      the workgroup (n <= blockDim.x), no sorted copy: every part dedupes the whole query (same table, same ranks: the
+                      representative of a k-mer is its smallest position whatever the order of the inserts), then hashes and writes
+                      only its share of the unique k-mers.  One CU takes 4 us to hash the ~970 k-mers of a 1 kbp query for 4 seeds
+                      (scripts/ab_k1_phases.py): that part of a latency-bound call is ALU work, and this spreads it over `parts` CUs */,
+    const SeqArg<ARGB> sarg)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    if (pos_off_out && threadIdx.x == 0) {
+    const uint32_t q = blockIdx.x / parts, part = blockIdx.x - q * parts, n_queries = gridDim.x / parts;
+    if (pos_off_out && threadIdx.x == 0 && part == 0) {
         if (one_len) {
             pos_off_out[0] = 0;
             pos_off_out[1] = one_len >= k ? one_len - k + 1 : 0u;
         } else {
-            pos_off_out[blockIdx.x] = pos_off[blockIdx.x];
-            if (blockIdx.x + 1 == gridDim.x) pos_off_out[gridDim.x] = pos_off[gridDim.x];
+            pos_off_out[q] = pos_off[q];
+            if (q + 1 == n_queries) pos_off_out[n_queries] = pos_off[n_queries];
         }
     }
-    if (preset) {
-        uint64_t *pq = preset + (uint64_t)blockIdx.x * preset_words;
+    if (preset && part == 0) {
+        uint64_t *pq = preset + (uint64_t)q * preset_words;
         for (uint64_t i = threadIdx.x; i < preset_words; i += blockDim.x) pq[i] = preset_value;
     }
     uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
@@ -476,7 +537,6 @@ __global__ __launch_bounds__(1024) void k_kmerize_lds(
     uint32_t *hs = scan + 16;                            // hs[i]: 32-bit hash of the k-mer at position i (hs_cap entries)
     char *sq = reinterpret_cast<char *>(hs + hs_cap);    // the query's bytes
     char *sc = sq + sq_bytes;                            // KF == 31: their complements, 4 pad bytes in front (kmer31_canonical_premix)
-    const uint32_t q = blockIdx.x;
     const char *s = one_len ? seqs : seqs + seq_off[q];
     const uint32_t len = one_len ? one_len : (uint32_t)(seq_off[q + 1] - seq_off[q]);
     const uint32_t n = len >= k ? len - k + 1 : 0u;
@@ -486,6 +546,15 @@ __global__ __launch_bounds__(1024) void k_kmerize_lds(
     const uint32_t mask = tsize - 1;
     BIGSI_PHASE(0);
     for (uint32_t i = threadIdx.x; i < tsize; i += blockDim.x) tab[i] = kEmpty;
+    if constexpr (ARGB > 0) {                            // (one_len <= ARGB, zero-padded to a word by the host; sq / sc hold sq_bytes >= that)
+        for (uint32_t j = threadIdx.x; j < (len + 3) / 4; j += blockDim.x) {
+            const uint32_t w = sarg.w[j];
+            reinterpret_cast<uint32_t *>(sq)[j] = w;
+            if (KF == 31)
+                reinterpret_cast<uint32_t *>(sc + 4)[j] = (uint32_t)complement((uint8_t)w) | (uint32_t)complement((uint8_t)(w >> 8)) << 8 |
+                                                          (uint32_t)complement((uint8_t)(w >> 16)) << 16 | (uint32_t)complement((uint8_t)(w >> 24)) << 24;
+        }
+    } else
     for (uint32_t base = 0; base < len; base += 4 * blockDim.x) {       // four loads in flight per thread and pass
         char c[4];
 #pragma unroll
@@ -535,6 +604,43 @@ __global__ __launch_bounds__(1024) void k_kmerize_lds(
     // (one scan over threads that each take several CONSECUTIVE positions -- fewer barriers -- measured slower: 0.37 against
     // 0.29 ms per 8192 queries; the strided positions keep the LDS reads and the global writes of a wavefront together)
     uint32_t u = 0;
+    if (parts > 1) {
+        // (n <= blockDim.x: thread i holds position i.)  Ranks as below; then the list of first positions and the rank of every
+        // representative go to LDS (the fingerprints and the table are no longer needed), and this part takes its share of both the
+        // per-position outputs and the unique k-mers -- whose hashing is repacked onto the first threads of the workgroup.
+        const uint32_t i = threadIdx.x;
+        const uint32_t c = i < n ? tab[my_slot] : kEmpty;
+        const uint32_t flag = (i < n && c == i) ? 1u : 0u;
+        const uint32_t pre = block_exclusive_scan_flag(flag != 0, &u, scan);       // (its barrier: every thread has read its table slot)
+        BIGSI_PHASE(4);
+        if (flag) {
+            hs[pre] = i;
+            tab[i] = pre;
+        }
+        __syncthreads();
+        const uint32_t pshift = 31u - (uint32_t)__clz((int)parts);         // (parts is a power of two: no division on the chain)
+        const uint32_t per_i = (n + parts - 1) >> pshift, i0 = part * per_i, i1 = min(n, i0 + per_i);
+        if (i >= i0 && i < i1) {
+            rp[i] = c;
+            pu[i] = tab[c];
+            if (flag) ux[i] = pre;
+        }
+        const uint32_t per_j = (u + parts - 1) >> pshift, j0 = min(u, part * per_j), j1 = min(u, j0 + per_j);
+        BIGSI_PHASE(5);
+        for (uint32_t t = threadIdx.x; t < (j1 - j0) * h; t += blockDim.x) {      // a thread per (unique k-mer, seed): the shortest chain
+            const uint32_t tj = t / h, j = j0 + tj, sd = t - tj * h, pos = hs[j];
+            if (sd == 0) fp[j] = pos;
+            kmer_rows<KF>(sq, sc, pos, k, sd, sd + 1, m, qrows + (uint64_t)j * h);
+        }
+        if (threadIdx.x == 0 && part == 0) {
+            num_kmers[q] = n;
+            num_unique[q] = u;
+            const double mk = ceil((double)u * threshold);
+            min_kmers[q] = mk > 0.0 ? (uint32_t)mk : 0u;
+        }
+        BIGSI_PHASE(6);
+        return;
+    }
     for (uint32_t base = 0; base < n; base += blockDim.x) {
         const uint32_t i = base + threadIdx.x;
         uint32_t c = kEmpty;
@@ -559,22 +665,7 @@ __global__ __launch_bounds__(1024) void k_kmerize_lds(
             const uint32_t j = u + pre;
             fp[j] = i;
             ux[i] = j;
-            uint64_t *dst = qrows + (uint64_t)j * h;
-            if (KF == 31) {
-                uint32_t wf[8], k1[8];
-                kmer31_words(reinterpret_cast<const uint32_t *>(sq), i, wf);
-                kmer31_canonical_premix(wf, reinterpret_cast<const uint32_t *>(sc), i, k1);
-                for (uint32_t sd = 0; sd < h; sd++) dst[sd] = row_of_hash(murmur3_31_finish(k1, sd), m);
-            } else if (KF > 0) {
-                RegKmer<KF> reg;
-                reg.load(sq + i);
-                uint32_t w[(KF + 3) / 4 > 0 ? (KF + 3) / 4 : 1];
-                reg.canonical_words(w);
-                for (uint32_t sd = 0; sd < h; sd++) dst[sd] = row_of_hash(murmur3_words<KF>(w, sd), m);
-            } else {
-                const KmerView v{sq + i, k, use_revcomp(sq + i, k)};
-                for (uint32_t sd = 0; sd < h; sd++) dst[sd] = row_of_hash(murmur3_32(v, sd), m);
-            }
+            kmer_rows<KF>(sq, sc, i, k, 0, h, m, qrows + (uint64_t)j * h);
         }
         u += tot;
     }
@@ -1405,7 +1496,8 @@ __global__ __launch_bounds__(kBlock) void k_reads_fused(
     uint32_t one_len /* as k_kmerize_lds */,
     uint64_t *exp_out /* non-null: a one-call search of ONE read -- the workgroup also writes the caller's block in pinned memory
                          (k_export_reads' layout) and raises the flag the host spins on: no export kernel, no launch boundary */,
-    uint32_t exp_spec, volatile uint64_t *exp_flag, uint64_t exp_serial)
+    uint32_t exp_spec, volatile uint64_t *exp_flag, uint64_t exp_serial,
+    const SeqArg<kSeqArgRead> sarg /* seqs == nullptr (one_len > 0): the one read of the call, passed in the kernel arguments */)
 {
     constexpr int KF = 31, P = 6;
     if (pos_off_out && threadIdx.x == 0) {
@@ -1441,7 +1533,8 @@ __global__ __launch_bounds__(kBlock) void k_reads_fused(
         const uint64_t P0 = one_len ? 0ull : pos_off[q];
         if (threadIdx.x < 100) {                           // s_cmp carries 4 pad bytes in front (the word at byte p - 1 is read)
             const uint32_t t = threadIdx.x;
-            const uint8_t c = t < len ? (uint8_t)s[t] : (uint8_t)0;
+            uint8_t c = 0;
+            if (t < len) c = seqs ? (uint8_t)s[t] : (uint8_t)(sarg.w[t >> 2] >> ((t & 3u) * 8u));
             if (t < 96) {
                 reinterpret_cast<uint8_t *>(s_seq)[t] = c;
                 reinterpret_cast<uint8_t *>(s_cmp)[4 + t] = complement(c);

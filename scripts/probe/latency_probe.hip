@@ -9,6 +9,7 @@
 //   H  hipGraphLaunch of [copy 1 KB, kernel, kernel] + flag
 //   I  D with a 64 KB input                  J  E with a 64 KB input (64 workgroups reading 1 KB each)
 //   K  kernel busy for ~10 us (dependent loads) + flag: the floor of a call whose device work is 10 us
+//   M  E with the input passed BY VALUE in the kernel arguments (1 KB / 3.9 KB of kernarg) instead of through pinned memory
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <chrono>
@@ -40,6 +41,20 @@ __global__ void k_read_flag(const uint8_t *src, uint32_t n_per_block, uint32_t *
         __threadfence_system();
         if (atomicAdd(counter, 1u) == gridDim.x - 1) { *counter = 0; __threadfence_system(); *flag = v; }
     }
+}
+template <int N>
+struct Blob { uint8_t b[N]; };
+template <int N>
+__global__ void k_arg_flag(const Blob<N> in, uint32_t n, uint32_t *out, volatile uint64_t *flag, uint64_t v)
+{
+    __shared__ uint32_t s;
+    if (threadIdx.x == 0) s = 0;
+    __syncthreads();
+    uint32_t acc = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) acc += in.b[i];
+    atomicAdd(&s, acc);
+    __syncthreads();
+    if (threadIdx.x == 0) { out[0] = s; __threadfence_system(); *flag = v; }
 }
 __global__ void k_chase(const uint32_t *next, uint32_t steps, uint32_t *out, volatile uint64_t *flag, uint64_t v)
 {
@@ -149,6 +164,19 @@ int main()
         char name[128];
         snprintf(name, sizeof name, "K kernel of %u dependent HBM loads + flag", steps);
         run(name, [&] { ++serial; hipLaunchKernelGGL(k_chase, dim3(1), dim3(1), 0, st, d_next, steps, d_out, flag, serial); spin(flag, serial); });
+    }
+    {
+        static Blob<1024> b1;
+        static Blob<3968> b4;
+        for (int i = 0; i < 1024; i++) b1.b[i] = (uint8_t)i;
+        for (int i = 0; i < 3968; i++) b4.b[i] = (uint8_t)i;
+        run("M 1 KB passed by value in the kernel arguments + flag", [&] { ++serial; hipLaunchKernelGGL(k_arg_flag<1024>, dim3(1), dim3(256), 0, st, b1, 1024u, d_out, flag, serial); spin(flag, serial); });
+        uint32_t got = 0;
+        CK(hipMemcpy(&got, d_out, 4, hipMemcpyDeviceToHost));
+        uint32_t want = 0;
+        for (int i = 0; i < 1024; i++) want += (uint8_t)i;
+        if (got != want) { fprintf(stderr, "M: sum %u != %u\n", got, want); return 1; }
+        run("M 3.9 KB passed by value in the kernel arguments + flag", [&] { ++serial; hipLaunchKernelGGL(k_arg_flag<3968>, dim3(1), dim3(256), 0, st, b4, 3968u, d_out, flag, serial); spin(flag, serial); });
     }
     run("L K(16) + event record + hipEventSynchronize instead of the flag", [&] {
         hipLaunchKernelGGL(k_chase, dim3(1), dim3(1), 0, st, d_next, 16u, d_out, (volatile uint64_t *)nullptr, 0ull);

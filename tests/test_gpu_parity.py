@@ -497,7 +497,7 @@ def test_one_call_searches_of_one_query_equal_the_batch_route(hip, n_cols, h):
     m = 200003
     _, st = synth_index(hip, m, n_cols, h, 4242)
     rng = np.random.default_rng(n_cols)
-    qs = random_seqs(rng, 6, 94, 1500) + ["".join(rng.choice(list("ACGT"), size=L)) for L in (93, 94, 95, 156, 157, 4062, 4063, 1000)]
+    qs = random_seqs(rng, 6, 94, 1500) + ["".join(rng.choice(list("ACGT"), size=L)) for L in (93, 94, 95, 96, 97, 156, 157, 4062, 4063, 1000, 1023, 1024, 1025, 3070, 3072, 3073)]      # (also around the sizes a query travels in the kernel arguments)
     rep = "".join(rng.choice(list("ACGT"), size=70))
     qs += [rep * 9, qs[0][:300] + "N" + qs[0][300:], qs[1].lower(), qs[2][:200] + qs[2][:200]]
     for i, q in enumerate(qs[:8]):
