@@ -2200,7 +2200,10 @@ int bigsi_batch_run(bigsi_hip_batch *b, double threshold, uint32_t flags, bool o
         // shard: 512 workgroups, 0.80-0.82 either way)
         if (blocks256 % 256 == 0 || (b->exact && blocks256 >= 2 * kb256)) mid = false;
     }
-    const int and_block = mid ? 64 : b->exact ? and_block_env : std::min(and_block_env, 256);
+    // (a sliced exact launch -- a latency-bound call -- in workgroups of two wavefronts: the pieces spread more evenly over the CUs and the
+    // stragglers end sooner; one 1 kbp query on 100 k samples, the call: 256 -> 41.9, 128 -> 41.2, 64 -> 41.4 us; counting: no difference)
+    static const int and_block_set = env_int("BIGSI_HIP_AND_BLOCK", 0);
+    const int and_block = mid ? 64 : (slices > 1 && b->exact && !and_block_set) ? 128 : b->exact ? and_block_env : std::min(and_block_env, 256);
     // row loads a lane keeps in flight: 8, or 4 when 8 would put more bytes in flight on the chip (queries of the launch x row bytes x
     // loads) than the memory system schedules well -- the optimum measured at 8-13 MB.  Interleaved A/B: 256 queries per launch on
     // 62.5 k-sample shards (7.8 KB rows: 16 MB at 8 loads): 4 -> +3.3 % (C4 shard 263 -> 272 M lookups/s) / +2.2 % (north-star shard),

@@ -130,12 +130,15 @@ __device__ __forceinline__ uint64_t row_of_hash(uint32_t h, uint64_t m)
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *total, uint32_t *lds /* >= blockDim.x/64 entries */)
 {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // inclusive scan of the wavefront on the DPP path (shifts within rows of 16 lanes, then the row broadcasts): seven VALU adds instead
+    // of six round trips through the LDS crossbar (__shfl_up = ds_bpermute) -- it is on the chain of every latency-bound call
     uint32_t incl = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t o = __shfl_up(incl, d, 64);
-        if (lane >= (uint32_t)d) incl += o;
-    }
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, false);      // row_shr:1
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, false);      // row_shr:2
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, false);      // row_shr:4
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, false);      // row_shr:8
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2 and 3
     __syncthreads();   // protect lds reuse across calls
     if (lane == 63) lds[wave] = incl;
     __syncthreads();
@@ -442,8 +445,12 @@ __global__ __launch_bounds__(kBlock) void k_kmer_rows(
 // tuning builds only: per-workgroup timestamps of the phases of k_reads_fused / k_kmerize_lds (100 MHz wall clock), read by bigsi_hip_debug_phases
 __device__ uint64_t g_phase[1024 * 8];
 #define BIGSI_PHASE(i) do { if (threadIdx.x == 0) g_phase[(blockIdx.x & 1023u) * 8 + (i)] = wall_clock64(); } while (0)
+#define BIGSI_PHASE_AT(group, i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_phase[(group) * 8 + (i)] = wall_clock64(); } while (0)
+#define BIGSI_PHASE_IF(cond, group, i) do { if (threadIdx.x == 0 && (cond)) g_phase[(group) * 8 + (i)] = wall_clock64(); } while (0)
 #else
 #define BIGSI_PHASE(i) do { } while (0)
+#define BIGSI_PHASE_AT(group, i) do { } while (0)
+#define BIGSI_PHASE_IF(cond, group, i) do { } while (0)
 #endif
 // K1 fused: ONE launch for batches whose longest query has at most kLdsMaxPos k-mer positions (a 4 kbp query; reads
 // and gene-length queries).  One workgroup per query; the sequence and the dedupe table live in LDS (ds_cmpst / ds_min
@@ -954,9 +961,12 @@ __global__ __launch_bounds__(1024) void k_and_exact(
 {
     const TileMap tm = map_block(blockIdx.x, q0, n_seqs, tiles, slices);
     if (!tm.valid) return;
+    BIGSI_PHASE_IF(blockIdx.x == 0, 1001, 0);
+    BIGSI_PHASE_IF(blockIdx.x == gridDim.x - 4, 1002, 0);
     const uint32_t w0 = (tm.tile * blockDim.x + threadIdx.x) * kVec;
     if (w0 >= wv) return;
     const uint64_t Rall = (uint64_t)num_unique[tm.q] * h;
+    BIGSI_PHASE_IF(blockIdx.x == 0, 1001, 1);
     const uint64_t per = (Rall + slices - 1) / slices;
     uint64_t r = (uint64_t)tm.slice * per;
     const uint64_t R = r + per < Rall ? r + per : Rall;
@@ -977,6 +987,8 @@ __global__ __launch_bounds__(1024) void k_and_exact(
     if (Rall == 0) acc = u64x2{0ull, 0ull};
     acc.x &= valid_mask(w0, n_cols);
     acc.y &= valid_mask(w0 + 1, n_cols);
+    BIGSI_PHASE_IF(blockIdx.x == 0 && (acc.x | 1ull), 1001, 2);
+    BIGSI_PHASE_IF(blockIdx.x == gridDim.x - 4 && (acc.x | 1ull), 1002, 2);
     uint64_t *o = out + (uint64_t)tm.q * out_stride_words + w0;
     if (slices > 1) {
         atomicAnd((unsigned long long *)o, (unsigned long long)acc.x);
@@ -1219,7 +1231,33 @@ __global__ __launch_bounds__(kBlock) void k_count_combine(
     for (int p = 0; p < P; p++) acc[p] = 0;
     const uint64_t slice_words = (uint64_t)planes_in * bm_stride;
     const uint64_t *base = partial + (uint64_t)q * slices * slice_words + w;
-    if (live_w) {
+    constexpr int KB = 12, PB = 4;
+    if (live_w && planes_in <= (uint32_t)PB && live <= (uint32_t)KB * G) {
+        // the usual shape of a latency-bound call (<= 96 slices of <= 15 k-mers each: 4 planes): ALL of the group's slices in one
+        // batch of loads -- one round trip where the loop below makes three
+        uint64_t x[KB][PB];
+#pragma unroll
+        for (int k = 0; k < KB; k++)
+#pragma unroll
+            for (int p = 0; p < PB; p++)
+                x[k][p] = (g + k * G < live && (uint32_t)p < planes_in) ? base[(uint64_t)(g + k * G) * slice_words + (uint64_t)p * bm_stride] : 0ull;
+#pragma unroll
+        for (int k = 0; k < KB; k++) {
+            uint64_t carry = 0;
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                const uint64_t a = acc[p];
+                if (p < PB) {
+                    const uint64_t t = a ^ x[k][p < PB ? p : 0];
+                    acc[p] = t ^ carry;
+                    carry = (a & x[k][p < PB ? p : 0]) | (carry & t);
+                } else {
+                    acc[p] = a ^ carry;
+                    carry &= a;
+                }
+            }
+        }
+    } else if (live_w) {
         for (uint32_t s0 = g; s0 < live; s0 += 4 * G) {
             uint64_t x[4][P];
 #pragma unroll
@@ -1378,6 +1416,11 @@ __global__ __launch_bounds__(kBlock) void k_hits_write(
         // CONSECUTIVE words of a query -- all its loads in flight together, one scan per query instead of one per 256 words
         // (7.5 -> ~4 us for one query on 100 k samples)
         uint64_t base = 0;
+        BIGSI_PHASE_AT(1000, 0);
+        // (the block's header numbers: fetched now, beside the words -- behind the scans they were a round trip of their own, 1.5 us)
+        uint32_t hdr = 0;
+        const bool hdr_early = 3u * n_seqs <= kBlock;                                 // (a handful of queries: always)
+        if (exp_out && hdr_early && threadIdx.x < 3u * n_seqs) hdr = exp_uniq[threadIdx.x];
         for (uint32_t q = 0; q < n_seqs; q++) {
             const uint32_t w_first = threadIdx.x * chunks;
             uint64_t bits[16];
@@ -1389,7 +1432,9 @@ __global__ __launch_bounds__(kBlock) void k_hits_write(
                 cnt += (uint32_t)__popcll(bits[j]);
             }
             uint32_t tot;
+            BIGSI_PHASE_AT(1000, 1);
             const uint32_t pre = block_exclusive_scan(cnt, &tot, lds);
+            BIGSI_PHASE_AT(1000, 2);
             if (threadIdx.x == 0) {
                 hit_off[q] = base;
                 if (exp_out) exp_out[q] = base;
@@ -1416,14 +1461,20 @@ __global__ __launch_bounds__(kBlock) void k_hits_write(
                 }
             }
         }
+        BIGSI_PHASE_AT(1000, 3);
         if (threadIdx.x == 0) hit_off[n_seqs] = base;
         if (exp_out) {
             if (threadIdx.x == 0) { exp_out[n_seqs] = base; exp_out[n_seqs + 1] = 0; }
             uint32_t *o32 = reinterpret_cast<uint32_t *>(exp_out + n_seqs + 2u);
-            for (uint32_t i = threadIdx.x; i < 3u * n_seqs; i += kBlock) o32[i] = exp_uniq[i];
+            if (!hdr_early)
+                for (uint32_t i = threadIdx.x; i < 3u * n_seqs; i += kBlock) o32[i] = exp_uniq[i];
+            else if (threadIdx.x < 3u * n_seqs) o32[threadIdx.x] = hdr;
+            BIGSI_PHASE_AT(1000, 4);
             __threadfence_system();
+            BIGSI_PHASE_AT(1000, 5);
             __syncthreads();
             if (threadIdx.x == 0) *exp_flag = exp_serial;
+            BIGSI_PHASE_AT(1000, 6);
         }
         return;
     }
