@@ -47,6 +47,10 @@ run ${R}_scored_stream   -- python scripts/scored_stream_probe.py
 python scripts/call_breakdown.py > $P/${R}_call_breakdown.txt 2>/dev/null
 BIGSI_HIP_LIB=$PWD/bigsi_amd/libbigsi_hip_tuning.so python scripts/call_breakdown.py 2>/dev/null | grep "inside the call" > $P/${R}_call_trace.txt      # host clock inside the one-call entry point (tuning build)
 BIGSI_HIP_LIB=$PWD/bigsi_amd/libbigsi_hip_tuning.so python scripts/ab_k1_phases.py > $P/${R}_k1_phases.txt 2>/dev/null
+BIGSI_HIP_LIB=$PWD/bigsi_amd/libbigsi_hip_tuning.so python scripts/ab_k1_phases.py 0.4 >> $P/${R}_k1_phases.txt 2>/dev/null
+# the device timeline of a one-call search of one 1 kbp query (kernel durations and gaps), exact and at 0.4
+( export TMPDIR=/tmp; mkdir -p $P/tl; rocprofv3 --kernel-trace --output-format csv -d $P/tl -o t -- python scripts/one_call_timeline.py run > $P/tl_run.log 2>&1
+  python scripts/one_call_timeline.py report $P/tl > $P/${R}_one_call_timeline.txt 2>&1 )
 scripts/probe/latency_probe > $P/${R}_latency_probe.txt 2>&1
 python scripts/frontend_probe.py > $P/${R}_frontend_probe.json 2>/dev/null
 # round 5: file <-> HBM (striped snapshot, one-file save for comparison, two-shard group), importers, the tmpfs write probe, the dict builder
