@@ -1417,7 +1417,8 @@ __global__ __launch_bounds__(kBlock) void k_hits_write(
         // (7.5 -> ~4 us for one query on 100 k samples)
         uint64_t base = 0;
         BIGSI_PHASE_AT(1000, 0);
-        // (the block's header numbers: fetched now, beside the words -- behind the scans they were a round trip of their own, 1.5 us)
+        // (the block's header numbers: fetched now, beside the words, not in a round trip of their own behind the scans.  What remains of
+        // this route's tail is the system-scope release before the flag: 1.5 us by the stamps -- the posted writes' acknowledgement)
         uint32_t hdr = 0;
         const bool hdr_early = 3u * n_seqs <= kBlock;                                 // (a handful of queries: always)
         if (exp_out && hdr_early && threadIdx.x < 3u * n_seqs) hdr = exp_uniq[threadIdx.x];

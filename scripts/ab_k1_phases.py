@@ -37,7 +37,7 @@ a = np.median(np.array(acc), axis=0)
 names = ["table + sequence in", "fingerprints", "insert", "resolve + scan + hash + rows out", "sort (off)", "pos_unique"]
 print({"threshold": thr, "phases_us": {n_: round(float(x), 2) for n_, x in zip(names, a)}, "sum_us": round(float(a.sum()), 2)})
 a4 = np.median(np.array(acc4), axis=0)
-names4 = ["words in", "scan", "hits out", "block header", "system fence", "barrier + flag"]
+names4 = ["words in", "scan", "hits out", "block header (stores issued)", "system fence (incl. waiting for the stores)", "barrier + flag"]
 print({"k_hits_write_us": {n_: round(float(x), 2) for n_, x in zip(names4, a4)}, "sum_us": round(float(a4.sum()), 2),
        "end of K1 -> start of K4 (the row kernel and two launch boundaries)": round(float(np.median(between)), 2)})
 st.delete_all()
