@@ -142,8 +142,9 @@ PyObject *build(PyObject *, PyObject *args)
 //     not reproducible by libm bit for bit, so they stay numpy's (scoring.score_transcendentals);
 //   * "kmer-presence": the hit's n bits (bitarray order: position p = byte p / 8, mask 0x80 >> p % 8) -> n characters, 8 at a
 //     time through a 256-entry table, written into the new str's own body;
-//   * the dict is a COPY of a 22-key template (one allocation + memcpy of the key table: CPython clones a combined table whose
-//     entries are all live) whose values are then replaced in key order -- no probing for free slots, no growth;
+//   * the dict is a COPY of a 22-key template whose values are then replaced in key order -- no probing for free slots, no growth.
+//     On CPython 3.10 the template is a split-table dict (the copies share its key table and own a values array each: see
+//     split_template below); elsewhere a combined one (one allocation + memcpy of the key table per copy);
 //   * small non-negative integers (lengths, identities, mismatch counts: < 2^14 for anything up to 16 kbp) come from a table of
 //     ready-made int objects.
 // build_scored(nu, off, cols, cnts, exact, names, keys, rec, bits, boff, trans, db_size_unused, lo, hi)
@@ -162,6 +163,7 @@ PyObject *build(PyObject *, PyObject *args)
 struct KeyEntry310 { Py_hash_t me_hash; PyObject *me_key; PyObject *me_value; };
 struct Keys310 { Py_ssize_t dk_refcnt, dk_size; void *dk_lookup; Py_ssize_t dk_usable, dk_nentries; char dk_indices[1]; };
 bool g_fast_dict = true;           // _results.fast_dict(False) switches it off (A/B, tests)
+bool g_split_dict = true;          // _results.fast_dict(True, False): direct stores into copies of a combined template (A/B, tests)
 
 // the 22 value slots of `d` (a fresh PyDict_Copy of the template), or nullptr if the table is not what is expected
 inline KeyEntry310 *entries_of(PyObject *d, PyObject *const *k)
@@ -174,6 +176,77 @@ inline KeyEntry310 *entries_of(PyObject *d, PyObject *const *k)
     for (int i = 0; i < 22; i++)
         if (e[i].me_key != k[i] || e[i].me_value != Py_None) return nullptr;
     return e;
+}
+
+// ---- the template as a SPLIT-table dict (CPython 3.10 only, verified like the above).  Copying a combined 22-key dict clones a
+// 1.1 KB key table (malloc + memcpy, and a free when the dict dies): 1.2 us + 0.6 us per dict in a plain Python loop.  The dicts of a
+// class's instances share ONE key table and own only their values array (42 pointers, from the small-object allocator): 0.32 + 0.08 us.
+// PyDict_Copy keeps that sharing, so the template is the __dict__ of an instance of a private class whose 22 attributes are the result
+// keys, set in order; every result dict is then a copy of it -- a real dict in every respect (a consumer that adds a key extends the
+// shared table or converts that one dict, as for any instance dict) -- and the values go straight into its values array.  The
+// template is untracked by the collector (it holds None and strs only, and so do its copies until a consumer stores something else):
+// what CPython itself does to such dicts at its next collection.
+PyObject *g_split_obj = nullptr;                 // the instance; its __dict__ is the template
+PyObject *g_split_keys[22];                      // the keys it was made for (strong references)
+PyObject *g_split_interned[22];                  // the key objects the shared table actually holds (borrowed from it)
+
+// new reference to the split template for these keys, or nullptr (no error set): the caller then takes the combined route
+PyObject *split_template(PyObject *const *k)
+{
+    bool same = g_split_obj != nullptr;
+    for (int i = 0; i < 22 && same; i++)
+        if (g_split_keys[i] != k[i]) {
+            const int eq = PyObject_RichCompareBool(g_split_keys[i], k[i], Py_EQ);
+            if (eq != 1) { same = false; PyErr_Clear(); }
+        }
+    if (!same) {
+        Py_CLEAR(g_split_obj);
+        for (int i = 0; i < 22; i++) {
+            if (!PyUnicode_Check(k[i])) return nullptr;
+            Py_XDECREF(g_split_keys[i]);
+            g_split_keys[i] = nullptr;
+        }
+        PyObject *type = PyObject_CallFunction(reinterpret_cast<PyObject *>(&PyType_Type), "s(){}", "_ScoredHit");
+        PyObject *obj = type ? PyObject_CallObject(type, nullptr) : nullptr;
+        Py_XDECREF(type);
+        if (!obj) { PyErr_Clear(); return nullptr; }
+        for (int i = 0; i < 22; i++)
+            if (PyObject_SetAttr(obj, k[i], Py_None) != 0) { PyErr_Clear(); Py_DECREF(obj); return nullptr; }
+        g_split_obj = obj;
+        for (int i = 0; i < 22; i++) { Py_INCREF(k[i]); g_split_keys[i] = k[i]; g_split_interned[i] = nullptr; }
+    }
+    PyObject *d = PyObject_GenericGetDict(g_split_obj, nullptr);
+    if (!d) { PyErr_Clear(); return nullptr; }
+    PyDictObject *mp = reinterpret_cast<PyDictObject *>(d);
+    bool ok = PyDict_CheckExact(d) && mp->ma_values != nullptr && mp->ma_used == 22;
+    if (ok) {
+        Keys310 *keys = reinterpret_cast<Keys310 *>(mp->ma_keys);
+        ok = keys->dk_size == 64 && keys->dk_nentries >= 22;
+        KeyEntry310 *e = reinterpret_cast<KeyEntry310 *>(keys->dk_indices + keys->dk_size);
+        for (int i = 0; i < 22 && ok; i++) {
+            if (!g_split_interned[i]) {            // first use: entry i must hold key i (an interned equal of it)
+                ok = e[i].me_key == k[i] || PyObject_RichCompareBool(e[i].me_key, k[i], Py_EQ) == 1;
+                if (ok) g_split_interned[i] = e[i].me_key;
+            } else {
+                ok = e[i].me_key == g_split_interned[i];
+            }
+            ok = ok && mp->ma_values[i] == Py_None;
+        }
+        PyErr_Clear();
+    }
+    if (!ok) { Py_DECREF(d); Py_CLEAR(g_split_obj); return nullptr; }
+    if (PyObject_GC_IsTracked(d)) PyObject_GC_UnTrack(d);
+    return d;
+}
+
+// the values array of `d` (a fresh PyDict_Copy of the split template `tmpl`), or nullptr if it is not what is expected
+inline PyObject **values_of(PyObject *d, PyObject *tmpl)
+{
+    PyDictObject *mp = reinterpret_cast<PyDictObject *>(d);
+    if (mp->ma_values == nullptr || mp->ma_keys != reinterpret_cast<PyDictObject *>(tmpl)->ma_keys || mp->ma_used != 22) return nullptr;
+    for (int i = 0; i < 22; i++)
+        if (mp->ma_values[i] != Py_None) return nullptr;
+    return mp->ma_values;
 }
 #else
 #define BIGSI_FAST_DICT 0
@@ -258,18 +331,22 @@ PyObject *build_scored(PyObject *, PyObject *args)
     if (!g_lut_ready) lut_init();
     PyObject *k[22];
     for (int i = 0; i < 22; i++) k[i] = PyTuple_GET_ITEM(keys, i);
-    PyObject *tmpl = PyDict_New();
-    if (!tmpl) return nullptr;
-    for (int i = 0; i < 22; i++)
-        if (PyDict_SetItem(tmpl, k[i], Py_None) != 0) { Py_DECREF(tmpl); return nullptr; }
+    PyObject *tmpl = nullptr;
+#if BIGSI_FAST_DICT
+    static const bool is_310 = strncmp(Py_GetVersion(), "3.10.", 5) == 0;
+    const bool fast = g_fast_dict && is_310;
+    const bool split = fast && g_split_dict && (tmpl = split_template(k)) != nullptr;
+#endif
+    if (!tmpl) {
+        tmpl = PyDict_New();
+        if (!tmpl) return nullptr;
+        for (int i = 0; i < 22; i++)
+            if (PyDict_SetItem(tmpl, k[i], Py_None) != 0) { Py_DECREF(tmpl); return nullptr; }
+    }
     PyObject *out = PyList_New(hi - lo);
     if (!out) { Py_DECREF(tmpl); return nullptr; }
     std::vector<int64_t> order;
     bool ok = true;
-#if BIGSI_FAST_DICT
-    static const bool is_310 = strncmp(Py_GetVersion(), "3.10.", 5) == 0;
-    const bool fast = g_fast_dict && is_310;
-#endif
     for (Py_ssize_t i = lo; i < hi && ok; i++) {
         const uint32_t u = p_nu[i];
         order.clear();
@@ -294,11 +371,17 @@ PyObject *build_scored(PyObject *, PyObject *args)
             if (!d) { ok = false; break; }
             PyList_SET_ITEM(res, (Py_ssize_t)r, d);
 #if BIGSI_FAST_DICT
-            KeyEntry310 *slots = fast ? entries_of(d, k) : nullptr;
+            PyObject **vals = split ? values_of(d, tmpl) : nullptr;
+            KeyEntry310 *slots = (fast && !split) ? entries_of(d, k) : nullptr;
 #endif
             auto put = [&](int kk, PyObject *v) {      // steals v
                 if (!v) { ok = false; return; }
 #if BIGSI_FAST_DICT
+                if (vals) {                             // values[kk] belongs to key kk and holds None: the value takes its place
+                    vals[kk] = v;
+                    Py_DECREF(Py_None);
+                    return;
+                }
                 if (slots) {                            // entry kk holds key kk and None: the value takes None's place
                     slots[kk].me_value = v;
                     Py_DECREF(Py_None);
@@ -399,10 +482,11 @@ PyObject *pack_rows(PyObject *, PyObject *args)
 // fast_dict(on) -> bool: switch the direct-store route of build_scored on / off (tests, A/B); returns whether it is compiled in and active
 PyObject *fast_dict(PyObject *, PyObject *args)
 {
-    int on = -1;
-    if (!PyArg_ParseTuple(args, "|p", &on)) return nullptr;
+    int on = -1, split = -1;
+    if (!PyArg_ParseTuple(args, "|pp", &on, &split)) return nullptr;
 #if BIGSI_FAST_DICT
     if (on >= 0) g_fast_dict = on != 0;
+    if (split >= 0) g_split_dict = split != 0;
     return PyBool_FromLong(g_fast_dict && strncmp(Py_GetVersion(), "3.10.", 5) == 0);
 #else
     Py_RETURN_FALSE;
@@ -423,7 +507,7 @@ PyObject *ascii_str(PyObject *, PyObject *args)
 
 PyMethodDef methods[] = {{"build", build, METH_VARARGS, "result dicts of the sequences [lo, hi) of a streaming search (see _results.cpp)"},
                          {"build_scored", build_scored, METH_VARARGS, "the same for score=True, from K6's records and presence bits"},
-                         {"fast_dict", fast_dict, METH_VARARGS, "fast_dict([on]) -> whether build_scored stores values straight into the copied dict's entries (CPython 3.10)"},
+                         {"fast_dict", fast_dict, METH_VARARGS, "fast_dict([on[, split]]) -> whether build_scored stores values straight into the copied dict (CPython 3.10); split: copies of a split-table template (default) or of a combined one"},
                          {"pack_rows", pack_rows, METH_VARARGS, "rows (list of bytes) -> uint8[n, rb] block, cut / zero-extended, threaded, without the GIL"},
                          {"ascii_str", ascii_str, METH_VARARGS, "(str of n ASCII characters to be filled, address of its body)"},
                          {nullptr, nullptr, 0, nullptr}};

@@ -119,30 +119,56 @@ def test_a_colour_without_a_name_on_the_exact_route_is_the_python_loops_keyerror
 
 @pytest.mark.parametrize("threshold", [1.0, 0.4])
 def test_direct_value_stores_give_the_same_dicts(threshold):
-    """build_scored's CPython-3.10 route (values stored straight into the copied template's entries, after a read-only check of the
-    table) against its own PyDict_SetItem route: equal dicts, equal key order and value types, and the dicts stay ordinary dicts
-    (they can be changed, grown past their table, serialised)."""
+    """build_scored's CPython-3.10 routes -- values stored straight into a copy of a split-table template (the default: the copies share
+    one key table), or of a combined template (fast_dict(True, False)) -- against its own PyDict_SetItem route: equal dicts, equal key
+    order and value types, and the dicts stay ordinary dicts: they can be changed, grown past their table, shrunk, serialised, copied,
+    without a trace in the dicts built before or after them."""
+    import copy
+    import gc
     import json
+    import pickle
     ext = bigsi_mod._results
     was = ext.fast_dict()
     rng = np.random.default_rng(11)
     nk, nu, off, col, cnt, bits, boff, rec = payload(rng, 400, True, threshold)
     names = [None if n_ == DELETION_SPECIAL_SAMPLE_NAME else n_ for n_ in NAMES]
+    build = lambda: list(bigsi_mod.native_result_lists(nk, nu, off.astype(np.int64), col, cnt, threshold == 1.0, names, (rec, bits, boff), NS))      # noqa: E731
     out = {}
     try:
-        for on in (True, False):
-            ext.fast_dict(on)
-            out[on] = list(bigsi_mod.native_result_lists(nk, nu, off.astype(np.int64), col, cnt, threshold == 1.0, names, (rec, bits, boff), NS))
+        for route in ((True, True), (True, False), (False, False)):
+            ext.fast_dict(*route)
+            out[route] = build()
+        ext.fast_dict(True, True)
+        a, b = out[(True, True)], out[(False, False)]
+        assert a == b == out[(True, False)] and sum(len(r) for r in a) > 100
+        for ra, rm, rb in zip(a, out[(True, False)], b):
+            for da, dm, db in zip(ra, rm, rb):
+                assert type(da) is dict and list(da) == list(dm) == list(db) and len(da) == 22
+                assert [type(v) for v in da.values()] == [type(v) for v in dm.values()] == [type(v) for v in db.values()]
+        assert json.dumps(a) == json.dumps(b) and pickle.loads(pickle.dumps(a)) == b and copy.deepcopy(a) == b
+        flat = [d_ for r in a for d_ in r]
+        d, e, f = flat[0], flat[1], flat[2]
+        before_e, before_f = dict(e), dict(f)
+        for i in range(100):
+            d["extra%d" % i] = i                # grows past the shared 64-slot table: that dict gets a table of its own
+        del d["score"]
+        assert len(d) == 121 and "score" not in d and d["extra99"] == 99 and list(d)[:3] == ["percent_kmers_found", "num_kmers", "num_kmers_found"]
+        e["one_more"] = 1                       # (a key added to ONE dict of a shared table)
+        assert list(e)[-1] == "one_more" and len(e) == 23 and f == before_f and "one_more" not in f and len(f) == 22
+        del e["one_more"]
+        assert e == before_e and list(e) == list(before_e)
+        f.pop("kmer-presence")
+        f.update(kmer_presence="x")
+        assert len(f) == 22 and list(f)[-1] == "kmer_presence"
+        gc.collect()
+        # dicts built AFTER consumers changed earlier ones: the same as ever (the template is the library's own, never handed out)
+        again = build()
+        assert again == b
+        for r in again:
+            for d_ in r:
+                assert list(d_) == list(b[0][0] if b[0] else d_) or len(d_) == 22
+                assert "one_more" not in d_ and "extra0" not in d_ and len(d_) == 22
+        # and they do not burden the collector: no cycles possible, not tracked (like the dicts of the other routes)
+        assert not any(gc.is_tracked(d_) for r in again for d_ in r)
     finally:
-        ext.fast_dict(was)
-    a, b = out[True], out[False]
-    assert a == b and sum(len(r) for r in a) > 100
-    for ra, rb in zip(a, b):
-        for da, db in zip(ra, rb):
-            assert list(da) == list(db) and [type(v) for v in da.values()] == [type(v) for v in db.values()] and len(da) == 22
-    assert json.dumps(a) == json.dumps(b)
-    d = next(d_ for r in a for d_ in r)
-    for i in range(100):
-        d["extra%d" % i] = i                # grows past the 64-slot table: an ordinary resize
-    del d["score"]
-    assert len(d) == 121 and "score" not in d and d["extra99"] == 99 and list(d)[:3] == ["percent_kmers_found", "num_kmers", "num_kmers_found"]
+        ext.fast_dict(was, True)
