@@ -908,7 +908,11 @@ def test_device_build_paths(hip):
 
 
 @pytest.mark.parametrize("k,lens", [(31, [31, 61, 500, 4126]), (31, [4127, 100]), (5, [5, 4100, 9, 4]), (33, [33, 2000, 40]),
-                                    (31, [31, 61, 94, 40, 30, 93]), (4, [4, 10, 67, 5, 3, 66]), (1, [64, 1, 2])])
+                                    (31, [31, 61, 94, 40, 30, 93]), (4, [4, 10, 67, 5, 3, 66]), (1, [64, 1, 2]),
+                                    # a handful of queries of 256 .. 1024 positions: K1 runs as 8 workgroups per query (dedupe replicated,
+                                    # hashing shared out) -- and on both sides of that window
+                                    (31, [1000, 500, 286]), (31, [1054]), (31, [1055]), (31, [286] + [900] * 31), (31, [285, 100]),
+                                    (5, [900, 260, 9]), (33, [1054, 300, 33]), (21, [1044, 1044, 20])])
 def test_k1_fused_lds_equals_global_path(hip, k, lens):
     """K1 has three routes -- one wavefront per query (all queries <= 64 positions), one fused launch with the dedupe table
     in LDS (all queries <= 4096 positions) and the four-kernel global-table route (longer queries, or forced by
