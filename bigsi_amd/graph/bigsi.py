@@ -425,7 +425,7 @@ class BIGSI(SampleMetadata, KmerSignatureIndex):
             # (a 1 kbp query against a 125 GB index: 35 us in the C call against ~90 through the batch object)
             from .. import _lib
             flags = _lib.RUN_EARLY_EXIT if self.config.get("early_exit", False) else 0
-            nk, nu, off, colours, counts = self.storage.search_batch_arrays(seqs, self.kmer_size, threshold, flags)
+            nk, nu, off, colours, counts = self.storage.search_batch_arrays(seqs, self.kmer_size, threshold, flags, borrow=True)
             return self._collect_end(self._check_degenerate(None, len(seqs), threshold, nk, nu, off, colours, counts))
         batch = self._workspace(0, seqs)
         self._launch(batch, threshold)

@@ -32,6 +32,7 @@ import os
 import re
 import shutil
 import struct
+import threading
 import weakref
 
 import numpy as np
@@ -234,11 +235,13 @@ class TooManyHits(Exception):
 class HipHbmStorage(BaseStorage):
     fused = True      # BIGSI.search/lookup may call search_batch / lookup_kmers
     _search_cap = 1 << 12     # hit entries search_batch brings buffers for (grows to what a call needed)
+    _one_ws = None            # search_batch_arrays: the argument arrays of single-query calls and their addresses
     _bits_cap = 1 << 16       # bytes of presence bits search_many_scored brings a buffer for
 
     def __init__(self, storage_config=None):
         self.storage_config = dict(storage_config or {})
         self.name = self.storage_config.get("name", "default")
+        self._one_lock = threading.Lock()
         _lib.lib()    # fail loudly, here, if the HIP library has not been built
         res = _RESIDENT.get(self.name)
         if res is not None and self.storage_config.get("replace"):
@@ -500,11 +503,39 @@ class HipHbmStorage(BaseStorage):
         o, e_col, e_cnt = off.tolist(), col[:0], cnt[:0]
         return [(k_, u_, col[x:y], cnt[x:y]) if y > x else (k_, u_, e_col, e_cnt) for k_, u_, x, y in zip(nk.tolist(), nu.tolist(), o, o[1:])]
 
-    def search_batch_arrays(self, seqs, k, threshold=1.0, flags=0):
+    def search_batch_arrays(self, seqs, k, threshold=1.0, flags=0, borrow=False):
         """The same call with its results as the C ABI leaves them: (num_kmers uint32[n], num_unique uint32[n], hit offsets
         uint64[n + 1], colours uint32[hits], counts uint32[hits]).  BIGSI.search / search_batch take this route for unscored
-        queries: one C call (bigsi_hip_search_batch) instead of reload + run + two fetches."""
+        queries: one C call (bigsi_hip_search_batch) instead of reload + run + two fetches.  `borrow`: the arrays of a single-query
+        call may be views of buffers this object keeps for the next such call (for a caller that is done with them before it calls
+        again: BIGSI.search, under its lock)."""
         n = len(seqs)
+        if n == 1 and type(seqs[0]) is str and not self.res.is_group and self._one_lock.acquire(False):
+            # ONE query -- the latency-bound call: its argument arrays and their addresses are kept between calls (numpy's
+            # .ctypes.data is ~1 us per pointer, fresh zeroed outputs another 2: together a third of what the C call itself takes)
+            try:
+                ws = self._one_ws
+                if ws is None or ws[0] != self._search_cap:
+                    cap = self._search_cap
+                    arrs = (np.zeros(2, np.uint64), np.zeros(1, np.uint32), np.zeros(1, np.uint32), np.zeros(2, np.uint64), np.zeros(cap, np.uint32), np.zeros(cap, np.uint32))
+                    ws = self._one_ws = (cap, arrs, tuple(_lib.ptr(a) for a in arrs), _lib.lib().bigsi_hip_search_batch)
+                cap, (soff, nk, nu, off, col, cnt), (p_soff, p_nk, p_nu, p_off, p_col, p_cnt), fn = ws
+                try:
+                    blob = seqs[0].encode("ascii")
+                except UnicodeEncodeError:
+                    raise ValueError("query sequences must be ASCII for the hip-hbm backend")
+                soff[1] = len(blob)
+                rc = fn(self.handle, blob, p_soff, 1, int(k), float(threshold), int(flags), p_nk, p_nu, None, p_off, p_col, p_cnt, cap)
+                if rc == _lib.OK:
+                    h = int(off[1])
+                    if borrow:
+                        return nk, nu, off, col[:h], cnt[:h]
+                    return nk.copy(), nu.copy(), off.copy(), col[:h].copy(), cnt[:h].copy()
+                if rc != _lib.ERR_CAPACITY or int(off[1]) <= cap:
+                    check(rc)
+                self._search_cap = int(off[1])            # more hits than the buffers hold: the general route below brings that many
+            finally:
+                self._one_lock.release()
         # the C ABI's one-call entry point (bigsi_hip_search_batch / bigsi_hip_group_search_batch): the index keeps the
         # workspace, so a call is two uploads, the kernels and three downloads -- no device allocation
         blob, soff = _lib.pack_seqs(seqs)

@@ -1565,6 +1565,50 @@ def test_storage_search_batch_entry_point(hip):
         b.delete()
 
 
+def test_single_query_arrays_route_keeps_its_buffers_between_calls(hip):
+    """HipHbmStorage.search_batch_arrays with ONE str query (what BIGSI.search calls): the argument arrays and their addresses are
+    kept between calls.  Same numbers as the general route (a bytes query, a pair), results handed out are copies unless the caller
+    borrows them, a query with more hits than the kept buffers hold grows them, non-ASCII text is refused as everywhere."""
+    m, n_cols, h = 200003, 5000, 3
+    _, st = synth_index(hip, m, n_cols, h, 99)
+    st._search_cap = 64                                  # (small on purpose: the regrow path below)
+    st._one_ws = None
+    rng = np.random.default_rng(5)
+    qs = ["".join(rng.choice(list("ACGT"), size=L)) for L in (61, 1000, 31, 300, 30)]
+    for i, q in enumerate(qs[:3]):
+        for c in rng.choice(n_cols, size=3 + i, replace=False):
+            st.insert_kmers(int(c), [q], 31)
+    kept = []
+    for rounds in range(2):
+        for thr in (1.0, 0.5):
+            for q in qs:
+                one = st.search_batch_arrays([q], 31, thr)
+                gen = st.search_batch_arrays([q.encode()], 31, thr)          # (bytes: the general route)
+                pair = st.search_batch_arrays([q, qs[0]], 31, thr)
+                for a, b_ in zip(one, gen):
+                    assert a.dtype == b_.dtype and np.array_equal(a, b_)
+                assert one[0][0] == pair[0][0] and one[1][0] == pair[1][0] and np.array_equal(one[3], pair[3][: int(pair[2][1])])
+                kept.append((q, thr, [a.copy() for a in one], one))
+    for q, thr, snap, handed in kept:                      # copies: later calls did not change what earlier ones returned
+        for a, b_ in zip(snap, handed):
+            assert np.array_equal(a, b_)
+    assert sum(len(x[2][3]) for x in kept) >= 2 * (3 + 4 + 5)
+    b1 = st.search_batch_arrays([qs[0]], 31, 1.0, borrow=True)
+    want = [a.copy() for a in st.search_batch_arrays([qs[1]], 31, 1.0)]
+    b2 = st.search_batch_arrays([qs[1]], 31, 1.0, borrow=True)
+    assert b1[0] is b2[0] and all(np.array_equal(a, w) for a, w in zip(b2, want))      # borrowed: the kept buffers themselves
+    # more hits than the kept buffers hold (64): threshold 0 returns every sample
+    nk, nu, off, col, cnt = st.search_batch_arrays([qs[3]], 31, 0.0)
+    assert int(off[1]) == n_cols and np.array_equal(col, np.arange(n_cols)) and st._search_cap >= n_cols
+    nk2, nu2, off2, col2, cnt2 = st.search_batch_arrays([qs[3]], 31, 0.0)             # ... and the next call has buffers of that size
+    assert np.array_equal(col2, col) and np.array_equal(cnt2, cnt) and st._one_ws[0] >= n_cols
+    with pytest.raises(ValueError):
+        st.search_batch_arrays(["ACGT" * 10 + "\u00e9"], 31, 1.0)
+    nk, nu, off, col, cnt = st.search_batch_arrays([qs[4]], 31, 1.0)                    # shorter than k: no k-mers, no hits
+    assert nk[0] == 0 and nu[0] == 0 and int(off[1]) == 0
+    st.delete_all()
+
+
 def test_transpose_on_device_matches_numpy(hip):
     from bigsi_amd import BitRow
     from bigsi_amd.matrix.transpose import transpose, transpose_packed
