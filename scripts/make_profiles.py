@@ -69,6 +69,9 @@ def stamp():
         out["libbigsi_hip_so_sha256"] = hashlib.sha256(open(so, "rb").read()).hexdigest()
     except OSError:
         pass
+    import glob
+    for ext in sorted(glob.glob(os.path.join(ROOT, "bigsi_amd", "_results*.so"))):       # the result-dict builder (host code: the dict rates)
+        out["results_ext_sha256"] = hashlib.sha256(open(ext, "rb").read()).hexdigest()
     return out
 
 
@@ -80,6 +83,7 @@ def main():
         ran = json.load(open(os.path.join(SRC, R + "_build.json")))
         st["ran_so_sha256"] = ran.get("so_sha256")
         assert ran.get("so_sha256") in (None, st.get("libbigsi_hip_so_sha256")), "the profiles were made with another build of libbigsi_hip.so than the one in the tree"
+        assert ran.get("results_ext_sha256") in (None, st.get("results_ext_sha256")), "the profiles were made with another build of bigsi_amd/_results than the one in the tree"
     except OSError:
         pass
     with open(os.path.join(DST, R + "_stamp.json"), "w") as f:

@@ -11,8 +11,9 @@ B="--cpu-seconds 0 --also none --host-visible 0 --alone-steps 0"      # (rocprof
 [ -f bigsi_amd/libbigsi_hip_tuning.so ] || bash bigsi_amd/csrc/build.sh tuning > /dev/null      # (two legs below A/B through it)
 run() { scripts/prof.sh "$@" > /dev/null; }
 python - <<PYEOF > $P/${R}_build.json
-import hashlib, json
-print(json.dumps({"so_sha256": hashlib.sha256(open("bigsi_amd/libbigsi_hip.so", "rb").read()).hexdigest()}))
+import glob, hashlib, json
+sha = lambda f: hashlib.sha256(open(f, "rb").read()).hexdigest()
+print(json.dumps({"so_sha256": sha("bigsi_amd/libbigsi_hip.so"), "results_ext_sha256": next((sha(f) for f in sorted(glob.glob("bigsi_amd/_results*.so"))), None)}))
 PYEOF
 run ${R}_c3_exact        -- python bench.py --steps 20 --warmup 5 $B
 run ${R}_c3_t04          -- python bench.py --steps 20 --warmup 5 $B --threshold 0.4
