@@ -195,7 +195,7 @@ def main():
     for name in (R + "_latency_probe.txt", R + "_frontend_probe.json", R + "_bench_default_full.json"):
         if os.path.exists(os.path.join(SRC, name)):
             shutil.copy(os.path.join(SRC, name), os.path.join(DST, name))
-    for name in (R + "_row_probe.txt", R + "_call_breakdown.txt", R + "_call_trace.txt", R + "_k1_phases.txt", R + "_one_call_timeline.txt", R + "_ingest.json", R + "_import.json", R + "_tmpfs_write_probe.txt",
+    for name in (R + "_row_probe.txt", R + "_call_breakdown.txt", R + "_call_trace.txt", R + "_k1_phases.txt", R + "_one_call_timeline.txt", R + "_python_stack_latency.txt", R + "_ingest.json", R + "_import.json", R + "_tmpfs_write_probe.txt",
                  R + "_bench_default.json", R + "_results_bench.txt"):
         if os.path.exists(os.path.join(SRC, name)):
             shutil.copy(os.path.join(SRC, name), os.path.join(DST, name))

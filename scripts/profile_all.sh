@@ -53,6 +53,7 @@ BIGSI_HIP_LIB=$PWD/bigsi_amd/libbigsi_hip_tuning.so python scripts/ab_k1_phases.
 ( export TMPDIR=/tmp; mkdir -p $P/tl; rocprofv3 --kernel-trace --output-format csv -d $P/tl -o t -- python scripts/one_call_timeline.py run > $P/tl_run.log 2>&1
   python scripts/one_call_timeline.py report $P/tl > $P/${R}_one_call_timeline.txt 2>&1 )
 scripts/probe/latency_probe > $P/${R}_latency_probe.txt 2>&1
+python scripts/latency_probe.py > $P/${R}_python_stack_latency.txt 2>&1      # BIGSI.search(seq): string in, the reference's dicts out
 python scripts/frontend_probe.py > $P/${R}_frontend_probe.json 2>/dev/null
 # round 5: file <-> HBM (striped snapshot, one-file save for comparison, two-shard group), importers, the tmpfs write probe, the dict builder
 python scripts/ingest_bench.py --gb 32 > $P/${R}_ingest.json 2>/dev/null
