@@ -27,7 +27,7 @@ def main():
     p.add_argument("--dir", default=None, help="where the snapshot goes (default: /dev/shm if it has room, else the system temp dir)")
     p.add_argument("--threads", type=int, default=0)
     p.add_argument("--sample-rows", type=int, default=64)
-    p.add_argument("--group-gb", type=float, default=8.0, help="size of the two-shard group whose snapshot is also written and loaded (0 = skip)")
+    p.add_argument("--group-gb", type=float, default=24.0, help="size of the two-shard group whose snapshot is also written and loaded (0 = skip)")
     a = p.parse_args()
     import tempfile
     from bigsi_amd import _lib
