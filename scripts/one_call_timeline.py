@@ -16,7 +16,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def run():
     from bigsi_amd import _lib
     from bigsi_amd.storage import get_storage
-    m, n_cols, h = int(os.environ.get("ROWS", 10_000_000)), 100_000, 4
+    reads = os.environ.get("MODE", "") == "reads"          # MODE=reads: 1000 x 61-mers in one call on the C2 index instead
+    m, n_cols, h = (1_000_000, 10_000, 3) if reads else (int(os.environ.get("ROWS", 10_000_000)), 100_000, 4)
     cfg = {"storage-engine": "hip-hbm", "storage-config": {"name": "tl", "max_cols": n_cols}, "k": 31, "m": m, "h": h}
     st = get_storage(cfg)
     st.delete_all()
@@ -25,13 +26,14 @@ def run():
     st.fill_synthetic(1, 0, 2)
     rng = np.random.default_rng(0)
     lut = np.frombuffer(b"ACGT", dtype=np.uint8)
-    sets = [[lut[r].tobytes().decode() for r in rng.integers(0, 4, size=(1, 1000), dtype=np.uint8)] for _ in range(8)]
+    nq, ql = (1000, 61) if reads else (1, 1000)
+    sets = [[lut[r].tobytes().decode() for r in rng.integers(0, 4, size=(nq, ql), dtype=np.uint8)] for _ in range(8)]
     packs = [_lib.pack_seqs(s_) for s_ in sets]
-    nk, nu, off = np.zeros(1, np.uint32), np.zeros(1, np.uint32), np.zeros(2, np.uint64)
+    nk, nu, off = np.zeros(nq, np.uint32), np.zeros(nq, np.uint32), np.zeros(nq + 1, np.uint64)
     col, cnt = np.zeros(1 << 16, np.uint32), np.zeros(1 << 16, np.uint32)
     fn = _lib.lib().bigsi_hip_search_batch
     for thr in (1.0, 0.4):
-        argv = [(st.handle, blob, _lib.ptr(soff), 1, 31, float(thr), 0, _lib.ptr(nk), _lib.ptr(nu), None, _lib.ptr(off), _lib.ptr(col), _lib.ptr(cnt), col.size) for blob, soff in packs]
+        argv = [(st.handle, blob, _lib.ptr(soff), nq, 31, float(thr), 0, _lib.ptr(nk), _lib.ptr(nu), None, _lib.ptr(off), _lib.ptr(col), _lib.ptr(cnt), col.size) for blob, soff in packs]
         ts = []
         for i in range(60):
             t0 = time.perf_counter()
