@@ -38,6 +38,114 @@ struct Column {
     bool is_float = false;
 };
 
+// ---- values written straight into a freshly copied dict's entry table (CPython 3.10 only, verified before every use)
+// PyDict_Copy of the 22-key template clones its combined key table: entry i holds key i, in insertion order.  Replacing the 22 values
+// through PyDict_SetItem costs 22 hash-table lookups per hit (0.26 of the 0.70 us a scored dict takes); the values can instead be
+// stored into the entries directly -- what insertdict does once it has found the slot -- IF the object layout is the one this code
+// was written against.  That layout (Objects/dict-common.h of CPython 3.10: PyDictKeysObject {dk_refcnt, dk_size, dk_lookup,
+// dk_usable, dk_nentries, dk_indices[]}, entries {me_hash, me_key, me_value} behind dk_size one-byte indices) is not public, so:
+// compiled only for 3.10, enabled only when the running interpreter says 3.10, and before each dict is touched its table is CHECKED
+// read-only (combined table, 64 slots, 22 entries, entry i's key IS key i); anything unexpected -> the PyDict_SetItem route.
+#if PY_VERSION_HEX >= 0x030A0000 && PY_VERSION_HEX < 0x030B0000
+#define BIGSI_FAST_DICT 1
+struct KeyEntry310 { Py_hash_t me_hash; PyObject *me_key; PyObject *me_value; };
+struct Keys310 { Py_ssize_t dk_refcnt, dk_size; void *dk_lookup; Py_ssize_t dk_usable, dk_nentries; char dk_indices[1]; };
+bool g_fast_dict = true;           // _results.fast_dict(False) switches it off (A/B, tests)
+bool g_split_dict = true;          // _results.fast_dict(True, False): direct stores into copies of a combined template (A/B, tests)
+
+// the 22 value slots of `d` (a fresh PyDict_Copy of the template), or nullptr if the table is not what is expected
+inline KeyEntry310 *entries_of(PyObject *d, PyObject *const *k)
+{
+    PyDictObject *mp = reinterpret_cast<PyDictObject *>(d);
+    if (mp->ma_values != nullptr || mp->ma_used != 22) return nullptr;                    // a split table, or not our template
+    Keys310 *keys = reinterpret_cast<Keys310 *>(mp->ma_keys);
+    if (keys->dk_size != 64 || keys->dk_nentries != 22 || keys->dk_refcnt != 1) return nullptr;      // (22 entries need 64 slots: one-byte indices)
+    KeyEntry310 *e = reinterpret_cast<KeyEntry310 *>(keys->dk_indices + keys->dk_size);
+    for (int i = 0; i < 22; i++)
+        if (e[i].me_key != k[i] || e[i].me_value != Py_None) return nullptr;
+    return e;
+}
+
+// ---- the template as a SPLIT-table dict (CPython 3.10 only, verified like the above).  Copying a combined 22-key dict clones a
+// 1.1 KB key table (malloc + memcpy, and a free when the dict dies): 1.2 us + 0.6 us per dict in a plain Python loop.  The dicts of a
+// class's instances share ONE key table and own only their values array (42 pointers, from the small-object allocator): 0.32 + 0.08 us.
+// PyDict_Copy keeps that sharing, so the template is the __dict__ of an instance of a private class whose 22 attributes are the result
+// keys, set in order (22 for scored hits, 4 for plain ones: two classes); every result dict is then a copy of it -- a real dict in every respect (a consumer that adds a key extends the
+// shared table or converts that one dict, as for any instance dict) -- and the values go straight into its values array.  The
+// template is untracked by the collector (it holds None and strs only, and so do its copies until a consumer stores something else):
+// what CPython itself does to such dicts at its next collection.
+struct SplitTemplate {
+    int n = 0;                                   // keys
+    Py_ssize_t dk_size = 0;                      // slots of the shared table a class of n attributes ends up with (one-byte indices)
+    PyObject *obj = nullptr;                     // the instance; its __dict__ is the template
+    PyObject *keys[22] = {};                     // the keys it was made for (strong references)
+    PyObject *interned[22] = {};                 // the key objects the shared table actually holds (borrowed from it)
+};
+SplitTemplate g_split22{22, 64}, g_split4{4, 8};
+
+// new reference to the split template for these keys, or nullptr (no error set): the caller then takes the combined route
+PyObject *split_template(SplitTemplate &T, PyObject *const *k)
+{
+    const int n = T.n;
+    bool same = T.obj != nullptr;
+    for (int i = 0; i < n && same; i++)
+        if (T.keys[i] != k[i]) {
+            const int eq = PyObject_RichCompareBool(T.keys[i], k[i], Py_EQ);
+            if (eq != 1) { same = false; PyErr_Clear(); }
+        }
+    if (!same) {
+        Py_CLEAR(T.obj);
+        for (int i = 0; i < n; i++) {
+            if (!PyUnicode_Check(k[i])) return nullptr;
+            Py_CLEAR(T.keys[i]);
+        }
+        PyObject *type = PyObject_CallFunction(reinterpret_cast<PyObject *>(&PyType_Type), "s(){}", n == 22 ? "_ScoredHit" : "_Hit");
+        PyObject *obj = type ? PyObject_CallObject(type, nullptr) : nullptr;
+        Py_XDECREF(type);
+        if (!obj) { PyErr_Clear(); return nullptr; }
+        for (int i = 0; i < n; i++)
+            if (PyObject_SetAttr(obj, k[i], Py_None) != 0) { PyErr_Clear(); Py_DECREF(obj); return nullptr; }
+        T.obj = obj;
+        for (int i = 0; i < n; i++) { Py_INCREF(k[i]); T.keys[i] = k[i]; T.interned[i] = nullptr; }
+    }
+    PyObject *d = PyObject_GenericGetDict(T.obj, nullptr);
+    if (!d) { PyErr_Clear(); return nullptr; }
+    PyDictObject *mp = reinterpret_cast<PyDictObject *>(d);
+    bool ok = PyDict_CheckExact(d) && mp->ma_values != nullptr && mp->ma_used == n;
+    if (ok) {
+        Keys310 *keys = reinterpret_cast<Keys310 *>(mp->ma_keys);
+        ok = keys->dk_size == T.dk_size && keys->dk_nentries >= n;
+        KeyEntry310 *e = reinterpret_cast<KeyEntry310 *>(keys->dk_indices + keys->dk_size);
+        for (int i = 0; i < n && ok; i++) {
+            if (!T.interned[i]) {                  // first use: entry i must hold key i (an interned equal of it)
+                ok = e[i].me_key == k[i] || PyObject_RichCompareBool(e[i].me_key, k[i], Py_EQ) == 1;
+                if (ok) T.interned[i] = e[i].me_key;
+            } else {
+                ok = e[i].me_key == T.interned[i];
+            }
+            ok = ok && mp->ma_values[i] == Py_None;
+        }
+        PyErr_Clear();
+    }
+    if (!ok) { Py_DECREF(d); Py_CLEAR(T.obj); return nullptr; }
+    if (PyObject_GC_IsTracked(d)) PyObject_GC_UnTrack(d);
+    return d;
+}
+
+// the values array of `d` (a fresh PyDict_Copy of the split template `tmpl` of n keys), or nullptr if it is not what is expected
+inline PyObject **values_of(PyObject *d, PyObject *tmpl, int n)
+{
+    PyDictObject *mp = reinterpret_cast<PyDictObject *>(d);
+    if (mp->ma_values == nullptr || mp->ma_keys != reinterpret_cast<PyDictObject *>(tmpl)->ma_keys || mp->ma_used != n) return nullptr;
+    for (int i = 0; i < n; i++)
+        if (mp->ma_values[i] != Py_None) return nullptr;
+    return mp->ma_values;
+}
+#else
+#define BIGSI_FAST_DICT 0
+#endif
+
+
 // build(nu, off, cols, cnts, exact, names, keys, columns, text, text_start, text_len, lo, hi) -> [results of sequence lo, ..., hi - 1]
 //   nu uint32[n], off int64[n + 1], cols / cnts uint32[hits]: what bigsi_hip_search_stream returns (hits of a sequence ascending by colour)
 //   names: list, names[c] = sample name of colour c, or None for a deleted sample (dropped); colours beyond the list are dropped on
@@ -80,6 +188,16 @@ PyObject *build(PyObject *, PyObject *args)
         p_tstart = static_cast<const int64_t *>(tstart.b.buf);
         p_tlen = static_cast<const int64_t *>(tlen.b.buf);
     }
+    // (plain hits, CPython 3.10: copies of a 4-key split-table template with the values stored straight into them, as build_scored)
+    PyObject *tmpl4 = nullptr;
+#if BIGSI_FAST_DICT
+    if (!scored && g_fast_dict && g_split_dict && strncmp(Py_GetVersion(), "3.10.", 5) == 0) {
+        PyObject *k4[4];
+        for (int i = 0; i < 4; i++) k4[i] = PyTuple_GET_ITEM(keys, i);
+        tmpl4 = split_template(g_split4, k4);
+    }
+#endif
+    struct Drop { PyObject *&o; ~Drop() { Py_XDECREF(o); } } drop_tmpl4{tmpl4};
     PyObject *out = PyList_New(hi - lo);
     if (!out) return nullptr;
     std::vector<int64_t> order;
@@ -102,12 +220,22 @@ PyObject *build(PyObject *, PyObject *args)
         for (size_t r = 0; r < order.size(); r++) {
             const int64_t t = order[r];
             const uint32_t f = exact ? u : p_cnt[t];
-            PyObject *d = _PyDict_NewPresized(n_keys);      // (no growth steps on the way to 22 keys)
+            PyObject *d = tmpl4 ? PyDict_Copy(tmpl4) : _PyDict_NewPresized(n_keys);      // (no growth steps on the way to 22 keys)
             if (!d) { Py_DECREF(py_u); Py_DECREF(out); return nullptr; }
             PyList_SET_ITEM(res, (Py_ssize_t)r, d);
             bool ok = true;
+#if BIGSI_FAST_DICT
+            PyObject **vals = tmpl4 ? values_of(d, tmpl4, 4) : nullptr;
+#endif
             auto put = [&](Py_ssize_t k, PyObject *v) {      // steals v
                 if (!v) { ok = false; return; }
+#if BIGSI_FAST_DICT
+                if (vals) {                                  // values[k] belongs to key k and holds None: the value takes its place
+                    vals[k] = v;
+                    Py_DECREF(Py_None);
+                    return;
+                }
+#endif
                 if (ok && PyDict_SetItem(d, PyTuple_GET_ITEM(keys, k), v) != 0) ok = false;
                 Py_DECREF(v);
             };
@@ -150,108 +278,6 @@ PyObject *build(PyObject *, PyObject *args)
 // build_scored(nu, off, cols, cnts, exact, names, keys, rec, bits, boff, trans, db_size_unused, lo, hi)
 //   rec: buffer of 64-byte records (HIT_SCORE_DTYPE), bits uint8[], boff uint64[hits + 1] (byte offsets, multiples of 8),
 //   trans: tuple of 4 float64 arrays over the hits
-// ---- values written straight into a freshly copied dict's entry table (CPython 3.10 only, verified before every use)
-// PyDict_Copy of the 22-key template clones its combined key table: entry i holds key i, in insertion order.  Replacing the 22 values
-// through PyDict_SetItem costs 22 hash-table lookups per hit (0.26 of the 0.70 us a scored dict takes); the values can instead be
-// stored into the entries directly -- what insertdict does once it has found the slot -- IF the object layout is the one this code
-// was written against.  That layout (Objects/dict-common.h of CPython 3.10: PyDictKeysObject {dk_refcnt, dk_size, dk_lookup,
-// dk_usable, dk_nentries, dk_indices[]}, entries {me_hash, me_key, me_value} behind dk_size one-byte indices) is not public, so:
-// compiled only for 3.10, enabled only when the running interpreter says 3.10, and before each dict is touched its table is CHECKED
-// read-only (combined table, 64 slots, 22 entries, entry i's key IS key i); anything unexpected -> the PyDict_SetItem route.
-#if PY_VERSION_HEX >= 0x030A0000 && PY_VERSION_HEX < 0x030B0000
-#define BIGSI_FAST_DICT 1
-struct KeyEntry310 { Py_hash_t me_hash; PyObject *me_key; PyObject *me_value; };
-struct Keys310 { Py_ssize_t dk_refcnt, dk_size; void *dk_lookup; Py_ssize_t dk_usable, dk_nentries; char dk_indices[1]; };
-bool g_fast_dict = true;           // _results.fast_dict(False) switches it off (A/B, tests)
-bool g_split_dict = true;          // _results.fast_dict(True, False): direct stores into copies of a combined template (A/B, tests)
-
-// the 22 value slots of `d` (a fresh PyDict_Copy of the template), or nullptr if the table is not what is expected
-inline KeyEntry310 *entries_of(PyObject *d, PyObject *const *k)
-{
-    PyDictObject *mp = reinterpret_cast<PyDictObject *>(d);
-    if (mp->ma_values != nullptr || mp->ma_used != 22) return nullptr;                    // a split table, or not our template
-    Keys310 *keys = reinterpret_cast<Keys310 *>(mp->ma_keys);
-    if (keys->dk_size != 64 || keys->dk_nentries != 22 || keys->dk_refcnt != 1) return nullptr;      // (22 entries need 64 slots: one-byte indices)
-    KeyEntry310 *e = reinterpret_cast<KeyEntry310 *>(keys->dk_indices + keys->dk_size);
-    for (int i = 0; i < 22; i++)
-        if (e[i].me_key != k[i] || e[i].me_value != Py_None) return nullptr;
-    return e;
-}
-
-// ---- the template as a SPLIT-table dict (CPython 3.10 only, verified like the above).  Copying a combined 22-key dict clones a
-// 1.1 KB key table (malloc + memcpy, and a free when the dict dies): 1.2 us + 0.6 us per dict in a plain Python loop.  The dicts of a
-// class's instances share ONE key table and own only their values array (42 pointers, from the small-object allocator): 0.32 + 0.08 us.
-// PyDict_Copy keeps that sharing, so the template is the __dict__ of an instance of a private class whose 22 attributes are the result
-// keys, set in order; every result dict is then a copy of it -- a real dict in every respect (a consumer that adds a key extends the
-// shared table or converts that one dict, as for any instance dict) -- and the values go straight into its values array.  The
-// template is untracked by the collector (it holds None and strs only, and so do its copies until a consumer stores something else):
-// what CPython itself does to such dicts at its next collection.
-PyObject *g_split_obj = nullptr;                 // the instance; its __dict__ is the template
-PyObject *g_split_keys[22];                      // the keys it was made for (strong references)
-PyObject *g_split_interned[22];                  // the key objects the shared table actually holds (borrowed from it)
-
-// new reference to the split template for these keys, or nullptr (no error set): the caller then takes the combined route
-PyObject *split_template(PyObject *const *k)
-{
-    bool same = g_split_obj != nullptr;
-    for (int i = 0; i < 22 && same; i++)
-        if (g_split_keys[i] != k[i]) {
-            const int eq = PyObject_RichCompareBool(g_split_keys[i], k[i], Py_EQ);
-            if (eq != 1) { same = false; PyErr_Clear(); }
-        }
-    if (!same) {
-        Py_CLEAR(g_split_obj);
-        for (int i = 0; i < 22; i++) {
-            if (!PyUnicode_Check(k[i])) return nullptr;
-            Py_XDECREF(g_split_keys[i]);
-            g_split_keys[i] = nullptr;
-        }
-        PyObject *type = PyObject_CallFunction(reinterpret_cast<PyObject *>(&PyType_Type), "s(){}", "_ScoredHit");
-        PyObject *obj = type ? PyObject_CallObject(type, nullptr) : nullptr;
-        Py_XDECREF(type);
-        if (!obj) { PyErr_Clear(); return nullptr; }
-        for (int i = 0; i < 22; i++)
-            if (PyObject_SetAttr(obj, k[i], Py_None) != 0) { PyErr_Clear(); Py_DECREF(obj); return nullptr; }
-        g_split_obj = obj;
-        for (int i = 0; i < 22; i++) { Py_INCREF(k[i]); g_split_keys[i] = k[i]; g_split_interned[i] = nullptr; }
-    }
-    PyObject *d = PyObject_GenericGetDict(g_split_obj, nullptr);
-    if (!d) { PyErr_Clear(); return nullptr; }
-    PyDictObject *mp = reinterpret_cast<PyDictObject *>(d);
-    bool ok = PyDict_CheckExact(d) && mp->ma_values != nullptr && mp->ma_used == 22;
-    if (ok) {
-        Keys310 *keys = reinterpret_cast<Keys310 *>(mp->ma_keys);
-        ok = keys->dk_size == 64 && keys->dk_nentries >= 22;
-        KeyEntry310 *e = reinterpret_cast<KeyEntry310 *>(keys->dk_indices + keys->dk_size);
-        for (int i = 0; i < 22 && ok; i++) {
-            if (!g_split_interned[i]) {            // first use: entry i must hold key i (an interned equal of it)
-                ok = e[i].me_key == k[i] || PyObject_RichCompareBool(e[i].me_key, k[i], Py_EQ) == 1;
-                if (ok) g_split_interned[i] = e[i].me_key;
-            } else {
-                ok = e[i].me_key == g_split_interned[i];
-            }
-            ok = ok && mp->ma_values[i] == Py_None;
-        }
-        PyErr_Clear();
-    }
-    if (!ok) { Py_DECREF(d); Py_CLEAR(g_split_obj); return nullptr; }
-    if (PyObject_GC_IsTracked(d)) PyObject_GC_UnTrack(d);
-    return d;
-}
-
-// the values array of `d` (a fresh PyDict_Copy of the split template `tmpl`), or nullptr if it is not what is expected
-inline PyObject **values_of(PyObject *d, PyObject *tmpl)
-{
-    PyDictObject *mp = reinterpret_cast<PyDictObject *>(d);
-    if (mp->ma_values == nullptr || mp->ma_keys != reinterpret_cast<PyDictObject *>(tmpl)->ma_keys || mp->ma_used != 22) return nullptr;
-    for (int i = 0; i < 22; i++)
-        if (mp->ma_values[i] != Py_None) return nullptr;
-    return mp->ma_values;
-}
-#else
-#define BIGSI_FAST_DICT 0
-#endif
-
 struct IntCache {
     std::vector<PyObject *> v;
     ~IntCache() { /* objects are immortal for the life of the module */ }
@@ -335,7 +361,7 @@ PyObject *build_scored(PyObject *, PyObject *args)
 #if BIGSI_FAST_DICT
     static const bool is_310 = strncmp(Py_GetVersion(), "3.10.", 5) == 0;
     const bool fast = g_fast_dict && is_310;
-    const bool split = fast && g_split_dict && (tmpl = split_template(k)) != nullptr;
+    const bool split = fast && g_split_dict && (tmpl = split_template(g_split22, k)) != nullptr;
 #endif
     if (!tmpl) {
         tmpl = PyDict_New();
@@ -371,7 +397,7 @@ PyObject *build_scored(PyObject *, PyObject *args)
             if (!d) { ok = false; break; }
             PyList_SET_ITEM(res, (Py_ssize_t)r, d);
 #if BIGSI_FAST_DICT
-            PyObject **vals = split ? values_of(d, tmpl) : nullptr;
+            PyObject **vals = split ? values_of(d, tmpl, 22) : nullptr;
             KeyEntry310 *slots = (fast && !split) ? entries_of(d, k) : nullptr;
 #endif
             auto put = [&](int kk, PyObject *v) {      // steals v

@@ -172,3 +172,39 @@ def test_direct_value_stores_give_the_same_dicts(threshold):
         assert not any(gc.is_tracked(d_) for r in again for d_ in r)
     finally:
         ext.fast_dict(was, True)
+
+
+@pytest.mark.parametrize("threshold", [1.0, 0.4])
+def test_plain_hit_dicts_of_every_route_are_the_same(threshold):
+    """The 4-key dicts of unscored searches: copies of a 4-key split-table template with direct stores (CPython 3.10, the default)
+    against the presized-dict + PyDict_SetItem route -- equal, same order and types, ordinary dicts, not tracked by the collector."""
+    import gc
+    import json
+    ext = bigsi_mod._results
+    was = ext.fast_dict()
+    rng = np.random.default_rng(12)
+    nk, nu, off, col, cnt = payload(rng, 600, False, threshold)
+    names = [None if n_ == DELETION_SPECIAL_SAMPLE_NAME else n_ for n_ in NAMES]
+    build = lambda: list(bigsi_mod.native_result_lists(None, nu, off.astype(np.int64), col, cnt, threshold == 1.0, names, None, NS))      # noqa: E731
+    try:
+        out = {}
+        for route in ((True, True), (True, False), (False, False)):
+            ext.fast_dict(*route)
+            out[route] = build()
+        ext.fast_dict(True, True)
+        a, b = out[(True, True)], out[(False, False)]
+        assert a == b == out[(True, False)] and sum(len(r) for r in a) > 300
+        for ra, rb in zip(a, b):
+            for da, db in zip(ra, rb):
+                assert type(da) is dict and list(da) == list(db) and [type(v) for v in da.values()] == [type(v) for v in db.values()] and len(da) == 4
+        assert json.dumps(a) == json.dumps(b)
+        flat = [d_ for r in a for d_ in r]
+        d, e = flat[0], flat[1]
+        before_e = dict(e)
+        for i in range(20):
+            d["x%d" % i] = i
+        del d["num_kmers"]
+        assert len(d) == 23 and list(d)[0] == "percent_kmers_found" and e == before_e and len(e) == 4
+        assert build() == b and not any(gc.is_tracked(d_) for r in build() for d_ in r)
+    finally:
+        ext.fast_dict(was, True)
