@@ -7,7 +7,13 @@ With N > 1 and no launcher environment the script starts its own N ranks (one pr
 WORLD_SIZE / MASTER_* set for them); under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` it is
 one of the launcher's ranks.  Either way rank 0 prints ONE JSON line.
 
-A "step" is one pass of the whole device path over one batch of synthetic queries that is already resident in HBM:
+A "step" is one pass of the whole path over one batch of synthetic queries, HOST-VISIBLE as SURVEY.md section 8d defines
+lookups/s (--timed host, the default): the batch's sequences start in host memory, its hit lists end in host memory -- on one
+GPU one bigsi_hip_search_stream call per step (the library cuts the batch into device chunks and overlaps upload, kernels and
+download itself), with N > 1 the batch object's reload + sharded run + fetch of the gathered lists.  The index is resident in
+HBM throughout.  (--timed resident, and always for score=True workloads and for batches of short reads -- c2's 1000 x 61 bp are one 48 us call,
+latency not throughput; their host-visible rate is that of one stream call over 256 batches, `hv` --: the batch is staged in HBM beforehand and the hit
+lists stay on the device -- that figure is also measured after a host-timed region: config.resident_lookups_per_s.)  The path:
 K1 k-merise/dedupe/hash -> K2 row fetch + AND (or bit-sliced counting) -> K4 threshold + compaction, and for N > 1 the RCCL
 all-gather of the per-sample result vectors, the compaction of the gathered result and (thresholded searches) the all-reduce
 of the per-hit counts, issued by libbigsi_hip.so on its own communicator.
@@ -39,7 +45,8 @@ BASELINE configurations as legs of >= 1 s each, every one a fresh process verifi
 (legs of a multi-GPU run: every rank starts its rank of the leg, rendezvous on ports rank 0 drew before the headline's group
 was closed).  Short keys of a leg: v lookups/s | ms per step | s timed | k kernel | f frac of 8 TB/s by the kernel's clock | sf
 by the step's wall clock | box frac of this box's bare row-stream rate (bigsi_hip_probe_rows) | tr PMC traffic / algorithmic
-bytes | ok verified | hv host-visible lookups/s (one search_stream call) | us1 one-call latency of one query | x_ms exchange
+bytes | ok verified | in h: the leg's steps take host sequences in and leave host hit lists out (v is the host-visible rate, rv the rate with
+the batches resident in HBM), r: resident steps (hv then = host-visible lookups/s of one search_stream call) | us1 one-call latency of one query | x_ms exchange
 (all-gather + gathered compaction + all-reduce, events on the communicator stream) | ranks = ncclCommCount | gbs per-rank GB/s.
 """
 import argparse
@@ -108,6 +115,13 @@ def parse():
     p.add_argument("--score-queue", default="beside", choices=["ordered", "beside"],
                    help="score=True workloads: K5 + K6 of a batch queued on the index stream behind the next batch's kernels (ordered) or on "
                         "the library's high-priority score stream beside them (beside)")
+    p.add_argument("--timed", default="host", choices=["host", "resident"],
+                   help="what a timed step starts from and leaves behind.  host (default; SURVEY.md section 8d metric (1)): the step's sequences are in HOST memory "
+                        "and its hit lists end in host memory -- one bigsi_hip_search_stream call per step on one GPU (the library uploads, runs and downloads its "
+                        "own chunks, overlapped); N > 1: reload (H2D) + sharded run + fetch of the previous batch's gathered hit lists.  resident: the "
+                        "round 1-5 step (batches staged in HBM beforehand, hit lists left on the device); it is also measured after a host-timed region "
+                        "and reported as config.resident_lookups_per_s.  score=True workloads, batches of short reads (< 128 KB of sequence: one latency-bound call) "
+                        "and --one-stream always run resident steps")
     p.add_argument("--host-visible", type=int, default=1, choices=[0, 1],
                    help="0: skip the host-visible measurements after the timed region (profiled runs: rocprofv3's per-kernel averages then "
                         "cover launches of the timed shape only)")
@@ -312,7 +326,7 @@ def leg_summary(d, what, extra, wall_s):
     rf, cf = d["roofline"], d["config"]
     out = {"v": d["value"], "ms": d["ms_per_step"], "s": sig(d["ms_per_step"] * d["steps"] / 1e3, 3), "k": rf.get("kernel"), "f": rf.get("frac"),
            "sf": rf.get("step_frac"), "box": rf.get("frac_of_box"), "tr": rf.get("traffic_ratio"), "ok": int(bool(cf.get("verified"))),
-           "hv": cf.get("host_visible_lookups_per_s"), "us1": cf.get("one_call_us"), "gb": cf.get("index_gb_per_gpu"), "wall": wall_s}
+           "hv": cf.get("host_visible_lookups_per_s"), "rv": cf.get("resident_lookups_per_s"), "in": {"host": "h", "resident": "r"}.get(cf.get("value_inputs")), "us1": cf.get("one_call_us"), "gb": cf.get("index_gb_per_gpu"), "wall": wall_s}
     for k_src, k_dst in (("exchange_ms", "x_ms"), ("rccl_ranks", "ranks"), ("per_rank_GBps", "gbs"), ("scored_hits", "hits"), ("scored_us_per_hit", "us_hit"),
                          ("hv_scored_lookups_per_s", "hvs"), ("distinct_gpus", "gpus_distinct"), ("one_call_us_batch", "usb"), ("frac_overlapped", "f3"),
                          ("hits_per_s", "hps"), ("hv_hits_per_s", "hvh"), ("hv_scored_hits_per_s", "hvsh"), ("dicts_per_s", "dps"), ("k5_traffic_ratio", "tr5"),
@@ -404,8 +418,11 @@ def condense(full):
         "workload": cut(cf["workload_short"]), "workload_key": cf["workload_key"], "rows": cf["rows"], "cols_per_gpu": cf["cols_per_gpu"],
         "total_cols": cf["total_cols"], "index_gb_per_gpu": sig(cf["index_gb_per_gpu"], 4), "hashes": cf["hashes"], "batch": cf["batch"], "qlen": cf["qlen"],
         "unique_kmers_per_batch": cf["unique_kmers_per_batch"], "hits_first_batch": cf["hits_first_batch"],
-        # host sequences in -> host hit lists out through ONE bigsi_hip_search_stream call (never `value`: that is the resident rate)
-        "host_visible_lookups_per_s": sig((hv.get("stream") or {}).get("kmer_lookups_per_s")),
+        # value_inputs "host": `value` IS the host-visible rate (host sequences in, host hit lists out, every step) and the figure with the
+        # batches resident in HBM stands beside it; "resident" (score=True legs): the other way round, the host-visible figure from ONE
+        # bigsi_hip_search_stream call over several batches after the timed region
+        "value_inputs": cf.get("value_inputs"), "resident_lookups_per_s": sig(cf.get("resident_lookups_per_s")),
+        "host_visible_lookups_per_s": sig((hv.get("stream") or {}).get("kmer_lookups_per_s")) if cf.get("value_inputs") != "host" else None,
         "hv_scored_lookups_per_s": sig((hv.get("stream_scored") or {}).get("kmer_lookups_per_s")),
         "one_call_us": sig((hv.get("one_call_us") or {}).get("single_query"), 4),
         "one_call_us_batch": sig(next((v for k_, v in (hv.get("one_call_us") or {}).items() if k_.startswith("whole_batch")), None), 4),
@@ -707,6 +724,31 @@ def run(args):
     count_bytes = 2 if (w["qlen"] - args.k + 1) < 65536 else 4
     sh.prepare(batches, exact, count_bytes)
     check(_lib.lib().bigsi_hip_set_profiling(st.handle, 1))
+    # --timed host: every step starts from sequences in host memory and ends with hit lists in host memory
+    # (batches of short reads stay resident: 1000 x 61 bp is ONE 48 us call -- latency, not throughput; their steps keep three launches
+    # in flight as before and the host-visible rate of one stream call over 256 such batches stands beside `value` as `hv`)
+    host_steps = args.timed == "host" and not w["score"] and not args.one_stream and w["batch"] * w["qlen"] >= (1 << 17)
+    stream_steps = host_steps and not use_dist
+    run_flags = _lib.RUN_EARLY_EXIT if args.early_exit else 0
+    if stream_steps:
+        packed = [_lib.pack_seqs(s_) for s_ in all_seqs]                     # what a caller holds: one blob + offsets per batch
+        s_nk, s_nu = np.zeros(w["batch"], np.uint32), np.zeros(w["batch"], np.uint32)
+        s_off = np.zeros(w["batch"] + 1, np.uint64)
+        s_cap = [max(1 << 16, 8 * w["batch"] * (9 if args.dense else 1))]
+        s_col, s_cnt = [np.zeros(s_cap[0], np.uint32)], [np.zeros(s_cap[0], np.uint32)]
+
+        def stream_step(i):
+            """ONE bigsi_hip_search_stream call: host sequences in, host hit lists out (the library cuts, uploads, runs, downloads)"""
+            blob_, soff_ = packed[i % nb]
+            while True:
+                rc_ = _lib.lib().bigsi_hip_search_stream(st.handle, blob_, _lib.ptr(soff_), w["batch"], args.k, float(thr), run_flags, _lib.ptr(s_nk), _lib.ptr(s_nu),
+                                                         None, _lib.ptr(s_off), _lib.ptr(s_col[0]), _lib.ptr(s_cnt[0]), s_cap[0])
+                if rc_ != _lib.ERR_CAPACITY:
+                    check(rc_)
+                    return
+                s_cap[0] = int(s_off[-1]) * 2                                  # (only ever in a warmup step: the buffers then fit)
+                s_col[0], s_cnt[0] = np.zeros(s_cap[0], np.uint32), np.zeros(s_cap[0], np.uint32)
+    unfetched = [None]
 
     # N > 1: before anything is timed, every rank says which physical GPU it drives; the run refuses ranks that share one (unless
     # asked to: --one-device dry runs) and a communicator whose size is not N; whether the GPUs can reach each other directly is reported
@@ -811,7 +853,12 @@ def run(args):
         scored["finish_s"] += time.perf_counter() - t_a
 
     def collect():
-        """drain the scoring pipeline (end of the timed region)"""
+        """drain the pipeline (end of the timed region): the last batch's hit lists (host steps), the scoring stages (score=True)"""
+        if host_steps:
+            last, unfetched[0] = unfetched[0], None
+            if last is not None:
+                sh.fetch(last)
+            return
         job, begun[0] = begun[0], None
         score_finish(job)
         score_begin()
@@ -820,8 +867,24 @@ def run(args):
 
     def step():
         """One pass of the path over the next staged batch (score=True: plus the scoring stages of the two batches before it)."""
-        batch = batches[step_no[0] % len(batches)]
+        i_step = step_no[0]
+        batch = batches[i_step % len(batches)]
         step_no[0] += 1
+        if stream_steps:
+            stream_step(i_step)
+            return
+        if host_steps:
+            # N > 1 (or --force-dist): the batch object's own halves of that call -- sequences up, sharded run with the exchange, the
+            # gathered hit lists of the batch before down while this one runs (one staged batch: its own, at once)
+            batch.reload(all_seqs[i_step % nb])
+            sh.step(batches, thr, early_exit=bool(args.early_exit))
+            prev, unfetched[0] = unfetched[0], batch
+            if len(batches) == 1:
+                sh.fetch(batch)
+                unfetched[0] = None
+            elif prev is not None:
+                sh.fetch(prev)
+            return
         if args.one_stream:
             batch.run(thr, sparse_counts=True, one_stream=True)
         else:
@@ -873,6 +936,34 @@ def run(args):
         elapsed = float(t.item())
     check(_lib.lib().bigsi_hip_stats(st.handle, _lib.C.byref(stats), 1))
 
+    # --timed host: the same steps once more with the batches RESIDENT (sequences staged in HBM beforehand, hit lists left on the
+    # device: the round 1-5 headline), untimed by the contract, reported beside `value` as config.resident_lookups_per_s; it also
+    # leaves the staged batches' last runs behind for the verification below
+    resident_rate = None
+    if host_steps:
+        check(_lib.lib().bigsi_hip_set_profiling(st.handle, 0))
+        if stream_steps:
+            stream_step(0)
+            first_stream = (s_nu.copy(), s_off.copy(), s_col[0][: int(s_off[-1])].copy(), s_cnt[0][: int(s_off[-1])].copy())
+        if use_dist:
+            for b_i, b_ in enumerate(batches):
+                b_.reload(all_seqs[b_i])
+        r_steps = max(len(batches), min(args.steps, 8 if w["batch"] * w["qlen"] >= (1 << 20) else 256))
+        for _ in range(len(batches)):
+            sh.step(batches, thr, early_exit=bool(args.early_exit))
+        sync_all()
+        t1 = time.perf_counter()
+        for _ in range(r_steps):
+            sh.step(batches, thr, early_exit=bool(args.early_exit))
+        sync_all()
+        r_elapsed = time.perf_counter() - t1
+        if use_dist:
+            t = torch.tensor([r_elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            r_elapsed = float(t.item())
+        resident_rate = (r_steps, r_elapsed)
+        check(_lib.lib().bigsi_hip_stats(st.handle, _lib.C.byref(_lib.Stats()), 1))
+
     # one-launch read kernels bound their waits and mark a launch in which a workgroup gave up (repeated when its hit lists are
     # fetched): fetch every staged batch's last run, so that such a launch -- none has ever been seen -- would be counted
     repeated = 0
@@ -903,6 +994,9 @@ def run(args):
     off, colours, counts = sh.fetch(batch)
     nk, nu, mk = batch.unique()
     total_unique = int(nu.sum())
+    if stream_steps:          # what the timed steps' call returns for this batch == what the staged batch object returns
+        assert np.array_equal(first_stream[0], nu[: w["batch"]]) and np.array_equal(first_stream[1], off.astype(np.uint64)), "search_stream != batch (offsets)"
+        assert np.array_equal(first_stream[2], colours[: int(off[-1])]) and (exact or np.array_equal(first_stream[3], counts[: int(off[-1])])), "search_stream != batch (hits)"
     wv = -(-my_cols // 64)
     uniq_rows = 0
     for i in range(w["batch"]):
@@ -1184,6 +1278,7 @@ def run(args):
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         rate = total_unique / (elapsed / args.steps)
+        resident = total_unique * resident_rate[0] / resident_rate[1] if resident_rate else None
         cr = sh.comm_ranks()
         whole = args.scaling == "strong" and parts == world
         line = {
@@ -1218,7 +1313,11 @@ def run(args):
                 "early_exit": bool(args.early_exit) or None,
                 "hits_per_s": int(off[-1]) / (elapsed / args.steps) if args.dense else None,
                 "k5_traffic_ratio": k5_ratio,
-                "value_is": "unique query k-mers per second against the %d samples held by this run, exchange included" % total_cols,
+                "value_is": "unique query k-mers per second against the %d samples held by this run, exchange included; a step %s" % (
+                    total_cols, "starts from sequences in HOST memory and ends with hit lists in host memory (SURVEY 8d (1)): %s" % (
+                        "one bigsi_hip_search_stream call" if stream_steps else "batch reload (H2D) + sharded run + fetch of the gathered hit lists")
+                    if host_steps else "runs a batch staged in HBM beforehand and leaves its hit lists on the device"),
+                "value_inputs": "host" if host_steps else "resident", "resident_lookups_per_s": resident,
                 "shard_lookups_per_s_sum": rate * world,
                 "aggregate_GBps": sum(per_rank_gbs), "per_rank_GBps": per_rank_gbs,
                 "parallelism": "column-shard x%d%s" % (world, "" if not use_dist else

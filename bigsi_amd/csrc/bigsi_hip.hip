@@ -1011,9 +1011,11 @@ extern "C" int bigsi_hip_insert_columns(bigsi_hip_index *ix, uint64_t col0, uint
     if (n == 0) return BIGSI_OK;
     TRY(use_device(ix));
     TRY(quiesce_index(ix));
-    // filters are staged a slab at a time at a 16-byte pitch (vector loads): at least 512 of them when 2 GB allow it (one
-    // transpose tile is 512 columns wide), otherwise about 256 MB worth
-    const uint64_t nb = ceil_div(ix->m, 8), pitch = round_up(nb, 16);
+    // filters are staged a slab at a time at a 128-byte pitch -- the transpose reads a filter in 128-byte runs, and a run that
+    // straddles two L2 lines is fetched twice by neighbouring tiles (round 6, TCC_EA0_RDREQ_128B: 1.32 x the filter bytes at a
+    // 16-byte pitch, 1.0 x at this one) --: at least 512 of them when 2 GB allow it (one transpose tile is 512 columns wide),
+    // otherwise about 256 MB worth
+    const uint64_t nb = ceil_div(ix->m, 8), pitch = round_up(nb, 128);
     const uint64_t stage_bytes = std::min<uint64_t>(std::max<uint64_t>(512 * pitch, 256ull << 20), 2048ull << 20);
     uint64_t per = std::max<uint64_t>(1, stage_bytes / pitch);
     if (per >= 128) per = per / 128 * 128;

@@ -2617,6 +2617,41 @@ __device__ __forceinline__ uint64_t transpose64_lanes(uint64_t a64, uint32_t lan
     return ((uint64_t)hi << 32) | lo;
 }
 
+// two independent blocks at once, step by step: the same operations as two calls of transpose64_lanes, written so that the
+// compiler sees the two chains side by side (k_transpose_tiles, phase 2)
+__device__ __forceinline__ void transpose64_lanes_x2(uint64_t &a64, uint64_t &b64, uint32_t lane)
+{
+    uint32_t lo = (uint32_t)a64, hi = (uint32_t)(a64 >> 32), lo2 = (uint32_t)b64, hi2 = (uint32_t)(b64 >> 32);
+    {
+        const bool s = (lane & 32u) != 0;
+        const uint32_t recv = lane_xor<32>(s ? lo : hi, lane), recv2 = lane_xor<32>(s ? lo2 : hi2, lane);
+        lo = s ? recv : lo;
+        hi = s ? hi : recv;
+        lo2 = s ? recv2 : lo2;
+        hi2 = s ? hi2 : recv2;
+    }
+#define BIGSI_TR_STEP2(J, M)                                                                                 \
+    {                                                                                                        \
+        const bool s = (lane & J) != 0;                                                                      \
+        const uint32_t rot = s ? (uint32_t)J : 32u - (uint32_t)J;                                            \
+        const uint32_t keep = s ? ~(uint32_t)M : (uint32_t)M;                                                \
+        const uint32_t rl = lane_xor<J>(rotl32v(lo, rot), lane), rl2 = lane_xor<J>(rotl32v(lo2, rot), lane); \
+        const uint32_t rh = lane_xor<J>(rotl32v(hi, rot), lane), rh2 = lane_xor<J>(rotl32v(hi2, rot), lane); \
+        lo = (lo & keep) | (rl & ~keep);                                                                     \
+        hi = (hi & keep) | (rh & ~keep);                                                                     \
+        lo2 = (lo2 & keep) | (rl2 & ~keep);                                                                  \
+        hi2 = (hi2 & keep) | (rh2 & ~keep);                                                                  \
+    }
+    BIGSI_TR_STEP2(16, 0x0000FFFFu)
+    BIGSI_TR_STEP2(8, 0x00FF00FFu)
+    BIGSI_TR_STEP2(4, 0x0F0F0F0Fu)
+    BIGSI_TR_STEP2(2, 0x33333333u)
+    BIGSI_TR_STEP2(1, 0x55555555u)
+#undef BIGSI_TR_STEP2
+    a64 = ((uint64_t)hi << 32) | lo;
+    b64 = ((uint64_t)hi2 << 32) | lo2;
+}
+
 #ifdef BIGSI_HIP_TUNING
 __device__ uint32_t g_tr_skip = 0;      // experiment (BIGSI_HIP_TR_SKIP=1): move the tiles without transposing them
 #endif
@@ -2689,25 +2724,41 @@ __global__ __launch_bounds__(kBlock * CT) void k_transpose_tiles(
         d[1] = ld[it].y;
     }
     __syncthreads();
-    // phase 2: the 36 unordered pairs {(cw, rc), (rc, cw)} of the 8 x 8 blocks, nine per wavefront
+    // phase 2: the 64 blocks of the 8 x 8 grid, two at a time per wavefront -- ALWAYS two, in one basic block, so that the two
+    // butterfly chains (each ~45 dependent vector operations, DPP / permlane exchanges among them) interleave: the two workgroups
+    // of a CU are rarely in this phase together, and with two wavefronts per SIMD a single chain leaves the ALUs waiting for
+    // their own results (round 6: +x % over one pair {(cw, rc), (rc, cw)} per trip with the second block behind a branch).
+    // Trips 0-6 of a wavefront take the off-diagonal pairs {(x, y), (y, x)}, x < y, number `wave + 4 trip` of the 28 (each block
+    // written where its mirror was read: 37 KB of LDS per tile instead of 74); trip 7 takes the diagonal blocks 2 wave and
+    // 2 wave + 1, each transposed in place.
 #ifdef BIGSI_HIP_TUNING
     if (!(g_tr_skip & 1u))
 #endif
-    for (uint32_t pi = wave; pi < 36; pi += kBlock / 64) {
-        // pi -> (x, y) with x <= y: row y of the lower triangle starts at y (y + 1) / 2
-        uint32_t y = 0;
-        while ((y + 1) * (y + 2) / 2 <= pi) y++;
-        const uint32_t x = pi - y * (y + 1) / 2;
-        uint8_t *pa = tile + (x * 64) * kTransposePitch + y * 8;      // block (cw = x, rc = y): lines of column word x
-        uint8_t *pb = tile + (y * 64) * kTransposePitch + x * 8;      // block (cw = y, rc = x)
+#pragma unroll 1
+    for (uint32_t trip = 0; trip < 8; trip++) {
+        uint32_t x, y, xb, yb;                              // block a = (cw = x, rc = y), block b = (cw = xb, rc = yb)
+        if (trip < 7) {
+            const uint32_t oi = wave + (kBlock / 64) * trip;          // oi -> (x, y) with x < y: row y of the strict lower triangle starts at y (y - 1) / 2
+            y = 1;
+            while (y * (y + 1) / 2 <= oi) y++;
+            x = oi - y * (y - 1) / 2;
+            xb = y, yb = x;
+        } else {
+            x = y = 2 * wave;
+            xb = yb = 2 * wave + 1;
+        }
+        uint8_t *pa = tile + (x * 64) * kTransposePitch + y * 8;        // lines of column word x, bytes of row chunk y
+        uint8_t *pb = tile + (xb * 64) * kTransposePitch + yb * 8;
         uint64_t va = *reinterpret_cast<const uint64_t *>(pa + mycol * kTransposePitch);
-        uint64_t vb = x != y ? *reinterpret_cast<const uint64_t *>(pb + mycol * kTransposePitch) : 0ull;
-        va = transpose64_lanes(by_column(va), lane);
-        if (x != y) vb = transpose64_lanes(by_column(vb), lane);
+        uint64_t vb = *reinterpret_cast<const uint64_t *>(pb + mycol * kTransposePitch);
+        va = by_column(va);
+        vb = by_column(vb);
+        transpose64_lanes_x2(va, vb, lane);
         // every lane of the wavefront has read both blocks before any lane overwrites them (the butterflies in between are
-        // wavefront-wide exchanges), and no other wavefront touches this pair
-        *reinterpret_cast<uint64_t *>(pb + lane * kTransposePitch) = va;      // rows of chunk y, column word x
-        if (x != y) *reinterpret_cast<uint64_t *>(pa + lane * kTransposePitch) = vb;
+        // wavefront-wide exchanges), and no other wavefront touches these two blocks.  The transpose of block (x, y) belongs at
+        // (y, x): for an off-diagonal pair that is where b was read (and vice versa), for a diagonal block its own place
+        *reinterpret_cast<uint64_t *>(tile + (y * 64 + lane) * kTransposePitch + x * 8) = va;
+        *reinterpret_cast<uint64_t *>(tile + (yb * 64 + lane) * kTransposePitch + xb * 8) = vb;
     }
     __syncthreads();
     // phase 3: tiles[..][row][0 .. 64) -> the rows' words [w_first + w0, +words_here): 4 * CT lanes per row, 16 bytes each

@@ -231,7 +231,8 @@ def transpose():
         for key, v in (("number_of_rows", m), ("number_of_cols", 0), ("ksi:bloomfilter_size", m), ("ksi:num_hashes", 3)):
             st.set_integer(key, v)
         nb = (m + 7) // 8
-        pitch = -(-nb // 16) * 16
+        align = int(os.environ.get("BIGSI_TR_PITCH_ALIGN", "128"))      # the library stages host filters at a 128-byte pitch (whole lines per run)
+        pitch = -(-nb // align) * align
         blooms = torch.randint(0, 256, (ncols, pitch), dtype=torch.uint8, device="cuda")
         torch.cuda.synchronize()
         check(L.bigsi_hip_insert_columns_device(st.handle, 0, 512, blooms.data_ptr(), pitch))      # warm
@@ -246,7 +247,7 @@ def transpose():
             bits = ((blooms[:, r >> 3] >> (7 - (r & 7))) & 1).cpu().numpy()
             assert np.array_equal(st.get_rows_packed([r], (ncols + 7) // 8)[0], np.packbits(bits)), r
         emit("transpose_device", m=m, cols=ncols, kernels_ms=s.transpose_ms, bytes_in_plus_out=moved,
-             GBps=moved / s.transpose_ms / 1e6, frac=moved / s.transpose_ms / 1e6 / PEAK,
+             GBps=moved / s.transpose_ms / 1e6, frac=moved / s.transpose_ms / 1e6 / PEAK, filter_pitch=pitch,
              note="k_transpose_tiles (+ k_insert_columns for ragged edges); filters resident in HBM")
         del blooms
         st.delete_all()

@@ -172,7 +172,8 @@ int main(int argc, char **argv)
     const uint64_t n_cols = argc > 2 ? strtoull(argv[2], nullptr, 10) : 8192ull;
     const uint32_t super = argc > 3 ? (uint32_t)atoi(argv[3]) : 32u;
     const uint64_t m_bytes = (m_bits + 7) / 8 / 16 * 16, n_bytes = (n_cols + 7) / 8 / 16 * 16;
-    const uint64_t pitch_in = m_bytes, pitch_out = (n_bytes + 127) / 128 * 128;
+    const uint64_t align_in = argc > 4 ? strtoull(argv[4], nullptr, 10) : 1ull;      // filter pitch rounded up to this (1: packed, as rounds 3-5 measured)
+    const uint64_t pitch_in = (m_bytes + align_in - 1) / align_in * align_in, pitch_out = (n_bytes + 127) / 128 * 128;
     uint8_t *in = nullptr, *out = nullptr;
     u64x2 *sink = nullptr;
     CK(hipMalloc(&in, pitch_in * n_cols + 4096));

@@ -5,7 +5,7 @@
 //   VAR & 1   tiles row-major inside the supertile instead of XCD groups
 //   VAR & 2   no phase 2 (no butterflies, no LDS traffic of theirs)
 //   VAR & 4   16-byte LDS accesses in phases 1 and 3 (pitch 80 instead of 72)
-// usage: transpose_ab <m_bits> <n_cols>
+// usage: transpose_ab <m_bits> <n_cols> [filter pitch alignment, default 128]
 #include "../../bigsi_amd/csrc/bigsi_kernels.hpp"
 #include <algorithm>
 #include <cstdio>
@@ -235,7 +235,8 @@ int main(int argc, char **argv)
     using namespace bigsi;
     const uint64_t m = argc > 1 ? strtoull(argv[1], nullptr, 10) : 10000000ull;
     const uint64_t n_cols = argc > 2 ? strtoull(argv[2], nullptr, 10) / 128 * 128 : 8192ull;
-    const uint64_t nb = (m + 7) / 8, bstride = (nb + 15) / 16 * 16, n_words = n_cols / 64, stride_words = (n_words + 15) / 16 * 16;
+    const uint64_t align = argc > 3 ? strtoull(argv[3], nullptr, 10) : 128ull;      // filter pitch rounded up to this (16: the packed pitch rounds 3-5 measured at)
+    const uint64_t nb = (m + 7) / 8, bstride = (nb + align - 1) / align * align, n_words = n_cols / 64, stride_words = (n_words + 15) / 16 * 16;
     uint8_t *blooms = nullptr;
     uint64_t *index = nullptr;
     CK(hipMalloc(&blooms, bstride * n_cols + 4096));

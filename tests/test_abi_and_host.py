@@ -307,7 +307,7 @@ def test_bench_line_is_condensed_under_the_drivers_tail():
     leg_line = {"value": 263123456.789, "ms_per_step": 0.94012345, "steps": 1200,
                 "roofline": {"kernel": "k_and_count", "frac": 0.81234567, "step_frac": 0.7712345, "frac_of_box": 0.98123456, "traffic_ratio": 1.00412345,
                              "read_launches_repeated": 0, "frac_overlapped": 0.2512345},
-                "config": {"verified": "x" * 100, "host_visible_lookups_per_s": 261234567.8, "one_call_us": 45.12345, "index_gb_per_gpu": 195.3125, "exchange_ms": 0.0712345,
+                "config": {"verified": "x" * 100, "host_visible_lookups_per_s": 261234567.8, "value_inputs": "host", "resident_lookups_per_s": 271234567.8, "one_call_us": 45.12345, "index_gb_per_gpu": 195.3125, "exchange_ms": 0.0712345,
                            "rccl_ranks": 8, "per_rank_GBps": [6512.3456] * 8, "scored_hits": 260075, "scored_us_per_hit": 3.912345, "hv_scored_lookups_per_s": 240123456.7,
                            "distinct_gpus": True, "one_call_us_batch": 69.12345}}
     legs = {k: bench.leg_summary(leg_line, "what", [], 12.3) for k in ("c3_t04", "c2", "c2_t04", "c4_shard", "c5_shard", "ns_shard", "extra")}
@@ -315,7 +315,7 @@ def test_bench_line_is_condensed_under_the_drivers_tail():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload_short": "configs[2]: 10M x 100k over 8 GPUs, h=4, 8192 x 1000 bp/step, t=1 exact" + " padding" * 10, "workload_key": "c3", "rows": 10000000,
                        "cols_per_gpu": 12500, "total_cols": 100000, "index_gb_per_gpu": 15.68, "hashes": 4, "batch": 8192, "qlen": 1000, "unique_kmers_per_batch": 7946240,
-                       "hits_first_batch": 64, "host_visible": {"stream": {"kmer_lookups_per_s": 132123456.7}, "stream_scored": {"kmer_lookups_per_s": 1.2e8},
+                       "hits_first_batch": 64, "value_inputs": "host", "resident_lookups_per_s": 135522511.9, "host_visible": {"stream": {"kmer_lookups_per_s": 132123456.7}, "stream_scored": {"kmer_lookups_per_s": 1.2e8},
                                                                  "one_call_us": {"single_query": 57.123, "whole_batch_of_1000": 69.2}},
                        "verified": "planted hits on 8 shard(s) + 4 queries == oracle (colours, counts) on EVERY shard; 264 scored dicts == oracle",
                        "parallelism": "column-shard x8 + ncclAllGather of 1 bit/sample (library-owned RCCL communicator)", "exchange": "rccl", "rccl_ranks": 8, "exchange_ms": 0.0712345,
@@ -336,7 +336,12 @@ def test_bench_line_is_condensed_under_the_drivers_tail():
     assert line["metric"] == "kmer_lookups_per_s" and line["n_gpus"] == 8 and line["roofline"]["bound"] == "hbm" and line["roofline"]["unit"] == "GB/s"
     assert line["roofline"]["frac"] == pytest.approx(0.85342, abs=1e-4) and line["roofline"]["traffic_ratio"] == pytest.approx(1.0041, abs=1e-4)
     assert line["cpu_baseline"]["cores"] == 1 and line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["best_cpu_cores"] == 128
-    assert line["config"]["host_visible_lookups_per_s"] == pytest.approx(1.3212e8, rel=1e-3) and line["config"]["rccl_ranks"] == 8
+    # `value` is the host-visible rate (value_inputs "host"): the resident figure stands beside it, the one-call stream figure is not repeated
+    assert line["config"]["value_inputs"] == "host" and line["config"]["resident_lookups_per_s"] == pytest.approx(1.3552e8, rel=1e-3)
+    assert "host_visible_lookups_per_s" not in line["config"] and line["config"]["rccl_ranks"] == 8
+    assert all(l["in"] == "h" and l["rv"] > 0 for l in line["config"]["also"].values())
+    full["config"]["value_inputs"] = "resident"          # (score=True workloads, batches of short reads: resident steps, the stream figure beside them)
+    assert bench.condense(full)["config"]["host_visible_lookups_per_s"] == pytest.approx(1.3212e8, rel=1e-3)
     assert set(line["config"]["also"]) == set(legs) and all(l["ok"] == 1 and l["ranks"] == 8 for l in line["config"]["also"].values())
 
     def strings(o):

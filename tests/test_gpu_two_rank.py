@@ -144,12 +144,14 @@ def test_bench_default_line_fits_the_drivers_tail():
         if key == "ingest":
             assert leg["load_GBps"] > 1 and leg["save_GBps"] > 0.5 and leg["gb"] > 0.5, leg
             continue
-        assert leg["box"] > 0.5 and leg["hv"] > 0 and leg["us1"] > 0, (key, leg)
+        assert leg["box"] > 0.5 and leg["us1"] > 0 and (leg["rv"] > 0 if leg["in"] == "h" else leg["hv"] > 0), (key, leg)
+        assert leg["in"] == ("h" if key in ("c3_t04", "c4_shard", "ns_shard", "c5_ee") else "r"), (key, leg)      # gene-length unscored legs: host-visible steps
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-3)
     assert r["box_sorted_GBps"] > 1000 and r["box_random_GBps"] > 1000 and 0.5 < r["frac_of_box"] < 2
     assert d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
-    assert d["config"]["host_visible_lookups_per_s"] > 0 and d["config"]["one_call_us"] > 0
+    # the headline's steps take host sequences in and leave host hit lists out; the resident figure stands beside `value`
+    assert d["config"]["value_inputs"] == "host" and d["config"]["resident_lookups_per_s"] > 0 and d["config"]["one_call_us"] > 0
     c2 = d["config"]["also"]["c2"]
     assert c2["k"].startswith("k_reads_fused") and c2["f3"] < c2["f"]          # the kernel alone on the device vs three launches overlapping
 
