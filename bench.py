@@ -45,7 +45,7 @@ BASELINE configurations as legs of >= 1 s each, every one a fresh process verifi
 (legs of a multi-GPU run: every rank starts its rank of the leg, rendezvous on ports rank 0 drew before the headline's group
 was closed).  Short keys of a leg: v lookups/s | ms per step | s timed | k kernel | f frac of 8 TB/s by the kernel's clock | sf
 by the step's wall clock | box frac of this box's bare row-stream rate (bigsi_hip_probe_rows) | tr PMC traffic / algorithmic
-bytes | ok verified | in h: the leg's steps take host sequences in and leave host hit lists out (v is the host-visible rate, rv the rate with
+bytes (tr5: K5's over the hit words' bytes, tr5l: over the bytes of the 128-byte lines they lie in -- the L2 never fetches less) | ok verified | in h: the leg's steps take host sequences in and leave host hit lists out (v is the host-visible rate, rv the rate with
 the batches resident in HBM), r: resident steps (hv then = host-visible lookups/s of one search_stream call) | us1 one-call latency of one query | x_ms exchange
 (all-gather + gathered compaction + all-reduce, events on the communicator stream) | ranks = ncclCommCount | gbs per-rank GB/s.
 """
@@ -329,7 +329,7 @@ def leg_summary(d, what, extra, wall_s):
            "hv": cf.get("host_visible_lookups_per_s"), "rv": cf.get("resident_lookups_per_s"), "in": {"host": "h", "resident": "r"}.get(cf.get("value_inputs")), "us1": cf.get("one_call_us"), "gb": cf.get("index_gb_per_gpu"), "wall": wall_s}
     for k_src, k_dst in (("exchange_ms", "x_ms"), ("rccl_ranks", "ranks"), ("per_rank_GBps", "gbs"), ("scored_hits", "hits"), ("scored_us_per_hit", "us_hit"),
                          ("hv_scored_lookups_per_s", "hvs"), ("distinct_gpus", "gpus_distinct"), ("one_call_us_batch", "usb"), ("frac_overlapped", "f3"),
-                         ("hits_per_s", "hps"), ("hv_hits_per_s", "hvh"), ("hv_scored_hits_per_s", "hvsh"), ("dicts_per_s", "dps"), ("k5_traffic_ratio", "tr5"),
+                         ("hits_per_s", "hps"), ("hv_hits_per_s", "hvh"), ("hv_scored_hits_per_s", "hvsh"), ("dicts_per_s", "dps"), ("k5_traffic_ratio", "tr5"), ("k5_line_ratio", "tr5l"),
                          ("k56_ms", "k56"), ("k56_GBps", "k56g"), ("early_exit", "ee")):
         v = cf.get(k_src, rf.get(k_src))
         if v is not None:
@@ -439,7 +439,7 @@ def condense(full):
         "hv_hits_per_s": sig((hv.get("stream") or {}).get("hits") / ((hv.get("stream") or {}).get("call_ms") * 1e-3), 4) if cf.get("dense") and hv.get("stream") else None,
         "hv_scored_hits_per_s": sig((hv.get("stream_scored") or {}).get("hits_per_s"), 4) if cf.get("dense") else None,
         "dicts_per_s": sig((hv.get("scored_dicts") or hv.get("dicts") or {}).get("dicts_per_s"), 4),
-        "k5_traffic_ratio": sig(cf.get("k5_traffic_ratio"), 4), "early_exit": 1 if cf.get("early_exit") else None,
+        "k5_traffic_ratio": sig(cf.get("k5_traffic_ratio"), 4), "k5_line_ratio": sig(cf.get("k5_line_ratio"), 4), "early_exit": 1 if cf.get("early_exit") else None,
         "k56_ms": sig(pres.get("kernels_ms"), 4) if cf.get("dense") else None, "k56_GBps": sig(pres.get("GBps"), 4) if cf.get("dense") else None,
     }
     roof = {"bound": "hbm", "achieved": sig(rf["achieved"]), "peak": rf["peak"], "unit": "GB/s", "frac": sig(rf["frac"], 4),
@@ -952,16 +952,17 @@ def run(args):
         for _ in range(len(batches)):
             sh.step(batches, thr, early_exit=bool(args.early_exit))
         sync_all()
-        t1 = time.perf_counter()
-        for _ in range(r_steps):
-            sh.step(batches, thr, early_exit=bool(args.early_exit))
-        sync_all()
-        r_elapsed = time.perf_counter() - t1
-        if use_dist:
-            t = torch.tensor([r_elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            r_elapsed = float(t.item())
-        resident_rate = (r_steps, r_elapsed)
+        if args.host_visible:          # (--host-visible 0, profiled runs: no further launches of another shape in rocprofv3's averages)
+            t1 = time.perf_counter()
+            for _ in range(r_steps):
+                sh.step(batches, thr, early_exit=bool(args.early_exit))
+            sync_all()
+            r_elapsed = time.perf_counter() - t1
+            if use_dist:
+                t = torch.tensor([r_elapsed], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                r_elapsed = float(t.item())
+            resident_rate = (r_steps, r_elapsed)
         check(_lib.lib().bigsi_hip_stats(st.handle, _lib.C.byref(_lib.Stats()), 1))
 
     # one-launch read kernels bound their waits and mark a launch in which a workgroup gave up (repeated when its hit lists are
@@ -1047,7 +1048,12 @@ def run(args):
         check(_lib.lib().bigsi_hip_stats(st.handle, _lib.C.byref(ps), 1))
         fetched[0] = batch
         collect()
-        presence = {"hits_per_batch": int(col_own.size), "presence_bits_bytes": int(boff[-1]), "score_record_bytes": int(rec.nbytes),
+        # what K5 must move at the memory system's granularity: gfx950's L2 asks the memory side for whole 128-byte lines whatever the load
+        # width or cache policy (TCC_EA0_RDREQ_32B = 0, _64B ~ 0 for every kernel of every leg: profiles/r06_pmc_requests.json), so a hit
+        # costs a line (1024 columns) of each of its query's u x h rows -- once for all the hits of the query in that line
+        off_i = off_own.astype(np.int64)
+        line_floor = sum(int(nu[q_]) * w["hashes"] * 128 * int(np.unique(col_own[off_i[q_]:off_i[q_ + 1]] >> 10).size) for q_ in range(w["batch"]) if off_i[q_ + 1] > off_i[q_])
+        presence = {"hits_per_batch": int(col_own.size), "presence_bits_bytes": int(boff[-1]), "score_record_bytes": int(rec.nbytes), "line_floor_bytes": line_floor,
                     "kernels_ms": ps.presence_ms, "score_hits_call_ms": call_ms,
                     "alg_bytes": int(ps.presence_bytes), "GBps": ps.presence_bytes / max(ps.presence_ms, 1e-9) / 1e6,
                     "in_timed_region": {"batches_scored": in_region["batches"], "hits_scored": in_region["hits"],
@@ -1182,7 +1188,7 @@ def run(args):
     traffic, traffic_src = None, None
     wkey = "rows=%d cols=%d hashes=%d batch=%d qlen=%d k=%d threshold=%s draws=%d%s" % (
         w["rows"], my_cols, w["hashes"], w["batch"], w["qlen"], args.k, repr(float(thr)), args.and_draws, (" dense=1" if args.dense else "") + (" ee=1" if args.early_exit else ""))
-    k5_ratio = None
+    k5_ratio, k5_line_ratio = None, None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             ent = json.load(f).get(wkey)
@@ -1192,6 +1198,8 @@ def run(args):
             if k5 and ent.get("presence_alg_bytes_per_call"):
                 # K5's HBM traffic over the algorithmic bytes of the whole K5 + K6 call (unique k-mers x h x 8 per distinct hit word + bits + records)
                 k5_ratio = k5["traffic_bytes_per_launch"] / ent["presence_alg_bytes_per_call"]
+                if ent.get("presence_line_floor_bytes_per_call"):      # ... and over the bytes of the 128-byte lines those words lie in (the hardware's floor)
+                    k5_line_ratio = k5["traffic_bytes_per_launch"] / ent["presence_line_floor_bytes_per_call"]
     except OSError:
         pass
 
@@ -1312,7 +1320,7 @@ def run(args):
                 "dense_plant_s": dense_s if args.dense else None,
                 "early_exit": bool(args.early_exit) or None,
                 "hits_per_s": int(off[-1]) / (elapsed / args.steps) if args.dense else None,
-                "k5_traffic_ratio": k5_ratio,
+                "k5_traffic_ratio": k5_ratio, "k5_line_ratio": k5_line_ratio,
                 "value_is": "unique query k-mers per second against the %d samples held by this run, exchange included; a step %s" % (
                     total_cols, "starts from sequences in HOST memory and ends with hit lists in host memory (SURVEY 8d (1)): %s" % (
                         "one bigsi_hip_search_stream call" if stream_steps else "batch reload (H2D) + sharded run + fetch of the gathered hit lists")

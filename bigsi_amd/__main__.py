@@ -149,15 +149,15 @@ def hold(config, handle=None, seconds=None, until_eof=False):
     for sig in (signal.SIGTERM, signal.SIGINT):
         signal.signal(sig, lambda *_: stop.set())
 
-    def until_eof():
+    def watch_stdin():
         try:
             while sys.stdin.read(4096):
                 pass
         except (OSError, ValueError):
             return
         stop.set()
-    if until_eof:
-        threading.Thread(target=until_eof, daemon=True).start()
+    if until_eof:                                       # (only then: a daemon's stdin is /dev/null, which is at its end at once)
+        threading.Thread(target=watch_stdin, daemon=True).start()
     t0 = time.time()
     while not stop.wait(0.2):
         if seconds is not None and time.time() - t0 >= seconds:

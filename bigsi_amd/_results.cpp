@@ -50,7 +50,8 @@ struct Column {
 #define BIGSI_FAST_DICT 1
 struct KeyEntry310 { Py_hash_t me_hash; PyObject *me_key; PyObject *me_value; };
 struct Keys310 { Py_ssize_t dk_refcnt, dk_size; void *dk_lookup; Py_ssize_t dk_usable, dk_nentries; char dk_indices[1]; };
-bool g_fast_dict = true;           // _results.fast_dict(False) switches it off (A/B, tests)
+bool g_fast_dict = false;          // OFF until _results.fast_dict(True): bigsi_amd/graph/bigsi.py switches it on only after its import-time self-test
+                                   // (one batch of dicts built both ways: equal, then mutated, copied, serialised: still equal) has passed
 bool g_split_dict = true;          // _results.fast_dict(True, False): direct stores into copies of a combined template (A/B, tests)
 
 // the 22 value slots of `d` (a fresh PyDict_Copy of the template), or nullptr if the table is not what is expected
@@ -247,6 +248,7 @@ PyObject *build(PyObject *, PyObject *args)
             PyObject *nm = PyList_GET_ITEM(names, p_col[t]);
             Py_INCREF(nm);
             put(3, nm);
+            if (!PyUnicode_CheckExact(nm) && !PyObject_GC_IsTracked(d)) PyObject_GC_Track(d);      // (copies of the untracked template: only atomic values may go unseen by the collector)
             if (scored) {
                 for (int j = 1; j < 18 && ok; j++)
                     put(3 + j, col[j].is_float ? PyFloat_FromDouble(static_cast<const double *>(col[j].buf.b.buf)[t])
@@ -428,6 +430,7 @@ PyObject *build_scored(PyObject *, PyObject *args)
             PyObject *nm = PyList_GET_ITEM(names, p_col[t]);
             Py_INCREF(nm);
             put(3, nm);
+            if (!PyUnicode_CheckExact(nm) && !PyObject_GC_IsTracked(d)) PyObject_GC_Track(d);      // (as in build: a name that is not a plain str may hold references)
             put(4, PyFloat_FromDouble(rc.score));
             put(5, PyFloat_FromDouble(rc.min_score));
             put(6, PyFloat_FromDouble(rc.max_score));

@@ -24,6 +24,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <new>
 #include <string>
 #include <string_view>
@@ -142,6 +143,10 @@ struct BdbRows {
     int fd = -1;
     BigsiBdb db;
     std::vector<BigsiBdb::Loc> loc;
+    // errno of the first record read that failed since the last check (an I/O error, a corrupt overflow chain): the entry point that
+    // was reading fails with it instead of answering from a zero / partial row (bdb_read_failed below; fork-pool workers have their own copy)
+    mutable std::atomic<int> io_error{0};
+    void note(int e) const { int none = 0; if (e) io_error.compare_exchange_strong(none, e); }
 };
 
 struct bigsi_cpu_index {
@@ -155,7 +160,7 @@ struct bigsi_cpu_index {
         if (!bdb) return rows + r * stride;
         tmp.assign(rb_, 0);
         const BigsiBdb::Loc &l = bdb->loc[r];
-        if (l.kind) bdb->db.read_value(l, tmp.data(), (uint32_t)std::min<uint64_t>(l.len, rb_), page);
+        if (l.kind) bdb->note(bdb->db.read_value(l, tmp.data(), (uint32_t)std::min<uint64_t>(l.len, rb_), page));
         return tmp.data();
     }
     uint64_t rb() const { return ceil_div(n_cols, 8); }
@@ -166,6 +171,16 @@ struct bigsi_cpu_index {
 namespace {
 
 uint64_t stride_for(uint64_t cols) { return std::max<uint64_t>(128, round_up(ceil_div(cols, 64) * 8, 128)); }
+
+// the result of an entry point that read rows: BIGSI_OK, or -- a BerkeleyDB-backed index whose file could not be read -- the failure
+int bdb_read_failed(const bigsi_cpu_index *ix)
+{
+    if (!ix->bdb) return BIGSI_OK;
+    const int e = ix->bdb->io_error.exchange(0);
+    return e ? fail(BIGSI_ERR_INVALID, "reading a record of the BerkeleyDB store failed: %s%s%s", strerror(e), ix->bdb->db.error.empty() ? "" : ": ",
+                    ix->bdb->db.error.c_str())
+             : BIGSI_OK;
+}
 
 int check_seqs(const char *seqs, const uint64_t *offsets, uint64_t n_seqs, uint32_t k)
 {
@@ -251,7 +266,7 @@ void search_reference_shaped(const bigsi_cpu_index *ix, const char *s, uint64_t 
                 if (ix->bdb) {          // the store's get(): the record's bytes read from the file (an overflow chain of pages for wide rows)
                     row_copy.emplace_back(rb, 0);
                     const BigsiBdb::Loc &l = ix->bdb->loc[r];
-                    if (l.kind) ix->bdb->db.read_value(l, row_copy.back().data(), (uint32_t)std::min<uint64_t>(l.len, rb), bdb_page);
+                    if (l.kind) ix->bdb->note(ix->bdb->db.read_value(l, row_copy.back().data(), (uint32_t)std::min<uint64_t>(l.len, rb), bdb_page));
                 } else row_copy.emplace_back(ix->row(r), ix->row(r) + rb);
             }
         }
@@ -517,7 +532,7 @@ int bigsi_cpu_get_rows(bigsi_cpu_index *ix, const uint64_t *row_ids, uint64_t n,
         if (row_ids[i] >= ix->m) return fail(BIGSI_ERR_RANGE, "row %llu out of range", (unsigned long long)row_ids[i]);
     std::vector<uint8_t> tmp, page;
     for (uint64_t i = 0; i < n; i++) memcpy(out + i * row_bytes, ix->fetch(row_ids[i], row_bytes, tmp, page), row_bytes);
-    return BIGSI_OK;
+    return bdb_read_failed(ix);
 }
 
 int bigsi_cpu_clear(bigsi_cpu_index *ix)
@@ -639,7 +654,7 @@ int bigsi_cpu_lookup(bigsi_cpu_index *ix, const char *kmers, uint32_t k, uint64_
             for (uint64_t b = 0; b < rb; b++) o[b] &= x[b];
         }
     }
-    return BIGSI_OK;
+    return bdb_read_failed(ix);
 }
 
 int bigsi_cpu_search_stream(bigsi_cpu_index *ix, const char *seqs, const uint64_t *offsets, uint64_t n_seqs, uint32_t k,
@@ -664,6 +679,7 @@ int bigsi_cpu_search_stream(bigsi_cpu_index *ix, const char *seqs, const uint64_
         if (min_kmers) min_kmers[i] = mk;
     }
     hit_offsets[n_seqs] = hits.total;
+    TRY(bdb_read_failed(ix));
     if (hits.total > hit_capacity)
         return fail(BIGSI_ERR_CAPACITY, "hit buffers hold %llu entries, %llu needed", (unsigned long long)hit_capacity, (unsigned long long)hits.total);
     return BIGSI_OK;
@@ -698,7 +714,7 @@ int bigsi_cpu_presence(bigsi_cpu_index *ix, const char *seq, uint64_t len, uint3
             out[(uint64_t)j * n + i] = present ? '1' : '0';
         }
     }
-    return BIGSI_OK;
+    return bdb_read_failed(ix);
 }
 
 int bigsi_cpu_score_presence(int, const uint8_t *bits, const uint64_t *bit_offsets, const uint32_t *num_kmers, const uint32_t *found,

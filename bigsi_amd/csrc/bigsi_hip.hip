@@ -447,16 +447,22 @@ extern "C" int bigsi_hip_set_rows(bigsi_hip_index *ix, const uint64_t *row_ids, 
     TRY(quiesce_index(ix));
     const uint64_t kMaxChunkRows = 1ull << 20;      // (the pinned buffers keep room for this many row ids behind the row bytes)
     const uint64_t per = std::min(kMaxChunkRows, std::max<uint64_t>(1, kStageBytes / row_bytes));
-    if (n * row_bytes < (4ull << 20)) {
-        // a few rows (the storage contract's own calls): one staged copy
-        TRY(ix->stage.reserve(n * row_bytes));
-        TRY(ix->stage_ids.reserve(n * 8));
-        HIP_TRY(hipMemcpyAsync(ix->stage.p, bytes, n * row_bytes, hipMemcpyHostToDevice, ix->stream));
-        HIP_TRY(hipMemcpyAsync(ix->stage_ids.p, row_ids, n * 8, hipMemcpyHostToDevice, ix->stream));
-        hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)n), dim3(kBlock), 0, ix->stream, (uint8_t *)ix->d_index,
-                           ix->stride_words * 8, ix->m, ix->stage_ids.as<uint64_t>(), ix->stage.as<uint8_t>(), row_bytes);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(ix->stream));
+    if (n * row_bytes < (4ull << 20) || row_bytes > kStageBytes) {
+        // a few rows (the storage contract's own calls): one staged copy.  Rows wider than a pinned buffer of the route below (64 MB:
+        // more than 512 M columns) come this way too, one row at a time -- that route sizes its buffers for kStageBytes and would
+        // overrun them (round-5 advisor)
+        const uint64_t rows_at_once = row_bytes > kStageBytes ? 1 : n;
+        for (uint64_t i0 = 0; i0 < n; i0 += rows_at_once) {
+            const uint64_t c = std::min(rows_at_once, n - i0);
+            TRY(ix->stage.reserve(c * row_bytes));
+            TRY(ix->stage_ids.reserve(c * 8));
+            HIP_TRY(hipMemcpyAsync(ix->stage.p, bytes + i0 * row_bytes, c * row_bytes, hipMemcpyHostToDevice, ix->stream));
+            HIP_TRY(hipMemcpyAsync(ix->stage_ids.p, row_ids + i0, c * 8, hipMemcpyHostToDevice, ix->stream));
+            hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)c), dim3(kBlock), 0, ix->stream, (uint8_t *)ix->d_index,
+                               ix->stride_words * 8, ix->m, ix->stage_ids.as<uint64_t>(), ix->stage.as<uint8_t>(), row_bytes);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(ix->stream));
+        }
         return BIGSI_OK;
     }
     // blocks of rows (importers: migrate_index, bdb.import_index): the caller's pageable memory goes into one of two pinned

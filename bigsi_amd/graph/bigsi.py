@@ -109,6 +109,86 @@ def native_result_lists(nk, nu, off64, cols, counts, exact, names, scored, db_si
         yield from _results.build(nu, off64, cols, cnts, bool(exact), names, keys, None, None, None, None, lo, min(n, lo + block))
 
 
+def _fast_dict_selftest():
+    """Whether the extension's direct-store route for result dicts may be used in THIS interpreter.  That route (bigsi_amd/_results.cpp:
+    copies of a split-table template, values written into the copy's values array) leans on CPython 3.10's private dict layout; it is
+    compiled for 3.10 only, checks every dict's table before it touches it -- and is OFF unless this test, run once at import, passes:
+    one small batch of scored and plain result lists is built both ways and must be equal in every respect a consumer can see (values,
+    key order, types, json text), stay equal under the same mutations (add / delete / pop / update a key, copy, pickle round trip) and
+    survive a collection.  Anything unexpected -- an exception included -- leaves the portable PyDict_SetItem route in place."""
+    if _results is None or not hasattr(_results, "fast_dict"):
+        return False
+    import copy
+    import gc
+    import json
+    import pickle
+    from ..scoring import HIT_SCORE_DTYPE
+
+    class Name(str):          # (a sample name that is not a plain str: such dicts must stay visible to the collector)
+        pass
+    try:
+        nk = np.array([40, 70, 33], np.uint32)
+        off = np.array([0, 3, 3, 8], np.int64)
+        cols = np.array([0, 2, 5, 1, 2, 3, 4, 6], np.uint32)
+        cnts = np.array([40, 31, 40, 33, 20, 33, 9, 14], np.uint32)
+        names = ["s0", "s1", Name("s2"), "s3", None, "s5", "s6"]
+        rec = np.zeros(8, HIT_SCORE_DTYPE)
+        rec["num_kmers"] = np.repeat(nk, np.diff(off))
+        rec["score"], rec["min_score"], rec["max_score"] = np.arange(8) * 1.25 + 3, np.arange(8) * 0.5, np.arange(8) * 2.0 + 7
+        rec["percent_kmers_found"] = np.round(100.0 * cnts / rec["num_kmers"], 2)
+        rec["max_mismatches"], rec["min_mismatches"], rec["mismatches"] = 5, 1, 3
+        boff = np.zeros(9, np.uint64)
+        boff[1:] = np.cumsum((rec["num_kmers"].astype(np.int64) + 63) // 64 * 8)
+        bits = (np.arange(int(boff[-1])) * 37 % 251).astype(np.uint8)
+
+        def build():
+            return (list(native_result_lists(nk, nk, off, cols, cnts, False, names, (rec, bits, boff), 1000)),
+                    list(native_result_lists(nk, nk, off, cols, cnts, True, names, None, 1000)))
+
+        def same(a, b):
+            if len(a) != len(b) or [len(x) for x in a] != [len(x) for x in b]:
+                return False
+            for x, y in zip(a, b):
+                for d, e in zip(x, y):
+                    if type(d) is not dict or type(e) is not dict or d != e or list(d) != list(e) or [type(v) for v in d.values()] != [type(v) for v in e.values()]:
+                        return False
+                    if json.dumps(d) != json.dumps(e) or dict(d) != e or len(d) != len(e):
+                        return False
+            return True
+        _results.fast_dict(False)
+        slow = build()
+        if not _results.fast_dict(True):
+            return False
+        fast = build()
+        if not all(same(a, b) for a, b in zip(slow, fast)):
+            raise ValueError("the two routes differ")
+        for lists in (slow, fast):              # the same mutations on both
+            for part in lists:
+                for res in part:
+                    for i, d in enumerate(res):
+                        d["extra"] = [i]
+                        d["num_kmers"] += 1
+                        del d["sample_name"]
+                        d.pop("percent_kmers_found")
+                        d.update(zzz=i)
+                        d.setdefault("sample_name", "again")
+        gc.collect()
+        if not all(same(a, b) for a, b in zip(slow, fast)):
+            raise ValueError("the two routes differ after mutation")
+        if pickle.loads(pickle.dumps(fast)) != slow or copy.deepcopy(fast) != slow:
+            raise ValueError("the two routes differ after a round trip")
+        del slow, fast
+        gc.collect()
+        return True
+    except Exception as e:  # noqa: BLE001 -- whatever went wrong, the portable route is the answer
+        logger.warning("bigsi_amd: the direct-store route for result dicts stays off (%s: %s)", type(e).__name__, e)
+        _results.fast_dict(False)
+        return False
+
+
+FAST_DICT_ACTIVE = _fast_dict_selftest()
+
+
 class _StreamTuning(object):
     """The two interpreter-wide settings a running search_stream changes -- a short thread switch interval, the cyclic collector's
     automatic passes paused -- owned by ALL live streams together: the first stream in saves and sets, the last one out restores,

@@ -338,7 +338,8 @@ class HipHbmStorage(BaseStorage):
         for f in ((fn, fn + ".tmp") if fn else ()):
             if os.path.exists(f):
                 os.remove(f)
-            shutil.rmtree(f + ".d", ignore_errors=True)
+            for d in _data_dirs(f):
+                shutil.rmtree(d, ignore_errors=True)
 
     def sync(self):
         fn = self.storage_config.get("filename")
@@ -959,19 +960,42 @@ def _save_snapshot(res, fn, threads=0):
     if res.ix is not None:
         stats = _lib.IoStats()
         if header["striped"]:
-            shutil.rmtree(tmp + ".d", ignore_errors=True)
-            check(res.fn("save_rows_file")(res.ix, (tmp + ".d/").encode(), 0, 0, res.m, header["stride"], int(threads), _lib.C.byref(stats)))
-            shutil.rmtree(fn + ".old.d", ignore_errors=True)
-            if os.path.isdir(fn + ".d"):
-                os.rename(fn + ".d", fn + ".old.d")
-            os.rename(tmp + ".d", fn + ".d")
-            shutil.rmtree(fn + ".old.d", ignore_errors=True)
+            # The part files go into a directory of their OWN that the header names (`data_dir`), alternating between two names, and
+            # the header is replaced -- atomically -- only when they are complete: a crash at any point leaves the previous header
+            # beside the previous, untouched directory (round-5 advisor: renaming directories around one fixed name left a window in
+            # which the old header sat next to the new part files).  The directory not named by the header is garbage and is removed.
+            data_dir = next(d for d in _data_dirs(fn) if os.path.basename(d) != _current_data_dir(fn))
+            shutil.rmtree(data_dir, ignore_errors=True)
+            check(res.fn("save_rows_file")(res.ix, (data_dir + "/").encode(), 0, 0, res.m, header["stride"], int(threads), _lib.C.byref(stats)))
+            header["data_dir"] = os.path.basename(data_dir)
+            hb = json.dumps(header).encode("utf-8")
+            with open(tmp, "wb") as f:
+                f.write(_MAGIC2 + struct.pack("<Q", len(hb)) + hb + extra)
         else:
             check(res.fn("save_rows_file")(res.ix, tmp.encode(), data_off, 0, res.m, header["stride"], int(threads), _lib.C.byref(stats)))
     os.replace(tmp, fn)
-    if not header.get("striped"):
-        shutil.rmtree(fn + ".d", ignore_errors=True)
+    for d in _data_dirs(fn):
+        if os.path.basename(d) != header.get("data_dir"):
+            shutil.rmtree(d, ignore_errors=True)
     return stats
+
+
+def _data_dirs(fn):
+    """The two names a striped snapshot's part-file directory alternates between."""
+    return [fn + ".d", fn + ".1.d"]
+
+
+def _current_data_dir(fn):
+    """basename of the directory the snapshot header at `fn` names, or None (no snapshot, not striped, unreadable)"""
+    try:
+        with open(fn, "rb") as f:
+            if f.read(len(_MAGIC2)) != _MAGIC2:
+                return None
+            (n,) = struct.unpack("<Q", f.read(8))
+            header = json.loads(f.read(n).decode("utf-8"))
+        return header.get("data_dir", os.path.basename(fn) + ".d") if header.get("striped") else None
+    except (OSError, ValueError, struct.error):
+        return None
 
 
 def _load_snapshot(res, fn, threads=0):
@@ -996,7 +1020,8 @@ def _load_snapshot(res, fn, threads=0):
                 raise BigsiHipError(_lib.ERR_CAPACITY, "%s holds rows of %d bytes, the index was opened with room for %d" % (fn, stride, have))
             stats = _lib.IoStats()
             if header.get("striped"):
-                check(res.fn("load_rows_file")(res.ix, (fn + ".d/").encode(), 0, 0, m, stride, int(threads), _lib.C.byref(stats)))
+                data_dir = os.path.join(os.path.dirname(fn), header.get("data_dir", os.path.basename(fn) + ".d"))
+                check(res.fn("load_rows_file")(res.ix, (data_dir + "/").encode(), 0, 0, m, stride, int(threads), _lib.C.byref(stats)))
             else:
                 check(res.fn("load_rows_file")(res.ix, fn.encode(), data_off, 0, m, stride, int(threads), _lib.C.byref(stats)))
             res.written = written if written is not None else np.ones(m, dtype=bool)

@@ -137,6 +137,7 @@ def main():
             if os.path.exists(f):
                 os.remove(f)
             shutil.rmtree(f + ".d", ignore_errors=True)
+            shutil.rmtree(f + ".1.d", ignore_errors=True)
     print(json.dumps(out))
 
 

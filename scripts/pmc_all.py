@@ -98,6 +98,7 @@ def main():
                                 "ratio": t["traffic_bytes_per_launch"] / alg, "dispatches": t["dispatches"], "workload": tag,
                                 "other_kernels": {w_: v for w_, v in ent.items() if w_ != wanted[0]},
                                 "presence_alg_bytes_per_call": (d["config"].get("presence") or {}).get("alg_bytes"),
+                                "presence_line_floor_bytes_per_call": (d["config"].get("presence") or {}).get("line_floor_bytes"),
                                 "source": "profiles/pmc_kernels.json [%s]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH x2 per MI355X_MICROARCH.md" % tag}
         # calibration of the x2: k_fill_synth writes the whole index once
         fill = [k for k in rec if "k_fill_synth" in k]

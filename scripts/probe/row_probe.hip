@@ -59,6 +59,8 @@ int main(int argc, char **argv)
     uint64_t row_bytes = 12500, rows_per_query = 3880, band_mb = 4096;
     uint32_t n_queries = 1024, wgs = 512;
     bool vmm = false, contig = false;
+    uint32_t hk = 4;                                   // kfirst: rows per k-mer
+    std::string modes = "seq,random,sorted,banded";
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto val = [&]() { return std::string(argv[++i]); };
@@ -68,6 +70,8 @@ int main(int argc, char **argv)
         else if (a == "--queries") n_queries = atoi(val().c_str());
         else if (a == "--wgs") wgs = atoi(val().c_str());
         else if (a == "--band-mb") band_mb = strtoull(val().c_str(), nullptr, 10);
+        else if (a == "--h") hk = atoi(val().c_str());
+        else if (a == "--modes") modes = val();
         else if (a == "--vmm") vmm = true;
         else if (a == "--contig") contig = true;
     }
@@ -116,7 +120,11 @@ int main(int argc, char **argv)
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    for (const char *mode : {"seq", "random", "sorted", "banded"}) {
+    // kfirst (round 6): the counting kernel's constraint -- the h rows of a k-mer are fetched together -- with the k-mers of a query
+    // ordered by the address of their FIRST row: 1/h of the fetches sweep the matrix in step across the co-resident queries, the
+    // other (h - 1)/h stay uniform.  kpage: the same with the first rows only bucketed (256 MB buckets), draw order inside a bucket
+    for (const char *mode : {"seq", "random", "sorted", "banded", "kfirst", "kpage"}) {
+        if (("," + modes + ",").find(std::string(",") + mode + ",") == std::string::npos) continue;
         std::vector<uint64_t> ids((size_t)n_queries * rows_per_query);
         for (uint32_t q = 0; q < n_queries; q++) {
             uint64_t *r = ids.data() + (size_t)q * rows_per_query;
@@ -130,6 +138,14 @@ int main(int argc, char **argv)
             } else {
                 for (uint64_t i = 0; i < rows_per_query; i++) r[i] = rng() % n_rows;
                 if (!strcmp(mode, "sorted")) std::sort(r, r + rows_per_query);
+                if (!strcmp(mode, "kfirst") || !strcmp(mode, "kpage")) {
+                    const uint64_t nk = rows_per_query / hk, bucket_rows = !strcmp(mode, "kpage") ? std::max<uint64_t>((256ull << 20) / pitch, 1) : 1;
+                    std::vector<uint64_t> order(nk), tmp(r, r + nk * hk);
+                    for (uint64_t i = 0; i < nk; i++) order[i] = i;
+                    std::stable_sort(order.begin(), order.end(), [&](uint64_t a_, uint64_t b_) { return tmp[a_ * hk] / bucket_rows < tmp[b_ * hk] / bucket_rows; });
+                    for (uint64_t i = 0; i < nk; i++)
+                        for (uint32_t s_ = 0; s_ < hk; s_++) r[i * hk + s_] = tmp[order[i] * hk + s_];
+                }
             }
         }
         CK(hipMemcpy(d_rows, ids.data(), ids.size() * 8, hipMemcpyHostToDevice));

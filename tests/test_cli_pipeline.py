@@ -213,3 +213,37 @@ def test_hold_keeps_the_index_resident_for_other_processes(tmp_path):
         if holder.poll() is None:
             holder.kill()
     assert holder.returncode == 0 and not os.path.exists(attach)
+
+
+def test_hold_without_until_eof_ignores_a_closed_stdin(tmp_path, monkeypatch):
+    """A daemon's stdin is /dev/null -- at its end at once.  Only `--until-eof` may take that as the signal to go (round-5 advisor:
+    the watcher thread used to start unconditionally, so `hold` under nohup / systemd removed its attach file immediately).
+    No GPU: the index is a stand-in; what is tested is who ends the wait."""
+    import io
+    import threading
+    import time
+    from bigsi_amd import __main__ as cli_main
+
+    class Storage(object):
+        def export_attach(self, path):
+            open(path, "w").write("{}")
+
+    class Index(object):
+        num_samples = 3
+        storage = Storage()
+
+        def __init__(self, config):
+            pass
+
+    monkeypatch.setattr(cli_main, "BIGSI", Index)
+    monkeypatch.setattr(sys, "stdin", io.StringIO(""))           # EOF on the first read
+    import signal
+    monkeypatch.setattr(signal, "signal", lambda *a: None)       # (hold() installs handlers: only possible on the main thread)
+    for until_eof, gone_early in ((False, False), (True, True)):
+        path = str(tmp_path / ("h%d.attach" % until_eof))
+        t = threading.Thread(target=cli_main.hold, args=({"storage-config": {}}, path, 1.5, until_eof))
+        t.start()
+        time.sleep(0.7)
+        assert os.path.exists(path) != gone_early, "until_eof=%r: attach file %s after 0.7 s" % (until_eof, "gone" if not os.path.exists(path) else "still there")
+        t.join(timeout=10)
+        assert not t.is_alive() and not os.path.exists(path)

@@ -432,8 +432,20 @@ def test_rows_file_striped_over_part_files(hip, tmp_path):
         a.res.written[:] = True
         a.save_snapshot(fn)
         assert os.path.isdir(fn + ".d") and os.path.getsize(fn) < 1 << 20
-        a.save_snapshot(fn)                                                 # over an existing snapshot
-        assert not os.path.exists(fn + ".old.d") and not os.path.exists(fn + ".tmp.d")
+        a.save_snapshot(fn)                                                 # over an existing snapshot: a directory of its own, the old one goes
+        assert os.path.isdir(fn + ".1.d") and not os.path.exists(fn + ".d") and not os.path.exists(fn + ".tmp.d")
+        # a save that dies between its part files and the header (the one step that switches snapshots is the header's atomic
+        # replace) leaves the previous snapshot whole: header and part files still belong together
+        real_replace = hip_hbm.os.replace
+        hip_hbm.os.replace = lambda *a_: (_ for _ in ()).throw(OSError("simulated crash before the header is replaced"))
+        try:
+            a.set_string("metadata:0:string", "never committed")
+            with pytest.raises(OSError):
+                a.save_snapshot(fn)
+        finally:
+            hip_hbm.os.replace = real_replace
+            a.set_string("metadata:0:string", "zero")
+        assert os.path.isdir(fn + ".1.d") and hip_hbm._current_data_dir(fn) == os.path.basename(fn) + ".1.d"
         s2, _ = hip_hbm.HipHbmStorage.load_snapshot({"name": "striped-snap", "max_cols": n_cols}, fn)
         assert s2.get_string("metadata:0:string") == "zero" and np.array_equal(np.asarray(s2.get_rows_packed(sel)), ref_rows)
         s3, _ = hip_hbm.HipHbmStorage.load_snapshot({"name": "striped-snap-g", "max_cols": n_cols, "devices": [0, 0]}, fn)      # ... and into two shards
@@ -441,8 +453,10 @@ def test_rows_file_striped_over_part_files(hip, tmp_path):
         s3.storage_config["filename"] = str(tmp_path / "snapg.hbm")
         s3.sync()
         assert os.path.isdir(s3.storage_config["filename"] + ".d")
+        s3.sync()
+        assert os.path.isdir(s3.storage_config["filename"] + ".1.d") and not os.path.exists(s3.storage_config["filename"] + ".d")
         s3.delete_all()
-        assert not os.path.exists(s3.storage_config["filename"] + ".d") and not os.path.exists(s3.storage_config["filename"])
+        assert not any(os.path.exists(s3.storage_config["filename"] + e) for e in (".d", ".1.d", ""))
         s2.delete_all()
     finally:
         hip_hbm._STRIPE_FROM = old

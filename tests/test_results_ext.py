@@ -208,3 +208,34 @@ def test_plain_hit_dicts_of_every_route_are_the_same(threshold):
         assert build() == b and not any(gc.is_tracked(d_) for r in build() for d_ in r)
     finally:
         ext.fast_dict(was, True)
+
+
+def test_the_direct_store_route_is_on_only_after_its_self_test(monkeypatch):
+    """bigsi_amd/_results.cpp's direct stores into copied dicts lean on CPython 3.10's private dict layout (round-5 verdict: fragile).  The
+    extension now starts with that route OFF; bigsi_amd.graph.bigsi switches it on at import only if one batch of result lists built both
+    ways is equal, stays equal under mutation and round trips (_fast_dict_selftest) -- and leaves it off the moment anything differs."""
+    import sys
+    from bigsi_amd.graph import bigsi as front
+    ext = front._results
+    if ext is None:
+        pytest.skip("the extension is not built")
+    was = ext.fast_dict()
+    try:
+        assert front.FAST_DICT_ACTIVE == (sys.version_info[:2] == (3, 10)) and was == front.FAST_DICT_ACTIVE
+        assert front._fast_dict_selftest() == front.FAST_DICT_ACTIVE            # repeatable
+        real = front.native_result_lists
+
+        def differs(*a, **k):                    # a route that answers differently when the direct stores are on
+            for res in real(*a, **k):
+                if ext.fast_dict() and res:
+                    res[0]["num_kmers"] += 1
+                yield res
+        monkeypatch.setattr(front, "native_result_lists", differs)
+        assert front._fast_dict_selftest() is False and ext.fast_dict() is False
+
+        def raises(*a, **k):
+            raise RuntimeError("unexpected layout")
+        monkeypatch.setattr(front, "native_result_lists", raises)
+        assert front._fast_dict_selftest() is False and ext.fast_dict() is False
+    finally:
+        ext.fast_dict(was, True)
