@@ -452,6 +452,12 @@ def condense(full):
             "kmerize_ms": sig(rf.get("kmerize_ms"), 4), "compact_ms": sig(rf.get("compact_ms"), 4)}
     line = {k_: full[k_] for k_ in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
     line["value"], line["ms_per_step"] = sig(line["value"], 7), sig(line["ms_per_step"], 6)
+    if full["n_gpus"] > 1 or cf.get("exchange"):
+        # N > 1: what makes the driver's SCALE record self-checking, at the top level of the line -- the size of the RCCL communicator as
+        # the library's own communicator reports it (ncclCommCount through bigsi_hip_comm_info; None: the exchange was not RCCL) and the
+        # row-AND kernel's achieved GB/s on every rank (their sum over N x 8000 is the aggregate roofline fraction)
+        line["rccl_ranks"] = cf.get("rccl_ranks")
+        line["per_rank_GBps"] = [sig(x, 4) for x in cf.get("per_rank_GBps") or []]
     line["config"] = {k_: v_ for k_, v_ in config.items() if v_ is not None}
     line["roofline"] = {k_: v_ for k_, v_ in roof.items() if v_ is not None or k_ == "traffic"}
     cb = full.get("cpu_baseline")

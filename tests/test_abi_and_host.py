@@ -339,6 +339,7 @@ def test_bench_line_is_condensed_under_the_drivers_tail():
     # `value` is the host-visible rate (value_inputs "host"): the resident figure stands beside it, the one-call stream figure is not repeated
     assert line["config"]["value_inputs"] == "host" and line["config"]["resident_lookups_per_s"] == pytest.approx(1.3552e8, rel=1e-3)
     assert "host_visible_lookups_per_s" not in line["config"] and line["config"]["rccl_ranks"] == 8
+    assert line["rccl_ranks"] == 8 and len(line["per_rank_GBps"]) == 8 and line["per_rank_GBps"][0] == pytest.approx(6251, rel=1e-3)      # top level at N > 1
     assert all(l["in"] == "h" and l["rv"] > 0 for l in line["config"]["also"].values())
     full["config"]["value_inputs"] = "resident"          # (score=True workloads, batches of short reads: resident steps, the stream figure beside them)
     assert bench.condense(full)["config"]["host_visible_lookups_per_s"] == pytest.approx(1.3212e8, rel=1e-3)
