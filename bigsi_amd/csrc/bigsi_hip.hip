@@ -968,7 +968,12 @@ static int transpose_device(bigsi_hip_index *ix, uint64_t col0, uint64_t n, cons
     const uint64_t c_lo = std::min(end, round_up(col0, 128)), n_words = (end - c_lo) / 64, c_hi = c_lo + n_words * 64;
     static const int tiled = env_int("BIGSI_HIP_TRANSPOSE_TILED", 1);
     static const int tr_rg = env_int("BIGSI_HIP_TR_RG", 4), tr_cg = env_int("BIGSI_HIP_TR_CG", 1);      // A/B in DESIGN.md section 7
-    static const int tr_double = env_int("BIGSI_HIP_TR_DOUBLE", 1), tr_wide = env_int("BIGSI_HIP_TR_WIDE", 1);
+    // RT = 1 (one 512-row tile per workgroup: 64-byte filter runs, the other half of each line read by the row-neighbour that runs on the
+    // same XCD right after: rg = 4) and CT = 2 (128-byte row runs).  Round 6, filters at a 128-byte pitch, interleaved three times on
+    // three shapes (profiles/r06_transpose_rt_ab.txt): RT = 1 4.05-4.20 / 4.30-4.32 / 4.62-4.71 TB/s against RT = 2 3.84-3.89 / 4.03-4.15 /
+    // 4.29-4.35 -- half the loads per lane (51 VGPRs against 116), half the work between a workgroup's barriers, so the two workgroups of
+    // a CU interleave their memory and butterfly phases more finely.  (At the packed 16-byte pitch of rounds 2-5 RT = 2 measured ahead.)
+    static const int tr_double = env_int("BIGSI_HIP_TR_DOUBLE", 0), tr_wide = env_int("BIGSI_HIP_TR_WIDE", 1);
     const uint64_t rt = tr_double ? 2 : 1, ct = tr_wide ? 2 : 1;
     // supertiles of 1024 tiles: 32 wide, narrower (and higher) when the matrix has fewer tile columns than that
     const uint64_t tiles_c = ceil_div(n_words, 8 * ct);
@@ -1843,6 +1848,16 @@ static hipStream_t k1_stream(const bigsi_hip_index *ix)
 {
     static const int overlap = env_int("BIGSI_HIP_K1_OVERLAP", 0);
     return overlap ? ix->pre_stream : ix->stream;
+}
+
+// see bigsi_internal.hpp; the same arithmetic as the launch rule in bigsi_batch_run below (256-thread workgroups, one slice)
+uint32_t bigsi_exact_launch_queries(const bigsi_hip_index *ix)
+{
+    const uint64_t wv = ceil_div(ix->n_cols, 64);
+    if (wv == 0) return 8;
+    const uint64_t tiles = ceil_div(wv, (uint64_t)256 * kVec), waves_per_q = ceil_div(wv, (uint64_t)64 * kVec);
+    const uint64_t kb = round_up(ceil_div((uint64_t)1600 * tiles, waves_per_q), 256);
+    return (uint32_t)std::max<uint64_t>(8, (kb / tiles) / 8 * 8);
 }
 
 enum K1Route { K1_ELEMENTS, K1_WAVE, K1_LDS, K1_GLOBAL };

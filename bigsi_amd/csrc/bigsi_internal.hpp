@@ -294,6 +294,9 @@ struct bigsi_hip_batch {
 int bigsi_batch_stage(bigsi_hip_index *ix, bigsi_hip_batch **pb, const char *seqs, const uint64_t *offsets, uint32_t n_seqs, uint32_t k);
 int bigsi_batch_run(bigsi_hip_batch *b, double threshold, uint32_t flags, bool one_call);
 int bigsi_batch_export(bigsi_hip_batch *b);
+// queries a row-AND launch of a large exact batch takes on this index (bigsi_batch_run's launch rule: a whole number of workgroups per
+// CU, ~1600 live wavefronts): bigsi_hip_search_stream cuts its device batches at multiples of it, so that none ends in a part launch
+uint32_t bigsi_exact_launch_queries(const bigsi_hip_index *ix);
 int bigsi_batch_collect(bigsi_hip_batch *b, uint32_t *num_kmers, uint32_t *num_unique, uint32_t *min_kmers, uint64_t *hit_offsets,
                         uint32_t *colours, uint32_t *counts, uint64_t capacity);
 int bigsi_use_device(const bigsi_hip_index *ix);

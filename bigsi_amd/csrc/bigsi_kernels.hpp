@@ -2727,7 +2727,7 @@ __global__ __launch_bounds__(kBlock * CT) void k_transpose_tiles(
     // phase 2: the 64 blocks of the 8 x 8 grid, two at a time per wavefront -- ALWAYS two, in one basic block, so that the two
     // butterfly chains (each ~45 dependent vector operations, DPP / permlane exchanges among them) interleave: the two workgroups
     // of a CU are rarely in this phase together, and with two wavefronts per SIMD a single chain leaves the ALUs waiting for
-    // their own results (round 6: +x % over one pair {(cw, rc), (rc, cw)} per trip with the second block behind a branch).
+    // their own results (round 6: +3 ... +5 % over one pair {(cw, rc), (rc, cw)} per trip with the second block behind a branch).
     // Trips 0-6 of a wavefront take the off-diagonal pairs {(x, y), (y, x)}, x < y, number `wave + 4 trip` of the 28 (each block
     // written where its mirror was read: 37 KB of LDS per tile instead of 74); trip 7 takes the diagonal blocks 2 wave and
     // 2 wave + 1, each transposed in place.
@@ -2774,6 +2774,12 @@ __global__ __launch_bounds__(kBlock * CT) void k_transpose_tiles(
     }
     }
 }
+
+// (Round 6 also built the form that takes a workgroup's two column tiles ONE AFTER THE OTHER through one LDS buffer -- 256 threads,
+// 37 KB, four workgroups per CU, the second tile's loads in flight under the first tile's butterflies, the first tile's rows waiting
+// in registers so that both 64-byte halves of a row's run leave in consecutive store instructions: bit-equal, 3.4-3.7 TB/s against
+// 4.1-4.8 for k_transpose_tiles<1,2>, with non-temporal or plain stores alike (profiles/r06_transpose_seq_ab.txt): the halves do not
+// merge on their way out, and a 64-byte write run is what the bare mover prices at 3.7.  Removed.)
 
 // merge_indexes (bigsi/graph/index.py:54-60): append the n2 columns of src after the n1 columns of dst, row by row,
 // device to device.  One thread per (row, destination byte); bits are MSB-first inside a byte, so a column offset that

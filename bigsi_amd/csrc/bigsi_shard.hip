@@ -161,9 +161,13 @@ int search_stream_impl(bigsi_hip_index *ix, const char *seqs, const uint64_t *of
     // read kernel that ordered its hit lists inside the launch (rounds 2-3) 2^14 reads per launch measured best; the wait-free kernel
     // of round 4 prefers smaller launches, more of them in flight: host-visible over 1 M reads of 61 bp 1.04 / 1.41 / 1.51 / 1.45 G
     // lookups/s at 1024 / 2048 / 4096 / 16384 reads per batch, over 64 k reads 1.01 / 1.36 / 1.39 / 1.27 G (interleaved, twice each)
-    constexpr uint64_t kChunkPositions = 1ull << 20;
+    // thresholded searches of gene-length queries take four times that: the counting kernel is ONE launch per chunk (chunked it measured
+    // -4 ... 0 %, bigsi_batch_run), and every launch pays its tail -- 8192 x 1 kbp at 0.4 on 10 M x 100 k: 8 launches of ~1080 queries
+    // 0.774 of peak by the kernel's clock, one launch of 8192 0.80 (round 6); the counters of a chunk are 2 bytes x samples per query
+    const uint64_t kChunkPositions = (threshold == 1.0 || so) ? 1ull << 20 : 1ull << 22;      // (scored: K5 + K6 of a chunk run beside the next chunk's row-AND -- more, smaller chunks)
     static const int chunk_seqs_env = env_int("BIGSI_HIP_STREAM_SEQS", 0);
     const uint64_t kChunkSeqs = chunk_seqs_env > 0 ? (uint64_t)chunk_seqs_env : 4096;
+    const uint32_t launch_q = bigsi_exact_launch_queries(ix);
     struct Chunk { uint64_t first; uint32_t n; uint64_t hit0, bit0; bool scoring; };
     Chunk inflight[kMaxSlots] = {};
     bool busy[kMaxSlots] = {};       // launched, hit lists not collected yet
@@ -236,6 +240,10 @@ int search_stream_impl(bigsi_hip_index *ix, const char *seqs, const uint64_t *of
             end++;
         }
         if (rc != BIGSI_OK) break;
+        // an exact chunk of gene-length queries goes out as several row-AND launches of launch_q queries each: end it on a multiple of
+        // that, so that no chunk closes with a part launch (10 M x 100 k, 8192 x 1 kbp per call: 8 chunks x 8 launches of 128 queries
+        // instead of 8 x (8 + a launch of 57); round 6)
+        if (threshold == 1.0 && end < n_seqs && end - next >= 2ull * launch_q) end = next + (end - next) / launch_q * launch_q;
         if (busy[slot]) rc = collect(slot);                    // this workspace's previous chunk (three chunks ago)
         if (rc == BIGSI_OK && so) rc = finish_score(slot);
         if (rc != BIGSI_OK) break;
