@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
 PEAK = 8000.0
-R = os.environ.get("ROUND", "r05")      # prefix of this round's files
+R = os.environ.get("ROUND", "r06")      # prefix of this round's files
 
 
 def short(name):
@@ -192,7 +192,7 @@ def main():
         shutil.copy(os.path.join(SRC, "pmc", "pmc_kernels.json"), os.path.join(DST, R + "_pmc_kernels.json"))
     except OSError:
         pass
-    for name in (R + "_latency_probe.txt", R + "_frontend_probe.json", R + "_bench_default_full.json"):
+    for name in (R + "_latency_probe.txt", R + "_frontend_probe.json", R + "_bench_default_full.json", R + "_pmc_requests.json"):
         if os.path.exists(os.path.join(SRC, name)):
             shutil.copy(os.path.join(SRC, name), os.path.join(DST, name))
     for name in (R + "_row_probe.txt", R + "_call_breakdown.txt", R + "_call_trace.txt", R + "_k1_phases.txt", R + "_one_call_timeline.txt", R + "_python_stack_latency.txt", R + "_ingest.json", R + "_import.json", R + "_tmpfs_write_probe.txt",

@@ -2071,3 +2071,38 @@ def test_search_stream_entry_point_equals_batch_runs(hip):
         for i, (a, b_, c_, d_) in enumerate(res):
             assert a == nk2[i] and b_ == nu2[i] and np.array_equal(c_, col2[int(off2[i]):int(off2[i + 1])]) and np.array_equal(d_, cnt2[int(off2[i]):int(off2[i + 1])])
     st.delete_all()
+
+
+def test_search_stream_chunks_cut_at_whole_row_and_launches(hip):
+    """Round 6: bigsi_hip_search_stream ends an exact chunk of gene-length queries on a multiple of the row-AND launch size (no chunk closes
+    with a part launch) and gives thresholded searches four times the positions per chunk.  On 20 000 samples a launch takes 768 queries
+    and 2^20 positions are 2093 queries of 531 bp: exact chunks of 1536, thresholded ones of 8371 -- several of each here, against plain
+    batches (hit lists whole) and the oracle (sampled)."""
+    from oracle.ref_model import SynthOracle
+    m, n_cols, h = 200_003, 20_000, 3
+    c, st = synth_index(hip, m, n_cols, h, 45, draws=1)
+    orc = SynthOracle(45, 0, m, n_cols, h, 31, 1)
+    rng = np.random.default_rng(9)
+    genes = random_seqs(rng, 9000, 531, 531)
+    for col_, i in ((7, 0), (19_999, 1535), (640, 1536), (12_345, 3071), (3, 3072), (9_000, 8370), (9_001, 8371), (5, 8999)):      # either side of every cut
+        st.insert_kmers(col_, [genes[i]], 31)
+        orc.insert_kmers(col_, genes[i])
+    for seqs, thr in ((genes[:5000], 1.0), (genes, 0.45)):
+        nk, nu, off, col, cnt = st.search_many(seqs, 31, thr)
+        assert off[0] == 0 and int(off[-1]) == col.size == cnt.size and int(off[-1]) >= 4
+        for lo in range(0, len(seqs), 3000):
+            part = seqs[lo:lo + 3000]
+            b = st.new_batch(part, 31)
+            b.run(thr, sparse_counts=True)
+            bnk, bnu, _ = b.unique()
+            boff, bcol, bcnt = b.hits()
+            b.close()
+            assert np.array_equal(nk[lo:lo + len(part)], bnk) and np.array_equal(nu[lo:lo + len(part)], bnu)
+            assert np.array_equal(off[lo:lo + len(part) + 1].astype(np.int64) - int(off[lo]), boff.astype(np.int64))
+            assert np.array_equal(col[int(off[lo]):int(off[lo + len(part)])], bcol) and np.array_equal(cnt[int(off[lo]):int(off[lo + len(part)])], bcnt)
+        for i in [0, 1535, 1536, 3071, 3072, len(seqs) - 1] + ([8370, 8371] if len(seqs) > 8371 else []) + list(range(11, len(seqs), 997)):
+            u, want_cnt = orc.counts(seqs[i])
+            want = np.flatnonzero(want_cnt >= (u if thr == 1.0 else int(np.ceil(u * thr))))
+            assert nu[i] == u and np.array_equal(col[int(off[i]):int(off[i + 1])], want), (thr, i)
+            assert np.array_equal(cnt[int(off[i]):int(off[i + 1])], want_cnt[want].astype(np.uint32))
+    st.delete_all()
