@@ -952,7 +952,7 @@ extern "C" int bigsi_hip_insert_column(bigsi_hip_index *ix, uint64_t col, const 
 #define ev_end bigsi_ev_end
 
 // n filters already on the device -> columns [col0, col0 + n): whole 64-column words through the tiled transpose
-// (k_transpose_tiles), the ragged head (up to the next multiple of 128 columns) and tail through k_insert_columns
+// (k_transpose_regs), the ragged head (up to the next multiple of 128 columns) and tail through k_insert_columns
 static int transpose_device(bigsi_hip_index *ix, uint64_t col0, uint64_t n, const uint8_t *d_blooms, uint64_t bstride)
 {
     const uint64_t nb = ceil_div(ix->m, 8), end = col0 + n;
@@ -967,14 +967,17 @@ static int transpose_device(bigsi_hip_index *ix, uint64_t col0, uint64_t n, cons
     };
     const uint64_t c_lo = std::min(end, round_up(col0, 128)), n_words = (end - c_lo) / 64, c_hi = c_lo + n_words * 64;
     static const int tiled = env_int("BIGSI_HIP_TRANSPOSE_TILED", 1);
-    static const int tr_rg = env_int("BIGSI_HIP_TR_RG", 4), tr_cg = env_int("BIGSI_HIP_TR_CG", 1);      // A/B in DESIGN.md section 7
-    // RT = 1 (one 512-row tile per workgroup: 64-byte filter runs, the other half of each line read by the row-neighbour that runs on the
-    // same XCD right after: rg = 4) and CT = 2 (128-byte row runs).  Round 6, filters at a 128-byte pitch, interleaved three times on
-    // three shapes (profiles/r06_transpose_rt_ab.txt): RT = 1 4.05-4.20 / 4.30-4.32 / 4.62-4.71 TB/s against RT = 2 3.84-3.89 / 4.03-4.15 /
-    // 4.29-4.35 -- half the loads per lane (51 VGPRs against 116), half the work between a workgroup's barriers, so the two workgroups of
-    // a CU interleave their memory and butterfly phases more finely.  (At the packed 16-byte pitch of rounds 2-5 RT = 2 measured ahead.)
-    static const int tr_double = env_int("BIGSI_HIP_TR_DOUBLE", 0), tr_wide = env_int("BIGSI_HIP_TR_WIDE", 1);
-    const uint64_t rt = tr_double ? 2 : 1, ct = tr_wide ? 2 : 1;
+    static const int tr_rg = env_int("BIGSI_HIP_TR_RG", 4), tr_cg = env_int("BIGSI_HIP_TR_CG", 1);      // XCD groups: A/B in profiles/r06_transpose_regs_ab.txt
+    // k_transpose_regs<2>: 1024 rows x 1024 columns per workgroup -- whole 128-byte lines of the filters in (two consecutive loads per
+    // lane), 128-byte runs of the rows out.  (RT = 1, 512 rows: 4.4-5.0 TB/s against 4.9-5.4, its half lines shared with another workgroup.)
+    static const int tr_double = env_int("BIGSI_HIP_TR_DOUBLE", 1);
+    bool regs = true;
+    uint64_t rt = tr_double ? 2 : 1, ct = 2;
+#ifdef BIGSI_HIP_TUNING
+    static const int tr_regs = env_int("BIGSI_HIP_TR_REGS", 1), tr_wide = env_int("BIGSI_HIP_TR_WIDE", 1);      // 0: k_transpose_tiles<RT, CT> of rounds 2-6
+    regs = tr_regs != 0;
+    if (!regs) ct = tr_wide ? 2 : 1;
+#endif
     // supertiles of 1024 tiles: 32 wide, narrower (and higher) when the matrix has fewer tile columns than that
     const uint64_t tiles_c = ceil_div(n_words, 8 * ct);
     uint32_t sup_w = kTransposeSuper;
@@ -986,18 +989,20 @@ static int transpose_device(bigsi_hip_index *ix, uint64_t col0, uint64_t n, cons
 #define BIGSI_TR_ARGS                                                                                                          \
     dim3((unsigned)sup_blocks), dim3(kBlock * (unsigned)ct), 0, ix->stream, ix->d_index, ix->stride_words, ix->m, c_lo / 64, n_words,  \
         d_blooms + (c_lo - col0) * bstride, bstride, nb, (uint32_t)tr_rg, cg_eff, sup_w
+#define COMMA ,
+    if (regs && rt == 2) hipLaunchKernelGGL((k_transpose_regs<2>), BIGSI_TR_ARGS);
+    else if (regs) hipLaunchKernelGGL((k_transpose_regs<1>), BIGSI_TR_ARGS);
 #ifdef BIGSI_HIP_TUNING
-    {
+    else {
         static const int skip = env_int("BIGSI_HIP_TR_SKIP", 0);
         static bool set = false;
         if (!set) { const uint32_t v = (uint32_t)skip; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_tr_skip), &v, 4)); set = true; }
+        if (rt == 2 && ct == 2) hipLaunchKernelGGL((k_transpose_tiles<2 COMMA 2>), BIGSI_TR_ARGS);
+        else if (rt == 2) hipLaunchKernelGGL((k_transpose_tiles<2 COMMA 1>), BIGSI_TR_ARGS);
+        else if (ct == 2) hipLaunchKernelGGL((k_transpose_tiles<1 COMMA 2>), BIGSI_TR_ARGS);
+        else hipLaunchKernelGGL((k_transpose_tiles<1 COMMA 1>), BIGSI_TR_ARGS);
     }
 #endif
-#define COMMA ,
-    if (tr_double && tr_wide) hipLaunchKernelGGL((k_transpose_tiles<2 COMMA 2>), BIGSI_TR_ARGS);
-    else if (tr_double) hipLaunchKernelGGL((k_transpose_tiles<2 COMMA 1>), BIGSI_TR_ARGS);
-    else if (tr_wide) hipLaunchKernelGGL((k_transpose_tiles<1 COMMA 2>), BIGSI_TR_ARGS);
-    else hipLaunchKernelGGL((k_transpose_tiles<1 COMMA 1>), BIGSI_TR_ARGS);
 #undef COMMA
 #undef BIGSI_TR_ARGS
     HIP_TRY(hipGetLastError());

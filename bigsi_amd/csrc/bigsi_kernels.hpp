@@ -2547,6 +2547,12 @@ __global__ __launch_bounds__(kBlock) void k_insert_columns(
     }
 }
 
+constexpr int kTransposeTile = 512, kTransposeSuper = 32;      // rows of a tile pass; supertile edge, in tiles
+
+#ifdef BIGSI_HIP_TUNING
+// ROUNDS 2-6's KERNEL, kept in tuning builds only (BIGSI_HIP_TR_REGS=0; scripts/ab_transpose_regs.sh, scripts/probe/transpose_ab.hip)
+// as the other side of the A/B that k_transpose_regs below is measured against.  The product library does not hold it.
+constexpr int kTransposePitch = 72;
 // The transpose as a bandwidth kernel (full 64-column words; k_insert_columns above keeps the ragged edges).
 // A tile is 512 rows x 512 columns: 64 bytes of each of 512 filters in, 64 bytes of each of 512 rows out, as whole runs
 // (16 bytes per lane), so every sector that crosses the memory interface is used in full and nothing is read-modified-written;
@@ -2557,7 +2563,6 @@ __global__ __launch_bounds__(kBlock) void k_insert_columns(
 // Bit order: both the filters and the rows keep the reference's byte format (bit 7 - (i & 7) of byte i >> 3), so in a
 // little-endian uint64 element i sits at bit_of_col(i); by_column() turns that into plain order for the butterfly, and lane
 // l is given column bit_of_col(l) of the word, which puts every result bit where the row format wants it.
-constexpr int kTransposeTile = 512, kTransposePitch = 72, kTransposeSuper = 32;
 
 // 64 x 64 bit transpose across the lanes of a wavefront, on 32-bit halves (64-bit shifts run at a quarter of the rate):
 // after it, bit k of lane i = bit i of (the original value of) lane k.  Step j (32, 16, .. 1) swaps, between lanes l and
@@ -2652,9 +2657,7 @@ __device__ __forceinline__ void transpose64_lanes_x2(uint64_t &a64, uint64_t &b6
     b64 = ((uint64_t)hi2 << 32) | lo2;
 }
 
-#ifdef BIGSI_HIP_TUNING
 __device__ uint32_t g_tr_skip = 0;      // experiment (BIGSI_HIP_TR_SKIP=1): move the tiles without transposing them
-#endif
 // RT = 1: one 512-row tile per workgroup (64-byte filter runs); 2: two stacked tiles, their 128-byte filter runs loaded in one go.
 // CT = 1: 512 columns per workgroup (64-byte row runs); 2: two tiles side by side, each handled by its own 256 threads in its
 // own LDS buffer, their rows stored together as 128-byte runs (half as many DRAM row activations on the write side).
@@ -2731,9 +2734,7 @@ __global__ __launch_bounds__(kBlock * CT) void k_transpose_tiles(
     // Trips 0-6 of a wavefront take the off-diagonal pairs {(x, y), (y, x)}, x < y, number `wave + 4 trip` of the 28 (each block
     // written where its mirror was read: 37 KB of LDS per tile instead of 74); trip 7 takes the diagonal blocks 2 wave and
     // 2 wave + 1, each transposed in place.
-#ifdef BIGSI_HIP_TUNING
     if (!(g_tr_skip & 1u))
-#endif
 #pragma unroll 1
     for (uint32_t trip = 0; trip < 8; trip++) {
         uint32_t x, y, xb, yb;                              // block a = (cw = x, rc = y), block b = (cw = xb, rc = yb)
@@ -2780,6 +2781,134 @@ __global__ __launch_bounds__(kBlock * CT) void k_transpose_tiles(
 // in registers so that both 64-byte halves of a row's run leave in consecutive store instructions: bit-equal, 3.4-3.7 TB/s against
 // 4.1-4.8 for k_transpose_tiles<1,2>, with non-temporal or plain stores alike (profiles/r06_transpose_seq_ab.txt): the halves do not
 // merge on their way out, and a 64-byte write run is what the bare mover prices at 3.7.  Removed.)
+#endif      // BIGSI_HIP_TUNING
+
+// ------------------------------------------------------------------------------ the transpose without lane butterflies (round 6)
+// k_transpose_tiles spends ~90 vector instructions per 64 x 64 bit block on six exchange steps between lanes, and passes every
+// tile through the LDS twice (in, block by block in place, out); with the filters at an aligned pitch the memory side of it moves
+// 5.0-5.2 TB/s and the kernel 4.1-4.4 (profiles/r06_transpose_ab_aligned.txt: "no phase 2").  k_transpose_regs does the BIT
+// level of the transpose between the REGISTERS of a thread and the BYTE level on the way out of the LDS:
+//   1. a thread loads 16 bytes (128 rows) of EIGHT neighbouring filters -- columns 8 g .. 8 g + 7, the columns of ONE byte of
+//      the rows -- and transposes the 8 x 8 bit blocks between its 8 registers, all 16 byte lanes at once: three steps of
+//      shift + v_bfi on register pairs (192 vector instructions per 128 bytes, an eighth of the butterflies).  Register t then
+//      holds, for each of the thread's 16 row-bytes e, the byte (columns 8 g .. 8 g + 7) of row 8 e + t;
+//   2. it stores them as 8-byte words -- 8 bytes = 8 rows that are 8 apart, one column byte -- at LDS word (t, e / 8, p; g);
+//   3. after ONE barrier, ds_read_b64_tr_b8 (gfx950's transposing LDS read: inside a group of 16 lanes, lane (a, b) receives byte
+//      b of the words addressed by lanes 2 j + a, j = 0 .. 7; scripts/probe/tr_probe.hip prints the map read off the hardware)
+//      hands every lane 8 CONSECUTIVE column bytes of one row: two reads = the 16 bytes of its store.  A wave instruction
+//      stores 8 rows x 128 bytes.
+// LDS: 64 x (128 + 4) words of 8 bytes = 66 KB per workgroup of 512 threads (512 rows x 1024 columns), two per CU; the +4
+// words make the stores of phase 2 conflict-free (16 lanes = 4 column bytes x 4 pieces), the flip of word bit 3 by bit 5 the reads
+// of phase 3 (32 lanes = 4 pieces x 8 column bytes, 16 words apart).
+// RT = 2: 1024 rows per workgroup -- the thread loads both 64-byte halves of its filters' 128-byte lines at once and the two
+// 512-row halves go through the LDS one after the other.
+constexpr uint32_t kTrRegsPitch = 132;      // 8-byte words per (t, eh, p) line of the LDS image: 128 column bytes + 4
+
+__device__ __forceinline__ uint32_t tr_regs_word(uint32_t line, uint32_t cb) { return line * kTrRegsPitch + (cb ^ ((cb >> 2) & 8u)); }
+
+// 8 x 8 bit blocks between 8 registers, bytes independent: x[i] bit (7 - t) of byte q  ->  x[t] bit (7 - i) of byte q
+__device__ __forceinline__ void transpose8_regs(uint32_t (&x)[8])
+{
+#define BIGSI_TR8_STEP(S, M)                                                                  \
+    _Pragma("unroll") for (int u = 0; u < 8; u++) {                                           \
+        if (u & S) continue;                                                                  \
+        const uint32_t xu = x[u], xv = x[u + S];                                              \
+        x[u + S] = (xv & (uint32_t)M) | ((xu << S) & ~(uint32_t)M);                           \
+        x[u] = (xu & ~(uint32_t)M) | ((xv >> S) & (uint32_t)M);                               \
+    }
+    BIGSI_TR8_STEP(4, 0x0F0F0F0Fu)
+    BIGSI_TR8_STEP(2, 0x33333333u)
+    BIGSI_TR8_STEP(1, 0x55555555u)
+#undef BIGSI_TR8_STEP
+}
+
+typedef int tr_v2i __attribute__((ext_vector_type(2)));
+
+template <int RT>
+__global__ __launch_bounds__(kBlock * 2) void k_transpose_regs(
+    uint64_t *__restrict__ index, uint64_t stride_words, uint64_t m, uint64_t w_first /* first column word written; even */,
+    uint64_t n_words /* whole 64-column words to write */, const uint8_t *__restrict__ blooms /* filter of column 64 * w_first */,
+    uint64_t bstride /* bytes between filters; multiple of 16 */, uint64_t nb /* valid bytes of a filter: ceil(m / 8) */,
+    uint32_t rg, uint32_t cg /* tiles per XCD group along rows / columns: powers of two, rg * cg <= 128, cg <= sup_w */,
+    uint32_t sup_w /* supertile width in tiles: a power of two <= 32 */)
+{
+    __shared__ __attribute__((aligned(16))) uint64_t image[64 * kTrRegsPitch];
+    constexpr uint32_t kWordsPerBlock = 16;             // 1024 columns
+    // workgroup -> tile: as k_transpose_tiles (supertiles of 1024 tiles, groups of rg x cg neighbours on one XCD)
+    const uint64_t tiles_c = (n_words + kWordsPerBlock - 1) / kWordsPerBlock, sup_c = (tiles_c + sup_w - 1) / sup_w;
+    const uint32_t sup_h = (uint32_t)(kTransposeSuper * kTransposeSuper) / sup_w;
+    const uint64_t sup = blockIdx.x / (kTransposeSuper * kTransposeSuper);
+    const uint32_t within = blockIdx.x % (kTransposeSuper * kTransposeSuper);
+    const uint32_t gsz = rg * cg, xcd = within & 7u, sl = within >> 3, tg = sl % gsz, grp = (sl / gsz) * 8u + xcd;
+    const uint32_t gpr = sup_w / cg;
+    const uint64_t tile_r = (sup / sup_c) * sup_h + (grp / gpr) * rg + tg % rg;
+    const uint64_t tile_c = (sup % sup_c) * sup_w + (grp % gpr) * cg + tg / rg;
+    if (tile_r * kTransposeTile * RT >= m || tile_c >= tiles_c) return;
+    const uint64_t byte0 = tile_r * (kTransposeTile / 8) * RT;
+    const uint64_t w0 = tile_c * kWordsPerBlock;
+    const uint32_t words_here = (uint32_t)(n_words - w0 < kWordsPerBlock ? n_words - w0 : kWordsPerBlock);
+    // phase 1: thread (g, p): 16 bytes at byte0 + 64 half + 16 p of the filters of columns 8 g .. 8 g + 7
+    const uint32_t g = threadIdx.x >> 2, p = threadIdx.x & 3u;
+    u64x2 ld[RT][8];
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+#pragma unroll
+        for (int half = 0; half < RT; half++) {
+            const uint64_t off = byte0 + 64 * half + 16 * p;
+            const bool ok = g < words_here * 8u && off + 16 <= bstride && off < nb;
+            const u64x2 *src = reinterpret_cast<const u64x2 *>(blooms + (w0 * 64 + (ok ? g * 8u + it : 0u)) * bstride + (ok ? off : 0));
+            // PLAIN loads: the two 64-byte halves of a filter's line are asked for by consecutive instructions, and only a line the
+            // vector L1 has allocated takes the second one as a hit -- with non-temporal loads the L2 was asked 1.19 times per line
+            // (1.31 with RT = 1, where the other half belongs to another workgroup; TCC_EA0_RDREQ, scripts/pmc_requests.py), with the
+            // halves eight instructions apart twice; with plain loads 1.000 (+5 ... +8 % on the kernel)
+            ld[half][it] = ok ? *src : u64x2{0ull, 0ull};
+        }
+    }
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // phase 3's places: the wavefront takes the 64 rows 128 pw + 64 ehw + (0 .. 63) of the half; instruction t reads line (t, ehw, pw)
+    // for the rows t + 8 b.  Lane = (gi, i): it ADDRESSES column byte 16 (2 gi + (i & 1)) + (i >> 1) (+ 8 for the second read) and
+    // RECEIVES (b = i & 7, a = i >> 3) the bytes 16 (2 gi + a) + 0 .. 7 (8 .. 15) of row 8 b + t
+    const uint32_t pw = wave >> 1, ehw = wave & 1u, gi = lane >> 4, li = lane & 15u;
+    const uint32_t cb_addr = 16u * (2u * gi + (li & 1u)) + (li >> 1);
+    const uint32_t piece = 2u * gi + (li >> 3), brow = li & 7u;
+#pragma unroll
+    for (int half = 0; half < RT; half++) {
+        if (half) __syncthreads();                          // phase 3 of the first half has read the image
+        // phases 1b + 2: bit transpose between the registers, dword by dword, then the words of the image
+#pragma unroll
+        for (int d2 = 0; d2 < 2; d2++) {                    // d2 = eh: row bytes 16 p + 8 eh + (0 .. 7)
+            uint32_t lo[8], hi[8];
+#pragma unroll
+            for (int it = 0; it < 8; it++) {
+                const uint64_t v = d2 ? ld[half][it].y : ld[half][it].x;
+                lo[it] = (uint32_t)v;
+                hi[it] = (uint32_t)(v >> 32);
+            }
+            transpose8_regs(lo);
+            transpose8_regs(hi);
+#pragma unroll
+            for (int t = 0; t < 8; t++) image[tr_regs_word((t * 2 + d2) * 4 + p, g)] = ((uint64_t)hi[t] << 32) | lo[t];
+        }
+        __syncthreads();
+        const uint64_t r0 = (tile_r * RT + half) * kTransposeTile + 128u * pw + 64u * ehw + 8u * brow;
+        tr_v2i v0[8], v1[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            const uint32_t line = (t * 2 + ehw) * 4 + pw;
+            v0[t] = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) tr_v2i *)(image + tr_regs_word(line, cb_addr)));
+            v1[t] = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) tr_v2i *)(image + tr_regs_word(line, cb_addr + 8u)));
+        }
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            const uint64_t r = r0 + t;
+            if (r >= m || piece * 2 >= words_here) continue;
+            const uint64_t a = ((uint64_t)(uint32_t)v0[t].y << 32) | (uint32_t)v0[t].x, b = ((uint64_t)(uint32_t)v1[t].y << 32) | (uint32_t)v1[t].x;
+            uint64_t *dst = index + r * stride_words + w_first + w0 + piece * 2;
+            if (piece * 2 + 1 < words_here) __builtin_nontemporal_store(u64x2{a, b}, reinterpret_cast<u64x2 *>(dst));
+            else dst[0] = a;
+        }
+    }
+}
 
 // merge_indexes (bigsi/graph/index.py:54-60): append the n2 columns of src after the n1 columns of dst, row by row,
 // device to device.  One thread per (row, destination byte); bits are MSB-first inside a byte, so a column offset that

@@ -1,5 +1,5 @@
 cd "${GRAFT_REPO_ROOT:-.}"
-export BIGSI_HIP_LIB=$PWD/bigsi_amd/libbigsi_hip_tuning.so BIGSI_TR_SHAPES=10000000x8192,1000000x100000,4000000x32768
+export BIGSI_HIP_LIB=$PWD/bigsi_amd/libbigsi_hip_tuning.so BIGSI_TR_SHAPES=10000000x8192,1000000x100000,4000000x32768 BIGSI_HIP_TR_REGS=0      # (the kernel of rounds 2-6: tuning builds only)
 for rep in 1 2 3; do for cfg in "1 1 4 1" "0 1 4 1" "0 1 8 1"; do
     set -- $cfg
     echo "== rep $rep RT=$((1 + $1)) CT=$((1 + $2)) rg=$3 cg=$4"

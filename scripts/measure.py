@@ -248,7 +248,7 @@ def transpose():
             assert np.array_equal(st.get_rows_packed([r], (ncols + 7) // 8)[0], np.packbits(bits)), r
         emit("transpose_device", m=m, cols=ncols, kernels_ms=s.transpose_ms, bytes_in_plus_out=moved,
              GBps=moved / s.transpose_ms / 1e6, frac=moved / s.transpose_ms / 1e6 / PEAK, filter_pitch=pitch,
-             note="k_transpose_tiles (+ k_insert_columns for ragged edges); filters resident in HBM")
+             note="k_transpose_regs (+ k_insert_columns for ragged edges); filters resident in HBM")
         del blooms
         st.delete_all()
 

@@ -33,7 +33,7 @@ WORKLOADS = [
     ("c2_dense", ["bench.py", "--workload", "c2", "--dense", "1", "--steps", "64", "--warmup", "8"] + B, ["k_reads_fused"]),
     ("ns_shard", ["bench.py", "--workload", "northstar", "--shard-of", "8", "--steps", "8", "--warmup", "2"] + B, ["k_and_exact"]),
     ("ns_shard_t04", ["bench.py", "--workload", "northstar", "--shard-of", "8", "--steps", "8", "--warmup", "2", "--threshold", "0.4"] + B, ["k_and_count"]),
-    ("transpose", ["scripts/measure.py", "transpose"], ["k_transpose_tiles"]),
+    ("transpose", ["scripts/measure.py", "transpose"], ["k_transpose_regs"]),
 ]
 
 

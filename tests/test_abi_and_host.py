@@ -563,17 +563,17 @@ def _library_kernels():
 
 
 def test_profiles_of_this_round_describe_the_built_library():
-    """Every kernel a rocprofv3 summary of THIS round names (profiles/r05_*_kernel_stats.csv) is a kernel of the library the tree
+    """Every kernel a rocprofv3 summary of THIS round names (profiles/r06_*_kernel_stats.csv) is a kernel of the library the tree
     builds -- a summary made before a kernel changed its template parameters names one that no longer exists -- and the round's stamp
-    (profiles/r05_stamp.json: commit and library hash the profiles were made with) is present."""
+    (profiles/r06_stamp.json: commit and library hash the profiles were made with) is present."""
     import csv
     import glob
     from bigsi_amd import _lib
     if not os.path.exists(_lib.LIB_PATH):
         pytest.skip("libbigsi_hip.so not built")
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_*_kernel_stats.csv")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r06_*_kernel_stats.csv")))
     if not files:
-        pytest.skip("no round-5 profiles yet")
+        pytest.skip("no round-6 profiles yet")
     have = _library_kernels()
     assert len(have) > 30
     norm = lambda s_: s_.replace(" ", "")      # noqa: E731 -- (demanglers differ in spacing)
@@ -587,7 +587,7 @@ def test_profiles_of_this_round_describe_the_built_library():
                     missing.setdefault(os.path.basename(fn), []).append(name)
     assert not missing, "profiles name kernels the built library does not hold: %r" % missing
     import json
-    st = json.load(open(os.path.join(ROOT, "profiles", "r05_stamp.json")))
+    st = json.load(open(os.path.join(ROOT, "profiles", "r06_stamp.json")))
     assert len(st.get("git_head", "")) == 40 and len(st.get("libbigsi_hip_so_sha256", "")) == 64
 
 

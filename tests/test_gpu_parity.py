@@ -1636,11 +1636,12 @@ def test_transpose_on_device_matches_numpy(hip):
 
 
 
-@pytest.mark.parametrize("m,first,second", [(5003, 700, 300), (4096, 1024, 64), (1000, 129, 1), (70000, 64, 1000), (513, 5, 250)])
+@pytest.mark.parametrize("m,first,second", [(5003, 700, 300), (4096, 1024, 64), (1000, 129, 1), (70000, 64, 1000), (513, 5, 250), (3001, 2304, 333), (1025, 3, 2110)])
 def test_tiled_transpose_matches_numpy(hip, m, first, second):
-    """bigsi_hip_insert_columns: whole 64-column words go through the tiled LDS transpose, ragged heads / tails through the
-    column-at-a-time kernel; appending at a column that is not a multiple of 128, row counts that are not multiples of 8 or
-    512, filters shorter than a vector load.  Rows must equal numpy's transpose of the filters bit for bit."""
+    """bigsi_hip_insert_columns: whole 64-column words go through the tiled transpose (k_transpose_regs: 1024 x 1024 tiles, bit level
+    between registers, byte level in the transposing LDS read), ragged heads / tails through the column-at-a-time kernel; appending at a
+    column that is not a multiple of 128, row counts that are not multiples of 8, 512 or 1024, several tile columns with a partial last
+    one, filters shorter than a vector load.  Rows must equal numpy's transpose of the filters bit for bit."""
     from bigsi_amd.storage import get_storage
     rng = np.random.default_rng(m + first)
     n = first + second
