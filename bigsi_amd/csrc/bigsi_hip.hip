@@ -980,7 +980,8 @@ static int transpose_device(bigsi_hip_index *ix, uint64_t col0, uint64_t n, cons
 #endif
     // supertiles of 1024 tiles: 32 wide, narrower (and higher) when the matrix has fewer tile columns than that
     const uint64_t tiles_c = ceil_div(n_words, 8 * ct);
-    uint32_t sup_w = kTransposeSuper;
+    static const int tr_supw = env_int("BIGSI_HIP_TR_SUPW", kTransposeSuper);
+    uint32_t sup_w = (uint32_t)tr_supw;
     while (sup_w > 1 && sup_w / 2 >= tiles_c) sup_w /= 2;
     const uint32_t sup_h = (uint32_t)(kTransposeSuper * kTransposeSuper) / sup_w, cg_eff = std::min<uint32_t>((uint32_t)tr_cg, sup_w);
     const uint64_t sup_blocks = ceil_div(ceil_div(ix->m, kTransposeTile * rt), sup_h) * ceil_div(tiles_c, sup_w) * (uint64_t)(kTransposeSuper * kTransposeSuper);

@@ -1665,6 +1665,30 @@ def test_tiled_transpose_matches_numpy(hip, m, first, second):
     st.delete_all()
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_transpose_fuzz_matches_numpy(hip, seed):
+    """Seeded shapes around the edges of k_transpose_regs' tiles (1024 rows x 1024 columns, passes of 512 rows, 128-column heads):
+    row counts from 1 to a few thousand, columns appended in two or three slabs of arbitrary widths (each slab: ragged head up to the next
+    multiple of 128 columns, whole words through the tiled kernel, ragged tail), dense and sparse filters."""
+    from bigsi_amd.storage import get_storage
+    rng = np.random.default_rng(1000 + seed)
+    m = int(rng.choice([1, 7, 8, 511, 512, 513, 1023, 1024, 1025, 2047, 2049, int(rng.integers(1, 6000))]))
+    slabs = [int(rng.integers(1, 2600)) for _ in range(int(rng.integers(2, 4)))]
+    n = sum(slabs)
+    dens = float(rng.choice([0.5, 0.03]))
+    bits = (rng.random((n, m)) < dens).astype(np.uint8)
+    st = get_storage(cfg(31, m, 3, max_cols=n))
+    st.delete_all()
+    for key, v in (("number_of_rows", m), ("number_of_cols", 0), ("ksi:bloomfilter_size", m), ("ksi:num_hashes", 3)):
+        st.set_integer(key, v)
+    c0 = 0
+    for w in slabs:
+        st.insert_columns(c0, np.packbits(bits[c0:c0 + w], axis=1))
+        c0 += w
+    assert np.array_equal(st.get_rows_packed(np.arange(m), (n + 7) // 8), np.packbits(bits.T, axis=1)), (m, slabs)
+    st.delete_all()
+
+
 @pytest.mark.parametrize("h,n_cols", [(3, 10000), (2, 700), (4, 32768), (3, 65)])
 def test_one_launch_read_path_equals_three_launch_path(hip, h, n_cols):
     """Batches of reads (< 64 k-mers each, k = 31, at most 1024 queries, rows of at most 512 words) take k_reads_fused: K1 + K2 +
