@@ -1194,12 +1194,15 @@ def run(args):
     traffic, traffic_src = None, None
     wkey = "rows=%d cols=%d hashes=%d batch=%d qlen=%d k=%d threshold=%s draws=%d%s" % (
         w["rows"], my_cols, w["hashes"], w["batch"], w["qlen"], args.k, repr(float(thr)), args.and_draws, (" dense=1" if args.dense else "") + (" ee=1" if args.early_exit else ""))
-    k5_ratio, k5_line_ratio = None, None
+    k5_ratio, k5_line_ratio, traffic_ratio_pmc = None, None, None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             ent = json.load(f).get(wkey)
         if ent:
+            # the PMC pass measured launches of ITS shape (--timed resident: whole batches); what carries over to this run's launches --
+            # a streamed thresholded batch goes out in two -- is the RATIO of traffic to algorithmic bytes (scaled below, once those are known)
             traffic, traffic_src = ent["traffic_bytes_per_launch"], ent["source"]
+            traffic_ratio_pmc = ent.get("ratio")
             k5 = (ent.get("other_kernels") or {}).get("k_presence_bits")
             if k5 and ent.get("presence_alg_bytes_per_call"):
                 # K5's HBM traffic over the algorithmic bytes of the whole K5 + K6 call (unique k-mers x h x 8 per distinct hit word + bits + records)
@@ -1345,7 +1348,7 @@ def run(args):
                 "clocks": {"before_timed_region": clocks_before, "after_timed_region": clocks_after},
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "traffic_measured_in_run": False, "pmc_key": wkey,
+                         "traffic": traffic_ratio_pmc * alg_bytes_launch if traffic_ratio_pmc else traffic, "traffic_source": traffic_src, "traffic_measured_in_run": False, "pmc_key": wkey,
                          "kernel": "k_reads_fused (K1 + row-AND + K4 in one launch)" if batch.info().one_launch else "k_and_exact" if exact else "k_and_count",
                          "alg_bytes_per_launch": alg_bytes_launch, "kernel_ms": and_ms, "launches_timed": int(stats.and_launches),
                          "kernel_ms_is": "alone on the device: one-stream pass of %d launches after the timed region (events); in the timed region launches overlap"
