@@ -2904,6 +2904,7 @@ __global__ __launch_bounds__(kBlock * 2) void k_transpose_regs(
             if (r >= m || piece * 2 >= words_here) continue;
             const uint64_t a = ((uint64_t)(uint32_t)v0[t].y << 32) | (uint32_t)v0[t].x, b = ((uint64_t)(uint32_t)v1[t].y << 32) | (uint32_t)v1[t].x;
             uint64_t *dst = index + r * stride_words + w_first + w0 + piece * 2;
+            // (non-temporal STORES stay: plain ones measured -2 ... -4 % on three shapes, three interleaved repetitions)
             if (piece * 2 + 1 < words_here) __builtin_nontemporal_store(u64x2{a, b}, reinterpret_cast<u64x2 *>(dst));
             else dst[0] = a;
         }

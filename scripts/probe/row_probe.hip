@@ -48,6 +48,34 @@ __global__ __launch_bounds__(256) void k_stream_rows(const uint8_t *__restrict__
     out[(uint64_t)q * segs * 64 + seg * 64 + lane] = acc;
 }
 
+// sliced (round 6): the traversal a counting kernel with an address-ordered row list would need -- a WORKGROUP owns one 128-byte column
+// slice of a query (the per-k-mer partial ANDs of a slice, 128 bytes each, would fit its LDS: 970 x 128 B = 124 KB, which is what limits
+// the CU to one workgroup: the dynamic LDS below stands for it) and its 16 wavefronts walk the query's SORTED rows, 8 rows per wave
+// instruction (8 lanes x 16 bytes = one line per row), 8 instructions in flight.  The slices of a query are neighbouring workgroups.
+__global__ __launch_bounds__(1024) void k_stream_slices(const uint8_t *__restrict__ base, uint64_t pitch, const uint64_t *__restrict__ rows,
+                                                        uint32_t rows_per_query, uint32_t slices, uint32_t q0, uint32_t n_queries, u64x2 *__restrict__ out)
+{
+    extern __shared__ uint8_t state[];
+    const uint32_t q = q0 + blockIdx.x / slices, sl = blockIdx.x % slices;
+    if (q >= n_queries) return;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = lane >> 3, part = lane & 7;
+    const uint64_t *r = rows + (uint64_t)q * rows_per_query;
+    const uint64_t off = (uint64_t)sl * 128 + part * 16;
+    u64x2 acc = {~0ull, ~0ull};
+    for (uint32_t i = wave * 64; i < rows_per_query; i += 16 * 64) {      // a wavefront takes 64 consecutive rows of every 1024
+        u64x2 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t x = i + j * 8 + sub;
+            v[j] = x < rows_per_query ? __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(base + r[x] * pitch + off)) : u64x2{~0ull, ~0ull};
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc &= v[j];
+    }
+    if (threadIdx.x == 0) state[0] = (uint8_t)acc.x;
+    out[(uint64_t)blockIdx.x * 1024 + threadIdx.x] = acc;
+}
+
 __global__ void k_fill(uint64_t *p, uint64_t n)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) p[i] = i * 0x9E3779B97F4A7C15ull;
@@ -114,7 +142,8 @@ int main(int argc, char **argv)
     uint64_t *d_rows;
     u64x2 *d_out;
     CK(hipMalloc((void **)&d_rows, (size_t)n_queries * rows_per_query * 8));
-    CK(hipMalloc((void **)&d_out, (size_t)n_queries * segs * 64 * 16));
+    CK(hipMalloc((void **)&d_out, (size_t)n_queries * std::max<size_t>(segs * 64, (pitch / 128) * 1024) * 16));
+    CK(hipFuncSetAttribute((const void *)k_stream_slices, hipFuncAttributeMaxDynamicSharedMemorySize, 124 * 1024));
     const uint32_t q_per_launch = std::max<uint32_t>(wgs * 4 / segs, 1);
     std::mt19937_64 rng(1);
     hipEvent_t e0, e1;
@@ -123,7 +152,7 @@ int main(int argc, char **argv)
     // kfirst (round 6): the counting kernel's constraint -- the h rows of a k-mer are fetched together -- with the k-mers of a query
     // ordered by the address of their FIRST row: 1/h of the fetches sweep the matrix in step across the co-resident queries, the
     // other (h - 1)/h stay uniform.  kpage: the same with the first rows only bucketed (256 MB buckets), draw order inside a bucket
-    for (const char *mode : {"seq", "random", "sorted", "banded", "kfirst", "kpage"}) {
+    for (const char *mode : {"seq", "random", "sorted", "banded", "kfirst", "kpage", "sliced"}) {
         if (("," + modes + ",").find(std::string(",") + mode + ",") == std::string::npos) continue;
         std::vector<uint64_t> ids((size_t)n_queries * rows_per_query);
         for (uint32_t q = 0; q < n_queries; q++) {
@@ -137,7 +166,7 @@ int main(int argc, char **argv)
                 for (uint64_t i = 0; i < rows_per_query; i++) r[i] = start + rng() % band_rows;
             } else {
                 for (uint64_t i = 0; i < rows_per_query; i++) r[i] = rng() % n_rows;
-                if (!strcmp(mode, "sorted")) std::sort(r, r + rows_per_query);
+                if (!strcmp(mode, "sorted") || !strcmp(mode, "sliced")) std::sort(r, r + rows_per_query);
                 if (!strcmp(mode, "kfirst") || !strcmp(mode, "kpage")) {
                     const uint64_t nk = rows_per_query / hk, bucket_rows = !strcmp(mode, "kpage") ? std::max<uint64_t>((256ull << 20) / pitch, 1) : 1;
                     std::vector<uint64_t> order(nk), tmp(r, r + nk * hk);
@@ -155,6 +184,10 @@ int main(int argc, char **argv)
                 const uint32_t nq = std::min(q_per_launch, n_queries - q0);
                 const uint32_t waves = nq * segs, blocks = (waves + 3) / 4;
                 CK(hipEventRecord(e0, 0));
+                if (!strcmp(mode, "sliced"))
+                    hipLaunchKernelGGL(k_stream_slices, dim3(nq * (uint32_t)(pitch / 128)), dim3(1024), 124 * 1024, 0, d, pitch, d_rows, (uint32_t)rows_per_query,
+                                       (uint32_t)(pitch / 128), q0, q0 + nq, d_out);
+                else
                 hipLaunchKernelGGL(k_stream_rows, dim3(blocks), dim3(256), 0, 0, d, pitch, d_rows, (uint32_t)rows_per_query, segs, q0, q0 + nq, d_out);
                 CK(hipEventRecord(e1, 0));
                 CK(hipEventSynchronize(e1));
@@ -163,7 +196,7 @@ int main(int argc, char **argv)
                 if (rep && nq == q_per_launch) ms.push_back(t);
             }
         std::sort(ms.begin(), ms.end());
-        const double med = ms[ms.size() / 2], by = (double)q_per_launch * rows_per_query * (segs * 1024.0 > pitch ? pitch : segs * 1024.0);
+        const double med = ms[ms.size() / 2], by = (double)q_per_launch * rows_per_query * (!strcmp(mode, "sliced") ? (double)pitch : segs * 1024.0 > pitch ? pitch : segs * 1024.0);
         printf("  %-7s median launch %.3f ms (%zu launches of %u queries)  %.0f GB/s  = %.3f of 8 TB/s\n", mode, med, ms.size(), q_per_launch, by / med / 1e6, by / med / 1e6 / 8000);
     }
     return 0;
