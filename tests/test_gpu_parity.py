@@ -1665,7 +1665,7 @@ def test_tiled_transpose_matches_numpy(hip, m, first, second):
     st.delete_all()
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BIGSI_TRANSPOSE_FUZZ", "6"))))      # (campaigns: BIGSI_TRANSPOSE_FUZZ=300)
 def test_transpose_fuzz_matches_numpy(hip, seed):
     """Seeded shapes around the edges of k_transpose_regs' tiles (1024 rows x 1024 columns, passes of 512 rows, 128-column heads):
     row counts from 1 to a few thousand, columns appended in two or three slabs of arbitrary widths (each slab: ragged head up to the next
