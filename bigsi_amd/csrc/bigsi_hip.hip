@@ -129,7 +129,11 @@ static int quiesce_index(bigsi_hip_index *ix)
     return BIGSI_OK;
 }
 
-static uint64_t stride_for(uint64_t cols) { return std::max<uint64_t>(16, round_up(ceil_div(cols, 64), 16)); }
+static uint64_t stride_for(uint64_t cols)
+{
+    static const int align_words = env_int("BIGSI_HIP_ROW_ALIGN_WORDS", 16);      // A/B (tuning builds): 256 = rows at a 2 KB pitch
+    return std::max<uint64_t>(16, round_up(ceil_div(cols, 64), (uint64_t)std::max(align_words, 16)));
+}
 
 // The matrix is an ordinary hipMalloc.  Tuning builds can ask for PHYSICALLY CONTIGUOUS memory instead (BIGSI_HIP_CONTIGUOUS=1:
 // hipDeviceMallocContiguous, largest page-table fragments): the bare-kernel probe measured +4 % on random 12.5 KB rows with it and
