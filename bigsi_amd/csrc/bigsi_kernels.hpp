@@ -2665,6 +2665,7 @@ template <int RT, int CT>
 __global__ __launch_bounds__(kBlock * CT) void k_transpose_tiles(
     uint64_t *__restrict__ index, uint64_t stride_words, uint64_t m, uint64_t w_first /* first column word written; even */,
     uint64_t n_words /* whole 64-column words to write */, const uint8_t *__restrict__ blooms /* filter of column 64 * w_first */,
+    uint64_t /* n_filters: k_transpose_regs' argument; here every word has all its filters */,
     uint64_t bstride /* bytes between filters; multiple of 16 */, uint64_t nb /* valid bytes of a filter: ceil(m / 8) */,
     uint32_t rg, uint32_t cg /* tiles per XCD group along rows / columns: powers of two, rg * cg <= 128, cg <= sup_w */,
     uint32_t sup_w /* supertile width in tiles: a power of two <= 32 */)
@@ -2827,7 +2828,8 @@ typedef int tr_v2i __attribute__((ext_vector_type(2)));
 template <int RT>
 __global__ __launch_bounds__(kBlock * 2) void k_transpose_regs(
     uint64_t *__restrict__ index, uint64_t stride_words, uint64_t m, uint64_t w_first /* first column word written; even */,
-    uint64_t n_words /* whole 64-column words to write */, const uint8_t *__restrict__ blooms /* filter of column 64 * w_first */,
+    uint64_t n_words /* 64-column words to write (all of each: columns at or beyond n_filters are written as zeros) */,
+    const uint8_t *__restrict__ blooms /* filter of column 64 * w_first */, uint64_t n_filters /* filters there are, from that one on */,
     uint64_t bstride /* bytes between filters; multiple of 16 */, uint64_t nb /* valid bytes of a filter: ceil(m / 8) */,
     uint32_t rg, uint32_t cg /* tiles per XCD group along rows / columns: powers of two, rg * cg <= 128, cg <= sup_w */,
     uint32_t sup_w /* supertile width in tiles: a power of two <= 32 */)
@@ -2855,7 +2857,7 @@ __global__ __launch_bounds__(kBlock * 2) void k_transpose_regs(
 #pragma unroll
         for (int half = 0; half < RT; half++) {
             const uint64_t off = byte0 + 64 * half + 16 * p;
-            const bool ok = g < words_here * 8u && off + 16 <= bstride && off < nb;
+            const bool ok = g < words_here * 8u && w0 * 64 + g * 8u + it < n_filters && off + 16 <= bstride && off < nb;
             const u64x2 *src = reinterpret_cast<const u64x2 *>(blooms + (w0 * 64 + (ok ? g * 8u + it : 0u)) * bstride + (ok ? off : 0));
             // PLAIN loads: the two 64-byte halves of a filter's line are asked for by consecutive instructions, and only a line the
             // vector L1 has allocated takes the second one as a hit -- with non-temporal loads the L2 was asked 1.19 times per line

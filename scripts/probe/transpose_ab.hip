@@ -270,7 +270,9 @@ int main(int argc, char **argv)
         fflush(stdout);
     };
 #define ARGS(rg, cg) dim3((unsigned)blocks), dim3(512), 0, 0, index, stride_words, m, 0ull, n_words, blooms, bstride, nb, (uint32_t)(rg), std::min<uint32_t>((cg), sup_w), sup_w
-    run([&] { hipLaunchKernelGGL((k_transpose_tiles<2, 2>), ARGS(4, 1)); }, "k_transpose_tiles<2,2> as shipped (XCD groups 4 x 1)");
+// (the library's own kernel takes the number of filters as well: k_transpose_regs' argument, unused by k_transpose_tiles)
+#define ARGS_LIB(rg, cg) dim3((unsigned)blocks), dim3(512), 0, 0, index, stride_words, m, 0ull, n_words, blooms, n_words * 64, bstride, nb, (uint32_t)(rg), std::min<uint32_t>((cg), sup_w), sup_w
+    run([&] { hipLaunchKernelGGL((k_transpose_tiles<2, 2>), ARGS_LIB(4, 1)); }, "k_transpose_tiles<2,2> as shipped (XCD groups 4 x 1)");
     run([&] { hipLaunchKernelGGL((k_tr_var<2, 2, 0>), ARGS(4, 1)); }, "the copy, no switch");
     run([&] { hipLaunchKernelGGL((k_tr_var<2, 2, 1>), ARGS(4, 1)); }, "1: tiles row-major inside the supertile");
     run([&] { hipLaunchKernelGGL((k_tr_var<2, 2, 2>), ARGS(4, 1)); }, "2: no phase 2");
@@ -291,7 +293,7 @@ int main(int argc, char **argv)
         const uint64_t words = stride_words * m;
         uint64_t *ref = nullptr;
         CK(hipMalloc(&ref, words * 8));
-        hipLaunchKernelGGL((k_transpose_tiles<2, 2>), ARGS(4, 1));
+        hipLaunchKernelGGL((k_transpose_tiles<2, 2>), ARGS_LIB(4, 1));
         CK(hipMemcpy(ref, index, words * 8, hipMemcpyDeviceToDevice));
         CK(hipMemset(index, 0, words * 8));
         hipLaunchKernelGGL((k_tr_pipe<0>), PARGS(512));
