@@ -52,6 +52,10 @@ the batches resident in HBM), r: resident steps (hv then = host-visible lookups/
 import argparse
 import json
 import os
+
+# multi-process GPU work on these hosts needs dmabuf IPC (RCCL across ranks fails with hipIpcGetMemHandle otherwise); the driver's
+# environment exports it -- keep it if it does not.  Must be in place before any HIP runtime loads (torch, libbigsi_hip.so below)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import socket
 import subprocess
 import sys
