@@ -982,6 +982,8 @@ static int transpose_device(bigsi_hip_index *ix, uint64_t col0, uint64_t n, cons
     static const int tr_regs = env_int("BIGSI_HIP_TR_REGS", 1), tr_wide = env_int("BIGSI_HIP_TR_WIDE", 1);      // 0: k_transpose_tiles<RT, CT> of rounds 2-6
     regs = tr_regs != 0;
     if (!regs) ct = tr_wide ? 2 : 1;
+    static const int tr_cw = env_int("BIGSI_HIP_TR_CW", 1);      // 2: 2048-column tiles (256-byte row runs), 1024 threads, one workgroup per CU
+    if (regs && tr_cw == 2) ct = 4;
 #endif
     // APPENDING (nothing valid at or beyond `end`: the usual build) the tiled kernel also takes the ragged tail: it writes whole 128-byte
     // lines, zeros for the columns that have no filter -- what those bits of the row hold anyway -- instead of leaving up to 63 columns to
@@ -1003,6 +1005,11 @@ static int transpose_device(bigsi_hip_index *ix, uint64_t col0, uint64_t n, cons
     dim3((unsigned)sup_blocks), dim3(kBlock * (unsigned)ct), 0, ix->stream, ix->d_index, ix->stride_words, ix->m, c_lo / 64, n_words,  \
         d_blooms + (c_lo - col0) * bstride, end - c_lo, bstride, nb, (uint32_t)tr_rg, cg_eff, sup_w
 #define COMMA ,
+#ifdef BIGSI_HIP_TUNING
+    if (regs && ct == 4 && rt == 2) hipLaunchKernelGGL((k_transpose_regs<2 COMMA 2>), BIGSI_TR_ARGS);
+    else if (regs && ct == 4) hipLaunchKernelGGL((k_transpose_regs<1 COMMA 2>), BIGSI_TR_ARGS);
+    else
+#endif
     if (regs && rt == 2) hipLaunchKernelGGL((k_transpose_regs<2>), BIGSI_TR_ARGS);
     else if (regs) hipLaunchKernelGGL((k_transpose_regs<1>), BIGSI_TR_ARGS);
 #ifdef BIGSI_HIP_TUNING

@@ -2803,10 +2803,6 @@ __global__ __launch_bounds__(kBlock * CT) void k_transpose_tiles(
 // of phase 3 (32 lanes = 4 pieces x 8 column bytes, 16 words apart).
 // RT = 2: 1024 rows per workgroup -- the thread loads both 64-byte halves of its filters' 128-byte lines at once and the two
 // 512-row halves go through the LDS one after the other.
-constexpr uint32_t kTrRegsPitch = 132;      // 8-byte words per (t, eh, p) line of the LDS image: 128 column bytes + 4
-
-__device__ __forceinline__ uint32_t tr_regs_word(uint32_t line, uint32_t cb) { return line * kTrRegsPitch + (cb ^ ((cb >> 2) & 8u)); }
-
 // 8 x 8 bit blocks between 8 registers, bytes independent: x[i] bit (7 - t) of byte q  ->  x[t] bit (7 - i) of byte q
 __device__ __forceinline__ void transpose8_regs(uint32_t (&x)[8])
 {
@@ -2825,8 +2821,8 @@ __device__ __forceinline__ void transpose8_regs(uint32_t (&x)[8])
 
 typedef int tr_v2i __attribute__((ext_vector_type(2)));
 
-template <int RT>
-__global__ __launch_bounds__(kBlock * 2) void k_transpose_regs(
+template <int RT, int CW = 1 /* tile width in units of 1024 columns: 2 = 256-byte row runs, 1024 threads, 133 KB of LDS (A/B) */>
+__global__ __launch_bounds__(kBlock * 2 * CW) void k_transpose_regs(
     uint64_t *__restrict__ index, uint64_t stride_words, uint64_t m, uint64_t w_first /* first column word written; even */,
     uint64_t n_words /* 64-column words to write (all of each: columns at or beyond n_filters are written as zeros) */,
     const uint8_t *__restrict__ blooms /* filter of column 64 * w_first */, uint64_t n_filters /* filters there are, from that one on */,
@@ -2834,8 +2830,10 @@ __global__ __launch_bounds__(kBlock * 2) void k_transpose_regs(
     uint32_t rg, uint32_t cg /* tiles per XCD group along rows / columns: powers of two, rg * cg <= 128, cg <= sup_w */,
     uint32_t sup_w /* supertile width in tiles: a power of two <= 32 */)
 {
-    __shared__ __attribute__((aligned(16))) uint64_t image[64 * kTrRegsPitch];
-    constexpr uint32_t kWordsPerBlock = 16;             // 1024 columns
+    constexpr uint32_t kPitch = 128u * CW + 4u;           // 8-byte words per (t, eh, p) line of the image: the tile's column bytes + 4
+    __shared__ __attribute__((aligned(16))) uint64_t image[64 * kPitch];
+    constexpr uint32_t kWordsPerBlock = 16 * CW;        // 1024 CW columns
+    auto word_at = [](uint32_t line, uint32_t cb) { return line * kPitch + (cb ^ ((cb >> 2) & 8u)); };
     // workgroup -> tile: as k_transpose_tiles (supertiles of 1024 tiles, groups of rg x cg neighbours on one XCD)
     const uint64_t tiles_c = (n_words + kWordsPerBlock - 1) / kWordsPerBlock, sup_c = (tiles_c + sup_w - 1) / sup_w;
     const uint32_t sup_h = (uint32_t)(kTransposeSuper * kTransposeSuper) / sup_w;
@@ -2870,7 +2868,8 @@ __global__ __launch_bounds__(kBlock * 2) void k_transpose_regs(
     // phase 3's places: the wavefront takes the 64 rows 128 pw + 64 ehw + (0 .. 63) of the half; instruction t reads line (t, ehw, pw)
     // for the rows t + 8 b.  Lane = (gi, i): it ADDRESSES column byte 16 (2 gi + (i & 1)) + (i >> 1) (+ 8 for the second read) and
     // RECEIVES (b = i & 7, a = i >> 3) the bytes 16 (2 gi + a) + 0 .. 7 (8 .. 15) of row 8 b + t
-    const uint32_t pw = wave >> 1, ehw = wave & 1u, gi = lane >> 4, li = lane & 15u;
+    // (CW = 2: 16 wavefronts; a wavefront takes 4 of the 8 values of t and both 128-byte halves of its rows' 256-byte runs, one right after the other)
+    const uint32_t pw = wave / (2u * CW), ehw = (wave / CW) & 1u, th = wave % CW, gi = lane >> 4, li = lane & 15u;
     const uint32_t cb_addr = 16u * (2u * gi + (li & 1u)) + (li >> 1);
     const uint32_t piece = 2u * gi + (li >> 3), brow = li & 7u;
 #pragma unroll
@@ -2889,25 +2888,26 @@ __global__ __launch_bounds__(kBlock * 2) void k_transpose_regs(
             transpose8_regs(lo);
             transpose8_regs(hi);
 #pragma unroll
-            for (int t = 0; t < 8; t++) image[tr_regs_word((t * 2 + d2) * 4 + p, g)] = ((uint64_t)hi[t] << 32) | lo[t];
+            for (int t = 0; t < 8; t++) image[word_at((t * 2 + d2) * 4 + p, g)] = ((uint64_t)hi[t] << 32) | lo[t];
         }
         __syncthreads();
         const uint64_t r0 = (tile_r * RT + half) * kTransposeTile + 128u * pw + 64u * ehw + 8u * brow;
         tr_v2i v0[8], v1[8];
 #pragma unroll
-        for (int t = 0; t < 8; t++) {
-            const uint32_t line = (t * 2 + ehw) * 4 + pw;
-            v0[t] = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) tr_v2i *)(image + tr_regs_word(line, cb_addr)));
-            v1[t] = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) tr_v2i *)(image + tr_regs_word(line, cb_addr + 8u)));
+        for (int sl = 0; sl < 8; sl++) {                     // store slot sl = (t, 128-byte half of the run)
+            const uint32_t t = (8u / CW) * th + sl / CW, ch = sl % CW, line = (t * 2 + ehw) * 4 + pw;
+            v0[sl] = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) tr_v2i *)(image + word_at(line, 128u * ch + cb_addr)));
+            v1[sl] = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) tr_v2i *)(image + word_at(line, 128u * ch + cb_addr + 8u)));
         }
 #pragma unroll
-        for (int t = 0; t < 8; t++) {
+        for (int sl = 0; sl < 8; sl++) {
+            const uint32_t t = (8u / CW) * th + sl / CW, pc = 8u * (sl % CW) + piece;
             const uint64_t r = r0 + t;
-            if (r >= m || piece * 2 >= words_here) continue;
-            const uint64_t a = ((uint64_t)(uint32_t)v0[t].y << 32) | (uint32_t)v0[t].x, b = ((uint64_t)(uint32_t)v1[t].y << 32) | (uint32_t)v1[t].x;
-            uint64_t *dst = index + r * stride_words + w_first + w0 + piece * 2;
+            if (r >= m || pc * 2 >= words_here) continue;
+            const uint64_t a = ((uint64_t)(uint32_t)v0[sl].y << 32) | (uint32_t)v0[sl].x, b = ((uint64_t)(uint32_t)v1[sl].y << 32) | (uint32_t)v1[sl].x;
+            uint64_t *dst = index + r * stride_words + w_first + w0 + pc * 2;
             // (non-temporal STORES stay: plain ones measured -2 ... -4 % on three shapes, three interleaved repetitions)
-            if (piece * 2 + 1 < words_here) __builtin_nontemporal_store(u64x2{a, b}, reinterpret_cast<u64x2 *>(dst));
+            if (pc * 2 + 1 < words_here) __builtin_nontemporal_store(u64x2{a, b}, reinterpret_cast<u64x2 *>(dst));
             else dst[0] = a;
         }
     }
