@@ -295,6 +295,9 @@ ALSO_LEGS = {
         ("c2_dense", "configs[1], every read held by 8 samples", ["--workload", "c2", "--dense", "1", "--warmup", "200"], 30000),
         # opt-in early exit on the hit-dense index (NOT the reference's byte count: `tr` = bytes read / algorithmic bytes says how much less)
         ("c5_ee", "the c5_dense shard with early_exit (unscored step)", ["--workload", "c5", "--shard-of", "8", "--dense", "1", "--early-exit", "1", "--score", "0", "--warmup", "6"], 1500),
+        # ... and on the headline's own workload: an exact search of the synthetic index settles every 8192-column segment after a dozen rows
+        # (its ANDs run empty), so this leg reads a few per cent of the bytes -- what early_exit buys when queries do not match, not a lookup rate
+        ("c3_ee", "configs[2] exact with early_exit (opt-in; reads a fraction of the algorithmic bytes)", ["--workload", "c3", "--early-exit", "1"], 350),
         # f1, index ingest: a 32 GB snapshot (device layout) written, dropped, loaded back (threads on the file, two pinned buffers,
         # asynchronous copies), sampled rows verified against the oracle's generator: scripts/ingest_bench.py, keys in GB/s
         ("ingest", "snapshot of a 32 GB index written / dropped / loaded back", ["--ingest", "32"], 0)],

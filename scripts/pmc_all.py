@@ -33,6 +33,7 @@ WORKLOADS = [
     ("c5_shard", ["bench.py", "--workload", "c5", "--shard-of", "8", "--steps", "8", "--warmup", "2"] + B, ["k_and_count", "k_presence_bits", "k_presence_score"]),
     ("c5_dense", ["bench.py", "--workload", "c5", "--shard-of", "8", "--dense", "1", "--steps", "8", "--warmup", "2"] + B, ["k_and_count", "k_presence_bits", "k_presence_score"]),
     ("c5_ee", ["bench.py", "--workload", "c5", "--shard-of", "8", "--dense", "1", "--early-exit", "1", "--score", "0", "--steps", "8", "--warmup", "2"] + B, ["k_and_count"]),
+    ("c3_ee", ["bench.py", "--steps", "8", "--warmup", "2", "--early-exit", "1", "--timed", "resident"] + B, ["k_and_exact"]),
     ("c2_dense", ["bench.py", "--workload", "c2", "--dense", "1", "--steps", "64", "--warmup", "8"] + B, ["k_reads_fused"]),
     ("ns_shard", ["bench.py", "--workload", "northstar", "--shard-of", "8", "--steps", "8", "--warmup", "2"] + B, ["k_and_exact"]),
     ("ns_shard_t04", ["bench.py", "--workload", "northstar", "--shard-of", "8", "--steps", "8", "--warmup", "2", "--threshold", "0.4"] + B, ["k_and_count"]),

@@ -355,7 +355,7 @@ def test_bench_line_is_condensed_under_the_drivers_tail():
     # every world size the driver uses has its legs; 8 GPUs run the configurations that need 8 GPUs as WHOLE indexes
     assert [k for k, *_ in bench.also_legs_for(8)] == ["c4", "c5", "northstar", "c3_t04"] and [k for k, *_ in bench.also_legs_for(4)][0] == "northstar"
     assert all("--shard-of" not in extra for n in (2, 4, 8) for _, _, extra, _ in bench.also_legs_for(n))
-    assert [k for k, *_ in bench.also_legs_for(1)][-1] == "ingest" and len(bench.also_legs_for(1)) == 10 and {"c5_dense", "c2_dense", "c5_ee"} <= {k for k, *_ in bench.also_legs_for(1)} and bench.also_legs_for(3)[0][0] == "c3_t04"
+    assert [k for k, *_ in bench.also_legs_for(1)][-1] == "ingest" and len(bench.also_legs_for(1)) == 11 and {"c5_dense", "c2_dense", "c5_ee", "c3_ee"} <= {k for k, *_ in bench.also_legs_for(1)} and bench.also_legs_for(3)[0][0] == "c3_t04"
 
 
 def test_cortex_reader_vs_reference(tmp_path):
