@@ -196,7 +196,7 @@ def main():
         if os.path.exists(os.path.join(SRC, name)):
             shutil.copy(os.path.join(SRC, name), os.path.join(DST, name))
     for name in (R + "_row_probe.txt", R + "_call_breakdown.txt", R + "_call_trace.txt", R + "_k1_phases.txt", R + "_one_call_timeline.txt", R + "_python_stack_latency.txt", R + "_ingest.json", R + "_import.json", R + "_tmpfs_write_probe.txt",
-                 R + "_bench_default.json", R + "_results_bench.txt"):
+                 R + "_bench_default.json", R + "_results_bench.txt", R + "_build_bench.jsonl", R + "_transpose_regs_ab.txt", R + "_tr_probe.txt"):
         if os.path.exists(os.path.join(SRC, name)):
             shutil.copy(os.path.join(SRC, name), os.path.join(DST, name))
     with open(os.path.join(DST, R + "_summary.json"), "w") as f:

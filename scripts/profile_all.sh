@@ -72,4 +72,9 @@ python scripts/pmc_requests.py $P/pmc_req c3_exact c5_shard c5_dense transpose >
 cp $P/pmc_req/pmc_requests.json $P/${R}_pmc_requests.json
 python bench.py --steps 20 --warmup 5 --details $P/${R}_bench_default_full.json > $P/${R}_bench_default.stdout 2> $P/${R}_bench_default.stderr      # the driver's command: headline + every other config as config.also legs + the CPU baseline
 python bench.py --steps 20 --warmup 5 --threshold 0.4 --also none > $P/${R}_bench_t04.stdout 2> $P/${R}_bench_t04.stderr
+# round 6: the Python stack's latency, the host-visible build, the transpose A/B against the previous kernel (tuning build), the transposing read's lane map
+python scripts/latency_probe.py > $P/${R}_python_stack_latency.txt 2>&1
+{ python scripts/build_bench.py 4000000 16384; python scripts/build_bench.py 1000000 100000; } > $P/${R}_build_bench.jsonl 2>/dev/null
+CFGS="1 1 4 1,0 0 4 1,0 1 4 1" REPS=3 scripts/ab_transpose_regs.sh > $P/${R}_transpose_regs_ab.txt 2>&1
+scripts/probe/tr_probe > $P/${R}_tr_probe.txt 2>&1
 ls $P | wc -l
